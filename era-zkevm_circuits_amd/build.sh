@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libzkgl.so (gfx950 only) in-tree.  Usage: era-zkevm_circuits_amd/build.sh
+set -euo pipefail
+cd "$(dirname "$0")/csrc"
+OUT=../libzkgl.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value"
+mkdir -p ../build
+pids=()
+for f in zkgl_device.hip; do
+  hipcc $FLAGS -c $f -o ../build/$(basename $f).o & pids+=($!)
+done
+for f in cs.cpp gadgets.cpp poseidon_consts.cpp capi.cpp circuits/ram_permutation.cpp circuits/vm_shaped.cpp; do
+  hipcc $FLAGS -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $f -o ../build/$(basename $f).o & pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../build/*.o
+echo "built $(readlink -f $OUT)"

@@ -1,0 +1,365 @@
+// capi.cpp — the extern "C" boundary declared in include/zkgl.h.  No torch types, no
+// exceptions across the boundary, no abort: every failure becomes a negative zk_status plus a
+// thread-local message (the reference panics instead: SURVEY.md §5 "Failure detection").
+#include <hip/hip_runtime_api.h>
+#include <cstring>
+#include <string>
+#include "../../include/zkgl.h"
+#include "cs.hpp"
+#include "device_api.hpp"
+#include "gadgets.hpp"
+#include "poseidon_consts.hpp"
+
+namespace zkgl {
+void ram_permutation_configure(CS& cs);
+void ram_permutation_entry_point(CS& cs, uint32_t limit);
+void vm_shaped_configure(CS& cs);
+void vm_shaped_entry_point(CS& cs, uint32_t limit);
+}  // namespace zkgl
+
+struct zk_cs {
+    zkgl::CS* cs;
+};
+
+namespace {
+thread_local std::string g_err;
+bool g_inited = false;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) { return fail(ZK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+int dev_rc(int rc) { return rc == 0 ? ZK_OK : fail(rc == -1 ? ZK_ERR_INVALID : ZK_ERR_HIP, zkdev::last_hip_error()); }
+
+template <class F>
+int guard(F&& f) {
+    try {
+        f();
+        return ZK_OK;
+    } catch (const zkgl::ZkError& e) {
+        return fail(e.code, e.what());
+    } catch (const std::exception& e) {
+        return fail(ZK_ERR_INVALID, e.what());
+    } catch (...) {
+        return fail(ZK_ERR_INVALID, "unknown exception");
+    }
+}
+int need_init() { return g_inited ? ZK_OK : fail(ZK_ERR_HIP, "zk_init() has not succeeded: no GPU context (there is no CPU fallback)"); }
+#define NEED_INIT() do { int rc__ = need_init(); if (rc__) return rc__; } while (0)
+#define NEED(p) do { if (!(p)) return fail(ZK_ERR_INVALID, "null argument: " #p); } while (0)
+}  // namespace
+
+extern "C" {
+
+const char* zk_last_error(void) { return g_err.c_str(); }
+
+int zk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int zk_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(ZK_ERR_HIP, "no HIP device visible: libzkgl has no CPU fallback");
+    if (device < 0 || device >= n) return fail(ZK_ERR_INVALID, "device index out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    int rc = zkdev::upload_round_constants(zkgl::poseidon_round_constants());
+    if (rc) return fail(ZK_ERR_HIP, zkdev::last_hip_error());
+    g_inited = true;
+    return ZK_OK;
+}
+
+int zk_poseidon_round_constants(uint64_t out[360]) {
+    NEED(out);
+    std::memcpy(out, zkgl::poseidon_round_constants(), 360 * sizeof(uint64_t));
+    return ZK_OK;
+}
+
+int zk_malloc(void** dptr, size_t bytes) {
+    NEED(dptr); NEED_INIT();
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+    return e == hipSuccess ? ZK_OK : hip_fail(e, "hipMalloc");
+}
+int zk_free(void* dptr) {
+    hipError_t e = hipFree(dptr);
+    return e == hipSuccess ? ZK_OK : hip_fail(e, "hipFree");
+}
+int zk_memset(void* dptr, int value, size_t bytes, void* stream) {
+    NEED_INIT();
+    hipError_t e = hipMemsetAsync(dptr, value, bytes, (hipStream_t)stream);
+    return e == hipSuccess ? ZK_OK : hip_fail(e, "hipMemsetAsync");
+}
+int zk_h2d(void* dptr, const void* hptr, size_t bytes, void* stream) {
+    NEED_INIT();
+    hipError_t e = hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? ZK_OK : hip_fail(e, "hipMemcpy H2D");
+}
+int zk_d2h(void* hptr, const void* dptr, size_t bytes, void* stream) {
+    NEED_INIT();
+    hipError_t e = hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? ZK_OK : hip_fail(e, "hipMemcpy D2H");
+}
+int zk_sync(void* stream) {
+    NEED_INIT();
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? ZK_OK : hip_fail(e, "hipStreamSynchronize");
+}
+
+// ---- K1 ----
+int zk_gl_fma_cols(uint64_t* dst, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t q, uint64_t l,
+                   size_t n, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_col(0, dst, a, b, c, q, l, n, stream));
+}
+int zk_gl_add_cols(uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_col(1, dst, a, b, a, 0, 0, n, stream));
+}
+int zk_gl_sub_cols(uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_col(2, dst, a, b, a, 0, 0, n, stream));
+}
+int zk_gl_mul_cols(uint64_t* dst, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_col(3, dst, a, b, a, 0, 0, n, stream));
+}
+int zk_gl_select_cols(uint64_t* dst, const uint64_t* s, const uint64_t* a, const uint64_t* b, size_t n, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_col(4, dst, s, a, b, 0, 0, n, stream));
+}
+int zk_gl_inv_cols(uint64_t* dst, const uint64_t* a, size_t n, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_col(5, dst, a, a, a, 0, 0, n, stream));
+}
+
+// ---- K2 / K3 / a9 / K4 ----
+int zk_poseidon2_permute_soa(uint64_t* states, size_t n, size_t stride, void* stream) {
+    NEED_INIT();
+    if (stride < n) return fail(ZK_ERR_INVALID, "stride < n");
+    return dev_rc(zkdev::launch_poseidon2_soa(states, n, stride, stream));
+}
+int zk_poseidon2_permute_aos(uint64_t* states, size_t n, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_poseidon2_aos(states, n, stream));
+}
+int zk_commit_encoding_batch(const uint64_t* input, size_t len, size_t n, uint64_t* out, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_commit_encoding(input, len, n, out, stream));
+}
+int zk_queue_full_push_chain(const uint64_t* enc, size_t nq, size_t items, uint64_t* tail_io, uint64_t* states_out,
+                             void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_queue_full_chain(enc, nq, items, tail_io, states_out, stream));
+}
+int zk_memory_query_encode(const uint64_t* q, size_t n, uint64_t* enc, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_memory_query_encode(q, n, enc, stream));
+}
+int zk_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* challenges, size_t enc_len, size_t n,
+                     uint64_t init, uint64_t* acc_out, uint64_t* scratch, void* stream) {
+    NEED_INIT();
+    if (enc_len == 0) return fail(ZK_ERR_INVALID, "ENCODING_LENGTH must be > 0");  // src/utils.rs:96
+    if (init >= 0xFFFFFFFF00000001ull) return fail(ZK_ERR_INVALID, "non-canonical init");
+    return dev_rc(zkdev::launch_grand_product(enc, flags, challenges, enc_len, n, init, acc_out, scratch, stream));
+}
+
+// ---- constraint system ----
+int zk_cs_create(const zk_geometry* geometry, uint64_t max_trace_len, uint64_t max_variables, zk_cs** out) {
+    NEED(geometry); NEED(out);
+    return guard([&] {
+        auto* h = new zk_cs;
+        try { h->cs = new zkgl::CS(*geometry, max_trace_len, max_variables); } catch (...) { delete h; throw; }
+        *out = h;
+    });
+}
+int zk_cs_destroy(zk_cs* cs) {
+    if (!cs) return ZK_OK;
+    delete cs->cs;
+    delete cs;
+    return ZK_OK;
+}
+int zk_cs_allow_lookup(zk_cs* cs, uint32_t width, uint32_t reps, int share) {
+    NEED(cs);
+    return guard([&] { cs->cs->allow_lookup(width, reps, share != 0); });
+}
+int zk_cs_allow_gate(zk_cs* cs, uint32_t kind) {
+    NEED(cs);
+    return guard([&] { cs->cs->allow_gate(kind); });
+}
+int zk_cs_gate_is_allowed(zk_cs* cs, uint32_t kind) { return cs && cs->cs->gate_is_allowed(kind) ? 1 : 0; }
+int zk_cs_add_table(zk_cs* cs, uint32_t marker, uint32_t n_keys, uint32_t n_vals, const uint64_t* rows, uint32_t n_rows,
+                    uint32_t* id) {
+    NEED(cs); NEED(rows); NEED(id);
+    return guard([&] { *id = cs->cs->add_table(marker, n_keys, n_vals, rows, n_rows); });
+}
+int zk_cs_table_id(zk_cs* cs, uint32_t marker, uint32_t* id) {
+    NEED(cs); NEED(id);
+    return guard([&] { *id = cs->cs->table_id(marker); });
+}
+int zk_cs_alloc_vars(zk_cs* cs, uint32_t n, zk_var* first) {
+    NEED(cs); NEED(first);
+    return guard([&] { *first = cs->cs->alloc_vars(n); });
+}
+int zk_cs_alloc_constant(zk_cs* cs, uint64_t value, zk_var* out) {
+    NEED(cs); NEED(out);
+    return guard([&] { *out = cs->cs->alloc_constant(value); });
+}
+int zk_cs_input(zk_cs* cs, uint32_t word, zk_var* out) {
+    NEED(cs); NEED(out);
+    return guard([&] { *out = cs->cs->input(word); });
+}
+int zk_cs_place_gate(zk_cs* cs, uint32_t kind, const zk_var* vars, uint32_t n_vars, const uint64_t* consts,
+                     uint32_t n_consts) {
+    NEED(cs);
+    return guard([&] { cs->cs->place_gate(kind, vars, n_vars, consts, n_consts); });
+}
+int zk_cs_emit_op(zk_cs* cs, uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uint32_t n_in,
+                  const zk_var* outs, uint32_t n_out, const uint64_t* imm, uint32_t n_imm) {
+    NEED(cs);
+    return guard([&] { cs->cs->emit_op(opcode, a, b, ins, n_in, outs, n_out, imm, n_imm); });
+}
+int zk_cs_lookup(zk_cs* cs, uint32_t table_id, const zk_var* keys, uint32_t n_keys, zk_var* vals, uint32_t n_vals) {
+    NEED(cs); NEED(keys); NEED(vals);
+    return guard([&] { cs->cs->lookup(table_id, keys, n_keys, vals, n_vals); });
+}
+int zk_cs_loop_begin(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { cs->cs->loop_begin(limit); });
+}
+int zk_cs_loop_end(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { cs->cs->loop_end(); });
+}
+int zk_cs_link(zk_cs* cs, uint32_t kind, zk_var loop_var, zk_var other) {
+    NEED(cs);
+    return guard([&] { cs->cs->link(kind, loop_var, other); });
+}
+int zk_cs_loop_last(zk_cs* cs, zk_var loop_var, zk_var* outer_out) {
+    NEED(cs); NEED(outer_out);
+    return guard([&] { *outer_out = cs->cs->loop_last(loop_var); });
+}
+int zk_cs_loop_import(zk_cs* cs, zk_var outer_var, zk_var* loop_out) {
+    NEED(cs); NEED(loop_out);
+    return guard([&] { *loop_out = cs->cs->loop_import(outer_var); });
+}
+int zk_cs_next_available_row(zk_cs* cs, uint64_t* row) {
+    NEED(cs); NEED(row);
+    return guard([&] { *row = cs->cs->next_available_row(); });
+}
+int zk_cs_finalize(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { cs->cs->finalize(); });
+}
+int zk_cs_set_batch(zk_cs* cs, uint32_t n) {
+    NEED(cs); NEED_INIT();
+    return guard([&] { cs->cs->set_batch(n); });
+}
+int zk_cs_bind_inputs(zk_cs* cs, int loop_scope, const uint64_t* dev_words, uint32_t n_words) {
+    NEED(cs);
+    return guard([&] { cs->cs->bind_inputs(loop_scope != 0, dev_words, n_words); });
+}
+int zk_cs_resolve(zk_cs* cs, void* stream) {
+    NEED(cs); NEED_INIT();
+    return guard([&] { cs->cs->resolve(stream); });
+}
+int zk_cs_check_satisfied(zk_cs* cs, void* stream, zk_failure* first) {
+    NEED(cs); NEED_INIT();
+    int result = ZK_OK;
+    int rc = guard([&] { result = cs->cs->check_satisfied(stream, first); });
+    if (rc) return rc;
+    if (result == ZK_ERR_UNSATISFIED) return fail(ZK_ERR_UNSATISFIED, "constraint system is not satisfied");
+    return result;
+}
+int zk_cs_read_var(zk_cs* cs, zk_var var, uint32_t instance, uint32_t iteration, uint64_t* out) {
+    NEED(cs); NEED(out);
+    return guard([&] { *out = cs->cs->read_var(var, instance, iteration); });
+}
+int zk_cs_write_cell(zk_cs* cs, int loop_scope, uint32_t cell, uint32_t lane, uint64_t value) {
+    NEED(cs);
+    return guard([&] { cs->cs->write_cell(loop_scope != 0, cell, lane, value); });
+}
+int zk_cs_public_inputs(zk_cs* cs, uint32_t instance, uint64_t* out, uint32_t max, uint32_t* n) {
+    NEED(cs); NEED(n);
+    return guard([&] {
+        auto v = cs->cs->public_inputs(instance);
+        *n = (uint32_t)v.size();
+        if (out) for (uint32_t i = 0; i < v.size() && i < max; ++i) out[i] = v[i];
+    });
+}
+int zk_cs_var_cell(zk_cs* cs, zk_var var, uint32_t* cell) {
+    NEED(cs); NEED(cell);
+    return guard([&] { *cell = cs->cs->var_cell(var); });
+}
+int zk_cs_public_cells(zk_cs* cs, uint32_t* cells, uint32_t max, uint32_t* n) {
+    NEED(cs); NEED(n);
+    return guard([&] {
+        auto v = cs->cs->public_cells();
+        *n = (uint32_t)v.size();
+        if (cells) for (uint32_t i = 0; i < v.size() && i < max; ++i) cells[i] = v[i];
+    });
+}
+int zk_cs_multiplicities(zk_cs* cs, uint32_t instance, uint32_t* out, uint32_t max, uint32_t* n) {
+    NEED(cs); NEED(n);
+    return guard([&] {
+        auto v = cs->cs->multiplicities(instance);
+        *n = (uint32_t)v.size();
+        if (out) for (uint32_t i = 0; i < v.size() && i < max; ++i) out[i] = v[i];
+    });
+}
+int zk_cs_stats(zk_cs* cs, zk_stats* out) {
+    NEED(cs); NEED(out);
+    return guard([&] { cs->cs->stats(out); });
+}
+int zk_cs_last_ms(zk_cs* cs, int which, float* ms) {
+    NEED(cs); NEED(ms);
+    *ms = cs->cs->last_ms(which);
+    return *ms < 0 ? fail(ZK_ERR_INVALID, "bad timer index") : ZK_OK;
+}
+int zk_cs_export(zk_cs* cs, int loop_scope, uint32_t* buf, size_t max_words, size_t* n_words) {
+    NEED(cs); NEED(n_words);
+    return guard([&] {
+        if (!cs->cs->finalized()) throw zkgl::ZkError(ZK_ERR_INVALID, "export before finalize");
+        auto v = cs->cs->export_scope(loop_scope != 0);
+        *n_words = v.size();
+        if (buf) {
+            if (max_words < v.size()) throw zkgl::ZkError(ZK_ERR_INVALID, "export buffer too small");
+            std::memcpy(buf, v.data(), v.size() * 4);
+        }
+    });
+}
+int zk_cs_trace_ptr(zk_cs* cs, int loop_scope, uint64_t** dev_cells, uint64_t* n_cells, uint64_t* stride) {
+    NEED(cs); NEED(dev_cells); NEED(n_cells); NEED(stride);
+    return guard([&] { cs->cs->trace_ptr(loop_scope != 0, dev_cells, n_cells, stride); });
+}
+
+// ---- circuits ----
+int zk_circuit_ram_permutation_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::ram_permutation_configure(*cs->cs); });
+}
+int zk_circuit_ram_permutation(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { zkgl::ram_permutation_entry_point(*cs->cs, limit); });
+}
+int zk_circuit_input_words(zk_cs* cs, uint32_t* outer_words, uint32_t* loop_words) {
+    NEED(cs); NEED(outer_words); NEED(loop_words);
+    *outer_words = cs->cs->outer_input_words();
+    *loop_words = cs->cs->loop_input_words();
+    return ZK_OK;
+}
+int zk_circuit_vm_shaped_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::vm_shaped_configure(*cs->cs); });
+}
+int zk_circuit_vm_shaped(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { zkgl::vm_shaped_entry_point(*cs->cs, limit); });
+}
+
+}  // extern "C"

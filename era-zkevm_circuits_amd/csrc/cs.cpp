@@ -1,0 +1,775 @@
+// cs.cpp — recorder / placer / program emitter / GPU executor.  See cs.hpp.
+#include "cs.hpp"
+#include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <cstring>
+#include "device_api.hpp"
+
+namespace zkgl {
+
+namespace {
+
+struct GateInfo { uint32_t width, n_consts, n_relations; };
+// widths match zke::GATE_WIDTH (kernels_engine.hpp)
+const GateInfo GATES[ZK_GATE__COUNT] = {
+    {0, 0, 0},   // NOP
+    {1, 1, 1},   // CONST (one constant per instance, see place_scope)
+    {1, 0, 1},   // BOOLEAN
+    {4, 2, 1},   // FMA
+    {5, 4, 1},   // REDUCTION4
+    {4, 0, 1},   // SELECT
+    {3, 0, 2},   // ZEROCHECK
+    {5, 1, 1},   // UINTX_ADD
+    {9, 0, 1},   // DOT4
+    {24, 0, 12}, // MATMUL12_EXT
+    {24, 0, 12}, // MATMUL12_INT
+    {1, 0, 0},   // PUBLIC_INPUT
+    {6, 0, 1},   // U32_FMA
+};
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw ZkError(ZK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+void dev_check(int rc) {
+    if (rc != 0) throw ZkError(ZK_ERR_HIP, zkdev::last_hip_error());
+}
+
+template <class T>
+T* upload(const std::vector<T>& v) {
+    T* d = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    hip_check(hipMalloc((void**)&d, bytes), "hipMalloc");
+    if (!v.empty()) hip_check(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
+    return d;
+}
+
+}  // namespace
+
+CS::CS(const zk_geometry& g, uint64_t max_trace_len, uint64_t max_variables)
+    : geo_(g), max_trace_len_(max_trace_len), max_variables_(max_variables) {
+    if (g.num_columns_under_copy_permutation < 24)
+        throw ZkError(ZK_ERR_INVALID, "geometry: need >= 24 copy columns (MatrixMultiplicationGate<12>)");
+    if (g.num_constant_columns < 4) throw ZkError(ZK_ERR_INVALID, "geometry: need >= 4 constant columns");
+    loop_.is_loop = true;
+    // NOP and PUBLIC_INPUT are always available
+    allowed_gates_ = (1ull << ZK_GATE_NOP) | (1ull << ZK_GATE_PUBLIC_INPUT);
+}
+
+CS::~CS() {
+    free_scope_device(outer_);
+    free_scope_device(loop_);
+    if (d_tables_) hipFree(d_tables_);
+    if (d_table_words_) hipFree(d_table_words_);
+    if (d_mult_) hipFree(d_mult_);
+    if (d_links_) hipFree(d_links_);
+    if (d_fail_) hipFree(d_fail_);
+    for (auto& e : ev_)
+        if (e) hipEventDestroy((hipEvent_t)e);
+}
+
+void CS::free_scope_device(Scope& s) {
+    if (s.d_prog) hipFree(s.d_prog);
+    if (s.d_consts) hipFree(s.d_consts);
+    if (s.d_rows) hipFree(s.d_rows);
+    if (s.d_rowconsts) hipFree(s.d_rowconsts);
+    if (s.d_lrows) hipFree(s.d_lrows);
+    if (s.d_copies) hipFree(s.d_copies);
+    if (s.d_cells) hipFree(s.d_cells);
+    s.d_prog = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
+    s.d_copies = nullptr; s.d_cells = nullptr;
+}
+
+// ------------------------------------------------------------------ configuration
+void CS::allow_lookup(uint32_t width, uint32_t reps, bool share) {
+    if (finalized_) throw ZkError(ZK_ERR_INVALID, "allow_lookup after finalize");
+    if (width < 2 || width > 4 || reps == 0) throw ZkError(ZK_ERR_INVALID, "lookup width must be 2..4, reps > 0");
+    lookup_width_ = width; lookup_reps_ = reps; lookup_share_id_ = share;
+}
+void CS::allow_gate(uint32_t kind) {
+    if (kind >= ZK_GATE__COUNT) throw ZkError(ZK_ERR_INVALID, "unknown gate kind");
+    allowed_gates_ |= 1ull << kind;
+}
+bool CS::gate_is_allowed(uint32_t kind) const { return kind < ZK_GATE__COUNT && ((allowed_gates_ >> kind) & 1); }
+
+uint32_t CS::add_table(uint32_t marker, uint32_t n_keys, uint32_t n_vals, const uint64_t* rows, uint32_t n_rows) {
+    if (finalized_) throw ZkError(ZK_ERR_INVALID, "add_table after finalize");
+    if (lookup_width_ == 0) throw ZkError(ZK_ERR_INVALID, "add_table: lookups not allowed in this CS");
+    if (n_keys == 0 || n_keys > 3 || n_keys + n_vals > lookup_width_ || n_rows == 0)
+        throw ZkError(ZK_ERR_INVALID, "add_table: bad shape for the configured lookup width");
+    for (auto& t : tables_)
+        if (t.marker == marker) throw ZkError(ZK_ERR_INVALID, "add_table: marker already registered");
+    TableRec t;
+    t.marker = marker; t.n_keys = n_keys; t.n_vals = n_vals; t.n_rows = n_rows;
+    const uint32_t w = n_keys + n_vals;
+    // sort rows by key tuple (the device binary-searches; the dense test below needs sorted rows too)
+    std::vector<uint32_t> order(n_rows);
+    for (uint32_t i = 0; i < n_rows; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        for (uint32_t k = 0; k < n_keys; ++k) {
+            if (rows[(size_t)x * w + k] != rows[(size_t)y * w + k]) return rows[(size_t)x * w + k] < rows[(size_t)y * w + k];
+        }
+        return x < y;
+    });
+    t.rows.resize((size_t)n_rows * w);
+    for (uint32_t i = 0; i < n_rows; ++i) {
+        std::memcpy(&t.rows[(size_t)i * w], &rows[(size_t)order[i] * w], w * sizeof(uint64_t));
+        for (uint32_t k = 0; k < w; ++k)
+            if (t.rows[(size_t)i * w + k] >= 0xFFFFFFFF00000001ull) throw ZkError(ZK_ERR_INVALID, "add_table: non-canonical element");
+        if (i > 0 && std::memcmp(&t.rows[(size_t)i * w], &t.rows[(size_t)(i - 1) * w], n_keys * sizeof(uint64_t)) == 0)
+            throw ZkError(ZK_ERR_INVALID, "add_table: duplicate key tuple");
+    }
+    // dense test: keys are a full product of power-of-two ranges, last key fastest
+    t.dense = false;
+    t.key_shift[0] = t.key_shift[1] = t.key_shift[2] = 0;
+    {
+        uint64_t maxk[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < n_rows; ++i)
+            for (uint32_t k = 0; k < n_keys; ++k) maxk[k] = std::max(maxk[k], t.rows[(size_t)i * w + k]);
+        uint32_t bits[3] = {0, 0, 0};
+        bool ok = true;
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < n_keys; ++k) {
+            uint64_t m = maxk[k] + 1;
+            if (m & (m - 1)) { ok = false; break; }
+            while ((1ull << bits[k]) < m) ++bits[k];
+            total += bits[k];
+        }
+        if (ok && total < 31 && (1ull << total) == n_rows) {
+            uint32_t sh = 0;
+            for (int k = (int)n_keys - 1; k >= 0; --k) { t.key_shift[k] = sh; sh += bits[k]; }
+            // sorted + unique + full product => row index == packed key
+            t.dense = true;
+        }
+    }
+    tables_.push_back(std::move(t));
+    return (uint32_t)tables_.size();
+}
+
+uint32_t CS::table_id(uint32_t marker) const {
+    for (size_t i = 0; i < tables_.size(); ++i)
+        if (tables_[i].marker == marker) return (uint32_t)i + 1;
+    throw ZkError(ZK_ERR_INVALID, "table must be added before");  // reference: src/main_vm/utils.rs:95-97
+}
+
+// ------------------------------------------------------------------ recording
+void CS::check_var(zk_var v, bool want_loop) const {
+    if (v == ZK_VAR_NONE) throw ZkError(ZK_ERR_INVALID, "placeholder variable used");
+    const Scope& s = is_loop_var(v) ? loop_ : outer_;
+    if (var_index(v) >= s.n_vars) throw ZkError(ZK_ERR_INVALID, "variable index out of range");
+    if (is_loop_var(v) != want_loop)
+        throw ZkError(ZK_ERR_INVALID, want_loop ? "outer variable used inside the loop without loop_import"
+                                                : "loop variable used outside the loop without loop_last");
+}
+
+zk_var CS::alloc_vars(uint32_t n) {
+    if (finalized_) throw ZkError(ZK_ERR_INVALID, "alloc after finalize");
+    Scope& s = cur();
+    if ((uint64_t)outer_.n_vars + loop_.n_vars + n > max_variables_) throw ZkError(ZK_ERR_CAPACITY, "max_variables exceeded");
+    uint32_t first = s.n_vars;
+    s.n_vars += n;
+    return first | (in_loop_ ? LOOP_BIT : 0);
+}
+zk_var CS::alloc_var() { return alloc_vars(1); }
+
+uint32_t CS::pool_const(Scope& s, uint64_t v) {
+    auto it = s.const_pool_idx.find(v);
+    if (it != s.const_pool_idx.end()) return it->second;
+    uint32_t idx = (uint32_t)s.const_pool.size();
+    s.const_pool.push_back(v);
+    s.const_pool_idx.emplace(v, idx);
+    return idx;
+}
+
+zk_var CS::alloc_constant(uint64_t value) {
+    if (value >= 0xFFFFFFFF00000001ull) throw ZkError(ZK_ERR_INVALID, "allocate_constant: non-canonical value");
+    Scope& s = cur();
+    auto it = s.const_vars.find(value);
+    if (it != s.const_vars.end()) return it->second | (in_loop_ ? LOOP_BIT : 0);
+    if (!gate_is_allowed(ZK_GATE_CONST)) throw ZkError(ZK_ERR_GATE_NOT_ALLOWED, "ConstantsAllocatorGate not allowed");
+    zk_var v = alloc_var();
+    OpRec op{ZK_OP_CONST, 0, 0, {{Operand::CONSTPOOL, pool_const(s, value)}}, {var_index(v)}};
+    s.ops.push_back(std::move(op));
+    GateRec g{ZK_GATE_CONST, {var_index(v)}, {value}};
+    s.gates.push_back(std::move(g));
+    s.const_vars.emplace(value, var_index(v));
+    return v;
+}
+
+zk_var CS::input(uint32_t word) {
+    Scope& s = cur();
+    zk_var v = alloc_var();
+    OpRec op{ZK_OP_INPUT, 0, 0, {{Operand::RAW, word}}, {var_index(v)}};
+    s.ops.push_back(std::move(op));
+    s.n_input_words = std::max(s.n_input_words, word + 1);
+    return v;
+}
+
+void CS::place_gate(uint32_t kind, const zk_var* vars, uint32_t n_vars, const uint64_t* consts, uint32_t n_consts) {
+    if (finalized_) throw ZkError(ZK_ERR_INVALID, "place_gate after finalize");
+    if (kind >= ZK_GATE__COUNT || kind == ZK_GATE_NOP) throw ZkError(ZK_ERR_INVALID, "place_gate: bad kind");
+    if (!gate_is_allowed(kind)) throw ZkError(ZK_ERR_GATE_NOT_ALLOWED, "gate kind not configured for this CS");
+    const GateInfo& gi = GATES[kind];
+    if (n_vars != gi.width || n_consts != gi.n_consts) throw ZkError(ZK_ERR_INVALID, "place_gate: wrong arity");
+    if (gi.n_consts > geo_.num_constant_columns) throw ZkError(ZK_ERR_INVALID, "gate needs more constant columns");
+    Scope& s = cur();
+    GateRec g;
+    g.kind = kind;
+    for (uint32_t i = 0; i < n_vars; ++i) {
+        check_var(vars[i], in_loop_);
+        g.vars.push_back(var_index(vars[i]));
+    }
+    for (uint32_t i = 0; i < n_consts; ++i) {
+        if (consts[i] >= 0xFFFFFFFF00000001ull) throw ZkError(ZK_ERR_INVALID, "place_gate: non-canonical constant");
+        g.consts.push_back(consts[i]);
+    }
+    if (kind == ZK_GATE_PUBLIC_INPUT) {
+        if (in_loop_) throw ZkError(ZK_ERR_INVALID, "public inputs must be outer-scope variables");
+        public_vars_.push_back(g.vars[0]);
+    }
+    s.gates.push_back(std::move(g));
+}
+
+void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uint32_t n_in, const zk_var* outs,
+                 uint32_t n_out, const uint64_t* imm, uint32_t n_imm) {
+    if (finalized_) throw ZkError(ZK_ERR_INVALID, "emit_op after finalize");
+    Scope& s = cur();
+    OpRec op;
+    op.opcode = (uint8_t)opcode; op.a = (uint8_t)a; op.b = (uint16_t)b;
+    auto need = [&](uint32_t nin, uint32_t nout, uint32_t nimm) {
+        if (n_in != nin || n_out != nout || n_imm != nimm) throw ZkError(ZK_ERR_INVALID, "emit_op: wrong arity for opcode");
+    };
+    switch (opcode) {
+    case ZK_OP_FMA: need(3, 1, 2); break;
+    case ZK_OP_LC4: need(4, 1, 4); break;
+    case ZK_OP_SELECT: need(3, 1, 0); break;
+    case ZK_OP_ISZERO: need(1, 2, 0); break;
+    case ZK_OP_UADD: case ZK_OP_USUB:
+        need(3, 2, 0);
+        if (a == 0 || a > 32) throw ZkError(ZK_ERR_INVALID, "UADD/USUB: bits must be 1..32");
+        break;
+    case ZK_OP_DOT4: need(8, 1, 0); break;
+    case ZK_OP_MATMUL12: need(12, 12, 0); if (a > 1) throw ZkError(ZK_ERR_INVALID, "MATMUL12: matrix id 0/1"); break;
+    case ZK_OP_SPLIT:
+        if (n_in != 1 || n_imm != 0 || n_out != a || a == 0 || b == 0 || b > 32) throw ZkError(ZK_ERR_INVALID, "SPLIT: bad shape");
+        break;
+    case ZK_OP_POSEIDON2: need(12, 12, 0); break;
+    case ZK_OP_P2_ROUNDS: need(12, 962, 0); break;
+    case ZK_OP_U32MULADD: need(4, 2, 0); break;
+    default: throw ZkError(ZK_ERR_INVALID, "emit_op: opcode not recordable through this entry");
+    }
+    for (uint32_t i = 0; i < n_imm; ++i) {
+        if (imm[i] >= 0xFFFFFFFF00000001ull) throw ZkError(ZK_ERR_INVALID, "emit_op: non-canonical immediate");
+        op.ins.push_back({Operand::CONSTPOOL, pool_const(s, imm[i])});
+    }
+    for (uint32_t i = 0; i < n_in; ++i) {
+        check_var(ins[i], in_loop_);
+        op.ins.push_back({Operand::VAR, var_index(ins[i])});
+    }
+    for (uint32_t i = 0; i < n_out; ++i) {
+        check_var(outs[i], in_loop_);
+        op.outs.push_back(var_index(outs[i]));
+    }
+    s.ops.push_back(std::move(op));
+}
+
+void CS::lookup(uint32_t tid, const zk_var* keys, uint32_t n_keys, zk_var* vals, uint32_t n_vals) {
+    if (tid == 0 || tid > tables_.size()) throw ZkError(ZK_ERR_INVALID, "perform_lookup: unknown table id");
+    const TableRec& t = tables_[tid - 1];
+    if (n_keys != t.n_keys || n_vals != t.n_vals) throw ZkError(ZK_ERR_INVALID, "perform_lookup: K/V mismatch with table");
+    Scope& s = cur();
+    LookupRec lr;
+    lr.table = tid;
+    OpRec op;
+    op.opcode = ZK_OP_LOOKUP; op.a = (uint8_t)n_keys; op.b = (uint16_t)n_vals;
+    op.ins.push_back({Operand::RAW, tid});
+    for (uint32_t i = 0; i < n_keys; ++i) {
+        check_var(keys[i], in_loop_);
+        op.ins.push_back({Operand::VAR, var_index(keys[i])});
+        lr.vars.push_back(var_index(keys[i]));
+    }
+    zk_var first = alloc_vars(n_vals);
+    for (uint32_t i = 0; i < n_vals; ++i) {
+        vals[i] = first + i;
+        op.outs.push_back(var_index(first) + i);
+        lr.vars.push_back(var_index(first) + i);
+    }
+    s.ops.push_back(std::move(op));
+    s.lookups.push_back(std::move(lr));
+}
+
+void CS::loop_begin(uint32_t limit) {
+    if (in_loop_ || loop_done_) throw ZkError(ZK_ERR_INVALID, "only one loop scope per circuit");
+    if (limit == 0) throw ZkError(ZK_ERR_INVALID, "loop limit must be > 0");
+    in_loop_ = true;
+    limit_ = limit;
+    outer_.pre_ops = outer_.ops.size();
+}
+void CS::loop_end() {
+    if (!in_loop_) throw ZkError(ZK_ERR_INVALID, "loop_end without loop_begin");
+    in_loop_ = false;
+    loop_done_ = true;
+}
+
+void CS::link(uint32_t kind, zk_var loop_var, zk_var other) {
+    if (kind > ZK_LINK_BCAST) throw ZkError(ZK_ERR_INVALID, "link: bad kind");
+    check_var(loop_var, true);
+    check_var(other, kind == ZK_LINK_CARRY);
+    links_raw_.push_back({kind, var_index(loop_var), var_index(other), 0});
+}
+
+zk_var CS::loop_last(zk_var loop_var) {
+    if (in_loop_ || !loop_done_) throw ZkError(ZK_ERR_INVALID, "loop_last only after loop_end");
+    check_var(loop_var, true);
+    zk_var v = alloc_var();
+    OpRec op{ZK_OP_LOOP_LAST, 0, 0, {{Operand::RAW, var_index(loop_var)}}, {var_index(v)}};
+    outer_.ops.push_back(std::move(op));
+    links_raw_.push_back({ZK_LINK_LAST, var_index(loop_var), var_index(v), 0});
+    return v;
+}
+
+zk_var CS::loop_import(zk_var outer_var) {
+    if (!in_loop_) throw ZkError(ZK_ERR_INVALID, "loop_import outside the loop");
+    check_var(outer_var, false);
+    zk_var v = alloc_var();
+    // value copy: FMA-free "select"-less move expressed as CONST-like op with an OUTER operand
+    OpRec op{ZK_OP_CONST, 0, 0, {{Operand::OUTER_VAR, var_index(outer_var)}}, {var_index(v)}};
+    loop_.ops.push_back(std::move(op));
+    links_raw_.push_back({ZK_LINK_BCAST, var_index(v), var_index(outer_var), 0});
+    return v;
+}
+
+uint64_t CS::next_available_row() const {
+    if (finalized_) return (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
+    return 0;
+}
+
+// ------------------------------------------------------------------ placement
+void CS::place_scope(Scope& s) {
+    const uint32_t C = geo_.num_columns_under_copy_permutation;
+    struct Open { uint32_t slot, used, cap; };
+    std::map<std::pair<uint32_t, std::vector<uint64_t>>, Open> open;
+    std::vector<std::pair<uint32_t, uint32_t>> tmp_cells;  // (col, slot) per placed cell, per var appended below
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> vc(s.n_vars);
+    s.rows.clear(); s.rowconsts.clear();
+    uint32_t n_gate_slots = 0;
+    for (auto& g : s.gates) {
+        const GateInfo& gi = GATES[g.kind];
+        std::pair<uint32_t, std::vector<uint64_t>> key{g.kind, g.kind == ZK_GATE_CONST ? std::vector<uint64_t>{} : g.consts};
+        uint32_t cap = C / gi.width;
+        if (g.kind == ZK_GATE_CONST) cap = std::min(cap, geo_.num_constant_columns);
+        auto it = open.find(key);
+        if (it == open.end() || it->second.used == it->second.cap) {
+            Open o{n_gate_slots++, 0, cap};
+            zk_row_desc rd{g.kind, 0, (uint32_t)s.rowconsts.size(), g.kind == ZK_GATE_CONST ? 0u : gi.n_consts};
+            s.rows.push_back(rd);
+            if (g.kind == ZK_GATE_CONST) s.rowconsts.resize(s.rowconsts.size() + cap, 0);
+            else s.rowconsts.insert(s.rowconsts.end(), g.consts.begin(), g.consts.end());
+            if (it == open.end()) it = open.emplace(key, o).first; else it->second = o;
+        }
+        Open& o = it->second;
+        uint32_t j = o.used++;
+        zk_row_desc& rd = s.rows[o.slot];
+        rd.n_instances = o.used;
+        if (g.kind == ZK_GATE_CONST) { s.rowconsts[rd.const_off + j] = g.consts[0]; rd.n_consts = o.used; }
+        for (uint32_t c = 0; c < gi.width; ++c) vc[g.vars[c]].push_back({j * gi.width + c, o.slot});
+        s.gate_counts[g.kind]++;
+        s.n_constraints += gi.n_relations;
+    }
+    // lookups: one table per row, lookup_reps_ tuples per row
+    s.lrows.clear();
+    uint32_t n_lookup_slots = 0;
+    std::map<uint32_t, Open> lopen;
+    for (auto& l : s.lookups) {
+        auto it = lopen.find(l.table);
+        if (it == lopen.end() || it->second.used == it->second.cap) {
+            Open o{n_lookup_slots++, 0, lookup_reps_};
+            s.lrows.push_back({l.table, 0});
+            if (it == lopen.end()) it = lopen.emplace(l.table, o).first; else it->second = o;
+        }
+        Open& o = it->second;
+        uint32_t u = o.used++;
+        s.lrows[o.slot].n_tuples = o.used;
+        for (uint32_t c = 0; c < l.vars.size(); ++c) vc[l.vars[c]].push_back({C + u * lookup_width_ + c, o.slot});
+        s.n_constraints += 1;
+    }
+    s.n_gate_slots = n_gate_slots;
+    s.n_lookup_slots = n_lookup_slots;
+    s.n_slots = std::max<uint32_t>(1, std::max(n_gate_slots, n_lookup_slots));
+    s.rows.resize(s.n_slots, zk_row_desc{ZK_GATE_NOP, 0, 0, 0});
+    s.lrows.resize(s.n_slots, zk_lookup_row_desc{0xffffffffu, 0});
+    const uint32_t total_cols = C + lookup_width_ * lookup_reps_;
+    uint64_t ntc = (uint64_t)total_cols * s.n_slots;
+    if (ntc >= 0x3fffffffull) throw ZkError(ZK_ERR_CAPACITY, "scope too large for 30-bit cell indices");
+    s.n_trace_cells = (uint32_t)ntc;
+    s.var_cells.assign(s.n_vars, {});
+    s.n_scratch = 0;
+    for (uint32_t v = 0; v < s.n_vars; ++v) {
+        for (auto& cs : vc[v]) s.var_cells[v].push_back(cs.first * s.n_slots + cs.second);
+        if (s.var_cells[v].empty()) s.var_cells[v].push_back(s.n_trace_cells + s.n_scratch++);
+    }
+    s.n_cells = s.n_trace_cells + s.n_scratch;
+    s.copies.clear();
+    for (uint32_t v = 0; v < s.n_vars; ++v)
+        for (size_t i = 1; i < s.var_cells[v].size(); ++i) s.copies.push_back({s.var_cells[v][i], s.var_cells[v][0]});
+}
+
+// ------------------------------------------------------------------ program emission
+void CS::emit_scope(Scope& s) {
+    std::vector<uint8_t> defined(s.n_vars, 0);
+    s.prog.clear();
+    s.pre_words = 0;
+    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+        if (!s.is_loop && oi == s.pre_ops) s.pre_words = (uint32_t)s.prog.size();
+        const OpRec& op = s.ops[oi];
+        s.prog.push_back((uint32_t)op.opcode | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
+        for (auto& in : op.ins) {
+            switch (in.kind) {
+            case Operand::VAR:
+                if (!defined[in.idx]) throw ZkError(ZK_ERR_UNRESOLVED, "witness op reads a variable no earlier op produced");
+                s.prog.push_back(s.var_cells[in.idx][0]);
+                break;
+            case Operand::CONSTPOOL: s.prog.push_back(ZK_OPERAND_CONST | in.idx); break;
+            case Operand::OUTER_VAR: s.prog.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]); break;
+            case Operand::RAW:
+                if (op.opcode == ZK_OP_LOOP_LAST) s.prog.push_back(loop_.var_cells[in.idx][0]);
+                else s.prog.push_back(in.idx);
+                break;
+            }
+        }
+        for (uint32_t ov : op.outs) {
+            if (defined[ov]) throw ZkError(ZK_ERR_INVALID, "variable produced twice");
+            defined[ov] = 1;
+            const auto& cells = s.var_cells[ov];
+            for (size_t i = 0; i < cells.size(); ++i) s.prog.push_back(cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0));
+        }
+    }
+    if (!s.is_loop && s.pre_ops >= s.ops.size()) s.pre_words = (uint32_t)s.prog.size();
+    for (auto& g : s.gates)
+        for (uint32_t v : g.vars)
+            if (!defined[v]) throw ZkError(ZK_ERR_UNRESOLVED, "gate references a variable without a witness producer");
+    for (auto& l : s.lookups)
+        for (uint32_t v : l.vars)
+            if (!defined[v]) throw ZkError(ZK_ERR_UNRESOLVED, "lookup references a variable without a witness producer");
+}
+
+void CS::upload_scope(Scope& s) {
+    s.d_prog = upload(s.prog);
+    s.d_consts = upload(s.const_pool);
+    s.d_rows = upload(s.rows);
+    s.d_rowconsts = upload(s.rowconsts);
+    s.d_lrows = upload(s.lrows);
+    s.d_copies = upload(s.copies);
+}
+
+void CS::finalize() {
+    if (finalized_) throw ZkError(ZK_ERR_INVALID, "already finalized");
+    if (in_loop_) throw ZkError(ZK_ERR_INVALID, "finalize inside loop scope");
+    if (!loop_done_) { limit_ = 0; outer_.pre_ops = outer_.ops.size(); }
+    place_scope(outer_);
+    place_scope(loop_);
+    // pre-phase outer vars imported by the loop must be produced before the loop: verified by op order
+    if (loop_done_) {
+        std::vector<uint8_t> pre_defined(outer_.n_vars, 0);
+        for (size_t oi = 0; oi < std::min(outer_.pre_ops, outer_.ops.size()); ++oi)
+            for (uint32_t ov : outer_.ops[oi].outs) pre_defined[ov] = 1;
+        for (auto& op : loop_.ops)
+            for (auto& in : op.ins)
+                if (in.kind == Operand::OUTER_VAR && !pre_defined[in.idx])
+                    throw ZkError(ZK_ERR_UNRESOLVED, "loop imports an outer variable that is produced after the loop");
+    }
+    emit_scope(outer_);
+    emit_scope(loop_);
+    uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
+    if (!loop_done_) rows = outer_.n_slots;
+    if (rows > max_trace_len_) throw ZkError(ZK_ERR_CAPACITY, "trace rows exceed max_trace_len");
+    // links: vars -> home cells
+    links_.clear();
+    for (auto& l : links_raw_) {
+        zk_link r;
+        r.kind = l.kind; r.pad = 0;
+        r.loop_cell = loop_.var_cells[l.loop_cell][0];
+        r.other_cell = (l.kind == ZK_LINK_CARRY ? loop_ : outer_).var_cells[l.other_cell][0];
+        links_.push_back(r);
+    }
+    // tables
+    std::vector<zk_table_desc> tdesc(tables_.size() + 1);
+    std::memset(tdesc.data(), 0, tdesc.size() * sizeof(zk_table_desc));
+    std::vector<uint64_t> words;
+    total_table_rows_ = 0;
+    for (size_t i = 0; i < tables_.size(); ++i) {
+        TableRec& t = tables_[i];
+        t.word_off = (uint32_t)words.size();
+        t.mult_off = total_table_rows_;
+        words.insert(words.end(), t.rows.begin(), t.rows.end());
+        total_table_rows_ += t.n_rows;
+        zk_table_desc& d = tdesc[i + 1];
+        d.word_off = t.word_off; d.mult_off = t.mult_off; d.n_rows = t.n_rows; d.n_keys = t.n_keys; d.n_vals = t.n_vals;
+        d.dense = t.dense ? 1 : 0;
+        for (int k = 0; k < 3; ++k) d.key_shift[k] = t.key_shift[k];
+    }
+    tdesc_host_ = tdesc;
+    table_words_host_ = words;
+    finalized_ = true;
+}
+
+// ------------------------------------------------------------------ execution
+// device upload (fails loudly without a GPU: the product path has no CPU fallback)
+void CS::ensure_uploaded() {
+    if (uploaded_) return;
+    upload_scope(outer_);
+    upload_scope(loop_);
+    d_tables_ = upload(tdesc_host_);
+    d_table_words_ = upload(table_words_host_);
+    d_links_ = upload(links_);
+    hip_check(hipMalloc((void**)&d_fail_, 8 * sizeof(unsigned long long)), "hipMalloc fail words");
+    for (auto& e : ev_) {
+        hipEvent_t he;
+        hip_check(hipEventCreate(&he), "hipEventCreate");
+        e = (void*)he;
+    }
+    uploaded_ = true;
+}
+
+void CS::set_batch(uint32_t n) {
+    if (!finalized_) throw ZkError(ZK_ERR_INVALID, "set_batch before finalize");
+    if (n == 0) throw ZkError(ZK_ERR_INVALID, "batch must be > 0");
+    ensure_uploaded();
+    auto alloc_cells = [&](Scope& s, uint64_t lanes) {
+        if (s.d_cells) { hipFree(s.d_cells); s.d_cells = nullptr; }
+        s.n_lanes = (uint32_t)lanes;
+        s.stride = (lanes + 31) / 32 * 32;
+        size_t bytes = std::max<size_t>((size_t)s.n_cells * s.stride * 8, 8);
+        hip_check(hipMalloc((void**)&s.d_cells, bytes), "hipMalloc trace cells");
+        hip_check(hipMemset(s.d_cells, 0, bytes), "hipMemset trace cells");
+    };
+    uint64_t loop_lanes = (uint64_t)n * limit_;
+    if (loop_lanes >= 0xffffffffull) throw ZkError(ZK_ERR_CAPACITY, "batch*limit exceeds 32-bit lane index");
+    alloc_cells(outer_, n);
+    alloc_cells(loop_, loop_lanes);
+    if (d_mult_) { hipFree(d_mult_); d_mult_ = nullptr; }
+    size_t mbytes = std::max<size_t>((size_t)n * total_table_rows_ * 4, 4);
+    hip_check(hipMalloc((void**)&d_mult_, mbytes), "hipMalloc multiplicities");
+    batch_ = n;
+    outer_.d_inputs = nullptr; loop_.d_inputs = nullptr;
+    outer_.bound_input_words = loop_.bound_input_words = 0;
+}
+
+void CS::bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words) {
+    if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "bind_inputs before set_batch");
+    Scope& s = loop_scope ? loop_ : outer_;
+    if (n_words < s.n_input_words) throw ZkError(ZK_ERR_INVALID, "bind_inputs: fewer words than the circuit reads");
+    s.d_inputs = dev_words;
+    s.bound_input_words = n_words;
+}
+
+static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Scope& loop, uint32_t limit,
+                                   const zk_table_desc* tables, const uint64_t* words, uint32_t* mult, uint32_t total_rows) {
+    zkdev::ScopeArgs a;
+    a.prog = s.d_prog; a.n_words = (uint32_t)s.prog.size(); a.n_lanes = s.n_lanes; a.consts = s.d_consts;
+    a.cells = s.d_cells; a.stride = s.stride; a.inputs = s.d_inputs;
+    a.outer_cells = outer.d_cells; a.outer_stride = outer.stride;
+    a.limit = s.is_loop ? limit : 1; a.is_loop = s.is_loop ? 1 : 0;
+    a.tables = tables; a.table_words = words; a.mult = mult; a.total_table_rows = total_rows;
+    a.loop_cells = loop.d_cells; a.loop_stride = loop.stride; a.loop_limit = limit;
+    return a;
+}
+
+void CS::resolve(void* stream) {
+    if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "resolve before set_batch");
+    if (outer_.n_input_words && !outer_.d_inputs) throw ZkError(ZK_ERR_INVALID, "outer input stream not bound");
+    if (loop_.n_input_words && !loop_.d_inputs) throw ZkError(ZK_ERR_INVALID, "loop input stream not bound");
+    hipStream_t st = (hipStream_t)stream;
+    hip_check(hipMemsetAsync(d_mult_, 0, std::max<size_t>((size_t)batch_ * total_table_rows_ * 4, 4), st), "memset mult");
+    auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
+    auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
+    hip_check(hipEventRecord((hipEvent_t)ev_[0], st), "event");
+    dev_check(zkdev::launch_witness(oa, 0, outer_.pre_words, st));
+    hip_check(hipEventRecord((hipEvent_t)ev_[1], st), "event");
+    if (limit_) dev_check(zkdev::launch_witness(la, 0, (uint32_t)loop_.prog.size(), st));
+    hip_check(hipEventRecord((hipEvent_t)ev_[2], st), "event");
+    dev_check(zkdev::launch_witness(oa, outer_.pre_words, (uint32_t)outer_.prog.size(), st));
+    hip_check(hipEventRecord((hipEvent_t)ev_[3], st), "event");
+    hip_check(hipStreamSynchronize(st), "resolve sync");
+    float a = 0, b = 0, c = 0;
+    hipEventElapsedTime(&a, (hipEvent_t)ev_[0], (hipEvent_t)ev_[1]);
+    hipEventElapsedTime(&b, (hipEvent_t)ev_[1], (hipEvent_t)ev_[2]);
+    hipEventElapsedTime(&c, (hipEvent_t)ev_[2], (hipEvent_t)ev_[3]);
+    ms_[0] = a + b + c; ms_[1] = b; ms_[4] = a + c;
+}
+
+int CS::check_satisfied(void* stream, zk_failure* first) {
+    if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "check_satisfied before set_batch");
+    hipStream_t st = (hipStream_t)stream;
+    hip_check(hipMemsetAsync(d_fail_, 0xff, 8 * sizeof(unsigned long long), st), "memset fail");
+    auto check_args = [&](const Scope& s, unsigned long long* fail) {
+        zkdev::CheckArgs a;
+        a.cells = s.d_cells; a.stride = s.stride; a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
+        a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
+        a.lookup_width = lookup_width_; a.tables = d_tables_; a.table_words = d_table_words_; a.fail = fail;
+        // >= ~2048 workgroups: lane tiles x slot chunks
+        uint32_t lane_tiles = (s.n_lanes + 255) / 256;
+        uint32_t chunks = std::max<uint32_t>(1, (2048 + lane_tiles - 1) / std::max<uint32_t>(lane_tiles, 1));
+        chunks = std::min(chunks, s.n_slots);
+        a.slots_per_chunk = (s.n_slots + chunks - 1) / chunks;
+        return a;
+    };
+    hip_check(hipEventRecord((hipEvent_t)ev_[4], st), "event");
+    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_), st));
+    dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.stride, outer_.n_lanes, outer_.d_copies,
+                                         (uint32_t)outer_.copies.size(), d_fail_, st));
+    hip_check(hipEventRecord((hipEvent_t)ev_[5], st), "event");
+    if (limit_) {
+        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3), st));
+        hip_check(hipEventRecord((hipEvent_t)ev_[6], st), "event");
+        dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.stride, loop_.n_lanes, loop_.d_copies,
+                                             (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
+        dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.stride, loop_.n_lanes, limit_, outer_.d_cells,
+                                            outer_.stride, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
+    } else {
+        hip_check(hipEventRecord((hipEvent_t)ev_[6], st), "event");
+    }
+    hip_check(hipEventRecord((hipEvent_t)ev_[7], st), "event");
+    unsigned long long f[8];
+    hip_check(hipMemcpyAsync(f, d_fail_, sizeof f, hipMemcpyDeviceToHost, st), "memcpy fail");
+    hip_check(hipStreamSynchronize(st), "check sync");
+    float tot = 0, g = 0;
+    hipEventElapsedTime(&tot, (hipEvent_t)ev_[4], (hipEvent_t)ev_[7]);
+    hipEventElapsedTime(&g, (hipEvent_t)ev_[5], (hipEvent_t)ev_[6]);
+    ms_[2] = tot; ms_[3] = g;
+    const unsigned long long NONE = ~0ull;
+    for (int sc = 0; sc < 2; ++sc) {
+        const Scope& s = sc ? loop_ : outer_;
+        const unsigned long long* ff = f + 3 * sc;
+        uint32_t lim = sc ? limit_ : 1;
+        auto fill = [&](unsigned long long key, uint32_t slot, uint32_t kind, uint32_t rel) {
+            if (first) {
+                uint32_t lane = (uint32_t)(key >> 32);
+                first->scope = sc; first->instance = lane / lim; first->iteration = lane % lim;
+                first->slot = slot; first->kind = kind; first->relation = rel;
+            }
+        };
+        if (ff[0] != NONE) {
+            uint32_t slot = (uint32_t)((ff[0] >> 12) & 0xfffff), j = (uint32_t)((ff[0] >> 4) & 0xff), rel = (uint32_t)(ff[0] & 0xf);
+            bool is_lookup = (j & 0x80) && rel == 15;
+            fill(ff[0], slot, is_lookup ? 0x100u : s.rows[slot].kind, is_lookup ? (j & 0x7f) : rel);
+            return ZK_ERR_UNSATISFIED;
+        }
+        if (ff[1] != NONE) {  // copy constraint: report the cell index in `slot`
+            uint32_t pi = (uint32_t)(ff[1] & 0xffffffffu);
+            fill(ff[1], s.copies[pi].cell, 0x200u, pi);
+            return ZK_ERR_UNSATISFIED;
+        }
+        if (ff[2] != NONE) {
+            uint32_t li = (uint32_t)(ff[2] & 0xffffffffu);
+            fill(ff[2], links_[li].loop_cell, 0x300u | links_[li].kind, li);
+            return ZK_ERR_UNSATISFIED;
+        }
+    }
+    return ZK_OK;
+}
+
+uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
+    if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "read_var before set_batch");
+    Scope& s = scope_of(v);
+    if (var_index(v) >= s.n_vars || instance >= batch_) throw ZkError(ZK_ERR_INVALID, "read_var: out of range");
+    uint64_t lane = instance;
+    if (s.is_loop) {
+        if (iteration >= limit_) throw ZkError(ZK_ERR_INVALID, "read_var: iteration out of range");
+        lane = (uint64_t)instance * limit_ + iteration;
+    }
+    uint64_t out = 0;
+    hip_check(hipMemcpy(&out, s.d_cells + (size_t)s.var_cells[var_index(v)][0] * s.stride + lane, 8, hipMemcpyDeviceToHost),
+              "read_var memcpy");
+    return out;
+}
+
+void CS::write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value) {
+    Scope& s = loop_scope ? loop_ : outer_;
+    if (batch_ == 0 || cell >= s.n_cells || lane >= s.n_lanes) throw ZkError(ZK_ERR_INVALID, "write_cell: out of range");
+    hip_check(hipMemcpy(s.d_cells + (size_t)cell * s.stride + lane, &value, 8, hipMemcpyHostToDevice), "write_cell memcpy");
+}
+
+std::vector<uint64_t> CS::public_inputs(uint32_t instance) {
+    std::vector<uint64_t> out;
+    for (uint32_t v : public_vars_) out.push_back(read_var(v, instance, 0));
+    return out;
+}
+
+uint32_t CS::var_cell(zk_var v) const {
+    if (!finalized_) throw ZkError(ZK_ERR_INVALID, "var_cell before finalize");
+    const Scope& s = is_loop_var(v) ? loop_ : outer_;
+    if (var_index(v) >= s.n_vars) throw ZkError(ZK_ERR_INVALID, "var_cell: out of range");
+    return s.var_cells[var_index(v)][0];
+}
+std::vector<uint32_t> CS::public_cells() const {
+    if (!finalized_) throw ZkError(ZK_ERR_INVALID, "public_cells before finalize");
+    std::vector<uint32_t> out;
+    for (uint32_t v : public_vars_) out.push_back(outer_.var_cells[v][0]);
+    return out;
+}
+
+std::vector<uint32_t> CS::multiplicities(uint32_t instance) {
+    if (instance >= batch_) throw ZkError(ZK_ERR_INVALID, "multiplicities: instance out of range");
+    std::vector<uint32_t> out(total_table_rows_);
+    if (total_table_rows_)
+        hip_check(hipMemcpy(out.data(), d_mult_ + (size_t)instance * total_table_rows_, (size_t)total_table_rows_ * 4,
+                            hipMemcpyDeviceToHost), "multiplicities memcpy");
+    return out;
+}
+
+void CS::stats(zk_stats* o) const {
+    std::memset(o, 0, sizeof *o);
+    o->loop_slots = loop_.n_slots * (limit_ ? 1 : 0); o->outer_slots = outer_.n_slots; o->limit = limit_;
+    o->rows_per_instance = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
+    o->copy_columns = geo_.num_columns_under_copy_permutation;
+    o->lookup_columns = lookup_width_ * lookup_reps_;
+    o->variables_outer = outer_.n_vars; o->variables_loop = loop_.n_vars;
+    o->constraints_per_instance = outer_.n_constraints + loop_.n_constraints * limit_;
+    o->var_cells_per_instance = o->rows_per_instance * (o->copy_columns + o->lookup_columns);
+    for (int k = 0; k < ZK_GATE__COUNT; ++k) o->gate_instances[k] = outer_.gate_counts[k] + loop_.gate_counts[k] * limit_;
+    o->lookups_per_instance = outer_.lookups.size() + loop_.lookups.size() * (uint64_t)limit_;
+    o->program_words_outer = outer_.prog.size(); o->program_words_loop = loop_.prog.size();
+    o->scratch_cells_outer = outer_.n_scratch; o->scratch_cells_loop = loop_.n_scratch;
+}
+
+float CS::last_ms(int which) const { return (which >= 0 && which < 5) ? ms_[which] : -1.0f; }
+
+// Serialised scope for the CPU oracle:
+// [magic, is_loop, n_cells, n_trace_cells, n_slots, n_copy_cols, lookup_width, n_input_words, limit,
+//  pre_words, n_prog, n_consts, n_rows, n_rowconsts, n_lrows, n_copies, n_tables, n_table_words, n_links]
+// followed by the sections in that order (u64 sections as lo,hi u32 pairs).
+std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
+    const Scope& s = loop_scope ? loop_ : outer_;
+    std::vector<uint32_t> o;
+    auto p64 = [&](uint64_t v) { o.push_back((uint32_t)v); o.push_back((uint32_t)(v >> 32)); };
+    std::vector<uint64_t> words;
+    for (auto& t : tables_) words.insert(words.end(), t.rows.begin(), t.rows.end());
+    uint32_t hdr[19] = {0x5a4b4731u, s.is_loop ? 1u : 0u, s.n_cells, s.n_trace_cells, s.n_slots,
+                        geo_.num_columns_under_copy_permutation, lookup_width_, s.n_input_words, limit_, s.pre_words,
+                        (uint32_t)s.prog.size(), (uint32_t)s.const_pool.size(), (uint32_t)s.rows.size(),
+                        (uint32_t)s.rowconsts.size(), (uint32_t)s.lrows.size(), (uint32_t)s.copies.size(),
+                        (uint32_t)tables_.size() + 1, (uint32_t)words.size(), (uint32_t)(loop_scope ? links_.size() : 0)};
+    o.insert(o.end(), hdr, hdr + 19);
+    o.insert(o.end(), s.prog.begin(), s.prog.end());
+    for (uint64_t c : s.const_pool) p64(c);
+    for (auto& r : s.rows) { o.push_back(r.kind); o.push_back(r.n_instances); o.push_back(r.const_off); o.push_back(r.n_consts); }
+    for (uint64_t c : s.rowconsts) p64(c);
+    for (auto& r : s.lrows) { o.push_back(r.table); o.push_back(r.n_tuples); }
+    for (auto& c : s.copies) { o.push_back(c.cell); o.push_back(c.home); }
+    for (uint32_t i = 0; i < 9; ++i) o.push_back(0);  // table 0 = none
+    for (auto& t : tables_) {
+        o.push_back(t.word_off); o.push_back(t.mult_off); o.push_back(t.n_rows); o.push_back(t.n_keys); o.push_back(t.n_vals);
+        o.push_back(t.dense ? 1 : 0); o.push_back(t.key_shift[0]); o.push_back(t.key_shift[1]); o.push_back(t.key_shift[2]);
+    }
+    for (uint64_t w : words) p64(w);
+    if (loop_scope)
+        for (auto& l : links_) { o.push_back(l.kind); o.push_back(l.loop_cell); o.push_back(l.other_cell); o.push_back(0); }
+    return o;
+}
+
+void CS::trace_ptr(bool loop_scope, uint64_t** cells, uint64_t* n_cells, uint64_t* stride) const {
+    const Scope& s = loop_scope ? loop_ : outer_;
+    *cells = s.d_cells; *n_cells = s.n_cells; *stride = s.stride;
+}
+
+}  // namespace zkgl

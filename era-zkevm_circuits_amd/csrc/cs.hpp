@@ -1,0 +1,194 @@
+// cs.hpp — host-side constraint-system recorder, placer, program emitter and GPU executor.
+//
+// Mirrors the surface of boojum's `ConstraintSystem<F>` + `CsBuilder` as the reference uses it
+// (/root/reference/src/ram_permutation/mod.rs:419-556; call-site inventory in SURVEY.md §8b).
+// Differences that make it MI355X-native:
+//   * witness closures are replaced by the closed op set of include/zkgl_ir.h;
+//   * the `for _cycle in 0..limit` body is recorded once (loop scope) and executed with
+//     lane == (instance, iteration); the per-instance prologue/epilogue is the outer scope;
+//   * the trace is slot-major/lane-minor (cells[(col*slots+slot)*stride + lane]) so every wave
+//     access is one coalesced 512 B transaction; gate selectors/constants are per-slot scalars.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/zkgl.h"
+
+namespace zkgl {
+
+struct ZkError : std::runtime_error {
+    int code;
+    ZkError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+constexpr uint32_t LOOP_BIT = 0x80000000u;
+inline bool is_loop_var(zk_var v) { return (v & LOOP_BIT) != 0; }
+inline uint32_t var_index(zk_var v) { return v & ~LOOP_BIT; }
+
+struct Operand {
+    enum Kind : uint8_t { VAR, CONSTPOOL, OUTER_VAR, RAW } kind;
+    uint32_t idx;
+};
+
+struct OpRec {
+    uint8_t opcode, a;
+    uint16_t b;
+    std::vector<Operand> ins;
+    std::vector<uint32_t> outs;  // var indices (same scope)
+};
+
+struct GateRec {
+    uint32_t kind;
+    std::vector<uint32_t> vars;  // var indices
+    std::vector<uint64_t> consts;
+};
+
+struct LookupRec {
+    uint32_t table;
+    std::vector<uint32_t> vars;  // keys then values, var indices
+};
+
+struct TableRec {
+    uint32_t marker, n_keys, n_vals, n_rows;
+    std::vector<uint64_t> rows;  // sorted by key tuple, row-major
+    bool dense;
+    uint32_t key_shift[3];
+    uint32_t word_off, mult_off;
+};
+
+struct Scope {
+    bool is_loop = false;
+    uint32_t n_vars = 0;
+    std::vector<OpRec> ops;
+    std::vector<GateRec> gates;
+    std::vector<LookupRec> lookups;
+    std::unordered_map<uint64_t, uint32_t> const_vars;  // allocate_constant cache
+    std::vector<uint64_t> const_pool;
+    std::unordered_map<uint64_t, uint32_t> const_pool_idx;
+    uint32_t n_input_words = 0;
+    size_t pre_ops = SIZE_MAX;  // outer scope: ops recorded before loop_begin
+
+    // ---- filled by finalize ----
+    uint32_t n_slots = 0, n_gate_slots = 0, n_lookup_slots = 0;
+    uint32_t n_trace_cells = 0, n_cells = 0, n_scratch = 0;
+    std::vector<std::vector<uint32_t>> var_cells;  // per var: cells, [0] = home
+    std::vector<uint32_t> prog;
+    uint32_t pre_words = 0;
+    std::vector<zk_row_desc> rows;
+    std::vector<uint64_t> rowconsts;
+    std::vector<zk_lookup_row_desc> lrows;
+    std::vector<zk_copy_pair> copies;
+    uint64_t gate_counts[ZK_GATE__COUNT] = {0};
+    uint64_t n_constraints = 0;
+
+    // ---- device ----
+    uint32_t* d_prog = nullptr;
+    uint64_t* d_consts = nullptr;
+    zk_row_desc* d_rows = nullptr;
+    uint64_t* d_rowconsts = nullptr;
+    zk_lookup_row_desc* d_lrows = nullptr;
+    zk_copy_pair* d_copies = nullptr;
+    uint64_t* d_cells = nullptr;
+    uint64_t stride = 0;
+    uint32_t n_lanes = 0;
+    const uint64_t* d_inputs = nullptr;
+    uint32_t bound_input_words = 0;
+};
+
+class CS {
+  public:
+    CS(const zk_geometry& g, uint64_t max_trace_len, uint64_t max_variables);
+    ~CS();
+
+    // configuration
+    void allow_lookup(uint32_t width, uint32_t reps, bool share_table_id);
+    void allow_gate(uint32_t kind);
+    bool gate_is_allowed(uint32_t kind) const;
+    uint32_t add_table(uint32_t marker, uint32_t n_keys, uint32_t n_vals, const uint64_t* rows, uint32_t n_rows);
+    uint32_t table_id(uint32_t marker) const;
+
+    // recording
+    zk_var alloc_var();
+    zk_var alloc_vars(uint32_t n);
+    zk_var alloc_constant(uint64_t value);
+    zk_var input(uint32_t word);
+    void place_gate(uint32_t kind, const zk_var* vars, uint32_t n_vars, const uint64_t* consts, uint32_t n_consts);
+    void emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uint32_t n_in, const zk_var* outs,
+                 uint32_t n_out, const uint64_t* imm, uint32_t n_imm);
+    void lookup(uint32_t table_id, const zk_var* keys, uint32_t n_keys, zk_var* vals, uint32_t n_vals);
+    void loop_begin(uint32_t limit);
+    void loop_end();
+    void link(uint32_t kind, zk_var loop_var, zk_var other);
+    zk_var loop_last(zk_var loop_var);
+    zk_var loop_import(zk_var outer_var);
+    uint64_t next_available_row() const;
+    void finalize();
+
+    // execution
+    void set_batch(uint32_t n_instances);
+    void bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words);
+    void resolve(void* stream);
+    int check_satisfied(void* stream, zk_failure* first);
+    uint64_t read_var(zk_var v, uint32_t instance, uint32_t iteration);
+    void write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value);
+    std::vector<uint64_t> public_inputs(uint32_t instance);
+    uint32_t var_cell(zk_var v) const;
+    std::vector<uint32_t> public_cells() const;
+    std::vector<uint32_t> multiplicities(uint32_t instance);
+    void stats(zk_stats* out) const;
+    float last_ms(int which) const;
+    std::vector<uint32_t> export_scope(bool loop_scope) const;
+    void trace_ptr(bool loop_scope, uint64_t** cells, uint64_t* n_cells, uint64_t* stride) const;
+
+    const zk_geometry& geometry() const { return geo_; }
+    bool in_loop() const { return in_loop_; }
+    uint32_t limit() const { return limit_; }
+    uint32_t lookup_width() const { return lookup_width_; }
+    bool finalized() const { return finalized_; }
+    // words of input the circuits layer registered (for zk_circuit_input_words)
+    uint32_t outer_input_words() const { return outer_.n_input_words; }
+    uint32_t loop_input_words() const { return loop_.n_input_words; }
+
+  private:
+    Scope& cur() { return in_loop_ ? loop_ : outer_; }
+    Scope& scope_of(zk_var v) { return is_loop_var(v) ? loop_ : outer_; }
+    uint32_t pool_const(Scope& s, uint64_t v);
+    void place_scope(Scope& s);
+    void emit_scope(Scope& s);
+    void upload_scope(Scope& s);
+    void ensure_uploaded();
+    void free_scope_device(Scope& s);
+    void check_var(zk_var v, bool want_loop) const;
+
+    zk_geometry geo_;
+    uint64_t max_trace_len_, max_variables_;
+    uint32_t lookup_width_ = 0, lookup_reps_ = 0;
+    bool lookup_share_id_ = true;
+    uint64_t allowed_gates_ = 0;
+    std::vector<TableRec> tables_;  // id = index + 1
+    Scope outer_, loop_;
+    bool in_loop_ = false, loop_done_ = false, finalized_ = false;
+    uint32_t limit_ = 0;
+    std::vector<zk_link> links_raw_;  // vars, resolved to cells at finalize
+    std::vector<zk_link> links_;
+    std::vector<uint32_t> public_vars_;
+
+    // device-wide
+    uint32_t batch_ = 0;
+    zk_table_desc* d_tables_ = nullptr;
+    uint64_t* d_table_words_ = nullptr;
+    uint32_t total_table_rows_ = 0;
+    std::vector<zk_table_desc> tdesc_host_;
+    std::vector<uint64_t> table_words_host_;
+    bool uploaded_ = false;
+    uint32_t* d_mult_ = nullptr;
+    zk_link* d_links_ = nullptr;
+    unsigned long long* d_fail_ = nullptr;
+    void* ev_[8] = {nullptr};
+    float ms_[5] = {0, 0, 0, 0, 0};
+};
+
+}  // namespace zkgl

@@ -1,0 +1,44 @@
+// device_api.hpp — internal launch interface between the host C++ (recorder, C ABI) and the
+// single device translation unit zkgl_device.hip.  Not part of the public ABI.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/zkgl_ir.h"
+
+namespace zkdev {
+
+struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
+    const uint32_t* prog; uint32_t n_words; uint32_t n_lanes;
+    const uint64_t* consts; uint64_t* cells; uint64_t stride; const uint64_t* inputs;
+    const uint64_t* outer_cells; uint64_t outer_stride; uint32_t limit; uint32_t is_loop;
+    const zk_table_desc* tables; const uint64_t* table_words; uint32_t* mult; uint32_t total_table_rows;
+    const uint64_t* loop_cells; uint64_t loop_stride; uint32_t loop_limit;
+};
+struct CheckArgs {  // mirrors zke::CheckDev
+    const uint64_t* cells; uint64_t stride; uint32_t n_lanes; uint32_t n_slots;
+    const zk_row_desc* rows; const uint64_t* rowconsts; const zk_lookup_row_desc* lrows;
+    uint32_t n_copy_cols; uint32_t lookup_width; const zk_table_desc* tables; const uint64_t* table_words;
+    unsigned long long* fail; uint32_t slots_per_chunk;
+};
+
+int upload_round_constants(const uint64_t rc[360]);
+int launch_col(int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t q, uint64_t l,
+               size_t n, void* stream);
+int launch_poseidon2_soa(uint64_t* st, size_t n, size_t stride, void* stream);
+int launch_poseidon2_aos(uint64_t* st, size_t n, void* stream);
+int launch_commit_encoding(const uint64_t* in, size_t len, size_t n, uint64_t* out, void* stream);
+int launch_queue_full_chain(const uint64_t* enc, size_t nq, size_t items, uint64_t* tail_io, uint64_t* states_out,
+                            void* stream);
+int launch_memory_query_encode(const uint64_t* q, size_t n, uint64_t* enc, void* stream);
+int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* ch, size_t enc_len, size_t n,
+                         uint64_t init, uint64_t* acc, uint64_t* scratch, void* stream);
+int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, void* stream);
+int launch_check_gates(const CheckArgs& cd, void* stream);
+int launch_check_copies(const uint64_t* cells, uint64_t stride, uint32_t n_lanes, const zk_copy_pair* pairs,
+                        uint32_t n_pairs, unsigned long long* fail, void* stream);
+int launch_check_links(const uint64_t* loop_cells, uint64_t loop_stride, uint32_t n_lanes, uint32_t limit,
+                       const uint64_t* outer_cells, uint64_t outer_stride, const zk_link* links, uint32_t n_links,
+                       unsigned long long* fail, void* stream);
+const char* last_hip_error();
+
+}  // namespace zkdev

@@ -1,0 +1,108 @@
+// gl_device.hpp — Goldilocks field (p = 2^64 - 2^32 + 1) for gfx950 device code.
+//
+// Replaces boojum::field::goldilocks::GoldilocksField as used by every circuit of the
+// reference (`type F = GoldilocksField`, /root/reference/src/ram_permutation/mod.rs:414).
+// CDNA4 has no 64x64->128 multiplier: a field multiply is a 32-bit partial-product tree
+// (v_mad_u64_u32 / v_mul_hi_u32) followed by the 2^64 == 2^32-1, 2^96 == -1 folding.
+// All values are kept canonical (< p) in memory so that bit-exact comparison is plain
+// u64 equality; lazy (non-canonical) forms exist only inside registers where noted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gl {
+
+constexpr uint64_t P = 0xFFFFFFFF00000001ull;
+constexpr uint64_t EPS = 0xFFFFFFFFull;
+
+__host__ __device__ __forceinline__ uint64_t reduce(uint64_t a) { return a >= P ? a - P : a; }
+
+__host__ __device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    // a wrap means the true sum is s + 2^64 == s + EPS (mod p) and that is already < p
+    if (s < a) return s + EPS;
+    return s >= P ? s - P : s;
+}
+
+__host__ __device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
+    uint64_t d = a - b;
+    return a >= b ? d : d - EPS;  // d + p (mod 2^64)
+}
+
+__host__ __device__ __forceinline__ uint64_t neg(uint64_t a) { return a ? P - a : 0; }
+
+// 128 -> 64 reduction of hi*2^64 + lo; result canonical.
+__host__ __device__ __forceinline__ uint64_t reduce128(uint64_t lo, uint64_t hi) {
+    uint64_t hi_hi = hi >> 32, hi_lo = hi & EPS;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= EPS;
+    uint64_t t1 = (hi_lo << 32) - hi_lo;  // hi_lo * (2^32 - 1)
+    uint64_t t2 = t0 + t1;
+    if (t2 < t1) t2 += EPS;
+    return t2 >= P ? t2 - P : t2;
+}
+
+__device__ __forceinline__ void mul_wide(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
+    lo = a * b;
+    hi = __umul64hi(a, b);
+}
+
+__device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
+    uint64_t lo, hi;
+    mul_wide(a, b, lo, hi);
+    return reduce128(lo, hi);
+}
+
+__device__ __forceinline__ uint64_t sqr(uint64_t a) { return mul(a, a); }
+
+// x * 2^k for k < 32 (Poseidon2 inner diagonal, encoding shifts)
+__device__ __forceinline__ uint64_t mul_pow2(uint64_t a, unsigned k) {
+    uint64_t lo = a << k;
+    uint64_t hi = k ? (a >> (64 - k)) : 0;
+    return reduce128(lo, hi);
+}
+
+// a*b + c
+__device__ __forceinline__ uint64_t fma(uint64_t a, uint64_t b, uint64_t c) {
+    uint64_t lo, hi;
+    mul_wide(a, b, lo, hi);
+    uint64_t l2 = lo + c;
+    hi += (l2 < lo);  // a,b < 2^64 => hi <= 2^64-2, no overflow
+    return reduce128(l2, hi);
+}
+
+__device__ __forceinline__ uint64_t pow7(uint64_t x) {
+    uint64_t x2 = sqr(x), x3 = mul(x2, x), x4 = sqr(x2);
+    return mul(x3, x4);
+}
+
+// x^(p-2); 0 -> 0.  Addition chain for p-2 = 2^64 - 2^32 - 1:
+// exponent bits: 32 ones, one zero, 31 ones  => x^(2^32-1) shifted by 32, times x^(2^31-1)... computed
+// with a sliding ladder of x^(2^k - 1).
+__device__ __forceinline__ uint64_t inv(uint64_t x) {
+    // e1 = x^(2^1-1) ... build x^(2^k-1) for k = 2,3,6,12,24,30,31,32
+    uint64_t e1 = x;
+    uint64_t e2 = mul(sqr(e1), e1);                       // 2^2-1
+    uint64_t e3 = mul(sqr(e2), e1);                       // 2^3-1
+    uint64_t t = e3;
+    for (int i = 0; i < 3; ++i) t = sqr(t);
+    uint64_t e6 = mul(t, e3);                             // 2^6-1
+    t = e6;
+    for (int i = 0; i < 6; ++i) t = sqr(t);
+    uint64_t e12 = mul(t, e6);                            // 2^12-1
+    t = e12;
+    for (int i = 0; i < 12; ++i) t = sqr(t);
+    uint64_t e24 = mul(t, e12);                           // 2^24-1
+    t = e24;
+    for (int i = 0; i < 6; ++i) t = sqr(t);
+    uint64_t e30 = mul(t, e6);                            // 2^30-1
+    uint64_t e31 = mul(sqr(e30), e1);                     // 2^31-1
+    uint64_t e32 = mul(sqr(e31), e1);                     // 2^32-1
+    // p-2 = (2^32-1)*2^32 - 1... write p-2 = 2^64 - 2^32 - 1 = (2^32 - 2)*2^32 + (2^32 - 1)
+    // (2^32-2) = 2*(2^31-1)  => x^(p-2) = (x^(2^31-1))^(2^33) * x^(2^32-1)
+    t = e31;
+    for (int i = 0; i < 33; ++i) t = sqr(t);
+    return mul(t, e32);
+}
+
+}  // namespace gl

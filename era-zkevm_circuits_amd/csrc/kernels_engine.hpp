@@ -1,0 +1,417 @@
+// kernels_engine.hpp — the generic engine kernels: witness-IR interpreter (K1/K5/K6 ops inside
+// a recorded scope), per-row gate evaluation (K7), lookup-membership check and copy-constraint
+// check.  Included once by zkgl_device.hip.
+//
+// Mapping: lane == (instance) for the outer scope, (instance*limit + iteration) for the loop
+// scope.  Every lane executes the same straight-line program, so the op stream is fetched with
+// scalar loads and there is no divergence; every cell access of a wavefront is one coalesced
+// 512-byte transaction (cells[cell*stride + lane]).
+#pragma once
+#include "../../include/zkgl_ir.h"
+#include "poseidon2_device.hpp"
+
+namespace zke {
+
+struct ScopeDev {
+    const uint32_t* prog;       // witness program words
+    uint32_t n_words;
+    uint32_t n_lanes;
+    const uint64_t* consts;     // constant pool
+    uint64_t* cells;            // [n_cells][stride]
+    uint64_t stride;
+    const uint64_t* inputs;     // [n_input_words][n_lanes]
+    // loop scope only
+    const uint64_t* outer_cells;
+    uint64_t outer_stride;
+    uint32_t limit;             // iterations per instance (1 for the outer scope)
+    uint32_t is_loop;
+    // lookup tables
+    const zk_table_desc* tables;
+    const uint64_t* table_words;
+    uint32_t* mult;             // [n_instances][total_table_rows]
+    uint32_t total_table_rows;
+    // loop cells for ZK_OP_LOOP_LAST (outer scope post phase)
+    const uint64_t* loop_cells;
+    uint64_t loop_stride;
+    uint32_t loop_limit;
+};
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// locate the table row for a key tuple; returns n_rows when absent
+__device__ __forceinline__ uint32_t table_find(const zk_table_desc& t, const uint64_t* __restrict__ words,
+                                               const uint64_t* key) {
+    const uint32_t w = t.n_keys + t.n_vals;
+    const uint64_t* rows = words + (size_t)t.word_off;
+    if (t.dense) {
+        uint64_t idx = 0;
+        bool ok = true;
+        for (uint32_t i = 0; i < t.n_keys; ++i) {
+            idx += key[i] << t.key_shift[i];
+            ok = ok && (key[i] >> 32) == 0;
+        }
+        if (!ok || idx >= t.n_rows) return t.n_rows;
+        for (uint32_t i = 0; i < t.n_keys; ++i)
+            if (rows[idx * w + i] != key[i]) return t.n_rows;
+        return (uint32_t)idx;
+    }
+    uint32_t lo = 0, hi = t.n_rows;  // rows sorted lexicographically by key tuple
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        int cmp = 0;
+        for (uint32_t i = 0; i < t.n_keys && cmp == 0; ++i) {
+            uint64_t r = rows[(size_t)mid * w + i];
+            cmp = r < key[i] ? -1 : (r > key[i] ? 1 : 0);
+        }
+        if (cmp == 0) return mid;
+        if (cmp < 0) lo = mid + 1; else hi = mid;
+    }
+    return t.n_rows;
+}
+
+// ------------------------------------------------------------------------------------------
+// Witness interpreter.  phase_begin/phase_end delimit the word range to execute (outer scope:
+// pre phase before the loop, post phase after it).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_witness(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
+    const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if (lane >= sc.n_lanes) return;
+    const uint32_t* __restrict__ prog = sc.prog;
+    uint64_t* __restrict__ cells = sc.cells;
+    const uint64_t stride = sc.stride;
+    const uint32_t inst = sc.is_loop ? lane / sc.limit : lane;
+
+    auto ld = [&](uint32_t w) -> uint64_t {
+        const uint32_t kind = w & ZK_OPERAND_KIND_MASK, idx = w & ZK_OPERAND_IDX_MASK;
+        if (kind == ZK_OPERAND_CONST) return sc.consts[idx];
+        if (kind == ZK_OPERAND_OUTER) return sc.outer_cells[(size_t)idx * sc.outer_stride + inst];
+        return cells[(size_t)idx * stride + lane];
+    };
+    uint32_t pc = word_begin;
+    auto st = [&](uint64_t v) {
+        uint32_t w;
+        do {
+            w = uni(prog[pc++]);
+            cells[(size_t)(w & ~ZK_DEST_MORE) * stride + lane] = v;
+        } while (w & ZK_DEST_MORE);
+    };
+
+    while (pc < word_end) {
+        const uint32_t h = uni(prog[pc++]);
+        const uint32_t op = h & 0xff, pa = (h >> 8) & 0xff, pb = h >> 16;
+        switch (op) {
+        case ZK_OP_CONST: {
+            uint64_t v = ld(uni(prog[pc++]));
+            st(v);
+        } break;
+        case ZK_OP_INPUT: {
+            uint32_t w = uni(prog[pc++]);
+            st(sc.inputs[(size_t)w * sc.n_lanes + lane]);
+        } break;
+        case ZK_OP_FMA: {
+            uint64_t q = ld(uni(prog[pc])), l = ld(uni(prog[pc + 1]));
+            uint64_t a = ld(uni(prog[pc + 2])), b = ld(uni(prog[pc + 3])), c = ld(uni(prog[pc + 4]));
+            pc += 5;
+            uint64_t ab = gl::mul(a, b);
+            uint64_t r = gl::add(q == 1 ? ab : gl::mul(q, ab), l == 1 ? c : gl::mul(l, c));
+            st(r);
+        } break;
+        case ZK_OP_LC4: {
+            uint64_t r = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r = gl::fma(ld(uni(prog[pc + i])), ld(uni(prog[pc + 4 + i])), r);
+            pc += 8;
+            st(r);
+        } break;
+        case ZK_OP_SELECT: {
+            uint64_t s = ld(uni(prog[pc])), a = ld(uni(prog[pc + 1])), b = ld(uni(prog[pc + 2]));
+            pc += 3;
+            st(s ? a : b);
+        } break;
+        case ZK_OP_ISZERO: {
+            uint64_t x = ld(uni(prog[pc++]));
+            st(x == 0 ? 1ull : 0ull);
+            st(gl::inv(x));
+        } break;
+        case ZK_OP_UADD: {
+            uint64_t x = ld(uni(prog[pc])), y = ld(uni(prog[pc + 1])), ci = ld(uni(prog[pc + 2]));
+            pc += 3;
+            uint64_t s = x + y + ci;  // operands < 2^32
+            st(s & ((1ull << pa) - 1));
+            st(s >> pa);
+        } break;
+        case ZK_OP_USUB: {
+            uint64_t x = ld(uni(prog[pc])), y = ld(uni(prog[pc + 1])), bi = ld(uni(prog[pc + 2]));
+            pc += 3;
+            uint64_t sub = y + bi;
+            uint64_t borrow = x < sub ? 1 : 0;
+            uint64_t d = (x + (borrow << pa)) - sub;
+            st(d);
+            st(borrow);
+        } break;
+        case ZK_OP_DOT4: {
+            uint64_t r = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r = gl::fma(ld(uni(prog[pc + 2 * i])), ld(uni(prog[pc + 2 * i + 1])), r);
+            pc += 8;
+            st(r);
+        } break;
+        case ZK_OP_MATMUL12: {
+            uint64_t s[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s[i] = ld(uni(prog[pc + i]));
+            pc += 12;
+            if (pa == 0) p2::mds_external(s); else p2::mds_inner(s);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) st(s[i]);
+        } break;
+        case ZK_OP_SPLIT: {
+            uint64_t x = ld(uni(prog[pc++]));
+            for (uint32_t i = 0; i < pa; ++i) {
+                st(i + 1 == pa ? x : (x & ((1ull << pb) - 1)));
+                x >>= pb;
+            }
+        } break;
+        case ZK_OP_LOOKUP: {
+            const uint32_t tid = uni(prog[pc++]);
+            const zk_table_desc t = sc.tables[tid];
+            uint64_t key[3] = {0, 0, 0};
+            for (uint32_t i = 0; i < pa; ++i) key[i] = ld(uni(prog[pc + i]));
+            pc += pa;
+            uint32_t row = table_find(t, sc.table_words, key);
+            const uint32_t w = t.n_keys + t.n_vals;
+            bool found = row < t.n_rows;
+            for (uint32_t i = 0; i < pb; ++i)
+                st(found ? sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i] : 0ull);
+            if (found && sc.mult)
+                atomicAdd(&sc.mult[(size_t)inst * sc.total_table_rows + t.mult_off + row], 1u);
+        } break;
+        case ZK_OP_POSEIDON2: {
+            uint64_t s[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s[i] = ld(uni(prog[pc + i]));
+            pc += 12;
+            p2::permute(s);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) st(s[i]);
+        } break;
+        case ZK_OP_P2_ROUNDS: {
+            // In-circuit permutation: every intermediate the gates constrain is produced in
+            // registers and streamed to its cells (order fixed by gadgets.cpp poseidon2_round_function).
+            uint64_t s[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s[i] = ld(uni(prog[pc + i]));
+            pc += 12;
+            p2::mds_external(s);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) st(s[i]);
+#pragma unroll 1
+            for (int r = 0; r < 30; ++r) {
+                const bool full = (r < 4) || (r >= 26);
+                if (full) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        uint64_t t = gl::add(s[i], p2::RC[12 * r + i]);
+                        uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+                        st(t); st(x2); st(x3); st(x4); st(x7);
+                        s[i] = x7;
+                    }
+                    p2::mds_external(s);
+                } else {
+                    uint64_t t = gl::add(s[0], p2::RC[12 * r]);
+                    uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+                    st(t); st(x2); st(x3); st(x4); st(x7);
+                    s[0] = x7;
+                    p2::mds_inner(s);
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) st(s[i]);
+            }
+        } break;
+        case ZK_OP_LOOP_LAST: {
+            uint32_t c = uni(prog[pc++]);
+            st(sc.loop_cells[(size_t)c * sc.loop_stride + (size_t)lane * sc.loop_limit + (sc.loop_limit - 1)]);
+        } break;
+        case ZK_OP_U32MULADD: {
+            uint64_t a = ld(uni(prog[pc])), b = ld(uni(prog[pc + 1])), c = ld(uni(prog[pc + 2])), d = ld(uni(prog[pc + 3]));
+            pc += 4;
+            uint64_t r = a * b + c + d;  // < 2^64 for u32 operands
+            st(r & 0xffffffffull);
+            st(r >> 32);
+        } break;
+        default:
+            return;  // malformed program: host validates before upload
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// K7: per-row gate evaluation (check_if_satisfied counterpart,
+// /root/reference/src/ram_permutation/mod.rs:556).  grid = (lane tiles, slot chunks); the gate
+// kind / instance count / constants of a slot are wave-uniform, each trace cell is read once.
+// A failing relation is reported through atomicMin on a packed key.
+// ------------------------------------------------------------------------------------------
+struct CheckDev {
+    const uint64_t* cells;
+    uint64_t stride;
+    uint32_t n_lanes;
+    uint32_t n_slots;
+    const zk_row_desc* rows;
+    const uint64_t* rowconsts;
+    const zk_lookup_row_desc* lrows;
+    uint32_t n_copy_cols;
+    uint32_t lookup_width;
+    const zk_table_desc* tables;
+    const uint64_t* table_words;
+    unsigned long long* fail;   // [0] gates/lookups, [1] copies, [2] links
+    uint32_t slots_per_chunk;
+};
+
+__device__ __constant__ const unsigned char GATE_WIDTH[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6};
+
+__device__ __forceinline__ void report(unsigned long long* f, uint32_t lane, uint32_t slot, uint32_t j, uint32_t rel) {
+    unsigned long long key = ((unsigned long long)lane << 32) | ((unsigned long long)slot << 12) | ((j & 0xff) << 4) | (rel & 0xf);
+    atomicMin(f, key);
+}
+
+__global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) {
+    const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if (lane >= cd.n_lanes) return;
+    const uint32_t s0 = blockIdx.y * cd.slots_per_chunk;
+    const uint32_t s1 = min(s0 + cd.slots_per_chunk, cd.n_slots);
+    const uint64_t* __restrict__ cells = cd.cells;
+    const size_t stride = cd.stride, S = cd.n_slots;
+    for (uint32_t slot = s0; slot < s1; ++slot) {
+        const zk_row_desc d = cd.rows[slot];
+        const uint32_t kind = uni(d.kind), ninst = uni(d.n_instances);
+        const uint64_t* __restrict__ k = cd.rowconsts + uni(d.const_off);
+        const uint32_t w = GATE_WIDTH[kind];
+        auto cell = [&](uint32_t col) -> uint64_t { return cells[((size_t)col * S + slot) * stride + lane]; };
+        for (uint32_t j = 0; j < ninst; ++j) {
+            const uint32_t c0 = j * w;
+            switch (kind) {
+            case ZK_GATE_CONST: {
+                // up to n_consts constants per row: instance j is bound to constant j
+                if (cell(c0) != k[j]) report(cd.fail, lane, slot, j, 0);
+            } break;
+            case ZK_GATE_BOOLEAN: {
+                uint64_t v = cell(c0);
+                if (gl::mul(v, v) != v) report(cd.fail, lane, slot, j, 0);
+            } break;
+            case ZK_GATE_FMA: {
+                uint64_t a = cell(c0), b = cell(c0 + 1), c = cell(c0 + 2), dd = cell(c0 + 3);
+                uint64_t r = gl::add(gl::mul(k[0], gl::mul(a, b)), gl::mul(k[1], c));
+                if (r != dd) report(cd.fail, lane, slot, j, 0);
+            } break;
+            case ZK_GATE_REDUCTION4: {
+                uint64_t r = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r = gl::fma(k[i], cell(c0 + i), r);
+                if (r != cell(c0 + 4)) report(cd.fail, lane, slot, j, 0);
+            } break;
+            case ZK_GATE_SELECT: {
+                uint64_t a = cell(c0), b = cell(c0 + 1), sel = cell(c0 + 2), r = cell(c0 + 3);
+                uint64_t e = gl::add(gl::mul(sel, gl::sub(a, b)), b);
+                if (e != r) report(cd.fail, lane, slot, j, 0);
+            } break;
+            case ZK_GATE_ZEROCHECK: {
+                uint64_t x = cell(c0), aux = cell(c0 + 1), flag = cell(c0 + 2);
+                if (gl::mul(x, aux) != gl::sub(1, flag)) report(cd.fail, lane, slot, j, 0);
+                if (gl::mul(x, flag) != 0) report(cd.fail, lane, slot, j, 1);
+            } break;
+            case ZK_GATE_UINTX_ADD: {
+                uint64_t a = cell(c0), b = cell(c0 + 1), ci = cell(c0 + 2), c = cell(c0 + 3), co = cell(c0 + 4);
+                uint64_t lhs = gl::add(gl::add(a, b), ci);
+                uint64_t rhs = gl::add(c, gl::mul(k[0], co));
+                if (lhs != rhs) report(cd.fail, lane, slot, j, 0);
+            } break;
+            case ZK_GATE_DOT4: {
+                uint64_t r = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r = gl::fma(cell(c0 + 2 * i), cell(c0 + 2 * i + 1), r);
+                if (r != cell(c0 + 8)) report(cd.fail, lane, slot, j, 0);
+            } break;
+            case ZK_GATE_MATMUL12_EXT:
+            case ZK_GATE_MATMUL12_INT: {
+                uint64_t s[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) s[i] = cell(c0 + i);
+                if (kind == ZK_GATE_MATMUL12_EXT) p2::mds_external(s); else p2::mds_inner(s);
+#pragma unroll
+                for (int i = 0; i < 12; ++i)
+                    if (s[i] != cell(c0 + 12 + i)) report(cd.fail, lane, slot, j, i);
+            } break;
+            case ZK_GATE_U32_FMA: {
+                uint64_t a = cell(c0), b = cell(c0 + 1), c = cell(c0 + 2), dd = cell(c0 + 3), lo = cell(c0 + 4), hi = cell(c0 + 5);
+                uint64_t lhs = gl::add(gl::add(gl::mul(a, b), c), dd);
+                uint64_t rhs = gl::add(lo, gl::mul(hi, 1ull << 32));
+                if (lhs != rhs) report(cd.fail, lane, slot, j, 0);
+            } break;
+            default: break;  // NOP, PUBLIC_INPUT: no relation
+            }
+        }
+        // lookup tuples of this row: (keys.., values..) must be a row of the row's table
+        const zk_lookup_row_desc lr = cd.lrows[slot];
+        const uint32_t ntup = uni(lr.n_tuples);
+        if (ntup) {
+            const zk_table_desc t = cd.tables[uni(lr.table)];
+            const uint32_t tw = t.n_keys + t.n_vals;
+            for (uint32_t u = 0; u < ntup; ++u) {
+                const uint32_t c0 = cd.n_copy_cols + u * cd.lookup_width;
+                uint64_t key[3] = {0, 0, 0};
+                for (uint32_t i = 0; i < t.n_keys; ++i) key[i] = cell(c0 + i);
+                uint32_t row = table_find(t, cd.table_words, key);
+                bool ok = row < t.n_rows;
+                for (uint32_t i = 0; ok && i < t.n_vals; ++i)
+                    ok = cd.table_words[(size_t)t.word_off + (size_t)row * tw + t.n_keys + i] == cell(c0 + t.n_keys + i);
+                if (!ok) report(cd.fail, lane, slot, 0x80 | u, 15);
+            }
+        }
+    }
+}
+
+// copy constraints inside a scope: every non-home cell of a variable equals the home cell
+__global__ __launch_bounds__(TPB) void k_check_copies(const uint64_t* __restrict__ cells, uint64_t stride, uint32_t n_lanes,
+                                                      const zk_copy_pair* __restrict__ pairs, uint32_t n_pairs,
+                                                      uint32_t pairs_per_chunk, unsigned long long* fail) {
+    const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if (lane >= n_lanes) return;
+    const uint32_t p0 = blockIdx.y * pairs_per_chunk, p1 = min(p0 + pairs_per_chunk, n_pairs);
+    for (uint32_t i = p0; i < p1; ++i) {
+        const zk_copy_pair p = pairs[i];
+        uint64_t a = cells[(size_t)uni(p.cell) * stride + lane], b = cells[(size_t)uni(p.home) * stride + lane];
+        if (a != b) atomicMin(fail + 1, ((unsigned long long)lane << 32) | i);
+    }
+}
+
+// copy constraints across iterations / scopes (the hidden_fsm chain of the reference:
+// /root/reference/src/ram_permutation/mod.rs:119-143,178-196)
+__global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict__ loop_cells, uint64_t loop_stride,
+                                                     uint32_t n_lanes, uint32_t limit,
+                                                     const uint64_t* __restrict__ outer_cells, uint64_t outer_stride,
+                                                     const zk_link* __restrict__ links, uint32_t n_links,
+                                                     unsigned long long* fail) {
+    const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if (lane >= n_lanes) return;
+    const uint32_t inst = lane / limit, k = lane % limit;
+    for (uint32_t i = 0; i < n_links; ++i) {
+        const zk_link L = links[i];
+        const uint32_t kind = uni(L.kind);
+        uint64_t mine = loop_cells[(size_t)uni(L.loop_cell) * loop_stride + lane];
+        bool ok = true;
+        if (kind == ZK_LINK_CARRY) {
+            if (k > 0) ok = mine == loop_cells[(size_t)uni(L.other_cell) * loop_stride + lane - 1];
+        } else {
+            uint64_t o = outer_cells[(size_t)uni(L.other_cell) * outer_stride + inst];
+            if (kind == ZK_LINK_FIRST) ok = (k != 0) || mine == o;
+            else if (kind == ZK_LINK_LAST) ok = (k != limit - 1) || mine == o;
+            else ok = mine == o;
+        }
+        if (!ok) atomicMin(fail + 2, ((unsigned long long)lane << 32) | i);
+    }
+}
+
+}  // namespace zke

@@ -1,0 +1,137 @@
+// zkgl_device.hip — the ONE device translation unit of libzkgl.so (gfx950 only).
+// Kernels live in kernels_primitives.hpp / kernels_engine.hpp; this file holds the launchers.
+#include <hip/hip_runtime.h>
+#include <string>
+#include "device_api.hpp"
+#include "kernels_primitives.hpp"
+#include "kernels_engine.hpp"
+
+namespace zkdev {
+
+static thread_local std::string g_hip_err;
+const char* last_hip_error() { return g_hip_err.c_str(); }
+
+static int chk(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    g_hip_err = std::string(what) + ": " + hipGetErrorString(e);
+    return -2;
+}
+#define LAUNCH_CHECK(what) chk(hipGetLastError(), what)
+
+static inline unsigned grid_for(size_t n, int per_block, unsigned cap = 0x7fffffffu) {
+    size_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+int upload_round_constants(const uint64_t rc[360]) {
+    return chk(hipMemcpyToSymbol(HIP_SYMBOL(p2::RC), rc, 360 * sizeof(uint64_t)), "hipMemcpyToSymbol(RC)");
+}
+
+int launch_col(int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t q, uint64_t l,
+               size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    // memory-bound: cap at 256 CUs x 8 workgroups and grid-stride the rest
+    unsigned g = grid_for(n / 2 + 1, zkk::TPB, 2048);
+    switch (op) {
+    case zkk::COL_FMA: zkk::k_col<zkk::COL_FMA><<<g, zkk::TPB, 0, s>>>(dst, a, b, c, q, l, n); break;
+    case zkk::COL_ADD: zkk::k_col<zkk::COL_ADD><<<g, zkk::TPB, 0, s>>>(dst, a, b, c, q, l, n); break;
+    case zkk::COL_SUB: zkk::k_col<zkk::COL_SUB><<<g, zkk::TPB, 0, s>>>(dst, a, b, c, q, l, n); break;
+    case zkk::COL_MUL: zkk::k_col<zkk::COL_MUL><<<g, zkk::TPB, 0, s>>>(dst, a, b, c, q, l, n); break;
+    case zkk::COL_SELECT: zkk::k_col<zkk::COL_SELECT><<<g, zkk::TPB, 0, s>>>(dst, a, b, c, q, l, n); break;
+    case zkk::COL_INV: zkk::k_col<zkk::COL_INV><<<g, zkk::TPB, 0, s>>>(dst, a, b, c, q, l, n); break;
+    default: g_hip_err = "bad column op"; return -1;
+    }
+    return LAUNCH_CHECK("k_col");
+}
+
+int launch_poseidon2_soa(uint64_t* st, size_t n, size_t stride, void* stream) {
+    if (n == 0) return 0;
+    zkk::k_poseidon2_soa<<<grid_for(n, zkk::TPB), zkk::TPB, 0, (hipStream_t)stream>>>(st, n, stride);
+    return LAUNCH_CHECK("k_poseidon2_soa");
+}
+int launch_poseidon2_aos(uint64_t* st, size_t n, void* stream) {
+    if (n == 0) return 0;
+    zkk::k_poseidon2_aos<<<grid_for(n, zkk::TPB), zkk::TPB, 0, (hipStream_t)stream>>>(st, n);
+    return LAUNCH_CHECK("k_poseidon2_aos");
+}
+int launch_commit_encoding(const uint64_t* in, size_t len, size_t n, uint64_t* out, void* stream) {
+    if (n == 0) return 0;
+    zkk::k_commit_encoding<<<grid_for(n, zkk::TPB), zkk::TPB, 0, (hipStream_t)stream>>>(in, len, n, out);
+    return LAUNCH_CHECK("k_commit_encoding");
+}
+int launch_queue_full_chain(const uint64_t* enc, size_t nq, size_t items, uint64_t* tail_io, uint64_t* states_out,
+                            void* stream) {
+    if (nq == 0) return 0;
+    zkk::k_queue_full_chain<<<grid_for(nq, 64), 64, 0, (hipStream_t)stream>>>(enc, nq, items, tail_io, states_out);
+    return LAUNCH_CHECK("k_queue_full_chain");
+}
+int launch_memory_query_encode(const uint64_t* q, size_t n, uint64_t* enc, void* stream) {
+    if (n == 0) return 0;
+    zkk::k_memory_query_encode<<<grid_for(n, zkk::TPB), zkk::TPB, 0, (hipStream_t)stream>>>(q, n, enc);
+    return LAUNCH_CHECK("k_memory_query_encode");
+}
+int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* ch, size_t enc_len, size_t n,
+                         uint64_t init, uint64_t* acc, uint64_t* scratch, void* stream) {
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    size_t ntiles = (n + zkk::GP_TILE - 1) / zkk::GP_TILE;
+    zkk::k_gp_local<<<(unsigned)ntiles, zkk::TPB, 0, s>>>(enc, flags, ch, enc_len, n, acc, scratch);
+    zkk::k_gp_tiles<<<1, zkk::TPB, 0, s>>>(scratch, ntiles, init);
+    zkk::k_gp_apply<<<(unsigned)ntiles, zkk::TPB, 0, s>>>(acc, scratch, n);
+    return LAUNCH_CHECK("k_gp");
+}
+
+static zke::ScopeDev to_dev(const ScopeArgs& a) {
+    zke::ScopeDev d;
+    d.prog = a.prog; d.n_words = a.n_words; d.n_lanes = a.n_lanes; d.consts = a.consts; d.cells = a.cells;
+    d.stride = a.stride; d.inputs = a.inputs; d.outer_cells = a.outer_cells; d.outer_stride = a.outer_stride;
+    d.limit = a.limit; d.is_loop = a.is_loop; d.tables = a.tables; d.table_words = a.table_words; d.mult = a.mult;
+    d.total_table_rows = a.total_table_rows; d.loop_cells = a.loop_cells; d.loop_stride = a.loop_stride;
+    d.loop_limit = a.loop_limit;
+    return d;
+}
+
+int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, void* stream) {
+    if (sc.n_lanes == 0 || word_begin >= word_end) return 0;
+    zke::k_witness<<<grid_for(sc.n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(to_dev(sc), word_begin, word_end);
+    return LAUNCH_CHECK("k_witness");
+}
+
+int launch_check_gates(const CheckArgs& a, void* stream) {
+    if (a.n_lanes == 0 || a.n_slots == 0) return 0;
+    zke::CheckDev d;
+    d.cells = a.cells; d.stride = a.stride; d.n_lanes = a.n_lanes; d.n_slots = a.n_slots; d.rows = a.rows;
+    d.rowconsts = a.rowconsts; d.lrows = a.lrows; d.n_copy_cols = a.n_copy_cols; d.lookup_width = a.lookup_width;
+    d.tables = a.tables; d.table_words = a.table_words; d.fail = a.fail; d.slots_per_chunk = a.slots_per_chunk;
+    dim3 grid(grid_for(a.n_lanes, zke::TPB), (a.n_slots + a.slots_per_chunk - 1) / a.slots_per_chunk);
+    zke::k_check_gates<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
+    return LAUNCH_CHECK("k_check_gates");
+}
+
+int launch_check_copies(const uint64_t* cells, uint64_t stride, uint32_t n_lanes, const zk_copy_pair* pairs,
+                        uint32_t n_pairs, unsigned long long* fail, void* stream) {
+    if (n_lanes == 0 || n_pairs == 0) return 0;
+    unsigned lane_tiles = grid_for(n_lanes, zke::TPB);
+    // aim for >= ~2048 workgroups
+    uint32_t chunks = (2048 + lane_tiles - 1) / lane_tiles;
+    if (chunks > n_pairs) chunks = n_pairs;
+    if (chunks < 1) chunks = 1;
+    uint32_t per = (n_pairs + chunks - 1) / chunks;
+    dim3 grid(lane_tiles, (n_pairs + per - 1) / per);
+    zke::k_check_copies<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(cells, stride, n_lanes, pairs, n_pairs, per, fail);
+    return LAUNCH_CHECK("k_check_copies");
+}
+
+int launch_check_links(const uint64_t* loop_cells, uint64_t loop_stride, uint32_t n_lanes, uint32_t limit,
+                       const uint64_t* outer_cells, uint64_t outer_stride, const zk_link* links, uint32_t n_links,
+                       unsigned long long* fail, void* stream) {
+    if (n_lanes == 0 || n_links == 0) return 0;
+    zke::k_check_links<<<grid_for(n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(
+        loop_cells, loop_stride, n_lanes, limit, outer_cells, outer_stride, links, n_links, fail);
+    return LAUNCH_CHECK("k_check_links");
+}
+
+}  // namespace zkdev

@@ -1,0 +1,448 @@
+"""zkgl — Python binding (ctypes) of libzkgl.so, the MI355X-native witness-generation and
+constraint-evaluation engine for the era-zkevm_circuits hot path.
+
+Everything here goes through the C ABI declared in include/zkgl.h; there is no CPU fallback:
+loading fails loudly when the HIP library has not been built, and every compute entry fails with
+ZkError(ZK_ERR_HIP) when no GPU is visible.
+
+Reference surface mirrored (names follow boojum as used by /root/reference):
+  ConstraintSystem.alloc_multiple_variables_without_values / allocate_constant / perform_lookup /
+  pad_and_shrink(=finalize) / check_if_satisfied / print_gate_stats(=stats)
+  (/root/reference/src/ram_permutation/mod.rs:419-556).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libzkgl.so")
+
+P = 0xFFFFFFFF00000001
+
+ZK_OK = 0
+ZK_ERR_INVALID = -1
+ZK_ERR_HIP = -2
+ZK_ERR_UNRESOLVED = -3
+ZK_ERR_CAPACITY = -4
+ZK_ERR_UNSATISFIED = -5
+ZK_ERR_GATE_NOT_ALLOWED = -6
+
+# zk_opcode / zk_gate_kind / zk_link_kind (include/zkgl_ir.h)
+OP = dict(END=0, CONST=1, INPUT=2, FMA=3, LC4=4, SELECT=5, ISZERO=6, UADD=7, USUB=8, DOT4=9, MATMUL12=10,
+          SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16)
+GATE = dict(NOP=0, CONST=1, BOOLEAN=2, FMA=3, REDUCTION4=4, SELECT=5, ZEROCHECK=6, UINTX_ADD=7, DOT4=8,
+            MATMUL12_EXT=9, MATMUL12_INT=10, PUBLIC_INPUT=11, U32_FMA=12)
+GATE_NAMES = {v: k for k, v in GATE.items()}
+LINK = dict(CARRY=0, FIRST=1, LAST=2, BCAST=3)
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"zkgl error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class _Geometry(C.Structure):
+    _fields_ = [("num_columns_under_copy_permutation", C.c_uint32), ("num_witness_columns", C.c_uint32),
+                ("num_constant_columns", C.c_uint32), ("max_allowed_constraint_degree", C.c_uint32)]
+
+
+class _Failure(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("scope", "instance", "iteration", "slot", "kind", "relation")]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("rows_per_instance", C.c_uint64), ("loop_slots", C.c_uint64), ("outer_slots", C.c_uint64),
+                ("limit", C.c_uint64), ("copy_columns", C.c_uint64), ("lookup_columns", C.c_uint64),
+                ("variables_outer", C.c_uint64), ("variables_loop", C.c_uint64),
+                ("constraints_per_instance", C.c_uint64), ("var_cells_per_instance", C.c_uint64),
+                ("gate_instances", C.c_uint64 * 13), ("lookups_per_instance", C.c_uint64),
+                ("program_words_outer", C.c_uint64), ("program_words_loop", C.c_uint64),
+                ("scratch_cells_outer", C.c_uint64), ("scratch_cells_loop", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libzkgl.so (built in-tree by `era-zkevm_circuits_amd/build.sh` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). zkgl has no CPU fallback.")
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.zk_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise ZkError(rc, lib().zk_last_error().decode())
+
+
+_inited_device = None
+
+
+def init(device: int = 0):
+    """zk_init: select the GPU and upload the Poseidon2 constants. Raises without a GPU."""
+    global _inited_device
+    _check(lib().zk_init(C.c_int(device)))
+    _inited_device = device
+
+
+def device_count() -> int:
+    return int(lib().zk_device_count())
+
+
+def poseidon_round_constants() -> np.ndarray:
+    out = np.zeros(360, dtype=np.uint64)
+    _check(lib().zk_poseidon_round_constants(out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def _ptr(x):
+    if isinstance(x, DeviceBuffer):
+        return C.c_void_p(x.ptr)
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):  # torch tensor on the GPU
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(f"not a device pointer: {type(x)}")
+
+
+class DeviceBuffer:
+    """A hipMalloc'd buffer of u64/u32 words owned by Python (zk_malloc / zk_free)."""
+
+    def __init__(self, n_words: int, dtype=np.uint64):
+        self.dtype = np.dtype(dtype)
+        self.n = int(n_words)
+        p = C.c_void_p()
+        _check(lib().zk_malloc(C.byref(p), C.c_size_t(max(self.n, 1) * self.dtype.itemsize)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, arr: np.ndarray) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.size, arr.dtype)
+        if arr.size:
+            _check(lib().zk_h2d(C.c_void_p(b.ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes), None))
+        return b
+
+    def to_numpy(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=self.dtype)
+        if self.n:
+            _check(lib().zk_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), None))
+        return out
+
+    def zero(self):
+        _check(lib().zk_memset(C.c_void_p(self.ptr), 0, C.c_size_t(self.n * self.dtype.itemsize), None))
+        sync()
+
+    def free(self):
+        if self.ptr:
+            lib().zk_free(C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sync(stream=None):
+    _check(lib().zk_sync(_ptr(stream)))
+
+
+# ------------------------------------------------------------------------------------------------
+# primitives (K1..K4, a9).  Arguments are DeviceBuffer / torch CUDA tensors / raw device addresses.
+# ------------------------------------------------------------------------------------------------
+def gl_fma_cols(dst, a, b, c, q: int, l: int, n: int, stream=None):
+    _check(lib().zk_gl_fma_cols(_ptr(dst), _ptr(a), _ptr(b), _ptr(c), C.c_uint64(q), C.c_uint64(l), C.c_size_t(n), _ptr(stream)))
+
+
+def gl_add_cols(dst, a, b, n, stream=None):
+    _check(lib().zk_gl_add_cols(_ptr(dst), _ptr(a), _ptr(b), C.c_size_t(n), _ptr(stream)))
+
+
+def gl_sub_cols(dst, a, b, n, stream=None):
+    _check(lib().zk_gl_sub_cols(_ptr(dst), _ptr(a), _ptr(b), C.c_size_t(n), _ptr(stream)))
+
+
+def gl_mul_cols(dst, a, b, n, stream=None):
+    _check(lib().zk_gl_mul_cols(_ptr(dst), _ptr(a), _ptr(b), C.c_size_t(n), _ptr(stream)))
+
+
+def gl_select_cols(dst, s, a, b, n, stream=None):
+    _check(lib().zk_gl_select_cols(_ptr(dst), _ptr(s), _ptr(a), _ptr(b), C.c_size_t(n), _ptr(stream)))
+
+
+def gl_inv_cols(dst, a, n, stream=None):
+    _check(lib().zk_gl_inv_cols(_ptr(dst), _ptr(a), C.c_size_t(n), _ptr(stream)))
+
+
+def poseidon2_permute_soa(states, n, stride=None, stream=None):
+    _check(lib().zk_poseidon2_permute_soa(_ptr(states), C.c_size_t(n), C.c_size_t(n if stride is None else stride), _ptr(stream)))
+
+
+def poseidon2_permute_aos(states, n, stream=None):
+    _check(lib().zk_poseidon2_permute_aos(_ptr(states), C.c_size_t(n), _ptr(stream)))
+
+
+def commit_encoding_batch(inp, length, n, out, stream=None):
+    _check(lib().zk_commit_encoding_batch(_ptr(inp), C.c_size_t(length), C.c_size_t(n), _ptr(out), _ptr(stream)))
+
+
+def queue_full_push_chain(enc, nq, items, tail_io, states_out=None, stream=None):
+    _check(lib().zk_queue_full_push_chain(_ptr(enc), C.c_size_t(nq), C.c_size_t(items), _ptr(tail_io), _ptr(states_out), _ptr(stream)))
+
+
+def memory_query_encode(q, n, enc, stream=None):
+    _check(lib().zk_memory_query_encode(_ptr(q), C.c_size_t(n), _ptr(enc), _ptr(stream)))
+
+
+def grand_product(enc, flags, challenges, enc_len, n, init, acc_out, scratch, stream=None):
+    _check(lib().zk_grand_product(_ptr(enc), _ptr(flags), _ptr(challenges), C.c_size_t(enc_len), C.c_size_t(n),
+                                  C.c_uint64(init), _ptr(acc_out), _ptr(scratch), _ptr(stream)))
+
+
+# ------------------------------------------------------------------------------------------------
+# constraint system
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class CSGeometry:  # boojum::cs::CSGeometry (src/main_vm/cycle.rs:959-966)
+    num_columns_under_copy_permutation: int
+    num_witness_columns: int
+    num_constant_columns: int
+    max_allowed_constraint_degree: int
+
+
+@dataclass
+class Failure:
+    scope: int
+    instance: int
+    iteration: int
+    slot: int
+    kind: int
+    relation: int
+
+
+class ConstraintSystem:
+    """Recorder + GPU executor handle (zk_cs). Recording works without a GPU; set_batch/resolve need one."""
+
+    def __init__(self, geometry: CSGeometry, max_trace_len: int = 1 << 20, max_variables: int = 1 << 26):
+        g = _Geometry(geometry.num_columns_under_copy_permutation, geometry.num_witness_columns,
+                      geometry.num_constant_columns, geometry.max_allowed_constraint_degree)
+        h = C.c_void_p()
+        _check(lib().zk_cs_create(C.byref(g), C.c_uint64(max_trace_len), C.c_uint64(max_variables), C.byref(h)))
+        self._h = h
+        self.geometry = geometry
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            lib().zk_cs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- configuration ---
+    def allow_lookup(self, width=3, num_repetitions=8, share_table_id=True):
+        _check(lib().zk_cs_allow_lookup(self._h, width, num_repetitions, int(share_table_id)))
+
+    def allow_gate(self, kind: int):
+        _check(lib().zk_cs_allow_gate(self._h, kind))
+
+    def gate_is_allowed(self, kind: int) -> bool:
+        return bool(lib().zk_cs_gate_is_allowed(self._h, kind))
+
+    def add_lookup_table(self, marker: int, n_keys: int, n_vals: int, rows: np.ndarray) -> int:
+        rows = np.ascontiguousarray(rows, dtype=np.uint64).reshape(-1, n_keys + n_vals)
+        tid = C.c_uint32()
+        _check(lib().zk_cs_add_table(self._h, marker, n_keys, n_vals, rows.ctypes.data_as(C.c_void_p), rows.shape[0], C.byref(tid)))
+        return tid.value
+
+    def get_table_id_for_marker(self, marker: int) -> int:
+        tid = C.c_uint32()
+        _check(lib().zk_cs_table_id(self._h, marker, C.byref(tid)))
+        return tid.value
+
+    # --- recording ---
+    def alloc_multiple_variables_without_values(self, n: int):
+        first = C.c_uint32()
+        _check(lib().zk_cs_alloc_vars(self._h, n, C.byref(first)))
+        return [first.value + i for i in range(n)]
+
+    def alloc_variable_without_value(self) -> int:
+        return self.alloc_multiple_variables_without_values(1)[0]
+
+    def allocate_constant(self, value: int) -> int:
+        v = C.c_uint32()
+        _check(lib().zk_cs_alloc_constant(self._h, C.c_uint64(value), C.byref(v)))
+        return v.value
+
+    def input(self, word: int) -> int:
+        v = C.c_uint32()
+        _check(lib().zk_cs_input(self._h, word, C.byref(v)))
+        return v.value
+
+    def place_gate(self, kind: int, variables, consts=()):
+        va = (C.c_uint32 * len(variables))(*variables)
+        ca = (C.c_uint64 * max(len(consts), 1))(*consts)
+        _check(lib().zk_cs_place_gate(self._h, kind, va, len(variables), ca, len(consts)))
+
+    def emit_op(self, opcode: int, ins, outs, imm=(), a=0, b=0):
+        ia = (C.c_uint32 * max(len(ins), 1))(*ins)
+        oa = (C.c_uint32 * max(len(outs), 1))(*outs)
+        ma = (C.c_uint64 * max(len(imm), 1))(*imm)
+        _check(lib().zk_cs_emit_op(self._h, opcode, a, b, ia, len(ins), oa, len(outs), ma, len(imm)))
+
+    def perform_lookup(self, table_id: int, keys, n_vals: int):
+        ka = (C.c_uint32 * len(keys))(*keys)
+        va = (C.c_uint32 * max(n_vals, 1))()
+        _check(lib().zk_cs_lookup(self._h, table_id, ka, len(keys), va, n_vals))
+        return [va[i] for i in range(n_vals)]
+
+    def loop_begin(self, limit: int):
+        _check(lib().zk_cs_loop_begin(self._h, limit))
+
+    def loop_end(self):
+        _check(lib().zk_cs_loop_end(self._h))
+
+    def link(self, kind: int, loop_var: int, other: int):
+        _check(lib().zk_cs_link(self._h, kind, loop_var, other))
+
+    def loop_last(self, loop_var: int) -> int:
+        v = C.c_uint32()
+        _check(lib().zk_cs_loop_last(self._h, loop_var, C.byref(v)))
+        return v.value
+
+    def loop_import(self, outer_var: int) -> int:
+        v = C.c_uint32()
+        _check(lib().zk_cs_loop_import(self._h, outer_var, C.byref(v)))
+        return v.value
+
+    def next_available_row(self) -> int:
+        r = C.c_uint64()
+        _check(lib().zk_cs_next_available_row(self._h, C.byref(r)))
+        return r.value
+
+    def pad_and_shrink(self):
+        """pad_and_shrink + into_assembly: placement and program emission (no GPU needed)."""
+        _check(lib().zk_cs_finalize(self._h))
+
+    finalize = pad_and_shrink
+
+    # --- circuits ---
+    def configure_ram_permutation(self):
+        _check(lib().zk_circuit_ram_permutation_configure(self._h))
+
+    def ram_permutation_entry_point(self, limit: int):
+        _check(lib().zk_circuit_ram_permutation(self._h, limit))
+
+    def configure_vm_shaped(self):
+        _check(lib().zk_circuit_vm_shaped_configure(self._h))
+
+    def vm_shaped_entry_point(self, limit: int):
+        _check(lib().zk_circuit_vm_shaped(self._h, limit))
+
+    def input_words(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        _check(lib().zk_circuit_input_words(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # --- execution ---
+    def set_batch(self, n_instances: int):
+        _check(lib().zk_cs_set_batch(self._h, n_instances))
+        self.batch = n_instances
+
+    def bind_inputs(self, loop_scope: bool, dev_words, n_words: int):
+        self._keep.append(dev_words)
+        _check(lib().zk_cs_bind_inputs(self._h, int(loop_scope), _ptr(dev_words), n_words))
+
+    def resolve(self, stream=None):
+        _check(lib().zk_cs_resolve(self._h, _ptr(stream)))
+
+    def check_if_satisfied(self, stream=None):
+        """Returns (True, None) or (False, Failure)."""
+        f = _Failure()
+        rc = lib().zk_cs_check_satisfied(self._h, _ptr(stream), C.byref(f))
+        if rc == 0:
+            return True, None
+        if rc == ZK_ERR_UNSATISFIED:
+            return False, Failure(f.scope, f.instance, f.iteration, f.slot, f.kind, f.relation)
+        _check(rc)
+
+    def read_var(self, var: int, instance: int = 0, iteration: int = 0) -> int:
+        out = C.c_uint64()
+        _check(lib().zk_cs_read_var(self._h, var, instance, iteration, C.byref(out)))
+        return out.value
+
+    def write_cell(self, loop_scope: bool, cell: int, lane: int, value: int):
+        _check(lib().zk_cs_write_cell(self._h, int(loop_scope), cell, lane, C.c_uint64(value)))
+
+    def public_inputs(self, instance: int = 0):
+        n = C.c_uint32()
+        buf = (C.c_uint64 * 64)()
+        _check(lib().zk_cs_public_inputs(self._h, instance, buf, 64, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def var_cell(self, var: int) -> int:
+        c = C.c_uint32()
+        _check(lib().zk_cs_var_cell(self._h, var, C.byref(c)))
+        return c.value
+
+    def public_cells(self):
+        n = C.c_uint32()
+        buf = (C.c_uint32 * 64)()
+        _check(lib().zk_cs_public_cells(self._h, buf, 64, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def multiplicities(self, instance: int = 0) -> np.ndarray:
+        n = C.c_uint32()
+        _check(lib().zk_cs_multiplicities(self._h, instance, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        _check(lib().zk_cs_multiplicities(self._h, instance, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
+
+    def stats(self) -> dict:
+        s = _Stats()
+        _check(lib().zk_cs_stats(self._h, C.byref(s)))
+        d = {f[0]: getattr(s, f[0]) for f in _Stats._fields_ if f[0] != "gate_instances"}
+        d["gate_instances"] = {GATE_NAMES[i]: s.gate_instances[i] for i in range(13)}
+        return d
+
+    print_gate_stats = stats
+
+    def last_ms(self, which: int) -> float:
+        ms = C.c_float()
+        _check(lib().zk_cs_last_ms(self._h, which, C.byref(ms)))
+        return ms.value
+
+    def export(self, loop_scope: bool) -> np.ndarray:
+        n = C.c_size_t()
+        _check(lib().zk_cs_export(self._h, int(loop_scope), None, 0, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint32)
+        _check(lib().zk_cs_export(self._h, int(loop_scope), buf.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return buf
+
+    def trace(self, loop_scope: bool) -> np.ndarray:
+        """Copy the scope's cells back: array [n_cells, stride] (lane-minor)."""
+        p, n, s = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        _check(lib().zk_cs_trace_ptr(self._h, int(loop_scope), C.byref(p), C.byref(n), C.byref(s)))
+        out = np.empty(n.value * s.value, dtype=np.uint64)
+        if out.size:
+            _check(lib().zk_d2h(out.ctypes.data_as(C.c_void_p), p, C.c_size_t(out.nbytes), None))
+        return out.reshape(n.value, s.value)

@@ -1,0 +1,204 @@
+/*
+ * zkgl.h — C ABI of libzkgl.so, the MI355X-native witness-generation + constraint-evaluation
+ * engine for the per-circuit hot path of matter-labs/era-zkevm_circuits.
+ *
+ * This is the drop-in boundary: what a Rust `impl ConstraintSystem<F>` shim
+ * would bind through `extern "C"` (INTEGRATION.md shows the stub).  Plain pointers and
+ * sizes only.  Every entry returns 0 on success, a negative zk_status otherwise, and never
+ * aborts; `zk_last_error()` returns the message of the last failure on the calling thread.
+ *
+ * Reference interfaces replaced (all in the external crate `boojum`, as *used* by the
+ * reference at the cited lines):
+ *   field / hash primitives  <- boojum::field::goldilocks, boojum::implementations::poseidon2
+ *                               (src/ram_permutation/mod.rs:405,411)
+ *   zk_cs_*                  <- boojum::cs::traits::cs::ConstraintSystem + cs_builder
+ *                               (call sites: src/ram_permutation/mod.rs:419-556,
+ *                                src/main_vm/utils.rs:51-99)
+ *   zk_circuit_*             <- the `*_entry_point` functions (src/ram_permutation/mod.rs:31)
+ *
+ * Device pointers are raw HIP device addresses (e.g. `torch.Tensor.data_ptr()`); `stream` is a
+ * `hipStream_t` passed as void* (NULL = the null stream).
+ */
+#ifndef ZKGL_H
+#define ZKGL_H
+#include <stddef.h>
+#include <stdint.h>
+#include "zkgl_ir.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum zk_status {
+    ZK_OK = 0,
+    ZK_ERR_INVALID = -1,   /* bad argument / API misuse (reference: panic / expect) */
+    ZK_ERR_HIP = -2,       /* HIP runtime failure, no usable GPU */
+    ZK_ERR_UNRESOLVED = -3,/* a variable has no witness producer (reference: resolver hang/panic) */
+    ZK_ERR_CAPACITY = -4,  /* trace exceeds max_trace_len / max_variables */
+    ZK_ERR_UNSATISFIED = -5,
+    ZK_ERR_GATE_NOT_ALLOWED = -6 /* reference: `unimplemented!()` src/main_vm/utils.rs:87-89 */
+} zk_status;
+
+const char *zk_last_error(void);
+/* Select the device, upload Poseidon2 constants.  Fails loudly (ZK_ERR_HIP) without a GPU. */
+int zk_init(int device);
+int zk_device_count(void);
+/* host-side derivation of the 360 round constants (no GPU needed) */
+int zk_poseidon_round_constants(uint64_t out[360]);
+
+/* ---------------- device memory helpers (thin hipMalloc/hipMemcpy wrappers) ---------------- */
+int zk_malloc(void **dptr, size_t bytes);
+int zk_free(void *dptr);
+int zk_memset(void *dptr, int value, size_t bytes, void *stream);
+int zk_h2d(void *dptr, const void *hptr, size_t bytes, void *stream);
+int zk_d2h(void *hptr, const void *dptr, size_t bytes, void *stream);
+int zk_sync(void *stream);
+
+/* ---------------- K1: Goldilocks column arithmetic ----------------------------------------- */
+/* dst[i] = q*a[i]*b[i] + l*c[i]   (FmaGateInBaseFieldWithoutConstant witness, column form) */
+int zk_gl_fma_cols(uint64_t *dst, const uint64_t *a, const uint64_t *b, const uint64_t *c,
+                   uint64_t q, uint64_t l, size_t n, void *stream);
+int zk_gl_add_cols(uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t n, void *stream);
+int zk_gl_sub_cols(uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t n, void *stream);
+int zk_gl_mul_cols(uint64_t *dst, const uint64_t *a, const uint64_t *b, size_t n, void *stream);
+/* dst[i] = s[i] ? a[i] : b[i] */
+int zk_gl_select_cols(uint64_t *dst, const uint64_t *s, const uint64_t *a, const uint64_t *b,
+                      size_t n, void *stream);
+/* dst[i] = a[i]^-1, 0 -> 0 */
+int zk_gl_inv_cols(uint64_t *dst, const uint64_t *a, size_t n, void *stream);
+
+/* ---------------- K2: batched Poseidon2 permutation ---------------------------------------- */
+/* column-major: element j of state i at states[j*stride + i]; in place */
+int zk_poseidon2_permute_soa(uint64_t *states, size_t n, size_t stride, void *stream);
+/* row-major: state i at states[12*i .. 12*i+11]; in place; staged through LDS */
+int zk_poseidon2_permute_aos(uint64_t *states, size_t n, void *stream);
+
+/* ---------------- K3: sponge chains --------------------------------------------------------- */
+/* commit_encoding (src/fsm_input_output/mod.rs:281-326) for n independent encodings of equal
+ * length `len`; input[j*n + i] = element j of encoding i; out[j*n + i], j < 4 */
+int zk_commit_encoding_batch(const uint64_t *input, size_t len, size_t n, uint64_t *out, void *stream);
+/* full-state queue hash chains (src/main_vm/utils.rs:194-213): nq independent queues, each
+ * pushing `items` encodings; enc[(q*items + t)*8 + j]; tail_io[q*12 + j] in/out;
+ * if states_out != NULL, states_out[(q*items + t)*12 + j] = tail BEFORE push t */
+int zk_queue_full_push_chain(const uint64_t *enc, size_t nq, size_t items, uint64_t *tail_io,
+                             uint64_t *states_out, void *stream);
+
+/* ---------------- a9: MemoryQuery::encode, column form ------------------------------------- */
+/* q[f*n + i], f < 13 (ts, page, index, rw, is_ptr, value limbs 0..7); enc[j*n + i], j < 8 */
+int zk_memory_query_encode(const uint64_t *q, size_t n, uint64_t *enc, void *stream);
+
+/* ---------------- K4: permutation grand product -------------------------------------------- */
+/* enc[j*n + i] (j < enc_len), flags[i] in {0,1}, challenges[enc_len+1];
+ * acc_out[i] = init * prod_{t<=i, flags[t]} (ch[enc_len] + sum_j enc[j][t]*ch[j])
+ * (src/utils.rs:81-137, one repetition).  scratch: >= n u64 device words. */
+int zk_grand_product(const uint64_t *enc, const uint64_t *flags, const uint64_t *challenges,
+                     size_t enc_len, size_t n, uint64_t init, uint64_t *acc_out,
+                     uint64_t *scratch, void *stream);
+
+/* ---------------- constraint-system recorder + GPU executor -------------------------------- */
+typedef struct zk_cs zk_cs; /* opaque handle; NOT thread-safe, one recording thread, one device */
+typedef uint32_t zk_var;
+#define ZK_VAR_NONE 0xffffffffu
+
+typedef struct zk_geometry { /* boojum::cs::CSGeometry, src/main_vm/cycle.rs:959-966 */
+    uint32_t num_columns_under_copy_permutation;
+    uint32_t num_witness_columns;
+    uint32_t num_constant_columns;
+    uint32_t max_allowed_constraint_degree;
+} zk_geometry;
+
+int zk_cs_create(const zk_geometry *geometry, uint64_t max_trace_len, uint64_t max_variables,
+                 zk_cs **out);
+int zk_cs_destroy(zk_cs *cs);
+/* LookupParameters::UseSpecializedColumnsWithTableIdAsConstant (src/ram_permutation/mod.rs:435-441) */
+int zk_cs_allow_lookup(zk_cs *cs, uint32_t width, uint32_t num_repetitions, int share_table_id);
+/* G::configure_builder(..) (src/ram_permutation/mod.rs:442-483) */
+int zk_cs_allow_gate(zk_cs *cs, uint32_t gate_kind);
+int zk_cs_gate_is_allowed(zk_cs *cs, uint32_t gate_kind); /* 1 / 0 */
+/* add_lookup_table::<T, W> (src/ram_permutation/mod.rs:500-501). rows[r*(n_keys+n_vals) + c].
+ * marker = caller-chosen table identity (the Rust type in the reference). Returns table id >= 1 in *id. */
+int zk_cs_add_table(zk_cs *cs, uint32_t marker, uint32_t n_keys, uint32_t n_vals,
+                    const uint64_t *rows, uint32_t n_rows, uint32_t *id);
+int zk_cs_table_id(zk_cs *cs, uint32_t marker, uint32_t *id); /* get_table_id_for_marker */
+
+/* --- recording (single thread) --- */
+int zk_cs_alloc_vars(zk_cs *cs, uint32_t n, zk_var *first);          /* alloc_multiple_variables_without_values */
+int zk_cs_alloc_constant(zk_cs *cs, uint64_t value, zk_var *out);    /* allocate_constant */
+int zk_cs_input(zk_cs *cs, uint32_t word, zk_var *out);              /* witness value from the bound input stream */
+/* Gate::add_to_cs: vars in the kind's column order, consts = the row-shared parameters */
+int zk_cs_place_gate(zk_cs *cs, uint32_t gate_kind, const zk_var *vars, uint32_t n_vars,
+                     const uint64_t *consts, uint32_t n_consts);
+/* set_values_with_dependencies with a closure from the closed op set (zk_opcode) */
+int zk_cs_emit_op(zk_cs *cs, uint32_t opcode, uint32_t a, uint32_t b, const zk_var *ins,
+                  uint32_t n_in, const zk_var *outs, uint32_t n_out, const uint64_t *imm,
+                  uint32_t n_imm);
+/* perform_lookup::<K,V> (src/main_vm/decoded_opcode.rs:492): allocates V outputs */
+int zk_cs_lookup(zk_cs *cs, uint32_t table_id, const zk_var *keys, uint32_t n_keys, zk_var *vals,
+                 uint32_t n_vals);
+/* loop scope: the `for _cycle in 0..limit` body (src/ram_permutation/mod.rs:246) is recorded ONCE */
+int zk_cs_loop_begin(zk_cs *cs, uint32_t limit);
+int zk_cs_loop_end(zk_cs *cs);
+int zk_cs_link(zk_cs *cs, uint32_t link_kind, zk_var loop_var, zk_var other_var);
+/* value of a loop variable at the last iteration, as an outer variable (post phase) */
+int zk_cs_loop_last(zk_cs *cs, zk_var loop_var, zk_var *outer_out);
+/* use an outer variable inside the loop (broadcast; pre phase must define it) */
+int zk_cs_loop_import(zk_cs *cs, zk_var outer_var, zk_var *loop_out);
+int zk_cs_next_available_row(zk_cs *cs, uint64_t *row);
+/* pad_and_shrink + into_assembly: placement, program emission, upload */
+int zk_cs_finalize(zk_cs *cs);
+
+/* --- execution --- */
+int zk_cs_set_batch(zk_cs *cs, uint32_t n_instances); /* allocates device trace for the batch */
+/* input streams: outer scope words[w*B + inst]; loop scope words[w*(B*limit) + inst*limit + k]; device ptrs */
+int zk_cs_bind_inputs(zk_cs *cs, int loop_scope, const uint64_t *dev_words, uint32_t n_words);
+int zk_cs_resolve(zk_cs *cs, void *stream);          /* witness generation */
+typedef struct zk_failure { uint32_t scope, instance, iteration, slot, kind, relation; } zk_failure;
+/* check_if_satisfied: 0 satisfied; ZK_ERR_UNSATISFIED + first failure otherwise */
+int zk_cs_check_satisfied(zk_cs *cs, void *stream, zk_failure *first);
+int zk_cs_read_var(zk_cs *cs, zk_var var, uint32_t instance, uint32_t iteration, uint64_t *out); /* witness_hook */
+int zk_cs_write_cell(zk_cs *cs, int loop_scope, uint32_t cell, uint32_t lane, uint64_t value); /* fault injection for tests */
+int zk_cs_public_inputs(zk_cs *cs, uint32_t instance, uint64_t *out, uint32_t max, uint32_t *n);
+/* placement query (after finalize, no GPU needed): home cell of a variable / of the public inputs */
+int zk_cs_var_cell(zk_cs *cs, zk_var var, uint32_t *cell);
+int zk_cs_public_cells(zk_cs *cs, uint32_t *cells, uint32_t max, uint32_t *n);
+/* lookup multiplicities of one instance: mult[table_row_global] (u32), n = total rows of all tables */
+int zk_cs_multiplicities(zk_cs *cs, uint32_t instance, uint32_t *out, uint32_t max, uint32_t *n);
+
+typedef struct zk_stats {
+    uint64_t rows_per_instance;      /* trace rows used (loop slots*limit + outer slots) */
+    uint64_t loop_slots, outer_slots, limit;
+    uint64_t copy_columns, lookup_columns;
+    uint64_t variables_outer, variables_loop;
+    uint64_t constraints_per_instance; /* relations of placed gate instances + lookup tuples */
+    uint64_t var_cells_per_instance;   /* trace cells (rows * variable columns) */
+    uint64_t gate_instances[ZK_GATE__COUNT]; /* per instance */
+    uint64_t lookups_per_instance;
+    uint64_t program_words_outer, program_words_loop;
+    uint64_t scratch_cells_outer, scratch_cells_loop;
+} zk_stats;
+int zk_cs_stats(zk_cs *cs, zk_stats *out);           /* print_gate_stats counterpart */
+/* last execution times in ms measured with HIP events on the execution stream:
+ * which: 0 resolve total, 1 loop witness kernel, 2 check total, 3 gate-check loop kernel, 4 outer kernels */
+int zk_cs_last_ms(zk_cs *cs, int which, float *ms);
+/* serialised scope (program + descriptors) for the CPU oracle / offline tooling.
+ * Call with buf = NULL to get the size in words. */
+int zk_cs_export(zk_cs *cs, int loop_scope, uint32_t *buf, size_t max_words, size_t *n_words);
+int zk_cs_trace_ptr(zk_cs *cs, int loop_scope, uint64_t **dev_cells, uint64_t *n_cells, uint64_t *stride);
+
+/* ---------------- circuits (host side mirrors of the reference entry points) ---------------- */
+/* ram_permutation_entry_point (src/ram_permutation/mod.rs:31-210) recorded with `limit` cycles.
+ * Input stream layouts are documented in DESIGN.md §ram_permutation. */
+int zk_circuit_ram_permutation(zk_cs *cs, uint32_t limit);
+/* configure a CS the way the reference test does (geometry 100/0/8/4, xor8 table, gate set):
+ * src/ram_permutation/mod.rs:419-501 */
+int zk_circuit_ram_permutation_configure(zk_cs *cs);
+/* number of input words per lane for (outer, loop) scopes of the recorded circuit */
+int zk_circuit_input_words(zk_cs *cs, uint32_t *outer_words, uint32_t *loop_words);
+/* main_vm-shaped synthetic cycle (geometry src/main_vm/cycle.rs:959-966) */
+int zk_circuit_vm_shaped_configure(zk_cs *cs);
+int zk_circuit_vm_shaped(zk_cs *cs, uint32_t limit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

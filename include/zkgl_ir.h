@@ -1,0 +1,107 @@
+/*
+ * zkgl_ir.h — the closed witness IR + placement tables the engine executes on the GPU.
+ *
+ * The reference produces witness values with opaque Rust closures handed to
+ * `set_values_with_dependencies{,_vararg}` (e.g. /root/reference/src/main_vm/opcodes/add_sub.rs:177-217,
+ * src/main_vm/cycle.rs:912-928) and gate instances with `Gate::add_to_cs`
+ * (src/main_vm/utils.rs:74-86).  Closures cannot cross to a GPU, so the recorder lowers every
+ * closure the circuits use to one of the ops below and every gate to a
+ * row descriptor.  One recorded *scope* = one straight-line program executed SIMT with
+ * lane == circuit instance (outer scope) or lane == (instance, loop iteration) (loop scope).
+ *
+ * Storage: cells[cell * stride + lane], cell = column * n_slots + slot for trace cells, scratch
+ * cells (variables that no gate references) follow.  A wavefront touching one cell therefore
+ * issues one coalesced 512-byte access.
+ *
+ * Program = array of u32 words.  Operand word: bit31 = 0 -> own-scope cell index;
+ * bits31..30 = 10 -> constant-pool index; 11 -> outer-scope cell index (loop scope only).
+ * Destination list per produced value: one or more cell words, bit31 set on every word but the
+ * last one of the list (a value is written to every cell its variable occupies).
+ */
+#ifndef ZKGL_IR_H
+#define ZKGL_IR_H
+#include <stdint.h>
+
+#define ZK_OPERAND_CONST 0x80000000u
+#define ZK_OPERAND_OUTER 0xC0000000u
+#define ZK_OPERAND_KIND_MASK 0xC0000000u
+#define ZK_OPERAND_IDX_MASK 0x3FFFFFFFu
+#define ZK_DEST_MORE 0x80000000u
+
+/* header word = opcode | (a << 8) | (b << 16) ; a,b are small op parameters */
+enum zk_opcode {
+    ZK_OP_END = 0,
+    ZK_OP_CONST = 1,     /* [const operand] -> out                                   (allocate_constant) */
+    ZK_OP_INPUT = 2,     /* [word index]    -> out : per-lane input stream word       (witness allocation) */
+    ZK_OP_FMA = 3,       /* [q, l, a, b, c] -> q*a*b + l*c                            (FmaGate witness) */
+    ZK_OP_LC4 = 4,       /* [k0..k3, t0..t3] -> sum k_i t_i                           (ReductionGate witness) */
+    ZK_OP_SELECT = 5,    /* [s, a, b] -> s ? a : b                                    (SelectionGate witness) */
+    ZK_OP_ISZERO = 6,    /* [x] -> flag = (x==0), aux = x^-1 or 0                     (ZeroCheckGate witness) */
+    ZK_OP_UADD = 7,      /* a=bits; [x, y, cin] -> (x+y+cin) mod 2^bits, carry        (UIntXAddGate witness) */
+    ZK_OP_USUB = 8,      /* a=bits; [x, y, bin] -> (x-y-bin) mod 2^bits, borrow */
+    ZK_OP_DOT4 = 9,      /* [a0,b0,..,a3,b3] -> sum a_i b_i                           (DotProductGate<4>) */
+    ZK_OP_MATMUL12 = 10, /* a=matrix id (0 external, 1 inner); [in0..11] -> out0..11  (MatrixMultiplicationGate) */
+    ZK_OP_SPLIT = 11,    /* a=nchunks, b=bits per chunk; [x] -> chunks (LSB first)    (decompose_into_bytes etc.) */
+    ZK_OP_LOOKUP = 12,   /* a=nkeys, b=nvals; [table id word, keys..] -> vals         (perform_lookup) */
+    ZK_OP_POSEIDON2 = 13,/* [in0..11] -> out0..11 witness-only permutation            (simulate_round_function) */
+    ZK_OP_P2_ROUNDS = 14,/* in-circuit permutation macro-op: [in0..11, rc cell x118] -> every intermediate, see zkgl_ir docs */
+    ZK_OP_LOOP_LAST = 15,/* outer scope, post phase: [loop cell word] -> value at the last iteration */
+    ZK_OP_U32MULADD = 16,/* [a, b, c, d] -> lo, hi of a*b + c + d  (u32 each)         (UInt32::fma_with_carry) */
+    ZK_OP_ADD_CONSTMUL = 17, /* reserved */
+    ZK_OP__COUNT
+};
+
+/* gate kinds (row descriptors).  Relations are restated from SURVEY.md §8 a2 / Appendix F. */
+enum zk_gate_kind {
+    ZK_GATE_NOP = 0,
+    ZK_GATE_CONST = 1,     /* 1 var, 1 const : v - c */
+    ZK_GATE_BOOLEAN = 2,   /* 1 var          : v^2 - v */
+    ZK_GATE_FMA = 3,       /* a,b,c,d ; q,l  : q*a*b + l*c - d */
+    ZK_GATE_REDUCTION4 = 4,/* t0..t3,r ; k0..k3 : sum k_i t_i - r */
+    ZK_GATE_SELECT = 5,    /* a,b,s,r        : s*(a-b) + b - r */
+    ZK_GATE_ZEROCHECK = 6, /* x,aux,flag     : x*aux - (1-flag) ; x*flag */
+    ZK_GATE_UINTX_ADD = 7, /* a,b,cin,c,cout ; const 2^X : a+b+cin - c - 2^X*cout */
+    ZK_GATE_DOT4 = 8,      /* a0,b0..a3,b3,r : sum a_i b_i - r */
+    ZK_GATE_MATMUL12_EXT = 9,  /* in0..11,out0..11 : out - M_E in (12 relations) */
+    ZK_GATE_MATMUL12_INT = 10, /* in0..11,out0..11 : out - M_I in (12 relations) */
+    ZK_GATE_PUBLIC_INPUT = 11, /* 1 var : marks the cell public, no relation */
+    ZK_GATE_U32_FMA = 12,  /* a,b,c,d,lo,hi  : a*b + c + d - lo - 2^32 hi  (U8x4FMAGate role) */
+    ZK_GATE__COUNT
+};
+
+/* per-slot gate row descriptor (uniform across lanes; lives in scalar/constant memory) */
+typedef struct zk_row_desc {
+    uint32_t kind;        /* zk_gate_kind */
+    uint32_t n_instances; /* instance j occupies columns [j*width, (j+1)*width) */
+    uint32_t const_off;   /* offset into the scope's row-constant pool */
+    uint32_t n_consts;    /* constants shared by every instance of the row */
+} zk_row_desc;
+
+/* per-slot lookup row descriptor: up to `reps` tuples of `width` columns, one table per row */
+typedef struct zk_lookup_row_desc {
+    uint32_t table;   /* table id, 0xffffffff = no lookups in this row */
+    uint32_t n_tuples;
+} zk_lookup_row_desc;
+
+/* table descriptor on the device */
+typedef struct zk_table_desc {
+    uint32_t word_off;  /* offset (in u64 words) into the packed table storage; rows are row-major */
+    uint32_t mult_off;  /* global row number of row 0 (index into the multiplicity vector) */
+    uint32_t n_rows;
+    uint32_t n_keys;
+    uint32_t n_vals;
+    uint32_t dense;     /* 1: row index = sum key_i << key_shift[i] */
+    uint32_t key_shift[3];
+} zk_table_desc;
+
+/* copy-constraint records */
+typedef struct zk_copy_pair { uint32_t cell; uint32_t home; } zk_copy_pair;
+enum zk_link_kind {
+    ZK_LINK_CARRY = 0, /* loop: in_cell[k+1] == out_cell[k] */
+    ZK_LINK_FIRST = 1, /* loop in_cell[k=0] == outer cell */
+    ZK_LINK_LAST = 2,  /* outer cell == loop out_cell[k=limit-1] */
+    ZK_LINK_BCAST = 3  /* loop cell[k] == outer cell for every k */
+};
+typedef struct zk_link { uint32_t kind; uint32_t loop_cell; uint32_t other_cell; uint32_t pad; } zk_link;
+
+#endif

@@ -1,0 +1,232 @@
+"""oracle/zko.py — Python face of the CPU ORACLE (test infrastructure; see oracle/zko.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+It loads oracle/libzko.so (plain C, built by oracle/Makefile with gcc) and never touches the
+product library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libzko.so")
+P = 0xFFFFFFFF00000001
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u64 = C.c_uint64
+        for name in ("zko_gl_add", "zko_gl_sub", "zko_gl_mul", "zko_gl_pow"):
+            getattr(L, name).restype = u64
+            getattr(L, name).argtypes = [u64, u64]
+        L.zko_gl_inv.restype = u64
+        L.zko_gl_inv.argtypes = [u64]
+        L.zko_poseidon_round_constants.restype = C.POINTER(u64)
+        L.zko_scope_parse.restype = C.c_void_p
+        L.zko_scope_parse.argtypes = [C.c_void_p, C.c_size_t]
+        L.zko_scope_free.argtypes = [C.c_void_p]
+        L.zko_scope_field.restype = C.c_uint32
+        L.zko_scope_field.argtypes = [C.c_void_p, C.c_int]
+        L.zko_scope_run.restype = C.c_int
+        L.zko_scope_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.zko_scope_check.restype = C.c_uint64
+        L.zko_scope_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.zko_links_check.restype = C.c_uint64
+        L.zko_links_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def u64arr(x) -> np.ndarray:
+    return np.ascontiguousarray(np.array(x, dtype=np.uint64))
+
+
+# ---- field ----
+def gl_add(a, b): return int(lib().zko_gl_add(a, b))
+def gl_sub(a, b): return int(lib().zko_gl_sub(a, b))
+def gl_mul(a, b): return int(lib().zko_gl_mul(a, b))
+def gl_inv(a): return int(lib().zko_gl_inv(a))
+
+
+def gl_fma_cols(a, b, c, q, l):
+    a, b, c = u64arr(a), u64arr(b), u64arr(c)
+    out = np.zeros_like(a)
+    lib().zko_gl_fma_cols(_p(out), _p(a), _p(b), _p(c), C.c_uint64(q), C.c_uint64(l), C.c_size_t(a.size))
+    return out
+
+
+# ---- poseidon2 / sponge ----
+def round_constants() -> np.ndarray:
+    rc = lib().zko_poseidon_round_constants()
+    return np.array([rc[i] for i in range(360)], dtype=np.uint64)
+
+
+def poseidon2_permute(state):
+    s = u64arr(state).copy()
+    assert s.size == 12
+    lib().zko_poseidon2_permute(_p(s))
+    return [int(x) for x in s]
+
+
+def poseidon2_permute_batch(states: np.ndarray) -> np.ndarray:
+    """states: [n, 12] AoS -> permuted copy"""
+    s = np.ascontiguousarray(states, dtype=np.uint64).copy()
+    lib().zko_poseidon2_permute_batch(_p(s), C.c_size_t(s.shape[0]))
+    return s
+
+
+def mds_external(state):
+    s = u64arr(state).copy(); lib().zko_poseidon2_mds_external(_p(s)); return [int(x) for x in s]
+
+
+def mds_inner(state):
+    s = u64arr(state).copy(); lib().zko_poseidon2_mds_inner(_p(s)); return [int(x) for x in s]
+
+
+def commit_encoding(values):
+    v = u64arr(values)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().zko_commit_encoding(_p(v), C.c_size_t(v.size), _p(out))
+    return [int(x) for x in out]
+
+
+def fs_challenges(fs_input, reps, nchal):
+    v = u64arr(fs_input)
+    out = np.zeros(reps * nchal, dtype=np.uint64)
+    lib().zko_fs_challenges(_p(v), C.c_size_t(v.size), _p(out), C.c_size_t(reps), C.c_size_t(nchal))
+    return [[int(out[r * nchal + i]) for i in range(nchal)] for r in range(reps)]
+
+
+def queue_full_push(tail, enc):
+    t = u64arr(tail).copy(); e = u64arr(enc)
+    lib().zko_queue_full_push(_p(t), _p(e))
+    return [int(x) for x in t]
+
+
+def queue_tail4_push20(tail, enc):
+    t = u64arr(tail).copy(); e = u64arr(enc)
+    lib().zko_queue_tail4_push20(_p(t), _p(e))
+    return [int(x) for x in t]
+
+
+def memory_query_encode(q13):
+    q = u64arr(q13); out = np.zeros(8, dtype=np.uint64)
+    lib().zko_memory_query_encode(_p(q), _p(out))
+    return [int(x) for x in out]
+
+
+def grand_product(enc: np.ndarray, flags, challenges, init=1):
+    """enc [n, enc_len] row-major; returns running accumulator after each item"""
+    enc = np.ascontiguousarray(enc, dtype=np.uint64)
+    n, L = enc.shape
+    fl = np.ascontiguousarray(np.array(flags, dtype=np.uint8))
+    ch = u64arr(challenges)
+    out = np.zeros(n, dtype=np.uint64)
+    lib().zko_grand_product(_p(enc), _p(fl), _p(ch), C.c_size_t(L), C.c_size_t(n), C.c_uint64(init), _p(out))
+    return out
+
+
+# ---- hashes ----
+def keccak256(msg: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().zko_keccak256(msg, C.c_size_t(len(msg)), out)
+    return bytes(out)
+
+
+def keccak_f1600(state25):
+    s = u64arr(state25).copy(); lib().zko_keccak_f1600(_p(s)); return [int(x) for x in s]
+
+
+def sha256_compress(state8, block: bytes):
+    s = np.ascontiguousarray(np.array(state8, dtype=np.uint32))
+    lib().zko_sha256_compress(_p(s), block)
+    return [int(x) for x in s]
+
+
+# ---- engine interpreter ----
+class Scope:
+    """A serialised zkgl scope (ConstraintSystem.export) loaded into the oracle interpreter."""
+
+    def __init__(self, words: np.ndarray):
+        self.words = np.ascontiguousarray(words, dtype=np.uint32)
+        self.h = lib().zko_scope_parse(_p(self.words), C.c_size_t(self.words.size))
+        if not self.h:
+            raise ValueError("zko_scope_parse: malformed scope export")
+        f = lambda i: int(lib().zko_scope_field(self.h, i))
+        self.is_loop, self.n_cells, self.n_trace_cells, self.n_slots = f(0), f(1), f(2), f(3)
+        self.n_input_words, self.limit, self.pre_words, self.n_prog = f(4), f(5), f(6), f(7)
+        self.n_copies, self.n_links, self.n_copy_cols, self.lookup_width = f(8), f(9), f(10), f(11)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().zko_scope_free(self.h)
+        except Exception:
+            pass
+
+
+def stride_for(lanes: int) -> int:
+    return (lanes + 31) // 32 * 32
+
+
+class CircuitRun:
+    """Run an exported circuit (outer + loop scope) on the CPU oracle for a batch of instances."""
+
+    def __init__(self, outer_words, loop_words, batch: int, total_table_rows: int = 0):
+        self.outer, self.loop = Scope(outer_words), Scope(loop_words)
+        self.B = batch
+        self.limit = self.loop.limit
+        self.so, self.sl = stride_for(batch), stride_for(batch * max(self.limit, 0))
+        self.oc = np.zeros((self.outer.n_cells, self.so), dtype=np.uint64)
+        self.lc = np.zeros((max(self.loop.n_cells, 1), max(self.sl, 32)), dtype=np.uint64)
+        self.mult = np.zeros(max(batch * total_table_rows, 1), dtype=np.uint32)
+        self.total_rows = total_table_rows
+
+    def resolve(self, outer_inputs: np.ndarray, loop_inputs: np.ndarray):
+        """outer_inputs [words, B]; loop_inputs [words, B*limit] (lane-minor)"""
+        L = lib()
+        oi = np.ascontiguousarray(outer_inputs, dtype=np.uint64)
+        li = np.ascontiguousarray(loop_inputs, dtype=np.uint64)
+        nl = self.B * self.limit
+        mult = _p(self.mult) if self.total_rows else None
+        rc = L.zko_scope_run(self.outer.h, 0, self.outer.pre_words, _p(self.oc), self.so, self.B, _p(oi), None, 0,
+                             _p(self.lc), self.lc.shape[1], self.limit, mult, self.total_rows)
+        assert rc == 0
+        if self.limit:
+            rc = L.zko_scope_run(self.loop.h, 0, self.loop.n_prog, _p(self.lc), self.lc.shape[1], nl, _p(li), _p(self.oc),
+                                 self.so, None, 0, self.limit, mult, self.total_rows)
+            assert rc == 0
+        rc = L.zko_scope_run(self.outer.h, self.outer.pre_words, self.outer.n_prog, _p(self.oc), self.so, self.B, _p(oi),
+                             None, 0, _p(self.lc), self.lc.shape[1], self.limit, mult, self.total_rows)
+        assert rc == 0
+
+    def check(self):
+        """-> (n_violations, n_relations_evaluated)"""
+        L = lib()
+        first = C.c_uint64(); nrel = C.c_uint64(); total_rel = 0
+        bad = int(L.zko_scope_check(self.outer.h, _p(self.oc), self.so, self.B, C.byref(first), C.byref(nrel)))
+        total_rel += nrel.value
+        if self.limit:
+            bad += int(L.zko_scope_check(self.loop.h, _p(self.lc), self.lc.shape[1], self.B * self.limit, C.byref(first), C.byref(nrel)))
+            total_rel += nrel.value
+            bad += int(L.zko_links_check(self.loop.h, _p(self.lc), self.lc.shape[1], self.B * self.limit, _p(self.oc), self.so))
+        return bad, total_rel

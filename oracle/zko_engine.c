@@ -1,0 +1,390 @@
+/* oracle/zko_engine.c — CPU ORACLE (test infrastructure, never shipped, never timed as product).
+ *
+ * Independent CPU interpreter + checker for a serialised zkgl scope (zk_cs_export): executes the
+ * witness IR of include/zkgl_ir.h lane by lane with the oracle's own field / Poseidon2 code and
+ * evaluates every gate relation, lookup tuple, copy pair and link.  It is the CPU counterpart of
+ * boojum's resolver + `check_if_satisfied` (/root/reference/src/ram_permutation/mod.rs:552-556)
+ * and the `cpu_baseline` ("port") leg of bench.py.  OpenMP over lanes.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "zko.h"
+#include "zkgl_ir.h"
+
+typedef struct zko_scope {
+    uint32_t is_loop, n_cells, n_trace_cells, n_slots, n_copy_cols, lookup_width, n_input_words, limit, pre_words;
+    uint32_t n_prog, n_consts, n_rows, n_rowconsts, n_lrows, n_copies, n_tables, n_table_words, n_links;
+    uint32_t *prog;
+    uint64_t *consts;
+    zk_row_desc *rows;
+    uint64_t *rowconsts;
+    zk_lookup_row_desc *lrows;
+    zk_copy_pair *copies;
+    zk_table_desc *tables;
+    uint64_t *table_words;
+    zk_link *links;
+} zko_scope;
+
+static uint64_t rd64(const uint32_t *p) { return (uint64_t)p[0] | ((uint64_t)p[1] << 32); }
+
+void zko_scope_free(zko_scope *s) {
+    if (!s) return;
+    free(s->prog); free(s->consts); free(s->rows); free(s->rowconsts); free(s->lrows); free(s->copies);
+    free(s->tables); free(s->table_words); free(s->links); free(s);
+}
+
+zko_scope *zko_scope_parse(const uint32_t *w, size_t n) {
+    if (n < 19 || w[0] != 0x5a4b4731u) return NULL;
+    zko_scope *s = calloc(1, sizeof *s);
+    s->is_loop = w[1]; s->n_cells = w[2]; s->n_trace_cells = w[3]; s->n_slots = w[4]; s->n_copy_cols = w[5];
+    s->lookup_width = w[6]; s->n_input_words = w[7]; s->limit = w[8]; s->pre_words = w[9]; s->n_prog = w[10];
+    s->n_consts = w[11]; s->n_rows = w[12]; s->n_rowconsts = w[13]; s->n_lrows = w[14]; s->n_copies = w[15];
+    s->n_tables = w[16]; s->n_table_words = w[17]; s->n_links = w[18];
+    const uint32_t *p = w + 19;
+#define TAKE(dst, type, count, words_each, conv)                                   \
+    do {                                                                          \
+        s->dst = malloc(sizeof(type) * ((count) ? (count) : 1));                  \
+        for (uint32_t i = 0; i < (count); ++i) { conv; p += (words_each); }       \
+    } while (0)
+    TAKE(prog, uint32_t, s->n_prog, 1, s->prog[i] = p[0]);
+    TAKE(consts, uint64_t, s->n_consts, 2, s->consts[i] = rd64(p));
+    TAKE(rows, zk_row_desc, s->n_rows, 4, (s->rows[i].kind = p[0], s->rows[i].n_instances = p[1], s->rows[i].const_off = p[2], s->rows[i].n_consts = p[3]));
+    TAKE(rowconsts, uint64_t, s->n_rowconsts, 2, s->rowconsts[i] = rd64(p));
+    TAKE(lrows, zk_lookup_row_desc, s->n_lrows, 2, (s->lrows[i].table = p[0], s->lrows[i].n_tuples = p[1]));
+    TAKE(copies, zk_copy_pair, s->n_copies, 2, (s->copies[i].cell = p[0], s->copies[i].home = p[1]));
+    TAKE(tables, zk_table_desc, s->n_tables, 9,
+         (s->tables[i].word_off = p[0], s->tables[i].mult_off = p[1], s->tables[i].n_rows = p[2], s->tables[i].n_keys = p[3],
+          s->tables[i].n_vals = p[4], s->tables[i].dense = p[5], s->tables[i].key_shift[0] = p[6],
+          s->tables[i].key_shift[1] = p[7], s->tables[i].key_shift[2] = p[8]));
+    TAKE(table_words, uint64_t, s->n_table_words, 2, s->table_words[i] = rd64(p));
+    TAKE(links, zk_link, s->n_links, 4, (s->links[i].kind = p[0], s->links[i].loop_cell = p[1], s->links[i].other_cell = p[2], s->links[i].pad = 0));
+#undef TAKE
+    if ((size_t)(p - w) != n) { zko_scope_free(s); return NULL; }
+    return s;
+}
+
+/* getters for the python side */
+uint32_t zko_scope_field(const zko_scope *s, int which) {
+    switch (which) {
+    case 0: return s->is_loop; case 1: return s->n_cells; case 2: return s->n_trace_cells; case 3: return s->n_slots;
+    case 4: return s->n_input_words; case 5: return s->limit; case 6: return s->pre_words; case 7: return s->n_prog;
+    case 8: return s->n_copies; case 9: return s->n_links; case 10: return s->n_copy_cols; case 11: return s->lookup_width;
+    default: return 0;
+    }
+}
+
+/* linear scan / binary search written independently of the device code: plain linear probe over
+ * the sorted table (tables are <= 2^16 rows; the oracle favours obviousness over speed) with a
+ * binary search fast path validated against it in tests. */
+static uint32_t table_find(const zko_scope *s, const zk_table_desc *t, const uint64_t *key) {
+    const uint32_t w = t->n_keys + t->n_vals;
+    const uint64_t *rows = s->table_words + t->word_off;
+    uint32_t lo = 0, hi = t->n_rows;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        int c = 0;
+        for (uint32_t i = 0; i < t->n_keys && !c; ++i) {
+            uint64_t r = rows[(size_t)mid * w + i];
+            c = (r > key[i]) - (r < key[i]);
+        }
+        if (!c) return mid;
+        if (c < 0) lo = mid + 1; else hi = mid;
+    }
+    return t->n_rows;
+}
+
+typedef struct {
+    const zko_scope *s;
+    uint64_t *cells; size_t stride; uint32_t n_lanes;
+    const uint64_t *inputs;
+    const uint64_t *outer_cells; size_t outer_stride;
+    const uint64_t *loop_cells; size_t loop_stride; uint32_t loop_limit;
+    uint32_t *mult; uint32_t total_rows;
+} run_ctx;
+
+static uint64_t ld(const run_ctx *c, uint32_t w, uint32_t lane, uint32_t inst) {
+    uint32_t kind = w & ZK_OPERAND_KIND_MASK, idx = w & ZK_OPERAND_IDX_MASK;
+    if (kind == ZK_OPERAND_CONST) return c->s->consts[idx];
+    if (kind == ZK_OPERAND_OUTER) return c->outer_cells[(size_t)idx * c->outer_stride + inst];
+    return c->cells[(size_t)idx * c->stride + lane];
+}
+static void st(const run_ctx *c, const uint32_t *prog, uint32_t *pc, uint32_t lane, uint64_t v) {
+    uint32_t w;
+    do {
+        w = prog[(*pc)++];
+        c->cells[(size_t)(w & ~ZK_DEST_MORE) * c->stride + lane] = v;
+    } while (w & ZK_DEST_MORE);
+}
+
+static uint64_t pow7(uint64_t x) {
+    uint64_t x2 = zko_gl_mul(x, x), x3 = zko_gl_mul(x2, x), x4 = zko_gl_mul(x2, x2);
+    return zko_gl_mul(x3, x4);
+}
+
+static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
+    const zko_scope *s = c->s;
+    const uint32_t *prog = s->prog;
+    const uint64_t *RC = zko_poseidon_round_constants();
+    uint32_t inst = s->is_loop ? lane / s->limit : lane;
+    uint32_t pc = wb;
+    while (pc < we) {
+        uint32_t h = prog[pc++], op = h & 0xff, pa = (h >> 8) & 0xff, pb = h >> 16;
+        switch (op) {
+        case ZK_OP_CONST: { uint64_t v = ld(c, prog[pc++], lane, inst); st(c, prog, &pc, lane, v); } break;
+        case ZK_OP_INPUT: { uint32_t w = prog[pc++]; st(c, prog, &pc, lane, c->inputs[(size_t)w * c->n_lanes + lane]); } break;
+        case ZK_OP_FMA: {
+            uint64_t q = ld(c, prog[pc], lane, inst), l = ld(c, prog[pc + 1], lane, inst);
+            uint64_t a = ld(c, prog[pc + 2], lane, inst), b = ld(c, prog[pc + 3], lane, inst), cc = ld(c, prog[pc + 4], lane, inst);
+            pc += 5;
+            st(c, prog, &pc, lane, zko_gl_add(zko_gl_mul(q, zko_gl_mul(a, b)), zko_gl_mul(l, cc)));
+        } break;
+        case ZK_OP_LC4: {
+            uint64_t r = 0;
+            for (int i = 0; i < 4; ++i) r = zko_gl_add(r, zko_gl_mul(ld(c, prog[pc + i], lane, inst), ld(c, prog[pc + 4 + i], lane, inst)));
+            pc += 8;
+            st(c, prog, &pc, lane, r);
+        } break;
+        case ZK_OP_SELECT: {
+            uint64_t sel = ld(c, prog[pc], lane, inst), a = ld(c, prog[pc + 1], lane, inst), b = ld(c, prog[pc + 2], lane, inst);
+            pc += 3;
+            st(c, prog, &pc, lane, sel ? a : b);
+        } break;
+        case ZK_OP_ISZERO: {
+            uint64_t x = ld(c, prog[pc++], lane, inst);
+            st(c, prog, &pc, lane, x == 0);
+            st(c, prog, &pc, lane, zko_gl_inv(x));
+        } break;
+        case ZK_OP_UADD: {
+            uint64_t x = ld(c, prog[pc], lane, inst), y = ld(c, prog[pc + 1], lane, inst), ci = ld(c, prog[pc + 2], lane, inst);
+            pc += 3;
+            uint64_t sum = x + y + ci;
+            st(c, prog, &pc, lane, sum % (1ull << pa));
+            st(c, prog, &pc, lane, sum >> pa);
+        } break;
+        case ZK_OP_USUB: {
+            uint64_t x = ld(c, prog[pc], lane, inst), y = ld(c, prog[pc + 1], lane, inst), bi = ld(c, prog[pc + 2], lane, inst);
+            pc += 3;
+            int borrow = x < y + bi;
+            st(c, prog, &pc, lane, borrow ? x + (1ull << pa) - y - bi : x - y - bi);
+            st(c, prog, &pc, lane, (uint64_t)borrow);
+        } break;
+        case ZK_OP_DOT4: {
+            uint64_t r = 0;
+            for (int i = 0; i < 4; ++i) r = zko_gl_add(r, zko_gl_mul(ld(c, prog[pc + 2 * i], lane, inst), ld(c, prog[pc + 2 * i + 1], lane, inst)));
+            pc += 8;
+            st(c, prog, &pc, lane, r);
+        } break;
+        case ZK_OP_MATMUL12: {
+            uint64_t v[12];
+            for (int i = 0; i < 12; ++i) v[i] = ld(c, prog[pc + i], lane, inst);
+            pc += 12;
+            if (pa == 0) zko_poseidon2_mds_external(v); else zko_poseidon2_mds_inner(v);
+            for (int i = 0; i < 12; ++i) st(c, prog, &pc, lane, v[i]);
+        } break;
+        case ZK_OP_SPLIT: {
+            uint64_t x = ld(c, prog[pc++], lane, inst);
+            for (uint32_t i = 0; i < pa; ++i) {
+                st(c, prog, &pc, lane, i + 1 == pa ? x : x % (1ull << pb));
+                x >>= pb;
+            }
+        } break;
+        case ZK_OP_LOOKUP: {
+            uint32_t tid = prog[pc++];
+            const zk_table_desc *t = &s->tables[tid];
+            uint64_t key[3] = {0, 0, 0};
+            for (uint32_t i = 0; i < pa; ++i) key[i] = ld(c, prog[pc + i], lane, inst);
+            pc += pa;
+            uint32_t row = table_find(s, t, key);
+            uint32_t w = t->n_keys + t->n_vals;
+            for (uint32_t i = 0; i < pb; ++i)
+                st(c, prog, &pc, lane, row < t->n_rows ? s->table_words[t->word_off + (size_t)row * w + t->n_keys + i] : 0);
+            if (row < t->n_rows && c->mult) {
+#pragma omp atomic
+                c->mult[(size_t)inst * c->total_rows + t->mult_off + row] += 1;
+            }
+        } break;
+        case ZK_OP_POSEIDON2: {
+            uint64_t v[12];
+            for (int i = 0; i < 12; ++i) v[i] = ld(c, prog[pc + i], lane, inst);
+            pc += 12;
+            zko_poseidon2_permute(v);
+            for (int i = 0; i < 12; ++i) st(c, prog, &pc, lane, v[i]);
+        } break;
+        case ZK_OP_P2_ROUNDS: {
+            uint64_t v[12];
+            for (int i = 0; i < 12; ++i) v[i] = ld(c, prog[pc + i], lane, inst);
+            pc += 12;
+            zko_poseidon2_mds_external(v);
+            for (int i = 0; i < 12; ++i) st(c, prog, &pc, lane, v[i]);
+            for (int r = 0; r < 30; ++r) {
+                int full = r < 4 || r >= 26, n = full ? 12 : 1;
+                for (int i = 0; i < n; ++i) {
+                    uint64_t t = zko_gl_add(v[i], RC[12 * r + i]);
+                    uint64_t x2 = zko_gl_mul(t, t), x3 = zko_gl_mul(x2, t), x4 = zko_gl_mul(x2, x2), x7 = zko_gl_mul(x3, x4);
+                    st(c, prog, &pc, lane, t); st(c, prog, &pc, lane, x2); st(c, prog, &pc, lane, x3);
+                    st(c, prog, &pc, lane, x4); st(c, prog, &pc, lane, x7);
+                    v[i] = x7;
+                }
+                if (full) zko_poseidon2_mds_external(v); else zko_poseidon2_mds_inner(v);
+                for (int i = 0; i < 12; ++i) st(c, prog, &pc, lane, v[i]);
+            }
+            (void)pow7;
+        } break;
+        case ZK_OP_LOOP_LAST: {
+            uint32_t cell = prog[pc++];
+            st(c, prog, &pc, lane, c->loop_cells[(size_t)cell * c->loop_stride + (size_t)lane * c->loop_limit + c->loop_limit - 1]);
+        } break;
+        case ZK_OP_U32MULADD: {
+            uint64_t a = ld(c, prog[pc], lane, inst), b = ld(c, prog[pc + 1], lane, inst), cc = ld(c, prog[pc + 2], lane, inst), d = ld(c, prog[pc + 3], lane, inst);
+            pc += 4;
+            uint64_t r = a * b + cc + d;
+            st(c, prog, &pc, lane, r & 0xffffffffull);
+            st(c, prog, &pc, lane, r >> 32);
+        } break;
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
+/* Execute words [wb, we) of the scope program for every lane. */
+int zko_scope_run(const zko_scope *s, uint32_t wb, uint32_t we, uint64_t *cells, size_t stride, uint32_t n_lanes,
+                  const uint64_t *inputs, const uint64_t *outer_cells, size_t outer_stride, const uint64_t *loop_cells,
+                  size_t loop_stride, uint32_t loop_limit, uint32_t *mult, uint32_t total_rows) {
+    run_ctx c = {s, cells, stride, n_lanes, inputs, outer_cells, outer_stride, loop_cells, loop_stride, loop_limit, mult, total_rows};
+    int bad = 0;
+#pragma omp parallel for schedule(static)
+    for (long lane = 0; lane < (long)n_lanes; ++lane)
+        if (run_lane(&c, (uint32_t)lane, wb, we)) bad = 1;
+    return bad ? -1 : 0;
+}
+
+static const unsigned char GW[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6};
+
+/* Evaluate every gate relation + lookup tuple + copy pair. Returns the number of violated
+ * relations; *first_key = packed (lane<<32 | slot<<12 | j<<4 | rel) of the smallest one (gates),
+ * or ~0.  count_only_constraints (may be NULL) receives the number of relations evaluated. */
+uint64_t zko_scope_check(const zko_scope *s, const uint64_t *cells, size_t stride, uint32_t n_lanes,
+                         uint64_t *first_key, uint64_t *n_relations) {
+    uint64_t bad = 0, nrel = 0, first = ~0ull;
+    const size_t S = s->n_slots;
+#pragma omp parallel for schedule(static) reduction(+ : bad, nrel) reduction(min : first)
+    for (long lane_ = 0; lane_ < (long)n_lanes; ++lane_) {
+        uint32_t lane = (uint32_t)lane_;
+#define CELL(col) cells[((size_t)(col) * S + slot) * stride + lane]
+#define FAIL(j, rel) do { ++bad; uint64_t k_ = ((uint64_t)lane << 32) | ((uint64_t)slot << 12) | (((j) & 0xff) << 4) | ((rel) & 0xf); if (k_ < first) first = k_; } while (0)
+        for (uint32_t slot = 0; slot < s->n_slots; ++slot) {
+            const zk_row_desc *d = &s->rows[slot];
+            const uint64_t *k = s->rowconsts + d->const_off;
+            uint32_t w = GW[d->kind];
+            for (uint32_t j = 0; j < d->n_instances; ++j) {
+                uint32_t c0 = j * w;
+                switch (d->kind) {
+                case ZK_GATE_CONST: ++nrel; if (CELL(c0) != k[j]) FAIL(j, 0); break;
+                case ZK_GATE_BOOLEAN: { ++nrel; uint64_t v = CELL(c0); if (zko_gl_mul(v, v) != v) FAIL(j, 0); } break;
+                case ZK_GATE_FMA: {
+                    ++nrel;
+                    uint64_t r = zko_gl_add(zko_gl_mul(k[0], zko_gl_mul(CELL(c0), CELL(c0 + 1))), zko_gl_mul(k[1], CELL(c0 + 2)));
+                    if (zko_gl_sub(r, CELL(c0 + 3)) != 0) FAIL(j, 0);
+                } break;
+                case ZK_GATE_REDUCTION4: {
+                    ++nrel;
+                    uint64_t r = 0;
+                    for (int i = 0; i < 4; ++i) r = zko_gl_add(r, zko_gl_mul(k[i], CELL(c0 + i)));
+                    if (r != CELL(c0 + 4)) FAIL(j, 0);
+                } break;
+                case ZK_GATE_SELECT: {
+                    ++nrel;
+                    uint64_t a = CELL(c0), b = CELL(c0 + 1), sel = CELL(c0 + 2), r = CELL(c0 + 3);
+                    /* s*a + (1-s)*b - r */
+                    uint64_t e = zko_gl_add(zko_gl_mul(sel, a), zko_gl_mul(zko_gl_sub(1, sel), b));
+                    if (e != r) FAIL(j, 0);
+                } break;
+                case ZK_GATE_ZEROCHECK: {
+                    nrel += 2;
+                    uint64_t x = CELL(c0), aux = CELL(c0 + 1), flag = CELL(c0 + 2);
+                    if (zko_gl_add(zko_gl_mul(x, aux), flag) != 1) FAIL(j, 0);
+                    if (zko_gl_mul(x, flag) != 0) FAIL(j, 1);
+                } break;
+                case ZK_GATE_UINTX_ADD: {
+                    ++nrel;
+                    uint64_t lhs = zko_gl_add(zko_gl_add(CELL(c0), CELL(c0 + 1)), CELL(c0 + 2));
+                    uint64_t rhs = zko_gl_add(CELL(c0 + 3), zko_gl_mul(k[0], CELL(c0 + 4)));
+                    if (lhs != rhs) FAIL(j, 0);
+                } break;
+                case ZK_GATE_DOT4: {
+                    ++nrel;
+                    uint64_t r = 0;
+                    for (int i = 0; i < 4; ++i) r = zko_gl_add(r, zko_gl_mul(CELL(c0 + 2 * i), CELL(c0 + 2 * i + 1)));
+                    if (r != CELL(c0 + 8)) FAIL(j, 0);
+                } break;
+                case ZK_GATE_MATMUL12_EXT:
+                case ZK_GATE_MATMUL12_INT: {
+                    nrel += 12;
+                    uint64_t v[12];
+                    for (int i = 0; i < 12; ++i) v[i] = CELL(c0 + i);
+                    if (d->kind == ZK_GATE_MATMUL12_EXT) zko_poseidon2_mds_external(v); else zko_poseidon2_mds_inner(v);
+                    for (int i = 0; i < 12; ++i) if (v[i] != CELL(c0 + 12 + i)) FAIL(j, i);
+                } break;
+                case ZK_GATE_U32_FMA: {
+                    ++nrel;
+                    uint64_t lhs = zko_gl_add(zko_gl_add(zko_gl_mul(CELL(c0), CELL(c0 + 1)), CELL(c0 + 2)), CELL(c0 + 3));
+                    uint64_t rhs = zko_gl_add(CELL(c0 + 4), zko_gl_mul(CELL(c0 + 5), 1ull << 32));
+                    if (lhs != rhs) FAIL(j, 0);
+                } break;
+                default: break;
+                }
+            }
+            const zk_lookup_row_desc *lr = &s->lrows[slot];
+            if (lr->n_tuples) {
+                const zk_table_desc *t = &s->tables[lr->table];
+                uint32_t tw = t->n_keys + t->n_vals;
+                for (uint32_t u = 0; u < lr->n_tuples; ++u) {
+                    ++nrel;
+                    uint32_t c0 = s->n_copy_cols + u * s->lookup_width;
+                    uint64_t key[3] = {0, 0, 0};
+                    for (uint32_t i = 0; i < t->n_keys; ++i) key[i] = CELL(c0 + i);
+                    uint32_t row = table_find(s, t, key);
+                    int ok = row < t->n_rows;
+                    for (uint32_t i = 0; ok && i < t->n_vals; ++i)
+                        ok = s->table_words[t->word_off + (size_t)row * tw + t->n_keys + i] == CELL(c0 + t->n_keys + i);
+                    if (!ok) FAIL(0x80 | u, 15);
+                }
+            }
+        }
+        for (uint32_t i = 0; i < s->n_copies; ++i)
+            if (cells[(size_t)s->copies[i].cell * stride + lane] != cells[(size_t)s->copies[i].home * stride + lane]) {
+                ++bad;
+                uint64_t k_ = ((uint64_t)lane << 32) | 0xfffff000ull | (i & 0xfff);
+                if (k_ < first) first = k_;
+            }
+#undef CELL
+#undef FAIL
+    }
+    if (first_key) *first_key = first;
+    if (n_relations) *n_relations = nrel;
+    return bad;
+}
+
+/* cross-iteration / cross-scope copy constraints; returns number of violated links */
+uint64_t zko_links_check(const zko_scope *loop, const uint64_t *loop_cells, size_t loop_stride, uint32_t n_lanes,
+                         const uint64_t *outer_cells, size_t outer_stride) {
+    uint64_t bad = 0;
+    uint32_t limit = loop->limit;
+    for (uint32_t lane = 0; lane < n_lanes; ++lane) {
+        uint32_t inst = lane / limit, k = lane % limit;
+        for (uint32_t i = 0; i < loop->n_links; ++i) {
+            const zk_link *L = &loop->links[i];
+            uint64_t mine = loop_cells[(size_t)L->loop_cell * loop_stride + lane];
+            if (L->kind == ZK_LINK_CARRY) {
+                if (k > 0 && mine != loop_cells[(size_t)L->other_cell * loop_stride + lane - 1]) ++bad;
+            } else {
+                uint64_t o = outer_cells[(size_t)L->other_cell * outer_stride + inst];
+                if (L->kind == ZK_LINK_FIRST) { if (k == 0 && mine != o) ++bad; }
+                else if (L->kind == ZK_LINK_LAST) { if (k == limit - 1 && mine != o) ++bad; }
+                else if (mine != o) ++bad;
+            }
+        }
+    }
+    return bad;
+}
