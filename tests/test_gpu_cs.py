@@ -1,0 +1,195 @@
+"""-m gpu: the engine on a real MI355X through the C ABI — witness generation bit-exact against the
+CPU oracle interpreter (whole trace, every cell), check_if_satisfied agreeing with the oracle
+checker, commitments equal to the native restatement, fault injection reporting the failing place."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import zkgl
+from helpers import GOLD, LINK, G, P, Rec, load_fixture, new_cs, oracle_run, ram_cs, rand_fe, random_instances
+from oracle import ram_native as rn
+from oracle import zko
+from test_cs_host import all_ops_circuit
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_run(zk, cs, outer, loop, batch):
+    cs.set_batch(batch)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    cs.resolve()
+    return d_o, d_l
+
+
+def assert_trace_equal(cs, run):
+    assert np.array_equal(cs.trace(False), run.oc), "outer-scope trace differs from the oracle"
+    got = cs.trace(True)
+    assert got.shape == run.lc.shape or run.lc.shape[0] == 1
+    if got.size:
+        assert np.array_equal(got, run.lc), "loop-scope trace differs from the oracle"
+
+
+def test_ram_fixture_trace_bit_exact(zk):
+    u, s, limit = load_fixture()
+    cs = ram_cs(limit)
+    inst = rn.instance(u, s, limit, 1)
+    outer, loop = rn.pack_streams([inst], limit)
+    keep = gpu_run(zk, cs, outer, loop, 1)
+    run = oracle_run(cs, outer, loop, 1)
+    assert_trace_equal(cs, run)
+    ok, f = cs.check_if_satisfied()
+    assert ok, f
+    assert cs.public_inputs(0) == inst["commitment"]
+    gold = json.load(open(os.path.join(GOLD, "ram_commitments.json")))
+    assert cs.public_inputs(0) == [int(x, 16) for x in gold["fixture_limit16"]]
+    assert np.array_equal(cs.multiplicities(0), run.mult[:65536])
+    assert int(cs.multiplicities(0).sum()) == cs.stats()["lookups_per_instance"]
+    del keep
+
+
+def test_ram_batch_of_instances(zk):
+    limit, batch = 16, 37  # batch*limit = 592 lanes: not a multiple of the wave or the workgroup
+    cs = ram_cs(limit)
+    insts = random_instances(11, batch, 13, limit)
+    insts[3] = rn.instance([], [], limit, 0)                      # empty queue
+    rng = np.random.default_rng(5)
+    u, s, nd = rn.random_ram_witness(rng, limit)
+    insts[7] = rn.instance(u, s, limit, nd)                        # queue exactly fills the chunk
+    outer, loop = rn.pack_streams(insts, limit)
+    keep = gpu_run(zk, cs, outer, loop, batch)
+    run = oracle_run(cs, outer, loop, batch)
+    assert_trace_equal(cs, run)
+    assert run.check()[0] == 0
+    ok, f = cs.check_if_satisfied()
+    assert ok, f
+    for i in (0, 3, 7, batch - 1):
+        assert cs.public_inputs(i) == insts[i]["commitment"]
+        assert np.array_equal(cs.multiplicities(i), run.mult[i * 65536:(i + 1) * 65536])
+    del keep
+
+
+def test_ram_unsatisfied_witnesses_are_rejected_like_the_oracle(zk):
+    u, s, limit = load_fixture()
+    cs = ram_cs(limit)
+    good = rn.instance(u, s, limit, 1)
+    s_bad = [list(x) for x in s]; s_bad[1][5] ^= 4; s_bad[2][5] ^= 4
+    not_perm = rn.instance(u, s_bad, limit, 1)
+    not_sorted = rn.instance(u, [s[1], s[0], s[2]], limit, 1)
+    insts = [good, not_perm, good, not_sorted]
+    outer, loop = rn.pack_streams(insts, limit)
+    keep = gpu_run(zk, cs, outer, loop, 4)
+    run = oracle_run(cs, outer, loop, 4)
+    assert_trace_equal(cs, run)     # the witness is deterministic even when it does not satisfy
+    assert run.check()[0] > 0
+    ok, f = cs.check_if_satisfied()
+    assert not ok and f.instance == 1  # first failing instance
+    del keep
+
+
+def test_fault_injection_reports_place(zk):
+    """flip one cell => first failing (scope, instance, iteration, slot) is reported"""
+    limit, batch = 8, 3
+    cs = ram_cs(limit)
+    insts = random_instances(3, batch, 6, limit)
+    outer, loop = rn.pack_streams(insts, limit)
+    keep = gpu_run(zk, cs, outer, loop, batch)
+    assert cs.check_if_satisfied()[0]
+    st = cs.stats()
+    n_slots = st["loop_slots"]
+    tr = cs.trace(True)
+    # pick a populated trace cell in the loop scope: column 2, slot 5, lane of (instance 1, iteration 4)
+    cell, lane = 2 * n_slots + 5, 1 * limit + 4
+    old = int(tr[cell, lane])
+    cs.write_cell(True, cell, lane, (old + 1) % P)
+    ok, f = cs.check_if_satisfied()
+    assert not ok and (f.scope, f.instance, f.iteration) == (1, 1, 4)
+    cs.write_cell(True, cell, lane, old)
+    assert cs.check_if_satisfied()[0]
+    # outer scope
+    tro = cs.trace(False)
+    cell_o = 1 * st["outer_slots"] + 3
+    old = int(tro[cell_o, 2])
+    cs.write_cell(False, cell_o, 2, old ^ 1)
+    ok, f = cs.check_if_satisfied()
+    assert not ok and (f.scope, f.instance) == (0, 2)
+    cs.write_cell(False, cell_o, 2, old)
+    # carried-state seed tampering is caught by the link (copy-constraint) check
+    loop_bad = loop.copy(); loop_bad[27, 2 * limit + 3] ^= 1   # lhs accumulator entering iteration 3 of instance 2
+    d_l = zk.DeviceBuffer.from_numpy(loop_bad)
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    cs.resolve()
+    ok, f = cs.check_if_satisfied()
+    assert not ok and f.instance == 2
+    del keep
+
+
+def test_all_ops_circuit_gpu_equals_oracle(zk):
+    limit, batch = 4, 130
+    rng = np.random.default_rng(17)
+    cs = new_cs()
+    n_outer, n_loop = all_ops_circuit(cs, limit)
+    cs.pad_and_shrink()
+    outer = np.zeros((n_outer, batch), dtype=np.uint64)
+    for i in range(batch):
+        a, b, c = rand_fe(rng, 3)
+        x32, y32 = int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32))
+        if i == 0: x32, y32 = 0xFFFFFFFF, 0xFFFFFFFF
+        if i == 1: x32, y32 = 0, 0xFFFFFFFF
+        if i == 2: a, b, c = 0, P - 1, 1
+        outer[:, i] = [a, b, c, x32, y32, int(rng.integers(0, 16)), int(rng.integers(0, 16)), int(rng.integers(0, 50)) * 7 + 3, i & 1]
+    loop = np.zeros((n_loop, batch * limit), dtype=np.uint64)
+    # acc0 via a first oracle pass, then the native recurrence for the carried state
+    pre = zko.CircuitRun(cs.export(False), cs.export(True), batch, 306)
+    pre.resolve(outer, loop)
+    sc = zko.Scope(cs.export(True))
+    links = sc.words[-4 * sc.n_links:].reshape(-1, 4)
+    first = [l for l in links if l[0] == LINK["FIRST"]][0]
+    for i in range(batch):
+        acc, a = int(pre.oc[first[2], i]), int(outer[0, i])
+        for k in range(limit):
+            t = 0 if k == 1 else rand_fe(rng, 1)[0]
+            loop[:, i * limit + k] = [acc, t, int(rng.integers(0, 16)), int(rng.integers(0, 16))]
+            acc = (acc * t + a) % P
+    keep = gpu_run(zk, cs, outer, loop, batch)
+    run = oracle_run(cs, outer, loop, batch, 306)
+    assert_trace_equal(cs, run)
+    assert run.check()[0] == 0
+    ok, f = cs.check_if_satisfied()
+    assert ok, f
+    for i in (0, 1, batch - 1):
+        assert np.array_equal(cs.multiplicities(i), run.mult[i * 306:(i + 1) * 306])
+    del keep
+
+
+def test_lookup_absent_key_gpu(zk):
+    cs = new_cs()
+    rows = np.array([[k * 7 + 3, k] for k in range(50)], dtype=np.uint64)
+    t = cs.add_lookup_table(5, 1, 1, rows)
+    key = cs.input(0)
+    cs.perform_lookup(t, [key], 1)
+    cs.pad_and_shrink()
+    keys = np.array([[10, 11, 3 + 49 * 7, 3 + 50 * 7, P - 1]], dtype=np.uint64)
+    cs.set_batch(5)
+    d = zk.DeviceBuffer.from_numpy(keys)
+    cs.bind_inputs(False, d, 1)
+    cs.resolve()
+    ok, f = cs.check_if_satisfied()
+    assert not ok and f.instance == 1 and f.kind == 0x100
+
+
+def test_resolve_is_repeatable_and_timed(zk):
+    limit, batch = 16, 8
+    cs = ram_cs(limit)
+    insts = random_instances(23, batch, 16, limit)
+    outer, loop = rn.pack_streams(insts, limit)
+    keep = gpu_run(zk, cs, outer, loop, batch)
+    t1 = cs.trace(True).copy()
+    cs.resolve()
+    assert np.array_equal(cs.trace(True), t1)
+    assert cs.last_ms(0) > 0 and cs.last_ms(1) > 0
+    assert cs.check_if_satisfied()[0] and cs.last_ms(2) > 0
+    del keep
