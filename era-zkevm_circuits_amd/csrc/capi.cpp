@@ -268,6 +268,10 @@ int zk_cs_resolve(zk_cs* cs, void* stream) {
     NEED(cs); NEED_INIT();
     return guard([&] { cs->cs->resolve(stream); });
 }
+int zk_cs_seed_carried_inputs(zk_cs* cs, uint64_t* dev_loop_inputs_rw, void* stream) {
+    NEED(cs); NEED_INIT();
+    return guard([&] { cs->cs->seed_carried_inputs(dev_loop_inputs_rw, stream); });
+}
 int zk_cs_check_satisfied(zk_cs* cs, void* stream, zk_failure* first) {
     NEED(cs); NEED_INIT();
     int result = ZK_OK;

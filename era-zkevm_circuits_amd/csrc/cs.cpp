@@ -62,6 +62,7 @@ CS::~CS() {
     if (d_table_words_) hipFree(d_table_words_);
     if (d_mult_) hipFree(d_mult_);
     if (d_links_) hipFree(d_links_);
+    if (d_carries_) hipFree(d_carries_);
     if (d_fail_) hipFree(d_fail_);
     for (auto& e : ev_)
         if (e) hipEventDestroy((hipEvent_t)e);
@@ -201,6 +202,7 @@ zk_var CS::input(uint32_t word) {
     OpRec op{ZK_OP_INPUT, 0, 0, {{Operand::RAW, word}}, {var_index(v)}};
     s.ops.push_back(std::move(op));
     s.n_input_words = std::max(s.n_input_words, word + 1);
+    s.input_word[var_index(v)] = word;
     return v;
 }
 
@@ -482,6 +484,20 @@ void CS::finalize() {
     uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
     if (!loop_done_) rows = outer_.n_slots;
     if (rows > max_trace_len_) throw ZkError(ZK_ERR_CAPACITY, "trace rows exceed max_trace_len");
+    // carried input words (for the sequential seeding mode): CARRY link whose `in` side is an INPUT
+    carries_.clear();
+    for (auto& l : links_raw_) {
+        if (l.kind != ZK_LINK_CARRY) continue;
+        auto it = loop_.input_word.find(l.loop_cell);
+        if (it == loop_.input_word.end()) continue;  // not stream-fed: nothing to seed
+        Carry c{it->second, loop_.var_cells[l.other_cell][0], 0, 0};
+        for (auto& f : links_raw_)
+            if (f.kind == ZK_LINK_FIRST && f.loop_cell == l.loop_cell) {
+                c.first_outer_cell = outer_.var_cells[f.other_cell][0];
+                c.has_first = 1;
+            }
+        carries_.push_back(c);
+    }
     // links: vars -> home cells
     links_.clear();
     for (auto& l : links_raw_) {
@@ -521,6 +537,7 @@ void CS::ensure_uploaded() {
     d_tables_ = upload(tdesc_host_);
     d_table_words_ = upload(table_words_host_);
     d_links_ = upload(links_);
+    d_carries_ = (void*)upload(carries_);
     hip_check(hipMalloc((void**)&d_fail_, 8 * sizeof(unsigned long long)), "hipMalloc fail words");
     for (auto& e : ev_) {
         hipEvent_t he;
@@ -572,6 +589,22 @@ static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Sco
     a.tables = tables; a.table_words = words; a.mult = mult; a.total_table_rows = total_rows;
     a.loop_cells = loop.d_cells; a.loop_stride = loop.stride; a.loop_limit = limit;
     return a;
+}
+
+void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {
+    if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "seed_carried_inputs before set_batch");
+    if (!limit_) return;
+    if (outer_.n_input_words && !outer_.d_inputs) throw ZkError(ZK_ERR_INVALID, "outer input stream not bound");
+    if (!dev_loop_inputs_rw || loop_.d_inputs != dev_loop_inputs_rw)
+        throw ZkError(ZK_ERR_INVALID, "seed_carried_inputs: pass the (writable) buffer bound as the loop input stream");
+    hipStream_t st = (hipStream_t)stream;
+    hip_check(hipMemsetAsync(d_mult_, 0, std::max<size_t>((size_t)batch_ * total_table_rows_ * 4, 4), st), "memset mult");
+    auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
+    auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
+    dev_check(zkdev::launch_witness(oa, 0, outer_.pre_words, st));
+    dev_check(zkdev::launch_witness_seq(la, (const zkdev::CarryArgs*)d_carries_, (uint32_t)carries_.size(), dev_loop_inputs_rw,
+                                        batch_, st));
+    hip_check(hipStreamSynchronize(st), "seed sync");
 }
 
 void CS::resolve(void* stream) {
@@ -736,7 +769,7 @@ float CS::last_ms(int which) const { return (which >= 0 && which < 5) ? ms_[whic
 
 // Serialised scope for the CPU oracle:
 // [magic, is_loop, n_cells, n_trace_cells, n_slots, n_copy_cols, lookup_width, n_input_words, limit,
-//  pre_words, n_prog, n_consts, n_rows, n_rowconsts, n_lrows, n_copies, n_tables, n_table_words, n_links]
+//  pre_words, n_prog, n_consts, n_rows, n_rowconsts, n_lrows, n_copies, n_tables, n_table_words, n_links, n_carries]
 // followed by the sections in that order (u64 sections as lo,hi u32 pairs).
 std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
     const Scope& s = loop_scope ? loop_ : outer_;
@@ -744,12 +777,13 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
     auto p64 = [&](uint64_t v) { o.push_back((uint32_t)v); o.push_back((uint32_t)(v >> 32)); };
     std::vector<uint64_t> words;
     for (auto& t : tables_) words.insert(words.end(), t.rows.begin(), t.rows.end());
-    uint32_t hdr[19] = {0x5a4b4731u, s.is_loop ? 1u : 0u, s.n_cells, s.n_trace_cells, s.n_slots,
+    uint32_t hdr[20] = {0x5a4b4732u, s.is_loop ? 1u : 0u, s.n_cells, s.n_trace_cells, s.n_slots,
                         geo_.num_columns_under_copy_permutation, lookup_width_, s.n_input_words, limit_, s.pre_words,
                         (uint32_t)s.prog.size(), (uint32_t)s.const_pool.size(), (uint32_t)s.rows.size(),
                         (uint32_t)s.rowconsts.size(), (uint32_t)s.lrows.size(), (uint32_t)s.copies.size(),
-                        (uint32_t)tables_.size() + 1, (uint32_t)words.size(), (uint32_t)(loop_scope ? links_.size() : 0)};
-    o.insert(o.end(), hdr, hdr + 19);
+                        (uint32_t)tables_.size() + 1, (uint32_t)words.size(), (uint32_t)(loop_scope ? links_.size() : 0),
+                        (uint32_t)(loop_scope ? carries_.size() : 0)};
+    o.insert(o.end(), hdr, hdr + 20);
     o.insert(o.end(), s.prog.begin(), s.prog.end());
     for (uint64_t c : s.const_pool) p64(c);
     for (auto& r : s.rows) { o.push_back(r.kind); o.push_back(r.n_instances); o.push_back(r.const_off); o.push_back(r.n_consts); }
@@ -764,6 +798,8 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
     for (uint64_t w : words) p64(w);
     if (loop_scope)
         for (auto& l : links_) { o.push_back(l.kind); o.push_back(l.loop_cell); o.push_back(l.other_cell); o.push_back(0); }
+    if (loop_scope)
+        for (auto& c : carries_) { o.push_back(c.word); o.push_back(c.out_cell); o.push_back(c.first_outer_cell); o.push_back(c.has_first); }
     return o;
 }
 

@@ -69,6 +69,7 @@ struct Scope {
     std::vector<uint64_t> const_pool;
     std::unordered_map<uint64_t, uint32_t> const_pool_idx;
     uint32_t n_input_words = 0;
+    std::unordered_map<uint32_t, uint32_t> input_word;  // var index -> input stream word (ZK_OP_INPUT)
     size_t pre_ops = SIZE_MAX;  // outer scope: ops recorded before loop_begin
 
     // ---- filled by finalize ----
@@ -131,6 +132,8 @@ class CS {
     void set_batch(uint32_t n_instances);
     void bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words);
     void resolve(void* stream);
+    // sequential seeding of the carried input words (generic, slow): see kernels_engine.hpp k_witness_seq
+    void seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream);
     int check_satisfied(void* stream, zk_failure* first);
     uint64_t read_var(zk_var v, uint32_t instance, uint32_t iteration);
     void write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value);
@@ -186,6 +189,9 @@ class CS {
     bool uploaded_ = false;
     uint32_t* d_mult_ = nullptr;
     zk_link* d_links_ = nullptr;
+    struct Carry { uint32_t word, out_cell, first_outer_cell, has_first; };
+    std::vector<Carry> carries_;
+    void* d_carries_ = nullptr;
     unsigned long long* d_fail_ = nullptr;
     void* ev_[8] = {nullptr};
     float ms_[5] = {0, 0, 0, 0, 0};

@@ -33,6 +33,9 @@ int launch_memory_query_encode(const uint64_t* q, size_t n, uint64_t* enc, void*
 int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* ch, size_t enc_len, size_t n,
                          uint64_t init, uint64_t* acc, uint64_t* scratch, void* stream);
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, void* stream);
+struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // mirrors zke::CarryDev
+int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
+                       uint32_t n_instances, void* stream);
 int launch_check_gates(const CheckArgs& cd, void* stream);
 int launch_check_copies(const uint64_t* cells, uint64_t stride, uint32_t n_lanes, const zk_copy_pair* pairs,
                         uint32_t n_pairs, unsigned long long* fail, void* stream);

@@ -75,13 +75,14 @@ __device__ __forceinline__ uint32_t table_find(const zk_table_desc& t, const uin
 // Witness interpreter.  phase_begin/phase_end delimit the word range to execute (outer scope:
 // pre phase before the loop, post phase after it).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_witness(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
-    const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
-    if (lane >= sc.n_lanes) return;
+// Executes words [word_begin, word_end) of the scope program for one lane.  Every lane of a wave is
+// at the same program position (also in the sequential seeding mode, where the wave's lanes are
+// different instances at the same iteration), so op words are broadcast through readfirstlane.
+__device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane, const uint32_t inst,
+                                         uint32_t word_begin, uint32_t word_end) {
     const uint32_t* __restrict__ prog = sc.prog;
     uint64_t* __restrict__ cells = sc.cells;
     const uint64_t stride = sc.stride;
-    const uint32_t inst = sc.is_loop ? lane / sc.limit : lane;
 
     auto ld = [&](uint32_t w) -> uint64_t {
         const uint32_t kind = w & ZK_OPERAND_KIND_MASK, idx = w & ZK_OPERAND_IDX_MASK;
@@ -244,6 +245,39 @@ __global__ __launch_bounds__(TPB) void k_witness(ScopeDev sc, uint32_t word_begi
         default:
             return;  // malformed program: host validates before upload
         }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_witness(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
+    const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if (lane >= sc.n_lanes) return;
+    run_lane(sc, lane, sc.is_loop ? lane / sc.limit : lane, word_begin, word_end);
+}
+
+// Sequential seeding mode (generic, slow): thread == instance, iterations in order.  Before
+// iteration k the carried input words are filled from iteration k-1's outputs (k == 0: from the
+// outer scope), so a host that only has the raw witness (what the reference's closures consume)
+// needs no precomputed per-iteration state.  The parallel mode afterwards reproduces the same
+// trace from the seeded stream.
+struct CarryDev { uint32_t word, out_cell, first_outer_cell, has_first; };
+__global__ __launch_bounds__(64) void k_witness_seq(ScopeDev sc, const CarryDev* carries, uint32_t n_carries,
+                                                    uint64_t* inputs_rw, uint32_t n_instances) {
+    const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= n_instances) return;
+    for (uint32_t k = 0; k < sc.limit; ++k) {
+        const uint32_t lane = inst * sc.limit + k;
+        for (uint32_t c = 0; c < n_carries; ++c) {
+            const CarryDev cd = carries[c];
+            if (k == 0) {
+                if (cd.has_first)
+                    inputs_rw[(size_t)cd.word * sc.n_lanes + lane] = sc.outer_cells[(size_t)cd.first_outer_cell * sc.outer_stride + inst];
+            } else {
+                inputs_rw[(size_t)cd.word * sc.n_lanes + lane] = sc.cells[(size_t)cd.out_cell * sc.stride + lane - 1];
+            }
+        }
+        __threadfence();
+        run_lane(sc, lane, inst, 0, sc.n_words);
+        __threadfence();
     }
 }
 

@@ -100,6 +100,15 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
     return LAUNCH_CHECK("k_witness");
 }
 
+int launch_witness_seq(const ScopeArgs& sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
+                       uint32_t n_instances, void* stream) {
+    if (n_instances == 0 || sc.limit == 0) return 0;
+    static_assert(sizeof(CarryArgs) == sizeof(zke::CarryDev), "CarryArgs layout");
+    zke::k_witness_seq<<<grid_for(n_instances, 64), 64, 0, (hipStream_t)stream>>>(
+        to_dev(sc), reinterpret_cast<const zke::CarryDev*>(d_carries), n_carries, inputs_rw, n_instances);
+    return LAUNCH_CHECK("k_witness_seq");
+}
+
 int launch_check_gates(const CheckArgs& a, void* stream) {
     if (a.n_lanes == 0 || a.n_slots == 0) return 0;
     zke::CheckDev d;

@@ -375,6 +375,10 @@ class ConstraintSystem:
     def resolve(self, stream=None):
         _check(lib().zk_cs_resolve(self._h, _ptr(stream)))
 
+    def seed_carried_inputs(self, dev_loop_inputs, stream=None):
+        """fill the loop-carried words of the bound loop input stream sequentially on the GPU"""
+        _check(lib().zk_cs_seed_carried_inputs(self._h, _ptr(dev_loop_inputs), _ptr(stream)))
+
     def check_if_satisfied(self, stream=None):
         """Returns (True, None) or (False, Failure)."""
         f = _Failure()

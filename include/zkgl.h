@@ -152,6 +152,11 @@ int zk_cs_set_batch(zk_cs *cs, uint32_t n_instances); /* allocates device trace 
 /* input streams: outer scope words[w*B + inst]; loop scope words[w*(B*limit) + inst*limit + k]; device ptrs */
 int zk_cs_bind_inputs(zk_cs *cs, int loop_scope, const uint64_t *dev_words, uint32_t n_words);
 int zk_cs_resolve(zk_cs *cs, void *stream);          /* witness generation */
+/* Generic sequential seeding: fills the loop-carried words of the bound (writable) loop input stream
+ * from the circuit's own recurrence, one iteration after another, lane == instance.  Needed only when
+ * the host has the raw witness but not the per-iteration state (the reference's closures get exactly
+ * that); hosts that already know the per-cycle state (e.g. VmLocalState per cycle) skip it. */
+int zk_cs_seed_carried_inputs(zk_cs *cs, uint64_t *dev_loop_inputs_rw, void *stream);
 typedef struct zk_failure { uint32_t scope, instance, iteration, slot, kind, relation; } zk_failure;
 /* check_if_satisfied: 0 satisfied; ZK_ERR_UNSATISFIED + first failure otherwise */
 int zk_cs_check_satisfied(zk_cs *cs, void *stream, zk_failure *first);

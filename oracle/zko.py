@@ -44,6 +44,8 @@ def lib():
         L.zko_scope_run.restype = C.c_int
         L.zko_scope_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.zko_scope_run_seq.restype = C.c_int
+        L.zko_scope_run_seq.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]
         L.zko_scope_check.restype = C.c_uint64
         L.zko_scope_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]
         L.zko_links_check.restype = C.c_uint64
@@ -218,6 +220,19 @@ class CircuitRun:
         rc = L.zko_scope_run(self.outer.h, self.outer.pre_words, self.outer.n_prog, _p(self.oc), self.so, self.B, _p(oi),
                              None, 0, _p(self.lc), self.lc.shape[1], self.limit, mult, self.total_rows)
         assert rc == 0
+
+    def seed(self, outer_inputs: np.ndarray, loop_inputs: np.ndarray) -> np.ndarray:
+        """sequential seeding: returns loop_inputs with the carried words filled in (oracle twin of
+        zk_cs_seed_carried_inputs)"""
+        L = lib()
+        oi = np.ascontiguousarray(outer_inputs, dtype=np.uint64)
+        li = np.ascontiguousarray(loop_inputs, dtype=np.uint64).copy()
+        rc = L.zko_scope_run(self.outer.h, 0, self.outer.pre_words, _p(self.oc), self.so, self.B, _p(oi), None, 0,
+                             _p(self.lc), self.lc.shape[1], self.limit, None, 0)
+        assert rc == 0
+        rc = L.zko_scope_run_seq(self.loop.h, _p(self.lc), self.lc.shape[1], self.B, _p(li), _p(self.oc), self.so)
+        assert rc == 0
+        return li
 
     def check(self):
         """-> (n_violations, n_relations_evaluated)"""

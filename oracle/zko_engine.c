@@ -13,7 +13,8 @@
 
 typedef struct zko_scope {
     uint32_t is_loop, n_cells, n_trace_cells, n_slots, n_copy_cols, lookup_width, n_input_words, limit, pre_words;
-    uint32_t n_prog, n_consts, n_rows, n_rowconsts, n_lrows, n_copies, n_tables, n_table_words, n_links;
+    uint32_t n_prog, n_consts, n_rows, n_rowconsts, n_lrows, n_copies, n_tables, n_table_words, n_links, n_carries;
+    uint32_t *carries; /* 4 words each: input word, out cell, first outer cell, has_first */
     uint32_t *prog;
     uint64_t *consts;
     zk_row_desc *rows;
@@ -30,17 +31,17 @@ static uint64_t rd64(const uint32_t *p) { return (uint64_t)p[0] | ((uint64_t)p[1
 void zko_scope_free(zko_scope *s) {
     if (!s) return;
     free(s->prog); free(s->consts); free(s->rows); free(s->rowconsts); free(s->lrows); free(s->copies);
-    free(s->tables); free(s->table_words); free(s->links); free(s);
+    free(s->tables); free(s->table_words); free(s->links); free(s->carries); free(s);
 }
 
 zko_scope *zko_scope_parse(const uint32_t *w, size_t n) {
-    if (n < 19 || w[0] != 0x5a4b4731u) return NULL;
+    if (n < 20 || w[0] != 0x5a4b4732u) return NULL;
     zko_scope *s = calloc(1, sizeof *s);
     s->is_loop = w[1]; s->n_cells = w[2]; s->n_trace_cells = w[3]; s->n_slots = w[4]; s->n_copy_cols = w[5];
     s->lookup_width = w[6]; s->n_input_words = w[7]; s->limit = w[8]; s->pre_words = w[9]; s->n_prog = w[10];
     s->n_consts = w[11]; s->n_rows = w[12]; s->n_rowconsts = w[13]; s->n_lrows = w[14]; s->n_copies = w[15];
-    s->n_tables = w[16]; s->n_table_words = w[17]; s->n_links = w[18];
-    const uint32_t *p = w + 19;
+    s->n_tables = w[16]; s->n_table_words = w[17]; s->n_links = w[18]; s->n_carries = w[19];
+    const uint32_t *p = w + 20;
 #define TAKE(dst, type, count, words_each, conv)                                   \
     do {                                                                          \
         s->dst = malloc(sizeof(type) * ((count) ? (count) : 1));                  \
@@ -58,6 +59,8 @@ zko_scope *zko_scope_parse(const uint32_t *w, size_t n) {
           s->tables[i].key_shift[1] = p[7], s->tables[i].key_shift[2] = p[8]));
     TAKE(table_words, uint64_t, s->n_table_words, 2, s->table_words[i] = rd64(p));
     TAKE(links, zk_link, s->n_links, 4, (s->links[i].kind = p[0], s->links[i].loop_cell = p[1], s->links[i].other_cell = p[2], s->links[i].pad = 0));
+    s->carries = malloc(sizeof(uint32_t) * 4 * (s->n_carries ? s->n_carries : 1));
+    for (uint32_t i = 0; i < 4 * s->n_carries; ++i) s->carries[i] = *p++;
 #undef TAKE
     if ((size_t)(p - w) != n) { zko_scope_free(s); return NULL; }
     return s;
@@ -69,6 +72,7 @@ uint32_t zko_scope_field(const zko_scope *s, int which) {
     case 0: return s->is_loop; case 1: return s->n_cells; case 2: return s->n_trace_cells; case 3: return s->n_slots;
     case 4: return s->n_input_words; case 5: return s->limit; case 6: return s->pre_words; case 7: return s->n_prog;
     case 8: return s->n_copies; case 9: return s->n_links; case 10: return s->n_copy_cols; case 11: return s->lookup_width;
+    case 12: return s->n_carries;
     default: return 0;
     }
 }
@@ -257,6 +261,30 @@ int zko_scope_run(const zko_scope *s, uint32_t wb, uint32_t we, uint64_t *cells,
     for (long lane = 0; lane < (long)n_lanes; ++lane)
         if (run_lane(&c, (uint32_t)lane, wb, we)) bad = 1;
     return bad ? -1 : 0;
+}
+
+/* Sequential seeding (counterpart of k_witness_seq): iteration by iteration, carried input words
+ * are taken from the previous iteration's outputs (k == 0: from the outer scope).  inputs is
+ * modified in place. */
+int zko_scope_run_seq(const zko_scope *s, uint64_t *cells, size_t stride, uint32_t n_instances, uint64_t *inputs,
+                      const uint64_t *outer_cells, size_t outer_stride) {
+    uint32_t n_lanes = n_instances * s->limit;
+    run_ctx c = {s, cells, stride, n_lanes, inputs, outer_cells, outer_stride, NULL, 0, 0, NULL, 0};
+    for (uint32_t k = 0; k < s->limit; ++k) {
+        int bad = 0;
+#pragma omp parallel for schedule(static)
+        for (long inst = 0; inst < (long)n_instances; ++inst) {
+            uint32_t lane = (uint32_t)inst * s->limit + k;
+            for (uint32_t i = 0; i < s->n_carries; ++i) {
+                const uint32_t *cr = s->carries + 4 * i;
+                if (k == 0) { if (cr[3]) inputs[(size_t)cr[0] * n_lanes + lane] = outer_cells[(size_t)cr[2] * outer_stride + inst]; }
+                else inputs[(size_t)cr[0] * n_lanes + lane] = cells[(size_t)cr[1] * stride + lane - 1];
+            }
+            if (run_lane(&c, lane, 0, s->n_prog)) bad = 1;
+        }
+        if (bad) return -1;
+    }
+    return 0;
 }
 
 static const unsigned char GW[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6};

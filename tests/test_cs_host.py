@@ -73,9 +73,9 @@ def all_ops_circuit(cs, limit=4):
 
 
 def all_ops_inputs(rng, batch, limit, n_outer, n_loop):
+    """raw (non-carried) witness words; loop word 0 (the carried accumulator) is left for seeding"""
     outer = np.zeros((n_outer, batch), dtype=np.uint64)
     loop = np.zeros((n_loop, batch * limit), dtype=np.uint64)
-    expected_pub = []
     for i in range(batch):
         a, b, c = rand_fe(rng, 3)
         x32, y32 = int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32))
@@ -83,57 +83,42 @@ def all_ops_inputs(rng, batch, limit, n_outer, n_loop):
             x32, y32 = 0xFFFFFFFF, 0xFFFFFFFF
         if i == 1:
             x32, y32 = 0, 0xFFFFFFFF
+        if i == 2:
+            a, b, c = 0, P - 1, 1
         outer[:, i] = [a, b, c, x32, y32, int(rng.integers(0, 16)), int(rng.integers(0, 16)), int(rng.integers(0, 50)) * 7 + 3, i & 1]
-    return outer, loop, expected_pub
-
-
-def fill_all_ops_loop(run_outer_cells_reader, cs, outer, loop, rng, batch, limit, acc0_var_cell):
-    pass
-
-
-def run_all_ops_on_oracle(limit=4, batch=3, seed=5):
-    """records the all-ops circuit, derives carried-state inputs natively, runs the oracle"""
-    rng = np.random.default_rng(seed)
-    cs = new_cs()
-    n_outer, n_loop = all_ops_circuit(cs, limit)
-    cs.pad_and_shrink()
-    outer, loop, _ = all_ops_inputs(rng, batch, limit, n_outer, n_loop)
-    # pass 1: outer pre-phase on the oracle gives acc0; the loop recurrence is then native python
-    run = zko.CircuitRun(cs.export(False), cs.export(True), batch, 256 + 50)
-    run.resolve(outer, loop)
-    # find acc0: the FIRST link's outer cell
-    words = cs.export(True)
-    sc = zko.Scope(words)
-    return cs, run, outer, loop, rng, sc
+        for k in range(limit):
+            t = 0 if k == 1 else rand_fe(rng, 1)[0]
+            loop[1:, i * limit + k] = [t, int(rng.integers(0, 16)), int(rng.integers(0, 16))]
+    return outer, loop
 
 
 def test_all_ops_circuit_on_oracle():
     limit, batch = 4, 3
-    cs, run, outer, loop, rng, sc = run_all_ops_on_oracle(limit, batch)
-    # carried state: acc_in[k+1] = acc_in[k]*t[k] + a ; recover acc0 from the outer trace via a link-free path:
-    # run with zero loop inputs, read acc0 through the FIRST link mismatch location is overkill — instead recompute
-    # natively from the oracle's outer cells (cell of acc0 = other_cell of link kind FIRST in the export tail).
-    links = sc.words[-4 * sc.n_links:].reshape(-1, 4)
-    first = [l for l in links if l[0] == LINK["FIRST"]][0]
-    acc0 = [int(run.oc[first[2], i]) for i in range(batch)]
+    rng = np.random.default_rng(5)
+    cs = new_cs()
+    n_outer, n_loop = all_ops_circuit(cs, limit)
+    cs.pad_and_shrink()
+    outer, loop_raw = all_ops_inputs(rng, batch, limit, n_outer, n_loop)
+    run = zko.CircuitRun(cs.export(False), cs.export(True), batch, 256 + 50)
+    # generic sequential seeding fills the carried accumulator: acc[k+1] = acc[k]*t[k] + a
+    loop = run.seed(outer, loop_raw)
     for i in range(batch):
-        acc = acc0[i]
         a = int(outer[0, i])
-        for k in range(limit):
-            t = 0 if k == 1 else rand_fe(rng, 1)[0]
-            lane = i * limit + k
-            loop[:, lane] = [acc, t, int(rng.integers(0, 16)), int(rng.integers(0, 16))]
-            acc = (acc * t + a) % P
+        for k in range(limit - 1):
+            acc, t = int(loop[0, i * limit + k]), int(loop[1, i * limit + k])
+            assert int(loop[0, i * limit + k + 1]) == (acc * t + a) % P
+    assert np.array_equal(loop[1:], loop_raw[1:])
     run2 = oracle_run(cs, outer, loop, batch, 256 + 50)
     bad, nrel = run2.check()
     assert bad == 0
     assert nrel == cs.stats()["constraints_per_instance"] * batch
+    assert np.array_equal(run2.lc, run.lc)  # parallel mode reproduces the sequential trace
     # multiplicities: every lookup counted once
     assert int(run2.mult.sum()) == cs.stats()["lookups_per_instance"] * batch
-    # a wrong carried value breaks exactly the link check
+    # a wrong carried value breaks the link check; the unseeded stream does as well
     loop_bad = loop.copy(); loop_bad[0, 2] ^= 1
-    run3 = oracle_run(cs, outer, loop_bad, batch, 256 + 50)
-    assert run3.check()[0] > 0
+    assert oracle_run(cs, outer, loop_bad, batch, 256 + 50).check()[0] > 0
+    assert oracle_run(cs, outer, loop_raw, batch, 256 + 50).check()[0] > 0
 
 
 def test_lookup_of_absent_key_is_unsatisfied():

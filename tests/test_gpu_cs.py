@@ -11,7 +11,7 @@ import zkgl
 from helpers import GOLD, LINK, G, P, Rec, load_fixture, new_cs, oracle_run, ram_cs, rand_fe, random_instances
 from oracle import ram_native as rn
 from oracle import zko
-from test_cs_host import all_ops_circuit
+from test_cs_host import all_ops_circuit, all_ops_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -128,33 +128,22 @@ def test_fault_injection_reports_place(zk):
 
 
 def test_all_ops_circuit_gpu_equals_oracle(zk):
+    """every op / gate kind; carried state seeded by the GPU's sequential mode == the oracle's"""
     limit, batch = 4, 130
     rng = np.random.default_rng(17)
     cs = new_cs()
     n_outer, n_loop = all_ops_circuit(cs, limit)
     cs.pad_and_shrink()
-    outer = np.zeros((n_outer, batch), dtype=np.uint64)
-    for i in range(batch):
-        a, b, c = rand_fe(rng, 3)
-        x32, y32 = int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32))
-        if i == 0: x32, y32 = 0xFFFFFFFF, 0xFFFFFFFF
-        if i == 1: x32, y32 = 0, 0xFFFFFFFF
-        if i == 2: a, b, c = 0, P - 1, 1
-        outer[:, i] = [a, b, c, x32, y32, int(rng.integers(0, 16)), int(rng.integers(0, 16)), int(rng.integers(0, 50)) * 7 + 3, i & 1]
-    loop = np.zeros((n_loop, batch * limit), dtype=np.uint64)
-    # acc0 via a first oracle pass, then the native recurrence for the carried state
-    pre = zko.CircuitRun(cs.export(False), cs.export(True), batch, 306)
-    pre.resolve(outer, loop)
-    sc = zko.Scope(cs.export(True))
-    links = sc.words[-4 * sc.n_links:].reshape(-1, 4)
-    first = [l for l in links if l[0] == LINK["FIRST"]][0]
-    for i in range(batch):
-        acc, a = int(pre.oc[first[2], i]), int(outer[0, i])
-        for k in range(limit):
-            t = 0 if k == 1 else rand_fe(rng, 1)[0]
-            loop[:, i * limit + k] = [acc, t, int(rng.integers(0, 16)), int(rng.integers(0, 16))]
-            acc = (acc * t + a) % P
-    keep = gpu_run(zk, cs, outer, loop, batch)
+    outer, loop_raw = all_ops_inputs(rng, batch, limit, n_outer, n_loop)
+    seeded_oracle = zko.CircuitRun(cs.export(False), cs.export(True), batch, 306).seed(outer, loop_raw)
+    cs.set_batch(batch)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop_raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop_raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    loop = d_l.to_numpy().reshape(loop_raw.shape)
+    assert np.array_equal(loop, seeded_oracle)
+    cs.resolve()
     run = oracle_run(cs, outer, loop, batch, 306)
     assert_trace_equal(cs, run)
     assert run.check()[0] == 0
@@ -162,7 +151,27 @@ def test_all_ops_circuit_gpu_equals_oracle(zk):
     assert ok, f
     for i in (0, 1, batch - 1):
         assert np.array_equal(cs.multiplicities(i), run.mult[i * 306:(i + 1) * 306])
-    del keep
+
+
+def test_ram_generic_seeding_equals_native_streams(zk):
+    """raw witness only (items + is_first flag): the engine's sequential seeding reproduces the
+    per-iteration state the native restatement derives from the reference code"""
+    limit, batch = 8, 5
+    cs = ram_cs(limit)
+    insts = random_instances(31, batch, 6, limit)
+    outer, loop = rn.pack_streams(insts, limit)
+    raw = loop.copy()
+    raw[0:46] = 0  # drop every carried word (layout: DESIGN.md, ram_permutation loop stream)
+    cs.set_batch(batch)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
+    cs.resolve()
+    assert cs.check_if_satisfied()[0]
+    for i in range(batch):
+        assert cs.public_inputs(i) == insts[i]["commitment"]
 
 
 def test_lookup_absent_key_gpu(zk):
