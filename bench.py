@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of BASELINE.json: constraints/s (+ witness-rows/s) on the
+main_vm-shaped 2^20-row trace (config C2), N MI355X, one process per GPU.
+
+A "step" = one pass of the hot path over one batch of B independent circuit instances per GPU whose
+inputs already live in HBM: witness generation (outer pre, loop, outer post kernels) followed by the
+full satisfiability check (gate + lookup + copy + link kernels).  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--log2-rows 20] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "era-zkevm_circuits_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+STATE_WORDS, RAW_WORDS = 183, 42
+TABLE_ROWS = 65536 * 2 + 2048 + 64 + 16 + 1024
+
+
+def vm_inputs(rng, n_outer, n_loop, batch, limit):
+    """synthetic VmLocalState + per-cycle oracle words (seed 0xC2); carried words left 0"""
+    P = 0xFFFFFFFF00000001
+    outer = rng.integers(0, 2**32, size=(n_outer, batch), dtype=np.uint64)
+    outer[120:135] = rng.integers(0, 2, size=(15, batch))          # register pointer flags
+    outer[135] = rng.integers(0, 2**16, size=batch)                 # pc
+    outer[138] = rng.integers(0, 2**30, size=batch)                 # timestamp
+    outer[139:142] = rng.integers(0, 2, size=(3, batch))           # flags
+    outer[142:154] = rng.integers(0, 2**63, size=(12, batch), dtype=np.uint64) % np.uint64(P)   # memory queue tail
+    outer[154] = rng.integers(0, 2**20, size=batch)
+    outer[155:167] = rng.integers(0, 2**63, size=(12, batch), dtype=np.uint64) % np.uint64(P)   # callstack sponge
+    loop = np.zeros((n_loop, batch * limit), dtype=np.uint64)
+    loop[STATE_WORDS:] = rng.integers(0, 2**32, size=(n_loop - STATE_WORDS, batch * limit), dtype=np.uint64)
+    loop[STATE_WORDS + 16] = rng.integers(0, 2, size=batch * limit)  # mem_read is_ptr
+    return outer, loop
+
+
+def build_vm_cs(zkgl, log2_rows):
+    """record the cycle once, with the largest `limit` that fits 2^log2_rows trace rows"""
+    probe = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), max_trace_len=1 << 30)
+    probe.configure_vm_shaped()
+    probe.vm_shaped_entry_point(1)
+    probe.pad_and_shrink()
+    st = probe.stats()
+    limit = ((1 << log2_rows) - st["outer_slots"]) // st["loop_slots"]
+    probe.close()
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), max_trace_len=1 << log2_rows)  # src/main_vm/cycle.rs:959-966
+    cs.configure_vm_shaped()
+    cs.vm_shaped_entry_point(limit)
+    cs.pad_and_shrink()
+    return cs, limit
+
+
+def cpu_baseline(cs_export, n_outer, n_loop, limit_full, constraints_per_cycle, rows_per_cycle, seconds_target=15.0):
+    """CPU restatement ("port"): the oracle interpreter + checker on a bounded sample of the same workload
+    (1 instance, fewer cycles), all host cores (OpenMP).  NOT the reference Rust binary (unbuildable here)."""
+    import zkgl
+    from oracle import zko
+
+    cores = os.cpu_count() or 1
+    limit, n_inst, reps = limit_full, 2, 4
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), max_trace_len=1 << 30)
+    cs.configure_vm_shaped()
+    cs.vm_shaped_entry_point(limit)
+    cs.pad_and_shrink()
+    rng = np.random.default_rng(0xC2)
+    outer, loop = vm_inputs(rng, n_outer, n_loop, n_inst, limit)
+    run = zko.CircuitRun(cs.export(False), cs.export(True), n_inst, TABLE_ROWS)
+    loop = run.seed(outer, loop)  # untimed, like the GPU leg
+    best = None
+    t_all = time.perf_counter()
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        run.resolve(outer, loop)
+        t1 = time.perf_counter()
+        bad, nrel = run.check()
+        t2 = time.perf_counter()
+        assert bad == 0
+        if best is None or (t2 - t0) < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1)
+        if time.perf_counter() - t_all > seconds_target:
+            break
+    st = cs.stats()
+    cs.close()
+    return {"value": nrel / best[0], "unit": "constraints/s", "cores": cores, "kind": "port",
+            "witness_rows_per_s": n_inst * st["rows_per_instance"] / best[1],
+            "sample": f"{n_inst} full-size instances ({limit} cycles, {st['rows_per_instance']} rows, {nrel} constraints in total), "
+                      f"best of <= {reps} passes: resolve {best[1]:.2f}s + check {best[2]:.2f}s, OpenMP {cores} threads; "
+                      f"CPU restatement (oracle), not the reference Rust binary"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="independent circuit instances per GPU per step")
+    ap.add_argument("--log2-rows", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import zkgl
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    zkgl.init(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cs, limit = build_vm_cs(zkgl, args.log2_rows)
+    st = cs.stats()
+    n_outer, n_loop = cs.input_words()
+    B = args.batch
+    rng = np.random.default_rng(0xC2 + rank)
+    outer, loop = vm_inputs(rng, n_outer, n_loop, B, limit)
+    cs.set_batch(B)
+    d_outer = torch.from_numpy(outer.view(np.int64)).to(dev)
+    d_loop = torch.from_numpy(loop.view(np.int64)).to(dev)
+    cs.bind_inputs(False, d_outer, n_outer)
+    cs.bind_inputs(True, d_loop, n_loop)
+    stream = torch.cuda.current_stream().cuda_stream
+    t_seed = time.perf_counter()
+    cs.seed_carried_inputs(d_loop, stream)  # untimed input preparation: per-cycle VM state (BASELINE: "same VmLocalState/cycle inputs")
+    t_seed = time.perf_counter() - t_seed
+
+    def step():
+        cs.resolve(stream)
+        ok, failure = cs.check_if_satisfied(stream)
+        if not ok:
+            raise RuntimeError(f"trace not satisfied: {failure}")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    loop_ms, check_ms, gate_ms, outer_ms = [], [], [], []
+    for _ in range(args.steps):
+        step()
+        loop_ms.append(cs.last_ms(1)); check_ms.append(cs.last_ms(2)); gate_ms.append(cs.last_ms(3)); outer_ms.append(cs.last_ms(4))
+    fence()
+    elapsed = time.perf_counter() - t0
+    # the path's only collective: gather the 4-element input commitments of every instance
+    commits = torch.tensor(np.array([cs.public_inputs(i) for i in range(B)], dtype=np.uint64).view(np.int64), device=dev)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        gathered = [torch.empty_like(commits) for _ in range(world)]
+        dist.all_gather(gathered, commits)
+        commits = torch.cat(gathered)
+    if rank == 0:
+        n_inst = B * world
+        constraints = st["constraints_per_instance"] * n_inst * args.steps
+        rows = st["rows_per_instance"] * n_inst * args.steps
+        var_cols = st["copy_columns"] + st["lookup_columns"]
+        # dominant kernel: the loop-scope witness interpreter.  ALGORITHMIC bytes per launch = every
+        # variable cell of the loop rows written once = B * loop_rows * 164 cols * 8 B
+        algo_bytes = B * st["loop_slots"] * st["limit"] * var_cols * 8
+        k_ms = float(np.mean(loop_ms))
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "constraints/s + witness-rows/s, main_vm 2^20 rows", "value": constraints / elapsed, "unit": "constraints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks)", "data": "synthetic",
+            "witness_rows_per_s": rows / elapsed,
+            "config": {"workload": f"main_vm-shaped cycle (config C2), geometry 140/0/8/deg8 + 3x8 lookups, 2^{args.log2_rows} rows/instance",
+                       "instances_per_gpu": B, "cycles_per_instance": limit, "rows_per_instance": st["rows_per_instance"],
+                       "constraints_per_instance": st["constraints_per_instance"], "parallelism": f"independent instances x{world}",
+                       "input_seeding_s": round(t_seed, 3)},
+            "roofline": {"bound": "hbm", "kernel": "zke::k_witness (loop scope)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                         "avg_launch_ms": k_ms,
+                         "other_kernels_ms": {"check_total": float(np.mean(check_ms)), "gate_check_loop": float(np.mean(gate_ms)),
+                                              "outer_witness": float(np.mean(outer_ms))}},
+            "commitment_checksum": int(commits.sum().item()) & 0xFFFFFFFFFFFF,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cpl = (st["constraints_per_instance"]) / max(limit, 1)
+            out["cpu_baseline"] = cpu_baseline(None, n_outer, n_loop, limit, cpl, st["loop_slots"])
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -455,7 +455,11 @@ void CS::emit_scope(Scope& s) {
 }
 
 void CS::upload_scope(Scope& s) {
-    s.d_prog = upload(s.prog);
+    {
+        std::vector<uint32_t> padded(s.prog);  // the device keeps a 128-word prefetch window (ProgWindow)
+        padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
+        s.d_prog = upload(padded);
+    }
     s.d_consts = upload(s.const_pool);
     s.d_rows = upload(s.rows);
     s.d_rowconsts = upload(s.rowconsts);

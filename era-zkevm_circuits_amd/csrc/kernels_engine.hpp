@@ -78,11 +78,47 @@ __device__ __forceinline__ uint32_t table_find(const zk_table_desc& t, const uin
 // Executes words [word_begin, word_end) of the scope program for one lane.  Every lane of a wave is
 // at the same program position (also in the sequential seeding mode, where the wave's lanes are
 // different instances at the same iteration), so op words are broadcast through readfirstlane.
-__device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane, const uint32_t inst,
+//
+// Program fetch: the op stream is identical for every lane, so the wave keeps a 128-word window of
+// it in two VGPRs (word i of the window in lane i), refilled with ONE coalesced 256-byte load per 64
+// words and prefetched one window ahead; a word is read with v_readlane (a few cycles) instead of a
+// dependent scalar load (an L2 round trip per word, which made the interpreter latency-bound).
+// All 64 lanes of a wave must stay alive for the window loads: surplus lanes are clamped to the last
+// valid lane by the callers and recompute/re-store that lane's values (benign), `active` only
+// guards the multiplicity atomics.
+struct ProgWindow {
+    const uint32_t* p;
+    uint32_t base, w0, w1, lid;
+    __device__ __forceinline__ void init(const uint32_t* prog, uint32_t start) {
+        p = prog;
+        lid = threadIdx.x & 63;
+        base = start & ~63u;
+        w0 = p[base + lid];
+        w1 = p[base + 64 + lid];  // host pads the program with >= 192 zero words
+    }
+    __device__ __forceinline__ void advance() {
+        w0 = w1;
+        base += 64;
+        w1 = p[base + 64 + lid];
+    }
+    // call where reads restart from `pc` (op boundary / sequential destination lists)
+    __device__ __forceinline__ void sync(uint32_t pc) {
+        while (pc - base >= 64) advance();
+    }
+    // idx wave-uniform, base <= idx < base + 128
+    __device__ __forceinline__ uint32_t at(uint32_t idx) const {
+        const uint32_t off = idx - base;
+        const uint32_t src = off < 64 ? w0 : w1;
+        return __builtin_amdgcn_readlane(src, off & 63);
+    }
+};
+
+__device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                          uint32_t word_begin, uint32_t word_end) {
-    const uint32_t* __restrict__ prog = sc.prog;
     uint64_t* __restrict__ cells = sc.cells;
     const uint64_t stride = sc.stride;
+    ProgWindow P;
+    P.init(sc.prog, word_begin);
 
     auto ld = [&](uint32_t w) -> uint64_t {
         const uint32_t kind = w & ZK_OPERAND_KIND_MASK, idx = w & ZK_OPERAND_IDX_MASK;
@@ -94,26 +130,28 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
     auto st = [&](uint64_t v) {
         uint32_t w;
         do {
-            w = uni(prog[pc++]);
+            P.sync(pc);
+            w = P.at(pc++);
             cells[(size_t)(w & ~ZK_DEST_MORE) * stride + lane] = v;
         } while (w & ZK_DEST_MORE);
     };
 
     while (pc < word_end) {
-        const uint32_t h = uni(prog[pc++]);
+        P.sync(pc);
+        const uint32_t h = P.at(pc++);
         const uint32_t op = h & 0xff, pa = (h >> 8) & 0xff, pb = h >> 16;
         switch (op) {
         case ZK_OP_CONST: {
-            uint64_t v = ld(uni(prog[pc++]));
+            uint64_t v = ld(P.at(pc++));
             st(v);
         } break;
         case ZK_OP_INPUT: {
-            uint32_t w = uni(prog[pc++]);
+            uint32_t w = P.at(pc++);
             st(sc.inputs[(size_t)w * sc.n_lanes + lane]);
         } break;
         case ZK_OP_FMA: {
-            uint64_t q = ld(uni(prog[pc])), l = ld(uni(prog[pc + 1]));
-            uint64_t a = ld(uni(prog[pc + 2])), b = ld(uni(prog[pc + 3])), c = ld(uni(prog[pc + 4]));
+            uint64_t q = ld(P.at(pc)), l = ld(P.at(pc + 1));
+            uint64_t a = ld(P.at(pc + 2)), b = ld(P.at(pc + 3)), c = ld(P.at(pc + 4));
             pc += 5;
             uint64_t ab = gl::mul(a, b);
             uint64_t r = gl::add(q == 1 ? ab : gl::mul(q, ab), l == 1 ? c : gl::mul(l, c));
@@ -122,29 +160,29 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         case ZK_OP_LC4: {
             uint64_t r = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r = gl::fma(ld(uni(prog[pc + i])), ld(uni(prog[pc + 4 + i])), r);
+            for (int i = 0; i < 4; ++i) r = gl::fma(ld(P.at(pc + i)), ld(P.at(pc + 4 + i)), r);
             pc += 8;
             st(r);
         } break;
         case ZK_OP_SELECT: {
-            uint64_t s = ld(uni(prog[pc])), a = ld(uni(prog[pc + 1])), b = ld(uni(prog[pc + 2]));
+            uint64_t s = ld(P.at(pc)), a = ld(P.at(pc + 1)), b = ld(P.at(pc + 2));
             pc += 3;
             st(s ? a : b);
         } break;
         case ZK_OP_ISZERO: {
-            uint64_t x = ld(uni(prog[pc++]));
+            uint64_t x = ld(P.at(pc++));
             st(x == 0 ? 1ull : 0ull);
             st(gl::inv(x));
         } break;
         case ZK_OP_UADD: {
-            uint64_t x = ld(uni(prog[pc])), y = ld(uni(prog[pc + 1])), ci = ld(uni(prog[pc + 2]));
+            uint64_t x = ld(P.at(pc)), y = ld(P.at(pc + 1)), ci = ld(P.at(pc + 2));
             pc += 3;
             uint64_t s = x + y + ci;  // operands < 2^32
             st(s & ((1ull << pa) - 1));
             st(s >> pa);
         } break;
         case ZK_OP_USUB: {
-            uint64_t x = ld(uni(prog[pc])), y = ld(uni(prog[pc + 1])), bi = ld(uni(prog[pc + 2]));
+            uint64_t x = ld(P.at(pc)), y = ld(P.at(pc + 1)), bi = ld(P.at(pc + 2));
             pc += 3;
             uint64_t sub = y + bi;
             uint64_t borrow = x < sub ? 1 : 0;
@@ -155,44 +193,44 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         case ZK_OP_DOT4: {
             uint64_t r = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r = gl::fma(ld(uni(prog[pc + 2 * i])), ld(uni(prog[pc + 2 * i + 1])), r);
+            for (int i = 0; i < 4; ++i) r = gl::fma(ld(P.at(pc + 2 * i)), ld(P.at(pc + 2 * i + 1)), r);
             pc += 8;
             st(r);
         } break;
         case ZK_OP_MATMUL12: {
             uint64_t s[12];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) s[i] = ld(uni(prog[pc + i]));
+            for (int i = 0; i < 12; ++i) s[i] = ld(P.at(pc + i));
             pc += 12;
             if (pa == 0) p2::mds_external(s); else p2::mds_inner(s);
 #pragma unroll
             for (int i = 0; i < 12; ++i) st(s[i]);
         } break;
         case ZK_OP_SPLIT: {
-            uint64_t x = ld(uni(prog[pc++]));
+            uint64_t x = ld(P.at(pc++));
             for (uint32_t i = 0; i < pa; ++i) {
                 st(i + 1 == pa ? x : (x & ((1ull << pb) - 1)));
                 x >>= pb;
             }
         } break;
         case ZK_OP_LOOKUP: {
-            const uint32_t tid = uni(prog[pc++]);
+            const uint32_t tid = P.at(pc++);
             const zk_table_desc t = sc.tables[tid];
             uint64_t key[3] = {0, 0, 0};
-            for (uint32_t i = 0; i < pa; ++i) key[i] = ld(uni(prog[pc + i]));
+            for (uint32_t i = 0; i < pa; ++i) key[i] = ld(P.at(pc + i));
             pc += pa;
             uint32_t row = table_find(t, sc.table_words, key);
             const uint32_t w = t.n_keys + t.n_vals;
             bool found = row < t.n_rows;
             for (uint32_t i = 0; i < pb; ++i)
                 st(found ? sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i] : 0ull);
-            if (found && sc.mult)
+            if (found && active && sc.mult)
                 atomicAdd(&sc.mult[(size_t)inst * sc.total_table_rows + t.mult_off + row], 1u);
         } break;
         case ZK_OP_POSEIDON2: {
             uint64_t s[12];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) s[i] = ld(uni(prog[pc + i]));
+            for (int i = 0; i < 12; ++i) s[i] = ld(P.at(pc + i));
             pc += 12;
             p2::permute(s);
 #pragma unroll
@@ -203,7 +241,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             // registers and streamed to its cells (order fixed by gadgets.cpp poseidon2_round_function).
             uint64_t s[12];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) s[i] = ld(uni(prog[pc + i]));
+            for (int i = 0; i < 12; ++i) s[i] = ld(P.at(pc + i));
             pc += 12;
             p2::mds_external(s);
 #pragma unroll
@@ -232,11 +270,11 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             }
         } break;
         case ZK_OP_LOOP_LAST: {
-            uint32_t c = uni(prog[pc++]);
+            uint32_t c = P.at(pc++);
             st(sc.loop_cells[(size_t)c * sc.loop_stride + (size_t)lane * sc.loop_limit + (sc.loop_limit - 1)]);
         } break;
         case ZK_OP_U32MULADD: {
-            uint64_t a = ld(uni(prog[pc])), b = ld(uni(prog[pc + 1])), c = ld(uni(prog[pc + 2])), d = ld(uni(prog[pc + 3]));
+            uint64_t a = ld(P.at(pc)), b = ld(P.at(pc + 1)), c = ld(P.at(pc + 2)), d = ld(P.at(pc + 3));
             pc += 4;
             uint64_t r = a * b + c + d;  // < 2^64 for u32 operands
             st(r & 0xffffffffull);
@@ -249,9 +287,11 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 }
 
 __global__ __launch_bounds__(TPB) void k_witness(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
-    const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
-    if (lane >= sc.n_lanes) return;
-    run_lane(sc, lane, sc.is_loop ? lane / sc.limit : lane, word_begin, word_end);
+    uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
+    const bool active = lane < sc.n_lanes;
+    lane = active ? lane : sc.n_lanes - 1;
+    run_lane(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
 }
 
 // Sequential seeding mode (generic, slow): thread == instance, iterations in order.  Before
@@ -262,8 +302,10 @@ __global__ __launch_bounds__(TPB) void k_witness(ScopeDev sc, uint32_t word_begi
 struct CarryDev { uint32_t word, out_cell, first_outer_cell, has_first; };
 __global__ __launch_bounds__(64) void k_witness_seq(ScopeDev sc, const CarryDev* carries, uint32_t n_carries,
                                                     uint64_t* inputs_rw, uint32_t n_instances) {
-    const uint32_t inst = blockIdx.x * 64 + threadIdx.x;
-    if (inst >= n_instances) return;
+    uint32_t inst = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * 64 >= n_instances) return;
+    const bool active = inst < n_instances;
+    inst = active ? inst : n_instances - 1;
     for (uint32_t k = 0; k < sc.limit; ++k) {
         const uint32_t lane = inst * sc.limit + k;
         for (uint32_t c = 0; c < n_carries; ++c) {
@@ -276,7 +318,7 @@ __global__ __launch_bounds__(64) void k_witness_seq(ScopeDev sc, const CarryDev*
             }
         }
         __threadfence();
-        run_lane(sc, lane, inst, 0, sc.n_words);
+        run_lane(sc, lane, inst, active, 0, sc.n_words);
         __threadfence();
     }
 }

@@ -246,3 +246,40 @@ def test_ram_two_chunk_continuation():
     assert run.check()[0] == 0
     assert [int(run.oc[c, 1]) for c in cs.public_cells()] == c2["commitment"]
     del first
+
+
+# ------------------------------------------------------------------ main_vm-shaped cycle (config C2)
+def vm_cs(limit):
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8))
+    cs.configure_vm_shaped()
+    cs.vm_shaped_entry_point(limit)
+    cs.pad_and_shrink()
+    return cs
+
+
+VM_TABLE_ROWS = 65536 * 2 + 2048 + 64 + 16 + 1024
+
+
+def test_vm_shaped_cycle_budget_and_satisfiability():
+    from bench import vm_inputs
+    limit, batch = 3, 2
+    cs = vm_cs(limit)
+    st1, st3 = vm_cs(1).stats(), cs.stats()
+    per_cycle = {k: (st3["gate_instances"][k] - st1["gate_instances"][k]) // 2 for k in st3["gate_instances"]}
+    # SURVEY §8 a15 budget: 9 in-circuit permutations, 2x8 UIntXAddGate<32> (+1 ergs), 3x64 fma_with_carry
+    assert per_cycle["MATMUL12_EXT"] == 9 * 9 and per_cycle["MATMUL12_INT"] == 9 * 22
+    assert per_cycle["UINTX_ADD"] == 17 and per_cycle["U32_FMA"] == 192
+    assert st3["copy_columns"] == 140 and st3["lookup_columns"] == 24
+    n_outer, n_loop = cs.input_words()
+    assert (n_outer, n_loop) == (183, 225)
+    rng = np.random.default_rng(0xC2)
+    outer, loop_raw = vm_inputs(rng, n_outer, n_loop, batch, limit)
+    run = zko.CircuitRun(cs.export(False), cs.export(True), batch, VM_TABLE_ROWS)
+    loop = run.seed(outer, loop_raw)
+    run2 = oracle_run(cs, outer, loop, batch, VM_TABLE_ROWS)
+    bad, nrel = run2.check()
+    assert bad == 0 and nrel == st3["constraints_per_instance"] * batch
+    assert np.array_equal(run2.lc, run.lc)
+    # tampering with one raw oracle word (a code word limb) must break satisfiability
+    loop_bad = loop.copy(); loop_bad[183, 1] ^= 1
+    assert oracle_run(cs, outer, loop_bad, batch, VM_TABLE_ROWS).check()[0] > 0

@@ -202,3 +202,28 @@ def test_resolve_is_repeatable_and_timed(zk):
     assert cs.last_ms(0) > 0 and cs.last_ms(1) > 0
     assert cs.check_if_satisfied()[0] and cs.last_ms(2) > 0
     del keep
+
+
+def test_vm_shaped_gpu_equals_oracle(zk):
+    from bench import vm_inputs
+    from test_cs_host import VM_TABLE_ROWS, vm_cs
+    limit, batch = 5, 70
+    cs = vm_cs(limit)
+    n_outer, n_loop = cs.input_words()
+    outer, loop_raw = vm_inputs(np.random.default_rng(0xC2), n_outer, n_loop, batch, limit)
+    seeded = zko.CircuitRun(cs.export(False), cs.export(True), batch, VM_TABLE_ROWS).seed(outer, loop_raw)
+    cs.set_batch(batch)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop_raw)
+    cs.bind_inputs(False, d_o, n_outer)
+    cs.bind_inputs(True, d_l, n_loop)
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(loop_raw.shape), seeded)
+    cs.resolve()
+    run = oracle_run(cs, outer, seeded, batch, VM_TABLE_ROWS)
+    assert_trace_equal(cs, run)
+    ok, f = cs.check_if_satisfied()
+    assert ok, f
+    assert run.check()[0] == 0
+    for i in (0, batch - 1):
+        assert cs.public_inputs(i) == [int(run.oc[c, i]) for c in cs.public_cells()]
+        assert np.array_equal(cs.multiplicities(i), run.mult[i * VM_TABLE_ROWS:(i + 1) * VM_TABLE_ROWS])
