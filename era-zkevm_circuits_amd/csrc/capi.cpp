@@ -280,6 +280,14 @@ int zk_cs_check_satisfied(zk_cs* cs, void* stream, zk_failure* first) {
     if (result == ZK_ERR_UNSATISFIED) return fail(ZK_ERR_UNSATISFIED, "constraint system is not satisfied");
     return result;
 }
+int zk_cs_resolve_and_check(zk_cs* cs, void* stream, zk_failure* first) {
+    NEED(cs); NEED_INIT();
+    int result = ZK_OK;
+    int rc = guard([&] { result = cs->cs->resolve_and_check(stream, first); });
+    if (rc) return rc;
+    if (result == ZK_ERR_UNSATISFIED) return fail(ZK_ERR_UNSATISFIED, "constraint system is not satisfied");
+    return result;
+}
 int zk_cs_read_var(zk_cs* cs, zk_var var, uint32_t instance, uint32_t iteration, uint64_t* out) {
     NEED(cs); NEED(out);
     return guard([&] { *out = cs->cs->read_var(var, instance, iteration); });

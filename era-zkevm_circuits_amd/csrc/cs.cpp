@@ -64,6 +64,9 @@ CS::~CS() {
     if (d_links_) hipFree(d_links_);
     if (d_carries_) hipFree(d_carries_);
     if (d_fail_) hipFree(d_fail_);
+    if (aux_stream_) hipStreamDestroy((hipStream_t)aux_stream_);
+    for (auto& e : ev2_)
+        if (e) hipEventDestroy((hipEvent_t)e);
     for (auto& e : ev_)
         if (e) hipEventDestroy((hipEvent_t)e);
 }
@@ -420,6 +423,7 @@ void CS::emit_scope(Scope& s) {
     std::vector<uint8_t> defined(s.n_vars, 0);
     s.prog.clear();
     s.pre_words = 0;
+    s.cells_written = 0;
     for (size_t oi = 0; oi < s.ops.size(); ++oi) {
         if (!s.is_loop && oi == s.pre_ops) s.pre_words = (uint32_t)s.prog.size();
         const OpRec& op = s.ops[oi];
@@ -443,6 +447,7 @@ void CS::emit_scope(Scope& s) {
             defined[ov] = 1;
             const auto& cells = s.var_cells[ov];
             for (size_t i = 0; i < cells.size(); ++i) s.prog.push_back(cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0));
+            s.cells_written += cells.size();
         }
     }
     if (!s.is_loop && s.pre_ops >= s.ops.size()) s.pre_words = (uint32_t)s.prog.size();
@@ -634,22 +639,23 @@ void CS::resolve(void* stream) {
     ms_[0] = a + b + c; ms_[1] = b; ms_[4] = a + c;
 }
 
+zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail) const {
+    zkdev::CheckArgs a;
+    a.cells = s.d_cells; a.stride = s.stride; a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
+    a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
+    a.lookup_width = lookup_width_; a.tables = d_tables_; a.table_words = d_table_words_; a.fail = fail;
+    // >= ~2048 workgroups: lane tiles x slot chunks
+    uint32_t lane_tiles = (s.n_lanes + 255) / 256;
+    uint32_t chunks = std::max<uint32_t>(1, (2048 + lane_tiles - 1) / std::max<uint32_t>(lane_tiles, 1));
+    chunks = std::min(chunks, s.n_slots);
+    a.slots_per_chunk = (s.n_slots + chunks - 1) / chunks;
+    return a;
+}
+
 int CS::check_satisfied(void* stream, zk_failure* first) {
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "check_satisfied before set_batch");
     hipStream_t st = (hipStream_t)stream;
     hip_check(hipMemsetAsync(d_fail_, 0xff, 8 * sizeof(unsigned long long), st), "memset fail");
-    auto check_args = [&](const Scope& s, unsigned long long* fail) {
-        zkdev::CheckArgs a;
-        a.cells = s.d_cells; a.stride = s.stride; a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
-        a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
-        a.lookup_width = lookup_width_; a.tables = d_tables_; a.table_words = d_table_words_; a.fail = fail;
-        // >= ~2048 workgroups: lane tiles x slot chunks
-        uint32_t lane_tiles = (s.n_lanes + 255) / 256;
-        uint32_t chunks = std::max<uint32_t>(1, (2048 + lane_tiles - 1) / std::max<uint32_t>(lane_tiles, 1));
-        chunks = std::min(chunks, s.n_slots);
-        a.slots_per_chunk = (s.n_slots + chunks - 1) / chunks;
-        return a;
-    };
     hip_check(hipEventRecord((hipEvent_t)ev_[4], st), "event");
     dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_), st));
     dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.stride, outer_.n_lanes, outer_.d_copies,
@@ -673,6 +679,10 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
     hipEventElapsedTime(&tot, (hipEvent_t)ev_[4], (hipEvent_t)ev_[7]);
     hipEventElapsedTime(&g, (hipEvent_t)ev_[5], (hipEvent_t)ev_[6]);
     ms_[2] = tot; ms_[3] = g;
+    return decode_failure(f, first);
+}
+
+int CS::decode_failure(const unsigned long long* f, zk_failure* first) const {
     const unsigned long long NONE = ~0ull;
     for (int sc = 0; sc < 2; ++sc) {
         const Scope& s = sc ? loop_ : outer_;
@@ -703,6 +713,69 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
         }
     }
     return ZK_OK;
+}
+
+
+// Fused witness generation + satisfiability check with the latency-bound outer scope (lane ==
+// instance, one wave) overlapped with the bandwidth-bound loop-scope kernels on a second stream:
+//   aux : outer PRE --ev--> ........................ outer POST -> gates(outer) -> copies(outer) --ev-->
+//   main:            wait -> LOOP witness --ev--> gates(loop) -> copies(loop) ............ wait -> links
+int CS::resolve_and_check(void* stream, zk_failure* first) {
+    if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "resolve_and_check before set_batch");
+    if (outer_.n_input_words && !outer_.d_inputs) throw ZkError(ZK_ERR_INVALID, "outer input stream not bound");
+    if (loop_.n_input_words && !loop_.d_inputs) throw ZkError(ZK_ERR_INVALID, "loop input stream not bound");
+    hipStream_t st = (hipStream_t)stream;
+    if (!aux_stream_) {
+        hipStream_t a;
+        hip_check(hipStreamCreateWithFlags(&a, hipStreamNonBlocking), "hipStreamCreate aux");
+        aux_stream_ = (void*)a;
+        for (auto& e : ev2_) { hipEvent_t he; hip_check(hipEventCreate(&he), "hipEventCreate"); e = (void*)he; }
+    }
+    hipStream_t ax = (hipStream_t)aux_stream_;
+    auto E = [&](int i) { return (hipEvent_t)ev2_[i]; };
+    hip_check(hipMemsetAsync(d_mult_, 0, std::max<size_t>((size_t)batch_ * total_table_rows_ * 4, 4), st), "memset mult");
+    hip_check(hipMemsetAsync(d_fail_, 0xff, 8 * sizeof(unsigned long long), st), "memset fail");
+    auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
+    auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
+    hip_check(hipEventRecord(E(0), st), "event");                     // t0 (+ memsets done)
+    hip_check(hipStreamWaitEvent(ax, E(0), 0), "wait");
+    dev_check(zkdev::launch_witness(oa, 0, outer_.pre_words, ax));    // outer PRE
+    hip_check(hipEventRecord(E(1), ax), "event");
+    hip_check(hipStreamWaitEvent(st, E(1), 0), "wait");
+    hip_check(hipEventRecord(E(2), st), "event");
+    if (limit_) dev_check(zkdev::launch_witness(la, 0, (uint32_t)loop_.prog.size(), st));   // LOOP
+    hip_check(hipEventRecord(E(3), st), "event");
+    hip_check(hipStreamWaitEvent(ax, E(3), 0), "wait");
+    dev_check(zkdev::launch_witness(oa, outer_.pre_words, (uint32_t)outer_.prog.size(), ax));  // outer POST
+    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_), ax));
+    dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.stride, outer_.n_lanes, outer_.d_copies,
+                                         (uint32_t)outer_.copies.size(), d_fail_, ax));
+    hip_check(hipEventRecord(E(4), ax), "event");
+    if (limit_) {
+        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3), st));
+        hip_check(hipEventRecord(E(5), st), "event");
+        dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.stride, loop_.n_lanes, loop_.d_copies,
+                                             (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
+    } else {
+        hip_check(hipEventRecord(E(5), st), "event");
+    }
+    hip_check(hipEventRecord(E(6), st), "event");
+    hip_check(hipStreamWaitEvent(st, E(4), 0), "wait");
+    if (limit_)
+        dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.stride, loop_.n_lanes, limit_, outer_.d_cells,
+                                            outer_.stride, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
+    hip_check(hipEventRecord(E(7), st), "event");
+    unsigned long long f[8];
+    hip_check(hipMemcpyAsync(f, d_fail_, sizeof f, hipMemcpyDeviceToHost, st), "memcpy fail");
+    hip_check(hipStreamSynchronize(st), "pipeline sync");
+    float loop_ms = 0, gates_ms = 0, copies_ms = 0, total = 0, outer_post = 0;
+    hipEventElapsedTime(&loop_ms, E(2), E(3));
+    hipEventElapsedTime(&gates_ms, E(3), E(5));
+    hipEventElapsedTime(&copies_ms, E(5), E(6));
+    hipEventElapsedTime(&total, E(0), E(7));
+    hipEventElapsedTime(&outer_post, E(3), E(4));
+    ms_[0] = total; ms_[1] = loop_ms; ms_[2] = gates_ms + copies_ms; ms_[3] = gates_ms; ms_[4] = outer_post;
+    return decode_failure(f, first);
 }
 
 uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
@@ -767,6 +840,8 @@ void CS::stats(zk_stats* o) const {
     o->lookups_per_instance = outer_.lookups.size() + loop_.lookups.size() * (uint64_t)limit_;
     o->program_words_outer = outer_.prog.size(); o->program_words_loop = loop_.prog.size();
     o->scratch_cells_outer = outer_.n_scratch; o->scratch_cells_loop = loop_.n_scratch;
+    o->cells_written_outer = outer_.cells_written; o->cells_written_loop = loop_.cells_written;
+    o->copy_pairs_outer = outer_.copies.size(); o->copy_pairs_loop = loop_.copies.size();
 }
 
 float CS::last_ms(int which) const { return (which >= 0 && which < 5) ? ms_[which] : -1.0f; }

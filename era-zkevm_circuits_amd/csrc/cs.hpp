@@ -16,6 +16,7 @@
 #include <unordered_map>
 #include <vector>
 #include "../../include/zkgl.h"
+#include "device_api.hpp"
 
 namespace zkgl {
 
@@ -84,6 +85,7 @@ struct Scope {
     std::vector<zk_copy_pair> copies;
     uint64_t gate_counts[ZK_GATE__COUNT] = {0};
     uint64_t n_constraints = 0;
+    uint64_t cells_written = 0;  // destination words of the program == cells one lane stores
 
     // ---- device ----
     uint32_t* d_prog = nullptr;
@@ -135,6 +137,7 @@ class CS {
     // sequential seeding of the carried input words (generic, slow): see kernels_engine.hpp k_witness_seq
     void seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream);
     int check_satisfied(void* stream, zk_failure* first);
+    int resolve_and_check(void* stream, zk_failure* first);
     uint64_t read_var(zk_var v, uint32_t instance, uint32_t iteration);
     void write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value);
     std::vector<uint64_t> public_inputs(uint32_t instance);
@@ -165,6 +168,8 @@ class CS {
     void ensure_uploaded();
     void free_scope_device(Scope& s);
     void check_var(zk_var v, bool want_loop) const;
+    int decode_failure(const unsigned long long* f, zk_failure* first) const;
+    zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail) const;
 
     zk_geometry geo_;
     uint64_t max_trace_len_, max_variables_;
@@ -194,6 +199,8 @@ class CS {
     void* d_carries_ = nullptr;
     unsigned long long* d_fail_ = nullptr;
     void* ev_[8] = {nullptr};
+    void* ev2_[8] = {nullptr};
+    void* aux_stream_ = nullptr;
     float ms_[5] = {0, 0, 0, 0, 0};
 };
 

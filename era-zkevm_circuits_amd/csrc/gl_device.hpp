@@ -85,15 +85,19 @@ __device__ __forceinline__ uint64_t inv(uint64_t x) {
     uint64_t e2 = mul(sqr(e1), e1);                       // 2^2-1
     uint64_t e3 = mul(sqr(e2), e1);                       // 2^3-1
     uint64_t t = e3;
+#pragma unroll 1
     for (int i = 0; i < 3; ++i) t = sqr(t);
     uint64_t e6 = mul(t, e3);                             // 2^6-1
     t = e6;
+#pragma unroll 1
     for (int i = 0; i < 6; ++i) t = sqr(t);
     uint64_t e12 = mul(t, e6);                            // 2^12-1
     t = e12;
+#pragma unroll 1
     for (int i = 0; i < 12; ++i) t = sqr(t);
     uint64_t e24 = mul(t, e12);                           // 2^24-1
     t = e24;
+#pragma unroll 1
     for (int i = 0; i < 6; ++i) t = sqr(t);
     uint64_t e30 = mul(t, e6);                            // 2^30-1
     uint64_t e31 = mul(sqr(e30), e1);                     // 2^31-1
@@ -101,6 +105,7 @@ __device__ __forceinline__ uint64_t inv(uint64_t x) {
     // p-2 = (2^32-1)*2^32 - 1... write p-2 = 2^64 - 2^32 - 1 = (2^32 - 2)*2^32 + (2^32 - 1)
     // (2^32-2) = 2*(2^31-1)  => x^(p-2) = (x^(2^31-1))^(2^33) * x^(2^32-1)
     t = e31;
+#pragma unroll 1
     for (int i = 0; i < 33; ++i) t = sqr(t);
     return mul(t, e32);
 }

@@ -119,6 +119,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
     const uint64_t stride = sc.stride;
     ProgWindow P;
     P.init(sc.prog, word_begin);
+    __shared__ uint64_t p2s[12 * TPB];  // Poseidon2 state, [element][thread]
 
     auto ld = [&](uint32_t w) -> uint64_t {
         const uint32_t kind = w & ZK_OPERAND_KIND_MASK, idx = w & ZK_OPERAND_IDX_MASK;
@@ -227,46 +228,48 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             if (found && active && sc.mult)
                 atomicAdd(&sc.mult[(size_t)inst * sc.total_table_rows + t.mult_off + row], 1u);
         } break;
-        case ZK_OP_POSEIDON2: {
-            uint64_t s[12];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) s[i] = ld(P.at(pc + i));
-            pc += 12;
-            p2::permute(s);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) st(s[i]);
-        } break;
-        case ZK_OP_P2_ROUNDS: {
-            // In-circuit permutation: every intermediate the gates constrain is produced in
-            // registers and streamed to its cells (order fixed by gadgets.cpp poseidon2_round_function).
+        case ZK_OP_POSEIDON2:      // witness-only permutation: 12 outputs
+        case ZK_OP_P2_ROUNDS: {    // in-circuit permutation: every intermediate the gates constrain is
+                                   // streamed to its cells (order fixed by gadgets.cpp compute_round_function)
+            // The per-lane state lives in LDS ([element][thread]: conflict-free) so that the S-box loop
+            // can run over a dynamic element index WITHOUT being unrolled: a fully unrolled body made
+            // this kernel ~400 KB of code and instruction-cache bound.
+            const bool emit = (op == ZK_OP_P2_ROUNDS);
             uint64_t s[12];
 #pragma unroll
             for (int i = 0; i < 12; ++i) s[i] = ld(P.at(pc + i));
             pc += 12;
             p2::mds_external(s);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) st(s[i]);
+            for (int i = 0; i < 12; ++i) p2s[i * TPB + threadIdx.x] = s[i];
+            if (emit) {
+#pragma unroll 1
+                for (int i = 0; i < 12; ++i) st(p2s[i * TPB + threadIdx.x]);
+            }
 #pragma unroll 1
             for (int r = 0; r < 30; ++r) {
                 const bool full = (r < 4) || (r >= 26);
-                if (full) {
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        uint64_t t = gl::add(s[i], p2::RC[12 * r + i]);
-                        uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
-                        st(t); st(x2); st(x3); st(x4); st(x7);
-                        s[i] = x7;
-                    }
-                    p2::mds_external(s);
-                } else {
-                    uint64_t t = gl::add(s[0], p2::RC[12 * r]);
+                const int n = full ? 12 : 1;
+#pragma unroll 1
+                for (int i = 0; i < n; ++i) {
+                    uint64_t t = gl::add(p2s[i * TPB + threadIdx.x], p2::RC[12 * r + i]);
                     uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
-                    st(t); st(x2); st(x3); st(x4); st(x7);
-                    s[0] = x7;
-                    p2::mds_inner(s);
+                    if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
+                    p2s[i * TPB + threadIdx.x] = x7;
                 }
 #pragma unroll
-                for (int i = 0; i < 12; ++i) st(s[i]);
+                for (int i = 0; i < 12; ++i) s[i] = p2s[i * TPB + threadIdx.x];
+                if (full) p2::mds_external(s); else p2::mds_inner(s);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) p2s[i * TPB + threadIdx.x] = s[i];
+                if (emit) {
+#pragma unroll 1
+                    for (int i = 0; i < 12; ++i) st(p2s[i * TPB + threadIdx.x]);
+                }
+            }
+            if (!emit) {
+#pragma unroll 1
+                for (int i = 0; i < 12; ++i) st(p2s[i * TPB + threadIdx.x]);
             }
         } break;
         case ZK_OP_LOOP_LAST: {
@@ -286,12 +289,20 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_witness(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
+// Two symbols for the same interpreter so that profiles separate the loop-scope launch (the dominant,
+// HBM-bound kernel: B*limit lanes) from the outer-scope launches (B lanes, latency-bound).
+__device__ __forceinline__ void witness_entry(const ScopeDev& sc, uint32_t word_begin, uint32_t word_end) {
     uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
     const bool active = lane < sc.n_lanes;
     lane = active ? lane : sc.n_lanes - 1;
     run_lane(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
+}
+__global__ __launch_bounds__(TPB) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
+    witness_entry(sc, word_begin, word_end);
+}
+__global__ __launch_bounds__(TPB) void k_witness_outer(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
+    witness_entry(sc, word_begin, word_end);
 }
 
 // Sequential seeding mode (generic, slow): thread == instance, iterations in order.  Before

@@ -96,7 +96,10 @@ static zke::ScopeDev to_dev(const ScopeArgs& a) {
 
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, void* stream) {
     if (sc.n_lanes == 0 || word_begin >= word_end) return 0;
-    zke::k_witness<<<grid_for(sc.n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(to_dev(sc), word_begin, word_end);
+    if (sc.is_loop)
+        zke::k_witness_loop<<<grid_for(sc.n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(to_dev(sc), word_begin, word_end);
+    else
+        zke::k_witness_outer<<<grid_for(sc.n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(to_dev(sc), word_begin, word_end);
     return LAUNCH_CHECK("k_witness");
 }
 

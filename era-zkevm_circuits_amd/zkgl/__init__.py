@@ -63,7 +63,9 @@ class _Stats(C.Structure):
                 ("constraints_per_instance", C.c_uint64), ("var_cells_per_instance", C.c_uint64),
                 ("gate_instances", C.c_uint64 * 13), ("lookups_per_instance", C.c_uint64),
                 ("program_words_outer", C.c_uint64), ("program_words_loop", C.c_uint64),
-                ("scratch_cells_outer", C.c_uint64), ("scratch_cells_loop", C.c_uint64)]
+                ("scratch_cells_outer", C.c_uint64), ("scratch_cells_loop", C.c_uint64),
+                ("cells_written_outer", C.c_uint64), ("cells_written_loop", C.c_uint64),
+                ("copy_pairs_outer", C.c_uint64), ("copy_pairs_loop", C.c_uint64)]
 
 
 _lib = None
@@ -383,6 +385,16 @@ class ConstraintSystem:
         """Returns (True, None) or (False, Failure)."""
         f = _Failure()
         rc = lib().zk_cs_check_satisfied(self._h, _ptr(stream), C.byref(f))
+        if rc == 0:
+            return True, None
+        if rc == ZK_ERR_UNSATISFIED:
+            return False, Failure(f.scope, f.instance, f.iteration, f.slot, f.kind, f.relation)
+        _check(rc)
+
+    def resolve_and_check(self, stream=None):
+        """fused witness generation + check_if_satisfied (outer scope overlapped on a second stream)"""
+        f = _Failure()
+        rc = lib().zk_cs_resolve_and_check(self._h, _ptr(stream), C.byref(f))
         if rc == 0:
             return True, None
         if rc == ZK_ERR_UNSATISFIED:

@@ -160,6 +160,9 @@ int zk_cs_seed_carried_inputs(zk_cs *cs, uint64_t *dev_loop_inputs_rw, void *str
 typedef struct zk_failure { uint32_t scope, instance, iteration, slot, kind, relation; } zk_failure;
 /* check_if_satisfied: 0 satisfied; ZK_ERR_UNSATISFIED + first failure otherwise */
 int zk_cs_check_satisfied(zk_cs *cs, void *stream, zk_failure *first);
+/* fused resolve + check_if_satisfied; the latency-bound outer scope runs on an internal second stream
+ * concurrently with the loop-scope kernels.  Same result contract as zk_cs_check_satisfied. */
+int zk_cs_resolve_and_check(zk_cs *cs, void *stream, zk_failure *first);
 int zk_cs_read_var(zk_cs *cs, zk_var var, uint32_t instance, uint32_t iteration, uint64_t *out); /* witness_hook */
 int zk_cs_write_cell(zk_cs *cs, int loop_scope, uint32_t cell, uint32_t lane, uint64_t value); /* fault injection for tests */
 int zk_cs_public_inputs(zk_cs *cs, uint32_t instance, uint64_t *out, uint32_t max, uint32_t *n);
@@ -180,10 +183,13 @@ typedef struct zk_stats {
     uint64_t lookups_per_instance;
     uint64_t program_words_outer, program_words_loop;
     uint64_t scratch_cells_outer, scratch_cells_loop;
+    uint64_t cells_written_outer, cells_written_loop; /* populated cells one lane writes (algorithmic bytes / 8) */
+    uint64_t copy_pairs_outer, copy_pairs_loop;
 } zk_stats;
 int zk_cs_stats(zk_cs *cs, zk_stats *out);           /* print_gate_stats counterpart */
 /* last execution times in ms measured with HIP events on the execution stream:
- * which: 0 resolve total, 1 loop witness kernel, 2 check total, 3 gate-check loop kernel, 4 outer kernels */
+ * which: 0 resolve total (fused: whole pipeline), 1 loop witness kernel, 2 check total (fused: loop gates+copies),
+ * 3 gate-check loop kernel, 4 outer kernels (fused: outer post + outer checks) */
 int zk_cs_last_ms(zk_cs *cs, int which, float *ms);
 /* serialised scope (program + descriptors) for the CPU oracle / offline tooling.
  * Call with buf = NULL to get the size in words. */

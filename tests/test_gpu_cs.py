@@ -227,3 +227,29 @@ def test_vm_shaped_gpu_equals_oracle(zk):
     for i in (0, batch - 1):
         assert cs.public_inputs(i) == [int(run.oc[c, i]) for c in cs.public_cells()]
         assert np.array_equal(cs.multiplicities(i), run.mult[i * VM_TABLE_ROWS:(i + 1) * VM_TABLE_ROWS])
+
+
+def test_fused_pipeline_equals_separate_calls(zk):
+    limit, batch = 8, 9
+    cs = ram_cs(limit)
+    insts = random_instances(41, batch, 7, limit)
+    outer, loop = rn.pack_streams(insts, limit)
+    keep = gpu_run(zk, cs, outer, loop, batch)
+    ref_loop, ref_outer = cs.trace(True).copy(), cs.trace(False).copy()
+    assert cs.check_if_satisfied()[0]
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    assert np.array_equal(cs.trace(True), ref_loop) and np.array_equal(cs.trace(False), ref_outer)
+    assert cs.last_ms(0) > 0 and cs.last_ms(1) > 0
+    for i in range(batch):
+        assert cs.public_inputs(i) == insts[i]["commitment"]
+    # an unsatisfiable instance is reported by the fused path as well
+    u, s, limit16 = load_fixture()
+    bad = rn.instance(u, [s[1], s[0], s[2]], limit, 1)
+    insts[4] = bad
+    outer, loop = rn.pack_streams(insts, limit)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert not ok and f.instance == 4
+    del keep
