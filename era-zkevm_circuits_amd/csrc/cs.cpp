@@ -27,6 +27,9 @@ const GateInfo GATES[ZK_GATE__COUNT] = {
     {6, 0, 1},   // U32_FMA
 };
 
+// element offset of (cell, lane) in the wave-tiled cell storage (see kernels_engine.hpp)
+size_t tiled_offset(uint64_t n_cells, uint64_t cell, uint64_t lane) { return (((lane >> 6) * n_cells + cell) << 6) + (lane & 63); }
+
 void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw ZkError(ZK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
@@ -409,7 +412,7 @@ void CS::place_scope(Scope& s) {
     s.var_cells.assign(s.n_vars, {});
     s.n_scratch = 0;
     for (uint32_t v = 0; v < s.n_vars; ++v) {
-        for (auto& cs : vc[v]) s.var_cells[v].push_back(cs.first * s.n_slots + cs.second);
+        for (auto& cs : vc[v]) s.var_cells[v].push_back(cs.second * total_cols + cs.first);
         if (s.var_cells[v].empty()) s.var_cells[v].push_back(s.n_trace_cells + s.n_scratch++);
     }
     s.n_cells = s.n_trace_cells + s.n_scratch;
@@ -563,7 +566,7 @@ void CS::set_batch(uint32_t n) {
     auto alloc_cells = [&](Scope& s, uint64_t lanes) {
         if (s.d_cells) { hipFree(s.d_cells); s.d_cells = nullptr; }
         s.n_lanes = (uint32_t)lanes;
-        s.stride = (lanes + 31) / 32 * 32;
+        s.stride = (lanes + 63) / 64 * 64;  // whole 64-lane tiles
         size_t bytes = std::max<size_t>((size_t)s.n_cells * s.stride * 8, 8);
         hip_check(hipMalloc((void**)&s.d_cells, bytes), "hipMalloc trace cells");
         hip_check(hipMemset(s.d_cells, 0, bytes), "hipMemset trace cells");
@@ -592,11 +595,11 @@ static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Sco
                                    const zk_table_desc* tables, const uint64_t* words, uint32_t* mult, uint32_t total_rows) {
     zkdev::ScopeArgs a;
     a.prog = s.d_prog; a.n_words = (uint32_t)s.prog.size(); a.n_lanes = s.n_lanes; a.consts = s.d_consts;
-    a.cells = s.d_cells; a.stride = s.stride; a.inputs = s.d_inputs;
-    a.outer_cells = outer.d_cells; a.outer_stride = outer.stride;
+    a.cells = s.d_cells; a.n_cells = s.n_cells; a.inputs = s.d_inputs;
+    a.outer_cells = outer.d_cells; a.outer_n_cells = outer.n_cells;
     a.limit = s.is_loop ? limit : 1; a.is_loop = s.is_loop ? 1 : 0;
     a.tables = tables; a.table_words = words; a.mult = mult; a.total_table_rows = total_rows;
-    a.loop_cells = loop.d_cells; a.loop_stride = loop.stride; a.loop_limit = limit;
+    a.loop_cells = loop.d_cells; a.loop_n_cells = loop.n_cells; a.loop_limit = limit;
     return a;
 }
 
@@ -641,7 +644,8 @@ void CS::resolve(void* stream) {
 
 zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail) const {
     zkdev::CheckArgs a;
-    a.cells = s.d_cells; a.stride = s.stride; a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
+    a.cells = s.d_cells; a.n_cells = s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
+    a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
     a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
     a.lookup_width = lookup_width_; a.tables = d_tables_; a.table_words = d_table_words_; a.fail = fail;
     // >= ~2048 workgroups: lane tiles x slot chunks
@@ -658,16 +662,16 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
     hip_check(hipMemsetAsync(d_fail_, 0xff, 8 * sizeof(unsigned long long), st), "memset fail");
     hip_check(hipEventRecord((hipEvent_t)ev_[4], st), "event");
     dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_), st));
-    dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.stride, outer_.n_lanes, outer_.d_copies,
+    dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies,
                                          (uint32_t)outer_.copies.size(), d_fail_, st));
     hip_check(hipEventRecord((hipEvent_t)ev_[5], st), "event");
     if (limit_) {
         dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3), st));
         hip_check(hipEventRecord((hipEvent_t)ev_[6], st), "event");
-        dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.stride, loop_.n_lanes, loop_.d_copies,
+        dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies,
                                              (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
-        dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.stride, loop_.n_lanes, limit_, outer_.d_cells,
-                                            outer_.stride, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
+        dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.n_cells, loop_.n_lanes, limit_, outer_.d_cells,
+                                            outer_.n_cells, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
     } else {
         hip_check(hipEventRecord((hipEvent_t)ev_[6], st), "event");
     }
@@ -748,13 +752,13 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hip_check(hipStreamWaitEvent(ax, E(3), 0), "wait");
     dev_check(zkdev::launch_witness(oa, outer_.pre_words, (uint32_t)outer_.prog.size(), ax));  // outer POST
     dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_), ax));
-    dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.stride, outer_.n_lanes, outer_.d_copies,
+    dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies,
                                          (uint32_t)outer_.copies.size(), d_fail_, ax));
     hip_check(hipEventRecord(E(4), ax), "event");
     if (limit_) {
         dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3), st));
         hip_check(hipEventRecord(E(5), st), "event");
-        dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.stride, loop_.n_lanes, loop_.d_copies,
+        dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies,
                                              (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
     } else {
         hip_check(hipEventRecord(E(5), st), "event");
@@ -762,8 +766,8 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hip_check(hipEventRecord(E(6), st), "event");
     hip_check(hipStreamWaitEvent(st, E(4), 0), "wait");
     if (limit_)
-        dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.stride, loop_.n_lanes, limit_, outer_.d_cells,
-                                            outer_.stride, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
+        dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.n_cells, loop_.n_lanes, limit_, outer_.d_cells,
+                                            outer_.n_cells, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
     hip_check(hipEventRecord(E(7), st), "event");
     unsigned long long f[8];
     hip_check(hipMemcpyAsync(f, d_fail_, sizeof f, hipMemcpyDeviceToHost, st), "memcpy fail");
@@ -788,7 +792,7 @@ uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
         lane = (uint64_t)instance * limit_ + iteration;
     }
     uint64_t out = 0;
-    hip_check(hipMemcpy(&out, s.d_cells + (size_t)s.var_cells[var_index(v)][0] * s.stride + lane, 8, hipMemcpyDeviceToHost),
+    hip_check(hipMemcpy(&out, s.d_cells + tiled_offset(s.n_cells, s.var_cells[var_index(v)][0], lane), 8, hipMemcpyDeviceToHost),
               "read_var memcpy");
     return out;
 }
@@ -796,7 +800,7 @@ uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
 void CS::write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value) {
     Scope& s = loop_scope ? loop_ : outer_;
     if (batch_ == 0 || cell >= s.n_cells || lane >= s.n_lanes) throw ZkError(ZK_ERR_INVALID, "write_cell: out of range");
-    hip_check(hipMemcpy(s.d_cells + (size_t)cell * s.stride + lane, &value, 8, hipMemcpyHostToDevice), "write_cell memcpy");
+    hip_check(hipMemcpy(s.d_cells + tiled_offset(s.n_cells, cell, lane), &value, 8, hipMemcpyHostToDevice), "write_cell memcpy");
 }
 
 std::vector<uint64_t> CS::public_inputs(uint32_t instance) {

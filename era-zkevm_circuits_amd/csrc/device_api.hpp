@@ -9,13 +9,13 @@ namespace zkdev {
 
 struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     const uint32_t* prog; uint32_t n_words; uint32_t n_lanes;
-    const uint64_t* consts; uint64_t* cells; uint64_t stride; const uint64_t* inputs;
-    const uint64_t* outer_cells; uint64_t outer_stride; uint32_t limit; uint32_t is_loop;
+    const uint64_t* consts; uint64_t* cells; uint64_t n_cells; const uint64_t* inputs;
+    const uint64_t* outer_cells; uint64_t outer_n_cells; uint32_t limit; uint32_t is_loop;
     const zk_table_desc* tables; const uint64_t* table_words; uint32_t* mult; uint32_t total_table_rows;
-    const uint64_t* loop_cells; uint64_t loop_stride; uint32_t loop_limit;
+    const uint64_t* loop_cells; uint64_t loop_n_cells; uint32_t loop_limit;
 };
 struct CheckArgs {  // mirrors zke::CheckDev
-    const uint64_t* cells; uint64_t stride; uint32_t n_lanes; uint32_t n_slots;
+    const uint64_t* cells; uint64_t n_cells; uint32_t n_cols; uint32_t n_lanes; uint32_t n_slots;
     const zk_row_desc* rows; const uint64_t* rowconsts; const zk_lookup_row_desc* lrows;
     uint32_t n_copy_cols; uint32_t lookup_width; const zk_table_desc* tables; const uint64_t* table_words;
     unsigned long long* fail; uint32_t slots_per_chunk;
@@ -37,10 +37,10 @@ struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // 
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);
 int launch_check_gates(const CheckArgs& cd, void* stream);
-int launch_check_copies(const uint64_t* cells, uint64_t stride, uint32_t n_lanes, const zk_copy_pair* pairs,
+int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs,
                         uint32_t n_pairs, unsigned long long* fail, void* stream);
-int launch_check_links(const uint64_t* loop_cells, uint64_t loop_stride, uint32_t n_lanes, uint32_t limit,
-                       const uint64_t* outer_cells, uint64_t outer_stride, const zk_link* links, uint32_t n_links,
+int launch_check_links(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_lanes, uint32_t limit,
+                       const uint64_t* outer_cells, uint64_t outer_n_cells, const zk_link* links, uint32_t n_links,
                        unsigned long long* fail, void* stream);
 const char* last_hip_error();
 

@@ -3,9 +3,13 @@
 // check.  Included once by zkgl_device.hip.
 //
 // Mapping: lane == (instance) for the outer scope, (instance*limit + iteration) for the loop
-// scope.  Every lane executes the same straight-line program, so the op stream is fetched with
-// scalar loads and there is no divergence; every cell access of a wavefront is one coalesced
-// 512-byte transaction (cells[cell*stride + lane]).
+// scope.  Every lane executes the same straight-line program (no divergence).
+//
+// Cell storage is TILED by wavefront: cells[((lane >> 6) * n_cells + cell) * 64 + (lane & 63)],
+// cell = slot * n_columns + column.  A wavefront owns one contiguous tile (n_cells * 512 B); every
+// cell access is one coalesced 512-byte transaction whose address is  tile_base + (cell << 9):
+// consecutive columns of a gate instance and consecutively placed rows are adjacent in DRAM, so a
+// wave streams through its tile (DRAM-page and TLB locality) instead of striding by the lane count.
 #pragma once
 #include "../../include/zkgl_ir.h"
 #include "poseidon2_device.hpp"
@@ -17,12 +21,12 @@ struct ScopeDev {
     uint32_t n_words;
     uint32_t n_lanes;
     const uint64_t* consts;     // constant pool
-    uint64_t* cells;            // [n_cells][stride]
-    uint64_t stride;
+    uint64_t* cells;            // [n_tiles][n_cells][64]
+    uint64_t n_cells;
     const uint64_t* inputs;     // [n_input_words][n_lanes]
     // loop scope only
     const uint64_t* outer_cells;
-    uint64_t outer_stride;
+    uint64_t outer_n_cells;
     uint32_t limit;             // iterations per instance (1 for the outer scope)
     uint32_t is_loop;
     // lookup tables
@@ -32,13 +36,18 @@ struct ScopeDev {
     uint32_t total_table_rows;
     // loop cells for ZK_OP_LOOP_LAST (outer scope post phase)
     const uint64_t* loop_cells;
-    uint64_t loop_stride;
+    uint64_t loop_n_cells;
     uint32_t loop_limit;
 };
 
 constexpr int TPB = 256;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// element offset of (cell, lane) in the tiled layout
+__device__ __forceinline__ size_t cell_off(uint64_t n_cells, uint32_t cell, uint32_t lane) {
+    return (((size_t)(lane >> 6) * n_cells + cell) << 6) + (lane & 63);
+}
 
 // locate the table row for a key tuple; returns n_rows when absent
 __device__ __forceinline__ uint32_t table_find(const zk_table_desc& t, const uint64_t* __restrict__ words,
@@ -115,8 +124,7 @@ struct ProgWindow {
 
 __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                          uint32_t word_begin, uint32_t word_end) {
-    uint64_t* __restrict__ cells = sc.cells;
-    const uint64_t stride = sc.stride;
+    uint64_t* __restrict__ cells = sc.cells + cell_off(sc.n_cells, 0, lane);  // this lane's column of its tile
     ProgWindow P;
     P.init(sc.prog, word_begin);
     __shared__ uint64_t p2s[12 * TPB];  // Poseidon2 state, [element][thread]
@@ -124,8 +132,8 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
     auto ld = [&](uint32_t w) -> uint64_t {
         const uint32_t kind = w & ZK_OPERAND_KIND_MASK, idx = w & ZK_OPERAND_IDX_MASK;
         if (kind == ZK_OPERAND_CONST) return sc.consts[idx];
-        if (kind == ZK_OPERAND_OUTER) return sc.outer_cells[(size_t)idx * sc.outer_stride + inst];
-        return cells[(size_t)idx * stride + lane];
+        if (kind == ZK_OPERAND_OUTER) return sc.outer_cells[cell_off(sc.outer_n_cells, idx, inst)];
+        return cells[(size_t)idx << 6];
     };
     uint32_t pc = word_begin;
     auto st = [&](uint64_t v) {
@@ -133,7 +141,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         do {
             P.sync(pc);
             w = P.at(pc++);
-            cells[(size_t)(w & ~ZK_DEST_MORE) * stride + lane] = v;
+            cells[(size_t)(w & ~ZK_DEST_MORE) << 6] = v;
         } while (w & ZK_DEST_MORE);
     };
 
@@ -274,7 +282,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         } break;
         case ZK_OP_LOOP_LAST: {
             uint32_t c = P.at(pc++);
-            st(sc.loop_cells[(size_t)c * sc.loop_stride + (size_t)lane * sc.loop_limit + (sc.loop_limit - 1)]);
+            st(sc.loop_cells[cell_off(sc.loop_n_cells, c, lane * sc.loop_limit + (sc.loop_limit - 1))]);
         } break;
         case ZK_OP_U32MULADD: {
             uint64_t a = ld(P.at(pc)), b = ld(P.at(pc + 1)), c = ld(P.at(pc + 2)), d = ld(P.at(pc + 3));
@@ -323,9 +331,9 @@ __global__ __launch_bounds__(64) void k_witness_seq(ScopeDev sc, const CarryDev*
             const CarryDev cd = carries[c];
             if (k == 0) {
                 if (cd.has_first)
-                    inputs_rw[(size_t)cd.word * sc.n_lanes + lane] = sc.outer_cells[(size_t)cd.first_outer_cell * sc.outer_stride + inst];
+                    inputs_rw[(size_t)cd.word * sc.n_lanes + lane] = sc.outer_cells[cell_off(sc.outer_n_cells, cd.first_outer_cell, inst)];
             } else {
-                inputs_rw[(size_t)cd.word * sc.n_lanes + lane] = sc.cells[(size_t)cd.out_cell * sc.stride + lane - 1];
+                inputs_rw[(size_t)cd.word * sc.n_lanes + lane] = sc.cells[cell_off(sc.n_cells, cd.out_cell, lane - 1)];
             }
         }
         __threadfence();
@@ -343,7 +351,8 @@ __global__ __launch_bounds__(64) void k_witness_seq(ScopeDev sc, const CarryDev*
 // ------------------------------------------------------------------------------------------
 struct CheckDev {
     const uint64_t* cells;
-    uint64_t stride;
+    uint64_t n_cells;
+    uint32_t n_cols;            // copy + lookup columns
     uint32_t n_lanes;
     uint32_t n_slots;
     const zk_row_desc* rows;
@@ -369,14 +378,14 @@ __global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) {
     if (lane >= cd.n_lanes) return;
     const uint32_t s0 = blockIdx.y * cd.slots_per_chunk;
     const uint32_t s1 = min(s0 + cd.slots_per_chunk, cd.n_slots);
-    const uint64_t* __restrict__ cells = cd.cells;
-    const size_t stride = cd.stride, S = cd.n_slots;
+    const uint64_t* __restrict__ cells = cd.cells + cell_off(cd.n_cells, 0, lane);
+    const size_t NC = cd.n_cols;
     for (uint32_t slot = s0; slot < s1; ++slot) {
         const zk_row_desc d = cd.rows[slot];
         const uint32_t kind = uni(d.kind), ninst = uni(d.n_instances);
         const uint64_t* __restrict__ k = cd.rowconsts + uni(d.const_off);
         const uint32_t w = GATE_WIDTH[kind];
-        auto cell = [&](uint32_t col) -> uint64_t { return cells[((size_t)col * S + slot) * stride + lane]; };
+        auto cell = [&](uint32_t col) -> uint64_t { return cells[((size_t)slot * NC + col) << 6]; };
         for (uint32_t j = 0; j < ninst; ++j) {
             const uint32_t c0 = j * w;
             switch (kind) {
@@ -461,24 +470,25 @@ __global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) {
 }
 
 // copy constraints inside a scope: every non-home cell of a variable equals the home cell
-__global__ __launch_bounds__(TPB) void k_check_copies(const uint64_t* __restrict__ cells, uint64_t stride, uint32_t n_lanes,
+__global__ __launch_bounds__(TPB) void k_check_copies(const uint64_t* __restrict__ cells_all, uint64_t n_cells, uint32_t n_lanes,
                                                       const zk_copy_pair* __restrict__ pairs, uint32_t n_pairs,
                                                       uint32_t pairs_per_chunk, unsigned long long* fail) {
     const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if (lane >= n_lanes) return;
+    const uint64_t* __restrict__ cells = cells_all + cell_off(n_cells, 0, lane);
     const uint32_t p0 = blockIdx.y * pairs_per_chunk, p1 = min(p0 + pairs_per_chunk, n_pairs);
     for (uint32_t i = p0; i < p1; ++i) {
         const zk_copy_pair p = pairs[i];
-        uint64_t a = cells[(size_t)uni(p.cell) * stride + lane], b = cells[(size_t)uni(p.home) * stride + lane];
+        uint64_t a = cells[(size_t)uni(p.cell) << 6], b = cells[(size_t)uni(p.home) << 6];
         if (a != b) atomicMin(fail + 1, ((unsigned long long)lane << 32) | i);
     }
 }
 
 // copy constraints across iterations / scopes (the hidden_fsm chain of the reference:
 // /root/reference/src/ram_permutation/mod.rs:119-143,178-196)
-__global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict__ loop_cells, uint64_t loop_stride,
+__global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict__ loop_cells, uint64_t loop_n_cells,
                                                      uint32_t n_lanes, uint32_t limit,
-                                                     const uint64_t* __restrict__ outer_cells, uint64_t outer_stride,
+                                                     const uint64_t* __restrict__ outer_cells, uint64_t outer_n_cells,
                                                      const zk_link* __restrict__ links, uint32_t n_links,
                                                      unsigned long long* fail) {
     const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
@@ -487,12 +497,12 @@ __global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict_
     for (uint32_t i = 0; i < n_links; ++i) {
         const zk_link L = links[i];
         const uint32_t kind = uni(L.kind);
-        uint64_t mine = loop_cells[(size_t)uni(L.loop_cell) * loop_stride + lane];
+        uint64_t mine = loop_cells[cell_off(loop_n_cells, uni(L.loop_cell), lane)];
         bool ok = true;
         if (kind == ZK_LINK_CARRY) {
-            if (k > 0) ok = mine == loop_cells[(size_t)uni(L.other_cell) * loop_stride + lane - 1];
+            if (k > 0) ok = mine == loop_cells[cell_off(loop_n_cells, uni(L.other_cell), lane - 1)];
         } else {
-            uint64_t o = outer_cells[(size_t)uni(L.other_cell) * outer_stride + inst];
+            uint64_t o = outer_cells[cell_off(outer_n_cells, uni(L.other_cell), inst)];
             if (kind == ZK_LINK_FIRST) ok = (k != 0) || mine == o;
             else if (kind == ZK_LINK_LAST) ok = (k != limit - 1) || mine == o;
             else ok = mine == o;

@@ -87,9 +87,9 @@ int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint6
 static zke::ScopeDev to_dev(const ScopeArgs& a) {
     zke::ScopeDev d;
     d.prog = a.prog; d.n_words = a.n_words; d.n_lanes = a.n_lanes; d.consts = a.consts; d.cells = a.cells;
-    d.stride = a.stride; d.inputs = a.inputs; d.outer_cells = a.outer_cells; d.outer_stride = a.outer_stride;
+    d.n_cells = a.n_cells; d.inputs = a.inputs; d.outer_cells = a.outer_cells; d.outer_n_cells = a.outer_n_cells;
     d.limit = a.limit; d.is_loop = a.is_loop; d.tables = a.tables; d.table_words = a.table_words; d.mult = a.mult;
-    d.total_table_rows = a.total_table_rows; d.loop_cells = a.loop_cells; d.loop_stride = a.loop_stride;
+    d.total_table_rows = a.total_table_rows; d.loop_cells = a.loop_cells; d.loop_n_cells = a.loop_n_cells;
     d.loop_limit = a.loop_limit;
     return d;
 }
@@ -115,7 +115,7 @@ int launch_witness_seq(const ScopeArgs& sc, const CarryArgs* d_carries, uint32_t
 int launch_check_gates(const CheckArgs& a, void* stream) {
     if (a.n_lanes == 0 || a.n_slots == 0) return 0;
     zke::CheckDev d;
-    d.cells = a.cells; d.stride = a.stride; d.n_lanes = a.n_lanes; d.n_slots = a.n_slots; d.rows = a.rows;
+    d.cells = a.cells; d.n_cells = a.n_cells; d.n_cols = a.n_cols; d.n_lanes = a.n_lanes; d.n_slots = a.n_slots; d.rows = a.rows;
     d.rowconsts = a.rowconsts; d.lrows = a.lrows; d.n_copy_cols = a.n_copy_cols; d.lookup_width = a.lookup_width;
     d.tables = a.tables; d.table_words = a.table_words; d.fail = a.fail; d.slots_per_chunk = a.slots_per_chunk;
     dim3 grid(grid_for(a.n_lanes, zke::TPB), (a.n_slots + a.slots_per_chunk - 1) / a.slots_per_chunk);
@@ -123,7 +123,7 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
     return LAUNCH_CHECK("k_check_gates");
 }
 
-int launch_check_copies(const uint64_t* cells, uint64_t stride, uint32_t n_lanes, const zk_copy_pair* pairs,
+int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs,
                         uint32_t n_pairs, unsigned long long* fail, void* stream) {
     if (n_lanes == 0 || n_pairs == 0) return 0;
     unsigned lane_tiles = grid_for(n_lanes, zke::TPB);
@@ -133,16 +133,16 @@ int launch_check_copies(const uint64_t* cells, uint64_t stride, uint32_t n_lanes
     if (chunks < 1) chunks = 1;
     uint32_t per = (n_pairs + chunks - 1) / chunks;
     dim3 grid(lane_tiles, (n_pairs + per - 1) / per);
-    zke::k_check_copies<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(cells, stride, n_lanes, pairs, n_pairs, per, fail);
+    zke::k_check_copies<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(cells, n_cells, n_lanes, pairs, n_pairs, per, fail);
     return LAUNCH_CHECK("k_check_copies");
 }
 
-int launch_check_links(const uint64_t* loop_cells, uint64_t loop_stride, uint32_t n_lanes, uint32_t limit,
-                       const uint64_t* outer_cells, uint64_t outer_stride, const zk_link* links, uint32_t n_links,
+int launch_check_links(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_lanes, uint32_t limit,
+                       const uint64_t* outer_cells, uint64_t outer_n_cells, const zk_link* links, uint32_t n_links,
                        unsigned long long* fail, void* stream) {
     if (n_lanes == 0 || n_links == 0) return 0;
     zke::k_check_links<<<grid_for(n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(
-        loop_cells, loop_stride, n_lanes, limit, outer_cells, outer_stride, links, n_links, fail);
+        loop_cells, loop_n_cells, n_lanes, limit, outer_cells, outer_n_cells, links, n_links, fail);
     return LAUNCH_CHECK("k_check_links");
 }
 

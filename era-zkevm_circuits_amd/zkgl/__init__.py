@@ -455,10 +455,12 @@ class ConstraintSystem:
         return buf
 
     def trace(self, loop_scope: bool) -> np.ndarray:
-        """Copy the scope's cells back: array [n_cells, stride] (lane-minor)."""
+        """Copy the scope's cells back as the logical array [n_cells, n_tiles*64] (cell-major, lane-minor).
+        Device storage is wave-tiled [tile][cell][64]; cell = slot * n_columns + column."""
         p, n, s = C.c_void_p(), C.c_uint64(), C.c_uint64()
         _check(lib().zk_cs_trace_ptr(self._h, int(loop_scope), C.byref(p), C.byref(n), C.byref(s)))
         out = np.empty(n.value * s.value, dtype=np.uint64)
         if out.size:
             _check(lib().zk_d2h(out.ctypes.data_as(C.c_void_p), p, C.c_size_t(out.nbytes), None))
-        return out.reshape(n.value, s.value)
+        tiles = s.value // 64
+        return np.ascontiguousarray(out.reshape(tiles, n.value, 64).transpose(1, 0, 2)).reshape(n.value, s.value)

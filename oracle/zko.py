@@ -187,7 +187,7 @@ class Scope:
 
 
 def stride_for(lanes: int) -> int:
-    return (lanes + 31) // 32 * 32
+    return (lanes + 63) // 64 * 64
 
 
 class CircuitRun:

@@ -295,11 +295,11 @@ static const unsigned char GW[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 
 uint64_t zko_scope_check(const zko_scope *s, const uint64_t *cells, size_t stride, uint32_t n_lanes,
                          uint64_t *first_key, uint64_t *n_relations) {
     uint64_t bad = 0, nrel = 0, first = ~0ull;
-    const size_t S = s->n_slots;
+    const size_t NC = s->n_slots ? s->n_trace_cells / s->n_slots : 0; /* cell = slot * n_columns + column */
 #pragma omp parallel for schedule(static) reduction(+ : bad, nrel) reduction(min : first)
     for (long lane_ = 0; lane_ < (long)n_lanes; ++lane_) {
         uint32_t lane = (uint32_t)lane_;
-#define CELL(col) cells[((size_t)(col) * S + slot) * stride + lane]
+#define CELL(col) cells[((size_t)slot * NC + (col)) * stride + lane]
 #define FAIL(j, rel) do { ++bad; uint64_t k_ = ((uint64_t)lane << 32) | ((uint64_t)slot << 12) | (((j) & 0xff) << 4) | ((rel) & 0xf); if (k_ < first) first = k_; } while (0)
         for (uint32_t slot = 0; slot < s->n_slots; ++slot) {
             const zk_row_desc *d = &s->rows[slot];

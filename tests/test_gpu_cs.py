@@ -99,10 +99,10 @@ def test_fault_injection_reports_place(zk):
     keep = gpu_run(zk, cs, outer, loop, batch)
     assert cs.check_if_satisfied()[0]
     st = cs.stats()
-    n_slots = st["loop_slots"]
+    n_cols = st["copy_columns"] + st["lookup_columns"]
     tr = cs.trace(True)
     # pick a populated trace cell in the loop scope: column 2, slot 5, lane of (instance 1, iteration 4)
-    cell, lane = 2 * n_slots + 5, 1 * limit + 4
+    cell, lane = 5 * n_cols + 2, 1 * limit + 4
     old = int(tr[cell, lane])
     cs.write_cell(True, cell, lane, (old + 1) % P)
     ok, f = cs.check_if_satisfied()
@@ -111,7 +111,7 @@ def test_fault_injection_reports_place(zk):
     assert cs.check_if_satisfied()[0]
     # outer scope
     tro = cs.trace(False)
-    cell_o = 1 * st["outer_slots"] + 3
+    cell_o = 3 * n_cols + 1
     old = int(tro[cell_o, 2])
     cs.write_cell(False, cell_o, 2, old ^ 1)
     ok, f = cs.check_if_satisfied()
