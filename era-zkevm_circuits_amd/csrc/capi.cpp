@@ -14,6 +14,8 @@ namespace zkgl {
 void ram_permutation_configure(CS& cs);
 void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
+void storage_validity_configure(CS& cs);
+void sort_and_deduplicate_storage_access_entry_point(CS& cs, uint32_t limit, bool enforce_permutation);
 void vm_shaped_entry_point(CS& cs, uint32_t limit);
 }  // namespace zkgl
 
@@ -364,6 +366,14 @@ int zk_circuit_input_words(zk_cs* cs, uint32_t* outer_words, uint32_t* loop_word
     *outer_words = cs->cs->outer_input_words();
     *loop_words = cs->cs->loop_input_words();
     return ZK_OK;
+}
+int zk_circuit_storage_validity_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::storage_validity_configure(*cs->cs); });
+}
+int zk_circuit_storage_validity(zk_cs* cs, uint32_t limit, int enforce_permutation) {
+    NEED(cs);
+    return guard([&] { zkgl::sort_and_deduplicate_storage_access_entry_point(*cs->cs, limit, enforce_permutation != 0); });
 }
 int zk_circuit_vm_shaped_configure(zk_cs* cs) {
     NEED(cs);

@@ -354,6 +354,12 @@ class ConstraintSystem:
     def ram_permutation_entry_point(self, limit: int):
         _check(lib().zk_circuit_ram_permutation(self._h, limit))
 
+    def configure_storage_validity(self):
+        _check(lib().zk_circuit_storage_validity_configure(self._h))
+
+    def sort_and_deduplicate_storage_access_entry_point(self, limit: int, enforce_permutation: bool = True):
+        _check(lib().zk_circuit_storage_validity(self._h, limit, int(enforce_permutation)))
+
     def configure_vm_shaped(self):
         _check(lib().zk_circuit_vm_shaped_configure(self._h))
 

@@ -205,6 +205,11 @@ int zk_circuit_ram_permutation(zk_cs *cs, uint32_t limit);
 int zk_circuit_ram_permutation_configure(zk_cs *cs);
 /* number of input words per lane for (outer, loop) scopes of the recorded circuit */
 int zk_circuit_input_words(zk_cs *cs, uint32_t *outer_words, uint32_t *loop_words);
+/* sort_and_deduplicate_storage_access_entry_point (src/storage_validity_by_grand_product/mod.rs:166-506).
+ * enforce_permutation = 0 drops the final lhs == rhs enforcement, i.e. checks what the reference's own test
+ * checks (the `_inner` function on the fixture of test_input.rs, mod.rs:1034-1135). */
+int zk_circuit_storage_validity_configure(zk_cs *cs);
+int zk_circuit_storage_validity(zk_cs *cs, uint32_t limit, int enforce_permutation);
 /* main_vm-shaped synthetic cycle (geometry src/main_vm/cycle.rs:959-966) */
 int zk_circuit_vm_shaped_configure(zk_cs *cs);
 int zk_circuit_vm_shaped(zk_cs *cs, uint32_t limit);

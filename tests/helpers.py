@@ -144,3 +144,29 @@ def random_instances(seed, n_inst, n_items, limit):
         u, s, nd = rn.random_ram_witness(rng, n_items)
         out.append(rn.instance(u, s, limit, nd))
     return out
+
+
+_STORAGE_CS = {}
+
+
+def storage_cs(limit, enforce_permutation=True):
+    key = (limit, enforce_permutation)
+    if key not in _STORAGE_CS:
+        cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
+        cs.configure_storage_validity()
+        cs.sort_and_deduplicate_storage_access_entry_point(limit, enforce_permutation)
+        cs.pad_and_shrink()
+        _STORAGE_CS[key] = cs
+    return _STORAGE_CS[key]
+
+
+def load_storage_fixture():
+    from oracle import storage_native as sn
+    f = json.load(open(os.path.join(GOLD, "storage_fixture.json")))
+    conv = lambda d: sn.log_query(address=int(d["address"]), key=int(d["key"]), read_value=int(d["read_value"]),
+                                  written_value=int(d["written_value"]), rw_flag=int(d["rw_flag"]), aux_byte=int(d["aux_byte"]),
+                                  rollback=int(d["rollback"]), is_service=int(d["is_service"]), shard_id=int(d["shard_id"]),
+                                  tx_number_in_block=int(d["tx_number_in_block"]), timestamp=int(d["timestamp"]))
+    unsorted = [conv(d) for d in f["unsorted"]]
+    sorted_records = [(conv(d), int(d["record_timestamp"])) for d in f["sorted"]]
+    return unsorted, sorted_records, f["limit"]

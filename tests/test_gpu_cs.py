@@ -253,3 +253,31 @@ def test_fused_pipeline_equals_separate_calls(zk):
     ok, f = cs.resolve_and_check()
     assert not ok and f.instance == 4
     del keep
+
+
+def test_storage_validity_gpu_equals_oracle(zk):
+    """config C4 circuit: reference fixture (inner logic) + seeded random logs, GPU trace bit-exact vs oracle"""
+    from helpers import load_storage_fixture, storage_cs
+    from oracle import storage_native as sn
+    unsorted, sorted_records, limit = load_storage_fixture()
+    cs = storage_cs(limit, enforce_permutation=False)
+    rng = np.random.default_rng(8)
+    insts = [sn.instance(unsorted, sorted_records, limit, enforce_permutation=False)]
+    for n in (0, 5, 16, 11):
+        u, s = sn.random_storage_witness(rng, n)
+        insts.append(sn.instance(u, s, limit))
+    outer, loop = sn.pack_streams(insts, limit)
+    keep = gpu_run(zk, cs, outer, loop, len(insts))
+    run = oracle_run(cs, outer, loop, len(insts))
+    assert_trace_equal(cs, run)
+    assert run.check()[0] == 0
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["commitment"]
+    # entry-point semantics (lhs == rhs enforced): the non-permutation fixture must now be rejected, instance 0
+    cs2 = storage_cs(limit, enforce_permutation=True)
+    keep2 = gpu_run(zk, cs2, outer, loop, len(insts))
+    ok, f = cs2.check_if_satisfied()
+    assert not ok and f.instance == 0 and f.scope == 0
+    del keep, keep2
