@@ -14,6 +14,8 @@ namespace zkgl {
 void ram_permutation_configure(CS& cs);
 void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
+void log_sorter_configure(CS& cs);
+void sort_and_deduplicate_events_entry_point(CS& cs, uint32_t limit);
 void storage_validity_configure(CS& cs);
 void sort_and_deduplicate_storage_access_entry_point(CS& cs, uint32_t limit, bool enforce_permutation);
 void vm_shaped_entry_point(CS& cs, uint32_t limit);
@@ -374,6 +376,14 @@ int zk_circuit_storage_validity_configure(zk_cs* cs) {
 int zk_circuit_storage_validity(zk_cs* cs, uint32_t limit, int enforce_permutation) {
     NEED(cs);
     return guard([&] { zkgl::sort_and_deduplicate_storage_access_entry_point(*cs->cs, limit, enforce_permutation != 0); });
+}
+int zk_circuit_log_sorter_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::log_sorter_configure(*cs->cs); });
+}
+int zk_circuit_log_sorter(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { zkgl::sort_and_deduplicate_events_entry_point(*cs->cs, limit); });
 }
 int zk_circuit_vm_shaped_configure(zk_cs* cs) {
     NEED(cs);

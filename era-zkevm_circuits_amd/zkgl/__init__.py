@@ -360,6 +360,12 @@ class ConstraintSystem:
     def sort_and_deduplicate_storage_access_entry_point(self, limit: int, enforce_permutation: bool = True):
         _check(lib().zk_circuit_storage_validity(self._h, limit, int(enforce_permutation)))
 
+    def configure_log_sorter(self):
+        _check(lib().zk_circuit_log_sorter_configure(self._h))
+
+    def sort_and_deduplicate_events_entry_point(self, limit: int):
+        _check(lib().zk_circuit_log_sorter(self._h, limit))
+
     def configure_vm_shaped(self):
         _check(lib().zk_circuit_vm_shaped_configure(self._h))
 

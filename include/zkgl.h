@@ -210,6 +210,9 @@ int zk_circuit_input_words(zk_cs *cs, uint32_t *outer_words, uint32_t *loop_word
  * checks (the `_inner` function on the fixture of test_input.rs, mod.rs:1034-1135). */
 int zk_circuit_storage_validity_configure(zk_cs *cs);
 int zk_circuit_storage_validity(zk_cs *cs, uint32_t limit, int enforce_permutation);
+/* sort_and_deduplicate_events_entry_point (src/log_sorter/mod.rs:34-232) */
+int zk_circuit_log_sorter_configure(zk_cs *cs);
+int zk_circuit_log_sorter(zk_cs *cs, uint32_t limit);
 /* main_vm-shaped synthetic cycle (geometry src/main_vm/cycle.rs:959-966) */
 int zk_circuit_vm_shaped_configure(zk_cs *cs);
 int zk_circuit_vm_shaped(zk_cs *cs, uint32_t limit);

@@ -281,3 +281,25 @@ def test_storage_validity_gpu_equals_oracle(zk):
     ok, f = cs2.check_if_satisfied()
     assert not ok and f.instance == 0 and f.scope == 0
     del keep, keep2
+
+
+def test_log_sorter_gpu_equals_oracle(zk):
+    from oracle import log_sorter_native as ln
+    from test_log_sorter_host import load_log_sorter_fixture, log_sorter_cs
+    u, s, limit = load_log_sorter_fixture()
+    cs = log_sorter_cs(limit)
+    rng = np.random.default_rng(4)
+    insts = [ln.instance(u, s, limit), ln.instance([], [], limit)]
+    for n in (3, 7, 5):
+        uu, ss = ln.random_events(rng, n, rollback_frac=0.4)
+        insts.append(ln.instance(uu, ss, limit))
+    assert all(i["satisfiable"] for i in insts)
+    outer, loop = ln.pack_streams(insts, limit)
+    keep = gpu_run(zk, cs, outer, loop, len(insts))
+    run = oracle_run(cs, outer, loop, len(insts))
+    assert_trace_equal(cs, run)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["commitment"]
+    del keep
