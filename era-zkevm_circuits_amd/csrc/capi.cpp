@@ -165,6 +165,10 @@ int zk_memory_query_encode(const uint64_t* q, size_t n, uint64_t* enc, void* str
     NEED_INIT();
     return dev_rc(zkdev::launch_memory_query_encode(q, n, enc, stream));
 }
+int zk_execution_context_encode(const uint64_t* rec, size_t n, uint64_t* enc, void* stream) {
+    NEED_INIT();
+    return dev_rc(zkdev::launch_execution_context_encode(rec, n, enc, stream));
+}
 int zk_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* challenges, size_t enc_len, size_t n,
                      uint64_t init, uint64_t* acc_out, uint64_t* scratch, void* stream) {
     NEED_INIT();

@@ -30,6 +30,7 @@ int launch_commit_encoding(const uint64_t* in, size_t len, size_t n, uint64_t* o
 int launch_queue_full_chain(const uint64_t* enc, size_t nq, size_t items, uint64_t* tail_io, uint64_t* states_out,
                             void* stream);
 int launch_memory_query_encode(const uint64_t* q, size_t n, uint64_t* enc, void* stream);
+int launch_execution_context_encode(const uint64_t* rec, size_t n, uint64_t* enc, void* stream);
 int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* ch, size_t enc_len, size_t n,
                          uint64_t init, uint64_t* acc, uint64_t* scratch, void* stream);
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, void* stream);

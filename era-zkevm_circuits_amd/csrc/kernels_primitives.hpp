@@ -181,6 +181,28 @@ __global__ __launch_bounds__(TPB) void k_memory_query_encode(const uint64_t* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// a11: ExecutionContextRecord::encode (/root/reference/src/base_structures/vm_state/saved_context.rs:111-266)
+// 42 columns in (declaration order, saved_context.rs:36-66), 32 columns out; pure bit packing (< 2^57).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_execution_context_encode(const uint64_t* __restrict__ rec, size_t n,
+                                                                  uint64_t* __restrict__ enc) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    auto R = [&](int f) { return rec[(size_t)f * n + i]; };
+    auto W = [&](int j, uint64_t v) { enc[(size_t)j * n + i] = v; };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { W(k, R(19 + k)); W(4 + k, R(23 + k)); W(23 + k, R(37 + k)); }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { W(8 + k, R(10 + k)); W(13 + k, R(k)); W(18 + k, R(5 + k)); }
+    const uint64_t seg = R(27);
+    W(27, R(15) + (R(28) << 32) + (R(34) << 48) + (R(32) << 56));
+    W(28, R(16) + (R(29) << 32) + (R(35) << 48) + (R(33) << 56));
+    W(29, R(31) + (R(30) << 32) + (R(36) << 48) + (R(41) << 56));
+    W(30, R(17) + ((seg & 0xff) << 32) + (((seg >> 8) & 0xff) << 40));
+    W(31, R(18) + (((seg >> 16) & 0xff) << 32) + (((seg >> 24) & 0xff) << 40));
+}
+
+// ------------------------------------------------------------------------------------------
 // K4: permutation grand product (/root/reference/src/utils.rs:81-137, one repetition).
 //   factor[i] = flags[i] ? ch[L] + sum_j enc[j][i]*ch[j] : 1
 //   acc[i]    = init * prod_{t<=i} factor[t]

@@ -73,6 +73,11 @@ int launch_memory_query_encode(const uint64_t* q, size_t n, uint64_t* enc, void*
     zkk::k_memory_query_encode<<<grid_for(n, zkk::TPB), zkk::TPB, 0, (hipStream_t)stream>>>(q, n, enc);
     return LAUNCH_CHECK("k_memory_query_encode");
 }
+int launch_execution_context_encode(const uint64_t* rec, size_t n, uint64_t* enc, void* stream) {
+    if (n == 0) return 0;
+    zkk::k_execution_context_encode<<<grid_for(n, zkk::TPB), zkk::TPB, 0, (hipStream_t)stream>>>(rec, n, enc);
+    return LAUNCH_CHECK("k_execution_context_encode");
+}
 int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* ch, size_t enc_len, size_t n,
                          uint64_t init, uint64_t* acc, uint64_t* scratch, void* stream) {
     if (n == 0) return 0;

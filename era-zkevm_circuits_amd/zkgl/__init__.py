@@ -211,6 +211,10 @@ def memory_query_encode(q, n, enc, stream=None):
     _check(lib().zk_memory_query_encode(_ptr(q), C.c_size_t(n), _ptr(enc), _ptr(stream)))
 
 
+def execution_context_encode(rec, n, enc, stream=None):
+    _check(lib().zk_execution_context_encode(_ptr(rec), C.c_size_t(n), _ptr(enc), _ptr(stream)))
+
+
 def grand_product(enc, flags, challenges, enc_len, n, init, acc_out, scratch, stream=None):
     _check(lib().zk_grand_product(_ptr(enc), _ptr(flags), _ptr(challenges), C.c_size_t(enc_len), C.c_size_t(n),
                                   C.c_uint64(init), _ptr(acc_out), _ptr(scratch), _ptr(stream)))

@@ -87,6 +87,11 @@ int zk_queue_full_push_chain(const uint64_t *enc, size_t nq, size_t items, uint6
 /* q[f*n + i], f < 13 (ts, page, index, rw, is_ptr, value limbs 0..7); enc[j*n + i], j < 8 */
 int zk_memory_query_encode(const uint64_t *q, size_t n, uint64_t *enc, void *stream);
 
+/* ---------------- a11: ExecutionContextRecord::encode, column form ------------------------- */
+/* rec[f*n + i], f < 42 in declaration order (src/base_structures/vm_state/saved_context.rs:36-66);
+ * enc[j*n + i], j < 32 (saved_context.rs:111-266) */
+int zk_execution_context_encode(const uint64_t *rec, size_t n, uint64_t *enc, void *stream);
+
 /* ---------------- K4: permutation grand product -------------------------------------------- */
 /* enc[j*n + i] (j < enc_len), flags[i] in {0,1}, challenges[enc_len+1];
  * acc_out[i] = init * prod_{t<=i, flags[t]} (ch[enc_len] + sum_j enc[j][t]*ch[j])

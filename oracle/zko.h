@@ -75,6 +75,13 @@ void zko_queue_tail4_push20(uint64_t tail[4], const uint64_t enc[20]);
  * q = {timestamp, memory_page, index, rw_flag, is_ptr, value limbs 0..7 (u32 LE)} */
 void zko_memory_query_encode(const uint64_t q[13], uint64_t enc[8]);
 
+/* ExecutionContextRecord::encode (src/base_structures/vm_state/saved_context.rs:111-266).
+ * rec = flattened record in declaration order (saved_context.rs:36-66): this[5], caller[5], code_address[5],
+ * code_page, base_page, heap_upper_bound, aux_heap_upper_bound, reverted_queue_head[4], reverted_queue_tail[4],
+ * reverted_queue_segment_len, pc, sp, exception_handler_loc, ergs_remaining, is_static_execution,
+ * is_kernel_mode, this_shard_id, caller_shard_id, code_shard_id, context_u128_value_composite[4], is_local_call */
+void zko_execution_context_encode(const uint64_t rec[42], uint64_t enc[32]);
+
 /* ---- grand product (src/utils.rs:81-137) ---- */
 /* contributions: contrib[i] = ch[enc_len] + sum_j enc[i*enc_len+j]*ch[j];
  * running accumulators: acc_out[i] = value of the accumulator AFTER item i,

@@ -136,6 +136,13 @@ def memory_query_encode(q13):
     return [int(x) for x in out]
 
 
+def execution_context_encode(rec42):
+    r = u64arr(rec42); out = np.zeros(32, dtype=np.uint64)
+    assert r.size == 42
+    lib().zko_execution_context_encode(_p(r), _p(out))
+    return [int(x) for x in out]
+
+
 def grand_product(enc: np.ndarray, flags, challenges, init=1):
     """enc [n, enc_len] row-major; returns running accumulator after each item"""
     enc = np.ascontiguousarray(enc, dtype=np.uint64)

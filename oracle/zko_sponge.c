@@ -84,6 +84,25 @@ void zko_memory_query_encode(const uint64_t q[13], uint64_t enc[8]) {
     enc[7] = v[4];
 }
 
+/* ExecutionContextRecord::encode — /root/reference/src/base_structures/vm_state/saved_context.rs:111-266 */
+void zko_execution_context_encode(const uint64_t r[42], uint64_t e[32]) {
+    const uint64_t *this_ = r, *caller = r + 5, *code_address = r + 10;
+    uint64_t code_page = r[15], base_page = r[16], heap_ub = r[17], aux_heap_ub = r[18];
+    const uint64_t *rq_head = r + 19, *rq_tail = r + 23;
+    uint64_t seg_len = r[27], pc = r[28], sp = r[29], eh_loc = r[30], ergs = r[31];
+    uint64_t is_static = r[32], is_kernel = r[33], this_shard = r[34], caller_shard = r[35], code_shard = r[36];
+    const uint64_t *ctx128 = r + 37;
+    uint64_t is_local = r[41];
+    for (int i = 0; i < 4; ++i) { e[i] = rq_head[i]; e[4 + i] = rq_tail[i]; }
+    for (int i = 0; i < 5; ++i) { e[8 + i] = code_address[i]; e[13 + i] = this_[i]; e[18 + i] = caller[i]; }
+    for (int i = 0; i < 4; ++i) e[23 + i] = ctx128[i];
+    e[27] = code_page + (pc << 32) + (this_shard << 48) + (is_static << 56);
+    e[28] = base_page + (sp << 32) + (caller_shard << 48) + (is_kernel << 56);
+    e[29] = ergs + (eh_loc << 32) + (code_shard << 48) + (is_local << 56);
+    e[30] = heap_ub + ((seg_len & 0xff) << 32) + (((seg_len >> 8) & 0xff) << 40);
+    e[31] = aux_heap_ub + (((seg_len >> 16) & 0xff) << 32) + (((seg_len >> 24) & 0xff) << 40);
+}
+
 /* accumulate_grand_products — /root/reference/src/utils.rs:81-137, one repetition */
 void zko_grand_product(const uint64_t *enc, const uint8_t *flags, const uint64_t *ch,
                        size_t enc_len, size_t n, uint64_t init, uint64_t *acc_out) {

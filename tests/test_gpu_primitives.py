@@ -137,6 +137,23 @@ def test_memory_query_encode(zk, oracle):
         assert [int(x) for x in got[:, i]] == oracle.memory_query_encode([int(x) for x in q[:, i]])
 
 
+def test_execution_context_encode(zk, oracle):
+    rng = np.random.default_rng(47)
+    n = 513
+    rec = np.zeros((42, n), dtype=np.uint64)
+    rec[:] = rng.integers(0, 2**32, size=(42, n), dtype=np.uint64)
+    rec[19:27] = rng.integers(0, 2**63, size=(8, n), dtype=np.uint64) % np.uint64(P)   # reverted queue head / tail
+    rec[28:31] = rng.integers(0, 2**16, size=(3, n))                                   # pc, sp, exception handler
+    rec[32:34] = rng.integers(0, 2, size=(2, n)); rec[41] = rng.integers(0, 2, size=n)  # booleans
+    rec[34:37] = rng.integers(0, 256, size=(3, n))                                     # shard ids
+    rec[:, 0] = 0
+    d_r, d_e = zk.DeviceBuffer.from_numpy(rec), zk.DeviceBuffer(32 * n)
+    zk.execution_context_encode(d_r, n, d_e); zk.sync()
+    got = d_e.to_numpy().reshape(32, n)
+    for i in range(n):
+        assert [int(x) for x in got[:, i]] == oracle.execution_context_encode([int(x) for x in rec[:, i]])
+
+
 @pytest.mark.parametrize("n,enc_len", [(1, 8), (5, 8), (1023, 8), (1024, 8), (1025, 20), (300000, 8), (70000, 20)])
 def test_grand_product(zk, oracle, n, enc_len):
     rng = np.random.default_rng(500 + n)

@@ -157,6 +157,32 @@ def test_memory_query_encode():
         assert all(e < P for e in exp)
 
 
+def test_execution_context_record_encode():
+    """a11: 42 variables -> 32 elements (src/base_structures/vm_state/saved_context.rs:111-266)"""
+    names = (["this"] * 5 + ["caller"] * 5 + ["code_address"] * 5 + ["code_page", "base_page", "heap_ub", "aux_heap_ub"] +
+             ["rq_head"] * 4 + ["rq_tail"] * 4 + ["seg_len", "pc", "sp", "eh_loc", "ergs", "is_static", "is_kernel",
+                                                   "this_shard", "caller_shard", "code_shard"] + ["ctx128"] * 4 + ["is_local"])
+    assert len(names) == 42
+    for _ in range(20):
+        rec = []
+        for nm in names:
+            if nm in ("rq_head", "rq_tail"): rec.append(rand_fe(1)[0])
+            elif nm in ("pc", "sp", "eh_loc"): rec.append(int(rng.integers(0, 2**16)))
+            elif nm.startswith("is_"): rec.append(int(rng.integers(0, 2)))
+            elif nm.endswith("_shard"): rec.append(int(rng.integers(0, 256)))
+            else: rec.append(int(rng.integers(0, 2**32)))
+        f = {nm: [rec[i] for i in range(42) if names[i] == nm] for nm in set(names)}
+        one = lambda k: f[k][0]
+        sb = [(one("seg_len") >> (8 * i)) & 0xFF for i in range(4)]
+        exp = (f["rq_head"] + f["rq_tail"] + f["code_address"] + f["this"] + f["caller"] + f["ctx128"] + [
+            one("code_page") + (one("pc") << 32) + (one("this_shard") << 48) + (one("is_static") << 56),
+            one("base_page") + (one("sp") << 32) + (one("caller_shard") << 48) + (one("is_kernel") << 56),
+            one("ergs") + (one("eh_loc") << 32) + (one("code_shard") << 48) + (one("is_local") << 56),
+            one("heap_ub") + (sb[0] << 32) + (sb[1] << 40),
+            one("aux_heap_ub") + (sb[2] << 32) + (sb[3] << 40)])
+        assert zko.execution_context_encode(rec) == exp and all(e < P for e in exp)
+
+
 def test_grand_product_and_permutation_property():
     n, L = 40, 8
     enc = np.array([rand_fe(L) for _ in range(n)], dtype=np.uint64)
