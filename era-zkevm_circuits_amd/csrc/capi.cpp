@@ -14,6 +14,8 @@ namespace zkgl {
 void ram_permutation_configure(CS& cs);
 void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
+void keccak_configure(CS& cs);
+void keccak256_blocks_entry_point(CS& cs, uint32_t n_blocks);
 void log_sorter_configure(CS& cs);
 void sort_and_deduplicate_events_entry_point(CS& cs, uint32_t limit);
 void storage_validity_configure(CS& cs);
@@ -388,6 +390,14 @@ int zk_circuit_log_sorter_configure(zk_cs* cs) {
 int zk_circuit_log_sorter(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { zkgl::sort_and_deduplicate_events_entry_point(*cs->cs, limit); });
+}
+int zk_circuit_keccak_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::keccak_configure(*cs->cs); });
+}
+int zk_circuit_keccak256_blocks(zk_cs* cs, uint32_t n_blocks) {
+    NEED(cs);
+    return guard([&] { zkgl::keccak256_blocks_entry_point(*cs->cs, n_blocks); });
 }
 int zk_circuit_vm_shaped_configure(zk_cs* cs) {
     NEED(cs);

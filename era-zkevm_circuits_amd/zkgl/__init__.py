@@ -370,6 +370,12 @@ class ConstraintSystem:
     def sort_and_deduplicate_events_entry_point(self, limit: int):
         _check(lib().zk_circuit_log_sorter(self._h, limit))
 
+    def configure_keccak(self):
+        _check(lib().zk_circuit_keccak_configure(self._h))
+
+    def keccak256_blocks_entry_point(self, n_blocks: int):
+        _check(lib().zk_circuit_keccak256_blocks(self._h, n_blocks))
+
     def configure_vm_shaped(self):
         _check(lib().zk_circuit_vm_shaped_configure(self._h))
 

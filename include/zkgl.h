@@ -218,6 +218,11 @@ int zk_circuit_storage_validity(zk_cs *cs, uint32_t limit, int enforce_permutati
 /* sort_and_deduplicate_events_entry_point (src/log_sorter/mod.rs:34-232) */
 int zk_circuit_log_sorter_configure(zk_cs *cs);
 int zk_circuit_log_sorter(zk_cs *cs, uint32_t limit);
+/* Keccak-256 over n_blocks pre-padded 136-byte blocks, Keccak-f[1600] through 8-bit lookup tables
+ * (keccak256_absorb_and_run_permutation, src/keccak256_round_function/mod.rs:796-838; eip_4844's keccak256
+ * gadget, src/eip_4844/mod.rs:156-163).  Public inputs = the 32 digest bytes. */
+int zk_circuit_keccak_configure(zk_cs *cs);
+int zk_circuit_keccak256_blocks(zk_cs *cs, uint32_t n_blocks);
 /* main_vm-shaped synthetic cycle (geometry src/main_vm/cycle.rs:959-966) */
 int zk_circuit_vm_shaped_configure(zk_cs *cs);
 int zk_circuit_vm_shaped(zk_cs *cs, uint32_t limit);

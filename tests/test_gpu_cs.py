@@ -283,6 +283,31 @@ def test_storage_validity_gpu_equals_oracle(zk):
     del keep, keep2
 
 
+def test_keccak256_gpu_digests(zk):
+    """K8 on the GPU: lookup-table Keccak-f, digests equal the software Keccak-256 for the reference's lengths
+    (src/keccak256_round_function/mod.rs:1096-1144), trace bit-exact vs the oracle interpreter"""
+    from test_keccak_host import TABLE_ROWS, keccak_cs, loop_stream
+    n_blocks = 2
+    cs = keccak_cs(n_blocks)
+    rng = np.random.default_rng(136)
+    msgs = [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in (136, 166, 180, 200, 137, 271)] * 11   # 66 instances
+    outer = np.zeros((0, len(msgs)), dtype=np.uint64)
+    raw = loop_stream(msgs, n_blocks)
+    cs.set_batch(len(msgs))
+    d_l = zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, m in enumerate(msgs):
+        assert bytes(cs.public_inputs(i)) == zko.keccak256(m)
+    seeded = d_l.to_numpy().reshape(raw.shape)
+    run = zko.CircuitRun(cs.export(False), cs.export(True), len(msgs), TABLE_ROWS)
+    run.resolve(outer, seeded)
+    assert_trace_equal(cs, run)
+    assert np.array_equal(cs.multiplicities(3), run.mult[3 * TABLE_ROWS:4 * TABLE_ROWS])
+
+
 def test_log_sorter_gpu_equals_oracle(zk):
     from oracle import log_sorter_native as ln
     from test_log_sorter_host import load_log_sorter_fixture, log_sorter_cs
