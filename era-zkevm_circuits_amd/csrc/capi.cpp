@@ -238,6 +238,10 @@ int zk_cs_lookup(zk_cs* cs, uint32_t table_id, const zk_var* keys, uint32_t n_ke
     NEED(cs); NEED(keys); NEED(vals);
     return guard([&] { cs->cs->lookup(table_id, keys, n_keys, vals, n_vals); });
 }
+int zk_cs_side_begin(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { cs->cs->side_begin(); });
+}
 int zk_cs_loop_begin(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { cs->cs->loop_begin(limit); });

@@ -191,6 +191,26 @@ void ram_permutation_entry_point(CS& cs, uint32_t limit) {
     g.enforce_equal(unsorted_state.length.v, sorted_state.length.v);
     zk_var outer_one = g.one();
 
+    // commitments of observable_input / hidden_fsm_input (from_full_form, src/fsm_input_output/mod.rs:196-201) do not
+    // depend on the loop: side phase, overlapped with the loop kernel
+    cs.side_begin();
+    std::vector<zk_var> obs_in;
+    for (auto v : g.flatten(obs_unsorted)) obs_in.push_back(v);
+    for (auto v : g.flatten(obs_sorted)) obs_in.push_back(v);
+    obs_in.push_back(obs_nondet_len.v);
+    std::vector<zk_var> fsm_in;
+    for (auto& x : fsm_lhs) fsm_in.push_back(x.v);
+    for (auto& x : fsm_rhs) fsm_in.push_back(x.v);
+    for (auto v : g.flatten(fsm_unsorted)) fsm_in.push_back(v);
+    for (auto v : g.flatten(fsm_sorted)) fsm_in.push_back(v);
+    for (auto& x : fsm_prev_sorting_key) fsm_in.push_back(x.v);
+    for (auto& x : fsm_prev_full_key) fsm_in.push_back(x.v);
+    for (auto& x : fsm_prev_value.inner) fsm_in.push_back(x.v);
+    fsm_in.push_back(fsm_prev_is_ptr.v);
+    fsm_in.push_back(fsm_nondet.v);
+    auto c_obs_in = g.commit_encoding(obs_in);
+    auto c_fsm_in = g.commit_encoding(fsm_in);
+
     // =========================== loop body (mod.rs:246-381), recorded once ===========================
     cs.loop_begin(limit);
     auto carry_in = [&](zk_var init_outer) {  // state entering the iteration
@@ -361,25 +381,8 @@ void ram_permutation_entry_point(CS& cs, uint32_t limit) {
     for (int i = 32; i < 46; ++i) fsm_out.push_back(fin[i]);  // prev sorting key, full key, value, is_ptr
     fsm_out.push_back(nondet_f.v);
 
-    std::vector<zk_var> obs_in;
-    for (auto v : g.flatten(obs_unsorted)) obs_in.push_back(v);
-    for (auto v : g.flatten(obs_sorted)) obs_in.push_back(v);
-    obs_in.push_back(obs_nondet_len.v);
-    std::vector<zk_var> fsm_in;
-    for (auto& x : fsm_lhs) fsm_in.push_back(x.v);
-    for (auto& x : fsm_rhs) fsm_in.push_back(x.v);
-    for (auto v : g.flatten(fsm_unsorted)) fsm_in.push_back(v);
-    for (auto v : g.flatten(fsm_sorted)) fsm_in.push_back(v);
-    for (auto& x : fsm_prev_sorting_key) fsm_in.push_back(x.v);
-    for (auto& x : fsm_prev_full_key) fsm_in.push_back(x.v);
-    for (auto& x : fsm_prev_value.inner) fsm_in.push_back(x.v);
-    fsm_in.push_back(fsm_prev_is_ptr.v);
-    fsm_in.push_back(fsm_nondet.v);
-
-    // ClosedFormInputCompactForm::from_full_form (src/fsm_input_output/mod.rs:178-253)
-    auto c_obs_in = g.commit_encoding(obs_in);
+    // ClosedFormInputCompactForm::from_full_form (src/fsm_input_output/mod.rs:178-253); c_obs_in / c_fsm_in: side phase
     auto c_obs_out = g.commit_encoding({});  // observable_output = ()
-    auto c_fsm_in = g.commit_encoding(fsm_in);
     auto c_fsm_out = g.commit_encoding(fsm_out);
     Num zero_num = g.num_const(0);
     std::vector<zk_var> compact = {start_flag.v, completed.v};

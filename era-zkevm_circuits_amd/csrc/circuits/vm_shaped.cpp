@@ -233,6 +233,12 @@ void vm_shaped_entry_point(CS& cs, uint32_t limit) {
     for (auto v : s0.flags) cs.place_gate(ZK_GATE_BOOLEAN, &v, 1, nullptr, 0);
     for (auto& r : s0.reg) for (auto v : r) g.range_check_u32(v);
 
+    // commitments that do not depend on the loop: side phase, overlapped with the loop kernel
+    cs.side_begin();
+    std::vector<zk_var> obs_in(init.begin() + NREG * 8 + NREG, init.begin() + NREG * 8 + NREG + 39);   // 39 words (SURVEY App. C)
+    auto c_obs_in = g.commit_encoding(obs_in);
+    auto c_fsm_in = g.commit_encoding(init);
+
     // ---------------- loop: one VM cycle (cycle.rs:28-795), recorded once ----------------
     cs.loop_begin(limit);
     std::vector<zk_var> in_flat(STATE_WORDS);
@@ -476,11 +482,8 @@ void vm_shaped_entry_point(CS& cs, uint32_t limit) {
     // ---------------- epilogue: final state, commitments, public inputs (main_vm/mod.rs:201-231) ----------------
     std::vector<zk_var> fin(STATE_WORDS);
     for (size_t i = 0; i < STATE_WORDS; ++i) fin[i] = cs.loop_last(out_flat[i]);
-    std::vector<zk_var> obs_in(init.begin() + NREG * 8 + NREG, init.begin() + NREG * 8 + NREG + 39);   // 39 words (SURVEY App. C)
     std::vector<zk_var> obs_out(fin.begin(), fin.begin() + 59);                                        // 59 words
-    auto c_obs_in = g.commit_encoding(obs_in);
     auto c_obs_out = g.commit_encoding(obs_out);
-    auto c_fsm_in = g.commit_encoding(init);
     auto c_fsm_out = g.commit_encoding(fin);
     std::vector<zk_var> compact = {g.one(), g.one()};  // start_flag = completion_flag = true (single chunk)
     for (auto& c : c_obs_in) compact.push_back(c.v);

@@ -310,6 +310,15 @@ void CS::loop_begin(uint32_t limit) {
     if (limit == 0) throw ZkError(ZK_ERR_INVALID, "loop limit must be > 0");
     in_loop_ = true;
     limit_ = limit;
+    if (outer_.pre_ops == SIZE_MAX) outer_.pre_ops = outer_.ops.size();  // no side phase recorded
+    outer_.side_ops = outer_.ops.size();
+}
+
+// Everything recorded between side_begin() and loop_begin() is outer-scope work that neither the loop needs
+// (it must not be loop_import-ed) nor depends on the loop: the fused pipeline runs it CONCURRENTLY with the
+// loop kernel (e.g. the commitments of observable_input / hidden_fsm_input).
+void CS::side_begin() {
+    if (in_loop_ || loop_done_ || outer_.pre_ops != SIZE_MAX) throw ZkError(ZK_ERR_INVALID, "side_begin: once, before loop_begin");
     outer_.pre_ops = outer_.ops.size();
 }
 void CS::loop_end() {
@@ -429,6 +438,7 @@ void CS::emit_scope(Scope& s) {
     s.cells_written = 0;
     for (size_t oi = 0; oi < s.ops.size(); ++oi) {
         if (!s.is_loop && oi == s.pre_ops) s.pre_words = (uint32_t)s.prog.size();
+        if (!s.is_loop && oi == s.side_ops) s.side_words = (uint32_t)s.prog.size();
         const OpRec& op = s.ops[oi];
         s.prog.push_back((uint32_t)op.opcode | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
         for (auto& in : op.ins) {
@@ -454,6 +464,8 @@ void CS::emit_scope(Scope& s) {
         }
     }
     if (!s.is_loop && s.pre_ops >= s.ops.size()) s.pre_words = (uint32_t)s.prog.size();
+    if (!s.is_loop && s.side_ops >= s.ops.size()) s.side_words = (uint32_t)s.prog.size();
+    if (!s.is_loop && s.side_words < s.pre_words) s.side_words = s.pre_words;
     for (auto& g : s.gates)
         for (uint32_t v : g.vars)
             if (!defined[v]) throw ZkError(ZK_ERR_UNRESOLVED, "gate references a variable without a witness producer");
@@ -478,7 +490,7 @@ void CS::upload_scope(Scope& s) {
 void CS::finalize() {
     if (finalized_) throw ZkError(ZK_ERR_INVALID, "already finalized");
     if (in_loop_) throw ZkError(ZK_ERR_INVALID, "finalize inside loop scope");
-    if (!loop_done_) { limit_ = 0; outer_.pre_ops = outer_.ops.size(); }
+    if (!loop_done_) { limit_ = 0; outer_.pre_ops = outer_.side_ops = outer_.ops.size(); }
     place_scope(outer_);
     place_scope(loop_);
     // pre-phase outer vars imported by the loop must be produced before the loop: verified by op order
@@ -749,8 +761,9 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hip_check(hipEventRecord(E(2), st), "event");
     if (limit_) dev_check(zkdev::launch_witness(la, 0, (uint32_t)loop_.prog.size(), st));   // LOOP
     hip_check(hipEventRecord(E(3), st), "event");
+    dev_check(zkdev::launch_witness(oa, outer_.pre_words, outer_.side_words, ax));             // outer SIDE (|| LOOP)
     hip_check(hipStreamWaitEvent(ax, E(3), 0), "wait");
-    dev_check(zkdev::launch_witness(oa, outer_.pre_words, (uint32_t)outer_.prog.size(), ax));  // outer POST
+    dev_check(zkdev::launch_witness(oa, outer_.side_words, (uint32_t)outer_.prog.size(), ax));  // outer POST
     dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_), ax));
     dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies,
                                          (uint32_t)outer_.copies.size(), d_fail_, ax));

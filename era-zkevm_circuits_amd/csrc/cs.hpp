@@ -71,14 +71,15 @@ struct Scope {
     std::unordered_map<uint64_t, uint32_t> const_pool_idx;
     uint32_t n_input_words = 0;
     std::unordered_map<uint32_t, uint32_t> input_word;  // var index -> input stream word (ZK_OP_INPUT)
-    size_t pre_ops = SIZE_MAX;  // outer scope: ops recorded before loop_begin
+    size_t pre_ops = SIZE_MAX;   // outer scope: ops recorded before side_begin/loop_begin (the loop may import them)
+    size_t side_ops = SIZE_MAX;  // outer scope: end of the side phase (== loop_begin position)
 
     // ---- filled by finalize ----
     uint32_t n_slots = 0, n_gate_slots = 0, n_lookup_slots = 0;
     uint32_t n_trace_cells = 0, n_cells = 0, n_scratch = 0;
     std::vector<std::vector<uint32_t>> var_cells;  // per var: cells, [0] = home
     std::vector<uint32_t> prog;
-    uint32_t pre_words = 0;
+    uint32_t pre_words = 0, side_words = 0;
     std::vector<zk_row_desc> rows;
     std::vector<uint64_t> rowconsts;
     std::vector<zk_lookup_row_desc> lrows;
@@ -122,6 +123,7 @@ class CS {
     void emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uint32_t n_in, const zk_var* outs,
                  uint32_t n_out, const uint64_t* imm, uint32_t n_imm);
     void lookup(uint32_t table_id, const zk_var* keys, uint32_t n_keys, zk_var* vals, uint32_t n_vals);
+    void side_begin();
     void loop_begin(uint32_t limit);
     void loop_end();
     void link(uint32_t kind, zk_var loop_var, zk_var other);

@@ -321,6 +321,9 @@ class ConstraintSystem:
         _check(lib().zk_cs_lookup(self._h, table_id, ka, len(keys), va, n_vals))
         return [va[i] for i in range(n_vals)]
 
+    def side_begin(self):
+        _check(lib().zk_cs_side_begin(self._h))
+
     def loop_begin(self, limit: int):
         _check(lib().zk_cs_loop_begin(self._h, limit))
 

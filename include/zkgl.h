@@ -141,6 +141,9 @@ int zk_cs_emit_op(zk_cs *cs, uint32_t opcode, uint32_t a, uint32_t b, const zk_v
 int zk_cs_lookup(zk_cs *cs, uint32_t table_id, const zk_var *keys, uint32_t n_keys, zk_var *vals,
                  uint32_t n_vals);
 /* loop scope: the `for _cycle in 0..limit` body (src/ram_permutation/mod.rs:246) is recorded ONCE */
+/* optional: outer-scope work recorded between zk_cs_side_begin and zk_cs_loop_begin neither feeds the loop
+ * nor depends on it; the fused pipeline runs it concurrently with the loop kernel */
+int zk_cs_side_begin(zk_cs *cs);
 int zk_cs_loop_begin(zk_cs *cs, uint32_t limit);
 int zk_cs_loop_end(zk_cs *cs);
 int zk_cs_link(zk_cs *cs, uint32_t link_kind, zk_var loop_var, zk_var other_var);
