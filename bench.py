@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="independent circuit instances per GPU per step")
+    ap.add_argument("--batch", type=int, default=145, help="independent circuit instances per GPU per step")
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -117,10 +117,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    zkgl.init(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise RuntimeError("bench.py needs a GPU: libzkgl has no CPU fallback")
+    dev_index = local_rank % n_dev
+    shared_gpu = world > n_dev            # only in smoke tests of the N>1 path on a 1-GPU box: RCCL refuses duplicate devices
+    if world > 1:
+        dist.init_process_group("gloo" if shared_gpu else "nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(dev_index)
+    zkgl.init(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = torch.device("cpu") if shared_gpu else dev
 
     cs, limit = build_vm_cs(zkgl, args.log2_rows)
     st = cs.stats()
@@ -161,9 +168,9 @@ def main():
     elapsed = time.perf_counter() - t0
     # the path's only collective: gather the 4-element input commitments of every instance
     from zkgl.dist import gather_commitments, max_over_ranks
-    elapsed = max_over_ranks(elapsed, dev)
+    elapsed = max_over_ranks(elapsed, coll_dev)
     local = np.array([cs.public_inputs(i) for i in range(B)], dtype=np.uint64)
-    commits = gather_commitments(local, dev)   # [world, B, 4] u64: RCCL all_gather over xGMI when world > 1
+    commits = gather_commitments(local, coll_dev)   # [world, B, 4] u64: RCCL all_gather over xGMI when world > 1
     if rank == 0:
         n_inst = B * world
         constraints = st["constraints_per_instance"] * n_inst * args.steps
