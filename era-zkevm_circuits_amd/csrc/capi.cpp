@@ -15,6 +15,8 @@ void ram_permutation_configure(CS& cs);
 void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
 void keccak_configure(CS& cs);
+void sha256_configure(CS& cs);
+void sha256_blocks_entry_point(CS& cs, uint32_t n_blocks);
 void keccak256_blocks_entry_point(CS& cs, uint32_t n_blocks);
 void log_sorter_configure(CS& cs);
 void sort_and_deduplicate_events_entry_point(CS& cs, uint32_t limit);
@@ -402,6 +404,14 @@ int zk_circuit_keccak_configure(zk_cs* cs) {
 int zk_circuit_keccak256_blocks(zk_cs* cs, uint32_t n_blocks) {
     NEED(cs);
     return guard([&] { zkgl::keccak256_blocks_entry_point(*cs->cs, n_blocks); });
+}
+int zk_circuit_sha256_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::sha256_configure(*cs->cs); });
+}
+int zk_circuit_sha256_blocks(zk_cs* cs, uint32_t n_blocks) {
+    NEED(cs);
+    return guard([&] { zkgl::sha256_blocks_entry_point(*cs->cs, n_blocks); });
 }
 int zk_circuit_vm_shaped_configure(zk_cs* cs) {
     NEED(cs);

@@ -379,6 +379,12 @@ class ConstraintSystem:
     def keccak256_blocks_entry_point(self, n_blocks: int):
         _check(lib().zk_circuit_keccak256_blocks(self._h, n_blocks))
 
+    def configure_sha256(self):
+        _check(lib().zk_circuit_sha256_configure(self._h))
+
+    def sha256_blocks_entry_point(self, n_blocks: int):
+        _check(lib().zk_circuit_sha256_blocks(self._h, n_blocks))
+
     def configure_vm_shaped(self):
         _check(lib().zk_circuit_vm_shaped_configure(self._h))
 

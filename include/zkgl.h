@@ -226,6 +226,10 @@ int zk_circuit_log_sorter(zk_cs *cs, uint32_t limit);
  * gadget, src/eip_4844/mod.rs:156-163).  Public inputs = the 32 digest bytes. */
 int zk_circuit_keccak_configure(zk_cs *cs);
 int zk_circuit_keccak256_blocks(zk_cs *cs, uint32_t n_blocks);
+/* SHA-256 over n_blocks pre-padded 64-byte blocks (compression step of sha256_precompile_inner,
+ * src/sha256_round_function/mod.rs:271-285) through 8-bit lookup tables.  Public inputs = the 32 digest bytes. */
+int zk_circuit_sha256_configure(zk_cs *cs);
+int zk_circuit_sha256_blocks(zk_cs *cs, uint32_t n_blocks);
 /* main_vm-shaped synthetic cycle (geometry src/main_vm/cycle.rs:959-966) */
 int zk_circuit_vm_shaped_configure(zk_cs *cs);
 int zk_circuit_vm_shaped(zk_cs *cs, uint32_t limit);

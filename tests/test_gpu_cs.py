@@ -308,6 +308,27 @@ def test_keccak256_gpu_digests(zk):
     assert np.array_equal(cs.multiplicities(3), run.mult[3 * TABLE_ROWS:4 * TABLE_ROWS])
 
 
+def test_sha256_gpu_digests(zk):
+    import hashlib
+    from test_sha256_host import TABLE_ROWS, loop_stream, sha_cs
+    n_blocks = 2
+    cs = sha_cs(n_blocks)
+    rng = np.random.default_rng(256)
+    msgs = [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in (56, 64, 100, 119, 57)] * 14   # 70 instances
+    raw = loop_stream(msgs, n_blocks)
+    cs.set_batch(len(msgs))
+    d_l = zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, m in enumerate(msgs):
+        assert bytes(cs.public_inputs(i)) == hashlib.sha256(m).digest()
+    run = zko.CircuitRun(cs.export(False), cs.export(True), len(msgs), TABLE_ROWS)
+    run.resolve(np.zeros((0, len(msgs)), dtype=np.uint64), d_l.to_numpy().reshape(raw.shape))
+    assert_trace_equal(cs, run)
+
+
 def test_log_sorter_gpu_equals_oracle(zk):
     from oracle import log_sorter_native as ln
     from test_log_sorter_host import load_log_sorter_fixture, log_sorter_cs
