@@ -181,6 +181,15 @@ def main():
         algo_bytes = B * st["limit"] * (st["cells_written_loop"] + n_loop) * 8
         k_ms = float(np.mean(loop_ms))
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        # HBM traffic per launch: PMC-measured ratio (FETCH_SIZE x2 + WRITE_SIZE over algorithmic bytes, separate rocprofv3
+        # --pmc passes at a smaller batch, profiles/pmc_r1.json) scaled to this launch; null when the profile file is absent
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_r1.json")))
+            traffic = pmc["traffic_over_algorithmic"] * algo_bytes
+            traffic_src = f"profiles/pmc_r1.json ratio {pmc['traffic_over_algorithmic']:.3f} measured at batch {pmc['batch']}"
+        except Exception:
+            pass
         out = {
             "metric": "constraints/s + witness-rows/s, main_vm 2^20 rows", "value": constraints / elapsed, "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -191,7 +200,7 @@ def main():
                        "constraints_per_instance": st["constraints_per_instance"], "parallelism": f"independent instances x{world}",
                        "input_seeding_s": round(t_seed, 3)},
             "roofline": {"bound": "hbm", "kernel": "zke::k_witness_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": k_ms,
                          "populated_cells_per_cycle": st["cells_written_loop"],
                          "other_kernels_ms": {"loop_gates_plus_copies_check": float(np.mean(check_ms)), "k_check_gates_loop": float(np.mean(gate_ms)),
