@@ -17,6 +17,7 @@ void vm_shaped_configure(CS& cs);
 void keccak_configure(CS& cs);
 void sha256_configure(CS& cs);
 void sha256_blocks_entry_point(CS& cs, uint32_t n_blocks);
+void sha256_round_function_entry_point(CS& cs, uint32_t limit);
 void keccak256_blocks_entry_point(CS& cs, uint32_t n_blocks);
 void log_sorter_configure(CS& cs);
 void sort_and_deduplicate_events_entry_point(CS& cs, uint32_t limit);
@@ -412,6 +413,10 @@ int zk_circuit_sha256_configure(zk_cs* cs) {
 int zk_circuit_sha256_blocks(zk_cs* cs, uint32_t n_blocks) {
     NEED(cs);
     return guard([&] { zkgl::sha256_blocks_entry_point(*cs->cs, n_blocks); });
+}
+int zk_circuit_sha256_round_function(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { zkgl::sha256_round_function_entry_point(*cs->cs, limit); });
 }
 int zk_circuit_vm_shaped_configure(zk_cs* cs) {
     NEED(cs);

@@ -385,6 +385,9 @@ class ConstraintSystem:
     def sha256_blocks_entry_point(self, n_blocks: int):
         _check(lib().zk_circuit_sha256_blocks(self._h, n_blocks))
 
+    def sha256_round_function_entry_point(self, limit: int):
+        _check(lib().zk_circuit_sha256_round_function(self._h, limit))
+
     def configure_vm_shaped(self):
         _check(lib().zk_circuit_vm_shaped_configure(self._h))
 

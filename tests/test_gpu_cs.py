@@ -349,3 +349,48 @@ def test_log_sorter_gpu_equals_oracle(zk):
     for i, inst in enumerate(insts):
         assert cs.public_inputs(i) == inst["commitment"]
     del keep
+
+
+def test_sha256_round_function_fsm_gpu(zk):
+    """a18 on the GPU: the precompile FSM (request pop, 2 reads + 1 write per cycle, compression); carried words
+    seeded on the device from the raw request / memory-read stream; trace bit-exact vs the oracle interpreter,
+    public inputs equal the native restatement, digests in the pushed writes equal hashlib (native side)."""
+    import hashlib
+    from oracle import sha256_native as sn
+    from test_sha256_fsm_host import TABLE_ROWS, fsm_cs, make_requests, messages, streams
+    limit = 5
+    cs = fsm_cs(limit)
+    rng = np.random.default_rng(18)
+    insts, all_msgs = [], []
+    for k in range(66):
+        lengths = [(3,), (0, 55, 56), (150, 64), (), (119, 1)][k % 5]
+        msgs = messages(rng, lengths)
+        insts.append(sn.instance(make_requests(msgs), limit))
+        all_msgs.append(msgs)
+    for inst, msgs in zip(insts, all_msgs):
+        writes = [q for q in inst["pushed"] if q[3] == 1]
+        assert [sum(l << (32 * i) for i, l in enumerate(q[5:13])).to_bytes(32, "big") for q in writes] == \
+            [hashlib.sha256(m).digest() for m in msgs]
+    outer, loop = streams(insts, limit)
+    raw = loop.copy()
+    raw[:sn.CARRIED, :] = 0
+    cs.set_batch(len(insts))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(raw.shape), loop), "device seeding differs from the native FSM trajectory"
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+    run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
+    run.resolve(outer, loop)
+    assert_trace_equal(cs, run)
+    # a corrupted memory read is rejected in the loop scope of the right instance
+    bad = loop.copy()
+    bad[97, 7 * limit] ^= 1
+    d_b = zk.DeviceBuffer.from_numpy(bad)
+    cs.bind_inputs(True, d_b, bad.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert not ok and f.instance == 7
