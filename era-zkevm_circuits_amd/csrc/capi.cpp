@@ -19,6 +19,7 @@ void sha256_configure(CS& cs);
 void sha256_blocks_entry_point(CS& cs, uint32_t n_blocks);
 void sha256_round_function_entry_point(CS& cs, uint32_t limit);
 void keccak256_blocks_entry_point(CS& cs, uint32_t n_blocks);
+void keccak256_round_function_entry_point(CS& cs, uint32_t limit);
 void log_sorter_configure(CS& cs);
 void sort_and_deduplicate_events_entry_point(CS& cs, uint32_t limit);
 void storage_validity_configure(CS& cs);
@@ -405,6 +406,10 @@ int zk_circuit_keccak_configure(zk_cs* cs) {
 int zk_circuit_keccak256_blocks(zk_cs* cs, uint32_t n_blocks) {
     NEED(cs);
     return guard([&] { zkgl::keccak256_blocks_entry_point(*cs->cs, n_blocks); });
+}
+int zk_circuit_keccak256_round_function(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { zkgl::keccak256_round_function_entry_point(*cs->cs, limit); });
 }
 int zk_circuit_sha256_configure(zk_cs* cs) {
     NEED(cs);

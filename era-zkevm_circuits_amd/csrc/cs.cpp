@@ -263,6 +263,7 @@ void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uin
     case ZK_OP_POSEIDON2: need(12, 12, 0); break;
     case ZK_OP_P2_ROUNDS: need(12, 962, 0); break;
     case ZK_OP_U32MULADD: need(4, 2, 0); break;
+    case ZK_OP_DIVREM: need(1, 2, 0); if (b == 0 || b > 65535) throw ZkError(ZK_ERR_INVALID, "DIVREM: divisor must be 1..65535"); break;
     default: throw ZkError(ZK_ERR_INVALID, "emit_op: opcode not recordable through this entry");
     }
     for (uint32_t i = 0; i < n_imm; ++i) {

@@ -172,6 +172,28 @@ std::pair<UInt32, Boolean> G::overflowing_add(UInt32 a, UInt32 b) {
     return {UInt32{outs[0]}, Boolean{outs[1]}};
 }
 
+std::pair<UInt32, UInt32> G::div_by_constant(UInt32 a, uint32_t c) {
+    if (c == 0 || c > 256) throw ZkError(ZK_ERR_INVALID, "div_by_constant: divisor must be 1..256");
+    zk_var outs[2] = {cs.alloc_var(), cs.alloc_var()};  // quotient, remainder
+    cs.emit_op(ZK_OP_DIVREM, 0, c, &a.v, 1, outs, 2, nullptr, 0);
+    enforce_equal(linear_combination({{outs[0], c}, {outs[1], 1}}), a.v);
+    range_check_u32(outs[0]);
+    range_check_u8_pair(outs[1], linear_combination({{one(), c - 1}, {outs[1], GL_P - 1}}));  // 0 <= r <= c-1
+    return {UInt32{outs[0]}, UInt32{outs[1]}};
+}
+
+std::pair<UInt8, Boolean> G::overflowing_sub_u8(UInt8 a, UInt8 b) {
+    zk_var outs[2] = {cs.alloc_var(), cs.alloc_var()};  // diff, borrow
+    zk_var ins[3] = {a.v, b.v, zero()};
+    cs.emit_op(ZK_OP_USUB, 8, 0, ins, 3, outs, 2, nullptr, 0);
+    zk_var vars[5] = {b.v, outs[0], ins[2], a.v, outs[1]};  // b + diff + 0 = a + 2^8 * borrow
+    uint64_t k = 1ull << 8;
+    cs.place_gate(ZK_GATE_UINTX_ADD, vars, 5, &k, 1);
+    cs.place_gate(ZK_GATE_BOOLEAN, &outs[1], 1, nullptr, 0);
+    range_check_u8_pair(outs[0], outs[0]);
+    return {UInt8{outs[0]}, Boolean{outs[1]}};
+}
+
 std::pair<UInt32, UInt32> G::u32_fma_with_carry(UInt32 a, UInt32 b, UInt32 c, UInt32 d) {
     zk_var outs[2] = {cs.alloc_var(), cs.alloc_var()};
     zk_var ins[4] = {a.v, b.v, c.v, d.v};

@@ -89,6 +89,10 @@ class G {  // gadget context bound to one CS
     std::pair<UInt32, Boolean> overflowing_sub_with_borrow_in(UInt32 a, UInt32 b, Boolean borrow_in);
     std::pair<UInt32, Boolean> overflowing_add(UInt32 a, UInt32 b);
     UInt32 increment_unchecked(UInt32 a) { return {add(a.v, one())}; }
+    // UInt32::div_by_constant: a = q*c + r, r < c (c <= 256), q range-checked
+    std::pair<UInt32, UInt32> div_by_constant(UInt32 a, uint32_t c);
+    // UInt8::overflowing_sub: (a - b) mod 2^8, borrow
+    std::pair<UInt8, Boolean> overflowing_sub_u8(UInt8 a, UInt8 b);
     // a*b + c + d = lo + 2^32 hi  [UInt32::fma_with_carry, src/main_vm/opcodes/mod.rs:152-158]
     std::pair<UInt32, UInt32> u32_fma_with_carry(UInt32 a, UInt32 b, UInt32 c, UInt32 d);
 

@@ -291,6 +291,11 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             st(r & 0xffffffffull);
             st(r >> 32);
         } break;
+        case ZK_OP_DIVREM: {
+            uint64_t x = ld(P.at(pc++));
+            st(x / pb);
+            st(x % pb);
+        } break;
         default:
             return;  // malformed program: host validates before upload
         }

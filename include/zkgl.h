@@ -226,6 +226,10 @@ int zk_circuit_log_sorter(zk_cs *cs, uint32_t limit);
  * gadget, src/eip_4844/mod.rs:156-163).  Public inputs = the 32 digest bytes. */
 int zk_circuit_keccak_configure(zk_cs *cs);
 int zk_circuit_keccak256_blocks(zk_cs *cs, uint32_t n_blocks);
+/* keccak256_round_function_entry_point (src/keccak256_round_function/mod.rs:672-794): the precompile FSM — request
+ * queue pop, 6 conditional unaligned memory reads into the 192-byte ByteBuffer, padding, one Keccak-f per cycle,
+ * conditional digest write; `limit` cycles.  Uses zk_circuit_keccak_configure.  Outer stream 474 words, loop 507. */
+int zk_circuit_keccak256_round_function(zk_cs *cs, uint32_t limit);
 /* SHA-256 over n_blocks pre-padded 64-byte blocks (compression step of sha256_precompile_inner,
  * src/sha256_round_function/mod.rs:271-285) through 8-bit lookup tables.  Public inputs = the 32 digest bytes. */
 int zk_circuit_sha256_configure(zk_cs *cs);

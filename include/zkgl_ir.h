@@ -48,6 +48,7 @@ enum zk_opcode {
     ZK_OP_LOOP_LAST = 15,/* outer scope, post phase: [loop cell word] -> value at the last iteration */
     ZK_OP_U32MULADD = 16,/* [a, b, c, d] -> lo, hi of a*b + c + d  (u32 each)         (UInt32::fma_with_carry) */
     ZK_OP_ADD_CONSTMUL = 17, /* reserved */
+    ZK_OP_DIVREM = 18,   /* b=divisor (1..65535); [x] -> x / b, x % b as integers       (UInt32::div_by_constant) */
     ZK_OP__COUNT
 };
 

@@ -245,6 +245,11 @@ static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
             st(c, prog, &pc, lane, r & 0xffffffffull);
             st(c, prog, &pc, lane, r >> 32);
         } break;
+        case ZK_OP_DIVREM: {
+            uint64_t x = ld(c, prog[pc++], lane, inst);
+            st(c, prog, &pc, lane, x / pb);
+            st(c, prog, &pc, lane, x % pb);
+        } break;
         default: return -1;
         }
     }

@@ -394,3 +394,43 @@ def test_sha256_round_function_fsm_gpu(zk):
     cs.bind_inputs(True, d_b, bad.shape[0])
     ok, f = cs.resolve_and_check()
     assert not ok and f.instance == 7
+
+
+def test_keccak256_round_function_fsm_gpu(zk):
+    """a17 on the GPU: the nine reference cases (src/keccak256_round_function/mod.rs:1096-1144) plus multi-request
+    instances, x8 to fill two wave tiles; carried words seeded on the device; trace bit-exact vs the oracle interpreter."""
+    from oracle import keccak_native as kn
+    from test_keccak_fsm_host import REFERENCE_CASES, TABLE_ROWS, fsm_cs, make_requests, reference_case, streams
+    limit = 2
+    cs = fsm_cs(limit)
+    cases = [reference_case(l, u) for l, u in REFERENCE_CASES]
+    for data, inst in cases:
+        q = inst["pushed"][-1]
+        assert q[3] == 1 and sum(l << (32 * i) for i, l in enumerate(q[5:13])).to_bytes(32, "big") == zko.keccak256(data)
+    insts = [c[1] for c in cases]
+    rng = np.random.default_rng(17)
+    insts.append(kn.instance(make_requests([bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in (0, 40)], [9, 33]), limit))
+    insts.append(kn.instance([], limit))
+    insts = insts * 6   # 66 instances
+    outer, loop = streams(insts, limit)
+    raw = loop.copy()
+    raw[:kn.CARRIED, :] = 0
+    cs.set_batch(len(insts))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(raw.shape), loop), "device seeding differs from the native FSM trajectory"
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+    run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
+    run.resolve(outer, loop)
+    assert_trace_equal(cs, run)
+    bad = loop.copy()
+    bad[460, 12 * limit] ^= 1   # instance 12 = reference case (180, 0): corrupt its first memory read
+    d_b = zk.DeviceBuffer.from_numpy(bad)
+    cs.bind_inputs(True, d_b, bad.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert not ok and f.instance == 12
