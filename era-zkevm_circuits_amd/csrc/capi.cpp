@@ -16,6 +16,8 @@ void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
 void keccak_configure(CS& cs);
 void sha256_configure(CS& cs);
+void eip_4844_configure(CS& cs);
+void eip_4844_entry_point(CS& cs, uint32_t n_chunks);
 void sha256_blocks_entry_point(CS& cs, uint32_t n_blocks);
 void sha256_round_function_entry_point(CS& cs, uint32_t limit);
 void keccak256_blocks_entry_point(CS& cs, uint32_t n_blocks);
@@ -258,6 +260,10 @@ int zk_cs_link(zk_cs* cs, uint32_t kind, zk_var loop_var, zk_var other) {
     NEED(cs);
     return guard([&] { cs->cs->link(kind, loop_var, other); });
 }
+int zk_cs_stream_link(zk_cs* cs, const zk_var* a_vars, uint32_t period_a, const zk_var* b_vars, uint32_t period_b, uint32_t n_total) {
+    NEED(cs); NEED(a_vars); NEED(b_vars);
+    return guard([&] { cs->cs->stream_link(a_vars, period_a, b_vars, period_b, n_total); });
+}
 int zk_cs_loop_last(zk_cs* cs, zk_var loop_var, zk_var* outer_out) {
     NEED(cs); NEED(outer_out);
     return guard([&] { *outer_out = cs->cs->loop_last(loop_var); });
@@ -410,6 +416,14 @@ int zk_circuit_keccak256_blocks(zk_cs* cs, uint32_t n_blocks) {
 int zk_circuit_keccak256_round_function(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { zkgl::keccak256_round_function_entry_point(*cs->cs, limit); });
+}
+int zk_circuit_eip_4844_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::eip_4844_configure(*cs->cs); });
+}
+int zk_circuit_eip_4844(zk_cs* cs, uint32_t n_chunks) {
+    NEED(cs);
+    return guard([&] { zkgl::eip_4844_entry_point(*cs->cs, n_chunks); });
 }
 int zk_circuit_sha256_configure(zk_cs* cs) {
     NEED(cs);

@@ -65,6 +65,7 @@ CS::~CS() {
     if (d_table_words_) hipFree(d_table_words_);
     if (d_mult_) hipFree(d_mult_);
     if (d_links_) hipFree(d_links_);
+    for (auto p : d_streams_) if (p) hipFree(p);
     if (d_carries_) hipFree(d_carries_);
     if (d_fail_) hipFree(d_fail_);
     if (aux_stream_) hipStreamDestroy((hipStream_t)aux_stream_);
@@ -263,6 +264,12 @@ void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uin
     case ZK_OP_POSEIDON2: need(12, 12, 0); break;
     case ZK_OP_P2_ROUNDS: need(12, 962, 0); break;
     case ZK_OP_U32MULADD: need(4, 2, 0); break;
+    case ZK_OP_NN_MULMOD:
+        if (a == 0 || a > 17 || b == 0 || b > 17 || a + b < 16 || n_in != a + b || n_imm != 16 || n_out != a + b - 15 + 16)
+            throw ZkError(ZK_ERR_INVALID, "NN_MULMOD: bad shape");
+        if (imm[15] == 0 || imm[15] > 0xffff) throw ZkError(ZK_ERR_INVALID, "NN_MULMOD: top modulus limb must be a non-zero u16");
+        s.uses_bigint = true;
+        break;
     case ZK_OP_DIVREM: need(1, 2, 0); if (b == 0 || b > 65535) throw ZkError(ZK_ERR_INVALID, "DIVREM: divisor must be 1..65535"); break;
     default: throw ZkError(ZK_ERR_INVALID, "emit_op: opcode not recordable through this entry");
     }
@@ -333,6 +340,17 @@ void CS::link(uint32_t kind, zk_var loop_var, zk_var other) {
     check_var(loop_var, true);
     check_var(other, kind == ZK_LINK_CARRY);
     links_raw_.push_back({kind, var_index(loop_var), var_index(other), 0});
+}
+
+void CS::stream_link(const zk_var* a, uint32_t pa, const zk_var* b, uint32_t pb, uint32_t n_total) {
+    if (!in_loop_) throw ZkError(ZK_ERR_INVALID, "stream_link outside the loop");
+    if (!pa || !pb || !n_total || (uint64_t)limit_ * pa < n_total || (uint64_t)limit_ * pb < n_total)
+        throw ZkError(ZK_ERR_INVALID, "stream_link: n_total exceeds limit * period");
+    StreamRec r;
+    r.n_total = n_total;
+    for (uint32_t i = 0; i < pa; ++i) { check_var(a[i], true); r.a.push_back(var_index(a[i])); }
+    for (uint32_t i = 0; i < pb; ++i) { check_var(b[i], true); r.b.push_back(var_index(b[i])); }
+    streams_raw_.push_back(std::move(r));
 }
 
 zk_var CS::loop_last(zk_var loop_var) {
@@ -532,6 +550,14 @@ void CS::finalize() {
         r.other_cell = (l.kind == ZK_LINK_CARRY ? loop_ : outer_).var_cells[l.other_cell][0];
         links_.push_back(r);
     }
+    streams_.clear();
+    for (auto& sr : streams_raw_) {
+        StreamRec r;
+        r.n_total = sr.n_total;
+        for (auto v : sr.a) r.a.push_back(loop_.var_cells[v][0]);
+        for (auto v : sr.b) r.b.push_back(loop_.var_cells[v][0]);
+        streams_.push_back(std::move(r));
+    }
     // tables
     std::vector<zk_table_desc> tdesc(tables_.size() + 1);
     std::memset(tdesc.data(), 0, tdesc.size() * sizeof(zk_table_desc));
@@ -562,6 +588,11 @@ void CS::ensure_uploaded() {
     d_tables_ = upload(tdesc_host_);
     d_table_words_ = upload(table_words_host_);
     d_links_ = upload(links_);
+    for (auto& sr : streams_) {
+        std::vector<uint32_t> cells(sr.a);
+        cells.insert(cells.end(), sr.b.begin(), sr.b.end());
+        d_streams_.push_back(upload(cells));
+    }
     d_carries_ = (void*)upload(carries_);
     hip_check(hipMalloc((void**)&d_fail_, 8 * sizeof(unsigned long long)), "hipMalloc fail words");
     for (auto& e : ev_) {
@@ -613,6 +644,7 @@ static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Sco
     a.limit = s.is_loop ? limit : 1; a.is_loop = s.is_loop ? 1 : 0;
     a.tables = tables; a.table_words = words; a.mult = mult; a.total_table_rows = total_rows;
     a.loop_cells = loop.d_cells; a.loop_n_cells = loop.n_cells; a.loop_limit = limit;
+    a.uses_bigint = s.uses_bigint ? 1 : 0;
     return a;
 }
 
@@ -685,6 +717,7 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
                                              (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
         dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.n_cells, loop_.n_lanes, limit_, outer_.d_cells,
                                             outer_.n_cells, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
+        check_streams(st);
     } else {
         hip_check(hipEventRecord((hipEvent_t)ev_[6], st), "event");
     }
@@ -697,6 +730,15 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
     hipEventElapsedTime(&g, (hipEvent_t)ev_[5], (hipEvent_t)ev_[6]);
     ms_[2] = tot; ms_[3] = g;
     return decode_failure(f, first);
+}
+
+void CS::check_streams(void* stream) {
+    for (size_t i = 0; i < streams_.size(); ++i) {
+        const auto& sr = streams_[i];
+        dev_check(zkdev::launch_check_stream(loop_.d_cells, loop_.n_cells, batch_, limit_, d_streams_[i], (uint32_t)sr.a.size(),
+                                             d_streams_[i] + sr.a.size(), (uint32_t)sr.b.size(), sr.n_total, (uint32_t)i,
+                                             d_fail_ + 3, stream));
+    }
 }
 
 int CS::decode_failure(const unsigned long long* f, zk_failure* first) const {
@@ -725,7 +767,8 @@ int CS::decode_failure(const unsigned long long* f, zk_failure* first) const {
         }
         if (ff[2] != NONE) {
             uint32_t li = (uint32_t)(ff[2] & 0xffffffffu);
-            fill(ff[2], links_[li].loop_cell, 0x300u | links_[li].kind, li);
+            if (li & 0x80000000u) fill(ff[2], 0, 0x400u, li & 0x7fffffffu);  // stream link: relation = stream index
+            else fill(ff[2], links_[li].loop_cell, 0x300u | links_[li].kind, li);
             return ZK_ERR_UNSATISFIED;
         }
     }
@@ -779,9 +822,11 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     }
     hip_check(hipEventRecord(E(6), st), "event");
     hip_check(hipStreamWaitEvent(st, E(4), 0), "wait");
-    if (limit_)
+    if (limit_) {
         dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.n_cells, loop_.n_lanes, limit_, outer_.d_cells,
                                             outer_.n_cells, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
+        check_streams(st);
+    }
     hip_check(hipEventRecord(E(7), st), "event");
     unsigned long long f[8];
     hip_check(hipMemcpyAsync(f, d_fail_, sizeof f, hipMemcpyDeviceToHost, st), "memcpy fail");
@@ -874,13 +919,20 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
     auto p64 = [&](uint64_t v) { o.push_back((uint32_t)v); o.push_back((uint32_t)(v >> 32)); };
     std::vector<uint64_t> words;
     for (auto& t : tables_) words.insert(words.end(), t.rows.begin(), t.rows.end());
-    uint32_t hdr[20] = {0x5a4b4732u, s.is_loop ? 1u : 0u, s.n_cells, s.n_trace_cells, s.n_slots,
+    std::vector<uint32_t> stream_words;
+    if (loop_scope)
+        for (auto& sr : streams_) {
+            stream_words.push_back((uint32_t)sr.a.size()); stream_words.push_back((uint32_t)sr.b.size()); stream_words.push_back(sr.n_total);
+            stream_words.insert(stream_words.end(), sr.a.begin(), sr.a.end());
+            stream_words.insert(stream_words.end(), sr.b.begin(), sr.b.end());
+        }
+    uint32_t hdr[21] = {0x5a4b4733u, s.is_loop ? 1u : 0u, s.n_cells, s.n_trace_cells, s.n_slots,
                         geo_.num_columns_under_copy_permutation, lookup_width_, s.n_input_words, limit_, s.pre_words,
                         (uint32_t)s.prog.size(), (uint32_t)s.const_pool.size(), (uint32_t)s.rows.size(),
                         (uint32_t)s.rowconsts.size(), (uint32_t)s.lrows.size(), (uint32_t)s.copies.size(),
                         (uint32_t)tables_.size() + 1, (uint32_t)words.size(), (uint32_t)(loop_scope ? links_.size() : 0),
-                        (uint32_t)(loop_scope ? carries_.size() : 0)};
-    o.insert(o.end(), hdr, hdr + 20);
+                        (uint32_t)(loop_scope ? carries_.size() : 0), (uint32_t)stream_words.size()};
+    o.insert(o.end(), hdr, hdr + 21);
     o.insert(o.end(), s.prog.begin(), s.prog.end());
     for (uint64_t c : s.const_pool) p64(c);
     for (auto& r : s.rows) { o.push_back(r.kind); o.push_back(r.n_instances); o.push_back(r.const_off); o.push_back(r.n_consts); }
@@ -897,6 +949,7 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
         for (auto& l : links_) { o.push_back(l.kind); o.push_back(l.loop_cell); o.push_back(l.other_cell); o.push_back(0); }
     if (loop_scope)
         for (auto& c : carries_) { o.push_back(c.word); o.push_back(c.out_cell); o.push_back(c.first_outer_cell); o.push_back(c.has_first); }
+    o.insert(o.end(), stream_words.begin(), stream_words.end());
     return o;
 }
 

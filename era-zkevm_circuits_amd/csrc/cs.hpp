@@ -71,6 +71,7 @@ struct Scope {
     std::unordered_map<uint64_t, uint32_t> const_pool_idx;
     uint32_t n_input_words = 0;
     std::unordered_map<uint32_t, uint32_t> input_word;  // var index -> input stream word (ZK_OP_INPUT)
+    bool uses_bigint = false;    // an op of the big-integer family (ZK_OP_NN_MULMOD) was recorded
     size_t pre_ops = SIZE_MAX;   // outer scope: ops recorded before side_begin/loop_begin (the loop may import them)
     size_t side_ops = SIZE_MAX;  // outer scope: end of the side phase (== loop_begin position)
 
@@ -127,6 +128,7 @@ class CS {
     void loop_begin(uint32_t limit);
     void loop_end();
     void link(uint32_t kind, zk_var loop_var, zk_var other);
+    void stream_link(const zk_var* a, uint32_t pa, const zk_var* b, uint32_t pb, uint32_t n_total);
     zk_var loop_last(zk_var loop_var);
     zk_var loop_import(zk_var outer_var);
     uint64_t next_available_row() const;
@@ -171,6 +173,7 @@ class CS {
     void free_scope_device(Scope& s);
     void check_var(zk_var v, bool want_loop) const;
     int decode_failure(const unsigned long long* f, zk_failure* first) const;
+    void check_streams(void* stream);
     zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail) const;
 
     zk_geometry geo_;
@@ -185,6 +188,9 @@ class CS {
     std::vector<zk_link> links_raw_;  // vars, resolved to cells at finalize
     std::vector<zk_link> links_;
     std::vector<uint32_t> public_vars_;
+    struct StreamRec { std::vector<uint32_t> a, b; uint32_t n_total; };  // loop var indices -> home cells at finalize
+    std::vector<StreamRec> streams_raw_, streams_;
+    std::vector<uint32_t*> d_streams_;  // per stream: a cells then b cells
 
     // device-wide
     uint32_t batch_ = 0;

@@ -13,6 +13,7 @@ struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     const uint64_t* outer_cells; uint64_t outer_n_cells; uint32_t limit; uint32_t is_loop;
     const zk_table_desc* tables; const uint64_t* table_words; uint32_t* mult; uint32_t total_table_rows;
     const uint64_t* loop_cells; uint64_t loop_n_cells; uint32_t loop_limit;
+    uint32_t uses_bigint;  // host only: the program contains ZK_OP_NN_MULMOD -> launch the *_bigint kernel variants
 };
 struct CheckArgs {  // mirrors zke::CheckDev
     const uint64_t* cells; uint64_t n_cells; uint32_t n_cols; uint32_t n_lanes; uint32_t n_slots;
@@ -40,6 +41,9 @@ int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uin
 int launch_check_gates(const CheckArgs& cd, void* stream);
 int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs,
                         uint32_t n_pairs, unsigned long long* fail, void* stream);
+int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
+                        const uint32_t* a_cells, uint32_t pa, const uint32_t* b_cells, uint32_t pb, uint32_t n_total,
+                        uint32_t stream_index, unsigned long long* fail, void* stream);
 int launch_check_links(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_lanes, uint32_t limit,
                        const uint64_t* outer_cells, uint64_t outer_n_cells, const zk_link* links, uint32_t n_links,
                        unsigned long long* fail, void* stream);

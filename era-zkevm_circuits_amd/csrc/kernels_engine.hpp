@@ -122,6 +122,66 @@ struct ProgWindow {
     }
 };
 
+// Big-integer witness helper of ZK_OP_NN_MULMOD: out = q[nq] | r[16] with A*B = q*M + r over base-2^16 limbs.
+// Schoolbook product with carry propagation, then Knuth algorithm D (32-bit arithmetic only).  Cold path:
+// kept out of line so that the interpreter loop's register budget and code size are not affected.
+__device__ __noinline__ void nn_mulmod(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, const uint32_t* m,
+                                       uint32_t nq, uint32_t* out) {
+    constexpr uint32_t N = 16, MAXP = 40;
+    uint32_t un[MAXP + 1], v[N];
+    const uint32_t np = na + nb + 2;
+    uint64_t carry = 0;
+    for (uint32_t k = 0; k < np; ++k) {
+        uint64_t acc = carry;
+        for (uint32_t i = 0; i < na; ++i) {
+            const uint32_t j = k - i;
+            if (j < nb) acc += (uint64_t)a[i] * b[j];
+        }
+        un[k] = (uint32_t)(acc & 0xffff);
+        carry = acc >> 16;
+    }
+    const uint32_t s = __clz(m[N - 1]) - 16;  // normalisation shift (top modulus limb is non-zero)
+    for (uint32_t i = N; i-- > 0;) v[i] = ((m[i] << s) | (i ? (m[i - 1] >> (16 - s)) : 0)) & 0xffff;
+    un[np] = un[np - 1] >> (16 - s);
+    for (uint32_t i = np; i-- > 1;) un[i] = ((un[i] << s) | (un[i - 1] >> (16 - s))) & 0xffff;
+    un[0] = (un[0] << s) & 0xffff;
+    for (uint32_t jj = np - N + 1; jj-- > 0;) {
+        const uint32_t num = (un[jj + N] << 16) | un[jj + N - 1];
+        uint32_t qhat = num / v[N - 1], rhat = num % v[N - 1];
+        while (qhat >= 65536 || qhat * v[N - 2] > ((rhat << 16) | un[jj + N - 2])) {
+            --qhat;
+            rhat += v[N - 1];
+            if (rhat >= 65536) break;
+        }
+        uint32_t mc = 0;
+        int32_t borrow = 0;
+        for (uint32_t i = 0; i < N; ++i) {
+            const uint32_t p = qhat * v[i] + mc;
+            mc = p >> 16;
+            int32_t t = (int32_t)un[i + jj] - (int32_t)(p & 0xffff) - borrow;
+            borrow = t < 0;
+            un[i + jj] = (uint32_t)t & 0xffff;
+        }
+        int32_t t = (int32_t)un[jj + N] - (int32_t)mc - borrow;
+        un[jj + N] = (uint32_t)t & 0xffff;
+        if (t < 0) {  // qhat was one too large: add the divisor back
+            --qhat;
+            uint32_t c = 0;
+            for (uint32_t i = 0; i < N; ++i) {
+                const uint32_t w = un[i + jj] + v[i] + c;
+                un[i + jj] = w & 0xffff;
+                c = w >> 16;
+            }
+            un[jj + N] = (un[jj + N] + c) & 0xffff;
+        }
+        if (jj < nq) out[jj] = qhat;
+    }
+    for (uint32_t i = 0; i < N; ++i) out[nq + i] = ((un[i] >> s) | (un[i + 1] << (16 - s))) & 0xffff;
+}
+
+// WITH_BIGINT: kernels compiled with the ZK_OP_NN_MULMOD case (an out-of-line call that costs the caller ~20 VGPRs
+// and 500 B of scratch); the launcher picks them only for programs that contain the op.
+template <bool WITH_BIGINT>
 __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                          uint32_t word_begin, uint32_t word_end) {
     uint64_t* __restrict__ cells = sc.cells + cell_off(sc.n_cells, 0, lane);  // this lane's column of its tile
@@ -291,6 +351,16 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             st(r & 0xffffffffull);
             st(r >> 32);
         } break;
+        case ZK_OP_NN_MULMOD: if constexpr (WITH_BIGINT) {
+            uint32_t mv[16], av[17], bv[17], res[19 + 16];
+            for (uint32_t i = 0; i < 16; ++i) mv[i] = (uint32_t)ld(P.at(pc + i));
+            for (uint32_t i = 0; i < pa; ++i) av[i] = (uint32_t)ld(P.at(pc + 16 + i));
+            for (uint32_t i = 0; i < pb; ++i) bv[i] = (uint32_t)ld(P.at(pc + 16 + pa + i));
+            pc += 16 + pa + pb;
+            const uint32_t nq = pa + pb - 15;
+            nn_mulmod(av, pa, bv, pb, mv, nq, res);
+            for (uint32_t i = 0; i < nq + 16; ++i) st(res[i]);
+        } else { return; } break;
         case ZK_OP_DIVREM: {
             uint64_t x = ld(P.at(pc++));
             st(x / pb);
@@ -304,18 +374,25 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 
 // Two symbols for the same interpreter so that profiles separate the loop-scope launch (the dominant,
 // HBM-bound kernel: B*limit lanes) from the outer-scope launches (B lanes, latency-bound).
+template <bool WITH_BIGINT>
 __device__ __forceinline__ void witness_entry(const ScopeDev& sc, uint32_t word_begin, uint32_t word_end) {
     uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
     const bool active = lane < sc.n_lanes;
     lane = active ? lane : sc.n_lanes - 1;
-    run_lane(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
+    run_lane<WITH_BIGINT>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
 }
 __global__ __launch_bounds__(TPB) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
-    witness_entry(sc, word_begin, word_end);
+    witness_entry<false>(sc, word_begin, word_end);
 }
 __global__ __launch_bounds__(TPB) void k_witness_outer(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
-    witness_entry(sc, word_begin, word_end);
+    witness_entry<false>(sc, word_begin, word_end);
+}
+__global__ __launch_bounds__(TPB) void k_witness_loop_bigint(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
+    witness_entry<true>(sc, word_begin, word_end);
+}
+__global__ __launch_bounds__(TPB) void k_witness_outer_bigint(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
+    witness_entry<true>(sc, word_begin, word_end);
 }
 
 // Sequential seeding mode (generic, slow): thread == instance, iterations in order.  Before
@@ -324,6 +401,7 @@ __global__ __launch_bounds__(TPB) void k_witness_outer(ScopeDev sc, uint32_t wor
 // needs no precomputed per-iteration state.  The parallel mode afterwards reproduces the same
 // trace from the seeded stream.
 struct CarryDev { uint32_t word, out_cell, first_outer_cell, has_first; };
+template <bool WITH_BIGINT>
 __global__ __launch_bounds__(64) void k_witness_seq(ScopeDev sc, const CarryDev* carries, uint32_t n_carries,
                                                     uint64_t* inputs_rw, uint32_t n_instances) {
     uint32_t inst = blockIdx.x * 64 + threadIdx.x;
@@ -342,7 +420,7 @@ __global__ __launch_bounds__(64) void k_witness_seq(ScopeDev sc, const CarryDev*
             }
         }
         __threadfence();
-        run_lane(sc, lane, inst, active, 0, sc.n_words);
+        run_lane<WITH_BIGINT>(sc, lane, inst, active, 0, sc.n_words);
         __threadfence();
     }
 }
@@ -514,6 +592,20 @@ __global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict_
         }
         if (!ok) atomicMin(fail + 2, ((unsigned long long)lane << 32) | i);
     }
+}
+
+// Stream links (include/zkgl_ir.h): thread == (instance, global index k); both copies of element k must agree.
+__global__ __launch_bounds__(TPB) void k_check_stream(const uint64_t* __restrict__ loop_cells, uint64_t loop_n_cells,
+                                                      uint32_t n_instances, uint32_t limit, const uint32_t* __restrict__ a_cells,
+                                                      uint32_t pa, const uint32_t* __restrict__ b_cells, uint32_t pb,
+                                                      uint32_t n_total, uint32_t stream_index, unsigned long long* fail) {
+    const uint64_t t = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (t >= (uint64_t)n_instances * n_total) return;
+    const uint32_t inst = (uint32_t)(t / n_total), k = (uint32_t)(t % n_total);
+    const uint32_t lane_a = inst * limit + k / pa, lane_b = inst * limit + k / pb;
+    const uint64_t va = loop_cells[cell_off(loop_n_cells, a_cells[k % pa], lane_a)];
+    const uint64_t vb = loop_cells[cell_off(loop_n_cells, b_cells[k % pb], lane_b)];
+    if (va != vb) atomicMin(fail + 2, ((unsigned long long)lane_a << 32) | 0x80000000u | stream_index);
 }
 
 }  // namespace zke

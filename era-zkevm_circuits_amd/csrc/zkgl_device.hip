@@ -101,10 +101,12 @@ static zke::ScopeDev to_dev(const ScopeArgs& a) {
 
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, void* stream) {
     if (sc.n_lanes == 0 || word_begin >= word_end) return 0;
-    if (sc.is_loop)
-        zke::k_witness_loop<<<grid_for(sc.n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(to_dev(sc), word_begin, word_end);
-    else
-        zke::k_witness_outer<<<grid_for(sc.n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(to_dev(sc), word_begin, word_end);
+    const dim3 grid = grid_for(sc.n_lanes, zke::TPB);
+    hipStream_t s = (hipStream_t)stream;
+    if (sc.is_loop && sc.uses_bigint) zke::k_witness_loop_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
+    else if (sc.is_loop) zke::k_witness_loop<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
+    else if (sc.uses_bigint) zke::k_witness_outer_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
+    else zke::k_witness_outer<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
     return LAUNCH_CHECK("k_witness");
 }
 
@@ -112,8 +114,12 @@ int launch_witness_seq(const ScopeArgs& sc, const CarryArgs* d_carries, uint32_t
                        uint32_t n_instances, void* stream) {
     if (n_instances == 0 || sc.limit == 0) return 0;
     static_assert(sizeof(CarryArgs) == sizeof(zke::CarryDev), "CarryArgs layout");
-    zke::k_witness_seq<<<grid_for(n_instances, 64), 64, 0, (hipStream_t)stream>>>(
-        to_dev(sc), reinterpret_cast<const zke::CarryDev*>(d_carries), n_carries, inputs_rw, n_instances);
+    if (sc.uses_bigint)
+        zke::k_witness_seq<true><<<grid_for(n_instances, 64), 64, 0, (hipStream_t)stream>>>(
+            to_dev(sc), reinterpret_cast<const zke::CarryDev*>(d_carries), n_carries, inputs_rw, n_instances);
+    else
+        zke::k_witness_seq<false><<<grid_for(n_instances, 64), 64, 0, (hipStream_t)stream>>>(
+            to_dev(sc), reinterpret_cast<const zke::CarryDev*>(d_carries), n_carries, inputs_rw, n_instances);
     return LAUNCH_CHECK("k_witness_seq");
 }
 
@@ -140,6 +146,15 @@ int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lane
     dim3 grid(lane_tiles, (n_pairs + per - 1) / per);
     zke::k_check_copies<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(cells, n_cells, n_lanes, pairs, n_pairs, per, fail);
     return LAUNCH_CHECK("k_check_copies");
+}
+
+int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
+                        const uint32_t* a_cells, uint32_t pa, const uint32_t* b_cells, uint32_t pb, uint32_t n_total,
+                        uint32_t stream_index, unsigned long long* fail, void* stream) {
+    if (!n_instances || !n_total) return 0;
+    zke::k_check_stream<<<grid_for((size_t)n_instances * n_total, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(
+        loop_cells, loop_n_cells, n_instances, limit, a_cells, pa, b_cells, pb, n_total, stream_index, fail);
+    return LAUNCH_CHECK("k_check_stream");
 }
 
 int launch_check_links(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_lanes, uint32_t limit,

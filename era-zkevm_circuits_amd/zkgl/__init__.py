@@ -33,7 +33,7 @@ ZK_ERR_GATE_NOT_ALLOWED = -6
 
 # zk_opcode / zk_gate_kind / zk_link_kind (include/zkgl_ir.h)
 OP = dict(END=0, CONST=1, INPUT=2, FMA=3, LC4=4, SELECT=5, ISZERO=6, UADD=7, USUB=8, DOT4=9, MATMUL12=10,
-          SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16, DIVREM=18)
+          SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16, DIVREM=18, NN_MULMOD=19)
 GATE = dict(NOP=0, CONST=1, BOOLEAN=2, FMA=3, REDUCTION4=4, SELECT=5, ZEROCHECK=6, UINTX_ADD=7, DOT4=8,
             MATMUL12_EXT=9, MATMUL12_INT=10, PUBLIC_INPUT=11, U32_FMA=12)
 GATE_NAMES = {v: k for k, v in GATE.items()}
@@ -333,6 +333,11 @@ class ConstraintSystem:
     def link(self, kind: int, loop_var: int, other: int):
         _check(lib().zk_cs_link(self._h, kind, loop_var, other))
 
+    def stream_link(self, a_vars, b_vars, n_total: int):
+        a = (C.c_uint32 * len(a_vars))(*a_vars)
+        b = (C.c_uint32 * len(b_vars))(*b_vars)
+        _check(lib().zk_cs_stream_link(self._h, a, len(a_vars), b, len(b_vars), n_total))
+
     def loop_last(self, loop_var: int) -> int:
         v = C.c_uint32()
         _check(lib().zk_cs_loop_last(self._h, loop_var, C.byref(v)))
@@ -381,6 +386,12 @@ class ConstraintSystem:
 
     def keccak256_round_function_entry_point(self, limit: int):
         _check(lib().zk_circuit_keccak256_round_function(self._h, limit))
+
+    def configure_eip_4844(self):
+        _check(lib().zk_circuit_eip_4844_configure(self._h))
+
+    def eip_4844_entry_point(self, n_chunks: int):
+        _check(lib().zk_circuit_eip_4844(self._h, n_chunks))
 
     def configure_sha256(self):
         _check(lib().zk_circuit_sha256_configure(self._h))

@@ -147,6 +147,9 @@ int zk_cs_side_begin(zk_cs *cs);
 int zk_cs_loop_begin(zk_cs *cs, uint32_t limit);
 int zk_cs_loop_end(zk_cs *cs);
 int zk_cs_link(zk_cs *cs, uint32_t link_kind, zk_var loop_var, zk_var other_var);
+/* stream link (include/zkgl_ir.h): loop variables a_vars[k % period_a] of iteration k / period_a and
+ * b_vars[k % period_b] of iteration k / period_b are the same value for every k < n_total */
+int zk_cs_stream_link(zk_cs *cs, const zk_var *a_vars, uint32_t period_a, const zk_var *b_vars, uint32_t period_b, uint32_t n_total);
 /* value of a loop variable at the last iteration, as an outer variable (post phase) */
 int zk_cs_loop_last(zk_cs *cs, zk_var loop_var, zk_var *outer_out);
 /* use an outer variable inside the loop (broadcast; pre phase must define it) */
@@ -230,6 +233,12 @@ int zk_circuit_keccak256_blocks(zk_cs *cs, uint32_t n_blocks);
  * queue pop, 6 conditional unaligned memory reads into the 192-byte ByteBuffer, padding, one Keccak-f per cycle,
  * conditional digest write; `limit` cycles.  Uses zk_circuit_keccak_configure.  Outer stream 474 words, loop 507. */
 int zk_circuit_keccak256_round_function(zk_cs *cs, uint32_t limit);
+/* eip_4844_entry_point (src/eip_4844/mod.rs:107-260): Horner evaluation of the blob polynomial at the Fiat-Shamir point
+ * over the non-native BLS12-381 scalar field + linear keccak256 of the blob + output hash; `n_chunks` 31-byte chunks
+ * (the reference fixes 4096).  Outer stream 64 words (versioned_hash | linear_hash_output); loop stream
+ * 217 + 136 + 31*ceil(n_chunks / n_blocks) words with n_blocks = 31*n_chunks / 136 + 1 (see circuits/eip4844.cpp). */
+int zk_circuit_eip_4844_configure(zk_cs *cs);
+int zk_circuit_eip_4844(zk_cs *cs, uint32_t n_chunks);
 /* SHA-256 over n_blocks pre-padded 64-byte blocks (compression step of sha256_precompile_inner,
  * src/sha256_round_function/mod.rs:271-285) through 8-bit lookup tables.  Public inputs = the 32 digest bytes. */
 int zk_circuit_sha256_configure(zk_cs *cs);

@@ -49,6 +49,9 @@ enum zk_opcode {
     ZK_OP_U32MULADD = 16,/* [a, b, c, d] -> lo, hi of a*b + c + d  (u32 each)         (UInt32::fma_with_carry) */
     ZK_OP_ADD_CONSTMUL = 17, /* reserved */
     ZK_OP_DIVREM = 18,   /* b=divisor (1..65535); [x] -> x / b, x % b as integers       (UInt32::div_by_constant) */
+    ZK_OP_NN_MULMOD = 19,/* a=nA, b=nB (<=17 each); [m0..m15 modulus limbs (consts), A limbs, B limbs] -> q limbs (nA+nB-15),
+                          * r limbs (16): integers A*B = q*M + r, 0 <= r < M; all limbs base 2^16, input limbs < 2^24
+                          *                                                           (NonNativeFieldOverU16 mul/normalize) */
     ZK_OP__COUNT
 };
 
@@ -104,5 +107,9 @@ enum zk_link_kind {
     ZK_LINK_BCAST = 3  /* loop cell[k] == outer cell for every k */
 };
 typedef struct zk_link { uint32_t kind; uint32_t loop_cell; uint32_t other_cell; uint32_t pad; } zk_link;
+/* Stream link: two periodic word sequences of the loop scope carry the same data with different chunking.  For every
+ * global index k < n_total:  cell a[k % pa] of iteration k / pa  ==  cell b[k % pb] of iteration k / pb  (copy
+ * constraints across iterations; e.g. the blob bytes of eip_4844 seen as 31-byte chunks and as 136-byte Keccak blocks).
+ * Serialised as: pa, pb, n_total, a cells[pa], b cells[pb]. */
 
 #endif

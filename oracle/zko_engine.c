@@ -15,6 +15,8 @@ typedef struct zko_scope {
     uint32_t is_loop, n_cells, n_trace_cells, n_slots, n_copy_cols, lookup_width, n_input_words, limit, pre_words;
     uint32_t n_prog, n_consts, n_rows, n_rowconsts, n_lrows, n_copies, n_tables, n_table_words, n_links, n_carries;
     uint32_t *carries; /* 4 words each: input word, out cell, first outer cell, has_first */
+    uint32_t n_stream_words;
+    uint32_t *streams; /* per stream link: pa, pb, n_total, a cells[pa], b cells[pb] */
     uint32_t *prog;
     uint64_t *consts;
     zk_row_desc *rows;
@@ -31,17 +33,17 @@ static uint64_t rd64(const uint32_t *p) { return (uint64_t)p[0] | ((uint64_t)p[1
 void zko_scope_free(zko_scope *s) {
     if (!s) return;
     free(s->prog); free(s->consts); free(s->rows); free(s->rowconsts); free(s->lrows); free(s->copies);
-    free(s->tables); free(s->table_words); free(s->links); free(s->carries); free(s);
+    free(s->tables); free(s->table_words); free(s->links); free(s->carries); free(s->streams); free(s);
 }
 
 zko_scope *zko_scope_parse(const uint32_t *w, size_t n) {
-    if (n < 20 || w[0] != 0x5a4b4732u) return NULL;
+    if (n < 21 || w[0] != 0x5a4b4733u) return NULL;
     zko_scope *s = calloc(1, sizeof *s);
     s->is_loop = w[1]; s->n_cells = w[2]; s->n_trace_cells = w[3]; s->n_slots = w[4]; s->n_copy_cols = w[5];
     s->lookup_width = w[6]; s->n_input_words = w[7]; s->limit = w[8]; s->pre_words = w[9]; s->n_prog = w[10];
     s->n_consts = w[11]; s->n_rows = w[12]; s->n_rowconsts = w[13]; s->n_lrows = w[14]; s->n_copies = w[15];
-    s->n_tables = w[16]; s->n_table_words = w[17]; s->n_links = w[18]; s->n_carries = w[19];
-    const uint32_t *p = w + 20;
+    s->n_tables = w[16]; s->n_table_words = w[17]; s->n_links = w[18]; s->n_carries = w[19]; s->n_stream_words = w[20];
+    const uint32_t *p = w + 21;
 #define TAKE(dst, type, count, words_each, conv)                                   \
     do {                                                                          \
         s->dst = malloc(sizeof(type) * ((count) ? (count) : 1));                  \
@@ -61,6 +63,8 @@ zko_scope *zko_scope_parse(const uint32_t *w, size_t n) {
     TAKE(links, zk_link, s->n_links, 4, (s->links[i].kind = p[0], s->links[i].loop_cell = p[1], s->links[i].other_cell = p[2], s->links[i].pad = 0));
     s->carries = malloc(sizeof(uint32_t) * 4 * (s->n_carries ? s->n_carries : 1));
     for (uint32_t i = 0; i < 4 * s->n_carries; ++i) s->carries[i] = *p++;
+    s->streams = malloc(sizeof(uint32_t) * (s->n_stream_words ? s->n_stream_words : 1));
+    for (uint32_t i = 0; i < s->n_stream_words; ++i) s->streams[i] = *p++;
 #undef TAKE
     if ((size_t)(p - w) != n) { zko_scope_free(s); return NULL; }
     return s;
@@ -245,6 +249,38 @@ static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
             st(c, prog, &pc, lane, r & 0xffffffffull);
             st(c, prog, &pc, lane, r >> 32);
         } break;
+        case ZK_OP_NN_MULMOD: { /* A*B = q*M + r, base 2^16: schoolbook product + bit-serial restoring division */
+            uint64_t prod[40] = {0}, rem[18] = {0}, mod[16];
+            uint32_t nq = pa + pb - 15, np = pa + pb + 2;
+            for (uint32_t i = 0; i < 16; ++i) mod[i] = ld(c, prog[pc + i], lane, inst);
+            for (uint32_t i = 0; i < pa; ++i)
+                for (uint32_t j = 0; j < pb; ++j)
+                    prod[i + j] += ld(c, prog[pc + 16 + i], lane, inst) * ld(c, prog[pc + 16 + pa + j], lane, inst);
+            pc += 16 + pa + pb;
+            for (uint32_t k = 0; k + 1 < np; ++k) { prod[k + 1] += prod[k] >> 16; prod[k] &= 0xffff; }
+            uint64_t quo[40] = {0};
+            for (int bit = (int)np * 16 - 1; bit >= 0; --bit) {
+                for (int i = 17; i > 0; --i) rem[i] = ((rem[i] << 1) | (rem[i - 1] >> 15)) & 0xffff;
+                rem[0] = ((rem[0] << 1) | ((prod[bit / 16] >> (bit % 16)) & 1)) & 0xffff;
+                int ge = rem[17] != 0 || rem[16] != 0;
+                if (!ge) {
+                    ge = 1;
+                    for (int i = 15; i >= 0; --i)
+                        if (rem[i] != mod[i]) { ge = rem[i] > mod[i]; break; }
+                }
+                if (ge) {
+                    int64_t br = 0;
+                    for (int i = 0; i < 18; ++i) {
+                        int64_t t = (int64_t)rem[i] - (i < 16 ? (int64_t)mod[i] : 0) - br;
+                        br = t < 0;
+                        rem[i] = (uint64_t)(t + (br << 16));
+                    }
+                    quo[bit / 16] |= 1ull << (bit % 16);
+                }
+            }
+            for (uint32_t i = 0; i < nq; ++i) st(c, prog, &pc, lane, quo[i]);
+            for (uint32_t i = 0; i < 16; ++i) st(c, prog, &pc, lane, rem[i]);
+        } break;
         case ZK_OP_DIVREM: {
             uint64_t x = ld(c, prog[pc++], lane, inst);
             st(c, prog, &pc, lane, x / pb);
@@ -403,6 +439,17 @@ uint64_t zko_scope_check(const zko_scope *s, const uint64_t *cells, size_t strid
 uint64_t zko_links_check(const zko_scope *loop, const uint64_t *loop_cells, size_t loop_stride, uint32_t n_lanes,
                          const uint64_t *outer_cells, size_t outer_stride) {
     uint64_t bad = 0;
+    for (uint32_t off = 0; off + 3 <= loop->n_stream_words;) { /* stream links */
+        const uint32_t pa = loop->streams[off], pb = loop->streams[off + 1], nt = loop->streams[off + 2];
+        const uint32_t *ac = loop->streams + off + 3, *bc = ac + pa;
+        for (uint32_t inst = 0; inst < n_lanes / loop->limit; ++inst)
+            for (uint32_t k = 0; k < nt; ++k) {
+                uint64_t va = loop_cells[(size_t)ac[k % pa] * loop_stride + (size_t)inst * loop->limit + k / pa];
+                uint64_t vb = loop_cells[(size_t)bc[k % pb] * loop_stride + (size_t)inst * loop->limit + k / pb];
+                if (va != vb) ++bad;
+            }
+        off += 3 + pa + pb;
+    }
     uint32_t limit = loop->limit;
     for (uint32_t lane = 0; lane < n_lanes; ++lane) {
         uint32_t inst = lane / limit, k = lane % limit;

@@ -434,3 +434,76 @@ def test_keccak256_round_function_fsm_gpu(zk):
     cs.bind_inputs(True, d_b, bad.shape[0])
     ok, f = cs.resolve_and_check()
     assert not ok and f.instance == 12
+
+
+def test_bigint_witness_ops_gpu(zk):
+    """ZK_OP_NN_MULMOD (Knuth D on the device, bit-serial division in the oracle) and ZK_OP_DIVREM vs Python integers"""
+    from test_eip4844_host import bigint_ops_cs, bigint_ops_expected, bigint_ops_inputs
+    cs, outs, qr = bigint_ops_cs()
+    inp = bigint_ops_inputs(192)
+    cs.set_batch(inp.shape[1])
+    d = zk.DeviceBuffer.from_numpy(inp)
+    cs.bind_inputs(False, d, inp.shape[0])
+    cs.resolve()
+    tr = cs.trace(False)
+    for i in range(inp.shape[1]):
+        e_nn, e_dr = bigint_ops_expected(inp, i)
+        assert [int(tr[cs.var_cell(v), i]) for v in outs] == e_nn
+        assert [int(tr[cs.var_cell(v), i]) for v in qr] == e_dr
+
+
+def test_eip4844_gpu(zk):
+    """a19 on the GPU: 27-chunk blobs (7 Keccak blocks, partially active last Horner iteration), 66 instances; carried
+    words seeded on the device; trace bit-exact vs the oracle; the stream link catches a blob byte that differs between
+    its block view and its chunk view"""
+    from test_eip4844_host import TABLE_ROWS, blob_cs, make_instances, streams
+    n_chunks = 27
+    cs = blob_cs(n_chunks)
+    insts = make_instances(n_chunks, range(66))
+    outer, loop = streams(insts)
+    limit = cs.stats()["limit"]
+    raw = loop.copy()
+    raw[:217, :] = 0
+    cs.set_batch(len(insts))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(raw.shape), loop), "device seeding differs from the native trajectory"
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+    run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
+    run.resolve(outer, loop)
+    assert_trace_equal(cs, run)
+    bad = loop.copy()
+    bad[217 + 136 + 40, 5 * limit + 1] ^= 1    # chunk view of a blob byte of instance 5, iteration 1
+    d_b = zk.DeviceBuffer.from_numpy(bad)
+    cs.bind_inputs(True, d_b, bad.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert not ok and f.instance == 5
+
+
+def test_eip4844_full_size_blobs_gpu(zk):
+    """the reference's size (4096 chunks, 934 blocks, ~1.17 M rows per blob): 3 blobs seeded, resolved and checked on the
+    device; linear hash / opening value / output hash agree with keccak256 + Python big-integer Horner through the public input"""
+    from test_eip4844_host import make_instances, streams
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(60, 0, 8, 4), 1 << 21, 1 << 28)
+    cs.configure_eip_4844()
+    cs.eip_4844_entry_point(4096)
+    cs.pad_and_shrink()
+    insts = make_instances(4096, [11, 12, 13])
+    outer, loop = streams(insts)
+    raw = loop.copy()
+    raw[:217, :] = 0
+    cs.set_batch(len(insts))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(raw.shape), loop)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
