@@ -1,0 +1,182 @@
+"""-m gpu: BASELINE.json's configurations at their FULL sizes through size-independent properties
+(the oracle interpreter would take minutes there; parity at oracle-sized cases is in test_gpu_cs.py):
+
+  C1  ram_permutation, 2^16 rows        : a permutation is accepted and its commitment equals the native restatement;
+                                          swapping two sorted items (order broken) or changing a value is rejected
+  C3  keccak256 + sha256 round functions, 2^20 rows : every digest the FSM writes equals the software hash (native
+                                          model) and the device reproduces the native public input; satisfied
+  C4  storage_validity + log_sorter, 2^22 rows      : accepted, commitments equal the native restatement; a broken
+                                          permutation is rejected
+  C2 is bench.py's workload (smoke + test_vm_shaped in test_gpu_cs.py); C5 (eip_4844, 4096 chunks) is in test_gpu_cs.py.
+
+Loop streams come from the native restatements (oracle/*_native.py: they hold the per-cycle state the device seeding
+reproduces, which is checked at small sizes)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import zkgl
+from oracle import keccak_native as kn
+from oracle import log_sorter_native as ln
+from oracle import ram_native as rn
+from oracle import sha256_native as shn
+from oracle import storage_native as sn
+from oracle import zko
+
+pytestmark = pytest.mark.gpu
+
+
+def fit(configure, entry, log2_rows, cols=100):
+    """largest `limit` whose trace fits 2^log2_rows rows, and the recorded circuit"""
+    def make(limit, max_rows):
+        cs = zkgl.ConstraintSystem(zkgl.CSGeometry(cols, 0, 8, 4), max_trace_len=max_rows, max_variables=1 << 28)
+        configure(cs)
+        entry(cs, limit)
+        cs.pad_and_shrink()
+        return cs
+    probe = make(1, 1 << 30)
+    st = probe.stats()
+    limit = ((1 << log2_rows) - st["outer_slots"]) // st["loop_slots"]
+    probe.close()
+    cs = make(limit, 1 << log2_rows)
+    assert cs.stats()["rows_per_instance"] <= 1 << log2_rows and cs.stats()["rows_per_instance"] > (1 << log2_rows) - 2 * st["loop_slots"]
+    return cs, limit
+
+
+def run_gpu(zk, cs, outer, loop, batch):
+    cs.set_batch(batch)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    ok, f = cs.resolve_and_check()
+    return ok, f, (d_o, d_l)
+
+
+def test_c1_ram_permutation_2_16_rows(zk):
+    cs, limit = fit(lambda c: c.configure_ram_permutation(), lambda c, l: c.ram_permutation_entry_point(l), 16)
+    rng = np.random.default_rng(0xC1)
+    insts = []
+    for n in (limit, limit - 7, limit // 2, 0):
+        u, s, nd = rn.random_ram_witness(rng, n, n_cells=64) if n else ([], [], 0)
+        insts.append(rn.instance(u, s, limit, nd))
+    assert all(i["completed"] for i in insts)
+    outer, loop = rn.pack_streams(insts, limit)
+    ok, f, keep = run_gpu(zk, cs, outer, loop, len(insts))
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["commitment"]
+    # order broken: swap two adjacent sorted items of instance 1 (heads/accumulators re-derived natively)
+    u, s, nd = rn.random_ram_witness(np.random.default_rng(5), limit, n_cells=64)
+    j = next(k for k in range(1, limit - 1) if s[k][:3] != s[k + 1][:3])
+    s[j], s[j + 1] = s[j + 1], s[j]
+    bad = rn.instance(u, s, limit, nd)
+    outer_b, loop_b = rn.pack_streams([insts[0], bad], limit)
+    ok, f, keep2 = run_gpu(zk, cs, outer_b, loop_b, 2)
+    assert not ok and f.instance == 1
+    del keep, keep2
+
+
+def _keccak_requests(rng, limit):
+    """lengths uniform in [0, 1024] B, misalignment uniform in [0, 31]; as many as fit `limit` cycles"""
+    reqs, datas, cycles = [], [], 0
+    while True:
+        n, off = int(rng.integers(0, 1025)), int(rng.integers(0, 32))
+        need = n // 136 + 2            # upper bound on the cycles a request takes (reads lag absorbs by < 1 cycle)
+        if cycles + need > limit:
+            break
+        d = bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
+        reqs.append(kn.request(d, timestamp=1 + 2 * len(reqs), input_page=100 + len(reqs), input_offset=off + 32 * int(rng.integers(0, 50)),
+                               output_page=5000 + len(reqs), output_offset=len(reqs)))
+        datas.append(d)
+        cycles += need
+    return reqs, datas
+
+
+def test_c3_keccak256_round_function_2_20_rows(zk):
+    cs, limit = fit(lambda c: c.configure_keccak(), lambda c, l: c.keccak256_round_function_entry_point(l), 20)
+    insts = []
+    for seed in (0xC3, 0xC3 + 1):
+        reqs, datas = _keccak_requests(np.random.default_rng(seed), limit)
+        inst = kn.instance(reqs, limit)
+        assert inst["satisfiable"] and inst["fsm_out"]["completed"] == 1
+        writes = [q for q in inst["pushed"] if q[3] == 1]
+        assert [sum(l << (32 * i) for i, l in enumerate(q[5:13])).to_bytes(32, "big") for q in writes] == [zko.keccak256(d) for d in datas]
+        insts.append(inst)
+    outer = np.array([i["outer"] for i in insts], dtype=np.uint64).T.copy()
+    loop = np.array([r for i in insts for r in i["rows"]], dtype=np.uint64).T.copy()
+    ok, f, keep = run_gpu(zk, cs, outer, loop, len(insts))
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+    loop[459, limit + 3] ^= 1   # a memory word read by instance 1 differs from the one its queue chain was built with
+    ok, f, keep2 = run_gpu(zk, cs, outer, loop, len(insts))
+    assert not ok and f.instance == 1
+    del keep, keep2
+
+
+def test_c3_sha256_round_function_2_20_rows(zk):
+    cs, limit = fit(lambda c: c.configure_sha256(), lambda c, l: c.sha256_round_function_entry_point(l), 20)
+    insts = []
+    for seed in (0xC3 + 2, 0xC3 + 3):
+        rng = np.random.default_rng(seed)
+        reqs, msgs, cycles = [], [], 0
+        while True:
+            rounds = int(rng.integers(1, 17))                 # 1-16 rounds per request
+            if cycles + rounds > limit:
+                break
+            n = 64 * rounds - 9 - int(rng.integers(0, 55))
+            m = bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
+            r = shn.request(m, timestamp=1 + 2 * len(reqs), input_page=10 + len(reqs), input_offset=int(rng.integers(0, 1000)),
+                            output_page=9000 + len(reqs), output_offset=len(reqs))
+            assert r["rounds"] == rounds
+            reqs.append(r); msgs.append(m); cycles += rounds
+        inst = shn.instance(reqs, limit)
+        assert inst["satisfiable"] and inst["fsm_out"]["completed"] == 1
+        writes = [q for q in inst["pushed"] if q[3] == 1]
+        assert [sum(l << (32 * i) for i, l in enumerate(q[5:13])).to_bytes(32, "big") for q in writes] == [hashlib.sha256(m).digest() for m in msgs]
+        insts.append(inst)
+    outer = np.array([i["outer"] for i in insts], dtype=np.uint64).T.copy()
+    loop = np.array([r for i in insts for r in i["rows"]], dtype=np.uint64).T.copy()
+    ok, f, keep = run_gpu(zk, cs, outer, loop, len(insts))
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+    del keep
+
+
+def test_c4_storage_validity_2_22_rows(zk):
+    cs, limit = fit(lambda c: c.configure_storage_validity(),
+                    lambda c, l: c.sort_and_deduplicate_storage_access_entry_point(l, True), 22)
+    rng = np.random.default_rng(0xC4)
+    u, s = sn.random_storage_witness(rng, limit - 3, n_cells=512)
+    inst = sn.instance(u, s, limit)
+    assert inst["satisfiable"] and inst["completed"]
+    outer, loop = sn.pack_streams([inst], limit)
+    ok, f, keep = run_gpu(zk, cs, outer, loop, 1)
+    assert ok, f
+    assert cs.public_inputs(0) == inst["commitment"]
+    del keep
+    # not a permutation: one sorted record's written value changed -> grand products differ (entry-point check)
+    q, ts = s[len(s) // 2]
+    q = list(q); q[21] ^= 1
+    s2 = list(s); s2[len(s) // 2] = (q, ts)
+    bad = sn.instance(u, s2, limit)
+    outer, loop = sn.pack_streams([bad], limit)
+    ok, f, keep = run_gpu(zk, cs, outer, loop, 1)
+    assert not ok
+    del keep
+
+
+def test_c4_log_sorter_2_22_rows(zk):
+    cs, limit = fit(lambda c: c.configure_log_sorter(), lambda c, l: c.sort_and_deduplicate_events_entry_point(l), 22)
+    rng = np.random.default_rng(0xC4 + 1)
+    u, s = ln.random_events(rng, int(limit / 1.1) - 8, rollback_frac=0.1)   # 10 % rollbacks, paired
+    assert len(u) <= limit
+    inst = ln.instance(u, s, limit)
+    assert inst["satisfiable"] and inst["completed"]
+    outer, loop = ln.pack_streams([inst], limit)
+    ok, f, keep = run_gpu(zk, cs, outer, loop, 1)
+    assert ok, f
+    assert cs.public_inputs(0) == inst["commitment"]
+    del keep
