@@ -2,6 +2,8 @@
 #include "cs.hpp"
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
+#include <climits>
+#include <cstdlib>
 #include <cstring>
 #include "device_api.hpp"
 
@@ -65,6 +67,8 @@ CS::~CS() {
     if (d_table_words_) hipFree(d_table_words_);
     if (d_mult_) hipFree(d_mult_);
     if (d_links_) hipFree(d_links_);
+    if (d_seed_prog_) hipFree(d_seed_prog_);
+    if (d_seed_carries_) hipFree(d_seed_carries_);
     for (auto p : d_streams_) if (p) hipFree(p);
     if (d_carries_) hipFree(d_carries_);
     if (d_fail_) hipFree(d_fail_);
@@ -493,6 +497,85 @@ void CS::emit_scope(Scope& s) {
             if (!defined[v]) throw ZkError(ZK_ERR_UNRESOLVED, "lookup references a variable without a witness producer");
 }
 
+// Cone seeding program.  The carried words of iteration k+1 depend on a (usually small) part of iteration k: queue
+// heads, accumulators, FSM flags — not on the range-check decompositions, gate intermediates or the 962 constrained
+// Poseidon2 intermediates.  Keep only the backward slice of the carried outputs, collapse P2_ROUNDS to the 12-output
+// permutation and assign every surviving value an LDS slot by linear scan over its live range.
+void CS::build_seed_program() {
+    seed_prog_.clear(); seed_carries_.clear(); seed_slots_ = 0; seed_ops_ = 0;
+    if (!limit_ || carries_.empty()) return;
+    const Scope& s = loop_;
+    std::vector<uint32_t> out_vars;  // same order as carries_
+    for (auto& l : links_raw_)
+        if (l.kind == ZK_LINK_CARRY && s.input_word.count(l.loop_cell)) out_vars.push_back(l.other_cell);
+    std::vector<uint8_t> need(s.n_vars, 0), keep(s.ops.size(), 0);
+    for (auto v : out_vars) need[v] = 1;
+    for (size_t oi = s.ops.size(); oi-- > 0;) {
+        const OpRec& op = s.ops[oi];
+        bool any = false;
+        for (auto o : op.outs) any |= need[o] != 0;
+        if (!any) continue;
+        if (op.opcode == ZK_OP_P2_ROUNDS)
+            for (size_t i = 0; i + 12 < op.outs.size(); ++i)
+                if (need[op.outs[i]]) return;  // an intermediate feeds the state: keep the generic mode
+        keep[oi] = 1;
+        for (auto& in : op.ins)
+            if (in.kind == Operand::VAR) need[in.idx] = 1;
+    }
+    const int64_t INF = INT64_MAX;
+    std::vector<int64_t> last_use(s.n_vars, -1);
+    for (size_t oi = 0; oi < s.ops.size(); ++oi)
+        if (keep[oi])
+            for (auto& in : s.ops[oi].ins)
+                if (in.kind == Operand::VAR) last_use[in.idx] = (int64_t)oi;
+    for (auto v : out_vars) last_use[v] = INF;
+    std::vector<uint32_t> slot_of(s.n_vars, UINT32_MAX), free_slots;
+    uint32_t n_slots = 0;
+    const uint32_t DISCARD_MARK = 0x3fffffffu;
+    std::vector<uint32_t> prog;
+    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+        if (!keep[oi]) continue;
+        const OpRec& op = s.ops[oi];
+        const bool collapse = op.opcode == ZK_OP_P2_ROUNDS;
+        prog.push_back((collapse ? (uint32_t)ZK_OP_POSEIDON2 : (uint32_t)op.opcode) | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
+        for (auto& in : op.ins) {
+            switch (in.kind) {
+            case Operand::VAR: prog.push_back(slot_of[in.idx]); break;
+            case Operand::CONSTPOOL: prog.push_back(ZK_OPERAND_CONST | in.idx); break;
+            case Operand::OUTER_VAR: prog.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]); break;
+            case Operand::RAW: prog.push_back(in.idx); break;
+            }
+        }
+        for (size_t i = collapse ? op.outs.size() - 12 : 0; i < op.outs.size(); ++i) {
+            const uint32_t ov = op.outs[i];
+            if (last_use[ov] < 0) { prog.push_back(DISCARD_MARK); continue; }
+            uint32_t sl;
+            if (!free_slots.empty()) { sl = free_slots.back(); free_slots.pop_back(); }
+            else sl = n_slots++;
+            slot_of[ov] = sl;
+            prog.push_back(sl);
+        }
+        for (auto& in : op.ins)  // release after the outputs are placed: an op never writes over its own operands
+            if (in.kind == Operand::VAR && last_use[in.idx] == (int64_t)oi && slot_of[in.idx] != UINT32_MAX) {
+                free_slots.push_back(slot_of[in.idx]);
+                last_use[in.idx] = -2;  // the same variable may appear twice among the operands
+            }
+        ++seed_ops_;
+    }
+    const uint32_t discard = n_slots++;
+    for (auto& w : prog)
+        if (w == DISCARD_MARK) w = discard;
+    if (n_slots + s.n_input_words > zkdev::seed_cone_max_slots()) { seed_ops_ = 0; return; }
+    for (size_t i = 0; i < carries_.size(); ++i) {
+        Carry c = carries_[i];
+        if (slot_of[out_vars[i]] == UINT32_MAX) { seed_ops_ = 0; return; }  // carried output produced by no op
+        c.out_cell = slot_of[out_vars[i]];
+        seed_carries_.push_back(c);
+    }
+    seed_prog_ = std::move(prog);
+    seed_slots_ = n_slots;
+}
+
 void CS::upload_scope(Scope& s) {
     {
         std::vector<uint32_t> padded(s.prog);  // the device keeps a 128-word prefetch window (ProgWindow)
@@ -541,6 +624,7 @@ void CS::finalize() {
             }
         carries_.push_back(c);
     }
+    build_seed_program();
     // links: vars -> home cells
     links_.clear();
     for (auto& l : links_raw_) {
@@ -594,6 +678,12 @@ void CS::ensure_uploaded() {
         d_streams_.push_back(upload(cells));
     }
     d_carries_ = (void*)upload(carries_);
+    if (!seed_prog_.empty()) {
+        std::vector<uint32_t> padded(seed_prog_);
+        padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
+        d_seed_prog_ = upload(padded);
+        d_seed_carries_ = (void*)upload(seed_carries_);
+    }
     hip_check(hipMalloc((void**)&d_fail_, 8 * sizeof(unsigned long long)), "hipMalloc fail words");
     for (auto& e : ev_) {
         hipEvent_t he;
@@ -659,8 +749,13 @@ void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {
     auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
     dev_check(zkdev::launch_witness(oa, 0, outer_.pre_words, st));
-    dev_check(zkdev::launch_witness_seq(la, (const zkdev::CarryArgs*)d_carries_, (uint32_t)carries_.size(), dev_loop_inputs_rw,
-                                        batch_, st));
+    const char* force_generic = std::getenv("ZKGL_SEED_GENERIC");
+    if (d_seed_prog_ && !(force_generic && force_generic[0] == '1'))
+        dev_check(zkdev::launch_seed_cone(la, d_seed_prog_, (uint32_t)seed_prog_.size(), seed_slots_, loop_.n_input_words, (const zkdev::CarryArgs*)d_seed_carries_,
+                                          (uint32_t)seed_carries_.size(), dev_loop_inputs_rw, batch_, st));
+    else
+        dev_check(zkdev::launch_witness_seq(la, (const zkdev::CarryArgs*)d_carries_, (uint32_t)carries_.size(), dev_loop_inputs_rw,
+                                            batch_, st));
     hip_check(hipStreamSynchronize(st), "seed sync");
 }
 
@@ -905,6 +1000,7 @@ void CS::stats(zk_stats* o) const {
     o->scratch_cells_outer = outer_.n_scratch; o->scratch_cells_loop = loop_.n_scratch;
     o->cells_written_outer = outer_.cells_written; o->cells_written_loop = loop_.cells_written;
     o->copy_pairs_outer = outer_.copies.size(); o->copy_pairs_loop = loop_.copies.size();
+    o->seed_ops = seed_ops_; o->seed_words = seed_prog_.size(); o->seed_slots = seed_slots_; o->loop_ops = loop_.ops.size();
 }
 
 float CS::last_ms(int which) const { return (which >= 0 && which < 5) ? ms_[which] : -1.0f; }

@@ -205,6 +205,13 @@ class CS {
     struct Carry { uint32_t word, out_cell, first_outer_cell, has_first; };
     std::vector<Carry> carries_;
     void* d_carries_ = nullptr;
+    // cone seeding: backward slice of the carried outputs over LDS slots (empty => generic sequential mode)
+    void build_seed_program();
+    std::vector<uint32_t> seed_prog_;
+    std::vector<Carry> seed_carries_;  // out_cell = slot of the carried output
+    uint32_t seed_slots_ = 0, seed_ops_ = 0;
+    uint32_t* d_seed_prog_ = nullptr;
+    void* d_seed_carries_ = nullptr;
     unsigned long long* d_fail_ = nullptr;
     void* ev_[8] = {nullptr};
     void* ev2_[8] = {nullptr};

@@ -41,6 +41,10 @@ int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uin
 int launch_check_gates(const CheckArgs& cd, void* stream);
 int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs,
                         uint32_t n_pairs, unsigned long long* fail, void* stream);
+// cone seeding: seed_prog in device memory (padded like every program), carries = {input word, out slot, first outer cell, has_first}
+int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_words, uint32_t n_slots, uint32_t n_input_words,
+                     const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream);
+uint32_t seed_cone_max_slots();
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
                         const uint32_t* a_cells, uint32_t pa, const uint32_t* b_cells, uint32_t pb, uint32_t n_total,
                         uint32_t stream_index, unsigned long long* fail, void* stream);

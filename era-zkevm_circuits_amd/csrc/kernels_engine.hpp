@@ -181,28 +181,37 @@ __device__ __noinline__ void nn_mulmod(const uint32_t* a, uint32_t na, const uin
 
 // WITH_BIGINT: kernels compiled with the ZK_OP_NN_MULMOD case (an out-of-line call that costs the caller ~20 VGPRs
 // and 500 B of scratch); the launcher picks them only for programs that contain the op.
-template <bool WITH_BIGINT>
+// SLOTS: seeding mode (k_seed_cone).  Values live in an LDS slot store instead of trace cells: cell-kind operands
+// and destinations are slot indices assigned by the host's liveness allocation, one destination word per output.
+template <bool WITH_BIGINT, bool SLOTS = false>
 __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
-                                         uint32_t word_begin, uint32_t word_end) {
+                                         uint32_t word_begin, uint32_t word_end, const uint32_t* prog = nullptr,
+                                         uint64_t* slots = nullptr, uint32_t slot_stride = 0, const uint64_t* in_area = nullptr) {
     uint64_t* __restrict__ cells = sc.cells + cell_off(sc.n_cells, 0, lane);  // this lane's column of its tile
     ProgWindow P;
-    P.init(sc.prog, word_begin);
+    P.init(SLOTS ? prog : sc.prog, word_begin);
     __shared__ uint64_t p2s[12 * TPB];  // Poseidon2 state, [element][thread]
 
     auto ld = [&](uint32_t w) -> uint64_t {
         const uint32_t kind = w & ZK_OPERAND_KIND_MASK, idx = w & ZK_OPERAND_IDX_MASK;
         if (kind == ZK_OPERAND_CONST) return sc.consts[idx];
         if (kind == ZK_OPERAND_OUTER) return sc.outer_cells[cell_off(sc.outer_n_cells, idx, inst)];
+        if constexpr (SLOTS) return slots[idx * slot_stride];
         return cells[(size_t)idx << 6];
     };
     uint32_t pc = word_begin;
     auto st = [&](uint64_t v) {
-        uint32_t w;
-        do {
+        if constexpr (SLOTS) {
             P.sync(pc);
-            w = P.at(pc++);
-            cells[(size_t)(w & ~ZK_DEST_MORE) << 6] = v;
-        } while (w & ZK_DEST_MORE);
+            slots[P.at(pc++) * slot_stride] = v;
+        } else {
+            uint32_t w;
+            do {
+                P.sync(pc);
+                w = P.at(pc++);
+                cells[(size_t)(w & ~ZK_DEST_MORE) << 6] = v;
+            } while (w & ZK_DEST_MORE);
+        }
     };
 
     while (pc < word_end) {
@@ -216,7 +225,8 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         } break;
         case ZK_OP_INPUT: {
             uint32_t w = P.at(pc++);
-            st(sc.inputs[(size_t)w * sc.n_lanes + lane]);
+            if constexpr (SLOTS) st(in_area[w * slot_stride]);  // staged in LDS by the kernel prologue
+            else st(sc.inputs[(size_t)w * sc.n_lanes + lane]);
         } break;
         case ZK_OP_FMA: {
             uint64_t q = ld(P.at(pc)), l = ld(P.at(pc + 1));
@@ -425,6 +435,49 @@ __global__ __launch_bounds__(64) void k_witness_seq(ScopeDev sc, const CarryDev*
     }
 }
 
+
+// Cone seeding (fast path of zk_cs_seed_carried_inputs): thread group == instance, iterations in order, but only the
+// backward slice of the carried outputs is executed (`seed_prog`, emitted by the host: P2_ROUNDS collapsed to the
+// 12-output permutation, destinations = LDS slots from a linear-scan liveness allocation).  `lpb` instances share a
+// 64-thread block (threads t >= lpb mirror lane t % lpb: identical values, benign duplicate stores), so a small batch
+// spreads over many CUs and the slot store (n_slots * lpb words) fits LDS.
+constexpr uint32_t SEED_LDS_WORDS = 5120;  // 40 KB slot store next to the 24 KB Poseidon2 staging array
+struct SeedCarryDev { uint32_t word, out_slot, first_outer_cell, has_first; };
+template <bool WITH_BIGINT>
+__global__ __launch_bounds__(64) void k_seed_cone(ScopeDev sc, const uint32_t* __restrict__ seed_prog, uint32_t n_words,
+                                                  const SeedCarryDev* carries, uint32_t n_carries, uint64_t* inputs_rw,
+                                                  uint32_t n_instances, uint32_t lpb, uint32_t n_slots, uint32_t n_input_words) {
+    __shared__ uint64_t lds[SEED_LDS_WORDS];
+    if (blockIdx.x * lpb >= n_instances) return;
+    uint64_t* const slot_store = lds;                    // [n_slots][lpb]
+    uint64_t* const in_store = lds + n_slots * lpb;      // [n_input_words][lpb]: this iteration's input stream words
+    const uint32_t l = threadIdx.x % lpb;
+    const uint32_t inst = min(blockIdx.x * lpb + l, n_instances - 1);  // surplus lanes mirror the last instance
+    const uint32_t ml = inst - blockIdx.x * lpb;                        // its column in the stores
+    for (uint32_t k = 0; k < sc.limit; ++k) {
+        // cooperative prologue (all 64 threads): stage the iteration's input words in LDS with independent loads,
+        // then overwrite the carried words with the previous iteration's outputs (k == 0: the outer scope's values)
+        // and publish them to the stream the parallel resolve will read.
+        for (uint32_t idx = threadIdx.x; idx < n_input_words * lpb; idx += 64) {
+            const uint32_t w = idx / lpb, ll = idx % lpb;
+            const uint32_t li = min(blockIdx.x * lpb + ll, n_instances - 1);
+            in_store[w * lpb + li - blockIdx.x * lpb] = inputs_rw[(size_t)w * sc.n_lanes + (size_t)li * sc.limit + k];
+        }
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < n_carries * lpb; idx += 64) {
+            const SeedCarryDev cd = carries[idx / lpb];
+            const uint32_t ll = idx % lpb;
+            const uint32_t li = min(blockIdx.x * lpb + ll, n_instances - 1), col = li - blockIdx.x * lpb;
+            if (k == 0 && !cd.has_first) continue;
+            const uint64_t v = k == 0 ? sc.outer_cells[cell_off(sc.outer_n_cells, cd.first_outer_cell, li)] : slot_store[cd.out_slot * lpb + col];
+            in_store[cd.word * lpb + col] = v;
+            inputs_rw[(size_t)cd.word * sc.n_lanes + (size_t)li * sc.limit + k] = v;
+        }
+        __syncthreads();
+        run_lane<WITH_BIGINT, true>(sc, inst * sc.limit + k, inst, false, 0, n_words, seed_prog, slot_store + ml, lpb, in_store + ml);
+        __syncthreads();
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // K7: per-row gate evaluation (check_if_satisfied counterpart,

@@ -148,6 +148,25 @@ int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lane
     return LAUNCH_CHECK("k_check_copies");
 }
 
+uint32_t seed_cone_max_slots() { return zke::SEED_LDS_WORDS; }
+
+int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_words, uint32_t n_slots, uint32_t n_input_words,
+                     const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream) {
+    if (n_instances == 0 || sc.limit == 0) return 0;
+    static_assert(sizeof(CarryArgs) == sizeof(zke::SeedCarryDev), "CarryArgs layout");
+    const uint32_t per_lane = n_slots + n_input_words;  // LDS words one instance needs
+    if (n_slots == 0 || per_lane > zke::SEED_LDS_WORDS) return -1;
+    uint32_t lpb = 1;
+    while (lpb < 16 && per_lane * (lpb * 2) <= zke::SEED_LDS_WORDS) lpb *= 2;  // instances per 64-thread block
+    const unsigned grid = (n_instances + lpb - 1) / lpb;
+    auto c = reinterpret_cast<const zke::SeedCarryDev*>(d_carries);
+    if (sc.uses_bigint)
+        zke::k_seed_cone<true><<<grid, 64, 0, (hipStream_t)stream>>>(to_dev(sc), seed_prog, n_words, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
+    else
+        zke::k_seed_cone<false><<<grid, 64, 0, (hipStream_t)stream>>>(to_dev(sc), seed_prog, n_words, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
+    return LAUNCH_CHECK("k_seed_cone");
+}
+
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
                         const uint32_t* a_cells, uint32_t pa, const uint32_t* b_cells, uint32_t pb, uint32_t n_total,
                         uint32_t stream_index, unsigned long long* fail, void* stream) {

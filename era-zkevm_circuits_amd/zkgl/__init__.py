@@ -65,7 +65,8 @@ class _Stats(C.Structure):
                 ("program_words_outer", C.c_uint64), ("program_words_loop", C.c_uint64),
                 ("scratch_cells_outer", C.c_uint64), ("scratch_cells_loop", C.c_uint64),
                 ("cells_written_outer", C.c_uint64), ("cells_written_loop", C.c_uint64),
-                ("copy_pairs_outer", C.c_uint64), ("copy_pairs_loop", C.c_uint64)]
+                ("copy_pairs_outer", C.c_uint64), ("copy_pairs_loop", C.c_uint64),
+                ("seed_ops", C.c_uint64), ("seed_words", C.c_uint64), ("seed_slots", C.c_uint64), ("loop_ops", C.c_uint64)]
 
 
 _lib = None

@@ -196,6 +196,8 @@ typedef struct zk_stats {
     uint64_t scratch_cells_outer, scratch_cells_loop;
     uint64_t cells_written_outer, cells_written_loop; /* populated cells one lane writes (algorithmic bytes / 8) */
     uint64_t copy_pairs_outer, copy_pairs_loop;
+    /* cone seeding program (backward slice of the carried outputs; 0 when the generic sequential mode is used) */
+    uint64_t seed_ops, seed_words, seed_slots, loop_ops;
 } zk_stats;
 int zk_cs_stats(zk_cs *cs, zk_stats *out);           /* print_gate_stats counterpart */
 /* last execution times in ms measured with HIP events on the execution stream:

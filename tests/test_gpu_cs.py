@@ -153,10 +153,14 @@ def test_all_ops_circuit_gpu_equals_oracle(zk):
         assert np.array_equal(cs.multiplicities(i), run.mult[i * 306:(i + 1) * 306])
 
 
-def test_ram_generic_seeding_equals_native_streams(zk):
+@pytest.mark.parametrize("mode", ["cone", "generic"])
+def test_ram_generic_seeding_equals_native_streams(zk, mode, monkeypatch):
     """raw witness only (items + is_first flag): the engine's sequential seeding reproduces the
-    per-iteration state the native restatement derives from the reference code"""
-    limit, batch = 8, 5
+    per-iteration state the native restatement derives from the reference code — both with the cone program
+    (backward slice of the carried outputs over LDS slots, k_seed_cone) and with the generic mode (k_witness_seq)"""
+    monkeypatch.setenv("ZKGL_SEED_GENERIC", "1" if mode == "generic" else "0")
+    limit, batch = 8, 21
+    assert ram_cs(limit).stats()["seed_ops"] > 0
     cs = ram_cs(limit)
     insts = random_instances(31, batch, 6, limit)
     outer, loop = rn.pack_streams(insts, limit)
