@@ -16,6 +16,8 @@ void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
 void keccak_configure(CS& cs);
 void sha256_configure(CS& cs);
+void demux_log_queue_configure(CS& cs);
+void demultiplex_storage_logs_entry_point(CS& cs, uint32_t limit);
 void eip_4844_configure(CS& cs);
 void eip_4844_entry_point(CS& cs, uint32_t n_chunks);
 void sha256_blocks_entry_point(CS& cs, uint32_t n_blocks);
@@ -424,6 +426,14 @@ int zk_circuit_eip_4844_configure(zk_cs* cs) {
 int zk_circuit_eip_4844(zk_cs* cs, uint32_t n_chunks) {
     NEED(cs);
     return guard([&] { zkgl::eip_4844_entry_point(*cs->cs, n_chunks); });
+}
+int zk_circuit_demux_log_queue_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::demux_log_queue_configure(*cs->cs); });
+}
+int zk_circuit_demux_log_queue(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { zkgl::demultiplex_storage_logs_entry_point(*cs->cs, limit); });
 }
 int zk_circuit_sha256_configure(zk_cs* cs) {
     NEED(cs);

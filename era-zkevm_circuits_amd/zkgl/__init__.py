@@ -394,6 +394,12 @@ class ConstraintSystem:
     def eip_4844_entry_point(self, n_chunks: int):
         _check(lib().zk_circuit_eip_4844(self._h, n_chunks))
 
+    def configure_demux_log_queue(self):
+        _check(lib().zk_circuit_demux_log_queue_configure(self._h))
+
+    def demultiplex_storage_logs_entry_point(self, limit: int):
+        _check(lib().zk_circuit_demux_log_queue(self._h, limit))
+
     def configure_sha256(self):
         _check(lib().zk_circuit_sha256_configure(self._h))
 

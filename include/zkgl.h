@@ -235,6 +235,10 @@ int zk_circuit_keccak256_blocks(zk_cs *cs, uint32_t n_blocks);
  * queue pop, 6 conditional unaligned memory reads into the 192-byte ByteBuffer, padding, one Keccak-f per cycle,
  * conditional digest write; `limit` cycles.  Uses zk_circuit_keccak_configure.  Outer stream 474 words, loop 507. */
 int zk_circuit_keccak256_round_function(zk_cs *cs, uint32_t limit);
+/* demultiplex_storage_logs_enty_point (src/demux_log_queue/mod.rs:38-232): one LogQuery popped per cycle and pushed to
+ * one of six queues by aux byte / shard / address.  Outer stream 73 words, loop stream 71 (see circuits/demux_log_queue.cpp). */
+int zk_circuit_demux_log_queue_configure(zk_cs *cs);
+int zk_circuit_demux_log_queue(zk_cs *cs, uint32_t limit);
 /* eip_4844_entry_point (src/eip_4844/mod.rs:107-260): Horner evaluation of the blob polynomial at the Fiat-Shamir point
  * over the non-native BLS12-381 scalar field + linear keccak256 of the blob + output hash; `n_chunks` 31-byte chunks
  * (the reference fixes 4096).  Outer stream 64 words (versioned_hash | linear_hash_output); loop stream

@@ -511,3 +511,30 @@ def test_eip4844_full_size_blobs_gpu(zk):
     assert ok, f
     for i, inst in enumerate(insts):
         assert cs.public_inputs(i) == inst["public_input"]
+
+
+def test_demux_log_queue_gpu(zk):
+    """8(f)-1 on the GPU: reference fixture + random mixes of the six classes, device seeding, trace bit-exact vs oracle"""
+    from oracle import demux_native as dn
+    from test_demux_host import demux_cs, load_demux_fixture, random_queries, streams
+    qs, limit = load_demux_fixture()
+    cs = demux_cs(limit)
+    rng = np.random.default_rng(66)
+    insts = [dn.instance(qs, limit)] + [dn.instance(random_queries(rng, int(rng.integers(0, limit + 1))), limit) for _ in range(69)]
+    assert all(i["satisfiable"] for i in insts)
+    outer, loop = streams(insts, limit)
+    raw = loop.copy()
+    raw[:dn.CARRIED] = 0
+    cs.set_batch(len(insts))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(raw.shape), loop)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+    run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), 65536)
+    run.resolve(outer, loop)
+    assert_trace_equal(cs, run)
