@@ -50,6 +50,17 @@ inline std::array<zk_var, 8> encode_memory_query(G& g, const MemoryQuery& q) {
     return encode_memory_query_with_bytes(g, q, d5, d6, d7);
 }
 
+// FullStateCircuitQueue::pop_front once the item is allocated and encoded (boojum [EXT]; by symmetry with push the
+// head advances along the same chain): head <- round_function(enc | head[8..12]) when `execute`, length -= execute
+inline void full_queue_pop(G& g, std::array<zk_var, 12>& head, UInt32& length, const std::array<zk_var, 8>& enc, Boolean execute) {
+    std::array<zk_var, 12> st;
+    for (int i = 0; i < 8; ++i) st[i] = enc[i];
+    for (int i = 8; i < 12; ++i) st[i] = head[i];
+    auto nh = g.compute_round_function(st);
+    for (int i = 0; i < 12; ++i) head[i] = g.select(execute, nh[i], head[i]);
+    length = g.select(execute, UInt32{g.sub(length.v, g.one())}, length);
+}
+
 // FullStateCircuitQueue::push: tail <- round_function(enc | tail[8..12]) when `execute`, length += execute
 inline void full_queue_push(G& g, std::array<zk_var, 12>& tail, UInt32& length, const std::array<zk_var, 8>& enc, Boolean execute) {
     std::array<zk_var, 12> st;

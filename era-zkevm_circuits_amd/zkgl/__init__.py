@@ -400,6 +400,12 @@ class ConstraintSystem:
     def demultiplex_storage_logs_entry_point(self, limit: int):
         _check(lib().zk_circuit_demux_log_queue(self._h, limit))
 
+    def configure_sort_decommits(self):
+        _check(lib().zk_circuit_sort_decommits_configure(self._h))
+
+    def sort_and_deduplicate_code_decommittments_entry_point(self, limit: int):
+        _check(lib().zk_circuit_sort_decommits(self._h, limit))
+
     def configure_sha256(self):
         _check(lib().zk_circuit_sha256_configure(self._h))
 

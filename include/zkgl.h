@@ -239,6 +239,11 @@ int zk_circuit_keccak256_round_function(zk_cs *cs, uint32_t limit);
  * one of six queues by aux byte / shard / address.  Outer stream 73 words, loop stream 71 (see circuits/demux_log_queue.cpp). */
 int zk_circuit_demux_log_queue_configure(zk_cs *cs);
 int zk_circuit_demux_log_queue(zk_cs *cs, uint32_t limit);
+/* sort_and_deduplicate_code_decommittments_entry_point (src/sort_decommittment_requests/mod.rs:40-222): two full-state
+ * DecommitQuery queues under the grand-product argument, equal code hashes collapsed into the result queue.
+ * Outer stream 151 words, loop stream 87 (see circuits/sort_decommits.cpp). */
+int zk_circuit_sort_decommits_configure(zk_cs *cs);
+int zk_circuit_sort_decommits(zk_cs *cs, uint32_t limit);
 /* eip_4844_entry_point (src/eip_4844/mod.rs:107-260): Horner evaluation of the blob polynomial at the Fiat-Shamir point
  * over the non-native BLS12-381 scalar field + linear keccak256 of the blob + output hash; `n_chunks` 31-byte chunks
  * (the reference fixes 4096).  Outer stream 64 words (versioned_hash | linear_hash_output); loop stream

@@ -538,3 +538,34 @@ def test_demux_log_queue_gpu(zk):
     run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), 65536)
     run.resolve(outer, loop)
     assert_trace_equal(cs, run)
+
+
+def test_sort_decommittment_requests_gpu(zk):
+    """8(f)-1 on the GPU: reference fixture (partial pass) + random request logs, device seeding, trace bit-exact vs oracle"""
+    from oracle import decommit_native as dn
+    from test_decommit_host import decommit_cs, load_decommit_fixture, streams
+    u, s, limit = load_decommit_fixture()
+    cs = decommit_cs(limit)
+    rng = np.random.default_rng(67)
+    insts = [dn.instance(u, s, limit)]
+    while len(insts) < 66:
+        uu, ss = dn.random_decommits(rng, int(rng.integers(1, 6)), max_repeats=3)
+        if len(uu) <= limit:
+            insts.append(dn.instance(uu, ss, limit))
+    assert all(i["satisfiable"] for i in insts)
+    outer, loop = streams(insts, limit)
+    raw = loop.copy()
+    raw[:dn.CARRIED] = 0
+    cs.set_batch(len(insts))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(raw.shape), loop)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+    run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), 65536)
+    run.resolve(outer, loop)
+    assert_trace_equal(cs, run)
