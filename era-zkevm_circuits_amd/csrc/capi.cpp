@@ -16,6 +16,8 @@ void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
 void keccak_configure(CS& cs);
 void sha256_configure(CS& cs);
+void code_unpacker_configure(CS& cs);
+void unpack_code_into_memory_entry_point(CS& cs, uint32_t limit);
 void sort_decommits_configure(CS& cs);
 void sort_and_deduplicate_code_decommittments_entry_point(CS& cs, uint32_t limit);
 void demux_log_queue_configure(CS& cs);
@@ -444,6 +446,14 @@ int zk_circuit_sort_decommits_configure(zk_cs* cs) {
 int zk_circuit_sort_decommits(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { zkgl::sort_and_deduplicate_code_decommittments_entry_point(*cs->cs, limit); });
+}
+int zk_circuit_code_unpacker_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::code_unpacker_configure(*cs->cs); });
+}
+int zk_circuit_code_unpacker(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { zkgl::unpack_code_into_memory_entry_point(*cs->cs, limit); });
 }
 int zk_circuit_sha256_configure(zk_cs* cs) {
     NEED(cs);

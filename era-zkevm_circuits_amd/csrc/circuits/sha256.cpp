@@ -14,6 +14,7 @@
 //
 // INPUT STREAMS: outer none; loop 96 words = carried state[32] (word w little-endian bytes at 4w..4w+3) | block[64].
 #include "../gadgets.hpp"
+#include "sha256_gadget.hpp"
 #include "log_query.hpp"
 #include "memory_query.hpp"
 
@@ -21,121 +22,7 @@ namespace zkgl {
 
 void keccak_configure(CS& cs);
 
-namespace {
-
-constexpr uint32_t T_ANDN8 = 32, T_SPLIT_BASE = 40;
-const uint32_t SHA_K[64] = {
-    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
-    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
-    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
-    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
-    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
-    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
-    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-const uint32_t SHA_IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-
-using Word = std::array<zk_var, 4>;  // little-endian bytes of a u32
-
-struct S {
-    G& g;
-    uint32_t t_xor, t_and, t_andn, t_split[8];
-    explicit S(G& g) : g(g) {
-        t_xor = g.cs.table_id(TABLE_XOR8);
-        t_and = g.cs.table_id(TABLE_AND8);
-        t_andn = g.cs.table_id(T_ANDN8);
-        for (int k = 1; k < 8; ++k) t_split[k] = g.cs.table_id(T_SPLIT_BASE + k);
-    }
-    Word bytewise(uint32_t table, const Word& a, const Word& b) {
-        Word r;
-        for (int k = 0; k < 4; ++k) r[k] = g.lookup(table, {a[k], b[k]}, 1)[0];
-        return r;
-    }
-    Word xor3(const Word& a, const Word& b, const Word& c) { return bytewise(t_xor, bytewise(t_xor, a, b), c); }
-    // split every byte at bit position `at`: byte = lo (at bits) + 2^at * hi (8-at bits)
-    void split_all(const Word& a, int at, Word& lo, Word& hi) {
-        for (int k = 0; k < 4; ++k) {
-            auto v = g.lookup(t_split[at], {a[k]}, 2);
-            lo[k] = v[0]; hi[k] = v[1];
-        }
-    }
-    Word rotr(const Word& a, int n) {  // rotate right by n bits (1 <= n < 32)
-        const int q = n / 8, b = n % 8;
-        Word r;
-        if (b == 0) {
-            for (int k = 0; k < 4; ++k) r[k] = a[(k + q) % 4];
-            return r;
-        }
-        Word lo, hi;  // byte = lo (b bits) + 2^b hi ; (x >> b): new byte j = hi[j] + lo[j+1] * 2^(8-b)
-        split_all(a, b, lo, hi);
-        for (int k = 0; k < 4; ++k) {
-            int j = (k + q) % 4;
-            r[k] = g.linear_combination({{hi[j], 1}, {lo[(j + 1) % 4], 1ull << (8 - b)}});
-        }
-        return r;
-    }
-    Word shr(const Word& a, int n) {  // logical shift right by n bits
-        const int q = n / 8, b = n % 8;
-        Word r, lo, hi;
-        if (b) split_all(a, b, lo, hi);
-        for (int k = 0; k < 4; ++k) {
-            int j = k + q;
-            if (j >= 4) { r[k] = g.zero(); continue; }
-            if (b == 0) { r[k] = a[j]; continue; }
-            if (j + 1 < 4) r[k] = g.linear_combination({{hi[j], 1}, {lo[j + 1], 1ull << (8 - b)}});
-            else r[k] = hi[j];
-        }
-        return r;
-    }
-    // (sum of the given words + constant) mod 2^32, as range-checkable bytes
-    Word add_mod32(const std::vector<Word>& words, uint64_t constant) {
-        std::vector<std::pair<zk_var, uint64_t>> terms;
-        for (auto& w : words)
-            for (int k = 0; k < 4; ++k) terms.push_back({w[k], 1ull << (8 * k)});
-        if (constant) terms.push_back({g.one(), constant});
-        zk_var sum = g.linear_combination(terms);  // < (n+1) * 2^32 << p
-        zk_var parts[5];
-        zk_var first = g.cs.alloc_vars(5);
-        for (int i = 0; i < 5; ++i) parts[i] = first + i;
-        g.cs.emit_op(ZK_OP_SPLIT, 5, 8, &sum, 1, parts, 5, nullptr, 0);  // 4 bytes + carry
-        zk_var low = g.linear_combination({{parts[0], 1}, {parts[1], 1ull << 8}, {parts[2], 1ull << 16}, {parts[3], 1ull << 24}});
-        g.enforce_equal(g.linear_combination({{low, 1}, {parts[4], 1ull << 32}}), sum);
-        g.range_check_u8_pair(parts[4], parts[4]);  // carry < 2^8 (it is < 8); the 4 bytes are range-checked by their consumers
-        return {parts[0], parts[1], parts[2], parts[3]};
-    }
-    void range_check_word(const Word& w) {
-        g.range_check_u8_pair(w[0], w[1]);
-        g.range_check_u8_pair(w[2], w[3]);
-    }
-    void compress(std::array<Word, 8>& st, const std::array<Word, 16>& block_words) {
-        std::vector<Word> w(block_words.begin(), block_words.end());
-        for (int i = 16; i < 64; ++i) {
-            Word s0 = xor3(rotr(w[i - 15], 7), rotr(w[i - 15], 18), shr(w[i - 15], 3));
-            Word s1 = xor3(rotr(w[i - 2], 17), rotr(w[i - 2], 19), shr(w[i - 2], 10));
-            w.push_back(add_mod32({w[i - 16], s0, w[i - 7], s1}, 0));
-        }
-        range_check_word(w[62]);  // the only schedule words no sigma lookup consumes
-        range_check_word(w[63]);
-        Word a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], gg = st[6], h = st[7];
-        for (int i = 0; i < 64; ++i) {
-            Word S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
-            Word ch = bytewise(t_xor, bytewise(t_and, e, f), bytewise(t_andn, e, gg));
-            Word S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
-            Word maj = bytewise(t_xor, bytewise(t_and, a, b), bytewise(t_and, c, bytewise(t_xor, a, b)));
-            Word new_e = add_mod32({d, h, S1, ch, w[i]}, SHA_K[i]);
-            Word new_a = add_mod32({h, S1, ch, w[i], S0, maj}, SHA_K[i]);
-            h = gg; gg = f; f = e; e = new_e; d = c; c = b; b = a; a = new_a;
-        }
-        range_check_word(a);  // outputs of the last round feed additions only
-        range_check_word(e);
-        const Word out[8] = {a, b, c, d, e, f, gg, h};
-        for (int i = 0; i < 8; ++i) {
-            st[i] = add_mod32({st[i], out[i]}, 0);
-            range_check_word(st[i]);
-        }
-    }
-};
-
-}  // namespace
+using namespace sha256_gadget;
 
 void sha256_configure(CS& cs) {
     keccak_configure(cs);  // gate set, xor8, andn8, ByteSplit<1..7>

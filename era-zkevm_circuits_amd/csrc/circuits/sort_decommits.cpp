@@ -11,6 +11,7 @@
 //   loop (87 words): carried[65] = previous_item_is_trivial, lhs[2], rhs[2], original head[12]+len, sorted head[12]+len,
 //       result tail[12]+len, previous_packed_key[9], first_encountered_timestamp, previous_record[11]
 //     | original DecommitQuery[11] | sorted DecommitQuery[11]
+#include "decommit_query.hpp"
 #include "log_query.hpp"
 #include "memory_query.hpp"
 
@@ -21,43 +22,6 @@ void log_sorter_configure(CS& cs);
 namespace {
 constexpr int REPS = 2, ENC = 8, KEY = 9, CARRIED = 65;
 
-struct DecommitQuery {
-    UInt256 code_hash;
-    UInt32 page;
-    Boolean is_first;
-    UInt32 timestamp;
-    std::vector<zk_var> flatten() const {
-        std::vector<zk_var> o;
-        for (auto& l : code_hash.inner) o.push_back(l.v);
-        o.push_back(page.v); o.push_back(is_first.v); o.push_back(timestamp.v);
-        return o;
-    }
-};
-DecommitQuery allocate_decommit_query(G& g) {
-    DecommitQuery q;
-    q.code_hash = g.alloc_u256_checked();
-    q.page = g.alloc_u32_checked();
-    q.is_first = g.alloc_bool();
-    q.timestamp = g.alloc_u32_checked();
-    return q;
-}
-DecommitQuery unflatten(const zk_var* f) {
-    DecommitQuery q;
-    for (int i = 0; i < 8; ++i) q.code_hash.inner[i] = UInt32{f[i]};
-    q.page = UInt32{f[8]}; q.is_first = Boolean{f[9]}; q.timestamp = UInt32{f[10]};
-    return q;
-}
-// DecommitQuery::encode — src/base_structures/decommit_query/mod.rs:33-113
-std::array<zk_var, ENC> encode_decommit_query(G& g, const DecommitQuery& q) {
-    const uint64_t S32 = 1ull << 32, S40 = 1ull << 40, S48 = 1ull << 48;
-    auto p = g.decompose_into_bytes(q.page);
-    auto t = g.decompose_into_bytes(q.timestamp);
-    zk_var v0 = g.linear_combination({{q.code_hash.inner[0].v, 1}, {p[0].v, S32}, {p[1].v, S40}, {p[2].v, S48}});
-    zk_var v1 = g.linear_combination({{q.code_hash.inner[1].v, 1}, {p[3].v, S32}, {t[0].v, S40}, {t[1].v, S48}});
-    zk_var v2 = g.linear_combination({{q.code_hash.inner[2].v, 1}, {t[2].v, S32}, {t[3].v, S40}, {q.is_first.v, S48}});
-    return {v0, v1, v2, q.code_hash.inner[3].v, q.code_hash.inner[4].v, q.code_hash.inner[5].v, q.code_hash.inner[6].v,
-            q.code_hash.inner[7].v};
-}
 void enforce_full_queue_consistency(G& g, const QueueState<12>& q) {  // empty => head == tail
     Boolean is_empty = g.is_zero(q.length.v);
     for (int i = 0; i < 12; ++i) conditionally_enforce_equal(g, is_empty, q.head[i].v, q.tail[i].v);
@@ -163,7 +127,7 @@ void sort_and_deduplicate_code_decommittments_entry_point(CS& cs, uint32_t limit
     std::array<UInt32, KEY> prev_key;
     for (int i = 0; i < KEY; ++i) prev_key[i] = UInt32{in[44 + i]};
     UInt32 first_ts{in[53]};
-    DecommitQuery prev_record = unflatten(&in[54]);
+    DecommitQuery prev_record = unflatten_decommit_query(&in[54]);
     std::array<std::array<zk_var, ENC + 1>, REPS> ch;
     for (int r = 0; r < REPS; ++r)
         for (int i = 0; i <= ENC; ++i) ch[r][i] = (i == 0) ? g.one() : cs.loop_import(challenges[r][i]);
@@ -234,7 +198,7 @@ void sort_and_deduplicate_code_decommittments_entry_point(CS& cs, uint32_t limit
     UInt32 rl{fin[43]};
     Boolean completed = g.is_zero(initial_f.length.v);
     g.enforce_bool_equal(completed, g.is_zero(sorted_f.length.v));
-    DecommitQuery last_record = unflatten(&fin[54]);
+    DecommitQuery last_record = unflatten_decommit_query(&fin[54]);
     {
         Boolean add = g.b_and(g.negated(Boolean{fin[0]}), completed);
         DecommitQuery record_to_add = last_record;

@@ -332,6 +332,7 @@ void CS::loop_begin(uint32_t limit) {
 void CS::side_begin() {
     if (in_loop_ || loop_done_ || outer_.pre_ops != SIZE_MAX) throw ZkError(ZK_ERR_INVALID, "side_begin: once, before loop_begin");
     outer_.pre_ops = outer_.ops.size();
+    pre_vars_ = outer_.n_vars;
 }
 void CS::loop_end() {
     if (!in_loop_) throw ZkError(ZK_ERR_INVALID, "loop_end without loop_begin");
@@ -343,6 +344,9 @@ void CS::link(uint32_t kind, zk_var loop_var, zk_var other) {
     if (kind > ZK_LINK_BCAST) throw ZkError(ZK_ERR_INVALID, "link: bad kind");
     check_var(loop_var, true);
     check_var(other, kind == ZK_LINK_CARRY);
+    // the loop (and the seeding pass) only sees outer values of the PRE phase
+    if ((kind == ZK_LINK_FIRST || kind == ZK_LINK_BCAST) && var_index(other) >= pre_vars_)
+        throw ZkError(ZK_ERR_INVALID, "link: the outer variable is produced after side_begin (side/post phase), not visible to the loop");
     links_raw_.push_back({kind, var_index(loop_var), var_index(other), 0});
 }
 
@@ -370,6 +374,7 @@ zk_var CS::loop_last(zk_var loop_var) {
 zk_var CS::loop_import(zk_var outer_var) {
     if (!in_loop_) throw ZkError(ZK_ERR_INVALID, "loop_import outside the loop");
     check_var(outer_var, false);
+    if (var_index(outer_var) >= pre_vars_) throw ZkError(ZK_ERR_INVALID, "loop_import: the outer variable is produced after side_begin");
     zk_var v = alloc_var();
     // value copy: FMA-free "select"-less move expressed as CONST-like op with an OUTER operand
     OpRec op{ZK_OP_CONST, 0, 0, {{Operand::OUTER_VAR, var_index(outer_var)}}, {var_index(v)}};

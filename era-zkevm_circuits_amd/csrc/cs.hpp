@@ -185,6 +185,7 @@ class CS {
     Scope outer_, loop_;
     bool in_loop_ = false, loop_done_ = false, finalized_ = false;
     uint32_t limit_ = 0;
+    uint32_t pre_vars_ = UINT32_MAX;  // outer variables allocated before side_begin (all of them when there is no side phase)
     std::vector<zk_link> links_raw_;  // vars, resolved to cells at finalize
     std::vector<zk_link> links_;
     std::vector<uint32_t> public_vars_;

@@ -406,6 +406,12 @@ class ConstraintSystem:
     def sort_and_deduplicate_code_decommittments_entry_point(self, limit: int):
         _check(lib().zk_circuit_sort_decommits(self._h, limit))
 
+    def configure_code_unpacker(self):
+        _check(lib().zk_circuit_code_unpacker_configure(self._h))
+
+    def unpack_code_into_memory_entry_point(self, limit: int):
+        _check(lib().zk_circuit_code_unpacker(self._h, limit))
+
     def configure_sha256(self):
         _check(lib().zk_circuit_sha256_configure(self._h))
 

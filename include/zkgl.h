@@ -244,6 +244,11 @@ int zk_circuit_demux_log_queue(zk_cs *cs, uint32_t limit);
  * Outer stream 151 words, loop stream 87 (see circuits/sort_decommits.cpp). */
 int zk_circuit_sort_decommits_configure(zk_cs *cs);
 int zk_circuit_sort_decommits(zk_cs *cs, uint32_t limit);
+/* unpack_code_into_memory_entry_point (src/code_unpacker_sha256/mod.rs:33-142): decommit requests popped from a full-state
+ * queue, bytecode words written to the memory queue two per cycle, SHA-256 over them compared with the versioned code hash.
+ * Outer stream 125 words, loop stream 101 (see circuits/code_unpacker.cpp). */
+int zk_circuit_code_unpacker_configure(zk_cs *cs);
+int zk_circuit_code_unpacker(zk_cs *cs, uint32_t limit);
 /* eip_4844_entry_point (src/eip_4844/mod.rs:107-260): Horner evaluation of the blob polynomial at the Fiat-Shamir point
  * over the non-native BLS12-381 scalar field + linear keccak256 of the blob + output hash; `n_chunks` 31-byte chunks
  * (the reference fixes 4096).  Outer stream 64 words (versioned_hash | linear_hash_output); loop stream

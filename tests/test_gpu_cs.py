@@ -569,3 +569,43 @@ def test_sort_decommittment_requests_gpu(zk):
     run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), 65536)
     run.resolve(outer, loop)
     assert_trace_equal(cs, run)
+
+
+def test_code_unpacker_sha256_gpu(zk):
+    """8(f)-4 on the GPU: the reference's SHA-256 known-answer fixture + random bytecodes; device seeding; trace parity"""
+    from oracle import code_unpacker_native as cn
+    from oracle.decommit_native import dq
+    from test_code_unpacker_host import TABLE_ROWS, load_code_unpacker_fixture, random_code, streams, unpacker_cs
+    req, words, limit = load_code_unpacker_fixture()
+    cs = unpacker_cs(limit)
+    rng = np.random.default_rng(68)
+    insts = [cn.instance([(req, words)], limit)]
+    while len(insts) < 66:
+        reqs, rounds = [], 0
+        while True:
+            n = 2 * int(rng.integers(0, 8)) + 1
+            if rounds + (n + 1) // 2 > limit:
+                break
+            w = random_code(rng, n)
+            reqs.append((dq(cn.versioned_hash(w), 2048 + 8 * len(reqs), 1, 5 + len(reqs)), w))
+            rounds += (n + 1) // 2
+            if rng.random() < 0.3:
+                break
+        insts.append(cn.instance(reqs, limit))
+    assert all(i["satisfiable"] for i in insts)
+    outer, loop = streams(insts, limit)
+    raw = loop.copy()
+    raw[:cn.CARRIED] = 0
+    cs.set_batch(len(insts))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(raw.shape), loop)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+    run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
+    run.resolve(outer, loop)
+    assert_trace_equal(cs, run)
