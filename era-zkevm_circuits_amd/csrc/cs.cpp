@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include "device_api.hpp"
@@ -444,7 +445,7 @@ void CS::place_scope(Scope& s) {
     s.lrows.resize(s.n_slots, zk_lookup_row_desc{0xffffffffu, 0});
     const uint32_t total_cols = C + lookup_width_ * lookup_reps_;
     uint64_t ntc = (uint64_t)total_cols * s.n_slots;
-    if (ntc >= 0x3fffffffull) throw ZkError(ZK_ERR_CAPACITY, "scope too large for 30-bit cell indices");
+    if (ntc >= (1ull << 23)) throw ZkError(ZK_ERR_CAPACITY, "scope too large: cell byte offsets within a tile must fit 32 bits (2^23 cells)");
     s.n_trace_cells = (uint32_t)ntc;
     s.var_cells.assign(s.n_vars, {});
     s.n_scratch = 0;
@@ -453,9 +454,107 @@ void CS::place_scope(Scope& s) {
         if (s.var_cells[v].empty()) s.var_cells[v].push_back(s.n_trace_cells + s.n_scratch++);
     }
     s.n_cells = s.n_trace_cells + s.n_scratch;
+    if (s.n_cells >= (1u << 23)) throw ZkError(ZK_ERR_CAPACITY, "scope too large: 2^23 cells per lane");
     s.copies.clear();
     for (uint32_t v = 0; v < s.n_vars; ++v)
         for (size_t i = 1; i < s.var_cells[v].size(); ++i) s.copies.push_back({s.var_cells[v][i], s.var_cells[v][0]});
+}
+
+// ------------------------------------------------------------------ op scheduling (loop scope)
+// The interpreter kernel is bound by two resources used in long separate phases when ops run in recording order:
+// VALU (Poseidon2 permutations: ~15k instructions each, the witness-only ones store 12 words) and the HBM write path
+// (everything else: ~1 instruction per stored word).  All waves run the same program nearly in lockstep, so the phases
+// of different waves coincide and the two resources idle in turn (measured: VALU busy 49 %, stores at 65 % of the
+// achievable write rate).  This pass reorders the ops — any topological order of the value dependencies fills the same
+// cells — so that every prefix of the program has used both resources in proportion: a greedy list scheduler that
+// always emits the ready op bringing |ALU_done/ALU_total - MEM_done/MEM_total| closest to zero, ties to recording order.
+void CS::schedule_loop_ops() {
+    const char* off = std::getenv("ZKGL_SCHEDULE");
+    Scope& s = loop_;
+    if (!limit_ || s.ops.size() < 3 || (off && off[0] == '0')) return;
+    const size_t n = s.ops.size();
+    auto alu_cost = [](const OpRec& op) -> double {
+        switch (op.opcode) {
+        case ZK_OP_POSEIDON2: case ZK_OP_P2_ROUNDS: return 14600;
+        case ZK_OP_ISZERO: return 2300;
+        case ZK_OP_NN_MULMOD: return 3000;
+        case ZK_OP_MATMUL12: return 250;
+        case ZK_OP_LOOKUP: return 60;
+        default: return 15;
+        }
+    };
+    std::vector<double> a(n), m(n);
+    double a_tot = 0, m_tot = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const OpRec& op = s.ops[i];
+        double stores = 0;
+        for (auto ov : op.outs) stores += (double)s.var_cells[ov].size();
+        a[i] = alu_cost(op);
+        m[i] = stores + 0.25 * (double)op.ins.size();
+        a_tot += a[i]; m_tot += m[i];
+    }
+    bool any_heavy = false;
+    for (size_t i = 0; i < n; ++i) any_heavy |= a[i] > 1000;
+    if (!any_heavy || a_tot <= 0 || m_tot <= 0) return;
+    // dependencies through loop variables
+    std::vector<uint32_t> producer(s.n_vars, UINT32_MAX);
+    for (size_t i = 0; i < n; ++i)
+        for (auto ov : s.ops[i].outs) producer[ov] = (uint32_t)i;
+    std::vector<std::vector<uint32_t>> succ(n);
+    std::vector<uint32_t> n_pred(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        std::vector<uint32_t> ps;
+        for (auto& in : s.ops[i].ins)
+            if (in.kind == Operand::VAR && producer[in.idx] != UINT32_MAX) ps.push_back(producer[in.idx]);
+        std::sort(ps.begin(), ps.end());
+        ps.erase(std::unique(ps.begin(), ps.end()), ps.end());
+        for (auto p : ps) {
+            if (p >= i) return;  // not in dependency order: leave the program alone (emit_scope reports it)
+            succ[p].push_back((uint32_t)i);
+            ++n_pred[i];
+        }
+    }
+    // Light ops keep their recording order among themselves (operand locality in L2): only the FIRST ready light op is a
+    // candidate; every ready heavy op is.
+    std::vector<uint8_t> done(n, 0), is_ready(n, 0);
+    std::vector<uint32_t> ready_heavy, order;
+    order.reserve(n);
+    for (size_t i = 0; i < n; ++i)
+        if (n_pred[i] == 0) { is_ready[i] = 1; if (a[i] > 1000) ready_heavy.push_back((uint32_t)i); }
+    size_t light_cursor = 0;
+    double a_done = 0, m_done = 0;
+    auto imbalance_after = [&](uint32_t i) { return std::fabs((a_done + a[i]) / a_tot - (m_done + m[i]) / m_tot); };
+    while (order.size() < n) {
+        while (light_cursor < n && (done[light_cursor] || a[light_cursor] > 1000)) ++light_cursor;
+        // first light op in recording order that is ready (light ops blocked by a pending heavy producer are skipped over)
+        uint32_t cand_light = UINT32_MAX;
+        for (size_t j = light_cursor, seen = 0; j < n && seen < 4096; ++j) {
+            if (done[j] || a[j] > 1000) continue;
+            ++seen;
+            if (is_ready[j]) { cand_light = (uint32_t)j; break; }
+        }
+        uint32_t best = cand_light;
+        double best_v = cand_light == UINT32_MAX ? 1e300 : imbalance_after(cand_light);
+        for (auto h : ready_heavy) {
+            double v = imbalance_after(h);
+            if (v < best_v - 1e-12 || (std::fabs(v - best_v) <= 1e-12 && h < best)) { best = h; best_v = v; }
+        }
+        if (best == UINT32_MAX) {  // nothing found in the window: fall back to the first ready op of any kind
+            for (size_t j = 0; j < n; ++j)
+                if (!done[j] && is_ready[j]) { best = (uint32_t)j; break; }
+            if (best == UINT32_MAX) return;  // cycle: leave as recorded
+        }
+        done[best] = 1;
+        order.push_back(best);
+        a_done += a[best]; m_done += m[best];
+        if (a[best] > 1000) ready_heavy.erase(std::find(ready_heavy.begin(), ready_heavy.end(), best));
+        for (auto nx : succ[best])
+            if (--n_pred[nx] == 0) { is_ready[nx] = 1; if (a[nx] > 1000) ready_heavy.push_back(nx); }
+    }
+    std::vector<OpRec> reordered;
+    reordered.reserve(n);
+    for (auto i : order) reordered.push_back(std::move(s.ops[i]));
+    s.ops = std::move(reordered);
 }
 
 // ------------------------------------------------------------------ program emission
@@ -610,6 +709,7 @@ void CS::finalize() {
                 if (in.kind == Operand::OUTER_VAR && !pre_defined[in.idx])
                     throw ZkError(ZK_ERR_UNRESOLVED, "loop imports an outer variable that is produced after the loop");
     }
+    schedule_loop_ops();
     emit_scope(outer_);
     emit_scope(loop_);
     uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;

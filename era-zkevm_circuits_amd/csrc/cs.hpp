@@ -167,6 +167,7 @@ class CS {
     Scope& scope_of(zk_var v) { return is_loop_var(v) ? loop_ : outer_; }
     uint32_t pool_const(Scope& s, uint64_t v);
     void place_scope(Scope& s);
+    void schedule_loop_ops();
     void emit_scope(Scope& s);
     void upload_scope(Scope& s);
     void ensure_uploaded();

@@ -183,11 +183,21 @@ __device__ __noinline__ void nn_mulmod(const uint32_t* a, uint32_t na, const uin
 // and 500 B of scratch); the launcher picks them only for programs that contain the op.
 // SLOTS: seeding mode (k_seed_cone).  Values live in an LDS slot store instead of trace cells: cell-kind operands
 // and destinations are slot indices assigned by the host's liveness allocation, one destination word per output.
-template <bool WITH_BIGINT, bool SLOTS = false>
+// TILE_UNIFORM: the 64 threads of the wave hold the 64 lanes of ONE tile (parallel kernels: consecutive lanes), so the
+// tile base is wave-uniform.  Cells are then accessed with raw buffer instructions: V# = tile base, soffset (SGPR) =
+// cell * 512 B straight from the program word, voffset (VGPR, constant per thread) = lane-in-tile * 8 — no vector
+// address arithmetic per load / store (`buffer_store_dwordx2 v[d], v_off, s[rsrc], s_cell offen`).  The host
+// guarantees cell * 512 < 2^32 (CS::place_scope).
+template <bool WITH_BIGINT, bool SLOTS = false, bool TILE_UNIFORM = false>
 __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                          uint32_t word_begin, uint32_t word_end, const uint32_t* prog = nullptr,
                                          uint64_t* slots = nullptr, uint32_t slot_stride = 0, const uint64_t* in_area = nullptr) {
     uint64_t* __restrict__ cells = sc.cells + cell_off(sc.n_cells, 0, lane);  // this lane's column of its tile
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane_byte = (lane & 63) * 8;
+    __amdgpu_buffer_rsrc_t tile_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        sc.cells + (size_t)(TILE_UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6)) : 0u) * sc.n_cells * 64, 0, -1,
+        0x00020000);  // gfx9 raw buffer descriptor: stride 0, num_records 2^32-1, 32-bit data format
     ProgWindow P;
     P.init(SLOTS ? prog : sc.prog, word_begin);
     __shared__ uint64_t p2s[12 * TPB];  // Poseidon2 state, [element][thread]
@@ -197,6 +207,10 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         if (kind == ZK_OPERAND_CONST) return sc.consts[idx];
         if (kind == ZK_OPERAND_OUTER) return sc.outer_cells[cell_off(sc.outer_n_cells, idx, inst)];
         if constexpr (SLOTS) return slots[idx * slot_stride];
+        if constexpr (TILE_UNIFORM) {
+            u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc, lane_byte, idx << 9, 0);
+            return (uint64_t)v.x | ((uint64_t)v.y << 32);
+        }
         return cells[(size_t)idx << 6];
     };
     uint32_t pc = word_begin;
@@ -209,7 +223,13 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             do {
                 P.sync(pc);
                 w = P.at(pc++);
-                cells[(size_t)(w & ~ZK_DEST_MORE) << 6] = v;
+                if constexpr (TILE_UNIFORM) {
+                    u32x2 o;
+                    o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ~ZK_DEST_MORE) << 9, 0);
+                } else {
+                    cells[(size_t)(w & ~ZK_DEST_MORE) << 6] = v;
+                }
             } while (w & ZK_DEST_MORE);
         }
     };
@@ -390,7 +410,7 @@ __device__ __forceinline__ void witness_entry(const ScopeDev& sc, uint32_t word_
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
     const bool active = lane < sc.n_lanes;
     lane = active ? lane : sc.n_lanes - 1;
-    run_lane<WITH_BIGINT>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
+    run_lane<WITH_BIGINT, false, true>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
 }
 __global__ __launch_bounds__(TPB) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
     witness_entry<false>(sc, word_begin, word_end);
