@@ -2,8 +2,8 @@
 # Builds libzkgl.so (gfx950 only) in-tree.  Usage: era-zkevm_circuits_amd/build.sh
 set -euo pipefail
 cd "$(dirname "$0")/csrc"
-OUT=../libzkgl.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value"
+OUT=${ZKGL_OUT:-../libzkgl.so}   # ZKGL_OUT / ZKGL_DEFS: side-by-side kernel variants for tools/variant_bench.sh
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value ${ZKGL_DEFS:-}"
 mkdir -p ../build
 pids=()
 for f in zkgl_device.hip; do

@@ -43,8 +43,21 @@ __host__ __device__ __forceinline__ uint64_t reduce128(uint64_t lo, uint64_t hi)
 }
 
 __device__ __forceinline__ void mul_wide(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
-    lo = a * b;
-    hi = __umul64hi(a, b);
+    // four v_mad_u64_u32 (32x32 + 64 -> 64) instead of a 64-bit multiply plus a separate __umul64hi
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t p00 = (uint64_t)a0 * b0;
+    const uint64_t p01 = (uint64_t)a0 * b1 + (p00 >> 32);
+    const uint64_t p10 = (uint64_t)a1 * b0 + (uint32_t)p01;
+    hi = (uint64_t)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    lo = ((uint64_t)(uint32_t)p10 << 32) | (uint32_t)p00;
+}
+
+// lo + hi * 2^64 (hi < 2^31) -> canonical.  Used by the lazily accumulated MDS layers.
+__device__ __forceinline__ uint64_t reduce96(uint64_t lo, uint32_t hi) {
+    const uint64_t t = ((uint64_t)hi << 32) - hi;  // hi * (2^32 - 1) == hi * 2^64 (mod p)
+    uint64_t r = lo + t;
+    if (r < t) r += EPS;
+    return r >= P ? r - P : r;
 }
 
 __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {

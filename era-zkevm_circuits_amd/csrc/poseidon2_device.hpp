@@ -20,43 +20,44 @@ __constant__ uint64_t RC[360];
 
 constexpr int INNER_SHIFT[12] = {4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12};
 
-// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] through the 8-addition chain
-__device__ __forceinline__ void m4(uint64_t& x0, uint64_t& x1, uint64_t& x2, uint64_t& x3) {
-    uint64_t t0 = gl::add(x0, x1);
-    uint64_t t1 = gl::add(x2, x3);
-    uint64_t t2 = gl::add(gl::add(x1, x1), t1);
-    uint64_t t3 = gl::add(gl::add(x3, x3), t0);
-    uint64_t t1_2 = gl::add(t1, t1);
-    uint64_t t0_2 = gl::add(t0, t0);
-    uint64_t t4 = gl::add(gl::add(t1_2, t1_2), t3);
-    uint64_t t5 = gl::add(gl::add(t0_2, t0_2), t2);
-    x0 = gl::add(t3, t5);
-    x1 = t5;
-    x2 = gl::add(t2, t4);
-    x3 = t4;
+// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] through the 8-addition chain; M_E = circ(2*M4, M4, M4); M_I = J + diag(2^k).
+// Lazily accumulated variants: sums are carried as 96-bit integers (lo, hi = number of 2^64 wraps) with 3-instruction
+// additions and reduced once per output, instead of a canonicalising 8-instruction gl::add per term.
+struct W { uint64_t lo; uint32_t hi; };
+__device__ __forceinline__ W wadd(W a, W b) { W r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u); return r; }
+__device__ __forceinline__ void m4w(W& x0, W& x1, W& x2, W& x3) {
+    W t0 = wadd(x0, x1), t1 = wadd(x2, x3);
+    W t2 = wadd(wadd(x1, x1), t1), t3 = wadd(wadd(x3, x3), t0);
+    W t1_2 = wadd(t1, t1), t0_2 = wadd(t0, t0);
+    W t4 = wadd(wadd(t1_2, t1_2), t3), t5 = wadd(wadd(t0_2, t0_2), t2);
+    x0 = wadd(t3, t5); x1 = t5; x2 = wadd(t2, t4); x3 = t4;
 }
-
 __device__ __forceinline__ void mds_external(uint64_t s[12]) {
-    m4(s[0], s[1], s[2], s[3]);
-    m4(s[4], s[5], s[6], s[7]);
-    m4(s[8], s[9], s[10], s[11]);
+    W w[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { w[i].lo = s[i]; w[i].hi = 0; }
+    m4w(w[0], w[1], w[2], w[3]);
+    m4w(w[4], w[5], w[6], w[7]);
+    m4w(w[8], w[9], w[10], w[11]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        uint64_t sum = gl::add(gl::add(s[i], s[4 + i]), s[8 + i]);
-        s[i] = gl::add(s[i], sum);
-        s[4 + i] = gl::add(s[4 + i], sum);
-        s[8 + i] = gl::add(s[8 + i], sum);
+        W sum = wadd(wadd(w[i], w[4 + i]), w[8 + i]);
+        W a = wadd(w[i], sum), b = wadd(w[4 + i], sum), c = wadd(w[8 + i], sum);
+        s[i] = gl::reduce96(a.lo, a.hi); s[4 + i] = gl::reduce96(b.lo, b.hi); s[8 + i] = gl::reduce96(c.lo, c.hi);
     }
 }
-
 __device__ __forceinline__ void mds_inner(uint64_t s[12]) {
-    uint64_t sum = s[0];
+    W sum{s[0], 0};
 #pragma unroll
-    for (int i = 1; i < 12; ++i) sum = gl::add(sum, s[i]);
+    for (int i = 1; i < 12; ++i) { sum.lo += s[i]; sum.hi += (sum.lo < s[i] ? 1u : 0u); }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = gl::add(sum, gl::mul_pow2(s[i], INNER_SHIFT[i]));
+    for (int i = 0; i < 12; ++i) {
+        const int k = INNER_SHIFT[i];
+        W t{s[i] << k, k ? (uint32_t)(s[i] >> (64 - k)) : 0u};
+        W r = wadd(sum, t);
+        s[i] = gl::reduce96(r.lo, r.hi);
+    }
 }
-
 __device__ __forceinline__ void full_round(uint64_t s[12], int r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl::pow7(gl::add(s[i], RC[12 * r + i]));

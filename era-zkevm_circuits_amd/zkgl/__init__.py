@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libzkgl.so")
+_LIB_PATH = os.environ.get("ZKGL_LIB") or os.path.join(os.path.dirname(_HERE), "libzkgl.so")  # ZKGL_LIB: kernel-variant experiments
 
 P = 0xFFFFFFFF00000001
 
