@@ -586,7 +586,11 @@ void CS::emit_scope(Scope& s) {
             if (defined[ov]) throw ZkError(ZK_ERR_INVALID, "variable produced twice");
             defined[ov] = 1;
             const auto& cells = s.var_cells[ov];
-            for (size_t i = 0; i < cells.size(); ++i) s.prog.push_back(cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0));
+            for (size_t i = 0; i < cells.size(); ++i) {
+                uint32_t w = cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0);
+                if (i == 0) w |= (uint32_t)std::min<size_t>(cells.size() - 1, ZK_DEST_COUNT_MASK) << ZK_DEST_COUNT_SHIFT;
+                s.prog.push_back(w);
+            }
             s.cells_written += cells.size();
         }
     }

@@ -226,9 +226,9 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                 if constexpr (TILE_UNIFORM) {
                     u32x2 o;
                     o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
-                    __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ~ZK_DEST_MORE) << 9, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ZK_DEST_CELL_MASK) << 9, 0);
                 } else {
-                    cells[(size_t)(w & ~ZK_DEST_MORE) << 6] = v;
+                    cells[(size_t)(w & ZK_DEST_CELL_MASK) << 6] = v;
                 }
             } while (w & ZK_DEST_MORE);
         }

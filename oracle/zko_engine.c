@@ -120,7 +120,7 @@ static void st(const run_ctx *c, const uint32_t *prog, uint32_t *pc, uint32_t la
     uint32_t w;
     do {
         w = prog[(*pc)++];
-        c->cells[(size_t)(w & ~ZK_DEST_MORE) * c->stride + lane] = v;
+        c->cells[(size_t)(w & ZK_DEST_CELL_MASK) * c->stride + lane] = v;
     } while (w & ZK_DEST_MORE);
 }
 
