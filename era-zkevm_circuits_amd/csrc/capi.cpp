@@ -354,6 +354,15 @@ int zk_cs_multiplicities(zk_cs* cs, uint32_t instance, uint32_t* out, uint32_t m
         if (out) for (uint32_t i = 0; i < v.size() && i < max; ++i) out[i] = v[i];
     });
 }
+int zk_cs_lookup_argument(zk_cs* cs, const uint64_t beta[2], const uint64_t gamma[2], void* stream, uint64_t* out, uint32_t max_instances,
+                          uint32_t* n_mismatch) {
+    NEED(cs); NEED(beta); NEED(gamma); NEED(n_mismatch); NEED_INIT();
+    return guard([&] {
+        std::vector<uint64_t> v;
+        *n_mismatch = cs->cs->lookup_argument(beta, gamma, stream, v);
+        if (out) for (size_t i = 0; i < v.size() && i < 4 * (size_t)max_instances; ++i) out[i] = v[i];
+    });
+}
 int zk_cs_stats(zk_cs* cs, zk_stats* out) {
     NEED(cs); NEED(out);
     return guard([&] { cs->cs->stats(out); });

@@ -936,6 +936,53 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
     return decode_failure(f, first);
 }
 
+// K5 (kernels_lookup_arg.hpp): the witness side sums 1/f over every lookup tuple of the trace, the table side sums
+// multiplicity/f over the table rows; equality per instance is the log-derivative lookup argument.
+uint32_t CS::lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], void* stream, std::vector<uint64_t>& out) {
+    if (batch_ == 0 || !uploaded_) throw ZkError(ZK_ERR_INVALID, "lookup_argument before set_batch / resolve");
+    if (lookup_reps_ > 32) throw ZkError(ZK_ERR_INVALID, "lookup_argument: more than 32 repetitions per row");
+    hipStream_t st = (hipStream_t)stream;
+    auto emul = [](const uint64_t x[2], const uint64_t y[2], uint64_t r[2]) {  // host GF(p^2), X^2 = 7
+        auto mulm = [](uint64_t a, uint64_t b) { return (uint64_t)((unsigned __int128)a * b % 0xFFFFFFFF00000001ull); };
+        auto addm = [](uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % 0xFFFFFFFF00000001ull); };
+        uint64_t a = addm(mulm(x[0], y[0]), mulm(7, mulm(x[1], y[1]))), b = addm(mulm(x[0], y[1]), mulm(x[1], y[0]));
+        r[0] = a; r[1] = b;
+    };
+    uint64_t ch[8] = {beta[0], beta[1], gamma[0], gamma[1], 0, 0, 0, 0};
+    emul(gamma, gamma, ch + 4);
+    emul(ch + 4, gamma, ch + 6);
+    for (int i = 0; i < 8; ++i)
+        if (ch[i] >= 0xFFFFFFFF00000001ull) throw ZkError(ZK_ERR_INVALID, "lookup_argument: non-canonical challenge");
+    uint64_t *d_acc_o = nullptr, *d_acc_l = nullptr, *d_inv = nullptr, *d_ab = nullptr;
+    auto alloc = [&](uint64_t** p, size_t words) { hip_check(hipMalloc((void**)p, std::max<size_t>(words, 1) * 8), "hipMalloc lookup_argument"); };
+    alloc(&d_acc_o, 2 * (size_t)outer_.n_lanes);
+    alloc(&d_acc_l, 2 * (size_t)loop_.n_lanes);
+    alloc(&d_inv, 2 * (size_t)total_table_rows_);
+    alloc(&d_ab, 4 * (size_t)batch_);
+    const uint32_t n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
+    auto side = [&](const Scope& s, uint64_t* acc) {
+        zkdev::LookupArgArgs a{s.d_cells, s.n_cells, n_cols, s.n_lanes, s.n_slots, geo_.num_columns_under_copy_permutation, lookup_width_, s.d_lrows, acc};
+        dev_check(zkdev::launch_lookup_arg_witness(a, ch, st));
+    };
+    side(outer_, d_acc_o);
+    if (limit_) side(loop_, d_acc_l);
+    dev_check(zkdev::launch_lookup_arg_witness_sum(d_acc_o, d_acc_l, limit_, batch_, d_ab, st));
+    dev_check(zkdev::launch_lookup_arg_tables(d_tables_, (uint32_t)tables_.size() + 1, d_table_words_, total_table_rows_, ch, d_inv, d_mult_, batch_,
+                                              d_ab + 2 * (size_t)batch_, st));
+    std::vector<uint64_t> h(4 * (size_t)batch_);
+    hip_check(hipMemcpyAsync(h.data(), d_ab, h.size() * 8, hipMemcpyDeviceToHost, st), "memcpy lookup_argument");
+    hip_check(hipStreamSynchronize(st), "lookup_argument sync");
+    hipFree(d_acc_o); hipFree(d_acc_l); hipFree(d_inv); hipFree(d_ab);
+    out.resize(4 * (size_t)batch_);
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < batch_; ++i) {
+        out[4 * i] = h[2 * i]; out[4 * i + 1] = h[2 * i + 1];
+        out[4 * i + 2] = h[2 * ((size_t)batch_ + i)]; out[4 * i + 3] = h[2 * ((size_t)batch_ + i) + 1];
+        bad += (out[4 * i] != out[4 * i + 2] || out[4 * i + 1] != out[4 * i + 3]);
+    }
+    return bad;
+}
+
 void CS::check_streams(void* stream) {
     for (size_t i = 0; i < streams_.size(); ++i) {
         const auto& sr = streams_[i];

@@ -148,6 +148,9 @@ class CS {
     uint32_t var_cell(zk_var v) const;
     std::vector<uint32_t> public_cells() const;
     std::vector<uint32_t> multiplicities(uint32_t instance);
+    // K5: log-derivative lookup-argument accumulators over the resolved trace; out[instance] = {A.a, A.b, B.a, B.b};
+    // returns the number of instances with A != B
+    uint32_t lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], void* stream, std::vector<uint64_t>& out);
     void stats(zk_stats* out) const;
     float last_ms(int which) const;
     std::vector<uint32_t> export_scope(bool loop_scope) const;

@@ -334,6 +334,15 @@ class ConstraintSystem:
     def link(self, kind: int, loop_var: int, other: int):
         _check(lib().zk_cs_link(self._h, kind, loop_var, other))
 
+    def lookup_argument(self, beta, gamma, stream=None):
+        """K5: -> (n_mismatch, array [batch, 4] = witness-side sum (a, b), table-side sum (a, b) in GF(p^2))"""
+        b = (C.c_uint64 * 2)(*beta)
+        g = (C.c_uint64 * 2)(*gamma)
+        out = np.zeros((self.batch, 4), dtype=np.uint64)
+        bad = C.c_uint32()
+        _check(lib().zk_cs_lookup_argument(self._h, b, g, C.c_void_p(stream or 0), out.ctypes.data_as(C.c_void_p), self.batch, C.byref(bad)))
+        return bad.value, out
+
     def stream_link(self, a_vars, b_vars, n_total: int):
         a = (C.c_uint32 * len(a_vars))(*a_vars)
         b = (C.c_uint32 * len(b_vars))(*b_vars)

@@ -199,6 +199,12 @@ typedef struct zk_stats {
     /* cone seeding program (backward slice of the carried outputs; 0 when the generic sequential mode is used) */
     uint64_t seed_ops, seed_words, seed_slots, loop_ops;
 } zk_stats;
+/* K5 — log-derivative lookup-argument accumulators over the resolved trace (prover stage after satisfiability, SURVEY 8f-3;
+ * boojum's polynomial form is [EXT], the sums are defined in csrc/kernels_lookup_arg.hpp).  beta, gamma: canonical GF(p^2)
+ * elements (a + bX, X^2 = 7).  out (4 words per instance, may be NULL): witness-side sum A (a, b) then table-side sum B (a, b);
+ * *n_mismatch = number of instances with A != B.  Call after zk_cs_resolve / zk_cs_resolve_and_check. */
+int zk_cs_lookup_argument(zk_cs *cs, const uint64_t beta[2], const uint64_t gamma[2], void *stream, uint64_t *out, uint32_t max_instances,
+                          uint32_t *n_mismatch);
 int zk_cs_stats(zk_cs *cs, zk_stats *out);           /* print_gate_stats counterpart */
 /* last execution times in ms measured with HIP events on the execution stream:
  * which: 0 resolve total (fused: whole pipeline), 1 loop witness kernel, 2 check total (fused: loop gates+copies),

@@ -252,3 +252,75 @@ class CircuitRun:
             total_rel += nrel.value
             bad += int(L.zko_links_check(self.loop.h, _p(self.lc), self.lc.shape[1], self.B * self.limit, _p(self.oc), self.so))
         return bad, total_rel
+
+
+# ---- K5 lookup-argument oracle (pure Python integers; CPU ORACLE, test infrastructure) ----
+def parse_export(words) -> dict:
+    """sections of a serialised scope (ConstraintSystem.export): header fields, lookup rows, table descriptors / words"""
+    w = [int(x) for x in np.asarray(words, dtype=np.uint32)]
+    assert w[0] == 0x5a4b4733
+    h = dict(is_loop=w[1], n_cells=w[2], n_trace_cells=w[3], n_slots=w[4], n_copy_cols=w[5], lookup_width=w[6], n_input_words=w[7],
+             limit=w[8], pre_words=w[9], n_prog=w[10], n_consts=w[11], n_rows=w[12], n_rowconsts=w[13], n_lrows=w[14], n_copies=w[15],
+             n_tables=w[16], n_table_words=w[17], n_links=w[18], n_carries=w[19], n_stream_words=w[20])
+    p = 21 + h["n_prog"] + 2 * h["n_consts"] + 4 * h["n_rows"] + 2 * h["n_rowconsts"]
+    h["lrows"] = [(w[p + 2 * i], w[p + 2 * i + 1]) for i in range(h["n_lrows"])]
+    p += 2 * h["n_lrows"] + 2 * h["n_copies"]
+    h["tables"] = [dict(word_off=w[p + 9 * i], mult_off=w[p + 9 * i + 1], n_rows=w[p + 9 * i + 2], n_keys=w[p + 9 * i + 3], n_vals=w[p + 9 * i + 4])
+                   for i in range(h["n_tables"])]
+    p += 9 * h["n_tables"]
+    h["table_words"] = [w[p + 2 * i] | (w[p + 2 * i + 1] << 32) for i in range(h["n_table_words"])]
+    return h
+
+
+def e2_mul(x, y):
+    return ((x[0] * y[0] + 7 * x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
+
+
+def e2_inv(x):
+    n = pow((x[0] * x[0] - 7 * x[1] * x[1]) % P, P - 2, P)
+    return (x[0] * n % P, (P - x[1]) * n % P)
+
+
+def lookup_argument(run: "CircuitRun", outer_words, loop_words, beta, gamma, n_cols: int):
+    """K5 restatement (csrc/kernels_lookup_arg.hpp): per instance (A, B) with A = sum over every lookup tuple of the trace of
+    1/f, B = sum over table rows of multiplicity/f, f = beta + c0 + gamma c1 + gamma^2 c2 + gamma^3 table."""
+    g1, g2 = tuple(gamma), e2_mul(gamma, gamma)
+    g3 = e2_mul(g2, g1)
+
+    def f(c, t):
+        c = list(c) + [0] * (3 - len(c))
+        return ((beta[0] + c[0] + g1[0] * c[1] + g2[0] * c[2] + g3[0] * t) % P, (beta[1] + g1[1] * c[1] + g2[1] * c[2] + g3[1] * t) % P)
+
+    def add(x, y):
+        return ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
+
+    out = []
+    ho = parse_export(outer_words)
+    hl = parse_export(loop_words) if run.limit else None
+    for inst in range(run.B):
+        A = (0, 0)
+        for h, cells, lanes in ((ho, run.oc, [inst]), (hl, run.lc, range(inst * run.limit, (inst + 1) * run.limit))):
+            if h is None:
+                continue
+            W, C0 = h["lookup_width"], h["n_copy_cols"]
+            for lane in lanes:
+                for slot, (table, n) in enumerate(h["lrows"]):
+                    if table == 0xFFFFFFFF:
+                        continue
+                    for u in range(n):
+                        c0 = slot * n_cols + C0 + u * W
+                        A = add(A, e2_inv(f([int(cells[c0 + j, lane]) for j in range(min(W, 3))], table)))
+        B = (0, 0)
+        total = run.total_rows
+        for t, td in enumerate(ho["tables"]):
+            if t == 0:
+                continue
+            w = td["n_keys"] + td["n_vals"]
+            for r in range(td["n_rows"]):
+                m = int(run.mult[inst * total + td["mult_off"] + r])
+                if m:
+                    row = ho["table_words"][td["word_off"] + r * w: td["word_off"] + (r + 1) * w]
+                    i = e2_inv(f(row[:3], t))
+                    B = add(B, (i[0] * m % P, i[1] * m % P))
+        out.append(A + B)
+    return out
