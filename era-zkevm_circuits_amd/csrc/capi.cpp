@@ -16,6 +16,8 @@ void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
 void keccak_configure(CS& cs);
 void sha256_configure(CS& cs);
+void linear_hasher_configure(CS& cs);
+void linear_hasher_entry_point(CS& cs, uint32_t limit);
 void code_unpacker_configure(CS& cs);
 void unpack_code_into_memory_entry_point(CS& cs, uint32_t limit);
 void sort_decommits_configure(CS& cs);
@@ -463,6 +465,14 @@ int zk_circuit_code_unpacker_configure(zk_cs* cs) {
 int zk_circuit_code_unpacker(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { zkgl::unpack_code_into_memory_entry_point(*cs->cs, limit); });
+}
+int zk_circuit_linear_hasher_configure(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::linear_hasher_configure(*cs->cs); });
+}
+int zk_circuit_linear_hasher(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { zkgl::linear_hasher_entry_point(*cs->cs, limit); });
 }
 int zk_circuit_sha256_configure(zk_cs* cs) {
     NEED(cs);

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <queue>
 #include "device_api.hpp"
 
 namespace zkgl {
@@ -445,7 +446,7 @@ void CS::place_scope(Scope& s) {
     s.lrows.resize(s.n_slots, zk_lookup_row_desc{0xffffffffu, 0});
     const uint32_t total_cols = C + lookup_width_ * lookup_reps_;
     uint64_t ntc = (uint64_t)total_cols * s.n_slots;
-    if (ntc >= (1ull << 23)) throw ZkError(ZK_ERR_CAPACITY, "scope too large: cell byte offsets within a tile must fit 32 bits (2^23 cells)");
+    if (ntc >= 0x3fffffffull) throw ZkError(ZK_ERR_CAPACITY, "scope too large for 30-bit cell indices");
     s.n_trace_cells = (uint32_t)ntc;
     s.var_cells.assign(s.n_vars, {});
     s.n_scratch = 0;
@@ -454,7 +455,7 @@ void CS::place_scope(Scope& s) {
         if (s.var_cells[v].empty()) s.var_cells[v].push_back(s.n_trace_cells + s.n_scratch++);
     }
     s.n_cells = s.n_trace_cells + s.n_scratch;
-    if (s.n_cells >= (1u << 23)) throw ZkError(ZK_ERR_CAPACITY, "scope too large: 2^23 cells per lane");
+    if (s.n_cells >= 0x3fffffffu) throw ZkError(ZK_ERR_CAPACITY, "scope too large for 30-bit cell indices");
     s.copies.clear();
     for (uint32_t v = 0; v < s.n_vars; ++v)
         for (size_t i = 1; i < s.var_cells[v].size(); ++i) s.copies.push_back({s.var_cells[v][i], s.var_cells[v][0]});
@@ -514,42 +515,32 @@ void CS::schedule_loop_ops() {
             ++n_pred[i];
         }
     }
-    // Light ops keep their recording order among themselves (operand locality in L2): only the FIRST ready light op is a
-    // candidate; every ready heavy op is.
-    std::vector<uint8_t> done(n, 0), is_ready(n, 0);
+    // Light ops keep their recording order among themselves (operand locality in L2): only the FIRST ready light op (a
+    // min-heap on the recording index) is a candidate; every ready heavy op is.
+    std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> ready_light;
     std::vector<uint32_t> ready_heavy, order;
     order.reserve(n);
+    auto make_ready = [&](uint32_t i) { if (a[i] > 1000) ready_heavy.push_back(i); else ready_light.push(i); };
     for (size_t i = 0; i < n; ++i)
-        if (n_pred[i] == 0) { is_ready[i] = 1; if (a[i] > 1000) ready_heavy.push_back((uint32_t)i); }
-    size_t light_cursor = 0;
+        if (n_pred[i] == 0) make_ready((uint32_t)i);
     double a_done = 0, m_done = 0;
     auto imbalance_after = [&](uint32_t i) { return std::fabs((a_done + a[i]) / a_tot - (m_done + m[i]) / m_tot); };
     while (order.size() < n) {
-        while (light_cursor < n && (done[light_cursor] || a[light_cursor] > 1000)) ++light_cursor;
-        // first light op in recording order that is ready (light ops blocked by a pending heavy producer are skipped over)
-        uint32_t cand_light = UINT32_MAX;
-        for (size_t j = light_cursor, seen = 0; j < n && seen < 4096; ++j) {
-            if (done[j] || a[j] > 1000) continue;
-            ++seen;
-            if (is_ready[j]) { cand_light = (uint32_t)j; break; }
-        }
-        uint32_t best = cand_light;
-        double best_v = cand_light == UINT32_MAX ? 1e300 : imbalance_after(cand_light);
-        for (auto h : ready_heavy) {
+        uint32_t best = ready_light.empty() ? UINT32_MAX : ready_light.top();
+        double best_v = best == UINT32_MAX ? 1e300 : imbalance_after(best);
+        size_t best_h = SIZE_MAX;
+        for (size_t hi = 0; hi < ready_heavy.size(); ++hi) {
+            const uint32_t h = ready_heavy[hi];
             double v = imbalance_after(h);
-            if (v < best_v - 1e-12 || (std::fabs(v - best_v) <= 1e-12 && h < best)) { best = h; best_v = v; }
+            if (v < best_v - 1e-12 || (std::fabs(v - best_v) <= 1e-12 && h < best)) { best = h; best_v = v; best_h = hi; }
         }
-        if (best == UINT32_MAX) {  // nothing found in the window: fall back to the first ready op of any kind
-            for (size_t j = 0; j < n; ++j)
-                if (!done[j] && is_ready[j]) { best = (uint32_t)j; break; }
-            if (best == UINT32_MAX) return;  // cycle: leave as recorded
-        }
-        done[best] = 1;
+        if (best == UINT32_MAX) return;  // dependency cycle: leave the program as recorded
+        if (best_h != SIZE_MAX) { ready_heavy[best_h] = ready_heavy.back(); ready_heavy.pop_back(); }
+        else ready_light.pop();
         order.push_back(best);
         a_done += a[best]; m_done += m[best];
-        if (a[best] > 1000) ready_heavy.erase(std::find(ready_heavy.begin(), ready_heavy.end(), best));
         for (auto nx : succ[best])
-            if (--n_pred[nx] == 0) { is_ready[nx] = 1; if (a[nx] > 1000) ready_heavy.push_back(nx); }
+            if (--n_pred[nx] == 0) make_ready(nx);
     }
     std::vector<OpRec> reordered;
     reordered.reserve(n);
@@ -586,11 +577,7 @@ void CS::emit_scope(Scope& s) {
             if (defined[ov]) throw ZkError(ZK_ERR_INVALID, "variable produced twice");
             defined[ov] = 1;
             const auto& cells = s.var_cells[ov];
-            for (size_t i = 0; i < cells.size(); ++i) {
-                uint32_t w = cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0);
-                if (i == 0) w |= (uint32_t)std::min<size_t>(cells.size() - 1, ZK_DEST_COUNT_MASK) << ZK_DEST_COUNT_SHIFT;
-                s.prog.push_back(w);
-            }
+            for (size_t i = 0; i < cells.size(); ++i) s.prog.push_back(cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0));
             s.cells_written += cells.size();
         }
     }

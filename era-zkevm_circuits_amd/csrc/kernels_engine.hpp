@@ -187,7 +187,8 @@ __device__ __noinline__ void nn_mulmod(const uint32_t* a, uint32_t na, const uin
 // tile base is wave-uniform.  Cells are then accessed with raw buffer instructions: V# = tile base, soffset (SGPR) =
 // cell * 512 B straight from the program word, voffset (VGPR, constant per thread) = lane-in-tile * 8 — no vector
 // address arithmetic per load / store (`buffer_store_dwordx2 v[d], v_off, s[rsrc], s_cell offen`).  The host
-// guarantees cell * 512 < 2^32 (CS::place_scope).
+// uses these kernels only when cell * 512 < 2^32 (n_cells < 2^23); larger scopes run the `_wide` variants with plain
+// 64-bit global addressing.
 template <bool WITH_BIGINT, bool SLOTS = false, bool TILE_UNIFORM = false>
 __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                          uint32_t word_begin, uint32_t word_end, const uint32_t* prog = nullptr,
@@ -404,19 +405,23 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 
 // Two symbols for the same interpreter so that profiles separate the loop-scope launch (the dominant,
 // HBM-bound kernel: B*limit lanes) from the outer-scope launches (B lanes, latency-bound).
-template <bool WITH_BIGINT>
+template <bool WITH_BIGINT, bool BUFFER_ADDRESSING = true>
 __device__ __forceinline__ void witness_entry(const ScopeDev& sc, uint32_t word_begin, uint32_t word_end) {
     uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
     const bool active = lane < sc.n_lanes;
     lane = active ? lane : sc.n_lanes - 1;
-    run_lane<WITH_BIGINT, false, true>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
+    run_lane<WITH_BIGINT, false, BUFFER_ADDRESSING>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
 }
 __global__ __launch_bounds__(TPB) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
     witness_entry<false>(sc, word_begin, word_end);
 }
 __global__ __launch_bounds__(TPB) void k_witness_outer(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
     witness_entry<false>(sc, word_begin, word_end);
+}
+// scopes with >= 2^23 cells per lane (e.g. linear_hasher: 28 Keccak permutations per iteration)
+__global__ __launch_bounds__(TPB) void k_witness_wide(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
+    witness_entry<true, false>(sc, word_begin, word_end);
 }
 __global__ __launch_bounds__(TPB) void k_witness_loop_bigint(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
     witness_entry<true>(sc, word_begin, word_end);

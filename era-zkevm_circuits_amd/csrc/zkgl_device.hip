@@ -104,7 +104,8 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
     if (sc.n_lanes == 0 || word_begin >= word_end) return 0;
     const dim3 grid = grid_for(sc.n_lanes, zke::TPB);
     hipStream_t s = (hipStream_t)stream;
-    if (sc.is_loop && sc.uses_bigint) zke::k_witness_loop_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
+    if (sc.n_cells >= (1ull << 23)) zke::k_witness_wide<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
+    else if (sc.is_loop && sc.uses_bigint) zke::k_witness_loop_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
     else if (sc.is_loop) zke::k_witness_loop<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
     else if (sc.uses_bigint) zke::k_witness_outer_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
     else zke::k_witness_outer<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);

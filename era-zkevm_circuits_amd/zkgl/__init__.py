@@ -421,6 +421,12 @@ class ConstraintSystem:
     def unpack_code_into_memory_entry_point(self, limit: int):
         _check(lib().zk_circuit_code_unpacker(self._h, limit))
 
+    def configure_linear_hasher(self):
+        _check(lib().zk_circuit_linear_hasher_configure(self._h))
+
+    def linear_hasher_entry_point(self, limit: int):
+        _check(lib().zk_circuit_linear_hasher(self._h, limit))
+
     def configure_sha256(self):
         _check(lib().zk_circuit_sha256_configure(self._h))
 

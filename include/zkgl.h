@@ -255,6 +255,11 @@ int zk_circuit_sort_decommits(zk_cs *cs, uint32_t limit);
  * Outer stream 125 words, loop stream 101 (see circuits/code_unpacker.cpp). */
 int zk_circuit_code_unpacker_configure(zk_cs *cs);
 int zk_circuit_code_unpacker(zk_cs *cs, uint32_t limit);
+/* linear_hasher_entry_point (src/linear_hasher/mod.rs:35-212): Keccak-256 of the 88-byte serialisations of a queue of L2->L1
+ * message logs; `limit` cycles, a multiple of 17 (the loop body is one 17-cycle / 11-block period of the reference's static buffer).
+ * Outer stream 10 words, loop stream 818 words per period (see circuits/linear_hasher.cpp). */
+int zk_circuit_linear_hasher_configure(zk_cs *cs);
+int zk_circuit_linear_hasher(zk_cs *cs, uint32_t limit);
 /* eip_4844_entry_point (src/eip_4844/mod.rs:107-260): Horner evaluation of the blob polynomial at the Fiat-Shamir point
  * over the non-native BLS12-381 scalar field + linear keccak256 of the blob + output hash; `n_chunks` 31-byte chunks
  * (the reference fixes 4096).  Outer stream 64 words (versioned_hash | linear_hash_output); loop stream

@@ -27,12 +27,8 @@
 #define ZK_OPERAND_KIND_MASK 0xC0000000u
 #define ZK_OPERAND_IDX_MASK 0x3FFFFFFFu
 #define ZK_DEST_MORE 0x80000000u
-/* destination word = cell index (23 bits) | ZK_DEST_MORE when another destination of the same value follows.  The FIRST
- * destination word of a value also carries, in bits 23..30, the number of destination words that follow it (0..254;
- * 255 = more than that, walk the MORE chain), so an executor can run a counted loop instead of testing every word. */
-#define ZK_DEST_CELL_MASK 0x007FFFFFu
-#define ZK_DEST_COUNT_SHIFT 23
-#define ZK_DEST_COUNT_MASK 0xFFu
+/* destination word = cell index (30 bits) | ZK_DEST_MORE when another destination of the same value follows */
+#define ZK_DEST_CELL_MASK 0x3FFFFFFFu
 
 /* header word = opcode | (a << 8) | (b << 16) ; a,b are small op parameters */
 enum zk_opcode {

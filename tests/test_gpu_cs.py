@@ -609,3 +609,35 @@ def test_code_unpacker_sha256_gpu(zk):
     run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
     run.resolve(outer, loop)
     assert_trace_equal(cs, run)
+
+
+def test_linear_hasher_gpu(zk):
+    """8(f)-4 on the GPU: 17-cycle period body (28 Keccak permutations, 10.7 M cells per lane -> the `_wide` interpreter
+    kernels with 64-bit addressing); digests equal software Keccak through the public input; device seeding"""
+    from oracle import linear_hasher_native as hn
+    from test_linear_hasher_host import TABLE_ROWS, hasher_cs, random_messages, streams
+    cs = hasher_cs(17)
+    rng = np.random.default_rng(90)
+    insts = []
+    for k in range(66):
+        qs = random_messages(rng, [0, 1, 3, 17, 9, 16][k % 6])
+        inst = hn.instance(qs, 17)
+        assert inst["satisfiable"] and inst["digest"] == zko.keccak256(b"".join(hn.into_bytes(q) for q in qs))
+        insts.append(inst)
+    outer, loop = streams(insts)
+    raw = loop.copy()
+    raw[:hn.CARRIED] = 0
+    cs.set_batch(len(insts))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, raw.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(raw.shape), loop)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+    # oracle parity on the first wave tile only (the oracle needs ~40 s per 64 lanes of this circuit)
+    run = zko.CircuitRun(cs.export(False), cs.export(True), 2, TABLE_ROWS)
+    run.resolve(outer[:, :2], loop[:, :2])
+    assert np.array_equal(cs.trace(True)[:, :2], run.lc[:, :2]) and np.array_equal(cs.trace(False)[:, :2], run.oc[:, :2])
