@@ -272,6 +272,10 @@ int zk_cs_stream_link(zk_cs* cs, const zk_var* a_vars, uint32_t period_a, const 
     NEED(cs); NEED(a_vars); NEED(b_vars);
     return guard([&] { cs->cs->stream_link(a_vars, period_a, b_vars, period_b, n_total); });
 }
+int zk_cs_seed_hint(zk_cs* cs, uint32_t opcode, const zk_var* ins, uint32_t n_in, const zk_var* outs, uint32_t n_out) {
+    NEED(cs); NEED(ins); NEED(outs);
+    return guard([&] { cs->cs->seed_hint(opcode, ins, n_in, outs, n_out); });
+}
 int zk_cs_loop_last(zk_cs* cs, zk_var loop_var, zk_var* outer_out) {
     NEED(cs); NEED(outer_out);
     return guard([&] { *outer_out = cs->cs->loop_last(loop_var); });

@@ -169,7 +169,7 @@ void unpack_code_into_memory_entry_point(CS& cs, uint32_t limit) {
             block[8 + j][k] = g.select(finalize, pad, block[8 + j][k]);
         }
     std::array<Word, 8> new_state = st;
-    s.compress(new_state, block);
+    s.compress_with_hint(new_state, block);
     for (int w = 0; w < 8; ++w)
         for (int k = 0; k < 4; ++k) st[w][k] = g.select(state_decommit, new_state[w][k], st[w][k]);
     // digest words 1..7 against the versioned hash (mod.rs:381-407)

@@ -136,16 +136,17 @@ void eip_4844_entry_point(CS& cs, uint32_t n_chunks) {
     }
 
     // Keccak block: data bytes, padding in the last block
+    std::array<zk_var, RATE> padded_block;
     for (int j = 0; j < RATE; ++j) {
         zk_var v = block_in[j];
         if ((uint32_t)j >= rem_bytes) {
             uint64_t pad = ((uint32_t)j == rem_bytes ? 0x01 : 0x00) | (j == RATE - 1 ? 0x80 : 0x00);
             v = g.select(is_last_block, g.constant(pad), v);
         }
-        st[j / 8][j % 8] = k.xor8(st[j / 8][j % 8], v);
+        padded_block[j] = v;
     }
     for (int j = RATE; j < 200; j += 2) g.range_check_u8_pair(st[j / 8][j % 8], st[(j + 1) / 8][(j + 1) % 8]);
-    k.permutation(st);
+    k.absorb_and_permute(st, padded_block.data());
 
     for (auto& lane : st)
         for (auto b : lane) out.push_back(b);

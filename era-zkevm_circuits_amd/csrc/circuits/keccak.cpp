@@ -63,14 +63,12 @@ void keccak256_blocks_entry_point(CS& cs, uint32_t n_blocks) {
         }
     // absorb: state[0..136) ^= block (keccak256_absorb_and_run_permutation, mod.rs:803-817); the xor lookup
     // range-checks both the carried byte and the fresh input byte
-    for (int j = 0; j < 136; ++j) {
-        zk_var in_byte = g.next_input();
-        s[j / 8][j % 8] = k.xor8(s[j / 8][j % 8], in_byte);
-    }
+    std::array<zk_var, 136> block;
+    for (auto& b : block) b = g.next_input();
     // capacity bytes of the carried state are range-checked through a pair lookup (they enter theta's xor anyway,
     // but only as the first key: make the check explicit)
     for (int j = 136; j < 200; j += 2) g.range_check_u8_pair(s[j / 8][j % 8], s[(j + 1) / 8][(j + 1) % 8]);
-    k.permutation(s);
+    k.absorb_and_permute(s, block.data());
     for (int i = 0; i < 25; ++i)
         for (int b = 0; b < 8; ++b) state_out.push_back(s[i][b]);
     for (size_t i = 0; i < 200; ++i) cs.link(ZK_LINK_CARRY, state_in[i], state_out[i]);
@@ -365,9 +363,8 @@ void keccak256_round_function_entry_point(CS& cs, uint32_t limit) {
         }
     }
     // keccak256_absorb_and_run_permutation (mod.rs:796-838)
-    for (int j = 0; j < RATE; ++j) st[j / 8][j % 8] = kk.xor8(st[j / 8][j % 8], input[j]);
     for (int j = RATE; j < 200; j += 2) g.range_check_u8_pair(st[j / 8][j % 8], st[(j + 1) / 8][(j + 1) % 8]);
-    kk.permutation(st);
+    kk.absorb_and_permute(st, input.data());
 
     // conditional write of the digest (mod.rs:592-627): UInt256::from_be_bytes(squeezed)
     Boolean write_result = g.b_or(apply_padding, padding_round);

@@ -55,6 +55,24 @@ struct K {
         }
         return r;
     }
+    // state <- Keccak-f(state ^ block) recorded gate by gate, plus (loop scope) the seed hint that lets the seeding cone
+    // compute the same 200 bytes with one native macro-op (include/zkgl_ir.h ZK_OP_KECCAK_ABSORB)
+    void absorb_and_permute(std::array<Lane, 25>& s, const zk_var* block136) {
+        std::vector<zk_var> ins;
+        for (auto& lane : s)
+            for (auto b : lane) ins.push_back(b);
+        for (int j = 0; j < 136; ++j) {
+            ins.push_back(block136[j]);
+            s[j / 8][j % 8] = xor8(s[j / 8][j % 8], block136[j]);
+        }
+        permutation(s);
+        if (g.cs.in_loop()) {
+            std::vector<zk_var> outs;
+            for (auto& lane : s)
+                for (auto b : lane) outs.push_back(b);
+            g.cs.seed_hint(ZK_OP_KECCAK_ABSORB, ins.data(), 336, outs.data(), 200);
+        }
+    }
     void permutation(std::array<Lane, 25>& s) {
         for (int rnd = 0; rnd < 24; ++rnd) {
             std::array<Lane, 5> c, d;

@@ -24,8 +24,7 @@ constexpr int RATE = 136, PERIOD = 17, CARRIED = 206;  // 88 bytes per serialise
 // keccak256_conditionally_absorb_and_run_permutation (boojum [EXT]): state <- cond ? f(state ^ block) : state
 void conditionally_absorb(G& g, K& k, Boolean cond, std::array<Lane, 25>& st, const std::array<zk_var, RATE>& block) {
     std::array<Lane, 25> next = st;
-    for (int j = 0; j < RATE; ++j) next[j / 8][j % 8] = k.xor8(next[j / 8][j % 8], block[j]);
-    k.permutation(next);
+    k.absorb_and_permute(next, block.data());
     for (int l = 0; l < 25; ++l)
         for (int b = 0; b < 8; ++b) st[l][b] = g.select(cond, next[l][b], st[l][b]);
 }

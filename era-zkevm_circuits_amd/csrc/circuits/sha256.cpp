@@ -55,7 +55,7 @@ void sha256_blocks_entry_point(CS& cs, uint32_t n_blocks) {
         g.range_check_u8_pair(be[2], be[3]);
         for (int k = 0; k < 4; ++k) block[w][k] = be[3 - k];
     }
-    s.compress(st, block);
+    s.compress_with_hint(st, block);
     for (int w = 0; w < 8; ++w)
         for (int k = 0; k < 4; ++k) state_out.push_back(st[w][k]);
     for (size_t i = 0; i < 32; ++i) cs.link(ZK_LINK_CARRY, state_in[i], state_out[i]);
@@ -240,7 +240,7 @@ void sha256_round_function_entry_point(CS& cs, uint32_t limit) {
     // absorb (mod.rs:271-285)
     for (int w = 0; w < 8; ++w)
         for (int k = 0; k < 4; ++k) st[w][k] = g.select(reset_buffer, g.constant((SHA_IV[w] >> (8 * k)) & 0xff), st[w][k]);
-    s.compress(st, block);
+    s.compress_with_hint(st, block);
 
     // conditional write of the digest (mod.rs:287-315)
     Boolean no_rounds_left = g.is_zero(num_rounds.v);

@@ -90,6 +90,21 @@ struct S {
         g.range_check_u8_pair(w[0], w[1]);
         g.range_check_u8_pair(w[2], w[3]);
     }
+    // compress + (loop scope) the seed hint ZK_OP_SHA256_COMPRESS over the same byte variables
+    void compress_with_hint(std::array<Word, 8>& st, const std::array<Word, 16>& block_words) {
+        std::vector<zk_var> ins;
+        for (auto& w : st)
+            for (auto b : w) ins.push_back(b);
+        for (auto& w : block_words)
+            for (auto b : w) ins.push_back(b);
+        compress(st, block_words);
+        if (g.cs.in_loop()) {
+            std::vector<zk_var> outs;
+            for (auto& w : st)
+                for (auto b : w) outs.push_back(b);
+            g.cs.seed_hint(ZK_OP_SHA256_COMPRESS, ins.data(), 96, outs.data(), 32);
+        }
+    }
     void compress(std::array<Word, 8>& st, const std::array<Word, 16>& block_words) {
         std::vector<Word> w(block_words.begin(), block_words.end());
         for (int i = 16; i < 64; ++i) {

@@ -352,6 +352,17 @@ void CS::link(uint32_t kind, zk_var loop_var, zk_var other) {
     links_raw_.push_back({kind, var_index(loop_var), var_index(other), 0});
 }
 
+void CS::seed_hint(uint32_t opcode, const zk_var* ins, uint32_t n_in, const zk_var* outs, uint32_t n_out) {
+    if (!in_loop_) throw ZkError(ZK_ERR_INVALID, "seed_hint outside the loop");
+    if (!((opcode == ZK_OP_KECCAK_ABSORB && n_in == 336 && n_out == 200) || (opcode == ZK_OP_SHA256_COMPRESS && n_in == 96 && n_out == 32)))
+        throw ZkError(ZK_ERR_INVALID, "seed_hint: unknown opcode / arity");
+    OpRec op;
+    op.opcode = (uint8_t)opcode; op.a = 0; op.b = 0; op.seed_only = true;
+    for (uint32_t i = 0; i < n_in; ++i) { check_var(ins[i], true); op.ins.push_back({Operand::VAR, var_index(ins[i])}); }
+    for (uint32_t i = 0; i < n_out; ++i) { check_var(outs[i], true); op.outs.push_back(var_index(outs[i])); }
+    loop_.ops.push_back(std::move(op));
+}
+
 void CS::stream_link(const zk_var* a, uint32_t pa, const zk_var* b, uint32_t pb, uint32_t n_total) {
     if (!in_loop_) throw ZkError(ZK_ERR_INVALID, "stream_link outside the loop");
     if (!pa || !pb || !n_total || (uint64_t)limit_ * pa < n_total || (uint64_t)limit_ * pb < n_total)
@@ -498,15 +509,21 @@ void CS::schedule_loop_ops() {
     for (size_t i = 0; i < n; ++i) any_heavy |= a[i] > 1000;
     if (!any_heavy || a_tot <= 0 || m_tot <= 0) return;
     // dependencies through loop variables
-    std::vector<uint32_t> producer(s.n_vars, UINT32_MAX);
+    std::vector<uint32_t> producer(s.n_vars, UINT32_MAX), hint_producer(s.n_vars, UINT32_MAX);
     for (size_t i = 0; i < n; ++i)
-        for (auto ov : s.ops[i].outs) producer[ov] = (uint32_t)i;
+        for (auto ov : s.ops[i].outs) (s.ops[i].seed_only ? hint_producer : producer)[ov] = (uint32_t)i;
     std::vector<std::vector<uint32_t>> succ(n);
     std::vector<uint32_t> n_pred(n, 0);
     for (size_t i = 0; i < n; ++i) {
         std::vector<uint32_t> ps;
         for (auto& in : s.ops[i].ins)
-            if (in.kind == Operand::VAR && producer[in.idx] != UINT32_MAX) ps.push_back(producer[in.idx]);
+            if (in.kind == Operand::VAR) {
+                if (producer[in.idx] != UINT32_MAX) ps.push_back(producer[in.idx]);
+                if (hint_producer[in.idx] != UINT32_MAX && hint_producer[in.idx] != i) ps.push_back(hint_producer[in.idx]);
+            }
+        if (s.ops[i].seed_only)  // a hint runs after the decomposed producers of its outputs (keeps it next to them)
+            for (auto ov : s.ops[i].outs)
+                if (producer[ov] != UINT32_MAX) ps.push_back(producer[ov]);
         std::sort(ps.begin(), ps.end());
         ps.erase(std::unique(ps.begin(), ps.end()), ps.end());
         for (auto p : ps) {
@@ -558,6 +575,7 @@ void CS::emit_scope(Scope& s) {
         if (!s.is_loop && oi == s.pre_ops) s.pre_words = (uint32_t)s.prog.size();
         if (!s.is_loop && oi == s.side_ops) s.side_words = (uint32_t)s.prog.size();
         const OpRec& op = s.ops[oi];
+        if (op.seed_only) continue;
         s.prog.push_back((uint32_t)op.opcode | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
         for (auto& in : op.ins) {
             switch (in.kind) {
@@ -614,6 +632,8 @@ void CS::build_seed_program() {
             for (size_t i = 0; i + 12 < op.outs.size(); ++i)
                 if (need[op.outs[i]]) return;  // an intermediate feeds the state: keep the generic mode
         keep[oi] = 1;
+        if (op.seed_only)  // the hint produces these values for the cone: their gate-by-gate producers are not needed
+            for (auto o : op.outs) need[o] = 0;
         for (auto& in : op.ins)
             if (in.kind == Operand::VAR) need[in.idx] = 1;
     }

@@ -39,6 +39,7 @@ struct OpRec {
     uint16_t b;
     std::vector<Operand> ins;
     std::vector<uint32_t> outs;  // var indices (same scope)
+    bool seed_only = false;      // seed hint: not part of the trace program, a second producer of `outs` for the seeding cone
 };
 
 struct GateRec {
@@ -129,6 +130,9 @@ class CS {
     void loop_end();
     void link(uint32_t kind, zk_var loop_var, zk_var other);
     void stream_link(const zk_var* a, uint32_t pa, const zk_var* b, uint32_t pb, uint32_t n_total);
+    // seed-only macro-op: `outs` are variables ALREADY produced by recorded ops; in the seeding program this op produces
+    // them directly from `ins` and the decomposition behind them drops out of the cone
+    void seed_hint(uint32_t opcode, const zk_var* ins, uint32_t n_in, const zk_var* outs, uint32_t n_out);
     zk_var loop_last(zk_var loop_var);
     zk_var loop_import(zk_var outer_var);
     uint64_t next_available_row() const;

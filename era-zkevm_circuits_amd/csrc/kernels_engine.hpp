@@ -183,6 +183,59 @@ __device__ __noinline__ void nn_mulmod(const uint32_t* a, uint32_t na, const uin
 // and 500 B of scratch); the launcher picks them only for programs that contain the op.
 // SLOTS: seeding mode (k_seed_cone).  Values live in an LDS slot store instead of trace cells: cell-kind operands
 // and destinations are slot indices assigned by the host's liveness allocation, one destination word per output.
+// Native hash cores of the seed-only macro-ops (ZK_OP_KECCAK_ABSORB / ZK_OP_SHA256_COMPRESS): cold code, kept small
+// (rolled loops, scratch-resident arrays); only the seeding kernels instantiate them.
+__device__ __noinline__ void keccak_f1600(uint64_t* A) {
+    const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+                             0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+                             0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+                             0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                             0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5y]
+    uint64_t B[25], C[5];
+#pragma unroll 1
+    for (int r = 0; r < 24; ++r) {
+        for (int x = 0; x < 5; ++x) C[x] = A[x] ^ A[x + 5] ^ A[x + 10] ^ A[x + 15] ^ A[x + 20];
+        for (int x = 0; x < 5; ++x) {
+            const uint64_t c1 = C[(x + 1) % 5], d = C[(x + 4) % 5] ^ ((c1 << 1) | (c1 >> 63));
+            for (int y = 0; y < 25; y += 5) A[x + y] ^= d;
+        }
+        for (int x = 0; x < 5; ++x)
+            for (int y = 0; y < 5; ++y) {
+                const uint64_t v = A[x + 5 * y];
+                const int n = ROT[x + 5 * y];
+                B[y + 5 * ((2 * x + 3 * y) % 5)] = n ? ((v << n) | (v >> (64 - n))) : v;
+            }
+        for (int y = 0; y < 25; y += 5)
+            for (int x = 0; x < 5; ++x) A[x + y] = B[x + y] ^ (~B[(x + 1) % 5 + y] & B[(x + 2) % 5 + y]);
+        A[0] ^= RC[r];
+    }
+}
+__device__ __noinline__ void sha256_compress(uint32_t* st, const uint32_t* blk) {
+    const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+        0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+        0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+        0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+        0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = blk[i];
+#pragma unroll 1
+    for (int i = 16; i < 64; ++i)
+        w[i] = w[i - 16] + (rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+        const uint32_t t1 = h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+        const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
 // TILE_UNIFORM: the 64 threads of the wave hold the 64 lanes of ONE tile (parallel kernels: consecutive lanes), so the
 // tile base is wave-uniform.  Cells are then accessed with raw buffer instructions: V# = tile base, soffset (SGPR) =
 // cell * 512 B straight from the program word, voffset (VGPR, constant per thread) = lane-in-tile * 8 — no vector
@@ -391,6 +444,46 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             const uint32_t nq = pa + pb - 15;
             nn_mulmod(av, pa, bv, pb, mv, nq, res);
             for (uint32_t i = 0; i < nq + 16; ++i) st(res[i]);
+        } else { return; } break;
+        case ZK_OP_KECCAK_ABSORB: if constexpr (SLOTS) {
+            uint64_t A[25];
+            for (int l = 0; l < 25; ++l) {
+                P.sync(pc);
+                uint64_t v = 0;
+                for (int k = 0; k < 8; ++k) v |= ld(P.at(pc + k)) << (8 * k);
+                A[l] = v;
+                pc += 8;
+            }
+            for (int l = 0; l < 17; ++l) {
+                P.sync(pc);
+                uint64_t v = 0;
+                for (int k = 0; k < 8; ++k) v |= ld(P.at(pc + k)) << (8 * k);
+                A[l] ^= v;
+                pc += 8;
+            }
+            keccak_f1600(A);
+            for (int l = 0; l < 25; ++l)
+                for (int k = 0; k < 8; ++k) st((A[l] >> (8 * k)) & 0xff);
+        } else { return; } break;
+        case ZK_OP_SHA256_COMPRESS: if constexpr (SLOTS) {
+            uint32_t hs[8], blk[16];
+            for (int w = 0; w < 8; ++w) {
+                P.sync(pc);
+                uint32_t v = 0;
+                for (int k = 0; k < 4; ++k) v |= (uint32_t)ld(P.at(pc + k)) << (8 * k);
+                hs[w] = v;
+                pc += 4;
+            }
+            for (int w = 0; w < 16; ++w) {
+                P.sync(pc);
+                uint32_t v = 0;
+                for (int k = 0; k < 4; ++k) v |= (uint32_t)ld(P.at(pc + k)) << (8 * k);
+                blk[w] = v;
+                pc += 4;
+            }
+            sha256_compress(hs, blk);
+            for (int w = 0; w < 8; ++w)
+                for (int k = 0; k < 4; ++k) st((hs[w] >> (8 * k)) & 0xff);
         } else { return; } break;
         case ZK_OP_DIVREM: {
             uint64_t x = ld(P.at(pc++));

@@ -33,7 +33,7 @@ ZK_ERR_GATE_NOT_ALLOWED = -6
 
 # zk_opcode / zk_gate_kind / zk_link_kind (include/zkgl_ir.h)
 OP = dict(END=0, CONST=1, INPUT=2, FMA=3, LC4=4, SELECT=5, ISZERO=6, UADD=7, USUB=8, DOT4=9, MATMUL12=10,
-          SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16, DIVREM=18, NN_MULMOD=19)
+          SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16, DIVREM=18, NN_MULMOD=19, KECCAK_ABSORB=20, SHA256_COMPRESS=21)
 GATE = dict(NOP=0, CONST=1, BOOLEAN=2, FMA=3, REDUCTION4=4, SELECT=5, ZEROCHECK=6, UINTX_ADD=7, DOT4=8,
             MATMUL12_EXT=9, MATMUL12_INT=10, PUBLIC_INPUT=11, U32_FMA=12)
 GATE_NAMES = {v: k for k, v in GATE.items()}
@@ -342,6 +342,11 @@ class ConstraintSystem:
         bad = C.c_uint32()
         _check(lib().zk_cs_lookup_argument(self._h, b, g, C.c_void_p(stream or 0), out.ctypes.data_as(C.c_void_p), self.batch, C.byref(bad)))
         return bad.value, out
+
+    def seed_hint(self, opcode: int, ins, outs):
+        a = (C.c_uint32 * len(ins))(*ins)
+        b = (C.c_uint32 * len(outs))(*outs)
+        _check(lib().zk_cs_seed_hint(self._h, opcode, a, len(ins), b, len(outs)))
 
     def stream_link(self, a_vars, b_vars, n_total: int):
         a = (C.c_uint32 * len(a_vars))(*a_vars)

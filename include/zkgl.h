@@ -150,6 +150,11 @@ int zk_cs_link(zk_cs *cs, uint32_t link_kind, zk_var loop_var, zk_var other_var)
 /* stream link (include/zkgl_ir.h): loop variables a_vars[k % period_a] of iteration k / period_a and
  * b_vars[k % period_b] of iteration k / period_b are the same value for every k < n_total */
 int zk_cs_stream_link(zk_cs *cs, const zk_var *a_vars, uint32_t period_a, const zk_var *b_vars, uint32_t period_b, uint32_t n_total);
+/* seed hint (loop scope): `outs` are variables already produced by recorded ops; the seed-only macro-op `opcode`
+ * (ZK_OP_KECCAK_ABSORB: 336 ins / 200 outs, ZK_OP_SHA256_COMPRESS: 96 ins / 32 outs, byte variables) produces them directly in
+ * the cone seeding program, so the gate-by-gate decomposition behind them is not replayed by zk_cs_seed_carried_inputs.
+ * The trace program, the gates and the checks are unaffected. */
+int zk_cs_seed_hint(zk_cs *cs, uint32_t opcode, const zk_var *ins, uint32_t n_in, const zk_var *outs, uint32_t n_out);
 /* value of a loop variable at the last iteration, as an outer variable (post phase) */
 int zk_cs_loop_last(zk_cs *cs, zk_var loop_var, zk_var *outer_out);
 /* use an outer variable inside the loop (broadcast; pre phase must define it) */

@@ -54,6 +54,12 @@ enum zk_opcode {
     ZK_OP_NN_MULMOD = 19,/* a=nA, b=nB (<=17 each); [m0..m15 modulus limbs (consts), A limbs, B limbs] -> q limbs (nA+nB-15),
                           * r limbs (16): integers A*B = q*M + r, 0 <= r < M; all limbs base 2^16, input limbs < 2^24
                           *                                                           (NonNativeFieldOverU16 mul/normalize) */
+    /* seed-only macro-ops (zk_cs_seed_hint): second producers of values the trace program computes gate by gate; they
+     * exist only in the cone seeding program, where they replace the whole decomposition behind them */
+    ZK_OP_KECCAK_ABSORB = 20, /* [state bytes x200 (byte k of lane x+5y at 8(x+5y)+k), block bytes x136] -> state bytes x200:
+                               * Keccak-f[1600](state ^ (block | 0^64))                        (keccak256_absorb_and_run_permutation) */
+    ZK_OP_SHA256_COMPRESS = 21,/* [state bytes x32 (word w little-endian at 4w), block bytes x64 (word j little-endian at 4j)]
+                               * -> state bytes x32                                            (round_function_over_uint32) */
     ZK_OP__COUNT
 };
 
