@@ -29,6 +29,7 @@ const GateInfo GATES[ZK_GATE__COUNT] = {
     {24, 0, 12}, // MATMUL12_INT
     {1, 0, 0},   // PUBLIC_INPUT
     {6, 0, 1},   // U32_FMA
+    {5, 1, 1},   // REDUCTION_BY_POWERS4
 };
 
 // element offset of (cell, lane) in the wave-tiled cell storage (see kernels_engine.hpp)
@@ -955,10 +956,12 @@ uint32_t CS::lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], vo
         uint64_t a = addm(mulm(x[0], y[0]), mulm(7, mulm(x[1], y[1]))), b = addm(mulm(x[0], y[1]), mulm(x[1], y[0]));
         r[0] = a; r[1] = b;
     };
-    uint64_t ch[8] = {beta[0], beta[1], gamma[0], gamma[1], 0, 0, 0, 0};
+    if (lookup_width_ > 4) throw ZkError(ZK_ERR_INVALID, "lookup_argument: lookup width above 4");
+    uint64_t ch[10] = {beta[0], beta[1], gamma[0], gamma[1], 0, 0, 0, 0, 0, 0};
     emul(gamma, gamma, ch + 4);
     emul(ch + 4, gamma, ch + 6);
-    for (int i = 0; i < 8; ++i)
+    emul(ch + 6, gamma, ch + 8);
+    for (int i = 0; i < 10; ++i)
         if (ch[i] >= 0xFFFFFFFF00000001ull) throw ZkError(ZK_ERR_INVALID, "lookup_argument: non-canonical challenge");
     uint64_t *d_acc_o = nullptr, *d_acc_l = nullptr, *d_inv = nullptr, *d_ab = nullptr;
     auto alloc = [&](uint64_t** p, size_t words) { hip_check(hipMalloc((void**)p, std::max<size_t>(words, 1) * 8), "hipMalloc lookup_argument"); };
@@ -974,7 +977,7 @@ uint32_t CS::lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], vo
     side(outer_, d_acc_o);
     if (limit_) side(loop_, d_acc_l);
     dev_check(zkdev::launch_lookup_arg_witness_sum(d_acc_o, d_acc_l, limit_, batch_, d_ab, st));
-    dev_check(zkdev::launch_lookup_arg_tables(d_tables_, (uint32_t)tables_.size() + 1, d_table_words_, total_table_rows_, ch, d_inv, d_mult_, batch_,
+    dev_check(zkdev::launch_lookup_arg_tables(d_tables_, (uint32_t)tables_.size() + 1, d_table_words_, total_table_rows_, lookup_width_, ch, d_inv, d_mult_, batch_,
                                               d_ab + 2 * (size_t)batch_, st));
     std::vector<uint64_t> h(4 * (size_t)batch_);
     hip_check(hipMemcpyAsync(h.data(), d_ab, h.size() * 8, hipMemcpyDeviceToHost, st), "memcpy lookup_argument");

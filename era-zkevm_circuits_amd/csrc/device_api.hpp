@@ -41,14 +41,14 @@ int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uin
 int launch_check_gates(const CheckArgs& cd, void* stream);
 int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs,
                         uint32_t n_pairs, unsigned long long* fail, void* stream);
-// K5 lookup-argument accumulators (kernels_lookup_arg.hpp).  ch = beta.a, beta.b, gamma.a, gamma.b, gamma^2 (2), gamma^3 (2)
+// K5 lookup-argument accumulators (kernels_lookup_arg.hpp).  ch = beta, gamma, gamma^2, gamma^3, gamma^4 (2 words each)
 struct LookupArgArgs {
     const uint64_t* cells; uint64_t n_cells; uint32_t n_cols, n_lanes, n_slots, n_copy_cols, lookup_width;
     const zk_lookup_row_desc* lrows; uint64_t* acc;
 };
-int launch_lookup_arg_witness(const LookupArgArgs& a, const uint64_t ch[8], void* stream);
-int launch_lookup_arg_tables(const zk_table_desc* tables, uint32_t n_tables, const uint64_t* table_words, uint32_t total_rows,
-                             const uint64_t ch[8], uint64_t* inv_f, const uint32_t* mult, uint32_t n_instances, uint64_t* out_b, void* stream);
+int launch_lookup_arg_witness(const LookupArgArgs& a, const uint64_t ch[10], void* stream);
+int launch_lookup_arg_tables(const zk_table_desc* tables, uint32_t n_tables, const uint64_t* table_words, uint32_t total_rows, uint32_t lookup_width,
+                             const uint64_t ch[10], uint64_t* inv_f, const uint32_t* mult, uint32_t n_instances, uint64_t* out_b, void* stream);
 int launch_lookup_arg_witness_sum(const uint64_t* acc_outer, const uint64_t* acc_loop, uint32_t limit, uint32_t n_instances,
                                   uint64_t* out_a, void* stream);
 // cone seeding: seed_prog in device memory (padded like every program), carries = {input word, out slot, first outer cell, has_first}

@@ -620,7 +620,7 @@ struct CheckDev {
     uint32_t slots_per_chunk;
 };
 
-__device__ __constant__ const unsigned char GATE_WIDTH[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6};
+__device__ __constant__ const unsigned char GATE_WIDTH[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5};
 
 __device__ __forceinline__ void report(unsigned long long* f, uint32_t lane, uint32_t slot, uint32_t j, uint32_t rel) {
     unsigned long long key = ((unsigned long long)lane << 32) | ((unsigned long long)slot << 12) | ((j & 0xff) << 4) | (rel & 0xf);
@@ -699,6 +699,13 @@ __global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) {
                 uint64_t lhs = gl::add(gl::add(gl::mul(a, b), c), dd);
                 uint64_t rhs = gl::add(lo, gl::mul(hi, 1ull << 32));
                 if (lhs != rhs) report(cd.fail, lane, slot, j, 0);
+            } break;
+            case ZK_GATE_REDUCTION_BY_POWERS4: {  // Horner in the row constant c
+                uint64_t r = cell(c0 + 3);
+                r = gl::fma(r, k[0], cell(c0 + 2));
+                r = gl::fma(r, k[0], cell(c0 + 1));
+                r = gl::fma(r, k[0], cell(c0));
+                if (r != cell(c0 + 4)) report(cd.fail, lane, slot, j, 0);
             } break;
             default: break;  // NOP, PUBLIC_INPUT: no relation
             }

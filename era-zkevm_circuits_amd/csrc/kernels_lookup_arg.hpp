@@ -5,7 +5,8 @@
 // algebraic content is the standard one and is defined here for this engine's layout:
 //
 //   challenges beta, gamma in GF(p^2) = GF(p)[X] / (X^2 - 7)
-//   tuple (c0, c1, c2) of a lookup row of table t:      f = beta + c0 + gamma c1 + gamma^2 c2 + gamma^3 t
+//   tuple (c0 .. c_{W-1}) of a lookup row of table t (W = lookup width, 3 or 4; missing columns are 0):
+//                                                       f = beta + sum_j gamma^j c_j + gamma^W t
 //   witness side, per lane:                             A_lane = sum over every tuple of the lane of 1 / f
 //   table side, per instance:                           B_inst = sum over table rows r of m[inst][r] / f(row r)
 //   argument:                                           sum over the lanes of the instance of A_lane == B_inst
@@ -42,21 +43,23 @@ struct LookupArgDev {
     uint64_t n_cells;
     uint32_t n_cols, n_lanes, n_slots, n_copy_cols, lookup_width;
     const zk_lookup_row_desc* lrows;
-    E beta, g1, g2, g3;  // gamma, gamma^2, gamma^3
-    uint64_t* acc;       // [n_lanes][2]
+    E beta, g1, g2, g3, g4;  // gamma .. gamma^4
+    uint64_t* acc;           // [n_lanes][2]
 };
 
 __device__ __forceinline__ size_t cell_off(uint64_t n_cells, uint32_t cell, uint32_t lane) {
     return ((size_t)(lane >> 6) * n_cells + cell) * 64 + (lane & 63);
 }
 
-// f = beta + c0 + gamma c1 + gamma^2 c2 + gamma^3 t
-__device__ __forceinline__ E tuple_value(const LookupArgDev& d, uint64_t c0, uint64_t c1, uint64_t c2, uint32_t table) {
+// f = beta + c0 + gamma c1 + gamma^2 c2 (+ gamma^3 c3) + gamma^W t
+template <typename D>
+__device__ __forceinline__ E tuple_value(const D& d, uint32_t width, uint64_t c0, uint64_t c1, uint64_t c2, uint64_t c3, uint32_t table) {
     E f = d.beta;
     f.a = gl::add(f.a, c0);
     f = eadd(f, escale(d.g1, c1));
     f = eadd(f, escale(d.g2, c2));
-    f = eadd(f, escale(d.g3, table));
+    if (width > 3) f = eadd(f, escale(d.g3, c3));
+    f = eadd(f, escale(width > 3 ? d.g4 : d.g3, table));
     return f;
 }
 
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(TPB) void k_lookup_arg_witness(LookupArgDev d) {
             uint64_t v0 = cells[(c0 + 0) << 6];
             uint64_t v1 = d.lookup_width > 1 ? cells[(c0 + 1) << 6] : 0;
             uint64_t v2 = d.lookup_width > 2 ? cells[(c0 + 2) << 6] : 0;
-            f[u] = tuple_value(d, v0, v1, v2, lr.table);
+            uint64_t v3 = d.lookup_width > 3 ? cells[(c0 + 3) << 6] : 0;
+            f[u] = tuple_value(d, d.lookup_width, v0, v1, v2, v3, lr.table);
             pre[u] = run;
             run = emul(run, f[u]);
         }
@@ -94,8 +98,8 @@ struct TableArgDev {
     const zk_table_desc* tables;  // index 0 unused
     uint32_t n_tables;            // including index 0
     const uint64_t* table_words;
-    uint32_t total_rows;
-    E beta, g1, g2, g3;
+    uint32_t total_rows, lookup_width;
+    E beta, g1, g2, g3, g4;
     uint64_t* inv_f;              // [total_rows][2]
 };
 
@@ -108,11 +112,7 @@ __global__ __launch_bounds__(TPB) void k_lookup_arg_table_rows(TableArgDev d) {
     const zk_table_desc td = d.tables[t];
     const uint32_t r = g - td.mult_off, w = td.n_keys + td.n_vals;
     const uint64_t* row = d.table_words + (size_t)td.word_off + (size_t)r * w;
-    E f = d.beta;
-    f.a = gl::add(f.a, row[0]);
-    if (w > 1) f = eadd(f, escale(d.g1, row[1]));
-    if (w > 2) f = eadd(f, escale(d.g2, row[2]));
-    f = eadd(f, escale(d.g3, t));
+    E f = tuple_value(d, d.lookup_width, row[0], w > 1 ? row[1] : 0, w > 2 ? row[2] : 0, w > 3 ? row[3] : 0, t);
     E i = einv(f);
     d.inv_f[2 * (size_t)g] = i.a;
     d.inv_f[2 * (size_t)g + 1] = i.b;

@@ -150,23 +150,24 @@ int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lane
     return LAUNCH_CHECK("k_check_copies");
 }
 
-int launch_lookup_arg_witness(const LookupArgArgs& a, const uint64_t ch[8], void* stream) {
+int launch_lookup_arg_witness(const LookupArgArgs& a, const uint64_t ch[10], void* stream) {
     if (a.n_lanes == 0) return 0;
     zkl::LookupArgDev d;
     d.cells = a.cells; d.n_cells = a.n_cells; d.n_cols = a.n_cols; d.n_lanes = a.n_lanes; d.n_slots = a.n_slots;
     d.n_copy_cols = a.n_copy_cols; d.lookup_width = a.lookup_width; d.lrows = a.lrows; d.acc = a.acc;
-    d.beta = {ch[0], ch[1]}; d.g1 = {ch[2], ch[3]}; d.g2 = {ch[4], ch[5]}; d.g3 = {ch[6], ch[7]};
+    d.beta = {ch[0], ch[1]}; d.g1 = {ch[2], ch[3]}; d.g2 = {ch[4], ch[5]}; d.g3 = {ch[6], ch[7]}; d.g4 = {ch[8], ch[9]};
     zkl::k_lookup_arg_witness<<<grid_for(a.n_lanes, zkl::TPB), zkl::TPB, 0, (hipStream_t)stream>>>(d);
     return LAUNCH_CHECK("k_lookup_arg_witness");
 }
 
-int launch_lookup_arg_tables(const zk_table_desc* tables, uint32_t n_tables, const uint64_t* table_words, uint32_t total_rows,
-                             const uint64_t ch[8], uint64_t* inv_f, const uint32_t* mult, uint32_t n_instances, uint64_t* out_b, void* stream) {
+int launch_lookup_arg_tables(const zk_table_desc* tables, uint32_t n_tables, const uint64_t* table_words, uint32_t total_rows, uint32_t lookup_width,
+                             const uint64_t ch[10], uint64_t* inv_f, const uint32_t* mult, uint32_t n_instances, uint64_t* out_b, void* stream) {
     if (n_instances == 0) return 0;
     if (total_rows) {
         zkl::TableArgDev d;
         d.tables = tables; d.n_tables = n_tables; d.table_words = table_words; d.total_rows = total_rows; d.inv_f = inv_f;
-        d.beta = {ch[0], ch[1]}; d.g1 = {ch[2], ch[3]}; d.g2 = {ch[4], ch[5]}; d.g3 = {ch[6], ch[7]};
+        d.beta = {ch[0], ch[1]}; d.g1 = {ch[2], ch[3]}; d.g2 = {ch[4], ch[5]}; d.g3 = {ch[6], ch[7]}; d.g4 = {ch[8], ch[9]};
+        d.lookup_width = lookup_width;
         zkl::k_lookup_arg_table_rows<<<grid_for(total_rows, zkl::TPB), zkl::TPB, 0, (hipStream_t)stream>>>(d);
     }
     zkl::k_lookup_arg_table_sum<<<n_instances, zkl::TPB, 0, (hipStream_t)stream>>>(mult, inv_f, total_rows, out_b);

@@ -35,7 +35,7 @@ ZK_ERR_GATE_NOT_ALLOWED = -6
 OP = dict(END=0, CONST=1, INPUT=2, FMA=3, LC4=4, SELECT=5, ISZERO=6, UADD=7, USUB=8, DOT4=9, MATMUL12=10,
           SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16, DIVREM=18, NN_MULMOD=19, KECCAK_ABSORB=20, SHA256_COMPRESS=21)
 GATE = dict(NOP=0, CONST=1, BOOLEAN=2, FMA=3, REDUCTION4=4, SELECT=5, ZEROCHECK=6, UINTX_ADD=7, DOT4=8,
-            MATMUL12_EXT=9, MATMUL12_INT=10, PUBLIC_INPUT=11, U32_FMA=12)
+            MATMUL12_EXT=9, MATMUL12_INT=10, PUBLIC_INPUT=11, U32_FMA=12, REDUCTION_BY_POWERS4=13)
 GATE_NAMES = {v: k for k, v in GATE.items()}
 LINK = dict(CARRY=0, FIRST=1, LAST=2, BCAST=3)
 
@@ -61,7 +61,7 @@ class _Stats(C.Structure):
                 ("limit", C.c_uint64), ("copy_columns", C.c_uint64), ("lookup_columns", C.c_uint64),
                 ("variables_outer", C.c_uint64), ("variables_loop", C.c_uint64),
                 ("constraints_per_instance", C.c_uint64), ("var_cells_per_instance", C.c_uint64),
-                ("gate_instances", C.c_uint64 * 13), ("lookups_per_instance", C.c_uint64),
+                ("gate_instances", C.c_uint64 * 14), ("lookups_per_instance", C.c_uint64),
                 ("program_words_outer", C.c_uint64), ("program_words_loop", C.c_uint64),
                 ("scratch_cells_outer", C.c_uint64), ("scratch_cells_loop", C.c_uint64),
                 ("cells_written_outer", C.c_uint64), ("cells_written_loop", C.c_uint64),
@@ -524,7 +524,7 @@ class ConstraintSystem:
         s = _Stats()
         _check(lib().zk_cs_stats(self._h, C.byref(s)))
         d = {f[0]: getattr(s, f[0]) for f in _Stats._fields_ if f[0] != "gate_instances"}
-        d["gate_instances"] = {GATE_NAMES[i]: s.gate_instances[i] for i in range(13)}
+        d["gate_instances"] = {GATE_NAMES[i]: s.gate_instances[i] for i in range(len(GATE))}
         return d
 
     print_gate_stats = stats

@@ -78,6 +78,8 @@ enum zk_gate_kind {
     ZK_GATE_MATMUL12_INT = 10, /* in0..11,out0..11 : out - M_I in (12 relations) */
     ZK_GATE_PUBLIC_INPUT = 11, /* 1 var : marks the cell public, no relation */
     ZK_GATE_U32_FMA = 12,  /* a,b,c,d,lo,hi  : a*b + c + d - lo - 2^32 hi  (U8x4FMAGate role) */
+    ZK_GATE_REDUCTION_BY_POWERS4 = 13, /* t0..t3,r ; c : t0 + c t1 + c^2 t2 + c^3 t3 - r  (ReductionByPowersGate<F,4>,
+                                        * /root/reference/src/main_vm/decoded_opcode.rs:275, opcodes/binop.rs:203-217) */
     ZK_GATE__COUNT
 };
 

@@ -283,19 +283,21 @@ def e2_inv(x):
 
 def lookup_argument(run: "CircuitRun", outer_words, loop_words, beta, gamma, n_cols: int):
     """K5 restatement (csrc/kernels_lookup_arg.hpp): per instance (A, B) with A = sum over every lookup tuple of the trace of
-    1/f, B = sum over table rows of multiplicity/f, f = beta + c0 + gamma c1 + gamma^2 c2 + gamma^3 table."""
-    g1, g2 = tuple(gamma), e2_mul(gamma, gamma)
-    g3 = e2_mul(g2, g1)
+    1/f, B = sum over table rows of multiplicity/f, f = beta + sum_j gamma^j c_j + gamma^W table (W = lookup width)."""
+    ho = parse_export(outer_words)
+    Wd = ho["lookup_width"]
+    gp = [(1, 0), tuple(gamma)]
+    while len(gp) <= Wd:
+        gp.append(e2_mul(gp[-1], gamma))
 
     def f(c, t):
-        c = list(c) + [0] * (3 - len(c))
-        return ((beta[0] + c[0] + g1[0] * c[1] + g2[0] * c[2] + g3[0] * t) % P, (beta[1] + g1[1] * c[1] + g2[1] * c[2] + g3[1] * t) % P)
+        c = list(c) + [0] * (Wd - len(c)) + [t]                 # the table id takes the power gamma^W
+        return ((beta[0] + sum(gp[j][0] * c[j] for j in range(Wd + 1))) % P, (beta[1] + sum(gp[j][1] * c[j] for j in range(Wd + 1))) % P)
 
     def add(x, y):
         return ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
 
     out = []
-    ho = parse_export(outer_words)
     hl = parse_export(loop_words) if run.limit else None
     for inst in range(run.B):
         A = (0, 0)
@@ -309,7 +311,7 @@ def lookup_argument(run: "CircuitRun", outer_words, loop_words, beta, gamma, n_c
                         continue
                     for u in range(n):
                         c0 = slot * n_cols + C0 + u * W
-                        A = add(A, e2_inv(f([int(cells[c0 + j, lane]) for j in range(min(W, 3))], table)))
+                        A = add(A, e2_inv(f([int(cells[c0 + j, lane]) for j in range(W)], table)))
         B = (0, 0)
         total = run.total_rows
         for t, td in enumerate(ho["tables"]):
@@ -320,7 +322,7 @@ def lookup_argument(run: "CircuitRun", outer_words, loop_words, beta, gamma, n_c
                 m = int(run.mult[inst * total + td["mult_off"] + r])
                 if m:
                     row = ho["table_words"][td["word_off"] + r * w: td["word_off"] + (r + 1) * w]
-                    i = e2_inv(f(row[:3], t))
+                    i = e2_inv(f(row[:Wd], t))
                     B = add(B, (i[0] * m % P, i[1] * m % P))
         out.append(A + B)
     return out

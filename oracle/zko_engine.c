@@ -328,7 +328,7 @@ int zko_scope_run_seq(const zko_scope *s, uint64_t *cells, size_t stride, uint32
     return 0;
 }
 
-static const unsigned char GW[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6};
+static const unsigned char GW[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5};
 
 /* Evaluate every gate relation + lookup tuple + copy pair. Returns the number of violated
  * relations; *first_key = packed (lane<<32 | slot<<12 | j<<4 | rel) of the smallest one (gates),
@@ -400,6 +400,13 @@ uint64_t zko_scope_check(const zko_scope *s, const uint64_t *cells, size_t strid
                     uint64_t lhs = zko_gl_add(zko_gl_add(zko_gl_mul(CELL(c0), CELL(c0 + 1)), CELL(c0 + 2)), CELL(c0 + 3));
                     uint64_t rhs = zko_gl_add(CELL(c0 + 4), zko_gl_mul(CELL(c0 + 5), 1ull << 32));
                     if (lhs != rhs) FAIL(j, 0);
+                } break;
+                case ZK_GATE_REDUCTION_BY_POWERS4: { /* t0 + c t1 + c^2 t2 + c^3 t3 == r, evaluated term by term */
+                    ++nrel;
+                    uint64_t c1 = k[0], c2 = zko_gl_mul(c1, c1), c3 = zko_gl_mul(c2, c1);
+                    uint64_t r = zko_gl_add(zko_gl_add(CELL(c0), zko_gl_mul(c1, CELL(c0 + 1))),
+                                            zko_gl_add(zko_gl_mul(c2, CELL(c0 + 2)), zko_gl_mul(c3, CELL(c0 + 3))));
+                    if (r != CELL(c0 + 4)) FAIL(j, 0);
                 } break;
                 default: break;
                 }

@@ -11,7 +11,7 @@ from oracle import zko
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 P = zko.P
 G, OP, LINK = zkgl.GATE, zkgl.OP, zkgl.LINK
-ALL_GATES = list(range(1, 13))
+ALL_GATES = list(range(1, 14))
 
 
 def load_fixture():
