@@ -39,7 +39,7 @@ timed("C1 ram_permutation 2^16 rows", cs, outer, loop, 512)
 cs, limit = T.fit(lambda c: c.configure_keccak(), lambda c, l: c.keccak256_round_function_entry_point(l), 20)
 reqs, _ = T._keccak_requests(np.random.default_rng(0xC3), limit)
 inst = kn.instance(reqs, limit)
-B = 32
+B = 128
 outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
 timed("C3 keccak256_round_function 2^20 rows", cs, outer, loop, B)
 cs, limit = T.fit(lambda c: c.configure_sha256(), lambda c, l: c.sha256_round_function_entry_point(l), 20)
