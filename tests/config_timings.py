@@ -1,8 +1,9 @@
 """Timings of BASELINE.json's other configurations at full size on one GPU (C1, C3, C4, C5): one fused
 resolve_and_check per configuration (after one warm-up), inputs from the native restatements used by the parity tests.
-Prints one JSON line per configuration.  usage (GPU box, repo root): python tools/config_timings.py"""
+Prints one JSON line per configuration.  It lives under tests/ because its input generators are the oracle's native restatements (test infrastructure).
+usage (GPU box, repo root): python tests/config_timings.py"""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file is tests/config_timings.py)
 for p in (ROOT, os.path.join(ROOT, "era-zkevm_circuits_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np
