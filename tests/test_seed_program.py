@@ -1,0 +1,43 @@
+"""The cone seeding program (CS::build_seed_program): a regression guard on its size per circuit — the backward slice must stay
+small for the queue circuits and the seed hints must keep the hash decompositions out of it — plus structural checks that need
+no GPU (every circuit with carried state gets a cone program; slot budget respected)."""
+import pytest
+
+import zkgl
+
+CASES = [
+    # (name, configure, entry, geometry cols, max seed ops, max seed slots)
+    ("ram_permutation", "configure_ram_permutation", lambda c: c.ram_permutation_entry_point(8), 100, 200, 128),
+    ("storage_validity", "configure_storage_validity", lambda c: c.sort_and_deduplicate_storage_access_entry_point(8, True), 100, 600, 256),
+    ("log_sorter", "configure_log_sorter", lambda c: c.sort_and_deduplicate_events_entry_point(8), 100, 450, 256),
+    ("demux_log_queue", "configure_demux_log_queue", lambda c: c.demultiplex_storage_logs_entry_point(8), 100, 400, 256),
+    ("sort_decommits", "configure_sort_decommits", lambda c: c.sort_and_deduplicate_code_decommittments_entry_point(8), 100, 400, 256),
+    ("sha256_round_function", "configure_sha256", lambda c: c.sha256_round_function_entry_point(4), 100, 400, 256),
+    ("code_unpacker", "configure_code_unpacker", lambda c: c.unpack_code_into_memory_entry_point(4), 100, 400, 256),
+    ("keccak256_blocks", "configure_keccak", lambda c: c.keccak256_blocks_entry_point(4), 100, 400, 640),
+    ("eip_4844", "configure_eip_4844", lambda c: c.eip_4844_entry_point(27), 60, 1000, 640),
+    ("vm_shaped", "configure_vm_shaped", lambda c: c.vm_shaped_entry_point(6), 140, 1100, 400),
+]
+
+
+@pytest.mark.parametrize("name,configure,entry,cols,max_ops,max_slots", CASES, ids=[c[0] for c in CASES])
+def test_cone_program_is_small(name, configure, entry, cols, max_ops, max_slots):
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(cols, 0, 8, 8 if name == "vm_shaped" else 4), 1 << 22, 1 << 28)
+    getattr(cs, configure)()
+    entry(cs)
+    cs.pad_and_shrink()
+    st = cs.stats()
+    assert 0 < st["seed_ops"] <= max_ops, st["seed_ops"]
+    assert 0 < st["seed_slots"] <= max_slots, st["seed_slots"]
+    assert st["seed_ops"] < st["loop_ops"]
+    assert st["seed_slots"] + cs.input_words()[1] <= 5120      # LDS budget of k_seed_cone (kernels_engine.hpp SEED_LDS_WORDS)
+
+
+def test_hash_fsm_keeps_its_byte_buffer_in_the_cone():
+    """keccak FSM: the Keccak-f decomposition is replaced by the hint, the ByteBuffer selects are genuine carried state"""
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
+    cs.configure_keccak()
+    cs.keccak256_round_function_entry_point(2)
+    cs.pad_and_shrink()
+    st = cs.stats()
+    assert 40000 < st["seed_ops"] < 50000 and st["loop_ops"] > 75000
