@@ -147,7 +147,7 @@ def main():
 
     def step():
         ok, failure = cs.resolve_and_check(stream)  # witness generation + full satisfiability check, one pipeline
-        if not ok:
+        if not ok and not os.environ.get("ZKGL_STUB_RUN"):  # ZKGL_STUB_RUN: tools/stub_bench.sh times deliberately wrong kernel variants
             raise RuntimeError(f"trace not satisfied: {failure}")
 
     def fence():

@@ -252,6 +252,16 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
     __amdgpu_buffer_rsrc_t tile_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         sc.cells + (size_t)(TILE_UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6)) : 0u) * sc.n_cells * 64, 0, -1,
         0x00020000);  // gfx9 raw buffer descriptor: stride 0, num_records 2^32-1, 32-bit data format
+    // the same descriptor as four SGPRs for the hand-scheduled destination loop in st()
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 tile_rsrc4;
+    {
+        const uint64_t bp = (uint64_t)(sc.cells + (size_t)(TILE_UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6)) : 0u) * sc.n_cells * 64);
+        tile_rsrc4.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)bp);
+        tile_rsrc4.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(bp >> 32));
+        tile_rsrc4.z = -1;
+        tile_rsrc4.w = 0x00020000;
+    }
     ProgWindow P;
     P.init(SLOTS ? prog : sc.prog, word_begin);
     __shared__ uint64_t p2s[12 * TPB];  // Poseidon2 state, [element][thread]
@@ -262,8 +272,12 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         if (kind == ZK_OPERAND_OUTER) return sc.outer_cells[cell_off(sc.outer_n_cells, idx, inst)];
         if constexpr (SLOTS) return slots[idx * slot_stride];
         if constexpr (TILE_UNIFORM) {
+#ifdef ZKGL_STUB_LOADS  // time attribution only (tools/stub_bench.sh): operand values without the memory access
+            return (uint64_t)idx * 0x9E3779B97F4A7C15ull + lane_byte;
+#else
             u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc, lane_byte, idx << 9, 0);
             return (uint64_t)v.x | ((uint64_t)v.y << 32);
+#endif
         }
         return cells[(size_t)idx << 6];
     };
@@ -273,6 +287,36 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             P.sync(pc);
             slots[P.at(pc++) * slot_stride] = v;
         } else {
+            if constexpr (TILE_UNIFORM) {
+                // Hand-scheduled walk of the destination words that sit in the current window half (8 instructions per word:
+                // readlane, store with the cell offset shifted straight into the buffer soffset, MORE test); a list that runs
+                // past the window half finishes in the generic loop below.
+                P.sync(pc);
+                uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pc - P.base));
+                if (off < 64) {
+                    u32x2 o;
+                    o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
+                    uint32_t wlast, addr;
+                    asm volatile(
+                        ".LDST%=:\n"
+                        "v_readlane_b32 %[w], %[w0], %[off]\n"
+                        "s_add_u32 %[off], %[off], 1\n"
+                        "s_lshl_b32 %[addr], %[w], 9\n"
+#ifndef ZKGL_STUB_STORES  // time attribution only (tools/stub_bench.sh): the walk of the destination words without the store
+                        "buffer_store_dwordx2 %[val], %[lb], %[rs], %[addr] offen\n"
+#endif
+                        "s_bitcmp1_b32 %[w], 31\n"
+                        "s_cbranch_scc0 .LDSTX%=\n"
+                        "s_cmp_lt_u32 %[off], 64\n"
+                        "s_cbranch_scc1 .LDST%=\n"
+                        ".LDSTX%=:\n"
+                        : [off] "+s"(off), [w] "=&s"(wlast), [addr] "=&s"(addr)
+                        : [w0] "v"(P.w0), [val] "v"(o), [lb] "v"(lane_byte), [rs] "s"(tile_rsrc4)
+                        : "scc", "memory");
+                    pc = P.base + off;
+                    if (!(wlast & ZK_DEST_MORE)) return;
+                }
+            }
             uint32_t w;
             do {
                 P.sync(pc);
@@ -280,7 +324,11 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                 if constexpr (TILE_UNIFORM) {
                     u32x2 o;
                     o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
+#ifdef ZKGL_STUB_STORES
+                    asm volatile("" ::"v"(o), "s"(w));
+#else
                     __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ZK_DEST_CELL_MASK) << 9, 0);
+#endif
                 } else {
                     cells[(size_t)(w & ZK_DEST_CELL_MASK) << 6] = v;
                 }
@@ -405,7 +453,11 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 #pragma unroll 1
                 for (int i = 0; i < n; ++i) {
                     uint64_t t = gl::add(p2s[i * TPB + threadIdx.x], p2::RC[12 * r + i]);
+#ifdef ZKGL_STUB_P2  // time attribution only (tools/stub_bench.sh): the S-box without its four multiplications
+                    uint64_t x2 = t ^ 1, x3 = t ^ 2, x4 = t ^ 3, x7 = t ^ 4;
+#else
                     uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+#endif
                     if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
                     p2s[i * TPB + threadIdx.x] = x7;
                 }

@@ -263,8 +263,12 @@ def parse_export(words) -> dict:
              limit=w[8], pre_words=w[9], n_prog=w[10], n_consts=w[11], n_rows=w[12], n_rowconsts=w[13], n_lrows=w[14], n_copies=w[15],
              n_tables=w[16], n_table_words=w[17], n_links=w[18], n_carries=w[19], n_stream_words=w[20])
     p = 21 + h["n_prog"] + 2 * h["n_consts"] + 4 * h["n_rows"] + 2 * h["n_rowconsts"]
+    q = 21 + h["n_prog"] + 2 * h["n_consts"]
+    h["rows"] = [tuple(w[q + 4 * i: q + 4 * i + 4]) for i in range(h["n_rows"])]  # (kind, n_instances, const_off, n_consts)
     h["lrows"] = [(w[p + 2 * i], w[p + 2 * i + 1]) for i in range(h["n_lrows"])]
-    p += 2 * h["n_lrows"] + 2 * h["n_copies"]
+    p += 2 * h["n_lrows"]
+    h["copies"] = [(w[p + 2 * i], w[p + 2 * i + 1]) for i in range(h["n_copies"])]  # (cell, partner cell)
+    p += 2 * h["n_copies"]
     h["tables"] = [dict(word_off=w[p + 9 * i], mult_off=w[p + 9 * i + 1], n_rows=w[p + 9 * i + 2], n_keys=w[p + 9 * i + 3], n_vals=w[p + 9 * i + 4])
                    for i in range(h["n_tables"])]
     p += 9 * h["n_tables"]

@@ -127,6 +127,64 @@ def test_fault_injection_reports_place(zk):
     del keep
 
 
+def test_copy_constraint_failures_name_the_pair(zk):
+    """The gate checker verifies the copy constraint of every cell it reads (chain partner = nearest earlier cell of the
+    variable); cells of rows without relations are left to k_check_copies.  Flipping a boolean cell keeps its gate
+    satisfied, so the report must be the copy pair (kind 0x200, slot = the pair's cell, relation = pair index) — the
+    smallest index among the pairs the cell takes part in, as the oracle's pair scan finds it."""
+    limit, batch = 8, 3
+    cs = ram_cs(limit)
+    insts = random_instances(5, batch, 6, limit)
+    outer, loop = rn.pack_streams(insts, limit)
+    keep = gpu_run(zk, cs, outer, loop, batch)
+    assert cs.check_if_satisfied()[0]
+    st = cs.stats()
+    n_cols = st["copy_columns"] + st["lookup_columns"]
+    h = zko.parse_export(cs.export(True))
+    tr = cs.trace(True)
+    pairs = h["copies"]
+    in_pair = {}
+    for pi, (c, partner) in enumerate(pairs):
+        in_pair.setdefault(c, []).append(pi)
+        in_pair.setdefault(partner, []).append(pi)
+    tried = 0
+    for slot, (kind, ninst, _, _) in enumerate(h["rows"]):
+        if kind != G["BOOLEAN"]:
+            continue
+        for j in range(ninst):
+            cell, lane = slot * n_cols + j, 2 * limit + 5
+            if cell not in in_pair:
+                continue
+            old = int(tr[cell, lane])
+            assert old in (0, 1)
+            cs.write_cell(True, cell, lane, 1 - old)
+            ok, f = cs.check_if_satisfied()
+            want = min(in_pair[cell])
+            assert not ok and (f.scope, f.instance, f.iteration, f.kind) == (1, 2, 5, 0x200), (f.scope, f.instance, f.iteration, hex(f.kind))
+            assert (f.relation, f.slot) == (want, pairs[want][0])
+            cs.write_cell(True, cell, lane, old)
+            tried += 1
+            if tried == 6:
+                break
+        if tried == 6:
+            break
+    assert tried > 0 and cs.check_if_satisfied()[0]
+    # a public-input cell sits in a row without relations: only the residual pair list covers it
+    ho = zko.parse_export(cs.export(False))
+    pub_slot = [slot for slot, row in enumerate(ho["rows"]) if row[0] == G["PUBLIC_INPUT"]][0]
+    pub = pub_slot * n_cols + 2
+    mine = [pi for pi, (c, partner) in enumerate(ho["copies"]) if pub in (c, partner)]
+    assert mine
+    tro = cs.trace(False)
+    old = int(tro[pub, 1])
+    cs.write_cell(False, pub, 1, (old + 1) % P)
+    ok, f = cs.check_if_satisfied()
+    assert not ok and (f.scope, f.instance, f.kind, f.relation) == (0, 1, 0x200, min(mine))
+    cs.write_cell(False, pub, 1, old)
+    assert cs.check_if_satisfied()[0]
+    del keep
+
+
 def test_all_ops_circuit_gpu_equals_oracle(zk):
     """every op / gate kind; carried state seeded by the GPU's sequential mode == the oracle's"""
     limit, batch = 4, 130
