@@ -369,6 +369,19 @@ int zk_cs_lookup_argument(zk_cs* cs, const uint64_t beta[2], const uint64_t gamm
         if (out) for (size_t i = 0; i < v.size() && i < 4 * (size_t)max_instances; ++i) out[i] = v[i];
     });
 }
+int zk_two_adic_root(uint32_t log_n, uint64_t* out) {
+    NEED(out);
+    return guard([&] { *out = zkgl::two_adic_root(log_n); });
+}
+int zk_ntt(uint64_t* dev_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, int inverse, uint64_t coset_shift, void* stream) {
+    NEED(dev_data); NEED_INIT();
+    return guard([&] { zkgl::ntt(dev_data, log_n, n_polys, stride, inverse != 0, coset_shift, stream); });
+}
+int zk_lde(const uint64_t* dev_coeffs, uint64_t src_stride, uint64_t* dev_out, uint32_t log_n, uint32_t log_blowup, uint32_t n_polys,
+           uint64_t coset_shift, void* stream) {
+    NEED(dev_coeffs); NEED(dev_out); NEED_INIT();
+    return guard([&] { zkgl::lde(dev_coeffs, src_stride, dev_out, log_n, log_blowup, n_polys, coset_shift, stream); });
+}
 int zk_cs_stats(zk_cs* cs, zk_stats* out) {
     NEED(cs); NEED(out);
     return guard([&] { cs->cs->stats(out); });

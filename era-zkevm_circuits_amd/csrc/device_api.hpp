@@ -51,6 +51,14 @@ int launch_lookup_arg_tables(const zk_table_desc* tables, uint32_t n_tables, con
                              const uint64_t ch[10], uint64_t* inv_f, const uint32_t* mult, uint32_t n_instances, uint64_t* out_b, void* stream);
 int launch_lookup_arg_witness_sum(const uint64_t* acc_outer, const uint64_t* acc_loop, uint32_t limit, uint32_t n_instances,
                                   uint64_t* out_a, void* stream);
+// K6 NTT (kernels_ntt.hpp); mirrors zkn::PassDev
+struct NttPassArgs {
+    const uint64_t* src; uint64_t* dst; uint64_t src_stride, dst_stride;
+    uint32_t log_n, seg, r, t, inverse;
+    const uint64_t* root1024; const uint64_t* tw_lo; const uint64_t* tw_hi; const uint64_t* c_lo; const uint64_t* c_hi;
+};
+int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream);
+int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t* c_hi, uint32_t n_hi, void* stream);
 // cone seeding: seed_prog in device memory (padded like every program), carries = {input word, out slot, first outer cell, has_first}
 int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_words, uint32_t n_slots, uint32_t n_input_words,
                      const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream);

@@ -6,6 +6,7 @@
 #include "kernels_primitives.hpp"
 #include "kernels_engine.hpp"
 #include "kernels_lookup_arg.hpp"
+#include "kernels_ntt.hpp"
 
 namespace zkdev {
 
@@ -148,6 +149,24 @@ int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lane
     dim3 grid(lane_tiles, (n_pairs + per - 1) / per);
     zke::k_check_copies<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(cells, n_cells, n_lanes, pairs, n_pairs, per, fail);
     return LAUNCH_CHECK("k_check_copies");
+}
+
+int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream) {
+    if (n_polys == 0) return 0;
+    zkn::PassDev d;
+    d.src = a.src; d.dst = a.dst; d.src_stride = a.src_stride; d.dst_stride = a.dst_stride;
+    d.log_n = a.log_n; d.seg = a.seg; d.r = a.r; d.t = a.t; d.inverse = a.inverse;
+    d.root1024 = a.root1024; d.tw_lo = a.tw_lo; d.tw_hi = a.tw_hi; d.c_lo = a.c_lo; d.c_hi = a.c_hi;
+    const uint64_t blocks = (uint64_t)n_polys << (a.log_n - a.r - a.t);
+    if (blocks > 0x7fffffffull) { g_hip_err = "k_ntt_pass: grid too large"; return -2; }
+    const size_t lds = sizeof(uint64_t) << (a.r + a.t);
+    zkn::k_ntt_pass<<<(unsigned)blocks, zkn::TPB, lds, (hipStream_t)stream>>>(d);
+    return LAUNCH_CHECK("k_ntt_pass");
+}
+
+int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t* c_hi, uint32_t n_hi, void* stream) {
+    zkn::k_coset_tables<<<grid_for(1024 + n_hi, zkn::TPB), zkn::TPB, 0, (hipStream_t)stream>>>(base, scale, c_lo, c_hi, n_hi);
+    return LAUNCH_CHECK("k_coset_tables");
 }
 
 int launch_lookup_arg_witness(const LookupArgArgs& a, const uint64_t ch[10], void* stream) {

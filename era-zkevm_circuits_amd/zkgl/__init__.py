@@ -224,6 +224,27 @@ def grand_product(enc, flags, challenges, enc_len, n, init, acc_out, scratch, st
 # ------------------------------------------------------------------------------------------------
 # constraint system
 # ------------------------------------------------------------------------------------------------
+# K6: Goldilocks NTT / coset LDE over device-resident polynomials (include/zkgl.h)
+def two_adic_root(log_n: int) -> int:
+    out = C.c_uint64()
+    _check(lib().zk_two_adic_root(C.c_uint32(log_n), C.byref(out)))
+    return out.value
+
+
+def ntt(data, log_n: int, n_polys: int = 1, stride=None, inverse: bool = False, coset_shift: int = 1, stream=None):
+    """in place: forward = natural coefficients -> bit-reversed values on coset_shift * <omega_N>, inverse = the inverse map"""
+    stride = (1 << log_n) if stride is None else stride
+    _check(lib().zk_ntt(_ptr(data), C.c_uint32(log_n), C.c_uint32(n_polys), C.c_uint64(stride), C.c_int(int(inverse)),
+                        C.c_uint64(coset_shift), _ptr(stream)))
+
+
+def lde(coeffs, out, log_n: int, log_blowup: int, n_polys: int = 1, src_stride=None, coset_shift: int = 1, stream=None):
+    """out[q][j][:] = forward transform of polynomial q on the coset coset_shift * eta^bitrev(j) * <omega_N>"""
+    src_stride = (1 << log_n) if src_stride is None else src_stride
+    _check(lib().zk_lde(_ptr(coeffs), C.c_uint64(src_stride), _ptr(out), C.c_uint32(log_n), C.c_uint32(log_blowup), C.c_uint32(n_polys),
+                        C.c_uint64(coset_shift), _ptr(stream)))
+
+
 @dataclass
 class CSGeometry:  # boojum::cs::CSGeometry (src/main_vm/cycle.rs:959-966)
     num_columns_under_copy_permutation: int

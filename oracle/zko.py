@@ -50,6 +50,11 @@ def lib():
         L.zko_scope_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]
         L.zko_links_check.restype = C.c_uint64
         L.zko_links_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.zko_two_adic_root.restype = u64
+        L.zko_two_adic_root.argtypes = [C.c_uint]
+        L.zko_ntt_naive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, u64]
+        L.zko_ntt_batch.argtypes = [C.c_void_p, C.c_uint, C.c_size_t, C.c_size_t, C.c_int, u64]
+        L.zko_lde.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, u64]
         _lib = L
     return _lib
 
@@ -329,4 +334,32 @@ def lookup_argument(run: "CircuitRun", outer_words, loop_words, beta, gamma, n_c
                     i = e2_inv(f(row[:Wd], t))
                     B = add(B, (i[0] * m % P, i[1] * m % P))
         out.append(A + B)
+    return out
+
+
+# ---- K6: NTT / coset LDE (zko_ntt.c) ----
+def two_adic_root(log_n: int) -> int:
+    return int(lib().zko_two_adic_root(log_n))
+
+
+def ntt_naive(a: np.ndarray, shift: int = 1) -> np.ndarray:
+    """the definition: out[bitrev(k)] = sum_i a[i] (shift * omega^k)^i, by Horner at every point"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().zko_ntt_naive(a.ctypes.data, out.ctypes.data, int(a.size).bit_length() - 1, shift)
+    return out
+
+
+def ntt(a: np.ndarray, inverse: bool = False, shift: int = 1) -> np.ndarray:
+    """a: [n_polys, N] (or [N]); returns the transformed copy"""
+    a = np.array(a, dtype=np.uint64, order="C", copy=True)
+    v = a.reshape(1, -1) if a.ndim == 1 else a
+    lib().zko_ntt_batch(v.ctypes.data, int(v.shape[1]).bit_length() - 1, v.shape[0], v.shape[1], int(inverse), shift)
+    return a
+
+
+def lde(coeffs: np.ndarray, log_blowup: int, shift: int = 1) -> np.ndarray:
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+    out = np.empty(coeffs.size << log_blowup, dtype=np.uint64)
+    lib().zko_lde(coeffs.ctypes.data, out.ctypes.data, int(coeffs.size).bit_length() - 1, log_blowup, shift)
     return out

@@ -1,0 +1,174 @@
+"""K6: Goldilocks NTT / coset LDE.  CPU part: the oracle's fast transform is pinned by the definition (Horner
+evaluation at every domain point, in C and independently in Python integers) and by algebraic identities.  GPU part (-m gpu):
+zk_ntt / zk_lde equal the oracle bit for bit at every size up to 2^16, and satisfy size-independent properties at 2^20-2^22."""
+import numpy as np
+import pytest
+
+from helpers import P
+from oracle import zko
+
+SHIFT = 7  # the multiplicative generator: the coset used by the usual quotient domains
+
+
+def bitrev(x, bits):
+    return int(format(x, f"0{bits}b")[::-1], 2) if bits else 0
+
+
+def rand_poly(rng, *shape):
+    return rng.integers(0, P, size=shape, dtype=np.uint64)
+
+
+# ------------------------------------------------------------------ CPU: oracle pins
+def test_two_adic_root_has_exact_order():
+    w32 = zko.two_adic_root(32)
+    assert w32 == pow(7, (P - 1) >> 32, P)
+    assert pow(w32, 1 << 32, P) == 1 and pow(w32, 1 << 31, P) == P - 1
+    for n in range(0, 33):
+        assert zko.two_adic_root(n) == pow(w32, 1 << (32 - n), P)
+    # 2 has order 192 in GF(p): the 64th roots of unity are powers of two, omega_64 = 8^k for an odd k
+    w64 = zko.two_adic_root(6)
+    assert any(pow(8, k, P) == w64 for k in range(1, 64, 2))
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 7])
+@pytest.mark.parametrize("shift", [1, SHIFT, 0x123456789ABCDEF])
+def test_fast_transform_equals_the_definition(log_n, shift):
+    rng = np.random.default_rng(100 + log_n)
+    n = 1 << log_n
+    a = rand_poly(rng, n)
+    w = zko.two_adic_root(log_n)
+    # the definition in Python integers
+    want = [0] * n
+    for k in range(n):
+        x = shift * pow(w, k, P) % P
+        acc = 0
+        for c in reversed([int(v) for v in a]):
+            acc = (acc * x + c) % P
+        want[bitrev(k, log_n)] = acc
+    assert [int(v) for v in zko.ntt_naive(a, shift)] == want
+    got = zko.ntt(a, False, shift)
+    assert [int(v) for v in got] == want
+    assert np.array_equal(zko.ntt(got, True, shift), a)
+
+
+def test_oracle_identities():
+    rng = np.random.default_rng(5)
+    a, b = rand_poly(rng, 4, 1 << 10), rand_poly(rng, 4, 1 << 10)
+    fa, fb = zko.ntt(a), zko.ntt(b)
+    s = ((a.astype(object) + b.astype(object)) % P).astype(np.uint64)
+    assert np.array_equal(zko.ntt(s), ((fa.astype(object) + fb.astype(object)) % P).astype(np.uint64))  # linearity
+    const = np.zeros(1 << 10, dtype=np.uint64); const[0] = 12345
+    assert np.all(zko.ntt(const, False, SHIFT) == 12345)                                                # constant polynomial
+    # convolution theorem on a subgroup twice the size: (a * b)(x) = a(x) b(x)
+    pa, pb = np.zeros(1 << 11, dtype=np.uint64), np.zeros(1 << 11, dtype=np.uint64)
+    pa[: 1 << 10], pb[: 1 << 10] = a[0], b[0]
+    prod = (zko.ntt(pa).astype(object) * zko.ntt(pb).astype(object)) % P
+    c = zko.ntt(prod.astype(np.uint64), True)
+    i = 777
+    want = sum(int(a[0][j]) * int(b[0][i - j]) for j in range(i + 1)) % P
+    assert int(c[i]) == want
+    # LDE blocks == one big transform of the zero-padded coefficients
+    big = np.zeros(1 << 13, dtype=np.uint64); big[: 1 << 10] = a[1]
+    assert np.array_equal(zko.lde(a[1], 3, SHIFT), zko.ntt(big, False, SHIFT))
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def zk():
+    import torch
+    import zkgl
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    zkgl.init(0)
+    return zkgl
+
+
+def dev_ntt(zk, a, log_n, inverse=False, shift=1, stride=None):
+    stride = stride or (1 << log_n)
+    flat = np.zeros(a.shape[0] * stride, dtype=np.uint64)
+    for q in range(a.shape[0]):
+        flat[q * stride: q * stride + (1 << log_n)] = a[q]
+    d = zk.DeviceBuffer.from_numpy(flat)
+    zk.ntt(d, log_n, a.shape[0], stride, inverse, shift)
+    zk.sync()
+    out = d.to_numpy()
+    return np.stack([out[q * stride: q * stride + (1 << log_n)] for q in range(a.shape[0])]), out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", list(range(0, 17)))
+def test_gpu_transform_equals_oracle(zk, log_n):
+    rng = np.random.default_rng(200 + log_n)
+    n_polys = 3 if log_n < 14 else 2
+    a = rand_poly(rng, n_polys, 1 << log_n)
+    for shift in (1, SHIFT):
+        f, _ = dev_ntt(zk, a, log_n, False, shift)
+        assert np.array_equal(f, zko.ntt(a, False, shift)), (log_n, shift)
+        b, _ = dev_ntt(zk, f, log_n, True, shift)
+        assert np.array_equal(b, a), (log_n, shift)
+    back, _ = dev_ntt(zk, a, log_n, True, 0x123456789ABCDEF)
+    assert np.array_equal(back, zko.ntt(a, True, 0x123456789ABCDEF))
+
+
+@pytest.mark.gpu
+def test_gpu_stride_leaves_the_gaps_alone(zk):
+    rng = np.random.default_rng(9)
+    log_n, stride = 11, (1 << 11) + 40
+    a = rand_poly(rng, 5, 1 << log_n)
+    f, raw = dev_ntt(zk, a, log_n, False, SHIFT, stride)
+    assert np.array_equal(f, zko.ntt(a, False, SHIFT))
+    for q in range(5):
+        assert not raw[q * stride + (1 << log_n): (q + 1) * stride].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,log_blowup", [(1, 1), (5, 3), (10, 2), (12, 3), (14, 1)])
+def test_gpu_lde_equals_oracle_and_the_big_transform(zk, log_n, log_blowup):
+    rng = np.random.default_rng(300 + log_n)
+    n, n_polys = 1 << log_n, 3
+    a = rand_poly(rng, n_polys, n)
+    src = zk.DeviceBuffer.from_numpy(a.reshape(-1))
+    out = zk.DeviceBuffer(n_polys * (n << log_blowup))
+    zk.lde(src, out, log_n, log_blowup, n_polys, None, SHIFT)
+    zk.sync()
+    got = out.to_numpy().reshape(n_polys, n << log_blowup)
+    assert np.array_equal(src.to_numpy().reshape(n_polys, n), a)  # source untouched
+    for q in range(n_polys):
+        assert np.array_equal(got[q], zko.lde(a[q], log_blowup, SHIFT))
+    big = np.zeros((n_polys, n << log_blowup), dtype=np.uint64)
+    big[:, :n] = a
+    f, _ = dev_ntt(zk, big, log_n + log_blowup, False, SHIFT)
+    assert np.array_equal(got, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [20, 22])
+def test_gpu_full_size_properties(zk, log_n):
+    """trace-sized transforms (2^20 rows main_vm / hashes, 2^22 storage): round trip, linearity, oracle on one polynomial"""
+    import torch
+    n, n_polys = 1 << log_n, 6
+    rng = np.random.default_rng(log_n)
+    a = rand_poly(rng, n_polys, n)
+    a[1] = 0; a[1][0] = 42                       # constant
+    a[2] = ((a[3].astype(object) + a[4].astype(object)) % P).astype(np.uint64)
+    d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    zk.ntt(d, log_n, n_polys, n, False, SHIFT)
+    torch.cuda.synchronize()
+    f = d.cpu().numpy().view(np.uint64)
+    assert np.all(f[1] == 42)
+    assert np.array_equal(f[2], ((f[3].astype(object) + f[4].astype(object)) % P).astype(np.uint64))
+    assert np.array_equal(f[0], zko.ntt(a[0], False, SHIFT))
+    zk.ntt(d, log_n, n_polys, n, True, SHIFT)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), a)
+
+
+@pytest.mark.gpu
+def test_gpu_argument_errors(zk):
+    d = zk.DeviceBuffer(16)
+    with pytest.raises(zk.ZkError):
+        zk.ntt(d, 3, 1, 8, False, 0)          # zero shift
+    with pytest.raises(zk.ZkError):
+        zk.ntt(d, 3, 2, 4, False, 1)          # stride smaller than the polynomial
+    with pytest.raises(zk.ZkError):
+        zk.ntt(d, 31, 1, None, False, 1)
