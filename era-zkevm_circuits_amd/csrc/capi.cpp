@@ -373,14 +373,14 @@ int zk_two_adic_root(uint32_t log_n, uint64_t* out) {
     NEED(out);
     return guard([&] { *out = zkgl::two_adic_root(log_n); });
 }
-int zk_ntt(uint64_t* dev_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, int inverse, uint64_t coset_shift, void* stream) {
+int zk_ntt(uint64_t* dev_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, uint32_t mode, uint64_t coset_shift, void* stream) {
     NEED(dev_data); NEED_INIT();
-    return guard([&] { zkgl::ntt(dev_data, log_n, n_polys, stride, inverse != 0, coset_shift, stream); });
+    return guard([&] { zkgl::ntt(dev_data, log_n, n_polys, stride, mode, coset_shift, stream); });
 }
 int zk_lde(const uint64_t* dev_coeffs, uint64_t src_stride, uint64_t* dev_out, uint32_t log_n, uint32_t log_blowup, uint32_t n_polys,
-           uint64_t coset_shift, void* stream) {
+           uint32_t mode, uint64_t coset_shift, void* stream) {
     NEED(dev_coeffs); NEED(dev_out); NEED_INIT();
-    return guard([&] { zkgl::lde(dev_coeffs, src_stride, dev_out, log_n, log_blowup, n_polys, coset_shift, stream); });
+    return guard([&] { zkgl::lde(dev_coeffs, src_stride, dev_out, log_n, log_blowup, n_polys, mode, coset_shift, stream); });
 }
 int zk_cs_stats(zk_cs* cs, zk_stats* out) {
     NEED(cs); NEED(out);

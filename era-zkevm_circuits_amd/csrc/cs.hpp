@@ -230,8 +230,8 @@ class CS {
 
 // K6 (ntt.cpp): batched Goldilocks NTT / coset LDE over device-resident polynomials, see include/zkgl.h
 uint64_t two_adic_root(uint32_t log_n);
-void ntt(uint64_t* d_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, bool inverse, uint64_t coset_shift, void* stream);
+void ntt(uint64_t* d_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, uint32_t mode, uint64_t coset_shift, void* stream);
 void lde(const uint64_t* d_coeffs, uint64_t src_stride, uint64_t* d_out, uint32_t log_n, uint32_t log_blowup, uint32_t n_polys,
-         uint64_t coset_shift, void* stream);
+         uint32_t mode, uint64_t coset_shift, void* stream);
 
 }  // namespace zkgl

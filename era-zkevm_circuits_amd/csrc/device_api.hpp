@@ -54,7 +54,7 @@ int launch_lookup_arg_witness_sum(const uint64_t* acc_outer, const uint64_t* acc
 // K6 NTT (kernels_ntt.hpp); mirrors zkn::PassDev
 struct NttPassArgs {
     const uint64_t* src; uint64_t* dst; uint64_t src_stride, dst_stride;
-    uint32_t log_n, seg, r, t, inverse;
+    uint32_t log_n, seg, r, t, dit, coset_store, coset_brev;
     const uint64_t* root1024; const uint64_t* tw_lo; const uint64_t* tw_hi; const uint64_t* c_lo; const uint64_t* c_hi;
 };
 int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream);

@@ -19,21 +19,23 @@
 // passes backwards with decimation-in-time butterflies and inverse tables.
 //
 // Bound: 16 B of HBM traffic per element per pass against ~(r/2 + 3) field multiplications (each four v_mad_u64_u32 plus
-// the 2^64 = 2^32 - 1 folding): on gfx950 the passes are VALU-bound, see profiles/.
+// the 2^64 = 2^32 - 1 folding): on gfx950 the passes are VALU-bound (VALUBusy 88 %), see profiles/r1_ntt.md.
 #pragma once
 #include "gl_device.hpp"
 
 namespace zkn {
 
-constexpr int TPB = 256;
-constexpr uint32_t LOG_BLOCK_ELEMS = 13;  // 8192 elements = 64 KB LDS per block
+constexpr int TPB = 512;
+constexpr uint32_t LOG_BLOCK_ELEMS = 13;  // 8192 elements = 64 KB (+ padding and 4 KB of twiddles) of LDS per block, 2 blocks per CU
 
 struct PassDev {
     const uint64_t* src;
     uint64_t* dst;
     uint64_t src_stride, dst_stride;  // elements between consecutive polynomials
     uint32_t log_n, seg, r, t;        // lo = seg - r
-    uint32_t inverse;
+    uint32_t dit;                     // 0: decimation in frequency (natural -> bit-reversed), 1: in time (bit-reversed -> natural)
+    uint32_t coset_store;             // coset / scale factors applied when storing (inverse direction) instead of when loading
+    uint32_t coset_brev;              // the coefficient side is in bit-reversed order: factor index = bitrev_n(position)
     const uint64_t* root1024;         // omega_1024^(+-j), j < 512
     const uint64_t* tw_lo;            // omega_{2^seg}^(+-j), j < 1024
     const uint64_t* tw_hi;            // omega_{2^seg}^(+-1024 j), j < max(1, 2^seg / 1024)
@@ -42,9 +44,78 @@ struct PassDev {
 };
 
 __device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) { return bits ? __brev(x) >> (32 - bits) : 0; }
+// one spare word per 32: a thread that owns 8 or 16 consecutive elements then starts in a bank of its own
+__device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 5); }
+__host__ __device__ constexpr uint32_t padded_elems(uint32_t n) { return n + (n >> 5) + 1; }
+
+// Stages lh = g_lo .. g_lo + M - 1 of the size-2^r transforms in registers: every work item owns the 2^M elements that differ in
+// those bits of h, so a group of M stages costs one LDS round trip and one barrier (r = 10 runs as 4 + 3 + 3).
+template <int M, bool INV>
+__device__ __forceinline__ void radix_group(uint64_t* __restrict__ s, const uint64_t* __restrict__ W, uint32_t g_lo, uint32_t r, uint32_t t,
+                                            bool strided, uint32_t n_elems) {
+    constexpr int R = 1 << M;
+    const uint32_t n_items = n_elems >> M;
+    for (uint32_t it = threadIdx.x; it < n_items; it += TPB) {
+        uint32_t p, l;
+        if (strided) { l = it & ((1u << t) - 1); p = it >> t; }
+        else { p = it & ((1u << (r - M)) - 1); l = it >> (r - M); }
+        const uint32_t low = p & ((1u << g_lo) - 1);
+        const uint32_t base_h = ((p >> g_lo) << (g_lo + M)) | low;
+        uint32_t addr[R];
+        uint64_t v[R];
+#pragma unroll
+        for (int x = 0; x < R; ++x) {
+            const uint32_t h = base_h | ((uint32_t)x << g_lo);
+            addr[x] = pad(strided ? (h << t) | l : (l << r) | h);
+            v[x] = s[addr[x]];
+        }
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            const int lv = INV ? q : M - 1 - q;  // decimation in frequency walks the big spans first, in time the small ones
+            const uint32_t lh = g_lo + lv;
+#pragma unroll
+            for (int x = 0; x < R; ++x) {
+                if (x & (1 << lv)) continue;
+                const uint32_t j = low | ((uint32_t)(x & ((1 << lv) - 1)) << g_lo);
+                const uint64_t w = W[j << (9 - lh)];  // omega_{2^(lh+1)}^(+-j)
+                const uint64_t a = v[x], b = v[x | (1 << lv)];
+                if (!INV) {
+                    v[x] = gl::add(a, b);
+                    v[x | (1 << lv)] = gl::mul(gl::sub(a, b), w);
+                } else {
+                    const uint64_t bw = gl::mul(b, w);
+                    v[x] = gl::add(a, bw);
+                    v[x | (1 << lv)] = gl::sub(a, bw);
+                }
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < R; ++x) s[addr[x]] = v[x];
+    }
+}
+
+template <bool INV>
+__device__ __forceinline__ void run_groups(uint64_t* s, const uint64_t* W, uint32_t r, uint32_t t, bool strided, uint32_t n_elems) {
+    const uint32_t n_groups = (r + 3) / 4, base = r / n_groups, extra = r % n_groups;  // 10 -> 4,3,3 ; 9 -> 3,3,3 ; 8 -> 4,4
+    uint32_t done = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t m = base + (g < extra ? 1 : 0);
+        const uint32_t g_lo = INV ? done : r - done - m;
+        switch (m) {
+        case 1: radix_group<1, INV>(s, W, g_lo, r, t, strided, n_elems); break;
+        case 2: radix_group<2, INV>(s, W, g_lo, r, t, strided, n_elems); break;
+        case 3: radix_group<3, INV>(s, W, g_lo, r, t, strided, n_elems); break;
+        default: radix_group<4, INV>(s, W, g_lo, r, t, strided, n_elems); break;
+        }
+        done += m;
+        __syncthreads();
+    }
+}
 
 __global__ __launch_bounds__(TPB) void k_ntt_pass(PassDev d) {
-    extern __shared__ uint64_t s[];
+    extern __shared__ uint64_t lds[];
+    uint64_t* W = lds;           // 512 twiddles of the in-block stages
+    uint64_t* s = lds + 512;     // the block's elements, padded
     const uint32_t r = d.r, t = d.t, lo = d.seg - d.r;
     const uint32_t n_elems = 1u << (r + t);
     const bool strided = lo > 0;  // lo > 0: element e = (h << t) | l ; lo == 0: e = (l << r) | h, one contiguous range
@@ -52,7 +123,6 @@ __global__ __launch_bounds__(TPB) void k_ntt_pass(PassDev d) {
     const uint32_t poly = blockIdx.x / tiles_per_poly, tile = blockIdx.x % tiles_per_poly;
     const uint64_t* __restrict__ src = d.src + (size_t)poly * d.src_stride;
     uint64_t* __restrict__ dst = d.dst + (size_t)poly * d.dst_stride;
-    // global index of block element e
     uint32_t seg_base, low_base;
     if (strided) {
         const uint32_t tiles_per_seg = 1u << (lo - t);
@@ -62,70 +132,42 @@ __global__ __launch_bounds__(TPB) void k_ntt_pass(PassDev d) {
         seg_base = tile << (r + t);
         low_base = 0;
     }
-    auto gidx = [&](uint32_t e) -> uint32_t {
+    auto gidx = [&](uint32_t e) -> uint32_t {  // global index of block element e
         return strided ? seg_base + ((e >> t) << lo) + low_base + (e & ((1u << t) - 1)) : seg_base + e;
     };
     auto inter_twiddle = [&](uint32_t e) -> uint64_t {  // omega_{2^seg}^(+-(low index) * k), k = bitrev_r(h)
         const uint32_t h = e >> t, l = e & ((1u << t) - 1);
-        const uint64_t ex = (uint64_t)(low_base + l) * brev(h, r);  // < 2^seg
+        const uint32_t ex = (low_base + l) * brev(h, r);  // < 2^seg <= 2^30
         return gl::mul(d.tw_lo[ex & 1023], d.tw_hi[ex >> 10]);
     };
-    auto coset = [&](uint32_t i) -> uint64_t { return gl::mul(d.c_lo[i & 1023], d.c_hi[i >> 10]); };
+    auto coset = [&](uint32_t pos) -> uint64_t {
+        const uint32_t i = d.coset_brev ? brev(pos, d.log_n) : pos;
+        return gl::mul(d.c_lo[i & 1023], d.c_hi[i >> 10]);
+    };
 
-    // ---- load ----
+    for (uint32_t e = threadIdx.x; e < 512; e += TPB) W[e] = d.root1024[e];
     for (uint32_t e = threadIdx.x; e < n_elems; e += TPB) {
         const uint32_t i = gidx(e);
         uint64_t v = src[i];
-        if (!d.inverse) {
-            if (d.c_lo) v = gl::mul(v, coset(i));               // first forward pass: a[i] * g^i
-        } else if (strided) {
-            v = gl::mul(v, inter_twiddle(e));                   // undo the inter-step twiddle before the DIT stages
-        }
-        s[e] = v;
+        if (d.c_lo && !d.coset_store) v = gl::mul(v, coset(i));  // forward direction: a[i] * g^i on the coefficient side
+        if (d.dit && strided) v = gl::mul(v, inter_twiddle(e));  // the inter-step twiddle precedes decimation-in-time stages
+        s[pad(e)] = v;
     }
     __syncthreads();
-    // ---- r radix-2 stages over h ----
-    const uint32_t sh = strided ? t : 0;          // log2 stride of h in LDS
-    const uint32_t n_bf = n_elems >> 1;
-    for (uint32_t st = 0; st < r; ++st) {
-        const uint32_t lh = d.inverse ? st : r - 1 - st;  // log2(half): DIF walks big -> small, DIT small -> big
-        for (uint32_t b = threadIdx.x; b < n_bf; b += TPB) {
-            uint32_t p, l;
-            if (strided) { l = b & ((1u << t) - 1); p = b >> t; }
-            else { p = b & ((1u << (r - 1)) - 1); l = b >> (r - 1); }
-            const uint32_t j = p & ((1u << lh) - 1);
-            const uint32_t h0 = ((p >> lh) << (lh + 1)) | j;
-            const uint32_t a0 = strided ? (h0 << sh) | l : (l << r) | h0;
-            const uint32_t a1 = a0 + ((1u << lh) << sh);
-            const uint64_t w = d.root1024[j << (9 - lh)];  // omega_{2^(lh+1)}^(+-j)
-            const uint64_t u = s[a0], v = s[a1];
-            if (!d.inverse) {
-                s[a0] = gl::add(u, v);
-                s[a1] = j ? gl::mul(gl::sub(u, v), w) : gl::sub(u, v);
-            } else {
-                const uint64_t vw = j ? gl::mul(v, w) : v;
-                s[a0] = gl::add(u, vw);
-                s[a1] = gl::sub(u, vw);
-            }
-        }
-        __syncthreads();
-    }
-    // ---- store ----
+    if (d.dit) run_groups<true>(s, W, r, t, strided, n_elems);
+    else run_groups<false>(s, W, r, t, strided, n_elems);
     for (uint32_t e = threadIdx.x; e < n_elems; e += TPB) {
         const uint32_t i = gidx(e);
-        uint64_t v = s[e];
-        if (!d.inverse) {
-            if (strided) v = gl::mul(v, inter_twiddle(e));
-        } else if (d.c_lo) {
-            v = gl::mul(v, coset(i));                           // last inverse pass: 1/N * g^-i
-        }
+        uint64_t v = s[pad(e)];
+        if (!d.dit && strided) v = gl::mul(v, inter_twiddle(e));
+        if (d.c_lo && d.coset_store) v = gl::mul(v, coset(i));   // inverse direction: 1/N * g^-i on the coefficient side
         dst[i] = v;
     }
 }
 
 // c_lo[j] = scale * base^j (j < 1024), c_hi[j] = base^(1024 j) (j < n_hi)
-__global__ __launch_bounds__(TPB) void k_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t* c_hi, uint32_t n_hi) {
-    const uint32_t g = blockIdx.x * TPB + threadIdx.x;
+__global__ __launch_bounds__(256) void k_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t* c_hi, uint32_t n_hi) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g >= 1024 + n_hi) return;
     uint64_t b = base;
     uint32_t ex = g;

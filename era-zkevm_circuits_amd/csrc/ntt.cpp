@@ -85,23 +85,27 @@ std::vector<Pass> plan(uint32_t log_n) {
 
 void dev_check(int rc) { if (rc) throw ZkError(ZK_ERR_HIP, zkdev::last_hip_error()); }
 
-// one transform over n_polys polynomials; src == dst allowed (in place)
-void run(const uint64_t* src, uint64_t src_stride, uint64_t* dst, uint64_t dst_stride, uint32_t log_n, uint32_t n_polys, int inverse,
-         const uint64_t* c_lo, const uint64_t* c_hi, hipStream_t st) {
+// one transform over n_polys polynomials; src == dst allowed (in place).
+//   inverse        : root sign and where the coset / scale factors act (coefficient side = input when forward, output when inverse)
+//   natural_values : values in natural order and coefficients bit-reversed (mirrored butterfly structure)
+void run(const uint64_t* src, uint64_t src_stride, uint64_t* dst, uint64_t dst_stride, uint32_t log_n, uint32_t n_polys, bool inverse,
+         bool natural_values, const uint64_t* c_lo, const uint64_t* c_hi, hipStream_t st) {
     NttContext& c = ctx();
     std::vector<Pass> ps = plan(log_n);
     const size_t n = ps.size();
+    const bool dit = inverse != natural_values;  // forward/bitrev values and inverse/natural values are decimation in frequency
     for (size_t q = 0; q < n; ++q) {
-        const Pass& p = inverse ? ps[n - 1 - q] : ps[q];
+        const Pass& p = dit ? ps[n - 1 - q] : ps[q];
         zkdev::NttPassArgs a;
         a.src = q == 0 ? src : dst; a.src_stride = q == 0 ? src_stride : dst_stride;
         a.dst = dst; a.dst_stride = dst_stride;
-        a.log_n = log_n; a.seg = p.seg; a.r = p.r; a.t = p.t; a.inverse = inverse;
+        a.log_n = log_n; a.seg = p.seg; a.r = p.r; a.t = p.t;
+        a.dit = dit; a.coset_store = inverse; a.coset_brev = natural_values;
         a.root1024 = c.roots(inverse);
         Tables t = c.twiddles(p.seg, inverse);
         a.tw_lo = t.lo; a.tw_hi = t.hi;
-        const bool natural_side = p.seg == log_n;  // the pass that touches natural indices: first forward / last inverse
-        a.c_lo = natural_side ? c_lo : nullptr; a.c_hi = natural_side ? c_hi : nullptr;
+        const bool coefficient_side = inverse ? q == n - 1 : q == 0;
+        a.c_lo = coefficient_side ? c_lo : nullptr; a.c_hi = coefficient_side ? c_hi : nullptr;
         dev_check(zkdev::launch_ntt_pass(a, n_polys, st));
     }
 }
@@ -125,43 +129,46 @@ uint64_t two_adic_root(uint32_t log_n) {
     return hpow(7, (P - 1) >> log_n);
 }
 
-void ntt(uint64_t* d_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, bool inverse, uint64_t coset_shift, void* stream) {
+void ntt(uint64_t* d_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, uint32_t mode, uint64_t coset_shift, void* stream) {
     if (log_n > 30) throw ZkError(ZK_ERR_INVALID, "ntt: log_n > 30");
+    if (mode > 3) throw ZkError(ZK_ERR_INVALID, "ntt: unknown mode bits");
     if (coset_shift == 0 || coset_shift >= P) throw ZkError(ZK_ERR_INVALID, "ntt: coset shift must be a nonzero canonical field element");
     if (stride < ((uint64_t)1 << log_n) && n_polys > 1) throw ZkError(ZK_ERR_INVALID, "ntt: stride smaller than the polynomial");
     if (log_n == 0 || n_polys == 0) return;  // a constant is its own transform (g^0 = 1, 1/N = 1)
+    const bool inverse = mode & ZK_NTT_INVERSE, natural = mode & ZK_NTT_NATURAL_VALUES;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> g(ctx().mu);
-    const uint64_t n_inv = hinv((uint64_t)1 << log_n);
     if (!inverse) {
-        if (coset_shift == 1) run(d_data, stride, d_data, stride, log_n, n_polys, 0, nullptr, nullptr, st);
+        if (coset_shift == 1) run(d_data, stride, d_data, stride, log_n, n_polys, false, natural, nullptr, nullptr, st);
         else {
             CosetTables ct(log_n, coset_shift, 1, st);
-            run(d_data, stride, d_data, stride, log_n, n_polys, 0, ct.lo, ct.hi, st);
+            run(d_data, stride, d_data, stride, log_n, n_polys, false, natural, ct.lo, ct.hi, st);
         }
     } else {
-        CosetTables ct(log_n, hinv(coset_shift), n_inv, st);
-        run(d_data, stride, d_data, stride, log_n, n_polys, 1, ct.lo, ct.hi, st);
+        CosetTables ct(log_n, hinv(coset_shift), hinv((uint64_t)1 << log_n), st);
+        run(d_data, stride, d_data, stride, log_n, n_polys, true, natural, ct.lo, ct.hi, st);
     }
 }
 
 void lde(const uint64_t* d_coeffs, uint64_t src_stride, uint64_t* d_out, uint32_t log_n, uint32_t log_blowup, uint32_t n_polys,
-         uint64_t coset_shift, void* stream) {
+         uint32_t mode, uint64_t coset_shift, void* stream) {
     if (log_n == 0 || log_n > 30 || log_blowup > 8 || log_n + log_blowup > 32) throw ZkError(ZK_ERR_INVALID, "lde: sizes out of range");
+    if (mode & ~(uint32_t)ZK_NTT_NATURAL_VALUES) throw ZkError(ZK_ERR_INVALID, "lde: only ZK_NTT_NATURAL_VALUES may be set");
     if (coset_shift == 0 || coset_shift >= P) throw ZkError(ZK_ERR_INVALID, "lde: coset shift must be a nonzero canonical field element");
     if (n_polys == 0) return;
+    const bool natural = mode & ZK_NTT_NATURAL_VALUES;
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> g(ctx().mu);
     const uint64_t n = (uint64_t)1 << log_n, blow = (uint64_t)1 << log_blowup;
     const uint64_t eta = two_adic_root(log_n + log_blowup);
     for (uint64_t j = 0; j < blow; ++j) {
-        // block j of every polynomial = its values on the coset g * eta^bitrev(j) * <omega_N>, bit-reversed inside the block:
-        // the blocks together are the size-(N * blow) transform of the zero-padded coefficients in bit-reversed order
+        // block j of every polynomial = its values on the coset g * eta^bitrev(j) * <omega_N>: with bit-reversed values the
+        // blocks together are the size-(N * blow) transform of the zero-padded coefficients in bit-reversed order
         uint64_t c = 0;
         for (uint32_t b = 0; b < log_blowup; ++b) c |= ((j >> b) & 1) << (log_blowup - 1 - b);
         const uint64_t shift = hmul(coset_shift, hpow(eta, c));
         CosetTables ct(log_n, shift, 1, st);
-        run(d_coeffs, src_stride, d_out + j * n, n * blow, log_n, n_polys, 0, ct.lo, ct.hi, st);
+        run(d_coeffs, src_stride, d_out + j * n, n * blow, log_n, n_polys, false, natural, ct.lo, ct.hi, st);
     }
 }
 

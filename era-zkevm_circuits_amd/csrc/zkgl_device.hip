@@ -155,17 +155,23 @@ int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream) {
     if (n_polys == 0) return 0;
     zkn::PassDev d;
     d.src = a.src; d.dst = a.dst; d.src_stride = a.src_stride; d.dst_stride = a.dst_stride;
-    d.log_n = a.log_n; d.seg = a.seg; d.r = a.r; d.t = a.t; d.inverse = a.inverse;
+    d.log_n = a.log_n; d.seg = a.seg; d.r = a.r; d.t = a.t; d.dit = a.dit; d.coset_store = a.coset_store; d.coset_brev = a.coset_brev;
     d.root1024 = a.root1024; d.tw_lo = a.tw_lo; d.tw_hi = a.tw_hi; d.c_lo = a.c_lo; d.c_hi = a.c_hi;
     const uint64_t blocks = (uint64_t)n_polys << (a.log_n - a.r - a.t);
     if (blocks > 0x7fffffffull) { g_hip_err = "k_ntt_pass: grid too large"; return -2; }
-    const size_t lds = sizeof(uint64_t) << (a.r + a.t);
+    const size_t lds = sizeof(uint64_t) * (512 + zkn::padded_elems(1u << (a.r + a.t)));
+    static bool lds_raised = false;  // > 64 KB of dynamic LDS needs the opt-in (gfx950: 160 KB per CU)
+    if (!lds_raised) {
+        if (int rc = chk(hipFuncSetAttribute((const void*)zkn::k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), "k_ntt_pass LDS"))
+            return rc;
+        lds_raised = true;
+    }
     zkn::k_ntt_pass<<<(unsigned)blocks, zkn::TPB, lds, (hipStream_t)stream>>>(d);
     return LAUNCH_CHECK("k_ntt_pass");
 }
 
 int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t* c_hi, uint32_t n_hi, void* stream) {
-    zkn::k_coset_tables<<<grid_for(1024 + n_hi, zkn::TPB), zkn::TPB, 0, (hipStream_t)stream>>>(base, scale, c_lo, c_hi, n_hi);
+    zkn::k_coset_tables<<<grid_for(1024 + n_hi, 256), 256, 0, (hipStream_t)stream>>>(base, scale, c_lo, c_hi, n_hi);
     return LAUNCH_CHECK("k_coset_tables");
 }
 

@@ -231,18 +231,24 @@ def two_adic_root(log_n: int) -> int:
     return out.value
 
 
-def ntt(data, log_n: int, n_polys: int = 1, stride=None, inverse: bool = False, coset_shift: int = 1, stream=None):
-    """in place: forward = natural coefficients -> bit-reversed values on coset_shift * <omega_N>, inverse = the inverse map"""
+NTT_INVERSE, NTT_NATURAL_VALUES = 1, 2
+
+
+def ntt(data, log_n: int, n_polys: int = 1, stride=None, inverse: bool = False, coset_shift: int = 1, stream=None, natural_values: bool = False):
+    """in place.  forward: coefficients -> values A[k] = sum_i a[i] (coset_shift * omega^k)^i, inverse: the inverse map.
+    natural_values=False: coefficients natural, values bit-reversed; True: values natural (trace rows), coefficients bit-reversed."""
     stride = (1 << log_n) if stride is None else stride
-    _check(lib().zk_ntt(_ptr(data), C.c_uint32(log_n), C.c_uint32(n_polys), C.c_uint64(stride), C.c_int(int(inverse)),
+    mode = (NTT_INVERSE if inverse else 0) | (NTT_NATURAL_VALUES if natural_values else 0)
+    _check(lib().zk_ntt(_ptr(data), C.c_uint32(log_n), C.c_uint32(n_polys), C.c_uint64(stride), C.c_uint32(mode),
                         C.c_uint64(coset_shift), _ptr(stream)))
 
 
-def lde(coeffs, out, log_n: int, log_blowup: int, n_polys: int = 1, src_stride=None, coset_shift: int = 1, stream=None):
+def lde(coeffs, out, log_n: int, log_blowup: int, n_polys: int = 1, src_stride=None, coset_shift: int = 1, stream=None,
+        natural_values: bool = False):
     """out[q][j][:] = forward transform of polynomial q on the coset coset_shift * eta^bitrev(j) * <omega_N>"""
     src_stride = (1 << log_n) if src_stride is None else src_stride
     _check(lib().zk_lde(_ptr(coeffs), C.c_uint64(src_stride), _ptr(out), C.c_uint32(log_n), C.c_uint32(log_blowup), C.c_uint32(n_polys),
-                        C.c_uint64(coset_shift), _ptr(stream)))
+                        C.c_uint32(NTT_NATURAL_VALUES if natural_values else 0), C.c_uint64(coset_shift), _ptr(stream)))
 
 
 @dataclass

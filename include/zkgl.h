@@ -206,18 +206,23 @@ typedef struct zk_stats {
 } zk_stats;
 /* K6 — batched Goldilocks NTT and coset low-degree extension over device-resident polynomials (prover stage after
  * satisfiability, SURVEY 8f-3 "LDE/NTT over Goldilocks"; boojum's transforms are [EXT], entry implied by `into_assembly`,
- * /root/reference/src/ram_permutation/mod.rs:554).  Defined here: omega_N = 7^((p-1)/N), N = 2^log_n.
- *   zk_ntt forward (inverse = 0): natural-order coefficients a[i] -> A[bitrev(k)] = sum_i a[i] (g omega_N^k)^i, g = coset_shift
- *   zk_ntt inverse (inverse = 1): the inverse map (bit-reversed values on g<omega_N> -> natural-order coefficients)
- * in place over n_polys polynomials, polynomial q at dev_data + q * stride (stride >= N).  coset_shift must be a nonzero
- * canonical field element (1 = the subgroup itself).  log_n <= 30.
- *   zk_lde: out[q][j][.] (q < n_polys, j < 2^log_blowup, stride N * 2^log_blowup per polynomial) = forward transform of
- * polynomial q on the coset g * eta^bitrev(j) * <omega_N>, eta = omega_{N * 2^log_blowup}; the blocks of one polynomial
- * read together are the size-(N * 2^log_blowup) forward transform of its zero-padded coefficients.  Source untouched. */
+ * /root/reference/src/ram_permutation/mod.rs:554).  Defined here: omega_N = 7^((p-1)/N), N = 2^log_n, g = coset_shift,
+ *   A[k] = sum_i a[i] (g omega_N^k)^i.
+ * zk_ntt works in place over n_polys polynomials, polynomial q at dev_data + q * stride (stride >= N); log_n <= 30; g must
+ * be a nonzero canonical field element (1 = the subgroup itself).  mode bits:
+ *   0                          forward: natural-order coefficients -> values, A[k] stored at bitrev(k)
+ *   ZK_NTT_INVERSE             the inverse map of the forward mode with the same other bits
+ *   ZK_NTT_NATURAL_VALUES      values in natural order (A[k] at k: trace rows), coefficients in bit-reversed order (a[i] at bitrev(i))
+ * zk_lde: out[q][j][.] (q < n_polys, j < 2^log_blowup, stride N * 2^log_blowup per polynomial) = forward transform of
+ * polynomial q on the coset g * eta^bitrev(j) * <omega_N>, eta = omega_{N * 2^log_blowup}; with mode 0 the blocks of one
+ * polynomial read together are the size-(N * 2^log_blowup) forward transform of its zero-padded coefficients; mode may be
+ * 0 or ZK_NTT_NATURAL_VALUES (bit-reversed coefficients in, natural-order values per coset out).  Source untouched. */
+#define ZK_NTT_INVERSE 1u
+#define ZK_NTT_NATURAL_VALUES 2u
 int zk_two_adic_root(uint32_t log_n, uint64_t *out);
-int zk_ntt(uint64_t *dev_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, int inverse, uint64_t coset_shift, void *stream);
+int zk_ntt(uint64_t *dev_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, uint32_t mode, uint64_t coset_shift, void *stream);
 int zk_lde(const uint64_t *dev_coeffs, uint64_t src_stride, uint64_t *dev_out, uint32_t log_n, uint32_t log_blowup, uint32_t n_polys,
-           uint64_t coset_shift, void *stream);
+           uint32_t mode, uint64_t coset_shift, void *stream);
 /* K5 — log-derivative lookup-argument accumulators over the resolved trace (prover stage after satisfiability, SURVEY 8f-3;
  * boojum's polynomial form is [EXT], the sums are defined in csrc/kernels_lookup_arg.hpp).  beta, gamma: canonical GF(p^2)
  * elements (a + bX, X^2 = 7).  out (4 words per instance, may be NULL): witness-side sum A (a, b) then table-side sum B (a, b);

@@ -83,13 +83,13 @@ def zk():
     return zkgl
 
 
-def dev_ntt(zk, a, log_n, inverse=False, shift=1, stride=None):
+def dev_ntt(zk, a, log_n, inverse=False, shift=1, stride=None, natural_values=False):
     stride = stride or (1 << log_n)
     flat = np.zeros(a.shape[0] * stride, dtype=np.uint64)
     for q in range(a.shape[0]):
         flat[q * stride: q * stride + (1 << log_n)] = a[q]
     d = zk.DeviceBuffer.from_numpy(flat)
-    zk.ntt(d, log_n, a.shape[0], stride, inverse, shift)
+    zk.ntt(d, log_n, a.shape[0], stride, inverse, shift, None, natural_values)
     zk.sync()
     out = d.to_numpy()
     return np.stack([out[q * stride: q * stride + (1 << log_n)] for q in range(a.shape[0])]), out
@@ -108,6 +108,34 @@ def test_gpu_transform_equals_oracle(zk, log_n):
         assert np.array_equal(b, a), (log_n, shift)
     back, _ = dev_ntt(zk, a, log_n, True, 0x123456789ABCDEF)
     assert np.array_equal(back, zko.ntt(a, True, 0x123456789ABCDEF))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [1, 4, 9, 10, 11, 13, 15])
+def test_gpu_natural_value_order(zk, log_n):
+    """ZK_NTT_NATURAL_VALUES: values at their natural index (trace rows), coefficients at bitrev(i) — the oracle's transform
+    with the bit-reversal permutation moved to the other side"""
+    rng = np.random.default_rng(400 + log_n)
+    n = 1 << log_n
+    perm = np.array([bitrev(i, log_n) for i in range(n)])
+    rows = rand_poly(rng, 2, n)                                     # natural-order values on SHIFT * <omega>
+    coeffs_brev, _ = dev_ntt(zk, rows, log_n, True, SHIFT, None, True)
+    want = zko.ntt(rows[:, perm], True, SHIFT)                      # oracle: bit-reversed values -> natural coefficients
+    assert np.array_equal(coeffs_brev, want[:, perm])
+    back, _ = dev_ntt(zk, coeffs_brev, log_n, False, SHIFT, None, True)
+    assert np.array_equal(back, rows)
+    # the two orders chain: bit-reversed coefficients -> natural coefficients is just the permutation
+    f, _ = dev_ntt(zk, np.ascontiguousarray(coeffs_brev[:, perm]), log_n, False, SHIFT)
+    assert np.array_equal(f[:, perm], rows)
+    # coset LDE from bit-reversed coefficients: natural-order values of every coset
+    src = zk.DeviceBuffer.from_numpy(coeffs_brev.reshape(-1))
+    out = zk.DeviceBuffer(2 * (n << 2))
+    zk.lde(src, out, log_n, 2, 2, None, 3, None, True)
+    zk.sync()
+    got = out.to_numpy().reshape(2, 4, n)
+    for q in range(2):
+        ref = zko.lde(want[q], 2, 3).reshape(4, n)
+        assert np.array_equal(got[q], ref[:, perm])
 
 
 @pytest.mark.gpu
@@ -172,3 +200,5 @@ def test_gpu_argument_errors(zk):
         zk.ntt(d, 3, 2, 4, False, 1)          # stride smaller than the polynomial
     with pytest.raises(zk.ZkError):
         zk.ntt(d, 31, 1, None, False, 1)
+    with pytest.raises(zk.ZkError):
+        zk._check(zk.lib().zk_ntt(zk._ptr(d), 3, 1, 8, 4, 1, None))   # unknown mode bit
