@@ -1215,6 +1215,20 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
     return o;
 }
 
+void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream) const {
+    if (!finalized_ || batch_ == 0) throw ZkError(ZK_ERR_INVALID, "trace_columns before set_batch");
+    if (instance >= batch_) throw ZkError(ZK_ERR_INVALID, "trace_columns: instance out of range");
+    const uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
+    if (log_n > 32 || ((uint64_t)1 << log_n) < rows) throw ZkError(ZK_ERR_INVALID, "trace_columns: 2^log_n smaller than the trace");
+    if (stride < ((uint64_t)1 << log_n)) throw ZkError(ZK_ERR_INVALID, "trace_columns: stride smaller than the column");
+    zkdev::ColumnsArgs a;
+    a.loop_cells = loop_.d_cells; a.loop_n_cells = loop_.n_cells; a.outer_cells = outer_.d_cells; a.outer_n_cells = outer_.n_cells;
+    a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
+    a.loop_slots = limit_ ? loop_.n_slots : 0; a.outer_slots = outer_.n_slots; a.limit = limit_; a.instance = instance;
+    a.out = d_out; a.stride = stride; a.n_rows_padded = (uint64_t)1 << log_n;
+    dev_check(zkdev::launch_trace_columns(a, stream));
+}
+
 void CS::trace_ptr(bool loop_scope, uint64_t** cells, uint64_t* n_cells, uint64_t* stride) const {
     const Scope& s = loop_scope ? loop_ : outer_;
     *cells = s.d_cells; *n_cells = s.n_cells; *stride = s.stride;

@@ -58,6 +58,11 @@ struct NttPassArgs {
     const uint64_t* root1024; const uint64_t* tw_lo; const uint64_t* tw_hi; const uint64_t* c_lo; const uint64_t* c_hi;
 };
 int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream);
+struct ColumnsArgs {  // mirrors zkn::ColumnsDev
+    const uint64_t* loop_cells; uint64_t loop_n_cells; const uint64_t* outer_cells; uint64_t outer_n_cells;
+    uint32_t n_cols, loop_slots, outer_slots, limit, instance; uint64_t* out; uint64_t stride; uint64_t n_rows_padded;
+};
+int launch_trace_columns(const ColumnsArgs& a, void* stream);
 int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t* c_hi, uint32_t n_hi, void* stream);
 // cone seeding: seed_prog in device memory (padded like every program), carries = {input word, out slot, first outer cell, has_first}
 int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_words, uint32_t n_slots, uint32_t n_input_words,

@@ -185,4 +185,43 @@ __global__ __launch_bounds__(256) void k_coset_tables(uint64_t base, uint64_t sc
     else c_hi[g - 1024] = acc;
 }
 
+// Trace of one instance as column polynomials: out[col * stride + row], rows = loop iterations in order (row = iteration *
+// loop_slots + slot) followed by the outer scope's slots, zero padded to n_rows_padded.  The wave-tiled cell storage keeps
+// 64 consecutive lanes of one cell together, the column layout wants consecutive rows of one lane together: a block
+// transposes 64 iterations x 32 slots of one column through LDS (512 B reads, 256 B writes).
+struct ColumnsDev {
+    const uint64_t* loop_cells; uint64_t loop_n_cells;
+    const uint64_t* outer_cells; uint64_t outer_n_cells;
+    uint32_t n_cols, loop_slots, outer_slots, limit, instance;
+    uint64_t* out; uint64_t stride; uint64_t n_rows_padded;
+};
+__device__ __forceinline__ size_t tiled(uint64_t n_cells, uint32_t cell, uint32_t lane) {
+    return ((size_t)(lane >> 6) * n_cells + cell) * 64 + (lane & 63);
+}
+__global__ __launch_bounds__(256) void k_trace_columns_loop(ColumnsDev d) {
+    __shared__ uint64_t tile[32][65];
+    const uint32_t col = blockIdx.x, k0 = blockIdx.y * 64, s0 = blockIdx.z * 32;
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (uint32_t sy = ty; sy < 32; sy += 4) {
+        const uint32_t slot = s0 + sy, k = k0 + tx;
+        if (slot < d.loop_slots && k < d.limit)
+            tile[sy][tx] = d.loop_cells[tiled(d.loop_n_cells, slot * d.n_cols + col, d.instance * d.limit + k)];
+    }
+    __syncthreads();
+    const uint32_t sx = threadIdx.x & 31, ky = threadIdx.x >> 5;
+    for (uint32_t kk = ky; kk < 64; kk += 8) {
+        const uint32_t slot = s0 + sx, k = k0 + kk;
+        if (slot < d.loop_slots && k < d.limit) d.out[(size_t)col * d.stride + (size_t)k * d.loop_slots + slot] = tile[sx][kk];
+    }
+}
+// the outer scope's rows and the zero padding behind them
+__global__ __launch_bounds__(256) void k_trace_columns_tail(ColumnsDev d) {
+    const uint32_t col = blockIdx.y;
+    const uint64_t first = (uint64_t)d.limit * d.loop_slots;
+    const uint64_t row = first + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= d.n_rows_padded) return;
+    const uint64_t s = row - first;
+    d.out[(size_t)col * d.stride + row] = s < d.outer_slots ? d.outer_cells[tiled(d.outer_n_cells, (uint32_t)s * d.n_cols + col, d.instance)] : 0;
+}
+
 }  // namespace zkn

@@ -170,6 +170,26 @@ int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream) {
     return LAUNCH_CHECK("k_ntt_pass");
 }
 
+int launch_trace_columns(const ColumnsArgs& a, void* stream) {
+    zkn::ColumnsDev d;
+    d.loop_cells = a.loop_cells; d.loop_n_cells = a.loop_n_cells; d.outer_cells = a.outer_cells; d.outer_n_cells = a.outer_n_cells;
+    d.n_cols = a.n_cols; d.loop_slots = a.loop_slots; d.outer_slots = a.outer_slots; d.limit = a.limit; d.instance = a.instance;
+    d.out = a.out; d.stride = a.stride; d.n_rows_padded = a.n_rows_padded;
+    if (a.limit && a.loop_slots) {
+        dim3 grid(a.n_cols, (a.limit + 63) / 64, (a.loop_slots + 31) / 32);
+        if (grid.y > 65535 || grid.z > 65535) { g_hip_err = "k_trace_columns_loop: grid too large"; return -2; }
+        zkn::k_trace_columns_loop<<<grid, 256, 0, (hipStream_t)stream>>>(d);
+        if (int rc = LAUNCH_CHECK("k_trace_columns_loop")) return rc;
+    }
+    const uint64_t tail = a.n_rows_padded - (uint64_t)a.limit * a.loop_slots;
+    if (tail) {
+        dim3 grid((unsigned)((tail + 255) / 256), a.n_cols);
+        zkn::k_trace_columns_tail<<<grid, 256, 0, (hipStream_t)stream>>>(d);
+        if (int rc = LAUNCH_CHECK("k_trace_columns_tail")) return rc;
+    }
+    return 0;
+}
+
 int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t* c_hi, uint32_t n_hi, void* stream) {
     zkn::k_coset_tables<<<grid_for(1024 + n_hi, 256), 256, 0, (hipStream_t)stream>>>(base, scale, c_lo, c_hi, n_hi);
     return LAUNCH_CHECK("k_coset_tables");

@@ -568,6 +568,11 @@ class ConstraintSystem:
         _check(lib().zk_cs_export(self._h, int(loop_scope), buf.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
         return buf
 
+    def trace_columns(self, instance: int, out, log_n: int, stride=None, stream=None):
+        """K6 input: out[col * stride + row] = the instance's trace columns (loop rows, then outer rows, zero padded to 2^log_n)"""
+        stride = (1 << log_n) if stride is None else stride
+        _check(lib().zk_cs_trace_columns(self._h, C.c_uint32(instance), _ptr(out), C.c_uint32(log_n), C.c_uint64(stride), _ptr(stream)))
+
     def trace(self, loop_scope: bool) -> np.ndarray:
         """Copy the scope's cells back as the logical array [n_cells, n_tiles*64] (cell-major, lane-minor).
         Device storage is wave-tiled [tile][cell][64]; cell = slot * n_columns + column."""

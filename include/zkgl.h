@@ -237,6 +237,11 @@ int zk_cs_last_ms(zk_cs *cs, int which, float *ms);
 /* serialised scope (program + descriptors) for the CPU oracle / offline tooling.
  * Call with buf = NULL to get the size in words. */
 int zk_cs_export(zk_cs *cs, int loop_scope, uint32_t *buf, size_t max_words, size_t *n_words);
+/* The resolved trace of one instance as column polynomials for K6: dev_out[col * stride + row] for every copy and lookup
+ * column, row = iteration * loop_slots + slot for the loop scope's rows, then the outer scope's slots, zero padded to
+ * 2^log_n (>= the instance's row count, zk_stats.rows_per_instance); stride >= 2^log_n.  The layout `into_assembly`
+ * hands to the prover (/root/reference/src/ram_permutation/mod.rs:554) is boojum's ([EXT]); this one is the engine's. */
+int zk_cs_trace_columns(zk_cs *cs, uint32_t instance, uint64_t *dev_out, uint32_t log_n, uint64_t stride, void *stream);
 int zk_cs_trace_ptr(zk_cs *cs, int loop_scope, uint64_t **dev_cells, uint64_t *n_cells, uint64_t *stride);
 
 /* ---------------- circuits (host side mirrors of the reference entry points) ---------------- */

@@ -202,3 +202,56 @@ def test_gpu_argument_errors(zk):
         zk.ntt(d, 31, 1, None, False, 1)
     with pytest.raises(zk.ZkError):
         zk._check(zk.lib().zk_ntt(zk._ptr(d), 3, 1, 8, 4, 1, None))   # unknown mode bit
+
+
+@pytest.mark.gpu
+def test_gpu_trace_columns_feed_the_transform(zk):
+    """zk_cs_trace_columns lays one instance's resolved trace out as column polynomials (loop rows, outer rows, zero padding);
+    interpolation in natural-value order and re-evaluation give the rows back, and every LDE coset of a column is consistent
+    with the oracle's transform of the same coefficients."""
+    from helpers import ram_cs, random_instances
+    from oracle import ram_native as rn
+    from test_gpu_cs import gpu_run
+    limit, batch, inst = 70, 3, 1                 # 70 iterations: the instance's lanes straddle wave tiles
+    cs = ram_cs(limit)
+    outer, loop = rn.pack_streams(random_instances(21, batch, 40, limit), limit)
+    keep = gpu_run(zk, cs, outer, loop, batch)
+    assert cs.check_if_satisfied()[0]
+    st = cs.stats()
+    n_cols = st["copy_columns"] + st["lookup_columns"]
+    S, So, rows = st["loop_slots"], st["outer_slots"], st["rows_per_instance"]
+    assert rows == limit * S + So
+    log_n = int(rows - 1).bit_length()
+    n, stride = 1 << log_n, (1 << log_n) + 24
+    out = zk.DeviceBuffer(n_cols * stride)
+    out.zero()
+    cs.trace_columns(inst, out, log_n, stride)
+    zk.sync()
+    got = out.to_numpy().reshape(n_cols, stride)
+    tl, to = cs.trace(True), cs.trace(False)
+    want = np.zeros((n_cols, stride), dtype=np.uint64)
+    for c in range(n_cols):
+        loop_part = tl[c::n_cols][:S, inst * limit:(inst + 1) * limit]      # [slot, iteration]
+        want[c, :limit * S] = loop_part.T.reshape(-1)
+        want[c, limit * S: rows] = to[c::n_cols][:So, inst]
+    assert np.array_equal(got, want)
+    with pytest.raises(zk.ZkError):
+        cs.trace_columns(inst, out, log_n - 1, stride)
+    with pytest.raises(zk.ZkError):
+        cs.trace_columns(batch, out, log_n, stride)
+    # rows -> bit-reversed coefficients -> rows
+    zk.ntt(out, log_n, n_cols, stride, True, 1, None, True)
+    zk.sync()
+    coeffs_brev = out.to_numpy().reshape(n_cols, stride)[:, :n].copy()
+    perm = np.array([bitrev(i, log_n) for i in range(n)])
+    c0 = 5
+    assert np.array_equal(coeffs_brev[c0][perm], zko.ntt(want[c0, :n][perm], True, 1))
+    lde_out = zk.DeviceBuffer(n_cols * (n << 1))
+    zk.lde(out, lde_out, log_n, 1, n_cols, stride, SHIFT, None, True)
+    zk.ntt(out, log_n, n_cols, stride, False, 1, None, True)
+    zk.sync()
+    assert np.array_equal(out.to_numpy().reshape(n_cols, stride), want)
+    ext = lde_out.to_numpy().reshape(n_cols, 2, n)
+    ref = zko.lde(coeffs_brev[c0][perm], 1, SHIFT).reshape(2, n)
+    assert np.array_equal(ext[c0], ref[:, perm])
+    del keep
