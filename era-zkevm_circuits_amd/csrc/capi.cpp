@@ -369,6 +369,23 @@ int zk_cs_lookup_argument(zk_cs* cs, const uint64_t beta[2], const uint64_t gamm
         if (out) for (size_t i = 0; i < v.size() && i < 4 * (size_t)max_instances; ++i) out[i] = v[i];
     });
 }
+int zk_cs_copy_permutation(zk_cs* cs, const uint64_t beta[2], const uint64_t gamma[2], void* stream, uint64_t* dev_z, uint64_t* out,
+                           uint32_t max_instances, uint32_t* n_mismatch) {
+    NEED(cs); NEED(beta); NEED(gamma); NEED(n_mismatch); NEED_INIT();
+    return guard([&] {
+        std::vector<uint64_t> v;
+        *n_mismatch = cs->cs->copy_permutation(beta, gamma, stream, dev_z, v);
+        if (out) for (size_t i = 0; i < v.size() && i < 4 * (size_t)max_instances; ++i) out[i] = v[i];
+    });
+}
+int zk_cs_sigma(zk_cs* cs, int loop_scope, uint32_t iteration, uint64_t* buf, size_t max_words, size_t* n_words) {
+    NEED(cs); NEED(n_words);
+    return guard([&] {
+        std::vector<uint64_t> v = cs->cs->sigma_labels(loop_scope != 0, iteration);
+        *n_words = v.size();
+        if (buf) for (size_t i = 0; i < v.size() && i < max_words; ++i) buf[i] = v[i];
+    });
+}
 int zk_two_adic_root(uint32_t log_n, uint64_t* out) {
     NEED(out);
     return guard([&] { *out = zkgl::two_adic_root(log_n); });

@@ -74,6 +74,11 @@ CS::~CS() {
     if (d_seed_carries_) hipFree(d_seed_carries_);
     for (auto p : d_streams_) if (p) hipFree(p);
     if (d_carries_) hipFree(d_carries_);
+    for (int i = 0; i < 2; ++i) {
+        if (d_sig_rel_[i]) hipFree(d_sig_rel_[i]);
+        if (d_ep_index_[i]) hipFree(d_ep_index_[i]);
+        if (d_ovr_[i]) hipFree(d_ovr_[i]);
+    }
     if (d_fail_) hipFree(d_fail_);
     if (aux_stream_) hipStreamDestroy((hipStream_t)aux_stream_);
     for (auto& e : ev2_)

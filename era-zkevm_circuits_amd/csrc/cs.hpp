@@ -155,6 +155,10 @@ class CS {
     // K5: log-derivative lookup-argument accumulators over the resolved trace; out[instance] = {A.a, A.b, B.a, B.b};
     // returns the number of instances with A != B
     uint32_t lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], void* stream, std::vector<uint64_t>& out);
+    // K7 (cs_perm.cpp): copy-permutation grand product over the resolved trace.  out[instance] = {num.a, num.b, den.a, den.b} of
+    // z[rows] = num / den; returns the number of instances with num != den.  d_z (optional, device): [batch][rows + 1][2]
+    uint32_t copy_permutation(const uint64_t beta[2], const uint64_t gamma[2], void* stream, uint64_t* d_z, std::vector<uint64_t>& out);
+    std::vector<uint64_t> sigma_labels(bool loop_scope, uint32_t iteration);  // sigma(label) of every trace cell of the scope / iteration
     void stats(zk_stats* out) const;
     float last_ms(int which) const;
     std::vector<uint32_t> export_scope(bool loop_scope) const;
@@ -223,6 +227,15 @@ class CS {
     uint32_t seed_slots_ = 0, seed_ops_ = 0;
     uint32_t* d_seed_prog_ = nullptr;
     void* d_seed_carries_ = nullptr;
+    // K7: sigma = per-cell image inside the scope / iteration + absolute labels of the link endpoints [endpoint][iteration]
+    void build_sigma();
+    bool sigma_built_ = false;
+    std::vector<uint32_t> sig_rel_[2], ep_index_[2];
+    std::vector<uint64_t> ovr_[2];
+    uint32_t n_ep_[2] = {0, 0};
+    uint32_t* d_sig_rel_[2] = {nullptr, nullptr};
+    uint32_t* d_ep_index_[2] = {nullptr, nullptr};
+    uint64_t* d_ovr_[2] = {nullptr, nullptr};
     unsigned long long* d_fail_ = nullptr;
     void* ev_[8] = {nullptr};
     void* ev2_[8] = {nullptr};

@@ -58,6 +58,19 @@ struct NttPassArgs {
     const uint64_t* root1024; const uint64_t* tw_lo; const uint64_t* tw_hi; const uint64_t* c_lo; const uint64_t* c_hi;
 };
 int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream);
+// K7 copy-permutation grand product (kernels_perm.hpp); mirrors zkp::PermDev
+struct PermArgs {
+    const uint64_t* cells; uint64_t n_cells; uint32_t n_cols, n_lanes, n_slots, n_copy_cols, lookup_width;
+    const zk_row_desc* rows; const zk_lookup_row_desc* lrows;
+    const uint32_t* sigma_rel; const uint32_t* ep_index; const uint64_t* ovr; uint32_t lanes_per_instance;
+    uint64_t label_base, label_step; const uint64_t* tb; uint64_t beta[2], gamma[2];
+    uint32_t slots_per_chunk, n_chunks; uint64_t* lane_out; uint64_t* prefix;
+};
+int launch_perm_lane(const PermArgs& a, void* stream);
+int launch_perm_tb(const uint64_t beta[2], const uint32_t* sigma_rel, uint64_t* tb, uint32_t n, void* stream);
+int launch_perm_scan(const uint64_t* part, uint32_t per, const uint64_t* seed, uint64_t* excl, uint64_t* total, uint32_t n_instances, void* stream);
+int launch_perm_z(const uint64_t* excl, const uint64_t* prefix, uint32_t n_lanes, uint32_t n_slots, uint32_t slots_per_chunk, uint32_t n_chunks,
+                  uint32_t lanes_per_instance, uint64_t row_base, uint64_t rows_per_instance, uint64_t* z, void* stream);
 struct ColumnsArgs {  // mirrors zkn::ColumnsDev
     const uint64_t* loop_cells; uint64_t loop_n_cells; const uint64_t* outer_cells; uint64_t outer_n_cells;
     uint32_t n_cols, loop_slots, outer_slots, limit, instance; uint64_t* out; uint64_t stride; uint64_t n_rows_padded;

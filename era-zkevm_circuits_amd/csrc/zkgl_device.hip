@@ -7,6 +7,7 @@
 #include "kernels_engine.hpp"
 #include "kernels_lookup_arg.hpp"
 #include "kernels_ntt.hpp"
+#include "kernels_perm.hpp"
 
 namespace zkdev {
 
@@ -168,6 +169,36 @@ int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream) {
     }
     zkn::k_ntt_pass<<<(unsigned)blocks, zkn::TPB, lds, (hipStream_t)stream>>>(d);
     return LAUNCH_CHECK("k_ntt_pass");
+}
+
+int launch_perm_lane(const PermArgs& a, void* stream) {
+    if (a.n_lanes == 0) return 0;
+    zkp::PermDev d;
+    d.cells = a.cells; d.n_cells = a.n_cells; d.n_cols = a.n_cols; d.n_lanes = a.n_lanes; d.n_slots = a.n_slots;
+    d.n_copy_cols = a.n_copy_cols; d.lookup_width = a.lookup_width; d.rows = a.rows; d.lrows = a.lrows;
+    d.sigma_rel = a.sigma_rel; d.ep_index = a.ep_index; d.ovr = a.ovr; d.lanes_per_instance = a.lanes_per_instance;
+    d.label_base = a.label_base; d.label_step = a.label_step; d.tb = a.tb;
+    d.beta = {a.beta[0], a.beta[1]}; d.gamma = {a.gamma[0], a.gamma[1]};
+    d.slots_per_chunk = a.slots_per_chunk; d.n_chunks = a.n_chunks; d.lane_out = a.lane_out; d.prefix = a.prefix;
+    zkp::k_perm_lane<<<dim3(grid_for(a.n_lanes, zkp::TPB), a.n_chunks), zkp::TPB, 0, (hipStream_t)stream>>>(d);
+    return LAUNCH_CHECK("k_perm_lane");
+}
+int launch_perm_tb(const uint64_t beta[2], const uint32_t* sigma_rel, uint64_t* tb, uint32_t n, void* stream) {
+    if (n == 0) return 0;
+    zkp::k_perm_tb<<<grid_for(n, zkp::TPB), zkp::TPB, 0, (hipStream_t)stream>>>(zkl::E{beta[0], beta[1]}, sigma_rel, tb, n);
+    return LAUNCH_CHECK("k_perm_tb");
+}
+int launch_perm_scan(const uint64_t* part, uint32_t per, const uint64_t* seed, uint64_t* excl, uint64_t* total, uint32_t n_instances, void* stream) {
+    if (n_instances == 0) return 0;
+    zkp::k_perm_scan<<<n_instances, zkp::TPB, 0, (hipStream_t)stream>>>(part, per, seed, excl, total);
+    return LAUNCH_CHECK("k_perm_scan");
+}
+int launch_perm_z(const uint64_t* excl, const uint64_t* prefix, uint32_t n_lanes, uint32_t n_slots, uint32_t slots_per_chunk, uint32_t n_chunks,
+                  uint32_t lanes_per_instance, uint64_t row_base, uint64_t rows_per_instance, uint64_t* z, void* stream) {
+    if (n_lanes == 0) return 0;
+    zkp::k_perm_z<<<dim3(grid_for(n_lanes, zkp::TPB), n_chunks), zkp::TPB, 0, (hipStream_t)stream>>>(excl, prefix, n_lanes, n_slots, slots_per_chunk,
+                                                                                                  n_chunks, lanes_per_instance, row_base, rows_per_instance, z);
+    return LAUNCH_CHECK("k_perm_z");
 }
 
 int launch_trace_columns(const ColumnsArgs& a, void* stream) {

@@ -568,6 +568,24 @@ class ConstraintSystem:
         _check(lib().zk_cs_export(self._h, int(loop_scope), buf.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
         return buf
 
+    def copy_permutation(self, beta, gamma, z_out=None, stream=None):
+        """K7: -> (n_mismatch, array [batch, 4] = numerator (a, b), denominator (a, b) of z[rows]); z_out: device buffer
+        [batch][rows + 1][2] receiving the column z"""
+        b = (C.c_uint64 * 2)(*beta)
+        g = (C.c_uint64 * 2)(*gamma)
+        out = np.zeros((self.batch, 4), dtype=np.uint64)
+        bad = C.c_uint32()
+        _check(lib().zk_cs_copy_permutation(self._h, b, g, _ptr(stream), _ptr(z_out), out.ctypes.data_as(C.c_void_p), C.c_uint32(self.batch),
+                                            C.byref(bad)))
+        return bad.value, out
+
+    def sigma(self, loop_scope: bool, iteration: int = 0) -> np.ndarray:
+        n = C.c_size_t()
+        _check(lib().zk_cs_sigma(self._h, int(loop_scope), C.c_uint32(iteration), None, 0, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint64)
+        _check(lib().zk_cs_sigma(self._h, int(loop_scope), C.c_uint32(iteration), buf.ctypes.data_as(C.c_void_p), C.c_size_t(n.value), C.byref(n)))
+        return buf
+
     def trace_columns(self, instance: int, out, log_n: int, stride=None, stream=None):
         """K6 input: out[col * stride + row] = the instance's trace columns (loop rows, then outer rows, zero padded to 2^log_n)"""
         stride = (1 << log_n) if stride is None else stride

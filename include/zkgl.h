@@ -204,6 +204,18 @@ typedef struct zk_stats {
     /* cone seeding program (backward slice of the carried outputs; 0 when the generic sequential mode is used) */
     uint64_t seed_ops, seed_words, seed_slots, loop_ops;
 } zk_stats;
+/* K7 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
+ * column chunking and cell identifiers are [EXT], the argument is defined in csrc/kernels_perm.hpp).  Labels: outer-scope
+ * trace cell c -> c; loop-scope cell c of iteration k -> NT_outer + k * NT_loop + c.  sigma permutes the labels with one cycle
+ * per copy class (cells of a variable, joined across iterations and scopes by the links).  Rows of an instance: iteration *
+ * loop_slots + slot, then the outer scope's slots (as in zk_cs_trace_columns).  z[0] = 1, z[r + 1] = z[r] * prod over the
+ * populated cells of row r of (w + beta * label + gamma) / (w + beta * sigma(label) + gamma) in GF(p^2), X^2 = 7.
+ *   out (4 words per instance, may be NULL): numerator (a, b) and denominator (a, b) of z[rows]; *n_mismatch = instances with
+ *   z[rows] != 1;  dev_z (device, may be NULL): [instances][rows + 1][2] words, the column z itself.
+ * zk_cs_sigma: sigma(label) for every trace cell of the scope (loop scope: of the given iteration); buf = NULL for the size. */
+int zk_cs_copy_permutation(zk_cs *cs, const uint64_t beta[2], const uint64_t gamma[2], void *stream, uint64_t *dev_z, uint64_t *out,
+                           uint32_t max_instances, uint32_t *n_mismatch);
+int zk_cs_sigma(zk_cs *cs, int loop_scope, uint32_t iteration, uint64_t *buf, size_t max_words, size_t *n_words);
 /* K6 — batched Goldilocks NTT and coset low-degree extension over device-resident polynomials (prover stage after
  * satisfiability, SURVEY 8f-3 "LDE/NTT over Goldilocks"; boojum's transforms are [EXT], entry implied by `into_assembly`,
  * /root/reference/src/ram_permutation/mod.rs:554).  Defined here: omega_N = 7^((p-1)/N), N = 2^log_n, g = coset_shift,

@@ -278,6 +278,15 @@ def parse_export(words) -> dict:
                    for i in range(h["n_tables"])]
     p += 9 * h["n_tables"]
     h["table_words"] = [w[p + 2 * i] | (w[p + 2 * i + 1] << 32) for i in range(h["n_table_words"])]
+    p += 2 * h["n_table_words"]
+    h["links"] = [tuple(w[p + 4 * i: p + 4 * i + 3]) for i in range(h["n_links"])]  # (kind, loop cell, other cell)
+    p += 4 * h["n_links"] + 4 * h["n_carries"]
+    h["streams"] = []
+    end = p + h["n_stream_words"]
+    while p < end:
+        pa, pb, n_total = w[p: p + 3]
+        h["streams"].append((w[p + 3: p + 3 + pa], w[p + 3 + pa: p + 3 + pa + pb], n_total))
+        p += 3 + pa + pb
     return h
 
 
@@ -363,3 +372,99 @@ def lde(coeffs: np.ndarray, log_blowup: int, shift: int = 1) -> np.ndarray:
     out = np.empty(coeffs.size << log_blowup, dtype=np.uint64)
     lib().zko_lde(coeffs.ctypes.data, out.ctypes.data, int(coeffs.size).bit_length() - 1, log_blowup, shift)
     return out
+
+
+# ---- K7: copy-permutation grand product (pure Python integers; CPU ORACLE, test infrastructure) ----
+GATE_WIDTH = [0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5]  # columns per gate instance, by zk_gate_kind
+LINK_CARRY, LINK_FIRST, LINK_LAST, LINK_BCAST = 0, 1, 2, 3
+
+
+def copy_classes(ho: dict, hl: dict, limit: int):
+    """union-find over the trace-cell labels (outer cell c -> c; loop cell c of iteration k -> NT_outer + k NT_loop + c) from the
+    exported structure alone: copy pairs of both scopes, links, stream links.  Returns find()."""
+    nto, ntl = ho["n_trace_cells"], hl["n_trace_cells"] if limit else 0
+    parent = list(range(nto + limit * ntl))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    def join(a, b):
+        parent[find(a)] = find(b)
+
+    lab = lambda k, c: nto + k * ntl + c
+    for c, partner in ho["copies"]:
+        join(c, partner)
+    for k in range(limit):
+        for c, partner in hl["copies"]:
+            join(lab(k, c), lab(k, partner))
+    for kind, lc, oc in (hl["links"] if limit else []):
+        if lc >= ntl or oc >= (ntl if kind == LINK_CARRY else nto):
+            continue  # a variable outside the trace (no gate references it)
+        if kind == LINK_CARRY:
+            for k in range(1, limit):
+                join(lab(k, lc), lab(k - 1, oc))
+        elif kind == LINK_FIRST:
+            join(lab(0, lc), oc)
+        elif kind == LINK_LAST:
+            join(lab(limit - 1, lc), oc)
+        else:
+            for k in range(limit):
+                join(lab(k, lc), oc)
+    for a, b, n_total in (hl["streams"] if limit else []):
+        if any(c >= ntl for c in list(a) + list(b)):
+            continue
+        for i in range(n_total):
+            join(lab(i // len(a), a[i % len(a)]), lab(i // len(b), b[i % len(b)]))
+    return find
+
+
+def sigma_matches_classes(sigma, ho: dict, hl: dict, limit: int) -> bool:
+    """sigma (list over all labels) is a permutation whose cycles are exactly the copy classes"""
+    n = len(sigma)
+    if sorted(int(x) for x in sigma) != list(range(n)):
+        return False
+    find = copy_classes(ho, hl, limit)
+    cyc = [-1] * n
+    for start in range(n):
+        if cyc[start] >= 0:
+            continue
+        x = start
+        while cyc[x] < 0:
+            cyc[x] = start
+            x = int(sigma[x])
+    rep_of_cycle, cycle_of_rep = {}, {}
+    for x in range(n):
+        r = find(x)
+        if rep_of_cycle.setdefault(cyc[x], r) != r or cycle_of_rep.setdefault(r, cyc[x]) != cyc[x]:
+            return False
+    return True
+
+
+def copy_permutation_z(ho: dict, hl: dict, limit: int, outer_col, loop_cols, sigma, beta, gamma, n_cols: int):
+    """z over the rows of one instance.  outer_col: values of the outer trace cells; loop_cols[k]: values of iteration k;
+    sigma: list over all labels.  Returns [(a, b)] of length rows + 1."""
+    nto, ntl = ho["n_trace_cells"], hl["n_trace_cells"] if limit else 0
+    z = [(1, 0)]
+
+    def rows_of(h, values, base):
+        W, C0 = h["lookup_width"], h["n_copy_cols"]
+        for slot in range(h["n_slots"]):
+            kind, ninst = h["rows"][slot][0], h["rows"][slot][1]
+            cols = list(range(ninst * GATE_WIDTH[kind])) + [C0 + i for i in range(h["lrows"][slot][1] * W)]
+            num, den = (1, 0), (1, 0)
+            for col in cols:
+                cell = slot * n_cols + col
+                w, lab = int(values[cell]), base + cell
+                tn = ((w + beta[0] * lab + gamma[0]) % P, (beta[1] * lab + gamma[1]) % P)
+                sg = int(sigma[lab])
+                td = ((w + beta[0] * sg + gamma[0]) % P, (beta[1] * sg + gamma[1]) % P)
+                num, den = e2_mul(num, tn), e2_mul(den, td)
+            z.append(e2_mul(z[-1], e2_mul(num, e2_inv(den))))
+
+    for k in range(limit):
+        rows_of(hl, loop_cols[k], nto + k * ntl)
+    rows_of(ho, outer_col, 0)
+    return z
