@@ -81,6 +81,18 @@ def test_width4_lookups_and_reduction_by_powers_on_the_gpu(zk):
     bad, sums = cs.lookup_argument((11, 12), (13, 14))
     want = zko.lookup_argument(run, cs.export(False), cs.export(True), (11, 12), (13, 14), 40 + 32)
     assert bad == 0 and [tuple(int(x) for x in row) for row in sums] == want
+    # K7 on a circuit without a loop scope (width-4 lookup columns take part in the permutation): z closes and equals the oracle
+    st = cs.stats()
+    rows, n_cols = st["rows_per_instance"], st["copy_columns"] + st["lookup_columns"]
+    zbuf = zk.DeviceBuffer(B * (rows + 1) * 2)
+    bad, out = cs.copy_permutation((21, 22), (23, 24), zbuf)
+    assert bad == 0 and np.array_equal(out[:, :2], out[:, 2:])
+    ho, hl = zko.parse_export(cs.export(False)), zko.parse_export(cs.export(True))
+    sigma = cs.sigma(False)
+    assert zko.sigma_matches_classes(sigma, ho, hl, 0)
+    z = zbuf.to_numpy().reshape(B, rows + 1, 2)
+    want_z = zko.copy_permutation_z(ho, hl, 0, cs.trace(False)[:, 77], [], sigma, (21, 22), (23, 24), n_cols)
+    assert [tuple(int(x) for x in r) for r in z[77]] == want_z and want_z[-1] == (1, 0)
     cs.write_cell(False, cs.public_cells()[1], 5, 12345)        # w1 of instance 5 no longer equals the powers sum
     ok, f = cs.check_if_satisfied()
     assert not ok and f.instance == 5 and f.kind == G["REDUCTION_BY_POWERS4"]
