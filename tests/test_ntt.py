@@ -255,3 +255,29 @@ def test_gpu_trace_columns_feed_the_transform(zk):
     ref = zko.lde(coeffs_brev[c0][perm], 1, SHIFT).reshape(2, n)
     assert np.array_equal(ext[c0], ref[:, perm])
     del keep
+
+
+@pytest.mark.gpu
+def test_gpu_degenerate_shapes(zk):
+    """empty batches, constants (log_n = 0), blow-up factor 1, a 2^17 transform whose passes split 9 + 8"""
+    d = zk.DeviceBuffer.from_numpy(np.array([5, 6, 7, 8], dtype=np.uint64))
+    zk.ntt(d, 2, 0, 4, False, 1)                       # no polynomials: nothing happens
+    zk.ntt(d, 0, 4, 1, False, SHIFT)                   # four constants: a[0] g^0
+    zk.ntt(d, 0, 4, 1, True, SHIFT)
+    zk.sync()
+    assert d.to_numpy().tolist() == [5, 6, 7, 8]
+    rng = np.random.default_rng(77)
+    a = rand_poly(rng, 2, 1 << 6)
+    src = zk.DeviceBuffer.from_numpy(a.reshape(-1))
+    out = zk.DeviceBuffer(2 << 6)
+    zk.lde(src, out, 6, 0, 2, None, SHIFT)             # blow-up 1 = the coset transform itself, out of place
+    zk.sync()
+    assert np.array_equal(out.to_numpy().reshape(2, -1), zko.ntt(a, False, SHIFT))
+    with pytest.raises(zk.ZkError):
+        zk.lde(src, out, 0, 1, 1, None, 1)
+    b = rand_poly(rng, 1, 1 << 17)
+    f, _ = dev_ntt(zk, b, 17, False, SHIFT)
+    assert np.array_equal(f, zko.ntt(b, False, SHIFT))
+    g, _ = dev_ntt(zk, b, 17, True, SHIFT, None, True)
+    perm = np.array([bitrev(i, 17) for i in range(1 << 17)])
+    assert np.array_equal(g[:, perm], zko.ntt(np.ascontiguousarray(b[:, perm]), True, SHIFT))
