@@ -949,7 +949,7 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
     return decode_failure(f, first);
 }
 
-// K5 (kernels_lookup_arg.hpp): the witness side sums 1/f over every lookup tuple of the trace, the table side sums
+// K10 (kernels_lookup_arg.hpp): the witness side sums 1/f over every lookup tuple of the trace, the table side sums
 // multiplicity/f over the table rows; equality per instance is the log-derivative lookup argument.
 uint32_t CS::lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], void* stream, std::vector<uint64_t>& out) {
     if (batch_ == 0 || !uploaded_) throw ZkError(ZK_ERR_INVALID, "lookup_argument before set_batch / resolve");

@@ -152,10 +152,10 @@ class CS {
     uint32_t var_cell(zk_var v) const;
     std::vector<uint32_t> public_cells() const;
     std::vector<uint32_t> multiplicities(uint32_t instance);
-    // K5: log-derivative lookup-argument accumulators over the resolved trace; out[instance] = {A.a, A.b, B.a, B.b};
+    // K10: log-derivative lookup-argument accumulators over the resolved trace; out[instance] = {A.a, A.b, B.a, B.b};
     // returns the number of instances with A != B
     uint32_t lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], void* stream, std::vector<uint64_t>& out);
-    // K7 (cs_perm.cpp): copy-permutation grand product over the resolved trace.  out[instance] = {num.a, num.b, den.a, den.b} of
+    // K12 (cs_perm.cpp): copy-permutation grand product over the resolved trace.  out[instance] = {num.a, num.b, den.a, den.b} of
     // z[rows] = num / den; returns the number of instances with num != den.  d_z (optional, device): [batch][rows + 1][2]
     uint32_t copy_permutation(const uint64_t beta[2], const uint64_t gamma[2], void* stream, uint64_t* d_z, std::vector<uint64_t>& out);
     std::vector<uint64_t> sigma_labels(bool loop_scope, uint32_t iteration);  // sigma(label) of every trace cell of the scope / iteration
@@ -227,7 +227,7 @@ class CS {
     uint32_t seed_slots_ = 0, seed_ops_ = 0;
     uint32_t* d_seed_prog_ = nullptr;
     void* d_seed_carries_ = nullptr;
-    // K7: sigma = per-cell image inside the scope / iteration + absolute labels of the link endpoints [endpoint][iteration]
+    // K12: sigma = per-cell image inside the scope / iteration + absolute labels of the link endpoints [endpoint][iteration]
     void build_sigma();
     bool sigma_built_ = false;
     std::vector<uint32_t> sig_rel_[2], ep_index_[2];
@@ -243,7 +243,7 @@ class CS {
     float ms_[5] = {0, 0, 0, 0, 0};
 };
 
-// K6 (ntt.cpp): batched Goldilocks NTT / coset LDE over device-resident polynomials, see include/zkgl.h
+// K11 (ntt.cpp): batched Goldilocks NTT / coset LDE over device-resident polynomials, see include/zkgl.h
 uint64_t two_adic_root(uint32_t log_n);
 void ntt(uint64_t* d_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, uint32_t mode, uint64_t coset_shift, void* stream);
 void lde(const uint64_t* d_coeffs, uint64_t src_stride, uint64_t* d_out, uint32_t log_n, uint32_t log_blowup, uint32_t n_polys,

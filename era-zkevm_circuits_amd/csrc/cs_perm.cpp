@@ -1,4 +1,4 @@
-// cs_perm.cpp — host side of K7 (kernels_perm.hpp): the permutation sigma over the trace-cell labels and the grand product.
+// cs_perm.cpp — host side of K12 (kernels_perm.hpp): the permutation sigma over the trace-cell labels and the grand product.
 //
 // Copy classes of this engine = the cells of one variable inside a scope and iteration (Scope::var_cells), joined by the
 // links that stand for the reference's cross-chunk / cross-cycle copies (hidden_fsm chain,

@@ -41,7 +41,7 @@ int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uin
 int launch_check_gates(const CheckArgs& cd, void* stream);
 int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs,
                         uint32_t n_pairs, unsigned long long* fail, void* stream);
-// K5 lookup-argument accumulators (kernels_lookup_arg.hpp).  ch = beta, gamma, gamma^2, gamma^3, gamma^4 (2 words each)
+// K10 lookup-argument accumulators (kernels_lookup_arg.hpp).  ch = beta, gamma, gamma^2, gamma^3, gamma^4 (2 words each)
 struct LookupArgArgs {
     const uint64_t* cells; uint64_t n_cells; uint32_t n_cols, n_lanes, n_slots, n_copy_cols, lookup_width;
     const zk_lookup_row_desc* lrows; uint64_t* acc;
@@ -51,14 +51,14 @@ int launch_lookup_arg_tables(const zk_table_desc* tables, uint32_t n_tables, con
                              const uint64_t ch[10], uint64_t* inv_f, const uint32_t* mult, uint32_t n_instances, uint64_t* out_b, void* stream);
 int launch_lookup_arg_witness_sum(const uint64_t* acc_outer, const uint64_t* acc_loop, uint32_t limit, uint32_t n_instances,
                                   uint64_t* out_a, void* stream);
-// K6 NTT (kernels_ntt.hpp); mirrors zkn::PassDev
+// K11 NTT (kernels_ntt.hpp); mirrors zkn::PassDev
 struct NttPassArgs {
     const uint64_t* src; uint64_t* dst; uint64_t src_stride, dst_stride;
     uint32_t log_n, seg, r, t, dit, coset_store, coset_brev;
     const uint64_t* root1024; const uint64_t* tw_lo; const uint64_t* tw_hi; const uint64_t* c_lo; const uint64_t* c_hi;
 };
 int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream);
-// K7 copy-permutation grand product (kernels_perm.hpp); mirrors zkp::PermDev
+// K12 copy-permutation grand product (kernels_perm.hpp); mirrors zkp::PermDev
 struct PermArgs {
     const uint64_t* cells; uint64_t n_cells; uint32_t n_cols, n_lanes, n_slots, n_copy_cols, lookup_width;
     const zk_row_desc* rows; const zk_lookup_row_desc* lrows;

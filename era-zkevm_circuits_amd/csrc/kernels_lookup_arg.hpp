@@ -1,4 +1,4 @@
-// kernels_lookup_arg.hpp — K5: log-derivative lookup-argument accumulators over the resolved trace.
+// kernels_lookup_arg.hpp — K10: log-derivative lookup-argument accumulators over the resolved trace.
 //
 // SURVEY.md §8f rank 3 / BASELINE north star ("grand-product/lookup-argument accumulators"): what a prover computes
 // from the lookup columns after witness generation.  boojum's exact polynomial form is not in the tree ([EXT]); the

@@ -1,4 +1,4 @@
-// kernels_ntt.hpp — K6: batched Goldilocks NTT / coset LDE over device-resident polynomials.
+// kernels_ntt.hpp — K11: batched Goldilocks NTT / coset LDE over device-resident polynomials.
 //
 // SURVEY.md §8f rank 3 ("LDE/NTT over Goldilocks"): the step a prover runs on the trace columns after satisfiability.
 // boojum's transform code is not in the tree ([EXT]); the mathematical object is fixed by the field alone and is defined

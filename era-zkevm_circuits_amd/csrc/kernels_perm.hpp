@@ -1,6 +1,6 @@
-// kernels_perm.hpp — K7: copy-permutation grand product z over the resolved trace.
+// kernels_perm.hpp — K12: copy-permutation grand product z over the resolved trace.
 //
-// SURVEY.md §8f rank 3 ("copy-permutation grand product z(X)"): with the lookup accumulators (K5) and the NTT / LDE (K6) the
+// SURVEY.md §8f rank 3 ("copy-permutation grand product z(X)"): with the lookup accumulators (K10) and the NTT / LDE (K11) the
 // third piece of the prover stage that follows satisfiability.  boojum's column chunking and its choice of cell identifiers
 // are not in the tree ([EXT]); the argument is the standard one over this engine's trace:
 //

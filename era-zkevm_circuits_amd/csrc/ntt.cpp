@@ -1,4 +1,4 @@
-// ntt.cpp — host side of K6 (kernels_ntt.hpp): pass plans, twiddle tables, zk_ntt / zk_lde.
+// ntt.cpp — host side of K11 (kernels_ntt.hpp): pass plans, twiddle tables, zk_ntt / zk_lde.
 //
 // SURVEY.md §8f rank 3.  The reference reaches this stage through boojum's prover after `into_assembly`
 // (/root/reference/src/ram_permutation/mod.rs:554); nothing of it is in the tree, so the transform is defined in

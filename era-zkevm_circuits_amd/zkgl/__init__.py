@@ -224,7 +224,7 @@ def grand_product(enc, flags, challenges, enc_len, n, init, acc_out, scratch, st
 # ------------------------------------------------------------------------------------------------
 # constraint system
 # ------------------------------------------------------------------------------------------------
-# K6: Goldilocks NTT / coset LDE over device-resident polynomials (include/zkgl.h)
+# K11: Goldilocks NTT / coset LDE over device-resident polynomials (include/zkgl.h)
 def two_adic_root(log_n: int) -> int:
     out = C.c_uint64()
     _check(lib().zk_two_adic_root(C.c_uint32(log_n), C.byref(out)))
@@ -362,7 +362,7 @@ class ConstraintSystem:
         _check(lib().zk_cs_link(self._h, kind, loop_var, other))
 
     def lookup_argument(self, beta, gamma, stream=None):
-        """K5: -> (n_mismatch, array [batch, 4] = witness-side sum (a, b), table-side sum (a, b) in GF(p^2))"""
+        """K10: -> (n_mismatch, array [batch, 4] = witness-side sum (a, b), table-side sum (a, b) in GF(p^2))"""
         b = (C.c_uint64 * 2)(*beta)
         g = (C.c_uint64 * 2)(*gamma)
         out = np.zeros((self.batch, 4), dtype=np.uint64)
@@ -569,7 +569,7 @@ class ConstraintSystem:
         return buf
 
     def copy_permutation(self, beta, gamma, z_out=None, stream=None):
-        """K7: -> (n_mismatch, array [batch, 4] = numerator (a, b), denominator (a, b) of z[rows]); z_out: device buffer
+        """K12: -> (n_mismatch, array [batch, 4] = numerator (a, b), denominator (a, b) of z[rows]); z_out: device buffer
         [batch][rows + 1][2] receiving the column z"""
         b = (C.c_uint64 * 2)(*beta)
         g = (C.c_uint64 * 2)(*gamma)
@@ -587,7 +587,7 @@ class ConstraintSystem:
         return buf
 
     def trace_columns(self, instance: int, out, log_n: int, stride=None, stream=None):
-        """K6 input: out[col * stride + row] = the instance's trace columns (loop rows, then outer rows, zero padded to 2^log_n)"""
+        """K11 input: out[col * stride + row] = the instance's trace columns (loop rows, then outer rows, zero padded to 2^log_n)"""
         stride = (1 << log_n) if stride is None else stride
         _check(lib().zk_cs_trace_columns(self._h, C.c_uint32(instance), _ptr(out), C.c_uint32(log_n), C.c_uint64(stride), _ptr(stream)))
 

@@ -204,7 +204,7 @@ typedef struct zk_stats {
     /* cone seeding program (backward slice of the carried outputs; 0 when the generic sequential mode is used) */
     uint64_t seed_ops, seed_words, seed_slots, loop_ops;
 } zk_stats;
-/* K7 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
+/* K12 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
  * column chunking and cell identifiers are [EXT], the argument is defined in csrc/kernels_perm.hpp).  Labels: outer-scope
  * trace cell c -> c; loop-scope cell c of iteration k -> NT_outer + k * NT_loop + c.  sigma permutes the labels with one cycle
  * per copy class (cells of a variable, joined across iterations and scopes by the links).  Rows of an instance: iteration *
@@ -216,7 +216,7 @@ typedef struct zk_stats {
 int zk_cs_copy_permutation(zk_cs *cs, const uint64_t beta[2], const uint64_t gamma[2], void *stream, uint64_t *dev_z, uint64_t *out,
                            uint32_t max_instances, uint32_t *n_mismatch);
 int zk_cs_sigma(zk_cs *cs, int loop_scope, uint32_t iteration, uint64_t *buf, size_t max_words, size_t *n_words);
-/* K6 — batched Goldilocks NTT and coset low-degree extension over device-resident polynomials (prover stage after
+/* K11 — batched Goldilocks NTT and coset low-degree extension over device-resident polynomials (prover stage after
  * satisfiability, SURVEY 8f-3 "LDE/NTT over Goldilocks"; boojum's transforms are [EXT], entry implied by `into_assembly`,
  * /root/reference/src/ram_permutation/mod.rs:554).  Defined here: omega_N = 7^((p-1)/N), N = 2^log_n, g = coset_shift,
  *   A[k] = sum_i a[i] (g omega_N^k)^i.
@@ -235,7 +235,7 @@ int zk_two_adic_root(uint32_t log_n, uint64_t *out);
 int zk_ntt(uint64_t *dev_data, uint32_t log_n, uint32_t n_polys, uint64_t stride, uint32_t mode, uint64_t coset_shift, void *stream);
 int zk_lde(const uint64_t *dev_coeffs, uint64_t src_stride, uint64_t *dev_out, uint32_t log_n, uint32_t log_blowup, uint32_t n_polys,
            uint32_t mode, uint64_t coset_shift, void *stream);
-/* K5 — log-derivative lookup-argument accumulators over the resolved trace (prover stage after satisfiability, SURVEY 8f-3;
+/* K10 — log-derivative lookup-argument accumulators over the resolved trace (prover stage after satisfiability, SURVEY 8f-3;
  * boojum's polynomial form is [EXT], the sums are defined in csrc/kernels_lookup_arg.hpp).  beta, gamma: canonical GF(p^2)
  * elements (a + bX, X^2 = 7).  out (4 words per instance, may be NULL): witness-side sum A (a, b) then table-side sum B (a, b);
  * *n_mismatch = number of instances with A != B.  Call after zk_cs_resolve / zk_cs_resolve_and_check. */
@@ -249,7 +249,7 @@ int zk_cs_last_ms(zk_cs *cs, int which, float *ms);
 /* serialised scope (program + descriptors) for the CPU oracle / offline tooling.
  * Call with buf = NULL to get the size in words. */
 int zk_cs_export(zk_cs *cs, int loop_scope, uint32_t *buf, size_t max_words, size_t *n_words);
-/* The resolved trace of one instance as column polynomials for K6: dev_out[col * stride + row] for every copy and lookup
+/* The resolved trace of one instance as column polynomials for K11: dev_out[col * stride + row] for every copy and lookup
  * column, row = iteration * loop_slots + slot for the loop scope's rows, then the outer scope's slots, zero padded to
  * 2^log_n (>= the instance's row count, zk_stats.rows_per_instance); stride >= 2^log_n.  The layout `into_assembly`
  * hands to the prover (/root/reference/src/ram_permutation/mod.rs:554) is boojum's ([EXT]); this one is the engine's. */

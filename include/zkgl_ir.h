@@ -9,9 +9,9 @@
  * row descriptor.  One recorded *scope* = one straight-line program executed SIMT with
  * lane == circuit instance (outer scope) or lane == (instance, loop iteration) (loop scope).
  *
- * Storage: cells[cell * stride + lane], cell = column * n_slots + slot for trace cells, scratch
- * cells (variables that no gate references) follow.  A wavefront touching one cell therefore
- * issues one coalesced 512-byte access.
+ * Storage: wave-tiled, cells[((lane >> 6) * n_cells + cell) * 64 + (lane & 63)] with cell = slot * n_columns + column for
+ * trace cells; scratch cells (variables that no gate references) follow.  A wavefront touching one cell of its 64 lanes
+ * therefore issues one coalesced 512-byte access, and everything one wavefront touches lies in one contiguous tile.
  *
  * Program = array of u32 words.  Operand word: bit31 = 0 -> own-scope cell index;
  * bits31..30 = 10 -> constant-pool index; 11 -> outer-scope cell index (loop scope only).

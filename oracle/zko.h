@@ -94,7 +94,7 @@ void zko_keccak_f1600(uint64_t st[25]);
 void zko_keccak256(const uint8_t *msg, size_t len, uint8_t out[32]);
 void zko_sha256_compress(uint32_t state[8], const uint8_t block[64]);
 
-/* ---- K6: NTT / coset LDE (zko_ntt.c; transform defined in include/zkgl.h, boojum's is [EXT]) ---- */
+/* ---- K11: NTT / coset LDE (zko_ntt.c; transform defined in include/zkgl.h, boojum's is [EXT]) ---- */
 uint64_t zko_two_adic_root(unsigned log_n);
 void zko_ntt_naive(const uint64_t *a, uint64_t *out, unsigned log_n, uint64_t shift);
 void zko_ntt(uint64_t *a, unsigned log_n, int inverse, uint64_t shift);

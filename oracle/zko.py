@@ -259,7 +259,7 @@ class CircuitRun:
         return bad, total_rel
 
 
-# ---- K5 lookup-argument oracle (pure Python integers; CPU ORACLE, test infrastructure) ----
+# ---- K10 lookup-argument oracle (pure Python integers; CPU ORACLE, test infrastructure) ----
 def parse_export(words) -> dict:
     """sections of a serialised scope (ConstraintSystem.export): header fields, lookup rows, table descriptors / words"""
     w = [int(x) for x in np.asarray(words, dtype=np.uint32)]
@@ -300,7 +300,7 @@ def e2_inv(x):
 
 
 def lookup_argument(run: "CircuitRun", outer_words, loop_words, beta, gamma, n_cols: int):
-    """K5 restatement (csrc/kernels_lookup_arg.hpp): per instance (A, B) with A = sum over every lookup tuple of the trace of
+    """K10 restatement (csrc/kernels_lookup_arg.hpp): per instance (A, B) with A = sum over every lookup tuple of the trace of
     1/f, B = sum over table rows of multiplicity/f, f = beta + sum_j gamma^j c_j + gamma^W table (W = lookup width)."""
     ho = parse_export(outer_words)
     Wd = ho["lookup_width"]
@@ -346,7 +346,7 @@ def lookup_argument(run: "CircuitRun", outer_words, loop_words, beta, gamma, n_c
     return out
 
 
-# ---- K6: NTT / coset LDE (zko_ntt.c) ----
+# ---- K11: NTT / coset LDE (zko_ntt.c) ----
 def two_adic_root(log_n: int) -> int:
     return int(lib().zko_two_adic_root(log_n))
 
@@ -374,7 +374,7 @@ def lde(coeffs: np.ndarray, log_blowup: int, shift: int = 1) -> np.ndarray:
     return out
 
 
-# ---- K7: copy-permutation grand product (pure Python integers; CPU ORACLE, test infrastructure) ----
+# ---- K12: copy-permutation grand product (pure Python integers; CPU ORACLE, test infrastructure) ----
 GATE_WIDTH = [0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5]  # columns per gate instance, by zk_gate_kind
 LINK_CARRY, LINK_FIRST, LINK_LAST, LINK_BCAST = 0, 1, 2, 3
 

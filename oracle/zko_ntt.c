@@ -1,5 +1,5 @@
 /*
- * oracle/zko_ntt.c — CPU ORACLE (test infrastructure, NOT product code) for K6: Goldilocks NTT / coset LDE.
+ * oracle/zko_ntt.c — CPU ORACLE (test infrastructure, NOT product code) for K11: Goldilocks NTT / coset LDE.
  *
  * boojum's transforms ([EXT], git dependency absent from /root/reference) are not available; the transform is defined by
  * the field alone (include/zkgl.h, zk_ntt) and this file restates it twice: zko_ntt_naive evaluates the polynomial at every

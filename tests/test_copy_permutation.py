@@ -1,4 +1,4 @@
-"""K7: copy-permutation grand product.  CPU part: the engine's sigma (zk_cs_sigma, host side) is a permutation
+"""K12: copy-permutation grand product.  CPU part: the engine's sigma (zk_cs_sigma, host side) is a permutation
 whose cycles are exactly the copy classes the oracle derives from the exported structure alone (copy pairs, links, stream
 links).  GPU part (-m gpu): z equals the oracle's integers row by row, closes at 1 on satisfied traces and does not on a
 tampered copy."""

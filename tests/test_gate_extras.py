@@ -1,6 +1,6 @@
 """a2 / a16 completeness: ReductionByPowersGate<F,4> (src/main_vm/decoded_opcode.rs:275, opcodes/binop.rs:203-217) and lookup
 sub-arguments of width 4 (the shape of boojum's 4-bit SHA tables Maj4 / Ch4 / TriXor4, src/code_unpacker_sha256/mod.rs:490-494,
-554-566): oracle on CPU, device vs oracle under -m gpu, K5 lookup argument at width 4."""
+554-566): oracle on CPU, device vs oracle under -m gpu, K10 lookup argument at width 4."""
 import numpy as np
 import pytest
 
@@ -57,7 +57,7 @@ def test_width4_lookups_and_reduction_by_powers_on_the_oracle():
     assert bad == 0 and nrel == 9 * cs.stats()["constraints_per_instance"]
     for i in range(9):
         assert [int(run.oc[c, i]) for c in cs.public_cells()] == expected(inp[:, i])
-    res = zko.lookup_argument(run, cs.export(False), cs.export(True), (5, 6), (7, 8), 40 + 32)     # K5 at width 4
+    res = zko.lookup_argument(run, cs.export(False), cs.export(True), (5, 6), (7, 8), 40 + 32)     # K10 at width 4
     assert all(r[0:2] == r[2:4] != (0, 0) for r in res)
     run.oc[cs.public_cells()[1], 3] += 1      # break the powers relation
     assert run.check()[0] > 0
@@ -81,7 +81,7 @@ def test_width4_lookups_and_reduction_by_powers_on_the_gpu(zk):
     bad, sums = cs.lookup_argument((11, 12), (13, 14))
     want = zko.lookup_argument(run, cs.export(False), cs.export(True), (11, 12), (13, 14), 40 + 32)
     assert bad == 0 and [tuple(int(x) for x in row) for row in sums] == want
-    # K7 on a circuit without a loop scope (width-4 lookup columns take part in the permutation): z closes and equals the oracle
+    # K12 on a circuit without a loop scope (width-4 lookup columns take part in the permutation): z closes and equals the oracle
     st = cs.stats()
     rows, n_cols = st["rows_per_instance"], st["copy_columns"] + st["lookup_columns"]
     zbuf = zk.DeviceBuffer(B * (rows + 1) * 2)

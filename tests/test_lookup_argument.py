@@ -1,4 +1,4 @@
-"""K5: log-derivative lookup-argument accumulators (csrc/kernels_lookup_arg.hpp).  CPU part: the pure-Python
+"""K10: log-derivative lookup-argument accumulators (csrc/kernels_lookup_arg.hpp).  CPU part: the pure-Python
 restatement balances (A == B) on the oracle trace of a circuit with lookups and stops balancing when a multiplicity or a
 looked-up value is tampered with.  GPU part (-m gpu): the device sums equal the restatement bit for bit."""
 import numpy as np

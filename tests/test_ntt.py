@@ -1,4 +1,4 @@
-"""K6: Goldilocks NTT / coset LDE.  CPU part: the oracle's fast transform is pinned by the definition (Horner
+"""K11: Goldilocks NTT / coset LDE.  CPU part: the oracle's fast transform is pinned by the definition (Horner
 evaluation at every domain point, in C and independently in Python integers) and by algebraic identities.  GPU part (-m gpu):
 zk_ntt / zk_lde equal the oracle bit for bit at every size up to 2^16, and satisfy size-independent properties at 2^20-2^22."""
 import numpy as np

@@ -1,4 +1,4 @@
-"""K6 throughput: batched 2^log_n transforms over trace-column-sized batches.  GPU box, repo root:
+"""K11 throughput: batched 2^log_n transforms over trace-column-sized batches.  GPU box, repo root:
 python tools/ntt_bench.py [log_n] [n_polys] -> one JSON line (elements/s, ms, HBM fraction of the 2-pass traffic)."""
 import json, os, sys
 import numpy as np

@@ -1,5 +1,5 @@
-"""Prover-stage kernels on the bench workload (main_vm-shaped, 2^20 rows per instance): K5 lookup accumulators, K7 copy-permutation
-grand product over the whole batch, and for one instance trace columns -> coefficients -> x8 coset LDE (K6).
+"""Prover-stage kernels on the bench workload (main_vm-shaped, 2^20 rows per instance): K10 lookup accumulators, K12 copy-permutation
+grand product over the whole batch, and for one instance trace columns -> coefficients -> x8 coset LDE (K11).
 GPU box, repo root: python tools/prover_stage_bench.py [batch] -> one JSON line (wall-clock around synchronous calls, second call)."""
 import json, os, sys, time
 import numpy as np
@@ -38,10 +38,10 @@ def wall(fn):
 out = {"batch": B, "rows_per_instance": rows, "populated_cells_per_instance": cells}
 ms, (bad, _) = wall(lambda: cs.lookup_argument((11, 12), (13, 14), stream))
 assert bad == 0
-out["K5_lookup_argument"] = {"ms": round(ms, 2), "ms_per_instance": round(ms / B, 3)}
+out["K10_lookup_argument"] = {"ms": round(ms, 2), "ms_per_instance": round(ms / B, 3)}
 ms, (bad, _) = wall(lambda: cs.copy_permutation((11, 12), (13, 14), None, stream))
 assert bad == 0
-out["K7_copy_permutation_check"] = {"ms": round(ms, 2), "ms_per_instance": round(ms / B, 3), "cells_per_s": round(B * cells / ms * 1e3 / 1e9, 2),
+out["K12_copy_permutation_check"] = {"ms": round(ms, 2), "ms_per_instance": round(ms / B, 3), "cells_per_s": round(B * cells / ms * 1e3 / 1e9, 2),
                                     "read_GBps": round(B * cells * 8 / ms / 1e6, 1)}
 zb = min(B, 8)   # the column z itself for a few instances: 33 MB of running products per instance
 log_n = 20
@@ -56,5 +56,5 @@ def pipeline():
 
 
 ms, _ = wall(pipeline)
-out["K6_columns_interpolate_lde8_one_instance"] = {"ms": round(ms, 2), "columns": n_cols, "values_out": n_cols * (8 << log_n)}
+out["K11_columns_interpolate_lde8_one_instance"] = {"ms": round(ms, 2), "columns": n_cols, "values_out": n_cols * (8 << log_n)}
 print(json.dumps(out))
