@@ -1,7 +1,7 @@
 """Timings of BASELINE.json's other configurations at full size on one GPU (C1, C3, C4, C5): one fused
 resolve_and_check per configuration (after one warm-up), inputs from the native restatements used by the parity tests.
 Prints one JSON line per configuration.  It lives under tests/ because its input generators are the oracle's native restatements (test infrastructure).
-usage (GPU box, repo root): python tests/config_timings.py"""
+usage (GPU box, repo root): python tests/config_timings.py            (CONFIGS=C3k,C5 selects: C1 C3k C3s C4s C4l C5)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file is tests/config_timings.py)
 for p in (ROOT, os.path.join(ROOT, "era-zkevm_circuits_amd"), os.path.join(ROOT, "tests")):
@@ -30,44 +30,53 @@ def timed(name, cs, outer, loop, batch, seed_carried=0):
 
 
 rng = np.random.default_rng(1)
+WANT = os.environ.get("CONFIGS")
+want = lambda tag: WANT is None or tag in WANT.split(",")
 # C1: ram_permutation 2^16 rows, 512 instances
-cs, limit = T.fit(lambda c: c.configure_ram_permutation(), lambda c, l: c.ram_permutation_entry_point(l), 16)
-u, s, nd = rn.random_ram_witness(rng, limit, n_cells=64)
-inst = rn.instance(u, s, limit, nd)
-outer, loop = rn.pack_streams([inst] * 512, limit)
-timed("C1 ram_permutation 2^16 rows", cs, outer, loop, 512)
+if want("C1"):
+    cs, limit = T.fit(lambda c: c.configure_ram_permutation(), lambda c, l: c.ram_permutation_entry_point(l), 16)
+    u, s, nd = rn.random_ram_witness(rng, limit, n_cells=64)
+    inst = rn.instance(u, s, limit, nd)
+    outer, loop = rn.pack_streams([inst] * 512, limit)
+    timed("C1 ram_permutation 2^16 rows", cs, outer, loop, 512)
 # C3
-cs, limit = T.fit(lambda c: c.configure_keccak(), lambda c, l: c.keccak256_round_function_entry_point(l), 20)
-reqs, _ = T._keccak_requests(np.random.default_rng(0xC3), limit)
-inst = kn.instance(reqs, limit)
-B = 128
-outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
-timed("C3 keccak256_round_function 2^20 rows", cs, outer, loop, B)
-cs, limit = T.fit(lambda c: c.configure_sha256(), lambda c, l: c.sha256_round_function_entry_point(l), 20)
-msgs = [bytes(rng.integers(0, 256, size=64 * 8 - 9, dtype=np.uint8)) for _ in range(limit // 8)]
-reqs = [shn.request(m, 1 + 2 * i, 10 + i, 0, 9000 + i, i) for i, m in enumerate(msgs)]
-inst = shn.instance(reqs, limit)
-outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
-timed("C3 sha256_round_function 2^20 rows", cs, outer, loop, B)
+if want("C3k"):
+    cs, limit = T.fit(lambda c: c.configure_keccak(), lambda c, l: c.keccak256_round_function_entry_point(l), 20)
+    reqs, _ = T._keccak_requests(np.random.default_rng(0xC3), limit)
+    inst = kn.instance(reqs, limit)
+    B = 128
+    outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
+    timed("C3 keccak256_round_function 2^20 rows", cs, outer, loop, B)
+if want("C3s"):
+    B = 128
+    cs, limit = T.fit(lambda c: c.configure_sha256(), lambda c, l: c.sha256_round_function_entry_point(l), 20)
+    msgs = [bytes(rng.integers(0, 256, size=64 * 8 - 9, dtype=np.uint8)) for _ in range(limit // 8)]
+    reqs = [shn.request(m, 1 + 2 * i, 10 + i, 0, 9000 + i, i) for i, m in enumerate(msgs)]
+    inst = shn.instance(reqs, limit)
+    outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
+    timed("C3 sha256_round_function 2^20 rows", cs, outer, loop, B)
 # C4 (4 instances on one GPU here; BASELINE shards them over 4 GPUs)
-cs, limit = T.fit(lambda c: c.configure_storage_validity(), lambda c, l: c.sort_and_deduplicate_storage_access_entry_point(l, True), 22)
-u, s = sn.random_storage_witness(np.random.default_rng(0xC4), limit - 3, n_cells=512)
-inst = sn.instance(u, s, limit)
-outer, loop = sn.pack_streams([inst] * 4, limit)
-timed("C4 storage_validity 2^22 rows", cs, outer, loop, 4)
-cs, limit = T.fit(lambda c: c.configure_log_sorter(), lambda c, l: c.sort_and_deduplicate_events_entry_point(l), 22)
-u, s = ln.random_events(np.random.default_rng(0xC4 + 1), int(limit / 1.1) - 8, rollback_frac=0.1)
-inst = ln.instance(u, s, limit)
-outer, loop = ln.pack_streams([inst] * 4, limit)
-timed("C4 log_sorter 2^22 rows", cs, outer, loop, 4)
+if want("C4s"):
+    cs, limit = T.fit(lambda c: c.configure_storage_validity(), lambda c, l: c.sort_and_deduplicate_storage_access_entry_point(l, True), 22)
+    u, s = sn.random_storage_witness(np.random.default_rng(0xC4), limit - 3, n_cells=512)
+    inst = sn.instance(u, s, limit)
+    outer, loop = sn.pack_streams([inst] * 4, limit)
+    timed("C4 storage_validity 2^22 rows", cs, outer, loop, 4)
+if want("C4l"):
+    cs, limit = T.fit(lambda c: c.configure_log_sorter(), lambda c, l: c.sort_and_deduplicate_events_entry_point(l), 22)
+    u, s = ln.random_events(np.random.default_rng(0xC4 + 1), int(limit / 1.1) - 8, rollback_frac=0.1)
+    inst = ln.instance(u, s, limit)
+    outer, loop = ln.pack_streams([inst] * 4, limit)
+    timed("C4 log_sorter 2^22 rows", cs, outer, loop, 4)
 # C5: 8 blobs (BASELINE: one per GPU)
-cs = zkgl.ConstraintSystem(zkgl.CSGeometry(60, 0, 8, 4), 1 << 21, 1 << 28)
-cs.configure_eip_4844(); cs.eip_4844_entry_point(4096); cs.pad_and_shrink()
-insts = []
-for k in range(8):
-    r = np.random.default_rng(0xC5 + k)
-    insts.append(en.instance(bytes(r.integers(0, 256, size=31 * 4096, dtype=np.uint8)), b"\x01" + bytes(r.integers(0, 256, size=31, dtype=np.uint8)), 4096))
-outer = np.array([i["outer"] for i in insts], dtype=np.uint64).T.copy()
-loop = np.array([r_ for i in insts for r_ in i["rows"]], dtype=np.uint64).T.copy()
-raw = loop.copy(); raw[:217] = 0
-timed("C5 eip_4844 8 blobs x 4096 chunks", cs, outer, raw, 8, seed_carried=1)
+if want("C5"):
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(60, 0, 8, 4), 1 << 21, 1 << 28)
+    cs.configure_eip_4844(); cs.eip_4844_entry_point(4096); cs.pad_and_shrink()
+    insts = []
+    for k in range(8):
+        r = np.random.default_rng(0xC5 + k)
+        insts.append(en.instance(bytes(r.integers(0, 256, size=31 * 4096, dtype=np.uint8)), b"\x01" + bytes(r.integers(0, 256, size=31, dtype=np.uint8)), 4096))
+    outer = np.array([i["outer"] for i in insts], dtype=np.uint64).T.copy()
+    loop = np.array([r_ for i in insts for r_ in i["rows"]], dtype=np.uint64).T.copy()
+    raw = loop.copy(); raw[:217] = 0
+    timed("C5 eip_4844 8 blobs x 4096 chunks", cs, outer, raw, 8, seed_carried=1)
