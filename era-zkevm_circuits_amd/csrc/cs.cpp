@@ -89,6 +89,8 @@ CS::~CS() {
 
 void CS::free_scope_device(Scope& s) {
     if (s.d_prog) hipFree(s.d_prog);
+    if (s.d_sprog) hipFree(s.d_sprog);
+    s.d_sprog = nullptr;
     if (s.d_consts) hipFree(s.d_consts);
     if (s.d_rows) hipFree(s.d_rows);
     if (s.d_rowconsts) hipFree(s.d_rowconsts);
@@ -572,6 +574,106 @@ void CS::schedule_loop_ops() {
 }
 
 // ------------------------------------------------------------------ program emission
+// header, operand words, destination lists of one op
+void CS::emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const {
+    out.push_back((uint32_t)op.opcode | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
+    for (auto& in : op.ins) {
+        switch (in.kind) {
+        case Operand::VAR: out.push_back(s.var_cells[in.idx][0]); break;
+        case Operand::CONSTPOOL: out.push_back(ZK_OPERAND_CONST | in.idx); break;
+        case Operand::OUTER_VAR: out.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]); break;
+        case Operand::RAW:
+            if (op.opcode == ZK_OP_LOOP_LAST) out.push_back(loop_.var_cells[in.idx][0]);
+            else out.push_back(in.idx);
+            break;
+        }
+    }
+    for (uint32_t ov : op.outs) {
+        const auto& cells = s.var_cells[ov];
+        for (size_t i = 0; i < cells.size(); ++i) out.push_back(cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0));
+    }
+}
+
+// Strand form of a scope's program (kernels_engine.hpp k_witness_strands).  Per phase: level(op) = 1 + the deepest producer of
+// its operands inside the phase; the ops of a level are independent of each other and are dealt out over the 8 strands
+// (heaviest first, always to the lightest strand); every strand ends the level with ZK_OP_BARRIER.  Values cross strands only
+// through the cells, between levels.
+void CS::build_strands(Scope& s) {
+    constexpr uint32_t NS = zkdev::STRANDS_PER_TILE;
+    s.sprog.clear();
+    if (s.n_cells >= (1u << 23)) return;  // wide scopes keep the plain kernel
+    const size_t n_ops = s.ops.size();
+    size_t bounds[4] = {0, n_ops, n_ops, n_ops};
+    if (!s.is_loop) { bounds[1] = std::min(s.pre_ops, n_ops); bounds[2] = std::min(std::max(s.side_ops, bounds[1]), n_ops); }
+    std::vector<int64_t> producer(s.n_vars, -1);
+    std::vector<uint32_t> level(n_ops, 0);
+    std::vector<std::vector<uint32_t>> strand(NS);
+    for (int ph = 0; ph < 3; ++ph) {
+        const size_t o0 = bounds[ph], o1 = bounds[ph + 1];
+        uint32_t n_levels = 0;
+        for (size_t oi = o0; oi < o1; ++oi) {
+            const OpRec& op = s.ops[oi];
+            if (op.seed_only) continue;
+            uint32_t lv = 0;
+            for (auto& in : op.ins)
+                if (in.kind == Operand::VAR && producer[in.idx] >= (int64_t)o0) lv = std::max(lv, level[producer[in.idx]] + 1);
+            level[oi] = lv;
+            n_levels = std::max(n_levels, lv + 1);
+            for (uint32_t ov : op.outs) producer[ov] = (int64_t)oi;
+        }
+        std::vector<std::vector<uint32_t>> by_level(n_levels);
+        for (size_t oi = o0; oi < o1; ++oi)
+            if (!s.ops[oi].seed_only) by_level[level[oi]].push_back((uint32_t)oi);
+        auto cost = [&](uint32_t oi) -> uint64_t {
+            const OpRec& op = s.ops[oi];
+            uint64_t c = 8 + op.ins.size();
+            for (uint32_t ov : op.outs) c += 2 * s.var_cells[ov].size();
+            if (op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2) c += 4000;
+            if (op.opcode == ZK_OP_NN_MULMOD) c += 2000;
+            return c;
+        };
+        for (auto& st : strand) st.clear();
+        uint64_t total = 0, critical = 0;
+        for (uint32_t lv = 0; lv < n_levels; ++lv) {
+            auto& ops = by_level[lv];
+            std::stable_sort(ops.begin(), ops.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
+            uint64_t load[NS] = {0};
+            for (uint32_t oi : ops) {
+                uint32_t best = 0;
+                for (uint32_t k = 1; k < NS; ++k) if (load[k] < load[best]) best = k;
+                load[best] += cost(oi);
+                emit_op(s, s.ops[oi], strand[best]);
+            }
+            for (uint32_t k = 0; k < NS; ++k) total += load[k];
+            critical += *std::max_element(load, load + NS) + 200;  // + the barrier: every strand drains its stores
+            if (lv + 1 < n_levels) for (auto& st : strand) st.push_back(ZK_OP_BARRIER);
+        }
+        s.s_gain[ph] = critical ? (float)total / (float)critical : 0.f;
+        if (getenv("ZKGL_STRANDS_DEBUG") && o1 > o0)
+            fprintf(stderr, "[zkgl] strands %s phase %d: %zu ops, %u levels, estimated gain %.2f\n", s.is_loop ? "loop" : "outer", ph, o1 - o0, n_levels, s.s_gain[ph]);
+        for (uint32_t k = 0; k < NS; ++k) {
+            s.s_begin[ph][k] = (uint32_t)s.sprog.size();
+            s.sprog.insert(s.sprog.end(), strand[k].begin(), strand[k].end());
+            s.s_end[ph][k] = (uint32_t)s.sprog.size();
+        }
+        s.s_levels[ph] = n_levels;
+    }
+}
+
+void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t word_begin, uint32_t word_end, void* stream) const {
+    const char* e = getenv("ZKGL_STRANDS");  // 0 off, 1 always, unset: by size and estimated gain
+    const int mode = e ? atoi(e) : -1;
+    const uint32_t waves = (s.n_lanes + 63) / 64;
+    // worth it when the scope is short of wavefronts AND its op graph is wide (hash circuits); chains of Poseidon2
+    // permutations (queue circuits, the commitments of every outer scope) only pay for the barriers.  A scope of a few
+    // wavefronts (outer scopes) has the chip to itself and takes any gain; one of hundreds needs a clear one (measured:
+    // log_sorter's loop body at an estimated 2.8 runs 1.4x slower in strand form, keccak's at 3.7 runs 1.9x faster).
+    const bool strands = s.d_sprog && mode != 0 && (mode == 1 || (waves <= 1024 && s.s_gain[phase] >= (waves <= 64 ? 1.5f : 3.2f)));
+    if (!strands) { dev_check(zkdev::launch_witness(a, word_begin, word_end, stream)); return; }
+    a.prog = s.d_sprog; a.n_words = (uint32_t)s.sprog.size();
+    dev_check(zkdev::launch_witness_strands(a, s.s_begin[phase], s.s_end[phase], stream));
+}
+
 void CS::emit_scope(Scope& s) {
     std::vector<uint8_t> defined(s.n_vars, 0);
     s.prog.clear();
@@ -582,27 +684,13 @@ void CS::emit_scope(Scope& s) {
         if (!s.is_loop && oi == s.side_ops) s.side_words = (uint32_t)s.prog.size();
         const OpRec& op = s.ops[oi];
         if (op.seed_only) continue;
-        s.prog.push_back((uint32_t)op.opcode | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
-        for (auto& in : op.ins) {
-            switch (in.kind) {
-            case Operand::VAR:
-                if (!defined[in.idx]) throw ZkError(ZK_ERR_UNRESOLVED, "witness op reads a variable no earlier op produced");
-                s.prog.push_back(s.var_cells[in.idx][0]);
-                break;
-            case Operand::CONSTPOOL: s.prog.push_back(ZK_OPERAND_CONST | in.idx); break;
-            case Operand::OUTER_VAR: s.prog.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]); break;
-            case Operand::RAW:
-                if (op.opcode == ZK_OP_LOOP_LAST) s.prog.push_back(loop_.var_cells[in.idx][0]);
-                else s.prog.push_back(in.idx);
-                break;
-            }
-        }
+        for (auto& in : op.ins)
+            if (in.kind == Operand::VAR && !defined[in.idx]) throw ZkError(ZK_ERR_UNRESOLVED, "witness op reads a variable no earlier op produced");
+        emit_op(s, op, s.prog);
         for (uint32_t ov : op.outs) {
             if (defined[ov]) throw ZkError(ZK_ERR_INVALID, "variable produced twice");
             defined[ov] = 1;
-            const auto& cells = s.var_cells[ov];
-            for (size_t i = 0; i < cells.size(); ++i) s.prog.push_back(cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0));
-            s.cells_written += cells.size();
+            s.cells_written += s.var_cells[ov].size();
         }
     }
     if (!s.is_loop && s.pre_ops >= s.ops.size()) s.pre_words = (uint32_t)s.prog.size();
@@ -703,6 +791,11 @@ void CS::upload_scope(Scope& s) {
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
         s.d_prog = upload(padded);
     }
+    if (!s.sprog.empty()) {
+        std::vector<uint32_t> padded(s.sprog);
+        padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
+        s.d_sprog = upload(padded);
+    }
     s.d_consts = upload(s.const_pool);
     s.d_rows = upload(s.rows);
     s.d_rowconsts = upload(s.rowconsts);
@@ -729,6 +822,8 @@ void CS::finalize() {
     schedule_loop_ops();
     emit_scope(outer_);
     emit_scope(loop_);
+    build_strands(outer_);
+    if (limit_) build_strands(loop_);
     uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
     if (!loop_done_) rows = outer_.n_slots;
     if (rows > max_trace_len_) throw ZkError(ZK_ERR_CAPACITY, "trace rows exceed max_trace_len");
@@ -890,11 +985,12 @@ void CS::resolve(void* stream) {
     auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
     hip_check(hipEventRecord((hipEvent_t)ev_[0], st), "event");
-    dev_check(zkdev::launch_witness(oa, 0, outer_.pre_words, st));
+    launch_phase(outer_, oa, 0, 0, outer_.pre_words, st);
     hip_check(hipEventRecord((hipEvent_t)ev_[1], st), "event");
-    if (limit_) dev_check(zkdev::launch_witness(la, 0, (uint32_t)loop_.prog.size(), st));
+    if (limit_) launch_phase(loop_, la, 0, 0, (uint32_t)loop_.prog.size(), st);
     hip_check(hipEventRecord((hipEvent_t)ev_[2], st), "event");
-    dev_check(zkdev::launch_witness(oa, outer_.pre_words, (uint32_t)outer_.prog.size(), st));
+    launch_phase(outer_, oa, 1, outer_.pre_words, outer_.side_words, st);
+    launch_phase(outer_, oa, 2, outer_.side_words, (uint32_t)outer_.prog.size(), st);
     hip_check(hipEventRecord((hipEvent_t)ev_[3], st), "event");
     hip_check(hipStreamSynchronize(st), "resolve sync");
     float a = 0, b = 0, c = 0;
@@ -1065,15 +1161,15 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
     hip_check(hipEventRecord(E(0), st), "event");                     // t0 (+ memsets done)
     hip_check(hipStreamWaitEvent(ax, E(0), 0), "wait");
-    dev_check(zkdev::launch_witness(oa, 0, outer_.pre_words, ax));    // outer PRE
+    launch_phase(outer_, oa, 0, 0, outer_.pre_words, ax);    // outer PRE
     hip_check(hipEventRecord(E(1), ax), "event");
     hip_check(hipStreamWaitEvent(st, E(1), 0), "wait");
     hip_check(hipEventRecord(E(2), st), "event");
-    if (limit_) dev_check(zkdev::launch_witness(la, 0, (uint32_t)loop_.prog.size(), st));   // LOOP
+    if (limit_) launch_phase(loop_, la, 0, 0, (uint32_t)loop_.prog.size(), st);   // LOOP
     hip_check(hipEventRecord(E(3), st), "event");
-    dev_check(zkdev::launch_witness(oa, outer_.pre_words, outer_.side_words, ax));             // outer SIDE (|| LOOP)
+    launch_phase(outer_, oa, 1, outer_.pre_words, outer_.side_words, ax);             // outer SIDE (|| LOOP)
     hip_check(hipStreamWaitEvent(ax, E(3), 0), "wait");
-    dev_check(zkdev::launch_witness(oa, outer_.side_words, (uint32_t)outer_.prog.size(), ax));  // outer POST
+    launch_phase(outer_, oa, 2, outer_.side_words, (uint32_t)outer_.prog.size(), ax);  // outer POST
     dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_), ax));
     dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies,
                                          (uint32_t)outer_.copies.size(), d_fail_, ax));

@@ -82,6 +82,11 @@ struct Scope {
     std::vector<std::vector<uint32_t>> var_cells;  // per var: cells, [0] = home
     std::vector<uint32_t> prog;
     uint32_t pre_words = 0, side_words = 0;
+    // strand form of the program (build_strands): phase 0 = loop body / outer pre, 1 = outer side, 2 = outer post
+    std::vector<uint32_t> sprog;
+    uint32_t s_begin[3][8] = {}, s_end[3][8] = {};
+    uint32_t s_levels[3] = {0, 0, 0};
+    float s_gain[3] = {0, 0, 0};  // estimated work / critical path over 8 strands: the strand form is used from 3 upwards
     std::vector<zk_row_desc> rows;
     std::vector<uint64_t> rowconsts;
     std::vector<zk_lookup_row_desc> lrows;
@@ -92,6 +97,7 @@ struct Scope {
 
     // ---- device ----
     uint32_t* d_prog = nullptr;
+    uint32_t* d_sprog = nullptr;
     uint64_t* d_consts = nullptr;
     zk_row_desc* d_rows = nullptr;
     uint64_t* d_rowconsts = nullptr;
@@ -182,6 +188,10 @@ class CS {
     void place_scope(Scope& s);
     void schedule_loop_ops();
     void emit_scope(Scope& s);
+    void emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const;
+    void build_strands(Scope& s);
+    // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
+    void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t word_begin, uint32_t word_end, void* stream) const;
     void upload_scope(Scope& s);
     void ensure_uploaded();
     void free_scope_device(Scope& s);

@@ -35,6 +35,9 @@ int launch_execution_context_encode(const uint64_t* rec, size_t n, uint64_t* enc
 int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* ch, size_t enc_len, size_t n,
                          uint64_t init, uint64_t* acc, uint64_t* scratch, void* stream);
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, void* stream);
+// strand mode (kernels_engine.hpp k_witness_strands): sc.prog = the strand program, begin/end = 8 word ranges
+constexpr uint32_t STRANDS_PER_TILE = 8;
+int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[8], const uint32_t end[8], void* stream);
 struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // mirrors zke::CarryDev
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);

@@ -242,7 +242,7 @@ __device__ __noinline__ void sha256_compress(uint32_t* st, const uint32_t* blk) 
 // address arithmetic per load / store (`buffer_store_dwordx2 v[d], v_off, s[rsrc], s_cell offen`).  The host
 // uses these kernels only when cell * 512 < 2^32 (n_cells < 2^23); larger scopes run the `_wide` variants with plain
 // 64-bit global addressing.
-template <bool WITH_BIGINT, bool SLOTS = false, bool TILE_UNIFORM = false>
+template <bool WITH_BIGINT, bool SLOTS = false, bool TILE_UNIFORM = false, int BLOCK = TPB, bool STRANDS = false>
 __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                          uint32_t word_begin, uint32_t word_end, const uint32_t* prog = nullptr,
                                          uint64_t* slots = nullptr, uint32_t slot_stride = 0, const uint64_t* in_area = nullptr) {
@@ -264,7 +264,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
     }
     ProgWindow P;
     P.init(SLOTS ? prog : sc.prog, word_begin);
-    __shared__ uint64_t p2s[12 * TPB];  // Poseidon2 state, [element][thread]
+    __shared__ uint64_t p2s[12 * BLOCK];  // Poseidon2 state, [element][thread]
 
     auto ld = [&](uint32_t w) -> uint64_t {
         const uint32_t kind = w & ZK_OPERAND_KIND_MASK, idx = w & ZK_OPERAND_IDX_MASK;
@@ -441,10 +441,10 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             pc += 12;
             p2::mds_external(s);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) p2s[i * TPB + threadIdx.x] = s[i];
+            for (int i = 0; i < 12; ++i) p2s[i * BLOCK + threadIdx.x] = s[i];
             if (emit) {
 #pragma unroll 1
-                for (int i = 0; i < 12; ++i) st(p2s[i * TPB + threadIdx.x]);
+                for (int i = 0; i < 12; ++i) st(p2s[i * BLOCK + threadIdx.x]);
             }
 #pragma unroll 1
             for (int r = 0; r < 30; ++r) {
@@ -452,28 +452,28 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                 const int n = full ? 12 : 1;
 #pragma unroll 1
                 for (int i = 0; i < n; ++i) {
-                    uint64_t t = gl::add(p2s[i * TPB + threadIdx.x], p2::RC[12 * r + i]);
+                    uint64_t t = gl::add(p2s[i * BLOCK + threadIdx.x], p2::RC[12 * r + i]);
 #ifdef ZKGL_STUB_P2  // time attribution only (tools/stub_bench.sh): the S-box without its four multiplications
                     uint64_t x2 = t ^ 1, x3 = t ^ 2, x4 = t ^ 3, x7 = t ^ 4;
 #else
                     uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
 #endif
                     if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
-                    p2s[i * TPB + threadIdx.x] = x7;
+                    p2s[i * BLOCK + threadIdx.x] = x7;
                 }
 #pragma unroll
-                for (int i = 0; i < 12; ++i) s[i] = p2s[i * TPB + threadIdx.x];
+                for (int i = 0; i < 12; ++i) s[i] = p2s[i * BLOCK + threadIdx.x];
                 if (full) p2::mds_external(s); else p2::mds_inner(s);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) p2s[i * TPB + threadIdx.x] = s[i];
+                for (int i = 0; i < 12; ++i) p2s[i * BLOCK + threadIdx.x] = s[i];
                 if (emit) {
 #pragma unroll 1
-                    for (int i = 0; i < 12; ++i) st(p2s[i * TPB + threadIdx.x]);
+                    for (int i = 0; i < 12; ++i) st(p2s[i * BLOCK + threadIdx.x]);
                 }
             }
             if (!emit) {
 #pragma unroll 1
-                for (int i = 0; i < 12; ++i) st(p2s[i * TPB + threadIdx.x]);
+                for (int i = 0; i < 12; ++i) st(p2s[i * BLOCK + threadIdx.x]);
             }
         } break;
         case ZK_OP_LOOP_LAST: {
@@ -542,6 +542,12 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             st(x / pb);
             st(x % pb);
         } break;
+        case ZK_OP_BARRIER: if constexpr (STRANDS) {
+            // end of a dependency level: this strand's stores must be visible to the other wavefronts of the tile (same CU,
+            // shared L1) before any of them starts the next level
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else { return; } break;
         default:
             return;  // malformed program: host validates before upload
         }
@@ -573,6 +579,22 @@ __global__ __launch_bounds__(TPB) void k_witness_loop_bigint(ScopeDev sc, uint32
 }
 __global__ __launch_bounds__(TPB) void k_witness_outer_bigint(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
     witness_entry<true>(sc, word_begin, word_end);
+}
+
+// Strand mode: a scope with too few lanes to fill the chip (hash circuits: lanes = instances x cycles; every outer scope:
+// lanes = instances) runs one 64-lane tile per BLOCK of 8 wavefronts.  Wavefront w walks strand w of the program: the ops of
+// every dependency level of the op graph are dealt out over the strands by the host (cs.cpp build_strands) and a
+// ZK_OP_BARRIER separates the levels.  The trace is the same, cell for cell.
+constexpr int STRANDS_PER_TILE = 8;
+struct StrandTab { uint32_t begin[STRANDS_PER_TILE], end[STRANDS_PER_TILE]; };
+template <bool WITH_BIGINT>
+__global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_witness_strands(ScopeDev sc, StrandTab tab) {
+    if (blockIdx.x * 64 >= sc.n_lanes) return;
+    const uint32_t w = uni(threadIdx.x >> 6);
+    uint32_t lane = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool active = lane < sc.n_lanes;
+    lane = active ? lane : sc.n_lanes - 1;
+    run_lane<WITH_BIGINT, false, true, 64 * STRANDS_PER_TILE, true>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, tab.begin[w], tab.end[w]);
 }
 
 // Sequential seeding mode (generic, slow): thread == instance, iterations in order.  Before

@@ -114,6 +114,19 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
     return LAUNCH_CHECK("k_witness");
 }
 
+int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[8], const uint32_t end[8], void* stream) {
+    if (sc.n_lanes == 0) return 0;
+    static_assert(zke::STRANDS_PER_TILE == (int)STRANDS_PER_TILE, "strand count");
+    zke::StrandTab tab;
+    bool any = false;
+    for (int i = 0; i < zke::STRANDS_PER_TILE; ++i) { tab.begin[i] = begin[i]; tab.end[i] = end[i]; any |= end[i] > begin[i]; }
+    if (!any) return 0;
+    const unsigned grid = grid_for(sc.n_lanes, 64);
+    if (sc.uses_bigint) zke::k_witness_strands<true><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
+    else zke::k_witness_strands<false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
+    return LAUNCH_CHECK("k_witness_strands");
+}
+
 int launch_witness_seq(const ScopeArgs& sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream) {
     if (n_instances == 0 || sc.limit == 0) return 0;

@@ -60,6 +60,9 @@ enum zk_opcode {
                                * Keccak-f[1600](state ^ (block | 0^64))                        (keccak256_absorb_and_run_permutation) */
     ZK_OP_SHA256_COMPRESS = 21,/* [state bytes x32 (word w little-endian at 4w), block bytes x64 (word j little-endian at 4j)]
                                * -> state bytes x32                                            (round_function_over_uint32) */
+    /* strand programs only (never recorded, never exported): a scope short of wavefronts runs as 8 strands per 64-lane tile,
+     * one wavefront each, with a workgroup barrier between the dependency levels of the op graph (cs.cpp build_strands) */
+    ZK_OP_BARRIER = 22,
     ZK_OP__COUNT
 };
 

@@ -490,6 +490,20 @@ def test_keccak256_round_function_fsm_gpu(zk):
     run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
     run.resolve(outer, loop)
     assert_trace_equal(cs, run)
+    # the strand form of the programs (8 wavefronts per tile, barriers between dependency levels) and the plain form fill
+    # the same cells: force each in turn (by default this circuit's loop body runs as strands, its outer phases do not)
+    traces = {}
+    for mode in ("0", "1"):
+        os.environ["ZKGL_STRANDS"] = mode
+        try:
+            cs.resolve()
+            ok, f = cs.check_if_satisfied()
+            assert ok, (mode, f)
+            traces[mode] = (cs.trace(False).copy(), cs.trace(True).copy())
+        finally:
+            del os.environ["ZKGL_STRANDS"]
+    assert np.array_equal(traces["0"][0], traces["1"][0]) and np.array_equal(traces["0"][1], traces["1"][1])
+    assert np.array_equal(traces["1"][1], run.lc) and np.array_equal(traces["1"][0], run.oc)
     bad = loop.copy()
     bad[460, 12 * limit] ^= 1   # instance 12 = reference case (180, 0): corrupt its first memory read
     d_b = zk.DeviceBuffer.from_numpy(bad)
