@@ -71,6 +71,8 @@ CS::~CS() {
     if (d_mult_) hipFree(d_mult_);
     if (d_links_) hipFree(d_links_);
     if (d_seed_prog_) hipFree(d_seed_prog_);
+    if (d_seed_sprog_) hipFree(d_seed_sprog_);
+    if (d_seed_scarries_) hipFree(d_seed_scarries_);
     if (d_seed_carries_) hipFree(d_seed_carries_);
     for (auto p : d_streams_) if (p) hipFree(p);
     if (d_carries_) hipFree(d_carries_);
@@ -783,6 +785,103 @@ void CS::build_seed_program() {
     }
     seed_prog_ = std::move(prog);
     seed_slots_ = n_slots;
+
+    // ---- strand form of the same cone (k_seed_cone_strands): one iteration is a latency chain for a single wavefront, but
+    // its op graph is wide (independent sponges, byte decompositions).  Ops are ordered by dependency level, dealt over 8
+    // strands per level, and an LDS slot is recycled only at the level after its last reader (readers of a level run
+    // concurrently with that level's writers).
+    seed_sprog_.clear(); seed_scarries_.clear(); seed_sslots_ = 0; seed_sgain_ = 0;
+    constexpr uint32_t NS = zkdev::STRANDS_PER_TILE;
+    std::vector<int64_t> producer(s.n_vars, -1);
+    std::vector<uint32_t> level(s.ops.size(), 0);
+    uint32_t n_levels = 0;
+    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+        if (!keep[oi]) continue;
+        uint32_t lv = 0;
+        for (auto& in : s.ops[oi].ins)
+            if (in.kind == Operand::VAR && producer[in.idx] >= 0) lv = std::max(lv, level[producer[in.idx]] + 1);
+        level[oi] = lv;
+        n_levels = std::max(n_levels, lv + 1);
+        const OpRec& op = s.ops[oi];
+        for (size_t i = op.opcode == ZK_OP_P2_ROUNDS ? op.outs.size() - 12 : 0; i < op.outs.size(); ++i) producer[op.outs[i]] = (int64_t)oi;
+    }
+    std::vector<std::vector<uint32_t>> by_level(n_levels);
+    std::vector<int64_t> last_level(s.n_vars, -1);
+    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+        if (!keep[oi]) continue;
+        by_level[level[oi]].push_back((uint32_t)oi);
+        for (auto& in : s.ops[oi].ins)
+            if (in.kind == Operand::VAR) last_level[in.idx] = std::max<int64_t>(last_level[in.idx], level[oi]);
+    }
+    for (auto v : out_vars) last_level[v] = INF;
+    auto cost = [&](uint32_t oi) -> uint64_t {
+        const OpRec& op = s.ops[oi];
+        uint64_t c = 8 + op.ins.size() + 2 * op.outs.size();
+        if (op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2) c = 4000;
+        if (op.opcode == ZK_OP_NN_MULMOD) c += 2000;
+        if (op.opcode == ZK_OP_KECCAK_ABSORB) c = 20000;
+        if (op.opcode == ZK_OP_SHA256_COMPRESS) c = 6000;
+        return c;
+    };
+    std::fill(slot_of.begin(), slot_of.end(), UINT32_MAX);
+    free_slots.clear();
+    uint32_t ns = 0;
+    std::vector<std::vector<uint32_t>> strand(NS);
+    std::vector<std::vector<uint32_t>> dying(n_levels);  // slots whose last reader sits at this level
+    uint64_t total = 0, critical = 0;
+    for (uint32_t lv = 0; lv < n_levels; ++lv) {
+        auto& ops = by_level[lv];
+        std::stable_sort(ops.begin(), ops.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
+        uint64_t load[NS] = {0};
+        for (uint32_t oi : ops) {
+            uint32_t best = 0;
+            for (uint32_t k = 1; k < NS; ++k) if (load[k] < load[best]) best = k;
+            load[best] += cost(oi);
+            const OpRec& op = s.ops[oi];
+            const bool collapse = op.opcode == ZK_OP_P2_ROUNDS;
+            auto& out = strand[best];
+            out.push_back((collapse ? (uint32_t)ZK_OP_POSEIDON2 : (uint32_t)op.opcode) | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
+            for (auto& in : op.ins) {
+                switch (in.kind) {
+                case Operand::VAR: out.push_back(slot_of[in.idx]); break;
+                case Operand::CONSTPOOL: out.push_back(ZK_OPERAND_CONST | in.idx); break;
+                case Operand::OUTER_VAR: out.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]); break;
+                case Operand::RAW: out.push_back(in.idx); break;
+                }
+            }
+            for (size_t i = collapse ? op.outs.size() - 12 : 0; i < op.outs.size(); ++i) {
+                const uint32_t ov = op.outs[i];
+                if (last_level[ov] < 0) { out.push_back(DISCARD_MARK); continue; }
+                uint32_t sl;
+                if (!free_slots.empty()) { sl = free_slots.back(); free_slots.pop_back(); }
+                else sl = ns++;
+                slot_of[ov] = sl;
+                out.push_back(sl);
+                if (last_level[ov] != INF) dying[(size_t)std::max<int64_t>(last_level[ov], lv)].push_back(sl);
+            }
+        }
+        for (uint32_t k = 0; k < NS; ++k) total += load[k];
+        critical += *std::max_element(load, load + NS) + 40;  // LDS barrier: no store drain
+        for (uint32_t sl : dying[lv]) free_slots.push_back(sl);  // free from the next level on
+        if (lv + 1 < n_levels) for (auto& st : strand) st.push_back(ZK_OP_BARRIER);
+    }
+    const uint32_t sdiscard = ns++;
+    if (ns + s.n_input_words > zkdev::seed_cone_max_slots()) return;
+    for (uint32_t k = 0; k < NS; ++k) {
+        seed_sbegin_[k] = (uint32_t)seed_sprog_.size();
+        for (uint32_t w : strand[k]) seed_sprog_.push_back(w == DISCARD_MARK ? sdiscard : w);
+        seed_send_[k] = (uint32_t)seed_sprog_.size();
+    }
+    for (size_t i = 0; i < carries_.size(); ++i) {
+        Carry c = carries_[i];
+        if (slot_of[out_vars[i]] == UINT32_MAX) { seed_sprog_.clear(); return; }
+        c.out_cell = slot_of[out_vars[i]];
+        seed_scarries_.push_back(c);
+    }
+    seed_sslots_ = ns;
+    seed_sgain_ = critical ? (float)total / (float)critical : 0.f;
+    if (getenv("ZKGL_STRANDS_DEBUG"))
+        fprintf(stderr, "[zkgl] seed cone: %u ops, %u levels, %u slots (plain %u), estimated gain %.2f\n", seed_ops_, n_levels, ns, n_slots, seed_sgain_);
 }
 
 void CS::upload_scope(Scope& s) {
@@ -901,6 +1000,12 @@ void CS::ensure_uploaded() {
         d_seed_prog_ = upload(padded);
         d_seed_carries_ = (void*)upload(seed_carries_);
     }
+    if (!seed_sprog_.empty()) {
+        std::vector<uint32_t> padded(seed_sprog_);
+        padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
+        d_seed_sprog_ = upload(padded);
+        d_seed_scarries_ = (void*)upload(seed_scarries_);
+    }
     hip_check(hipMalloc((void**)&d_fail_, 8 * sizeof(unsigned long long)), "hipMalloc fail words");
     for (auto& e : ev_) {
         hipEvent_t he;
@@ -967,7 +1072,13 @@ void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
     dev_check(zkdev::launch_witness(oa, 0, outer_.pre_words, st));
     const char* force_generic = std::getenv("ZKGL_SEED_GENERIC");
-    if (d_seed_prog_ && !(force_generic && force_generic[0] == '1'))
+    const char* seed_strands = std::getenv("ZKGL_SEED_STRANDS");  // 0: plain cone, 1: strand form whenever it exists
+    const bool generic = force_generic && force_generic[0] == '1';
+    const bool use_strands = d_seed_sprog_ && !(seed_strands && seed_strands[0] == '0') && ((seed_strands && seed_strands[0] == '1') || seed_sgain_ >= 1.5f);
+    if (use_strands && !generic)
+        dev_check(zkdev::launch_seed_cone_strands(la, d_seed_sprog_, seed_sbegin_, seed_send_, seed_sslots_, loop_.n_input_words,
+                                                  (const zkdev::CarryArgs*)d_seed_scarries_, (uint32_t)seed_scarries_.size(), dev_loop_inputs_rw, batch_, st));
+    else if (d_seed_prog_ && !generic)
         dev_check(zkdev::launch_seed_cone(la, d_seed_prog_, (uint32_t)seed_prog_.size(), seed_slots_, loop_.n_input_words, (const zkdev::CarryArgs*)d_seed_carries_,
                                           (uint32_t)seed_carries_.size(), dev_loop_inputs_rw, batch_, st));
     else

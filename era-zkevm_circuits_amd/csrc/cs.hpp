@@ -237,6 +237,13 @@ class CS {
     uint32_t seed_slots_ = 0, seed_ops_ = 0;
     uint32_t* d_seed_prog_ = nullptr;
     void* d_seed_carries_ = nullptr;
+    // strand form of the cone (8 wavefronts per block, level barriers; slots recycled per level)
+    std::vector<uint32_t> seed_sprog_;
+    std::vector<Carry> seed_scarries_;
+    uint32_t seed_sslots_ = 0, seed_sbegin_[8] = {}, seed_send_[8] = {};
+    float seed_sgain_ = 0;
+    uint32_t* d_seed_sprog_ = nullptr;
+    void* d_seed_scarries_ = nullptr;
     // K12: sigma = per-cell image inside the scope / iteration + absolute labels of the link endpoints [endpoint][iteration]
     void build_sigma();
     bool sigma_built_ = false;

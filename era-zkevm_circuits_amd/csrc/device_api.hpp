@@ -83,6 +83,8 @@ int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t*
 // cone seeding: seed_prog in device memory (padded like every program), carries = {input word, out slot, first outer cell, has_first}
 int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_words, uint32_t n_slots, uint32_t n_input_words,
                      const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream);
+int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, const uint32_t begin[8], const uint32_t end[8], uint32_t n_slots,
+                             uint32_t n_input_words, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream);
 uint32_t seed_cone_max_slots();
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
                         const uint32_t* a_cells, uint32_t pa, const uint32_t* b_cells, uint32_t pb, uint32_t n_total,

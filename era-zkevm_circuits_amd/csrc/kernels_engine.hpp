@@ -671,6 +671,45 @@ __global__ __launch_bounds__(64) void k_seed_cone(ScopeDev sc, const uint32_t* _
     }
 }
 
+// Strand form of the cone (cs.cpp build_seed_program, second half): the block is 8 wavefronts, wavefront w walks strand w of
+// the level-ordered cone with an LDS barrier between levels — one iteration's independent sponges and decompositions run side
+// by side instead of as one latency chain.
+template <bool WITH_BIGINT>
+__global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_seed_cone_strands(ScopeDev sc, const uint32_t* __restrict__ seed_sprog, StrandTab tab,
+                                                                            const SeedCarryDev* carries, uint32_t n_carries, uint64_t* inputs_rw,
+                                                                            uint32_t n_instances, uint32_t lpb, uint32_t n_slots, uint32_t n_input_words) {
+    constexpr uint32_t NT = 64 * STRANDS_PER_TILE;
+    __shared__ uint64_t lds[SEED_LDS_WORDS];
+    if (blockIdx.x * lpb >= n_instances) return;
+    uint64_t* const slot_store = lds;
+    uint64_t* const in_store = lds + n_slots * lpb;
+    const uint32_t w = uni(threadIdx.x >> 6);
+    const uint32_t l = (threadIdx.x & 63) % lpb;
+    const uint32_t inst = min(blockIdx.x * lpb + l, n_instances - 1);
+    const uint32_t ml = inst - blockIdx.x * lpb;
+    const uint32_t wb = tab.begin[w], we = tab.end[w];
+    for (uint32_t k = 0; k < sc.limit; ++k) {
+        for (uint32_t idx = threadIdx.x; idx < n_input_words * lpb; idx += NT) {
+            const uint32_t wd = idx / lpb, ll = idx % lpb;
+            const uint32_t li = min(blockIdx.x * lpb + ll, n_instances - 1);
+            in_store[wd * lpb + li - blockIdx.x * lpb] = inputs_rw[(size_t)wd * sc.n_lanes + (size_t)li * sc.limit + k];
+        }
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < n_carries * lpb; idx += NT) {
+            const SeedCarryDev cd = carries[idx / lpb];
+            const uint32_t ll = idx % lpb;
+            const uint32_t li = min(blockIdx.x * lpb + ll, n_instances - 1), col = li - blockIdx.x * lpb;
+            if (k == 0 && !cd.has_first) continue;
+            const uint64_t v = k == 0 ? sc.outer_cells[cell_off(sc.outer_n_cells, cd.first_outer_cell, li)] : slot_store[cd.out_slot * lpb + col];
+            in_store[cd.word * lpb + col] = v;
+            inputs_rw[(size_t)cd.word * sc.n_lanes + (size_t)li * sc.limit + k] = v;
+        }
+        __syncthreads();
+        run_lane<WITH_BIGINT, true, false, (int)NT, true>(sc, inst * sc.limit + k, inst, false, wb, we, seed_sprog, slot_store + ml, lpb, in_store + ml);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K7: per-row gate evaluation (check_if_satisfied counterpart,
 // /root/reference/src/ram_permutation/mod.rs:556).  grid = (lane tiles, slot chunks); the gate

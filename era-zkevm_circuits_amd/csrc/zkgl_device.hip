@@ -289,6 +289,26 @@ int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_
     return LAUNCH_CHECK("k_seed_cone");
 }
 
+int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, const uint32_t begin[8], const uint32_t end[8], uint32_t n_slots,
+                             uint32_t n_input_words, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream) {
+    if (n_instances == 0 || sc.limit == 0) return 0;
+    const uint32_t per_lane = n_slots + n_input_words;
+    if (n_slots == 0 || per_lane > zke::SEED_LDS_WORDS) return -1;
+    uint32_t lpb = 1;
+    while (lpb < 16 && per_lane * (lpb * 2) <= zke::SEED_LDS_WORDS) lpb *= 2;
+    // few instances: spread them over more blocks (each block is a latency chain of sc.limit iterations)
+    while (lpb > 1 && (n_instances + lpb - 1) / lpb < 128 && (n_instances + lpb / 2 - 1) / (lpb / 2) <= 256) lpb /= 2;
+    const unsigned grid = (n_instances + lpb - 1) / lpb;
+    zke::StrandTab tab;
+    for (int i = 0; i < zke::STRANDS_PER_TILE; ++i) { tab.begin[i] = begin[i]; tab.end[i] = end[i]; }
+    auto c = reinterpret_cast<const zke::SeedCarryDev*>(d_carries);
+    if (sc.uses_bigint)
+        zke::k_seed_cone_strands<true><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
+    else
+        zke::k_seed_cone_strands<false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
+    return LAUNCH_CHECK("k_seed_cone_strands");
+}
+
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
                         const uint32_t* a_cells, uint32_t pa, const uint32_t* b_cells, uint32_t pb, uint32_t n_total,
                         uint32_t stream_index, unsigned long long* fail, void* stream) {
