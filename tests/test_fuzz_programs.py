@@ -135,3 +135,17 @@ def test_random_programs_gpu_equals_oracle(zk, seed):
     run.resolve(outer, seeded)
     assert run.check()[0] == 0
     assert np.array_equal(cs.trace(False), run.oc) and np.array_equal(cs.trace(True), run.lc)
+    # the same circuit with every program (witness phases and seeding cone) forced into strand form, then into plain form
+    import os
+    for strands in ("1", "0"):
+        os.environ["ZKGL_STRANDS"] = os.environ["ZKGL_SEED_STRANDS"] = strands
+        try:
+            d_l2 = zk.DeviceBuffer.from_numpy(loop)
+            cs.bind_inputs(True, d_l2, n_loop)
+            cs.seed_carried_inputs(d_l2)
+            assert np.array_equal(d_l2.to_numpy().reshape(loop.shape), seeded), strands
+            ok, f = cs.resolve_and_check()
+            assert ok, (strands, f)
+            assert np.array_equal(cs.trace(False), run.oc) and np.array_equal(cs.trace(True), run.lc), strands
+        finally:
+            del os.environ["ZKGL_STRANDS"], os.environ["ZKGL_SEED_STRANDS"]
