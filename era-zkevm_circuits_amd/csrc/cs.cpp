@@ -603,7 +603,6 @@ void CS::emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) co
 void CS::build_strands(Scope& s) {
     constexpr uint32_t NS = zkdev::STRANDS_PER_TILE;
     s.sprog.clear();
-    if (s.n_cells >= (1u << 23)) return;  // wide scopes keep the plain kernel
     const size_t n_ops = s.ops.size();
     size_t bounds[4] = {0, n_ops, n_ops, n_ops};
     if (!s.is_loop) { bounds[1] = std::min(s.pre_ops, n_ops); bounds[2] = std::min(std::max(s.side_ops, bounds[1]), n_ops); }

@@ -587,14 +587,14 @@ __global__ __launch_bounds__(TPB) void k_witness_outer_bigint(ScopeDev sc, uint3
 // ZK_OP_BARRIER separates the levels.  The trace is the same, cell for cell.
 constexpr int STRANDS_PER_TILE = 8;
 struct StrandTab { uint32_t begin[STRANDS_PER_TILE], end[STRANDS_PER_TILE]; };
-template <bool WITH_BIGINT>
+template <bool WITH_BIGINT, bool BUFFER_ADDRESSING = true>
 __global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_witness_strands(ScopeDev sc, StrandTab tab) {
     if (blockIdx.x * 64 >= sc.n_lanes) return;
     const uint32_t w = uni(threadIdx.x >> 6);
     uint32_t lane = blockIdx.x * 64 + (threadIdx.x & 63);
     const bool active = lane < sc.n_lanes;
     lane = active ? lane : sc.n_lanes - 1;
-    run_lane<WITH_BIGINT, false, true, 64 * STRANDS_PER_TILE, true>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, tab.begin[w], tab.end[w]);
+    run_lane<WITH_BIGINT, false, BUFFER_ADDRESSING, 64 * STRANDS_PER_TILE, true>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, tab.begin[w], tab.end[w]);
 }
 
 // Sequential seeding mode (generic, slow): thread == instance, iterations in order.  Before
