@@ -93,6 +93,15 @@ def test_width4_lookups_and_reduction_by_powers_on_the_gpu(zk):
     z = zbuf.to_numpy().reshape(B, rows + 1, 2)
     want_z = zko.copy_permutation_z(ho, hl, 0, cs.trace(False)[:, 77], [], sigma, (21, 22), (23, 24), n_cols)
     assert [tuple(int(x) for x in r) for r in z[77]] == want_z and want_z[-1] == (1, 0)
+    # trace columns of a loop-free circuit: the outer scope's rows, zero padded
+    log_n = int(rows - 1).bit_length()
+    cols = zk.DeviceBuffer(n_cols << log_n)
+    cs.trace_columns(77, cols, log_n)
+    zk.sync()
+    got = cols.to_numpy().reshape(n_cols, 1 << log_n)
+    to = cs.trace(False)
+    for c in (0, 7, n_cols - 1):
+        assert np.array_equal(got[c, :rows], to[c::n_cols][:rows, 77]) and not got[c, rows:].any()
     cs.write_cell(False, cs.public_cells()[1], 5, 12345)        # w1 of instance 5 no longer equals the powers sum
     ok, f = cs.check_if_satisfied()
     assert not ok and f.instance == 5 and f.kind == G["REDUCTION_BY_POWERS4"]
