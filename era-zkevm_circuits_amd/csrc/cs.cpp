@@ -142,6 +142,9 @@ uint32_t CS::add_table(uint32_t marker, uint32_t n_keys, uint32_t n_vals, const 
         if (i > 0 && std::memcmp(&t.rows[(size_t)i * w], &t.rows[(size_t)(i - 1) * w], n_keys * sizeof(uint64_t)) == 0)
             throw ZkError(ZK_ERR_INVALID, "add_table: duplicate key tuple");
     }
+    t.byte_valued = n_vals > 0;
+    for (uint32_t i = 0; i < n_rows && t.byte_valued; ++i)
+        for (uint32_t k = n_keys; k < w; ++k) t.byte_valued = t.byte_valued && t.rows[(size_t)i * w + k] < 256;
     // dense test: keys are a full product of power-of-two ranges, last key fastest
     t.dense = false;
     t.key_shift[0] = t.key_shift[1] = t.key_shift[2] = 0;
@@ -972,6 +975,22 @@ void CS::finalize() {
         d.word_off = t.word_off; d.mult_off = t.mult_off; d.n_rows = t.n_rows; d.n_keys = t.n_keys; d.n_vals = t.n_vals;
         d.dense = t.dense ? 1 : 0;
         for (int k = 0; k < 3; ++k) d.key_shift[k] = t.key_shift[k];
+    }
+    // Device-only packed copies of the dense byte-valued tables (xor8 / and8 / andn8 / byte splits ...): one byte per value,
+    // appended behind the rows; zk_table_desc.dense = 1 | 2 | (first word of the packed copy << 2).  A lookup then gathers
+    // from a 64 KB array instead of a 1.5 MB one, and dense tables need no key words at all (row index == packed key).
+    for (size_t i = 0; i < tables_.size(); ++i) {
+        const TableRec& t = tables_[i];
+        if (!t.dense || !t.byte_valued) continue;
+        const uint32_t w = t.n_keys + t.n_vals;
+        const size_t first = words.size();
+        if (first >= (1u << 29)) break;
+        std::vector<uint8_t> bytes((size_t)t.n_rows * t.n_vals);
+        for (uint32_t r = 0; r < t.n_rows; ++r)
+            for (uint32_t k = 0; k < t.n_vals; ++k) bytes[(size_t)r * t.n_vals + k] = (uint8_t)t.rows[(size_t)r * w + t.n_keys + k];
+        words.resize(first + (bytes.size() + 7) / 8, 0);
+        std::memcpy(&words[first], bytes.data(), bytes.size());
+        tdesc[i + 1].dense = 1u | 2u | ((uint32_t)first << 2);
     }
     tdesc_host_ = tdesc;
     table_words_host_ = words;

@@ -56,6 +56,7 @@ struct LookupRec {
 struct TableRec {
     uint32_t marker, n_keys, n_vals, n_rows;
     std::vector<uint64_t> rows;  // sorted by key tuple, row-major
+    bool byte_valued = false;    // every value column < 256: the device keeps a packed copy, one byte per value
     bool dense;
     uint32_t key_shift[3];
     uint32_t word_off, mult_off;

@@ -55,16 +55,18 @@ __device__ __forceinline__ uint32_t table_find(const zk_table_desc& t, const uin
     const uint32_t w = t.n_keys + t.n_vals;
     const uint64_t* rows = words + (size_t)t.word_off;
     if (t.dense) {
+        // full product of power-of-two key ranges, last key fastest: the row index is the packed key, and a key tuple is in
+        // the table iff every key is inside its range — no key words are read
         uint64_t idx = 0;
         bool ok = true;
+        uint32_t hi_bit = 31 - __clz(t.n_rows);  // n_rows = 2^(sum of the key widths)
         for (uint32_t i = 0; i < t.n_keys; ++i) {
+            const uint32_t bits = hi_bit - t.key_shift[i];
+            ok = ok && (key[i] >> bits) == 0;
             idx += key[i] << t.key_shift[i];
-            ok = ok && (key[i] >> 32) == 0;
+            hi_bit = t.key_shift[i];
         }
-        if (!ok || idx >= t.n_rows) return t.n_rows;
-        for (uint32_t i = 0; i < t.n_keys; ++i)
-            if (rows[idx * w + i] != key[i]) return t.n_rows;
-        return (uint32_t)idx;
+        return ok ? (uint32_t)idx : t.n_rows;
     }
     uint32_t lo = 0, hi = t.n_rows;  // rows sorted lexicographically by key tuple
     while (lo < hi) {
@@ -423,8 +425,13 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             uint32_t row = table_find(t, sc.table_words, key);
             const uint32_t w = t.n_keys + t.n_vals;
             bool found = row < t.n_rows;
-            for (uint32_t i = 0; i < pb; ++i)
-                st(found ? sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i] : 0ull);
+            if (t.dense & 2u) {  // packed byte copy of a dense byte-valued table
+                const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(sc.table_words + (t.dense >> 2));
+                for (uint32_t i = 0; i < pb; ++i) st(found ? (uint64_t)tb[(size_t)row * t.n_vals + i] : 0ull);
+            } else {
+                for (uint32_t i = 0; i < pb; ++i)
+                    st(found ? sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i] : 0ull);
+            }
             if (found && active && sc.mult)
                 atomicAdd(&sc.mult[(size_t)inst * sc.total_table_rows + t.mult_off + row], 1u);
         } break;
