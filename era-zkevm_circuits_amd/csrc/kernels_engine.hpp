@@ -842,8 +842,13 @@ __global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) {
                 for (uint32_t i = 0; i < t.n_keys; ++i) key[i] = cell(c0 + i);
                 uint32_t row = table_find(t, cd.table_words, key);
                 bool ok = row < t.n_rows;
-                for (uint32_t i = 0; ok && i < t.n_vals; ++i)
-                    ok = cd.table_words[(size_t)t.word_off + (size_t)row * tw + t.n_keys + i] == cell(c0 + t.n_keys + i);
+                if (t.dense & 2u) {  // packed byte copy (cs.cpp finalize)
+                    const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(cd.table_words + (t.dense >> 2));
+                    for (uint32_t i = 0; ok && i < t.n_vals; ++i) ok = (uint64_t)tb[(size_t)row * t.n_vals + i] == cell(c0 + t.n_keys + i);
+                } else {
+                    for (uint32_t i = 0; ok && i < t.n_vals; ++i)
+                        ok = cd.table_words[(size_t)t.word_off + (size_t)row * tw + t.n_keys + i] == cell(c0 + t.n_keys + i);
+                }
                 if (!ok) report(cd.fail, lane, slot, 0x80 | u, 15);
             }
         }
