@@ -614,16 +614,43 @@ void CS::build_strands(Scope& s) {
     std::vector<std::vector<uint32_t>> strand(NS);
     for (int ph = 0; ph < 3; ++ph) {
         const size_t o0 = bounds[ph], o1 = bounds[ph + 1];
+        // two-tier levels (see build_seed_program): tier = heavy ops (Poseidon2 permutations) on the longest producer
+        // path; light ops levelled as soon as possible inside the tier, the tier's heavy ops share its last level
         uint32_t n_levels = 0;
-        for (size_t oi = o0; oi < o1; ++oi) {
-            const OpRec& op = s.ops[oi];
-            if (op.seed_only) continue;
-            uint32_t lv = 0;
-            for (auto& in : op.ins)
-                if (in.kind == Operand::VAR && producer[in.idx] >= (int64_t)o0) lv = std::max(lv, level[producer[in.idx]] + 1);
-            level[oi] = lv;
-            n_levels = std::max(n_levels, lv + 1);
-            for (uint32_t ov : op.outs) producer[ov] = (int64_t)oi;
+        {
+            auto heavy = [&](const OpRec& op) { return op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2; };
+            std::vector<uint32_t> tier(o1 - o0, 0), local(o1 - o0, 0);
+            uint32_t n_tiers = 0;
+            for (size_t oi = o0; oi < o1; ++oi) {
+                const OpRec& op = s.ops[oi];
+                if (op.seed_only) continue;
+                uint32_t t = 0, l = 0;
+                for (auto& in : op.ins)
+                    if (in.kind == Operand::VAR && producer[in.idx] >= (int64_t)o0) {
+                        const size_t p = (size_t)producer[in.idx];
+                        t = std::max(t, tier[p - o0] + (heavy(s.ops[p]) ? 1u : 0u));
+                    }
+                if (!heavy(op))
+                    for (auto& in : op.ins)
+                        if (in.kind == Operand::VAR && producer[in.idx] >= (int64_t)o0) {
+                            const size_t p = (size_t)producer[in.idx];
+                            if (tier[p - o0] == t && !heavy(s.ops[p])) l = std::max(l, local[p - o0] + 1);
+                        }
+                tier[oi - o0] = t; local[oi - o0] = l;
+                n_tiers = std::max(n_tiers, t + 1);
+                for (uint32_t ov : op.outs) producer[ov] = (int64_t)oi;
+            }
+            std::vector<uint32_t> light_levels(n_tiers, 0), has_heavy(n_tiers, 0), base(n_tiers + 1, 0);
+            for (size_t oi = o0; oi < o1; ++oi) {
+                if (s.ops[oi].seed_only) continue;
+                if (heavy(s.ops[oi])) has_heavy[tier[oi - o0]] = 1;
+                else light_levels[tier[oi - o0]] = std::max(light_levels[tier[oi - o0]], local[oi - o0] + 1);
+            }
+            for (uint32_t t = 0; t < n_tiers; ++t) base[t + 1] = base[t] + light_levels[t] + has_heavy[t];
+            n_levels = base[n_tiers];
+            for (size_t oi = o0; oi < o1; ++oi)
+                if (!s.ops[oi].seed_only)
+                    level[oi] = base[tier[oi - o0]] + (heavy(s.ops[oi]) ? light_levels[tier[oi - o0]] : local[oi - o0]);
         }
         std::vector<std::vector<uint32_t>> by_level(n_levels);
         for (size_t oi = o0; oi < o1; ++oi)
@@ -794,18 +821,50 @@ void CS::build_seed_program() {
     // concurrently with that level's writers).
     seed_sprog_.clear(); seed_scarries_.clear(); seed_sslots_ = 0; seed_sgain_ = 0;
     constexpr uint32_t NS = zkdev::STRANDS_PER_TILE;
+    // Levels in two tiers so that the heavy ops of independent chains line up: tier(op) = the number of heavy ops (permutations,
+    // hash macro-ops) on the longest path of producers before it; inside a tier the light ops are levelled as soon as
+    // possible and ALL heavy ops of the tier share one final level (their consumers sit in the next tier).  With plain
+    // as-soon-as-possible levels the k-th permutations of different sponges land on different levels, one strand busy each.
     std::vector<int64_t> producer(s.n_vars, -1);
     std::vector<uint32_t> level(s.ops.size(), 0);
     uint32_t n_levels = 0;
-    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
-        if (!keep[oi]) continue;
-        uint32_t lv = 0;
-        for (auto& in : s.ops[oi].ins)
-            if (in.kind == Operand::VAR && producer[in.idx] >= 0) lv = std::max(lv, level[producer[in.idx]] + 1);
-        level[oi] = lv;
-        n_levels = std::max(n_levels, lv + 1);
-        const OpRec& op = s.ops[oi];
-        for (size_t i = op.opcode == ZK_OP_P2_ROUNDS ? op.outs.size() - 12 : 0; i < op.outs.size(); ++i) producer[op.outs[i]] = (int64_t)oi;
+    {
+        auto heavy = [&](const OpRec& op) {
+            return op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2 || op.opcode == ZK_OP_KECCAK_ABSORB || op.opcode == ZK_OP_SHA256_COMPRESS ||
+                   op.opcode == ZK_OP_NN_MULMOD;
+        };
+        std::vector<uint32_t> tier(s.ops.size(), 0), local(s.ops.size(), 0);
+        uint32_t n_tiers = 0;
+        for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+            if (!keep[oi]) continue;
+            const OpRec& op = s.ops[oi];
+            uint32_t t = 0;
+            for (auto& in : op.ins)
+                if (in.kind == Operand::VAR && producer[in.idx] >= 0) {
+                    const size_t p = (size_t)producer[in.idx];
+                    t = std::max(t, tier[p] + (heavy(s.ops[p]) ? 1u : 0u));
+                }
+            uint32_t l = 0;
+            if (!heavy(op))
+                for (auto& in : op.ins)
+                    if (in.kind == Operand::VAR && producer[in.idx] >= 0) {
+                        const size_t p = (size_t)producer[in.idx];
+                        if (tier[p] == t && !heavy(s.ops[p])) l = std::max(l, local[p] + 1);
+                    }
+            tier[oi] = t; local[oi] = l;
+            n_tiers = std::max(n_tiers, t + 1);
+            for (size_t i = op.opcode == ZK_OP_P2_ROUNDS ? op.outs.size() - 12 : 0; i < op.outs.size(); ++i) producer[op.outs[i]] = (int64_t)oi;
+        }
+        std::vector<uint32_t> light_levels(n_tiers, 0), has_heavy(n_tiers, 0), base(n_tiers + 1, 0);
+        for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+            if (!keep[oi]) continue;
+            if (heavy(s.ops[oi])) has_heavy[tier[oi]] = 1;
+            else light_levels[tier[oi]] = std::max(light_levels[tier[oi]], local[oi] + 1);
+        }
+        for (uint32_t t = 0; t < n_tiers; ++t) base[t + 1] = base[t] + light_levels[t] + has_heavy[t];
+        n_levels = base[n_tiers];
+        for (size_t oi = 0; oi < s.ops.size(); ++oi)
+            if (keep[oi]) level[oi] = base[tier[oi]] + (heavy(s.ops[oi]) ? light_levels[tier[oi]] : local[oi]);
     }
     std::vector<std::vector<uint32_t>> by_level(n_levels);
     std::vector<int64_t> last_level(s.n_vars, -1);
