@@ -593,6 +593,9 @@ void CS::emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) co
             break;
         }
     }
+    emit_dests(s, op, out);
+}
+void CS::emit_dests(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const {
     for (uint32_t ov : op.outs) {
         const auto& cells = s.var_cells[ov];
         for (size_t i = 0; i < cells.size(); ++i) out.push_back(cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0));
@@ -669,11 +672,45 @@ void CS::build_strands(Scope& s) {
             auto& ops = by_level[lv];
             std::stable_sort(ops.begin(), ops.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
             uint64_t load[NS] = {0};
+            std::vector<uint32_t> mine[NS];
             for (uint32_t oi : ops) {
                 uint32_t best = 0;
                 for (uint32_t k = 1; k < NS; ++k) if (load[k] < load[best]) best = k;
                 load[best] += cost(oi);
-                emit_op(s, s.ops[oi], strand[best]);
+                mine[best].push_back(oi);
+            }
+            // The ops of a level are independent, so a strand's lookups into one table are emitted in groups of up to 8 under one
+            // header (b = n_vals | (group - 1) << 8; table word, keys of every member, then destinations of every member): the
+            // interpreter issues all key loads, then all table gathers, then all stores — one latency chain instead of eight.
+            const char* grp_env = getenv("ZKGL_LOOKUP_GROUPS");
+            const bool grouping = !(grp_env && grp_env[0] == '0');
+            for (uint32_t k = 0; k < NS; ++k) {
+                std::map<uint64_t, std::vector<uint32_t>> groups;  // (table, n_keys, n_vals) -> lookups of this strand and level
+                for (uint32_t oi : mine[k]) {
+                    const OpRec& op = s.ops[oi];
+                    if (grouping && op.opcode == ZK_OP_LOOKUP && op.a <= 2 && op.b <= 2) groups[((uint64_t)op.ins[0].idx << 32) | ((uint64_t)op.a << 16) | op.b].push_back(oi);
+                    else emit_op(s, op, strand[k]);
+                }
+                for (auto& kv : groups) {
+                    const auto& g = kv.second;
+                    for (size_t i0 = 0; i0 < g.size(); i0 += 8) {
+                        const size_t n = std::min<size_t>(8, g.size() - i0);
+                        const OpRec& first = s.ops[g[i0]];
+                        strand[k].push_back((uint32_t)ZK_OP_LOOKUP | ((uint32_t)first.a << 8) | (((uint32_t)first.b | ((uint32_t)(n - 1) << 8)) << 16));
+                        strand[k].push_back(first.ins[0].idx);  // table id
+                        for (size_t i = 0; i < n; ++i) {
+                            const OpRec& op = s.ops[g[i0 + i]];
+                            for (size_t q = 1; q < op.ins.size(); ++q) {
+                                const Operand& in = op.ins[q];
+                                if (in.kind == Operand::VAR) strand[k].push_back(s.var_cells[in.idx][0]);
+                                else if (in.kind == Operand::CONSTPOOL) strand[k].push_back(ZK_OPERAND_CONST | in.idx);
+                                else if (in.kind == Operand::OUTER_VAR) strand[k].push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]);
+                                else strand[k].push_back(in.idx);
+                            }
+                        }
+                        for (size_t i = 0; i < n; ++i) emit_dests(s, s.ops[g[i0 + i]], strand[k]);
+                    }
+                }
             }
             for (uint32_t k = 0; k < NS; ++k) total += load[k];
             critical += *std::max_element(load, load + NS) + 200;  // + the barrier: every strand drains its stores

@@ -190,6 +190,7 @@ class CS {
     void schedule_loop_ops();
     void emit_scope(Scope& s);
     void emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const;
+    void emit_dests(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const;
     void build_strands(Scope& s);
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t word_begin, uint32_t word_end, void* stream) const;

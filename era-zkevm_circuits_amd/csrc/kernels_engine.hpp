@@ -419,6 +419,49 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         case ZK_OP_LOOKUP: {
             const uint32_t tid = P.at(pc++);
             const zk_table_desc t = sc.tables[tid];
+            const uint32_t nv = pb & 0xff;
+            if constexpr (STRANDS && !SLOTS) {
+                // strand programs: up to 8 independent lookups into one table under one header (cs.cpp build_strands); all key loads
+                // first, then all table gathers, then the stores and the multiplicities
+                const uint32_t grp = (pb >> 8) + 1;
+                if (grp > 1) {
+                    uint64_t key[8][2];
+                    uint32_t row[8];
+                    uint64_t val[8][2];
+#pragma unroll
+                    for (uint32_t g = 0; g < 8; ++g)
+                        if (g < grp) {
+                            key[g][0] = ld(P.at(pc + g * pa));
+                            key[g][1] = pa > 1 ? ld(P.at(pc + g * pa + 1)) : 0;
+                        }
+                    pc += grp * pa;
+                    const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(sc.table_words + (t.dense >> 2));
+                    const uint32_t w = t.n_keys + t.n_vals;
+#pragma unroll
+                    for (uint32_t g = 0; g < 8; ++g)
+                        if (g < grp) {
+                            uint64_t k3[3] = {key[g][0], key[g][1], 0};
+                            row[g] = table_find(t, sc.table_words, k3);
+                            const bool found = row[g] < t.n_rows;
+#pragma unroll
+                            for (uint32_t i = 0; i < 2; ++i)
+                                if (i < nv)
+                                    val[g][i] = !found ? 0ull
+                                                : (t.dense & 2u) ? (uint64_t)tb[(size_t)row[g] * t.n_vals + i]
+                                                                 : sc.table_words[(size_t)t.word_off + (size_t)row[g] * w + t.n_keys + i];
+                        }
+#pragma unroll
+                    for (uint32_t g = 0; g < 8; ++g)
+                        if (g < grp) {
+                            P.sync(pc);
+#pragma unroll
+                            for (uint32_t i = 0; i < 2; ++i)
+                                if (i < nv) st(val[g][i]);
+                            if (row[g] < t.n_rows && active && sc.mult) atomicAdd(&sc.mult[(size_t)inst * sc.total_table_rows + t.mult_off + row[g]], 1u);
+                        }
+                    break;
+                }
+            }
             uint64_t key[3] = {0, 0, 0};
             for (uint32_t i = 0; i < pa; ++i) key[i] = ld(P.at(pc + i));
             pc += pa;
@@ -427,9 +470,9 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             bool found = row < t.n_rows;
             if (t.dense & 2u) {  // packed byte copy of a dense byte-valued table
                 const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(sc.table_words + (t.dense >> 2));
-                for (uint32_t i = 0; i < pb; ++i) st(found ? (uint64_t)tb[(size_t)row * t.n_vals + i] : 0ull);
+                for (uint32_t i = 0; i < nv; ++i) st(found ? (uint64_t)tb[(size_t)row * t.n_vals + i] : 0ull);
             } else {
-                for (uint32_t i = 0; i < pb; ++i)
+                for (uint32_t i = 0; i < nv; ++i)
                     st(found ? sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i] : 0ull);
             }
             if (found && active && sc.mult)
