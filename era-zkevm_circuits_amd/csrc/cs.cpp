@@ -686,11 +686,33 @@ void CS::build_strands(Scope& s) {
             const bool grouping = !(grp_env && grp_env[0] == '0');
             for (uint32_t k = 0; k < NS; ++k) {
                 std::map<uint64_t, std::vector<uint32_t>> groups;  // (table, n_keys, n_vals) -> lookups of this strand and level
+                std::map<uint8_t, std::vector<uint32_t>> plain_groups;  // opcode -> SELECT / FMA / LC4 ops of this strand and level
                 for (uint32_t oi : mine[k]) {
                     const OpRec& op = s.ops[oi];
                     if (grouping && op.opcode == ZK_OP_LOOKUP && op.a <= 2 && op.b <= 2) groups[((uint64_t)op.ins[0].idx << 32) | ((uint64_t)op.a << 16) | op.b].push_back(oi);
+                    else if (grouping && (op.opcode == ZK_OP_SELECT || op.opcode == ZK_OP_FMA || op.opcode == ZK_OP_LC4)) plain_groups[op.opcode].push_back(oi);
                     else emit_op(s, op, strand[k]);
                 }
+                // the same for SELECT (8 to a header), FMA and LC4 (4): b = group - 1, operand words of every member, then destinations
+                for (auto& kv : plain_groups) {
+                    const auto& g = kv.second;
+                    const size_t cap = kv.first == ZK_OP_SELECT ? 8 : 4;
+                    for (size_t i0 = 0; i0 < g.size(); i0 += cap) {
+                        const size_t n = std::min(cap, g.size() - i0);
+                        strand[k].push_back((uint32_t)kv.first | ((uint32_t)(n - 1) << 16));
+                        for (size_t i = 0; i < n; ++i) {
+                            const OpRec& op = s.ops[g[i0 + i]];
+                            for (auto& in : op.ins) {
+                                if (in.kind == Operand::VAR) strand[k].push_back(s.var_cells[in.idx][0]);
+                                else if (in.kind == Operand::CONSTPOOL) strand[k].push_back(ZK_OPERAND_CONST | in.idx);
+                                else if (in.kind == Operand::OUTER_VAR) strand[k].push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]);
+                                else strand[k].push_back(in.idx);
+                            }
+                        }
+                        for (size_t i = 0; i < n; ++i) emit_dests(s, s.ops[g[i0 + i]], strand[k]);
+                    }
+                }
+                plain_groups.clear();
                 for (auto& kv : groups) {
                     const auto& g = kv.second;
                     for (size_t i0 = 0; i0 < g.size(); i0 += 8) {

@@ -353,6 +353,26 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             else st(sc.inputs[(size_t)w * sc.n_lanes + lane]);
         } break;
         case ZK_OP_FMA: {
+            if constexpr (STRANDS && !SLOTS) {
+                const uint32_t grp = pb + 1;  // strand programs: up to 4 independent ops under one header
+                if (grp > 1) {
+                    uint64_t in[4][5];
+#pragma unroll
+                    for (uint32_t g = 0; g < 4; ++g)
+                        if (g < grp) {
+#pragma unroll
+                            for (uint32_t i = 0; i < 5; ++i) in[g][i] = ld(P.at(pc + g * 5 + i));
+                        }
+                    pc += grp * 5;
+#pragma unroll
+                    for (uint32_t g = 0; g < 4; ++g)
+                        if (g < grp) {
+                            const uint64_t ab = gl::mul(in[g][2], in[g][3]);
+                            st(gl::add(in[g][0] == 1 ? ab : gl::mul(in[g][0], ab), in[g][1] == 1 ? in[g][4] : gl::mul(in[g][1], in[g][4])));
+                        }
+                    break;
+                }
+            }
             uint64_t q = ld(P.at(pc)), l = ld(P.at(pc + 1));
             uint64_t a = ld(P.at(pc + 2)), b = ld(P.at(pc + 3)), c = ld(P.at(pc + 4));
             pc += 5;
@@ -361,6 +381,28 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             st(r);
         } break;
         case ZK_OP_LC4: {
+            if constexpr (STRANDS && !SLOTS) {
+                const uint32_t grp = pb + 1;
+                if (grp > 1) {
+                    uint64_t in[4][8];
+#pragma unroll
+                    for (uint32_t g = 0; g < 4; ++g)
+                        if (g < grp) {
+#pragma unroll
+                            for (uint32_t i = 0; i < 8; ++i) in[g][i] = ld(P.at(pc + g * 8 + i));
+                        }
+                    pc += grp * 8;
+#pragma unroll
+                    for (uint32_t g = 0; g < 4; ++g)
+                        if (g < grp) {
+                            uint64_t r = 0;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) r = gl::fma(in[g][i], in[g][4 + i], r);
+                            st(r);
+                        }
+                    break;
+                }
+            }
             uint64_t r = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) r = gl::fma(ld(P.at(pc + i)), ld(P.at(pc + 4 + i)), r);
@@ -368,6 +410,23 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             st(r);
         } break;
         case ZK_OP_SELECT: {
+            if constexpr (STRANDS && !SLOTS) {
+                const uint32_t grp = pb + 1;
+                if (grp > 1) {
+                    uint64_t in[8][3];
+#pragma unroll
+                    for (uint32_t g = 0; g < 8; ++g)
+                        if (g < grp) {
+#pragma unroll
+                            for (uint32_t i = 0; i < 3; ++i) in[g][i] = ld(P.at(pc + g * 3 + i));
+                        }
+                    pc += grp * 3;
+#pragma unroll
+                    for (uint32_t g = 0; g < 8; ++g)
+                        if (g < grp) st(in[g][0] ? in[g][1] : in[g][2]);
+                    break;
+                }
+            }
             uint64_t s = ld(P.at(pc)), a = ld(P.at(pc + 1)), b = ld(P.at(pc + 2));
             pc += 3;
             st(s ? a : b);
