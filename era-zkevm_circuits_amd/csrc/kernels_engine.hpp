@@ -332,7 +332,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                     __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ZK_DEST_CELL_MASK) << 9, 2 /* nt */);
 #endif
                 } else {
-                    cells[(size_t)(w & ZK_DEST_CELL_MASK) << 6] = v;
+                    __builtin_nontemporal_store(v, &cells[(size_t)(w & ZK_DEST_CELL_MASK) << 6]);  // 64-bit addressed scopes: same streaming stores
                 }
             } while (w & ZK_DEST_MORE);
         }
