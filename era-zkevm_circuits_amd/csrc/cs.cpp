@@ -1255,7 +1255,9 @@ zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail) const 
     a.lookup_width = lookup_width_; a.tables = d_tables_; a.table_words = d_table_words_; a.fail = fail;
     // >= ~2048 workgroups: lane tiles x slot chunks
     uint32_t lane_tiles = (s.n_lanes + 255) / 256;
-    uint32_t chunks = std::max<uint32_t>(1, (2048 + lane_tiles - 1) / std::max<uint32_t>(lane_tiles, 1));
+    // at least two slot chunks per lane tile: with one, a thread walks every row of its lane and the kernel runs ~25 % slower
+    // (measured at 152 instances of the VM shape, where the lane tiles alone exceed 2048)
+    uint32_t chunks = std::max<uint32_t>(2, (2048 + lane_tiles - 1) / std::max<uint32_t>(lane_tiles, 1));
     chunks = std::min(chunks, s.n_slots);
     a.slots_per_chunk = (s.n_slots + chunks - 1) / chunks;
     return a;

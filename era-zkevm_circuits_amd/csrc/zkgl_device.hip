@@ -1,6 +1,8 @@
 // zkgl_device.hip — the ONE device translation unit of libzkgl.so (gfx950 only).
 // Kernels live in kernels_primitives.hpp / kernels_engine.hpp; this file holds the launchers.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <algorithm>
 #include <string>
 #include "device_api.hpp"
 #include "kernels_primitives.hpp"
@@ -157,7 +159,7 @@ int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lane
     if (n_lanes == 0 || n_pairs == 0) return 0;
     unsigned lane_tiles = grid_for(n_lanes, zke::TPB);
     // aim for >= ~2048 workgroups
-    uint32_t chunks = (2048 + lane_tiles - 1) / lane_tiles;
+    uint32_t chunks = std::max<uint32_t>(2, (2048 + lane_tiles - 1) / lane_tiles);  // never one chunk: see CS::check_args
     if (chunks > n_pairs) chunks = n_pairs;
     if (chunks < 1) chunks = 1;
     uint32_t per = (n_pairs + chunks - 1) / chunks;
