@@ -739,8 +739,12 @@ void CS::build_strands(Scope& s) {
             if (lv + 1 < n_levels) for (auto& st : strand) st.push_back(ZK_OP_BARRIER);
         }
         s.s_gain[ph] = critical ? (float)total / (float)critical : 0.f;
-        if (getenv("ZKGL_STRANDS_DEBUG") && o1 > o0)
-            fprintf(stderr, "[zkgl] strands %s phase %d: %zu ops, %u levels, estimated gain %.2f\n", s.is_loop ? "loop" : "outer", ph, o1 - o0, n_levels, s.s_gain[ph]);
+        if (getenv("ZKGL_STRANDS_DEBUG") && o1 > o0) {
+            uint32_t narrow = 0, wide = 0;
+            for (auto& l : by_level) { narrow += l.size() < 8; wide += l.size() >= 64; }
+            fprintf(stderr, "[zkgl] strands %s phase %d: %zu ops, %u levels (%u with fewer than 8 ops, %u with 64 or more), estimated gain %.2f\n",
+                    s.is_loop ? "loop" : "outer", ph, o1 - o0, n_levels, narrow, wide, s.s_gain[ph]);
+        }
         for (uint32_t k = 0; k < NS; ++k) {
             s.s_begin[ph][k] = (uint32_t)s.sprog.size();
             s.sprog.insert(s.sprog.end(), strand[k].begin(), strand[k].end());
