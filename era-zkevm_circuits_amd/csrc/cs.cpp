@@ -290,6 +290,7 @@ void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uin
         s.uses_bigint = true;
         break;
     case ZK_OP_DIVREM: need(1, 2, 0); if (b == 0 || b > 65535) throw ZkError(ZK_ERR_INVALID, "DIVREM: divisor must be 1..65535"); break;
+    case ZK_OP_U256_MULWIDE: case ZK_OP_U256_DIVREM: need(16, 16, 0); break;
     default: throw ZkError(ZK_ERR_INVALID, "emit_op: opcode not recordable through this entry");
     }
     for (uint32_t i = 0; i < n_imm; ++i) {
@@ -503,6 +504,8 @@ void CS::schedule_loop_ops() {
         case ZK_OP_POSEIDON2: case ZK_OP_P2_ROUNDS: return 14600;
         case ZK_OP_ISZERO: return 2300;
         case ZK_OP_NN_MULMOD: return 3000;
+        case ZK_OP_U256_DIVREM: return 8000;
+        case ZK_OP_U256_MULWIDE: return 300;
         case ZK_OP_MATMUL12: return 250;
         case ZK_OP_LOOKUP: return 60;
         default: return 15;
@@ -664,6 +667,7 @@ void CS::build_strands(Scope& s) {
             for (uint32_t ov : op.outs) c += 2 * s.var_cells[ov].size();
             if (op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2) c += 4000;
             if (op.opcode == ZK_OP_NN_MULMOD) c += 2000;
+            if (op.opcode == ZK_OP_U256_DIVREM) c += 2500;
             return c;
         };
         for (auto& st : strand) st.clear();
@@ -943,6 +947,7 @@ void CS::build_seed_program() {
         uint64_t c = 8 + op.ins.size() + 2 * op.outs.size();
         if (op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2) c = 4000;
         if (op.opcode == ZK_OP_NN_MULMOD) c += 2000;
+        if (op.opcode == ZK_OP_U256_DIVREM) c += 2500;
         if (op.opcode == ZK_OP_KECCAK_ABSORB) c = 20000;
         if (op.opcode == ZK_OP_SHA256_COMPRESS) c = 6000;
         return c;

@@ -651,6 +651,85 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             st(x / pb);
             st(x % pb);
         } break;
+        case ZK_OP_U256_MULWIDE: {
+            // column-wise schoolbook product, a 96-bit column accumulator (up to 8 products of 64 bits + carry)
+            uint32_t a[8], b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = (uint32_t)ld(P.at(pc + i));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b[i] = (uint32_t)ld(P.at(pc + 8 + i));
+            pc += 16;
+            uint64_t lo = 0;
+            uint32_t hi = 0, out[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int j = k - i;
+                    if (j >= 0 && j < 8) {
+                        const uint64_t p = (uint64_t)a[i] * b[j];
+                        lo += p;
+                        hi += lo < p;
+                    }
+                }
+                out[k] = (uint32_t)lo;
+                lo = (lo >> 32) | ((uint64_t)hi << 32);
+                hi = 0;
+            }
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v = (i == j) ? out[j] : v;
+                st((uint64_t)v);
+            }
+        } break;
+        case ZK_OP_U256_DIVREM: {
+            // restoring shift-subtract division, 256 fixed steps in registers (two per VM cycle: Div and the right shifts)
+            uint32_t a[8], b[8], r[8];
+            uint32_t bnz = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = (uint32_t)ld(P.at(pc + i));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { b[i] = (uint32_t)ld(P.at(pc + 8 + i)); bnz |= b[i]; r[i] = 0; }
+            pc += 16;
+            if (bnz) {
+#pragma unroll 1
+                for (int step = 0; step < 256; ++step) {
+                    // (r, a) <<= 1 : the quotient bits enter a from the bottom as the dividend bits leave at the top
+                    const uint32_t top = r[7] >> 31;  // r < b <= 2^256 - 1 before the shift; a 257-bit r is handled by `top`
+#pragma unroll
+                    for (int i = 7; i > 0; --i) r[i] = (r[i] << 1) | (r[i - 1] >> 31);
+                    r[0] = (r[0] << 1) | (a[7] >> 31);
+#pragma unroll
+                    for (int i = 7; i > 0; --i) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
+                    a[0] <<= 1;
+                    uint32_t d[8];
+                    uint32_t borrow = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint64_t t = (uint64_t)r[i] - b[i] - borrow;
+                        d[i] = (uint32_t)t;
+                        borrow = (uint32_t)(t >> 63);
+                    }
+                    if (top | (borrow ^ 1u)) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) r[i] = d[i];
+                        a[0] |= 1u;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { r[i] = a[i]; a[i] = 0; }
+            }
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v = (i == j) ? a[j] : ((i == 8 + j) ? r[j] : v);
+                st((uint64_t)v);
+            }
+        } break;
         case ZK_OP_BARRIER: if constexpr (STRANDS) {
             // end of a dependency level: this strand's stores must be visible to the other wavefronts of the tile (same CU,
             // shared L1) before any of them starts the next level

@@ -33,7 +33,7 @@ ZK_ERR_GATE_NOT_ALLOWED = -6
 
 # zk_opcode / zk_gate_kind / zk_link_kind (include/zkgl_ir.h)
 OP = dict(END=0, CONST=1, INPUT=2, FMA=3, LC4=4, SELECT=5, ISZERO=6, UADD=7, USUB=8, DOT4=9, MATMUL12=10,
-          SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16, DIVREM=18, NN_MULMOD=19, KECCAK_ABSORB=20, SHA256_COMPRESS=21, BARRIER=22)
+          SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16, DIVREM=18, NN_MULMOD=19, KECCAK_ABSORB=20, SHA256_COMPRESS=21, BARRIER=22, U256_MULWIDE=23, U256_DIVREM=24)
 GATE = dict(NOP=0, CONST=1, BOOLEAN=2, FMA=3, REDUCTION4=4, SELECT=5, ZEROCHECK=6, UINTX_ADD=7, DOT4=8,
             MATMUL12_EXT=9, MATMUL12_INT=10, PUBLIC_INPUT=11, U32_FMA=12, REDUCTION_BY_POWERS4=13)
 GATE_NAMES = {v: k for k, v in GATE.items()}

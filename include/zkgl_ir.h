@@ -63,6 +63,11 @@ enum zk_opcode {
     /* strand programs only (never recorded, never exported): a scope short of wavefronts runs as 8 strands per 64-lane tile,
      * one wavefront each, with a workgroup barrier between the dependency levels of the op graph (cs.cpp build_strands) */
     ZK_OP_BARRIER = 22,
+    /* 256-bit integer witness ops of the VM's mul / div / shift closures (limbs are u32, least significant first) */
+    ZK_OP_U256_MULWIDE = 23, /* [a0..7, b0..7] -> 16 limbs of a * b         (allocate_mul_result_unchecked,
+                              * /root/reference/src/main_vm/opcodes/mul_div.rs:20-92: ethereum_types::U256::full_mul) */
+    ZK_OP_U256_DIVREM = 24,  /* [a0..7, b0..7] -> q0..7, r0..7 of a / b; b == 0 => q = 0, r = a
+                              *                                              (allocate_div_result_unchecked, mul_div.rs:96-172) */
     ZK_OP__COUNT
 };
 

@@ -286,6 +286,72 @@ static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
             st(c, prog, &pc, lane, x / pb);
             st(c, prog, &pc, lane, x % pb);
         } break;
+        case ZK_OP_U256_MULWIDE: { /* row-wise schoolbook product over u32 limbs (the device sums column-wise) */
+            uint64_t a[8], b[8], out[16] = {0};
+            for (int i = 0; i < 8; ++i) a[i] = ld(c, prog[pc + i], lane, inst);
+            for (int i = 0; i < 8; ++i) b[i] = ld(c, prog[pc + 8 + i], lane, inst);
+            pc += 16;
+            for (int i = 0; i < 8; ++i) {
+                uint64_t carry = 0;
+                for (int j = 0; j < 8; ++j) {
+                    uint64_t t = a[i] * b[j] + out[i + j] + carry;
+                    out[i + j] = t & 0xffffffffull;
+                    carry = t >> 32;
+                }
+                out[i + 8] = carry;
+            }
+            for (int i = 0; i < 16; ++i) st(c, prog, &pc, lane, out[i]);
+        } break;
+        case ZK_OP_U256_DIVREM: { /* Knuth algorithm D over u32 limbs with 128-bit temporaries (the device divides bit-serially) */
+            uint32_t a[8], b[8], q[8] = {0}, r[8] = {0};
+            for (int i = 0; i < 8; ++i) a[i] = (uint32_t)ld(c, prog[pc + i], lane, inst);
+            for (int i = 0; i < 8; ++i) b[i] = (uint32_t)ld(c, prog[pc + 8 + i], lane, inst);
+            pc += 16;
+            int n = 8;
+            while (n > 0 && b[n - 1] == 0) --n;
+            if (n == 0) { for (int i = 0; i < 8; ++i) r[i] = a[i]; }
+            else if (n == 1) {
+                uint64_t rem = 0;
+                for (int i = 7; i >= 0; --i) { uint64_t cur = (rem << 32) | a[i]; q[i] = (uint32_t)(cur / b[0]); rem = cur % b[0]; }
+                r[0] = (uint32_t)rem;
+            } else {
+                int s = __builtin_clz(b[n - 1]);
+                uint32_t v[8], u[9];
+                for (int i = n - 1; i > 0; --i) v[i] = (b[i] << s) | (s ? (b[i - 1] >> (32 - s)) : 0);
+                v[0] = b[0] << s;
+                u[8] = s ? (a[7] >> (32 - s)) : 0;
+                for (int i = 7; i > 0; --i) u[i] = (a[i] << s) | (s ? (a[i - 1] >> (32 - s)) : 0);
+                u[0] = a[0] << s;
+                for (int j = 8 - n; j >= 0; --j) {
+                    uint64_t num = ((uint64_t)u[j + n] << 32) | u[j + n - 1];
+                    uint64_t qhat = num / v[n - 1], rhat = num % v[n - 1];
+                    while (qhat >= (1ull << 32) || qhat * v[n - 2] > ((rhat << 32) | u[j + n - 2])) {
+                        --qhat; rhat += v[n - 1];
+                        if (rhat >= (1ull << 32)) break;
+                    }
+                    int64_t borrow = 0; uint64_t carry = 0;
+                    for (int i = 0; i < n; ++i) {
+                        uint64_t p = qhat * v[i] + carry;
+                        carry = p >> 32;
+                        int64_t t = (int64_t)u[i + j] - (int64_t)(p & 0xffffffffull) - borrow;
+                        borrow = t < 0;
+                        u[i + j] = (uint32_t)t;
+                    }
+                    int64_t t = (int64_t)u[j + n] - (int64_t)carry - borrow;
+                    u[j + n] = (uint32_t)t;
+                    if (t < 0) {
+                        --qhat;
+                        uint64_t cc = 0;
+                        for (int i = 0; i < n; ++i) { uint64_t w = (uint64_t)u[i + j] + v[i] + cc; u[i + j] = (uint32_t)w; cc = w >> 32; }
+                        u[j + n] += (uint32_t)cc;
+                    }
+                    q[j] = (uint32_t)qhat;
+                }
+                for (int i = 0; i < n; ++i) r[i] = (u[i] >> s) | ((s && i + 1 < n) ? (u[i + 1] << (32 - s)) : 0);
+            }
+            for (int i = 0; i < 8; ++i) st(c, prog, &pc, lane, q[i]);
+            for (int i = 0; i < 8; ++i) st(c, prog, &pc, lane, r[i]);
+        } break;
         default: return -1;
         }
     }
