@@ -5,6 +5,7 @@
 #include <cstring>
 #include <string>
 #include "../../include/zkgl.h"
+#include "../../include/zkgl_vm.h"
 #include "cs.hpp"
 #include "device_api.hpp"
 #include "gadgets.hpp"
@@ -14,6 +15,8 @@ namespace zkgl {
 void ram_permutation_configure(CS& cs);
 void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
+void main_vm_configure(CS& cs, const zk_opcode_defs& defs);
+void main_vm_entry_point(CS& cs, uint32_t limit);
 void keccak_configure(CS& cs);
 void sha256_configure(CS& cs);
 void linear_hasher_configure(CS& cs);
@@ -531,6 +534,24 @@ int zk_circuit_vm_shaped_configure(zk_cs* cs) {
 int zk_circuit_vm_shaped(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { zkgl::vm_shaped_entry_point(*cs->cs, limit); });
+}
+int zk_circuit_main_vm_configure(zk_cs* cs, const zk_opcode_defs* defs) {
+    NEED(cs);
+    if (!defs) return fail(ZK_ERR_INVALID, "zk_circuit_main_vm_configure: null opcode-defs blob");
+    return guard([&] { zkgl::main_vm_configure(*cs->cs, *defs); });
+}
+int zk_circuit_main_vm(zk_cs* cs, uint32_t limit) {
+    NEED(cs);
+    return guard([&] { zkgl::main_vm_entry_point(*cs->cs, limit); });
+}
+int zk_circuit_main_vm_layout(zk_cs* cs, char* buf, size_t max_bytes, size_t* n_bytes) {
+    NEED(cs);
+    const std::string& t = cs->cs->input_layout;
+    if (n_bytes) *n_bytes = t.size();
+    if (!buf) return ZK_OK;
+    if (max_bytes < t.size()) return fail(ZK_ERR_CAPACITY, "zk_circuit_main_vm_layout: buffer too small");
+    std::memcpy(buf, t.data(), t.size());
+    return ZK_OK;
 }
 
 }  // extern "C"

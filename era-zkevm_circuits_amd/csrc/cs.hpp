@@ -173,6 +173,11 @@ class CS {
     void trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream) const;
     void trace_ptr(bool loop_scope, uint64_t** cells, uint64_t* n_cells, uint64_t* stride) const;
 
+    // circuit-layer attachments: the main_vm opcode-defs blob (include/zkgl_vm.h) handed to configure, and the text
+    // description of the input streams the recorded circuit reads (zk_circuit_main_vm_layout)
+    std::vector<uint8_t> circuit_blob;
+    std::string input_layout;
+
     const zk_geometry& geometry() const { return geo_; }
     bool in_loop() const { return in_loop_; }
     uint32_t limit() const { return limit_; }

@@ -154,6 +154,10 @@ enum TableMarker : uint32_t {
     TABLE_VM_DECODE = 16, // opcode decode + price shaped table (src/tables/opcodes_decoding.rs:14-38)
     TABLE_VM_BITSHIFT = 17,
     TABLE_VM_CONDITIONAL = 18,
+    TABLE_VM_REG_TO_BITMASK = 19,       // RegisterIndexToBitmaskTable (src/tables/integer_to_boolean_mask.rs:9-11)
+    TABLE_VM_SUBPC_TO_BITMASK = 20,     // VMSubPCToBitmaskTable
+    TABLE_VM_UMA_SHIFT_TO_BITMASK = 21, // UMAShiftToBitmaskTable
+    TABLE_VM_UMA_PTR_READ_CLEANUP = 22, // UMAPtrReadCleanupTable (src/tables/uma_ptr_read_cleanup.rs:9)
 };
 void add_xor8_table(CS& cs);
 void add_and8_table(CS& cs);

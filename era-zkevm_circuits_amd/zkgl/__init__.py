@@ -251,6 +251,52 @@ def lde(coeffs, out, log_n: int, log_blowup: int, n_polys: int = 1, src_stride=N
                         C.c_uint32(NTT_NATURAL_VALUES if natural_values else 0), C.c_uint64(coset_shift), _ptr(stream)))
 
 
+# ---- include/zkgl_vm.h
+VM_FAMILY = dict(INVALID=0, NOP=1, ADD=2, SUB=3, MUL=4, DIV=5, JUMP=6, CONTEXT=7, SHIFT=8, BINOP=9, PTR=10, NEAR_CALL=11, LOG=12,
+                 FAR_CALL=13, RET=14, UMA=15)
+VM_VARIANT = {n: i for i, n in enumerate(
+    "SHIFT_SHL SHIFT_SHR SHIFT_ROL SHIFT_ROR BINOP_XOR BINOP_AND BINOP_OR PTR_ADD PTR_SUB PTR_PACK PTR_SHRINK CTX_THIS CTX_CALLER "
+    "CTX_CODE_ADDRESS CTX_META CTX_ERGS_LEFT CTX_SP CTX_GET_CONTEXT_U128 CTX_SET_CONTEXT_U128 CTX_SET_ERGS_PER_PUBDATA CTX_INC_TX_NUMBER "
+    "LOG_STORAGE_READ LOG_STORAGE_WRITE LOG_TO_L1 LOG_EVENT LOG_PRECOMPILE_CALL FAR_NORMAL FAR_DELEGATE FAR_MIMIC RET_OK RET_REVERT RET_PANIC "
+    "UMA_HEAP_READ UMA_HEAP_WRITE UMA_AUX_HEAP_READ UMA_AUX_HEAP_WRITE UMA_FAT_PTR_READ".split())}
+VM_FLAG = {n: i for i, n in enumerate("SET_FLAGS SWAP_ARITH SWAP_PTR FIRST_MESSAGE UMA_INCREMENT FAR_CALL_STATIC FAR_CALL_SHARD RET_TO_LABEL".split())}
+VM_MODE = dict(REG_ONLY=0, STACK_PUSH_POP=1, STACK_OFFSET=2, ABSOLUTE_STACK=3, IMM16=4, CODE_PAGE=5)
+VM_CONDITION = dict(ALWAYS=0, LT=1, EQ=2, GT=3, GE=4, LE=5, NE=6, GT_OR_LT=7)
+VM_PARAM = {n: i for i, n in enumerate(
+    "VM_MAX_STACK_DEPTH NEW_FRAME_MEMORY_STIPEND NEW_MEMORY_PAGES_PER_FAR_CALL UNMAPPED_PAGE BOOTLOADER_BASE_PAGE BOOTLOADER_CODE_PAGE "
+    "BOOTLOADER_CALLDATA_PAGE STARTING_BASE_PAGE STARTING_TIMESTAMP INITIAL_FRAME_FORMAL_EH_LOCATION VM_INITIAL_FRAME_ERGS "
+    "BOOTLOADER_FORMAL_ADDRESS_LOW BOOTLOADER_MAX_MEMORY DEPLOYER_SYSTEM_CONTRACT_ADDRESS_LOW ERGS_PER_CODE_WORD_DECOMMITTMENT "
+    "INITIAL_STORAGE_WRITE_PUBDATA_BYTES L1_MESSAGE_PUBDATA_BYTES STORAGE_AUX_BYTE EVENT_AUX_BYTE L1_MESSAGE_AUX_BYTE PRECOMPILE_AUX_BYTE "
+    "CODE_HASH_VERSION_BYTE CODE_YET_CONSTRUCTED_MARKER CODE_AT_REST_MARKER FAR_CALL_FORWARDING_MODE_BYTE_IDX FAR_CALL_SHARD_ID_BYTE_IDX "
+    "FAR_CALL_CONSTRUCTOR_CALL_BYTE_IDX FAR_CALL_SYSTEM_CALL_BYTE_IDX FORWARD_USE_HEAP FORWARD_FAT_POINTER FORWARD_USE_AUX_HEAP "
+    "CALL_IMPLICIT_PARAMETER_REG_IDX CALL_SYSTEM_ABI_REGISTERS_BEGIN CALL_SYSTEM_ABI_REGISTERS_END CALL_RESERVED_RANGE_BEGIN "
+    "CALL_RESERVED_RANGE_END".split())}
+
+
+class OpcodeDefs(C.Structure):
+    """zk_opcode_defs: everything main_vm takes from zkevm_opcode_defs, as one data blob"""
+    _fields_ = [("version", C.c_uint32), ("n_valid", C.c_uint32), ("props", C.c_uint64 * 2048), ("prices", C.c_uint32 * 2048),
+                ("type_bits", C.c_uint32), ("variant_bits", C.c_uint32), ("flag_bits", C.c_uint32), ("src_mode_bits", C.c_uint32),
+                ("dst_mode_bits", C.c_uint32), ("description_bits_flattened", C.c_uint32), ("aux_bits", C.c_uint32),
+                ("aux_kernel_mode", C.c_uint32), ("aux_static_ok", C.c_uint32), ("aux_explicit_panic", C.c_uint32),
+                ("variant_idx", C.c_uint32 * len(VM_VARIANT)), ("flag_idx", C.c_uint32 * len(VM_FLAG)), ("condition_idx", C.c_uint32 * 8),
+                ("can_write_dst0_into_memory", C.c_uint32 * 16), ("nop_encoding", C.c_uint64), ("panic_encoding", C.c_uint64),
+                ("nop_bitspread", C.c_uint64), ("panic_bitspread", C.c_uint64), ("params", C.c_uint32 * len(VM_PARAM))]
+
+    def find(self, family: int, variant: int = 0, src_mode: int = 0, dst_mode: int = 0, flags: int = 0) -> int:
+        r = int(lib().zk_opcode_defs_find(C.byref(self), C.c_uint32(family), C.c_uint32(variant), C.c_uint32(src_mode), C.c_uint32(dst_mode),
+                                          C.c_uint32(flags)))
+        if r < 0:
+            raise KeyError((family, variant, src_mode, dst_mode, flags))
+        return r
+
+
+def opcode_defs_default() -> OpcodeDefs:
+    d = OpcodeDefs()
+    _check(lib().zk_opcode_defs_default(C.byref(d)))
+    return d
+
+
 @dataclass
 class CSGeometry:  # boojum::cs::CSGeometry (src/main_vm/cycle.rs:959-966)
     num_columns_under_copy_permutation: int
@@ -473,6 +519,26 @@ class ConstraintSystem:
 
     def vm_shaped_entry_point(self, limit: int):
         _check(lib().zk_circuit_vm_shaped(self._h, limit))
+
+    def configure_main_vm(self, defs: "OpcodeDefs | None" = None):
+        """zk_circuit_main_vm_configure: tables / gate set of the VM CS from the opcode-defs blob (include/zkgl_vm.h)"""
+        self._defs = defs if defs is not None else opcode_defs_default()
+        _check(lib().zk_circuit_main_vm_configure(self._h, C.byref(self._defs)))
+
+    def main_vm_entry_point(self, limit: int):
+        _check(lib().zk_circuit_main_vm(self._h, C.c_uint32(limit)))
+
+    def main_vm_layout(self) -> dict:
+        """{'outer': {name: (first word, n words)}, 'loop': {...}} of the recorded main_vm circuit"""
+        n = C.c_size_t(0)
+        _check(lib().zk_circuit_main_vm_layout(self._h, None, C.c_size_t(0), C.byref(n)))
+        buf = C.create_string_buffer(n.value + 1)
+        _check(lib().zk_circuit_main_vm_layout(self._h, buf, C.c_size_t(n.value), C.byref(n)))
+        out = {"outer": {}, "loop": {}}
+        for line in buf.raw[:n.value].decode().splitlines():
+            scope, name, first, cnt = line.split()
+            out[scope][name] = (int(first), int(cnt))
+        return out
 
     def input_words(self):
         a, b = C.c_uint32(), C.c_uint32()

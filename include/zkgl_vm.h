@@ -1,0 +1,112 @@
+/*
+ * zkgl_vm.h — everything the main_vm circuit takes from the crate `zkevm_opcode_defs` (absent from /root/reference: a git
+ * dependency, Cargo.toml:18, branch v1.4.1), gathered into ONE data blob that the host passes to
+ * zk_circuit_main_vm_configure().  The circuit STRUCTURE is restated from /root/reference/src/main_vm; the blob holds only
+ * data: the 2^11-row opcode table (OPCODES_PROPS_INTEGER_BITMASKS / OPCODES_PRICES, src/tables/opcodes_decoding.rs:14-38), the
+ * bit positions `OpcodeBitmask::from_full_mask` slices (src/main_vm/opcode_bitmask.rs:60-128), the sub-variant / flag indices the
+ * opcode closures ask for by name, and `system_params::*`.
+ *
+ * [EXT] zk_opcode_defs_default() fills a blob of the reference's SHAPE with this build's own enumeration of the variants and
+ * recollected constants; a host that links the real crate fills the same struct from it.
+ */
+#ifndef ZKGL_VM_H
+#define ZKGL_VM_H
+#include <stdint.h>
+#include "zkgl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_VM_OPCODE_TABLE_ROWS 2048 /* 1 << OPCODES_TABLE_WIDTH */
+#define ZK_VM_REGISTERS 15           /* REGISTERS_COUNT, src/base_structures/vm_state/mod.rs:29 */
+
+/* Opcode::variant_idx(): index of the family's one-hot boolean in opcode_type_booleans (16 = OPCODE_TYPE_BITS) */
+enum zk_vm_family {
+    ZK_VMF_INVALID = 0, ZK_VMF_NOP, ZK_VMF_ADD, ZK_VMF_SUB, ZK_VMF_MUL, ZK_VMF_DIV, ZK_VMF_JUMP, ZK_VMF_CONTEXT, ZK_VMF_SHIFT,
+    ZK_VMF_BINOP, ZK_VMF_PTR, ZK_VMF_NEAR_CALL, ZK_VMF_LOG, ZK_VMF_FAR_CALL, ZK_VMF_RET, ZK_VMF_UMA, ZK_VMF__COUNT
+};
+/* the sub-variants the circuit asks for through boolean_for_variant (materialize_subvariant_idx) */
+enum zk_vm_variant {
+    ZK_VMV_SHIFT_SHL = 0, ZK_VMV_SHIFT_SHR, ZK_VMV_SHIFT_ROL, ZK_VMV_SHIFT_ROR,
+    ZK_VMV_BINOP_XOR, ZK_VMV_BINOP_AND, ZK_VMV_BINOP_OR,
+    ZK_VMV_PTR_ADD, ZK_VMV_PTR_SUB, ZK_VMV_PTR_PACK, ZK_VMV_PTR_SHRINK,
+    ZK_VMV_CTX_THIS, ZK_VMV_CTX_CALLER, ZK_VMV_CTX_CODE_ADDRESS, ZK_VMV_CTX_META, ZK_VMV_CTX_ERGS_LEFT, ZK_VMV_CTX_SP,
+    ZK_VMV_CTX_GET_CONTEXT_U128, ZK_VMV_CTX_SET_CONTEXT_U128, ZK_VMV_CTX_SET_ERGS_PER_PUBDATA, ZK_VMV_CTX_INC_TX_NUMBER,
+    ZK_VMV_LOG_STORAGE_READ, ZK_VMV_LOG_STORAGE_WRITE, ZK_VMV_LOG_TO_L1, ZK_VMV_LOG_EVENT, ZK_VMV_LOG_PRECOMPILE_CALL,
+    ZK_VMV_FAR_NORMAL, ZK_VMV_FAR_DELEGATE, ZK_VMV_FAR_MIMIC,
+    ZK_VMV_RET_OK, ZK_VMV_RET_REVERT, ZK_VMV_RET_PANIC,
+    ZK_VMV_UMA_HEAP_READ, ZK_VMV_UMA_HEAP_WRITE, ZK_VMV_UMA_AUX_HEAP_READ, ZK_VMV_UMA_AUX_HEAP_WRITE, ZK_VMV_UMA_FAT_PTR_READ,
+    ZK_VMV__COUNT
+};
+/* flag_booleans indices by their reference names */
+enum zk_vm_flag {
+    ZK_VMFL_SET_FLAGS = 0,   /* SET_FLAGS_FLAG_IDX */
+    ZK_VMFL_SWAP_ARITH,      /* SWAP_OPERANDS_FLAG_IDX_FOR_ARITH_OPCODES */
+    ZK_VMFL_SWAP_PTR,        /* SWAP_OPERANDS_FLAG_IDX_FOR_PTR_OPCODE */
+    ZK_VMFL_FIRST_MESSAGE,   /* FIRST_MESSAGE_FLAG_IDX */
+    ZK_VMFL_UMA_INCREMENT,   /* UMA_INCREMENT_FLAG_IDX */
+    ZK_VMFL_FAR_CALL_STATIC, /* FAR_CALL_STATIC_FLAG_IDX */
+    ZK_VMFL_FAR_CALL_SHARD,  /* FAR_CALL_SHARD_FLAG_IDX */
+    ZK_VMFL_RET_TO_LABEL,    /* ret::RET_TO_LABEL_BIT_IDX */
+    ZK_VMFL__COUNT
+};
+/* ImmMemHandlerFlags::variant_index() */
+enum zk_vm_operand_mode {
+    ZK_VMM_REG_ONLY = 0, ZK_VMM_STACK_PUSH_POP, ZK_VMM_STACK_OFFSET, ZK_VMM_ABSOLUTE_STACK, ZK_VMM_IMM16, ZK_VMM_CODE_PAGE, ZK_VMM__COUNT
+};
+/* Condition, in the order of the match in src/tables/conditional.rs:35-44 */
+enum zk_vm_condition { ZK_VMC_ALWAYS = 0, ZK_VMC_LT, ZK_VMC_EQ, ZK_VMC_GT, ZK_VMC_GE, ZK_VMC_LE, ZK_VMC_NE, ZK_VMC_GT_OR_LT, ZK_VMC__COUNT };
+/* system_params / constants read by the circuit */
+enum zk_vm_param {
+    ZK_VMP_VM_MAX_STACK_DEPTH = 0, ZK_VMP_NEW_FRAME_MEMORY_STIPEND, ZK_VMP_NEW_MEMORY_PAGES_PER_FAR_CALL, ZK_VMP_UNMAPPED_PAGE,
+    ZK_VMP_BOOTLOADER_BASE_PAGE, ZK_VMP_BOOTLOADER_CODE_PAGE, ZK_VMP_BOOTLOADER_CALLDATA_PAGE, ZK_VMP_STARTING_BASE_PAGE,
+    ZK_VMP_STARTING_TIMESTAMP, ZK_VMP_INITIAL_FRAME_FORMAL_EH_LOCATION, ZK_VMP_VM_INITIAL_FRAME_ERGS,
+    ZK_VMP_BOOTLOADER_FORMAL_ADDRESS_LOW, ZK_VMP_BOOTLOADER_MAX_MEMORY, ZK_VMP_DEPLOYER_SYSTEM_CONTRACT_ADDRESS_LOW,
+    ZK_VMP_ERGS_PER_CODE_WORD_DECOMMITTMENT, ZK_VMP_INITIAL_STORAGE_WRITE_PUBDATA_BYTES, ZK_VMP_L1_MESSAGE_PUBDATA_BYTES,
+    ZK_VMP_STORAGE_AUX_BYTE, ZK_VMP_EVENT_AUX_BYTE, ZK_VMP_L1_MESSAGE_AUX_BYTE, ZK_VMP_PRECOMPILE_AUX_BYTE,
+    ZK_VMP_CODE_HASH_VERSION_BYTE, ZK_VMP_CODE_YET_CONSTRUCTED_MARKER, ZK_VMP_CODE_AT_REST_MARKER,
+    ZK_VMP_FAR_CALL_FORWARDING_MODE_BYTE_IDX, ZK_VMP_FAR_CALL_SHARD_ID_BYTE_IDX, ZK_VMP_FAR_CALL_CONSTRUCTOR_CALL_BYTE_IDX,
+    ZK_VMP_FAR_CALL_SYSTEM_CALL_BYTE_IDX, ZK_VMP_FORWARD_USE_HEAP, ZK_VMP_FORWARD_FAT_POINTER, ZK_VMP_FORWARD_USE_AUX_HEAP,
+    ZK_VMP_CALL_IMPLICIT_PARAMETER_REG_IDX, ZK_VMP_CALL_SYSTEM_ABI_REGISTERS_BEGIN, ZK_VMP_CALL_SYSTEM_ABI_REGISTERS_END,
+    ZK_VMP_CALL_RESERVED_RANGE_BEGIN, ZK_VMP_CALL_RESERVED_RANGE_END,
+    ZK_VMP__COUNT
+};
+
+typedef struct zk_opcode_defs {
+    uint32_t version;                              /* SUPPORTED_ISA_VERSION, src/main_vm/opcode_bitmask.rs:16 */
+    uint32_t n_valid;                              /* rows [0, n_valid) hold defined variants, the rest decode as Invalid */
+    uint64_t props[ZK_VM_OPCODE_TABLE_ROWS];       /* OPCODES_PROPS_INTEGER_BITMASKS: 48 description bits, then the aux bits */
+    uint32_t prices[ZK_VM_OPCODE_TABLE_ROWS];      /* OPCODES_PRICES */
+    /* description bits: [type 16 | variant 10 | flags 2 | src mode 6 | dst mode 4] = 38 meaningful of 48, aux from bit 48 */
+    uint32_t type_bits, variant_bits, flag_bits, src_mode_bits, dst_mode_bits, description_bits_flattened, aux_bits;
+    uint32_t aux_kernel_mode, aux_static_ok, aux_explicit_panic; /* KERNER_MODE_FLAG_IDX, CAN_BE_USED_IN_STATIC_CONTEXT_FLAG_IDX, EXPLICIT_PANIC_FLAG_IDX */
+    uint32_t variant_idx[ZK_VMV__COUNT];           /* index into opcode_variant_booleans */
+    uint32_t flag_idx[ZK_VMFL__COUNT];             /* index into flag_booleans */
+    uint32_t condition_idx[ZK_VMC__COUNT];         /* Condition::variant_index(): key of the conditional resolution table */
+    uint32_t can_write_dst0_into_memory[ZK_VMF__COUNT];
+    uint64_t nop_encoding, panic_encoding;         /* EncodingModeProduction::nop_encoding() / exception_revert_encoding() */
+    uint64_t nop_bitspread, panic_bitspread;       /* NOP_BITSPREAD_U64 / PANIC_BITSPREAD_U64 */
+    uint32_t params[ZK_VMP__COUNT];
+} zk_opcode_defs;
+
+/* [EXT] this build's blob (csrc/circuits/opcode_defs.cpp).  Opcode word layout (EncodingModeProduction, visible at
+ * src/main_vm/decoded_opcode.rs:408-514): bits 0..11 variant, 11..13 unused, 13..16 condition, 16..20 src0 register, 20..24 src1,
+ * 24..28 dst0, 28..32 dst1, 32..48 imm0, 48..64 imm1. */
+int zk_opcode_defs_default(zk_opcode_defs *out);
+/* index of the table row that encodes (family, variant index inside the family, src mode, dst mode, flag bits), or -1 */
+int zk_opcode_defs_find(const zk_opcode_defs *defs, uint32_t family, uint32_t variant, uint32_t src_mode, uint32_t dst_mode, uint32_t flags);
+
+/* main_vm_entry_point (src/main_vm/mod.rs:47-232) recorded with `limit` cycles: vm_cycle (src/main_vm/cycle.rs:28-795) is the
+ * loop body.  configure: geometry check (src/main_vm/cycle.rs:959-966), gate set, the VM tables of the src/tables sources built from
+ * the blob, BinopTable, Xor8 (range checks).  Input streams: see csrc/circuits/main_vm.cpp and zk_circuit_main_vm_layout. */
+int zk_circuit_main_vm_configure(zk_cs *cs, const zk_opcode_defs *defs);
+int zk_circuit_main_vm(zk_cs *cs, uint32_t limit);
+/* text description of the input streams of the recorded circuit, one field per line: "<scope> <name> <first word> <n words>\n"
+ * (scope = outer | loop).  buf = NULL returns the size. */
+int zk_circuit_main_vm_layout(zk_cs *cs, char *buf, size_t max_bytes, size_t *n_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
