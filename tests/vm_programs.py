@@ -63,10 +63,10 @@ class Asm:
                 self.emit("BINOP", "BINOP_OR", src0=reg, src1=tmp, dst0=reg)
 
 
-def program_arith(D):
+def program_arith(D, seed=0):
     a = Asm(D)
-    a.li(1, 0x1234)
-    a.li(2, 77)
+    a.li(1, (0x1234 + 977 * seed) & 0xFFFF)
+    a.li(2, 77 + seed)
     a.emit("ADD", src0=1, src1=2, dst0=3, flags=("SET_FLAGS",))
     a.emit("SUB", src0=2, src1=1, dst0=4, flags=("SET_FLAGS",))                      # underflow: of = 1
     a.emit("SUB", src0=2, src1=1, dst0=5, flags=("SET_FLAGS", "SWAP_ARITH"))         # swapped: r1 - r2
@@ -118,13 +118,13 @@ def program_arith(D):
     return a.ops
 
 
-def program_memory_and_logs(D):
+def program_memory_and_logs(D, seed=0):
     a = Asm(D)
-    a.load_u256(1, 0x0102030405060708090A0B0C0D0E0F101112131415161718191A1B1C1D1E1F20)
+    a.load_u256(1, 0x0102030405060708090A0B0C0D0E0F101112131415161718191A1B1C1D1E1F20 ^ (seed * 0x0101010101010101))
     a.li(2, 64)
     a.emit("UMA", "UMA_HEAP_WRITE", src0=2, src1=1, dst0=3, flags=("UMA_INCREMENT",))     # aligned write at 64, r3 = 96
-    a.li(2, 77)
-    a.emit("UMA", "UMA_HEAP_WRITE", src0=2, src1=1)                                        # unaligned write at 77: two cells
+    a.li(2, 65 + (12 + 5 * seed) % 31)
+    a.emit("UMA", "UMA_HEAP_WRITE", src0=2, src1=1)                                        # unaligned write (offset 77 for seed 0): two cells
     a.emit("UMA", "UMA_HEAP_READ", src0=2, dst0=4, dst1=5, flags=("UMA_INCREMENT",))      # unaligned read, r5 = 109
     a.emit("UMA", "UMA_HEAP_READ", src_mode="IMM16", imm0=64, dst0=4)                      # aligned read, immediate offset
     a.emit("UMA", "UMA_AUX_HEAP_WRITE", src0=5, src1=4)
@@ -146,10 +146,10 @@ def program_memory_and_logs(D):
     return a.ops
 
 
-def program_logs(D):
+def program_logs(D, seed=0):
     a = Asm(D)
-    a.li(1, 5)        # key
-    a.li(2, 0x3333)   # value
+    a.li(1, 5 + seed)        # key
+    a.li(2, 0x3333 + seed)   # value
     a.li(9, 3)
     a.emit("CONTEXT", "CTX_SET_ERGS_PER_PUBDATA", src0=9)
     a.emit("LOG", "LOG_STORAGE_WRITE", src0=1, src1=2)
@@ -168,19 +168,19 @@ FAR_ABI_FORWARD_FAT_POINTER = 1 << (8 * 28)
 FAR_ABI_AUX_HEAP = 2 << (8 * 28)
 
 
-def program_calls(D, callee_a=0x10001, callee_b=0x10002, callee_c=0x10004, missing=0x10003):
+def program_calls(D, seed=0, callee_a=0x10001, callee_b=0x10002, callee_c=0x10004, missing=0x10003):
     """near calls (ok / revert with writes inside, nested), far calls (ok with returndata, static violation -> panic, revert with
     writes, missing code -> exception), fat pointers in both directions.  A far return clears r2..r15, so the ABI registers are
     rebuilt before every far call."""
     a = Asm(D)
-    a.li(1, 5)
-    a.li(2, 0x4444)
+    a.li(1, 5 + seed)
+    a.li(2, 0x4444 + 3 * seed)
     a.emit("LOG", "LOG_STORAGE_WRITE", src0=1, src1=2)                 # a write in the root frame before any call
     a.li(3, 0)                                                         # near call abi: pass all ergs
     nc1 = a.emit("NEAR_CALL", src0=3, imm0=0, imm1=0)                  # patched below
     nc2 = a.emit("NEAR_CALL", src0=3, imm0=0, imm1=0)
     a.li(6, 64)
-    a.load_u256(7, 0xA1A2A3A4A5A6A7A8A9AAABACADAEAFB0B1B2B3B4B5B6B7B8B9BABBBCBDBEBFC0)
+    a.load_u256(7, 0xA1A2A3A4A5A6A7A8A9AAABACADAEAFB0B1B2B3B4B5B6B7B8B9BABBBCBDBEBFC0 ^ seed)
     a.emit("UMA", "UMA_HEAP_WRITE", src0=6, src1=7)                    # calldata at heap [64, 96)
     abi = (64 << 64) | (64 << 96) | (100000 << 192)                    # start 64, length 64, ergs passed 100000, forwarding = heap
 
@@ -312,3 +312,27 @@ def expected_commitment(D, run, limit, instance, first_cycle=0):
     c_fsm_in, c_fsm_out = zko.commit_encoding(fsm_in), zko.commit_encoding(final.flatten())
     compact = [start, done] + c_obs_in + (c_obs_out if done else z(4)) + (z(4) if start else c_fsm_in) + (z(4) if done else c_fsm_out)
     return zko.commit_encoding(compact)
+
+
+def mixed_batch(cs, D, limit, min_instances, seeds=None):
+    """instances drawn from the four programs with different seeds, each execution cut into consecutive `limit`-cycle chunks up to
+    (and including) the chunk in which the bootloader frame returns.  -> (outer, loop, [expected commitment per instance], info)"""
+    outers, loops, commits, info = [], [], [], []
+    seed = 0
+    while sum(o.shape[1] for o in outers) < min_instances:
+        for name in ("arith", "memory", "logs", "calls"):
+            contracts = None
+            if name == "calls":
+                ops, contracts = program_calls(D, seed)
+            else:
+                ops = dict(arith=program_arith, memory=program_memory_and_logs, logs=program_logs)[name](D, seed)
+            probe = vn.VmRun(D, make_world_factory(D, ops, contracts), 4 * len(ops) + 64)
+            done_at = next(i for i, s in enumerate(probe.states) if s.depth == 0)
+            n_inst = (done_at + 1 + limit - 1) // limit
+            vrun = vn.VmRun(D, make_world_factory(D, ops, contracts), n_inst * limit)
+            o, l = pack_instance_streams(cs, D, vrun, limit, n_inst)
+            outers.append(o); loops.append(l)
+            commits += [expected_commitment(D, vrun, limit, i) for i in range(n_inst)]
+            info += [(name, seed, i) for i in range(n_inst)]
+        seed += 1
+    return np.concatenate(outers, axis=1), np.concatenate(loops, axis=1), commits, info
