@@ -115,7 +115,7 @@ extern "C" int zk_opcode_defs_default(zk_opcode_defs* d) {
     P[ZK_VMP_BOOTLOADER_BASE_PAGE] = 8;
     P[ZK_VMP_BOOTLOADER_CODE_PAGE] = 8;
     P[ZK_VMP_BOOTLOADER_CALLDATA_PAGE] = 7;
-    P[ZK_VMP_STARTING_BASE_PAGE] = 8;
+    P[ZK_VMP_STARTING_BASE_PAGE] = 16;  // first free page after the bootloader's frame (base 8: code 8, stack 9, heap 10, aux heap 11)
     P[ZK_VMP_STARTING_TIMESTAMP] = 1024;
     P[ZK_VMP_INITIAL_FRAME_FORMAL_EH_LOCATION] = 0xffff;
     P[ZK_VMP_BOOTLOADER_FORMAL_ADDRESS_LOW] = 0x8001;

@@ -36,3 +36,16 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value: float, device=None):
+    """one float per rank -> list over ranks (per-rank step times of bench.py, so that a multi-GPU run is diagnosable)"""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

@@ -41,6 +41,7 @@ extern "C" {
 uint64_t zko_gl_add(uint64_t a, uint64_t b);
 uint64_t zko_gl_sub(uint64_t a, uint64_t b);
 uint64_t zko_gl_mul(uint64_t a, uint64_t b);
+uint64_t zko_gl_mul_slow(uint64_t a, uint64_t b); /* (a * b) % p by 128-bit division: cross-check only */
 uint64_t zko_gl_pow(uint64_t a, uint64_t e);
 uint64_t zko_gl_inv(uint64_t a); /* 0 -> 0 */
 uint64_t zko_gl_reduce(uint64_t a); /* canonical representative */

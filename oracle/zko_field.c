@@ -16,10 +16,25 @@ uint64_t zko_gl_sub(uint64_t a, uint64_t b) {
     return a >= b ? a - b : a + (ZKO_P - b);
 }
 
+/* the textbook definition: the 128-bit product's remainder (a libgcc __umodti3 call).  Kept as the cross-check of
+ * zko_gl_mul (tests/test_oracle.py) — it is what the oracle used in round 1 and it made the CPU baseline slow. */
+uint64_t zko_gl_mul_slow(uint64_t a, uint64_t b) {
+    unsigned __int128 w = (unsigned __int128)a * b;
+    return (uint64_t)(w % ZKO_P);
+}
+
+/* Standard Goldilocks reduction of a 128-bit product (the one production CPU provers use): with
+ * x = lo + 2^64 (hi_lo + 2^32 hi_hi), 2^64 = 2^32 - 1 and 2^96 = -1 (mod p):  x = lo - hi_hi + hi_lo (2^32 - 1). */
 uint64_t zko_gl_mul(uint64_t a, uint64_t b) {
     unsigned __int128 w = (unsigned __int128)a * b;
-    /* independent of the GPU's 96-bit folding: plain 128-bit remainder */
-    return (uint64_t)(w % ZKO_P);
+    uint64_t lo = (uint64_t)w, hi = (uint64_t)(w >> 64);
+    uint64_t hi_hi = hi >> 32, hi_lo = hi & ZKO_EPS;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= ZKO_EPS;         /* borrow: subtract 2^64 = eps (mod p) */
+    uint64_t t1 = hi_lo * ZKO_EPS;         /* < 2^64 */
+    uint64_t r = t0 + t1;
+    if (r < t1) r += ZKO_EPS;              /* carry */
+    return r >= ZKO_P ? r - ZKO_P : r;
 }
 
 uint64_t zko_gl_pow(uint64_t a, uint64_t e) {

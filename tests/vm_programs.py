@@ -250,6 +250,88 @@ def program_calls(D, seed=0, callee_a=0x10001, callee_b=0x10002, callee_c=0x1000
     return a.ops, {callee_a: ca.ops, callee_b: cb.ops, callee_c: cc.ops}
 
 
+def program_bench_loop(D, seed=0, callee_a=0x10001, callee_c=0x10004):
+    """endless mixed workload for the throughput runs (bench.py config C2): every family, calls nested two deep, the root frame
+    never returns.  One trip around the loop is ~150 cycles."""
+    a = Asm(D)
+    a.li(9, 3)
+    a.emit("CONTEXT", "CTX_SET_ERGS_PER_PUBDATA", src0=9)
+    top = len(a.ops)
+    a.li(1, (0x1234 + 977 * seed) & 0xFFFF)
+    a.li(2, 77 + seed)
+    a.emit("SUB", src0=2, src1=1, dst0=4, flags=("SET_FLAGS",))
+    a.emit("MUL", src0=4, src1=4, dst0=6, dst1=7, flags=("SET_FLAGS",))
+    a.emit("DIV", src0=6, src1=1, dst0=8, dst1=9)
+    a.emit("BINOP", "BINOP_XOR", src0=4, src1=6, dst0=10, flags=("SET_FLAGS",))
+    a.emit("BINOP", "BINOP_AND", src0=4, src1=8, dst0=11)
+    a.li(13, 100 + seed)
+    a.emit("SHIFT", "SHIFT_ROL", src0=4, src1=13, dst0=3)
+    a.emit("SHIFT", "SHIFT_SHR", src0=6, src1=13, dst0=5, flags=("SET_FLAGS",))
+    a.emit("ADD", src0=4, src1=0, dst_mode="STACK_PUSH_POP", imm1=1)
+    a.emit("ADD", src_mode="STACK_PUSH_POP", imm0=1, src1=3, dst0=5, cond="NE")
+    a.emit("ADD", src_mode="STACK_PUSH_POP", imm0=1, src1=3, dst0=5, cond="EQ")
+    a.li(12, 64)
+    a.emit("UMA", "UMA_HEAP_WRITE", src0=12, src1=6, dst0=12, flags=("UMA_INCREMENT",))
+    a.li(12, 77)
+    a.emit("UMA", "UMA_HEAP_WRITE", src0=12, src1=10)
+    a.emit("UMA", "UMA_HEAP_READ", src0=12, dst0=8, dst1=9, flags=("UMA_INCREMENT",))
+    a.emit("UMA", "UMA_AUX_HEAP_WRITE", src0=9, src1=8)
+    a.emit("LOG", "LOG_STORAGE_WRITE", src0=1, src1=2)
+    a.emit("LOG", "LOG_STORAGE_READ", src0=1, dst0=3)
+    a.emit("LOG", "LOG_EVENT", src0=1, src1=2, flags=("FIRST_MESSAGE",))
+    a.emit("LOG", "LOG_TO_L1", src0=1, src1=2)
+    a.li(3, 1000)
+    a.emit("LOG", "LOG_PRECOMPILE_CALL", src0=1, src1=3, dst0=5)
+    a.emit("CONTEXT", "CTX_META", dst0=3)
+    a.emit("CONTEXT", "CTX_INC_TX_NUMBER")
+    a.li(3, 0)
+    nc1 = a.emit("NEAR_CALL", src0=3, imm0=0, imm1=0)
+    nc2 = a.emit("NEAR_CALL", src0=3, imm0=0, imm1=0)
+    abi = (64 << 64) | (64 << 96) | (100000 << 192)
+
+    def far_call(variant, target, flags=()):
+        a.load_u256(4, abi)
+        a.load_u256(5, target)
+        i = a.emit("FAR_CALL", variant, src0=4, src1=5, imm0=0, flags=flags)
+        a.ops[i] |= (i + 1) << 32
+        return i
+
+    far_call("FAR_NORMAL", callee_a)
+    a.li(3, 0)
+    a.emit("PTR", "PTR_ADD", src0=1, src1=3, dst0=8)
+    a.emit("UMA", "UMA_FAT_PTR_READ", src0=1, dst0=9)
+    far_call("FAR_NORMAL", callee_c)
+    a.emit("JUMP", src_mode="IMM16", imm0=top)
+    body1 = len(a.ops)
+    a.emit("LOG", "LOG_STORAGE_WRITE", src0=1, src1=1)
+    inner = a.emit("NEAR_CALL", src0=3, imm0=0, imm1=0)
+    a.emit("RET", "RET_OK", src0=0)
+    body2 = len(a.ops)
+    a.emit("LOG", "LOG_STORAGE_WRITE", src0=2, src1=2)
+    a.emit("LOG", "LOG_EVENT", src0=2, src1=1)
+    a.emit("RET", "RET_REVERT", src0=0, flags=("RET_TO_LABEL",), imm0=nc2 + 1)
+    body3 = len(a.ops)
+    a.emit("LOG", "LOG_EVENT", src0=1, src1=2)
+    a.emit("RET", "RET_OK", src0=0)
+    for i, (dst, eh) in ((nc1, (body1, 0xFFFF)), (nc2, (body2, nc2 + 1)), (inner, (body3, 0xFFFF))):
+        a.ops[i] = (a.ops[i] & 0xFFFFFFFF) | (dst << 32) | (eh << 48)
+    ca = Asm(D)
+    ca.emit("UMA", "UMA_FAT_PTR_READ", src0=1, dst0=2, dst1=3, flags=("UMA_INCREMENT",))
+    ca.emit("UMA", "UMA_FAT_PTR_READ", src0=3, dst0=4)
+    ca.li(6, 9)
+    ca.emit("LOG", "LOG_STORAGE_WRITE", src0=6, src1=2)
+    ca.li(7, 0)
+    ca.emit("UMA", "UMA_HEAP_WRITE", src0=7, src1=2)
+    ca.load_u256(8, (0 << 64) | (32 << 96))
+    ca.emit("RET", "RET_OK", src0=8)
+    cc = Asm(D)
+    cc.li(6, 11)
+    cc.emit("LOG", "LOG_STORAGE_WRITE", src0=6, src1=6)
+    cc.load_u256(8, (0 << 64) | (40 << 96) | FAR_ABI_AUX_HEAP)
+    cc.emit("RET", "RET_REVERT", src0=8)
+    return a.ops, {callee_a: ca.ops, callee_c: cc.ops}
+
+
 def make_world_factory(D, boot_ops, contracts=None):
     def make():
         w = vn.World()
