@@ -98,6 +98,8 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_rowconsts) hipFree(s.d_rowconsts);
     if (s.d_lrows) hipFree(s.d_lrows);
     if (s.d_copies) hipFree(s.d_copies);
+    if (s.d_alias) hipFree(s.d_alias);
+    s.d_alias = nullptr;
     if (s.d_cells) hipFree(s.d_cells);
     s.d_prog = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
     s.d_copies = nullptr; s.d_cells = nullptr;
@@ -482,8 +484,13 @@ void CS::place_scope(Scope& s) {
     s.n_cells = s.n_trace_cells + s.n_scratch;
     if (s.n_cells >= 0x3fffffffu) throw ZkError(ZK_ERR_CAPACITY, "scope too large for 30-bit cell indices");
     s.copies.clear();
+    s.alias.resize(s.n_trace_cells);
+    for (uint32_t c = 0; c < s.n_trace_cells; ++c) s.alias[c] = c;
     for (uint32_t v = 0; v < s.n_vars; ++v)
-        for (size_t i = 1; i < s.var_cells[v].size(); ++i) s.copies.push_back({s.var_cells[v][i], s.var_cells[v][0]});
+        for (size_t i = 1; i < s.var_cells[v].size(); ++i) {
+            s.copies.push_back({s.var_cells[v][i], s.var_cells[v][0]});
+            s.alias[s.var_cells[v][i]] = s.var_cells[v][0];
+        }
 }
 
 // ------------------------------------------------------------------ op scheduling (loop scope)
@@ -601,6 +608,7 @@ void CS::emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) co
 void CS::emit_dests(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const {
     for (uint32_t ov : op.outs) {
         const auto& cells = s.var_cells[ov];
+        if (!emit_full_) { out.push_back(cells[0]); continue; }  // compact device program: the home cell only
         for (size_t i = 0; i < cells.size(); ++i) out.push_back(cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0));
     }
 }
@@ -774,24 +782,29 @@ void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t wo
 
 void CS::emit_scope(Scope& s) {
     std::vector<uint8_t> defined(s.n_vars, 0);
-    s.prog.clear();
-    s.pre_words = 0;
-    s.cells_written = 0;
+    s.prog.clear(); s.prog_full.clear();
+    s.pre_words = 0; s.pre_words_full = 0;
+    s.cells_written = 0; s.cells_populated = 0;
     for (size_t oi = 0; oi < s.ops.size(); ++oi) {
-        if (!s.is_loop && oi == s.pre_ops) s.pre_words = (uint32_t)s.prog.size();
+        if (!s.is_loop && oi == s.pre_ops) { s.pre_words = (uint32_t)s.prog.size(); s.pre_words_full = (uint32_t)s.prog_full.size(); }
         if (!s.is_loop && oi == s.side_ops) s.side_words = (uint32_t)s.prog.size();
         const OpRec& op = s.ops[oi];
         if (op.seed_only) continue;
         for (auto& in : op.ins)
             if (in.kind == Operand::VAR && !defined[in.idx]) throw ZkError(ZK_ERR_UNRESOLVED, "witness op reads a variable no earlier op produced");
+        emit_full_ = false;
         emit_op(s, op, s.prog);
+        emit_full_ = true;
+        emit_op(s, op, s.prog_full);
+        emit_full_ = false;
         for (uint32_t ov : op.outs) {
             if (defined[ov]) throw ZkError(ZK_ERR_INVALID, "variable produced twice");
             defined[ov] = 1;
-            s.cells_written += s.var_cells[ov].size();
+            s.cells_written += 1;
+            s.cells_populated += s.var_cells[ov].size();
         }
     }
-    if (!s.is_loop && s.pre_ops >= s.ops.size()) s.pre_words = (uint32_t)s.prog.size();
+    if (!s.is_loop && s.pre_ops >= s.ops.size()) { s.pre_words = (uint32_t)s.prog.size(); s.pre_words_full = (uint32_t)s.prog_full.size(); }
     if (!s.is_loop && s.side_ops >= s.ops.size()) s.side_words = (uint32_t)s.prog.size();
     if (!s.is_loop && s.side_words < s.pre_words) s.side_words = s.pre_words;
     for (auto& g : s.gates)
@@ -1029,6 +1042,7 @@ void CS::upload_scope(Scope& s) {
     s.d_rowconsts = upload(s.rowconsts);
     s.d_lrows = upload(s.lrows);
     s.d_copies = upload(s.copies);
+    s.d_alias = upload(s.alias);
 }
 
 void CS::finalize() {
@@ -1254,10 +1268,12 @@ void CS::resolve(void* stream) {
     hipEventElapsedTime(&b, (hipEvent_t)ev_[1], (hipEvent_t)ev_[2]);
     hipEventElapsedTime(&c, (hipEvent_t)ev_[2], (hipEvent_t)ev_[3]);
     ms_[0] = a + b + c; ms_[1] = b; ms_[4] = a + c;
+    compact_ = true;  // home cells only: see check_satisfied / ensure_materialized
 }
 
-zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail) const {
+zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool compact) const {
     zkdev::CheckArgs a;
+    a.alias = compact ? s.d_alias : nullptr;
     a.cells = s.d_cells; a.n_cells = s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
     a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
     a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
@@ -1275,17 +1291,24 @@ zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail) const 
 int CS::check_satisfied(void* stream, zk_failure* first) {
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "check_satisfied before set_batch");
     hipStream_t st = (hipStream_t)stream;
+    // compact trace (straight from the witness kernels): a variable has ONE stored value, the gate checker reads every cell
+    // through the alias map and copy constraints inside a scope hold by construction (boojum's check_if_satisfied has no such
+    // pass either: its values live per variable).  Materialised trace (zk_cs_trace_ptr / write_cell / prover-stage kernels were
+    // used): every cell is checked as stored, and every copy pair explicitly.
+    const bool compact = compact_;
     hip_check(hipMemsetAsync(d_fail_, 0xff, 8 * sizeof(unsigned long long), st), "memset fail");
     hip_check(hipEventRecord((hipEvent_t)ev_[4], st), "event");
-    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_), st));
-    dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies,
-                                         (uint32_t)outer_.copies.size(), d_fail_, st));
+    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, compact), st));
+    if (!compact)
+        dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies,
+                                             (uint32_t)outer_.copies.size(), d_fail_, st));
     hip_check(hipEventRecord((hipEvent_t)ev_[5], st), "event");
     if (limit_) {
-        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3), st));
+        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, compact), st));
         hip_check(hipEventRecord((hipEvent_t)ev_[6], st), "event");
-        dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies,
-                                             (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
+        if (!compact)
+            dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies,
+                                                 (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
         dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.n_cells, loop_.n_lanes, limit_, outer_.d_cells,
                                             outer_.n_cells, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
         check_streams(st);
@@ -1303,10 +1326,20 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
     return decode_failure(f, first);
 }
 
+void CS::ensure_materialized(void* stream) {
+    if (!compact_ || batch_ == 0) return;
+    hipStream_t st = (hipStream_t)stream;
+    dev_check(zkdev::launch_materialize(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies, (uint32_t)outer_.copies.size(), st));
+    if (limit_) dev_check(zkdev::launch_materialize(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies, (uint32_t)loop_.copies.size(), st));
+    hip_check(hipStreamSynchronize(st), "materialize sync");
+    compact_ = false;
+}
+
 // K10 (kernels_lookup_arg.hpp): the witness side sums 1/f over every lookup tuple of the trace, the table side sums
 // multiplicity/f over the table rows; equality per instance is the log-derivative lookup argument.
 uint32_t CS::lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], void* stream, std::vector<uint64_t>& out) {
     if (batch_ == 0 || !uploaded_) throw ZkError(ZK_ERR_INVALID, "lookup_argument before set_batch / resolve");
+    ensure_materialized(stream);
     if (lookup_reps_ > 32) throw ZkError(ZK_ERR_INVALID, "lookup_argument: more than 32 repetitions per row");
     hipStream_t st = (hipStream_t)stream;
     auto emul = [](const uint64_t x[2], const uint64_t y[2], uint64_t r[2]) {  // host GF(p^2), X^2 = 7
@@ -1428,15 +1461,12 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     launch_phase(outer_, oa, 1, outer_.pre_words, outer_.side_words, ax);             // outer SIDE (|| LOOP)
     hip_check(hipStreamWaitEvent(ax, E(3), 0), "wait");
     launch_phase(outer_, oa, 2, outer_.side_words, (uint32_t)outer_.prog.size(), ax);  // outer POST
-    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_), ax));
-    dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies,
-                                         (uint32_t)outer_.copies.size(), d_fail_, ax));
+    // compact traces: the gate checkers read every cell through the alias map; no copy pass (see check_satisfied)
+    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, true), ax));
     hip_check(hipEventRecord(E(4), ax), "event");
     if (limit_) {
-        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3), st));
+        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, true), st));
         hip_check(hipEventRecord(E(5), st), "event");
-        dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies,
-                                             (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
     } else {
         hip_check(hipEventRecord(E(5), st), "event");
     }
@@ -1458,6 +1488,7 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hipEventElapsedTime(&total, E(0), E(7));
     hipEventElapsedTime(&outer_post, E(3), E(4));
     ms_[0] = total; ms_[1] = loop_ms; ms_[2] = gates_ms + copies_ms; ms_[3] = gates_ms; ms_[4] = outer_post;
+    compact_ = true;
     return decode_failure(f, first);
 }
 
@@ -1479,6 +1510,7 @@ uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
 void CS::write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value) {
     Scope& s = loop_scope ? loop_ : outer_;
     if (batch_ == 0 || cell >= s.n_cells || lane >= s.n_lanes) throw ZkError(ZK_ERR_INVALID, "write_cell: out of range");
+    ensure_materialized(nullptr);  // an externally modified trace is checked cell by cell, copies included
     hip_check(hipMemcpy(s.d_cells + tiled_offset(s.n_cells, cell, lane), &value, 8, hipMemcpyHostToDevice), "write_cell memcpy");
 }
 
@@ -1524,6 +1556,7 @@ void CS::stats(zk_stats* o) const {
     o->program_words_outer = outer_.prog.size(); o->program_words_loop = loop_.prog.size();
     o->scratch_cells_outer = outer_.n_scratch; o->scratch_cells_loop = loop_.n_scratch;
     o->cells_written_outer = outer_.cells_written; o->cells_written_loop = loop_.cells_written;
+    o->cells_populated_outer = outer_.cells_populated; o->cells_populated_loop = loop_.cells_populated;
     o->copy_pairs_outer = outer_.copies.size(); o->copy_pairs_loop = loop_.copies.size();
     o->seed_ops = seed_ops_; o->seed_words = seed_prog_.size(); o->seed_slots = seed_slots_; o->loop_ops = loop_.ops.size();
 }
@@ -1548,13 +1581,13 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
             stream_words.insert(stream_words.end(), sr.b.begin(), sr.b.end());
         }
     uint32_t hdr[21] = {0x5a4b4733u, s.is_loop ? 1u : 0u, s.n_cells, s.n_trace_cells, s.n_slots,
-                        geo_.num_columns_under_copy_permutation, lookup_width_, s.n_input_words, limit_, s.pre_words,
-                        (uint32_t)s.prog.size(), (uint32_t)s.const_pool.size(), (uint32_t)s.rows.size(),
+                        geo_.num_columns_under_copy_permutation, lookup_width_, s.n_input_words, limit_, s.pre_words_full,
+                        (uint32_t)s.prog_full.size(), (uint32_t)s.const_pool.size(), (uint32_t)s.rows.size(),
                         (uint32_t)s.rowconsts.size(), (uint32_t)s.lrows.size(), (uint32_t)s.copies.size(),
                         (uint32_t)tables_.size() + 1, (uint32_t)words.size(), (uint32_t)(loop_scope ? links_.size() : 0),
                         (uint32_t)(loop_scope ? carries_.size() : 0), (uint32_t)stream_words.size()};
     o.insert(o.end(), hdr, hdr + 21);
-    o.insert(o.end(), s.prog.begin(), s.prog.end());
+    o.insert(o.end(), s.prog_full.begin(), s.prog_full.end());  // the oracle materialises every cell
     for (uint64_t c : s.const_pool) p64(c);
     for (auto& r : s.rows) { o.push_back(r.kind); o.push_back(r.n_instances); o.push_back(r.const_off); o.push_back(r.n_consts); }
     for (uint64_t c : s.rowconsts) p64(c);
@@ -1574,8 +1607,9 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
     return o;
 }
 
-void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream) const {
+void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream) {
     if (!finalized_ || batch_ == 0) throw ZkError(ZK_ERR_INVALID, "trace_columns before set_batch");
+    ensure_materialized(stream);
     if (instance >= batch_) throw ZkError(ZK_ERR_INVALID, "trace_columns: instance out of range");
     const uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
     if (log_n > 32 || ((uint64_t)1 << log_n) < rows) throw ZkError(ZK_ERR_INVALID, "trace_columns: 2^log_n smaller than the trace");
@@ -1588,7 +1622,8 @@ void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint6
     dev_check(zkdev::launch_trace_columns(a, stream));
 }
 
-void CS::trace_ptr(bool loop_scope, uint64_t** cells, uint64_t* n_cells, uint64_t* stride) const {
+void CS::trace_ptr(bool loop_scope, uint64_t** cells, uint64_t* n_cells, uint64_t* stride) {
+    ensure_materialized(nullptr);
     const Scope& s = loop_scope ? loop_ : outer_;
     *cells = s.d_cells; *n_cells = s.n_cells; *stride = s.stride;
 }

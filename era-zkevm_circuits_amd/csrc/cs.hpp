@@ -81,8 +81,12 @@ struct Scope {
     uint32_t n_slots = 0, n_gate_slots = 0, n_lookup_slots = 0;
     uint32_t n_trace_cells = 0, n_cells = 0, n_scratch = 0;
     std::vector<std::vector<uint32_t>> var_cells;  // per var: cells, [0] = home
-    std::vector<uint32_t> prog;
-    uint32_t pre_words = 0, side_words = 0;
+    // device program: COMPACT — every value is stored to the home cell of its variable only (the gate checker reads through
+    // `alias`, k_materialize fills the other cells on demand).  prog_full: every cell of every variable (export to the oracle).
+    std::vector<uint32_t> prog, prog_full;
+    uint32_t pre_words = 0, side_words = 0, pre_words_full = 0;
+    std::vector<uint32_t> alias;  // trace cell -> home cell of the variable placed there (itself for unpopulated cells)
+    uint64_t cells_populated = 0; // trace cells + scratch cells holding a value == destination words of prog_full
     // strand form of the program (build_strands): phase 0 = loop body / outer pre, 1 = outer side, 2 = outer post
     std::vector<uint32_t> sprog;
     uint32_t s_begin[3][8] = {}, s_end[3][8] = {};
@@ -104,6 +108,7 @@ struct Scope {
     uint64_t* d_rowconsts = nullptr;
     zk_lookup_row_desc* d_lrows = nullptr;
     zk_copy_pair* d_copies = nullptr;
+    uint32_t* d_alias = nullptr;
     uint64_t* d_cells = nullptr;
     uint64_t stride = 0;
     uint32_t n_lanes = 0;
@@ -170,8 +175,8 @@ class CS {
     float last_ms(int which) const;
     std::vector<uint32_t> export_scope(bool loop_scope) const;
     // columns of one instance's trace as polynomials of 2^log_n values (kernels_ntt.hpp k_trace_columns_*)
-    void trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream) const;
-    void trace_ptr(bool loop_scope, uint64_t** cells, uint64_t* n_cells, uint64_t* stride) const;
+    void trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream);
+    void trace_ptr(bool loop_scope, uint64_t** cells, uint64_t* n_cells, uint64_t* stride);
 
     // circuit-layer attachments: the main_vm opcode-defs blob (include/zkgl_vm.h) handed to configure, and the text
     // description of the input streams the recorded circuit reads (zk_circuit_main_vm_layout)
@@ -196,6 +201,10 @@ class CS {
     void emit_scope(Scope& s);
     void emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const;
     void emit_dests(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const;
+    mutable bool emit_full_ = false;  // emit_dests: every cell of the variable (export) instead of the home cell only
+    // compact trace -> full trace (kernels_engine.hpp k_materialize); no-op when the trace is already materialised
+    void ensure_materialized(void* stream);
+    bool compact_ = true;
     void build_strands(Scope& s);
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t word_begin, uint32_t word_end, void* stream) const;
@@ -205,7 +214,7 @@ class CS {
     void check_var(zk_var v, bool want_loop) const;
     int decode_failure(const unsigned long long* f, zk_failure* first) const;
     void check_streams(void* stream);
-    zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail) const;
+    zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail, bool compact) const;
 
     zk_geometry geo_;
     uint64_t max_trace_len_, max_variables_;

@@ -120,6 +120,7 @@ uint32_t CS::copy_permutation(const uint64_t beta[2], const uint64_t gamma[2], v
     if (batch_ == 0 || !uploaded_) throw ZkError(ZK_ERR_INVALID, "copy_permutation before set_batch / resolve");
     for (int i = 0; i < 2; ++i)
         if (beta[i] >= P || gamma[i] >= P) throw ZkError(ZK_ERR_INVALID, "copy_permutation: non-canonical challenge");
+    ensure_materialized(stream);  // the argument runs over every trace cell
     build_sigma();
     if (!d_sig_rel_[0]) {
         for (int s = 0; s < 2; ++s) { d_sig_rel_[s] = up(sig_rel_[s]); d_ep_index_[s] = up(ep_index_[s]); d_ovr_[s] = up(ovr_[s]); }

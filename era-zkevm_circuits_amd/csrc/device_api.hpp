@@ -20,6 +20,7 @@ struct CheckArgs {  // mirrors zke::CheckDev
     const zk_row_desc* rows; const uint64_t* rowconsts; const zk_lookup_row_desc* lrows;
     uint32_t n_copy_cols; uint32_t lookup_width; const zk_table_desc* tables; const uint64_t* table_words;
     unsigned long long* fail; uint32_t slots_per_chunk;
+    const uint32_t* alias;  // compact trace: trace cell -> home cell (nullptr: materialised trace)
 };
 
 int upload_round_constants(const uint64_t rc[360]);
@@ -42,6 +43,7 @@ struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // 
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);
 int launch_check_gates(const CheckArgs& cd, void* stream);
+int launch_materialize(uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs, uint32_t n_pairs, void* stream);
 int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs,
                         uint32_t n_pairs, unsigned long long* fail, void* stream);
 // K10 lookup-argument accumulators (kernels_lookup_arg.hpp).  ch = beta, gamma, gamma^2, gamma^3, gamma^4 (2 words each)

@@ -919,6 +919,9 @@ struct CheckDev {
     const uint64_t* table_words;
     unsigned long long* fail;   // [0] gates/lookups, [1] copies, [2] links
     uint32_t slots_per_chunk;
+    // compact traces (only the home cell of every variable is stored by the witness kernels): trace cell -> home cell of the
+    // variable placed there; nullptr for a materialised trace
+    const uint32_t* alias;
 };
 
 __device__ __constant__ const unsigned char GATE_WIDTH[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5};
@@ -928,7 +931,8 @@ __device__ __forceinline__ void report(unsigned long long* f, uint32_t lane, uin
     atomicMin(f, key);
 }
 
-__global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) {
+template <bool ALIAS>
+__device__ __forceinline__ void check_gates_body(const CheckDev& cd) {
     const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if (lane >= cd.n_lanes) return;
     const uint32_t s0 = blockIdx.y * cd.slots_per_chunk;
@@ -940,8 +944,13 @@ __global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) {
         const uint32_t kind = uni(d.kind), ninst = uni(d.n_instances);
         const uint64_t* __restrict__ k = cd.rowconsts + uni(d.const_off);
         const uint32_t w = GATE_WIDTH[kind];
-        // every cell is read exactly once by this kernel: non-temporal loads (-2.8 % kernel time)
-        auto cell = [&](uint32_t col) -> uint64_t { return __builtin_nontemporal_load(&cells[((size_t)slot * NC + col) << 6]); };
+        // materialised trace: every cell is read exactly once by this kernel, non-temporal loads (-2.8 % kernel time).
+        // compact trace: the cell's variable lives in its home cell (wave-uniform index from the alias map); homes are read
+        // once per occurrence of the variable, so these loads stay cacheable
+        auto cell = [&](uint32_t col) -> uint64_t {
+            if constexpr (ALIAS) return cells[(size_t)uni(cd.alias[(size_t)slot * NC + col]) << 6];
+            else return __builtin_nontemporal_load(&cells[((size_t)slot * NC + col) << 6]);
+        };
         for (uint32_t j = 0; j < ninst; ++j) {
             const uint32_t c0 = j * w;
             switch (kind) {
@@ -1034,6 +1043,23 @@ __global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) {
                 if (!ok) report(cd.fail, lane, slot, 0x80 | u, 15);
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) { check_gates_body<false>(cd); }
+__global__ __launch_bounds__(TPB) void k_check_gates_compact(CheckDev cd) { check_gates_body<true>(cd); }
+
+// compact -> materialised trace: every non-home cell of a variable receives the home cell's value (the prover-stage kernels,
+// zk_cs_trace_columns and the trace readers want the full trace; the witness + check pipeline never needs it)
+__global__ __launch_bounds__(TPB) void k_materialize(uint64_t* __restrict__ cells_all, uint64_t n_cells, uint32_t n_lanes,
+                                                     const zk_copy_pair* __restrict__ pairs, uint32_t n_pairs, uint32_t pairs_per_chunk) {
+    const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if (lane >= n_lanes) return;
+    uint64_t* __restrict__ cells = cells_all + cell_off(n_cells, 0, lane);
+    const uint32_t p0 = blockIdx.y * pairs_per_chunk, p1 = min(p0 + pairs_per_chunk, n_pairs);
+    for (uint32_t i = p0; i < p1; ++i) {
+        const zk_copy_pair p = pairs[i];
+        __builtin_nontemporal_store(cells[(size_t)uni(p.home) << 6], &cells[(size_t)uni(p.cell) << 6]);
     }
 }
 

@@ -148,10 +148,22 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
     zke::CheckDev d;
     d.cells = a.cells; d.n_cells = a.n_cells; d.n_cols = a.n_cols; d.n_lanes = a.n_lanes; d.n_slots = a.n_slots; d.rows = a.rows;
     d.rowconsts = a.rowconsts; d.lrows = a.lrows; d.n_copy_cols = a.n_copy_cols; d.lookup_width = a.lookup_width;
-    d.tables = a.tables; d.table_words = a.table_words; d.fail = a.fail; d.slots_per_chunk = a.slots_per_chunk;
+    d.tables = a.tables; d.table_words = a.table_words; d.fail = a.fail; d.slots_per_chunk = a.slots_per_chunk; d.alias = a.alias;
     dim3 grid(grid_for(a.n_lanes, zke::TPB), (a.n_slots + a.slots_per_chunk - 1) / a.slots_per_chunk);
-    zke::k_check_gates<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
+    if (a.alias) zke::k_check_gates_compact<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
+    else zke::k_check_gates<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
     return LAUNCH_CHECK("k_check_gates");
+}
+
+int launch_materialize(uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs, uint32_t n_pairs, void* stream) {
+    if (n_lanes == 0 || n_pairs == 0) return 0;
+    unsigned lane_tiles = grid_for(n_lanes, zke::TPB);
+    uint32_t chunks = std::max<uint32_t>(2, (2048 + lane_tiles - 1) / lane_tiles);
+    if (chunks > n_pairs) chunks = n_pairs;
+    uint32_t per = (n_pairs + chunks - 1) / chunks;
+    dim3 grid(lane_tiles, (n_pairs + per - 1) / per);
+    zke::k_materialize<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(cells, n_cells, n_lanes, pairs, n_pairs, per);
+    return LAUNCH_CHECK("k_materialize");
 }
 
 int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs,

@@ -66,7 +66,8 @@ class _Stats(C.Structure):
                 ("scratch_cells_outer", C.c_uint64), ("scratch_cells_loop", C.c_uint64),
                 ("cells_written_outer", C.c_uint64), ("cells_written_loop", C.c_uint64),
                 ("copy_pairs_outer", C.c_uint64), ("copy_pairs_loop", C.c_uint64),
-                ("seed_ops", C.c_uint64), ("seed_words", C.c_uint64), ("seed_slots", C.c_uint64), ("loop_ops", C.c_uint64)]
+                ("seed_ops", C.c_uint64), ("seed_words", C.c_uint64), ("seed_slots", C.c_uint64), ("loop_ops", C.c_uint64),
+                ("cells_populated_outer", C.c_uint64), ("cells_populated_loop", C.c_uint64)]
 
 
 _lib = None

@@ -199,10 +199,11 @@ typedef struct zk_stats {
     uint64_t lookups_per_instance;
     uint64_t program_words_outer, program_words_loop;
     uint64_t scratch_cells_outer, scratch_cells_loop;
-    uint64_t cells_written_outer, cells_written_loop; /* populated cells one lane writes (algorithmic bytes / 8) */
+    uint64_t cells_written_outer, cells_written_loop; /* words one lane's witness kernels store: one per variable (home cells) */
     uint64_t copy_pairs_outer, copy_pairs_loop;
     /* cone seeding program (backward slice of the carried outputs; 0 when the generic sequential mode is used) */
     uint64_t seed_ops, seed_words, seed_slots, loop_ops;
+    uint64_t cells_populated_outer, cells_populated_loop; /* trace + scratch cells holding a value == cells the gate checker reads */
 } zk_stats;
 /* K12 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
  * column chunking and cell identifiers are [EXT], the argument is defined in csrc/kernels_perm.hpp).  Labels: outer-scope
