@@ -780,20 +780,81 @@ void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t wo
     dev_check(zkdev::launch_witness_strands(a, s.s_begin[phase], s.s_end[phase], stream));
 }
 
+// Device programs group runs of consecutive, mutually independent ops of one kind under ONE header (INPUT up to 8, SELECT and LOOKUP into one
+// table up to 4, FMA / LC4 up to 2; strand programs: 8 / 8 / 4): header b carries (members - 1), the operand words of every member follow, then
+// the destination words of every member.  The interpreter issues all operand loads of a group before the first use, so a
+// wavefront has up to 24 loads in flight instead of 3 — the plain one-op-at-a-time form is bound by the latency of each op's
+// dependent loads, not by bandwidth (main_vm: 7 073 ops per cycle, 55 % of them SELECTs, most of them recorded as
+// parallel_select over 8 / 12 elements).  The exported program (oracle) stays ungrouped.
+static uint32_t group_cap(const OpRec& op) {
+    switch (op.opcode) {
+    // the plain kernels' caps (kernels_engine.hpp GS / GF for !STRANDS); INPUT members cost one register pair each
+    case ZK_OP_INPUT: return 8;
+    case ZK_OP_SELECT: return 4;
+    case ZK_OP_FMA: case ZK_OP_LC4: return 2;
+    case ZK_OP_LOOKUP: return (op.a <= 2 && op.b <= 2) ? 4 : 1;
+    default: return 1;
+    }
+}
+
 void CS::emit_scope(Scope& s) {
     std::vector<uint8_t> defined(s.n_vars, 0);
     s.prog.clear(); s.prog_full.clear();
     s.pre_words = 0; s.pre_words_full = 0;
     s.cells_written = 0; s.cells_populated = 0;
+    const char* grp_env = getenv("ZKGL_OP_GROUPS");
+    const bool grouping = !(grp_env && grp_env[0] == '0');
+    std::vector<uint32_t> produced_in_group(s.n_vars, UINT32_MAX);  // var -> id of the open group that produces it
+    uint32_t group_id = 0;
+    std::vector<size_t> group;  // op indices of the open group (device program)
+    auto flush = [&]() {
+        if (group.empty()) return;
+        const OpRec& first = s.ops[group[0]];
+        const size_t n = group.size();
+        emit_full_ = false;
+        if (n == 1) emit_op(s, first, s.prog);
+        else {
+            auto operand = [&](const Operand& in) {
+                if (in.kind == Operand::VAR) s.prog.push_back(s.var_cells[in.idx][0]);
+                else if (in.kind == Operand::CONSTPOOL) s.prog.push_back(ZK_OPERAND_CONST | in.idx);
+                else if (in.kind == Operand::OUTER_VAR) s.prog.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]);
+                else s.prog.push_back(in.idx);
+            };
+            if (first.opcode == ZK_OP_LOOKUP) {
+                s.prog.push_back((uint32_t)ZK_OP_LOOKUP | ((uint32_t)first.a << 8) | (((uint32_t)first.b | ((uint32_t)(n - 1) << 8)) << 16));
+                s.prog.push_back(first.ins[0].idx);  // table id
+                for (size_t oi : group)
+                    for (size_t q = 1; q < s.ops[oi].ins.size(); ++q) operand(s.ops[oi].ins[q]);
+            } else {
+                s.prog.push_back((uint32_t)first.opcode | ((uint32_t)first.a << 8) | ((uint32_t)(n - 1) << 16));
+                for (size_t oi : group)
+                    for (auto& in : s.ops[oi].ins) operand(in);
+            }
+            for (size_t oi : group) emit_dests(s, s.ops[oi], s.prog);
+        }
+        group.clear();
+        ++group_id;
+    };
     for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+        if (!s.is_loop && (oi == s.pre_ops || oi == s.side_ops)) flush();  // phases are launched separately
         if (!s.is_loop && oi == s.pre_ops) { s.pre_words = (uint32_t)s.prog.size(); s.pre_words_full = (uint32_t)s.prog_full.size(); }
         if (!s.is_loop && oi == s.side_ops) s.side_words = (uint32_t)s.prog.size();
         const OpRec& op = s.ops[oi];
         if (op.seed_only) continue;
         for (auto& in : op.ins)
             if (in.kind == Operand::VAR && !defined[in.idx]) throw ZkError(ZK_ERR_UNRESOLVED, "witness op reads a variable no earlier op produced");
-        emit_full_ = false;
-        emit_op(s, op, s.prog);
+        // device program: join the open group when the kind matches and no operand comes from a member of that group
+        bool joins = grouping && !group.empty() && group.size() < group_cap(op) && s.ops[group[0]].opcode == op.opcode;
+        if (joins && op.opcode == ZK_OP_LOOKUP) {
+            const OpRec& f = s.ops[group[0]];
+            joins = f.a == op.a && f.b == op.b && f.ins[0].idx == op.ins[0].idx;
+        }
+        if (joins)
+            for (auto& in : op.ins)
+                if (in.kind == Operand::VAR && produced_in_group[in.idx] == group_id) { joins = false; break; }
+        if (!joins) flush();
+        group.push_back(oi);
+        for (uint32_t ov : op.outs) produced_in_group[ov] = group_id;
         emit_full_ = true;
         emit_op(s, op, s.prog_full);
         emit_full_ = false;
@@ -804,6 +865,7 @@ void CS::emit_scope(Scope& s) {
             s.cells_populated += s.var_cells[ov].size();
         }
     }
+    flush();
     if (!s.is_loop && s.pre_ops >= s.ops.size()) { s.pre_words = (uint32_t)s.prog.size(); s.pre_words_full = (uint32_t)s.prog_full.size(); }
     if (!s.is_loop && s.side_ops >= s.ops.size()) s.side_words = (uint32_t)s.prog.size();
     if (!s.is_loop && s.side_words < s.pre_words) s.side_words = s.pre_words;

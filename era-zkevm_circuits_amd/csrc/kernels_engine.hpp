@@ -14,6 +14,20 @@
 #include "../../include/zkgl_ir.h"
 #include "poseidon2_device.hpp"
 
+// Trace stores.  Round 1 stored every cell of a variable (55 k words per VM cycle) and streamed them out non-temporally.  With
+// compact traces a value is stored once, to its home cell, and is usually an operand of an op a few hundred words later: a
+// cacheable store keeps it in L2 for that load (the interpreter is bound by the latency of its dependent operand loads).
+#ifdef ZKGL_NT_STORES
+#define ZKGL_STORE_ASM "buffer_store_dwordx2 %[val], %[lb], %[rs], %[addr] offen nt\n"
+#define ZKGL_STORE_AUX 2
+#else
+#define ZKGL_STORE_ASM "buffer_store_dwordx2 %[val], %[lb], %[rs], %[addr] offen\n"
+#define ZKGL_STORE_AUX 0
+#endif
+#ifndef ZKGL_LOOP_WAVES
+#define ZKGL_LOOP_WAVES 4
+#endif
+
 namespace zke {
 
 struct ScopeDev {
@@ -264,6 +278,11 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         tile_rsrc4.z = -1;
         tile_rsrc4.w = 0x00020000;
     }
+    // largest group of independent ops under one header (cs.cpp emit_scope: plain programs, build_strands: strand programs).
+    // The members' operands are all in registers at once: strand kernels (2 waves per SIMD anyway) take 8 / 4, the plain
+    // kernels 4 / 2 so that they stay at 4-5 waves per SIMD.
+    constexpr uint32_t GS = STRANDS ? 8 : 4;  // SELECT, LOOKUP
+    constexpr uint32_t GF = STRANDS ? 4 : 2;  // FMA, LC4
     ProgWindow P;
     P.init(SLOTS ? prog : sc.prog, word_begin);
     __shared__ uint64_t p2s[12 * BLOCK];  // Poseidon2 state, [element][thread]
@@ -305,7 +324,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                         "s_add_u32 %[off], %[off], 1\n"
                         "s_lshl_b32 %[addr], %[w], 9\n"
 #ifndef ZKGL_STUB_STORES  // time attribution only (tools/stub_bench.sh): the walk of the destination words without the store
-                        "buffer_store_dwordx2 %[val], %[lb], %[rs], %[addr] offen nt\n"  // trace cells stream out: non-temporal (-3.6 % kernel time)
+                        ZKGL_STORE_ASM  // see ZKGL_NT_STORES above
 #endif
                         "s_bitcmp1_b32 %[w], 31\n"
                         "s_cbranch_scc0 .LDSTX%=\n"
@@ -329,10 +348,10 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 #ifdef ZKGL_STUB_STORES
                     asm volatile("" ::"v"(o), "s"(w));
 #else
-                    __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ZK_DEST_CELL_MASK) << 9, 2 /* nt */);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ZK_DEST_CELL_MASK) << 9, ZKGL_STORE_AUX);
 #endif
                 } else {
-                    __builtin_nontemporal_store(v, &cells[(size_t)(w & ZK_DEST_CELL_MASK) << 6]);  // 64-bit addressed scopes: same streaming stores
+                    cells[(size_t)(w & ZK_DEST_CELL_MASK) << 6] = v;  // 64-bit addressed scopes
                 }
             } while (w & ZK_DEST_MORE);
         }
@@ -348,24 +367,38 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             st(v);
         } break;
         case ZK_OP_INPUT: {
+            if constexpr (!SLOTS) {
+                const uint32_t grp = pb + 1;  // device programs: up to 8 stream words under one header
+                if (grp > 1) {
+                    uint64_t v[8];
+#pragma unroll
+                    for (uint32_t g = 0; g < 8; ++g)
+                        if (g < grp) v[g] = sc.inputs[(size_t)P.at(pc + g) * sc.n_lanes + lane];
+                    pc += grp;
+#pragma unroll
+                    for (uint32_t g = 0; g < 8; ++g)
+                        if (g < grp) st(v[g]);
+                    break;
+                }
+            }
             uint32_t w = P.at(pc++);
             if constexpr (SLOTS) st(in_area[w * slot_stride]);  // staged in LDS by the kernel prologue
             else st(sc.inputs[(size_t)w * sc.n_lanes + lane]);
         } break;
         case ZK_OP_FMA: {
-            if constexpr (STRANDS && !SLOTS) {
-                const uint32_t grp = pb + 1;  // strand programs: up to 4 independent ops under one header
+            if constexpr (!SLOTS) {
+                const uint32_t grp = pb + 1;  // device programs: up to 4 independent ops under one header (cs.cpp emit_scope / build_strands)
                 if (grp > 1) {
-                    uint64_t in[4][5];
+                    uint64_t in[GF][5];
 #pragma unroll
-                    for (uint32_t g = 0; g < 4; ++g)
+                    for (uint32_t g = 0; g < GF; ++g)
                         if (g < grp) {
 #pragma unroll
                             for (uint32_t i = 0; i < 5; ++i) in[g][i] = ld(P.at(pc + g * 5 + i));
                         }
                     pc += grp * 5;
 #pragma unroll
-                    for (uint32_t g = 0; g < 4; ++g)
+                    for (uint32_t g = 0; g < GF; ++g)
                         if (g < grp) {
                             const uint64_t ab = gl::mul(in[g][2], in[g][3]);
                             st(gl::add(in[g][0] == 1 ? ab : gl::mul(in[g][0], ab), in[g][1] == 1 ? in[g][4] : gl::mul(in[g][1], in[g][4])));
@@ -381,19 +414,19 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             st(r);
         } break;
         case ZK_OP_LC4: {
-            if constexpr (STRANDS && !SLOTS) {
+            if constexpr (!SLOTS) {
                 const uint32_t grp = pb + 1;
                 if (grp > 1) {
-                    uint64_t in[4][8];
+                    uint64_t in[GF][8];
 #pragma unroll
-                    for (uint32_t g = 0; g < 4; ++g)
+                    for (uint32_t g = 0; g < GF; ++g)
                         if (g < grp) {
 #pragma unroll
                             for (uint32_t i = 0; i < 8; ++i) in[g][i] = ld(P.at(pc + g * 8 + i));
                         }
                     pc += grp * 8;
 #pragma unroll
-                    for (uint32_t g = 0; g < 4; ++g)
+                    for (uint32_t g = 0; g < GF; ++g)
                         if (g < grp) {
                             uint64_t r = 0;
 #pragma unroll
@@ -410,19 +443,19 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             st(r);
         } break;
         case ZK_OP_SELECT: {
-            if constexpr (STRANDS && !SLOTS) {
+            if constexpr (!SLOTS) {
                 const uint32_t grp = pb + 1;
                 if (grp > 1) {
-                    uint64_t in[8][3];
+                    uint64_t in[GS][3];
 #pragma unroll
-                    for (uint32_t g = 0; g < 8; ++g)
+                    for (uint32_t g = 0; g < GS; ++g)
                         if (g < grp) {
 #pragma unroll
                             for (uint32_t i = 0; i < 3; ++i) in[g][i] = ld(P.at(pc + g * 3 + i));
                         }
                     pc += grp * 3;
 #pragma unroll
-                    for (uint32_t g = 0; g < 8; ++g)
+                    for (uint32_t g = 0; g < GS; ++g)
                         if (g < grp) st(in[g][0] ? in[g][1] : in[g][2]);
                     break;
                 }
@@ -479,16 +512,16 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             const uint32_t tid = P.at(pc++);
             const zk_table_desc t = sc.tables[tid];
             const uint32_t nv = pb & 0xff;
-            if constexpr (STRANDS && !SLOTS) {
-                // strand programs: up to 8 independent lookups into one table under one header (cs.cpp build_strands); all key loads
-                // first, then all table gathers, then the stores and the multiplicities
+            if constexpr (!SLOTS) {
+                // device programs: up to 8 independent lookups into one table under one header (cs.cpp emit_scope / build_strands);
+                // all key loads first, then all table gathers, then the stores and the multiplicities
                 const uint32_t grp = (pb >> 8) + 1;
                 if (grp > 1) {
-                    uint64_t key[8][2];
-                    uint32_t row[8];
-                    uint64_t val[8][2];
+                    uint64_t key[GS][2];
+                    uint32_t row[GS];
+                    uint64_t val[GS][2];
 #pragma unroll
-                    for (uint32_t g = 0; g < 8; ++g)
+                    for (uint32_t g = 0; g < GS; ++g)
                         if (g < grp) {
                             key[g][0] = ld(P.at(pc + g * pa));
                             key[g][1] = pa > 1 ? ld(P.at(pc + g * pa + 1)) : 0;
@@ -497,7 +530,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                     const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(sc.table_words + (t.dense >> 2));
                     const uint32_t w = t.n_keys + t.n_vals;
 #pragma unroll
-                    for (uint32_t g = 0; g < 8; ++g)
+                    for (uint32_t g = 0; g < GS; ++g)
                         if (g < grp) {
                             uint64_t k3[3] = {key[g][0], key[g][1], 0};
                             row[g] = table_find(t, sc.table_words, k3);
@@ -510,7 +543,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                                                                  : sc.table_words[(size_t)t.word_off + (size_t)row[g] * w + t.n_keys + i];
                         }
 #pragma unroll
-                    for (uint32_t g = 0; g < 8; ++g)
+                    for (uint32_t g = 0; g < GS; ++g)
                         if (g < grp) {
                             P.sync(pc);
 #pragma unroll
@@ -752,7 +785,7 @@ __device__ __forceinline__ void witness_entry(const ScopeDev& sc, uint32_t word_
     lane = active ? lane : sc.n_lanes - 1;
     run_lane<WITH_BIGINT, false, BUFFER_ADDRESSING>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
 }
-__global__ __launch_bounds__(TPB) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_LOOP_WAVES, 8))) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
     witness_entry<false>(sc, word_begin, word_end);
 }
 __global__ __launch_bounds__(TPB) void k_witness_outer(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
