@@ -70,6 +70,8 @@ CS::~CS() {
     if (d_table_words_) hipFree(d_table_words_);
     if (d_mult_) hipFree(d_mult_);
     if (d_links_) hipFree(d_links_);
+    if (d_links_store_) hipFree(d_links_store_);
+    for (auto p : d_streams_store_) if (p) hipFree(p);
     if (d_seed_prog_) hipFree(d_seed_prog_);
     if (d_seed_sprog_) hipFree(d_seed_sprog_);
     if (d_seed_scarries_) hipFree(d_seed_scarries_);
@@ -100,6 +102,10 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_copies) hipFree(s.d_copies);
     if (s.d_alias) hipFree(s.d_alias);
     s.d_alias = nullptr;
+    if (s.d_mat_pairs) hipFree(s.d_mat_pairs);
+    s.d_mat_pairs = nullptr;
+    if (s.d_store) hipFree(s.d_store);
+    s.d_store = nullptr;
     if (s.d_cells) hipFree(s.d_cells);
     s.d_prog = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
     s.d_copies = nullptr; s.d_cells = nullptr;
@@ -484,12 +490,30 @@ void CS::place_scope(Scope& s) {
     s.n_cells = s.n_trace_cells + s.n_scratch;
     if (s.n_cells >= 0x3fffffffu) throw ZkError(ZK_ERR_CAPACITY, "scope too large for 30-bit cell indices");
     s.copies.clear();
-    s.alias.resize(s.n_trace_cells);
-    for (uint32_t c = 0; c < s.n_trace_cells; ++c) s.alias[c] = c;
     for (uint32_t v = 0; v < s.n_vars; ++v)
-        for (size_t i = 1; i < s.var_cells[v].size(); ++i) {
-            s.copies.push_back({s.var_cells[v][i], s.var_cells[v][0]});
-            s.alias[s.var_cells[v][i]] = s.var_cells[v][0];
+        for (size_t i = 1; i < s.var_cells[v].size(); ++i) s.copies.push_back({s.var_cells[v][i], s.var_cells[v][0]});
+}
+
+// Store slots in production order of the FINAL op order (after scheduling); variables no op produces keep slot 0 and are
+// reported by emit_scope.  Also the trace-cell -> slot alias of the compact gate checker and the materialisation list.
+void CS::assign_store_slots(Scope& s) {
+    s.var_slot.assign(s.n_vars, 0);
+    std::vector<uint8_t> seen(s.n_vars, 0);
+    uint32_t next = 0;
+    for (auto& op : s.ops) {
+        if (op.seed_only) continue;
+        for (uint32_t ov : op.outs)
+            if (!seen[ov]) { seen[ov] = 1; s.var_slot[ov] = next++; }
+    }
+    for (uint32_t v = 0; v < s.n_vars; ++v)
+        if (!seen[v]) s.var_slot[v] = next++;
+    s.n_store = std::max<uint32_t>(next, 1);
+    s.alias.assign(s.n_trace_cells, 0);
+    s.mat_pairs.clear();
+    for (uint32_t v = 0; v < s.n_vars; ++v)
+        for (uint32_t c : s.var_cells[v]) {
+            if (c < s.n_trace_cells) s.alias[c] = s.var_slot[v];
+            s.mat_pairs.push_back({c, s.var_slot[v]});
         }
 }
 
@@ -523,7 +547,7 @@ void CS::schedule_loop_ops() {
     for (size_t i = 0; i < n; ++i) {
         const OpRec& op = s.ops[i];
         double stores = 0;
-        for (auto ov : op.outs) stores += (double)s.var_cells[ov].size();
+        stores += (double)op.outs.size();
         a[i] = alu_cost(op);
         m[i] = stores + 0.25 * (double)op.ins.size();
         a_tot += a[i]; m_tot += m[i];
@@ -594,11 +618,11 @@ void CS::emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) co
     out.push_back((uint32_t)op.opcode | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
     for (auto& in : op.ins) {
         switch (in.kind) {
-        case Operand::VAR: out.push_back(s.var_cells[in.idx][0]); break;
+        case Operand::VAR: out.push_back(home(s, in.idx)); break;
         case Operand::CONSTPOOL: out.push_back(ZK_OPERAND_CONST | in.idx); break;
-        case Operand::OUTER_VAR: out.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]); break;
+        case Operand::OUTER_VAR: out.push_back(ZK_OPERAND_OUTER | home(outer_, in.idx)); break;
         case Operand::RAW:
-            if (op.opcode == ZK_OP_LOOP_LAST) out.push_back(loop_.var_cells[in.idx][0]);
+            if (op.opcode == ZK_OP_LOOP_LAST) out.push_back(home(loop_, in.idx));
             else out.push_back(in.idx);
             break;
         }
@@ -608,7 +632,7 @@ void CS::emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) co
 void CS::emit_dests(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const {
     for (uint32_t ov : op.outs) {
         const auto& cells = s.var_cells[ov];
-        if (!emit_full_) { out.push_back(cells[0]); continue; }  // compact device program: the home cell only
+        if (!emit_full_) { out.push_back(s.var_slot[ov]); continue; }  // device program: the variable's store slot
         for (size_t i = 0; i < cells.size(); ++i) out.push_back(cells[i] | (i + 1 < cells.size() ? ZK_DEST_MORE : 0));
     }
 }
@@ -672,7 +696,7 @@ void CS::build_strands(Scope& s) {
         auto cost = [&](uint32_t oi) -> uint64_t {
             const OpRec& op = s.ops[oi];
             uint64_t c = 8 + op.ins.size();
-            for (uint32_t ov : op.outs) c += 2 * s.var_cells[ov].size();
+            c += 2 * op.outs.size();
             if (op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2) c += 4000;
             if (op.opcode == ZK_OP_NN_MULMOD) c += 2000;
             if (op.opcode == ZK_OP_U256_DIVREM) c += 2500;
@@ -715,9 +739,9 @@ void CS::build_strands(Scope& s) {
                         for (size_t i = 0; i < n; ++i) {
                             const OpRec& op = s.ops[g[i0 + i]];
                             for (auto& in : op.ins) {
-                                if (in.kind == Operand::VAR) strand[k].push_back(s.var_cells[in.idx][0]);
+                                if (in.kind == Operand::VAR) strand[k].push_back(s.var_slot[in.idx]);
                                 else if (in.kind == Operand::CONSTPOOL) strand[k].push_back(ZK_OPERAND_CONST | in.idx);
-                                else if (in.kind == Operand::OUTER_VAR) strand[k].push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]);
+                                else if (in.kind == Operand::OUTER_VAR) strand[k].push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
                                 else strand[k].push_back(in.idx);
                             }
                         }
@@ -736,9 +760,9 @@ void CS::build_strands(Scope& s) {
                             const OpRec& op = s.ops[g[i0 + i]];
                             for (size_t q = 1; q < op.ins.size(); ++q) {
                                 const Operand& in = op.ins[q];
-                                if (in.kind == Operand::VAR) strand[k].push_back(s.var_cells[in.idx][0]);
+                                if (in.kind == Operand::VAR) strand[k].push_back(s.var_slot[in.idx]);
                                 else if (in.kind == Operand::CONSTPOOL) strand[k].push_back(ZK_OPERAND_CONST | in.idx);
-                                else if (in.kind == Operand::OUTER_VAR) strand[k].push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]);
+                                else if (in.kind == Operand::OUTER_VAR) strand[k].push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
                                 else strand[k].push_back(in.idx);
                             }
                         }
@@ -815,9 +839,9 @@ void CS::emit_scope(Scope& s) {
         if (n == 1) emit_op(s, first, s.prog);
         else {
             auto operand = [&](const Operand& in) {
-                if (in.kind == Operand::VAR) s.prog.push_back(s.var_cells[in.idx][0]);
+                if (in.kind == Operand::VAR) s.prog.push_back(s.var_slot[in.idx]);
                 else if (in.kind == Operand::CONSTPOOL) s.prog.push_back(ZK_OPERAND_CONST | in.idx);
-                else if (in.kind == Operand::OUTER_VAR) s.prog.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]);
+                else if (in.kind == Operand::OUTER_VAR) s.prog.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
                 else s.prog.push_back(in.idx);
             };
             if (first.opcode == ZK_OP_LOOKUP) {
@@ -883,7 +907,7 @@ void CS::emit_scope(Scope& s) {
 // permutation and assign every surviving value an LDS slot by linear scan over its live range.
 void CS::build_seed_program() {
     seed_prog_.clear(); seed_carries_.clear(); seed_slots_ = 0; seed_ops_ = 0;
-    if (!limit_ || carries_.empty()) return;
+    if (!limit_ || carries_store_.empty()) return;
     const Scope& s = loop_;
     std::vector<uint32_t> out_vars;  // same order as carries_
     for (auto& l : links_raw_)
@@ -924,7 +948,7 @@ void CS::build_seed_program() {
             switch (in.kind) {
             case Operand::VAR: prog.push_back(slot_of[in.idx]); break;
             case Operand::CONSTPOOL: prog.push_back(ZK_OPERAND_CONST | in.idx); break;
-            case Operand::OUTER_VAR: prog.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]); break;
+            case Operand::OUTER_VAR: prog.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]); break;
             case Operand::RAW: prog.push_back(in.idx); break;
             }
         }
@@ -948,8 +972,8 @@ void CS::build_seed_program() {
     for (auto& w : prog)
         if (w == DISCARD_MARK) w = discard;
     if (n_slots + s.n_input_words > zkdev::seed_cone_max_slots()) { seed_ops_ = 0; return; }
-    for (size_t i = 0; i < carries_.size(); ++i) {
-        Carry c = carries_[i];
+    for (size_t i = 0; i < carries_store_.size(); ++i) {
+        Carry c = carries_store_[i];
         if (slot_of[out_vars[i]] == UINT32_MAX) { seed_ops_ = 0; return; }  // carried output produced by no op
         c.out_cell = slot_of[out_vars[i]];
         seed_carries_.push_back(c);
@@ -1049,7 +1073,7 @@ void CS::build_seed_program() {
                 switch (in.kind) {
                 case Operand::VAR: out.push_back(slot_of[in.idx]); break;
                 case Operand::CONSTPOOL: out.push_back(ZK_OPERAND_CONST | in.idx); break;
-                case Operand::OUTER_VAR: out.push_back(ZK_OPERAND_OUTER | outer_.var_cells[in.idx][0]); break;
+                case Operand::OUTER_VAR: out.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]); break;
                 case Operand::RAW: out.push_back(in.idx); break;
                 }
             }
@@ -1076,8 +1100,8 @@ void CS::build_seed_program() {
         for (uint32_t w : strand[k]) seed_sprog_.push_back(w == DISCARD_MARK ? sdiscard : w);
         seed_send_[k] = (uint32_t)seed_sprog_.size();
     }
-    for (size_t i = 0; i < carries_.size(); ++i) {
-        Carry c = carries_[i];
+    for (size_t i = 0; i < carries_store_.size(); ++i) {
+        Carry c = carries_store_[i];
         if (slot_of[out_vars[i]] == UINT32_MAX) { seed_sprog_.clear(); return; }
         c.out_cell = slot_of[out_vars[i]];
         seed_scarries_.push_back(c);
@@ -1105,6 +1129,7 @@ void CS::upload_scope(Scope& s) {
     s.d_lrows = upload(s.lrows);
     s.d_copies = upload(s.copies);
     s.d_alias = upload(s.alias);
+    s.d_mat_pairs = upload(s.mat_pairs);
 }
 
 void CS::finalize() {
@@ -1124,6 +1149,8 @@ void CS::finalize() {
                     throw ZkError(ZK_ERR_UNRESOLVED, "loop imports an outer variable that is produced after the loop");
     }
     schedule_loop_ops();
+    assign_store_slots(outer_);
+    assign_store_slots(loop_);
     emit_scope(outer_);
     emit_scope(loop_);
     build_strands(outer_);
@@ -1132,36 +1159,43 @@ void CS::finalize() {
     if (!loop_done_) rows = outer_.n_slots;
     if (rows > max_trace_len_) throw ZkError(ZK_ERR_CAPACITY, "trace rows exceed max_trace_len");
     // carried input words (for the sequential seeding mode): CARRY link whose `in` side is an INPUT
-    carries_.clear();
+    carries_.clear(); carries_store_.clear();
     for (auto& l : links_raw_) {
         if (l.kind != ZK_LINK_CARRY) continue;
         auto it = loop_.input_word.find(l.loop_cell);
         if (it == loop_.input_word.end()) continue;  // not stream-fed: nothing to seed
-        Carry c{it->second, loop_.var_cells[l.other_cell][0], 0, 0};
+        Carry c{it->second, loop_.var_cells[l.other_cell][0], 0, 0}, cs{it->second, loop_.var_slot[l.other_cell], 0, 0};
         for (auto& f : links_raw_)
             if (f.kind == ZK_LINK_FIRST && f.loop_cell == l.loop_cell) {
                 c.first_outer_cell = outer_.var_cells[f.other_cell][0];
-                c.has_first = 1;
+                cs.first_outer_cell = outer_.var_slot[f.other_cell];
+                c.has_first = cs.has_first = 1;
             }
         carries_.push_back(c);
+        carries_store_.push_back(cs);
     }
     build_seed_program();
-    // links: vars -> home cells
-    links_.clear();
+    // links / stream links: variables -> trace cells (export, materialised-trace check) and -> store slots (compact check)
+    links_.clear(); links_store_.clear();
     for (auto& l : links_raw_) {
         zk_link r;
         r.kind = l.kind; r.pad = 0;
+        const Scope& other = l.kind == ZK_LINK_CARRY ? loop_ : outer_;
         r.loop_cell = loop_.var_cells[l.loop_cell][0];
-        r.other_cell = (l.kind == ZK_LINK_CARRY ? loop_ : outer_).var_cells[l.other_cell][0];
+        r.other_cell = other.var_cells[l.other_cell][0];
         links_.push_back(r);
+        r.loop_cell = loop_.var_slot[l.loop_cell];
+        r.other_cell = other.var_slot[l.other_cell];
+        links_store_.push_back(r);
     }
-    streams_.clear();
+    streams_.clear(); streams_store_.clear();
     for (auto& sr : streams_raw_) {
-        StreamRec r;
-        r.n_total = sr.n_total;
-        for (auto v : sr.a) r.a.push_back(loop_.var_cells[v][0]);
-        for (auto v : sr.b) r.b.push_back(loop_.var_cells[v][0]);
+        StreamRec r, rs;
+        r.n_total = rs.n_total = sr.n_total;
+        for (auto v : sr.a) { r.a.push_back(loop_.var_cells[v][0]); rs.a.push_back(loop_.var_slot[v]); }
+        for (auto v : sr.b) { r.b.push_back(loop_.var_cells[v][0]); rs.b.push_back(loop_.var_slot[v]); }
         streams_.push_back(std::move(r));
+        streams_store_.push_back(std::move(rs));
     }
     // tables
     std::vector<zk_table_desc> tdesc(tables_.size() + 1);
@@ -1209,12 +1243,14 @@ void CS::ensure_uploaded() {
     d_tables_ = upload(tdesc_host_);
     d_table_words_ = upload(table_words_host_);
     d_links_ = upload(links_);
-    for (auto& sr : streams_) {
-        std::vector<uint32_t> cells(sr.a);
-        cells.insert(cells.end(), sr.b.begin(), sr.b.end());
-        d_streams_.push_back(upload(cells));
-    }
-    d_carries_ = (void*)upload(carries_);
+    d_links_store_ = upload(links_store_);
+    for (int k = 0; k < 2; ++k)
+        for (auto& sr : (k ? streams_store_ : streams_)) {
+            std::vector<uint32_t> cells(sr.a);
+            cells.insert(cells.end(), sr.b.begin(), sr.b.end());
+            (k ? d_streams_store_ : d_streams_).push_back(upload(cells));
+        }
+    d_carries_ = (void*)upload(carries_store_);
     if (!seed_prog_.empty()) {
         std::vector<uint32_t> padded(seed_prog_);
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
@@ -1241,12 +1277,13 @@ void CS::set_batch(uint32_t n) {
     if (n == 0) throw ZkError(ZK_ERR_INVALID, "batch must be > 0");
     ensure_uploaded();
     auto alloc_cells = [&](Scope& s, uint64_t lanes) {
-        if (s.d_cells) { hipFree(s.d_cells); s.d_cells = nullptr; }
+        if (s.d_store) { hipFree(s.d_store); s.d_store = nullptr; }
+        if (s.d_cells) { hipFree(s.d_cells); s.d_cells = nullptr; }  // the materialised trace is re-allocated on demand
         s.n_lanes = (uint32_t)lanes;
         s.stride = (lanes + 63) / 64 * 64;  // whole 64-lane tiles
-        size_t bytes = std::max<size_t>((size_t)s.n_cells * s.stride * 8, 8);
-        hip_check(hipMalloc((void**)&s.d_cells, bytes), "hipMalloc trace cells");
-        hip_check(hipMemset(s.d_cells, 0, bytes), "hipMemset trace cells");
+        size_t bytes = std::max<size_t>((size_t)s.n_store * s.stride * 8, 8);
+        hip_check(hipMalloc((void**)&s.d_store, bytes), "hipMalloc variable store");
+        hip_check(hipMemset(s.d_store, 0, bytes), "hipMemset variable store");
     };
     uint64_t loop_lanes = (uint64_t)n * limit_;
     if (loop_lanes >= 0xffffffffull) throw ZkError(ZK_ERR_CAPACITY, "batch*limit exceeds 32-bit lane index");
@@ -1256,6 +1293,7 @@ void CS::set_batch(uint32_t n) {
     size_t mbytes = std::max<size_t>((size_t)n * total_table_rows_ * 4, 4);
     hip_check(hipMalloc((void**)&d_mult_, mbytes), "hipMalloc multiplicities");
     batch_ = n;
+    compact_ = true;
     outer_.d_inputs = nullptr; loop_.d_inputs = nullptr;
     outer_.bound_input_words = loop_.bound_input_words = 0;
 }
@@ -1272,11 +1310,11 @@ static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Sco
                                    const zk_table_desc* tables, const uint64_t* words, uint32_t* mult, uint32_t total_rows) {
     zkdev::ScopeArgs a;
     a.prog = s.d_prog; a.n_words = (uint32_t)s.prog.size(); a.n_lanes = s.n_lanes; a.consts = s.d_consts;
-    a.cells = s.d_cells; a.n_cells = s.n_cells; a.inputs = s.d_inputs;
-    a.outer_cells = outer.d_cells; a.outer_n_cells = outer.n_cells;
+    a.cells = s.d_store; a.n_cells = s.n_store; a.inputs = s.d_inputs;  // the witness kernels work on the variable store
+    a.outer_cells = outer.d_store; a.outer_n_cells = outer.n_store;
     a.limit = s.is_loop ? limit : 1; a.is_loop = s.is_loop ? 1 : 0;
     a.tables = tables; a.table_words = words; a.mult = mult; a.total_table_rows = total_rows;
-    a.loop_cells = loop.d_cells; a.loop_n_cells = loop.n_cells; a.loop_limit = limit;
+    a.loop_cells = loop.d_store; a.loop_n_cells = loop.n_store; a.loop_limit = limit;
     a.uses_bigint = s.uses_bigint ? 1 : 0;
     return a;
 }
@@ -1303,7 +1341,7 @@ void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {
         dev_check(zkdev::launch_seed_cone(la, d_seed_prog_, (uint32_t)seed_prog_.size(), seed_slots_, loop_.n_input_words, (const zkdev::CarryArgs*)d_seed_carries_,
                                           (uint32_t)seed_carries_.size(), dev_loop_inputs_rw, batch_, st));
     else
-        dev_check(zkdev::launch_witness_seq(la, (const zkdev::CarryArgs*)d_carries_, (uint32_t)carries_.size(), dev_loop_inputs_rw,
+        dev_check(zkdev::launch_witness_seq(la, (const zkdev::CarryArgs*)d_carries_, (uint32_t)carries_store_.size(), dev_loop_inputs_rw,
                                             batch_, st));
     hip_check(hipStreamSynchronize(st), "seed sync");
 }
@@ -1336,7 +1374,7 @@ void CS::resolve(void* stream) {
 zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool compact) const {
     zkdev::CheckArgs a;
     a.alias = compact ? s.d_alias : nullptr;
-    a.cells = s.d_cells; a.n_cells = s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
+    a.cells = compact ? s.d_store : s.d_cells; a.n_cells = compact ? s.n_store : s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
     a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
     a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
     a.lookup_width = lookup_width_; a.tables = d_tables_; a.table_words = d_table_words_; a.fail = fail;
@@ -1371,9 +1409,13 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
         if (!compact)
             dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies,
                                                  (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
-        dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.n_cells, loop_.n_lanes, limit_, outer_.d_cells,
-                                            outer_.n_cells, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
-        check_streams(st);
+        if (compact)
+            dev_check(zkdev::launch_check_links(loop_.d_store, loop_.n_store, loop_.n_lanes, limit_, outer_.d_store,
+                                                outer_.n_store, d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));
+        else
+            dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.n_cells, loop_.n_lanes, limit_, outer_.d_cells,
+                                                outer_.n_cells, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
+        check_streams(st, compact);
     } else {
         hip_check(hipEventRecord((hipEvent_t)ev_[6], st), "event");
     }
@@ -1391,8 +1433,21 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
 void CS::ensure_materialized(void* stream) {
     if (!compact_ || batch_ == 0) return;
     hipStream_t st = (hipStream_t)stream;
-    dev_check(zkdev::launch_materialize(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies, (uint32_t)outer_.copies.size(), st));
-    if (limit_) dev_check(zkdev::launch_materialize(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies, (uint32_t)loop_.copies.size(), st));
+    for (Scope* s : {&outer_, &loop_}) {
+        if (s->is_loop && !limit_) {
+            if (!s->d_cells) hip_check(hipMalloc((void**)&s->d_cells, 8), "hipMalloc trace");
+            continue;
+        }
+        if (!s->d_cells) {  // the full trace exists only for its consumers: prover-stage kernels, trace readers, write_cell
+            size_t bytes = std::max<size_t>((size_t)s->n_cells * s->stride * 8, 8);
+            if (hipMalloc((void**)&s->d_cells, bytes) != hipSuccess) {
+                s->d_cells = nullptr;
+                throw ZkError(ZK_ERR_CAPACITY, "materialised trace does not fit in device memory at this batch size (the variable store is 4x smaller)");
+            }
+            hip_check(hipMemsetAsync(s->d_cells, 0, bytes, st), "hipMemset trace");
+        }
+        dev_check(zkdev::launch_materialize(s->d_cells, s->n_cells, s->d_store, s->n_store, s->n_lanes, s->d_mat_pairs, (uint32_t)s->mat_pairs.size(), st));
+    }
     hip_check(hipStreamSynchronize(st), "materialize sync");
     compact_ = false;
 }
@@ -1447,11 +1502,13 @@ uint32_t CS::lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], vo
     return bad;
 }
 
-void CS::check_streams(void* stream) {
-    for (size_t i = 0; i < streams_.size(); ++i) {
-        const auto& sr = streams_[i];
-        dev_check(zkdev::launch_check_stream(loop_.d_cells, loop_.n_cells, batch_, limit_, d_streams_[i], (uint32_t)sr.a.size(),
-                                             d_streams_[i] + sr.a.size(), (uint32_t)sr.b.size(), sr.n_total, (uint32_t)i,
+void CS::check_streams(void* stream, bool compact) {
+    const auto& streams = compact ? streams_store_ : streams_;
+    const auto& dev = compact ? d_streams_store_ : d_streams_;
+    for (size_t i = 0; i < streams.size(); ++i) {
+        const auto& sr = streams[i];
+        dev_check(zkdev::launch_check_stream(compact ? loop_.d_store : loop_.d_cells, compact ? loop_.n_store : loop_.n_cells, batch_, limit_, dev[i],
+                                             (uint32_t)sr.a.size(), dev[i] + sr.a.size(), (uint32_t)sr.b.size(), sr.n_total, (uint32_t)i,
                                              d_fail_ + 3, stream));
     }
 }
@@ -1535,9 +1592,9 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hip_check(hipEventRecord(E(6), st), "event");
     hip_check(hipStreamWaitEvent(st, E(4), 0), "wait");
     if (limit_) {
-        dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.n_cells, loop_.n_lanes, limit_, outer_.d_cells,
-                                            outer_.n_cells, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
-        check_streams(st);
+        dev_check(zkdev::launch_check_links(loop_.d_store, loop_.n_store, loop_.n_lanes, limit_, outer_.d_store,
+                                            outer_.n_store, d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));
+        check_streams(st, true);
     }
     hip_check(hipEventRecord(E(7), st), "event");
     unsigned long long f[8];
@@ -1564,15 +1621,17 @@ uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
         lane = (uint64_t)instance * limit_ + iteration;
     }
     uint64_t out = 0;
-    hip_check(hipMemcpy(&out, s.d_cells + tiled_offset(s.n_cells, s.var_cells[var_index(v)][0], lane), 8, hipMemcpyDeviceToHost),
-              "read_var memcpy");
+    if (compact_)
+        hip_check(hipMemcpy(&out, s.d_store + tiled_offset(s.n_store, s.var_slot[var_index(v)], lane), 8, hipMemcpyDeviceToHost), "read_var memcpy");
+    else
+        hip_check(hipMemcpy(&out, s.d_cells + tiled_offset(s.n_cells, s.var_cells[var_index(v)][0], lane), 8, hipMemcpyDeviceToHost), "read_var memcpy");
     return out;
 }
 
 void CS::write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value) {
     Scope& s = loop_scope ? loop_ : outer_;
     if (batch_ == 0 || cell >= s.n_cells || lane >= s.n_lanes) throw ZkError(ZK_ERR_INVALID, "write_cell: out of range");
-    ensure_materialized(nullptr);  // an externally modified trace is checked cell by cell, copies included
+    ensure_materialized(nullptr);  // an externally modified trace is checked cell by cell, copies and links included
     hip_check(hipMemcpy(s.d_cells + tiled_offset(s.n_cells, cell, lane), &value, 8, hipMemcpyHostToDevice), "write_cell memcpy");
 }
 

@@ -85,7 +85,14 @@ struct Scope {
     // `alias`, k_materialize fills the other cells on demand).  prog_full: every cell of every variable (export to the oracle).
     std::vector<uint32_t> prog, prog_full;
     uint32_t pre_words = 0, side_words = 0, pre_words_full = 0;
-    std::vector<uint32_t> alias;  // trace cell -> home cell of the variable placed there (itself for unpopulated cells)
+    // VARIABLE STORE: the witness kernels keep ONE value per variable, in a dense store indexed by production order
+    // (store[((lane >> 6) * n_store + slot) * 64 + (lane & 63)]): a wave streams its results out sequentially and reads its
+    // operands from recently written, nearby slots (TLB / L2 locality), and a VM instance needs 4x less memory than its trace.
+    // The trace (cell = slot * n_columns + column, scratch behind) exists on demand only: k_materialize copies store -> trace.
+    std::vector<uint32_t> var_slot;   // variable -> store slot
+    uint32_t n_store = 0;
+    std::vector<uint32_t> alias;      // trace cell -> store slot of the variable placed there (0 for unpopulated cells)
+    std::vector<zk_copy_pair> mat_pairs;  // {trace or scratch cell, store slot} of every populated cell
     uint64_t cells_populated = 0; // trace cells + scratch cells holding a value == destination words of prog_full
     // strand form of the program (build_strands): phase 0 = loop body / outer pre, 1 = outer side, 2 = outer post
     std::vector<uint32_t> sprog;
@@ -109,7 +116,9 @@ struct Scope {
     zk_lookup_row_desc* d_lrows = nullptr;
     zk_copy_pair* d_copies = nullptr;
     uint32_t* d_alias = nullptr;
-    uint64_t* d_cells = nullptr;
+    zk_copy_pair* d_mat_pairs = nullptr;
+    uint64_t* d_store = nullptr;   // variable store, allocated by set_batch
+    uint64_t* d_cells = nullptr;   // materialised trace, allocated by the first ensure_materialized
     uint64_t stride = 0;
     uint32_t n_lanes = 0;
     const uint64_t* d_inputs = nullptr;
@@ -206,6 +215,9 @@ class CS {
     void ensure_materialized(void* stream);
     bool compact_ = true;
     void build_strands(Scope& s);
+    void assign_store_slots(Scope& s);
+    uint32_t home(const Scope& s, uint32_t var) const { return emit_full_ ? s.var_cells[var][0] : s.var_slot[var]; }
+    void check_streams(void* stream, bool compact);
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t word_begin, uint32_t word_end, void* stream) const;
     void upload_scope(Scope& s);
@@ -213,7 +225,6 @@ class CS {
     void free_scope_device(Scope& s);
     void check_var(zk_var v, bool want_loop) const;
     int decode_failure(const unsigned long long* f, zk_failure* first) const;
-    void check_streams(void* stream);
     zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail, bool compact) const;
 
     zk_geometry geo_;
@@ -227,11 +238,13 @@ class CS {
     uint32_t limit_ = 0;
     uint32_t pre_vars_ = UINT32_MAX;  // outer variables allocated before side_begin (all of them when there is no side phase)
     std::vector<zk_link> links_raw_;  // vars, resolved to cells at finalize
-    std::vector<zk_link> links_;
+    std::vector<zk_link> links_;       // endpoints as trace cells (export, materialised-trace check)
+    std::vector<zk_link> links_store_; // endpoints as store slots (compact check)
+    zk_link* d_links_store_ = nullptr;
     std::vector<uint32_t> public_vars_;
     struct StreamRec { std::vector<uint32_t> a, b; uint32_t n_total; };  // loop var indices -> home cells at finalize
-    std::vector<StreamRec> streams_raw_, streams_;
-    std::vector<uint32_t*> d_streams_;  // per stream: a cells then b cells
+    std::vector<StreamRec> streams_raw_, streams_, streams_store_;
+    std::vector<uint32_t*> d_streams_, d_streams_store_;  // per stream: a cells then b cells (trace cells / store slots)
 
     // device-wide
     uint32_t batch_ = 0;
@@ -244,7 +257,8 @@ class CS {
     uint32_t* d_mult_ = nullptr;
     zk_link* d_links_ = nullptr;
     struct Carry { uint32_t word, out_cell, first_outer_cell, has_first; };
-    std::vector<Carry> carries_;
+    std::vector<Carry> carries_;        // out / first cells as trace cells (export)
+    std::vector<Carry> carries_store_;  // as store slots (device)
     void* d_carries_ = nullptr;
     // cone seeding: backward slice of the carried outputs over LDS slots (empty => generic sequential mode)
     void build_seed_program();

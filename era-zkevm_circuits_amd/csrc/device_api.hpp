@@ -43,7 +43,8 @@ struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // 
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);
 int launch_check_gates(const CheckArgs& cd, void* stream);
-int launch_materialize(uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs, uint32_t n_pairs, void* stream);
+int launch_materialize(uint64_t* trace, uint64_t n_cells, const uint64_t* store, uint64_t n_store, uint32_t n_lanes, const zk_copy_pair* pairs,
+                       uint32_t n_pairs, void* stream);  // pairs: {trace cell, store slot}
 int launch_check_copies(const uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs,
                         uint32_t n_pairs, unsigned long long* fail, void* stream);
 // K10 lookup-argument accumulators (kernels_lookup_arg.hpp).  ch = beta, gamma, gamma^2, gamma^3, gamma^4 (2 words each)

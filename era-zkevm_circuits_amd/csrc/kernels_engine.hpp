@@ -952,8 +952,8 @@ struct CheckDev {
     const uint64_t* table_words;
     unsigned long long* fail;   // [0] gates/lookups, [1] copies, [2] links
     uint32_t slots_per_chunk;
-    // compact traces (only the home cell of every variable is stored by the witness kernels): trace cell -> home cell of the
-    // variable placed there; nullptr for a materialised trace
+    // compact check: `cells` is the variable store and alias maps a trace cell to the store slot of the variable placed there;
+    // nullptr: `cells` is a materialised trace
     const uint32_t* alias;
 };
 
@@ -1082,17 +1082,20 @@ __device__ __forceinline__ void check_gates_body(const CheckDev& cd) {
 __global__ __launch_bounds__(TPB) void k_check_gates(CheckDev cd) { check_gates_body<false>(cd); }
 __global__ __launch_bounds__(TPB) void k_check_gates_compact(CheckDev cd) { check_gates_body<true>(cd); }
 
-// compact -> materialised trace: every non-home cell of a variable receives the home cell's value (the prover-stage kernels,
-// zk_cs_trace_columns and the trace readers want the full trace; the witness + check pipeline never needs it)
-__global__ __launch_bounds__(TPB) void k_materialize(uint64_t* __restrict__ cells_all, uint64_t n_cells, uint32_t n_lanes,
-                                                     const zk_copy_pair* __restrict__ pairs, uint32_t n_pairs, uint32_t pairs_per_chunk) {
+// variable store -> materialised trace: every populated trace / scratch cell receives the value of its variable (the prover-stage
+// kernels, zk_cs_trace_columns and the trace readers want the full trace; the witness + check pipeline never needs it).
+// pairs: {trace cell, store slot}
+__global__ __launch_bounds__(TPB) void k_materialize(uint64_t* __restrict__ trace_all, uint64_t n_cells, const uint64_t* __restrict__ store_all,
+                                                     uint64_t n_store, uint32_t n_lanes, const zk_copy_pair* __restrict__ pairs, uint32_t n_pairs,
+                                                     uint32_t pairs_per_chunk) {
     const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if (lane >= n_lanes) return;
-    uint64_t* __restrict__ cells = cells_all + cell_off(n_cells, 0, lane);
+    uint64_t* __restrict__ trace = trace_all + cell_off(n_cells, 0, lane);
+    const uint64_t* __restrict__ store = store_all + cell_off(n_store, 0, lane);
     const uint32_t p0 = blockIdx.y * pairs_per_chunk, p1 = min(p0 + pairs_per_chunk, n_pairs);
     for (uint32_t i = p0; i < p1; ++i) {
         const zk_copy_pair p = pairs[i];
-        __builtin_nontemporal_store(cells[(size_t)uni(p.home) << 6], &cells[(size_t)uni(p.cell) << 6]);
+        __builtin_nontemporal_store(store[(size_t)uni(p.home) << 6], &trace[(size_t)uni(p.cell) << 6]);
     }
 }
 

@@ -155,14 +155,15 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
     return LAUNCH_CHECK("k_check_gates");
 }
 
-int launch_materialize(uint64_t* cells, uint64_t n_cells, uint32_t n_lanes, const zk_copy_pair* pairs, uint32_t n_pairs, void* stream) {
+int launch_materialize(uint64_t* trace, uint64_t n_cells, const uint64_t* store, uint64_t n_store, uint32_t n_lanes, const zk_copy_pair* pairs,
+                       uint32_t n_pairs, void* stream) {
     if (n_lanes == 0 || n_pairs == 0) return 0;
     unsigned lane_tiles = grid_for(n_lanes, zke::TPB);
     uint32_t chunks = std::max<uint32_t>(2, (2048 + lane_tiles - 1) / lane_tiles);
     if (chunks > n_pairs) chunks = n_pairs;
     uint32_t per = (n_pairs + chunks - 1) / chunks;
     dim3 grid(lane_tiles, (n_pairs + per - 1) / per);
-    zke::k_materialize<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(cells, n_cells, n_lanes, pairs, n_pairs, per);
+    zke::k_materialize<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(trace, n_cells, store, n_store, n_lanes, pairs, n_pairs, per);
     return LAUNCH_CHECK("k_materialize");
 }
 
