@@ -6,6 +6,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <cstdio>
+#include <map>
 #include <queue>
 #include "device_api.hpp"
 
@@ -93,6 +96,7 @@ CS::~CS() {
 
 void CS::free_scope_device(Scope& s) {
     if (s.d_prog) hipFree(s.d_prog);
+    if (s.d_prog2) hipFree(s.d_prog2);
     if (s.d_sprog) hipFree(s.d_sprog);
     s.d_sprog = nullptr;
     if (s.d_consts) hipFree(s.d_consts);
@@ -107,7 +111,7 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_store) hipFree(s.d_store);
     s.d_store = nullptr;
     if (s.d_cells) hipFree(s.d_cells);
-    s.d_prog = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
+    s.d_prog = nullptr; s.d_prog2 = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
     s.d_copies = nullptr; s.d_cells = nullptr;
 }
 
@@ -790,7 +794,8 @@ void CS::build_strands(Scope& s) {
     }
 }
 
-void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t word_begin, uint32_t word_end, void* stream) const {
+// phase 0 = loop body / outer pre, 1 = outer side, 2 = outer post
+void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream) const {
     const char* e = getenv("ZKGL_STRANDS");  // 0 off, 1 always, unset: by size and estimated gain
     const int mode = e ? atoi(e) : -1;
     const uint32_t waves = (s.n_lanes + 63) / 64;
@@ -799,23 +804,39 @@ void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t wo
     // wavefronts (outer scopes) has the chip to itself and takes any gain; one of hundreds needs a clear one (measured:
     // log_sorter's loop body at an estimated 2.8 runs 1.4x slower in strand form, keccak's at 3.7 runs 1.9x faster).
     const bool strands = s.d_sprog && mode != 0 && (mode == 1 || (waves <= 1024 && s.s_gain[phase] >= (waves <= 64 ? 1.5f : 3.2f)));
-    if (!strands) { dev_check(zkdev::launch_witness(a, word_begin, word_end, stream)); return; }
+    if (!strands) {
+        const uint32_t end = (uint32_t)s.prog2.size();
+        uint32_t w0 = 0, w1 = end, slot0 = 0;
+        if (!s.is_loop) {
+            if (phase == 0) w1 = s.pre_words2;
+            else if (phase == 1) { w0 = s.pre_words2; w1 = s.side_words2; slot0 = s.pre_slots; }
+            else { w0 = s.side_words2; slot0 = s.side_slots; }
+        }
+        a.prog = s.d_prog2; a.n_words = end;
+        dev_check(zkdev::launch_witness(a, w0, w1, slot0, stream));
+        return;
+    }
     a.prog = s.d_sprog; a.n_words = (uint32_t)s.sprog.size();
     dev_check(zkdev::launch_witness_strands(a, s.s_begin[phase], s.s_end[phase], stream));
 }
 
-// Device programs group runs of consecutive, mutually independent ops of one kind under ONE header (INPUT up to 8, SELECT and LOOKUP into one
-// table up to 4, FMA / LC4 up to 2; strand programs: 8 / 8 / 4): header b carries (members - 1), the operand words of every member follow, then
-// the destination words of every member.  The interpreter issues all operand loads of a group before the first use, so a
-// wavefront has up to 24 loads in flight instead of 3 — the plain one-op-at-a-time form is bound by the latency of each op's
-// dependent loads, not by bandwidth (main_vm: 7 073 ops per cycle, 55 % of them SELECTs, most of them recorded as
-// parallel_select over 8 / 12 elements).  The exported program (oracle) stays ungrouped.
-static uint32_t group_cap(const OpRec& op) {
+// Device programs group runs of consecutive, mutually independent ops of one kind under ONE header: header b carries
+// (members - 1), the operand words of every member follow.  The interpreter issues all operand loads of a group before the
+// first use — the one-op-at-a-time form is bound by the latency of each op's dependent loads, not by bandwidth (main_vm:
+// 7 073 ops per cycle, 55 % of them SELECTs, most of them recorded as parallel_select over 8 / 12 elements).  Two device forms:
+//   v1 (`prog`: strand builder input, k_witness_seq): operands carry a kind, explicit destination words (store slots);
+//       caps INPUT 8, SELECT / LOOKUP 4, FMA / LC4 2 (kernels_engine.hpp GS / GF).
+//   v2 (`prog2`: the plain kernels, kernels_engine2.hpp): scalar-decoded, data operands are bare store slots, FMA / LC4
+//       coefficients bare pool indices, NO destination words (an op's outputs are the next consecutive store slots);
+//       caps INPUT 8, SELECT 5, FMA 3, LOOKUP 4, U32MULADD 3 — header + operands of a group fit one 16-word scalar fetch.
+// The exported program (oracle) stays ungrouped with every destination cell spelled out.
+static uint32_t group_cap(const OpRec& op, bool v2) {
     switch (op.opcode) {
-    // the plain kernels' caps (kernels_engine.hpp GS / GF for !STRANDS); INPUT members cost one register pair each
     case ZK_OP_INPUT: return 8;
-    case ZK_OP_SELECT: return 4;
-    case ZK_OP_FMA: case ZK_OP_LC4: return 2;
+    case ZK_OP_SELECT: return v2 ? 5 : 4;
+    case ZK_OP_FMA: return v2 ? 3 : 2;
+    case ZK_OP_LC4: return v2 ? 1 : 2;
+    case ZK_OP_U32MULADD: return v2 ? 3 : 1;
     case ZK_OP_LOOKUP: return (op.a <= 2 && op.b <= 2) ? 4 : 1;
     default: return 1;
     }
@@ -823,76 +844,135 @@ static uint32_t group_cap(const OpRec& op) {
 
 void CS::emit_scope(Scope& s) {
     std::vector<uint8_t> defined(s.n_vars, 0);
-    s.prog.clear(); s.prog_full.clear();
-    s.pre_words = 0; s.pre_words_full = 0;
+    s.prog.clear(); s.prog_full.clear(); s.prog2.clear();
+    s.pre_words = 0; s.pre_words_full = 0; s.pre_words2 = 0; s.side_words2 = 0; s.pre_slots = 0; s.side_slots = 0;
     s.cells_written = 0; s.cells_populated = 0;
     const char* grp_env = getenv("ZKGL_OP_GROUPS");
     const bool grouping = !(grp_env && grp_env[0] == '0');
-    std::vector<uint32_t> produced_in_group(s.n_vars, UINT32_MAX);  // var -> id of the open group that produces it
-    uint32_t group_id = 0;
-    std::vector<size_t> group;  // op indices of the open group (device program)
-    auto flush = [&]() {
-        if (group.empty()) return;
-        const OpRec& first = s.ops[group[0]];
-        const size_t n = group.size();
-        emit_full_ = false;
-        if (n == 1) emit_op(s, first, s.prog);
-        else {
-            auto operand = [&](const Operand& in) {
-                if (in.kind == Operand::VAR) s.prog.push_back(s.var_slot[in.idx]);
-                else if (in.kind == Operand::CONSTPOOL) s.prog.push_back(ZK_OPERAND_CONST | in.idx);
-                else if (in.kind == Operand::OUTER_VAR) s.prog.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
-                else s.prog.push_back(in.idx);
-            };
-            if (first.opcode == ZK_OP_LOOKUP) {
-                s.prog.push_back((uint32_t)ZK_OP_LOOKUP | ((uint32_t)first.a << 8) | (((uint32_t)first.b | ((uint32_t)(n - 1) << 8)) << 16));
-                s.prog.push_back(first.ins[0].idx);  // table id
-                for (size_t oi : group)
-                    for (size_t q = 1; q < s.ops[oi].ins.size(); ++q) operand(s.ops[oi].ins[q]);
-            } else {
-                s.prog.push_back((uint32_t)first.opcode | ((uint32_t)first.a << 8) | ((uint32_t)(n - 1) << 16));
-                for (size_t oi : group)
-                    for (auto& in : s.ops[oi].ins) operand(in);
-            }
-            for (size_t oi : group) emit_dests(s, s.ops[oi], s.prog);
-        }
-        group.clear();
-        ++group_id;
-    };
+    // ---- the exported program + validation
     for (size_t oi = 0; oi < s.ops.size(); ++oi) {
-        if (!s.is_loop && (oi == s.pre_ops || oi == s.side_ops)) flush();  // phases are launched separately
-        if (!s.is_loop && oi == s.pre_ops) { s.pre_words = (uint32_t)s.prog.size(); s.pre_words_full = (uint32_t)s.prog_full.size(); }
-        if (!s.is_loop && oi == s.side_ops) s.side_words = (uint32_t)s.prog.size();
+        if (!s.is_loop && oi == s.pre_ops) s.pre_words_full = (uint32_t)s.prog_full.size();
         const OpRec& op = s.ops[oi];
         if (op.seed_only) continue;
         for (auto& in : op.ins)
             if (in.kind == Operand::VAR && !defined[in.idx]) throw ZkError(ZK_ERR_UNRESOLVED, "witness op reads a variable no earlier op produced");
-        // device program: join the open group when the kind matches and no operand comes from a member of that group
-        bool joins = grouping && !group.empty() && group.size() < group_cap(op) && s.ops[group[0]].opcode == op.opcode;
-        if (joins && op.opcode == ZK_OP_LOOKUP) {
-            const OpRec& f = s.ops[group[0]];
-            joins = f.a == op.a && f.b == op.b && f.ins[0].idx == op.ins[0].idx;
-        }
-        if (joins)
-            for (auto& in : op.ins)
-                if (in.kind == Operand::VAR && produced_in_group[in.idx] == group_id) { joins = false; break; }
-        if (!joins) flush();
-        group.push_back(oi);
-        for (uint32_t ov : op.outs) produced_in_group[ov] = group_id;
         emit_full_ = true;
         emit_op(s, op, s.prog_full);
         emit_full_ = false;
         for (uint32_t ov : op.outs) {
             if (defined[ov]) throw ZkError(ZK_ERR_INVALID, "variable produced twice");
+            if (s.var_slot[ov] != s.cells_written) throw ZkError(ZK_ERR_INVALID, "internal: store slots are not in production order");
             defined[ov] = 1;
             s.cells_written += 1;
             s.cells_populated += s.var_cells[ov].size();
         }
     }
-    flush();
-    if (!s.is_loop && s.pre_ops >= s.ops.size()) { s.pre_words = (uint32_t)s.prog.size(); s.pre_words_full = (uint32_t)s.prog_full.size(); }
-    if (!s.is_loop && s.side_ops >= s.ops.size()) s.side_words = (uint32_t)s.prog.size();
-    if (!s.is_loop && s.side_words < s.pre_words) s.side_words = s.pre_words;
+    if (!s.is_loop && s.pre_ops >= s.ops.size()) s.pre_words_full = (uint32_t)s.prog_full.size();
+    // ---- the two device forms
+    for (int form = 1; form <= 2; ++form) {
+        const bool v2 = form == 2;
+        std::vector<uint32_t>& out = v2 ? s.prog2 : s.prog;
+        std::vector<uint32_t> produced_in_group(s.n_vars, UINT32_MAX);  // var -> id of the open group that produces it
+        uint32_t group_id = 0, slots_done = 0;
+        std::vector<size_t> group;  // op indices of the open group
+        auto operand = [&](const OpRec& op, size_t pos) {
+            const Operand& in = op.ins[pos];
+            if (v2) {
+                const bool coeff = (op.opcode == ZK_OP_FMA && pos < 2) || (op.opcode == ZK_OP_LC4 && pos < 4) || (op.opcode == ZK_OP_NN_MULMOD && pos < 16);
+                if (coeff) {
+                    if (in.kind != Operand::CONSTPOOL) throw ZkError(ZK_ERR_INVALID, "internal: FMA / LC4 / NN_MULMOD immediate is not a pool constant");
+                    out.push_back(in.idx);
+                } else if (op.opcode == ZK_OP_CONST) {
+                    if (in.kind == Operand::CONSTPOOL) out.push_back(ZK_OPERAND_CONST | in.idx);
+                    else if (in.kind == Operand::OUTER_VAR) out.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
+                    else throw ZkError(ZK_ERR_INVALID, "internal: ZK_OP_CONST of a variable");
+                } else if (in.kind == Operand::VAR) out.push_back(s.var_slot[in.idx]);
+                else if (in.kind == Operand::RAW) out.push_back(op.opcode == ZK_OP_LOOP_LAST ? loop_.var_slot[in.idx] : in.idx);
+                else throw ZkError(ZK_ERR_INVALID, "internal: pool constant / outer value in a data operand position");
+                return;
+            }
+            if (in.kind == Operand::VAR) out.push_back(s.var_slot[in.idx]);
+            else if (in.kind == Operand::CONSTPOOL) out.push_back(ZK_OPERAND_CONST | in.idx);
+            else if (in.kind == Operand::OUTER_VAR) out.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
+            else out.push_back(op.opcode == ZK_OP_LOOP_LAST ? loop_.var_slot[in.idx] : in.idx);
+        };
+        auto flush = [&]() {
+            if (group.empty()) return;
+            const OpRec& first = s.ops[group[0]];
+            const size_t n = group.size();
+            if (first.opcode == ZK_OP_LOOKUP) {
+                out.push_back((uint32_t)ZK_OP_LOOKUP | ((uint32_t)first.a << 8) | (((uint32_t)first.b | ((uint32_t)(n - 1) << 8)) << 16));
+                out.push_back(first.ins[0].idx);  // table id
+                for (size_t oi : group)
+                    for (size_t q = 1; q < s.ops[oi].ins.size(); ++q) operand(s.ops[oi], q);
+            } else {
+                const bool counted = group_cap(first, v2) > 1 || first.opcode == ZK_OP_INPUT || first.opcode == ZK_OP_SELECT || first.opcode == ZK_OP_FMA ||
+                                     first.opcode == ZK_OP_LC4 || (v2 && first.opcode == ZK_OP_U32MULADD);
+                out.push_back((uint32_t)first.opcode | ((uint32_t)first.a << 8) | ((counted ? (uint32_t)(n - 1) : (uint32_t)first.b) << 16));
+                for (size_t oi : group)
+                    for (size_t q = 0; q < s.ops[oi].ins.size(); ++q) operand(s.ops[oi], q);
+            }
+            for (size_t oi : group) {
+                if (!v2) emit_dests(s, s.ops[oi], out);
+                slots_done += (uint32_t)s.ops[oi].outs.size();
+            }
+            group.clear();
+            ++group_id;
+        };
+        for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+            if (!s.is_loop && (oi == s.pre_ops || oi == s.side_ops)) flush();  // phases are launched separately
+            if (!s.is_loop && oi == s.pre_ops) { (v2 ? s.pre_words2 : s.pre_words) = (uint32_t)out.size(); if (v2) s.pre_slots = slots_done; }
+            if (!s.is_loop && oi == s.side_ops) { (v2 ? s.side_words2 : s.side_words) = (uint32_t)out.size(); if (v2) s.side_slots = slots_done; }
+            const OpRec& op = s.ops[oi];
+            if (op.seed_only) continue;
+            // join the open group when the kind matches and no operand comes from a member of that group
+            bool joins = grouping && !group.empty() && group.size() < group_cap(op, v2) && s.ops[group[0]].opcode == op.opcode;
+            if (joins && op.opcode == ZK_OP_LOOKUP) {
+                const OpRec& f = s.ops[group[0]];
+                joins = f.a == op.a && f.b == op.b && f.ins[0].idx == op.ins[0].idx;
+            }
+            if (joins)
+                for (auto& in : op.ins)
+                    if (in.kind == Operand::VAR && produced_in_group[in.idx] == group_id) { joins = false; break; }
+            if (!joins) flush();
+            group.push_back(oi);
+            for (uint32_t ov : op.outs) produced_in_group[ov] = group_id;
+        }
+        flush();
+        if (!s.is_loop && s.pre_ops >= s.ops.size()) { (v2 ? s.pre_words2 : s.pre_words) = (uint32_t)out.size(); if (v2) s.pre_slots = slots_done; }
+        if (!s.is_loop && s.side_ops >= s.ops.size()) { (v2 ? s.side_words2 : s.side_words) = (uint32_t)out.size(); if (v2) s.side_slots = slots_done; }
+    }
+    if (!s.is_loop && s.side_words < s.pre_words) { s.side_words = s.pre_words; s.side_words2 = s.pre_words2; s.side_slots = s.pre_slots; }
+    if (getenv("ZKGL_PROG_STATS")) {
+        // op mix of the scope: ops, operands by kind (data positions), outputs; distance (in produced values) from an operand's producer
+        std::map<uint32_t, std::array<uint64_t, 6>> mix;  // opcode -> ops, var operands, const operands, outer operands, outs, raw
+        std::vector<uint32_t> born(s.n_vars, 0);
+        uint64_t produced = 0, hist[8] = {0};
+        for (auto& op : s.ops) {
+            if (op.seed_only) continue;
+            auto& m = mix[op.opcode];
+            m[0]++;
+            for (auto& in : op.ins) {
+                if (in.kind == Operand::VAR) {
+                    m[1]++;
+                    const uint64_t d = produced - born[in.idx];
+                    hist[d <= 8 ? 0 : d <= 32 ? 1 : d <= 128 ? 2 : d <= 512 ? 3 : d <= 2048 ? 4 : d <= 8192 ? 5 : 6]++;
+                } else if (in.kind == Operand::CONSTPOOL) m[2]++;
+                else if (in.kind == Operand::OUTER_VAR) m[3]++;
+                else m[5]++;
+            }
+            m[4] += op.outs.size();
+            for (uint32_t ov : op.outs) born[ov] = (uint32_t)produced++;
+        }
+        fprintf(stderr, "[zkgl] %s scope: %zu ops, %u vars, device programs %zu (v1) / %zu (v2) words\n", s.is_loop ? "loop" : "outer", s.ops.size(), s.n_vars, s.prog.size(), s.prog2.size());
+        for (auto& kv : mix)
+            fprintf(stderr, "   op %2u: n=%6llu var=%7llu const=%6llu outer=%6llu raw=%6llu outs=%7llu\n", kv.first, (unsigned long long)kv.second[0],
+                    (unsigned long long)kv.second[1], (unsigned long long)kv.second[2], (unsigned long long)kv.second[3], (unsigned long long)kv.second[5],
+                    (unsigned long long)kv.second[4]);
+        fprintf(stderr, "   operand age (values produced since): <=8 %llu, <=32 %llu, <=128 %llu, <=512 %llu, <=2048 %llu, <=8192 %llu, more %llu\n",
+                (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2], (unsigned long long)hist[3], (unsigned long long)hist[4],
+                (unsigned long long)hist[5], (unsigned long long)hist[6]);
+    }
     for (auto& g : s.gates)
         for (uint32_t v : g.vars)
             if (!defined[v]) throw ZkError(ZK_ERR_UNRESOLVED, "gate references a variable without a witness producer");
@@ -1118,6 +1198,11 @@ void CS::upload_scope(Scope& s) {
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
         s.d_prog = upload(padded);
     }
+    {
+        std::vector<uint32_t> padded(s.prog2);  // one 16-word scalar fetch per op, the last op's fetch runs past the end
+        padded.resize(((padded.size() + 63) / 64) * 64 + 64, 0);
+        s.d_prog2 = upload(padded);
+    }
     if (!s.sprog.empty()) {
         std::vector<uint32_t> padded(s.sprog);
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
@@ -1329,7 +1414,7 @@ void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {
     hip_check(hipMemsetAsync(d_mult_, 0, std::max<size_t>((size_t)batch_ * total_table_rows_ * 4, 4), st), "memset mult");
     auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
-    dev_check(zkdev::launch_witness(oa, 0, outer_.pre_words, st));
+    launch_phase(outer_, oa, 0, st);
     const char* force_generic = std::getenv("ZKGL_SEED_GENERIC");
     const char* seed_strands = std::getenv("ZKGL_SEED_STRANDS");  // 0: plain cone, 1: strand form whenever it exists
     const bool generic = force_generic && force_generic[0] == '1';
@@ -1355,12 +1440,12 @@ void CS::resolve(void* stream) {
     auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
     hip_check(hipEventRecord((hipEvent_t)ev_[0], st), "event");
-    launch_phase(outer_, oa, 0, 0, outer_.pre_words, st);
+    launch_phase(outer_, oa, 0, st);
     hip_check(hipEventRecord((hipEvent_t)ev_[1], st), "event");
-    if (limit_) launch_phase(loop_, la, 0, 0, (uint32_t)loop_.prog.size(), st);
+    if (limit_) launch_phase(loop_, la, 0, st);
     hip_check(hipEventRecord((hipEvent_t)ev_[2], st), "event");
-    launch_phase(outer_, oa, 1, outer_.pre_words, outer_.side_words, st);
-    launch_phase(outer_, oa, 2, outer_.side_words, (uint32_t)outer_.prog.size(), st);
+    launch_phase(outer_, oa, 1, st);
+    launch_phase(outer_, oa, 2, st);
     hip_check(hipEventRecord((hipEvent_t)ev_[3], st), "event");
     hip_check(hipStreamSynchronize(st), "resolve sync");
     float a = 0, b = 0, c = 0;
@@ -1571,15 +1656,15 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
     hip_check(hipEventRecord(E(0), st), "event");                     // t0 (+ memsets done)
     hip_check(hipStreamWaitEvent(ax, E(0), 0), "wait");
-    launch_phase(outer_, oa, 0, 0, outer_.pre_words, ax);    // outer PRE
+    launch_phase(outer_, oa, 0, ax);    // outer PRE
     hip_check(hipEventRecord(E(1), ax), "event");
     hip_check(hipStreamWaitEvent(st, E(1), 0), "wait");
     hip_check(hipEventRecord(E(2), st), "event");
-    if (limit_) launch_phase(loop_, la, 0, 0, (uint32_t)loop_.prog.size(), st);   // LOOP
+    if (limit_) launch_phase(loop_, la, 0, st);   // LOOP
     hip_check(hipEventRecord(E(3), st), "event");
-    launch_phase(outer_, oa, 1, outer_.pre_words, outer_.side_words, ax);             // outer SIDE (|| LOOP)
+    launch_phase(outer_, oa, 1, ax);             // outer SIDE (|| LOOP)
     hip_check(hipStreamWaitEvent(ax, E(3), 0), "wait");
-    launch_phase(outer_, oa, 2, outer_.side_words, (uint32_t)outer_.prog.size(), ax);  // outer POST
+    launch_phase(outer_, oa, 2, ax);  // outer POST
     // compact traces: the gate checkers read every cell through the alias map; no copy pass (see check_satisfied)
     dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, true), ax));
     hip_check(hipEventRecord(E(4), ax), "event");
@@ -1674,7 +1759,7 @@ void CS::stats(zk_stats* o) const {
     o->var_cells_per_instance = o->rows_per_instance * (o->copy_columns + o->lookup_columns);
     for (int k = 0; k < ZK_GATE__COUNT; ++k) o->gate_instances[k] = outer_.gate_counts[k] + loop_.gate_counts[k] * limit_;
     o->lookups_per_instance = outer_.lookups.size() + loop_.lookups.size() * (uint64_t)limit_;
-    o->program_words_outer = outer_.prog.size(); o->program_words_loop = loop_.prog.size();
+    o->program_words_outer = outer_.prog2.size(); o->program_words_loop = loop_.prog2.size();
     o->scratch_cells_outer = outer_.n_scratch; o->scratch_cells_loop = loop_.n_scratch;
     o->cells_written_outer = outer_.cells_written; o->cells_written_loop = loop_.cells_written;
     o->cells_populated_outer = outer_.cells_populated; o->cells_populated_loop = loop_.cells_populated;

@@ -85,6 +85,10 @@ struct Scope {
     // `alias`, k_materialize fills the other cells on demand).  prog_full: every cell of every variable (export to the oracle).
     std::vector<uint32_t> prog, prog_full;
     uint32_t pre_words = 0, side_words = 0, pre_words_full = 0;
+    // prog2: the scalar-decoded form of the plain kernels (kernels_engine2.hpp) — bare slot operands, no destination words;
+    // pre/side_slots = store slot of the first output of the side / post phase
+    std::vector<uint32_t> prog2;
+    uint32_t pre_words2 = 0, side_words2 = 0, pre_slots = 0, side_slots = 0;
     // VARIABLE STORE: the witness kernels keep ONE value per variable, in a dense store indexed by production order
     // (store[((lane >> 6) * n_store + slot) * 64 + (lane & 63)]): a wave streams its results out sequentially and reads its
     // operands from recently written, nearby slots (TLB / L2 locality), and a VM instance needs 4x less memory than its trace.
@@ -109,6 +113,7 @@ struct Scope {
 
     // ---- device ----
     uint32_t* d_prog = nullptr;
+    uint32_t* d_prog2 = nullptr;
     uint32_t* d_sprog = nullptr;
     uint64_t* d_consts = nullptr;
     zk_row_desc* d_rows = nullptr;
@@ -219,7 +224,7 @@ class CS {
     uint32_t home(const Scope& s, uint32_t var) const { return emit_full_ ? s.var_cells[var][0] : s.var_slot[var]; }
     void check_streams(void* stream, bool compact);
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
-    void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, uint32_t word_begin, uint32_t word_end, void* stream) const;
+    void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream) const;
     void upload_scope(Scope& s);
     void ensure_uploaded();
     void free_scope_device(Scope& s);

@@ -35,7 +35,7 @@ int launch_memory_query_encode(const uint64_t* q, size_t n, uint64_t* enc, void*
 int launch_execution_context_encode(const uint64_t* rec, size_t n, uint64_t* enc, void* stream);
 int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* ch, size_t enc_len, size_t n,
                          uint64_t init, uint64_t* acc, uint64_t* scratch, void* stream);
-int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, void* stream);
+int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, void* stream);
 // strand mode (kernels_engine.hpp k_witness_strands): sc.prog = the strand program, begin/end = 8 word ranges
 constexpr uint32_t STRANDS_PER_TILE = 8;
 int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[8], const uint32_t end[8], void* stream);

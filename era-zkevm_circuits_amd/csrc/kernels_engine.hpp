@@ -96,6 +96,21 @@ __device__ __forceinline__ uint32_t table_find(const zk_table_desc& t, const uin
     return t.n_rows;
 }
 
+// One multiplicity increment per lane with `pred`.  Lanes of a wavefront are consecutive cycles of one instance and very often
+// look up the SAME row (a zero limb, a cleared flag): 64 same-address atomics serialise at the memory side — on main_vm they
+// were 26 of the loop kernel's 37 ms.  The wave aggregates first: one atomic per distinct row with the number of lanes on it.
+__device__ __forceinline__ void mult_add(uint32_t* mult, size_t index, bool pred) {
+    uint64_t todo = __builtin_amdgcn_ballot_w64(pred);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const size_t li = ((size_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(index >> 32), leader) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)index, leader);
+        const uint64_t same = __builtin_amdgcn_ballot_w64(pred && index == li);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(mult + li, (uint32_t)__builtin_popcountll(same));
+        todo &= ~same;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Witness interpreter.  phase_begin/phase_end delimit the word range to execute (outer scope:
 // pre phase before the loop, post phase after it).
@@ -549,7 +564,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 #pragma unroll
                             for (uint32_t i = 0; i < 2; ++i)
                                 if (i < nv) st(val[g][i]);
-                            if (row[g] < t.n_rows && active && sc.mult) atomicAdd(&sc.mult[(size_t)inst * sc.total_table_rows + t.mult_off + row[g]], 1u);
+                            mult_add(sc.mult, (size_t)inst * sc.total_table_rows + t.mult_off + row[g], row[g] < t.n_rows && active && sc.mult);
                         }
                     break;
                 }
@@ -567,8 +582,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                 for (uint32_t i = 0; i < nv; ++i)
                     st(found ? sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i] : 0ull);
             }
-            if (found && active && sc.mult)
-                atomicAdd(&sc.mult[(size_t)inst * sc.total_table_rows + t.mult_off + row], 1u);
+            mult_add(sc.mult, (size_t)inst * sc.total_table_rows + t.mult_off + row, found && active && sc.mult);
         } break;
         case ZK_OP_POSEIDON2:      // witness-only permutation: 12 outputs
         case ZK_OP_P2_ROUNDS: {    // in-circuit permutation: every intermediate the gates constrain is
@@ -775,32 +789,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
     }
 }
 
-// Two symbols for the same interpreter so that profiles separate the loop-scope launch (the dominant,
-// HBM-bound kernel: B*limit lanes) from the outer-scope launches (B lanes, latency-bound).
-template <bool WITH_BIGINT, bool BUFFER_ADDRESSING = true>
-__device__ __forceinline__ void witness_entry(const ScopeDev& sc, uint32_t word_begin, uint32_t word_end) {
-    uint32_t lane = blockIdx.x * TPB + threadIdx.x;
-    if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
-    const bool active = lane < sc.n_lanes;
-    lane = active ? lane : sc.n_lanes - 1;
-    run_lane<WITH_BIGINT, false, BUFFER_ADDRESSING>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end);
-}
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_LOOP_WAVES, 8))) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
-    witness_entry<false>(sc, word_begin, word_end);
-}
-__global__ __launch_bounds__(TPB) void k_witness_outer(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
-    witness_entry<false>(sc, word_begin, word_end);
-}
-// scopes with >= 2^23 cells per lane (e.g. linear_hasher: 28 Keccak permutations per iteration)
-__global__ __launch_bounds__(TPB) void k_witness_wide(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
-    witness_entry<true, false>(sc, word_begin, word_end);
-}
-__global__ __launch_bounds__(TPB) void k_witness_loop_bigint(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
-    witness_entry<true>(sc, word_begin, word_end);
-}
-__global__ __launch_bounds__(TPB) void k_witness_outer_bigint(ScopeDev sc, uint32_t word_begin, uint32_t word_end) {
-    witness_entry<true>(sc, word_begin, word_end);
-}
+// The plain (one lane per thread, whole program) kernels live in kernels_engine2.hpp: scalar-decoded v2 programs.
 
 // Strand mode: a scope with too few lanes to fill the chip (hash circuits: lanes = instances x cycles; every outer scope:
 // lanes = instances) runs one 64-lane tile per BLOCK of 8 wavefronts.  Wavefront w walks strand w of the program: the ops of

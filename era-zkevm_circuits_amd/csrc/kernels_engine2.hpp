@@ -1,0 +1,514 @@
+// kernels_engine2.hpp — the plain witness interpreter, scalar-decoded ("v2" device programs, cs.cpp emit_scope).
+//
+// The first interpreter (kernels_engine.hpp run_lane) fetched program words through a VGPR window + v_readlane and
+// resolved every operand through a three-way kind branch; rocprofv3 PMC on main_vm (profiles/r2_pmc_vm_loop_v1.txt)
+// showed what that costs: 2.1 M instructions per wavefront for 7 073 ops, 80 % of every wave's life in s_waitcnt, and
+// — from the ISA — a vmcnt(0) behind nearly EVERY operand load: the compiler could not keep the loads of a group in flight
+// across the kind branches, so each of the 28 k loads per lane paid its own L2 round trip (TCP_TCC_READ_REQ_LATENCY ~ 950 clk).
+//
+// This interpreter is built around what the variable store (cs.cpp assign_store_slots) guarantees:
+//   * Program words are read by the SCALAR unit: one s_load_dwordx16 per op (header + operands land in SGPRs; every
+//     wavefront walks the same words, so they are scalar-cache / L2 hits), no readlane, no window bookkeeping.
+//   * Data operands are always store slots (the recorder never puts a pool constant or an outer value in a data position;
+//     the only ops that read those are ZK_OP_CONST imports and the FMA / LC4 coefficients): an operand load is ONE
+//     instruction, buffer_load_dwordx2 with soffset = slot * 512 from an SGPR, branch-free, so all operand loads of a
+//     group are issued back to back and waited for once.
+//   * Coefficients (FMA q, l; LC4 k0..3) are pool indices read with scalar loads; "coefficient == 1" is a scalar branch.
+//   * Outputs have NO destination words: an op's outputs are the next consecutive store slots (production order), the
+//     kernel keeps one running SGPR byte offset; a store is buffer_store_dwordx2 + s_add.
+// Same values, same slots as the strand / wide / sequential kernels that still run the v1 form.
+#pragma once
+#include "kernels_engine.hpp"
+
+namespace zke {
+
+typedef uint32_t u32x16_a4 __attribute__((ext_vector_type(16), aligned(4)));
+typedef __attribute__((address_space(4))) const u32x16_a4* prog16_ptr;
+typedef __attribute__((address_space(4))) const uint32_t* prog1_ptr;
+typedef __attribute__((address_space(4))) const uint64_t* cpool_ptr;
+
+// v2 group caps (cs.cpp group_cap must agree): members of one header
+constexpr uint32_t G2_INPUT = 8, G2_SELECT = 5, G2_FMA = 3, G2_LOOKUP = 4, G2_U32MULADD = 3;
+#ifdef ZKGL_STUB_MULT  // time attribution only: lookups without the multiplicity atomics
+#define ZKGL_MULT_ON false
+#else
+#define ZKGL_MULT_ON true
+#endif
+template <uint32_t N> struct GroupSize { static constexpr uint32_t value = N; };
+
+// table row of a key tuple of <= 2 keys (the grouped lookups), no key array: a dynamically indexed array would live in scratch
+__device__ __forceinline__ uint32_t table_find2(const zk_table_desc& t, const uint64_t* __restrict__ words, uint64_t k0, uint64_t k1) {
+    if (t.dense) {
+        // full product of power-of-two key ranges, last key fastest: row index = packed key; in the table iff every key is in range
+        const uint32_t top = 31 - __clz(t.n_rows);
+        const uint32_t bits0 = top - t.key_shift[0];
+        bool ok = (k0 >> bits0) == 0;
+        uint64_t idx = k0 << t.key_shift[0];
+        if (t.n_keys > 1) {
+            const uint32_t bits1 = t.key_shift[0] - t.key_shift[1];
+            ok = ok && (k1 >> bits1) == 0;
+            idx += k1 << t.key_shift[1];
+        }
+        return ok ? (uint32_t)idx : t.n_rows;
+    }
+    const uint32_t w = t.n_keys + t.n_vals;
+    const uint64_t* rows = words + (size_t)t.word_off;
+    uint32_t lo = 0, hi = t.n_rows;  // rows sorted lexicographically by key tuple
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t r0 = rows[(size_t)mid * w];
+        int cmp = r0 < k0 ? -1 : (r0 > k0 ? 1 : 0);
+        if (cmp == 0 && t.n_keys > 1) {
+            const uint64_t r1 = rows[(size_t)mid * w + 1];
+            cmp = r1 < k1 ? -1 : (r1 > k1 ? 1 : 0);
+        }
+        if (cmp == 0) return mid;
+        if (cmp < 0) lo = mid + 1; else hi = mid;
+    }
+    return t.n_rows;
+}
+
+template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB>
+__device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
+                                          uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane_byte = (lane & 63) * 8;
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(sc.cells + (size_t)tile * sc.n_cells * 64, 0, -1, 0x00020000);
+    uint64_t* __restrict__ wide_cells = sc.cells + (size_t)tile * sc.n_cells * 64 + (lane & 63);
+    const prog1_ptr prog = (prog1_ptr)(uintptr_t)sc.prog;
+    const cpool_ptr cpool = (cpool_ptr)(uintptr_t)sc.consts;
+    __shared__ uint64_t p2s[12 * BLOCK];  // Poseidon2 state, [element][thread]
+
+    uint32_t dst = WIDE ? slot_begin : slot_begin << 9;  // next output: slot index (WIDE) or byte offset in the tile
+    auto ldv = [&](uint32_t slot) -> uint64_t {
+#ifdef ZKGL_STUB_LOADS  // time attribution only (tools/stub_vm.sh): operand values without the memory access
+        return (uint64_t)slot * 0x9E3779B97F4A7C15ull + lane_byte;
+#else
+        if constexpr (WIDE) return wide_cells[(size_t)slot << 6];
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << 9, 0);
+        return (uint64_t)v.x | ((uint64_t)v.y << 32);
+#endif
+    };
+    auto st = [&](uint64_t v) {
+#ifdef ZKGL_STUB_STORES
+        asm volatile("" ::"v"(v), "s"(dst));
+        dst += WIDE ? 1 : 512;
+#else
+        if constexpr (WIDE) {
+            wide_cells[(size_t)dst << 6] = v;
+            dst += 1;
+        } else {
+            u32x2 o;
+            o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
+            __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, dst, 0);
+            dst += 512;
+        }
+#endif
+    };
+
+    uint32_t pc = word_begin;
+    while (pc < word_end) {
+        const u32x16_a4 W = *(prog16_ptr)(prog + pc);  // s_load_dwordx16: header + up to 15 operand words (host pads the program)
+        const uint32_t h = W[0];
+        const uint32_t op = h & 0xff, pa = (h >> 8) & 0xff, pb = h >> 16;
+        switch (op) {
+        case ZK_OP_CONST: {  // the only op whose operand carries a kind: a pool constant, or (loop scope) a value of the outer scope
+            const uint32_t w = W[1];
+            pc += 2;
+            uint64_t v;
+            if ((w & ZK_OPERAND_KIND_MASK) == ZK_OPERAND_OUTER) v = sc.outer_cells[cell_off(sc.outer_n_cells, w & ZK_OPERAND_IDX_MASK, inst)];
+            else v = cpool[w & ZK_OPERAND_IDX_MASK];
+            st(v);
+        } break;
+        // Grouped ops: one straight-line instance per group size (no predication: every operand load of the group is issued
+        // before the first wait, and the register allocator sees exactly the live set of that size).
+        case ZK_OP_INPUT: {
+            auto body = [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) v[g] = sc.inputs[(size_t)W[1 + g] * sc.n_lanes + lane];
+                pc += 1 + N;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) st(v[g]);
+            };
+            switch (pb) {
+            case 0: body(GroupSize<1>{}); break;
+            case 1: body(GroupSize<2>{}); break;
+            case 2: body(GroupSize<3>{}); break;
+            case 3: body(GroupSize<4>{}); break;
+            case 4: body(GroupSize<5>{}); break;
+            case 5: body(GroupSize<6>{}); break;
+            case 6: body(GroupSize<7>{}); break;
+            default: body(GroupSize<8>{}); break;
+            }
+        } break;
+        case ZK_OP_FMA: {  // [q, l: pool indices][a, b, c: slots] per member
+            auto body = [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t in[N][3], q[N], l[N];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 3; ++i) in[g][i] = ldv(W[1 + g * 5 + 2 + i]);
+                    q[g] = cpool[W[1 + g * 5]];
+                    l[g] = cpool[W[1 + g * 5 + 1]];
+                }
+                pc += 1 + N * 5;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+                    const uint64_t ab = gl::mul(in[g][0], in[g][1]);
+                    st(gl::add(q[g] == 1 ? ab : gl::mul(q[g], ab), l[g] == 1 ? in[g][2] : gl::mul(l[g], in[g][2])));
+                }
+            };
+            switch (pb) {
+            case 0: body(GroupSize<1>{}); break;
+            case 1: body(GroupSize<2>{}); break;
+            default: body(GroupSize<3>{}); break;
+            }
+        } break;
+        case ZK_OP_LC4: {  // [k0..3: pool indices][t0..3: slots]
+            uint64_t t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = ldv(W[5 + i]);
+            uint64_t r = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r = gl::fma(cpool[W[1 + i]], t[i], r);
+            pc += 9;
+            st(r);
+        } break;
+        case ZK_OP_SELECT: {
+            auto body = [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t in[N][3];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 3; ++i) in[g][i] = ldv(W[1 + g * 3 + i]);
+                }
+                pc += 1 + N * 3;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) st(in[g][0] ? in[g][1] : in[g][2]);
+            };
+            switch (pb) {
+            case 0: body(GroupSize<1>{}); break;
+            case 1: body(GroupSize<2>{}); break;
+            case 2: body(GroupSize<3>{}); break;
+            case 3: body(GroupSize<4>{}); break;
+            default: body(GroupSize<5>{}); break;
+            }
+        } break;
+        case ZK_OP_ISZERO: {
+            const uint64_t x = ldv(W[1]);
+            pc += 2;
+            st(x == 0 ? 1ull : 0ull);
+            // x^-1: flags and small counters dominate; 0 and 1 are their own (pseudo-)inverses, skip the 73-multiplication chain
+            // when the whole wavefront holds such values
+            st(__builtin_amdgcn_ballot_w64(x > 1) == 0 ? x : gl::inv(x));
+        } break;
+        case ZK_OP_UADD: {
+            const uint64_t x = ldv(W[1]), y = ldv(W[2]), ci = ldv(W[3]);
+            pc += 4;
+            const uint64_t s = x + y + ci;  // operands < 2^32
+            st(s & ((1ull << pa) - 1));
+            st(s >> pa);
+        } break;
+        case ZK_OP_USUB: {
+            const uint64_t x = ldv(W[1]), y = ldv(W[2]), bi = ldv(W[3]);
+            pc += 4;
+            const uint64_t sub = y + bi;
+            const uint64_t borrow = x < sub ? 1 : 0;
+            st((x + (borrow << pa)) - sub);
+            st(borrow);
+        } break;
+        case ZK_OP_DOT4: {
+            uint64_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = ldv(W[1 + i]);
+            pc += 9;
+            uint64_t r = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r = gl::fma(v[2 * i], v[2 * i + 1], r);
+            st(r);
+        } break;
+        case ZK_OP_MATMUL12: {
+            uint64_t s[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s[i] = ldv(W[1 + i]);
+            pc += 13;
+            if (pa == 0) p2::mds_external(s); else p2::mds_inner(s);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) st(s[i]);
+        } break;
+        case ZK_OP_SPLIT: {
+            uint64_t x = ldv(W[1]);
+            pc += 2;
+            for (uint32_t i = 0; i < pa; ++i) {
+                st(i + 1 == pa ? x : (x & ((1ull << pb) - 1)));
+                x >>= pb;
+            }
+        } break;
+        case ZK_OP_LOOKUP: {  // [table id][keys of every member]; pb = n_vals | (members - 1) << 8
+            const uint32_t tid = W[1];
+            const zk_table_desc t = sc.tables[tid];
+            const uint32_t nv = pb & 0xff, grp = (pb >> 8) + 1;
+            const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(sc.table_words + (t.dense >> 2));
+            const uint32_t w = t.n_keys + t.n_vals;
+            if (pa <= 2 && nv <= 2) {
+                auto body = [&](auto n_) {
+                    constexpr uint32_t N = decltype(n_)::value;
+                    uint64_t k0[N], k1[N], val[N][2];
+                    uint32_t row[N];
+#pragma unroll
+                    for (uint32_t g = 0; g < N; ++g) {
+                        k0[g] = pa == 2 ? ldv(W[2 + 2 * g]) : ldv(W[2 + g]);
+                        k1[g] = pa == 2 ? ldv(W[3 + 2 * g]) : 0;
+                    }
+                    pc += 2 + N * pa;
+#pragma unroll
+                    for (uint32_t g = 0; g < N; ++g) {
+                        row[g] = table_find2(t, sc.table_words, k0[g], k1[g]);
+                        const bool found = row[g] < t.n_rows;
+#pragma unroll
+                        for (uint32_t i = 0; i < 2; ++i)
+                            if (i < nv)
+                                val[g][i] = !found ? 0ull
+                                            : (t.dense & 2u) ? (uint64_t)tb[(size_t)row[g] * t.n_vals + i]
+                                                             : sc.table_words[(size_t)t.word_off + (size_t)row[g] * w + t.n_keys + i];
+                    }
+#pragma unroll
+                    for (uint32_t g = 0; g < N; ++g) {
+#pragma unroll
+                        for (uint32_t i = 0; i < 2; ++i)
+                            if (i < nv) st(val[g][i]);
+                        mult_add(sc.mult, (size_t)inst * sc.total_table_rows + t.mult_off + row[g], ZKGL_MULT_ON && row[g] < t.n_rows && active && sc.mult);
+                    }
+                };
+                switch (grp) {
+                case 1: body(GroupSize<1>{}); break;
+                case 2: body(GroupSize<2>{}); break;
+                case 3: body(GroupSize<3>{}); break;
+                default: body(GroupSize<4>{}); break;
+                }
+            } else {  // wide tuples: one lookup per header
+                uint64_t key[3] = {0, 0, 0};
+                key[0] = ldv(W[2]);
+                if (pa > 1) key[1] = ldv(W[3]);
+                if (pa > 2) key[2] = ldv(W[4]);
+                pc += 2 + pa;
+                const uint32_t row = table_find(t, sc.table_words, key);
+                const bool found = row < t.n_rows;
+                for (uint32_t i = 0; i < nv; ++i)
+                    st(!found ? 0ull
+                       : (t.dense & 2u) ? (uint64_t)tb[(size_t)row * t.n_vals + i]
+                                        : sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i]);
+                mult_add(sc.mult, (size_t)inst * sc.total_table_rows + t.mult_off + row, ZKGL_MULT_ON && found && active && sc.mult);
+            }
+        } break;
+        case ZK_OP_POSEIDON2:      // witness-only permutation: 12 outputs
+        case ZK_OP_P2_ROUNDS: {    // in-circuit permutation: every intermediate the gates constrain, in the order of gadgets.cpp
+                                   // compute_round_function; state in LDS so that the S-box loop is not unrolled (I-cache)
+            const bool emit = (op == ZK_OP_P2_ROUNDS);
+            uint64_t s[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s[i] = ldv(W[1 + i]);
+            pc += 13;
+            p2::mds_external(s);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) p2s[i * BLOCK + threadIdx.x] = s[i];
+            if (emit) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) st(s[i]);
+            }
+#pragma unroll 1
+            for (int r = 0; r < 30; ++r) {
+                const bool full = (r < 4) || (r >= 26);
+                const int n = full ? 12 : 1;
+#pragma unroll 1
+                for (int i = 0; i < n; ++i) {
+                    const uint64_t t = gl::add(p2s[i * BLOCK + threadIdx.x], p2::RC[12 * r + i]);
+#ifdef ZKGL_STUB_P2  // time attribution only: the S-box without its four multiplications
+                    const uint64_t x2 = t ^ 1, x3 = t ^ 2, x4 = t ^ 3, x7 = t ^ 4;
+#else
+                    const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+#endif
+                    if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
+                    p2s[i * BLOCK + threadIdx.x] = x7;
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) s[i] = p2s[i * BLOCK + threadIdx.x];
+                if (full) p2::mds_external(s); else p2::mds_inner(s);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) p2s[i * BLOCK + threadIdx.x] = s[i];
+                if (emit) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) st(s[i]);
+                }
+            }
+            if (!emit) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) st(s[i]);
+            }
+        } break;
+        case ZK_OP_LOOP_LAST: {
+            const uint32_t c = W[1];
+            pc += 2;
+            st(sc.loop_cells[cell_off(sc.loop_n_cells, c, lane * sc.loop_limit + (sc.loop_limit - 1))]);
+        } break;
+        case ZK_OP_U32MULADD: {
+            auto body = [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t in[N][4];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) in[g][i] = ldv(W[1 + g * 4 + i]);
+                }
+                pc += 1 + N * 4;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+                    const uint64_t r = in[g][0] * in[g][1] + in[g][2] + in[g][3];  // < 2^64 for u32 operands
+                    st(r & 0xffffffffull);
+                    st(r >> 32);
+                }
+            };
+            switch (pb) {
+            case 0: body(GroupSize<1>{}); break;
+            case 1: body(GroupSize<2>{}); break;
+            default: body(GroupSize<3>{}); break;
+            }
+        } break;
+        case ZK_OP_NN_MULMOD: if constexpr (WITH_BIGINT) {
+            uint32_t mv[16], av[17], bv[17], res[19 + 16];
+            for (uint32_t i = 0; i < 16; ++i) mv[i] = (uint32_t)cpool[prog[pc + 1 + i]];  // modulus limbs: pool indices
+            for (uint32_t i = 0; i < pa; ++i) av[i] = (uint32_t)ldv(prog[pc + 17 + i]);
+            for (uint32_t i = 0; i < pb; ++i) bv[i] = (uint32_t)ldv(prog[pc + 17 + pa + i]);
+            pc += 17 + pa + pb;
+            const uint32_t nq = pa + pb - 15;
+            nn_mulmod(av, pa, bv, pb, mv, nq, res);
+            for (uint32_t i = 0; i < nq + 16; ++i) st(res[i]);
+        } else { return; } break;
+        case ZK_OP_DIVREM: {
+            const uint64_t x = ldv(W[1]);
+            pc += 2;
+            st(x / pb);
+            st(x % pb);
+        } break;
+        case ZK_OP_U256_MULWIDE: {
+            // column-wise schoolbook product, a 96-bit column accumulator (up to 8 products of 64 bits + carry)
+            const uint32_t w16 = prog[pc + 16];
+            uint32_t a[8], b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = (uint32_t)ldv(W[1 + i]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) b[i] = (uint32_t)ldv(W[9 + i]);
+            b[7] = (uint32_t)ldv(w16);
+            pc += 17;
+            uint64_t lo = 0;
+            uint32_t hi = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int j = k - i;
+                    if (j >= 0 && j < 8) {
+                        const uint64_t p = (uint64_t)a[i] * b[j];
+                        lo += p;
+                        hi += lo < p;
+                    }
+                }
+                st((uint64_t)(uint32_t)lo);
+                lo = (lo >> 32) | ((uint64_t)hi << 32);
+                hi = 0;
+            }
+        } break;
+        case ZK_OP_U256_DIVREM: {
+            // restoring shift-subtract division, 256 fixed steps in registers (two per VM cycle: Div and the right shifts)
+            const uint32_t w16 = prog[pc + 16];
+            uint32_t a[8], b[8], r[8];
+            uint32_t bnz = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = (uint32_t)ldv(W[1 + i]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) b[i] = (uint32_t)ldv(W[9 + i]);
+            b[7] = (uint32_t)ldv(w16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { bnz |= b[i]; r[i] = 0; }
+            pc += 17;
+            // b == 0: q = 0, r = a (mul_div.rs:96-172).  A wavefront whose lanes all divide by zero (the VM's masked-out Div / Shr
+            // cycles) skips the loop; a zero divisor next to real ones walks it with b = 0, which shifts a into r bit by bit
+            // (r == a at the end) and fills the quotient with ones, cleared below.
+            if (__builtin_amdgcn_ballot_w64(bnz != 0) != 0) {
+#pragma unroll 1
+                for (int step = 0; step < 256; ++step) {
+                    // (r, a) <<= 1 : the quotient bits enter a from the bottom as the dividend bits leave at the top
+                    const uint32_t top = r[7] >> 31;  // r < b <= 2^256 - 1 before the shift; a 257-bit r is handled by `top`
+#pragma unroll
+                    for (int i = 7; i > 0; --i) r[i] = (r[i] << 1) | (r[i - 1] >> 31);
+                    r[0] = (r[0] << 1) | (a[7] >> 31);
+#pragma unroll
+                    for (int i = 7; i > 0; --i) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
+                    a[0] <<= 1;
+                    uint32_t d[8];
+                    uint32_t borrow = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint64_t t = (uint64_t)r[i] - b[i] - borrow;
+                        d[i] = (uint32_t)t;
+                        borrow = (uint32_t)(t >> 63);
+                    }
+                    if (top | (borrow ^ 1u)) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) r[i] = d[i];
+                        a[0] |= 1u;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = bnz ? a[i] : 0u;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { r[i] = a[i]; a[i] = 0; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st((uint64_t)a[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st((uint64_t)r[i]);
+        } break;
+        default:
+            return;  // malformed program: host validates before upload
+        }
+    }
+}
+
+template <bool WITH_BIGINT, bool WIDE>
+__device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+    uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
+    const bool active = lane < sc.n_lanes;
+    lane = active ? lane : sc.n_lanes - 1;
+    run_tile2<WITH_BIGINT, WIDE>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end, slot_begin);
+}
+// Separate symbols so that profiles separate the loop-scope launch (the dominant kernel: B * limit lanes) from the
+// outer-scope launches (B lanes, latency-bound).
+#ifndef ZKGL_LOOP_WAVES2
+#define ZKGL_LOOP_WAVES2 4
+#endif
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_LOOP_WAVES2, 8))) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+    witness_entry2<false, false>(sc, word_begin, word_end, slot_begin);
+}
+__global__ __launch_bounds__(TPB) void k_witness_outer(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+    witness_entry2<false, false>(sc, word_begin, word_end, slot_begin);
+}
+// scopes with >= 2^23 store slots per lane: 64-bit addressing
+__global__ __launch_bounds__(TPB) void k_witness_wide(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+    witness_entry2<true, true>(sc, word_begin, word_end, slot_begin);
+}
+__global__ __launch_bounds__(TPB) void k_witness_loop_bigint(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+    witness_entry2<true, false>(sc, word_begin, word_end, slot_begin);
+}
+__global__ __launch_bounds__(TPB) void k_witness_outer_bigint(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+    witness_entry2<true, false>(sc, word_begin, word_end, slot_begin);
+}
+
+}  // namespace zke

@@ -7,6 +7,7 @@
 #include "device_api.hpp"
 #include "kernels_primitives.hpp"
 #include "kernels_engine.hpp"
+#include "kernels_engine2.hpp"
 #include "kernels_lookup_arg.hpp"
 #include "kernels_ntt.hpp"
 #include "kernels_perm.hpp"
@@ -104,15 +105,16 @@ static zke::ScopeDev to_dev(const ScopeArgs& a) {
     return d;
 }
 
-int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, void* stream) {
+int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, void* stream) {
+    // sc.prog = the scope's v2 program (kernels_engine2.hpp), slot_begin = the store slot of the first output of word_begin
     if (sc.n_lanes == 0 || word_begin >= word_end) return 0;
     const dim3 grid = grid_for(sc.n_lanes, zke::TPB);
     hipStream_t s = (hipStream_t)stream;
-    if (sc.n_cells >= (1ull << 23)) zke::k_witness_wide<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
-    else if (sc.is_loop && sc.uses_bigint) zke::k_witness_loop_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
-    else if (sc.is_loop) zke::k_witness_loop<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
-    else if (sc.uses_bigint) zke::k_witness_outer_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
-    else zke::k_witness_outer<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end);
+    if (sc.n_cells >= (1ull << 23)) zke::k_witness_wide<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
+    else if (sc.is_loop && sc.uses_bigint) zke::k_witness_loop_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
+    else if (sc.is_loop) zke::k_witness_loop<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
+    else if (sc.uses_bigint) zke::k_witness_outer_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
+    else zke::k_witness_outer<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     return LAUNCH_CHECK("k_witness");
 }
 
