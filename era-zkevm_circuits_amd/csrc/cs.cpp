@@ -97,6 +97,8 @@ CS::~CS() {
 void CS::free_scope_device(Scope& s) {
     if (s.d_prog) hipFree(s.d_prog);
     if (s.d_prog2) hipFree(s.d_prog2);
+    if (s.d_cprog) hipFree(s.d_cprog);
+    if (s.d_cchunks) hipFree(s.d_cchunks);
     if (s.d_sprog) hipFree(s.d_sprog);
     s.d_sprog = nullptr;
     if (s.d_consts) hipFree(s.d_consts);
@@ -111,7 +113,7 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_store) hipFree(s.d_store);
     s.d_store = nullptr;
     if (s.d_cells) hipFree(s.d_cells);
-    s.d_prog = nullptr; s.d_prog2 = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
+    s.d_prog = nullptr; s.d_prog2 = nullptr; s.d_cprog = nullptr; s.d_cchunks = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
     s.d_copies = nullptr; s.d_cells = nullptr;
 }
 
@@ -496,6 +498,64 @@ void CS::place_scope(Scope& s) {
     s.copies.clear();
     for (uint32_t v = 0; v < s.n_vars; ++v)
         for (size_t i = 1; i < s.var_cells[v].size(); ++i) s.copies.push_back({s.var_cells[v][i], s.var_cells[v][0]});
+}
+
+// Check program of the compact checker (kernels_engine2.hpp k_check_prog): per row, packets of consecutive gate instances
+// (kind | count << 8 | first instance << 16, row, offset of the row constants, then the store slots of their columns) and of
+// lookup tuples (0x40 | count << 8 | first tuple << 16, row, table id, 4 slot words per tuple).  A packet fits one 16-word
+// scalar fetch (the 24-column matrix gates take two).  Chunks of whole packets, balanced by words, for the launch grid.
+void CS::build_check_program(Scope& s) {
+    s.cprog.clear(); s.cchunks.clear();
+    const uint32_t C = geo_.num_columns_under_copy_permutation, NC = C + lookup_width_ * lookup_reps_;
+    std::vector<uint32_t> starts;
+    auto cap_of = [](uint32_t kind) -> uint32_t {
+        switch (kind) {
+        case ZK_GATE_CONST: case ZK_GATE_BOOLEAN: return 8;
+        case ZK_GATE_FMA: case ZK_GATE_SELECT: return 3;
+        case ZK_GATE_ZEROCHECK: return 4;
+        case ZK_GATE_REDUCTION4: case ZK_GATE_UINTX_ADD: case ZK_GATE_U32_FMA: case ZK_GATE_REDUCTION_BY_POWERS4: return 2;
+        case ZK_GATE_DOT4: case ZK_GATE_MATMUL12_EXT: case ZK_GATE_MATMUL12_INT: return 1;
+        default: return 0;  // NOP, PUBLIC_INPUT: no relation
+        }
+    };
+    for (uint32_t slot = 0; slot < s.n_slots; ++slot) {
+        const zk_row_desc& rd = s.rows[slot];
+        const uint32_t cap = rd.kind < ZK_GATE__COUNT ? cap_of(rd.kind) : 0, w = rd.kind < ZK_GATE__COUNT ? GATES[rd.kind].width : 0;
+        for (uint32_t j0 = 0; cap && j0 < rd.n_instances; j0 += cap) {
+            const uint32_t cnt = std::min(cap, rd.n_instances - j0);
+            starts.push_back((uint32_t)s.cprog.size());
+            s.cprog.push_back(rd.kind | (cnt << 8) | (j0 << 16));
+            s.cprog.push_back(slot);
+            s.cprog.push_back(rd.const_off);
+            for (uint32_t g = 0; g < cnt; ++g)
+                for (uint32_t c = 0; c < w; ++c) s.cprog.push_back(s.alias[(size_t)slot * NC + (j0 + g) * w + c]);
+        }
+        const zk_lookup_row_desc& lr = s.lrows[slot];
+        if (lr.table == 0xffffffffu || lr.n_tuples == 0) continue;
+        const TableRec& t = tables_[lr.table - 1];
+        const uint32_t tw = t.n_keys + t.n_vals;
+        if (tw > 4 || t.n_keys > 3) { s.cprog.clear(); s.cchunks.clear(); return; }  // the row-descriptor checker handles such scopes
+        for (uint32_t u0 = 0; u0 < lr.n_tuples; u0 += 3) {
+            const uint32_t cnt = std::min(3u, lr.n_tuples - u0);
+            starts.push_back((uint32_t)s.cprog.size());
+            s.cprog.push_back(0x40u | (cnt << 8) | (u0 << 16));
+            s.cprog.push_back(slot);
+            s.cprog.push_back(lr.table);
+            for (uint32_t g = 0; g < cnt; ++g)
+                for (uint32_t i = 0; i < 4; ++i) s.cprog.push_back(i < tw ? s.alias[(size_t)slot * NC + C + (u0 + g) * lookup_width_ + i] : 0u);
+        }
+    }
+    if (starts.empty()) { s.cprog.clear(); return; }
+    const uint32_t total = (uint32_t)s.cprog.size();
+    const uint32_t n_chunks = (uint32_t)std::min<size_t>(256, starts.size());
+    s.cchunks.push_back(0);
+    size_t p = 0;
+    for (uint32_t c = 1; c < n_chunks; ++c) {
+        const uint32_t target = (uint32_t)((uint64_t)total * c / n_chunks);
+        while (p + 1 < starts.size() && starts[p] < target) ++p;
+        if (starts[p] > s.cchunks.back()) s.cchunks.push_back(starts[p]);
+    }
+    s.cchunks.push_back(total);
 }
 
 // Store slots in production order of the FINAL op order (after scheduling); variables no op produces keep slot 0 and are
@@ -1203,6 +1263,12 @@ void CS::upload_scope(Scope& s) {
         padded.resize(((padded.size() + 63) / 64) * 64 + 64, 0);
         s.d_prog2 = upload(padded);
     }
+    if (!s.cprog.empty()) {
+        std::vector<uint32_t> padded(s.cprog);  // a packet is read with one or two 16-word scalar fetches
+        padded.resize(((padded.size() + 63) / 64) * 64 + 64, 0);
+        s.d_cprog = upload(padded);
+        s.d_cchunks = upload(s.cchunks);
+    }
     if (!s.sprog.empty()) {
         std::vector<uint32_t> padded(s.sprog);
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
@@ -1238,6 +1304,8 @@ void CS::finalize() {
     assign_store_slots(loop_);
     emit_scope(outer_);
     emit_scope(loop_);
+    build_check_program(outer_);
+    build_check_program(loop_);
     build_strands(outer_);
     if (limit_) build_strands(loop_);
     uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
@@ -1459,6 +1527,7 @@ void CS::resolve(void* stream) {
 zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool compact) const {
     zkdev::CheckArgs a;
     a.alias = compact ? s.d_alias : nullptr;
+    a.cprog = compact ? s.d_cprog : nullptr; a.chunk_tab = s.d_cchunks; a.n_chunks = s.cchunks.empty() ? 0 : (uint32_t)s.cchunks.size() - 1;
     a.cells = compact ? s.d_store : s.d_cells; a.n_cells = compact ? s.n_store : s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
     a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
     a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;

@@ -88,6 +88,9 @@ struct Scope {
     // prog2: the scalar-decoded form of the plain kernels (kernels_engine2.hpp) — bare slot operands, no destination words;
     // pre/side_slots = store slot of the first output of the side / post phase
     std::vector<uint32_t> prog2;
+    // check program of the compact gate / lookup checker (kernels_engine2.hpp k_check_prog) + its chunk table (word offsets of
+    // whole-packet chunks, n_chunks + 1 entries); empty when the scope cannot use it (a lookup tuple wider than 4 columns)
+    std::vector<uint32_t> cprog, cchunks;
     uint32_t pre_words2 = 0, side_words2 = 0, pre_slots = 0, side_slots = 0;
     // VARIABLE STORE: the witness kernels keep ONE value per variable, in a dense store indexed by production order
     // (store[((lane >> 6) * n_store + slot) * 64 + (lane & 63)]): a wave streams its results out sequentially and reads its
@@ -114,6 +117,8 @@ struct Scope {
     // ---- device ----
     uint32_t* d_prog = nullptr;
     uint32_t* d_prog2 = nullptr;
+    uint32_t* d_cprog = nullptr;
+    uint32_t* d_cchunks = nullptr;
     uint32_t* d_sprog = nullptr;
     uint64_t* d_consts = nullptr;
     zk_row_desc* d_rows = nullptr;
@@ -225,6 +230,7 @@ class CS {
     void check_streams(void* stream, bool compact);
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream) const;
+    void build_check_program(Scope& s);
     void upload_scope(Scope& s);
     void ensure_uploaded();
     void free_scope_device(Scope& s);

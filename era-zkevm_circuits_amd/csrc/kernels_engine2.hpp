@@ -511,4 +511,270 @@ __global__ __launch_bounds__(TPB) void k_witness_outer_bigint(ScopeDev sc, uint3
     witness_entry2<true, false>(sc, word_begin, word_end, slot_begin);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Gate / lookup checker over the variable store, scalar-decoded like the witness interpreter ("check program", cs.cpp
+// build_check_program).  The row-descriptor checker (kernels_engine.hpp check_gates_body) reads, per gate instance, the row
+// descriptor, then one alias word per column, then the value — three dependent round trips, 87 % of its wave time in
+// s_waitcnt (profiles/r2_pmc_vm_v2_before_mult_fix.txt).  Here a packet carries everything in one scalar fetch:
+//   w0 = kind | count << 8 | first instance << 16, w1 = row (for the failure report), w2 = offset of the row's constants,
+//   then the store slots of the columns of `count` consecutive instances of the row (lookup packets: kind 0x40, w2 = table
+//   id, count tuples of n_keys + n_vals slots).  All loads of a packet are issued back to back; a packet never exceeds the
+//   16-word fetch except the 24-column matrix gates (second fetch).
+// The program is cut into chunks of whole packets (chunk_tab); a workgroup checks 256 lanes x chunks_per_block chunks.
+// ------------------------------------------------------------------------------------------------------------------------
+struct CheckProgDev {
+    const uint64_t* cells; uint64_t n_cells; uint32_t n_lanes;
+    const uint32_t* prog; const uint32_t* chunk_tab; uint32_t n_chunks, chunks_per_block;
+    const uint64_t* rowconsts; const zk_table_desc* tables; const uint64_t* table_words;
+    unsigned long long* fail;
+};
+constexpr uint32_t ZK_CHECK_LOOKUP = 0x40;
+
+template <uint32_t N, class F>
+__device__ __forceinline__ void dispatch_count(uint32_t n, F&& f) {
+    if constexpr (N == 1) f(GroupSize<1>{});
+    else { if (n >= N) f(GroupSize<N>{}); else dispatch_count<N - 1>(n, f); }
+}
+
+// table row of a key tuple of <= 3 keys without a key array (see table_find2)
+__device__ __forceinline__ uint32_t table_find3(const zk_table_desc& t, const uint64_t* __restrict__ words, uint64_t k0, uint64_t k1, uint64_t k2) {
+    if (t.n_keys <= 2) return table_find2(t, words, k0, k1);
+    if (t.dense) {
+        const uint32_t top = 31 - __clz(t.n_rows);
+        const bool ok = (k0 >> (top - t.key_shift[0])) == 0 && (k1 >> (t.key_shift[0] - t.key_shift[1])) == 0 && (k2 >> (t.key_shift[1] - t.key_shift[2])) == 0;
+        const uint64_t idx = (k0 << t.key_shift[0]) + (k1 << t.key_shift[1]) + (k2 << t.key_shift[2]);
+        return ok ? (uint32_t)idx : t.n_rows;
+    }
+    const uint32_t w = t.n_keys + t.n_vals;
+    const uint64_t* rows = words + (size_t)t.word_off;
+    uint32_t lo = 0, hi = t.n_rows;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t r0 = rows[(size_t)mid * w], r1 = rows[(size_t)mid * w + 1], r2 = rows[(size_t)mid * w + 2];
+        const int cmp = r0 != k0 ? (r0 < k0 ? -1 : 1) : r1 != k1 ? (r1 < k1 ? -1 : 1) : r2 != k2 ? (r2 < k2 ? -1 : 1) : 0;
+        if (cmp == 0) return mid;
+        if (cmp < 0) lo = mid + 1; else hi = mid;
+    }
+    return t.n_rows;
+}
+
+__global__ __launch_bounds__(TPB) void k_check_prog(CheckProgDev cd) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= cd.n_lanes) return;
+    const bool active = lane < cd.n_lanes;
+    lane = active ? lane : cd.n_lanes - 1;
+    const uint32_t lane_byte = (lane & 63) * 8;
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(cd.cells) + (size_t)tile * cd.n_cells * 64, 0, -1, 0x00020000);
+    const prog1_ptr prog = (prog1_ptr)(uintptr_t)cd.prog;
+    const prog1_ptr tab = (prog1_ptr)(uintptr_t)cd.chunk_tab;
+    const cpool_ptr consts = (cpool_ptr)(uintptr_t)cd.rowconsts;
+    const uint32_t c0 = blockIdx.y * cd.chunks_per_block, c1 = min(c0 + cd.chunks_per_block, cd.n_chunks);
+    uint32_t pc = tab[c0];
+    const uint32_t end = tab[c1];
+    auto ldv = [&](uint32_t slot) -> uint64_t {
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << 9, 0);
+        return (uint64_t)v.x | ((uint64_t)v.y << 32);
+    };
+    while (pc < end) {
+        const u32x16_a4 W = *(prog16_ptr)(prog + pc);
+        const uint32_t kind = W[0] & 0xff, cnt = (W[0] >> 8) & 0xff, j0 = W[0] >> 16, slot = W[1];
+        const cpool_ptr k = consts + W[2];
+        auto bad = [&](bool cond, uint32_t j, uint32_t rel) { if (cond && active) report(cd.fail, lane, slot, j, rel); };
+        switch (kind) {
+        case ZK_GATE_CONST: {
+            dispatch_count<8>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) v[g] = ldv(W[3 + g]);
+                pc += 3 + N;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) bad(v[g] != k[j0 + g], j0 + g, 0);  // instance j is bound to constant j
+            });
+        } break;
+        case ZK_GATE_BOOLEAN: {
+            dispatch_count<8>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) v[g] = ldv(W[3 + g]);
+                pc += 3 + N;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) bad(v[g] > 1, j0 + g, 0);  // v^2 == v over a field: v in {0, 1}
+            });
+        } break;
+        case ZK_GATE_FMA: {
+            dispatch_count<3>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N][4];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) v[g][i] = ldv(W[3 + g * 4 + i]);
+                pc += 3 + N * 4;
+                const uint64_t q = k[0], l = k[1];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+                    const uint64_t ab = gl::mul(v[g][0], v[g][1]);
+                    bad(gl::add(q == 1 ? ab : gl::mul(q, ab), l == 1 ? v[g][2] : gl::mul(l, v[g][2])) != v[g][3], j0 + g, 0);
+                }
+            });
+        } break;
+        case ZK_GATE_REDUCTION4: {
+            dispatch_count<2>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N][5];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+#pragma unroll
+                    for (uint32_t i = 0; i < 5; ++i) v[g][i] = ldv(W[3 + g * 5 + i]);
+                pc += 3 + N * 5;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+                    uint64_t r = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r = gl::fma(k[i], v[g][i], r);
+                    bad(r != v[g][4], j0 + g, 0);
+                }
+            });
+        } break;
+        case ZK_GATE_SELECT: {
+            dispatch_count<3>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N][4];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) v[g][i] = ldv(W[3 + g * 4 + i]);
+                pc += 3 + N * 4;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)  // a, b, s, r : s * (a - b) + b == r
+                    bad(gl::add(gl::mul(v[g][2], gl::sub(v[g][0], v[g][1])), v[g][1]) != v[g][3], j0 + g, 0);
+            });
+        } break;
+        case ZK_GATE_ZEROCHECK: {
+            dispatch_count<4>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N][3];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+#pragma unroll
+                    for (uint32_t i = 0; i < 3; ++i) v[g][i] = ldv(W[3 + g * 3 + i]);
+                pc += 3 + N * 3;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+                    bad(gl::mul(v[g][0], v[g][1]) != gl::sub(1, v[g][2]), j0 + g, 0);
+                    bad(gl::mul(v[g][0], v[g][2]) != 0, j0 + g, 1);
+                }
+            });
+        } break;
+        case ZK_GATE_UINTX_ADD: {
+            dispatch_count<2>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N][5];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+#pragma unroll
+                    for (uint32_t i = 0; i < 5; ++i) v[g][i] = ldv(W[3 + g * 5 + i]);
+                pc += 3 + N * 5;
+                const uint64_t shift = k[0];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+                    bad(gl::add(gl::add(v[g][0], v[g][1]), v[g][2]) != gl::add(v[g][3], gl::mul(shift, v[g][4])), j0 + g, 0);
+            });
+        } break;
+        case ZK_GATE_DOT4: {
+            uint64_t v[9];
+#pragma unroll
+            for (uint32_t i = 0; i < 9; ++i) v[i] = ldv(W[3 + i]);
+            pc += 12;
+            uint64_t r = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r = gl::fma(v[2 * i], v[2 * i + 1], r);
+            bad(r != v[8], j0, 0);
+        } break;
+        case ZK_GATE_MATMUL12_EXT:
+        case ZK_GATE_MATMUL12_INT: {
+            const u32x16_a4 W2 = *(prog16_ptr)(prog + pc + 16);
+            uint64_t s[12], o[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s[i] = ldv(W[3 + i]);
+            o[0] = ldv(W[15]);
+#pragma unroll
+            for (int i = 1; i < 12; ++i) o[i] = ldv(W2[i - 1]);
+            pc += 27;
+            if (kind == ZK_GATE_MATMUL12_EXT) p2::mds_external(s); else p2::mds_inner(s);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) bad(s[i] != o[i], j0, i);
+        } break;
+        case ZK_GATE_U32_FMA: {
+            dispatch_count<2>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N][6];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+#pragma unroll
+                    for (uint32_t i = 0; i < 6; ++i) v[g][i] = ldv(W[3 + g * 6 + i]);
+                pc += 3 + N * 6;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+                    bad(gl::add(gl::add(gl::mul(v[g][0], v[g][1]), v[g][2]), v[g][3]) != gl::add(v[g][4], gl::mul(v[g][5], 1ull << 32)), j0 + g, 0);
+            });
+        } break;
+        case ZK_GATE_REDUCTION_BY_POWERS4: {
+            dispatch_count<2>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t v[N][5];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+#pragma unroll
+                    for (uint32_t i = 0; i < 5; ++i) v[g][i] = ldv(W[3 + g * 5 + i]);
+                pc += 3 + N * 5;
+                const uint64_t c = k[0];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {  // Horner in the row constant c
+                    uint64_t r = gl::fma(v[g][3], c, v[g][2]);
+                    r = gl::fma(r, c, v[g][1]);
+                    r = gl::fma(r, c, v[g][0]);
+                    bad(r != v[g][4], j0 + g, 0);
+                }
+            });
+        } break;
+        case ZK_CHECK_LOOKUP: {  // w2 = table id; cnt tuples of n_keys + n_vals (<= 4) slots each, (keys.., values..) must be a table row
+            const zk_table_desc t = cd.tables[W[2]];
+            const uint32_t nk = t.n_keys, nv = t.n_vals, tw = nk + nv;
+            const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(cd.table_words + (t.dense >> 2));
+            dispatch_count<3>(cnt, [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t x[N][4];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g)
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) x[g][i] = i < tw ? ldv(W[3 + g * 4 + i]) : 0;
+                pc += 3 + N * 4;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+                    const uint32_t row = table_find3(t, cd.table_words, x[g][0], nk > 1 ? x[g][1] : 0, nk > 2 ? x[g][2] : 0);
+                    bool ok = row < t.n_rows;
+#pragma unroll
+                    for (uint32_t i = 0; i < 3; ++i)
+                        if (ok && i < nv) {
+                            const uint64_t have = nk == 1 ? x[g][(1 + i) & 3] : nk == 2 ? x[g][(2 + i) & 3] : x[g][3];
+                            const uint64_t want = (t.dense & 2u) ? (uint64_t)tb[(size_t)row * nv + i]
+                                                                 : cd.table_words[(size_t)t.word_off + (size_t)row * tw + nk + i];
+                            ok = have == want;
+                        }
+                    bad(!ok, 0x80 | (j0 + g), 15);
+                }
+            });
+        } break;
+        default:
+            return;  // malformed program: built by the host
+        }
+    }
+}
+
 }  // namespace zke

@@ -151,6 +151,17 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
     d.cells = a.cells; d.n_cells = a.n_cells; d.n_cols = a.n_cols; d.n_lanes = a.n_lanes; d.n_slots = a.n_slots; d.rows = a.rows;
     d.rowconsts = a.rowconsts; d.lrows = a.lrows; d.n_copy_cols = a.n_copy_cols; d.lookup_width = a.lookup_width;
     d.tables = a.tables; d.table_words = a.table_words; d.fail = a.fail; d.slots_per_chunk = a.slots_per_chunk; d.alias = a.alias;
+    if (a.alias && a.cprog && a.n_chunks && a.n_cells < (1ull << 23)) {
+        zke::CheckProgDev p;
+        p.cells = a.cells; p.n_cells = a.n_cells; p.n_lanes = a.n_lanes; p.prog = a.cprog; p.chunk_tab = a.chunk_tab; p.n_chunks = a.n_chunks;
+        p.rowconsts = a.rowconsts; p.tables = a.tables; p.table_words = a.table_words; p.fail = a.fail;
+        const unsigned lane_tiles = grid_for(a.n_lanes, zke::TPB);
+        const uint32_t wanted = std::max<uint32_t>(2, (2048 + lane_tiles - 1) / lane_tiles);  // >= ~2048 workgroups
+        p.chunks_per_block = std::max<uint32_t>(1, a.n_chunks / wanted);
+        dim3 grid(lane_tiles, (a.n_chunks + p.chunks_per_block - 1) / p.chunks_per_block);
+        zke::k_check_prog<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(p);
+        return LAUNCH_CHECK("k_check_prog");
+    }
     dim3 grid(grid_for(a.n_lanes, zke::TPB), (a.n_slots + a.slots_per_chunk - 1) / a.slots_per_chunk);
     if (a.alias) zke::k_check_gates_compact<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
     else zke::k_check_gates<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
