@@ -969,6 +969,12 @@ void CS::emit_scope(Scope& s) {
                 const bool counted = group_cap(first, v2) > 1 || first.opcode == ZK_OP_INPUT || first.opcode == ZK_OP_SELECT || first.opcode == ZK_OP_FMA ||
                                      first.opcode == ZK_OP_LC4 || (v2 && first.opcode == ZK_OP_U32MULADD);
                 out.push_back((uint32_t)first.opcode | ((uint32_t)first.a << 8) | ((counted ? (uint32_t)(n - 1) : (uint32_t)first.b) << 16));
+                if (v2 && first.opcode == ZK_OP_NN_MULMOD) {
+                    // fixed layout: 16 modulus limbs, 17 A slots, 17 B slots (unused ones 0): static word positions for the kernel's scalar fetches
+                    for (size_t q = 0; q < 16; ++q) operand(first, q);
+                    for (size_t q = 0; q < 17; ++q) { if (q < first.a) operand(first, 16 + q); else out.push_back(0); }
+                    for (size_t q = 0; q < 17; ++q) { if (q < first.b) operand(first, 16 + first.a + q); else out.push_back(0); }
+                } else
                 for (size_t oi : group)
                     for (size_t q = 0; q < s.ops[oi].ins.size(); ++q) operand(s.ops[oi], q);
             }

@@ -98,10 +98,13 @@ __device__ __forceinline__ uint32_t table_find(const zk_table_desc& t, const uin
 
 // One multiplicity increment per lane with `pred`.  Lanes of a wavefront are consecutive cycles of one instance and very often
 // look up the SAME row (a zero limb, a cleared flag): 64 same-address atomics serialise at the memory side — on main_vm they
-// were 26 of the loop kernel's 37 ms.  The wave aggregates first: one atomic per distinct row with the number of lanes on it.
+// were 26 of the loop kernel's 37 ms.  The wave aggregates first: one atomic per distinct row with the number of lanes on it,
+// for the first three distinct rows it meets; whatever is left (hash circuits: 64 lanes, 64 different
+// table rows) goes out as plain per-lane atomics, which do not collide.
 __device__ __forceinline__ void mult_add(uint32_t* mult, size_t index, bool pred) {
     uint64_t todo = __builtin_amdgcn_ballot_w64(pred);
-    while (todo) {
+#pragma unroll 1
+    for (int round = 0; round < 3 && todo; ++round) {
         const int leader = __builtin_ctzll(todo);
         const size_t li = ((size_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(index >> 32), leader) << 32) |
                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)index, leader);
@@ -109,6 +112,7 @@ __device__ __forceinline__ void mult_add(uint32_t* mult, size_t index, bool pred
         if ((int)(threadIdx.x & 63) == leader) atomicAdd(mult + li, (uint32_t)__builtin_popcountll(same));
         todo &= ~same;
     }
+    if (todo & (1ull << (threadIdx.x & 63))) atomicAdd(mult + index, 1u);
 }
 
 // ------------------------------------------------------------------------------------------

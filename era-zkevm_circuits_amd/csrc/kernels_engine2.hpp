@@ -19,6 +19,7 @@
 // Same values, same slots as the strand / wide / sequential kernels that still run the v1 form.
 #pragma once
 #include "kernels_engine.hpp"
+#include <utility>
 
 namespace zke {
 
@@ -380,11 +381,28 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }
         } break;
         case ZK_OP_NN_MULMOD: if constexpr (WITH_BIGINT) {
+            // fixed layout (cs.cpp emit_scope): 16 modulus limbs (pool indices), 17 A slots, 17 B slots (unused ones 0) = 51 words,
+            // four scalar fetches with static word positions
+            const u32x16_a4 W1 = *(prog16_ptr)(prog + pc + 16), W2 = *(prog16_ptr)(prog + pc + 32), W3 = *(prog16_ptr)(prog + pc + 48);
+            auto word = [&](auto k_) -> uint32_t {
+                constexpr uint32_t K = decltype(k_)::value;
+                if constexpr (K < 16) return W[K];
+                else if constexpr (K < 32) return W1[K - 16];
+                else if constexpr (K < 48) return W2[K - 32];
+                else return W3[K - 48];
+            };
             uint32_t mv[16], av[17], bv[17], res[19 + 16];
-            for (uint32_t i = 0; i < 16; ++i) mv[i] = (uint32_t)cpool[prog[pc + 1 + i]];  // modulus limbs: pool indices
-            for (uint32_t i = 0; i < pa; ++i) av[i] = (uint32_t)ldv(prog[pc + 17 + i]);
-            for (uint32_t i = 0; i < pb; ++i) bv[i] = (uint32_t)ldv(prog[pc + 17 + pa + i]);
-            pc += 17 + pa + pb;
+            uint64_t mraw[16], araw[17], braw[17];
+            [&]<uint32_t... I>(std::integer_sequence<uint32_t, I...>) {
+                ((mraw[I] = cpool[word(GroupSize<1 + I>{})]), ...);
+            }(std::make_integer_sequence<uint32_t, 16>{});
+            [&]<uint32_t... I>(std::integer_sequence<uint32_t, I...>) {
+                ((araw[I] = I < pa ? ldv(word(GroupSize<17 + I>{})) : 0), ...);
+                ((braw[I] = I < pb ? ldv(word(GroupSize<34 + I>{})) : 0), ...);
+            }(std::make_integer_sequence<uint32_t, 17>{});
+            for (int i = 0; i < 16; ++i) mv[i] = (uint32_t)mraw[i];
+            for (int i = 0; i < 17; ++i) { av[i] = (uint32_t)araw[i]; bv[i] = (uint32_t)braw[i]; }
+            pc += 51;
             const uint32_t nq = pa + pb - 15;
             nn_mulmod(av, pa, bv, pb, mv, nq, res);
             for (uint32_t i = 0; i < nq + 16; ++i) st(res[i]);
@@ -559,7 +577,10 @@ __device__ __forceinline__ uint32_t table_find3(const zk_table_desc& t, const ui
     return t.n_rows;
 }
 
-__global__ __launch_bounds__(TPB) void k_check_prog(CheckProgDev cd) {
+#ifndef ZKGL_CHECK_WAVES
+#define ZKGL_CHECK_WAVES 4
+#endif
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_WAVES, 8))) void k_check_prog(CheckProgDev cd) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= cd.n_lanes) return;
