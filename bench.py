@@ -162,7 +162,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=96, help="independent circuit instances per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="independent circuit instances per GPU per step")
+    ap.add_argument("--seed-windows", type=int, default=8, help="batches of raw witness seeded in one zk_cs_seed_stream pass (the stream = batch x windows instances)")
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--workload", default="main_vm", choices=["main_vm", "vm_shaped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -190,35 +191,55 @@ def main():
     coll_dev = torch.device("cpu") if shared_gpu else dev
 
     B = args.batch
+    K = max(1, args.seed_windows)     # the raw witness stream holds K batches: seeded in ONE pass, resolved window by window
+    S = B * K
     expect = None
+    stream = torch.cuda.current_stream().cuda_stream
     if args.workload == "main_vm":
         cs, limit = build_main_vm_cs(zkgl, args.log2_rows)
         n_outer, n_loop = cs.input_words()
-        outer, loop, expect = main_vm_streams(cs, limit, B, first=rank * B)
+        # the stream is assembled on the device: instance i replays execution (rank * S + i) % n_exec of the fixture
+        outer8, loop8, expect8 = main_vm_streams(cs, limit, 8, first=0)
+        n_exec = 8
+        sel = (torch.arange(S, device=dev) + rank * S) % n_exec
+        d_outer = torch.from_numpy(outer8.view(np.int64)).to(dev)[:, sel].contiguous()
+        l8 = torch.from_numpy(loop8.view(np.int64)).to(dev).view(n_loop, n_exec, limit)
+        d_loop = l8[:, sel, :].reshape(n_loop, S * limit).contiguous()
+        del l8, loop8
+        expect = None if expect8 is None else expect8[((np.arange(S) + rank * S) % n_exec)]
         state_words = VM_STATE_WORDS
     else:
         cs, limit = build_vm_shaped_cs(zkgl, args.log2_rows)
         n_outer, n_loop = cs.input_words()
-        outer, loop = vm_shaped_inputs(np.random.default_rng(0xC2 + rank), n_outer, n_loop, B, limit)
+        outer, loop = vm_shaped_inputs(np.random.default_rng(0xC2 + rank), n_outer, n_loop, S, limit)
+        d_outer = torch.from_numpy(outer.view(np.int64)).to(dev)
+        d_loop = torch.from_numpy(loop.view(np.int64)).to(dev)
+        del loop
         state_words = 183
     st = cs.stats()
     cs.set_batch(B)
-    d_outer = torch.from_numpy(outer.view(np.int64)).to(dev)
-    d_loop = torch.from_numpy(loop.view(np.int64)).to(dev)
-    del loop
-    cs.bind_inputs(False, d_outer, n_outer)
-    cs.bind_inputs(True, d_loop, n_loop)
-    stream = torch.cuda.current_stream().cuda_stream
     seed_s = []
     for _ in range(2):  # the second pass overwrites the carried words with the same values: a clean timing of the seeding alone
         torch.cuda.synchronize()
         t = time.perf_counter()
-        cs.seed_carried_inputs(d_loop, stream)
+        cs.seed_stream(S, d_outer, d_loop, stream)   # zk_cs_seed_stream: the sequential part, all K windows at once
         torch.cuda.synchronize()
         seed_s.append(time.perf_counter() - t)
     t_seed = min(seed_s)
+    window = [0]
+
+    def bind(k):
+        cs.bind_inputs(False, d_outer, n_outer, lane_stride=S, lane_offset=k * B)
+        cs.bind_inputs(True, d_loop, n_loop, lane_stride=S * limit, lane_offset=k * B * limit)
+        window[0] = k
+
+    bind(0)
+
+    step_no = [0]
 
     def step():
+        bind(step_no[0] % K)   # every step takes the next window of the seeded stream
+        step_no[0] += 1
         ok, failure = cs.resolve_and_check(stream)  # witness generation + full satisfiability check, one pipeline
         if not ok and not os.environ.get("ZKGL_STUB_RUN"):  # ZKGL_STUB_RUN: tools/stub_bench.sh times deliberately wrong kernel variants
             raise RuntimeError(f"trace not satisfied: {failure}")
@@ -249,7 +270,7 @@ def main():
     local = np.array([cs.public_inputs(i) for i in range(B)], dtype=np.uint64)
     parity = None
     if expect is not None:
-        parity = bool(np.array_equal(local, expect))
+        parity = bool(np.array_equal(local, expect[window[0] * B:(window[0] + 1) * B]))
         if not parity and not os.environ.get("ZKGL_STUB_RUN"):
             raise RuntimeError("public inputs differ from the native restatement's commitments stored in the fixture")
     commits = gather_commitments(local, coll_dev)   # [world, B, 4] u64: RCCL all_gather over xGMI when world > 1
@@ -276,13 +297,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * step_s,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks)", "data": "synthetic",
             "witness_rows_per_s": rows / elapsed,
-            "value_from_raw_witness": st["constraints_per_instance"] * n_inst / (seed_all + step_s),
+            # the whole path from the raw witness: one seeding pass over the K-window stream + K steps
+            "value_from_raw_witness": st["constraints_per_instance"] * n_inst * K / (seed_all + K * step_s),
             "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/vm_bench_witness.npz)"
                                     if args.workload == "main_vm" else "main_vm-shaped micro-workload (round 1)") +
                                    f", geometry 140/0/8/deg8 + 3x8 lookups, 2^{args.log2_rows} rows/instance",
                        "instances_per_gpu": B, "cycles_per_instance": limit, "rows_per_instance": st["rows_per_instance"],
                        "constraints_per_instance": st["constraints_per_instance"], "parallelism": f"independent instances x{world}",
-                       "input_seeding_s": round(seed_all, 4), "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
+                       "input_seeding_s": round(seed_all, 4), "seeded_stream_instances_per_gpu": S, "seeding_s_per_batch": round(seed_all / K, 4), "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
                        "commitments_equal_native_restatement": parity},
             "roofline": {"bound": "hbm", "kernel": "zke::k_witness_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,

@@ -303,6 +303,14 @@ int zk_cs_bind_inputs(zk_cs* cs, int loop_scope, const uint64_t* dev_words, uint
     NEED(cs);
     return guard([&] { cs->cs->bind_inputs(loop_scope != 0, dev_words, n_words); });
 }
+int zk_cs_bind_inputs_window(zk_cs* cs, int loop_scope, const uint64_t* dev_words, uint32_t n_words, uint64_t lane_stride) {
+    NEED(cs);
+    return guard([&] { cs->cs->bind_inputs(loop_scope != 0, dev_words, n_words, lane_stride); });
+}
+int zk_cs_seed_stream(zk_cs* cs, uint32_t n_instances, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream) {
+    NEED(cs); NEED_INIT();
+    return guard([&] { cs->cs->seed_stream(n_instances, dev_outer_inputs, dev_loop_inputs_rw, stream); });
+}
 int zk_cs_resolve(zk_cs* cs, void* stream) {
     NEED(cs); NEED_INIT();
     return guard([&] { cs->cs->resolve(stream); });

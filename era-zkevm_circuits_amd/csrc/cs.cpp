@@ -1074,6 +1074,16 @@ void CS::build_seed_program() {
         for (auto& in : op.ins)
             if (in.kind == Operand::VAR) need[in.idx] = 1;
     }
+    seed_v2_ok_ = true;  // every op of the cone has a handler in the scalar-decoded seed kernel (kernels_engine2.hpp run_seed2)
+    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+        if (!keep[oi]) continue;
+        switch (s.ops[oi].opcode) {
+        case ZK_OP_CONST: case ZK_OP_INPUT: case ZK_OP_FMA: case ZK_OP_LC4: case ZK_OP_SELECT: case ZK_OP_ISZERO: case ZK_OP_UADD: case ZK_OP_USUB:
+        case ZK_OP_DOT4: case ZK_OP_MATMUL12: case ZK_OP_SPLIT: case ZK_OP_LOOKUP: case ZK_OP_POSEIDON2: case ZK_OP_P2_ROUNDS: case ZK_OP_U32MULADD:
+        case ZK_OP_DIVREM: case ZK_OP_U256_MULWIDE: case ZK_OP_U256_DIVREM: break;
+        default: seed_v2_ok_ = false;
+        }
+    }
     const int64_t INF = INT64_MAX;
     std::vector<int64_t> last_use(s.n_vars, -1);
     for (size_t oi = 0; oi < s.ops.size(); ++oi)
@@ -1255,7 +1265,14 @@ void CS::build_seed_program() {
     seed_sslots_ = ns;
     seed_sgain_ = critical ? (float)total / (float)critical : 0.f;
     if (getenv("ZKGL_STRANDS_DEBUG"))
+    {
         fprintf(stderr, "[zkgl] seed cone: %u ops, %u levels, %u slots (plain %u), estimated gain %.2f\n", seed_ops_, n_levels, ns, n_slots, seed_sgain_);
+        std::map<uint32_t, uint32_t> hist;
+        for (size_t oi = 0; oi < s.ops.size(); ++oi) if (keep[oi]) hist[s.ops[oi].opcode]++;
+        for (auto& kv : hist) fprintf(stderr, "   cone op %2u: %u\n", kv.first, kv.second);
+        uint32_t widest = 0; for (auto& l : by_level) widest = std::max<uint32_t>(widest, (uint32_t)l.size());
+        fprintf(stderr, "   widest level %u ops\n", widest);
+    }
 }
 
 void CS::upload_scope(Scope& s) {
@@ -1455,14 +1472,17 @@ void CS::set_batch(uint32_t n) {
     compact_ = true;
     outer_.d_inputs = nullptr; loop_.d_inputs = nullptr;
     outer_.bound_input_words = loop_.bound_input_words = 0;
+    outer_.input_stride = loop_.input_stride = 0;
 }
 
-void CS::bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words) {
+void CS::bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words, uint64_t lane_stride) {
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "bind_inputs before set_batch");
     Scope& s = loop_scope ? loop_ : outer_;
     if (n_words < s.n_input_words) throw ZkError(ZK_ERR_INVALID, "bind_inputs: fewer words than the circuit reads");
+    if (lane_stride && lane_stride < s.n_lanes) throw ZkError(ZK_ERR_INVALID, "bind_inputs: lane stride shorter than the batch");
     s.d_inputs = dev_words;
     s.bound_input_words = n_words;
+    s.input_stride = lane_stride;
 }
 
 static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Scope& loop, uint32_t limit,
@@ -1470,12 +1490,31 @@ static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Sco
     zkdev::ScopeArgs a;
     a.prog = s.d_prog; a.n_words = (uint32_t)s.prog.size(); a.n_lanes = s.n_lanes; a.consts = s.d_consts;
     a.cells = s.d_store; a.n_cells = s.n_store; a.inputs = s.d_inputs;  // the witness kernels work on the variable store
+    a.in_stride = s.input_stride ? s.input_stride : s.n_lanes;
     a.outer_cells = outer.d_store; a.outer_n_cells = outer.n_store;
     a.limit = s.is_loop ? limit : 1; a.is_loop = s.is_loop ? 1 : 0;
     a.tables = tables; a.table_words = words; a.mult = mult; a.total_table_rows = total_rows;
     a.loop_cells = loop.d_store; a.loop_n_cells = loop.n_store; a.loop_limit = limit;
     a.uses_bigint = s.uses_bigint ? 1 : 0;
     return a;
+}
+
+// the cone seeding launch over `n` instances: la = loop-scope arguments whose outer_cells hold the pre phase of those instances
+void CS::launch_seed(const zkdev::ScopeArgs& la, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const char* force_generic = std::getenv("ZKGL_SEED_GENERIC");
+    const char* seed_strands = std::getenv("ZKGL_SEED_STRANDS");  // 0: plain cone, 1: strand form whenever it exists
+    const bool generic = force_generic && force_generic[0] == '1';
+    const bool use_strands = d_seed_sprog_ && !(seed_strands && seed_strands[0] == '0') && ((seed_strands && seed_strands[0] == '1') || seed_sgain_ >= 1.5f);
+    if (use_strands && !generic)
+        dev_check(zkdev::launch_seed_cone_strands(la, d_seed_sprog_, seed_sbegin_, seed_send_, seed_sslots_, loop_.n_input_words,
+                                                  (const zkdev::CarryArgs*)d_seed_scarries_, (uint32_t)seed_scarries_.size(), dev_loop_inputs_rw, n, seed_v2_ok_ && !(getenv("ZKGL_SEED_V1")), st));
+    else if (d_seed_prog_ && !generic)
+        dev_check(zkdev::launch_seed_cone(la, d_seed_prog_, (uint32_t)seed_prog_.size(), seed_slots_, loop_.n_input_words, (const zkdev::CarryArgs*)d_seed_carries_,
+                                          (uint32_t)seed_carries_.size(), dev_loop_inputs_rw, n, st));
+    else
+        dev_check(zkdev::launch_witness_seq(la, (const zkdev::CarryArgs*)d_carries_, (uint32_t)carries_store_.size(), dev_loop_inputs_rw,
+                                            n, st));
 }
 
 void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {
@@ -1489,20 +1528,41 @@ void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {
     auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
     launch_phase(outer_, oa, 0, st);
-    const char* force_generic = std::getenv("ZKGL_SEED_GENERIC");
-    const char* seed_strands = std::getenv("ZKGL_SEED_STRANDS");  // 0: plain cone, 1: strand form whenever it exists
-    const bool generic = force_generic && force_generic[0] == '1';
-    const bool use_strands = d_seed_sprog_ && !(seed_strands && seed_strands[0] == '0') && ((seed_strands && seed_strands[0] == '1') || seed_sgain_ >= 1.5f);
-    if (use_strands && !generic)
-        dev_check(zkdev::launch_seed_cone_strands(la, d_seed_sprog_, seed_sbegin_, seed_send_, seed_sslots_, loop_.n_input_words,
-                                                  (const zkdev::CarryArgs*)d_seed_scarries_, (uint32_t)seed_scarries_.size(), dev_loop_inputs_rw, batch_, st));
-    else if (d_seed_prog_ && !generic)
-        dev_check(zkdev::launch_seed_cone(la, d_seed_prog_, (uint32_t)seed_prog_.size(), seed_slots_, loop_.n_input_words, (const zkdev::CarryArgs*)d_seed_carries_,
-                                          (uint32_t)seed_carries_.size(), dev_loop_inputs_rw, batch_, st));
-    else
-        dev_check(zkdev::launch_witness_seq(la, (const zkdev::CarryArgs*)d_carries_, (uint32_t)carries_store_.size(), dev_loop_inputs_rw,
-                                            batch_, st));
+    launch_seed(la, dev_loop_inputs_rw, batch_, st);
     hip_check(hipStreamSynchronize(st), "seed sync");
+}
+
+// Seeds a STREAM of n instances (any n, independent of set_batch): the outer pre phase runs on a temporary outer store of n
+// lanes, then the cone.  The chain of `limit` iterations is a latency bound per instance and the kernel keeps one small block
+// per few instances, so a pass over ~1000 instances costs what a pass over 8 does; a host seeds a long stream once and then
+// resolves it in windows (bind_inputs with lane_stride = the stream length).  Layouts: outer [word][n], loop [word][n * limit].
+void CS::seed_stream(uint32_t n, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream) {
+    if (!finalized_) throw ZkError(ZK_ERR_INVALID, "seed_stream before finalize");
+    if (!limit_ || n == 0) return;
+    ensure_uploaded();
+    if (outer_.n_input_words && !dev_outer_inputs) throw ZkError(ZK_ERR_INVALID, "seed_stream: outer input stream missing");
+    if (!dev_loop_inputs_rw) throw ZkError(ZK_ERR_INVALID, "seed_stream: loop input stream missing");
+    if ((uint64_t)n * limit_ >= 0xffffffffull) throw ZkError(ZK_ERR_CAPACITY, "n*limit exceeds 32-bit lane index");
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t tiles = ((uint64_t)n + 63) / 64;
+    uint64_t* tmp_outer = nullptr;
+    hip_check(hipMalloc((void**)&tmp_outer, std::max<size_t>((size_t)outer_.n_store * tiles * 64 * 8, 8)), "hipMalloc seed outer store");
+    Scope o = outer_, l = loop_;  // shallow views with the stream's lane counts (device pointers are shared, nothing is freed through them)
+    o.d_store = tmp_outer; o.n_lanes = n; o.d_inputs = dev_outer_inputs; o.input_stride = 0;
+    l.d_store = nullptr; l.n_lanes = (uint32_t)((uint64_t)n * limit_); l.d_inputs = dev_loop_inputs_rw; l.input_stride = 0;
+    try {
+        auto oa = scope_args(o, o, l, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
+        auto la = scope_args(l, o, l, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
+        launch_phase(o, oa, 0, st);
+        launch_seed(la, dev_loop_inputs_rw, n, st);
+        hip_check(hipStreamSynchronize(st), "seed sync");
+    } catch (...) {
+        o.d_store = nullptr; l.d_store = nullptr;
+        hipFree(tmp_outer);
+        throw;
+    }
+    o.d_store = nullptr; l.d_store = nullptr;
+    hipFree(tmp_outer);
 }
 
 void CS::resolve(void* stream) {

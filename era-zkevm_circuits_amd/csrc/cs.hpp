@@ -132,6 +132,7 @@ struct Scope {
     uint64_t stride = 0;
     uint32_t n_lanes = 0;
     const uint64_t* d_inputs = nullptr;
+    uint64_t input_stride = 0;     // lanes between consecutive stream words (0: n_lanes)
     uint32_t bound_input_words = 0;
 };
 
@@ -171,10 +172,12 @@ class CS {
 
     // execution
     void set_batch(uint32_t n_instances);
-    void bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words);
+    void bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words, uint64_t lane_stride = 0);
+    void seed_stream(uint32_t n_instances, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream);
     void resolve(void* stream);
     // sequential seeding of the carried input words (generic, slow): see kernels_engine.hpp k_witness_seq
     void seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream);
+    void launch_seed(const zkdev::ScopeArgs& la, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream);
     int check_satisfied(void* stream, zk_failure* first);
     int resolve_and_check(void* stream, zk_failure* first);
     uint64_t read_var(zk_var v, uint32_t instance, uint32_t iteration);
@@ -279,6 +282,7 @@ class CS {
     uint32_t* d_seed_prog_ = nullptr;
     void* d_seed_carries_ = nullptr;
     // strand form of the cone (8 wavefronts per block, level barriers; slots recycled per level)
+    bool seed_v2_ok_ = false;
     std::vector<uint32_t> seed_sprog_;
     std::vector<Carry> seed_scarries_;
     uint32_t seed_sslots_ = 0, seed_sbegin_[8] = {}, seed_send_[8] = {};

@@ -13,6 +13,7 @@ struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     const uint64_t* outer_cells; uint64_t outer_n_cells; uint32_t limit; uint32_t is_loop;
     const zk_table_desc* tables; const uint64_t* table_words; uint32_t* mult; uint32_t total_table_rows;
     const uint64_t* loop_cells; uint64_t loop_n_cells; uint32_t loop_limit;
+    uint64_t in_stride;    // lanes between consecutive words of the input stream (>= n_lanes: a batch may be a window of a longer stream)
     uint32_t uses_bigint;  // host only: the program contains ZK_OP_NN_MULMOD -> launch the *_bigint kernel variants
 };
 struct CheckArgs {  // mirrors zke::CheckDev
@@ -88,7 +89,7 @@ int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t*
 int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_words, uint32_t n_slots, uint32_t n_input_words,
                      const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream);
 int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, const uint32_t begin[8], const uint32_t end[8], uint32_t n_slots,
-                             uint32_t n_input_words, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream);
+                             uint32_t n_input_words, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, bool v2, void* stream);
 uint32_t seed_cone_max_slots();
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
                         const uint32_t* a_cells, uint32_t pa, const uint32_t* b_cells, uint32_t pb, uint32_t n_total,

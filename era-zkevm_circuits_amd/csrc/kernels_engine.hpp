@@ -37,7 +37,8 @@ struct ScopeDev {
     const uint64_t* consts;     // constant pool
     uint64_t* cells;            // [n_tiles][n_cells][64]
     uint64_t n_cells;
-    const uint64_t* inputs;     // [n_input_words][n_lanes]
+    const uint64_t* inputs;     // [n_input_words][in_stride >= n_lanes]: word w of lane l at inputs[w * in_stride + l]
+    uint64_t in_stride;
     // loop scope only
     const uint64_t* outer_cells;
     uint64_t outer_n_cells;
@@ -392,7 +393,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                     uint64_t v[8];
 #pragma unroll
                     for (uint32_t g = 0; g < 8; ++g)
-                        if (g < grp) v[g] = sc.inputs[(size_t)P.at(pc + g) * sc.n_lanes + lane];
+                        if (g < grp) v[g] = sc.inputs[(size_t)P.at(pc + g) * sc.in_stride + lane];
                     pc += grp;
 #pragma unroll
                     for (uint32_t g = 0; g < 8; ++g)
@@ -402,7 +403,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             }
             uint32_t w = P.at(pc++);
             if constexpr (SLOTS) st(in_area[w * slot_stride]);  // staged in LDS by the kernel prologue
-            else st(sc.inputs[(size_t)w * sc.n_lanes + lane]);
+            else st(sc.inputs[(size_t)w * sc.in_stride + lane]);
         } break;
         case ZK_OP_FMA: {
             if constexpr (!SLOTS) {
@@ -830,9 +831,9 @@ __global__ __launch_bounds__(64) void k_witness_seq(ScopeDev sc, const CarryDev*
             const CarryDev cd = carries[c];
             if (k == 0) {
                 if (cd.has_first)
-                    inputs_rw[(size_t)cd.word * sc.n_lanes + lane] = sc.outer_cells[cell_off(sc.outer_n_cells, cd.first_outer_cell, inst)];
+                    inputs_rw[(size_t)cd.word * sc.in_stride + lane] = sc.outer_cells[cell_off(sc.outer_n_cells, cd.first_outer_cell, inst)];
             } else {
-                inputs_rw[(size_t)cd.word * sc.n_lanes + lane] = sc.cells[cell_off(sc.n_cells, cd.out_cell, lane - 1)];
+                inputs_rw[(size_t)cd.word * sc.in_stride + lane] = sc.cells[cell_off(sc.n_cells, cd.out_cell, lane - 1)];
             }
         }
         __threadfence();
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(64) void k_seed_cone(ScopeDev sc, const uint32_t* _
         for (uint32_t idx = threadIdx.x; idx < n_input_words * lpb; idx += 64) {
             const uint32_t w = idx / lpb, ll = idx % lpb;
             const uint32_t li = min(blockIdx.x * lpb + ll, n_instances - 1);
-            in_store[w * lpb + li - blockIdx.x * lpb] = inputs_rw[(size_t)w * sc.n_lanes + (size_t)li * sc.limit + k];
+            in_store[w * lpb + li - blockIdx.x * lpb] = inputs_rw[(size_t)w * sc.in_stride + (size_t)li * sc.limit + k];
         }
         __syncthreads();
         for (uint32_t idx = threadIdx.x; idx < n_carries * lpb; idx += 64) {
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(64) void k_seed_cone(ScopeDev sc, const uint32_t* _
             if (k == 0 && !cd.has_first) continue;
             const uint64_t v = k == 0 ? sc.outer_cells[cell_off(sc.outer_n_cells, cd.first_outer_cell, li)] : slot_store[cd.out_slot * lpb + col];
             in_store[cd.word * lpb + col] = v;
-            inputs_rw[(size_t)cd.word * sc.n_lanes + (size_t)li * sc.limit + k] = v;
+            inputs_rw[(size_t)cd.word * sc.in_stride + (size_t)li * sc.limit + k] = v;
         }
         __syncthreads();
         run_lane<WITH_BIGINT, true>(sc, inst * sc.limit + k, inst, false, 0, n_words, seed_prog, slot_store + ml, lpb, in_store + ml);
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_seed_cone_strands(Sco
         for (uint32_t idx = threadIdx.x; idx < n_input_words * lpb; idx += NT) {
             const uint32_t wd = idx / lpb, ll = idx % lpb;
             const uint32_t li = min(blockIdx.x * lpb + ll, n_instances - 1);
-            in_store[wd * lpb + li - blockIdx.x * lpb] = inputs_rw[(size_t)wd * sc.n_lanes + (size_t)li * sc.limit + k];
+            in_store[wd * lpb + li - blockIdx.x * lpb] = inputs_rw[(size_t)wd * sc.in_stride + (size_t)li * sc.limit + k];
         }
         __syncthreads();
         for (uint32_t idx = threadIdx.x; idx < n_carries * lpb; idx += NT) {
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_seed_cone_strands(Sco
             if (k == 0 && !cd.has_first) continue;
             const uint64_t v = k == 0 ? sc.outer_cells[cell_off(sc.outer_n_cells, cd.first_outer_cell, li)] : slot_store[cd.out_slot * lpb + col];
             in_store[cd.word * lpb + col] = v;
-            inputs_rw[(size_t)cd.word * sc.n_lanes + (size_t)li * sc.limit + k] = v;
+            inputs_rw[(size_t)cd.word * sc.in_stride + (size_t)li * sc.limit + k] = v;
         }
         __syncthreads();
         run_lane<WITH_BIGINT, true, false, (int)NT, true>(sc, inst * sc.limit + k, inst, false, wb, we, seed_sprog, slot_store + ml, lpb, in_store + ml);

@@ -69,6 +69,28 @@ __device__ __forceinline__ uint32_t table_find2(const zk_table_desc& t, const ui
     return t.n_rows;
 }
 
+// table row of a key tuple of <= 3 keys without a key array (see table_find2)
+__device__ __forceinline__ uint32_t table_find3(const zk_table_desc& t, const uint64_t* __restrict__ words, uint64_t k0, uint64_t k1, uint64_t k2) {
+    if (t.n_keys <= 2) return table_find2(t, words, k0, k1);
+    if (t.dense) {
+        const uint32_t top = 31 - __clz(t.n_rows);
+        const bool ok = (k0 >> (top - t.key_shift[0])) == 0 && (k1 >> (t.key_shift[0] - t.key_shift[1])) == 0 && (k2 >> (t.key_shift[1] - t.key_shift[2])) == 0;
+        const uint64_t idx = (k0 << t.key_shift[0]) + (k1 << t.key_shift[1]) + (k2 << t.key_shift[2]);
+        return ok ? (uint32_t)idx : t.n_rows;
+    }
+    const uint32_t w = t.n_keys + t.n_vals;
+    const uint64_t* rows = words + (size_t)t.word_off;
+    uint32_t lo = 0, hi = t.n_rows;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t r0 = rows[(size_t)mid * w], r1 = rows[(size_t)mid * w + 1], r2 = rows[(size_t)mid * w + 2];
+        const int cmp = r0 != k0 ? (r0 < k0 ? -1 : 1) : r1 != k1 ? (r1 < k1 ? -1 : 1) : r2 != k2 ? (r2 < k2 ? -1 : 1) : 0;
+        if (cmp == 0) return mid;
+        if (cmp < 0) lo = mid + 1; else hi = mid;
+    }
+    return t.n_rows;
+}
+
 template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB>
 __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                           uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
@@ -129,7 +151,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 constexpr uint32_t N = decltype(n_)::value;
                 uint64_t v[N];
 #pragma unroll
-                for (uint32_t g = 0; g < N; ++g) v[g] = sc.inputs[(size_t)W[1 + g] * sc.n_lanes + lane];
+                for (uint32_t g = 0; g < N; ++g) v[g] = sc.inputs[(size_t)W[1 + g] * sc.in_stride + lane];
                 pc += 1 + N;
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) st(v[g]);
@@ -531,6 +553,331 @@ __global__ __launch_bounds__(TPB) void k_witness_outer_bigint(ScopeDev sc, uint3
 
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Cone seeding, scalar-decoded (k_seed_cone_strands2).  Same strand program words as kernels_engine.hpp k_seed_cone_strands
+// (header, operands, destination slots; values in an LDS slot store), but fetched by the scalar unit — the seeding loop is a
+// latency chain of limit x levels steps for ONE wavefront per strand, so what counts is the number of dependent instructions
+// per op: 2 384 cycles x 136 levels of main_vm took 2.77 s through the readlane-window interpreter, 0.49 s of it Poseidon2.
+// Ops without a handler here (hash macro-ops, NN_MULMOD) keep the v1 kernel (cs.cpp seed_v2_ok_).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int BLOCK>
+__device__ __forceinline__ void run_seed2(const ScopeDev& sc, const uint32_t inst, uint32_t word_begin, uint32_t word_end, const uint32_t* seed_prog,
+                                          uint64_t* slots, const uint32_t stride, const uint64_t* in_area, uint64_t* prof = nullptr) {
+    const prog1_ptr prog = (prog1_ptr)(uintptr_t)seed_prog;
+    const cpool_ptr cpool = (cpool_ptr)(uintptr_t)sc.consts;
+    auto ldv = [&](uint32_t slot) -> uint64_t { return slots[slot * stride]; };
+    auto stv = [&](uint32_t slot, uint64_t v) { slots[slot * stride] = v; };
+    // The op stream is a dependent chain for this one wavefront, so the NEXT op's words are fetched before the current op runs:
+    // its length follows from the header alone (fixed per opcode, SPLIT / LOOKUP add their counts).  Lengths, 6 bits per opcode:
+    constexpr uint64_t LEN_A = 0ull | (3ull << 6) | (3ull << 12) | (7ull << 18) | (10ull << 24) | (5ull << 30) | (4ull << 36) | (6ull << 42) | (6ull << 48) | (10ull << 54);  // ops 0..9
+    constexpr uint64_t LEN_B = 25ull | (2ull << 6) | (2ull << 12) | (25ull << 18) | (25ull << 24) | (0ull << 30) | (7ull << 36) | (0ull << 42) | (4ull << 48) | (0ull << 54);  // ops 10..19
+    constexpr uint64_t LEN_C = 0ull | (0ull << 6) | (1ull << 12) | (33ull << 18) | (33ull << 24);  // ops 20..24
+    uint32_t pc = word_begin;
+    u32x16_a4 Wn = *(prog16_ptr)(prog + pc);
+    while (pc < word_end) {
+        const u32x16_a4 W = Wn;
+        const uint32_t h = W[0];
+        const uint32_t op = h & 0xff, pa = (h >> 8) & 0xff, pb = h >> 16;
+        {
+            const uint64_t tab = op < 10 ? LEN_A : op < 20 ? LEN_B : LEN_C;
+            const uint32_t sub = op < 10 ? op : op < 20 ? op - 10 : op - 20;
+            uint32_t len = (uint32_t)(tab >> (6 * sub)) & 63u;
+            if (op == ZK_OP_SPLIT) len += pa;
+            if (op == ZK_OP_LOOKUP) len += pa + (pb & 0xff);
+            Wn = *(prog16_ptr)(prog + pc + len);
+        }
+#ifdef ZKGL_SEED_PROFILE
+        const uint64_t t_op0 = __builtin_readcyclecounter();
+        const uint32_t prof_op = op;
+#endif
+        switch (op) {
+        case ZK_OP_BARRIER:
+            pc += 1;
+            __syncthreads();  // LDS only: no store drain needed beyond the barrier's own lgkmcnt wait
+            break;
+        case ZK_OP_CONST: {
+            const uint32_t w = W[1];
+            stv(W[2], (w & ZK_OPERAND_KIND_MASK) == ZK_OPERAND_OUTER ? sc.outer_cells[cell_off(sc.outer_n_cells, w & ZK_OPERAND_IDX_MASK, inst)]
+                                                                      : (uint64_t)cpool[w & ZK_OPERAND_IDX_MASK]);
+            pc += 3;
+        } break;
+        case ZK_OP_INPUT:
+            stv(W[2], in_area[W[1] * stride]);  // staged in LDS by the kernel prologue
+            pc += 3;
+            break;
+        case ZK_OP_FMA: {
+            const uint64_t a = ldv(W[3]), b = ldv(W[4]), c = ldv(W[5]);
+            const uint64_t q = cpool[W[1] & ZK_OPERAND_IDX_MASK], l = cpool[W[2] & ZK_OPERAND_IDX_MASK];
+            const uint64_t ab = gl::mul(a, b);
+            stv(W[6], gl::add(q == 1 ? ab : gl::mul(q, ab), l == 1 ? c : gl::mul(l, c)));
+            pc += 7;
+        } break;
+        case ZK_OP_LC4: {
+            uint64_t t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = ldv(W[5 + i]);
+            uint64_t r = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r = gl::fma(cpool[W[1 + i] & ZK_OPERAND_IDX_MASK], t[i], r);
+            stv(W[9], r);
+            pc += 10;
+        } break;
+        case ZK_OP_SELECT: {
+            const uint64_t sl = ldv(W[1]), a = ldv(W[2]), b = ldv(W[3]);
+            stv(W[4], sl ? a : b);
+            pc += 5;
+        } break;
+        case ZK_OP_ISZERO: {
+            const uint64_t x = ldv(W[1]);
+            stv(W[2], x == 0 ? 1ull : 0ull);
+            stv(W[3], __builtin_amdgcn_ballot_w64(x > 1) == 0 ? x : gl::inv(x));
+            pc += 4;
+        } break;
+        case ZK_OP_UADD: {
+            const uint64_t sum = ldv(W[1]) + ldv(W[2]) + ldv(W[3]);
+            stv(W[4], sum & ((1ull << pa) - 1));
+            stv(W[5], sum >> pa);
+            pc += 6;
+        } break;
+        case ZK_OP_USUB: {
+            const uint64_t x = ldv(W[1]), sub = ldv(W[2]) + ldv(W[3]);
+            const uint64_t borrow = x < sub ? 1 : 0;
+            stv(W[4], (x + (borrow << pa)) - sub);
+            stv(W[5], borrow);
+            pc += 6;
+        } break;
+        case ZK_OP_DOT4: {
+            uint64_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = ldv(W[1 + i]);
+            uint64_t r = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r = gl::fma(v[2 * i], v[2 * i + 1], r);
+            stv(W[9], r);
+            pc += 10;
+        } break;
+        case ZK_OP_MATMUL12: {
+            const u32x16_a4 W1 = *(prog16_ptr)(prog + pc + 16);
+            uint64_t st[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) st[i] = ldv(W[1 + i]);
+            if (pa == 0) p2::mds_external(st); else p2::mds_inner(st);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) stv(W[13 + i], st[i]);
+#pragma unroll
+            for (int i = 3; i < 12; ++i) stv(W1[i - 3], st[i]);
+            pc += 25;
+        } break;
+        case ZK_OP_SPLIT: {
+            uint64_t x = ldv(W[1]);
+            for (uint32_t i = 0; i < pa; ++i) {
+                stv(prog[pc + 2 + i], i + 1 == pa ? x : (x & ((1ull << pb) - 1)));
+                x >>= pb;
+            }
+            pc += 2 + pa;
+        } break;
+        case ZK_OP_LOOKUP: {
+            const zk_table_desc t = sc.tables[W[1]];
+            const uint32_t nv = pb & 0xff;
+            const uint64_t k0 = ldv(W[2]), k1 = pa > 1 ? ldv(W[3]) : 0, k2 = pa > 2 ? ldv(W[4]) : 0;
+            const uint32_t row = table_find3(t, sc.table_words, k0, k1, k2);
+            const bool found = row < t.n_rows;
+            const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(sc.table_words + (t.dense >> 2));
+            const uint32_t w = t.n_keys + t.n_vals;
+            for (uint32_t i = 0; i < nv; ++i)
+                stv(prog[pc + 2 + pa + i], !found ? 0ull
+                                           : (t.dense & 2u) ? (uint64_t)tb[(size_t)row * t.n_vals + i]
+                                                            : sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i]);
+            pc += 2 + pa + nv;
+        } break;
+        case ZK_OP_POSEIDON2: {
+            // The permutation is a dependent chain for this one wavefront (six of them in a row per main_vm cycle): state in
+            // registers, the twelve S-boxes of a full round unrolled — the LDS-staged form of the throughput kernels costs twice
+            // the latency here (143 k vs ~70 k clock ticks per permutation, in-kernel profile).  One copy of the full-round body.
+            const u32x16_a4 W1 = *(prog16_ptr)(prog + pc + 16);
+            uint64_t st[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) st[i] = ldv(W[1 + i]);
+            p2::mds_external(st);
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int r = half * 26 + r4;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) st[i] = gl::pow7(gl::add(st[i], p2::RC[12 * r + i]));
+                    p2::mds_external(st);
+                }
+                if (half == 0) {
+#pragma unroll 1
+                    for (int r = 4; r < 26; ++r) {
+                        st[0] = gl::pow7(gl::add(st[0], p2::RC[12 * r]));
+                        p2::mds_inner(st);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) stv(W[13 + i], st[i]);
+#pragma unroll
+            for (int i = 3; i < 12; ++i) stv(W1[i - 3], st[i]);
+            pc += 25;
+        } break;
+        case ZK_OP_U32MULADD: {
+            const uint64_t r = ldv(W[1]) * ldv(W[2]) + ldv(W[3]) + ldv(W[4]);
+            stv(W[5], r & 0xffffffffull);
+            stv(W[6], r >> 32);
+            pc += 7;
+        } break;
+        case ZK_OP_DIVREM: {
+            const uint64_t x = ldv(W[1]);
+            stv(W[2], x / pb);
+            stv(W[3], x % pb);
+            pc += 4;
+        } break;
+        case ZK_OP_U256_MULWIDE: {
+            const u32x16_a4 W1 = *(prog16_ptr)(prog + pc + 16), W2 = *(prog16_ptr)(prog + pc + 32);
+            uint32_t a[8], b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = (uint32_t)ldv(W[1 + i]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) b[i] = (uint32_t)ldv(W[9 + i]);
+            b[7] = (uint32_t)ldv(W1[0]);
+            uint64_t lo = 0;
+            uint32_t hi = 0, out[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int j = k - i;
+                    if (j >= 0 && j < 8) {
+                        const uint64_t p = (uint64_t)a[i] * b[j];
+                        lo += p;
+                        hi += lo < p;
+                    }
+                }
+                out[k] = (uint32_t)lo;
+                lo = (lo >> 32) | ((uint64_t)hi << 32);
+                hi = 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 15; ++i) stv(W1[1 + i], (uint64_t)out[i]);
+            stv(W2[0], (uint64_t)out[15]);
+            pc += 33;
+        } break;
+        case ZK_OP_U256_DIVREM: {
+            const u32x16_a4 W1 = *(prog16_ptr)(prog + pc + 16), W2 = *(prog16_ptr)(prog + pc + 32);
+            uint32_t a[8], b[8], r[8];
+            uint32_t bnz = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = (uint32_t)ldv(W[1 + i]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) b[i] = (uint32_t)ldv(W[9 + i]);
+            b[7] = (uint32_t)ldv(W1[0]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { bnz |= b[i]; r[i] = 0; }
+            if (__builtin_amdgcn_ballot_w64(bnz != 0) != 0) {  // see run_tile2
+#pragma unroll 1
+                for (int step = 0; step < 256; ++step) {
+                    const uint32_t top = r[7] >> 31;
+#pragma unroll
+                    for (int i = 7; i > 0; --i) r[i] = (r[i] << 1) | (r[i - 1] >> 31);
+                    r[0] = (r[0] << 1) | (a[7] >> 31);
+#pragma unroll
+                    for (int i = 7; i > 0; --i) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
+                    a[0] <<= 1;
+                    uint32_t d[8];
+                    uint32_t borrow = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint64_t t = (uint64_t)r[i] - b[i] - borrow;
+                        d[i] = (uint32_t)t;
+                        borrow = (uint32_t)(t >> 63);
+                    }
+                    if (top | (borrow ^ 1u)) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) r[i] = d[i];
+                        a[0] |= 1u;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = bnz ? a[i] : 0u;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { r[i] = a[i]; a[i] = 0; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) stv(W1[1 + i], (uint64_t)a[i]);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) stv(W1[9 + i], (uint64_t)r[i]);
+            stv(W2[0], (uint64_t)r[7]);
+            pc += 33;
+        } break;
+        default:
+            return;  // not a seed-v2 op: the host never selects this kernel for such cones
+        }
+#ifdef ZKGL_SEED_PROFILE
+        if (prof) { prof[prof_op * 2] += __builtin_readcyclecounter() - t_op0; prof[prof_op * 2 + 1] += 1; }
+#endif
+    }
+}
+
+__global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_seed_cone_strands2(ScopeDev sc, const uint32_t* __restrict__ seed_sprog, StrandTab tab,
+                                                                             const SeedCarryDev* carries, uint32_t n_carries, uint64_t* inputs_rw,
+                                                                             uint32_t n_instances, uint32_t lpb, uint32_t n_slots, uint32_t n_input_words) {
+    constexpr uint32_t NT = 64 * STRANDS_PER_TILE;
+    __shared__ uint64_t lds[SEED_LDS_WORDS];
+    if (blockIdx.x * lpb >= n_instances) return;
+    uint64_t* const slot_store = lds;                 // [n_slots][lpb]
+    uint64_t* const in_store = lds + n_slots * lpb;   // [n_input_words][lpb]: this iteration's input stream words
+    const uint32_t w = uni(threadIdx.x >> 6);
+    const uint32_t l = (threadIdx.x & 63) % lpb;      // lanes >= lpb mirror lane % lpb: identical values, benign duplicate stores
+    const uint32_t inst = min(blockIdx.x * lpb + l, n_instances - 1);
+    const uint32_t ml = inst - blockIdx.x * lpb;
+    const uint32_t wb = tab.begin[w], we = tab.end[w];
+#ifdef ZKGL_SEED_PROFILE
+    uint64_t prof[64];
+    for (int i = 0; i < 64; ++i) prof[i] = 0;
+    uint64_t t_pro = 0, t_run = 0;
+#endif
+    for (uint32_t k = 0; k < sc.limit; ++k) {
+#ifdef ZKGL_SEED_PROFILE
+        const uint64_t t0 = __builtin_readcyclecounter();
+#endif
+        for (uint32_t idx = threadIdx.x; idx < n_input_words * lpb; idx += NT) {
+            const uint32_t wd = idx / lpb, ll = idx % lpb;
+            const uint32_t li = min(blockIdx.x * lpb + ll, n_instances - 1);
+            in_store[wd * lpb + li - blockIdx.x * lpb] = inputs_rw[(size_t)wd * sc.in_stride + (size_t)li * sc.limit + k];
+        }
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < n_carries * lpb; idx += NT) {
+            const SeedCarryDev cd = carries[idx / lpb];
+            const uint32_t ll = idx % lpb;
+            const uint32_t li = min(blockIdx.x * lpb + ll, n_instances - 1), col = li - blockIdx.x * lpb;
+            if (k == 0 && !cd.has_first) continue;
+            const uint64_t v = k == 0 ? sc.outer_cells[cell_off(sc.outer_n_cells, cd.first_outer_cell, li)] : slot_store[cd.out_slot * lpb + col];
+            in_store[cd.word * lpb + col] = v;
+            inputs_rw[(size_t)cd.word * sc.in_stride + (size_t)li * sc.limit + k] = v;
+        }
+        __syncthreads();
+#ifdef ZKGL_SEED_PROFILE
+        const uint64_t t1 = __builtin_readcyclecounter();
+        run_seed2<(int)NT>(sc, inst, wb, we, seed_sprog, slot_store + ml, lpb, in_store + ml, prof);
+        __syncthreads();
+        t_pro += t1 - t0; t_run += __builtin_readcyclecounter() - t1;
+#else
+        run_seed2<(int)NT>(sc, inst, wb, we, seed_sprog, slot_store + ml, lpb, in_store + ml);
+        __syncthreads();
+#endif
+    }
+#ifdef ZKGL_SEED_PROFILE
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        printf("[seed profile] strand %u: prologue %llu cycles, run %llu cycles (s_memtime ticks)\n", w, (unsigned long long)t_pro, (unsigned long long)t_run);
+        for (int o = 0; o < 25; ++o)
+            if (prof[2 * o + 1]) printf("   strand %u op %2d: n=%llu ticks=%llu (%.0f per op)\n", w, o, (unsigned long long)prof[2 * o + 1], (unsigned long long)prof[2 * o], (double)prof[2 * o] / (double)prof[2 * o + 1]);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Gate / lookup checker over the variable store, scalar-decoded like the witness interpreter ("check program", cs.cpp
 // build_check_program).  The row-descriptor checker (kernels_engine.hpp check_gates_body) reads, per gate instance, the row
 // descriptor, then one alias word per column, then the value — three dependent round trips, 87 % of its wave time in
@@ -553,28 +900,6 @@ template <uint32_t N, class F>
 __device__ __forceinline__ void dispatch_count(uint32_t n, F&& f) {
     if constexpr (N == 1) f(GroupSize<1>{});
     else { if (n >= N) f(GroupSize<N>{}); else dispatch_count<N - 1>(n, f); }
-}
-
-// table row of a key tuple of <= 3 keys without a key array (see table_find2)
-__device__ __forceinline__ uint32_t table_find3(const zk_table_desc& t, const uint64_t* __restrict__ words, uint64_t k0, uint64_t k1, uint64_t k2) {
-    if (t.n_keys <= 2) return table_find2(t, words, k0, k1);
-    if (t.dense) {
-        const uint32_t top = 31 - __clz(t.n_rows);
-        const bool ok = (k0 >> (top - t.key_shift[0])) == 0 && (k1 >> (t.key_shift[0] - t.key_shift[1])) == 0 && (k2 >> (t.key_shift[1] - t.key_shift[2])) == 0;
-        const uint64_t idx = (k0 << t.key_shift[0]) + (k1 << t.key_shift[1]) + (k2 << t.key_shift[2]);
-        return ok ? (uint32_t)idx : t.n_rows;
-    }
-    const uint32_t w = t.n_keys + t.n_vals;
-    const uint64_t* rows = words + (size_t)t.word_off;
-    uint32_t lo = 0, hi = t.n_rows;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint64_t r0 = rows[(size_t)mid * w], r1 = rows[(size_t)mid * w + 1], r2 = rows[(size_t)mid * w + 2];
-        const int cmp = r0 != k0 ? (r0 < k0 ? -1 : 1) : r1 != k1 ? (r1 < k1 ? -1 : 1) : r2 != k2 ? (r2 < k2 ? -1 : 1) : 0;
-        if (cmp == 0) return mid;
-        if (cmp < 0) lo = mid + 1; else hi = mid;
-    }
-    return t.n_rows;
 }
 
 #ifndef ZKGL_CHECK_WAVES

@@ -98,7 +98,7 @@ int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint6
 static zke::ScopeDev to_dev(const ScopeArgs& a) {
     zke::ScopeDev d;
     d.prog = a.prog; d.n_words = a.n_words; d.n_lanes = a.n_lanes; d.consts = a.consts; d.cells = a.cells;
-    d.n_cells = a.n_cells; d.inputs = a.inputs; d.outer_cells = a.outer_cells; d.outer_n_cells = a.outer_n_cells;
+    d.n_cells = a.n_cells; d.inputs = a.inputs; d.in_stride = a.in_stride ? a.in_stride : a.n_lanes; d.outer_cells = a.outer_cells; d.outer_n_cells = a.outer_n_cells;
     d.limit = a.limit; d.is_loop = a.is_loop; d.tables = a.tables; d.table_words = a.table_words; d.mult = a.mult;
     d.total_table_rows = a.total_table_rows; d.loop_cells = a.loop_cells; d.loop_n_cells = a.loop_n_cells;
     d.loop_limit = a.loop_limit;
@@ -319,7 +319,7 @@ int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_
 }
 
 int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, const uint32_t begin[8], const uint32_t end[8], uint32_t n_slots,
-                             uint32_t n_input_words, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream) {
+                             uint32_t n_input_words, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, bool v2, void* stream) {
     if (n_instances == 0 || sc.limit == 0) return 0;
     const uint32_t per_lane = n_slots + n_input_words;
     if (n_slots == 0 || per_lane > zke::SEED_LDS_WORDS) return -1;
@@ -331,7 +331,9 @@ int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, co
     zke::StrandTab tab;
     for (int i = 0; i < zke::STRANDS_PER_TILE; ++i) { tab.begin[i] = begin[i]; tab.end[i] = end[i]; }
     auto c = reinterpret_cast<const zke::SeedCarryDev*>(d_carries);
-    if (sc.uses_bigint)
+    if (v2)  // scalar-decoded (kernels_engine2.hpp); the host selects it when every op of the cone has a handler there
+        zke::k_seed_cone_strands2<<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
+    else if (sc.uses_bigint)
         zke::k_seed_cone_strands<true><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
     else
         zke::k_seed_cone_strands<false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);

@@ -551,9 +551,14 @@ class ConstraintSystem:
         _check(lib().zk_cs_set_batch(self._h, n_instances))
         self.batch = n_instances
 
-    def bind_inputs(self, loop_scope: bool, dev_words, n_words: int):
+    def bind_inputs(self, loop_scope: bool, dev_words, n_words: int, lane_stride: int = 0, lane_offset: int = 0):
+        """lane_stride / lane_offset: the batch is a window of a longer stream ([word][lane_stride] u64, first lane lane_offset)"""
         self._keep.append(dev_words)
-        _check(lib().zk_cs_bind_inputs(self._h, int(loop_scope), _ptr(dev_words), n_words))
+        if lane_stride or lane_offset:
+            base = (_ptr(dev_words).value or 0) + 8 * lane_offset
+            _check(lib().zk_cs_bind_inputs_window(self._h, int(loop_scope), C.c_void_p(base), n_words, C.c_uint64(lane_stride)))
+        else:
+            _check(lib().zk_cs_bind_inputs(self._h, int(loop_scope), _ptr(dev_words), n_words))
 
     def resolve(self, stream=None):
         _check(lib().zk_cs_resolve(self._h, _ptr(stream)))
@@ -561,6 +566,10 @@ class ConstraintSystem:
     def seed_carried_inputs(self, dev_loop_inputs, stream=None):
         """fill the loop-carried words of the bound loop input stream sequentially on the GPU"""
         _check(lib().zk_cs_seed_carried_inputs(self._h, _ptr(dev_loop_inputs), _ptr(stream)))
+
+    def seed_stream(self, n_instances: int, dev_outer_inputs, dev_loop_inputs, stream=None):
+        """seed a stream of n_instances (any n, independent of set_batch): outer [word][n], loop [word][n * limit] (zk_cs_seed_stream)"""
+        _check(lib().zk_cs_seed_stream(self._h, n_instances, _ptr(dev_outer_inputs), _ptr(dev_loop_inputs), _ptr(stream)))
 
     def check_if_satisfied(self, stream=None):
         """Returns (True, None) or (False, Failure)."""

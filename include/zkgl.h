@@ -167,12 +167,21 @@ int zk_cs_finalize(zk_cs *cs);
 int zk_cs_set_batch(zk_cs *cs, uint32_t n_instances); /* allocates device trace for the batch */
 /* input streams: outer scope words[w*B + inst]; loop scope words[w*(B*limit) + inst*limit + k]; device ptrs */
 int zk_cs_bind_inputs(zk_cs *cs, int loop_scope, const uint64_t *dev_words, uint32_t n_words);
+/* a batch that is a WINDOW of a longer stream: dev_words points at the window's first lane, consecutive words are lane_stride
+ * lanes apart (outer scope: the stream's instance count; loop scope: instances * limit) */
+int zk_cs_bind_inputs_window(zk_cs *cs, int loop_scope, const uint64_t *dev_words, uint32_t n_words, uint64_t lane_stride);
 int zk_cs_resolve(zk_cs *cs, void *stream);          /* witness generation */
 /* Generic sequential seeding: fills the loop-carried words of the bound (writable) loop input stream
  * from the circuit's own recurrence, one iteration after another, lane == instance.  Needed only when
  * the host has the raw witness but not the per-iteration state (the reference's closures get exactly
  * that); hosts that already know the per-cycle state (e.g. VmLocalState per cycle) skip it. */
 int zk_cs_seed_carried_inputs(zk_cs *cs, uint64_t *dev_loop_inputs_rw, void *stream);
+/* The same over a stream of n_instances, independent of zk_cs_set_batch (layouts: outer words[w*n + inst], loop
+ * words[w*(n*limit) + inst*limit + k]).  Seeding is a latency chain of `limit` iterations per instance: one pass over ~1000
+ * instances costs what a pass over 8 does, so a host seeds a long stream once and resolves it in windows
+ * (zk_cs_bind_inputs_window).  Replaces the sequential part of the reference's witness resolution
+ * (/root/reference/src/main_vm/mod.rs: the `for _cycle_idx in 0..limit` loop over vm_cycle). */
+int zk_cs_seed_stream(zk_cs *cs, uint32_t n_instances, const uint64_t *dev_outer_inputs, uint64_t *dev_loop_inputs_rw, void *stream);
 typedef struct zk_failure { uint32_t scope, instance, iteration, slot, kind, relation; } zk_failure;
 /* check_if_satisfied: 0 satisfied; ZK_ERR_UNSATISFIED + first failure otherwise */
 int zk_cs_check_satisfied(zk_cs *cs, void *stream, zk_failure *first);

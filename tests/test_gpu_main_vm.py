@@ -84,3 +84,24 @@ def test_main_vm_gpu_reports_tampered_witness(zk, batch):
     cs.bind_inputs(True, d_l, bad.shape[0])
     ok, f = cs.resolve_and_check()
     assert not ok and f.instance == victim
+
+
+def test_main_vm_gpu_stream_seeding_and_windows(zk, batch):
+    """zk_cs_seed_stream over the whole stream (no batch set for it), then the stream resolved in windows of 24 instances
+    through zk_cs_bind_inputs_window: same seeded words, every window satisfied, same commitments"""
+    cs, D, outer, loop, commits, info = batch
+    S = outer.shape[1]
+    raw = loop.copy()
+    raw[0:243] = 0
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.seed_stream(S, d_o, d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop), "stream-seeded VmLocalState differs from the native restatement"
+    W = 24
+    cs.set_batch(W)
+    for first in range(0, S - W + 1, W):
+        cs.bind_inputs(False, d_o, outer.shape[0], lane_stride=S, lane_offset=first)
+        cs.bind_inputs(True, d_l, raw.shape[0], lane_stride=S * LIMIT, lane_offset=first * LIMIT)
+        ok, f = cs.resolve_and_check()
+        assert ok, (first, f)
+        for i in range(W):
+            assert cs.public_inputs(i) == commits[first + i], info[first + i]
