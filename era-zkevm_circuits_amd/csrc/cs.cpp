@@ -779,58 +779,43 @@ void CS::build_strands(Scope& s) {
                 load[best] += cost(oi);
                 mine[best].push_back(oi);
             }
-            // The ops of a level are independent, so a strand's lookups into one table are emitted in groups of up to 8 under one
-            // header (b = n_vals | (group - 1) << 8; table word, keys of every member, then destinations of every member): the
-            // interpreter issues all key loads, then all table gathers, then all stores — one latency chain instead of eight.
+            // The ops of a level are independent, so a strand's ops of one kind go out in groups under one header (scalar-decoded
+            // strand form, kernels_engine2.hpp k_witness_strands2): header, operand words of every member as in the plain v2
+            // form, then ONE destination word per member — the store slot of its first output (an op's outputs are consecutive
+            // slots).  Caps: a group fits the 16-word fetch (SELECT 3, FMA 2, INPUT 7, LOOKUP of <= 2 keys 3, U32MULADD 2).
             const char* grp_env = getenv("ZKGL_LOOKUP_GROUPS");
             const bool grouping = !(grp_env && grp_env[0] == '0');
             for (uint32_t k = 0; k < NS; ++k) {
-                std::map<uint64_t, std::vector<uint32_t>> groups;  // (table, n_keys, n_vals) -> lookups of this strand and level
-                std::map<uint8_t, std::vector<uint32_t>> plain_groups;  // opcode -> SELECT / FMA / LC4 ops of this strand and level
+                std::map<uint64_t, std::vector<size_t>> groups;  // kind key -> ops of this strand and level
+                std::vector<uint64_t> order;
                 for (uint32_t oi : mine[k]) {
                     const OpRec& op = s.ops[oi];
-                    if (grouping && op.opcode == ZK_OP_LOOKUP && op.a <= 2 && op.b <= 2) groups[((uint64_t)op.ins[0].idx << 32) | ((uint64_t)op.a << 16) | op.b].push_back(oi);
-                    else if (grouping && (op.opcode == ZK_OP_SELECT || op.opcode == ZK_OP_FMA || op.opcode == ZK_OP_LC4)) plain_groups[op.opcode].push_back(oi);
-                    else emit_op(s, op, strand[k]);
-                }
-                // the same for SELECT (8 to a header), FMA and LC4 (4): b = group - 1, operand words of every member, then destinations
-                for (auto& kv : plain_groups) {
-                    const auto& g = kv.second;
-                    const size_t cap = kv.first == ZK_OP_SELECT ? 8 : 4;
-                    for (size_t i0 = 0; i0 < g.size(); i0 += cap) {
-                        const size_t n = std::min(cap, g.size() - i0);
-                        strand[k].push_back((uint32_t)kv.first | ((uint32_t)(n - 1) << 16));
-                        for (size_t i = 0; i < n; ++i) {
-                            const OpRec& op = s.ops[g[i0 + i]];
-                            for (auto& in : op.ins) {
-                                if (in.kind == Operand::VAR) strand[k].push_back(s.var_slot[in.idx]);
-                                else if (in.kind == Operand::CONSTPOOL) strand[k].push_back(ZK_OPERAND_CONST | in.idx);
-                                else if (in.kind == Operand::OUTER_VAR) strand[k].push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
-                                else strand[k].push_back(in.idx);
-                            }
-                        }
-                        for (size_t i = 0; i < n; ++i) emit_dests(s, s.ops[g[i0 + i]], strand[k]);
+                    uint64_t key = ((uint64_t)1 << 63) | oi;  // ungrouped: its own key
+                    if (grouping) {
+                        if (op.opcode == ZK_OP_LOOKUP && op.a <= 2 && op.b <= 2) key = ((uint64_t)ZK_OP_LOOKUP << 56) | ((uint64_t)op.ins[0].idx << 24) | ((uint64_t)op.a << 8) | op.b;
+                        else if (op.opcode == ZK_OP_SELECT || op.opcode == ZK_OP_FMA || op.opcode == ZK_OP_INPUT || op.opcode == ZK_OP_U32MULADD) key = (uint64_t)op.opcode << 56;
                     }
+                    if (!groups.count(key)) order.push_back(key);
+                    groups[key].push_back(oi);
                 }
-                plain_groups.clear();
-                for (auto& kv : groups) {
-                    const auto& g = kv.second;
-                    for (size_t i0 = 0; i0 < g.size(); i0 += 8) {
-                        const size_t n = std::min<size_t>(8, g.size() - i0);
-                        const OpRec& first = s.ops[g[i0]];
-                        strand[k].push_back((uint32_t)ZK_OP_LOOKUP | ((uint32_t)first.a << 8) | (((uint32_t)first.b | ((uint32_t)(n - 1) << 8)) << 16));
-                        strand[k].push_back(first.ins[0].idx);  // table id
-                        for (size_t i = 0; i < n; ++i) {
-                            const OpRec& op = s.ops[g[i0 + i]];
-                            for (size_t q = 1; q < op.ins.size(); ++q) {
-                                const Operand& in = op.ins[q];
-                                if (in.kind == Operand::VAR) strand[k].push_back(s.var_slot[in.idx]);
-                                else if (in.kind == Operand::CONSTPOOL) strand[k].push_back(ZK_OPERAND_CONST | in.idx);
-                                else if (in.kind == Operand::OUTER_VAR) strand[k].push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
-                                else strand[k].push_back(in.idx);
-                            }
+                for (uint64_t key : order) {
+                    const auto& g = groups[key];
+                    const OpRec& f0 = s.ops[g[0]];
+                    size_t cap = 1;
+                    bool counted = false;
+                    if (!(key >> 63)) {
+                        counted = true;
+                        cap = f0.opcode == ZK_OP_SELECT ? 3 : f0.opcode == ZK_OP_FMA ? 2 : f0.opcode == ZK_OP_INPUT ? 7 : f0.opcode == ZK_OP_U32MULADD ? 2 : 3;
+                    } else counted = f0.opcode == ZK_OP_SELECT || f0.opcode == ZK_OP_FMA || f0.opcode == ZK_OP_INPUT || f0.opcode == ZK_OP_U32MULADD || f0.opcode == ZK_OP_LC4;
+                    for (size_t i0 = 0; i0 < g.size(); i0 += cap) {
+                        std::vector<size_t> part(g.begin() + i0, g.begin() + std::min(g.size(), i0 + cap));
+                        emit_group_v2(s, part, counted, strand[k]);
+                        for (size_t oi : part) {
+                            const OpRec& op = s.ops[oi];
+                            for (size_t q = 0; q < op.outs.size(); ++q)
+                                if (s.var_slot[op.outs[q]] != s.var_slot[op.outs[0]] + q) throw ZkError(ZK_ERR_INVALID, "internal: an op's outputs are not consecutive store slots");
+                            strand[k].push_back(op.outs.empty() ? 0u : s.var_slot[op.outs[0]]);
                         }
-                        for (size_t i = 0; i < n; ++i) emit_dests(s, s.ops[g[i0 + i]], strand[k]);
                     }
                 }
             }
@@ -878,6 +863,45 @@ void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* strea
     }
     a.prog = s.d_sprog; a.n_words = (uint32_t)s.sprog.size();
     dev_check(zkdev::launch_witness_strands(a, s.s_begin[phase], s.s_end[phase], stream));
+}
+
+// one operand word of the scalar-decoded device forms (kernels_engine2.hpp): data operands are bare store slots, FMA / LC4 /
+// NN_MULMOD immediates bare pool indices, ZK_OP_CONST keeps a kind (pool constant or outer value), raw words as recorded
+void CS::operand_v2(const Scope& s, const OpRec& op, size_t pos, std::vector<uint32_t>& out) const {
+    const Operand& in = op.ins[pos];
+    const bool coeff = (op.opcode == ZK_OP_FMA && pos < 2) || (op.opcode == ZK_OP_LC4 && pos < 4) || (op.opcode == ZK_OP_NN_MULMOD && pos < 16);
+    if (coeff) {
+        if (in.kind != Operand::CONSTPOOL) throw ZkError(ZK_ERR_INVALID, "internal: FMA / LC4 / NN_MULMOD immediate is not a pool constant");
+        out.push_back(in.idx);
+    } else if (op.opcode == ZK_OP_CONST) {
+        if (in.kind == Operand::CONSTPOOL) out.push_back(ZK_OPERAND_CONST | in.idx);
+        else if (in.kind == Operand::OUTER_VAR) out.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
+        else throw ZkError(ZK_ERR_INVALID, "internal: ZK_OP_CONST of a variable");
+    } else if (in.kind == Operand::VAR) out.push_back(s.var_slot[in.idx]);
+    else if (in.kind == Operand::RAW) out.push_back(op.opcode == ZK_OP_LOOP_LAST ? loop_.var_slot[in.idx] : in.idx);
+    else throw ZkError(ZK_ERR_INVALID, "internal: pool constant / outer value in a data operand position");
+}
+// header + operand words of a group of same-kind ops in the scalar-decoded forms (no destinations)
+void CS::emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool counted, std::vector<uint32_t>& out) const {
+    const OpRec& first = s.ops[group[0]];
+    const size_t n = group.size();
+    if (first.opcode == ZK_OP_LOOKUP) {
+        out.push_back((uint32_t)ZK_OP_LOOKUP | ((uint32_t)first.a << 8) | (((uint32_t)first.b | ((uint32_t)(n - 1) << 8)) << 16));
+        out.push_back(first.ins[0].idx);  // table id
+        for (size_t oi : group)
+            for (size_t q = 1; q < s.ops[oi].ins.size(); ++q) operand_v2(s, s.ops[oi], q, out);
+        return;
+    }
+    out.push_back((uint32_t)first.opcode | ((uint32_t)first.a << 8) | ((counted ? (uint32_t)(n - 1) : (uint32_t)first.b) << 16));
+    if (first.opcode == ZK_OP_NN_MULMOD) {
+        // fixed layout: 16 modulus limbs, 17 A slots, 17 B slots (unused ones 0): static word positions for the kernel's scalar fetches
+        for (size_t q = 0; q < 16; ++q) operand_v2(s, first, q, out);
+        for (size_t q = 0; q < 17; ++q) { if (q < first.a) operand_v2(s, first, 16 + q, out); else out.push_back(0); }
+        for (size_t q = 0; q < 17; ++q) { if (q < first.b) operand_v2(s, first, 16 + first.a + q, out); else out.push_back(0); }
+        return;
+    }
+    for (size_t oi : group)
+        for (size_t q = 0; q < s.ops[oi].ins.size(); ++q) operand_v2(s, s.ops[oi], q, out);
 }
 
 // Device programs group runs of consecutive, mutually independent ops of one kind under ONE header: header b carries
@@ -937,20 +961,7 @@ void CS::emit_scope(Scope& s) {
         std::vector<size_t> group;  // op indices of the open group
         auto operand = [&](const OpRec& op, size_t pos) {
             const Operand& in = op.ins[pos];
-            if (v2) {
-                const bool coeff = (op.opcode == ZK_OP_FMA && pos < 2) || (op.opcode == ZK_OP_LC4 && pos < 4) || (op.opcode == ZK_OP_NN_MULMOD && pos < 16);
-                if (coeff) {
-                    if (in.kind != Operand::CONSTPOOL) throw ZkError(ZK_ERR_INVALID, "internal: FMA / LC4 / NN_MULMOD immediate is not a pool constant");
-                    out.push_back(in.idx);
-                } else if (op.opcode == ZK_OP_CONST) {
-                    if (in.kind == Operand::CONSTPOOL) out.push_back(ZK_OPERAND_CONST | in.idx);
-                    else if (in.kind == Operand::OUTER_VAR) out.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
-                    else throw ZkError(ZK_ERR_INVALID, "internal: ZK_OP_CONST of a variable");
-                } else if (in.kind == Operand::VAR) out.push_back(s.var_slot[in.idx]);
-                else if (in.kind == Operand::RAW) out.push_back(op.opcode == ZK_OP_LOOP_LAST ? loop_.var_slot[in.idx] : in.idx);
-                else throw ZkError(ZK_ERR_INVALID, "internal: pool constant / outer value in a data operand position");
-                return;
-            }
+            if (v2) { operand_v2(s, op, pos, out); return; }
             if (in.kind == Operand::VAR) out.push_back(s.var_slot[in.idx]);
             else if (in.kind == Operand::CONSTPOOL) out.push_back(ZK_OPERAND_CONST | in.idx);
             else if (in.kind == Operand::OUTER_VAR) out.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
@@ -960,21 +971,16 @@ void CS::emit_scope(Scope& s) {
             if (group.empty()) return;
             const OpRec& first = s.ops[group[0]];
             const size_t n = group.size();
-            if (first.opcode == ZK_OP_LOOKUP) {
+            const bool counted = group_cap(first, v2) > 1 || first.opcode == ZK_OP_INPUT || first.opcode == ZK_OP_SELECT || first.opcode == ZK_OP_FMA ||
+                                 first.opcode == ZK_OP_LC4 || (v2 && first.opcode == ZK_OP_U32MULADD);
+            if (v2) emit_group_v2(s, group, counted, out);
+            else if (first.opcode == ZK_OP_LOOKUP) {
                 out.push_back((uint32_t)ZK_OP_LOOKUP | ((uint32_t)first.a << 8) | (((uint32_t)first.b | ((uint32_t)(n - 1) << 8)) << 16));
                 out.push_back(first.ins[0].idx);  // table id
                 for (size_t oi : group)
                     for (size_t q = 1; q < s.ops[oi].ins.size(); ++q) operand(s.ops[oi], q);
             } else {
-                const bool counted = group_cap(first, v2) > 1 || first.opcode == ZK_OP_INPUT || first.opcode == ZK_OP_SELECT || first.opcode == ZK_OP_FMA ||
-                                     first.opcode == ZK_OP_LC4 || (v2 && first.opcode == ZK_OP_U32MULADD);
                 out.push_back((uint32_t)first.opcode | ((uint32_t)first.a << 8) | ((counted ? (uint32_t)(n - 1) : (uint32_t)first.b) << 16));
-                if (v2 && first.opcode == ZK_OP_NN_MULMOD) {
-                    // fixed layout: 16 modulus limbs, 17 A slots, 17 B slots (unused ones 0): static word positions for the kernel's scalar fetches
-                    for (size_t q = 0; q < 16; ++q) operand(first, q);
-                    for (size_t q = 0; q < 17; ++q) { if (q < first.a) operand(first, 16 + q); else out.push_back(0); }
-                    for (size_t q = 0; q < 17; ++q) { if (q < first.b) operand(first, 16 + first.a + q); else out.push_back(0); }
-                } else
                 for (size_t oi : group)
                     for (size_t q = 0; q < s.ops[oi].ins.size(); ++q) operand(s.ops[oi], q);
             }

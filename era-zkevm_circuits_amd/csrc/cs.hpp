@@ -234,6 +234,8 @@ class CS {
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream) const;
     void build_check_program(Scope& s);
+    void operand_v2(const Scope& s, const OpRec& op, size_t pos, std::vector<uint32_t>& out) const;
+    void emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool counted, std::vector<uint32_t>& out) const;
     void upload_scope(Scope& s);
     void ensure_uploaded();
     void free_scope_device(Scope& s);

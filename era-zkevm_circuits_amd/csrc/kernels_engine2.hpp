@@ -91,7 +91,9 @@ __device__ __forceinline__ uint32_t table_find3(const zk_table_desc& t, const ui
     return t.n_rows;
 }
 
-template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB>
+// STRANDS: the strand form (k_witness_strands2): one destination word per op behind the operands — the store slot of its first
+// output (a strand's ops are not consecutive in production order) — and ZK_OP_BARRIER between the dependency levels.
+template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB, bool STRANDS = false>
 __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                           uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -130,6 +132,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #endif
     };
 
+    constexpr uint32_t D = STRANDS ? 1 : 0;  // destination words per op
+    auto out_to = [&](uint32_t slot) { if constexpr (STRANDS) dst = WIDE ? slot : slot << 9; };
     uint32_t pc = word_begin;
     while (pc < word_end) {
         const u32x16_a4 W = *(prog16_ptr)(prog + pc);  // s_load_dwordx16: header + up to 15 operand words (host pads the program)
@@ -138,7 +142,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
         switch (op) {
         case ZK_OP_CONST: {  // the only op whose operand carries a kind: a pool constant, or (loop scope) a value of the outer scope
             const uint32_t w = W[1];
-            pc += 2;
+            out_to(W[2]);
+            pc += 2 + D;
             uint64_t v;
             if ((w & ZK_OPERAND_KIND_MASK) == ZK_OPERAND_OUTER) v = sc.outer_cells[cell_off(sc.outer_n_cells, w & ZK_OPERAND_IDX_MASK, inst)];
             else v = cpool[w & ZK_OPERAND_IDX_MASK];
@@ -152,9 +157,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 uint64_t v[N];
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) v[g] = sc.inputs[(size_t)W[1 + g] * sc.in_stride + lane];
-                pc += 1 + N;
+                pc += 1 + N + D * N;
 #pragma unroll
-                for (uint32_t g = 0; g < N; ++g) st(v[g]);
+                for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N + g) & 15]); st(v[g]); }
             };
             switch (pb) {
             case 0: body(GroupSize<1>{}); break;
@@ -178,9 +183,10 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                     q[g] = cpool[W[1 + g * 5]];
                     l[g] = cpool[W[1 + g * 5 + 1]];
                 }
-                pc += 1 + N * 5;
+                pc += 1 + N * 5 + D * N;
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) {
+                    out_to(W[(1 + N * 5 + g) & 15]);
                     const uint64_t ab = gl::mul(in[g][0], in[g][1]);
                     st(gl::add(q[g] == 1 ? ab : gl::mul(q[g], ab), l[g] == 1 ? in[g][2] : gl::mul(l[g], in[g][2])));
                 }
@@ -198,7 +204,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             uint64_t r = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) r = gl::fma(cpool[W[1 + i]], t[i], r);
-            pc += 9;
+            out_to(W[9]);
+            pc += 9 + D;
             st(r);
         } break;
         case ZK_OP_SELECT: {
@@ -210,9 +217,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
                     for (uint32_t i = 0; i < 3; ++i) in[g][i] = ldv(W[1 + g * 3 + i]);
                 }
-                pc += 1 + N * 3;
+                pc += 1 + N * 3 + D * N;
 #pragma unroll
-                for (uint32_t g = 0; g < N; ++g) st(in[g][0] ? in[g][1] : in[g][2]);
+                for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N * 3 + g) & 15]); st(in[g][0] ? in[g][1] : in[g][2]); }
             };
             switch (pb) {
             case 0: body(GroupSize<1>{}); break;
@@ -224,7 +231,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
         } break;
         case ZK_OP_ISZERO: {
             const uint64_t x = ldv(W[1]);
-            pc += 2;
+            out_to(W[2]);
+            pc += 2 + D;
             st(x == 0 ? 1ull : 0ull);
             // x^-1: flags and small counters dominate; 0 and 1 are their own (pseudo-)inverses, skip the 73-multiplication chain
             // when the whole wavefront holds such values
@@ -232,14 +240,16 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
         } break;
         case ZK_OP_UADD: {
             const uint64_t x = ldv(W[1]), y = ldv(W[2]), ci = ldv(W[3]);
-            pc += 4;
+            out_to(W[4]);
+            pc += 4 + D;
             const uint64_t s = x + y + ci;  // operands < 2^32
             st(s & ((1ull << pa) - 1));
             st(s >> pa);
         } break;
         case ZK_OP_USUB: {
             const uint64_t x = ldv(W[1]), y = ldv(W[2]), bi = ldv(W[3]);
-            pc += 4;
+            out_to(W[4]);
+            pc += 4 + D;
             const uint64_t sub = y + bi;
             const uint64_t borrow = x < sub ? 1 : 0;
             st((x + (borrow << pa)) - sub);
@@ -249,7 +259,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             uint64_t v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = ldv(W[1 + i]);
-            pc += 9;
+            out_to(W[9]);
+            pc += 9 + D;
             uint64_t r = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) r = gl::fma(v[2 * i], v[2 * i + 1], r);
@@ -259,14 +270,16 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             uint64_t s[12];
 #pragma unroll
             for (int i = 0; i < 12; ++i) s[i] = ldv(W[1 + i]);
-            pc += 13;
+            out_to(W[13]);
+            pc += 13 + D;
             if (pa == 0) p2::mds_external(s); else p2::mds_inner(s);
 #pragma unroll
             for (int i = 0; i < 12; ++i) st(s[i]);
         } break;
         case ZK_OP_SPLIT: {
             uint64_t x = ldv(W[1]);
-            pc += 2;
+            out_to(W[2]);
+            pc += 2 + D;
             for (uint32_t i = 0; i < pa; ++i) {
                 st(i + 1 == pa ? x : (x & ((1ull << pb) - 1)));
                 x >>= pb;
@@ -288,7 +301,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                         k0[g] = pa == 2 ? ldv(W[2 + 2 * g]) : ldv(W[2 + g]);
                         k1[g] = pa == 2 ? ldv(W[3 + 2 * g]) : 0;
                     }
-                    pc += 2 + N * pa;
+                    const uint32_t dpos = 2 + N * pa;  // destination words (strand form)
+                    pc += 2 + N * pa + D * N;
 #pragma unroll
                     for (uint32_t g = 0; g < N; ++g) {
                         row[g] = table_find2(t, sc.table_words, k0[g], k1[g]);
@@ -302,6 +316,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                     }
 #pragma unroll
                     for (uint32_t g = 0; g < N; ++g) {
+                        if constexpr (STRANDS) out_to(pa == 2 ? W[(2 + 2 * N + g) & 15] : W[(2 + N + g) & 15]);
+                        (void)dpos;
 #pragma unroll
                         for (uint32_t i = 0; i < 2; ++i)
                             if (i < nv) st(val[g][i]);
@@ -319,7 +335,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 key[0] = ldv(W[2]);
                 if (pa > 1) key[1] = ldv(W[3]);
                 if (pa > 2) key[2] = ldv(W[4]);
-                pc += 2 + pa;
+                if constexpr (STRANDS) out_to(pa == 1 ? W[3] : pa == 2 ? W[4] : W[5]);
+                pc += 2 + pa + D;
                 const uint32_t row = table_find(t, sc.table_words, key);
                 const bool found = row < t.n_rows;
                 for (uint32_t i = 0; i < nv; ++i)
@@ -336,7 +353,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             uint64_t s[12];
 #pragma unroll
             for (int i = 0; i < 12; ++i) s[i] = ldv(W[1 + i]);
-            pc += 13;
+            out_to(W[13]);
+            pc += 13 + D;
             p2::mds_external(s);
 #pragma unroll
             for (int i = 0; i < 12; ++i) p2s[i * BLOCK + threadIdx.x] = s[i];
@@ -376,7 +394,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
         } break;
         case ZK_OP_LOOP_LAST: {
             const uint32_t c = W[1];
-            pc += 2;
+            out_to(W[2]);
+            pc += 2 + D;
             st(sc.loop_cells[cell_off(sc.loop_n_cells, c, lane * sc.loop_limit + (sc.loop_limit - 1))]);
         } break;
         case ZK_OP_U32MULADD: {
@@ -388,9 +407,10 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
                     for (uint32_t i = 0; i < 4; ++i) in[g][i] = ldv(W[1 + g * 4 + i]);
                 }
-                pc += 1 + N * 4;
+                pc += 1 + N * 4 + D * N;
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) {
+                    out_to(W[(1 + N * 4 + g) & 15]);
                     const uint64_t r = in[g][0] * in[g][1] + in[g][2] + in[g][3];  // < 2^64 for u32 operands
                     st(r & 0xffffffffull);
                     st(r >> 32);
@@ -424,14 +444,16 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }(std::make_integer_sequence<uint32_t, 17>{});
             for (int i = 0; i < 16; ++i) mv[i] = (uint32_t)mraw[i];
             for (int i = 0; i < 17; ++i) { av[i] = (uint32_t)araw[i]; bv[i] = (uint32_t)braw[i]; }
-            pc += 51;
+            out_to(W3[3]);
+            pc += 51 + D;
             const uint32_t nq = pa + pb - 15;
             nn_mulmod(av, pa, bv, pb, mv, nq, res);
             for (uint32_t i = 0; i < nq + 16; ++i) st(res[i]);
         } else { return; } break;
         case ZK_OP_DIVREM: {
             const uint64_t x = ldv(W[1]);
-            pc += 2;
+            out_to(W[2]);
+            pc += 2 + D;
             st(x / pb);
             st(x % pb);
         } break;
@@ -444,7 +466,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
             for (int i = 0; i < 7; ++i) b[i] = (uint32_t)ldv(W[9 + i]);
             b[7] = (uint32_t)ldv(w16);
-            pc += 17;
+            if constexpr (STRANDS) out_to(prog[pc + 17]);
+            pc += 17 + D;
             uint64_t lo = 0;
             uint32_t hi = 0;
 #pragma unroll
@@ -475,7 +498,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             b[7] = (uint32_t)ldv(w16);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { bnz |= b[i]; r[i] = 0; }
-            pc += 17;
+            if constexpr (STRANDS) out_to(prog[pc + 17]);
+            pc += 17 + D;
             // b == 0: q = 0, r = a (mul_div.rs:96-172).  A wavefront whose lanes all divide by zero (the VM's masked-out Div / Shr
             // cycles) skips the loop; a zero divisor next to real ones walks it with b = 0, which shifts a into r bit by bit
             // (r == a at the end) and fills the quotient with ones, cleared below.
@@ -515,6 +539,13 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
             for (int i = 0; i < 8; ++i) st((uint64_t)r[i]);
         } break;
+        case ZK_OP_BARRIER: if constexpr (STRANDS) {
+            // end of a dependency level: this strand's stores must be visible to the other wavefronts of the tile (same CU, shared
+            // L1) before any of them starts the next level
+            pc += 1;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else { return; } break;
         default:
             return;  // malformed program: host validates before upload
         }
@@ -529,6 +560,19 @@ __device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word
     lane = active ? lane : sc.n_lanes - 1;
     run_tile2<WITH_BIGINT, WIDE>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end, slot_begin);
 }
+// Strand mode: a scope with too few lanes to fill the chip (hash circuits: lanes = instances x cycles; every outer scope: lanes =
+// instances) runs one 64-lane tile per BLOCK of 8 wavefronts.  Wavefront w walks strand w of the program: the ops of every
+// dependency level of the op graph are dealt out over the strands by the host (cs.cpp build_strands), ZK_OP_BARRIER between levels.
+template <bool WITH_BIGINT, bool WIDE>
+__global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_witness_strands2(ScopeDev sc, StrandTab tab) {
+    if (blockIdx.x * 64 >= sc.n_lanes) return;
+    const uint32_t w = uni(threadIdx.x >> 6);
+    uint32_t lane = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool active = lane < sc.n_lanes;
+    lane = active ? lane : sc.n_lanes - 1;
+    run_tile2<WITH_BIGINT, WIDE, 64 * STRANDS_PER_TILE, true>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, tab.begin[w], tab.end[w], 0);
+}
+
 // Separate symbols so that profiles separate the loop-scope launch (the dominant kernel: B * limit lanes) from the
 // outer-scope launches (B lanes, latency-bound).
 #ifndef ZKGL_LOOP_WAVES2

@@ -126,9 +126,9 @@ int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[8], const u
     for (int i = 0; i < zke::STRANDS_PER_TILE; ++i) { tab.begin[i] = begin[i]; tab.end[i] = end[i]; any |= end[i] > begin[i]; }
     if (!any) return 0;
     const unsigned grid = grid_for(sc.n_lanes, 64);
-    if (sc.n_cells >= (1ull << 23)) zke::k_witness_strands<true, false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);  // 64-bit addressing
-    else if (sc.uses_bigint) zke::k_witness_strands<true><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
-    else zke::k_witness_strands<false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
+    if (sc.n_cells >= (1ull << 23)) zke::k_witness_strands2<true, true><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);  // 64-bit addressing
+    else if (sc.uses_bigint) zke::k_witness_strands2<true, false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
+    else zke::k_witness_strands2<false, false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
     return LAUNCH_CHECK("k_witness_strands");
 }
 
