@@ -168,6 +168,11 @@ def main():
     ap.add_argument("--workload", default="main_vm", choices=["main_vm", "vm_shaped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    # stdout carries the ONE JSON line and nothing else: libraries that write to fd 1 on their own (librccl prints a version banner
+    # at its first communicator, possibly from another thread) are sent to stderr; the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -273,7 +278,27 @@ def main():
         parity = bool(np.array_equal(local, expect[window[0] * B:(window[0] + 1) * B]))
         if not parity and not os.environ.get("ZKGL_STUB_RUN"):
             raise RuntimeError("public inputs differ from the native restatement's commitments stored in the fixture")
-    commits = gather_commitments(local, coll_dev)   # [world, B, 4] u64: RCCL all_gather over xGMI when world > 1
+    # the collective behind the C ABI: zk_comm_* + zk_cs_gather_commitments (one ncclAllGather of the packed public inputs over
+    # RCCL / xGMI); the launcher's part — handing rank 0's unique id to the other ranks — is a torch.distributed broadcast here
+    gather_path = "zk_cs_gather_commitments (RCCL all-gather behind the C ABI)"
+    try:
+        if shared_gpu:
+            raise RuntimeError("ranks share one GPU (smoke test): RCCL refuses duplicate devices")
+        uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(zkgl.Comm.unique_id()), dtype=torch.uint8).to(coll_dev)
+        if world > 1:
+            dist.broadcast(uid, src=0)
+        comm = zkgl.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        commits = cs.gather_commitments(comm, stream)          # [world, B, 4] u64
+        torch.cuda.synchronize()
+        comm.close()
+        if not np.array_equal(commits[rank], local):
+            raise RuntimeError("gathered commitments differ from this rank's public inputs")
+    except Exception as e:  # noqa: BLE001 — keep the bench line; say which path ran
+        print(f"[bench] C-ABI gather unavailable ({e}); using torch.distributed.all_gather", file=sys.stderr)
+        gather_path = "torch.distributed all_gather (fallback)"
+        commits = gather_commitments(local, coll_dev)   # [world, B, 4] u64: RCCL all_gather over xGMI when world > 1
     if rank == 0:
         n_inst = B * world
         constraints = st["constraints_per_instance"] * n_inst * args.steps
@@ -305,7 +330,7 @@ def main():
                        "instances_per_gpu": B, "cycles_per_instance": limit, "rows_per_instance": st["rows_per_instance"],
                        "constraints_per_instance": st["constraints_per_instance"], "parallelism": f"independent instances x{world}",
                        "input_seeding_s": round(seed_all, 4), "seeded_stream_instances_per_gpu": S, "seeding_s_per_batch": round(seed_all / K, 4), "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
-                       "commitments_equal_native_restatement": parity},
+                       "commitments_equal_native_restatement": parity, "commitment_gather": gather_path},
             "roofline": {"bound": "hbm", "kernel": "zke::k_witness_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": k_ms,
@@ -318,7 +343,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.log2_rows)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         dist.destroy_process_group()
 

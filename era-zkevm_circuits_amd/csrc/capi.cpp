@@ -73,6 +73,11 @@ int need_init() { return g_inited ? ZK_OK : fail(ZK_ERR_HIP, "zk_init() has not 
 #define NEED(p) do { if (!(p)) return fail(ZK_ERR_INVALID, "null argument: " #p); } while (0)
 }  // namespace
 
+namespace zkgl {  // for comm.cpp
+void set_last_error(const std::string& m) { g_err = m; }
+CS* cs_of(zk_cs* h) { return h->cs; }
+}  // namespace zkgl
+
 extern "C" {
 
 const char* zk_last_error(void) { return g_err.c_str(); }

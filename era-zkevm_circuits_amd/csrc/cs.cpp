@@ -75,6 +75,7 @@ CS::~CS() {
     if (d_links_) hipFree(d_links_);
     if (d_links_store_) hipFree(d_links_store_);
     for (auto p : d_streams_store_) if (p) hipFree(p);
+    if (d_public_slots_) hipFree(d_public_slots_);
     if (d_seed_prog_) hipFree(d_seed_prog_);
     if (d_seed_sprog_) hipFree(d_seed_sprog_);
     if (d_seed_scarries_) hipFree(d_seed_scarries_);
@@ -1859,6 +1860,19 @@ void CS::write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t valu
     if (batch_ == 0 || cell >= s.n_cells || lane >= s.n_lanes) throw ZkError(ZK_ERR_INVALID, "write_cell: out of range");
     ensure_materialized(nullptr);  // an externally modified trace is checked cell by cell, copies and links included
     hip_check(hipMemcpy(s.d_cells + tiled_offset(s.n_cells, cell, lane), &value, 8, hipMemcpyHostToDevice), "write_cell memcpy");
+}
+
+uint32_t CS::pack_public_inputs(uint64_t* dev_out, void* stream) {
+    if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "pack_public_inputs before set_batch");
+    const uint32_t n = (uint32_t)public_vars_.size();
+    if (!n) return 0;
+    if (!d_public_slots_) {
+        std::vector<uint32_t> slots;
+        for (uint32_t v : public_vars_) slots.push_back(outer_.var_slot[v]);
+        d_public_slots_ = upload(slots);
+    }
+    dev_check(zkdev::launch_pack_public(outer_.d_store, outer_.n_store, d_public_slots_, n, batch_, dev_out, stream));
+    return n;
 }
 
 std::vector<uint64_t> CS::public_inputs(uint32_t instance) {

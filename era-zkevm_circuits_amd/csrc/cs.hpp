@@ -103,7 +103,7 @@ struct Scope {
     uint64_t cells_populated = 0; // trace cells + scratch cells holding a value == destination words of prog_full
     // strand form of the program (build_strands): phase 0 = loop body / outer pre, 1 = outer side, 2 = outer post
     std::vector<uint32_t> sprog;
-    uint32_t s_begin[3][8] = {}, s_end[3][8] = {};
+    uint32_t s_begin[3][zkdev::STRANDS_PER_TILE] = {}, s_end[3][zkdev::STRANDS_PER_TILE] = {};
     uint32_t s_levels[3] = {0, 0, 0};
     float s_gain[3] = {0, 0, 0};  // estimated work / critical path over 8 strands: the strand form is used from 3 upwards
     std::vector<zk_row_desc> rows;
@@ -173,6 +173,9 @@ class CS {
     // execution
     void set_batch(uint32_t n_instances);
     void bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words, uint64_t lane_stride = 0);
+    // public inputs of the whole batch packed on the device: out[instance * n_public + k]; returns n_public
+    uint32_t pack_public_inputs(uint64_t* dev_out, void* stream);
+    uint32_t batch() const { return batch_; }
     void seed_stream(uint32_t n_instances, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream);
     void resolve(void* stream);
     // sequential seeding of the carried input words (generic, slow): see kernels_engine.hpp k_witness_seq
@@ -284,10 +287,11 @@ class CS {
     uint32_t* d_seed_prog_ = nullptr;
     void* d_seed_carries_ = nullptr;
     // strand form of the cone (8 wavefronts per block, level barriers; slots recycled per level)
+    uint32_t* d_public_slots_ = nullptr;
     bool seed_v2_ok_ = false;
     std::vector<uint32_t> seed_sprog_;
     std::vector<Carry> seed_scarries_;
-    uint32_t seed_sslots_ = 0, seed_sbegin_[8] = {}, seed_send_[8] = {};
+    uint32_t seed_sslots_ = 0, seed_sbegin_[zkdev::STRANDS_PER_TILE] = {}, seed_send_[zkdev::STRANDS_PER_TILE] = {};
     float seed_sgain_ = 0;
     uint32_t* d_seed_sprog_ = nullptr;
     void* d_seed_scarries_ = nullptr;

@@ -37,10 +37,14 @@ int launch_memory_query_encode(const uint64_t* q, size_t n, uint64_t* enc, void*
 int launch_execution_context_encode(const uint64_t* rec, size_t n, uint64_t* enc, void* stream);
 int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* ch, size_t enc_len, size_t n,
                          uint64_t init, uint64_t* acc, uint64_t* scratch, void* stream);
+int launch_pack_public(const uint64_t* outer_store, uint64_t n_store, const uint32_t* slots, uint32_t n_public, uint32_t n_instances, uint64_t* out, void* stream);
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, void* stream);
 // strand mode (kernels_engine.hpp k_witness_strands): sc.prog = the strand program, begin/end = 8 word ranges
-constexpr uint32_t STRANDS_PER_TILE = 8;
-int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[8], const uint32_t end[8], void* stream);
+#ifndef ZKGL_STRANDS_PER_TILE
+#define ZKGL_STRANDS_PER_TILE 16
+#endif
+constexpr uint32_t STRANDS_PER_TILE = ZKGL_STRANDS_PER_TILE;
+int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], void* stream);
 struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // mirrors zke::CarryDev
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);
@@ -88,7 +92,7 @@ int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t*
 // cone seeding: seed_prog in device memory (padded like every program), carries = {input word, out slot, first outer cell, has_first}
 int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_words, uint32_t n_slots, uint32_t n_input_words,
                      const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream);
-int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, const uint32_t begin[8], const uint32_t end[8], uint32_t n_slots,
+int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], uint32_t n_slots,
                              uint32_t n_input_words, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, bool v2, void* stream);
 uint32_t seed_cone_max_slots();
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,

@@ -800,7 +800,10 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 // lanes = instances) runs one 64-lane tile per BLOCK of 8 wavefronts.  Wavefront w walks strand w of the program: the ops of
 // every dependency level of the op graph are dealt out over the strands by the host (cs.cpp build_strands) and a
 // ZK_OP_BARRIER separates the levels.  The trace is the same, cell for cell.
-constexpr int STRANDS_PER_TILE = 8;
+#ifndef ZKGL_STRANDS_PER_TILE
+#define ZKGL_STRANDS_PER_TILE 16
+#endif
+constexpr int STRANDS_PER_TILE = ZKGL_STRANDS_PER_TILE;
 struct StrandTab { uint32_t begin[STRANDS_PER_TILE], end[STRANDS_PER_TILE]; };
 template <bool WITH_BIGINT, bool BUFFER_ADDRESSING = true>
 __global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_witness_strands(ScopeDev sc, StrandTab tab) {

@@ -1167,4 +1167,13 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_
     }
 }
 
+// public inputs of every instance of the batch, packed [instance][n_public] (the payload of zk_cs_gather_commitments)
+__global__ void k_pack_public(const uint64_t* __restrict__ outer_store, uint64_t n_store, const uint32_t* __restrict__ slots, uint32_t n_public,
+                              uint32_t n_instances, uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_instances * n_public) return;
+    const uint32_t inst = i / n_public, k = i % n_public;
+    out[i] = outer_store[cell_off(n_store, slots[k], inst)];
+}
+
 }  // namespace zke

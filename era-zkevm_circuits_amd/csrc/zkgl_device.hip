@@ -118,7 +118,7 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
     return LAUNCH_CHECK("k_witness");
 }
 
-int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[8], const uint32_t end[8], void* stream) {
+int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], void* stream) {
     if (sc.n_lanes == 0) return 0;
     static_assert(zke::STRANDS_PER_TILE == (int)STRANDS_PER_TILE, "strand count");
     zke::StrandTab tab;
@@ -166,6 +166,12 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
     if (a.alias) zke::k_check_gates_compact<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
     else zke::k_check_gates<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
     return LAUNCH_CHECK("k_check_gates");
+}
+
+int launch_pack_public(const uint64_t* outer_store, uint64_t n_store, const uint32_t* slots, uint32_t n_public, uint32_t n_instances, uint64_t* out, void* stream) {
+    if (!n_public || !n_instances) return 0;
+    zke::k_pack_public<<<grid_for((size_t)n_public * n_instances, 256), 256, 0, (hipStream_t)stream>>>(outer_store, n_store, slots, n_public, n_instances, out);
+    return LAUNCH_CHECK("k_pack_public");
 }
 
 int launch_materialize(uint64_t* trace, uint64_t n_cells, const uint64_t* store, uint64_t n_store, uint32_t n_lanes, const zk_copy_pair* pairs,
@@ -318,7 +324,7 @@ int launch_seed_cone(const ScopeArgs& sc, const uint32_t* seed_prog, uint32_t n_
     return LAUNCH_CHECK("k_seed_cone");
 }
 
-int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, const uint32_t begin[8], const uint32_t end[8], uint32_t n_slots,
+int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], uint32_t n_slots,
                              uint32_t n_input_words, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, bool v2, void* stream) {
     if (n_instances == 0 || sc.limit == 0) return 0;
     const uint32_t per_lane = n_slots + n_input_words;

@@ -122,6 +122,28 @@ def _ptr(x):
     raise TypeError(f"not a device pointer: {type(x)}")
 
 
+class Comm:
+    """RCCL communicator behind the C ABI (zk_comm_*): one process per GPU; rank 0's `unique_id()` bytes reach the other ranks through
+    the host's launcher (bench.py: a torch.distributed broadcast)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _check(lib().zk_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid: bytes, rank: int, world: int):
+        self._h = C.c_void_p()
+        self.rank, self.world, self._out = rank, world, None
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        _check(lib().zk_comm_create(C.byref(self._h), buf, rank, world))
+
+    def close(self):
+        if self._h:
+            lib().zk_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 class DeviceBuffer:
     """A hipMalloc'd buffer of u64/u32 words owned by Python (zk_malloc / zk_free)."""
 
@@ -549,6 +571,7 @@ class ConstraintSystem:
     # --- execution ---
     def set_batch(self, n_instances: int):
         _check(lib().zk_cs_set_batch(self._h, n_instances))
+        self._batch = int(n_instances)
         self.batch = n_instances
 
     def bind_inputs(self, loop_scope: bool, dev_words, n_words: int, lane_stride: int = 0, lane_offset: int = 0):
@@ -566,6 +589,15 @@ class ConstraintSystem:
     def seed_carried_inputs(self, dev_loop_inputs, stream=None):
         """fill the loop-carried words of the bound loop input stream sequentially on the GPU"""
         _check(lib().zk_cs_seed_carried_inputs(self._h, _ptr(dev_loop_inputs), _ptr(stream)))
+
+    def gather_commitments(self, comm: "Comm", stream=None):
+        """all ranks' public inputs -> u64 [world, batch, n_public] (zk_cs_gather_commitments: one RCCL all-gather)"""
+        n = C.c_uint32(0)
+        if comm._out is None or comm._out.n < comm.world * self._batch * 8:
+            comm._out = DeviceBuffer(comm.world * self._batch * 8)
+        _check(lib().zk_cs_gather_commitments(self._h, comm._h, _ptr(comm._out), C.byref(n), _ptr(stream)))
+        flat = comm._out.to_numpy()[: comm.world * self._batch * n.value]
+        return flat.reshape(comm.world, self._batch, n.value)
 
     def seed_stream(self, n_instances: int, dev_outer_inputs, dev_loop_inputs, stream=None):
         """seed a stream of n_instances (any n, independent of set_batch): outer [word][n], loop [word][n * limit] (zk_cs_seed_stream)"""

@@ -191,6 +191,19 @@ int zk_cs_resolve_and_check(zk_cs *cs, void *stream, zk_failure *first);
 int zk_cs_read_var(zk_cs *cs, zk_var var, uint32_t instance, uint32_t iteration, uint64_t *out); /* witness_hook */
 int zk_cs_write_cell(zk_cs *cs, int loop_scope, uint32_t cell, uint32_t lane, uint64_t value); /* fault injection for tests */
 int zk_cs_public_inputs(zk_cs *cs, uint32_t instance, uint64_t *out, uint32_t max, uint32_t *n);
+/* ---- the path's only collective: instances are sharded across GPUs with no data-path exchange; the 4-element
+ * input commitments of every instance are all-gathered once per step over RCCL / xGMI (32 B per instance: latency-bound).
+ * One process per GPU.  Rank 0 draws the id, the host's launcher distributes it, every rank creates its communicator after
+ * zk_init (the communicator binds to that device).  Replaces nothing in the reference (its circuits are synthesised one at a
+ * time on CPU threads, /root/reference/src/main_vm/mod.rs); it is what a multi-GPU host of this library needs instead. */
+#define ZK_COMM_ID_BYTES 128
+typedef struct zk_comm zk_comm;
+int zk_comm_unique_id(uint8_t id[ZK_COMM_ID_BYTES]);
+int zk_comm_create(zk_comm **out, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int world);
+int zk_comm_destroy(zk_comm *comm);
+/* dev_out[rank][instance][k], k < *n_public (the circuit's public inputs: 4 for every circuit of the path), u64 device buffer of
+ * world * batch * n_public words; every rank holds the same batch size.  Enqueued on `stream`. */
+int zk_cs_gather_commitments(zk_cs *cs, zk_comm *comm, uint64_t *dev_out, uint32_t *n_public, void *stream);
 /* placement query (after finalize, no GPU needed): home cell of a variable / of the public inputs */
 int zk_cs_var_cell(zk_cs *cs, zk_var var, uint32_t *cell);
 int zk_cs_public_cells(zk_cs *cs, uint32_t *cells, uint32_t max, uint32_t *n);

@@ -105,3 +105,24 @@ def test_main_vm_gpu_stream_seeding_and_windows(zk, batch):
         assert ok, (first, f)
         for i in range(W):
             assert cs.public_inputs(i) == commits[first + i], info[first + i]
+
+
+def test_gather_commitments_through_the_c_abi(zk, batch):
+    """zk_comm_* + zk_cs_gather_commitments (RCCL all-gather behind the C ABI) on a one-rank communicator: the gathered
+    [world, batch, 4] words are the public inputs of every instance"""
+    cs, D, outer, loop, commits, info = batch
+    B = 16
+    cs.set_batch(B)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer[:, :B].copy()), zk.DeviceBuffer.from_numpy(loop[:, :B * LIMIT].copy())
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    comm = zk.Comm(zk.Comm.unique_id(), 0, 1)
+    try:
+        got = cs.gather_commitments(comm)
+    finally:
+        comm.close()
+    assert got.shape == (1, B, 4)
+    for i in range(B):
+        assert [int(x) for x in got[0, i]] == commits[i]
