@@ -1,0 +1,151 @@
+// witness_pack.cpp — product-side witness packers + the bincode decoder of include/zkgl_witness.h.  Host-only code (no GPU):
+// structs -> the input-stream words in the order the recorded circuits allocate them (circuits/ram_permutation.cpp).
+#include <cstring>
+#include <string>
+#include "../../include/zkgl.h"
+#include "../../include/zkgl_witness.h"
+
+namespace zkgl { void set_last_error(const std::string& m); }
+
+namespace {
+int bad(int code, const char* m) { zkgl::set_last_error(m); return code; }
+
+struct Cursor {
+    const uint8_t* p; size_t n, at = 0; bool ok = true;
+    bool need(size_t k) { if (!ok || n - at < k) { ok = false; return false; } return true; }
+    uint8_t u8() { if (!need(1)) return 0; return p[at++]; }
+    uint32_t u32() { if (!need(4)) return 0; uint32_t v; std::memcpy(&v, p + at, 4); at += 4; return v; }
+    uint64_t u64() { if (!need(8)) return 0; uint64_t v; std::memcpy(&v, p + at, 8); at += 8; return v; }
+    bool boolean() { const uint8_t b = u8(); if (b > 1) ok = false; return b == 1; }
+    uint64_t field() { const uint64_t v = u64(); if (v >= 0xFFFFFFFF00000001ull) ok = false; return v; }
+    // U256 as impl-serde writes it: a string "0x" + hex digits without leading zeros
+    void u256(uint32_t limbs[8]) {
+        std::memset(limbs, 0, 32);
+        const uint64_t len = u64();
+        if (!ok || len < 3 || len > 66 || !need((size_t)len)) { ok = false; return; }
+        if (p[at] != '0' || p[at + 1] != 'x') { ok = false; return; }
+        const size_t digits = (size_t)len - 2;
+        for (size_t i = 0; i < digits; ++i) {
+            const uint8_t c = p[at + 2 + i];
+            uint32_t d;
+            if (c >= '0' && c <= '9') d = c - '0';
+            else if (c >= 'a' && c <= 'f') d = 10 + c - 'a';
+            else if (c >= 'A' && c <= 'F') d = 10 + c - 'A';
+            else { ok = false; return; }
+            const size_t nib = digits - 1 - i;  // nibble position, least significant = 0
+            limbs[nib / 8] |= d << (4 * (nib % 8));
+        }
+        at += (size_t)len;
+    }
+    void queue_state(zk_full_queue_state_witness& q) {
+        for (auto& x : q.head) x = field();
+        for (auto& x : q.tail) x = field();
+        q.length = u32();
+    }
+    void memory_query(zk_memory_query_witness& m) {
+        m.timestamp = u32(); m.memory_page = u32(); m.index = u32();
+        m.rw_flag = boolean(); m.is_ptr = boolean();
+        u256(m.value);
+    }
+    void ram_fsm(zk_ram_fsm_witness& f) {
+        for (auto& x : f.lhs_accumulator) x = field();
+        for (auto& x : f.rhs_accumulator) x = field();
+        queue_state(f.current_unsorted_queue_state);
+        queue_state(f.current_sorted_queue_state);
+        for (auto& x : f.previous_sorting_key) x = u32();
+        for (auto& x : f.previous_full_key) x = u32();
+        u256(f.previous_value);
+        f.previous_is_ptr = boolean();
+        f.num_nondeterministic_writes = u32();
+    }
+};
+
+void put_queue_state(uint64_t* dst, size_t stride, size_t& w, const zk_full_queue_state_witness& q) {
+    for (auto x : q.head) dst[(w++) * stride] = x;
+    for (auto x : q.tail) dst[(w++) * stride] = x;
+    dst[(w++) * stride] = q.length;
+}
+}  // namespace
+
+extern "C" {
+
+int zk_pack_ram_witness(const zk_ram_permutation_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_ram_witness: bad argument");
+    if (w->n_unsorted != w->n_sorted) return bad(ZK_ERR_INVALID, "zk_pack_ram_witness: the two queue witnesses differ in length");
+    if (w->n_unsorted > limit) return bad(ZK_ERR_INVALID, "zk_pack_ram_witness: more queue elements than cycles");
+    if (w->n_unsorted && (!w->unsorted_queue_witness || !w->sorted_queue_witness)) return bad(ZK_ERR_INVALID, "zk_pack_ram_witness: null queue witness");
+    // ---- outer scope: start_flag, observable input, hidden FSM input (circuits/ram_permutation.cpp allocation order)
+    {
+        uint64_t* o = outer_words + instance;
+        const size_t st = batch;
+        size_t k = 0;
+        o[(k++) * st] = w->start_flag ? 1 : 0;
+        put_queue_state(o, st, k, w->unsorted_queue_initial_state);
+        put_queue_state(o, st, k, w->sorted_queue_initial_state);
+        o[(k++) * st] = w->non_deterministic_bootloader_memory_snapshot_length;
+        const zk_ram_fsm_witness& f = w->hidden_fsm_input;
+        for (auto x : f.lhs_accumulator) o[(k++) * st] = x;
+        for (auto x : f.rhs_accumulator) o[(k++) * st] = x;
+        put_queue_state(o, st, k, f.current_unsorted_queue_state);
+        put_queue_state(o, st, k, f.current_sorted_queue_state);
+        for (auto x : f.previous_sorting_key) o[(k++) * st] = x;
+        for (auto x : f.previous_full_key) o[(k++) * st] = x;
+        for (auto x : f.previous_value) o[(k++) * st] = x;
+        o[(k++) * st] = f.previous_is_ptr ? 1 : 0;
+        o[(k++) * st] = f.num_nondeterministic_writes;
+        if (k != ZK_RAM_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: ram outer layout");
+    }
+    // ---- loop scope: 46 carried words (device seeding), then the popped unsorted and sorted elements of the cycle
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        uint64_t* l = loop_words + (size_t)instance * limit + c;
+        size_t k = 0;
+        for (; k < 46; ++k) l[k * lanes] = 0;
+        for (int side = 0; side < 2; ++side) {
+            const zk_memory_query_witness* q = side == 0 ? w->unsorted_queue_witness : w->sorted_queue_witness;
+            if (c < w->n_unsorted) {
+                const zk_memory_query_witness& m = q[c];
+                l[(k++) * lanes] = m.timestamp; l[(k++) * lanes] = m.memory_page; l[(k++) * lanes] = m.index;
+                l[(k++) * lanes] = m.rw_flag ? 1 : 0; l[(k++) * lanes] = m.is_ptr ? 1 : 0;
+                for (auto x : m.value) l[(k++) * lanes] = x;
+            } else {
+                for (int i = 0; i < 13; ++i) l[(k++) * lanes] = 0;
+            }
+        }
+        if (k != ZK_RAM_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: ram loop layout");
+    }
+    return ZK_OK;
+}
+
+int zk_decode_ram_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_ram_permutation_witness* out, zk_memory_query_witness* unsorted_buf,
+                                  uint32_t unsorted_cap, zk_memory_query_witness* sorted_buf, uint32_t sorted_cap, size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_ram_witness_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    // closed_form_input: start_flag, completion_flag, observable_input, observable_output = () (nothing), hidden_fsm_input, hidden_fsm_output
+    out->start_flag = c.boolean();
+    out->completion_flag = c.boolean();
+    c.queue_state(out->unsorted_queue_initial_state);
+    c.queue_state(out->sorted_queue_initial_state);
+    out->non_deterministic_bootloader_memory_snapshot_length = c.u32();
+    c.ram_fsm(out->hidden_fsm_input);
+    c.ram_fsm(out->hidden_fsm_output);
+    for (int side = 0; side < 2 && c.ok; ++side) {
+        const uint64_t n = c.u64();  // VecDeque length
+        zk_memory_query_witness* buf = side == 0 ? unsorted_buf : sorted_buf;
+        const uint32_t cap = side == 0 ? unsorted_cap : sorted_cap;
+        if (!c.ok) break;
+        if (n > cap || (n && !buf)) return bad(ZK_ERR_CAPACITY, "zk_decode_ram_witness_bincode: queue witness longer than the caller's buffer");
+        for (uint64_t i = 0; i < n && c.ok; ++i) {
+            c.memory_query(buf[i]);
+            for (int t = 0; t < 12; ++t) c.field();  // the queue tail before the push: not consumed by the circuit
+        }
+        if (side == 0) { out->unsorted_queue_witness = buf; out->n_unsorted = (uint32_t)n; }
+        else { out->sorted_queue_witness = buf; out->n_sorted = (uint32_t)n; }
+    }
+    if (!c.ok) return bad(ZK_ERR_INVALID, "zk_decode_ram_witness_bincode: truncated or malformed input");
+    if (consumed) *consumed = c.at;
+    return ZK_OK;
+}
+
+}  // extern "C"

@@ -122,6 +122,54 @@ def _ptr(x):
     raise TypeError(f"not a device pointer: {type(x)}")
 
 
+# ---- product-side witness packers (include/zkgl_witness.h)
+class MemoryQueryWitness(C.Structure):
+    _fields_ = [("timestamp", C.c_uint32), ("memory_page", C.c_uint32), ("index", C.c_uint32), ("rw_flag", C.c_uint8), ("is_ptr", C.c_uint8),
+                ("value", C.c_uint32 * 8)]
+
+
+class FullQueueStateWitness(C.Structure):
+    _fields_ = [("head", C.c_uint64 * 12), ("tail", C.c_uint64 * 12), ("length", C.c_uint32)]
+
+
+class RamFsmWitness(C.Structure):
+    _fields_ = [("lhs_accumulator", C.c_uint64 * 2), ("rhs_accumulator", C.c_uint64 * 2),
+                ("current_unsorted_queue_state", FullQueueStateWitness), ("current_sorted_queue_state", FullQueueStateWitness),
+                ("previous_sorting_key", C.c_uint32 * 3), ("previous_full_key", C.c_uint32 * 2), ("previous_value", C.c_uint32 * 8),
+                ("previous_is_ptr", C.c_uint8), ("num_nondeterministic_writes", C.c_uint32)]
+
+
+class RamPermutationWitness(C.Structure):
+    _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8),
+                ("unsorted_queue_initial_state", FullQueueStateWitness), ("sorted_queue_initial_state", FullQueueStateWitness),
+                ("non_deterministic_bootloader_memory_snapshot_length", C.c_uint32),
+                ("hidden_fsm_input", RamFsmWitness), ("hidden_fsm_output", RamFsmWitness),
+                ("unsorted_queue_witness", C.POINTER(MemoryQueryWitness)), ("n_unsorted", C.c_uint32),
+                ("sorted_queue_witness", C.POINTER(MemoryQueryWitness)), ("n_sorted", C.c_uint32)]
+
+
+RAM_OUTER_WORDS, RAM_LOOP_WORDS = 121, 72
+
+
+def pack_ram_witness(w: RamPermutationWitness, limit: int, instance: int, outer: np.ndarray, loop: np.ndarray):
+    """zk_pack_ram_witness: one instance into the host staging arrays outer [121, B], loop [72, B * limit] (C-contiguous u64)"""
+    batch = outer.shape[1]
+    assert outer.shape == (RAM_OUTER_WORDS, batch) and loop.shape == (RAM_LOOP_WORDS, batch * limit)
+    assert outer.dtype == np.uint64 and loop.dtype == np.uint64 and outer.flags.c_contiguous and loop.flags.c_contiguous
+    _check(lib().zk_pack_ram_witness(C.byref(w), limit, instance, batch, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
+
+
+def decode_ram_witness_bincode(data: bytes, max_elements: int):
+    """zk_decode_ram_witness_bincode -> (RamPermutationWitness, bytes consumed); the element arrays stay referenced by the result"""
+    w = RamPermutationWitness()
+    ub, sb = (MemoryQueryWitness * max(max_elements, 1))(), (MemoryQueryWitness * max(max_elements, 1))()
+    used = C.c_size_t(0)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    _check(lib().zk_decode_ram_witness_bincode(buf, C.c_size_t(len(data)), C.byref(w), ub, max_elements, sb, max_elements, C.byref(used)))
+    w._keep = (ub, sb)
+    return w, used.value
+
+
 class Comm:
     """RCCL communicator behind the C ABI (zk_comm_*): one process per GPU; rank 0's `unique_id()` bytes reach the other ranks through
     the host's launcher (bench.py: a torch.distributed broadcast)."""

@@ -1,0 +1,80 @@
+/*
+ * zkgl_witness.h — product-side witness packers: the reference's per-circuit witness structs as plain C structs, turned into the
+ * input streams the recorded circuits consume.  The host fills the structs (or decodes them from the
+ * bincode bytes the reference's witness generator emits), the packer writes one instance's words into the host staging arrays of a
+ * batch, the arrays are copied to the device and bound with zk_cs_bind_inputs; the loop-carried words are left zero and filled on
+ * the device by zk_cs_seed_carried_inputs / zk_cs_seed_stream.
+ *
+ * Stream layouts (words are u64, canonical Goldilocks values): outer scope words[w * batch + instance];
+ * loop scope words[w * (batch * limit) + instance * limit + cycle].
+ */
+#ifndef ZKGL_WITNESS_H
+#define ZKGL_WITNESS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MemoryQueryWitness, /root/reference/src/base_structures/memory_query/mod.rs:30-37 (value: UInt256 as 8 little-endian u32 limbs) */
+typedef struct zk_memory_query_witness {
+    uint32_t timestamp, memory_page, index;
+    uint8_t rw_flag, is_ptr;
+    uint32_t value[8];
+} zk_memory_query_witness;
+
+/* QueueStateWitness<F, FULL_SPONGE_QUEUE_STATE_WIDTH = 12>: head, tail.tail, tail.length ([EXT] boojum gadgets::queue) */
+typedef struct zk_full_queue_state_witness {
+    uint64_t head[12];
+    uint64_t tail[12];
+    uint32_t length;
+} zk_full_queue_state_witness;
+
+/* RamPermutationFSMInputOutput witness, /root/reference/src/ram_permutation/input.rs:53-63 */
+typedef struct zk_ram_fsm_witness {
+    uint64_t lhs_accumulator[2], rhs_accumulator[2];
+    zk_full_queue_state_witness current_unsorted_queue_state, current_sorted_queue_state;
+    uint32_t previous_sorting_key[3];
+    uint32_t previous_full_key[2];
+    uint32_t previous_value[8];
+    uint8_t previous_is_ptr;
+    uint32_t num_nondeterministic_writes;
+} zk_ram_fsm_witness;
+
+/* RamPermutationCircuitInstanceWitness, /root/reference/src/ram_permutation/input.rs:99-117: closed_form_input (start_flag,
+ * completion_flag, observable_input = RamPermutationInputData :28-32, observable_output = (), hidden_fsm_input, hidden_fsm_output,
+ * /root/reference/src/fsm_input_output/mod.rs:42-47), then the two queue witnesses: the elements in pop order (the previous-tail
+ * half of every (element, tail) pair is not consumed by the circuit: the pops re-derive the heads) */
+typedef struct zk_ram_permutation_witness {
+    uint8_t start_flag, completion_flag;
+    zk_full_queue_state_witness unsorted_queue_initial_state, sorted_queue_initial_state;
+    uint32_t non_deterministic_bootloader_memory_snapshot_length;
+    zk_ram_fsm_witness hidden_fsm_input, hidden_fsm_output;
+    const zk_memory_query_witness *unsorted_queue_witness; uint32_t n_unsorted;
+    const zk_memory_query_witness *sorted_queue_witness; uint32_t n_sorted;
+} zk_ram_permutation_witness;
+
+#define ZK_RAM_OUTER_WORDS 121
+#define ZK_RAM_LOOP_WORDS 72
+/* One instance of ram_permutation_entry_point (/root/reference/src/ram_permutation/mod.rs:31-382) into the batch's host staging
+ * arrays: outer_words[ZK_RAM_OUTER_WORDS][batch], loop_words[ZK_RAM_LOOP_WORDS][batch * limit].  The 46 loop-carried words of every
+ * cycle are zeroed (device seeding fills them); cycles past the queue length get the zero item, as the reference's
+ * `pop_front().unwrap_or_default()` does.  ZK_ERR_INVALID: more elements than `limit`, lengths of the two queues differ. */
+int zk_pack_ram_witness(const zk_ram_permutation_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                        uint64_t *outer_words, uint64_t *loop_words);
+
+/* bincode 1.x (little-endian, fixed-width integers, u64 sequence lengths) of RamPermutationCircuitInstanceWitness in the field
+ * order above.  [EXT] parts — not visible in /root/reference, restated from the crates' public behaviour and marked "unpinned" in
+ * a field element is its canonical u64; QueueStateWitness = head[12], tail[12], length u32; a queue witness is
+ * `elements: VecDeque<(MemoryQueryWitness, [F; 12])>`; U256 (ethereum-types with impl-serde) is a string: u64 length, then "0x" and
+ * the hex digits without leading zeros ("0x0" for zero).
+ * The element arrays are caller-owned (capacity in elements); *consumed = bytes read.  ZK_ERR_INVALID on truncated / malformed
+ * input, ZK_ERR_CAPACITY when a queue holds more elements than its buffer. */
+int zk_decode_ram_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_ram_permutation_witness *out,
+                                  zk_memory_query_witness *unsorted_buf, uint32_t unsorted_cap,
+                                  zk_memory_query_witness *sorted_buf, uint32_t sorted_cap, size_t *consumed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

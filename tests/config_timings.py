@@ -26,7 +26,8 @@ def timed(name, cs, outer, loop, batch, seed_carried=0):
     st = cs.stats()
     print(json.dumps({"config": name, "instances": batch, "rows_per_instance": st["rows_per_instance"], "constraints_per_instance": st["constraints_per_instance"],
                       "step_ms": round(1e3 * dt, 2), "constraints_per_s": round(batch * st["constraints_per_instance"] / dt), "rows_per_s": round(batch * st["rows_per_instance"] / dt),
-                      "k_witness_loop_ms": round(cs.last_ms(1), 2), "seed_s": None if t_seed is None else round(t_seed, 3)}), flush=True)
+                      "k_witness_loop_ms": round(cs.last_ms(1), 2), "seed_s": None if t_seed is None else round(t_seed, 3),
+                      "values_GBps_loop_kernel": round(batch * st["limit"] * st["cells_written_loop"] * 8 / (cs.last_ms(1) * 1e-3) / 1e9, 1) if cs.last_ms(1) > 0 else None}), flush=True)
 
 
 rng = np.random.default_rng(1)
@@ -62,12 +63,16 @@ if want("C4s"):
     inst = sn.instance(u, s, limit)
     outer, loop = sn.pack_streams([inst] * 4, limit)
     timed("C4 storage_validity 2^22 rows", cs, outer, loop, 4)
+    o1, l1 = sn.pack_streams([inst], limit)
+    timed("C4 storage_validity 2^22 rows, ONE instance (one GPU of BASELINE's 4)", cs, o1, l1, 1)
 if want("C4l"):
     cs, limit = T.fit(lambda c: c.configure_log_sorter(), lambda c, l: c.sort_and_deduplicate_events_entry_point(l), 22)
     u, s = ln.random_events(np.random.default_rng(0xC4 + 1), int(limit / 1.1) - 8, rollback_frac=0.1)
     inst = ln.instance(u, s, limit)
     outer, loop = ln.pack_streams([inst] * 4, limit)
     timed("C4 log_sorter 2^22 rows", cs, outer, loop, 4)
+    o1, l1 = ln.pack_streams([inst], limit)
+    timed("C4 log_sorter 2^22 rows, ONE instance", cs, o1, l1, 1)
 # C5: 8 blobs (BASELINE: one per GPU)
 if want("C5"):
     cs = zkgl.ConstraintSystem(zkgl.CSGeometry(60, 0, 8, 4), 1 << 21, 1 << 28)

@@ -57,3 +57,61 @@ def test_two_rank_sharding_and_commitment_gather():
     for r in range(world):
         for j, i in enumerate(range(r, n_total, world)):
             assert [int(x) for x in allc[r, j]] == insts[i]["commitment"]
+
+
+# ---- the same on the GPU: every rank drives libzkgl (the product path) on the visible device; the two ranks of this test share one
+# GPU, where RCCL refuses duplicate devices, so the gather here is the gloo face of zkgl.dist — the RCCL collective behind the C ABI
+# (zk_cs_gather_commitments) is covered by tests/test_gpu_main_vm.py on a one-rank communicator and by bench.py --gpus N.
+import pytest  # noqa: E402
+
+
+def _gpu_worker(rank, world, port, n_total, limit, q):
+    for p in (ROOT, os.path.join(ROOT, "era-zkevm_circuits_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import zkgl
+    from helpers import ram_cs, random_instances
+    from oracle import ram_native as rn
+    from zkgl.dist import gather_commitments, shard_instances
+
+    zkgl.init(0)
+    insts = random_instances(77, n_total, 5, limit)
+    mine = shard_instances(n_total, rank, world)
+    cs = ram_cs(limit)
+    outer, loop = rn.pack_streams([insts[i] for i in mine], limit)
+    cs.set_batch(len(mine))
+    d_o, d_l = zkgl.DeviceBuffer.from_numpy(outer), zkgl.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    ok, failure = cs.resolve_and_check()
+    assert ok, failure
+    local = np.array([cs.public_inputs(j) for j in range(len(mine))], dtype=np.uint64)
+    allc = gather_commitments(local)
+    if rank == 0:
+        q.put(allc.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_drive_libzkgl_on_the_gpu():
+    n_total, limit, world = 6, 8, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n_total, limit, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    allc = np.array(q.get(timeout=300), dtype=np.uint64)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import random_instances
+    insts = random_instances(77, n_total, 5, limit)
+    for r in range(world):
+        for j, i in enumerate(range(r, n_total, world)):
+            assert [int(x) for x in allc[r, j]] == insts[i]["commitment"]

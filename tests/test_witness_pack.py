@@ -1,0 +1,152 @@
+"""Product-side witness packers (include/zkgl_witness.h): the streams of ram_permutation built THROUGH THE C ABI
+from the reference's witness struct (and from its bincode bytes) must equal what the oracle's packer builds from the same witness;
+on the GPU the C-ABI-built streams are seeded, resolved and satisfied, with the oracle's commitment.  The oracle packer
+(oracle/ram_native.py) is only the comparison here."""
+import struct
+
+import numpy as np
+import pytest
+
+import zkgl
+from oracle import ram_native as rn
+
+LIMIT = 24
+
+
+def _qstate(head, tail, length):
+    q = zkgl.FullQueueStateWitness()
+    q.head[:] = [int(x) for x in head]
+    q.tail[:] = [int(x) for x in tail]
+    q.length = int(length)
+    return q
+
+
+def _fsm(f):
+    w = zkgl.RamFsmWitness()
+    w.lhs_accumulator[:] = f["lhs"]; w.rhs_accumulator[:] = f["rhs"]
+    w.current_unsorted_queue_state = _qstate(f["unsorted"][0:12], f["unsorted"][12:24], f["unsorted"][24])
+    w.current_sorted_queue_state = _qstate(f["sorted"][0:12], f["sorted"][12:24], f["sorted"][24])
+    w.previous_sorting_key[:] = f["prev_sorting_key"]; w.previous_full_key[:] = f["prev_full_key"]
+    w.previous_value[:] = f["prev_value"]; w.previous_is_ptr = int(f["prev_is_ptr"]); w.num_nondeterministic_writes = int(f["nondet"])
+    return w
+
+
+def _queries(items):
+    arr = (zkgl.MemoryQueryWitness * max(len(items), 1))()
+    for a, it in zip(arr, items):
+        a.timestamp, a.memory_page, a.index, a.rw_flag, a.is_ptr = it[0], it[1], it[2], it[3], it[4]
+        a.value[:] = it[5:13]
+    return arr
+
+
+def witness_struct(inst, unsorted, sorted_, nondet, fsm_in):
+    w = zkgl.RamPermutationWitness()
+    w.start_flag, w.completion_flag = 1, int(inst["completed"])
+    ou, os_ = inst["obs_unsorted"], inst["obs_sorted"]
+    w.unsorted_queue_initial_state = _qstate(ou[0:12], ou[12:24], ou[24])
+    w.sorted_queue_initial_state = _qstate(os_[0:12], os_[12:24], os_[24])
+    w.non_deterministic_bootloader_memory_snapshot_length = nondet
+    w.hidden_fsm_input, w.hidden_fsm_output = _fsm(fsm_in), _fsm(inst["fsm_out"])
+    ua, sa = _queries(unsorted), _queries(sorted_)
+    w.unsorted_queue_witness, w.n_unsorted, w.sorted_queue_witness, w.n_sorted = ua, len(unsorted), sa, len(sorted_)
+    w._keep = (ua, sa)
+    return w
+
+
+# ---- a bincode 1.x writer for the same struct (test side): the decoder under test is the C one
+def _b_u256(limbs):
+    v = sum(int(x) << (32 * i) for i, x in enumerate(limbs))
+    s = ("0x%x" % v).encode()
+    return struct.pack("<Q", len(s)) + s
+
+
+def _b_qstate(q):
+    return b"".join(struct.pack("<Q", int(x)) for x in list(q.head) + list(q.tail)) + struct.pack("<I", q.length)
+
+
+def _b_fsm(f):
+    return (b"".join(struct.pack("<Q", int(x)) for x in list(f.lhs_accumulator) + list(f.rhs_accumulator)) + _b_qstate(f.current_unsorted_queue_state) +
+            _b_qstate(f.current_sorted_queue_state) + b"".join(struct.pack("<I", int(x)) for x in list(f.previous_sorting_key) + list(f.previous_full_key)) +
+            _b_u256(f.previous_value) + struct.pack("<B", f.previous_is_ptr) + struct.pack("<I", f.num_nondeterministic_writes))
+
+
+def bincode_bytes(w, tails_u, tails_s):
+    out = struct.pack("<BB", w.start_flag, w.completion_flag) + _b_qstate(w.unsorted_queue_initial_state) + _b_qstate(w.sorted_queue_initial_state)
+    out += struct.pack("<I", w.non_deterministic_bootloader_memory_snapshot_length) + _b_fsm(w.hidden_fsm_input) + _b_fsm(w.hidden_fsm_output)
+    for q, n, tails in ((w.unsorted_queue_witness, w.n_unsorted, tails_u), (w.sorted_queue_witness, w.n_sorted, tails_s)):
+        out += struct.pack("<Q", n)
+        for i in range(n):
+            m = q[i]
+            out += struct.pack("<IIIBB", m.timestamp, m.memory_page, m.index, m.rw_flag, m.is_ptr) + _b_u256(m.value)
+            out += b"".join(struct.pack("<Q", int(x)) for x in tails[i])
+    return out
+
+
+def _case(seed, n_items):
+    rng = np.random.default_rng(seed)
+    u, s, nd = rn.random_ram_witness(rng, n_items, n_cells=6)
+    inst = rn.instance(u, s, LIMIT, nd)
+    return u, s, nd, inst
+
+
+def _expected(insts):
+    outer, loop = rn.pack_streams(insts, LIMIT)
+    loop = loop.copy()
+    loop[0:46] = 0          # the packer leaves the carried words to the device seeding
+    return outer, loop
+
+
+def test_ram_packer_equals_the_oracle_packer():
+    cases = [_case(100 + i, n) for i, n in enumerate((LIMIT, LIMIT - 5, 1))]
+    B = len(cases)
+    outer = np.zeros((zkgl.RAM_OUTER_WORDS, B), dtype=np.uint64)
+    loop = np.full((zkgl.RAM_LOOP_WORDS, B * LIMIT), 0xDEAD, dtype=np.uint64)
+    for i, (u, s, nd, inst) in enumerate(cases):
+        zkgl.pack_ram_witness(witness_struct(inst, u, s, nd, rn.empty_fsm()), LIMIT, i, outer, loop)
+    eo, el = _expected([c[3] for c in cases])
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+def test_ram_bincode_round_trip_and_errors():
+    u, s, nd, inst = _case(7, LIMIT - 2)
+    w = witness_struct(inst, u, s, nd, rn.empty_fsm())
+    ub, sb = inst["heads"]
+    data = bincode_bytes(w, ub, sb)
+    d, used = zkgl.decode_ram_witness_bincode(data + b"tail", LIMIT)
+    assert used == len(data)
+    outer = np.zeros((zkgl.RAM_OUTER_WORDS, 1), dtype=np.uint64)
+    loop = np.zeros((zkgl.RAM_LOOP_WORDS, LIMIT), dtype=np.uint64)
+    zkgl.pack_ram_witness(d, LIMIT, 0, outer, loop)
+    eo, el = _expected([inst])
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+    with pytest.raises(zkgl.ZkError):
+        zkgl.decode_ram_witness_bincode(data[:-9], LIMIT)          # truncated
+    with pytest.raises(zkgl.ZkError):
+        zkgl.decode_ram_witness_bincode(data, LIMIT - 10)          # more elements than the caller's buffers
+    with pytest.raises(zkgl.ZkError):
+        zkgl.pack_ram_witness(d, LIMIT - 10, 0, np.zeros((121, 1), dtype=np.uint64), np.zeros((72, LIMIT - 10), dtype=np.uint64))
+
+
+@pytest.mark.gpu
+def test_ram_streams_built_through_the_c_abi_run_on_the_gpu(zk):
+    from helpers import ram_cs
+    cases = [_case(300 + i, n) for i, n in enumerate((LIMIT, LIMIT - 7, LIMIT - 1, 3))]
+    B = len(cases)
+    outer = np.zeros((zkgl.RAM_OUTER_WORDS, B), dtype=np.uint64)
+    loop = np.zeros((zkgl.RAM_LOOP_WORDS, B * LIMIT), dtype=np.uint64)
+    for i, (u, s, nd, inst) in enumerate(cases):
+        ub, sb = inst["heads"]
+        w, _ = zkgl.decode_ram_witness_bincode(bincode_bytes(witness_struct(inst, u, s, nd, rn.empty_fsm()), ub, sb), LIMIT)
+        zkgl.pack_ram_witness(w, LIMIT, i, outer, loop)
+    cs = ram_cs(LIMIT)
+    cs.set_batch(B)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    cs.seed_carried_inputs(d_l)
+    full_o, full_l = rn.pack_streams([c[3] for c in cases], LIMIT)
+    assert np.array_equal(d_l.to_numpy().reshape(loop.shape), full_l), "device-seeded carried words differ from the native restatement"
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, c in enumerate(cases):
+        assert cs.public_inputs(i) == c[3]["commitment"]
