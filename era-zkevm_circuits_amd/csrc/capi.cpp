@@ -344,6 +344,13 @@ int zk_cs_read_var(zk_cs* cs, zk_var var, uint32_t instance, uint32_t iteration,
     NEED(cs); NEED(out);
     return guard([&] { *out = cs->cs->read_var(var, instance, iteration); });
 }
+int zk_cs_hook_compare_witness(zk_cs* cs, const zk_var* vars, uint32_t n_vars, const uint64_t* dev_expected, void* stream, zk_failure* first) {
+    NEED(cs); NEED_INIT();
+    int result = ZK_OK;
+    int rc = guard([&] { result = cs->cs->hook_compare_witness(vars, n_vars, dev_expected, stream, first); });
+    if (rc) return rc;
+    return result == ZK_OK ? ZK_OK : fail(ZK_ERR_UNSATISFIED, "circuit values differ from the expected closed-form input");
+}
 int zk_cs_write_cell(zk_cs* cs, int loop_scope, uint32_t cell, uint32_t lane, uint64_t value) {
     NEED(cs);
     return guard([&] { cs->cs->write_cell(loop_scope != 0, cell, lane, value); });
@@ -453,6 +460,14 @@ int zk_circuit_ram_permutation_configure(zk_cs* cs) {
 int zk_circuit_ram_permutation(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { zkgl::ram_permutation_entry_point(*cs->cs, limit); });
+}
+int zk_circuit_hook_vars(zk_cs* cs, const char* name, zk_var* vars, uint32_t max, uint32_t* n) {
+    NEED(cs); NEED(name); NEED(n);
+    auto it = cs->cs->hooks.find(name);
+    if (it == cs->cs->hooks.end()) return fail(ZK_ERR_INVALID, std::string("the recorded circuit publishes no hook group named ") + name);
+    *n = (uint32_t)it->second.size();
+    if (vars) for (uint32_t i = 0; i < std::min<uint32_t>(max, *n); ++i) vars[i] = it->second[i];
+    return ZK_OK;
 }
 int zk_circuit_input_words(zk_cs* cs, uint32_t* outer_words, uint32_t* loop_words) {
     NEED(cs); NEED(outer_words); NEED(loop_words);

@@ -383,6 +383,7 @@ void ram_permutation_entry_point(CS& cs, uint32_t limit) {
 
     // ClosedFormInputCompactForm::from_full_form (src/fsm_input_output/mod.rs:178-253); c_obs_in / c_fsm_in: side phase
     auto c_obs_out = g.commit_encoding({});  // observable_output = ()
+    cs.hooks["hidden_fsm_output"] = fsm_out;  // zk_cs_hook_compare_witness (src/fsm_input_output/mod.rs:102-133)
     auto c_fsm_out = g.commit_encoding(fsm_out);
     Num zero_num = g.num_const(0);
     std::vector<zk_var> compact = {start_flag.v, completed.v};

@@ -1862,6 +1862,28 @@ void CS::write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t valu
     hip_check(hipMemcpy(s.d_cells + tiled_offset(s.n_cells, cell, lane), &value, 8, hipMemcpyHostToDevice), "write_cell memcpy");
 }
 
+int CS::hook_compare_witness(const zk_var* vars, uint32_t n_vars, const uint64_t* dev_expected, void* stream, zk_failure* first) {
+    if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "hook_compare_witness before set_batch");
+    if (!vars || !n_vars || !dev_expected) throw ZkError(ZK_ERR_INVALID, "hook_compare_witness: null argument");
+    std::vector<uint32_t> slots;
+    for (uint32_t i = 0; i < n_vars; ++i) {
+        if (is_loop_var(vars[i])) throw ZkError(ZK_ERR_INVALID, "hook_compare_witness: the closed-form input lives in the outer scope");
+        if (var_index(vars[i]) >= outer_.n_vars) throw ZkError(ZK_ERR_INVALID, "hook_compare_witness: variable out of range");
+        slots.push_back(outer_.var_slot[var_index(vars[i])]);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* d_slots = upload(slots);
+    hip_check(hipMemsetAsync(d_fail_, 0xff, sizeof(unsigned long long), st), "memset fail");
+    dev_check(zkdev::launch_hook_compare(outer_.d_store, outer_.n_store, d_slots, n_vars, batch_, dev_expected, d_fail_, st));
+    unsigned long long f = 0;
+    hip_check(hipMemcpyAsync(&f, d_fail_, sizeof f, hipMemcpyDeviceToHost, st), "memcpy fail");
+    hip_check(hipStreamSynchronize(st), "hook sync");
+    hipFree(d_slots);
+    if (f == ~0ull) return ZK_OK;
+    if (first) { std::memset(first, 0, sizeof *first); first->instance = (uint32_t)(f >> 32); first->slot = (uint32_t)f; first->kind = ZK_FAILURE_HOOK_DIFF; }
+    return ZK_ERR_UNSATISFIED;
+}
+
 uint32_t CS::pack_public_inputs(uint64_t* dev_out, void* stream) {
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "pack_public_inputs before set_batch");
     const uint32_t n = (uint32_t)public_vars_.size();

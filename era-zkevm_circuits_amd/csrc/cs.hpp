@@ -175,6 +175,8 @@ class CS {
     void bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words, uint64_t lane_stride = 0);
     // public inputs of the whole batch packed on the device: out[instance * n_public + k]; returns n_public
     uint32_t pack_public_inputs(uint64_t* dev_out, void* stream);
+    // 0 equal; ZK_ERR_UNSATISFIED + first difference (scope 0, instance, slot = position in `vars`, kind = ZK_FAILURE_HOOK_DIFF)
+    int hook_compare_witness(const zk_var* vars, uint32_t n_vars, const uint64_t* dev_expected, void* stream, zk_failure* first);
     uint32_t batch() const { return batch_; }
     void seed_stream(uint32_t n_instances, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream);
     void resolve(void* stream);
@@ -207,6 +209,8 @@ class CS {
     // description of the input streams the recorded circuit reads (zk_circuit_main_vm_layout)
     std::vector<uint8_t> circuit_blob;
     std::string input_layout;
+    // closed-form-input variable groups a circuit publishes for zk_cs_hook_compare_witness ("hidden_fsm_output", ...)
+    std::map<std::string, std::vector<zk_var>> hooks;
 
     const zk_geometry& geometry() const { return geo_; }
     bool in_loop() const { return in_loop_; }

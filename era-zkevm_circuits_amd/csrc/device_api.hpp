@@ -38,6 +38,8 @@ int launch_execution_context_encode(const uint64_t* rec, size_t n, uint64_t* enc
 int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint64_t* ch, size_t enc_len, size_t n,
                          uint64_t init, uint64_t* acc, uint64_t* scratch, void* stream);
 int launch_pack_public(const uint64_t* outer_store, uint64_t n_store, const uint32_t* slots, uint32_t n_public, uint32_t n_instances, uint64_t* out, void* stream);
+int launch_hook_compare(const uint64_t* outer_store, uint64_t n_store, const uint32_t* slots, uint32_t n_vars, uint32_t n_instances, const uint64_t* expected,
+                        unsigned long long* fail, void* stream);
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, void* stream);
 // strand mode (kernels_engine.hpp k_witness_strands): sc.prog = the strand program, begin/end = 8 word ranges
 #ifndef ZKGL_STRANDS_PER_TILE

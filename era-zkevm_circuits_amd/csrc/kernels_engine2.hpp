@@ -1176,4 +1176,16 @@ __global__ void k_pack_public(const uint64_t* __restrict__ outer_store, uint64_t
     out[i] = outer_store[cell_off(n_store, slots[k], inst)];
 }
 
+// hook_compare_witness (/root/reference/src/fsm_input_output/mod.rs:102-133) on the device: the circuit's values of a list of outer
+// variables (the closed-form input: hidden_fsm_output, observable_output ...) against the host's expectation [n_vars][n_instances];
+// the first difference (lowest instance, then lowest position) is reported through the packed failure key of the checkers
+__global__ void k_hook_compare(const uint64_t* __restrict__ outer_store, uint64_t n_store, const uint32_t* __restrict__ slots, uint32_t n_vars,
+                               uint32_t n_instances, const uint64_t* __restrict__ expected, unsigned long long* fail) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_instances * n_vars) return;
+    const uint32_t inst = i / n_vars, k = i % n_vars;
+    if (outer_store[cell_off(n_store, slots[k], inst)] != expected[(size_t)k * n_instances + inst])
+        atomicMin(fail, ((unsigned long long)inst << 32) | k);
+}
+
 }  // namespace zke

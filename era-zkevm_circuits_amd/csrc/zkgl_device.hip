@@ -174,6 +174,13 @@ int launch_pack_public(const uint64_t* outer_store, uint64_t n_store, const uint
     return LAUNCH_CHECK("k_pack_public");
 }
 
+int launch_hook_compare(const uint64_t* outer_store, uint64_t n_store, const uint32_t* slots, uint32_t n_vars, uint32_t n_instances, const uint64_t* expected,
+                        unsigned long long* fail, void* stream) {
+    if (!n_vars || !n_instances) return 0;
+    zke::k_hook_compare<<<grid_for((size_t)n_vars * n_instances, 256), 256, 0, (hipStream_t)stream>>>(outer_store, n_store, slots, n_vars, n_instances, expected, fail);
+    return LAUNCH_CHECK("k_hook_compare");
+}
+
 int launch_materialize(uint64_t* trace, uint64_t n_cells, const uint64_t* store, uint64_t n_store, uint32_t n_lanes, const zk_copy_pair* pairs,
                        uint32_t n_pairs, void* stream) {
     if (n_lanes == 0 || n_pairs == 0) return 0;

@@ -647,6 +647,24 @@ class ConstraintSystem:
         flat = comm._out.to_numpy()[: comm.world * self._batch * n.value]
         return flat.reshape(comm.world, self._batch, n.value)
 
+    def hook_vars(self, name: str):
+        n = C.c_uint32(0)
+        _check(lib().zk_circuit_hook_vars(self._h, name.encode(), None, 0, C.byref(n)))
+        arr = (C.c_uint32 * n.value)()
+        _check(lib().zk_circuit_hook_vars(self._h, name.encode(), arr, n.value, C.byref(n)))
+        return list(arr)
+
+    def hook_compare_witness(self, vars_, dev_expected, stream=None):
+        """(True, None) when the circuit's values of `vars_` equal dev_expected [len(vars_), batch]; else (False, (instance, position))"""
+        f = _Failure()
+        arr = (C.c_uint32 * len(vars_))(*vars_)
+        rc = lib().zk_cs_hook_compare_witness(self._h, arr, len(vars_), _ptr(dev_expected), _ptr(stream), C.byref(f))
+        if rc == 0:
+            return True, None
+        if rc == -5:
+            return False, (f.instance, f.slot)
+        _check(rc)
+
     def seed_stream(self, n_instances: int, dev_outer_inputs, dev_loop_inputs, stream=None):
         """seed a stream of n_instances (any n, independent of set_batch): outer [word][n], loop [word][n * limit] (zk_cs_seed_stream)"""
         _check(lib().zk_cs_seed_stream(self._h, n_instances, _ptr(dev_outer_inputs), _ptr(dev_loop_inputs), _ptr(stream)))

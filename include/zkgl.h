@@ -189,6 +189,14 @@ int zk_cs_check_satisfied(zk_cs *cs, void *stream, zk_failure *first);
  * concurrently with the loop-scope kernels.  Same result contract as zk_cs_check_satisfied. */
 int zk_cs_resolve_and_check(zk_cs *cs, void *stream, zk_failure *first);
 int zk_cs_read_var(zk_cs *cs, zk_var var, uint32_t instance, uint32_t iteration, uint64_t *out); /* witness_hook */
+/* hook_compare_witness (/root/reference/src/fsm_input_output/mod.rs:102-133) as a device-side diff: the circuit's values of the outer
+ * variables `vars` (the closed-form input the host cares about: hidden_fsm_output, observable_output ...; recorded handles) against
+ * dev_expected[k * batch + instance].  0 when equal; ZK_ERR_UNSATISFIED and *first = {instance, slot = position k in `vars`,
+ * kind = ZK_FAILURE_HOOK_DIFF} of the first difference (the reference panics with the pretty-printed diff). */
+/* the variable groups a recorded circuit publishes for the comparison, by the reference's field name ("hidden_fsm_output"); *n = group size */
+int zk_circuit_hook_vars(zk_cs *cs, const char *name, zk_var *vars, uint32_t max, uint32_t *n);
+#define ZK_FAILURE_HOOK_DIFF 0xfeu
+int zk_cs_hook_compare_witness(zk_cs *cs, const zk_var *vars, uint32_t n_vars, const uint64_t *dev_expected, void *stream, zk_failure *first);
 int zk_cs_write_cell(zk_cs *cs, int loop_scope, uint32_t cell, uint32_t lane, uint64_t value); /* fault injection for tests */
 int zk_cs_public_inputs(zk_cs *cs, uint32_t instance, uint64_t *out, uint32_t max, uint32_t *n);
 /* ---- the path's only collective: instances are sharded across GPUs with no data-path exchange; the 4-element

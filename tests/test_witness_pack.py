@@ -150,3 +150,26 @@ def test_ram_streams_built_through_the_c_abi_run_on_the_gpu(zk):
     assert ok, f
     for i, c in enumerate(cases):
         assert cs.public_inputs(i) == c[3]["commitment"]
+
+
+@pytest.mark.gpu
+def test_hook_compare_witness_on_the_device(zk):
+    """zk_cs_hook_compare_witness: the circuit's hidden_fsm_output against the expectation (here: the native restatement's), equal for
+    the true witness, first difference (instance, position) for a tampered expectation"""
+    from helpers import ram_cs
+    cases = [_case(500 + i, n) for i, n in enumerate((LIMIT, LIMIT - 3, 5))]
+    B = len(cases)
+    outer, loop = rn.pack_streams([c[3] for c in cases], LIMIT)
+    cs = ram_cs(LIMIT)
+    cs.set_batch(B)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
+    cs.resolve()
+    hv = cs.hook_vars("hidden_fsm_output")
+    expected = np.array([rn.flatten_fsm(c[3]["fsm_out"]) for c in cases], dtype=np.uint64).T.copy()   # [69, B]
+    assert expected.shape == (len(hv), B)
+    ok, where = cs.hook_compare_witness(hv, zk.DeviceBuffer.from_numpy(expected))
+    assert ok, where
+    bad = expected.copy(); bad[40, 2] ^= 1; bad[50, 2] ^= 1
+    ok, where = cs.hook_compare_witness(hv, zk.DeviceBuffer.from_numpy(bad))
+    assert not ok and where == (2, 40)
