@@ -254,6 +254,7 @@ void CS::place_gate(uint32_t kind, const zk_var* vars, uint32_t n_vars, const ui
     const GateInfo& gi = GATES[kind];
     if (n_vars != gi.width || n_consts != gi.n_consts) throw ZkError(ZK_ERR_INVALID, "place_gate: wrong arity");
     if (gi.n_consts > geo_.num_constant_columns) throw ZkError(ZK_ERR_INVALID, "gate needs more constant columns");
+    if (gi.width > geo_.num_columns_under_copy_permutation) throw ZkError(ZK_ERR_INVALID, "gate is wider than the copy-permutation columns of this geometry");
     Scope& s = cur();
     GateRec g;
     g.kind = kind;
@@ -1626,6 +1627,7 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
     hip_check(hipMemsetAsync(d_fail_, 0xff, 8 * sizeof(unsigned long long), st), "memset fail");
     hip_check(hipEventRecord((hipEvent_t)ev_[4], st), "event");
     dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, compact), st));
+    check_inputs_canonical(st, st);
     if (!compact)
         dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies,
                                              (uint32_t)outer_.copies.size(), d_fail_, st));
@@ -1740,6 +1742,16 @@ void CS::check_streams(void* stream, bool compact) {
     }
 }
 
+// every word of the bound input streams is a canonical field element (< p): the kernels compare values as plain u64
+void CS::check_inputs_canonical(void* outer_stream, void* loop_stream) {
+    for (int sc = 0; sc < 2; ++sc) {
+        const Scope& s = sc ? loop_ : outer_;
+        if (!s.d_inputs || !s.n_input_words || (sc && !limit_)) continue;
+        dev_check(zkdev::launch_check_inputs(s.d_inputs, s.n_input_words, s.n_lanes, s.input_stride ? s.input_stride : s.n_lanes, d_fail_ + 3 * sc,
+                                             sc ? loop_stream : outer_stream));
+    }
+}
+
 int CS::decode_failure(const unsigned long long* f, zk_failure* first) const {
     const unsigned long long NONE = ~0ull;
     for (int sc = 0; sc < 2; ++sc) {
@@ -1756,6 +1768,7 @@ int CS::decode_failure(const unsigned long long* f, zk_failure* first) const {
         if (ff[0] != NONE) {
             uint32_t slot = (uint32_t)((ff[0] >> 12) & 0xfffff), j = (uint32_t)((ff[0] >> 4) & 0xff), rel = (uint32_t)(ff[0] & 0xf);
             bool is_lookup = (j & 0x80) && rel == 15;
+            if (slot == 0xfffffu) { fill(ff[0], j, ZK_FAILURE_NONCANONICAL_INPUT, 0); return ZK_ERR_UNSATISFIED; }  // input word j (mod 256) >= p
             fill(ff[0], slot, is_lookup ? 0x100u : s.rows[slot].kind, is_lookup ? (j & 0x7f) : rel);
             return ZK_ERR_UNSATISFIED;
         }
@@ -1809,6 +1822,7 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     launch_phase(outer_, oa, 2, ax);  // outer POST
     // compact traces: the gate checkers read every cell through the alias map; no copy pass (see check_satisfied)
     dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, true), ax));
+    check_inputs_canonical(ax, st);
     hip_check(hipEventRecord(E(4), ax), "event");
     if (limit_) {
         dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, true), st));

@@ -238,6 +238,7 @@ class CS {
     void assign_store_slots(Scope& s);
     uint32_t home(const Scope& s, uint32_t var) const { return emit_full_ ? s.var_cells[var][0] : s.var_slot[var]; }
     void check_streams(void* stream, bool compact);
+    void check_inputs_canonical(void* outer_stream, void* loop_stream);
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream) const;
     void build_check_program(Scope& s);

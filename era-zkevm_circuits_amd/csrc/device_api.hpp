@@ -40,6 +40,7 @@ int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint6
 int launch_pack_public(const uint64_t* outer_store, uint64_t n_store, const uint32_t* slots, uint32_t n_public, uint32_t n_instances, uint64_t* out, void* stream);
 int launch_hook_compare(const uint64_t* outer_store, uint64_t n_store, const uint32_t* slots, uint32_t n_vars, uint32_t n_instances, const uint64_t* expected,
                         unsigned long long* fail, void* stream);
+int launch_check_inputs(const uint64_t* inputs, uint32_t n_words, uint32_t n_lanes, uint64_t stride, unsigned long long* fail, void* stream);
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, void* stream);
 // strand mode (kernels_engine.hpp k_witness_strands): sc.prog = the strand program, begin/end = 8 word ranges
 #ifndef ZKGL_STRANDS_PER_TILE

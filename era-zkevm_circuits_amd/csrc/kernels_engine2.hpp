@@ -1188,4 +1188,12 @@ __global__ void k_hook_compare(const uint64_t* __restrict__ outer_store, uint64_
         atomicMin(fail, ((unsigned long long)inst << 32) | k);
 }
 
+// every input stream word must be a canonical field element; failure key: lane, slot 0xfffff, j = word index (mod 256)
+__global__ void k_check_inputs(const uint64_t* __restrict__ inputs, uint32_t n_words, uint32_t n_lanes, uint64_t stride, unsigned long long* fail) {
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= n_lanes) return;
+    for (uint32_t w = blockIdx.y; w < n_words; w += gridDim.y)
+        if (inputs[(size_t)w * stride + lane] >= gl::P) report(fail, lane, 0xfffffu, w & 0xff, 0);
+}
+
 }  // namespace zke

@@ -181,6 +181,13 @@ int launch_hook_compare(const uint64_t* outer_store, uint64_t n_store, const uin
     return LAUNCH_CHECK("k_hook_compare");
 }
 
+int launch_check_inputs(const uint64_t* inputs, uint32_t n_words, uint32_t n_lanes, uint64_t stride, unsigned long long* fail, void* stream) {
+    if (!n_words || !n_lanes) return 0;
+    dim3 grid(grid_for(n_lanes, 256), std::min<uint32_t>(n_words, 64));
+    zke::k_check_inputs<<<grid, 256, 0, (hipStream_t)stream>>>(inputs, n_words, n_lanes, stride, fail);
+    return LAUNCH_CHECK("k_check_inputs");
+}
+
 int launch_materialize(uint64_t* trace, uint64_t n_cells, const uint64_t* store, uint64_t n_store, uint32_t n_lanes, const zk_copy_pair* pairs,
                        uint32_t n_pairs, void* stream) {
     if (n_lanes == 0 || n_pairs == 0) return 0;

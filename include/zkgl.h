@@ -183,6 +183,9 @@ int zk_cs_seed_carried_inputs(zk_cs *cs, uint64_t *dev_loop_inputs_rw, void *str
  * (/root/reference/src/main_vm/mod.rs: the `for _cycle_idx in 0..limit` loop over vm_cycle). */
 int zk_cs_seed_stream(zk_cs *cs, uint32_t n_instances, const uint64_t *dev_outer_inputs, uint64_t *dev_loop_inputs_rw, void *stream);
 typedef struct zk_failure { uint32_t scope, instance, iteration, slot, kind, relation; } zk_failure;
+/* kind: a zk_gate_kind; 0x100 lookup tuple (relation = tuple); 0x200 copy constraint; 0x300 link / stream link;
+ * ZK_FAILURE_NONCANONICAL_INPUT: input stream word `slot` (mod 256) of that lane is not a canonical field element (>= p) */
+#define ZK_FAILURE_NONCANONICAL_INPUT 0x400u
 /* check_if_satisfied: 0 satisfied; ZK_ERR_UNSATISFIED + first failure otherwise */
 int zk_cs_check_satisfied(zk_cs *cs, void *stream, zk_failure *first);
 /* fused resolve + check_if_satisfied; the latency-bound outer scope runs on an internal second stream

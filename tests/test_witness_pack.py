@@ -173,3 +173,22 @@ def test_hook_compare_witness_on_the_device(zk):
     bad = expected.copy(); bad[40, 2] ^= 1; bad[50, 2] ^= 1
     ok, where = cs.hook_compare_witness(hv, zk.DeviceBuffer.from_numpy(bad))
     assert not ok and where == (2, 40)
+
+
+@pytest.mark.gpu
+def test_non_canonical_input_word_is_reported(zk):
+    """an input stream word >= p is reported by check_if_satisfied (kind ZK_FAILURE_NONCANONICAL_INPUT), whatever the gates make of it"""
+    from helpers import ram_cs
+    u, s, nd, inst = _case(900, LIMIT)
+    outer, loop = rn.pack_streams([inst, inst], LIMIT)
+    loop = loop.copy()
+    loop[50, LIMIT + 3] = np.uint64(0xFFFFFFFF00000001)   # == p: the same field element as 0, but not canonical
+    cs = ram_cs(LIMIT)
+    cs.set_batch(2)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert not ok
+    cs.resolve()
+    ok, f = cs.check_if_satisfied()
+    assert not ok and f.scope == 1 and f.instance == 1
