@@ -1150,7 +1150,7 @@ void CS::build_seed_program() {
     // strands per level, and an LDS slot is recycled only at the level after its last reader (readers of a level run
     // concurrently with that level's writers).
     seed_sprog_.clear(); seed_scarries_.clear(); seed_sslots_ = 0; seed_sgain_ = 0;
-    constexpr uint32_t NS = zkdev::STRANDS_PER_TILE;
+    constexpr uint32_t NS = zkdev::SEED_STRANDS_PER_TILE;
     // Levels in two tiers so that the heavy ops of independent chains line up: tier(op) = the number of heavy ops (permutations,
     // hash macro-ops) on the longest path of producers before it; inside a tier the light ops are levelled as soon as
     // possible and ALL heavy ops of the tier share one final level (their consumers sit in the next tier).  With plain

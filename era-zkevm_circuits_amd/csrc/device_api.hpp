@@ -47,6 +47,9 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
 #define ZKGL_STRANDS_PER_TILE 16
 #endif
 constexpr uint32_t STRANDS_PER_TILE = ZKGL_STRANDS_PER_TILE;
+// the seeding kernels keep 8: a seeding pass is a latency chain per instance and its throughput is the number of resident blocks
+// (2048 instances: 2.5 s with 8-wave blocks, 3.6 s with 16-wave blocks)
+constexpr uint32_t SEED_STRANDS_PER_TILE = 8;
 int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], void* stream);
 struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // mirrors zke::CarryDev
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,

@@ -804,6 +804,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 #define ZKGL_STRANDS_PER_TILE 16
 #endif
 constexpr int STRANDS_PER_TILE = ZKGL_STRANDS_PER_TILE;
+constexpr int SEED_STRANDS_PER_TILE = 8;  // device_api.hpp
 struct StrandTab { uint32_t begin[STRANDS_PER_TILE], end[STRANDS_PER_TILE]; };
 template <bool WITH_BIGINT, bool BUFFER_ADDRESSING = true>
 __global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_witness_strands(ScopeDev sc, StrandTab tab) {
@@ -893,10 +894,10 @@ __global__ __launch_bounds__(64) void k_seed_cone(ScopeDev sc, const uint32_t* _
 // the level-ordered cone with an LDS barrier between levels — one iteration's independent sponges and decompositions run side
 // by side instead of as one latency chain.
 template <bool WITH_BIGINT>
-__global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_seed_cone_strands(ScopeDev sc, const uint32_t* __restrict__ seed_sprog, StrandTab tab,
+__global__ __launch_bounds__(64 * SEED_STRANDS_PER_TILE) void k_seed_cone_strands(ScopeDev sc, const uint32_t* __restrict__ seed_sprog, StrandTab tab,
                                                                             const SeedCarryDev* carries, uint32_t n_carries, uint64_t* inputs_rw,
                                                                             uint32_t n_instances, uint32_t lpb, uint32_t n_slots, uint32_t n_input_words) {
-    constexpr uint32_t NT = 64 * STRANDS_PER_TILE;
+    constexpr uint32_t NT = 64 * SEED_STRANDS_PER_TILE;
     __shared__ uint64_t lds[SEED_LDS_WORDS];
     if (blockIdx.x * lpb >= n_instances) return;
     uint64_t* const slot_store = lds;

@@ -864,10 +864,10 @@ __device__ __forceinline__ void run_seed2(const ScopeDev& sc, const uint32_t ins
     }
 }
 
-__global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_seed_cone_strands2(ScopeDev sc, const uint32_t* __restrict__ seed_sprog, StrandTab tab,
+__global__ __launch_bounds__(64 * SEED_STRANDS_PER_TILE) void k_seed_cone_strands2(ScopeDev sc, const uint32_t* __restrict__ seed_sprog, StrandTab tab,
                                                                              const SeedCarryDev* carries, uint32_t n_carries, uint64_t* inputs_rw,
                                                                              uint32_t n_instances, uint32_t lpb, uint32_t n_slots, uint32_t n_input_words) {
-    constexpr uint32_t NT = 64 * STRANDS_PER_TILE;
+    constexpr uint32_t NT = 64 * SEED_STRANDS_PER_TILE;
     __shared__ uint64_t lds[SEED_LDS_WORDS];
     if (blockIdx.x * lpb >= n_instances) return;
     uint64_t* const slot_store = lds;                 // [n_slots][lpb]

@@ -349,14 +349,14 @@ int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, co
     while (lpb > 1 && (n_instances + lpb - 1) / lpb < 128 && (n_instances + lpb / 2 - 1) / (lpb / 2) <= 256) lpb /= 2;
     const unsigned grid = (n_instances + lpb - 1) / lpb;
     zke::StrandTab tab;
-    for (int i = 0; i < zke::STRANDS_PER_TILE; ++i) { tab.begin[i] = begin[i]; tab.end[i] = end[i]; }
+    for (int i = 0; i < zke::STRANDS_PER_TILE; ++i) { tab.begin[i] = i < zke::SEED_STRANDS_PER_TILE ? begin[i] : 0; tab.end[i] = i < zke::SEED_STRANDS_PER_TILE ? end[i] : 0; }
     auto c = reinterpret_cast<const zke::SeedCarryDev*>(d_carries);
     if (v2)  // scalar-decoded (kernels_engine2.hpp); the host selects it when every op of the cone has a handler there
-        zke::k_seed_cone_strands2<<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
+        zke::k_seed_cone_strands2<<<grid, 64 * zke::SEED_STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
     else if (sc.uses_bigint)
-        zke::k_seed_cone_strands<true><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
+        zke::k_seed_cone_strands<true><<<grid, 64 * zke::SEED_STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
     else
-        zke::k_seed_cone_strands<false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
+        zke::k_seed_cone_strands<false><<<grid, 64 * zke::SEED_STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
     return LAUNCH_CHECK("k_seed_cone_strands");
 }
 
