@@ -100,6 +100,7 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_prog2) hipFree(s.d_prog2);
     if (s.d_cprog) hipFree(s.d_cprog);
     if (s.d_cchunks) hipFree(s.d_cchunks);
+    if (s.d_mult_sites) hipFree(s.d_mult_sites);
     if (s.d_sprog) hipFree(s.d_sprog);
     s.d_sprog = nullptr;
     if (s.d_consts) hipFree(s.d_consts);
@@ -114,7 +115,7 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_store) hipFree(s.d_store);
     s.d_store = nullptr;
     if (s.d_cells) hipFree(s.d_cells);
-    s.d_prog = nullptr; s.d_prog2 = nullptr; s.d_cprog = nullptr; s.d_cchunks = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
+    s.d_prog = nullptr; s.d_prog2 = nullptr; s.d_cprog = nullptr; s.d_cchunks = nullptr; s.d_mult_sites = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
     s.d_copies = nullptr; s.d_cells = nullptr;
 }
 
@@ -558,6 +559,60 @@ void CS::build_check_program(Scope& s) {
         if (starts[p] > s.cchunks.back()) s.cchunks.push_back(starts[p]);
     }
     s.cchunks.push_back(total);
+}
+
+// Lookup sites of a scope grouped by table (k_multiplicities): the key slots of every recorded lookup
+void CS::build_mult_sites(Scope& s) {
+    const size_t nt = tables_.size() + 1;  // table ids are 1-based
+    std::vector<std::vector<uint32_t>> by_table(nt);
+    for (auto& op : s.ops) {
+        if (op.seed_only || op.opcode != ZK_OP_LOOKUP) continue;
+        const uint32_t tid = op.ins[0].idx;
+        if (tid >= nt) throw ZkError(ZK_ERR_INVALID, "internal: lookup into an unknown table");
+        for (size_t q = 1; q <= 3; ++q) {
+            if (q < op.ins.size()) {
+                if (op.ins[q].kind != Operand::VAR) throw ZkError(ZK_ERR_INVALID, "internal: lookup key is not a variable");
+                by_table[tid].push_back(s.var_slot[op.ins[q].idx]);
+            } else by_table[tid].push_back(0xffffffffu);
+        }
+    }
+    s.mult_sites.clear(); s.mult_site_off.assign(nt + 1, 0);
+    for (size_t t = 0; t < nt; ++t) {
+        s.mult_site_off[t] = (uint32_t)(s.mult_sites.size() / 3);
+        s.mult_sites.insert(s.mult_sites.end(), by_table[t].begin(), by_table[t].end());
+    }
+    s.mult_site_off[nt] = (uint32_t)(s.mult_sites.size() / 3);
+}
+
+// Two ways to the lookup multiplicities.  INLINE: the witness kernels add as they go, one atomic per distinct row among a
+// wavefront's 64 lanes — cheap when the lanes (consecutive cycles of one instance) mostly look up the same rows (main_vm: a
+// cleared flag, a zero limb; < 1 ms of the loop kernel), ruinous when they do not (hash circuits: byte tables over pseudo-random
+// state, 64 lanes = 64 rows, ~1e9 L2 atomics per step = 60 % of keccak's loop kernel).  PASS: no atomics in the witness kernels,
+// k_multiplicities recounts from the stored keys afterwards (keccak 57.7 -> 22.9 ms loop kernel + 6 ms pass; but +5 ms for
+// main_vm at B=384 against 1.5 ms of inline atomics).  ZKGL_MULT_MODE=inline|pass forces one; default: by the number of lookups a
+// loop lane makes (> 2 048: a hash-style circuit -> PASS).
+bool CS::inline_multiplicities() const {
+    const char* e = getenv("ZKGL_MULT_MODE");
+    if (e && e[0] == 'i') return true;
+    if (e && e[0] == 'p') return false;
+    size_t per_lane = 0;
+    for (auto& op : (limit_ ? loop_ : outer_).ops) per_lane += (!op.seed_only && op.opcode == ZK_OP_LOOKUP);
+    return per_lane <= 2048;
+}
+
+// multiplicities of the batch from the resolved variable stores (PASS mode): per scope, per table
+void CS::count_multiplicities(void* stream) {
+    if (inline_multiplicities() || !total_table_rows_) return;
+    for (int sc = 0; sc < 2; ++sc) {
+        const Scope& s = sc ? loop_ : outer_;
+        if ((sc && !limit_) || !s.d_mult_sites) continue;
+        for (size_t t = 1; t <= tables_.size(); ++t) {
+            const uint32_t n = s.mult_site_off[t + 1] - s.mult_site_off[t];
+            if (!n) continue;
+            dev_check(zkdev::launch_multiplicities(s.d_store, s.n_store, sc ? limit_ : 1, s.n_lanes, batch_, s.d_mult_sites + 3 * (size_t)s.mult_site_off[t], n,
+                                                   tdesc_host_[t], d_table_words_, d_mult_, total_table_rows_, stream));
+        }
+    }
 }
 
 // Store slots in production order of the FINAL op order (after scheduling); variables no op produces keep slot 0 and are
@@ -1305,6 +1360,7 @@ void CS::upload_scope(Scope& s) {
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
         s.d_sprog = upload(padded);
     }
+    if (!s.mult_sites.empty()) s.d_mult_sites = upload(s.mult_sites);
     s.d_consts = upload(s.const_pool);
     s.d_rows = upload(s.rows);
     s.d_rowconsts = upload(s.rowconsts);
@@ -1337,6 +1393,8 @@ void CS::finalize() {
     emit_scope(loop_);
     build_check_program(outer_);
     build_check_program(loop_);
+    build_mult_sites(outer_);
+    build_mult_sites(loop_);
     build_strands(outer_);
     if (limit_) build_strands(loop_);
     uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
@@ -1579,8 +1637,9 @@ void CS::resolve(void* stream) {
     if (loop_.n_input_words && !loop_.d_inputs) throw ZkError(ZK_ERR_INVALID, "loop input stream not bound");
     hipStream_t st = (hipStream_t)stream;
     hip_check(hipMemsetAsync(d_mult_, 0, std::max<size_t>((size_t)batch_ * total_table_rows_ * 4, 4), st), "memset mult");
-    auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
-    auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
+    uint32_t* const mult_inline = inline_multiplicities() ? d_mult_ : nullptr;
+    auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, mult_inline, total_table_rows_);
+    auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, mult_inline, total_table_rows_);
     hip_check(hipEventRecord((hipEvent_t)ev_[0], st), "event");
     launch_phase(outer_, oa, 0, st);
     hip_check(hipEventRecord((hipEvent_t)ev_[1], st), "event");
@@ -1588,6 +1647,7 @@ void CS::resolve(void* stream) {
     hip_check(hipEventRecord((hipEvent_t)ev_[2], st), "event");
     launch_phase(outer_, oa, 1, st);
     launch_phase(outer_, oa, 2, st);
+    count_multiplicities(st);
     hip_check(hipEventRecord((hipEvent_t)ev_[3], st), "event");
     hip_check(hipStreamSynchronize(st), "resolve sync");
     float a = 0, b = 0, c = 0;
@@ -1807,8 +1867,9 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     auto E = [&](int i) { return (hipEvent_t)ev2_[i]; };
     hip_check(hipMemsetAsync(d_mult_, 0, std::max<size_t>((size_t)batch_ * total_table_rows_ * 4, 4), st), "memset mult");
     hip_check(hipMemsetAsync(d_fail_, 0xff, 8 * sizeof(unsigned long long), st), "memset fail");
-    auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
-    auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, d_mult_, total_table_rows_);
+    uint32_t* const mult_inline = inline_multiplicities() ? d_mult_ : nullptr;
+    auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, mult_inline, total_table_rows_);
+    auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, mult_inline, total_table_rows_);
     hip_check(hipEventRecord(E(0), st), "event");                     // t0 (+ memsets done)
     hip_check(hipStreamWaitEvent(ax, E(0), 0), "wait");
     launch_phase(outer_, oa, 0, ax);    // outer PRE
@@ -1832,6 +1893,7 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     }
     hip_check(hipEventRecord(E(6), st), "event");
     hip_check(hipStreamWaitEvent(st, E(4), 0), "wait");
+    count_multiplicities(st);   // both scopes resolved: the lookup multiplicities of the batch (k_multiplicities, no atomics in the witness kernels)
     if (limit_) {
         dev_check(zkdev::launch_check_links(loop_.d_store, loop_.n_store, loop_.n_lanes, limit_, outer_.d_store,
                                             outer_.n_store, d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));

@@ -91,6 +91,8 @@ struct Scope {
     // check program of the compact gate / lookup checker (kernels_engine2.hpp k_check_prog) + its chunk table (word offsets of
     // whole-packet chunks, n_chunks + 1 entries); empty when the scope cannot use it (a lookup tuple wider than 4 columns)
     std::vector<uint32_t> cprog, cchunks;
+    // lookup sites by table for k_multiplicities: 3 key slots per site; site_off[table id] .. site_off[table id + 1]
+    std::vector<uint32_t> mult_sites, mult_site_off;
     uint32_t pre_words2 = 0, side_words2 = 0, pre_slots = 0, side_slots = 0;
     // VARIABLE STORE: the witness kernels keep ONE value per variable, in a dense store indexed by production order
     // (store[((lane >> 6) * n_store + slot) * 64 + (lane & 63)]): a wave streams its results out sequentially and reads its
@@ -119,6 +121,7 @@ struct Scope {
     uint32_t* d_prog2 = nullptr;
     uint32_t* d_cprog = nullptr;
     uint32_t* d_cchunks = nullptr;
+    uint32_t* d_mult_sites = nullptr;
     uint32_t* d_sprog = nullptr;
     uint64_t* d_consts = nullptr;
     zk_row_desc* d_rows = nullptr;
@@ -242,6 +245,10 @@ class CS {
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream) const;
     void build_check_program(Scope& s);
+    void build_mult_sites(Scope& s);
+    void count_multiplicities(void* stream);
+    // true: wave-aggregated atomics inside the witness kernels; false: the k_multiplicities pass after them (cs.cpp)
+    bool inline_multiplicities() const;
     void operand_v2(const Scope& s, const OpRec& op, size_t pos, std::vector<uint32_t>& out) const;
     void emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool counted, std::vector<uint32_t>& out) const;
     void upload_scope(Scope& s);

@@ -41,6 +41,8 @@ int launch_pack_public(const uint64_t* outer_store, uint64_t n_store, const uint
 int launch_hook_compare(const uint64_t* outer_store, uint64_t n_store, const uint32_t* slots, uint32_t n_vars, uint32_t n_instances, const uint64_t* expected,
                         unsigned long long* fail, void* stream);
 int launch_check_inputs(const uint64_t* inputs, uint32_t n_words, uint32_t n_lanes, uint64_t stride, unsigned long long* fail, void* stream);
+int launch_multiplicities(const uint64_t* store, uint64_t n_store, uint32_t lanes_per_instance, uint32_t n_lanes, uint32_t n_instances, const uint32_t* sites,
+                          uint32_t n_sites, const zk_table_desc& t, const uint64_t* table_words, uint32_t* mult, uint32_t total_table_rows, void* stream);
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, void* stream);
 // strand mode (kernels_engine.hpp k_witness_strands): sc.prog = the strand program, begin/end = 8 word ranges
 #ifndef ZKGL_STRANDS_PER_TILE

@@ -113,7 +113,11 @@ __device__ __forceinline__ void mult_add(uint32_t* mult, size_t index, bool pred
         if ((int)(threadIdx.x & 63) == leader) atomicAdd(mult + li, (uint32_t)__builtin_popcountll(same));
         todo &= ~same;
     }
+#ifdef ZKGL_MULT_WG_SCOPE  // experiment: L2-local atomics (correct only with one copy of the counters per XCD)
+    if (todo & (1ull << (threadIdx.x & 63))) __hip_atomic_fetch_add(mult + index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     if (todo & (1ull << (threadIdx.x & 63))) atomicAdd(mult + index, 1u);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

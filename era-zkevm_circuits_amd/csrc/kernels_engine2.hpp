@@ -30,7 +30,9 @@ typedef __attribute__((address_space(4))) const uint64_t* cpool_ptr;
 
 // v2 group caps (cs.cpp group_cap must agree): members of one header
 constexpr uint32_t G2_INPUT = 8, G2_SELECT = 5, G2_FMA = 3, G2_LOOKUP = 4, G2_U32MULADD = 3;
-#ifdef ZKGL_STUB_MULT  // time attribution only: lookups without the multiplicity atomics
+// multiplicities: wave-aggregated atomics in the interpreter when the host passes the vector (sc.mult), or the k_multiplicities pass
+// after the witness kernels when it passes nullptr (cs.cpp multiplicity_mode); -DZKGL_STUB_MULT: neither (time attribution)
+#ifdef ZKGL_STUB_MULT
 #define ZKGL_MULT_ON false
 #else
 #define ZKGL_MULT_ON true
@@ -103,7 +105,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     uint64_t* __restrict__ wide_cells = sc.cells + (size_t)tile * sc.n_cells * 64 + (lane & 63);
     const prog1_ptr prog = (prog1_ptr)(uintptr_t)sc.prog;
     const cpool_ptr cpool = (cpool_ptr)(uintptr_t)sc.consts;
-    __shared__ uint64_t p2s[12 * BLOCK];  // Poseidon2 state, [element][thread]
+    constexpr bool P2_IN_REGISTERS = STRANDS;
+    __shared__ uint64_t p2s[P2_IN_REGISTERS ? 1 : 12 * BLOCK];  // Poseidon2 state, [element][thread] (plain kernels: rolled S-box loops)
 
     uint32_t dst = WIDE ? slot_begin : slot_begin << 9;  // next output: slot index (WIDE) or byte offset in the tile
     auto ldv = [&](uint32_t slot) -> uint64_t {
@@ -356,6 +359,51 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             out_to(W[13]);
             pc += 13 + D;
             p2::mds_external(s);
+            if constexpr (P2_IN_REGISTERS) {
+                // strand kernels: state in registers, the twelve S-boxes of a full round unrolled, ONE copy of the full-round body
+                // (no LDS: a 1 024-thread strand block would need 96 KB for the staged state and sit alone on its CU)
+                if (emit) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) st(s[i]);
+                }
+#pragma unroll 1
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int r = half * 26 + r4;
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) {
+                            const uint64_t t = gl::add(s[i], p2::RC[12 * r + i]);
+                            const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+                            if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
+                            s[i] = x7;
+                        }
+                        p2::mds_external(s);
+                        if (emit) {
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) st(s[i]);
+                        }
+                    }
+                    if (half == 0) {
+#pragma unroll 1
+                        for (int r = 4; r < 26; ++r) {
+                            const uint64_t t = gl::add(s[0], p2::RC[12 * r]);
+                            const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+                            if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
+                            s[0] = x7;
+                            p2::mds_inner(s);
+                            if (emit) {
+#pragma unroll
+                                for (int i = 0; i < 12; ++i) st(s[i]);
+                            }
+                        }
+                    }
+                }
+                if (!emit) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) st(s[i]);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 12; ++i) p2s[i * BLOCK + threadIdx.x] = s[i];
             if (emit) {
@@ -390,6 +438,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             if (!emit) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) st(s[i]);
+            }
             }
         } break;
         case ZK_OP_LOOP_LAST: {
@@ -1194,6 +1243,54 @@ __global__ void k_check_inputs(const uint64_t* __restrict__ inputs, uint32_t n_w
     if (lane >= n_lanes) return;
     for (uint32_t w = blockIdx.y; w < n_words; w += gridDim.y)
         if (inputs[(size_t)w * stride + lane] >= gl::P) report(fail, lane, 0xfffffu, w & 0xff, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Lookup multiplicities WITHOUT global atomics (k_multiplicities).  The witness kernels used to add 1 to
+// mult[instance][table row] per lookup: ~1e9 L2 atomic operations per step for the hash circuits (64 lanes, 64 different rows: the
+// L2 atomic rate, 31 G/s, was 60 % of keccak's and 48 % of sha256's loop kernel) and serialised same-address storms for the VM.
+// Now a pass of its own after the witness kernels: one workgroup owns (instance, table, chunk of <= 32 768 rows), walks every
+// lookup site of that table over the instance's lanes — key values read back from the variable store, coalesced over lanes —
+// counts in LDS (ds atomics) and adds its counts to the instance's multiplicity vector with plain stores (exclusive ownership).
+// ------------------------------------------------------------------------------------------------------------------------
+struct MultDev {
+    const uint64_t* store; uint64_t n_store; uint32_t lanes_per_instance, n_lanes;
+    const uint32_t* sites; uint32_t n_sites;   // 3 key slots per site (0xffffffff: absent)
+    zk_table_desc t; const uint64_t* table_words;
+    uint32_t* mult; uint32_t total_table_rows; uint32_t chunk_rows;
+};
+constexpr uint32_t MULT_CHUNK_ROWS = 32768;
+__global__ __launch_bounds__(1024) void k_multiplicities(MultDev a) {
+    __shared__ uint32_t cnt[MULT_CHUNK_ROWS];
+    const uint32_t base = blockIdx.x * a.chunk_rows, inst = blockIdx.y;
+    const uint32_t rows_here = min(a.chunk_rows, a.t.n_rows - base);
+    for (uint32_t i = threadIdx.x; i < rows_here; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    // few instances: gridDim.z workgroups share an instance, each takes a contiguous range of its lanes (multiples of 64)
+    const uint32_t per = ((a.lanes_per_instance + gridDim.z - 1) / gridDim.z + 63) & ~63u;
+    const uint32_t lo = blockIdx.z * per, hi = min(lo + per, a.lanes_per_instance);
+    const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, l0 = threadIdx.x & 63;
+    for (uint32_t site = wave; site < a.n_sites; site += n_waves) {
+        const uint32_t s0 = uni(a.sites[3 * site]), s1 = uni(a.sites[3 * site + 1]), s2 = uni(a.sites[3 * site + 2]);
+        for (uint32_t l = lo + l0; l < hi; l += 64) {
+            const uint32_t lane = inst * a.lanes_per_instance + l;
+            if (lane >= a.n_lanes) break;
+            const uint64_t k0 = a.store[cell_off(a.n_store, s0, lane)];
+            const uint64_t k1 = s1 != 0xffffffffu ? a.store[cell_off(a.n_store, s1, lane)] : 0;
+            const uint64_t k2 = s2 != 0xffffffffu ? a.store[cell_off(a.n_store, s2, lane)] : 0;
+            const uint32_t row = table_find3(a.t, a.table_words, k0, k1, k2);
+            if (row < a.t.n_rows && row - base < rows_here) atomicAdd(&cnt[row - base], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* out = a.mult + (size_t)inst * a.total_table_rows + a.t.mult_off + base;
+    for (uint32_t i = threadIdx.x; i < rows_here; i += blockDim.x) {
+        const uint32_t v = cnt[i];
+        if (!v) continue;
+        // the vector is zeroed at the start of resolve and the launches of the two scopes are ordered on the stream; only the
+        // workgroups sharing an instance (gridDim.z > 1) meet on a counter
+        if (gridDim.z > 1) atomicAdd(out + i, v); else out[i] += v;
+    }
 }
 
 }  // namespace zke

@@ -188,6 +188,22 @@ int launch_check_inputs(const uint64_t* inputs, uint32_t n_words, uint32_t n_lan
     return LAUNCH_CHECK("k_check_inputs");
 }
 
+int launch_multiplicities(const uint64_t* store, uint64_t n_store, uint32_t lanes_per_instance, uint32_t n_lanes, uint32_t n_instances, const uint32_t* sites,
+                          uint32_t n_sites, const zk_table_desc& t, const uint64_t* table_words, uint32_t* mult, uint32_t total_table_rows, void* stream) {
+    if (!n_sites || !n_instances || !t.n_rows) return 0;
+    zke::MultDev a;
+    a.store = store; a.n_store = n_store; a.lanes_per_instance = lanes_per_instance; a.n_lanes = n_lanes; a.sites = sites; a.n_sites = n_sites;
+    a.t = t; a.table_words = table_words; a.mult = mult; a.total_table_rows = total_table_rows; a.chunk_rows = zke::MULT_CHUNK_ROWS;
+    const uint32_t chunks = (t.n_rows + a.chunk_rows - 1) / a.chunk_rows;
+    // >= ~512 workgroups: few instances share each one among several workgroups (lane ranges)
+    uint32_t splits = std::max<uint32_t>(1, 512 / std::max<uint32_t>(1, chunks * n_instances));
+    splits = std::min<uint32_t>(splits, std::max<uint32_t>(1, lanes_per_instance / 256));
+    dim3 grid(chunks, n_instances, splits);
+    // one wavefront per site at a time: small site lists (outer scopes) do not need 16 wavefronts
+    const unsigned threads = n_sites >= 16 ? 1024 : 256;
+    zke::k_multiplicities<<<grid, threads, 0, (hipStream_t)stream>>>(a);
+    return LAUNCH_CHECK("k_multiplicities");
+}
 int launch_materialize(uint64_t* trace, uint64_t n_cells, const uint64_t* store, uint64_t n_store, uint32_t n_lanes, const zk_copy_pair* pairs,
                        uint32_t n_pairs, void* stream) {
     if (n_lanes == 0 || n_pairs == 0) return 0;

@@ -7,7 +7,7 @@ pids=()
 for kv in "$@"; do
   tag=${kv%%=*}; defs=${kv#*=}
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value $defs -c zkgl_device.hip -o ../build/var/dev_$tag.o 2>/dev/null &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o ../libzkgl_var_$tag.so ../build/var/dev_$tag.o $(ls ../build/*.o | grep -v zkgl_device) && echo "built $tag" ) &
+    hipcc --offload-arch=gfx950 -shared -fPIC -o ../libzkgl_var_$tag.so ../build/var/dev_$tag.o $(ls ../build/*.o | grep -v zkgl_device) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib && echo "built $tag" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
