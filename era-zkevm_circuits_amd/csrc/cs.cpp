@@ -77,6 +77,8 @@ CS::~CS() {
     for (auto p : d_streams_store_) if (p) hipFree(p);
     if (d_public_slots_) hipFree(d_public_slots_);
     if (d_seed_prog_) hipFree(d_seed_prog_);
+    if (d_seed_wprog_) hipFree(d_seed_wprog_);
+    if (d_seed_wcarries_) hipFree(d_seed_wcarries_);
     if (d_seed_sprog_) hipFree(d_seed_sprog_);
     if (d_seed_scarries_) hipFree(d_seed_scarries_);
     if (d_seed_carries_) hipFree(d_seed_carries_);
@@ -1205,6 +1207,7 @@ void CS::build_seed_program() {
     // strands per level, and an LDS slot is recycled only at the level after its last reader (readers of a level run
     // concurrently with that level's writers).
     seed_sprog_.clear(); seed_scarries_.clear(); seed_sslots_ = 0; seed_sgain_ = 0;
+    seed_wprog_.clear(); seed_wcarries_.clear();
     constexpr uint32_t NS = zkdev::SEED_STRANDS_PER_TILE;
     // Levels in two tiers so that the heavy ops of independent chains line up: tier(op) = the number of heavy ops (permutations,
     // hash macro-ops) on the longest path of producers before it; inside a tier the light ops are levelled as soon as
@@ -1260,6 +1263,144 @@ void CS::build_seed_program() {
             if (in.kind == Operand::VAR) last_level[in.idx] = std::max<int64_t>(last_level[in.idx], level[oi]);
     }
     for (auto v : out_vars) last_level[v] = INF;
+    // ---- op-parallel form of the same cone (kernels_seed_wave.hpp k_seed_wave): ONE wavefront per instance, its 64 lanes run up to
+    // 64 independent ops of a dependency level at once (segments of one op kind, 16-bit records resident in LDS), Poseidon2
+    // permutations cooperatively on 12 lanes each.  No workgroup barrier per level, no wasted lanes: the latency chain of a cycle is
+    // levels x (a few dozen instructions) + permutation tiers.  Loop-invariant ZK_OP_CONST ops (pool constants, outer imports) run once
+    // in a prologue and keep their slots.  Cones with ops the kernel has no lane form for keep the strand kernel.
+    {
+        seed_wprog_.clear(); seed_wcarries_.clear(); seed_wslots_ = 0; seed_wpro_words_ = 0;
+        bool ok = true;
+        int fail_reason = 0;
+        auto fail_ = [&](int why) { if (ok) fail_reason = why; ok = false; };
+        enum : uint16_t { WK_CONST = 1, WK_INPUT, WK_SELECT, WK_FMA, WK_LC4, WK_ISZERO, WK_UADD, WK_USUB, WK_DOT4, WK_SPLIT_S, WK_SPLIT_L, WK_LOOKUP, WK_P2,
+                          WK_U32MULADD, WK_DIVREM, WK_U256MUL, WK_U256DIV, WK_END = 0xffff };
+        auto kind_of = [&](const OpRec& op) -> uint16_t {
+            switch (op.opcode) {
+            case ZK_OP_CONST: return WK_CONST; case ZK_OP_INPUT: return WK_INPUT; case ZK_OP_SELECT: return WK_SELECT; case ZK_OP_FMA: return WK_FMA;
+            case ZK_OP_LC4: return WK_LC4; case ZK_OP_ISZERO: return WK_ISZERO; case ZK_OP_UADD: return WK_UADD; case ZK_OP_USUB: return WK_USUB;
+            case ZK_OP_DOT4: return WK_DOT4; case ZK_OP_SPLIT: return op.a <= 9 ? WK_SPLIT_S : (op.a <= 65 ? WK_SPLIT_L : 0);
+            case ZK_OP_LOOKUP: return WK_LOOKUP; case ZK_OP_POSEIDON2: case ZK_OP_P2_ROUNDS: return WK_P2; case ZK_OP_U32MULADD: return WK_U32MULADD;
+            case ZK_OP_DIVREM: return WK_DIVREM; case ZK_OP_U256_MULWIDE: return WK_U256MUL; case ZK_OP_U256_DIVREM: return WK_U256DIV;
+            default: return 0;
+            }
+        };
+        auto rec_words = [](uint16_t k) -> uint32_t {
+            switch (k) {
+            case WK_CONST: case WK_INPUT: case WK_SELECT: case WK_ISZERO: case WK_DIVREM: return 4;
+            case WK_FMA: case WK_UADD: case WK_USUB: case WK_U32MULADD: case WK_LOOKUP: return 8;
+            case WK_LC4: case WK_DOT4: case WK_SPLIT_S: return 12;
+            case WK_P2: return 24; case WK_U256MUL: case WK_U256DIV: return 32; case WK_SPLIT_L: return 68;
+            default: return 0;
+            }
+        };
+        std::vector<uint32_t> wslot(s.n_vars, UINT32_MAX), wfree;
+        uint32_t nws = 0;
+        auto new_slot = [&]() { if (!wfree.empty()) { uint32_t v = wfree.back(); wfree.pop_back(); return v; } return nws++; };
+        const uint32_t NOSLOT = 0xffff;
+        std::vector<std::vector<uint32_t>> wdying(n_levels);
+        std::vector<uint16_t> pro, cyc;
+        uint32_t wdiscard = UINT32_MAX;
+        auto dst_slot = [&](uint32_t ov, uint32_t lv, bool pinned) -> uint16_t {
+            if (last_level[ov] < 0) { if (wdiscard == UINT32_MAX) wdiscard = nws++; return (uint16_t)wdiscard; }
+            const uint32_t sl = pinned ? nws++ : new_slot();
+            wslot[ov] = sl;
+            if (!pinned && last_level[ov] != INF) wdying[(size_t)std::max<int64_t>(last_level[ov], lv)].push_back(sl);
+            return (uint16_t)sl;
+        };
+        auto src = [&](const Operand& in) -> uint16_t {
+            if (in.kind != Operand::VAR || wslot[in.idx] == UINT32_MAX) { fail_(1); return 0; }
+            return (uint16_t)wslot[in.idx];
+        };
+        auto emit_segment = [&](std::vector<uint16_t>& out, uint16_t kind, const std::vector<uint32_t>& ops, uint32_t lv) {
+            const uint32_t rw = rec_words(kind);
+            out.push_back(kind); out.push_back((uint16_t)ops.size()); out.push_back(0); out.push_back(0);
+            for (uint32_t oi : ops) {
+                const OpRec& op = s.ops[oi];
+                std::vector<uint16_t> r;
+                auto outs = [&](size_t first = 0) { for (size_t i = first; i < op.outs.size(); ++i) r.push_back(dst_slot(op.outs[i], lv, kind == WK_CONST)); };
+                switch (kind) {
+                case WK_CONST: {
+                    outs();
+                    const Operand& in = op.ins[0];
+                    const uint32_t idx = in.kind == Operand::OUTER_VAR ? outer_.var_slot[in.idx] : in.idx;
+                    if (in.kind != Operand::OUTER_VAR && in.kind != Operand::CONSTPOOL) fail_(2);
+                    r.push_back((uint16_t)idx); r.push_back((uint16_t)(idx >> 16)); r.push_back(in.kind == Operand::OUTER_VAR ? 1 : 0);
+                } break;
+                case WK_INPUT: outs(); r.push_back((uint16_t)op.ins[0].idx); if (op.ins[0].idx > 0xfffe) fail_(3); break;
+                case WK_SELECT: for (auto& in : op.ins) r.push_back(src(in)); outs(); break;
+                case WK_FMA: case WK_LC4: {
+                    const size_t nc = kind == WK_FMA ? 2 : 4;
+                    for (size_t i = 0; i < nc; ++i) { if (op.ins[i].kind != Operand::CONSTPOOL || op.ins[i].idx > 0xfffe) fail_(4); r.push_back((uint16_t)op.ins[i].idx); }
+                    for (size_t i = nc; i < op.ins.size(); ++i) r.push_back(src(op.ins[i]));
+                    outs();
+                } break;
+                case WK_ISZERO:
+                    r.push_back(src(op.ins[0]));
+                    outs();
+                    r.push_back(last_level[op.outs[1]] < 0 ? 0 : 1);  // the inverse (a gate witness) only if the cone reads it
+                    break;
+                case WK_DOT4: case WK_U32MULADD: case WK_U256MUL: case WK_U256DIV:
+                    for (auto& in : op.ins) r.push_back(src(in));
+                    outs();
+                    break;
+                case WK_UADD: case WK_USUB: r.push_back(op.a); for (auto& in : op.ins) r.push_back(src(in)); outs(); break;
+                case WK_DIVREM: r.push_back(op.b); r.push_back(src(op.ins[0])); outs(); break;
+                case WK_SPLIT_S: case WK_SPLIT_L: r.push_back(op.a); r.push_back(op.b); r.push_back(src(op.ins[0])); outs(); break;
+                case WK_LOOKUP: {
+                    if (op.ins.size() > 4 || op.outs.size() > 3 || op.ins[0].idx > 0xfffe) { fail_(5); break; }
+                    r.push_back((uint16_t)op.ins[0].idx);
+                    r.push_back((uint16_t)((op.ins.size() - 1) | (op.outs.size() << 8)));
+                    for (size_t i = 1; i < 4; ++i) r.push_back(i < op.ins.size() ? src(op.ins[i]) : NOSLOT);
+                    for (size_t i = 0; i < 3; ++i) r.push_back(i < op.outs.size() ? dst_slot(op.outs[i], lv, false) : NOSLOT);
+                } break;
+                case WK_P2:
+                    for (auto& in : op.ins) r.push_back(src(in));
+                    outs(op.outs.size() - 12);  // P2_ROUNDS collapses to its 12 outputs
+                    break;
+                default: fail_(6);
+                }
+                if (r.size() > rw) fail_(7);
+                r.resize(rw, 0);
+                out.insert(out.end(), r.begin(), r.end());
+            }
+        };
+        for (uint32_t lv = 0; lv < n_levels && ok; ++lv) {
+            std::map<uint16_t, std::vector<uint32_t>> by_kind;
+            for (uint32_t oi : by_level[lv]) {
+                const uint16_t k = kind_of(s.ops[oi]);
+                if (!k) { fail_(8); break; }
+                by_kind[k].push_back(oi);
+            }
+            for (auto& kv : by_kind) {
+                if (kv.first == WK_CONST) emit_segment(pro, kv.first, kv.second, lv);   // loop-invariant: once, pinned slots
+                else
+                    for (size_t i0 = 0; i0 < kv.second.size(); i0 += 0xfff0) {
+                        std::vector<uint32_t> part(kv.second.begin() + i0, kv.second.begin() + std::min(kv.second.size(), i0 + 0xfff0));
+                        emit_segment(cyc, kv.first, part, lv);
+                    }
+            }
+            for (uint32_t sl : wdying[lv]) wfree.push_back(sl);
+        }
+        for (size_t i = 0; i < carries_store_.size() && ok; ++i) {
+            Carry cw = carries_store_[i];
+            if (wslot[out_vars[i]] == UINT32_MAX) { fail_(9); break; }
+            cw.out_cell = wslot[out_vars[i]];
+            seed_wcarries_.push_back(cw);
+        }
+        if (ok && nws < 0xfff0) {
+            for (uint16_t w : {(uint16_t)WK_END, (uint16_t)0, (uint16_t)0, (uint16_t)0}) pro.push_back(w);
+            for (uint16_t w : {(uint16_t)WK_END, (uint16_t)0, (uint16_t)0, (uint16_t)0}) cyc.push_back(w);
+            seed_wpro_words_ = (uint32_t)pro.size();
+            seed_wprog_ = pro;
+            seed_wprog_.insert(seed_wprog_.end(), cyc.begin(), cyc.end());
+            seed_wslots_ = nws;
+            if (!zkdev::seed_wave_fits((uint32_t)seed_wprog_.size(), nws, s.n_input_words)) { seed_wprog_.clear(); seed_wcarries_.clear(); }
+        } else { seed_wcarries_.clear(); }
+        if (getenv("ZKGL_STRANDS_DEBUG"))
+            fprintf(stderr, "[zkgl] seed wave program: %zu u16 words (%u prologue; built %zu + %zu, lane forms %s (%d)), %u slots%s\n", seed_wprog_.size(), seed_wpro_words_,
+                    pro.size(), cyc.size(), ok ? "ok" : "MISSING", fail_reason, nws, seed_wprog_.empty() ? " - not usable, strand kernel stays" : "");
+    }
     auto cost = [&](uint32_t oi) -> uint64_t {
         const OpRec& op = s.ops[oi];
         uint64_t c = 8 + op.ins.size() + 2 * op.outs.size();
@@ -1499,6 +1640,12 @@ void CS::ensure_uploaded() {
         d_seed_prog_ = upload(padded);
         d_seed_carries_ = (void*)upload(seed_carries_);
     }
+    if (!seed_wprog_.empty()) {
+        std::vector<uint16_t> padded(seed_wprog_);
+        padded.resize((padded.size() + 63) / 64 * 64 + 64, 0);
+        d_seed_wprog_ = upload(padded);
+        d_seed_wcarries_ = (void*)upload(seed_wcarries_);
+    }
     if (!seed_sprog_.empty()) {
         std::vector<uint32_t> padded(seed_sprog_);
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
@@ -1572,7 +1719,11 @@ void CS::launch_seed(const zkdev::ScopeArgs& la, uint64_t* dev_loop_inputs_rw, u
     const char* seed_strands = std::getenv("ZKGL_SEED_STRANDS");  // 0: plain cone, 1: strand form whenever it exists
     const bool generic = force_generic && force_generic[0] == '1';
     const bool use_strands = d_seed_sprog_ && !(seed_strands && seed_strands[0] == '0') && ((seed_strands && seed_strands[0] == '1') || seed_sgain_ >= 1.5f);
-    if (use_strands && !generic)
+    const char* seed_wave = std::getenv("ZKGL_SEED_WAVE");  // 0: never use the op-parallel kernel
+    if (d_seed_wprog_ && !generic && !(seed_wave && seed_wave[0] == '0'))
+        dev_check(zkdev::launch_seed_wave(la, d_seed_wprog_, (uint32_t)seed_wprog_.size(), seed_wpro_words_, seed_wslots_, loop_.n_input_words,
+                                          (const zkdev::CarryArgs*)d_seed_wcarries_, (uint32_t)seed_wcarries_.size(), dev_loop_inputs_rw, n, st));
+    else if (use_strands && !generic)
         dev_check(zkdev::launch_seed_cone_strands(la, d_seed_sprog_, seed_sbegin_, seed_send_, seed_sslots_, loop_.n_input_words,
                                                   (const zkdev::CarryArgs*)d_seed_scarries_, (uint32_t)seed_scarries_.size(), dev_loop_inputs_rw, n, seed_v2_ok_ && !(getenv("ZKGL_SEED_V1")), st));
     else if (d_seed_prog_ && !generic)

@@ -301,6 +301,12 @@ class CS {
     // strand form of the cone (8 wavefronts per block, level barriers; slots recycled per level)
     uint32_t* d_public_slots_ = nullptr;
     bool seed_v2_ok_ = false;
+    // op-parallel seed program (k_seed_wave): 16-bit records, prologue segments then cycle segments
+    std::vector<uint16_t> seed_wprog_;
+    std::vector<Carry> seed_wcarries_;
+    uint32_t seed_wslots_ = 0, seed_wpro_words_ = 0;
+    uint16_t* d_seed_wprog_ = nullptr;
+    void* d_seed_wcarries_ = nullptr;
     std::vector<uint32_t> seed_sprog_;
     std::vector<Carry> seed_scarries_;
     uint32_t seed_sslots_ = 0, seed_sbegin_[zkdev::STRANDS_PER_TILE] = {}, seed_send_[zkdev::STRANDS_PER_TILE] = {};

@@ -54,6 +54,10 @@ constexpr uint32_t STRANDS_PER_TILE = ZKGL_STRANDS_PER_TILE;
 constexpr uint32_t SEED_STRANDS_PER_TILE = 8;
 int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], void* stream);
 struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // mirrors zke::CarryDev
+// op-parallel seeding (kernels_seed_wave.hpp): one wavefront per instance, the program resident in LDS
+bool seed_wave_fits(uint32_t prog_u16, uint32_t n_slots, uint32_t n_input_words);
+int launch_seed_wave(const ScopeArgs& sc, const uint16_t* prog, uint32_t prog_u16, uint32_t pro_words, uint32_t n_slots, uint32_t n_input_words,
+                     const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream);
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);
 int launch_check_gates(const CheckArgs& cd, void* stream);

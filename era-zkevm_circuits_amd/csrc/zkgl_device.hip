@@ -8,6 +8,7 @@
 #include "kernels_primitives.hpp"
 #include "kernels_engine.hpp"
 #include "kernels_engine2.hpp"
+#include "kernels_seed_wave.hpp"
 #include "kernels_lookup_arg.hpp"
 #include "kernels_ntt.hpp"
 #include "kernels_perm.hpp"
@@ -374,6 +375,24 @@ int launch_seed_cone_strands(const ScopeArgs& sc, const uint32_t* seed_sprog, co
     else
         zke::k_seed_cone_strands<false><<<grid, 64 * zke::SEED_STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), seed_sprog, tab, c, n_carries, inputs_rw, n_instances, lpb, n_slots, n_input_words);
     return LAUNCH_CHECK("k_seed_cone_strands");
+}
+
+bool seed_wave_fits(uint32_t prog_u16, uint32_t n_slots, uint32_t n_input_words) {
+    return prog_u16 + 64 <= zke::SW_PROG_U16 && n_slots + n_input_words + 128 <= zke::SW_AREA && n_input_words <= 512;
+}
+int launch_seed_wave(const ScopeArgs& sc, const uint16_t* prog, uint32_t prog_u16, uint32_t pro_words, uint32_t n_slots, uint32_t n_input_words,
+                     const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream) {
+    if (n_instances == 0 || sc.limit == 0) return 0;
+    if (!seed_wave_fits(prog_u16, n_slots, n_input_words)) return -1;
+    zke::SeedWaveDev a;
+    a.sc = to_dev(sc); a.prog = prog; a.prog_u16 = prog_u16; a.pro_words = pro_words;
+    a.carries = reinterpret_cast<const zke::SeedCarryDev*>(d_carries); a.n_carries = n_carries;
+    a.inputs_rw = inputs_rw; a.n_instances = n_instances; a.n_slots = n_slots; a.n_input_words = n_input_words;
+    // one wavefront per instance; up to 8 instances share a workgroup (and its LDS copy of the program); few instances spread over the CUs
+    uint32_t waves = std::min<uint32_t>(zke::SW_WAVES, std::max<uint32_t>(1, (n_instances + 255) / 256));
+    const unsigned grid = (n_instances + waves - 1) / waves;
+    zke::k_seed_wave<<<grid, 64 * waves, 0, (hipStream_t)stream>>>(a);
+    return LAUNCH_CHECK("k_seed_wave");
 }
 
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
