@@ -163,7 +163,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=384, help="independent circuit instances per GPU per step")
-    ap.add_argument("--seed-windows", type=int, default=4, help="batches of raw witness seeded in one zk_cs_seed_stream pass (the stream = batch x windows instances)")
+    ap.add_argument("--seed-windows", type=int, default=5, help="batches of raw witness seeded in one zk_cs_seed_stream pass (the stream = batch x windows instances)")
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--workload", default="main_vm", choices=["main_vm", "vm_shaped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -91,8 +91,10 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_seed_wave(SeedWaveDev a) {
     const cpool_ptr cpool = (cpool_ptr)(uintptr_t)sc.consts;
     __syncthreads();
 
-    // executes the segments from `pos` up to the end marker; every wavefront of the workgroup walks the same segments, so the
-    // barriers between segments (LDS visibility of the previous segment's stores) are reached by all of them
+    // executes the segments from `pos` up to the end marker.  A wavefront only ever reads what IT wrote to its slot area (the
+    // program is read-only), and LDS instructions of one wavefront complete in issue order: between segments a compiler-level
+    // fence is enough, no workgroup barrier — the wavefronts of a workgroup drift freely and fill each other's stalls.
+    auto wave_fence = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     auto run = [&](uint32_t pos) {
         for (;;) {
             const uint32_t kind = uni(prog[pos]), count = uni(prog[pos + 1]);  // the same words for every lane: scalar control flow
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_seed_wave(SeedWaveDev a) {
                         uint64_t* const xb = xbuf + flip * 64;
                         flip ^= 1;
                         xb[lane] = x;
-                        __syncthreads();
+                        wave_fence();
 #pragma unroll
                         for (int i = 0; i < 12; ++i) v[i] = xb[min(g, 4u) * 12 + i];
                     };
@@ -342,12 +344,12 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_seed_wave(SeedWaveDev a) {
             default:
                 return;  // malformed program: built by the host
             }
-            __syncthreads();
+            wave_fence();
         }
     };
 
     run(0);  // prologue: loop-invariant constants and outer imports
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
     // the raw input words of cycle k+1 are fetched while cycle k runs (a strided gather: one cache line per word), 8 per lane
     uint64_t nxt[8];
 #pragma unroll
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_seed_wave(SeedWaveDev a) {
                 if (w < a.n_input_words) nxt[j] = a.inputs_rw[(size_t)w * sc.in_stride + lane0 + k + 1];
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         for (uint32_t c = lane; c < a.n_carries; c += 64) {
             const SeedCarryDev cd = a.carries[c];
             if (k == 0 && !cd.has_first) continue;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_seed_wave(SeedWaveDev a) {
             in_store[cd.word] = v;
             a.inputs_rw[(size_t)cd.word * sc.in_stride + lane0 + k] = v;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         run(a.pro_words);
     }
 }
