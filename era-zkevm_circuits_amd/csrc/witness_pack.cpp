@@ -65,6 +65,19 @@ void put_queue_state(uint64_t* dst, size_t stride, size_t& w, const zk_full_queu
     for (auto x : q.tail) dst[(w++) * stride] = x;
     dst[(w++) * stride] = q.length;
 }
+
+// strided word writer: word k of the instance at dst[k * stride]
+struct Out {
+    uint64_t* dst; size_t stride; size_t k = 0;
+    void w(uint64_t v) { dst[(k++) * stride] = v; }
+    template <class T, size_t N> void arr(const T (&a)[N]) { for (auto x : a) w(x); }
+    void qstate(const zk_queue_state_witness& q) { arr(q.head); arr(q.tail); w(q.length); }
+    void log_query(const zk_log_query_witness* q) {  // LogQuery field order, 36 words; nullptr: the zero item
+        if (!q) { for (int i = 0; i < 36; ++i) w(0); return; }
+        arr(q->address); arr(q->key); arr(q->read_value); arr(q->written_value);
+        w(q->aux_byte); w(q->rw_flag ? 1 : 0); w(q->rollback ? 1 : 0); w(q->is_service ? 1 : 0); w(q->shard_id); w(q->tx_number_in_block); w(q->timestamp);
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -145,6 +158,57 @@ int zk_decode_ram_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_ram_p
     }
     if (!c.ok) return bad(ZK_ERR_INVALID, "zk_decode_ram_witness_bincode: truncated or malformed input");
     if (consumed) *consumed = c.at;
+    return ZK_OK;
+}
+
+
+int zk_pack_storage_witness(const zk_storage_validity_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_storage_witness: bad argument");
+    if (w->n_unsorted != w->n_sorted) return bad(ZK_ERR_INVALID, "zk_pack_storage_witness: the two queue witnesses differ in length");
+    if (w->n_unsorted > limit) return bad(ZK_ERR_INVALID, "zk_pack_storage_witness: more queue elements than cycles");
+    if (w->n_unsorted && (!w->unsorted_queue_witness || !w->intermediate_sorted_queue_witness)) return bad(ZK_ERR_INVALID, "zk_pack_storage_witness: null queue witness");
+    Out o{outer_words + instance, batch};
+    o.w(w->start_flag ? 1 : 0);
+    o.w(w->shard_id_to_process); o.qstate(w->unsorted_log_queue_state); o.qstate(w->intermediate_sorted_queue_state);
+    const zk_storage_fsm_witness& f = w->hidden_fsm_input;  // StorageDeduplicatorFSMInputOutput order (input.rs:37-52)
+    o.arr(f.lhs_accumulator); o.arr(f.rhs_accumulator);
+    o.qstate(f.current_unsorted_queue_state); o.qstate(f.current_intermediate_sorted_queue_state); o.qstate(f.current_final_sorted_queue_state);
+    o.w(f.cycle_idx); o.arr(f.previous_packed_key); o.arr(f.previous_key); o.arr(f.previous_address); o.w(f.previous_timestamp);
+    o.w(f.this_cell_has_explicit_read_and_rollback_depth_zero ? 1 : 0); o.arr(f.this_cell_base_value); o.arr(f.this_cell_current_value); o.w(f.this_cell_current_depth);
+    if (o.k != ZK_STORAGE_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: storage outer layout");
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        for (int i = 0; i < 67; ++i) l.w(0);
+        l.log_query(c < w->n_unsorted ? &w->unsorted_queue_witness[c] : nullptr);
+        if (c < w->n_sorted) { l.log_query(&w->intermediate_sorted_queue_witness[c].record); l.w(w->intermediate_sorted_queue_witness[c].timestamp); }
+        else { l.log_query(nullptr); l.w(0); }
+        if (l.k != ZK_STORAGE_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: storage loop layout");
+    }
+    return ZK_OK;
+}
+
+int zk_pack_log_sorter_witness(const zk_log_sorter_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_log_sorter_witness: bad argument");
+    if (w->n_initial != w->n_sorted) return bad(ZK_ERR_INVALID, "zk_pack_log_sorter_witness: the two queue witnesses differ in length");
+    if (w->n_initial > limit) return bad(ZK_ERR_INVALID, "zk_pack_log_sorter_witness: more queue elements than cycles");
+    if (w->n_initial && (!w->initial_queue_witness || !w->intermediate_sorted_queue_witness)) return bad(ZK_ERR_INVALID, "zk_pack_log_sorter_witness: null queue witness");
+    Out o{outer_words + instance, batch};
+    o.w(w->start_flag ? 1 : 0);
+    o.qstate(w->initial_log_queue_state); o.qstate(w->intermediate_sorted_queue_state);
+    const zk_log_sorter_fsm_witness& f = w->hidden_fsm_input;  // EventsDeduplicatorFSMInputOutput order (input.rs:28-36)
+    o.arr(f.lhs_accumulator); o.arr(f.rhs_accumulator);
+    o.qstate(f.initial_unsorted_queue_state); o.qstate(f.intermediate_sorted_queue_state); o.qstate(f.final_result_queue_state);
+    o.w(f.previous_key); o.log_query(&f.previous_item);
+    if (o.k != ZK_LOG_SORTER_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: log_sorter outer layout");
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        for (int i = 0; i < 57; ++i) l.w(0);
+        l.log_query(c < w->n_initial ? &w->initial_queue_witness[c] : nullptr);
+        l.log_query(c < w->n_sorted ? &w->intermediate_sorted_queue_witness[c] : nullptr);
+        if (l.k != ZK_LOG_SORTER_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: log_sorter loop layout");
+    }
     return ZK_OK;
 }
 

@@ -170,6 +170,67 @@ def decode_ram_witness_bincode(data: bytes, max_elements: int):
     return w, used.value
 
 
+class LogQueryWitness(C.Structure):
+    _fields_ = [("address", C.c_uint32 * 5), ("key", C.c_uint32 * 8), ("read_value", C.c_uint32 * 8), ("written_value", C.c_uint32 * 8),
+                ("aux_byte", C.c_uint8), ("rw_flag", C.c_uint8), ("rollback", C.c_uint8), ("is_service", C.c_uint8), ("shard_id", C.c_uint8),
+                ("tx_number_in_block", C.c_uint32), ("timestamp", C.c_uint32)]
+
+
+class QueueStateWitness(C.Structure):
+    _fields_ = [("head", C.c_uint64 * 4), ("tail", C.c_uint64 * 4), ("length", C.c_uint32)]
+
+
+class StorageFsmWitness(C.Structure):
+    _fields_ = [("lhs_accumulator", C.c_uint64 * 2), ("rhs_accumulator", C.c_uint64 * 2),
+                ("current_unsorted_queue_state", QueueStateWitness), ("current_intermediate_sorted_queue_state", QueueStateWitness),
+                ("current_final_sorted_queue_state", QueueStateWitness), ("cycle_idx", C.c_uint32), ("previous_packed_key", C.c_uint32 * 13),
+                ("previous_key", C.c_uint32 * 8), ("previous_address", C.c_uint32 * 5), ("previous_timestamp", C.c_uint32),
+                ("this_cell_has_explicit_read_and_rollback_depth_zero", C.c_uint8), ("this_cell_base_value", C.c_uint32 * 8),
+                ("this_cell_current_value", C.c_uint32 * 8), ("this_cell_current_depth", C.c_uint32)]
+
+
+class TimestampedLogRecordWitness(C.Structure):
+    _fields_ = [("record", LogQueryWitness), ("timestamp", C.c_uint32)]
+
+
+class StorageValidityWitness(C.Structure):
+    _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("shard_id_to_process", C.c_uint8),
+                ("unsorted_log_queue_state", QueueStateWitness), ("intermediate_sorted_queue_state", QueueStateWitness),
+                ("hidden_fsm_input", StorageFsmWitness), ("hidden_fsm_output", StorageFsmWitness),
+                ("unsorted_queue_witness", C.POINTER(LogQueryWitness)), ("n_unsorted", C.c_uint32),
+                ("intermediate_sorted_queue_witness", C.POINTER(TimestampedLogRecordWitness)), ("n_sorted", C.c_uint32)]
+
+
+class LogSorterFsmWitness(C.Structure):
+    _fields_ = [("lhs_accumulator", C.c_uint64 * 2), ("rhs_accumulator", C.c_uint64 * 2), ("initial_unsorted_queue_state", QueueStateWitness),
+                ("intermediate_sorted_queue_state", QueueStateWitness), ("final_result_queue_state", QueueStateWitness),
+                ("previous_key", C.c_uint32), ("previous_item", LogQueryWitness)]
+
+
+class LogSorterWitness(C.Structure):
+    _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("initial_log_queue_state", QueueStateWitness),
+                ("intermediate_sorted_queue_state", QueueStateWitness), ("hidden_fsm_input", LogSorterFsmWitness),
+                ("hidden_fsm_output", LogSorterFsmWitness), ("initial_queue_witness", C.POINTER(LogQueryWitness)), ("n_initial", C.c_uint32),
+                ("intermediate_sorted_queue_witness", C.POINTER(LogQueryWitness)), ("n_sorted", C.c_uint32)]
+
+
+def _pack(fn, w, limit, instance, outer, loop, n_outer, n_loop):
+    batch = outer.shape[1]
+    assert outer.shape == (n_outer, batch) and loop.shape == (n_loop, batch * limit)
+    assert outer.dtype == np.uint64 and loop.dtype == np.uint64 and outer.flags.c_contiguous and loop.flags.c_contiguous
+    _check(fn(C.byref(w), limit, instance, batch, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
+
+
+def pack_storage_witness(w, limit, instance, outer, loop):
+    """zk_pack_storage_witness: outer [97, B], loop [140, B * limit]"""
+    _pack(lib().zk_pack_storage_witness, w, limit, instance, outer, loop, 97, 140)
+
+
+def pack_log_sorter_witness(w, limit, instance, outer, loop):
+    """zk_pack_log_sorter_witness: outer [87, B], loop [129, B * limit]"""
+    _pack(lib().zk_pack_log_sorter_witness, w, limit, instance, outer, loop, 87, 129)
+
+
 class Comm:
     """RCCL communicator behind the C ABI (zk_comm_*): one process per GPU; rank 0's `unique_id()` bytes reach the other ranks through
     the host's launcher (bench.py: a torch.distributed broadcast)."""

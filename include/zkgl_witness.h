@@ -74,6 +74,68 @@ int zk_decode_ram_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_ram_p
                                   zk_memory_query_witness *unsorted_buf, uint32_t unsorted_cap,
                                   zk_memory_query_witness *sorted_buf, uint32_t sorted_cap, size_t *consumed);
 
+
+/* ---- LogQuery witness, /root/reference/src/base_structures/log_query/mod.rs:23-35 (UInt160 address: 5 little-endian u32 limbs) */
+typedef struct zk_log_query_witness {
+    uint32_t address[5];
+    uint32_t key[8], read_value[8], written_value[8];
+    uint8_t aux_byte, rw_flag, rollback, is_service, shard_id;
+    uint32_t tx_number_in_block, timestamp;
+} zk_log_query_witness;
+/* QueueStateWitness<F, QUEUE_STATE_WIDTH = 4>: head, tail.tail, tail.length */
+typedef struct zk_queue_state_witness { uint64_t head[4]; uint64_t tail[4]; uint32_t length; } zk_queue_state_witness;
+
+/* StorageDeduplicatorInstanceWitness, /root/reference/src/storage_validity_by_grand_product/input.rs:131-136 (FSM :37-52, input data :84-88) */
+typedef struct zk_storage_fsm_witness {
+    uint64_t lhs_accumulator[2], rhs_accumulator[2];
+    zk_queue_state_witness current_unsorted_queue_state, current_intermediate_sorted_queue_state, current_final_sorted_queue_state;
+    uint32_t cycle_idx;
+    uint32_t previous_packed_key[13];
+    uint32_t previous_key[8];
+    uint32_t previous_address[5];
+    uint32_t previous_timestamp;
+    uint8_t this_cell_has_explicit_read_and_rollback_depth_zero;
+    uint32_t this_cell_base_value[8], this_cell_current_value[8];
+    uint32_t this_cell_current_depth;
+} zk_storage_fsm_witness;
+typedef struct zk_timestamped_log_record_witness { zk_log_query_witness record; uint32_t timestamp; } zk_timestamped_log_record_witness;
+typedef struct zk_storage_validity_witness {
+    uint8_t start_flag, completion_flag;
+    uint8_t shard_id_to_process;
+    zk_queue_state_witness unsorted_log_queue_state, intermediate_sorted_queue_state;
+    zk_storage_fsm_witness hidden_fsm_input, hidden_fsm_output;
+    const zk_log_query_witness *unsorted_queue_witness; uint32_t n_unsorted;
+    const zk_timestamped_log_record_witness *intermediate_sorted_queue_witness; uint32_t n_sorted;
+} zk_storage_validity_witness;
+#define ZK_STORAGE_OUTER_WORDS 97
+#define ZK_STORAGE_LOOP_WORDS 140
+/* sort_and_deduplicate_storage_access_entry_point (/root/reference/src/storage_validity_by_grand_product/mod.rs:166-506): outer_words
+ * [97][batch], loop_words[140][batch * limit]; the 67 carried words of every cycle zeroed (device seeding), popped LogQuery (36 words)
+ * and TimestampedStorageLogRecord (37 words) per cycle, zero items past the queue length */
+int zk_pack_storage_witness(const zk_storage_validity_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                            uint64_t *outer_words, uint64_t *loop_words);
+
+/* EventsDeduplicatorInstanceWitness, /root/reference/src/log_sorter/input.rs:101-106 (FSM :28-36, input data :57-60) */
+typedef struct zk_log_sorter_fsm_witness {
+    uint64_t lhs_accumulator[2], rhs_accumulator[2];
+    zk_queue_state_witness initial_unsorted_queue_state, intermediate_sorted_queue_state, final_result_queue_state;
+    uint32_t previous_key;
+    zk_log_query_witness previous_item;
+} zk_log_sorter_fsm_witness;
+typedef struct zk_log_sorter_witness {
+    uint8_t start_flag, completion_flag;
+    zk_queue_state_witness initial_log_queue_state, intermediate_sorted_queue_state;
+    zk_log_sorter_fsm_witness hidden_fsm_input, hidden_fsm_output;
+    const zk_log_query_witness *initial_queue_witness; uint32_t n_initial;
+    const zk_log_query_witness *intermediate_sorted_queue_witness; uint32_t n_sorted;
+} zk_log_sorter_witness;
+#define ZK_LOG_SORTER_OUTER_WORDS 87
+#define ZK_LOG_SORTER_LOOP_WORDS 129
+/* sort_and_deduplicate_events_entry_point (/root/reference/src/log_sorter/mod.rs:34-441): outer_words[87][batch],
+ * loop_words[129][batch * limit]; 57 carried words zeroed, two LogQuery items (36 words each) per cycle */
+int zk_pack_log_sorter_witness(const zk_log_sorter_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                               uint64_t *outer_words, uint64_t *loop_words);
+
 #ifdef __cplusplus
 }
 #endif

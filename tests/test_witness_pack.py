@@ -192,3 +192,76 @@ def test_non_canonical_input_word_is_reported(zk):
     cs.resolve()
     ok, f = cs.check_if_satisfied()
     assert not ok and f.scope == 1 and f.instance == 1
+
+
+# ---------------------------------------------------------------- storage_validity / log_sorter packers
+def _lq(words):
+    q = zkgl.LogQueryWitness()
+    q.address[:] = words[0:5]; q.key[:] = words[5:13]; q.read_value[:] = words[13:21]; q.written_value[:] = words[21:29]
+    q.aux_byte, q.rw_flag, q.rollback, q.is_service, q.shard_id, q.tx_number_in_block, q.timestamp = [int(x) for x in words[29:36]]
+    return q
+
+
+def _q4(words):
+    q = zkgl.QueueStateWitness()
+    q.head[:] = [int(x) for x in words[0:4]]; q.tail[:] = [int(x) for x in words[4:8]]; q.length = int(words[8])
+    return q
+
+
+def test_storage_packer_equals_the_oracle_packer():
+    from oracle import storage_native as sn
+    limit = 20
+    cases = []
+    for seed, n in ((11, 17), (12, 5)):
+        u, s = sn.random_storage_witness(np.random.default_rng(seed), n, n_cells=3)
+        cases.append((u, s, sn.instance(u, s, limit)))
+    B = len(cases)
+    outer = np.zeros((97, B), dtype=np.uint64); loop = np.full((140, B * limit), 7, dtype=np.uint64)
+    for i, (u, s, inst) in enumerate(cases):
+        o = inst["outer"]
+        w = zkgl.StorageValidityWitness()
+        w.start_flag, w.completion_flag, w.shard_id_to_process = int(o[0]), int(inst["completed"]), int(o[1])
+        w.unsorted_log_queue_state, w.intermediate_sorted_queue_state = _q4(o[2:11]), _q4(o[11:20])
+        f, x = w.hidden_fsm_input, o[20:97]
+        f.lhs_accumulator[:] = x[0:2]; f.rhs_accumulator[:] = x[2:4]
+        f.current_unsorted_queue_state, f.current_intermediate_sorted_queue_state, f.current_final_sorted_queue_state = _q4(x[4:13]), _q4(x[13:22]), _q4(x[22:31])
+        f.cycle_idx = int(x[31]); f.previous_packed_key[:] = x[32:45]; f.previous_key[:] = x[45:53]; f.previous_address[:] = x[53:58]
+        f.previous_timestamp = int(x[58]); f.this_cell_has_explicit_read_and_rollback_depth_zero = int(x[59])
+        f.this_cell_base_value[:] = x[60:68]; f.this_cell_current_value[:] = x[68:76]; f.this_cell_current_depth = int(x[76])
+        ua = (zkgl.LogQueryWitness * len(u))(*[_lq(q) for q in u])
+        sa = (zkgl.TimestampedLogRecordWitness * len(s))()
+        for rec, (q, t) in zip(sa, s):
+            rec.record, rec.timestamp = _lq(q), int(t)
+        w.unsorted_queue_witness, w.n_unsorted, w.intermediate_sorted_queue_witness, w.n_sorted = ua, len(u), sa, len(s)
+        zkgl.pack_storage_witness(w, limit, i, outer, loop)
+    eo, el = sn.pack_streams([c[2] for c in cases], limit)
+    el = el.copy(); el[0:67] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+def test_log_sorter_packer_equals_the_oracle_packer():
+    from oracle import log_sorter_native as ln
+    limit = 20
+    cases = []
+    for seed, n in ((21, 12), (22, 4)):
+        u, s = ln.random_events(np.random.default_rng(seed), n, rollback_frac=0.3)
+        u, s = u[:limit], s[:limit]
+        cases.append((u, s, ln.instance(u, s, limit)))
+    B = len(cases)
+    outer = np.zeros((87, B), dtype=np.uint64); loop = np.full((129, B * limit), 7, dtype=np.uint64)
+    for i, (u, s, inst) in enumerate(cases):
+        o = inst["outer"]
+        w = zkgl.LogSorterWitness()
+        w.start_flag, w.completion_flag = int(o[0]), int(inst["completed"])
+        w.initial_log_queue_state, w.intermediate_sorted_queue_state = _q4(o[1:10]), _q4(o[10:19])
+        f, x = w.hidden_fsm_input, o[19:87]
+        f.lhs_accumulator[:] = x[0:2]; f.rhs_accumulator[:] = x[2:4]
+        f.initial_unsorted_queue_state, f.intermediate_sorted_queue_state, f.final_result_queue_state = _q4(x[4:13]), _q4(x[13:22]), _q4(x[22:31])
+        f.previous_key = int(x[31]); f.previous_item = _lq(x[32:68])
+        ua = (zkgl.LogQueryWitness * len(u))(*[_lq(q) for q in u])
+        sa = (zkgl.LogQueryWitness * len(s))(*[_lq(q) for q in s])
+        w.initial_queue_witness, w.n_initial, w.intermediate_sorted_queue_witness, w.n_sorted = ua, len(u), sa, len(s)
+        zkgl.pack_log_sorter_witness(w, limit, i, outer, loop)
+    eo, el = ln.pack_streams([c[2] for c in cases], limit)
+    el = el.copy(); el[0:57] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
