@@ -47,6 +47,7 @@ struct zk_cs {
 namespace {
 thread_local std::string g_err;
 bool g_inited = false;
+int g_device = -1;
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -93,11 +94,15 @@ int zk_init(int device) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(ZK_ERR_HIP, "no HIP device visible: libzkgl has no CPU fallback");
     if (device < 0 || device >= n) return fail(ZK_ERR_INVALID, "device index out of range");
+    // one device per process (one process per GPU, as the multi-GPU path runs): the Poseidon2 constants, the NTT twiddle tables and the
+    // kernels' LDS opt-ins are process-wide state bound to the first device
+    if (g_inited && device != g_device) return fail(ZK_ERR_INVALID, "zk_init: this process is already bound to another device (one process per GPU)");
     e = hipSetDevice(device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     int rc = zkdev::upload_round_constants(zkgl::poseidon_round_constants());
     if (rc) return fail(ZK_ERR_HIP, zkdev::last_hip_error());
     g_inited = true;
+    g_device = device;
     return ZK_OK;
 }
 

@@ -40,7 +40,8 @@ typedef enum zk_status {
 } zk_status;
 
 const char *zk_last_error(void);
-/* Select the device, upload Poseidon2 constants.  Fails loudly (ZK_ERR_HIP) without a GPU. */
+/* Select the device, upload Poseidon2 constants.  Fails loudly (ZK_ERR_HIP) without a GPU.  One device per process: a second
+ * call with another device index is ZK_ERR_INVALID (process-wide device tables are bound to the first). */
 int zk_init(int device);
 int zk_device_count(void);
 /* host-side derivation of the 360 round constants (no GPU needed) */
