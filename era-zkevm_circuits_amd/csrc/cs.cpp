@@ -1100,6 +1100,16 @@ void CS::emit_scope(Scope& s) {
             fprintf(stderr, "   op %2u: n=%6llu var=%7llu const=%6llu outer=%6llu raw=%6llu outs=%7llu\n", kv.first, (unsigned long long)kv.second[0],
                     (unsigned long long)kv.second[1], (unsigned long long)kv.second[2], (unsigned long long)kv.second[3], (unsigned long long)kv.second[5],
                     (unsigned long long)kv.second[4]);
+        {
+            std::vector<uint8_t> is_const(s.n_vars, 0);
+            for (auto& op : s.ops) if (!op.seed_only && op.opcode == ZK_OP_CONST) for (uint32_t ov : op.outs) is_const[ov] = 1;
+            uint64_t op_refs = 0, op_const = 0, gate_refs = 0, gate_const = 0;
+            for (auto& op : s.ops) if (!op.seed_only) for (auto& in : op.ins) if (in.kind == Operand::VAR) { op_refs++; op_const += is_const[in.idx]; }
+            for (auto& g : s.gates) for (uint32_t v : g.vars) { gate_refs++; gate_const += is_const[v]; }
+            for (auto& l : s.lookups) for (uint32_t v : l.vars) { gate_refs++; gate_const += is_const[v]; }
+            fprintf(stderr, "   operand references to constant variables: ops %llu of %llu, gates/lookups %llu of %llu\n", (unsigned long long)op_const,
+                    (unsigned long long)op_refs, (unsigned long long)gate_const, (unsigned long long)gate_refs);
+        }
         fprintf(stderr, "   operand age (values produced since): <=8 %llu, <=32 %llu, <=128 %llu, <=512 %llu, <=2048 %llu, <=8192 %llu, more %llu\n",
                 (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2], (unsigned long long)hist[3], (unsigned long long)hist[4],
                 (unsigned long long)hist[5], (unsigned long long)hist[6]);

@@ -126,3 +126,25 @@ def test_gather_commitments_through_the_c_abi(zk, batch):
     assert got.shape == (1, B, 4)
     for i in range(B):
         assert [int(x) for x in got[0, i]] == commits[i]
+
+
+@pytest.mark.parametrize("mode", ["inline", "pass"])
+def test_multiplicities_in_both_modes(zk, batch, monkeypatch, mode):
+    """lookup multiplicities by wave-aggregated atomics inside the witness kernels (inline) and by the k_multiplicities pass over the
+    stored keys (pass: what hash-style circuits use by default) — the same vectors, equal to the oracle's"""
+    cs, D, outer, loop, commits, info = batch
+    monkeypatch.setenv("ZKGL_MULT_MODE", mode)
+    B = 16
+    o, l = outer[:, :B].copy(), loop[:, :B * LIMIT].copy()
+    cs.set_batch(B)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(o), zk.DeviceBuffer.from_numpy(l)
+    cs.bind_inputs(False, d_o, o.shape[0]); cs.bind_inputs(True, d_l, l.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    run = run_oracle(cs, B)
+    run.resolve(o, l)
+    total = run.mult.size // B
+    for i in range(B):
+        assert np.array_equal(cs.multiplicities(i), run.mult[i * total:(i + 1) * total]), (mode, i)
+    cs.resolve()   # the plain resolve path counts them too
+    assert np.array_equal(cs.multiplicities(3), run.mult[3 * total:4 * total])
