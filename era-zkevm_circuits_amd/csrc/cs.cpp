@@ -1228,8 +1228,10 @@ void CS::build_seed_program() {
     uint32_t n_levels = 0;
     {
         auto heavy = [&](const OpRec& op) {
+            // U256_DIVREM (256 dependent shift-subtract steps) is a heavy op too: the VM cycle's two divisions then share a level (one
+            // segment of the op-parallel kernel, two strands of the strand kernel) instead of running one after the other
             return op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2 || op.opcode == ZK_OP_KECCAK_ABSORB || op.opcode == ZK_OP_SHA256_COMPRESS ||
-                   op.opcode == ZK_OP_NN_MULMOD;
+                   op.opcode == ZK_OP_NN_MULMOD || op.opcode == ZK_OP_U256_DIVREM;
         };
         std::vector<uint32_t> tier(s.ops.size(), 0), local(s.ops.size(), 0);
         uint32_t n_tiers = 0;
