@@ -2046,7 +2046,7 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     launch_phase(outer_, oa, 2, ax);  // outer POST
     // compact traces: the gate checkers read every cell through the alias map; no copy pass (see check_satisfied)
     dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, true), ax));
-    check_inputs_canonical(ax, st);
+    check_inputs_canonical(ax, ax);   // both scopes on the auxiliary stream: it has slack behind the loop-scope kernels
     hip_check(hipEventRecord(E(4), ax), "event");
     if (limit_) {
         dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, true), st));

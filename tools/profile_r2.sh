@@ -6,7 +6,7 @@
 #  4. the other BASELINE configurations                                         -> r2_config_timings.jsonl
 set -u
 ROOT=$(pwd); mkdir -p "$ROOT/gpurun_out"
-B=${B:-256}
+B=${B:-384}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt_r2
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_r2 -o kt -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline < /dev/null > "$ROOT/gpurun_out/r2_bench_under_rocprof.json" 2> /tmp/kt_r2.err
@@ -18,7 +18,7 @@ tools/pmc_pass.sh r2_fetch FETCH_SIZE > /dev/null
 tools/pmc_pass.sh r2_write WRITE_SIZE > /dev/null
 tools/pmc_pass.sh r2_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY > /dev/null
 unset PMC_CMD
-for b in ${BATCHES:-256 384 512}; do
+for b in ${BATCHES:-64 256 384}; do
   timeout 900 python bench.py --steps 4 --warmup 1 --batch $b --no-cpu-baseline < /dev/null > gpurun_out/r2_bench_b$b.json 2> gpurun_out/r2_bench_b$b.err || tail -2 gpurun_out/r2_bench_b$b.err
   python - <<PY
 import json
