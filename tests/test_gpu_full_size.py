@@ -7,7 +7,12 @@
                                           model) and the device reproduces the native public input; satisfied
   C4  storage_validity + log_sorter, 2^22 rows      : accepted, commitments equal the native restatement; a broken
                                           permutation is rejected
-  C2 is bench.py's workload (smoke + test_vm_shaped in test_gpu_cs.py); C5 (eip_4844, 4096 chunks) is in test_gpu_cs.py.
+  C2  main_vm, 2^20 rows (2 384 cycles)  : the raw witness of the committed fixture (8 executions of synthetic zkEVM programs,
+                                          tests/golden/vm_bench_witness.npz) is seeded on the device, resolved and satisfied; the
+                                          public inputs equal the native restatement's commitments stored with the fixture; the
+                                          seeded stream is idempotent under a second seeding pass; a flipped oracle word is rejected
+                                          at its instance
+  C5 (eip_4844, 4096 chunks) is in test_gpu_cs.py.
 
 Loop streams come from the native restatements (oracle/*_native.py: they hold the per-cycle state the device seeding
 reproduces, which is checked at small sizes)."""
@@ -180,3 +185,39 @@ def test_c4_log_sorter_2_22_rows(zk):
     assert ok, f
     assert cs.public_inputs(0) == inst["commitment"]
     del keep
+
+
+def test_c2_main_vm_2_20_rows(zk):
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    cs, limit = bench.build_main_vm_cs(zkgl, 20)
+    st = cs.stats()
+    assert st["rows_per_instance"] <= 1 << 20 and st["rows_per_instance"] > (1 << 20) - 2 * st["loop_slots"]
+    B = 8
+    outer, loop, expect = bench.main_vm_streams(cs, limit, B)
+    assert expect is not None, "the fixture was generated for another limit"
+    assert not loop[0:bench.VM_STATE_WORDS].any()                      # raw witness only: the carried VmLocalState words are blank
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.seed_stream(B, d_o, d_l)
+    seeded = d_l.to_numpy().reshape(loop.shape)
+    assert np.array_equal(seeded[bench.VM_STATE_WORDS:], loop[bench.VM_STATE_WORDS:])   # seeding writes carried words only
+    cs.seed_stream(B, d_o, d_l)                                         # idempotent: the same recurrence from the same raw words
+    assert np.array_equal(d_l.to_numpy().reshape(loop.shape), seeded)
+    cs.set_batch(B)
+    cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i in range(B):
+        assert cs.public_inputs(i) == [int(x) for x in expect[i]], i
+    assert int(cs.multiplicities(0).sum()) == st["lookups_per_instance"]
+    # a flipped limb of an opcode word in the middle of instance 5
+    lay = cs.main_vm_layout()["loop"]
+    bad = seeded.copy()
+    bad[lay["code_word"][0] + 1, 5 * limit + limit // 2] ^= 1
+    d_b = zk.DeviceBuffer.from_numpy(bad)
+    cs.bind_inputs(True, d_b, bad.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert not ok and f.instance == 5
