@@ -1925,7 +1925,14 @@ uint32_t CS::lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], vo
     for (int i = 0; i < 10; ++i)
         if (ch[i] >= 0xFFFFFFFF00000001ull) throw ZkError(ZK_ERR_INVALID, "lookup_argument: non-canonical challenge");
     uint64_t *d_acc_o = nullptr, *d_acc_l = nullptr, *d_inv = nullptr, *d_ab = nullptr;
-    auto alloc = [&](uint64_t** p, size_t words) { hip_check(hipMalloc((void**)p, std::max<size_t>(words, 1) * 8), "hipMalloc lookup_argument"); };
+    struct Temps {  // device temporaries of this call: released on every exit path, exceptions included
+        std::vector<void*> ptrs;
+        ~Temps() { for (void* p : ptrs) hipFree(p); }
+    } temps;
+    auto alloc = [&](uint64_t** p, size_t words) {
+        hip_check(hipMalloc((void**)p, std::max<size_t>(words, 1) * 8), "hipMalloc lookup_argument");
+        temps.ptrs.push_back(*p);
+    };
     alloc(&d_acc_o, 2 * (size_t)outer_.n_lanes);
     alloc(&d_acc_l, 2 * (size_t)loop_.n_lanes);
     alloc(&d_inv, 2 * (size_t)total_table_rows_);
@@ -1943,7 +1950,6 @@ uint32_t CS::lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], vo
     std::vector<uint64_t> h(4 * (size_t)batch_);
     hip_check(hipMemcpyAsync(h.data(), d_ab, h.size() * 8, hipMemcpyDeviceToHost, st), "memcpy lookup_argument");
     hip_check(hipStreamSynchronize(st), "lookup_argument sync");
-    hipFree(d_acc_o); hipFree(d_acc_l); hipFree(d_inv); hipFree(d_ab);
     out.resize(4 * (size_t)batch_);
     uint32_t bad = 0;
     for (uint32_t i = 0; i < batch_; ++i) {

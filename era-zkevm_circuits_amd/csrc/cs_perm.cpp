@@ -142,7 +142,14 @@ uint32_t CS::copy_permutation(const uint64_t beta[2], const uint64_t gamma[2], v
     }
     uint64_t *d_tb[2] = {nullptr, nullptr}, *d_part[2] = {nullptr, nullptr}, *d_excl[2] = {nullptr, nullptr}, *d_pre[2] = {nullptr, nullptr};
     uint64_t *d_total_l = nullptr, *d_inst = nullptr;
-    auto alloc = [&](uint64_t** p, size_t words) { hipc(hipMalloc((void**)p, std::max<size_t>(words, 1) * 8), "hipMalloc copy_permutation"); };
+    struct Temps {  // device temporaries of this call: released on every exit path, exceptions included
+        std::vector<void*> ptrs;
+        ~Temps() { for (void* p : ptrs) hipFree(p); }
+    } temps;
+    auto alloc = [&](uint64_t** p, size_t words) {
+        hipc(hipMalloc((void**)p, std::max<size_t>(words, 1) * 8), "hipMalloc copy_permutation");
+        temps.ptrs.push_back(*p);
+    };
     alloc(&d_tb[0], 4 * (size_t)NTo);
     alloc(&d_tb[1], 4 * (size_t)NTl);
     alloc(&d_part[0], 4 * (size_t)outer_.n_lanes * chunks[0]);
@@ -181,8 +188,6 @@ uint32_t CS::copy_permutation(const uint64_t beta[2], const uint64_t gamma[2], v
     out.resize(4 * (size_t)batch_);
     hipc(hipMemcpyAsync(out.data(), d_inst, out.size() * 8, hipMemcpyDeviceToHost, st), "memcpy copy_permutation");
     hipc(hipStreamSynchronize(st), "copy_permutation sync");
-    for (uint64_t* p : {d_tb[0], d_tb[1], d_part[0], d_part[1], d_excl[0], d_excl[1], d_pre[0], d_pre[1], d_total_l, d_inst})
-        if (p) hipFree(p);
     uint32_t bad = 0;
     for (uint32_t i = 0; i < batch_; ++i) bad += (out[4 * i] != out[4 * i + 2] || out[4 * i + 1] != out[4 * i + 3]);
     return bad;
