@@ -212,4 +212,85 @@ int zk_pack_log_sorter_witness(const zk_log_sorter_witness* w, uint32_t limit, u
     return ZK_OK;
 }
 
+
+int zk_eip4844_stream_shape(uint32_t n_chunks, uint32_t* n_iterations, uint32_t* loop_words) {
+    if (!n_chunks || !n_iterations || !loop_words) return bad(ZK_ERR_INVALID, "zk_eip4844_stream_shape: bad argument");
+    const uint64_t n_bytes = 31ull * n_chunks;
+    const uint32_t n_blocks = (uint32_t)(n_bytes / 136 + 1);               // the padding always opens a block (circuits/eip4844.cpp)
+    const uint32_t cpi = (n_chunks + n_blocks - 1) / n_blocks;               // Horner steps per iteration
+    *n_iterations = n_blocks;
+    *loop_words = 217 + 136 + 31 * cpi;
+    return ZK_OK;
+}
+
+int zk_pack_eip4844_witness(const zk_eip4844_witness* w, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || instance >= batch || !w->n_chunks || !w->data_chunks) return bad(ZK_ERR_INVALID, "zk_pack_eip4844_witness: bad argument");
+    uint32_t n_it = 0, lw = 0;
+    zk_eip4844_stream_shape(w->n_chunks, &n_it, &lw);
+    const uint32_t cpi = (lw - 217 - 136) / 31;
+    const uint64_t n_bytes = 31ull * w->n_chunks;
+    Out o{outer_words + instance, batch};
+    o.arr(w->versioned_hash); o.arr(w->linear_hash_output);
+    const size_t lanes = (size_t)batch * n_it;
+    for (uint32_t t = 0; t < n_it; ++t) {
+        Out l{loop_words + (size_t)instance * n_it + t, lanes};
+        for (int i = 0; i < 217; ++i) l.w(0);
+        for (uint32_t j = 0; j < 136; ++j) { const uint64_t at = 136ull * t + j; l.w(at < n_bytes ? w->data_chunks[at] : 0); }
+        for (uint32_t j = 0; j < 31 * cpi; ++j) { const uint64_t at = 31ull * cpi * t + j; l.w(at < n_bytes ? w->data_chunks[at] : 0); }
+        if (l.k != lw) return bad(ZK_ERR_INVALID, "internal: eip_4844 loop layout");
+    }
+    return ZK_OK;
+}
+
+
+int zk_pack_sha256_witness(const zk_sha256_round_function_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_sha256_witness: bad argument");
+    if ((w->n_requests && !w->requests_queue_witness) || (w->n_reads && !w->memory_reads_witness)) return bad(ZK_ERR_INVALID, "zk_pack_sha256_witness: null witness array");
+    auto full = [](Out& o, const zk_full_queue_state_witness& q) { o.arr(q.head); o.arr(q.tail); o.w(q.length); };
+    Out o{outer_words + instance, batch};
+    o.w(w->start_flag ? 1 : 0);
+    o.qstate(w->initial_log_queue_state); full(o, w->initial_memory_queue_state);
+    const zk_sha256_fsm_witness& f = w->hidden_fsm_input;
+    o.w(f.read_precompile_call ? 1 : 0); o.w(f.read_words_for_round ? 1 : 0); o.w(f.completed ? 1 : 0);
+    o.arr(f.sha256_inner_state); o.w(f.timestamp_to_use_for_read); o.w(f.timestamp_to_use_for_write);
+    o.w(f.input_page); o.w(f.input_offset); o.w(f.output_page); o.w(f.output_offset); o.w(f.num_rounds);
+    o.qstate(f.log_queue_state); full(o, f.memory_queue_state);
+    if (o.k != ZK_SHA256_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: sha256 outer layout");
+    // the FSM's schedule (mod.rs:120-137 can_finish_immediatelly, :150-181 request pop, :199-255 reads, :380-418 next flags)
+    bool rpc, rwfr, completed;
+    uint64_t num_rounds, req_len;
+    if (w->start_flag) { rpc = true; rwfr = false; completed = false; num_rounds = 0; req_len = w->initial_log_queue_state.length; }
+    else { rpc = f.read_precompile_call; rwfr = f.read_words_for_round; completed = f.completed; num_rounds = f.num_rounds; req_len = f.log_queue_state.length; }
+    if (rpc && req_len == 0) { rpc = false; rwfr = false; completed = true; }
+    uint32_t next_req = 0, next_read = 0;
+    const size_t lanes = (size_t)batch * limit;
+    const uint64_t P = 0xFFFFFFFF00000001ull;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        for (int i = 0; i < 60; ++i) l.w(0);
+        const zk_log_query_witness* call = nullptr;
+        if (rpc && req_len != 0) {
+            if (next_req >= w->n_requests) return bad(ZK_ERR_INVALID, "zk_pack_sha256_witness: the request queue witness is shorter than its length");
+            call = &w->requests_queue_witness[next_req++];
+            --req_len;
+            num_rounds = call->key[6];   // precompile call ABI: the number of rounds is limb 6 of the key
+        }
+        l.log_query(call);
+        rwfr = rpc || rwfr;
+        rpc = false;
+        const bool should_read = num_rounds != 0;
+        for (int r = 0; r < 2; ++r) {
+            if (should_read && next_read < w->n_reads) { for (int i = 0; i < 8; ++i) l.w(w->memory_reads_witness[next_read][i]); ++next_read; }
+            else for (int i = 0; i < 8; ++i) l.w(0);
+        }
+        if (rwfr) num_rounds = num_rounds ? num_rounds - 1 : P - 1;   // the circuit's field subtraction
+        const bool write_result = rwfr && num_rounds == 0, input_is_empty = req_len == 0;
+        rpc = write_result && !input_is_empty;
+        completed = (write_result && input_is_empty) || completed;
+        rwfr = !(rpc || completed);
+        if (l.k != ZK_SHA256_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: sha256 loop layout");
+    }
+    return ZK_OK;
+}
+
 }  // extern "C"

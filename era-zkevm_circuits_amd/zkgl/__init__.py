@@ -231,6 +231,49 @@ def pack_log_sorter_witness(w, limit, instance, outer, loop):
     _pack(lib().zk_pack_log_sorter_witness, w, limit, instance, outer, loop, 87, 129)
 
 
+class Eip4844Witness(C.Structure):
+    _fields_ = [("versioned_hash", C.c_uint8 * 32), ("linear_hash_output", C.c_uint8 * 32), ("data_chunks", C.POINTER(C.c_uint8)), ("n_chunks", C.c_uint32)]
+
+
+def eip4844_stream_shape(n_chunks: int):
+    it, lw = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().zk_eip4844_stream_shape(n_chunks, C.byref(it), C.byref(lw)))
+    return it.value, lw.value
+
+
+def pack_eip4844_witness(blob: bytes, versioned_hash: bytes, linear_hash: bytes, instance, outer, loop):
+    """zk_pack_eip4844_witness: outer [64, B], loop [loop_words, B * iterations]"""
+    n_chunks = len(blob) // 31
+    assert len(blob) == 31 * n_chunks and len(versioned_hash) == 32 and len(linear_hash) == 32
+    w = Eip4844Witness()
+    w.versioned_hash[:] = versioned_hash; w.linear_hash_output[:] = linear_hash
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    w.data_chunks, w.n_chunks = buf, n_chunks
+    batch = outer.shape[1]
+    it, lw = eip4844_stream_shape(n_chunks)
+    assert outer.shape == (64, batch) and loop.shape == (lw, batch * it) and outer.flags.c_contiguous and loop.flags.c_contiguous
+    _check(lib().zk_pack_eip4844_witness(C.byref(w), instance, batch, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
+
+
+class Sha256FsmWitness(C.Structure):
+    _fields_ = [("read_precompile_call", C.c_uint8), ("read_words_for_round", C.c_uint8), ("completed", C.c_uint8),
+                ("sha256_inner_state", C.c_uint32 * 8), ("timestamp_to_use_for_read", C.c_uint32), ("timestamp_to_use_for_write", C.c_uint32),
+                ("input_page", C.c_uint32), ("input_offset", C.c_uint32), ("output_page", C.c_uint32), ("output_offset", C.c_uint32),
+                ("num_rounds", C.c_uint32), ("log_queue_state", QueueStateWitness), ("memory_queue_state", FullQueueStateWitness)]
+
+
+class Sha256RoundFunctionWitness(C.Structure):
+    _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("initial_log_queue_state", QueueStateWitness),
+                ("initial_memory_queue_state", FullQueueStateWitness), ("hidden_fsm_input", Sha256FsmWitness), ("hidden_fsm_output", Sha256FsmWitness),
+                ("requests_queue_witness", C.POINTER(LogQueryWitness)), ("n_requests", C.c_uint32),
+                ("memory_reads_witness", C.POINTER(C.c_uint32 * 8)), ("n_reads", C.c_uint32)]
+
+
+def pack_sha256_witness(w, limit, instance, outer, loop):
+    """zk_pack_sha256_witness: outer [87, B], loop [112, B * limit]"""
+    _pack(lib().zk_pack_sha256_witness, w, limit, instance, outer, loop, 87, 112)
+
+
 class Comm:
     """RCCL communicator behind the C ABI (zk_comm_*): one process per GPU; rank 0's `unique_id()` bytes reach the other ranks through
     the host's launcher (bench.py: a torch.distributed broadcast)."""

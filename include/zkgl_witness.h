@@ -136,6 +136,51 @@ typedef struct zk_log_sorter_witness {
 int zk_pack_log_sorter_witness(const zk_log_sorter_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                                uint64_t *outer_words, uint64_t *loop_words);
 
+/* EIP4844CircuitInstanceWitness, /root/reference/src/eip_4844/input.rs:61-66: versioned_hash, linear_hash_output, data_chunks
+ * (BlobChunkWitness = 31 bytes, :31-33); the closed-form input has no observable input and no FSM state to pack */
+typedef struct zk_eip4844_witness {
+    uint8_t versioned_hash[32];
+    uint8_t linear_hash_output[32];
+    const uint8_t *data_chunks;   /* n_chunks x 31 bytes, chunk after chunk */
+    uint32_t n_chunks;
+} zk_eip4844_witness;
+#define ZK_EIP4844_OUTER_WORDS 64
+/* loop-scope shape of zk_circuit_eip_4844(cs, n_chunks): iterations (= Keccak blocks of the blob) and words per iteration */
+int zk_eip4844_stream_shape(uint32_t n_chunks, uint32_t *n_iterations, uint32_t *loop_words);
+/* eip_4844_entry_point (/root/reference/src/eip_4844/mod.rs:107-260) recorded with zk_circuit_eip_4844(cs, n_chunks): outer_words
+ * [64][batch] = versioned_hash | linear_hash_output bytes; loop_words[loop_words][batch * n_iterations]: 217 carried words zeroed (Keccak
+ * state, opening limbs, iteration counter: device seeding), then the 136 blob bytes of the iteration's Keccak block and the 31-byte
+ * chunks of its Horner steps (zero bytes past the blob: the circuit pads the last block itself) */
+int zk_pack_eip4844_witness(const zk_eip4844_witness *w, uint32_t instance, uint32_t batch, uint64_t *outer_words, uint64_t *loop_words);
+
+/* Sha256RoundFunctionCircuitInstanceWitness, /root/reference/src/sha256_round_function/input.rs:85-89 (FSM :24-32, :53-57; call params:
+ * input_page, input_offset, output_page, output_offset, num_rounds) */
+typedef struct zk_sha256_fsm_witness {
+    uint8_t read_precompile_call, read_words_for_round, completed;
+    uint32_t sha256_inner_state[8];
+    uint32_t timestamp_to_use_for_read, timestamp_to_use_for_write;
+    uint32_t input_page, input_offset, output_page, output_offset, num_rounds;
+    zk_queue_state_witness log_queue_state;
+    zk_full_queue_state_witness memory_queue_state;
+} zk_sha256_fsm_witness;
+typedef struct zk_sha256_round_function_witness {
+    uint8_t start_flag, completion_flag;
+    zk_queue_state_witness initial_log_queue_state;
+    zk_full_queue_state_witness initial_memory_queue_state;
+    zk_sha256_fsm_witness hidden_fsm_input, hidden_fsm_output;
+    const zk_log_query_witness *requests_queue_witness; uint32_t n_requests;   /* in pop order */
+    const uint32_t (*memory_reads_witness)[8]; uint32_t n_reads;               /* VecDeque<U256> in pop order, 8 LE u32 limbs each */
+} zk_sha256_round_function_witness;
+#define ZK_SHA256_OUTER_WORDS 87
+#define ZK_SHA256_LOOP_WORDS 112
+/* sha256_round_function_entry_point (/root/reference/src/sha256_round_function/mod.rs:88-468).  The reference pops requests and read
+ * values lazily inside the cycle loop; the streams want them at the cycle that consumes them, so the packer walks the FSM's
+ * SCHEDULE (flags, rounds left, queue length — no hashing): a request is placed at the cycle whose read_precompile_call is set,
+ * two read values at every cycle with rounds left.  60 carried words per cycle zeroed (device seeding).  ZK_ERR_INVALID when the
+ * witness runs out of requests / read values before the schedule does. */
+int zk_pack_sha256_witness(const zk_sha256_round_function_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                           uint64_t *outer_words, uint64_t *loop_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -265,3 +265,78 @@ def test_log_sorter_packer_equals_the_oracle_packer():
     eo, el = ln.pack_streams([c[2] for c in cases], limit)
     el = el.copy(); el[0:57] = 0
     assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+def test_eip4844_packer_equals_the_oracle_rows():
+    from oracle import eip4844_native as en
+    rng = np.random.default_rng(44)
+    cases = []
+    for n_chunks in (27, 27):
+        blob = bytes(rng.integers(0, 256, size=31 * n_chunks, dtype=np.uint8))
+        vh = b"\x01" + bytes(rng.integers(0, 256, size=31, dtype=np.uint8))
+        cases.append((blob, vh, en.instance(blob, vh, n_chunks)))
+    it, lw = zkgl.eip4844_stream_shape(27)
+    assert (it, lw) == (len(cases[0][2]["rows"]), len(cases[0][2]["rows"][0]))
+    B = len(cases)
+    outer = np.zeros((64, B), dtype=np.uint64); loop = np.full((lw, B * it), 9, dtype=np.uint64)
+    for i, (blob, vh, inst) in enumerate(cases):
+        zkgl.pack_eip4844_witness(blob, vh, inst["linear_hash"], i, outer, loop)
+    eo = np.array([c[2]["outer"] for c in cases], dtype=np.uint64).T
+    el = np.array([r for c in cases for r in c[2]["rows"]], dtype=np.uint64).T.copy()
+    el[0:217] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+def _q12(words):
+    q = zkgl.FullQueueStateWitness()
+    q.head[:] = [int(x) for x in words[0:12]]; q.tail[:] = [int(x) for x in words[12:24]]; q.length = int(words[24])
+    return q
+
+
+def _sha_fsm(f, x):
+    f.read_precompile_call, f.read_words_for_round, f.completed = int(x[0]), int(x[1]), int(x[2])
+    f.sha256_inner_state[:] = x[3:11]; f.timestamp_to_use_for_read, f.timestamp_to_use_for_write = int(x[11]), int(x[12])
+    f.input_page, f.input_offset, f.output_page, f.output_offset, f.num_rounds = [int(v) for v in x[13:18]]
+    f.log_queue_state, f.memory_queue_state = _q4(x[18:27]), _q12(x[27:52])
+
+
+def test_sha256_packer_walks_the_fsm_schedule():
+    """requests and read values are placed at the cycles that consume them (the reference pops them lazily): several requests in one
+    instance, and a continuation instance that starts in the middle of a request"""
+    from oracle import sha256_native as shn
+    rng = np.random.default_rng(256)
+    msgs = [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in (10, 100, 64 * 3 - 9, 0)]
+    reqs = [shn.request(m, 1 + 2 * i, 10 + i, 3 * i, 9000 + i, i) for i, m in enumerate(msgs)]
+    limit = 5
+    first = shn.instance(reqs, limit)
+    second = shn.instance(first["rest"][0], limit, start_flag=False, fsm_in=first["fsm_out"], obs_req=first["obs_req"], obs_mem=first["obs_mem"],
+                          pending=first["rest"][1])
+    insts = [first, second]
+    B = 2
+    outer = np.zeros((87, B), dtype=np.uint64); loop = np.full((112, B * limit), 5, dtype=np.uint64)
+    all_reads = [v for r in reqs for v in r["reads"]]
+    consumed_reads = 0
+    consumed_reqs = 0
+    for i, inst in enumerate(insts):
+        o = inst["outer"]
+        w = zkgl.Sha256RoundFunctionWitness()
+        w.start_flag = int(o[0])
+        w.initial_log_queue_state, w.initial_memory_queue_state = _q4(o[1:10]), _q12(o[10:35])
+        _sha_fsm(w.hidden_fsm_input, o[35:87])
+        # what the witness generator would hand over for this instance: the requests / reads from here on
+        rq = reqs[consumed_reqs:]
+        rd = all_reads[consumed_reads:]
+        qa = (zkgl.LogQueryWitness * max(len(rq), 1))(*[_lq(r["query"]) for r in rq])
+        ra = ((C_u32x8 := (zkgl.C.c_uint32 * 8)) * max(len(rd), 1))()
+        for dst, v in zip(ra, rd):
+            dst[:] = [(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
+        w.requests_queue_witness, w.n_requests, w.memory_reads_witness, w.n_reads = qa, len(rq), ra, len(rd)
+        zkgl.pack_sha256_witness(w, limit, i, outer, loop)
+        rows = np.array(inst["rows"], dtype=np.uint64)
+        consumed_reqs += int(sum(1 for r in rows if r[60:96].any()))
+        consumed_reads += int(sum((1 if r[96:104].any() else 0) + (1 if r[104:112].any() else 0) for r in rows))
+    eo = np.array([x["outer"] for x in insts], dtype=np.uint64).T
+    el = np.array([r for x in insts for r in x["rows"]], dtype=np.uint64).T.copy()
+    el[0:60] = 0
+    assert np.array_equal(outer, eo)
+    assert np.array_equal(loop, el)
