@@ -293,4 +293,76 @@ int zk_pack_sha256_witness(const zk_sha256_round_function_witness* w, uint32_t l
     return ZK_OK;
 }
 
+
+int zk_pack_keccak_witness(const zk_keccak_round_function_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_keccak_witness: bad argument");
+    if ((w->n_requests && !w->requests_queue_witness) || (w->n_reads && !w->memory_reads_witness)) return bad(ZK_ERR_INVALID, "zk_pack_keccak_witness: null witness array");
+    constexpr uint32_t RATE = 136, BUF = 192, READS = 6;
+    auto full = [](Out& o, const zk_full_queue_state_witness& q) { o.arr(q.head); o.arr(q.tail); o.w(q.length); };
+    Out o{outer_words + instance, batch};
+    o.w(w->start_flag ? 1 : 0);
+    o.qstate(w->initial_log_queue_state); full(o, w->initial_memory_queue_state);
+    const zk_keccak_fsm_witness& f = w->hidden_fsm_input;
+    o.w(f.read_precompile_call ? 1 : 0); o.w(f.read_unaligned_words_for_round ? 1 : 0); o.w(f.padding_round ? 1 : 0); o.w(f.completed ? 1 : 0);
+    for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) for (int k = 0; k < 8; ++k) o.w(f.keccak_internal_state[i][j][k]);
+    o.w(f.timestamp_to_use_for_read); o.w(f.timestamp_to_use_for_write);
+    o.w(f.input_page); o.w(f.input_memory_byte_offset); o.w(f.input_memory_byte_length); o.w(f.output_page); o.w(f.output_word_offset);
+    o.w(f.needs_full_padding_round ? 1 : 0);
+    o.arr(f.buffer_bytes); o.w(f.buffer_filled);
+    o.qstate(f.log_queue_state); full(o, f.memory_queue_state);
+    if (o.k != ZK_KECCAK_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: keccak outer layout");
+    // the schedule: which cycle pops a request, which of its six read slots fetch a word (mod.rs:200-213, :228-297, :300-420, :690-740)
+    bool rpc, ruw, padding_round, completed, needs_full;
+    uint64_t byte_offset, byte_length, filled, req_len;
+    if (w->start_flag) { rpc = true; ruw = padding_round = completed = needs_full = false; byte_offset = byte_length = filled = 0; req_len = w->initial_log_queue_state.length; }
+    else {
+        rpc = f.read_precompile_call; ruw = f.read_unaligned_words_for_round; padding_round = f.padding_round; completed = f.completed;
+        needs_full = f.needs_full_padding_round; byte_offset = f.input_memory_byte_offset; byte_length = f.input_memory_byte_length;
+        filled = f.buffer_filled; req_len = f.log_queue_state.length;
+    }
+    if (rpc && req_len == 0) { rpc = false; ruw = false; completed = true; }
+    uint32_t next_req = 0, next_read = 0;
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        for (int i = 0; i < 423; ++i) l.w(0);
+        const zk_log_query_witness* call = nullptr;
+        if (rpc && req_len != 0) {
+            if (next_req >= w->n_requests) return bad(ZK_ERR_INVALID, "zk_pack_keccak_witness: the request queue witness is shorter than its length");
+            call = &w->requests_queue_witness[next_req++];
+            --req_len;
+        }
+        l.log_query(call);
+        const uint64_t call_length = call ? call->key[1] : 0;
+        if (rpc) {  // precompile call ABI in the key limbs: byte offset, byte length (an absent call reads as zeros, as in the circuit)
+            byte_offset = call ? call->key[0] : 0; byte_length = call_length;
+            needs_full = call_length % RATE == 0;
+        }
+        const bool reset_buffer = rpc || completed;
+        if (rpc && call_length == 0) padding_round = true;
+        if (rpc && call_length != 0) ruw = true;
+        rpc = false;
+        if (reset_buffer) filled = 0;
+        for (uint32_t r = 0; r < READS; ++r) {
+            const uint64_t unalignment = byte_offset % 32, at_most = 32 - unalignment;
+            const uint64_t meaningful = byte_length < at_most ? byte_length : at_most;
+            const bool should_read = meaningful != 0 && filled + meaningful <= BUF && ruw;
+            if (should_read && next_read < w->n_reads) { for (int i = 0; i < 8; ++i) l.w(w->memory_reads_witness[next_read][i]); ++next_read; }
+            else for (int i = 0; i < 8; ++i) l.w(0);
+            if (should_read) { byte_offset += meaningful; byte_length -= meaningful; filled += meaningful; }
+        }
+        const bool zero_bytes_left = byte_length == 0;
+        filled = filled >= RATE ? filled - RATE : 0;
+        const bool buffer_now_empty = filled == 0;
+        const bool apply_padding = zero_bytes_left && buffer_now_empty && ruw && !needs_full;
+        const bool write_result = apply_padding || padding_round, input_is_empty = req_len == 0;
+        rpc = write_result && !input_is_empty;
+        completed = (write_result && input_is_empty) || completed;
+        padding_round = ruw && zero_bytes_left && buffer_now_empty && needs_full;
+        ruw = !(rpc || padding_round || completed);
+        if (l.k != ZK_KECCAK_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: keccak loop layout");
+    }
+    return ZK_OK;
+}
+
 }  // extern "C"

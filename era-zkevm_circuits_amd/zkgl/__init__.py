@@ -274,6 +274,26 @@ def pack_sha256_witness(w, limit, instance, outer, loop):
     _pack(lib().zk_pack_sha256_witness, w, limit, instance, outer, loop, 87, 112)
 
 
+class KeccakFsmWitness(C.Structure):
+    _fields_ = [("read_precompile_call", C.c_uint8), ("read_unaligned_words_for_round", C.c_uint8), ("padding_round", C.c_uint8), ("completed", C.c_uint8),
+                ("keccak_internal_state", ((C.c_uint8 * 8) * 5) * 5), ("timestamp_to_use_for_read", C.c_uint32), ("timestamp_to_use_for_write", C.c_uint32),
+                ("input_page", C.c_uint32), ("input_memory_byte_offset", C.c_uint32), ("input_memory_byte_length", C.c_uint32), ("output_page", C.c_uint32),
+                ("output_word_offset", C.c_uint32), ("needs_full_padding_round", C.c_uint8), ("buffer_bytes", C.c_uint8 * 192), ("buffer_filled", C.c_uint32),
+                ("log_queue_state", QueueStateWitness), ("memory_queue_state", FullQueueStateWitness)]
+
+
+class KeccakRoundFunctionWitness(C.Structure):
+    _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("initial_log_queue_state", QueueStateWitness),
+                ("initial_memory_queue_state", FullQueueStateWitness), ("hidden_fsm_input", KeccakFsmWitness), ("hidden_fsm_output", KeccakFsmWitness),
+                ("requests_queue_witness", C.POINTER(LogQueryWitness)), ("n_requests", C.c_uint32),
+                ("memory_reads_witness", C.POINTER(C.c_uint32 * 8)), ("n_reads", C.c_uint32)]
+
+
+def pack_keccak_witness(w, limit, instance, outer, loop):
+    """zk_pack_keccak_witness: outer [474, B], loop [507, B * limit]"""
+    _pack(lib().zk_pack_keccak_witness, w, limit, instance, outer, loop, 474, 507)
+
+
 class Comm:
     """RCCL communicator behind the C ABI (zk_comm_*): one process per GPU; rank 0's `unique_id()` bytes reach the other ranks through
     the host's launcher (bench.py: a torch.distributed broadcast)."""

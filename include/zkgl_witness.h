@@ -181,6 +181,35 @@ typedef struct zk_sha256_round_function_witness {
 int zk_pack_sha256_witness(const zk_sha256_round_function_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                            uint64_t *outer_words, uint64_t *loop_words);
 
+/* Keccak256RoundFunctionCircuitInstanceWitness, /root/reference/src/keccak256_round_function/input.rs (FSM :29-39, call params
+ * mod.rs:48-55, ByteBuffer buffer/mod.rs:42-48: bytes[192] + filled) */
+typedef struct zk_keccak_fsm_witness {
+    uint8_t read_precompile_call, read_unaligned_words_for_round, padding_round, completed;
+    uint8_t keccak_internal_state[5][5][8];   /* [i][j][k]: byte k of lane x = i, y = j */
+    uint32_t timestamp_to_use_for_read, timestamp_to_use_for_write;
+    uint32_t input_page, input_memory_byte_offset, input_memory_byte_length, output_page, output_word_offset;
+    uint8_t needs_full_padding_round;
+    uint8_t buffer_bytes[192];
+    uint32_t buffer_filled;
+    zk_queue_state_witness log_queue_state;
+    zk_full_queue_state_witness memory_queue_state;
+} zk_keccak_fsm_witness;
+typedef struct zk_keccak_round_function_witness {
+    uint8_t start_flag, completion_flag;
+    zk_queue_state_witness initial_log_queue_state;
+    zk_full_queue_state_witness initial_memory_queue_state;
+    zk_keccak_fsm_witness hidden_fsm_input, hidden_fsm_output;
+    const zk_log_query_witness *requests_queue_witness; uint32_t n_requests;
+    const uint32_t (*memory_reads_witness)[8]; uint32_t n_reads;
+} zk_keccak_round_function_witness;
+#define ZK_KECCAK_OUTER_WORDS 474
+#define ZK_KECCAK_LOOP_WORDS 507
+/* keccak256_round_function_entry_point (/root/reference/src/keccak256_round_function/mod.rs:155-794): like the sha256 packer, the
+ * FSM's schedule is walked — flags, bytes left, byte offset, ByteBuffer fill level (six conditional unaligned reads per cycle,
+ * mod.rs:300-420; buffer/mod.rs:90-163) — to place every request and read value at its cycle; 423 carried words zeroed */
+int zk_pack_keccak_witness(const zk_keccak_round_function_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                           uint64_t *outer_words, uint64_t *loop_words);
+
 #ifdef __cplusplus
 }
 #endif

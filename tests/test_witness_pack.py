@@ -340,3 +340,53 @@ def test_sha256_packer_walks_the_fsm_schedule():
     el[0:60] = 0
     assert np.array_equal(outer, eo)
     assert np.array_equal(loop, el)
+
+
+def test_keccak_packer_walks_the_fsm_schedule():
+    """the keccak precompile: six conditional unaligned reads per cycle through the 192-byte buffer — requests and read values placed
+    at their cycles by the schedule walk; several requests (aligned, unaligned, empty, block-sized) and a continuation instance"""
+    from oracle import keccak_native as kn
+    rng = np.random.default_rng(1600)
+    specs = [(50, 0), (135, 31), (0, 0), (136, 0), (200, 7)]
+    reqs = [kn.request(bytes(rng.integers(0, 256, size=n, dtype=np.uint8)), 1 + 2 * i, 10 + i, 64 * i + mis, 9000 + i, i) for i, (n, mis) in enumerate(specs)]
+    limit = 4
+    first = kn.instance(reqs, limit)
+    second = kn.instance(first["rest"][0], limit, start_flag=False, fsm_in=first["fsm_out"], obs_req=first["obs_req"], obs_mem=first["obs_mem"],
+                         pending=first["rest"][1])
+    third = kn.instance(second["rest"][0], limit, start_flag=False, fsm_in=second["fsm_out"], obs_req=second["obs_req"], obs_mem=second["obs_mem"],
+                        pending=second["rest"][1])
+    insts = [first, second, third]
+    B = len(insts)
+    outer = np.zeros((474, B), dtype=np.uint64); loop = np.full((507, B * limit), 5, dtype=np.uint64)
+    all_reads = [v for r in reqs for v in r["reads"]]
+    used_reqs = used_reads = 0
+    for i, inst in enumerate(insts):
+        o = inst["outer"]
+        w = zkgl.KeccakRoundFunctionWitness()
+        w.start_flag = int(o[0])
+        w.initial_log_queue_state, w.initial_memory_queue_state = _q4(o[1:10]), _q12(o[10:35])
+        f, x = w.hidden_fsm_input, o[35:474]
+        f.read_precompile_call, f.read_unaligned_words_for_round, f.padding_round, f.completed = [int(v) for v in x[0:4]]
+        st = x[4:204]
+        for a in range(5):
+            for b in range(5):
+                for k in range(8):
+                    f.keccak_internal_state[a][b][k] = int(st[(a * 5 + b) * 8 + k])
+        f.timestamp_to_use_for_read, f.timestamp_to_use_for_write = int(x[204]), int(x[205])
+        (f.input_page, f.input_memory_byte_offset, f.input_memory_byte_length, f.output_page, f.output_word_offset, f.needs_full_padding_round) = [int(v) for v in x[206:212]]
+        f.buffer_bytes[:] = [int(v) for v in x[212:404]]; f.buffer_filled = int(x[404])
+        f.log_queue_state, f.memory_queue_state = _q4(x[405:414]), _q12(x[414:439])
+        rq, rd = reqs[used_reqs:], all_reads[used_reads:]
+        qa = (zkgl.LogQueryWitness * max(len(rq), 1))(*[_lq(r["query"]) for r in rq])
+        ra = ((zkgl.C.c_uint32 * 8) * max(len(rd), 1))()
+        for dst, v in zip(ra, rd):
+            dst[:] = [(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
+        w.requests_queue_witness, w.n_requests, w.memory_reads_witness, w.n_reads = qa, len(rq), ra, len(rd)
+        zkgl.pack_keccak_witness(w, limit, i, outer, loop)
+        used_reqs = len(reqs) - len(inst["rest"][0])
+        used_reads = len(all_reads) - len(inst["rest"][1]) - sum(len(r["reads"]) for r in inst["rest"][0])
+    eo = np.array([x["outer"] for x in insts], dtype=np.uint64).T
+    el = np.array([r for x in insts for r in x["rows"]], dtype=np.uint64).T.copy()
+    el[0:423] = 0
+    assert np.array_equal(outer, eo)
+    assert np.array_equal(loop, el)
