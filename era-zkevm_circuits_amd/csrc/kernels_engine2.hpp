@@ -105,7 +105,11 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     uint64_t* __restrict__ wide_cells = sc.cells + (size_t)tile * sc.n_cells * 64 + (lane & 63);
     const prog1_ptr prog = (prog1_ptr)(uintptr_t)sc.prog;
     const cpool_ptr cpool = (cpool_ptr)(uintptr_t)sc.consts;
+#ifdef ZKGL_P2_IN_LDS  // A/B: the round-1 form (state staged in LDS, rolled S-box loops) for the plain kernels
     constexpr bool P2_IN_REGISTERS = STRANDS;
+#else
+    constexpr bool P2_IN_REGISTERS = true;
+#endif
     __shared__ uint64_t p2s[P2_IN_REGISTERS ? 1 : 12 * BLOCK];  // Poseidon2 state, [element][thread] (plain kernels: rolled S-box loops)
 
     uint32_t dst = WIDE ? slot_begin : slot_begin << 9;  // next output: slot index (WIDE) or byte offset in the tile
@@ -360,8 +364,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             pc += 13 + D;
             p2::mds_external(s);
             if constexpr (P2_IN_REGISTERS) {
-                // strand kernels: state in registers, the twelve S-boxes of a full round unrolled, ONE copy of the full-round body
-                // (no LDS: a 1 024-thread strand block would need 96 KB for the staged state and sit alone on its CU)
+                // state in registers, the twelve S-boxes of a full round unrolled, ONE copy of the full-round body (12 KB of code: the
+                // fully unrolled permutation of round 1 was 190 KB and instruction-cache-bound, the LDS-staged rolled form that replaced
+                // it costs 10 % of the loop kernel against this one; no LDS: a 1 024-thread strand block would need 96 KB for it)
                 if (emit) {
 #pragma unroll
                     for (int i = 0; i < 12; ++i) st(s[i]);
