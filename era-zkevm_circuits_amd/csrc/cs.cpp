@@ -550,6 +550,50 @@ void CS::build_check_program(Scope& s) {
                 for (uint32_t i = 0; i < 4; ++i) s.cprog.push_back(i < tw ? s.alias[(size_t)slot * NC + C + (u0 + g) * lookup_width_ + i] : 0u);
         }
     }
+    if (getenv("ZKGL_CHECK_ORDER_STATS")) {
+        // how many value fetches a small LRU window (the share of L2 a wavefront can count on) leaves to HBM: packets in row order (as
+        // emitted) against gate instances ordered by their youngest operand
+        struct Inst { uint32_t key; std::vector<uint32_t> slots; };
+        std::vector<Inst> insts;
+        for (uint32_t slot = 0; slot < s.n_slots; ++slot) {
+            const zk_row_desc& rd = s.rows[slot];
+            const uint32_t w = rd.kind < ZK_GATE__COUNT ? GATES[rd.kind].width : 0;
+            if (rd.kind < ZK_GATE__COUNT && cap_of(rd.kind))
+                for (uint32_t j = 0; j < rd.n_instances; ++j) {
+                    Inst in; in.key = 0;
+                    for (uint32_t c = 0; c < w; ++c) { const uint32_t v = s.alias[(size_t)slot * NC + j * w + c]; in.slots.push_back(v); in.key = std::max(in.key, v); }
+                    insts.push_back(std::move(in));
+                }
+            const zk_lookup_row_desc& lr = s.lrows[slot];
+            if (lr.table != 0xffffffffu)
+                for (uint32_t u = 0; u < lr.n_tuples; ++u) {
+                    const TableRec& t = tables_[lr.table - 1];
+                    Inst in; in.key = 0;
+                    for (uint32_t c = 0; c < t.n_keys + t.n_vals; ++c) { const uint32_t v = s.alias[(size_t)slot * NC + C + u * lookup_width_ + c]; in.slots.push_back(v); in.key = std::max(in.key, v); }
+                    insts.push_back(std::move(in));
+                }
+        }
+        auto misses = [&](const std::vector<Inst>& order, size_t K) {
+            std::vector<int64_t> last(s.n_store, -1);
+            std::vector<uint32_t> ring;  // distinct-slot LRU approximated by a stamp of distinct touches
+            int64_t stamp = 0; uint64_t miss = 0, refs = 0;
+            for (auto& in : order)
+                for (uint32_t v : in.slots) {
+                    ++refs;
+                    if (last[v] < 0 || stamp - last[v] > (int64_t)K) { ++miss; }
+                    if (last[v] < 0 || stamp - last[v] > 0) ++stamp;
+                    last[v] = stamp;
+                }
+            return std::make_pair(miss, refs);
+        };
+        std::vector<Inst> sorted = insts;
+        std::stable_sort(sorted.begin(), sorted.end(), [](const Inst& a, const Inst& b) { return a.key < b.key; });
+        for (size_t K : {16, 32, 64, 256, 1024}) {
+            auto a = misses(insts, K), b = misses(sorted, K);
+            fprintf(stderr, "[zkgl] %s scope check order, window %zu touches: row order %llu fetches of %llu refs, slot order %llu (unique values %u)\n", s.is_loop ? "loop" : "outer", K,
+                    (unsigned long long)a.first, (unsigned long long)a.second, (unsigned long long)b.first, s.n_store);
+        }
+    }
     if (starts.empty()) { s.cprog.clear(); return; }
     const uint32_t total = (uint32_t)s.cprog.size();
     const uint32_t n_chunks = (uint32_t)std::min<size_t>(256, starts.size());
