@@ -281,22 +281,46 @@ def main():
     # the collective behind the C ABI: zk_comm_* + zk_cs_gather_commitments (one ncclAllGather of the packed public inputs over
     # RCCL / xGMI); the launcher's part — handing rank 0's unique id to the other ranks — is a torch.distributed broadcast here
     gather_path = "zk_cs_gather_commitments (RCCL all-gather behind the C ABI)"
-    try:
-        if shared_gpu:
-            raise RuntimeError("ranks share one GPU (smoke test): RCCL refuses duplicate devices")
-        uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(zkgl.Comm.unique_id()), dtype=torch.uint8).to(coll_dev)
-        if world > 1:
-            dist.broadcast(uid, src=0)
-        comm = zkgl.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
-        commits = cs.gather_commitments(comm, stream)          # [world, B, 4] u64
-        torch.cuda.synchronize()
-        comm.close()
-        if not np.array_equal(commits[rank], local):
-            raise RuntimeError("gathered commitments differ from this rank's public inputs")
-    except Exception as e:  # noqa: BLE001 — keep the bench line; say which path ran
-        print(f"[bench] C-ABI gather unavailable ({e}); using torch.distributed.all_gather", file=sys.stderr)
+    import threading
+    attempt = {}
+
+    def c_abi_gather():   # on its own thread with a deadline: a communicator that cannot be formed must not cost the bench line
+        try:
+            torch.cuda.set_device(dev_index)   # the current device is per thread
+            uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(zkgl.Comm.unique_id()), dtype=torch.uint8).to(coll_dev)
+            if world > 1:
+                dist.broadcast(uid, src=0)
+            comm = zkgl.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            got = cs.gather_commitments(comm, stream)          # [world, B, 4] u64
+            torch.cuda.synchronize()
+            comm.close()
+            if not np.array_equal(got[rank], local):
+                raise RuntimeError("gathered commitments differ from this rank's public inputs")
+            attempt["commits"] = got
+        except Exception as e:  # noqa: BLE001
+            attempt["error"] = e
+
+    hung = False
+    if shared_gpu:
+        attempt["error"] = RuntimeError("ranks share one GPU (smoke test): RCCL refuses duplicate devices")
+    else:
+        th = threading.Thread(target=c_abi_gather, daemon=True)
+        th.start()
+        th.join(180.0)
+        if th.is_alive():
+            hung = True
+            attempt["error"] = TimeoutError("no communicator within 180 s")
+    ok_everywhere = 1 if "commits" in attempt else 0
+    if world > 1 and not hung:   # every rank takes the same path
+        flag = torch.tensor([ok_everywhere], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok_everywhere = int(flag.item())
+    if ok_everywhere:
+        commits = attempt["commits"]
+    else:
+        print(f"[bench] C-ABI gather unavailable ({attempt.get('error', 'another rank failed')}); using torch.distributed.all_gather", file=sys.stderr)
         gather_path = "torch.distributed all_gather (fallback)"
         commits = gather_commitments(local, coll_dev)   # [world, B, 4] u64: RCCL all_gather over xGMI when world > 1
     if rank == 0:
@@ -349,6 +373,8 @@ def main():
             out["cpu_baseline"] = None
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+    if hung:
+        os._exit(0)   # a thread is still inside a collective that will never complete
     if world > 1:
         dist.destroy_process_group()
 
