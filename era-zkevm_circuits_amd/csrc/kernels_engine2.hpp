@@ -489,13 +489,15 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             };
             uint32_t mv[16], av[17], bv[17], res[19 + 16];
             uint64_t mraw[16], araw[17], braw[17];
-            [&]<uint32_t... I>(std::integer_sequence<uint32_t, I...>) {
-                ((mraw[I] = cpool[word(GroupSize<1 + I>{})]), ...);
-            }(std::make_integer_sequence<uint32_t, 16>{});
-            [&]<uint32_t... I>(std::integer_sequence<uint32_t, I...>) {
-                ((araw[I] = I < pa ? ldv(word(GroupSize<17 + I>{})) : 0), ...);
-                ((braw[I] = I < pb ? ldv(word(GroupSize<34 + I>{})) : 0), ...);
-            }(std::make_integer_sequence<uint32_t, 17>{});
+            // static word positions: the loops below are fully unrolled, `word` needs its index as a compile-time constant
+#define ZK_NN_M(I) mraw[I] = cpool[word(GroupSize<1 + I>{})];
+#define ZK_NN_AB(I) araw[I] = I < pa ? ldv(word(GroupSize<17 + I>{})) : 0; braw[I] = I < pb ? ldv(word(GroupSize<34 + I>{})) : 0;
+            ZK_NN_M(0) ZK_NN_M(1) ZK_NN_M(2) ZK_NN_M(3) ZK_NN_M(4) ZK_NN_M(5) ZK_NN_M(6) ZK_NN_M(7)
+            ZK_NN_M(8) ZK_NN_M(9) ZK_NN_M(10) ZK_NN_M(11) ZK_NN_M(12) ZK_NN_M(13) ZK_NN_M(14) ZK_NN_M(15)
+            ZK_NN_AB(0) ZK_NN_AB(1) ZK_NN_AB(2) ZK_NN_AB(3) ZK_NN_AB(4) ZK_NN_AB(5) ZK_NN_AB(6) ZK_NN_AB(7) ZK_NN_AB(8)
+            ZK_NN_AB(9) ZK_NN_AB(10) ZK_NN_AB(11) ZK_NN_AB(12) ZK_NN_AB(13) ZK_NN_AB(14) ZK_NN_AB(15) ZK_NN_AB(16)
+#undef ZK_NN_M
+#undef ZK_NN_AB
             for (int i = 0; i < 16; ++i) mv[i] = (uint32_t)mraw[i];
             for (int i = 0; i < 17; ++i) { av[i] = (uint32_t)araw[i]; bv[i] = (uint32_t)braw[i]; }
             out_to(W3[3]);

@@ -88,7 +88,6 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_seed_wave(SeedWaveDev a) {
     uint64_t* const xbuf = slots + SW_AREA - 128;
     const uint32_t inst = min(blockIdx.x * n_waves + wv, a.n_instances - 1);  // surplus wavefronts mirror the last instance (benign duplicate stores)
     const size_t lane0 = (size_t)inst * sc.limit;
-    const cpool_ptr cpool = (cpool_ptr)(uintptr_t)sc.consts;
     __syncthreads();
 
     // executes the segments from `pos` up to the end marker.  A wavefront only ever reads what IT wrote to its slot area (the
