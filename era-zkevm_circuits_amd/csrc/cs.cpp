@@ -586,12 +586,17 @@ void CS::build_check_program(Scope& s) {
                 }
             return std::make_pair(miss, refs);
         };
-        std::vector<Inst> sorted = insts;
+        std::vector<Inst> sorted = insts, by_min = insts, by_mean = insts;
         std::stable_sort(sorted.begin(), sorted.end(), [](const Inst& a, const Inst& b) { return a.key < b.key; });
+        auto mn = [](const Inst& a) { uint32_t m = UINT32_MAX; for (auto v : a.slots) m = std::min(m, v); return m; };
+        auto mean = [](const Inst& a) { uint64_t t = 0; for (auto v : a.slots) t += v; return a.slots.empty() ? 0 : t / a.slots.size(); };
+        std::stable_sort(by_min.begin(), by_min.end(), [&](const Inst& a, const Inst& b) { return mn(a) < mn(b); });
+        std::stable_sort(by_mean.begin(), by_mean.end(), [&](const Inst& a, const Inst& b) { return mean(a) < mean(b); });
         for (size_t K : {16, 32, 64, 256, 1024}) {
-            auto a = misses(insts, K), b = misses(sorted, K);
-            fprintf(stderr, "[zkgl] %s scope check order, window %zu touches: row order %llu fetches of %llu refs, slot order %llu (unique values %u)\n", s.is_loop ? "loop" : "outer", K,
-                    (unsigned long long)a.first, (unsigned long long)a.second, (unsigned long long)b.first, s.n_store);
+            auto a = misses(insts, K), b = misses(sorted, K), c = misses(by_min, K), d = misses(by_mean, K);
+            fprintf(stderr, "[zkgl] %s scope check order, window %zu touches: row order %llu fetches of %llu refs; by youngest operand %llu, by oldest %llu, by mean %llu (unique values %u)\n",
+                    s.is_loop ? "loop" : "outer", K, (unsigned long long)a.first, (unsigned long long)a.second, (unsigned long long)b.first, (unsigned long long)c.first,
+                    (unsigned long long)d.first, s.n_store);
         }
     }
     if (starts.empty()) { s.cprog.clear(); return; }
