@@ -356,6 +356,15 @@ int zk_cs_hook_compare_witness(zk_cs* cs, const zk_var* vars, uint32_t n_vars, c
     if (rc) return rc;
     return result == ZK_OK ? ZK_OK : fail(ZK_ERR_UNSATISFIED, "circuit values differ from the expected closed-form input");
 }
+int zk_cs_debug_poke_store(zk_cs* cs, int loop_scope, uint32_t slot, uint32_t lane, uint64_t value) {
+    NEED(cs); NEED_INIT();
+    return guard([&] { cs->cs->debug_poke_store(loop_scope != 0, slot, lane, value); });
+}
+int zk_cs_store_slots(zk_cs* cs, int loop_scope, uint32_t* n) {
+    NEED(cs); NEED(n);
+    *n = cs->cs->store_slots(loop_scope != 0);
+    return ZK_OK;
+}
 int zk_cs_write_cell(zk_cs* cs, int loop_scope, uint32_t cell, uint32_t lane, uint64_t value) {
     NEED(cs);
     return guard([&] { cs->cs->write_cell(loop_scope != 0, cell, lane, value); });

@@ -11,6 +11,9 @@
 #include <map>
 #include <queue>
 #include "device_api.hpp"
+#include "poseidon_consts.hpp"
+
+static constexpr int ZK_MACRO_FAILURE = 0x7fff0001;  // internal: a macro check packet failed, re-run the gate-by-gate program
 
 namespace zkgl {
 
@@ -102,6 +105,9 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_prog2) hipFree(s.d_prog2);
     if (s.d_cprog) hipFree(s.d_cprog);
     if (s.d_cchunks) hipFree(s.d_cchunks);
+    if (s.d_cprog_full) hipFree(s.d_cprog_full);
+    if (s.d_cmacros) hipFree(s.d_cmacros);
+    if (s.d_cchunks_full) hipFree(s.d_cchunks_full);
     if (s.d_mult_sites) hipFree(s.d_mult_sites);
     if (s.d_sprog) hipFree(s.d_sprog);
     s.d_sprog = nullptr;
@@ -117,7 +123,7 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_store) hipFree(s.d_store);
     s.d_store = nullptr;
     if (s.d_cells) hipFree(s.d_cells);
-    s.d_prog = nullptr; s.d_prog2 = nullptr; s.d_cprog = nullptr; s.d_cchunks = nullptr; s.d_mult_sites = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
+    s.d_prog = nullptr; s.d_prog2 = nullptr; s.d_cprog = nullptr; s.d_cchunks = nullptr; s.d_cprog_full = nullptr; s.d_cchunks_full = nullptr; s.d_cmacros = nullptr; s.d_mult_sites = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
     s.d_copies = nullptr; s.d_cells = nullptr;
 }
 
@@ -441,7 +447,7 @@ void CS::place_scope(Scope& s) {
     std::map<std::pair<uint32_t, std::vector<uint64_t>>, Open> open;
     std::vector<std::pair<uint32_t, uint32_t>> tmp_cells;  // (col, slot) per placed cell, per var appended below
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> vc(s.n_vars);
-    s.rows.clear(); s.rowconsts.clear();
+    s.rows.clear(); s.rowconsts.clear(); s.row_gates.clear();
     uint32_t n_gate_slots = 0;
     for (auto& g : s.gates) {
         const GateInfo& gi = GATES[g.kind];
@@ -459,6 +465,8 @@ void CS::place_scope(Scope& s) {
         }
         Open& o = it->second;
         uint32_t j = o.used++;
+        if (s.row_gates.size() <= o.slot) s.row_gates.resize(o.slot + 1);
+        s.row_gates[o.slot].push_back((uint32_t)(&g - s.gates.data()));  // instance j of the row == this gate
         zk_row_desc& rd = s.rows[o.slot];
         rd.n_instances = o.used;
         if (g.kind == ZK_GATE_CONST) { s.rowconsts[rd.const_off + j] = g.consts[0]; rd.n_consts = o.used; }
@@ -510,7 +518,7 @@ void CS::place_scope(Scope& s) {
 // lookup tuples (0x40 | count << 8 | first tuple << 16, row, table id, 4 slot words per tuple).  A packet fits one 16-word
 // scalar fetch (the 24-column matrix gates take two).  Chunks of whole packets, balanced by words, for the launch grid.
 void CS::build_check_program(Scope& s) {
-    s.cprog.clear(); s.cchunks.clear();
+    s.cprog.clear(); s.cchunks.clear(); s.cprog_full.clear(); s.cchunks_full.clear(); s.cmacros.clear(); s.n_macro_p2 = 0;
     const uint32_t C = geo_.num_columns_under_copy_permutation, NC = C + lookup_width_ * lookup_reps_;
     std::vector<uint32_t> starts;
     auto cap_of = [](uint32_t kind) -> uint32_t {
@@ -523,33 +531,160 @@ void CS::build_check_program(Scope& s) {
         default: return 0;  // NOP, PUBLIC_INPUT: no relation
         }
     };
-    for (uint32_t slot = 0; slot < s.n_slots; ++slot) {
-        const zk_row_desc& rd = s.rows[slot];
-        const uint32_t cap = rd.kind < ZK_GATE__COUNT ? cap_of(rd.kind) : 0, w = rd.kind < ZK_GATE__COUNT ? GATES[rd.kind].width : 0;
-        for (uint32_t j0 = 0; cap && j0 < rd.n_instances; j0 += cap) {
-            const uint32_t cnt = std::min(cap, rd.n_instances - j0);
-            starts.push_back((uint32_t)s.cprog.size());
-            s.cprog.push_back(rd.kind | (cnt << 8) | (j0 << 16));
-            s.cprog.push_back(slot);
-            s.cprog.push_back(rd.const_off);
-            for (uint32_t g = 0; g < cnt; ++g)
-                for (uint32_t c = 0; c < w; ++c) s.cprog.push_back(s.alias[(size_t)slot * NC + (j0 + g) * w + c]);
+    // ---- in-circuit Poseidon2 permutations as MACRO packets.  compute_round_function (gadgets.cpp) constrains the 962 outputs of a
+    // ZK_OP_P2_ROUNDS op with 31 matrix gates and 590 FMA gates = 3 104 value references for 974 distinct values; gate by gate the
+    // checker re-fetches most of them from HBM (every value sits in two or three rows visited at different times).  A macro packet
+    // loads the 12 inputs and the 962 stored outputs ONCE, in order, and evaluates the same 621 relations on the stored values in
+    // registers.  The ownership of every gate is verified here against the gadget's structure (variables, constants, the `one` and
+    // round-constant variables); anything unexpected leaves the op to the ordinary packets.
+    std::vector<int32_t> gate_macro(s.gates.size(), -1);
+    struct MacroP2 { uint32_t in_slots[12]; uint32_t first_out; uint32_t first_gate; };
+    std::vector<MacroP2> macros;
+    if (!getenv("ZKGL_NO_CHECK_MACROS")) {
+        std::vector<uint64_t> const_full(s.n_vars, 0);
+        std::vector<uint8_t> is_const(s.n_vars, 0);
+        for (auto& op : s.ops)
+            if (!op.seed_only && op.opcode == ZK_OP_CONST && op.ins[0].kind == Operand::CONSTPOOL) { const_full[op.outs[0]] = s.const_pool[op.ins[0].idx]; is_const[op.outs[0]] = 1; }
+        std::unordered_map<uint32_t, uint32_t> fma_by_d, mm_by_out0;   // output variable -> gate index
+        for (uint32_t gi = 0; gi < s.gates.size(); ++gi) {
+            const GateRec& g = s.gates[gi];
+            if (g.kind == ZK_GATE_FMA) { if (fma_by_d.count(g.vars[3])) fma_by_d[g.vars[3]] = UINT32_MAX; else fma_by_d[g.vars[3]] = gi; }
+            else if (g.kind == ZK_GATE_MATMUL12_EXT || g.kind == ZK_GATE_MATMUL12_INT) { if (mm_by_out0.count(g.vars[12])) mm_by_out0[g.vars[12]] = UINT32_MAX; else mm_by_out0[g.vars[12]] = gi; }
         }
-        const zk_lookup_row_desc& lr = s.lrows[slot];
-        if (lr.table == 0xffffffffu || lr.n_tuples == 0) continue;
-        const TableRec& t = tables_[lr.table - 1];
-        const uint32_t tw = t.n_keys + t.n_vals;
-        if (tw > 4 || t.n_keys > 3) { s.cprog.clear(); s.cchunks.clear(); return; }  // the row-descriptor checker handles such scopes
-        for (uint32_t u0 = 0; u0 < lr.n_tuples; u0 += 3) {
-            const uint32_t cnt = std::min(3u, lr.n_tuples - u0);
-            starts.push_back((uint32_t)s.cprog.size());
-            s.cprog.push_back(0x40u | (cnt << 8) | (u0 << 16));
-            s.cprog.push_back(slot);
-            s.cprog.push_back(lr.table);
-            for (uint32_t g = 0; g < cnt; ++g)
-                for (uint32_t i = 0; i < 4; ++i) s.cprog.push_back(i < tw ? s.alias[(size_t)slot * NC + C + (u0 + g) * lookup_width_ + i] : 0u);
+        const uint64_t* RC = poseidon_round_constants();
+        for (auto& op : s.ops) {
+            if (op.seed_only || op.opcode != ZK_OP_P2_ROUNDS || op.outs.size() != 962 || op.ins.size() != 12) continue;
+            std::vector<uint32_t> owned;
+            bool ok = true;
+            auto want_mm = [&](uint32_t kind, const uint32_t* in12, const uint32_t* out12) {
+                auto it = mm_by_out0.find(out12[0]);
+                if (it == mm_by_out0.end() || it->second == UINT32_MAX) { ok = false; return; }
+                const GateRec& g = s.gates[it->second];
+                if (g.kind != kind) { ok = false; return; }
+                for (int i = 0; i < 12; ++i) if (g.vars[i] != in12[i] || g.vars[12 + i] != out12[i]) { ok = false; return; }
+                owned.push_back(it->second);
+            };
+            // an FMA gate (q, l; a, b, c -> d) of the gadget: d identifies it; t_gate: b must be the constant 1 and c the constant `rc`
+            auto want_fma = [&](uint64_t q, uint64_t l, uint32_t va, uint32_t vb, uint32_t vc, uint32_t vd, bool t_gate, uint64_t rc) {
+                auto it = fma_by_d.find(vd);
+                if (it == fma_by_d.end() || it->second == UINT32_MAX) { ok = false; return; }
+                const GateRec& g = s.gates[it->second];
+                if (g.consts.size() != 2 || g.consts[0] != q || g.consts[1] != l || g.vars[0] != va) { ok = false; return; }
+                if (t_gate) {
+                    if (!is_const[g.vars[1]] || const_full[g.vars[1]] != 1 || !is_const[g.vars[2]] || const_full[g.vars[2]] != rc) { ok = false; return; }
+                } else if (g.vars[1] != vb || g.vars[2] != vc) { ok = false; return; }
+                owned.push_back(it->second);
+            };
+            uint32_t in12[12], cur[12];
+            for (int i = 0; i < 12; ++i) { if (op.ins[i].kind != Operand::VAR) ok = false; in12[i] = op.ins[i].idx; }
+            if (!ok) continue;
+            size_t pos = 0;
+            want_mm(ZK_GATE_MATMUL12_EXT, in12, &op.outs[0]);
+            for (int i = 0; i < 12; ++i) cur[i] = op.outs[i];
+            pos = 12;
+            for (int r = 0; r < 30 && ok; ++r) {
+                const bool full = r < 4 || r >= 26;
+                const int n = full ? 12 : 1;
+                for (int i = 0; i < n && ok; ++i) {
+                    const uint32_t t = op.outs[pos], x2 = op.outs[pos + 1], x3 = op.outs[pos + 2], x4 = op.outs[pos + 3], x7 = op.outs[pos + 4];
+                    want_fma(1, 1, cur[i], 0, 0, t, true, RC[12 * r + i]);
+                    want_fma(1, 0, t, t, t, x2, false, 0);
+                    want_fma(1, 0, x2, t, t, x3, false, 0);
+                    want_fma(1, 0, x2, x2, x2, x4, false, 0);
+                    want_fma(1, 0, x3, x4, x3, x7, false, 0);
+                    cur[i] = x7;
+                    pos += 5;
+                }
+                if (!ok) break;
+                want_mm(full ? ZK_GATE_MATMUL12_EXT : ZK_GATE_MATMUL12_INT, cur, &op.outs[pos]);
+                for (int i = 0; i < 12; ++i) cur[i] = op.outs[pos + i];
+                pos += 12;
+            }
+            if (!ok || pos != 962 || owned.size() != 621) continue;
+            for (size_t q = 0; q < 962; ++q) if (s.var_slot[op.outs[q]] != s.var_slot[op.outs[0]] + q) { ok = false; break; }
+            if (!ok) continue;
+            for (uint32_t gi : owned) if (gate_macro[gi] >= 0) { ok = false; break; }
+            if (!ok) continue;
+            MacroP2 m;
+            for (int i = 0; i < 12; ++i) m.in_slots[i] = s.var_slot[in12[i]];
+            m.first_out = s.var_slot[op.outs[0]];
+            m.first_gate = owned[0];
+            for (uint32_t gi : owned) gate_macro[gi] = (int32_t)macros.size();
+            macros.push_back(m);
         }
     }
+    bool lookups_ok = true;
+    auto emit = [&](std::vector<uint32_t>& prog, std::vector<uint32_t>& chunks, bool use_macros) {
+        starts.clear();
+        std::vector<uint8_t> macro_done(macros.size(), 0);
+        for (uint32_t slot = 0; slot < s.n_slots; ++slot) {
+            const zk_row_desc& rd = s.rows[slot];
+            const uint32_t cap = rd.kind < ZK_GATE__COUNT ? cap_of(rd.kind) : 0, w = rd.kind < ZK_GATE__COUNT ? GATES[rd.kind].width : 0;
+            uint32_t j = 0;
+            while (cap && j < rd.n_instances) {
+                const int32_t mi = use_macros && slot < s.row_gates.size() && j < s.row_gates[slot].size() ? gate_macro[s.row_gates[slot][j]] : -1;
+                if (mi >= 0) {   // owned by a macro packet: emitted once, where its first gate sits
+                    if (!macro_done[mi]) {   // the permutation goes to k_check_p2: descriptor = inputs, first output, row of its first gate
+                        macro_done[mi] = 1;
+                        for (int i = 0; i < 12; ++i) s.cmacros.push_back(macros[mi].in_slots[i]);
+                        s.cmacros.push_back(macros[mi].first_out);
+                        s.cmacros.push_back(slot);
+                    }
+                    ++j;
+                    continue;
+                }
+                uint32_t cnt = 0;
+                while (cnt < cap && j + cnt < rd.n_instances &&
+                       !(use_macros && slot < s.row_gates.size() && j + cnt < s.row_gates[slot].size() && gate_macro[s.row_gates[slot][j + cnt]] >= 0))
+                    ++cnt;
+                starts.push_back((uint32_t)prog.size());
+                prog.push_back(rd.kind | (cnt << 8) | (j << 16));
+                prog.push_back(slot);
+                prog.push_back(rd.const_off);
+                for (uint32_t g = 0; g < cnt; ++g)
+                    for (uint32_t c = 0; c < w; ++c) prog.push_back(s.alias[(size_t)slot * NC + (j + g) * w + c]);
+                j += cnt;
+            }
+            const zk_lookup_row_desc& lr = s.lrows[slot];
+            if (lr.table == 0xffffffffu || lr.n_tuples == 0) continue;
+            const TableRec& t = tables_[lr.table - 1];
+            const uint32_t tw = t.n_keys + t.n_vals;
+            if (tw > 4 || t.n_keys > 3) { lookups_ok = false; return; }  // the row-descriptor checker handles such scopes
+            for (uint32_t u0 = 0; u0 < lr.n_tuples; u0 += 3) {
+                const uint32_t cnt = std::min(3u, lr.n_tuples - u0);
+                starts.push_back((uint32_t)prog.size());
+                prog.push_back(0x40u | (cnt << 8) | (u0 << 16));
+                prog.push_back(slot);
+                prog.push_back(lr.table);
+                for (uint32_t g = 0; g < cnt; ++g)
+                    for (uint32_t i = 0; i < 4; ++i) prog.push_back(i < tw ? s.alias[(size_t)slot * NC + C + (u0 + g) * lookup_width_ + i] : 0u);
+            }
+        }
+        if (starts.empty()) { prog.clear(); return; }
+        // chunks of whole packets, balanced by words
+        std::vector<uint64_t> weight(starts.size() + 1, 0);
+        for (size_t p = 0; p < starts.size(); ++p) {
+            const uint32_t end = p + 1 < starts.size() ? starts[p + 1] : (uint32_t)prog.size();
+            weight[p + 1] = weight[p] + (end - starts[p]);
+        }
+        const uint64_t total_w = weight.back();
+        const uint32_t n_chunks = (uint32_t)std::min<size_t>(256, starts.size());
+        chunks.push_back(0);
+        size_t p = 0;
+        for (uint32_t cidx = 1; cidx < n_chunks; ++cidx) {
+            const uint64_t target = total_w * cidx / n_chunks;
+            while (p + 1 < starts.size() && weight[p] < target) ++p;
+            if (starts[p] > chunks.back()) chunks.push_back(starts[p]);
+        }
+        chunks.push_back((uint32_t)prog.size());
+    };
+    emit(s.cprog, s.cchunks, true);
+    if (lookups_ok && !macros.empty()) emit(s.cprog_full, s.cchunks_full, false);
+    if (!lookups_ok) { s.cprog.clear(); s.cchunks.clear(); s.cprog_full.clear(); s.cchunks_full.clear(); s.cmacros.clear(); return; }
+    s.n_macro_p2 = (uint32_t)macros.size();
+    if (getenv("ZKGL_PROG_STATS"))
+        fprintf(stderr, "[zkgl] %s scope check program: %zu words, %u Poseidon2 macro packets (gate by gate: %zu words)\n", s.is_loop ? "loop" : "outer", s.cprog.size(),
+                s.n_macro_p2, s.cprog_full.size());
     if (getenv("ZKGL_CHECK_ORDER_STATS")) {
         // how many value fetches a small LRU window (the share of L2 a wavefront can count on) leaves to HBM: packets in row order (as
         // emitted) against gate instances ordered by their youngest operand
@@ -599,17 +734,6 @@ void CS::build_check_program(Scope& s) {
                     (unsigned long long)d.first, s.n_store);
         }
     }
-    if (starts.empty()) { s.cprog.clear(); return; }
-    const uint32_t total = (uint32_t)s.cprog.size();
-    const uint32_t n_chunks = (uint32_t)std::min<size_t>(256, starts.size());
-    s.cchunks.push_back(0);
-    size_t p = 0;
-    for (uint32_t c = 1; c < n_chunks; ++c) {
-        const uint32_t target = (uint32_t)((uint64_t)total * c / n_chunks);
-        while (p + 1 < starts.size() && starts[p] < target) ++p;
-        if (starts[p] > s.cchunks.back()) s.cchunks.push_back(starts[p]);
-    }
-    s.cchunks.push_back(total);
 }
 
 // Lookup sites of a scope grouped by table (k_multiplicities): the key slots of every recorded lookup
@@ -1557,6 +1681,17 @@ void CS::upload_scope(Scope& s) {
         s.d_cprog = upload(padded);
         s.d_cchunks = upload(s.cchunks);
     }
+    if (!s.cmacros.empty()) {
+        std::vector<uint32_t> padded(s.cmacros);
+        padded.resize(padded.size() + 16, 0);   // 16-word scalar fetch of a 14-word descriptor
+        s.d_cmacros = upload(padded);
+    }
+    if (!s.cprog_full.empty()) {
+        std::vector<uint32_t> padded(s.cprog_full);
+        padded.resize(((padded.size() + 63) / 64) * 64 + 64, 0);
+        s.d_cprog_full = upload(padded);
+        s.d_cchunks_full = upload(s.cchunks_full);
+    }
     if (!s.sprog.empty()) {
         std::vector<uint32_t> padded(s.sprog);
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
@@ -1870,10 +2005,13 @@ void CS::resolve(void* stream) {
     compact_ = true;  // home cells only: see check_satisfied / ensure_materialized
 }
 
-zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool compact) const {
+zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro) const {
     zkdev::CheckArgs a;
     a.alias = compact ? s.d_alias : nullptr;
-    a.cprog = compact ? s.d_cprog : nullptr; a.chunk_tab = s.d_cchunks; a.n_chunks = s.cchunks.empty() ? 0 : (uint32_t)s.cchunks.size() - 1;
+    const bool full = !macro && s.d_cprog_full;   // the program without macro packets: locates a failure a macro packet reported
+    a.cprog = compact ? (full ? s.d_cprog_full : s.d_cprog) : nullptr; a.chunk_tab = full ? s.d_cchunks_full : s.d_cchunks;
+    a.n_chunks = full ? (uint32_t)s.cchunks_full.size() - 1 : (s.cchunks.empty() ? 0 : (uint32_t)s.cchunks.size() - 1);
+    a.macros = (compact && !full) ? s.d_cmacros : nullptr; a.n_macros = (compact && !full) ? s.n_macro_p2 : 0;
     a.cells = compact ? s.d_store : s.d_cells; a.n_cells = compact ? s.n_store : s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
     a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
     a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
@@ -1889,6 +2027,12 @@ zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool c
 }
 
 int CS::check_satisfied(void* stream, zk_failure* first) {
+    const int rc = check_satisfied_impl(stream, first, true);
+    // a macro packet reported: the gate-by-gate program names the gate (same verdict, rare path)
+    return rc == ZK_MACRO_FAILURE ? check_satisfied_impl(stream, first, false) : rc;
+}
+
+int CS::check_satisfied_impl(void* stream, zk_failure* first, bool macro) {
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "check_satisfied before set_batch");
     hipStream_t st = (hipStream_t)stream;
     // compact trace (straight from the witness kernels): a variable has ONE stored value, the gate checker reads every cell
@@ -1898,14 +2042,14 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
     const bool compact = compact_;
     hip_check(hipMemsetAsync(d_fail_, 0xff, 8 * sizeof(unsigned long long), st), "memset fail");
     hip_check(hipEventRecord((hipEvent_t)ev_[4], st), "event");
-    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, compact), st));
+    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, compact, macro), st));
     check_inputs_canonical(st, st);
     if (!compact)
         dev_check(zkdev::launch_check_copies(outer_.d_cells, outer_.n_cells, outer_.n_lanes, outer_.d_copies,
                                              (uint32_t)outer_.copies.size(), d_fail_, st));
     hip_check(hipEventRecord((hipEvent_t)ev_[5], st), "event");
     if (limit_) {
-        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, compact), st));
+        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, compact, macro), st));
         hip_check(hipEventRecord((hipEvent_t)ev_[6], st), "event");
         if (!compact)
             dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies,
@@ -2047,6 +2191,7 @@ int CS::decode_failure(const unsigned long long* f, zk_failure* first) const {
             uint32_t slot = (uint32_t)((ff[0] >> 12) & 0xfffff), j = (uint32_t)((ff[0] >> 4) & 0xff), rel = (uint32_t)(ff[0] & 0xf);
             bool is_lookup = (j & 0x80) && rel == 15;
             if (slot == 0xfffffu) { fill(ff[0], j, ZK_FAILURE_NONCANONICAL_INPUT, 0); return ZK_ERR_UNSATISFIED; }  // input word j (mod 256) >= p
+            if (slot == 0xffffeu) return ZK_MACRO_FAILURE;  // a macro packet: the caller re-runs the gate-by-gate program to name the gate
             fill(ff[0], slot, is_lookup ? 0x100u : s.rows[slot].kind, is_lookup ? (j & 0x7f) : rel);
             return ZK_ERR_UNSATISFIED;
         }
@@ -2129,7 +2274,8 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hipEventElapsedTime(&outer_post, E(3), E(4));
     ms_[0] = total; ms_[1] = loop_ms; ms_[2] = gates_ms + copies_ms; ms_[3] = gates_ms; ms_[4] = outer_post;
     compact_ = true;
-    return decode_failure(f, first);
+    const int rc = decode_failure(f, first);
+    return rc == ZK_MACRO_FAILURE ? check_satisfied_impl(stream, first, false) : rc;
 }
 
 uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
@@ -2176,6 +2322,14 @@ int CS::hook_compare_witness(const zk_var* vars, uint32_t n_vars, const uint64_t
     if (f == ~0ull) return ZK_OK;
     if (first) { std::memset(first, 0, sizeof *first); first->instance = (uint32_t)(f >> 32); first->slot = (uint32_t)f; first->kind = ZK_FAILURE_HOOK_DIFF; }
     return ZK_ERR_UNSATISFIED;
+}
+
+// test hook: overwrite one value of the variable store (the compact trace stays compact) — fault injection below the level of
+// write_cell, which materialises the trace; lets tests corrupt a Poseidon2 intermediate that only a macro check packet reads
+void CS::debug_poke_store(bool loop_scope, uint32_t slot, uint32_t lane, uint64_t value) {
+    Scope& s = loop_scope ? loop_ : outer_;
+    if (batch_ == 0 || !compact_ || slot >= s.n_store || lane >= s.n_lanes) throw ZkError(ZK_ERR_INVALID, "debug_poke_store: out of range or trace materialised");
+    hip_check(hipMemcpy(s.d_store + tiled_offset(s.n_store, slot, lane), &value, 8, hipMemcpyHostToDevice), "poke memcpy");
 }
 
 uint32_t CS::pack_public_inputs(uint64_t* dev_out, void* stream) {

@@ -91,6 +91,11 @@ struct Scope {
     // check program of the compact gate / lookup checker (kernels_engine2.hpp k_check_prog) + its chunk table (word offsets of
     // whole-packet chunks, n_chunks + 1 entries); empty when the scope cannot use it (a lookup tuple wider than 4 columns)
     std::vector<uint32_t> cprog, cchunks;
+    // the same without macro packets (every gate instance on its own): run when a macro packet reports, to locate the failing gate
+    std::vector<uint32_t> cprog_full, cchunks_full;
+    std::vector<uint32_t> cmacros;   // Poseidon2 macro descriptors (k_check_p2), 14 words each
+    std::vector<std::vector<uint32_t>> row_gates;  // [row][instance] -> index into `gates`
+    uint32_t n_macro_p2 = 0;
     // lookup sites by table for k_multiplicities: 3 key slots per site; site_off[table id] .. site_off[table id + 1]
     std::vector<uint32_t> mult_sites, mult_site_off;
     uint32_t pre_words2 = 0, side_words2 = 0, pre_slots = 0, side_slots = 0;
@@ -121,6 +126,9 @@ struct Scope {
     uint32_t* d_prog2 = nullptr;
     uint32_t* d_cprog = nullptr;
     uint32_t* d_cchunks = nullptr;
+    uint32_t* d_cmacros = nullptr;
+    uint32_t* d_cprog_full = nullptr;
+    uint32_t* d_cchunks_full = nullptr;
     uint32_t* d_mult_sites = nullptr;
     uint32_t* d_sprog = nullptr;
     uint64_t* d_consts = nullptr;
@@ -177,8 +185,11 @@ class CS {
     void set_batch(uint32_t n_instances);
     void bind_inputs(bool loop_scope, const uint64_t* dev_words, uint32_t n_words, uint64_t lane_stride = 0);
     // public inputs of the whole batch packed on the device: out[instance * n_public + k]; returns n_public
+    void debug_poke_store(bool loop_scope, uint32_t slot, uint32_t lane, uint64_t value);
+    uint32_t store_slots(bool loop_scope) const { return (loop_scope ? loop_ : outer_).n_store; }
     uint32_t pack_public_inputs(uint64_t* dev_out, void* stream);
     // 0 equal; ZK_ERR_UNSATISFIED + first difference (scope 0, instance, slot = position in `vars`, kind = ZK_FAILURE_HOOK_DIFF)
+    int check_satisfied_impl(void* stream, zk_failure* first, bool macro);
     int hook_compare_witness(const zk_var* vars, uint32_t n_vars, const uint64_t* dev_expected, void* stream, zk_failure* first);
     uint32_t batch() const { return batch_; }
     void seed_stream(uint32_t n_instances, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream);
@@ -256,7 +267,7 @@ class CS {
     void free_scope_device(Scope& s);
     void check_var(zk_var v, bool want_loop) const;
     int decode_failure(const unsigned long long* f, zk_failure* first) const;
-    zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail, bool compact) const;
+    zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro = true) const;
 
     zk_geometry geo_;
     uint64_t max_trace_len_, max_variables_;

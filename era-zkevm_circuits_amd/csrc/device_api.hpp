@@ -22,7 +22,8 @@ struct CheckArgs {  // mirrors zke::CheckDev
     uint32_t n_copy_cols; uint32_t lookup_width; const zk_table_desc* tables; const uint64_t* table_words;
     unsigned long long* fail; uint32_t slots_per_chunk;
     const uint32_t* alias;  // compact trace: trace cell -> home cell (nullptr: materialised trace)
-    const uint32_t* cprog = nullptr; const uint32_t* chunk_tab = nullptr; uint32_t n_chunks = 0;  // compact trace: the check program (k_check_prog)
+    const uint32_t* cprog = nullptr; const uint32_t* chunk_tab = nullptr; uint32_t n_chunks = 0;
+    const uint32_t* macros = nullptr; uint32_t n_macros = 0;  // Poseidon2 macro descriptors whose gates the check program leaves out (k_check_p2)  // compact trace: the check program (k_check_prog)
 };
 
 int upload_round_constants(const uint64_t rc[360]);

@@ -994,7 +994,7 @@ struct CheckProgDev {
     const uint64_t* rowconsts; const zk_table_desc* tables; const uint64_t* table_words;
     unsigned long long* fail;
 };
-constexpr uint32_t ZK_CHECK_LOOKUP = 0x40;
+constexpr uint32_t ZK_CHECK_LOOKUP = 0x40, ZK_CHECK_P2 = 0x41;
 
 template <uint32_t N, class F>
 __device__ __forceinline__ void dispatch_count(uint32_t n, F&& f) {
@@ -1221,6 +1221,88 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_
             return;  // malformed program: built by the host
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// In-circuit Poseidon2 permutations, checked as MACRO packets (k_check_p2; cs.cpp build_check_program).  gadgets.cpp
+// compute_round_function constrains the 962 outputs of a ZK_OP_P2_ROUNDS op with 31 matrix gates and 590 FMA gates: 3 104 value
+// references to 974 distinct values that the gate-by-gate program meets in three different rows.  Here every stored value is loaded
+// ONCE, in order (the outputs are consecutive slots), and the same 621 relations — t = x + rc, x2 = t t, x3 = x2 t, x4 = x2 x2,
+// x7 = x3 x4, out = M in — are evaluated on the STORED operands.  A kernel of its own: the unrolled rounds are 40 KB of code and want
+// their own register budget.  A failure is reported under row 0xffffe; the host then runs the gate-by-gate program to name the gate.
+// descriptor = 14 words: 12 input slots, slot of the first output, row of the first gate.
+// ------------------------------------------------------------------------------------------------------------------------
+struct CheckP2Dev { const uint64_t* cells; uint64_t n_cells; uint32_t n_lanes; const uint32_t* macros; uint32_t n_macros, per_block; unsigned long long* fail; };
+__global__ __launch_bounds__(TPB) void k_check_p2(CheckP2Dev cd) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= cd.n_lanes) return;
+    const bool active = lane < cd.n_lanes;
+    lane = active ? lane : cd.n_lanes - 1;
+    const uint32_t lane_byte = (lane & 63) * 8;
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(cd.cells) + (size_t)tile * cd.n_cells * 64, 0, -1, 0x00020000);
+    const prog1_ptr macros = (prog1_ptr)(uintptr_t)cd.macros;
+    auto ldv = [&](uint32_t slot) -> uint64_t {
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << 9, 0);
+        return (uint64_t)v.x | ((uint64_t)v.y << 32);
+    };
+    const uint32_t m0 = blockIdx.y * cd.per_block, m1 = min(m0 + cd.per_block, cd.n_macros);
+    bool wrong = false;
+    for (uint32_t m = m0; m < m1; ++m) {
+        const u32x16_a4 W = *(prog16_ptr)(macros + 14 * m);
+        uint64_t cur[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cur[i] = ldv(W[i]);
+        uint32_t o = W[12];
+        auto matrix = [&](bool external) {
+            uint64_t mm[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) mm[i] = ldv(o + i);
+            o += 12;
+            if (external) p2::mds_external(cur); else p2::mds_inner(cur);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { wrong |= cur[i] != mm[i]; cur[i] = mm[i]; }
+        };
+        auto sbox_check = [&](uint64_t& x, uint64_t rc, uint64_t t, uint64_t x2, uint64_t x3, uint64_t x4, uint64_t x7) {
+            wrong |= t != gl::add(x, rc);
+            wrong |= x2 != gl::sqr(t);
+            wrong |= x3 != gl::mul(x2, t);
+            wrong |= x4 != gl::sqr(x2);
+            wrong |= x7 != gl::mul(x3, x4);
+            x = x7;
+        };
+        matrix(true);
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = half * 26 + r4;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {   // four S-boxes at a time: 20 loads in flight
+                    uint64_t v[20];
+#pragma unroll
+                    for (int i = 0; i < 20; ++i) v[i] = ldv(o + i);
+                    o += 20;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sbox_check(cur[4 * q + i], p2::RC[12 * r + 4 * q + i], v[5 * i], v[5 * i + 1], v[5 * i + 2], v[5 * i + 3], v[5 * i + 4]);
+                }
+                matrix(true);
+            }
+            if (half == 0) {
+#pragma unroll 1
+                for (int r = 4; r < 26; ++r) {
+                    uint64_t v[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) v[i] = ldv(o + i);
+                    o += 5;
+                    sbox_check(cur[0], p2::RC[12 * r], v[0], v[1], v[2], v[3], v[4]);
+                    matrix(false);
+                }
+            }
+        }
+    }
+    if (wrong && active) report(cd.fail, lane, 0xffffeu, 0, 0);
 }
 
 // public inputs of every instance of the batch, packed [instance][n_public] (the payload of zk_cs_gather_commitments)

@@ -161,6 +161,14 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
         p.chunks_per_block = std::max<uint32_t>(1, a.n_chunks / wanted);
         dim3 grid(lane_tiles, (a.n_chunks + p.chunks_per_block - 1) / p.chunks_per_block);
         zke::k_check_prog<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(p);
+        if (a.macros && a.n_macros) {
+            zke::CheckP2Dev m;
+            m.cells = a.cells; m.n_cells = a.n_cells; m.n_lanes = a.n_lanes; m.macros = a.macros; m.n_macros = a.n_macros; m.fail = a.fail;
+            const uint32_t want_y = std::max<uint32_t>(1, std::min<uint32_t>(a.n_macros, (2048 + lane_tiles - 1) / lane_tiles));
+            m.per_block = (a.n_macros + want_y - 1) / want_y;
+            dim3 g2(lane_tiles, (a.n_macros + m.per_block - 1) / m.per_block);
+            zke::k_check_p2<<<g2, zke::TPB, 0, (hipStream_t)stream>>>(m);
+        }
         return LAUNCH_CHECK("k_check_prog");
     }
     dim3 grid(grid_for(a.n_lanes, zke::TPB), (a.n_slots + a.slots_per_chunk - 1) / a.slots_per_chunk);

@@ -771,6 +771,14 @@ class ConstraintSystem:
         flat = comm._out.to_numpy()[: comm.world * self._batch * n.value]
         return flat.reshape(comm.world, self._batch, n.value)
 
+    def debug_poke_store(self, loop_scope: bool, slot: int, lane: int, value: int):
+        _check(lib().zk_cs_debug_poke_store(self._h, int(loop_scope), slot, lane, C.c_uint64(value)))
+
+    def store_slots(self, loop_scope: bool) -> int:
+        n = C.c_uint32(0)
+        _check(lib().zk_cs_store_slots(self._h, int(loop_scope), C.byref(n)))
+        return n.value
+
     def hook_vars(self, name: str):
         n = C.c_uint32(0)
         _check(lib().zk_circuit_hook_vars(self._h, name.encode(), None, 0, C.byref(n)))

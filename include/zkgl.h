@@ -202,6 +202,10 @@ int zk_circuit_hook_vars(zk_cs *cs, const char *name, zk_var *vars, uint32_t max
 #define ZK_FAILURE_HOOK_DIFF 0xfeu
 int zk_cs_hook_compare_witness(zk_cs *cs, const zk_var *vars, uint32_t n_vars, const uint64_t *dev_expected, void *stream, zk_failure *first);
 int zk_cs_write_cell(zk_cs *cs, int loop_scope, uint32_t cell, uint32_t lane, uint64_t value); /* fault injection for tests */
+/* fault injection below write_cell: overwrite one value of the VARIABLE STORE after zk_cs_resolve (the trace stays compact), slot <
+ * zk_cs_store_slots; a following zk_cs_check_satisfied sees the corrupted witness value */
+int zk_cs_debug_poke_store(zk_cs *cs, int loop_scope, uint32_t slot, uint32_t lane, uint64_t value);
+int zk_cs_store_slots(zk_cs *cs, int loop_scope, uint32_t *n);
 int zk_cs_public_inputs(zk_cs *cs, uint32_t instance, uint64_t *out, uint32_t max, uint32_t *n);
 /* ---- the path's only collective: instances are sharded across GPUs with no data-path exchange; the 4-element
  * input commitments of every instance are all-gathered once per step over RCCL / xGMI (32 B per instance: latency-bound).

@@ -390,3 +390,29 @@ def test_keccak_packer_walks_the_fsm_schedule():
     el[0:423] = 0
     assert np.array_equal(outer, eo)
     assert np.array_equal(loop, el)
+
+
+@pytest.mark.gpu
+def test_corrupted_poseidon2_intermediate_is_caught_by_the_macro_packet(zk):
+    """the checker evaluates an in-circuit Poseidon2 permutation as ONE macro packet (all 621 relations on the stored values, each value
+    loaded once); a corrupted stored intermediate must be caught there and named by the gate-by-gate re-run"""
+    from helpers import ram_cs
+    cases = [_case(700 + i, LIMIT) for i in range(2)]
+    outer, loop = rn.pack_streams([c[3] for c in cases], LIMIT)
+    cs = ram_cs(LIMIT)
+    cs.set_batch(2)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
+    n = cs.store_slots(True)
+    rng = np.random.default_rng(5)
+    kinds = set()
+    for slot in sorted(set(int(x) for x in rng.integers(0, n, size=12))):
+        cs.resolve()
+        ok, f = cs.check_if_satisfied()
+        assert ok, f
+        lane = LIMIT + 7                       # instance 1, cycle 7
+        cs.debug_poke_store(True, slot, lane, 0x1234567)
+        ok, f = cs.check_if_satisfied()
+        assert not ok and f.scope == 1 and f.instance == 1 and f.iteration == 7, (slot, ok, f)
+        kinds.add(f.kind)
+    assert zkgl.GATE["MATMUL12_EXT"] in kinds or zkgl.GATE["MATMUL12_INT"] in kinds or zkgl.GATE["FMA"] in kinds, kinds
