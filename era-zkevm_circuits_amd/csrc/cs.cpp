@@ -695,6 +695,7 @@ void CS::build_check_program(Scope& s) {
             const uint32_t w = rd.kind < ZK_GATE__COUNT ? GATES[rd.kind].width : 0;
             if (rd.kind < ZK_GATE__COUNT && cap_of(rd.kind))
                 for (uint32_t j = 0; j < rd.n_instances; ++j) {
+                    if (slot < s.row_gates.size() && j < s.row_gates[slot].size() && gate_macro[s.row_gates[slot][j]] >= 0) continue;  // checked by k_check_p2
                     Inst in; in.key = 0;
                     for (uint32_t c = 0; c < w; ++c) { const uint32_t v = s.alias[(size_t)slot * NC + j * w + c]; in.slots.push_back(v); in.key = std::max(in.key, v); }
                     insts.push_back(std::move(in));
@@ -727,6 +728,21 @@ void CS::build_check_program(Scope& s) {
         auto mean = [](const Inst& a) { uint64_t t = 0; for (auto v : a.slots) t += v; return a.slots.empty() ? 0 : t / a.slots.size(); };
         std::stable_sort(by_min.begin(), by_min.end(), [&](const Inst& a, const Inst& b) { return mn(a) < mn(b); });
         std::stable_sort(by_mean.begin(), by_mean.end(), [&](const Inst& a, const Inst& b) { return mean(a) < mean(b); });
+        {   // references of the remaining gates to values pinned by a constant gate, by constant
+            std::vector<int64_t> pinned(s.n_store, -1);
+            for (uint32_t slot = 0; slot < s.n_slots; ++slot) {
+                const zk_row_desc& rd = s.rows[slot];
+                if (rd.kind != ZK_GATE_CONST) continue;
+                for (uint32_t j = 0; j < rd.n_instances; ++j) pinned[s.alias[(size_t)slot * NC + j]] = (int64_t)(s.rowconsts[rd.const_off + j] & 0x7fffffffffffffffull);
+            }
+            std::map<int64_t, uint64_t> by_value; uint64_t tot = 0;
+            for (auto& in : insts) for (auto v : in.slots) if (pinned[v] >= 0) { by_value[pinned[v]]++; ++tot; }
+            std::vector<std::pair<uint64_t, int64_t>> top; for (auto& kv : by_value) top.push_back({kv.second, kv.first});
+            std::sort(top.rbegin(), top.rend());
+            fprintf(stderr, "[zkgl] %s scope: %llu references to constant-pinned values (incl. the constant gates themselves):", s.is_loop ? "loop" : "outer", (unsigned long long)tot);
+            for (size_t i = 0; i < top.size() && i < 8; ++i) fprintf(stderr, " %lld x%llu", (long long)top[i].second, (unsigned long long)top[i].first);
+            fprintf(stderr, "\n");
+        }
         for (size_t K : {16, 32, 64, 256, 1024}) {
             auto a = misses(insts, K), b = misses(sorted, K), c = misses(by_min, K), d = misses(by_mean, K);
             fprintf(stderr, "[zkgl] %s scope check order, window %zu touches: row order %llu fetches of %llu refs; by youngest operand %llu, by oldest %llu, by mean %llu (unique values %u)\n",
