@@ -743,6 +743,37 @@ void CS::build_check_program(Scope& s) {
             for (size_t i = 0; i < top.size() && i < 8; ++i) fprintf(stderr, " %lld x%llu", (long long)top[i].second, (unsigned long long)top[i].first);
             fprintf(stderr, "\n");
         }
+        if (getenv("ZKGL_CHECK_GREEDY")) {   // gate instances in a greedy locality order (no dependencies between checks): potential of reordering
+            const int64_t W = std::atoll(getenv("ZKGL_CHECK_GREEDY"));
+            std::vector<int64_t> last(s.n_store, INT64_MIN / 2);
+            std::vector<std::vector<uint32_t>> users(s.n_store);
+            for (uint32_t i = 0; i < insts.size(); ++i) for (auto v : insts[i].slots) users[v].push_back(i);
+            std::vector<uint8_t> done(insts.size(), 0);
+            std::vector<Inst> greedy; greedy.reserve(insts.size());
+            int64_t stamp = 0; size_t next_unplaced = 0;
+            std::vector<uint32_t> recent;   // values touched lately (candidates come from their users)
+            while (greedy.size() < insts.size()) {
+                int64_t best = -1; double bs = -1e300;
+                for (size_t r = recent.size() > 24 ? recent.size() - 24 : 0; r < recent.size(); ++r)
+                    for (uint32_t i : users[recent[r]]) {
+                        if (done[i]) continue;
+                        double sc = 0;
+                        for (auto v : insts[i].slots) sc += (stamp - last[v] <= W) ? 1.0 : -1.0;
+                        if (sc > bs + 1e-12 || (std::fabs(sc - bs) <= 1e-12 && (int64_t)i < best)) { bs = sc; best = i; }
+                    }
+                if (best < 0 || bs < -1.5) {   // nothing near: continue in row order
+                    while (next_unplaced < insts.size() && done[next_unplaced]) ++next_unplaced;
+                    if (best < 0 || true) best = (int64_t)next_unplaced;
+                }
+                done[best] = 1; greedy.push_back(insts[best]);
+                for (auto v : insts[best].slots) { last[v] = ++stamp; recent.push_back(v); }
+            }
+            for (size_t K : {16, 32, 64}) {
+                auto a = misses(insts, K), g = misses(greedy, K);
+                fprintf(stderr, "[zkgl] %s scope greedy check order (window %lld): LRU %zu touches: row order %llu fetches, greedy %llu of %llu refs\n", s.is_loop ? "loop" : "outer",
+                        (long long)W, K, (unsigned long long)a.first, (unsigned long long)g.first, (unsigned long long)g.second);
+            }
+        }
         for (size_t K : {16, 32, 64, 256, 1024}) {
             auto a = misses(insts, K), b = misses(sorted, K), c = misses(by_min, K), d = misses(by_mean, K);
             fprintf(stderr, "[zkgl] %s scope check order, window %zu touches: row order %llu fetches of %llu refs; by youngest operand %llu, by oldest %llu, by mean %llu (unique values %u)\n",
@@ -837,6 +868,7 @@ void CS::assign_store_slots(Scope& s) {
 // achievable write rate).  This pass reorders the ops — any topological order of the value dependencies fills the same
 // cells — so that every prefix of the program has used both resources in proportion: a greedy list scheduler that
 // always emits the ready op bringing |ALU_done/ALU_total - MEM_done/MEM_total| closest to zero, ties to recording order.
+static uint32_t group_cap(const OpRec& op, bool v2);
 void CS::schedule_loop_ops() {
     const char* off = std::getenv("ZKGL_SCHEDULE");
     Scope& s = loop_;
@@ -893,6 +925,10 @@ void CS::schedule_loop_ops() {
     }
     // Light ops keep their recording order among themselves (operand locality in L2): only the FIRST ready light op (a
     // min-heap on the recording index) is a candidate; every ready heavy op is.
+    if (!(off && off[0] == '1')) {   // default: light ops by operand locality (schedule_by_locality); ZKGL_SCHEDULE=1: the round-1 rule below
+        schedule_by_locality(a, m, a_tot, m_tot, succ, n_pred);
+        return;
+    }
     std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> ready_light;
     std::vector<uint32_t> ready_heavy, order;
     order.reserve(n);
@@ -917,6 +953,69 @@ void CS::schedule_loop_ops() {
         a_done += a[best]; m_done += m[best];
         for (auto nx : succ[best])
             if (--n_pred[nx] == 0) make_ready(nx);
+    }
+    std::vector<OpRec> reordered;
+    reordered.reserve(n);
+    for (auto i : order) reordered.push_back(std::move(s.ops[i]));
+    s.ops = std::move(reordered);
+}
+
+// The default schedule: the same resource balance for the heavy ops, but among the ready light ops the one whose operands were touched
+// most recently goes first (consumers of a value cluster behind its producer and behind each other), continuing the open group of
+// same-kind ops when it can; ties to recording order.  Why: a wavefront of k_witness_loop can count on ~16 values (8 KB) of L2, and in
+// recording order 10.3 k of a VM cycle's 18.8 k operand reads come back later than that (LRU model, ZKGL_PROG_STATS=1; measured
+// FETCH_SIZE agrees); this order leaves 6.6 k.  A window of 16 touches is the flat optimum of the model (12..20: 6.6-6.8 k; 8: 7.4 k,
+// 48: 8.2 k) and of the kernel (B=384, one box: recording order 43.5 ms, windows 8 / 16 / 48: 42.2 / 40.0 / 42.9 ms).  Weighting misses,
+// a last-consumer bonus or a larger group bonus change the model by < 2 %.
+void CS::schedule_by_locality(const std::vector<double>& a, const std::vector<double>& m, double a_tot, double m_tot,
+                              const std::vector<std::vector<uint32_t>>& succ, std::vector<uint32_t>& n_pred) {
+    Scope& s = loop_;
+    const size_t n = s.ops.size();
+    const char* kenv = std::getenv("ZKGL_SCHEDULE_WINDOW");
+    const int64_t W = kenv ? std::atoll(kenv) : 16;   // touches (reads + writes) a value stays "near" for
+    std::vector<int64_t> last(s.n_vars, INT64_MIN / 2);
+    int64_t stamp = 0;
+    std::vector<uint32_t> ready_light, ready_heavy, order;
+    std::vector<uint8_t> in_ready(n, 0);
+    auto make_ready = [&](uint32_t i) { (a[i] > 1000 ? ready_heavy : ready_light).push_back(i); };
+    for (size_t i = 0; i < n; ++i) if (n_pred[i] == 0) make_ready((uint32_t)i);
+    double a_done = 0, m_done = 0;
+    auto imbalance_after = [&](uint32_t i) { return std::fabs((a_done + a[i]) / a_tot - (m_done + m[i]) / m_tot); };
+    uint32_t prev_opcode = UINT32_MAX, run = 0;
+    auto score = [&](uint32_t i) {
+        const OpRec& op = s.ops[i];
+        double sc = 0; int vars = 0;
+        for (auto& in : op.ins) if (in.kind == Operand::VAR) { ++vars; sc += (stamp - last[in.idx] <= W) ? 1.0 : -1.0; }
+        if (!vars) sc = 0.25;   // constants / inputs: neutral, slightly ahead of a miss
+        if ((uint32_t)op.opcode == prev_opcode && run < group_cap(op, true)) sc += 0.6;
+        return sc;
+    };
+    while (order.size() < n) {
+        // light candidate: best score, ties to the lowest recording index
+        size_t bl = SIZE_MAX; double bs = -1e300;
+        for (size_t k = 0; k < ready_light.size(); ++k) {
+            const double sc = score(ready_light[k]);
+            if (sc > bs + 1e-12 || (std::fabs(sc - bs) <= 1e-12 && ready_light[k] < ready_light[bl])) { bs = sc; bl = k; }
+        }
+        uint32_t best = bl == SIZE_MAX ? UINT32_MAX : ready_light[bl];
+        double best_v = best == UINT32_MAX ? 1e300 : imbalance_after(best);
+        size_t best_h = SIZE_MAX;
+        for (size_t hi = 0; hi < ready_heavy.size(); ++hi) {
+            const uint32_t h = ready_heavy[hi];
+            const double v = imbalance_after(h);
+            if (v < best_v - 1e-12 || (std::fabs(v - best_v) <= 1e-12 && h < best)) { best = h; best_v = v; best_h = hi; }
+        }
+        if (best == UINT32_MAX) return;
+        if (best_h != SIZE_MAX) { ready_heavy[best_h] = ready_heavy.back(); ready_heavy.pop_back(); }
+        else { ready_light[bl] = ready_light.back(); ready_light.pop_back(); }
+        order.push_back(best);
+        const OpRec& op = s.ops[best];
+        if ((uint32_t)op.opcode == prev_opcode) ++run; else { prev_opcode = op.opcode; run = 1; }
+        for (auto& in : op.ins) if (in.kind == Operand::VAR) last[in.idx] = ++stamp;
+        if (op.opcode == ZK_OP_P2_ROUNDS) { stamp += (int64_t)op.outs.size(); for (size_t q = op.outs.size() - 12; q < op.outs.size(); ++q) last[op.outs[q]] = stamp; }
+        else for (auto ov : op.outs) last[ov] = ++stamp;
+        a_done += a[best]; m_done += m[best];
+        for (auto nx : succ[best]) if (--n_pred[nx] == 0) make_ready(nx);
     }
     std::vector<OpRec> reordered;
     reordered.reserve(n);
@@ -1299,6 +1398,39 @@ void CS::emit_scope(Scope& s) {
             fprintf(stderr, "   operand references to constant variables: ops %llu of %llu, gates/lookups %llu of %llu\n", (unsigned long long)op_const,
                     (unsigned long long)op_refs, (unsigned long long)gate_const, (unsigned long long)gate_refs);
         }
+        {   // LRU model of a wavefront's share of L2 (K values of 512 B; reads and writes touch): operand fetches left to HBM, with the
+            // Poseidon2 intermediates (never read again by the witness kernel) allocating like any store, or streamed past the cache
+            auto lru_misses = [&](size_t K, bool p2_bypass) {
+                std::vector<int64_t> last(s.n_vars, -1);
+                int64_t stamp = 0; uint64_t miss = 0;
+                std::vector<int64_t> ring;   // stamps are distinct per touch; a value is resident iff fewer than K distinct values were touched since
+                // distinct-touch counting with a Fenwick tree over stamps
+                const size_t cap = 4 * (size_t)s.n_vars + 8 * s.ops.size() + 64;
+                std::vector<int32_t> bit(cap + 1, 0);
+                auto upd = [&](size_t i, int d) { for (++i; i <= cap; i += i & (~i + 1)) bit[i] += d; };
+                auto sum = [&](size_t i) { int64_t r = 0; for (++i; i > 0; i -= i & (~i + 1)) r += bit[i]; return r; };
+                auto touch = [&](uint32_t v, bool read) {
+                    if (read) {
+                        if (last[v] < 0) ++miss;
+                        else { const int64_t distinct_since = sum((size_t)stamp) - sum((size_t)last[v]); if ((size_t)distinct_since >= K) ++miss; }
+                    }
+                    if (last[v] >= 0) upd((size_t)last[v], -1);
+                    ++stamp; last[v] = stamp; upd((size_t)stamp, +1);
+                };
+                for (auto& op : s.ops) {
+                    if (op.seed_only) continue;
+                    for (auto& in : op.ins) if (in.kind == Operand::VAR) touch(in.idx, true);
+                    for (size_t q = 0; q < op.outs.size(); ++q) {
+                        if (p2_bypass && op.opcode == ZK_OP_P2_ROUNDS && q + 12 < op.outs.size()) continue;
+                        touch(op.outs[q], false);
+                    }
+                }
+                return miss;
+            };
+            for (size_t K : {16, 32, 64, 128})
+                fprintf(stderr, "   LRU model, %zu values per wavefront: %llu operand fetches; with the Poseidon2 intermediates streamed past the cache %llu\n", K,
+                        (unsigned long long)lru_misses(K, false), (unsigned long long)lru_misses(K, true));
+        }
         fprintf(stderr, "   operand age (values produced since): <=8 %llu, <=32 %llu, <=128 %llu, <=512 %llu, <=2048 %llu, <=8192 %llu, more %llu\n",
                 (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2], (unsigned long long)hist[3], (unsigned long long)hist[4],
                 (unsigned long long)hist[5], (unsigned long long)hist[6]);
@@ -1319,13 +1451,16 @@ void CS::build_seed_program() {
     seed_prog_.clear(); seed_carries_.clear(); seed_slots_ = 0; seed_ops_ = 0;
     if (!limit_ || carries_store_.empty()) return;
     const Scope& s = loop_;
+    // the cone is built from the ops in RECORDING order: the locality schedule of the trace program (schedule_by_locality) stretches
+    // live ranges inside the cone, and the seed kernels hold every live value of an instance in LDS
+    const std::vector<OpRec>& sops = loop_ops_recorded_.empty() ? s.ops : loop_ops_recorded_;
     std::vector<uint32_t> out_vars;  // same order as carries_
     for (auto& l : links_raw_)
         if (l.kind == ZK_LINK_CARRY && s.input_word.count(l.loop_cell)) out_vars.push_back(l.other_cell);
-    std::vector<uint8_t> need(s.n_vars, 0), keep(s.ops.size(), 0);
+    std::vector<uint8_t> need(s.n_vars, 0), keep(sops.size(), 0);
     for (auto v : out_vars) need[v] = 1;
-    for (size_t oi = s.ops.size(); oi-- > 0;) {
-        const OpRec& op = s.ops[oi];
+    for (size_t oi = sops.size(); oi-- > 0;) {
+        const OpRec& op = sops[oi];
         bool any = false;
         for (auto o : op.outs) any |= need[o] != 0;
         if (!any) continue;
@@ -1339,9 +1474,9 @@ void CS::build_seed_program() {
             if (in.kind == Operand::VAR) need[in.idx] = 1;
     }
     seed_v2_ok_ = true;  // every op of the cone has a handler in the scalar-decoded seed kernel (kernels_engine2.hpp run_seed2)
-    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+    for (size_t oi = 0; oi < sops.size(); ++oi) {
         if (!keep[oi]) continue;
-        switch (s.ops[oi].opcode) {
+        switch (sops[oi].opcode) {
         case ZK_OP_CONST: case ZK_OP_INPUT: case ZK_OP_FMA: case ZK_OP_LC4: case ZK_OP_SELECT: case ZK_OP_ISZERO: case ZK_OP_UADD: case ZK_OP_USUB:
         case ZK_OP_DOT4: case ZK_OP_MATMUL12: case ZK_OP_SPLIT: case ZK_OP_LOOKUP: case ZK_OP_POSEIDON2: case ZK_OP_P2_ROUNDS: case ZK_OP_U32MULADD:
         case ZK_OP_DIVREM: case ZK_OP_U256_MULWIDE: case ZK_OP_U256_DIVREM: break;
@@ -1350,18 +1485,18 @@ void CS::build_seed_program() {
     }
     const int64_t INF = INT64_MAX;
     std::vector<int64_t> last_use(s.n_vars, -1);
-    for (size_t oi = 0; oi < s.ops.size(); ++oi)
+    for (size_t oi = 0; oi < sops.size(); ++oi)
         if (keep[oi])
-            for (auto& in : s.ops[oi].ins)
+            for (auto& in : sops[oi].ins)
                 if (in.kind == Operand::VAR) last_use[in.idx] = (int64_t)oi;
     for (auto v : out_vars) last_use[v] = INF;
     std::vector<uint32_t> slot_of(s.n_vars, UINT32_MAX), free_slots;
     uint32_t n_slots = 0;
     const uint32_t DISCARD_MARK = 0x3fffffffu;
     std::vector<uint32_t> prog;
-    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+    for (size_t oi = 0; oi < sops.size(); ++oi) {
         if (!keep[oi]) continue;
-        const OpRec& op = s.ops[oi];
+        const OpRec& op = sops[oi];
         const bool collapse = op.opcode == ZK_OP_P2_ROUNDS;
         prog.push_back((collapse ? (uint32_t)ZK_OP_POSEIDON2 : (uint32_t)op.opcode) | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
         for (auto& in : op.ins) {
@@ -1413,7 +1548,7 @@ void CS::build_seed_program() {
     // possible and ALL heavy ops of the tier share one final level (their consumers sit in the next tier).  With plain
     // as-soon-as-possible levels the k-th permutations of different sponges land on different levels, one strand busy each.
     std::vector<int64_t> producer(s.n_vars, -1);
-    std::vector<uint32_t> level(s.ops.size(), 0);
+    std::vector<uint32_t> level(sops.size(), 0);
     uint32_t n_levels = 0;
     {
         auto heavy = [&](const OpRec& op) {
@@ -1422,45 +1557,45 @@ void CS::build_seed_program() {
             return op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2 || op.opcode == ZK_OP_KECCAK_ABSORB || op.opcode == ZK_OP_SHA256_COMPRESS ||
                    op.opcode == ZK_OP_NN_MULMOD || op.opcode == ZK_OP_U256_DIVREM;
         };
-        std::vector<uint32_t> tier(s.ops.size(), 0), local(s.ops.size(), 0);
+        std::vector<uint32_t> tier(sops.size(), 0), local(sops.size(), 0);
         uint32_t n_tiers = 0;
-        for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+        for (size_t oi = 0; oi < sops.size(); ++oi) {
             if (!keep[oi]) continue;
-            const OpRec& op = s.ops[oi];
+            const OpRec& op = sops[oi];
             uint32_t t = 0;
             for (auto& in : op.ins)
                 if (in.kind == Operand::VAR && producer[in.idx] >= 0) {
                     const size_t p = (size_t)producer[in.idx];
-                    t = std::max(t, tier[p] + (heavy(s.ops[p]) ? 1u : 0u));
+                    t = std::max(t, tier[p] + (heavy(sops[p]) ? 1u : 0u));
                 }
             uint32_t l = 0;
             if (!heavy(op))
                 for (auto& in : op.ins)
                     if (in.kind == Operand::VAR && producer[in.idx] >= 0) {
                         const size_t p = (size_t)producer[in.idx];
-                        if (tier[p] == t && !heavy(s.ops[p])) l = std::max(l, local[p] + 1);
+                        if (tier[p] == t && !heavy(sops[p])) l = std::max(l, local[p] + 1);
                     }
             tier[oi] = t; local[oi] = l;
             n_tiers = std::max(n_tiers, t + 1);
             for (size_t i = op.opcode == ZK_OP_P2_ROUNDS ? op.outs.size() - 12 : 0; i < op.outs.size(); ++i) producer[op.outs[i]] = (int64_t)oi;
         }
         std::vector<uint32_t> light_levels(n_tiers, 0), has_heavy(n_tiers, 0), base(n_tiers + 1, 0);
-        for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+        for (size_t oi = 0; oi < sops.size(); ++oi) {
             if (!keep[oi]) continue;
-            if (heavy(s.ops[oi])) has_heavy[tier[oi]] = 1;
+            if (heavy(sops[oi])) has_heavy[tier[oi]] = 1;
             else light_levels[tier[oi]] = std::max(light_levels[tier[oi]], local[oi] + 1);
         }
         for (uint32_t t = 0; t < n_tiers; ++t) base[t + 1] = base[t] + light_levels[t] + has_heavy[t];
         n_levels = base[n_tiers];
-        for (size_t oi = 0; oi < s.ops.size(); ++oi)
-            if (keep[oi]) level[oi] = base[tier[oi]] + (heavy(s.ops[oi]) ? light_levels[tier[oi]] : local[oi]);
+        for (size_t oi = 0; oi < sops.size(); ++oi)
+            if (keep[oi]) level[oi] = base[tier[oi]] + (heavy(sops[oi]) ? light_levels[tier[oi]] : local[oi]);
     }
     std::vector<std::vector<uint32_t>> by_level(n_levels);
     std::vector<int64_t> last_level(s.n_vars, -1);
-    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+    for (size_t oi = 0; oi < sops.size(); ++oi) {
         if (!keep[oi]) continue;
         by_level[level[oi]].push_back((uint32_t)oi);
-        for (auto& in : s.ops[oi].ins)
+        for (auto& in : sops[oi].ins)
             if (in.kind == Operand::VAR) last_level[in.idx] = std::max<int64_t>(last_level[in.idx], level[oi]);
     }
     for (auto v : out_vars) last_level[v] = INF;
@@ -1517,7 +1652,7 @@ void CS::build_seed_program() {
             const uint32_t rw = rec_words(kind);
             out.push_back(kind); out.push_back((uint16_t)ops.size()); out.push_back(0); out.push_back(0);
             for (uint32_t oi : ops) {
-                const OpRec& op = s.ops[oi];
+                const OpRec& op = sops[oi];
                 std::vector<uint16_t> r;
                 auto outs = [&](size_t first = 0) { for (size_t i = first; i < op.outs.size(); ++i) r.push_back(dst_slot(op.outs[i], lv, kind == WK_CONST)); };
                 switch (kind) {
@@ -1569,7 +1704,7 @@ void CS::build_seed_program() {
         for (uint32_t lv = 0; lv < n_levels && ok; ++lv) {
             std::map<uint16_t, std::vector<uint32_t>> by_kind;
             for (uint32_t oi : by_level[lv]) {
-                const uint16_t k = kind_of(s.ops[oi]);
+                const uint16_t k = kind_of(sops[oi]);
                 if (!k) { fail_(8); break; }
                 by_kind[k].push_back(oi);
             }
@@ -1603,7 +1738,7 @@ void CS::build_seed_program() {
                     pro.size(), cyc.size(), ok ? "ok" : "MISSING", fail_reason, nws, seed_wprog_.empty() ? " - not usable, strand kernel stays" : "");
     }
     auto cost = [&](uint32_t oi) -> uint64_t {
-        const OpRec& op = s.ops[oi];
+        const OpRec& op = sops[oi];
         uint64_t c = 8 + op.ins.size() + 2 * op.outs.size();
         if (op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2) c = 4000;
         if (op.opcode == ZK_OP_NN_MULMOD) c += 2000;
@@ -1626,7 +1761,7 @@ void CS::build_seed_program() {
             uint32_t best = 0;
             for (uint32_t k = 1; k < NS; ++k) if (load[k] < load[best]) best = k;
             load[best] += cost(oi);
-            const OpRec& op = s.ops[oi];
+            const OpRec& op = sops[oi];
             const bool collapse = op.opcode == ZK_OP_P2_ROUNDS;
             auto& out = strand[best];
             out.push_back((collapse ? (uint32_t)ZK_OP_POSEIDON2 : (uint32_t)op.opcode) | ((uint32_t)op.a << 8) | ((uint32_t)op.b << 16));
@@ -1673,7 +1808,7 @@ void CS::build_seed_program() {
     {
         fprintf(stderr, "[zkgl] seed cone: %u ops, %u levels, %u slots (plain %u), estimated gain %.2f\n", seed_ops_, n_levels, ns, n_slots, seed_sgain_);
         std::map<uint32_t, uint32_t> hist;
-        for (size_t oi = 0; oi < s.ops.size(); ++oi) if (keep[oi]) hist[s.ops[oi].opcode]++;
+        for (size_t oi = 0; oi < sops.size(); ++oi) if (keep[oi]) hist[sops[oi].opcode]++;
         for (auto& kv : hist) fprintf(stderr, "   cone op %2u: %u\n", kv.first, kv.second);
         uint32_t widest = 0; for (auto& l : by_level) widest = std::max<uint32_t>(widest, (uint32_t)l.size());
         fprintf(stderr, "   widest level %u ops\n", widest);
@@ -1739,6 +1874,7 @@ void CS::finalize() {
                 if (in.kind == Operand::OUTER_VAR && !pre_defined[in.idx])
                     throw ZkError(ZK_ERR_UNRESOLVED, "loop imports an outer variable that is produced after the loop");
     }
+    loop_ops_recorded_ = loop_.ops;
     schedule_loop_ops();
     assign_store_slots(outer_);
     assign_store_slots(loop_);

@@ -240,7 +240,10 @@ class CS {
     Scope& scope_of(zk_var v) { return is_loop_var(v) ? loop_ : outer_; }
     uint32_t pool_const(Scope& s, uint64_t v);
     void place_scope(Scope& s);
+    std::vector<OpRec> loop_ops_recorded_;   // the loop body as recorded (build_seed_program)
     void schedule_loop_ops();
+    void schedule_by_locality(const std::vector<double>& a, const std::vector<double>& m, double a_tot, double m_tot,
+                              const std::vector<std::vector<uint32_t>>& succ, std::vector<uint32_t>& n_pred);
     void emit_scope(Scope& s);
     void emit_op(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const;
     void emit_dests(const Scope& s, const OpRec& op, std::vector<uint32_t>& out) const;

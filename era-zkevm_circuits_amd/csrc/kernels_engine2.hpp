@@ -631,8 +631,10 @@ __global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_witness_strands2(Scop
 
 // Separate symbols so that profiles separate the loop-scope launch (the dominant kernel: B * limit lanes) from the
 // outer-scope launches (B lanes, latency-bound).
+// Occupancy (measured at B=384 on one box, profiles/r2_summary.md): capped by LDS padding 2 / 3 / 4 wavefronts per SIMD = 58.8 / 50.0 /
+// 46.4 ms, the natural 6 (77 VGPRs) 41.4, 7 (72 VGPRs, 12 B of scratch) 40.1, 8 (64 VGPRs, 60 B of scratch) 41.7.
 #ifndef ZKGL_LOOP_WAVES2
-#define ZKGL_LOOP_WAVES2 4
+#define ZKGL_LOOP_WAVES2 7
 #endif
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_LOOP_WAVES2, 8))) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
     witness_entry2<false, false>(sc, word_begin, word_end, slot_begin);

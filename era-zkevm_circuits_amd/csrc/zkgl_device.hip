@@ -106,6 +106,13 @@ static zke::ScopeDev to_dev(const ScopeArgs& a) {
     return d;
 }
 
+// Occupancy experiments: unused dynamic LDS per workgroup caps the workgroups resident on a CU (fewer wavefronts = a larger share of
+// L2 per wavefront against less latency hiding).  Bytes from the environment, 0 by default.
+static unsigned lds_pad(const char* name) {
+    const char* v = std::getenv(name);
+    return v ? (unsigned)std::strtoul(v, nullptr, 10) : 0u;
+}
+
 int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, void* stream) {
     // sc.prog = the scope's v2 program (kernels_engine2.hpp), slot_begin = the store slot of the first output of word_begin
     if (sc.n_lanes == 0 || word_begin >= word_end) return 0;
@@ -113,7 +120,7 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
     hipStream_t s = (hipStream_t)stream;
     if (sc.n_cells >= (1ull << 23)) zke::k_witness_wide<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.is_loop && sc.uses_bigint) zke::k_witness_loop_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
-    else if (sc.is_loop) zke::k_witness_loop<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
+    else if (sc.is_loop) zke::k_witness_loop<<<grid, zke::TPB, lds_pad("ZKGL_LOOP_LDS_PAD"), s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.uses_bigint) zke::k_witness_outer_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else zke::k_witness_outer<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     return LAUNCH_CHECK("k_witness");
@@ -160,14 +167,14 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
         const uint32_t wanted = std::max<uint32_t>(2, (2048 + lane_tiles - 1) / lane_tiles);  // >= ~2048 workgroups
         p.chunks_per_block = std::max<uint32_t>(1, a.n_chunks / wanted);
         dim3 grid(lane_tiles, (a.n_chunks + p.chunks_per_block - 1) / p.chunks_per_block);
-        zke::k_check_prog<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(p);
+        zke::k_check_prog<<<grid, zke::TPB, lds_pad("ZKGL_CHECK_LDS_PAD"), (hipStream_t)stream>>>(p);
         if (a.macros && a.n_macros) {
             zke::CheckP2Dev m;
             m.cells = a.cells; m.n_cells = a.n_cells; m.n_lanes = a.n_lanes; m.macros = a.macros; m.n_macros = a.n_macros; m.fail = a.fail;
             const uint32_t want_y = std::max<uint32_t>(1, std::min<uint32_t>(a.n_macros, (2048 + lane_tiles - 1) / lane_tiles));
             m.per_block = (a.n_macros + want_y - 1) / want_y;
             dim3 g2(lane_tiles, (a.n_macros + m.per_block - 1) / m.per_block);
-            zke::k_check_p2<<<g2, zke::TPB, 0, (hipStream_t)stream>>>(m);
+            zke::k_check_p2<<<g2, zke::TPB, lds_pad("ZKGL_CHECK_P2_LDS_PAD"), (hipStream_t)stream>>>(m);
         }
         return LAUNCH_CHECK("k_check_prog");
     }
