@@ -78,8 +78,10 @@ void unpack_code_into_memory_entry_point(CS& cs, uint32_t limit) {
     }
 
     cs.side_begin();
-    std::vector<zk_var> obs_in = g.flatten(obs_req);
-    for (auto v : g.flatten(obs_mem)) obs_in.push_back(v);
+    // the commitment follows CodeDecommitterInputData's field order (input.rs:80-83): memory queue first, then the requests queue
+    // (the input STREAM keeps requests first: an engine-defined layout)
+    std::vector<zk_var> obs_in = g.flatten(obs_mem);
+    for (auto v : g.flatten(obs_req)) obs_in.push_back(v);
     std::vector<zk_var> fsm_in;
     for (auto& x : f_state) fsm_in.push_back(x.v);
     for (auto& x : f_hash.inner) fsm_in.push_back(x.v);

@@ -977,7 +977,8 @@ void CS::schedule_by_locality(const std::vector<double>& a, const std::vector<do
     int64_t stamp = 0;
     std::vector<uint32_t> ready_light, ready_heavy, order;
     std::vector<uint8_t> in_ready(n, 0);
-    auto make_ready = [&](uint32_t i) { (a[i] > 1000 ? ready_heavy : ready_light).push_back(i); };
+    const bool balance = !(std::getenv("ZKGL_SCHEDULE_BALANCE") && std::getenv("ZKGL_SCHEDULE_BALANCE")[0] == '0');
+    auto make_ready = [&](uint32_t i) { (balance && a[i] > 1000 ? ready_heavy : ready_light).push_back(i); };
     for (size_t i = 0; i < n; ++i) if (n_pred[i] == 0) make_ready((uint32_t)i);
     double a_done = 0, m_done = 0;
     auto imbalance_after = [&](uint32_t i) { return std::fabs((a_done + a[i]) / a_tot - (m_done + m[i]) / m_tot); };
@@ -2021,6 +2022,7 @@ void CS::set_batch(uint32_t n) {
         size_t bytes = std::max<size_t>((size_t)s.n_store * s.stride * 8, 8);
         hip_check(hipMalloc((void**)&s.d_store, bytes), "hipMalloc variable store");
         hip_check(hipMemset(s.d_store, 0, bytes), "hipMemset variable store");
+        if (std::getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] %s store at %p (%zu bytes)\n", s.is_loop ? "loop" : "outer", (void*)s.d_store, bytes);
     };
     uint64_t loop_lanes = (uint64_t)n * limit_;
     if (loop_lanes >= 0xffffffffull) throw ZkError(ZK_ERR_CAPACITY, "batch*limit exceeds 32-bit lane index");

@@ -365,4 +365,133 @@ int zk_pack_keccak_witness(const zk_keccak_round_function_witness* w, uint32_t l
     return ZK_OK;
 }
 
+
+int zk_pack_demux_witness(const zk_demux_log_queue_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_demux_witness: bad argument");
+    if (w->n_initial > limit) return bad(ZK_ERR_INVALID, "zk_pack_demux_witness: more queue elements than cycles");
+    if (w->n_initial && !w->initial_queue_witness) return bad(ZK_ERR_INVALID, "zk_pack_demux_witness: null queue witness");
+    Out o{outer_words + instance, batch};
+    o.w(w->start_flag ? 1 : 0);
+    o.qstate(w->initial_log_queue_state);
+    const zk_demux_fsm_witness& f = w->hidden_fsm_input;   // LogDemuxerFSMInputOutput order (input.rs:26-34)
+    o.qstate(f.initial_log_queue_state);
+    for (const auto& q : f.output_queue_states) o.qstate(q);
+    if (o.k != ZK_DEMUX_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: demux outer layout");
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        for (int i = 0; i < 35; ++i) l.w(0);
+        l.log_query(c < w->n_initial ? &w->initial_queue_witness[c] : nullptr);
+        if (l.k != ZK_DEMUX_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: demux loop layout");
+    }
+    return ZK_OK;
+}
+
+namespace {
+void put_decommit(Out& o, const zk_decommit_query_witness* q) {   // DecommitQuery field order, 11 words; nullptr: the zero item
+    if (!q) { for (int i = 0; i < 11; ++i) o.w(0); return; }
+    o.arr(q->code_hash); o.w(q->page); o.w(q->is_first ? 1 : 0); o.w(q->timestamp);
+}
+void put_full(Out& o, const zk_full_queue_state_witness& q) { o.arr(q.head); o.arr(q.tail); o.w(q.length); }
+}  // namespace
+
+int zk_pack_sort_decommits_witness(const zk_sort_decommits_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_sort_decommits_witness: bad argument");
+    if (w->n_initial != w->n_sorted) return bad(ZK_ERR_INVALID, "zk_pack_sort_decommits_witness: the two queue witnesses differ in length");
+    if (w->n_initial > limit) return bad(ZK_ERR_INVALID, "zk_pack_sort_decommits_witness: more queue elements than cycles");
+    if (w->n_initial && (!w->initial_queue_witness || !w->sorted_queue_witness)) return bad(ZK_ERR_INVALID, "zk_pack_sort_decommits_witness: null queue witness");
+    Out o{outer_words + instance, batch};
+    o.w(w->start_flag ? 1 : 0);
+    put_full(o, w->initial_queue_state); put_full(o, w->sorted_queue_initial_state);
+    const zk_sort_decommits_fsm_witness& f = w->hidden_fsm_input;   // CodeDecommittmentsDeduplicatorFSMInputOutput order (input.rs:26-37)
+    put_full(o, f.initial_queue_state); put_full(o, f.sorted_queue_state); put_full(o, f.final_queue_state);
+    o.arr(f.lhs_accumulator); o.arr(f.rhs_accumulator); o.arr(f.previous_packed_key); o.w(f.first_encountered_timestamp);
+    put_decommit(o, &f.previous_record);
+    if (o.k != ZK_SORT_DECOMMITS_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: sort_decommits outer layout");
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        for (int i = 0; i < 65; ++i) l.w(0);
+        put_decommit(l, c < w->n_initial ? &w->initial_queue_witness[c] : nullptr);
+        put_decommit(l, c < w->n_sorted ? &w->sorted_queue_witness[c] : nullptr);
+        if (l.k != ZK_SORT_DECOMMITS_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: sort_decommits loop layout");
+    }
+    return ZK_OK;
+}
+
+int zk_pack_code_unpacker_witness(const zk_code_unpacker_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_code_unpacker_witness: bad argument");
+    if ((w->n_requests && !w->sorted_requests_queue_witness) || (w->n_code_words && !w->code_words)) return bad(ZK_ERR_INVALID, "zk_pack_code_unpacker_witness: null witness array");
+    Out o{outer_words + instance, batch};
+    o.w(w->start_flag ? 1 : 0);
+    put_full(o, w->sorted_requests_queue_initial_state); put_full(o, w->memory_queue_initial_state);   // the circuit's stream order
+    const zk_code_unpacker_fsm_witness& f = w->hidden_fsm_input;   // CodeDecommittmentFSM (input.rs:23-34), then the two queue states (:61-65)
+    o.arr(f.sha256_inner_state); o.arr(f.hash_to_compare_against);
+    o.w(f.current_index); o.w(f.current_page); o.w(f.timestamp); o.w(f.num_rounds_left); o.w(f.length_in_bits);
+    o.w(f.state_get_from_queue ? 1 : 0); o.w(f.state_decommit ? 1 : 0); o.w(f.finished ? 1 : 0);
+    put_full(o, f.decommittment_requests_queue_state); put_full(o, f.memory_queue_state);
+    if (o.k != ZK_CODE_UNPACKER_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: code_unpacker outer layout");
+    // the FSM's schedule (mod.rs:167-255 pop and parameters, :257-300 the two words of a round, :402-430 next flags)
+    bool get, decommit, finished;
+    uint64_t rounds_left, req_len;
+    if (w->start_flag) { get = true; decommit = false; finished = false; rounds_left = 0; req_len = w->sorted_requests_queue_initial_state.length; }
+    else { get = f.state_get_from_queue; decommit = f.state_decommit; finished = f.finished; rounds_left = f.num_rounds_left; req_len = f.decommittment_requests_queue_state.length; }
+    uint32_t next_req = 0, next_word = 0;
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        for (int i = 0; i < 74; ++i) l.w(0);
+        const zk_decommit_query_witness* req = nullptr;
+        if (get) {
+            if (req_len != 0) {
+                if (next_req >= w->n_requests) return bad(ZK_ERR_INVALID, "zk_pack_code_unpacker_witness: the request queue witness is shorter than its length");
+                req = &w->sorted_requests_queue_witness[next_req++];
+                --req_len;
+            }
+            const uint32_t top = req ? req->code_hash[7] : 0;   // versioned hash: 0x01 0x00 | length in words (u16)
+            rounds_left = ((uint64_t)(top & 0xffff) + 1) / 2;
+        }
+        put_decommit(l, req);
+        decommit = decommit || get;
+        get = false;
+        if (decommit) rounds_left = (rounds_left - 1) & 0xffff;   // UInt16 subtraction in the circuit
+        const bool last_round = rounds_left == 0, finalize = last_round && decommit, second = !last_round && decommit;
+        for (int r = 0; r < 2; ++r) {
+            const bool take = r == 0 ? decommit : second;
+            if (take && next_word < w->n_code_words) { for (int i = 0; i < 8; ++i) l.w(w->code_words[next_word][i]); ++next_word; }
+            else for (int i = 0; i < 8; ++i) l.w(0);
+        }
+        const bool is_empty = req_len == 0;
+        finished = finished || (is_empty && finalize);
+        get = !is_empty && finalize;
+        decommit = second;
+        if (l.k != ZK_CODE_UNPACKER_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: code_unpacker loop layout");
+    }
+    (void)finished;
+    return ZK_OK;
+}
+
+int zk_pack_linear_hasher_witness(const zk_linear_hasher_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
+    if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_linear_hasher_witness: bad argument");
+    if (limit % ZK_LINEAR_HASHER_PERIOD) return bad(ZK_ERR_INVALID, "zk_pack_linear_hasher_witness: limit must be a multiple of 17");
+    if (w->n_queue > limit) return bad(ZK_ERR_INVALID, "zk_pack_linear_hasher_witness: more queue elements than cycles");
+    if (w->n_queue && !w->queue_witness) return bad(ZK_ERR_INVALID, "zk_pack_linear_hasher_witness: null queue witness");
+    Out o{outer_words + instance, batch};
+    o.w(w->start_flag ? 1 : 0);
+    o.qstate(w->queue_state);
+    if (o.k != ZK_LINEAR_HASHER_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: linear_hasher outer layout");
+    const uint32_t iters = limit / ZK_LINEAR_HASHER_PERIOD;
+    const size_t lanes = (size_t)batch * iters;
+    for (uint32_t it = 0; it < iters; ++it) {
+        Out l{loop_words + (size_t)instance * iters + it, lanes};
+        for (int i = 0; i < 206; ++i) l.w(0);
+        for (uint32_t c = 0; c < ZK_LINEAR_HASHER_PERIOD; ++c) {
+            const uint32_t idx = it * ZK_LINEAR_HASHER_PERIOD + c;
+            l.log_query(idx < w->n_queue ? &w->queue_witness[idx] : nullptr);
+        }
+        if (l.k != ZK_LINEAR_HASHER_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: linear_hasher loop layout");
+    }
+    return ZK_OK;
+}
+
 }  // extern "C"

@@ -294,6 +294,75 @@ def pack_keccak_witness(w, limit, instance, outer, loop):
     _pack(lib().zk_pack_keccak_witness, w, limit, instance, outer, loop, 474, 507)
 
 
+class DemuxFsmWitness(C.Structure):
+    _fields_ = [("initial_log_queue_state", QueueStateWitness), ("output_queue_states", QueueStateWitness * 6)]
+
+
+class DemuxLogQueueWitness(C.Structure):
+    _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("initial_log_queue_state", QueueStateWitness),
+                ("hidden_fsm_input", DemuxFsmWitness), ("hidden_fsm_output", DemuxFsmWitness),
+                ("initial_queue_witness", C.POINTER(LogQueryWitness)), ("n_initial", C.c_uint32)]
+
+
+def pack_demux_witness(w, limit, instance, outer, loop):
+    """zk_pack_demux_witness: outer [73, B], loop [71, B * limit]"""
+    _pack(lib().zk_pack_demux_witness, w, limit, instance, outer, loop, 73, 71)
+
+
+class DecommitQueryWitness(C.Structure):
+    _fields_ = [("code_hash", C.c_uint32 * 8), ("page", C.c_uint32), ("is_first", C.c_uint8), ("timestamp", C.c_uint32)]
+
+
+class SortDecommitsFsmWitness(C.Structure):
+    _fields_ = [("initial_queue_state", FullQueueStateWitness), ("sorted_queue_state", FullQueueStateWitness), ("final_queue_state", FullQueueStateWitness),
+                ("lhs_accumulator", C.c_uint64 * 2), ("rhs_accumulator", C.c_uint64 * 2), ("previous_packed_key", C.c_uint32 * 9),
+                ("first_encountered_timestamp", C.c_uint32), ("previous_record", DecommitQueryWitness)]
+
+
+class SortDecommitsWitness(C.Structure):
+    _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("initial_queue_state", FullQueueStateWitness),
+                ("sorted_queue_initial_state", FullQueueStateWitness), ("hidden_fsm_input", SortDecommitsFsmWitness),
+                ("hidden_fsm_output", SortDecommitsFsmWitness), ("initial_queue_witness", C.POINTER(DecommitQueryWitness)), ("n_initial", C.c_uint32),
+                ("sorted_queue_witness", C.POINTER(DecommitQueryWitness)), ("n_sorted", C.c_uint32)]
+
+
+def pack_sort_decommits_witness(w, limit, instance, outer, loop):
+    """zk_pack_sort_decommits_witness: outer [151, B], loop [87, B * limit]"""
+    _pack(lib().zk_pack_sort_decommits_witness, w, limit, instance, outer, loop, 151, 87)
+
+
+class CodeUnpackerFsmWitness(C.Structure):
+    _fields_ = [("sha256_inner_state", C.c_uint32 * 8), ("hash_to_compare_against", C.c_uint32 * 8), ("current_index", C.c_uint32),
+                ("current_page", C.c_uint32), ("timestamp", C.c_uint32), ("num_rounds_left", C.c_uint16), ("length_in_bits", C.c_uint32),
+                ("state_get_from_queue", C.c_uint8), ("state_decommit", C.c_uint8), ("finished", C.c_uint8),
+                ("decommittment_requests_queue_state", FullQueueStateWitness), ("memory_queue_state", FullQueueStateWitness)]
+
+
+class CodeUnpackerWitness(C.Structure):
+    _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("memory_queue_initial_state", FullQueueStateWitness),
+                ("sorted_requests_queue_initial_state", FullQueueStateWitness), ("hidden_fsm_input", CodeUnpackerFsmWitness),
+                ("hidden_fsm_output", CodeUnpackerFsmWitness), ("sorted_requests_queue_witness", C.POINTER(DecommitQueryWitness)),
+                ("n_requests", C.c_uint32), ("code_words", C.POINTER(C.c_uint32 * 8)), ("n_code_words", C.c_uint32)]
+
+
+def pack_code_unpacker_witness(w, limit, instance, outer, loop):
+    """zk_pack_code_unpacker_witness: outer [125, B], loop [101, B * limit]"""
+    _pack(lib().zk_pack_code_unpacker_witness, w, limit, instance, outer, loop, 125, 101)
+
+
+class LinearHasherWitness(C.Structure):
+    _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("queue_state", QueueStateWitness),
+                ("queue_witness", C.POINTER(LogQueryWitness)), ("n_queue", C.c_uint32)]
+
+
+def pack_linear_hasher_witness(w, limit, instance, outer, loop):
+    """zk_pack_linear_hasher_witness: outer [10, B], loop [818, B * limit / 17] (one loop iteration = a period of 17 pops)"""
+    batch = outer.shape[1]
+    assert limit % 17 == 0 and outer.shape == (10, batch) and loop.shape == (818, batch * (limit // 17))
+    assert outer.dtype == np.uint64 and loop.dtype == np.uint64 and outer.flags.c_contiguous and loop.flags.c_contiguous
+    _check(lib().zk_pack_linear_hasher_witness(C.byref(w), limit, instance, batch, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
+
+
 class Comm:
     """RCCL communicator behind the C ABI (zk_comm_*): one process per GPU; rank 0's `unique_id()` bytes reach the other ranks through
     the host's launcher (bench.py: a torch.distributed broadcast)."""

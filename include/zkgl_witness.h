@@ -210,6 +210,98 @@ typedef struct zk_keccak_round_function_witness {
 int zk_pack_keccak_witness(const zk_keccak_round_function_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                            uint64_t *outer_words, uint64_t *loop_words);
 
+/* ---- LogDemuxerCircuitInstanceWitness, /root/reference/src/demux_log_queue/input.rs:118-121 (FSM :26-34, input data :57-59; output
+ * queues in the FSM's field order: storage, events, l1 messages, keccak256, sha256, ecrecover) */
+typedef struct zk_demux_fsm_witness {
+    zk_queue_state_witness initial_log_queue_state;
+    zk_queue_state_witness output_queue_states[6];
+} zk_demux_fsm_witness;
+typedef struct zk_demux_log_queue_witness {
+    uint8_t start_flag, completion_flag;
+    zk_queue_state_witness initial_log_queue_state;
+    zk_demux_fsm_witness hidden_fsm_input, hidden_fsm_output;
+    const zk_log_query_witness *initial_queue_witness; uint32_t n_initial;   /* in pop order */
+} zk_demux_log_queue_witness;
+#define ZK_DEMUX_OUTER_WORDS 73
+#define ZK_DEMUX_LOOP_WORDS 71
+/* demultiplex_storage_logs_enty_point (/root/reference/src/demux_log_queue/mod.rs:38-396): outer_words[73][batch],
+ * loop_words[71][batch * limit]; 35 carried words zeroed (device seeding), one popped LogQuery (36 words) per cycle */
+int zk_pack_demux_witness(const zk_demux_log_queue_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                          uint64_t *outer_words, uint64_t *loop_words);
+
+/* ---- DecommitQuery witness, /root/reference/src/base_structures/decommit_query/mod.rs:22-29 */
+typedef struct zk_decommit_query_witness {
+    uint32_t code_hash[8];   /* U256, little-endian u32 limbs */
+    uint32_t page;
+    uint8_t is_first;
+    uint32_t timestamp;
+} zk_decommit_query_witness;
+/* CodeDecommittmentsDeduplicatorInstanceWitness, /root/reference/src/sort_decommittment_requests/input.rs:110-124 (FSM :26-37, input
+ * data :62-65) */
+typedef struct zk_sort_decommits_fsm_witness {
+    zk_full_queue_state_witness initial_queue_state, sorted_queue_state, final_queue_state;
+    uint64_t lhs_accumulator[2], rhs_accumulator[2];
+    uint32_t previous_packed_key[9];
+    uint32_t first_encountered_timestamp;
+    zk_decommit_query_witness previous_record;
+} zk_sort_decommits_fsm_witness;
+typedef struct zk_sort_decommits_witness {
+    uint8_t start_flag, completion_flag;
+    zk_full_queue_state_witness initial_queue_state, sorted_queue_initial_state;
+    zk_sort_decommits_fsm_witness hidden_fsm_input, hidden_fsm_output;
+    const zk_decommit_query_witness *initial_queue_witness; uint32_t n_initial;
+    const zk_decommit_query_witness *sorted_queue_witness; uint32_t n_sorted;
+} zk_sort_decommits_witness;
+#define ZK_SORT_DECOMMITS_OUTER_WORDS 151
+#define ZK_SORT_DECOMMITS_LOOP_WORDS 87
+/* sort_and_deduplicate_code_decommittments_entry_point (/root/reference/src/sort_decommittment_requests/mod.rs:40-372):
+ * outer_words[151][batch], loop_words[87][batch * limit]; 65 carried words zeroed, one DecommitQuery (11 words) of each queue per cycle */
+int zk_pack_sort_decommits_witness(const zk_sort_decommits_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                                   uint64_t *outer_words, uint64_t *loop_words);
+
+/* CodeDecommitterCircuitInstanceWitness, /root/reference/src/code_unpacker_sha256/input.rs:134-140 (internal FSM :23-34, FSM :61-65,
+ * input data :80-83) */
+typedef struct zk_code_unpacker_fsm_witness {
+    uint32_t sha256_inner_state[8];
+    uint32_t hash_to_compare_against[8];
+    uint32_t current_index, current_page, timestamp;
+    uint16_t num_rounds_left;
+    uint32_t length_in_bits;
+    uint8_t state_get_from_queue, state_decommit, finished;
+    zk_full_queue_state_witness decommittment_requests_queue_state, memory_queue_state;
+} zk_code_unpacker_fsm_witness;
+typedef struct zk_code_unpacker_witness {
+    uint8_t start_flag, completion_flag;
+    zk_full_queue_state_witness memory_queue_initial_state, sorted_requests_queue_initial_state;
+    zk_code_unpacker_fsm_witness hidden_fsm_input, hidden_fsm_output;
+    const zk_decommit_query_witness *sorted_requests_queue_witness; uint32_t n_requests;   /* in pop order */
+    const uint32_t (*code_words)[8]; uint32_t n_code_words;   /* Vec<Vec<U256>> flattened in consumption order, 8 LE u32 limbs each */
+} zk_code_unpacker_witness;
+#define ZK_CODE_UNPACKER_OUTER_WORDS 125
+#define ZK_CODE_UNPACKER_LOOP_WORDS 101
+/* unpack_code_into_memory_entry_point (/root/reference/src/code_unpacker_sha256/mod.rs:33-442).  Requests and code words are placed at
+ * the cycles that consume them by walking the FSM's schedule (state_get_from_queue / state_decommit / rounds left: mod.rs:167-255,
+ * :402-430; no hashing): a request at every cycle that pops, one code word at every decommit cycle and a second one unless it is the
+ * last round.  Outer stream order: start_flag, requests queue state, memory queue state (the circuit's allocation order), FSM;
+ * 74 carried words zeroed.  ZK_ERR_INVALID when the witness runs out of requests before the schedule does. */
+int zk_pack_code_unpacker_witness(const zk_code_unpacker_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                                  uint64_t *outer_words, uint64_t *loop_words);
+
+/* LinearHasherCircuitInstanceWitness, /root/reference/src/linear_hasher/input.rs:71-80 (input data :27-29; no FSM state) */
+typedef struct zk_linear_hasher_witness {
+    uint8_t start_flag, completion_flag;
+    zk_queue_state_witness queue_state;
+    const zk_log_query_witness *queue_witness; uint32_t n_queue;
+} zk_linear_hasher_witness;
+#define ZK_LINEAR_HASHER_OUTER_WORDS 10
+#define ZK_LINEAR_HASHER_LOOP_WORDS 818
+#define ZK_LINEAR_HASHER_PERIOD 17
+/* linear_hasher_entry_point (/root/reference/src/linear_hasher/mod.rs:35-212): one loop iteration = one period of 17 pops (the
+ * reference's statically unrolled byte buffer repeats every 17 cycles = 11 blocks); `limit` (cycles) must be a multiple of 17.
+ * outer_words[10][batch], loop_words[818][batch * limit / 17]: 206 carried words zeroed, then 17 LogQuery items (36 words each) */
+int zk_pack_linear_hasher_witness(const zk_linear_hasher_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                                  uint64_t *outer_words, uint64_t *loop_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,7 +122,8 @@ def instance(requests, limit, start_flag=True, fsm_in=None, obs=None, pending=No
                    get=get, decommit=decommit, finished=finished, req=req_head + req_tail + [req_len], mem=mem_head + mem_tail + [mem_len])
     done = finished
     z4 = [0] * 4
-    compact = [int(start_flag), done] + zko.commit_encoding(list(obs_req) + list(obs_mem)) + \
+    # observable input in CodeDecommitterInputData's field order (input.rs:80-83): memory queue state, then the requests queue state
+    compact = [int(start_flag), done] + zko.commit_encoding(list(obs_mem) + list(obs_req)) + \
         (zko.commit_encoding(fsm_out["mem"]) if done else z4) + \
         (z4 if start_flag else zko.commit_encoding(flatten_fsm(fsm_in))) + \
         (z4 if done else zko.commit_encoding(flatten_fsm(fsm_out)))

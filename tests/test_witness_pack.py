@@ -2,12 +2,15 @@
 from the reference's witness struct (and from its bincode bytes) must equal what the oracle's packer builds from the same witness;
 on the GPU the C-ABI-built streams are seeded, resolved and satisfied, with the oracle's commitment.  The oracle packer
 (oracle/ram_native.py) is only the comparison here."""
+import ctypes as C
 import struct
 
 import numpy as np
 import pytest
 
 import zkgl
+
+C_u32x8 = C.c_uint32 * 8
 from oracle import ram_native as rn
 
 LIMIT = 24
@@ -416,3 +419,142 @@ def test_corrupted_poseidon2_intermediate_is_caught_by_the_macro_packet(zk):
         assert not ok and f.scope == 1 and f.instance == 1 and f.iteration == 7, (slot, ok, f)
         kinds.add(f.kind)
     assert zkgl.GATE["MATMUL12_EXT"] in kinds or zkgl.GATE["MATMUL12_INT"] in kinds or zkgl.GATE["FMA"] in kinds, kinds
+
+
+# ---------------------------------------------------------------- demux / sort_decommits / code_unpacker / linear_hasher packers
+def _streams(insts):
+    outer = np.array([i["outer"] for i in insts], dtype=np.uint64).T.copy()
+    loop = np.array([r for i in insts for r in i["rows"]], dtype=np.uint64).T.copy()
+    return outer, loop
+
+
+def _dq(words):
+    q = zkgl.DecommitQueryWitness()
+    q.code_hash[:] = [int(x) for x in words[0:8]]; q.page, q.is_first, q.timestamp = int(words[8]), int(words[9]), int(words[10])
+    return q
+
+
+def test_demux_packer_equals_the_oracle_streams():
+    """a start instance and its continuation (the reference's witness of the second instance holds the rest of the queue)"""
+    from oracle import demux_native as dn
+    from oracle.storage_native import log_query
+    rng = np.random.default_rng(61)
+    qs = []
+    for t in range(11):
+        kind = int(rng.integers(0, 6))
+        address = {3: 0x8010, 4: 0x02, 5: 0x01}.get(kind, int(rng.integers(1 << 20, 1 << 40)))
+        qs.append(log_query(address=address, key=int.from_bytes(rng.bytes(32), "little"), read_value=int.from_bytes(rng.bytes(32), "little"),
+                            written_value=int.from_bytes(rng.bytes(32), "little"), rw_flag=int(rng.integers(0, 2)), aux_byte=[0, 1, 2, 3, 3, 3][kind],
+                            rollback=int(rng.integers(0, 2)), is_service=int(rng.integers(0, 2)), shard_id=0,
+                            tx_number_in_block=int(rng.integers(0, 1000)), timestamp=100 + t))
+    limit = 7
+    a = dn.instance(qs, limit)
+    b = dn.instance(a["rest"], limit, start_flag=False, fsm_in=a["fsm_out"], obs_initial=a["obs_initial"])
+    assert a["satisfiable"] and b["satisfiable"] and b["completed"]
+    insts, queues = [a, b], [qs, a["rest"]]
+    outer = np.zeros((73, 2), dtype=np.uint64); loop = np.full((71, 2 * limit), 9, dtype=np.uint64)
+    for i, (inst, queue) in enumerate(zip(insts, queues)):
+        o = inst["outer"]
+        w = zkgl.DemuxLogQueueWitness()
+        w.start_flag, w.completion_flag = int(o[0]), int(inst["completed"])
+        w.initial_log_queue_state = _q4(o[1:10])
+        w.hidden_fsm_input.initial_log_queue_state = _q4(o[10:19])
+        for k in range(6):
+            w.hidden_fsm_input.output_queue_states[k] = _q4(o[19 + 9 * k:28 + 9 * k])
+        popped = queue[:limit]
+        arr = (zkgl.LogQueryWitness * max(len(popped), 1))(*[_lq(q) for q in popped])
+        w.initial_queue_witness, w.n_initial = arr, len(popped)
+        zkgl.pack_demux_witness(w, limit, i, outer, loop)
+    eo, el = _streams(insts)
+    el = el.copy(); el[0:35] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+def test_sort_decommits_packer_equals_the_oracle_streams():
+    from oracle import decommit_native as dn
+    u, s = dn.random_decommits(np.random.default_rng(62), 5)
+    limit = len(u) + 3
+    inst = dn.instance(u, s, limit)
+    assert inst["satisfiable"] and inst["completed"]
+    o = inst["outer"]
+    w = zkgl.SortDecommitsWitness()
+    w.start_flag, w.completion_flag = int(o[0]), 1
+    w.initial_queue_state, w.sorted_queue_initial_state = _q12(o[1:26]), _q12(o[26:51])
+    f, x = w.hidden_fsm_input, o[51:151]
+    f.initial_queue_state, f.sorted_queue_state, f.final_queue_state = _q12(x[0:25]), _q12(x[25:50]), _q12(x[50:75])
+    f.lhs_accumulator[:] = x[75:77]; f.rhs_accumulator[:] = x[77:79]; f.previous_packed_key[:] = x[79:88]
+    f.first_encountered_timestamp = int(x[88]); f.previous_record = _dq(x[89:100])
+    ua = (zkgl.DecommitQueryWitness * len(u))(*[_dq(q) for q in u])
+    sa = (zkgl.DecommitQueryWitness * len(s))(*[_dq(q) for q in s])
+    w.initial_queue_witness, w.n_initial, w.sorted_queue_witness, w.n_sorted = ua, len(u), sa, len(s)
+    outer = np.zeros((151, 1), dtype=np.uint64); loop = np.full((87, limit), 9, dtype=np.uint64)
+    zkgl.pack_sort_decommits_witness(w, limit, 0, outer, loop)
+    eo, el = _streams([inst])
+    el = el.copy(); el[0:65] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+    w.n_sorted = len(s) - 1
+    with pytest.raises(zkgl.ZkError):
+        zkgl.pack_sort_decommits_witness(w, limit, 0, outer, loop)
+
+
+def test_code_unpacker_packer_walks_the_fsm_schedule():
+    """requests and code words land on the cycles that consume them: three bytecodes (1, 5 and 3 words: 1 + 3 + 2 rounds) over a start
+    instance and a continuation that begins in the middle of the second bytecode"""
+    from oracle import code_unpacker_native as cn
+    from oracle.decommit_native import dq
+    rng = np.random.default_rng(63)
+    reqs = []
+    for k, n in enumerate((1, 5, 3)):
+        words = [int.from_bytes(rng.bytes(32), "big") for _ in range(n)]
+        reqs.append((dq(cn.versioned_hash(words), 2000 + 8 * k, 1, 100 + k), words))
+    limit = 3
+    a = cn.instance(reqs, limit)
+    b = cn.instance(a["rest"][0], limit, start_flag=False, fsm_in=a["fsm_out"], obs=a["obs"], pending=a["rest"][1])
+    assert a["satisfiable"] and b["satisfiable"] and b["fsm_out"]["finished"] == 1
+    insts = [a, b]
+    remaining = [(reqs, []), (a["rest"][0], a["rest"][1])]
+    outer = np.zeros((125, 2), dtype=np.uint64); loop = np.full((101, 2 * limit), 9, dtype=np.uint64)
+    for i, (inst, (rq, pending)) in enumerate(zip(insts, remaining)):
+        o = inst["outer"]
+        w = zkgl.CodeUnpackerWitness()
+        w.start_flag = int(o[0])
+        w.sorted_requests_queue_initial_state, w.memory_queue_initial_state = _q12(o[1:26]), _q12(o[26:51])
+        f, x = w.hidden_fsm_input, o[51:125]
+        f.sha256_inner_state[:] = x[0:8]; f.hash_to_compare_against[:] = x[8:16]
+        f.current_index, f.current_page, f.timestamp, f.num_rounds_left, f.length_in_bits = [int(v) for v in x[16:21]]
+        f.state_get_from_queue, f.state_decommit, f.finished = [int(v) for v in x[21:24]]
+        f.decommittment_requests_queue_state, f.memory_queue_state = _q12(x[24:49]), _q12(x[49:74])
+        qa = (zkgl.DecommitQueryWitness * max(len(rq), 1))(*[_dq(q) for q, _ in rq])
+        words = list(pending) + [wd for _, ws in rq for wd in ws]   # the words of the code in flight, then the queued bytecodes
+        wa = ((C_u32x8) * max(len(words), 1))()
+        for dst, v in zip(wa, words):
+            dst[:] = [(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
+        w.sorted_requests_queue_witness, w.n_requests, w.code_words, w.n_code_words = qa, len(rq), wa, len(words)
+        zkgl.pack_code_unpacker_witness(w, limit, i, outer, loop)
+    eo, el = _streams(insts)
+    el = el.copy(); el[0:74] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+def test_linear_hasher_packer_equals_the_oracle_streams():
+    from oracle import linear_hasher_native as hn
+    from oracle.storage_native import log_query
+    rng = np.random.default_rng(64)
+    qs = [log_query(address=int(rng.integers(1, 1 << 60)), key=int.from_bytes(rng.bytes(32), "little"),
+                    written_value=int.from_bytes(rng.bytes(32), "little"), rw_flag=1, aux_byte=2, is_service=int(rng.integers(0, 2)),
+                    shard_id=int(rng.integers(0, 2)), tx_number_in_block=int(rng.integers(0, 65536)), timestamp=5 + t) for t in range(20)]
+    limit = 34
+    inst = hn.instance(qs, limit)
+    assert inst["satisfiable"]
+    w = zkgl.LinearHasherWitness()
+    w.start_flag, w.completion_flag = 1, 1
+    w.queue_state = _q4(inst["outer"][1:10])
+    arr = (zkgl.LogQueryWitness * len(qs))(*[_lq(q) for q in qs])
+    w.queue_witness, w.n_queue = arr, len(qs)
+    outer = np.zeros((10, 1), dtype=np.uint64); loop = np.full((818, 2), 9, dtype=np.uint64)
+    zkgl.pack_linear_hasher_witness(w, limit, 0, outer, loop)
+    eo, el = _streams([inst])
+    el = el.copy(); el[0:206] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+    with pytest.raises(zkgl.ZkError):
+        zkgl._check(zkgl.lib().zk_pack_linear_hasher_witness(C.byref(w), 33, 0, 1, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
