@@ -1428,6 +1428,42 @@ void CS::emit_scope(Scope& s) {
                 }
                 return miss;
             };
+            {   // how many of the modelled fetches (16 values) are SELECT flags, and how concentrated they are
+                const size_t K = 16;
+                std::vector<int64_t> last(s.n_vars, -1);
+                int64_t stamp = 0;
+                const size_t cap = 4 * (size_t)s.n_vars + 8 * s.ops.size() + 64;
+                std::vector<int32_t> bit(cap + 1, 0);
+                auto upd = [&](size_t i, int d) { for (++i; i <= cap; i += i & (~i + 1)) bit[i] += d; };
+                auto sum = [&](size_t i) { int64_t r = 0; for (++i; i > 0; i -= i & (~i + 1)) r += bit[i]; return r; };
+                std::vector<uint32_t> flag_miss(s.n_vars, 0), flag_uses(s.n_vars, 0);
+                uint64_t miss_all = 0, miss_flags = 0, sel = 0;
+                auto touch = [&](uint32_t v, bool read) -> bool {
+                    bool miss = false;
+                    if (read) miss = last[v] < 0 || (size_t)(sum((size_t)stamp) - sum((size_t)last[v])) >= K;
+                    if (last[v] >= 0) upd((size_t)last[v], -1);
+                    ++stamp; last[v] = stamp; upd((size_t)stamp, +1);
+                    return miss;
+                };
+                for (auto& op : s.ops) {
+                    if (op.seed_only) continue;
+                    for (size_t q = 0; q < op.ins.size(); ++q) {
+                        if (op.ins[q].kind != Operand::VAR) continue;
+                        const bool m = touch(op.ins[q].idx, true);
+                        miss_all += m;
+                        if (op.opcode == ZK_OP_SELECT && q == 0) { ++sel; ++flag_uses[op.ins[q].idx]; if (m) { ++miss_flags; ++flag_miss[op.ins[q].idx]; } }
+                    }
+                    for (auto ov : op.outs) touch(ov, false);
+                }
+                std::vector<std::pair<uint32_t, uint32_t>> fl;
+                for (uint32_t v = 0; v < s.n_vars; ++v) if (flag_uses[v]) fl.push_back({flag_miss[v], flag_uses[v]});
+                std::sort(fl.rbegin(), fl.rend());
+                fprintf(stderr, "   SELECT flags: %llu selects, %zu distinct flags, %llu of %llu modelled fetches are flags;", (unsigned long long)sel, fl.size(),
+                        (unsigned long long)miss_flags, (unsigned long long)miss_all);
+                uint64_t acc = 0, accu = 0; size_t k = 0;
+                for (size_t N : {16, 32, 64, 128, 256}) { for (; k < fl.size() && k < N; ++k) { acc += fl[k].first; accu += fl[k].second; } fprintf(stderr, " top %zu: %llu fetches / %llu uses;", N, (unsigned long long)acc, (unsigned long long)accu); }
+                fprintf(stderr, "\n");
+            }
             for (size_t K : {16, 32, 64, 128})
                 fprintf(stderr, "   LRU model, %zu values per wavefront: %llu operand fetches; with the Poseidon2 intermediates streamed past the cache %llu\n", K,
                         (unsigned long long)lru_misses(K, false), (unsigned long long)lru_misses(K, true));

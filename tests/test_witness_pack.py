@@ -434,8 +434,7 @@ def _dq(words):
     return q
 
 
-def test_demux_packer_equals_the_oracle_streams():
-    """a start instance and its continuation (the reference's witness of the second instance holds the rest of the queue)"""
+def _demux_packed():
     from oracle import demux_native as dn
     from oracle.storage_native import log_query
     rng = np.random.default_rng(61)
@@ -465,6 +464,12 @@ def test_demux_packer_equals_the_oracle_streams():
         arr = (zkgl.LogQueryWitness * max(len(popped), 1))(*[_lq(q) for q in popped])
         w.initial_queue_witness, w.n_initial = arr, len(popped)
         zkgl.pack_demux_witness(w, limit, i, outer, loop)
+    return outer, loop, insts, limit
+
+
+def test_demux_packer_equals_the_oracle_streams():
+    """a start instance and its continuation (the reference's witness of the second instance holds the rest of the queue)"""
+    outer, loop, insts, limit = _demux_packed()
     eo, el = _streams(insts)
     el = el.copy(); el[0:35] = 0
     assert np.array_equal(outer, eo) and np.array_equal(loop, el)
@@ -497,9 +502,7 @@ def test_sort_decommits_packer_equals_the_oracle_streams():
         zkgl.pack_sort_decommits_witness(w, limit, 0, outer, loop)
 
 
-def test_code_unpacker_packer_walks_the_fsm_schedule():
-    """requests and code words land on the cycles that consume them: three bytecodes (1, 5 and 3 words: 1 + 3 + 2 rounds) over a start
-    instance and a continuation that begins in the middle of the second bytecode"""
+def _code_unpacker_packed():
     from oracle import code_unpacker_native as cn
     from oracle.decommit_native import dq
     rng = np.random.default_rng(63)
@@ -531,9 +534,42 @@ def test_code_unpacker_packer_walks_the_fsm_schedule():
             dst[:] = [(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
         w.sorted_requests_queue_witness, w.n_requests, w.code_words, w.n_code_words = qa, len(rq), wa, len(words)
         zkgl.pack_code_unpacker_witness(w, limit, i, outer, loop)
+    return outer, loop, insts, limit
+
+
+def test_code_unpacker_packer_walks_the_fsm_schedule():
+    """requests and code words land on the cycles that consume them: three bytecodes (1, 5 and 3 words: 1 + 3 + 2 rounds) over a start
+    instance and a continuation that begins in the middle of the second bytecode"""
+    outer, loop, insts, limit = _code_unpacker_packed()
     eo, el = _streams(insts)
     el = el.copy(); el[0:74] = 0
     assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("circuit", ["demux", "code_unpacker"])
+def test_packed_streams_of_a_start_and_a_continuation_instance_run_on_the_gpu(zk, circuit):
+    """the product path end to end for two more circuits: C-ABI packers -> device seeding -> resolve + check; commitments and the seeded
+    streams equal the native restatement's (instance 1 continues instance 0: its hidden_fsm_input is instance 0's output)"""
+    if circuit == "demux":
+        from test_demux_host import demux_cs
+        outer, loop, insts, limit = _demux_packed()
+        cs = demux_cs(limit)
+    else:
+        from test_code_unpacker_host import unpacker_cs
+        outer, loop, insts, limit = _code_unpacker_packed()
+        cs = unpacker_cs(limit)
+    cs.set_batch(len(insts))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    cs.seed_carried_inputs(d_l)
+    _, el = _streams(insts)
+    assert np.array_equal(d_l.to_numpy().reshape(loop.shape), el)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
 
 
 def test_linear_hasher_packer_equals_the_oracle_streams():
