@@ -37,6 +37,43 @@ struct Cursor {
         }
         at += (size_t)len;
     }
+    // H160 as impl-serde's fixed-hash writes it: the string "0x" + 40 hex digits (leading zeros kept)
+    void h160(uint32_t limbs[5]) {
+        std::memset(limbs, 0, 20);
+        const uint64_t len = u64();
+        if (!ok || len != 42 || !need(42)) { ok = false; return; }
+        if (p[at] != '0' || p[at + 1] != 'x') { ok = false; return; }
+        for (size_t i = 0; i < 40; ++i) {
+            const uint8_t c = p[at + 2 + i];
+            uint32_t d;
+            if (c >= '0' && c <= '9') d = c - '0';
+            else if (c >= 'a' && c <= 'f') d = 10 + c - 'a';
+            else if (c >= 'A' && c <= 'F') d = 10 + c - 'A';
+            else { ok = false; return; }
+            const size_t nib = 39 - i;
+            limbs[nib / 8] |= d << (4 * (nib % 8));
+        }
+        at += 42;
+    }
+    void queue_state4(zk_queue_state_witness& q) {
+        for (auto& x : q.head) x = field();
+        for (auto& x : q.tail) x = field();
+        q.length = u32();
+    }
+    void log_query(zk_log_query_witness& q) {   // LogQuery field order (log_query/mod.rs:23-35)
+        h160(q.address); u256(q.key); u256(q.read_value); u256(q.written_value);
+        q.aux_byte = u8(); q.rw_flag = boolean(); q.rollback = boolean(); q.is_service = boolean(); q.shard_id = u8();
+        q.tx_number_in_block = u32(); q.timestamp = u32();
+    }
+    // CircuitQueueRawWitness<LogQuery, 4, 20>: u64 count, then (item, previous tail[4]) pairs; the tails are not consumed by the circuits
+    bool log_queue(zk_log_query_witness* buf, uint32_t cap, uint32_t& n_out, int& err) {
+        const uint64_t n = u64();
+        if (!ok) return false;
+        if (n > cap || (n && !buf)) { err = ZK_ERR_CAPACITY; return false; }
+        for (uint64_t i = 0; i < n && ok; ++i) { log_query(buf[i]); for (int t = 0; t < 4; ++t) field(); }
+        n_out = (uint32_t)n;
+        return ok;
+    }
     void queue_state(zk_full_queue_state_witness& q) {
         for (auto& x : q.head) x = field();
         for (auto& x : q.tail) x = field();
@@ -492,6 +529,105 @@ int zk_pack_linear_hasher_witness(const zk_linear_hasher_witness* w, uint32_t li
         if (l.k != ZK_LINEAR_HASHER_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: linear_hasher loop layout");
     }
     return ZK_OK;
+}
+
+
+namespace {
+void storage_fsm(Cursor& c, zk_storage_fsm_witness& f) {   // StorageDeduplicatorFSMInputOutput (input.rs:37-52)
+    for (auto& x : f.lhs_accumulator) x = c.field();
+    for (auto& x : f.rhs_accumulator) x = c.field();
+    c.queue_state4(f.current_unsorted_queue_state); c.queue_state4(f.current_intermediate_sorted_queue_state); c.queue_state4(f.current_final_sorted_queue_state);
+    f.cycle_idx = c.u32();
+    for (auto& x : f.previous_packed_key) x = c.u32();
+    c.u256(f.previous_key); c.h160(f.previous_address); f.previous_timestamp = c.u32();
+    f.this_cell_has_explicit_read_and_rollback_depth_zero = c.boolean();
+    c.u256(f.this_cell_base_value); c.u256(f.this_cell_current_value); f.this_cell_current_depth = c.u32();
+}
+void log_sorter_fsm(Cursor& c, zk_log_sorter_fsm_witness& f) {   // EventsDeduplicatorFSMInputOutput (input.rs:28-36)
+    for (auto& x : f.lhs_accumulator) x = c.field();
+    for (auto& x : f.rhs_accumulator) x = c.field();
+    c.queue_state4(f.initial_unsorted_queue_state); c.queue_state4(f.intermediate_sorted_queue_state); c.queue_state4(f.final_result_queue_state);
+    f.previous_key = c.u32();
+    c.log_query(f.previous_item);
+}
+int finish(Cursor& c, int err, size_t* consumed, const char* what) {
+    if (err != ZK_OK) return bad(err, what);
+    if (!c.ok) return bad(ZK_ERR_INVALID, what);
+    if (consumed) *consumed = c.at;
+    return ZK_OK;
+}
+}  // namespace
+
+int zk_decode_storage_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_storage_validity_witness* out, zk_log_query_witness* unsorted_buf, uint32_t unsorted_cap,
+                                      zk_timestamped_log_record_witness* sorted_buf, uint32_t sorted_cap, size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_storage_witness_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    int err = ZK_OK;
+    out->start_flag = c.boolean(); out->completion_flag = c.boolean();
+    out->shard_id_to_process = c.u8(); c.queue_state4(out->unsorted_log_queue_state); c.queue_state4(out->intermediate_sorted_queue_state);
+    zk_queue_state_witness final_sorted;   // observable_output.final_sorted_queue_state: read, not needed by the packer
+    c.queue_state4(final_sorted);
+    storage_fsm(c, out->hidden_fsm_input); storage_fsm(c, out->hidden_fsm_output);
+    if (c.log_queue(unsorted_buf, unsorted_cap, out->n_unsorted, err)) {
+        out->unsorted_queue_witness = unsorted_buf;
+        const uint64_t n = c.u64();   // CircuitQueueRawWitness<TimestampedStorageLogRecord, 4, ..>
+        if (c.ok && (n > sorted_cap || (n && !sorted_buf))) err = ZK_ERR_CAPACITY;
+        else {
+            for (uint64_t i = 0; i < n && c.ok; ++i) { c.log_query(sorted_buf[i].record); sorted_buf[i].timestamp = c.u32(); for (int t = 0; t < 4; ++t) c.field(); }
+            out->intermediate_sorted_queue_witness = sorted_buf; out->n_sorted = (uint32_t)n;
+        }
+    }
+    return finish(c, err, consumed, "zk_decode_storage_witness_bincode: truncated, malformed or longer than the caller's buffers");
+}
+
+int zk_decode_log_sorter_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_log_sorter_witness* out, zk_log_query_witness* initial_buf, uint32_t initial_cap,
+                                         zk_log_query_witness* sorted_buf, uint32_t sorted_cap, size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_log_sorter_witness_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    int err = ZK_OK;
+    out->start_flag = c.boolean(); out->completion_flag = c.boolean();
+    c.queue_state4(out->initial_log_queue_state); c.queue_state4(out->intermediate_sorted_queue_state);
+    zk_queue_state_witness final_queue;   // observable_output.final_queue_state
+    c.queue_state4(final_queue);
+    log_sorter_fsm(c, out->hidden_fsm_input); log_sorter_fsm(c, out->hidden_fsm_output);
+    if (c.log_queue(initial_buf, initial_cap, out->n_initial, err)) {
+        out->initial_queue_witness = initial_buf;
+        if (c.log_queue(sorted_buf, sorted_cap, out->n_sorted, err)) out->intermediate_sorted_queue_witness = sorted_buf;
+    }
+    return finish(c, err, consumed, "zk_decode_log_sorter_witness_bincode: truncated, malformed or longer than the caller's buffers");
+}
+
+int zk_decode_demux_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_demux_log_queue_witness* out, zk_log_query_witness* initial_buf, uint32_t initial_cap,
+                                    size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_demux_witness_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    int err = ZK_OK;
+    out->start_flag = c.boolean(); out->completion_flag = c.boolean();
+    c.queue_state4(out->initial_log_queue_state);
+    zk_queue_state_witness outq;   // observable_output: the six output queue states (LogDemuxerOutputData, input.rs:77-84)
+    for (int i = 0; i < 6; ++i) c.queue_state4(outq);
+    for (zk_demux_fsm_witness* f : {&out->hidden_fsm_input, &out->hidden_fsm_output}) {
+        c.queue_state4(f->initial_log_queue_state);
+        for (auto& q : f->output_queue_states) c.queue_state4(q);
+    }
+    if (c.log_queue(initial_buf, initial_cap, out->n_initial, err)) out->initial_queue_witness = initial_buf;
+    return finish(c, err, consumed, "zk_decode_demux_witness_bincode: truncated, malformed or longer than the caller's buffer");
+}
+
+int zk_decode_linear_hasher_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_linear_hasher_witness* out, zk_log_query_witness* queue_buf, uint32_t queue_cap,
+                                            size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_linear_hasher_witness_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    int err = ZK_OK;
+    out->start_flag = c.boolean(); out->completion_flag = c.boolean();
+    c.queue_state4(out->queue_state);
+    for (int i = 0; i < 32; ++i) c.u8();   // observable_output.keccak256_hash; hidden FSM states are () : nothing on the wire
+    if (c.log_queue(queue_buf, queue_cap, out->n_queue, err)) out->queue_witness = queue_buf;
+    return finish(c, err, consumed, "zk_decode_linear_hasher_witness_bincode: truncated, malformed or longer than the caller's buffer");
 }
 
 }  // extern "C"

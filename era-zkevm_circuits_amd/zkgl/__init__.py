@@ -363,6 +363,36 @@ def pack_linear_hasher_witness(w, limit, instance, outer, loop):
     _check(lib().zk_pack_linear_hasher_witness(C.byref(w), limit, instance, batch, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
 
 
+def _decode_bincode(fn, w, data: bytes, bufs):
+    used = C.c_size_t(0)
+    raw = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+    args = []
+    for arr in bufs:
+        args += [arr, len(arr)]
+    _check(fn(raw, C.c_size_t(len(data)), C.byref(w), *args, C.byref(used)))
+    w._keep = bufs
+    return w, used.value
+
+
+def decode_storage_witness_bincode(data: bytes, max_elements: int):
+    """zk_decode_storage_witness_bincode -> (StorageValidityWitness, bytes consumed)"""
+    n = max(max_elements, 1)
+    return _decode_bincode(lib().zk_decode_storage_witness_bincode, StorageValidityWitness(), data, [(LogQueryWitness * n)(), (TimestampedLogRecordWitness * n)()])
+
+
+def decode_log_sorter_witness_bincode(data: bytes, max_elements: int):
+    n = max(max_elements, 1)
+    return _decode_bincode(lib().zk_decode_log_sorter_witness_bincode, LogSorterWitness(), data, [(LogQueryWitness * n)(), (LogQueryWitness * n)()])
+
+
+def decode_demux_witness_bincode(data: bytes, max_elements: int):
+    return _decode_bincode(lib().zk_decode_demux_witness_bincode, DemuxLogQueueWitness(), data, [(LogQueryWitness * max(max_elements, 1))()])
+
+
+def decode_linear_hasher_witness_bincode(data: bytes, max_elements: int):
+    return _decode_bincode(lib().zk_decode_linear_hasher_witness_bincode, LinearHasherWitness(), data, [(LogQueryWitness * max(max_elements, 1))()])
+
+
 class Comm:
     """RCCL communicator behind the C ABI (zk_comm_*): one process per GPU; rank 0's `unique_id()` bytes reach the other ranks through
     the host's launcher (bench.py: a torch.distributed broadcast)."""

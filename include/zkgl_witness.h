@@ -302,6 +302,23 @@ typedef struct zk_linear_hasher_witness {
 int zk_pack_linear_hasher_witness(const zk_linear_hasher_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                                   uint64_t *outer_words, uint64_t *loop_words);
 
+/* ---- bincode decoders for the witnesses built from LogQuery queues (same conventions and the same [EXT] caveats as
+ * zk_decode_ram_witness_bincode: "parity unpinned" until reference-produced bytes exist).  ClosedFormInputWitness = start_flag,
+ * completion_flag, observable_input, observable_output, hidden_fsm_input, hidden_fsm_output (src/fsm_input_output/mod.rs:32-47; the
+ * observable output is read and dropped: the packers do not need it); a QueueStateWitness<F, 4> = head[4], tail[4], length u32; a queue
+ * witness = `elements: VecDeque<(ItemWitness, [F; 4])>`; LogQueryWitness in its field order with the address (ethereum-types H160 with
+ * impl-serde) as the string "0x" + 40 hex digits and U256 as "0x" + hex digits without leading zeros.  Element arrays are caller-owned. */
+int zk_decode_storage_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_storage_validity_witness *out,
+                                      zk_log_query_witness *unsorted_buf, uint32_t unsorted_cap,
+                                      zk_timestamped_log_record_witness *sorted_buf, uint32_t sorted_cap, size_t *consumed);
+int zk_decode_log_sorter_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_log_sorter_witness *out,
+                                         zk_log_query_witness *initial_buf, uint32_t initial_cap,
+                                         zk_log_query_witness *sorted_buf, uint32_t sorted_cap, size_t *consumed);
+int zk_decode_demux_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_demux_log_queue_witness *out,
+                                    zk_log_query_witness *initial_buf, uint32_t initial_cap, size_t *consumed);
+int zk_decode_linear_hasher_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_linear_hasher_witness *out,
+                                            zk_log_query_witness *queue_buf, uint32_t queue_cap, size_t *consumed);
+
 #ifdef __cplusplus
 }
 #endif

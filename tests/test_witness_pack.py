@@ -594,3 +594,146 @@ def test_linear_hasher_packer_equals_the_oracle_streams():
     assert np.array_equal(outer, eo) and np.array_equal(loop, el)
     with pytest.raises(zkgl.ZkError):
         zkgl._check(zkgl.lib().zk_pack_linear_hasher_witness(C.byref(w), 33, 0, 1, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
+
+
+# ---------------------------------------------------------------- bincode of the LogQuery-queue witnesses (test-side writer, C decoder)
+def _b_h160(limbs):
+    v = sum(int(x) << (32 * i) for i, x in enumerate(limbs))
+    s_ = ("0x%040x" % v).encode()
+    return struct.pack("<Q", len(s_)) + s_
+
+
+def _b_q4(q):
+    return b"".join(struct.pack("<Q", int(x)) for x in list(q.head) + list(q.tail)) + struct.pack("<I", q.length)
+
+
+def _b_lq(q):
+    return (_b_h160(q.address) + _b_u256(q.key) + _b_u256(q.read_value) + _b_u256(q.written_value) +
+            struct.pack("<BBBBBII", q.aux_byte, q.rw_flag, q.rollback, q.is_service, q.shard_id, q.tx_number_in_block, q.timestamp))
+
+
+def _b_log_queue(arr, n, with_ts=False):
+    out = struct.pack("<Q", n)
+    for i in range(n):
+        out += (_b_lq(arr[i].record) + struct.pack("<I", arr[i].timestamp)) if with_ts else _b_lq(arr[i])
+        out += b"".join(struct.pack("<Q", 1000 + 4 * i + t) for t in range(4))   # the tail before the push: skipped by the decoder
+    return out
+
+
+def _b_storage_fsm(f):
+    return (b"".join(struct.pack("<Q", int(x)) for x in list(f.lhs_accumulator) + list(f.rhs_accumulator)) + _b_q4(f.current_unsorted_queue_state) +
+            _b_q4(f.current_intermediate_sorted_queue_state) + _b_q4(f.current_final_sorted_queue_state) + struct.pack("<I", f.cycle_idx) +
+            b"".join(struct.pack("<I", int(x)) for x in f.previous_packed_key) + _b_u256(f.previous_key) + _b_h160(f.previous_address) +
+            struct.pack("<IB", f.previous_timestamp, f.this_cell_has_explicit_read_and_rollback_depth_zero) + _b_u256(f.this_cell_base_value) +
+            _b_u256(f.this_cell_current_value) + struct.pack("<I", f.this_cell_current_depth))
+
+
+def _b_log_sorter_fsm(f):
+    return (b"".join(struct.pack("<Q", int(x)) for x in list(f.lhs_accumulator) + list(f.rhs_accumulator)) + _b_q4(f.initial_unsorted_queue_state) +
+            _b_q4(f.intermediate_sorted_queue_state) + _b_q4(f.final_result_queue_state) + struct.pack("<I", f.previous_key) + _b_lq(f.previous_item))
+
+
+def test_storage_bincode_round_trip():
+    """a continuation-shaped witness (non-trivial FSM input: accumulators, previous key / address / values) through bytes and back"""
+    from oracle import storage_native as sn
+    limit = 12
+    u, s_ = sn.random_storage_witness(np.random.default_rng(71), 9, n_cells=3)
+    a = sn.instance(u, s_, limit)
+    o = a["outer"]
+    w = zkgl.StorageValidityWitness()
+    w.start_flag, w.completion_flag, w.shard_id_to_process = int(o[0]), int(a["completed"]), int(o[1])
+    w.unsorted_log_queue_state, w.intermediate_sorted_queue_state = _q4(o[2:11]), _q4(o[11:20])
+    for f, x in ((w.hidden_fsm_input, o[20:97]), (w.hidden_fsm_output, sn.flatten_fsm(a["fsm_out"]) if hasattr(sn, "flatten_fsm") else o[20:97])):
+        f.lhs_accumulator[:] = x[0:2]; f.rhs_accumulator[:] = x[2:4]
+        f.current_unsorted_queue_state, f.current_intermediate_sorted_queue_state, f.current_final_sorted_queue_state = _q4(x[4:13]), _q4(x[13:22]), _q4(x[22:31])
+        f.cycle_idx = int(x[31]); f.previous_packed_key[:] = x[32:45]; f.previous_key[:] = x[45:53]; f.previous_address[:] = x[53:58]
+        f.previous_timestamp = int(x[58]); f.this_cell_has_explicit_read_and_rollback_depth_zero = int(x[59])
+        f.this_cell_base_value[:] = x[60:68]; f.this_cell_current_value[:] = x[68:76]; f.this_cell_current_depth = int(x[76])
+    ua = (zkgl.LogQueryWitness * len(u))(*[_lq(q) for q in u])
+    sa = (zkgl.TimestampedLogRecordWitness * len(s_))()
+    for rec, (q, t) in zip(sa, s_):
+        rec.record, rec.timestamp = _lq(q), int(t)
+    w.unsorted_queue_witness, w.n_unsorted, w.intermediate_sorted_queue_witness, w.n_sorted = ua, len(u), sa, len(s_)
+    data = (struct.pack("<BBB", w.start_flag, w.completion_flag, w.shard_id_to_process) + _b_q4(w.unsorted_log_queue_state) + _b_q4(w.intermediate_sorted_queue_state) +
+            _b_q4(w.hidden_fsm_output.current_final_sorted_queue_state) + _b_storage_fsm(w.hidden_fsm_input) + _b_storage_fsm(w.hidden_fsm_output) +
+            _b_log_queue(ua, len(u)) + _b_log_queue(sa, len(s_), with_ts=True))
+    d, used = zkgl.decode_storage_witness_bincode(data + b"xx", limit)
+    assert used == len(data)
+    outer = np.zeros((97, 1), dtype=np.uint64); loop = np.zeros((140, limit), dtype=np.uint64)
+    zkgl.pack_storage_witness(d, limit, 0, outer, loop)
+    eo, el = sn.pack_streams([a], limit)
+    el = el.copy(); el[0:67] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+    assert bytes(d.hidden_fsm_output) == bytes(w.hidden_fsm_output)
+    with pytest.raises(zkgl.ZkError):
+        zkgl.decode_storage_witness_bincode(data[:-5], limit)
+    with pytest.raises(zkgl.ZkError):
+        zkgl.decode_storage_witness_bincode(data, len(u) - 1)
+
+
+def test_log_sorter_demux_linear_hasher_bincode_round_trips():
+    from oracle import demux_native as dn, linear_hasher_native as hn, log_sorter_native as ln
+    # log_sorter
+    limit = 14
+    u, s_ = ln.random_events(np.random.default_rng(72), 10, rollback_frac=0.3)
+    u, s_ = u[:limit], s_[:limit]
+    inst = ln.instance(u, s_, limit)
+    o = inst["outer"]
+    w = zkgl.LogSorterWitness()
+    w.start_flag, w.completion_flag = int(o[0]), int(inst["completed"])
+    w.initial_log_queue_state, w.intermediate_sorted_queue_state = _q4(o[1:10]), _q4(o[10:19])
+    f, x = w.hidden_fsm_input, o[19:87]
+    f.lhs_accumulator[:] = x[0:2]; f.rhs_accumulator[:] = x[2:4]
+    f.initial_unsorted_queue_state, f.intermediate_sorted_queue_state, f.final_result_queue_state = _q4(x[4:13]), _q4(x[13:22]), _q4(x[22:31])
+    f.previous_key = int(x[31]); f.previous_item = _lq(x[32:68])
+    ua = (zkgl.LogQueryWitness * len(u))(*[_lq(q) for q in u]); sa = (zkgl.LogQueryWitness * len(s_))(*[_lq(q) for q in s_])
+    data = (struct.pack("<BB", w.start_flag, w.completion_flag) + _b_q4(w.initial_log_queue_state) + _b_q4(w.intermediate_sorted_queue_state) +
+            _b_q4(zkgl.QueueStateWitness()) + _b_log_sorter_fsm(w.hidden_fsm_input) + _b_log_sorter_fsm(w.hidden_fsm_output) +
+            _b_log_queue(ua, len(u)) + _b_log_queue(sa, len(s_)))
+    d, used = zkgl.decode_log_sorter_witness_bincode(data, limit)
+    assert used == len(data)
+    outer = np.zeros((87, 1), dtype=np.uint64); loop = np.zeros((129, limit), dtype=np.uint64)
+    zkgl.pack_log_sorter_witness(d, limit, 0, outer, loop)
+    eo, el = ln.pack_streams([inst], limit)
+    el = el.copy(); el[0:57] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+    # demux: the packed start instance of _demux_packed, through bytes
+    pouter, ploop, insts, limit = _demux_packed()
+    o = insts[0]["outer"]
+    w = zkgl.DemuxLogQueueWitness()
+    w.start_flag, w.completion_flag = int(o[0]), int(insts[0]["completed"])
+    w.initial_log_queue_state = _q4(o[1:10])
+    w.hidden_fsm_input.initial_log_queue_state = _q4(o[10:19])
+    for k in range(6):
+        w.hidden_fsm_input.output_queue_states[k] = _q4(o[19 + 9 * k:28 + 9 * k])
+    rows = [r[35:71] for r in insts[0]["rows"]]
+    n = sum(1 for r in rows if any(r))
+    qa = (zkgl.LogQueryWitness * max(n, 1))(*[_lq(r) for r in rows[:n]])
+    fsm = lambda f: _b_q4(f.initial_log_queue_state) + b"".join(_b_q4(q) for q in f.output_queue_states)
+    data = (struct.pack("<BB", w.start_flag, w.completion_flag) + _b_q4(w.initial_log_queue_state) + b"".join(_b_q4(zkgl.QueueStateWitness()) for _ in range(6)) +
+            fsm(w.hidden_fsm_input) + fsm(w.hidden_fsm_output) + _b_log_queue(qa, n))
+    d, used = zkgl.decode_demux_witness_bincode(data, limit)
+    assert used == len(data)
+    outer = np.zeros((73, 2), dtype=np.uint64); loop = np.full((71, 2 * limit), 9, dtype=np.uint64)
+    zkgl.pack_demux_witness(d, limit, 0, outer, loop)
+    assert np.array_equal(outer[:, 0], pouter[:, 0]) and np.array_equal(loop[:, :limit], ploop[:, :limit])
+    # linear_hasher
+    from oracle.storage_native import log_query
+    rng = np.random.default_rng(73)
+    qs = [log_query(address=int(rng.integers(1, 1 << 60)), key=int.from_bytes(rng.bytes(32), "little"), written_value=int.from_bytes(rng.bytes(32), "little"),
+                    rw_flag=1, aux_byte=2, shard_id=int(rng.integers(0, 2)), tx_number_in_block=int(rng.integers(0, 65536)), timestamp=5 + t) for t in range(9)]
+    inst = hn.instance(qs, 17)
+    w = zkgl.LinearHasherWitness()
+    w.start_flag, w.completion_flag = 1, 1
+    w.queue_state = _q4(inst["outer"][1:10])
+    qa = (zkgl.LogQueryWitness * len(qs))(*[_lq(q) for q in qs])
+    data = struct.pack("<BB", 1, 1) + _b_q4(w.queue_state) + inst["digest"] + _b_log_queue(qa, len(qs))
+    d, used = zkgl.decode_linear_hasher_witness_bincode(data, 17)
+    assert used == len(data)
+    outer = np.zeros((10, 1), dtype=np.uint64); loop = np.zeros((818, 1), dtype=np.uint64)
+    zkgl.pack_linear_hasher_witness(d, 17, 0, outer, loop)
+    eo, el = _streams([inst])
+    el = el.copy(); el[0:206] = 0
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+    with pytest.raises(zkgl.ZkError):
+        zkgl.decode_linear_hasher_witness_bincode(data[:40], 17)
