@@ -630,4 +630,136 @@ int zk_decode_linear_hasher_witness_bincode(const uint8_t* bytes, size_t n_bytes
     return finish(c, err, consumed, "zk_decode_linear_hasher_witness_bincode: truncated, malformed or longer than the caller's buffer");
 }
 
+
+namespace {
+void decommit_query(Cursor& c, zk_decommit_query_witness& q) {   // DecommitQuery field order (decommit_query/mod.rs:22-29)
+    c.u256(q.code_hash); q.page = c.u32(); q.is_first = c.boolean(); q.timestamp = c.u32();
+}
+bool decommit_queue(Cursor& c, zk_decommit_query_witness* buf, uint32_t cap, uint32_t& n_out, int& err) {
+    const uint64_t n = c.u64();
+    if (!c.ok) return false;
+    if (n > cap || (n && !buf)) { err = ZK_ERR_CAPACITY; return false; }
+    for (uint64_t i = 0; i < n && c.ok; ++i) { decommit_query(c, buf[i]); for (int t = 0; t < 12; ++t) c.field(); }
+    n_out = (uint32_t)n;
+    return c.ok;
+}
+bool u256_seq(Cursor& c, uint32_t (*buf)[8], uint32_t cap, uint32_t& n_out, int& err) {   // VecDeque<U256> / Vec<U256>, appended at n_out
+    const uint64_t n = c.u64();
+    if (!c.ok) return false;
+    if (n > (uint64_t)cap - n_out || (n && !buf)) { err = ZK_ERR_CAPACITY; return false; }
+    for (uint64_t i = 0; i < n && c.ok; ++i) c.u256(buf[n_out + i]);
+    n_out += (uint32_t)n;
+    return c.ok;
+}
+void sha256_fsm(Cursor& c, zk_sha256_fsm_witness& f) {   // Sha256RoundFunctionFSMInputOutput (input.rs:24-32, 53-57; call params mod.rs:44-50)
+    f.read_precompile_call = c.boolean(); f.read_words_for_round = c.boolean(); f.completed = c.boolean();
+    for (auto& x : f.sha256_inner_state) x = c.u32();
+    f.timestamp_to_use_for_read = c.u32(); f.timestamp_to_use_for_write = c.u32();
+    f.input_page = c.u32(); f.input_offset = c.u32(); f.output_page = c.u32(); f.output_offset = c.u32(); f.num_rounds = c.u32();
+    c.queue_state4(f.log_queue_state); c.queue_state(f.memory_queue_state);
+}
+void keccak_fsm(Cursor& c, zk_keccak_fsm_witness& f) {   // Keccak256RoundFunctionFSMInputOutput (input.rs:29-39, 63-67; call params mod.rs:48-55)
+    f.read_precompile_call = c.boolean(); f.read_unaligned_words_for_round = c.boolean(); f.padding_round = c.boolean(); f.completed = c.boolean();
+    for (auto& i : f.keccak_internal_state) for (auto& j : i) for (auto& k : j) k = c.u8();
+    f.timestamp_to_use_for_read = c.u32(); f.timestamp_to_use_for_write = c.u32();
+    f.input_page = c.u32(); f.input_memory_byte_offset = c.u32(); f.input_memory_byte_length = c.u32(); f.output_page = c.u32(); f.output_word_offset = c.u32();
+    f.needs_full_padding_round = c.boolean();
+    for (auto& b : f.buffer_bytes) b = c.u8();
+    f.buffer_filled = c.u8();
+    c.queue_state4(f.log_queue_state); c.queue_state(f.memory_queue_state);
+}
+void sort_decommits_fsm(Cursor& c, zk_sort_decommits_fsm_witness& f) {   // CodeDecommittmentsDeduplicatorFSMInputOutput (input.rs:26-37)
+    c.queue_state(f.initial_queue_state); c.queue_state(f.sorted_queue_state); c.queue_state(f.final_queue_state);
+    for (auto& x : f.lhs_accumulator) x = c.field();
+    for (auto& x : f.rhs_accumulator) x = c.field();
+    for (auto& x : f.previous_packed_key) x = c.u32();
+    f.first_encountered_timestamp = c.u32();
+    decommit_query(c, f.previous_record);
+}
+void code_unpacker_fsm(Cursor& c, zk_code_unpacker_fsm_witness& f) {   // CodeDecommitterFSMInputOutput (input.rs:23-34, 61-65)
+    for (auto& x : f.sha256_inner_state) x = c.u32();
+    c.u256(f.hash_to_compare_against);
+    f.current_index = c.u32(); f.current_page = c.u32(); f.timestamp = c.u32();
+    if (c.need(2)) { uint16_t v; std::memcpy(&v, c.p + c.at, 2); c.at += 2; f.num_rounds_left = v; }
+    f.length_in_bits = c.u32();
+    f.state_get_from_queue = c.boolean(); f.state_decommit = c.boolean(); f.finished = c.boolean();
+    c.queue_state(f.decommittment_requests_queue_state); c.queue_state(f.memory_queue_state);
+}
+}  // namespace
+
+int zk_decode_sha256_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_sha256_round_function_witness* out, zk_log_query_witness* requests_buf, uint32_t requests_cap,
+                                     uint32_t (*reads_buf)[8], uint32_t reads_cap, size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_sha256_witness_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    int err = ZK_OK;
+    out->start_flag = c.boolean(); out->completion_flag = c.boolean();
+    c.queue_state4(out->initial_log_queue_state); c.queue_state(out->initial_memory_queue_state);
+    zk_full_queue_state_witness final_memory;   // observable_output.final_memory_state
+    c.queue_state(final_memory);
+    sha256_fsm(c, out->hidden_fsm_input); sha256_fsm(c, out->hidden_fsm_output);
+    if (c.log_queue(requests_buf, requests_cap, out->n_requests, err)) {
+        out->requests_queue_witness = requests_buf;
+        if (u256_seq(c, reads_buf, reads_cap, out->n_reads, err)) out->memory_reads_witness = reads_buf;
+    }
+    return finish(c, err, consumed, "zk_decode_sha256_witness_bincode: truncated, malformed or longer than the caller's buffers");
+}
+
+int zk_decode_keccak_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_keccak_round_function_witness* out, zk_log_query_witness* requests_buf, uint32_t requests_cap,
+                                     uint32_t (*reads_buf)[8], uint32_t reads_cap, size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_keccak_witness_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    int err = ZK_OK;
+    out->start_flag = c.boolean(); out->completion_flag = c.boolean();
+    c.queue_state4(out->initial_log_queue_state); c.queue_state(out->initial_memory_queue_state);
+    zk_full_queue_state_witness final_memory;
+    c.queue_state(final_memory);
+    keccak_fsm(c, out->hidden_fsm_input); keccak_fsm(c, out->hidden_fsm_output);
+    if (c.log_queue(requests_buf, requests_cap, out->n_requests, err)) {
+        out->requests_queue_witness = requests_buf;
+        if (u256_seq(c, reads_buf, reads_cap, out->n_reads, err)) out->memory_reads_witness = reads_buf;
+    }
+    return finish(c, err, consumed, "zk_decode_keccak_witness_bincode: truncated, malformed or longer than the caller's buffers");
+}
+
+int zk_decode_sort_decommits_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_sort_decommits_witness* out, zk_decommit_query_witness* initial_buf, uint32_t initial_cap,
+                                             zk_decommit_query_witness* sorted_buf, uint32_t sorted_cap, size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_sort_decommits_witness_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    int err = ZK_OK;
+    out->start_flag = c.boolean(); out->completion_flag = c.boolean();
+    c.queue_state(out->initial_queue_state); c.queue_state(out->sorted_queue_initial_state);
+    zk_full_queue_state_witness final_queue;   // observable_output.final_queue_state
+    c.queue_state(final_queue);
+    sort_decommits_fsm(c, out->hidden_fsm_input); sort_decommits_fsm(c, out->hidden_fsm_output);
+    if (decommit_queue(c, initial_buf, initial_cap, out->n_initial, err)) {
+        out->initial_queue_witness = initial_buf;
+        if (decommit_queue(c, sorted_buf, sorted_cap, out->n_sorted, err)) out->sorted_queue_witness = sorted_buf;
+    }
+    return finish(c, err, consumed, "zk_decode_sort_decommits_witness_bincode: truncated, malformed or longer than the caller's buffers");
+}
+
+int zk_decode_code_unpacker_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_code_unpacker_witness* out, zk_decommit_query_witness* requests_buf, uint32_t requests_cap,
+                                            uint32_t (*words_buf)[8], uint32_t words_cap, size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_code_unpacker_witness_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    int err = ZK_OK;
+    out->start_flag = c.boolean(); out->completion_flag = c.boolean();
+    c.queue_state(out->memory_queue_initial_state); c.queue_state(out->sorted_requests_queue_initial_state);   // CodeDecommitterInputData order (input.rs:80-83)
+    zk_full_queue_state_witness final_memory;   // observable_output.memory_queue_final_state
+    c.queue_state(final_memory);
+    code_unpacker_fsm(c, out->hidden_fsm_input); code_unpacker_fsm(c, out->hidden_fsm_output);
+    if (decommit_queue(c, requests_buf, requests_cap, out->n_requests, err)) {
+        out->sorted_requests_queue_witness = requests_buf;
+        const uint64_t n_codes = c.u64();   // Vec<Vec<U256>>
+        bool good = c.ok;
+        for (uint64_t k = 0; k < n_codes && good; ++k) good = u256_seq(c, words_buf, words_cap, out->n_code_words, err);
+        if (good) out->code_words = words_buf;
+    }
+    return finish(c, err, consumed, "zk_decode_code_unpacker_witness_bincode: truncated, malformed or longer than the caller's buffers");
+}
+
 }  // extern "C"

@@ -393,6 +393,26 @@ def decode_linear_hasher_witness_bincode(data: bytes, max_elements: int):
     return _decode_bincode(lib().zk_decode_linear_hasher_witness_bincode, LinearHasherWitness(), data, [(LogQueryWitness * max(max_elements, 1))()])
 
 
+def decode_sha256_witness_bincode(data: bytes, max_requests: int, max_reads: int):
+    return _decode_bincode(lib().zk_decode_sha256_witness_bincode, Sha256RoundFunctionWitness(), data,
+                           [(LogQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_reads, 1))()])
+
+
+def decode_keccak_witness_bincode(data: bytes, max_requests: int, max_reads: int):
+    return _decode_bincode(lib().zk_decode_keccak_witness_bincode, KeccakRoundFunctionWitness(), data,
+                           [(LogQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_reads, 1))()])
+
+
+def decode_sort_decommits_witness_bincode(data: bytes, max_elements: int):
+    n = max(max_elements, 1)
+    return _decode_bincode(lib().zk_decode_sort_decommits_witness_bincode, SortDecommitsWitness(), data, [(DecommitQueryWitness * n)(), (DecommitQueryWitness * n)()])
+
+
+def decode_code_unpacker_witness_bincode(data: bytes, max_requests: int, max_words: int):
+    return _decode_bincode(lib().zk_decode_code_unpacker_witness_bincode, CodeUnpackerWitness(), data,
+                           [(DecommitQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_words, 1))()])
+
+
 class Comm:
     """RCCL communicator behind the C ABI (zk_comm_*): one process per GPU; rank 0's `unique_id()` bytes reach the other ranks through
     the host's launcher (bench.py: a torch.distributed broadcast)."""

@@ -319,6 +319,23 @@ int zk_decode_demux_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_dem
 int zk_decode_linear_hasher_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_linear_hasher_witness *out,
                                             zk_log_query_witness *queue_buf, uint32_t queue_cap, size_t *consumed);
 
+/* the precompile and decommitment witnesses: PrecompileFunctionInputData = log queue state (4-wide), memory queue state (12-wide);
+ * the observable output (final memory queue state) is read and dropped; `memory_reads_witness: VecDeque<U256>` = u64 count + U256
+ * strings; ByteBuffer = bytes[192] + filled (u8); a full-state queue witness = `elements: VecDeque<(DecommitQueryWitness, [F; 12])>`;
+ * `code_words: Vec<Vec<U256>>` is flattened into the caller's word buffer in order */
+int zk_decode_sha256_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_sha256_round_function_witness *out,
+                                     zk_log_query_witness *requests_buf, uint32_t requests_cap,
+                                     uint32_t (*reads_buf)[8], uint32_t reads_cap, size_t *consumed);
+int zk_decode_keccak_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_keccak_round_function_witness *out,
+                                     zk_log_query_witness *requests_buf, uint32_t requests_cap,
+                                     uint32_t (*reads_buf)[8], uint32_t reads_cap, size_t *consumed);
+int zk_decode_sort_decommits_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_sort_decommits_witness *out,
+                                             zk_decommit_query_witness *initial_buf, uint32_t initial_cap,
+                                             zk_decommit_query_witness *sorted_buf, uint32_t sorted_cap, size_t *consumed);
+int zk_decode_code_unpacker_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_code_unpacker_witness *out,
+                                            zk_decommit_query_witness *requests_buf, uint32_t requests_cap,
+                                            uint32_t (*words_buf)[8], uint32_t words_cap, size_t *consumed);
+
 #ifdef __cplusplus
 }
 #endif

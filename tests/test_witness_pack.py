@@ -737,3 +737,168 @@ def test_log_sorter_demux_linear_hasher_bincode_round_trips():
     assert np.array_equal(outer, eo) and np.array_equal(loop, el)
     with pytest.raises(zkgl.ZkError):
         zkgl.decode_linear_hasher_witness_bincode(data[:40], 17)
+
+
+# ---------------------------------------------------------------- bincode of the precompile / decommitment witnesses
+P_GL = 0xFFFFFFFF00000001
+
+
+def _rand_q(rng, cls, width):
+    q = cls()
+    q.head[:] = [int(rng.integers(0, P_GL, dtype=np.uint64)) for _ in range(width)]
+    q.tail[:] = [int(rng.integers(0, P_GL, dtype=np.uint64)) for _ in range(width)]
+    q.length = int(rng.integers(0, 1 << 32))
+    return q
+
+
+def _rand_limbs(rng, n, zero_top=0):
+    v = [int(x) for x in rng.integers(0, 1 << 32, size=n)]
+    for i in range(zero_top):
+        v[n - 1 - i] = 0          # short hex strings: U256 is written without leading zeros
+    return v
+
+
+def _rand_lq_struct(rng):
+    q = zkgl.LogQueryWitness()
+    q.address[:] = _rand_limbs(rng, 5, int(rng.integers(0, 3))); q.key[:] = _rand_limbs(rng, 8, int(rng.integers(0, 9)))
+    q.read_value[:] = _rand_limbs(rng, 8); q.written_value[:] = _rand_limbs(rng, 8, 8)
+    q.aux_byte, q.shard_id = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+    q.rw_flag, q.rollback, q.is_service = [int(x) for x in rng.integers(0, 2, size=3)]
+    q.tx_number_in_block, q.timestamp = int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32))
+    return q
+
+
+def _rand_dq_struct(rng):
+    q = zkgl.DecommitQueryWitness()
+    q.code_hash[:] = _rand_limbs(rng, 8, int(rng.integers(0, 2)))
+    q.page, q.is_first, q.timestamp = int(rng.integers(0, 1 << 32)), int(rng.integers(0, 2)), int(rng.integers(0, 1 << 32))
+    return q
+
+
+def _b_q12(q):
+    return _b_q4(q)   # same shape: head, tail, length
+
+
+def _b_dq(q):
+    return _b_u256(q.code_hash) + struct.pack("<IBI", q.page, q.is_first, q.timestamp)
+
+
+def _b_dq_queue(arr, n):
+    out = struct.pack("<Q", n)
+    for i in range(n):
+        out += _b_dq(arr[i]) + b"".join(struct.pack("<Q", 77 + 12 * i + t) for t in range(12))
+    return out
+
+
+def _b_u256_seq(arr, n):
+    return struct.pack("<Q", n) + b"".join(_b_u256(arr[i]) for i in range(n))
+
+
+def _words(rng, n):
+    arr = (C_u32x8 * max(n, 1))()
+    for i in range(n):
+        arr[i][:] = _rand_limbs(rng, 8, int(rng.integers(0, 9)))
+    return arr
+
+
+def test_sha256_and_keccak_bincode_round_trips():
+    rng = np.random.default_rng(81)
+    for kind in ("sha256", "keccak"):
+        w = zkgl.Sha256RoundFunctionWitness() if kind == "sha256" else zkgl.KeccakRoundFunctionWitness()
+        w.start_flag, w.completion_flag = 0, 1
+        w.initial_log_queue_state, w.initial_memory_queue_state = _rand_q(rng, zkgl.QueueStateWitness, 4), _rand_q(rng, zkgl.FullQueueStateWitness, 12)
+        fsm_bytes = []
+        for f in (w.hidden_fsm_input, w.hidden_fsm_output):
+            f.log_queue_state, f.memory_queue_state = _rand_q(rng, zkgl.QueueStateWitness, 4), _rand_q(rng, zkgl.FullQueueStateWitness, 12)
+            f.timestamp_to_use_for_read, f.timestamp_to_use_for_write = int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32))
+            if kind == "sha256":
+                f.read_precompile_call, f.read_words_for_round, f.completed = [int(x) for x in rng.integers(0, 2, size=3)]
+                f.sha256_inner_state[:] = _rand_limbs(rng, 8)
+                f.input_page, f.input_offset, f.output_page, f.output_offset, f.num_rounds = _rand_limbs(rng, 5)
+                b = (struct.pack("<BBB", f.read_precompile_call, f.read_words_for_round, f.completed) + struct.pack("<8I", *f.sha256_inner_state) +
+                     struct.pack("<7I", f.timestamp_to_use_for_read, f.timestamp_to_use_for_write, f.input_page, f.input_offset, f.output_page, f.output_offset, f.num_rounds))
+            else:
+                f.read_precompile_call, f.read_unaligned_words_for_round, f.padding_round, f.completed = [int(x) for x in rng.integers(0, 2, size=4)]
+                st = bytes(rng.integers(0, 256, size=200, dtype=np.uint8))
+                for a in range(5):
+                    for c in range(5):
+                        for k in range(8):
+                            f.keccak_internal_state[a][c][k] = st[(a * 5 + c) * 8 + k]
+                f.input_page, f.input_memory_byte_offset, f.input_memory_byte_length, f.output_page, f.output_word_offset = _rand_limbs(rng, 5)
+                f.needs_full_padding_round = int(rng.integers(0, 2))
+                buf = bytes(rng.integers(0, 256, size=192, dtype=np.uint8))
+                f.buffer_bytes[:] = list(buf); f.buffer_filled = int(rng.integers(0, 193))
+                b = (struct.pack("<BBBB", f.read_precompile_call, f.read_unaligned_words_for_round, f.padding_round, f.completed) + st +
+                     struct.pack("<7I", f.timestamp_to_use_for_read, f.timestamp_to_use_for_write, f.input_page, f.input_memory_byte_offset,
+                                 f.input_memory_byte_length, f.output_page, f.output_word_offset) + struct.pack("<B", f.needs_full_padding_round) + buf +
+                     struct.pack("<B", f.buffer_filled))
+            fsm_bytes.append(b + _b_q4(f.log_queue_state) + _b_q12(f.memory_queue_state))
+        nq, nr = 3, 7
+        qa = (zkgl.LogQueryWitness * nq)(*[_rand_lq_struct(rng) for _ in range(nq)])
+        ra = _words(rng, nr)
+        data = (struct.pack("<BB", w.start_flag, w.completion_flag) + _b_q4(w.initial_log_queue_state) + _b_q12(w.initial_memory_queue_state) +
+                _b_q12(_rand_q(rng, zkgl.FullQueueStateWitness, 12)) + fsm_bytes[0] + fsm_bytes[1] + _b_log_queue(qa, nq) + _b_u256_seq(ra, nr))
+        dec = zkgl.decode_sha256_witness_bincode if kind == "sha256" else zkgl.decode_keccak_witness_bincode
+        d, used = dec(data + b"!", nq, nr)
+        assert used == len(data) and (d.start_flag, d.completion_flag, d.n_requests, d.n_reads) == (0, 1, nq, nr)
+        assert bytes(d.initial_log_queue_state) == bytes(w.initial_log_queue_state) and bytes(d.initial_memory_queue_state) == bytes(w.initial_memory_queue_state)
+        assert bytes(d.hidden_fsm_input) == bytes(w.hidden_fsm_input) and bytes(d.hidden_fsm_output) == bytes(w.hidden_fsm_output)
+        assert all(bytes(d.requests_queue_witness[i]) == bytes(qa[i]) for i in range(nq))
+        assert all(list(d.memory_reads_witness[i]) == list(ra[i]) for i in range(nr))
+        with pytest.raises(zkgl.ZkError):
+            dec(data, nq, nr - 1)
+        with pytest.raises(zkgl.ZkError):
+            dec(data[:-3], nq, nr)
+
+
+def test_sort_decommits_and_code_unpacker_bincode_round_trips():
+    rng = np.random.default_rng(82)
+    # sort_decommittment_requests
+    w = zkgl.SortDecommitsWitness()
+    w.start_flag, w.completion_flag = 1, 0
+    w.initial_queue_state, w.sorted_queue_initial_state = _rand_q(rng, zkgl.FullQueueStateWitness, 12), _rand_q(rng, zkgl.FullQueueStateWitness, 12)
+    fb = []
+    for f in (w.hidden_fsm_input, w.hidden_fsm_output):
+        f.initial_queue_state, f.sorted_queue_state, f.final_queue_state = [_rand_q(rng, zkgl.FullQueueStateWitness, 12) for _ in range(3)]
+        f.lhs_accumulator[:] = [int(rng.integers(0, P_GL, dtype=np.uint64)) for _ in range(2)]
+        f.rhs_accumulator[:] = [int(rng.integers(0, P_GL, dtype=np.uint64)) for _ in range(2)]
+        f.previous_packed_key[:] = _rand_limbs(rng, 9); f.first_encountered_timestamp = int(rng.integers(0, 1 << 32)); f.previous_record = _rand_dq_struct(rng)
+        fb.append(_b_q12(f.initial_queue_state) + _b_q12(f.sorted_queue_state) + _b_q12(f.final_queue_state) +
+                  struct.pack("<4Q", *f.lhs_accumulator, *f.rhs_accumulator) + struct.pack("<9I", *f.previous_packed_key) +
+                  struct.pack("<I", f.first_encountered_timestamp) + _b_dq(f.previous_record))
+    n = 5
+    ia = (zkgl.DecommitQueryWitness * n)(*[_rand_dq_struct(rng) for _ in range(n)]); sa = (zkgl.DecommitQueryWitness * n)(*[_rand_dq_struct(rng) for _ in range(n)])
+    data = (struct.pack("<BB", 1, 0) + _b_q12(w.initial_queue_state) + _b_q12(w.sorted_queue_initial_state) + _b_q12(_rand_q(rng, zkgl.FullQueueStateWitness, 12)) +
+            fb[0] + fb[1] + _b_dq_queue(ia, n) + _b_dq_queue(sa, n))
+    d, used = zkgl.decode_sort_decommits_witness_bincode(data, n)
+    assert used == len(data) and (d.n_initial, d.n_sorted) == (n, n)
+    assert bytes(d.hidden_fsm_input) == bytes(w.hidden_fsm_input) and bytes(d.hidden_fsm_output) == bytes(w.hidden_fsm_output)
+    assert bytes(d.initial_queue_state) == bytes(w.initial_queue_state) and bytes(d.sorted_queue_initial_state) == bytes(w.sorted_queue_initial_state)
+    assert all(bytes(d.initial_queue_witness[i]) == bytes(ia[i]) and bytes(d.sorted_queue_witness[i]) == bytes(sa[i]) for i in range(n))
+    with pytest.raises(zkgl.ZkError):
+        zkgl.decode_sort_decommits_witness_bincode(data, n - 1)
+    # code_unpacker_sha256: bytes of the start instance of _code_unpacker_packed -> decode -> pack == the oracle's streams
+    from oracle import code_unpacker_native as cn
+    outer, loop, insts, limit = _code_unpacker_packed()
+    o = insts[0]["outer"]
+    rows = insts[0]["rows"]
+    reqs = [r[74:85] for r in rows if any(r[74:85])]
+    words = []
+    for r in rows:
+        for lo in (85, 93):
+            if any(r[lo:lo + 8]):
+                words.append(r[lo:lo + 8])
+    qstate = lambda x: struct.pack("<24Q", *[int(v) for v in x[0:24]]) + struct.pack("<I", int(x[24]))
+    x = o[51:125]
+    fsm = (struct.pack("<8I", *[int(v) for v in x[0:8]]) + _b_u256(x[8:16]) + struct.pack("<III", int(x[16]), int(x[17]), int(x[18])) + struct.pack("<H", int(x[19])) +
+           struct.pack("<I", int(x[20])) + struct.pack("<BBB", int(x[21]), int(x[22]), int(x[23])) + qstate(x[24:49]) + qstate(x[49:74]))
+    code_words = struct.pack("<Q", 2) + struct.pack("<Q", 1) + _b_u256(words[0]) + struct.pack("<Q", len(words) - 1) + b"".join(_b_u256(wd) for wd in words[1:])
+    dq_queue = struct.pack("<Q", len(reqs)) + b"".join(_b_u256(q[0:8]) + struct.pack("<IBI", int(q[8]), int(q[9]), int(q[10])) + bytes(96) for q in reqs)
+    data = struct.pack("<BB", 1, 0) + qstate(o[26:51]) + qstate(o[1:26]) + qstate([0] * 25) + fsm + fsm + dq_queue + code_words
+    d, used = zkgl.decode_code_unpacker_witness_bincode(data, len(reqs), len(words))
+    assert used == len(data) and d.n_requests == len(reqs) and d.n_code_words == len(words)
+    o2 = np.zeros((125, 2), dtype=np.uint64); l2 = np.full((101, 2 * limit), 9, dtype=np.uint64)
+    zkgl.pack_code_unpacker_witness(d, limit, 0, o2, l2)
+    assert np.array_equal(o2[:, 0], outer[:, 0]) and np.array_equal(l2[:, :limit], loop[:, :limit])
+    with pytest.raises(zkgl.ZkError):
+        zkgl.decode_code_unpacker_witness_bincode(data, len(reqs), len(words) - 1)
