@@ -994,7 +994,8 @@ void CS::schedule_by_locality(const std::vector<double>& a, const std::vector<do
     while (order.size() < n) {
         // light candidate: best score, ties to the lowest recording index
         size_t bl = SIZE_MAX; double bs = -1e300;
-        for (size_t k = 0; k < ready_light.size(); ++k) {
+        const size_t scan0 = ready_light.size() > 4096 ? ready_light.size() - 4096 : 0;   // bound the scan: the newest ready ops are the local ones
+        for (size_t k = scan0; k < ready_light.size(); ++k) {
             const double sc = score(ready_light[k]);
             if (sc > bs + 1e-12 || (std::fabs(sc - bs) <= 1e-12 && ready_light[k] < ready_light[bl])) { bs = sc; bl = k; }
         }
