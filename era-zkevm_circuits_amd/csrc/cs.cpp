@@ -851,6 +851,9 @@ void CS::assign_store_slots(Scope& s) {
     for (uint32_t v = 0; v < s.n_vars; ++v)
         if (!seen[v]) s.var_slot[v] = next++;
     s.n_store = std::max<uint32_t>(next, 1);
+    // experiment (ZKGL_STORE_PAD_SLOTS=k): unused slots behind the last value change the tile stride (n_store * 512 B) and with it how the
+    // concurrent accesses of the wavefronts (same slot, different tiles) spread over the memory channels
+    if (const char* pad = std::getenv("ZKGL_STORE_PAD_SLOTS")) s.n_store += (uint32_t)std::atoi(pad);
     s.alias.assign(s.n_trace_cells, 0);
     s.mat_pairs.clear();
     for (uint32_t v = 0; v < s.n_vars; ++v)
@@ -2057,7 +2060,15 @@ void CS::set_batch(uint32_t n) {
         s.n_lanes = (uint32_t)lanes;
         s.stride = (lanes + 63) / 64 * 64;  // whole 64-lane tiles
         size_t bytes = std::max<size_t>((size_t)s.n_store * s.stride * 8, 8);
-        hip_check(hipMalloc((void**)&s.d_store, bytes), "hipMalloc variable store");
+        // experiment (ZKGL_STORE_CONTIGUOUS=1): physically contiguous VRAM for the store.  The loop kernel's time varies from one process
+        // to the next (38.6 ... 41.5 ms at B=384, profiles/r2_summary.md) with the physical pages the allocation happens to get; a
+        // contiguous block is consistently the slowest layout (43.6 ms)
+        bool got = false;
+        if (std::getenv("ZKGL_STORE_CONTIGUOUS") && s.is_loop) {
+            got = hipExtMallocWithFlags((void**)&s.d_store, bytes, hipDeviceMallocContiguous) == hipSuccess;
+            if (!got) { (void)hipGetLastError(); fprintf(stderr, "[zkgl] contiguous store allocation refused, falling back\n"); }
+        }
+        if (!got) hip_check(hipMalloc((void**)&s.d_store, bytes), "hipMalloc variable store");
         hip_check(hipMemset(s.d_store, 0, bytes), "hipMemset variable store");
         if (std::getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] %s store at %p (%zu bytes)\n", s.is_loop ? "loop" : "outer", (void*)s.d_store, bytes);
     };
