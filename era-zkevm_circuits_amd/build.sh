@@ -9,7 +9,7 @@ pids=()
 for f in zkgl_device.hip; do
   hipcc $FLAGS -c $f -o ../build/$(basename $f).o & pids+=($!)
 done
-for f in comm.cpp witness_pack.cpp cs.cpp cs_perm.cpp ntt.cpp gadgets.cpp poseidon_consts.cpp capi.cpp circuits/ram_permutation.cpp circuits/vm_shaped.cpp circuits/main_vm.cpp circuits/opcode_defs.cpp circuits/storage_validity.cpp circuits/log_sorter.cpp circuits/keccak.cpp circuits/sha256.cpp circuits/eip4844.cpp circuits/demux_log_queue.cpp circuits/sort_decommits.cpp circuits/code_unpacker.cpp circuits/linear_hasher.cpp; do
+for f in comm.cpp witness_pack.cpp vm_pack.cpp cs.cpp cs_perm.cpp ntt.cpp gadgets.cpp poseidon_consts.cpp capi.cpp circuits/ram_permutation.cpp circuits/vm_shaped.cpp circuits/main_vm.cpp circuits/opcode_defs.cpp circuits/storage_validity.cpp circuits/log_sorter.cpp circuits/keccak.cpp circuits/sha256.cpp circuits/eip4844.cpp circuits/demux_log_queue.cpp circuits/sort_decommits.cpp circuits/code_unpacker.cpp circuits/linear_hasher.cpp; do
   hipcc $FLAGS -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $f -o ../build/$(basename $f).o & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

@@ -1733,6 +1733,10 @@ void VmCircuit::entry_point(uint32_t limit) {
     for (int i = 0; i < 4; ++i) compact.push_back(g.select(completion_flag, zero_num, c_fsm_out[i]).v);
     auto input_commitment = g.commit_encoding(compact);
     for (auto& el : input_commitment) cs.place_gate(ZK_GATE_PUBLIC_INPUT, &el.v, 1, nullptr, 0);
+    // structured_input.hook_compare_witness (mod.rs:218): the groups a host compares with its own closed-form input
+    cs.hooks["hidden_fsm_output"] = fin;
+    cs.hooks["observable_output"] = observable_output;
+    cs.native_seed_kind = 1;  // the carried VmLocalState has a native walker + chain kernels (vm_native.hpp, kernels_vm_seed.hpp)
 }
 
 }  // namespace

@@ -12,6 +12,7 @@
 #include <queue>
 #include "device_api.hpp"
 #include "poseidon_consts.hpp"
+#include "../../include/zkgl_vm.h"
 
 static constexpr int ZK_MACRO_FAILURE = 0x7fff0001;  // internal: a macro check packet failed, re-run the gate-by-gate program
 
@@ -85,6 +86,9 @@ CS::~CS() {
     if (d_seed_sprog_) hipFree(d_seed_sprog_);
     if (d_seed_scarries_) hipFree(d_seed_scarries_);
     if (d_seed_carries_) hipFree(d_seed_carries_);
+    if (d_native_blob_) hipFree(d_native_blob_);
+    if (d_state0_slot_) hipFree(d_state0_slot_);
+    if (d_native_scratch_) hipFree(d_native_scratch_);
     for (auto p : d_streams_) if (p) hipFree(p);
     if (d_carries_) hipFree(d_carries_);
     for (int i = 0; i < 2; ++i) {
@@ -2111,8 +2115,69 @@ static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Sco
 }
 
 // the cone seeding launch over `n` instances: la = loop-scope arguments whose outer_cells hold the pre phase of those instances
-void CS::launch_seed(const zkdev::ScopeArgs& la, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream) {
+uint32_t CS::layout_word(const char* scope, const char* name) const {
+    const std::string key = std::string(scope) + " " + name + " ";
+    size_t pos = 0;
+    while (pos < input_layout.size()) {
+        size_t eol = input_layout.find('\n', pos);
+        if (eol == std::string::npos) eol = input_layout.size();
+        if (input_layout.compare(pos, key.size(), key) == 0) return (uint32_t)std::strtoul(input_layout.c_str() + pos + key.size(), nullptr, 10);
+        pos = eol + 1;
+    }
+    return UINT32_MAX;
+}
+
+// main_vm (native_seed_kind 1): walker + Poseidon2 chains + fill (kernels_vm_seed.hpp) instead of the cone of the carried outputs
+bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream) {
+    if (native_seed_kind != 1) return false;
+    const char* e = std::getenv("ZKGL_SEED_NATIVE");
+    if (e && e[0] == '0') return false;
+    if (circuit_blob.size() != sizeof(zk_opcode_defs)) return false;
+    zkdev::VmSeedArgs a;
+    const char* names[14] = {"code_word", "src0_read_value", "src0_read_is_ptr", "log_pubdata_refund", "log_storage_read_value", "log_rollback_queue_prev_head",
+                             "near_call_rollback_queue_tail", "far_call_code_hash_read_value", "far_call_decommit_suggested_page", "far_call_rollback_queue_tail",
+                             "ret_popped_context", "ret_previous_callstack_state", "uma_read_a", "uma_read_b"};
+    uint32_t* raw = &a.raw.code_word;
+    for (int i = 0; i < 14; ++i) {
+        raw[i] = layout_word("loop", names[i]);
+        if (raw[i] == UINT32_MAX) return false;
+    }
+    a.w_zkporter = layout_word("outer", "zkporter_is_available");
+    a.w_default_aa = layout_word("outer", "default_aa_code_hash");
+    const uint32_t w_state = layout_word("loop", "state");
+    if (a.w_zkporter == UINT32_MAX || a.w_default_aa == UINT32_MAX || w_state != 0) return false;
     hipStream_t st = (hipStream_t)stream;
+    if (!d_native_blob_) {
+        std::vector<uint32_t> slots(243, UINT32_MAX);
+        for (auto& c : carries_store_)
+            if (c.word < 243 && c.has_first) slots[c.word] = c.first_outer_cell;
+        for (uint32_t sl : slots)
+            if (sl == UINT32_MAX) return false;
+        hip_check(hipMalloc(&d_native_blob_, circuit_blob.size()), "hipMalloc vm defs");
+        hip_check(hipMemcpy(d_native_blob_, circuit_blob.data(), circuit_blob.size(), hipMemcpyHostToDevice), "copy vm defs");
+        hip_check(hipMalloc((void**)&d_state0_slot_, slots.size() * 4), "hipMalloc state0 slots");
+        hip_check(hipMemcpy(d_state0_slot_, slots.data(), slots.size() * 4, hipMemcpyHostToDevice), "copy state0 slots");
+    }
+    const size_t need = zkdev::vm_seed_scratch_bytes(limit_, n);
+    if (need > native_scratch_bytes_) {
+        if (d_native_scratch_) hipFree(d_native_scratch_);
+        d_native_scratch_ = nullptr; native_scratch_bytes_ = 0;
+        hip_check(hipMalloc((void**)&d_native_scratch_, need), "hipMalloc vm seed scratch");
+        native_scratch_bytes_ = need;
+    }
+    a.defs_dev = d_native_blob_; a.defs_host = circuit_blob.data();
+    a.loop = dev_loop_inputs_rw; a.in_stride = la.in_stride; a.limit = limit_; a.n_instances = n;
+    a.outer_store = la.outer_cells; a.outer_n_store = la.outer_n_cells; a.state0_slot = d_state0_slot_;
+    a.outer_inputs = oa.inputs; a.outer_in_stride = oa.in_stride;
+    a.scratch = d_native_scratch_;
+    const bool timed = std::getenv("ZKGL_SEED_PHASE_MS") != nullptr;
+    dev_check(zkdev::launch_vm_seed(a, st, timed ? last_seed_phase_ms : nullptr));
+    return true;
+}
+
+void CS::launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (launch_seed_native(la, oa, dev_loop_inputs_rw, n, stream)) return;
     const char* force_generic = std::getenv("ZKGL_SEED_GENERIC");
     const char* seed_strands = std::getenv("ZKGL_SEED_STRANDS");  // 0: plain cone, 1: strand form whenever it exists
     const bool generic = force_generic && force_generic[0] == '1';
@@ -2143,7 +2208,7 @@ void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {
     auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
     launch_phase(outer_, oa, 0, st);
-    launch_seed(la, dev_loop_inputs_rw, batch_, st);
+    launch_seed(la, oa, dev_loop_inputs_rw, batch_, st);
     hip_check(hipStreamSynchronize(st), "seed sync");
 }
 
@@ -2169,7 +2234,7 @@ void CS::seed_stream(uint32_t n, const uint64_t* dev_outer_inputs, uint64_t* dev
         auto oa = scope_args(o, o, l, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
         auto la = scope_args(l, o, l, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
         launch_phase(o, oa, 0, st);
-        launch_seed(la, dev_loop_inputs_rw, n, st);
+        launch_seed(la, oa, dev_loop_inputs_rw, n, st);
         hip_check(hipStreamSynchronize(st), "seed sync");
     } catch (...) {
         o.d_store = nullptr; l.d_store = nullptr;
@@ -2594,7 +2659,10 @@ void CS::stats(zk_stats* o) const {
     o->seed_ops = seed_ops_; o->seed_words = seed_prog_.size(); o->seed_slots = seed_slots_; o->loop_ops = loop_.ops.size();
 }
 
-float CS::last_ms(int which) const { return (which >= 0 && which < 5) ? ms_[which] : -1.0f; }
+float CS::last_ms(int which) const {
+    if (which >= 5 && which < 8) return last_seed_phase_ms[which - 5];  // native seeding phases (ZKGL_SEED_PHASE_MS=1): walker, chains, fill
+    return (which >= 0 && which < 5) ? ms_[which] : -1.0f;
+}
 
 // Serialised scope for the CPU oracle:
 // [magic, is_loop, n_cells, n_trace_cells, n_slots, n_copy_cols, lookup_width, n_input_words, limit,

@@ -196,7 +196,14 @@ class CS {
     void resolve(void* stream);
     // sequential seeding of the carried input words (generic, slow): see kernels_engine.hpp k_witness_seq
     void seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream);
-    void launch_seed(const zkdev::ScopeArgs& la, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream);
+    void launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream);
+    // chain-specialised seeding: a circuit whose carried state has a native walker registers it here (main_vm: kind 1).  Used by
+    // launch_seed instead of the cone kernels unless ZKGL_SEED_NATIVE=0; last_seed_phase_ms: walker / chains / fill of the last pass.
+    int native_seed_kind = 0;
+    float last_seed_phase_ms[3] = {0, 0, 0};
+    bool launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream);
+    // first word of a field of the recorded input layout ("outer" / "loop"), UINT32_MAX when absent
+    uint32_t layout_word(const char* scope, const char* name) const;
     int check_satisfied(void* stream, zk_failure* first);
     int resolve_and_check(void* stream, zk_failure* first);
     uint64_t read_var(zk_var v, uint32_t instance, uint32_t iteration);
@@ -337,6 +344,11 @@ class CS {
     uint32_t* d_ep_index_[2] = {nullptr, nullptr};
     uint64_t* d_ovr_[2] = {nullptr, nullptr};
     unsigned long long* d_fail_ = nullptr;
+    // native seeding: device copies of the circuit blob and of the state-word -> outer slot table, scratch grown on demand
+    void* d_native_blob_ = nullptr;
+    uint32_t* d_state0_slot_ = nullptr;
+    uint64_t* d_native_scratch_ = nullptr;
+    size_t native_scratch_bytes_ = 0;
     void* ev_[8] = {nullptr};
     void* ev2_[8] = {nullptr};
     void* aux_stream_ = nullptr;

@@ -59,6 +59,20 @@ struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // 
 bool seed_wave_fits(uint32_t prog_u16, uint32_t n_slots, uint32_t n_input_words);
 int launch_seed_wave(const ScopeArgs& sc, const uint16_t* prog, uint32_t prog_u16, uint32_t pro_words, uint32_t n_slots, uint32_t n_input_words,
                      const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw, uint32_t n_instances, void* stream);
+// chain-specialised main_vm seeding (kernels_vm_seed.hpp): native walker + Poseidon2 chains + fill.  Plain mirror of zkvm::SeedDev.
+struct VmRawLayout { uint32_t code_word, src0_value, src0_is_ptr, refund, log_read, log_prev_head, near_tail, far_code_hash, far_page, far_tail, ret_ctx, ret_state, uma_a, uma_b; };
+struct VmSeedArgs {
+    const void* defs_dev;            // zk_opcode_defs, device copy
+    const void* defs_host;           // the same blob on the host (derived fields are computed from it)
+    uint64_t* loop; uint64_t in_stride; uint32_t limit, n_instances;
+    VmRawLayout raw;
+    const uint64_t* outer_store; uint64_t outer_n_store; const uint32_t* state0_slot;
+    const uint64_t* outer_inputs; uint64_t outer_in_stride; uint32_t w_zkporter, w_default_aa;
+    uint64_t* scratch;               // vm_seed_scratch_bytes(limit, n_instances) bytes
+};
+size_t vm_seed_scratch_bytes(uint32_t limit, uint32_t n_instances);
+// phase_ms (optional, 3 floats): walker / chains / fill, measured with events on `stream` (synchronises)
+int launch_vm_seed(const VmSeedArgs& a, void* stream, float* phase_ms);
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);
 int launch_check_gates(const CheckArgs& cd, void* stream);

@@ -2,6 +2,7 @@
 // Kernels live in kernels_primitives.hpp / kernels_engine.hpp; this file holds the launchers.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <string>
 #include "device_api.hpp"
@@ -9,6 +10,7 @@
 #include "kernels_engine.hpp"
 #include "kernels_engine2.hpp"
 #include "kernels_seed_wave.hpp"
+#include "kernels_vm_seed.hpp"
 #include "kernels_lookup_arg.hpp"
 #include "kernels_ntt.hpp"
 #include "kernels_perm.hpp"
@@ -408,6 +410,73 @@ int launch_seed_wave(const ScopeArgs& sc, const uint16_t* prog, uint32_t prog_u1
     const unsigned grid = (n_instances + waves - 1) / waves;
     zke::k_seed_wave<<<grid, 64 * waves, 0, (hipStream_t)stream>>>(a);
     return LAUNCH_CHECK("k_seed_wave");
+}
+
+// ---- chain-specialised main_vm seeding
+namespace {
+struct VmScratch { size_t mem_ev, dec_ev, fwd_ev, sp_ev, mem_snap, dec_snap, fwd_snap, sp_snap, counts, totals, end; };
+VmScratch vm_scratch_layout(uint32_t limit, uint32_t n) {
+    VmScratch L;
+    const size_t cap_mem = (size_t)limit * zkvm::MEM_EVENTS_PER_CYCLE, cap_one = limit;
+    size_t off = 0;
+    auto take = [&](size_t words) { const size_t o = off; off += (words * 8 + 255) & ~(size_t)255; return o; };
+    L.mem_ev = take((size_t)n * cap_mem * zkvm::EV_MEM);
+    L.dec_ev = take((size_t)n * cap_one * zkvm::EV_DEC);
+    L.fwd_ev = take((size_t)n * cap_one * zkvm::EV_FWD);
+    L.sp_ev = take((size_t)n * cap_one * zkvm::EV_SP);
+    L.mem_snap = take((size_t)n * cap_mem * 12);
+    L.dec_snap = take((size_t)n * cap_one * 12);
+    L.fwd_snap = take((size_t)n * cap_one * 4);
+    L.sp_snap = take((size_t)n * cap_one * 12);
+    L.counts = take((size_t)n * limit * 2);
+    L.totals = take((size_t)n * 2);
+    L.end = off;
+    return L;
+}
+}  // namespace
+size_t vm_seed_scratch_bytes(uint32_t limit, uint32_t n_instances) { return vm_scratch_layout(limit, n_instances).end; }
+
+int launch_vm_seed(const VmSeedArgs& v, void* stream, float* phase_ms) {
+    if (v.n_instances == 0 || v.limit == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    zkvm::SeedDev a;
+    vmn::defs_prepare(a.D, (const zk_opcode_defs*)v.defs_host, (const zk_opcode_defs*)v.defs_dev);
+    a.loop = v.loop; a.in_stride = v.in_stride; a.limit = v.limit; a.n_instances = v.n_instances;
+    static_assert(sizeof(zkvm::RawLayout) == sizeof(VmRawLayout), "layout mirrors");
+    std::memcpy(&a.raw, &v.raw, sizeof a.raw);
+    a.outer_store = v.outer_store; a.outer_n_store = v.outer_n_store; a.state0_slot = v.state0_slot;
+    a.outer_inputs = v.outer_inputs; a.outer_in_stride = v.outer_in_stride; a.w_zkporter = v.w_zkporter; a.w_default_aa = v.w_default_aa;
+    const VmScratch L = vm_scratch_layout(v.limit, v.n_instances);
+    char* const base = (char*)v.scratch;
+    a.mem_ev = (uint64_t*)(base + L.mem_ev); a.dec_ev = (uint64_t*)(base + L.dec_ev); a.fwd_ev = (uint64_t*)(base + L.fwd_ev); a.sp_ev = (uint64_t*)(base + L.sp_ev);
+    a.mem_snap = (uint64_t*)(base + L.mem_snap); a.dec_snap = (uint64_t*)(base + L.dec_snap); a.fwd_snap = (uint64_t*)(base + L.fwd_snap);
+    a.sp_snap = (uint64_t*)(base + L.sp_snap);
+    a.counts = (uint4*)(base + L.counts); a.totals = (uint4*)(base + L.totals);
+    a.cap_mem = v.limit * zkvm::MEM_EVENTS_PER_CYCLE; a.cap_one = v.limit;
+    // phase A: few instances per wavefront (instances on different opcodes serialise each other inside a wavefront); fill the SIMDs first
+    uint32_t lpw = 1;
+    if (const char* e = std::getenv("ZKGL_VM_WALK_LANES")) lpw = (uint32_t)std::max(1, atoi(e));
+    else while (lpw < 64 && (v.n_instances + lpw - 1) / lpw > 2048) lpw *= 2;
+    a.lanes_per_wave = std::min<uint32_t>(lpw, 64);
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (phase_ms) for (auto& e : ev) if (int r = chk(hipEventCreate(&e), "hipEventCreate")) return r;
+    if (phase_ms) hipEventRecord(ev[0], st);
+    zkvm::k_vm_walk<<<(v.n_instances + a.lanes_per_wave - 1) / a.lanes_per_wave, 64, 0, st>>>(a);
+    if (int r = LAUNCH_CHECK("k_vm_walk")) return r;
+    if (phase_ms) hipEventRecord(ev[1], st);
+    const uint64_t groups = (uint64_t)v.n_instances * 4, per_block = 4 * zkvm::CH_GROUPS;
+    zkvm::k_vm_chains<<<(unsigned)((groups + per_block - 1) / per_block), 256, 0, st>>>(a);
+    if (int r = LAUNCH_CHECK("k_vm_chains")) return r;
+    if (phase_ms) hipEventRecord(ev[2], st);
+    zkvm::k_vm_fill<<<grid_for((size_t)v.n_instances * v.limit, 256), 256, 0, st>>>(a);
+    if (int r = LAUNCH_CHECK("k_vm_fill")) return r;
+    if (phase_ms) {
+        hipEventRecord(ev[3], st);
+        if (int r = chk(hipEventSynchronize(ev[3]), "vm seed sync")) return r;
+        for (int i = 0; i < 3; ++i) hipEventElapsedTime(&phase_ms[i], ev[i], ev[i + 1]);
+        for (auto& e : ev) hipEventDestroy(e);
+    }
+    return 0;
 }
 
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,

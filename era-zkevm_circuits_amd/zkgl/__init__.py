@@ -605,6 +605,83 @@ class OpcodeDefs(C.Structure):
         return r
 
 
+class VmMemoryWitness(C.Structure):          # zk_vm_memory_witness
+    _fields_ = [("value", C.c_uint32 * 8), ("is_ptr", C.c_uint32)]
+
+
+class VmCallstackWitness(C.Structure):       # zk_vm_callstack_witness
+    _fields_ = [("context", C.c_uint64 * 42), ("state", C.c_uint64 * 12)]
+
+
+class VmWitnessOracle(C.Structure):          # zk_vm_witness_oracle: one FIFO per WitnessOracle getter (witness_oracle.rs:45-91)
+    _fields_ = [("memory_reads", C.POINTER(VmMemoryWitness)), ("n_memory_reads", C.c_size_t),
+                ("storage_reads", C.POINTER(C.c_uint32 * 8)), ("n_storage_reads", C.c_size_t),
+                ("refunds", C.POINTER(C.c_uint32)), ("n_refunds", C.c_size_t),
+                ("rollback_queue_witness", C.POINTER(C.c_uint64 * 4)), ("n_rollback_queue_witness", C.c_size_t),
+                ("rollback_tails_for_call", C.POINTER(C.c_uint64 * 4)), ("n_rollback_tails_for_call", C.c_size_t),
+                ("callstack", C.POINTER(VmCallstackWitness)), ("n_callstack", C.c_size_t),
+                ("decommit_pages", C.POINTER(C.c_uint32)), ("n_decommit_pages", C.c_size_t)]
+
+
+class VmClosedFormInput(C.Structure):        # zk_vm_closed_form_input
+    _fields_ = [("start_flag", C.c_uint32), ("rollback_queue_tail_for_block", C.c_uint64 * 4),
+                ("memory_queue_initial_tail", C.c_uint64 * 12), ("memory_queue_initial_length", C.c_uint32),
+                ("decommitment_queue_initial_tail", C.c_uint64 * 12), ("decommitment_queue_initial_length", C.c_uint32),
+                ("zkporter_is_available", C.c_uint32), ("default_aa_code_hash", C.c_uint32 * 8), ("hidden_fsm_input", C.c_uint64 * 243)]
+
+
+class VmPackReport(C.Structure):             # zk_vm_pack_report
+    _fields_ = [("used_memory_reads", C.c_size_t), ("used_storage_reads", C.c_size_t), ("used_refunds", C.c_size_t),
+                ("used_rollback_queue_witness", C.c_size_t), ("used_rollback_tails_for_call", C.c_size_t), ("used_callstack", C.c_size_t),
+                ("used_decommit_pages", C.c_size_t), ("underflow", C.c_uint32), ("final_state", C.c_uint64 * 243)]
+
+
+VM_PACK_FILL_STATE = 1
+
+
+class VmOracleQueues:
+    """the WitnessOracle's per-getter FIFOs as Python lists; view(used) -> the zk_vm_witness_oracle of what is left"""
+
+    def __init__(self):
+        self.memory_reads, self.storage_reads, self.refunds = [], [], []
+        self.rollback_queue_witness, self.rollback_tails_for_call, self.callstack, self.decommit_pages = [], [], [], []
+
+    def freeze(self):
+        self._mem = (VmMemoryWitness * max(1, len(self.memory_reads)))()
+        for i, (v, p) in enumerate(self.memory_reads):
+            self._mem[i].value[:] = [int(x) for x in v]
+            self._mem[i].is_ptr = int(p)
+        self._sto = ((C.c_uint32 * 8) * max(1, len(self.storage_reads)))()
+        for i, v in enumerate(self.storage_reads):
+            self._sto[i][:] = [int(x) for x in v]
+        self._ref = (C.c_uint32 * max(1, len(self.refunds)))(*[int(x) for x in self.refunds])
+        self._rq = ((C.c_uint64 * 4) * max(1, len(self.rollback_queue_witness)))()
+        for i, v in enumerate(self.rollback_queue_witness):
+            self._rq[i][:] = [int(x) for x in v]
+        self._ct = ((C.c_uint64 * 4) * max(1, len(self.rollback_tails_for_call)))()
+        for i, v in enumerate(self.rollback_tails_for_call):
+            self._ct[i][:] = [int(x) for x in v]
+        self._cs = (VmCallstackWitness * max(1, len(self.callstack)))()
+        for i, (ctx, st) in enumerate(self.callstack):
+            self._cs[i].context[:] = [int(x) for x in ctx]
+            self._cs[i].state[:] = [int(x) for x in st]
+        self._dp = (C.c_uint32 * max(1, len(self.decommit_pages)))(*[int(x) for x in self.decommit_pages])
+        return self
+
+    def view(self, used=(0,) * 7) -> VmWitnessOracle:
+        o = VmWitnessOracle()
+        def sub(arr, n, k, typ):
+            return C.cast(C.byref(arr, k * C.sizeof(arr._type_)), C.POINTER(typ)), n - k
+        o.memory_reads, o.n_memory_reads = sub(self._mem, len(self.memory_reads), used[0], VmMemoryWitness)
+        o.storage_reads, o.n_storage_reads = sub(self._sto, len(self.storage_reads), used[1], C.c_uint32 * 8)
+        o.refunds, o.n_refunds = sub(self._ref, len(self.refunds), used[2], C.c_uint32)
+        o.rollback_queue_witness, o.n_rollback_queue_witness = sub(self._rq, len(self.rollback_queue_witness), used[3], C.c_uint64 * 4)
+        o.rollback_tails_for_call, o.n_rollback_tails_for_call = sub(self._ct, len(self.rollback_tails_for_call), used[4], C.c_uint64 * 4)
+        o.callstack, o.n_callstack = sub(self._cs, len(self.callstack), used[5], VmCallstackWitness)
+        o.decommit_pages, o.n_decommit_pages = sub(self._dp, len(self.decommit_pages), used[6], C.c_uint32)
+        return o
+
+
 def opcode_defs_default() -> OpcodeDefs:
     d = OpcodeDefs()
     _check(lib().zk_opcode_defs_default(C.byref(d)))
@@ -853,6 +930,16 @@ class ConstraintSystem:
             scope, name, first, cnt = line.split()
             out[scope][name] = (int(first), int(cnt))
         return out
+
+    def pack_main_vm_witness(self, closed_form: "VmClosedFormInput", oracle: "VmWitnessOracle", instance: int, batch: int,
+                             outer_words: np.ndarray, loop_words: np.ndarray, flags: int = 0) -> "VmPackReport":
+        """zk_pack_main_vm_witness: one chunk into outer_words [words, batch] / loop_words [words, batch * limit] (C-contiguous u64)"""
+        assert outer_words.dtype == np.uint64 and loop_words.dtype == np.uint64 and outer_words.flags.c_contiguous and loop_words.flags.c_contiguous
+        rep = VmPackReport()
+        _check(lib().zk_pack_main_vm_witness(self._h, C.byref(closed_form), C.byref(oracle), C.c_uint32(instance), C.c_uint32(batch),
+                                             outer_words.ctypes.data_as(C.c_void_p), loop_words.ctypes.data_as(C.c_void_p), C.c_uint32(flags),
+                                             C.byref(rep)))
+        return rep
 
     def input_words(self):
         a, b = C.c_uint32(), C.c_uint32()

@@ -283,7 +283,9 @@ int zk_cs_lookup_argument(zk_cs *cs, const uint64_t beta[2], const uint64_t gamm
 int zk_cs_stats(zk_cs *cs, zk_stats *out);           /* print_gate_stats counterpart */
 /* last execution times in ms measured with HIP events on the execution stream:
  * which: 0 resolve total (fused: whole pipeline), 1 loop witness kernel, 2 check total (fused: loop gates+copies),
- * 3 gate-check loop kernel, 4 outer kernels (fused: outer post + outer checks) */
+ * 3 gate-check loop kernel, 4 outer kernels (fused: outer post + outer checks);
+ * 5 / 6 / 7: the last seeding pass of a circuit with a native seeder (main_vm) when ZKGL_SEED_PHASE_MS is set: state walker,
+ * Poseidon2 chains, fill */
 int zk_cs_last_ms(zk_cs *cs, int which, float *ms);
 /* serialised scope (program + descriptors) for the CPU oracle / offline tooling.
  * Call with buf = NULL to get the size in words. */

@@ -106,6 +106,50 @@ int zk_circuit_main_vm(zk_cs *cs, uint32_t limit);
  * (scope = outer | loop).  buf = NULL returns the size. */
 int zk_circuit_main_vm_layout(zk_cs *cs, char *buf, size_t max_bytes, size_t *n_bytes);
 
+/* ---- product-side input path of main_vm: VmCircuitWitness { closed_form_input, witness_oracle }
+ * (/root/reference/src/fsm_input_output/circuit_inputs/main_vm.rs:64-71) -> the circuit's two input streams.
+ *
+ * The reference's WitnessOracle (src/main_vm/witness_oracle.rs:45-91) is a trait whose getters answer only under `execute`; the
+ * production implementation keeps one FIFO per getter.  zk_vm_witness_oracle is exactly that: the answers of every getter in call
+ * order, consumed front to back by the calls made with execute == true.  The streams want every answer AT ITS CYCLE, and which
+ * cycle pops which queue depends on the VM state (decode, `execute` flags) — so the packer walks the cycles natively
+ * (csrc/vm_native.hpp: the same walker the device seeding runs) and never hashes. */
+typedef struct zk_vm_memory_witness { uint32_t value[8]; uint32_t is_ptr; } zk_vm_memory_witness;        /* MemoryWitness :9-13 */
+typedef struct zk_vm_callstack_witness { uint64_t context[42]; uint64_t state[12]; } zk_vm_callstack_witness;
+                                            /* (ExecutionContextRecordWitness flattened as saved_context.rs:279-323, [F; 12]) */
+typedef struct zk_vm_witness_oracle {
+    const zk_vm_memory_witness *memory_reads; size_t n_memory_reads;             /* get_memory_witness_for_read: code word, src0, UMA a, UMA b */
+    const uint32_t (*storage_reads)[8]; size_t n_storage_reads;                  /* get_storage_read_witness (needs_witness && execute): LOG, far-call code hash */
+    const uint32_t *refunds; size_t n_refunds;                                   /* get_refunds */
+    const uint64_t (*rollback_queue_witness)[4]; size_t n_rollback_queue_witness;/* get_rollback_queue_witness: the claimed previous head */
+    const uint64_t (*rollback_tails_for_call)[4]; size_t n_rollback_tails_for_call; /* get_rollback_queue_tail_witness_for_call: near / far call */
+    const zk_vm_callstack_witness *callstack; size_t n_callstack;                /* get_callstack_witness: ret */
+    const uint32_t *decommit_pages; size_t n_decommit_pages;                     /* get_decommittment_request_suggested_page */
+} zk_vm_witness_oracle;
+/* VmCircuitInputOutputWitness: start_flag, VmInputData (circuit_inputs/main_vm.rs:9-17), hidden_fsm_input = VmLocalState flattened in
+ * declaration order (src/base_structures/vm_state/mod.rs:92-109; 243 words, ignored under start_flag) */
+typedef struct zk_vm_closed_form_input {
+    uint32_t start_flag;
+    uint64_t rollback_queue_tail_for_block[4];
+    uint64_t memory_queue_initial_tail[12]; uint32_t memory_queue_initial_length;
+    uint64_t decommitment_queue_initial_tail[12]; uint32_t decommitment_queue_initial_length;
+    uint32_t zkporter_is_available; uint32_t default_aa_code_hash[8];
+    uint64_t hidden_fsm_input[243];
+} zk_vm_closed_form_input;
+typedef struct zk_vm_pack_report {
+    size_t used_memory_reads, used_storage_reads, used_refunds, used_rollback_queue_witness, used_rollback_tails_for_call, used_callstack,
+        used_decommit_pages;      /* how far every FIFO was consumed: the next chunk of the same execution continues there */
+    uint32_t underflow;           /* a getter was called under `execute` with its FIFO empty (answered with zeros) */
+    uint64_t final_state[243];    /* hidden_fsm_output of this chunk (hash-chain words valid only with ZK_VM_PACK_FILL_STATE) */
+} zk_vm_pack_report;
+#define ZK_VM_PACK_FILL_STATE 1u  /* also write the 243 VmLocalState words of every cycle (host-side chains: one core, for hosts
+                                     that want a finished stream; the default leaves them to zk_cs_seed_stream on the device) */
+/* One instance (chunk of `limit` cycles of the recorded circuit) into the batch's host staging arrays, in the layout of every other
+ * packer (include/zkgl_witness.h): outer_words[w * batch + instance], loop_words[w * (batch * limit) + instance * limit + cycle].
+ * ZK_ERR_INVALID: cs is not a recorded main_vm circuit.  FIFO underflow is reported, not fatal (the circuit will reject the trace). */
+int zk_pack_main_vm_witness(zk_cs *cs, const zk_vm_closed_form_input *input, const zk_vm_witness_oracle *oracle, uint32_t instance, uint32_t batch,
+                            uint64_t *outer_words, uint64_t *loop_words, uint32_t flags, zk_vm_pack_report *report);
+
 #ifdef __cplusplus
 }
 #endif

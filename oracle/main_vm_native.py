@@ -343,6 +343,9 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
     ts1, ts2, ts3 = ts0 + 1, ts0 + 2, ts0 + 3
     code_word = world.memory.get((c.code_page, super_pc), (0, 0))[0] if should_read_opcode else 0
     W["code_word"] = limbs(code_word)
+    calls = W["_oracle_calls"] = []   # the getters answered under execute == true, in call order (witness_oracle.rs:45-91)
+    if should_read_opcode:
+        calls.append(("memory_read", limbs(code_word), 0))
     if should_read_opcode:
         st.mem_tail = push12(st.mem_tail, memory_query_encode(ts0, c.code_page, super_pc, 0, 0, code_word))
         st.mem_len += 1
@@ -415,6 +418,8 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
     # may_be_read_memory_for_source_operand (utils.rs:388-522)
     mem_val, mem_ptr = world.memory.get((src0_page, src0_index), (0, 0)) if should_read_src0 else (0, 0)
     W["src0_read_value"], W["src0_read_is_ptr"] = limbs(mem_val), [mem_ptr]
+    if should_read_src0:
+        calls.append(("memory_read", limbs(mem_val), mem_ptr))
     if should_read_src0:
         st.mem_tail = push12(st.mem_tail, memory_query_encode(ts0, src0_page, src0_index, 0, mem_ptr, mem_val))
         st.mem_len += 1
@@ -558,6 +563,7 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
             (D.p("PRECOMPILE_AUX_BYTE") if is_pre else 0)
         refund = world.refund
         W["log_pubdata_refund"] = [refund]
+        calls.append(("refund", refund))
         burn = 0
         if is_write and dc.this_shard == 0:
             burn = draft.ergs_per_pubdata * (D.p("INITIAL_STORAGE_WRITE_PUBDATA_BYTES") - refund)
@@ -573,6 +579,8 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
         skey = (dc.this_shard, dc.this, key)
         read_w = world.storage.get(skey, 0) if (execute and is_storage) else 0
         W["log_storage_read_value"] = limbs(read_w)
+        if execute and is_storage:
+            calls.append(("storage_read", limbs(read_w)))
         read_value = read_w if is_storage else 0
         written = s1 if is_revertable else read_value
         q = log_words(dc.this, key, read_value, written, is_revertable, aux_byte, 0, flag("FIRST_MESSAGE"), dc.this_shard, draft.tx_number, ts1)
@@ -589,6 +597,7 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
         if execute_rollback:
             prev_head = rec.log_prev_head()
             W["log_rollback_queue_prev_head"] = list(prev_head)
+            calls.append(("rollback_queue_witness", list(prev_head)))
             rec.events.append(("write", rb_enc))
             if rec.plan:
                 assert push4(prev_head, rb_enc) == list(dc.rq_head), "rollback head claim does not hash to the current head"
@@ -639,6 +648,10 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
         va = world.memory.get((mem_page, cell), (0, 0))[0] if read_a else 0
         vb = world.memory.get((mem_page, cell_b), (0, 0))[0] if read_b else 0
         W["uma_read_a"], W["uma_read_b"] = limbs(va), limbs(vb)
+        if read_a:
+            calls.append(("memory_read", limbs(va), 0))
+        if read_b:
+            calls.append(("memory_read", limbs(vb), 0))
         tail, ln = draft.mem_tail, draft.mem_len
         if read_a:
             tail, ln = push12(tail, memory_query_encode(ts0, mem_page, cell, 0, 0, va)), ln + 1
@@ -695,6 +708,7 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
             new_ctx = copy.deepcopy(old_ctx)
             tail = rec.call_tail()
             W["near_call_rollback_queue_tail"] = list(tail)
+            calls.append(("rollback_tail_for_call", list(tail)))
             rec.events.append(("call",))
             new_ctx.rq_tail, new_ctx.rq_head, new_ctx.rq_len = list(tail), list(tail), 0
             passed_abi = s0l[0]
@@ -732,6 +746,8 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
             dkey = (dest_shard, D.p("DEPLOYER_SYSTEM_CONTRACT_ADDRESS_LOW"), destination)
             code_hash = world.storage.get(dkey, 0) if should_read else 0
             W["far_call_code_hash_read_value"] = limbs(code_hash)
+            if should_read:
+                calls.append(("storage_read", limbs(code_hash)))
             q = log_words(D.p("DEPLOYER_SYSTEM_CONTRACT_ADDRESS_LOW"), destination, code_hash, code_hash, 0, D.p("STORAGE_AUX_BYTE"), 0, 0, dest_shard, draft.tx_number, ts1)
             new_fwd_tail, new_fwd_len = draft.fwd_tail, draft.fwd_len
             if should_read:
@@ -790,6 +806,8 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
                     if code is not None:
                         world.load_code(target_page, code)
             W["far_call_decommit_suggested_page"] = [suggested]
+            if should_decommit:
+                calls.append(("decommit_page", suggested))
             is_first = int(target_page == suggested)
             if should_decommit and not is_first:
                 ergs_rem = ergs_after_growth
@@ -800,6 +818,7 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
             pend = int(exception or ufd)
             tail = rec.call_tail()
             W["far_call_rollback_queue_tail"] = list(tail)
+            calls.append(("rollback_tail_for_call", list(tail)))
             rec.events.append(("call",))
             new_ctx.rq_tail, new_ctx.rq_head, new_ctx.rq_len = list(tail), list(tail), 0
             max_passable = (ergs_rem // 64) * 63
@@ -838,6 +857,7 @@ def vm_cycle(D: Defs, st: VmState, world: World, rec: Recorder, gctx):
             r0p = 0 if is_panic else s0p
             popped, prev_sponge = world.callstack.pop() if world.callstack else (Ctx(), [0] * 12)
             W["ret_popped_context"], W["ret_previous_callstack_state"] = popped.flatten(), list(prev_sponge)
+            calls.append(("callstack", popped.flatten(), list(prev_sponge)))
             old_ctx = copy.deepcopy(popped)
             new_ctx = copy.deepcopy(popped)
             is_far_return = not is_local

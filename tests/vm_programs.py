@@ -418,3 +418,62 @@ def mixed_batch(cs, D, limit, min_instances, seeds=None):
             info += [(name, seed, i) for i in range(n_inst)]
         seed += 1
     return np.concatenate(outers, axis=1), np.concatenate(loops, axis=1), commits, info
+
+
+# ------------------------------------------------------------------------------------------------ the product-side input path
+def oracle_queues(run: "vn.VmRun", first_cycle=0, n_cycles=None):
+    """the reference WitnessOracle's per-getter FIFOs (witness_oracle.rs:45-91) of an execution, from the calls the native model
+    answered under execute == true — what a host holding a VmCircuitWitness has (NOT placed at cycles)"""
+    q = zkgl.VmOracleQueues()
+    rows = run.rows[first_cycle:] if n_cycles is None else run.rows[first_cycle:first_cycle + n_cycles]
+    for _, W in rows:
+        for call in W["_oracle_calls"]:
+            kind = call[0]
+            if kind == "memory_read":
+                q.memory_reads.append((call[1], call[2]))
+            elif kind == "storage_read":
+                q.storage_reads.append(call[1])
+            elif kind == "refund":
+                q.refunds.append(call[1])
+            elif kind == "rollback_queue_witness":
+                q.rollback_queue_witness.append(call[1])
+            elif kind == "rollback_tail_for_call":
+                q.rollback_tails_for_call.append(call[1])
+            elif kind == "callstack":
+                q.callstack.append((call[1], call[2]))
+            elif kind == "decommit_page":
+                q.decommit_pages.append(call[1])
+            else:
+                raise KeyError(kind)
+    return q.freeze()
+
+
+def closed_form_input(run: "vn.VmRun", c0):
+    """VmCircuitInputOutputWitness of the chunk that starts at cycle c0 (circuit_inputs/main_vm.rs:7-62)"""
+    cf = zkgl.VmClosedFormInput()
+    cf.start_flag = 1 if c0 == 0 else 0
+    cf.rollback_queue_tail_for_block[:] = [int(x) for x in run.rollback_tail_for_block]
+    zporter, default_aa = run.gctx
+    cf.zkporter_is_available = int(zporter)
+    cf.default_aa_code_hash[:] = vn.limbs(default_aa)
+    if c0:
+        cf.hidden_fsm_input[:] = [int(x) for x in run.states[c0].flatten()]
+    return cf
+
+
+def pack_through_the_c_abi(cs, run: "vn.VmRun", limit, n_instances, first_cycle=0, fill_state=False):
+    """(outer, loop, reports): consecutive chunks of one execution through zk_pack_main_vm_witness, the FIFOs continued chunk to chunk"""
+    ow, lw = cs.input_words()
+    outer = np.zeros((ow, n_instances), dtype=np.uint64)
+    loop = np.zeros((lw, n_instances * limit), dtype=np.uint64)
+    q = oracle_queues(run, first_cycle, n_instances * limit)
+    used = [0] * 7
+    reports = []
+    for i in range(n_instances):
+        rep = cs.pack_main_vm_witness(closed_form_input(run, first_cycle + i * limit), q.view(used), i, n_instances, outer, loop,
+                                      zkgl.VM_PACK_FILL_STATE if fill_state else 0)
+        got = [rep.used_memory_reads, rep.used_storage_reads, rep.used_refunds, rep.used_rollback_queue_witness, rep.used_rollback_tails_for_call,
+               rep.used_callstack, rep.used_decommit_pages]
+        used = [a + b for a, b in zip(used, got)]
+        reports.append(rep)
+    return outer, loop, reports
