@@ -2166,7 +2166,7 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
         native_scratch_bytes_ = need;
     }
     a.defs_dev = d_native_blob_; a.defs_host = circuit_blob.data();
-    a.loop = dev_loop_inputs_rw; a.in_stride = la.in_stride; a.limit = limit_; a.n_instances = n;
+    a.loop = dev_loop_inputs_rw; a.in_stride = la.in_stride; a.limit = limit_; a.n_instances = n; a.n_loop_words = loop_.n_input_words;
     a.outer_store = la.outer_cells; a.outer_n_store = la.outer_n_cells; a.state0_slot = d_state0_slot_;
     a.outer_inputs = oa.inputs; a.outer_in_stride = oa.in_stride;
     a.scratch = d_native_scratch_;

@@ -64,7 +64,7 @@ struct VmRawLayout { uint32_t code_word, src0_value, src0_is_ptr, refund, log_re
 struct VmSeedArgs {
     const void* defs_dev;            // zk_opcode_defs, device copy
     const void* defs_host;           // the same blob on the host (derived fields are computed from it)
-    uint64_t* loop; uint64_t in_stride; uint32_t limit, n_instances;
+    uint64_t* loop; uint64_t in_stride; uint32_t limit, n_instances, n_loop_words;
     VmRawLayout raw;
     const uint64_t* outer_store; uint64_t outer_n_store; const uint32_t* state0_slot;
     const uint64_t* outer_inputs; uint64_t outer_in_stride; uint32_t w_zkporter, w_default_aa;

@@ -14,6 +14,7 @@
 // Values that the circuit range-checks are carried as u32; the walker never fails: on inputs no satisfiable trace has, it produces
 // SOME state and the circuit's own links / gates report the trace.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include "../../include/zkgl_vm.h"
 
@@ -63,32 +64,48 @@ struct State {
     Ctx ctx;
     u32 fwd_len, depth, mem_len, dec_len;
     u32 ctx_u128[4];
+    u32 last_family;  // bookkeeping (profiling / tests): the family the last cycle applied; not a state word
 };
 
-// the blob plus what the walker derives from it once (host side, vm_defs_prepare)
+// the blob as the walker wants it: the two 2048-row tables by pointer (host or device memory, matching the caller), everything
+// else BY VALUE — as a kernel argument these become scalar loads of the kernarg segment instead of dependent global loads
+struct DefsSmall {
+    u32 type_bits, variant_bits, flag_bits, src_mode_bits, dst_mode_bits, description_bits_flattened, aux_bits;
+    u32 aux_kernel_mode, aux_static_ok, aux_explicit_panic;
+    u32 variant_idx[ZK_VMV__COUNT], flag_idx[ZK_VMFL__COUNT], condition_idx[ZK_VMC__COUNT], can_write_dst0_into_memory[ZK_VMF__COUNT];
+    u64 nop_encoding, panic_encoding, nop_bitspread, panic_bitspread;
+    u32 params[ZK_VMP__COUNT];
+};
 struct Defs {
-    const zk_opcode_defs* d;   // host or device pointer, matching the caller
+    DefsSmall s;
+    const u64* props;
+    const u32* prices;
     u32 variant_bit0, flag_bit0, src_bit0, dst_bit0, aux_bit0;
     u64 props_mask;
-    u32 cond_of_key[8];        // condition key (3 bits of the opcode) -> zk_vm_condition, 0xff = not a key
-    u32 zkporter_is_available;
-    U256 default_aa_code_hash;
 };
+// GlobalContext (src/base_structures/vm_state/mod.rs: per_block_context), per instance
+struct Gctx { u32 zkporter_is_available; U256 default_aa_code_hash; };
 
-VMN_HD void defs_prepare(Defs& D, const zk_opcode_defs* host_view, const zk_opcode_defs* use_ptr) {
+// host_view: the blob in host memory; tables: where props / prices live for the code that will walk (the same blob, or its device copy)
+inline void defs_prepare(Defs& D, const zk_opcode_defs* host_view, const zk_opcode_defs* tables) {
     const zk_opcode_defs& d = *host_view;
-    D.d = use_ptr;
+    DefsSmall& t = D.s;
+    t.type_bits = d.type_bits; t.variant_bits = d.variant_bits; t.flag_bits = d.flag_bits; t.src_mode_bits = d.src_mode_bits;
+    t.dst_mode_bits = d.dst_mode_bits; t.description_bits_flattened = d.description_bits_flattened; t.aux_bits = d.aux_bits;
+    t.aux_kernel_mode = d.aux_kernel_mode; t.aux_static_ok = d.aux_static_ok; t.aux_explicit_panic = d.aux_explicit_panic;
+    for (int i = 0; i < ZK_VMV__COUNT; ++i) t.variant_idx[i] = d.variant_idx[i];
+    for (int i = 0; i < ZK_VMFL__COUNT; ++i) t.flag_idx[i] = d.flag_idx[i];
+    for (int i = 0; i < ZK_VMC__COUNT; ++i) t.condition_idx[i] = d.condition_idx[i];
+    for (int i = 0; i < ZK_VMF__COUNT; ++i) t.can_write_dst0_into_memory[i] = d.can_write_dst0_into_memory[i];
+    t.nop_encoding = d.nop_encoding; t.panic_encoding = d.panic_encoding; t.nop_bitspread = d.nop_bitspread; t.panic_bitspread = d.panic_bitspread;
+    for (int i = 0; i < ZK_VMP__COUNT; ++i) t.params[i] = d.params[i];
+    D.props = tables->props; D.prices = tables->prices;
     D.variant_bit0 = d.type_bits;
     D.flag_bit0 = D.variant_bit0 + d.variant_bits;
     D.src_bit0 = D.flag_bit0 + d.flag_bits;
     D.dst_bit0 = D.src_bit0 + d.src_mode_bits;
     D.aux_bit0 = d.description_bits_flattened;
     D.props_mask = (1ull << d.description_bits_flattened) - 1;
-    for (int i = 0; i < 8; ++i) D.cond_of_key[i] = 0xff;
-    for (int c = 0; c < ZK_VMC__COUNT; ++c)
-        if (d.condition_idx[c] < 8) D.cond_of_key[d.condition_idx[c]] = (u32)c;
-    D.zkporter_is_available = 0;
-    for (int i = 0; i < 8; ++i) D.default_aa_code_hash.l[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ flatten / unflatten
@@ -117,6 +134,26 @@ VMN_HD void ctx_unflatten(Ctx& c, const u64* f) {
     c.is_static = (u32)f[n++]; c.is_kernel = (u32)f[n++]; c.this_shard = (u32)f[n++]; c.caller_shard = (u32)f[n++]; c.code_shard = (u32)f[n++];
     for (int i = 0; i < 4; ++i) c.ctx_u128[i] = (u32)f[n++];
     c.is_local = (u32)f[n++];
+}
+static_assert(offsetof(State, regs) == 4 * SW_REGS && offsetof(State, of) == 4 * SW_FLAGS && offsetof(State, timestamp) == 4 * SW_TIMESTAMP &&
+              offsetof(State, ergs_per_pubdata) == 4 * SW_ERGS_PER_PUBDATA && sizeof(Reg) == 36, "State: the words before the context are u32 in flatten order");
+static_assert(offsetof(Ctx, aux_heap_bound) == 4 * 18 && offsetof(Ctx, pc) == offsetof(Ctx, rq_len) + 4 && offsetof(Ctx, is_local) == offsetof(Ctx, rq_len) + 4 * 14,
+              "Ctx: u32 runs in flatten order around the two u64 queue states");
+// word w of the flattened VmLocalState read straight from the struct (chain words: 0) — the struct is the walker's working state, so
+// nothing has to be flattened per cycle; every lane of a wavefront can fetch some of the words
+VMN_HD u64 state_word(const State& s, int w) {
+    const char* const base = (const char*)&s;
+    if (w < SW_CTX) return *(const u32*)(base + 4 * w);     // prev_code_word, regs, flags, scalars: u32 words in declaration order
+    if (w < SW_CTX + 19) return *(const u32*)((const char*)&s.ctx + 4 * (w - SW_CTX));
+    if (w < SW_CTX + 23) return s.ctx.rq_head[w - (SW_CTX + 19)];
+    if (w < SW_CTX + 27) return s.ctx.rq_tail[w - (SW_CTX + 23)];
+    if (w < SW_CTX + CTX_WORDS) return *(const u32*)((const char*)&s.ctx.rq_len + 4 * (w - (SW_CTX + 27)));
+    if (w == SW_FWD_LEN) return s.fwd_len;
+    if (w == SW_DEPTH) return s.depth;
+    if (w == SW_MEM_LEN) return s.mem_len;
+    if (w == SW_DEC_LEN) return s.dec_len;
+    if (w >= SW_CTX_U128 && w < SW_CTX_U128 + 4) return s.ctx_u128[w - SW_CTX_U128];
+    return 0;
 }
 // every non-chain word of the state through `put(word index, value)`
 template <class Put>
@@ -230,7 +267,8 @@ VMN_HD void u256_mul_wide(u32 out[16], const U256& a, const U256& b) {
     }
 }
 // q, r = divmod(a, b), b != 0 — Knuth algorithm D in base 2^32
-VMN_HD void u256_divrem(U256& q, U256& r, const U256& a, const U256& b) {
+// (operands by value: the limbs are indexed dynamically, and only this function's copies may live in addressable memory)
+VMN_HD void u256_divrem(U256& q, U256& r, const U256 a, const U256 b) {
     q = u256_zero(); r = u256_zero();
     int n = 8;
     while (n > 0 && b.l[n - 1] == 0) --n;
@@ -279,19 +317,44 @@ VMN_HD void u256_divrem(U256& q, U256& r, const U256& a, const U256& b) {
     for (int i = 0; i < n - 1; ++i) r.l[i] = s ? (un[i] >> s) | (un[i + 1] << (32 - s)) : un[i];
     r.l[n - 1] = un[n - 1] >> s;
 }
-VMN_HD u32 u256_byte(const U256& a, u32 byte_idx) { return (a.l[(byte_idx >> 2) & 7] >> (8 * (byte_idx & 3))) & 0xff; }
-// big-endian byte k (0 = most significant) of a 256-bit word
-VMN_HD u32 u256_be_byte(const U256& a, u32 k) { return u256_byte(a, 31 - k); }
-VMN_HD void u256_set_be_byte(U256& a, u32 k, u32 v) {
-    const u32 le = 31 - k, sh = 8 * (le & 3);
-    a.l[le >> 2] = (a.l[le >> 2] & ~(0xffu << sh)) | ((v & 0xff) << sh);
+// No dynamic indexing into U256 values anywhere on the common path: an indexed local lives in scratch memory on the GPU and drags
+// every use of the operand (src0 / src1 / dst0: all families) with it.  Picks are select chains, shifts are barrel shifters.
+VMN_HD u32 u256_byte(const U256& a, u32 byte_idx) {
+    const u32 li = (byte_idx >> 2) & 7;
+    u32 limb = 0;
+    for (u32 k = 0; k < 8; ++k) limb = li == k ? a.l[k] : limb;
+    return (limb >> (8 * (byte_idx & 3))) & 0xff;
+}
+// x <<= sh / x >>= sh over N little-endian u32 limbs, sh < 32 N
+template <int N>
+VMN_HD void limbs_shl(u32* x, u32 sh) {
+    const u32 ws = sh >> 5, b = sh & 31;
+    for (int k = 1; k < N; k <<= 1) {
+        const bool on = (ws & (u32)k) != 0;
+        for (int i = N - 1; i >= 0; --i) { const u32 src = i - k >= 0 ? x[i - k] : 0; x[i] = on ? src : x[i]; }
+    }
+    for (int i = N - 1; i >= 0; --i) { const u32 below = i ? x[i - 1] : 0; x[i] = b ? (x[i] << b) | (below >> (32 - b)) : x[i]; }
+}
+template <int N>
+VMN_HD void limbs_shr(u32* x, u32 sh) {
+    const u32 ws = sh >> 5, b = sh & 31;
+    for (int k = 1; k < N; k <<= 1) {
+        const bool on = (ws & (u32)k) != 0;
+        for (int i = 0; i < N; ++i) { const u32 src = i + k < N ? x[i + k] : 0; x[i] = on ? src : x[i]; }
+    }
+    for (int i = 0; i < N; ++i) { const u32 above = i + 1 < N ? x[i + 1] : 0; x[i] = b ? (x[i] >> b) | (above << (32 - b)) : x[i]; }
 }
 
+// c ? a : b on aggregates, member by member (a C++ `?:` on struct lvalues is a pointer select + copy: both sides become addressable memory)
+VMN_HD U256 sel256(bool c, const U256& a, const U256& b) { U256 r; for (int i = 0; i < 8; ++i) r.l[i] = c ? a.l[i] : b.l[i]; return r; }
+VMN_HD Reg sel_reg(bool c, const Reg& a, const Reg& b) { Reg r; r.ptr = c ? a.ptr : b.ptr; r.v = sel256(c, a.v, b.v); return r; }
 struct FatPtr { u32 offset, page, start, length; };
+VMN_HD FatPtr sel_fp(bool c, const FatPtr& a, const FatPtr& b) { return FatPtr{c ? a.offset : b.offset, c ? a.page : b.page, c ? a.start : b.start, c ? a.length : b.length}; }
 VMN_HD FatPtr fp_readjust(const FatPtr& p) { return FatPtr{0, p.page, p.start + p.offset, p.length - p.offset}; }
 
 // ------------------------------------------------------------------------------------------------ the cycle
 // Env supplies the WitnessOracle answers and takes the hash-chain events:
+//   void opcode_row(const Defs&, u32 variant, u32& price, u64& props)   the decode table row (where the caller keeps the table)
 //   void code_word(bool exec, U256&)                       get_memory_witness_for_read (utils.rs:170)
 //   void src0(bool exec, U256&, u32& is_ptr)               get_memory_witness_for_read (utils.rs:434)
 //   u32  refund(bool exec)                                 get_refunds (log.rs:235)
@@ -306,8 +369,8 @@ VMN_HD FatPtr fp_readjust(const FatPtr& p) { return FatPtr{0, p.page, p.start + 
 //   void mem_push(const u64[8]) / dec_push(const u64[8]) / fwd_push(const u64[20]) / fwd_set(const u64[4]) /
 //   sponge_push(const u64[32]) / sponge_set(const u64[12])    the chains' events, in order
 template <class Env>
-VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
-    const zk_opcode_defs& d = *D.d;
+VMN_HD void vm_cycle(const Defs& D, const Gctx& G, State& st, Env& env) {
+    const DefsSmall& d = D.s;
     Ctx& c = st.ctx;
     // ---------------- create_prestate (pre_state.rs:88-221)
     const bool skip = st.depth == 0;
@@ -329,7 +392,8 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
     } else {
         code_word = st.prev_code_word;
     }
-    u64 opcode = ((u64)code_word.l[2 * (3 - sub_pc) + 1] << 32) | code_word.l[2 * (3 - sub_pc)];
+    u64 opcode = 0;  // four opcodes per word, the first in the most significant 8 bytes (pre_state.rs:184-206)
+    for (u32 k = 0; k < 4; ++k) opcode = sub_pc == k ? (((u64)code_word.l[2 * (3 - k) + 1] << 32) | code_word.l[2 * (3 - k)]) : opcode;
     if (skip) opcode = d.nop_encoding;
     if (pending) opcode = d.panic_encoding;
     st.prev_code_word = code_word;
@@ -341,10 +405,14 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
     const u32 variant = (u32)(opcode & 0x7ff), cond_key = (u32)((opcode >> 13) & 7);
     u32 src_byte = (u32)((opcode >> 16) & 0xff), dst_byte = (u32)((opcode >> 24) & 0xff);
     const u32 imm0 = (u32)((opcode >> 32) & 0xffff), imm1 = (u32)((opcode >> 48) & 0xffff);
-    const u32 price = d.prices[variant];
-    const u64 props_full = d.props[variant];
+    u32 price;
+    u64 props_full;
+    env.opcode_row(D, variant, price, props_full);  // OPCODES_PRICES / OPCODES_PROPS_INTEGER_BITMASKS row (src/tables/opcodes_decoding.rs:14-38)
     bool condition = false;
-    switch (D.cond_of_key[cond_key]) {  // src/tables/conditional.rs:35-44
+    u32 cond_kind = 0xff;  // constant indices only: a dynamically indexed kernel-argument array would push the whole argument into scratch
+    for (int k = 0; k < ZK_VMC__COUNT; ++k)
+        if (d.condition_idx[k] == cond_key) cond_kind = (u32)k;
+    switch (cond_kind) {  // src/tables/conditional.rs:35-44
     case ZK_VMC_ALWAYS: condition = true; break;
     case ZK_VMC_LT: condition = st.of; break;
     case ZK_VMC_EQ: condition = st.eq; break;
@@ -382,8 +450,10 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
     const u32 preliminary_ergs_left = ergs_left;
     Reg zero_reg;
     zero_reg.ptr = 0; zero_reg.v = u256_zero();
-    const Reg draft_src0 = src0_idx ? st.regs[src0_idx - 1] : zero_reg;
-    const Reg src1_register = src1_idx ? st.regs[src1_idx - 1] : zero_reg;
+    // (no `cond ? st.regs[i] : zero_reg`: a select between an LDS object and a local one makes both addressable)
+    Reg draft_src0 = zero_reg, src1_register = zero_reg;
+    if (src0_idx) draft_src0 = st.regs[src0_idx - 1];
+    if (src1_idx) src1_register = st.regs[src1_idx - 1];
     const u32 src0_reg_lowest = draft_src0.v.l[0] & 0xffff;
     const u32 dst0_reg_lowest = (dst0_idx ? st.regs[dst0_idx - 1].v.l[0] : 0) & 0xffff;
     const u32 stack_page = c.base_page + 1, heap_page = c.base_page + 2, aux_heap_page = c.base_page + 3;
@@ -414,15 +484,16 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
         env.mem_push(enc);
         st.mem_len += 1;
     }
-    Reg src0 = src_mode(ZK_VMM_REG_ONLY) ? draft_src0 : src0_from_mem;
+    Reg src0 = sel_reg(src_mode(ZK_VMM_REG_ONLY), draft_src0, src0_from_mem);
     if (src_mode(ZK_VMM_IMM16)) { src0 = zero_reg; src0.v.l[0] = imm0; }
     Reg src1 = src1_register;
     const bool swap = ((fam == ZK_VMF_SUB || fam == ZK_VMF_DIV || fam == ZK_VMF_SHIFT) && flag(ZK_VMFL_SWAP_ARITH)) || (fam == ZK_VMF_PTR && flag(ZK_VMFL_SWAP_PTR));
-    if (swap) { const Reg t = src0; src0 = src1; src1 = t; }
+    { const Reg a0 = src0, a1 = src1; src0 = sel_reg(swap, a1, a0); src1 = sel_reg(swap, a0, a1); }
     {   // conditionally_erase_fat_pointer_data (pre_state.rs:417-452; register/mod.rs:74-84)
         const bool keeps_ptr = fam == ZK_VMF_RET || fam == ZK_VMF_PTR || fam == ZK_VMF_UMA || fam == ZK_VMF_FAR_CALL;
-        if (src0.ptr && !keeps_ptr && !is_kernel) { src0.ptr = 0; src0.v.l[1] = 0; src0.v.l[2] = 0; }
-        if (src1.ptr && !is_kernel) { src1.ptr = 0; src1.v.l[1] = 0; src1.v.l[2] = 0; }
+        const bool erase0 = src0.ptr && !keeps_ptr && !is_kernel, erase1 = src1.ptr && !is_kernel;
+        src0.ptr = erase0 ? 0 : src0.ptr; src0.v.l[1] = erase0 ? 0 : src0.v.l[1]; src0.v.l[2] = erase0 ? 0 : src0.v.l[2];
+        src1.ptr = erase1 ? 0 : src1.ptr; src1.v.l[1] = erase1 ? 0 : src1.v.l[1]; src1.v.l[2] = erase1 ? 0 : src1.v.l[2];
     }
     const U256 &s0 = src0.v, &s1 = src1.v;
     const bool s0p = src0.ptr != 0, s1p = src1.ptr != 0;
@@ -518,20 +589,13 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
         const bool is_rol = var(ZK_VMV_SHIFT_ROL), is_ror = var(ZK_VMV_SHIFT_ROR), is_shr = var(ZK_VMV_SHIFT_SHR);
         const u32 full_shift = (is_ror && shift) ? 256 - shift : shift;
         const bool is_cyclic = is_rol || is_ror, is_right = is_ror || is_shr;
-        const u32 ws = full_shift >> 5, bs = full_shift & 31;
-        U256 r = u256_zero();
+        U256 r = s0;
         if (is_right && !is_cyclic) {
-            for (int i = 0; i < 8; ++i) {
-                const u32 lo = (u32)i + ws < 8 ? s0.l[i + ws] : 0, hi = (u32)i + ws + 1 < 8 ? s0.l[i + ws + 1] : 0;
-                r.l[i] = bs ? (lo >> bs) | (hi << (32 - bs)) : lo;
-            }
+            limbs_shr<8>(r.l, full_shift);
         } else {
             u32 w[16];
-            for (int i = 0; i < 16; ++i) {
-                const int a = i - (int)ws;
-                const u32 lo = (a >= 0 && a < 8) ? s0.l[a] : 0, below = (a - 1 >= 0 && a - 1 < 8) ? s0.l[a - 1] : 0;
-                w[i] = bs ? (lo << bs) | (below >> (32 - bs)) : lo;
-            }
+            for (int i = 0; i < 16; ++i) w[i] = i < 8 ? s0.l[i] : 0;
+            limbs_shl<16>(w, full_shift);
             for (int i = 0; i < 8; ++i) r.l[i] = w[i] + (is_cyclic ? w[8 + i] : 0);  // disjoint bit ranges: + == |
         }
         dst0.v = r;
@@ -559,10 +623,10 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
         const bool execute = !not_enough;
         U256 read_w;
         env.log_read(execute && is_storage, read_w);
-        const U256 read_value = is_storage ? read_w : u256_zero();
+        const U256 read_value = sel256(is_storage, read_w, u256_zero());
         for (int i = 0; i < 5; ++i) q.address[i] = c.this_[i];
         q.read_value = read_value;
-        q.written_value = is_revertable ? s1 : read_value;
+        q.written_value = sel256(is_revertable, s1, read_value);
         q.rw_flag = is_revertable; q.rollback = 0; q.is_service = flag(ZK_VMFL_FIRST_MESSAGE); q.shard_id = c.this_shard;
         q.tx_number = st.tx_number; q.timestamp = ts1;
         const bool execute_rollback = execute && is_revertable;
@@ -632,22 +696,34 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
         u64 enc[8];
         if (read_a) { memory_query_encode(enc, ts0, mem_page, cell, 0, 0, va); env.mem_push(enc); st.mem_len += 1; }
         if (read_b) { memory_query_encode(enc, ts0, mem_page, cell_b, 0, 0, vb); env.mem_push(enc); st.mem_len += 1; }
-        // the 64-byte big-endian window [va | vb]; the word read = bytes unalign .. unalign+31
-        U256 read_value = u256_zero();
-        for (u32 k = 0; k < 32; ++k) {
-            const u32 p = unalign + k;
-            u256_set_be_byte(read_value, k, p < 32 ? u256_be_byte(va, p) : u256_be_byte(vb, p - 32));
+        // the 64-byte big-endian window [va | vb] as one 512-bit integer X = va * 2^256 + vb: the word at byte `unalign` is
+        // (X >> 8 (32 - unalign)) mod 2^256
+        const u32 window_shift = 8 * (32 - unalign);  // 8 .. 256
+        u32 X[16];
+        for (int i = 0; i < 8; ++i) { X[i] = vb.l[i]; X[8 + i] = va.l[i]; }
+        U256 read_value;
+        {
+            u32 t[16];
+            for (int i = 0; i < 16; ++i) t[i] = X[i];
+            limbs_shr<16>(t, window_shift);
+            for (int i = 0; i < 8; ++i) read_value.l[i] = t[i];
         }
-        const u32 nclean = is_fp ? bytes_to_cleanup : 0;
-        for (u32 k = 0; k < nclean; ++k) u256_set_be_byte(read_value, 31 - k, 0);
+        {   // fat-pointer reads past the slice: the lowest `nclean` bytes are zeroed (src/tables/uma_ptr_read_cleanup.rs)
+            const u32 nbits = 8 * (is_fp ? bytes_to_cleanup : 0);
+            for (u32 i = 0; i < 8; ++i) {
+                const u32 m = 32 * (i + 1) <= nbits ? 0u : (32 * i >= nbits ? 0xffffffffu : ~((1u << (nbits - 32 * i)) - 1u));
+                read_value.l[i] &= m;
+            }
+        }
         const bool is_write_access = is_hw || is_aw;
         const bool exec_write = is_write_access && !skip_mem;
         if (exec_write) {
-            U256 na = va, nb = vb;
-            for (u32 k = 0; k < 32; ++k) {
-                const u32 p = unalign + k, b = u256_be_byte(s1, k);
-                if (p < 32) u256_set_be_byte(na, p, b); else u256_set_be_byte(nb, p - 32, b);
-            }
+            u32 wv[16], wm[16];
+            for (int i = 0; i < 16; ++i) { wv[i] = i < 8 ? s1.l[i] : 0; wm[i] = i < 8 ? 0xffffffffu : 0; }
+            limbs_shl<16>(wv, window_shift);
+            limbs_shl<16>(wm, window_shift);
+            U256 na, nb;
+            for (int i = 0; i < 8; ++i) { nb.l[i] = (X[i] & ~wm[i]) | wv[i]; na.l[i] = (X[8 + i] & ~wm[8 + i]) | wv[8 + i]; }
             memory_query_encode(enc, ts3, mem_page, cell, 1, 0, na); env.mem_push(enc); st.mem_len += 1;
             if (unalign) { memory_query_encode(enc, ts3, mem_page, cell_b, 1, 0, nb); env.mem_push(enc); st.mem_len += 1; }
         }
@@ -673,7 +749,7 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
         const u32 end_non_inclusive = start + length;
         const bool range_overflow = end_non_inclusive < start;
         const bool ptr_invalid = (offset != 0 && !forward_fat_pointer) || range_overflow || length < offset;
-        const FatPtr fp = ptr_invalid ? FatPtr{0, 0, 0, 0} : FatPtr{offset, page, start, length};
+        const FatPtr fp = sel_fp(ptr_invalid, FatPtr{0, 0, 0, 0}, FatPtr{offset, page, start, length});
         const u32 upper_bound_abi = end_non_inclusive;
         Ctx old_ctx = c, new_ctx;
         bool fwd_is_set = false;
@@ -718,7 +794,7 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
             const u32 default_page = st.page_counter;
             st.page_counter = st.page_counter + d.params[ZK_VMP_NEW_MEMORY_PAGES_PER_FAR_CALL];
             // may_be_read_code_hash (far_call.rs:1104-1280)
-            const bool zkporter_ok = D.zkporter_is_available != 0;
+            const bool zkporter_ok = G.zkporter_is_available != 0;
             const bool should_read = !target_is_zkporter || zkporter_ok;
             const bool needs_porter_mask = target_is_zkporter && !zkporter_ok;
             U256 code_hash;
@@ -740,7 +816,7 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
             U256 bytecode_hash = code_hash;
             const bool empty = u256_is_zero(bytecode_hash);
             const bool mask_default_aa = should_read && empty && !target_is_kernel;
-            if (mask_default_aa) bytecode_hash = D.default_aa_code_hash;
+            bytecode_hash = sel256(mask_default_aa, G.default_aa_code_hash, bytecode_hash);
             if (needs_porter_mask) bytecode_hash = u256_zero();
             const bool trivial = (empty && !mask_default_aa) || needs_porter_mask || !should_read;
             u32 target_page = trivial ? 0 : default_page;
@@ -751,10 +827,10 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
             const bool can_call_code = (normal_marker && !ctor) || (ctor_marker && ctor);
             U256 at_rest = bytecode_hash;
             at_rest.l[7] = (top & 0xffff) | (d.params[ZK_VMP_CODE_AT_REST_MARKER] << 16) | (d.params[ZK_VMP_CODE_HASH_VERSION_BYTE] << 24);
-            const U256 masked_hash = can_call_code ? at_rest : (target_is_kernel ? u256_zero() : D.default_aa_code_hash);
+            const U256 masked_hash = sel256(can_call_code, at_rest, sel256(target_is_kernel, u256_zero(), G.default_aa_code_hash));
             const u32 code_len_words = code_format_exception ? 0 : (masked_hash.l[7] & 0xffff);
             const bool exceptions = code_format_exception || (!can_call_code && target_is_kernel) || (forward_fat_pointer && !s0p) || ptr_invalid || range_overflow;
-            FatPtr final_fp = forward_fat_pointer ? fp_readjust(fp) : FatPtr{0, use_heap ? heap_page : aux_heap_page, fp.start, fp.length};
+            FatPtr final_fp = sel_fp(forward_fat_pointer, fp_readjust(fp), FatPtr{0, use_heap ? heap_page : aux_heap_page, fp.start, fp.length});
             if (exceptions) final_fp = FatPtr{0, 0, 0, 0};
             u32 upper = exceptions ? 0 : upper_bound_abi;
             if (range_overflow && !forward_fat_pointer) upper = 0xffffffffu;
@@ -837,8 +913,8 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
             const bool is_far_return = !is_local;
             // the circuit erases src0 on panic BEFORE parsing nothing else of it: the ABI parts above were parsed from the unerased value
             const bool exc = (forward_fat_pointer && !r0p && is_far_return) || (forward_fat_pointer && fp.page < c.base_page) || is_panic;
-            FatPtr fpr = exc ? FatPtr{0, 0, 0, 0} : fp;
-            fpr = forward_fat_pointer ? fp_readjust(fpr) : FatPtr{0, use_heap ? heap_page : aux_heap_page, fpr.start, fpr.length};
+            FatPtr fpr = sel_fp(exc, FatPtr{0, 0, 0, 0}, fp);
+            fpr = sel_fp(forward_fat_pointer, fp_readjust(fpr), FatPtr{0, use_heap ? heap_page : aux_heap_page, fpr.start, fpr.length});
             u32 upper = exc ? 0 : upper_bound_abi;
             if (range_overflow && !forward_fat_pointer) upper = 0xffffffffu;
             u32 growth = 0;
@@ -848,7 +924,7 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
             u32 ergs_after = ufg ? 0 : preliminary_ergs_left - growth;
             if (is_local) ergs_after = preliminary_ergs_left;
             const bool non_local_panic = (exc || ufg || is_panic) && is_far_return;
-            const FatPtr final_fp = non_local_panic ? FatPtr{0, 0, 0, 0} : fpr;
+            const FatPtr final_fp = sel_fp(non_local_panic, FatPtr{0, 0, 0, 0}, fpr);
             new_ctx.ergs = ergs_after + popped.ergs;
             if (is_local) { new_ctx.heap_bound = c.heap_bound; new_ctx.aux_heap_bound = c.aux_heap_bound; }
             const bool perform_revert = is_revert || is_panic || non_local_panic;
@@ -903,11 +979,15 @@ VMN_HD void vm_cycle(const Defs& D, State& st, Env& env) {
             st.regs[dst0_idx - 1] = dst0;
         }
     }
-    if (dst1_idx) st.regs[dst1_idx - 1] = have_dst1 ? dst1 : zero_reg;  // written unconditionally from the (possibly empty) dot product
+    if (dst1_idx) {  // written unconditionally from the (possibly empty) dot product
+        if (!have_dst1) dst1 = zero_reg;
+        st.regs[dst1_idx - 1] = dst1;
+    }
     if (have_pc) nc.pc = new_pc;
     if (have_ergs) nc.ergs = new_ergs;
     if (have_flags) { st.of = nf_of; st.eq = nf_eq; st.gt = nf_gt; }
     st.pending_exception = pend;
+    st.last_family = fam;
 }
 
 }  // namespace vmn

@@ -86,6 +86,7 @@ struct PackEnv {
     bool chains_on;
     Chains ch;
     void put(u32 w, u64 v) { col[(u64)w * stride] = v; }
+    void opcode_row(const vmn::Defs& D, u32 variant, u32& price, u64& props) { price = D.prices[variant]; props = D.props[variant]; }
     void mem_read(bool exec, u32 w_value, int w_ptr, vmn::U256& v, u32* is_ptr) {
         v = vmn::u256_zero();
         if (is_ptr) *is_ptr = 0;
@@ -266,8 +267,9 @@ extern "C" int zk_pack_main_vm_witness(zk_cs* h, const zk_vm_closed_form_input* 
     // ---- the cycles
     vmn::Defs D;
     vmn::defs_prepare(D, &defs, &defs);
-    D.zkporter_is_available = in->zkporter_is_available ? 1 : 0;
-    for (int i = 0; i < 8; ++i) D.default_aa_code_hash.l[i] = in->default_aa_code_hash[i];
+    vmn::Gctx G;
+    G.zkporter_is_available = in->zkporter_is_available ? 1 : 0;
+    for (int i = 0; i < 8; ++i) G.default_aa_code_hash.l[i] = in->default_aa_code_hash[i];
     vmn::State st;
     if (in->start_flag) bootloader_state(defs, *in, st, env.ch, chains_on);
     else {
@@ -285,7 +287,7 @@ extern "C" int zk_pack_main_vm_witness(zk_cs* h, const zk_vm_closed_form_input* 
         for (uint32_t w = 0; w < n_loop_words; ++w) col[(u64)w * env.stride] = 0;
         if (chains_on) write_state(st, env.ch, true, col, env.stride);
         env.col = col;
-        vmn::vm_cycle(D, st, env);
+        vmn::vm_cycle(D, G, st, env);
     }
     u64 fin[vmn::STATE_WORDS] = {0};
     write_state(st, env.ch, true, fin, 1);

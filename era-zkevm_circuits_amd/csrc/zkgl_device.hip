@@ -440,7 +440,7 @@ int launch_vm_seed(const VmSeedArgs& v, void* stream, float* phase_ms) {
     if (v.n_instances == 0 || v.limit == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     zkvm::SeedDev a;
-    vmn::defs_prepare(a.D, (const zk_opcode_defs*)v.defs_host, (const zk_opcode_defs*)v.defs_dev);
+    vmn::defs_prepare(a.D, (const zk_opcode_defs*)v.defs_host, (const zk_opcode_defs*)v.defs_dev);  // tables on the device, the rest by value
     a.loop = v.loop; a.in_stride = v.in_stride; a.limit = v.limit; a.n_instances = v.n_instances;
     static_assert(sizeof(zkvm::RawLayout) == sizeof(VmRawLayout), "layout mirrors");
     std::memcpy(&a.raw, &v.raw, sizeof a.raw);
@@ -453,15 +453,12 @@ int launch_vm_seed(const VmSeedArgs& v, void* stream, float* phase_ms) {
     a.sp_snap = (uint64_t*)(base + L.sp_snap);
     a.counts = (uint4*)(base + L.counts); a.totals = (uint4*)(base + L.totals);
     a.cap_mem = v.limit * zkvm::MEM_EVENTS_PER_CYCLE; a.cap_one = v.limit;
-    // phase A: few instances per wavefront (instances on different opcodes serialise each other inside a wavefront); fill the SIMDs first
-    uint32_t lpw = 1;
-    if (const char* e = std::getenv("ZKGL_VM_WALK_LANES")) lpw = (uint32_t)std::max(1, atoi(e));
-    else while (lpw < 64 && (v.n_instances + lpw - 1) / lpw > 2048) lpw *= 2;
-    a.lanes_per_wave = std::min<uint32_t>(lpw, 64);
+    a.n_loop_words = v.n_loop_words;
+    if (v.n_loop_words < (uint32_t)vmn::STATE_WORDS || v.n_loop_words - vmn::STATE_WORDS > zkvm::RAW_MAX) { g_hip_err = "vm seed: oracle words per cycle exceed the staging buffer"; return -1; }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (phase_ms) for (auto& e : ev) if (int r = chk(hipEventCreate(&e), "hipEventCreate")) return r;
     if (phase_ms) hipEventRecord(ev[0], st);
-    zkvm::k_vm_walk<<<(v.n_instances + a.lanes_per_wave - 1) / a.lanes_per_wave, 64, 0, st>>>(a);
+    zkvm::k_vm_walk<<<v.n_instances, 64, 0, st>>>(a);
     if (int r = LAUNCH_CHECK("k_vm_walk")) return r;
     if (phase_ms) hipEventRecord(ev[1], st);
     const uint64_t groups = (uint64_t)v.n_instances * 4, per_block = 4 * zkvm::CH_GROUPS;

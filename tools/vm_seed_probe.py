@@ -31,6 +31,7 @@ out["mixed_batch_native_equals_restatement"] = bool(len(bad) == 0)
 out["mixed_batch_native_equals_cone"] = bool(np.array_equal(res["1"], res["0"]))
 if len(bad):
     w, col = bad[0]
+    out["differing_words"] = sorted(set(int(x) for x in bad[:, 0]))
     out["first_difference"] = {"word": int(w), "column": int(col), "instance": info[col // LIMIT], "cycle": int(col % LIMIT), "native": int(res["1"][w, col]), "want": int(loop[w, col]), "n": len(bad)}
 print(json.dumps(out)); sys.stdout.flush()
 # ---- (2) bench-sized stream
