@@ -3,18 +3,24 @@
 (config C2), N MI355X, one process per GPU.
 
 Workload = the REAL main_vm circuit (csrc/circuits/main_vm.cpp: vm_cycle of /root/reference/src/main_vm/cycle.rs:28-795 with
-all eleven opcode families) executing synthetic zkEVM programs: tests/golden/vm_bench_witness.npz holds the raw WitnessOracle
-words of 8 executions of an endless mixed program (far calls, returns, reverts, UMA, logs, arithmetic; generator:
-tests/golden/make_vm_bench_witness.py), tiled over the B instances of the batch.  Instance = one `limit`-cycle chunk filling
-2^20 trace rows.
+all eleven opcode families) executing synthetic zkEVM programs.  tests/golden/vm_bench_witness.npz holds the VmCircuitWitness of 64
+distinct executions of an endless mixed program (far calls, returns, reverts, UMA, logs, arithmetic; generator:
+tests/golden/make_vm_bench_witness.py) the way a host of the reference holds it: the WitnessOracle's per-getter FIFOs.  The
+product's own packer (zk_pack_main_vm_witness) turns them into the circuit's input streams; instance i of a rank replays execution
+(rank * S + i) mod 64.  Instance = one `limit`-cycle chunk filling 2^20 trace rows.
 
-A "step" = one pass of the hot path over one batch of B independent circuit instances per GPU whose inputs already live in HBM:
-witness generation (outer pre, loop, outer post kernels) followed by the full satisfiability check (gate + lookup + copy + link
-kernels).  The per-cycle VmLocalState the loop scope consumes is derived on the device from the raw oracle words
-(zk_cs_seed_carried_inputs, a sequential chain per instance) BEFORE the timed region; its time is reported as
-config.input_seeding_s and folded into `value_from_raw_witness` = constraints / (seeding + step).  Rank 0 prints ONE JSON line.
+A "step" = one pass of the WHOLE hot path over one batch of B independent circuit instances per GPU whose RAW witness (oracle
+words placed at their cycles, no VM state) already lives in HBM:
+  * seeding — the sequential half: the per-cycle VmLocalState from the raw words (native walker + Poseidon2 chains + fill,
+    zk_cs_seed_window_async) of the NEXT window of the stream, on a second HIP stream;
+  * witness generation (outer pre, loop, outer post kernels) + the full satisfiability check (gate + lookup + copy + link kernels)
+    of THIS window (zk_cs_resolve_and_check).
+`value` = constraints / time of K such steps: from the raw witness, seeding inside the timed region.  `value_inputs_resident` (the
+figure rounds 1-2 quoted) is measured right after it without the seeding, `value_from_raw_witness_serial` counts the seeding of
+a window as if nothing overlapped.  Rank 0 prints ONE JSON line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--log2-rows 20] [--no-cpu-baseline] [--workload main_vm|vm_shaped]
+(--gpus N > 1 without a launcher re-executes itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -52,28 +58,37 @@ def build_main_vm_cs(zkgl, log2_rows):
     return cs, limit
 
 
-def main_vm_streams(cs, limit, batch, first=0):
-    """(outer [words, B], loop [words, B * limit] with the carried words zero, expected commitments [B, 4] or None) from the fixture"""
+_FIFOS = ("memory_reads", "storage_reads", "refunds", "rollback_queue_witness", "rollback_tails_for_call", "callstack", "decommit_pages")
+
+
+def main_vm_streams(zkgl, cs, limit, n_exec=None):
+    """(outer [words, E], loop [words, E * limit] with the carried VM state zero, expected commitments [E, 4] or None): the fixture's
+    VmCircuitWitnesses — closed-form input + the WitnessOracle's per-getter FIFOs — through the product's zk_pack_main_vm_witness"""
     fx = np.load(FIXTURE)
-    lay = cs.main_vm_layout()
-    if json.loads(bytes(fx["layout"]).decode()) != {k: {n: list(v) for n, v in d.items()} for k, d in lay.items()}:
-        raise RuntimeError("tests/golden/vm_bench_witness.npz was generated for another stream layout: re-run tests/golden/make_vm_bench_witness.py")
-    raw, tails, commits = fx["raw"], fx["rollback_tail"], fx["commitment"]
-    n_exec, cycles, n_raw = raw.shape
-    if cycles < limit:
-        raise RuntimeError(f"fixture holds {cycles} cycles per execution, the circuit needs {limit}")
+    E = int(fx["commitment"].shape[0]) if n_exec is None else min(int(n_exec), int(fx["commitment"].shape[0]))
     n_outer, n_loop = cs.input_words()
-    assert n_loop == VM_STATE_WORDS + n_raw
-    outer = np.zeros((n_outer, batch), dtype=np.uint64)
-    loop = np.zeros((n_loop, batch * limit), dtype=np.uint64)
-    per_exec = [np.ascontiguousarray(raw[e, :limit].T) for e in range(n_exec)]   # [words, limit]
-    t0 = lay["outer"]["rollback_queue_tail_for_block"][0]
-    for i in range(batch):
-        e = (first + i) % n_exec
-        outer[lay["outer"]["start_flag"][0], i] = 1
-        outer[t0:t0 + 4, i] = tails[e]
-        loop[VM_STATE_WORDS:, i * limit:(i + 1) * limit] = per_exec[e]
-    expect = np.stack([commits[(first + i) % n_exec] for i in range(batch)]) if int(fx["limit"][0]) == limit else None
+    outer = np.zeros((n_outer, E), dtype=np.uint64)
+    loop = np.zeros((n_loop, E * limit), dtype=np.uint64)
+    arr = {k: fx[k] for k in _FIFOS}
+    off = {k: fx[k + "_offsets"] for k in _FIFOS}
+    for e in range(E):
+        q = zkgl.VmOracleQueues()
+        sl = {k: arr[k][off[k][e]:off[k][e + 1]] for k in _FIFOS}
+        q.memory_reads = [(r[:8], r[8]) for r in sl["memory_reads"]]
+        q.storage_reads = list(sl["storage_reads"])
+        q.refunds = [r[0] for r in sl["refunds"]]
+        q.rollback_queue_witness = list(sl["rollback_queue_witness"])
+        q.rollback_tails_for_call = list(sl["rollback_tails_for_call"])
+        q.callstack = [(r[:42], r[42:]) for r in sl["callstack"]]
+        q.decommit_pages = [r[0] for r in sl["decommit_pages"]]
+        q.freeze()
+        cf = zkgl.VmClosedFormInput()
+        cf.start_flag = 1
+        cf.rollback_queue_tail_for_block[:] = [int(x) for x in fx["rollback_tail"][e]]
+        rep = cs.pack_main_vm_witness(cf, q.view(), e, E, outer, loop)
+        if rep.underflow:
+            raise RuntimeError(f"fixture execution {e}: the packer ran out of oracle answers (fixture made for another circuit?)")
+    expect = fx["commitment"][:E].copy() if int(fx["limit"][0]) == limit else None
     return outer, loop, expect
 
 
@@ -126,7 +141,7 @@ def cpu_baseline(log2_rows, seconds_target=20.0):
     cores = os.cpu_count() or 1
     cs, limit = build_main_vm_cs(zkgl, log2_rows)
     n_inst = 8 if cores >= 16 else 2
-    outer, loop, _ = main_vm_streams(cs, limit, n_inst)
+    outer, loop, _ = main_vm_streams(zkgl, cs, limit, n_inst)
     total_rows = int(sum(t["n_rows"] for t in zko.parse_export(cs.export(False))["tables"]))
     run = zko.CircuitRun(cs.export(False), cs.export(True), n_inst, total_rows)
     t0 = time.perf_counter()
@@ -157,17 +172,28 @@ def cpu_baseline(log2_rows, seconds_target=20.0):
                       f"CPU restatement (oracle), not the reference Rust binary"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=384, help="independent circuit instances per GPU per step")
-    ap.add_argument("--seed-windows", type=int, default=5, help="batches of raw witness seeded in one zk_cs_seed_stream pass (the stream = batch x windows instances)")
+    ap.add_argument("--seed-windows", type=int, default=5, help="batches of raw witness resident per GPU (the stream = batch x windows instances, >= 2)")
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--workload", default="main_vm", choices=["main_vm", "vm_shaped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    # ---- N > 1 without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                   "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:])
     # stdout carries the ONE JSON line and nothing else: libraries that write to fd 1 on their own (librccl prints a version banner
     # at its first communicator, possibly from another thread) are sent to stderr; the JSON line goes to the saved descriptor
     sys.stdout.flush()
@@ -181,38 +207,41 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     n_dev = torch.cuda.device_count()
     if n_dev == 0:
         raise RuntimeError("bench.py needs a GPU: libzkgl has no CPU fallback")
     dev_index = local_rank % n_dev
     shared_gpu = world > n_dev            # only in smoke tests of the N>1 path on a 1-GPU box: RCCL refuses duplicate devices
     if world > 1:
-        dist.init_process_group("gloo" if shared_gpu else "nccl", rank=rank, world_size=world)
+        # control plane (barriers, the communicator id, max over ranks) over gloo; the ONE RCCL communicator of the run is the
+        # product's (zk_comm_create), used by the path's only collective: the commitment gather
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(dev_index)
     zkgl.init(dev_index)
     dev = torch.device("cuda", dev_index)
-    coll_dev = torch.device("cpu") if shared_gpu else dev
 
     B = args.batch
-    K = max(1, args.seed_windows)     # the raw witness stream holds K batches: seeded in ONE pass, resolved window by window
+    K = max(2, args.seed_windows)     # the raw witness stream holds K batches: window k+1 is seeded while window k is resolved
     S = B * K
     expect = None
-    stream = torch.cuda.current_stream().cuda_stream
+    step_stream = torch.cuda.current_stream()
+    seed_stream = torch.cuda.Stream(device=dev, priority=-1)   # few long-lived wavefronts: let them in first
+    stream = step_stream.cuda_stream
     if args.workload == "main_vm":
         cs, limit = build_main_vm_cs(zkgl, args.log2_rows)
         n_outer, n_loop = cs.input_words()
+        t_pack = time.perf_counter()
+        outer_e, loop_e, expect_e = main_vm_streams(zkgl, cs, limit)   # zk_pack_main_vm_witness: FIFOs -> streams, all executions
+        t_pack = time.perf_counter() - t_pack
+        n_exec = outer_e.shape[1]
         # the stream is assembled on the device: instance i replays execution (rank * S + i) % n_exec of the fixture
-        outer8, loop8, expect8 = main_vm_streams(cs, limit, 8, first=0)
-        n_exec = 8
         sel = (torch.arange(S, device=dev) + rank * S) % n_exec
-        d_outer = torch.from_numpy(outer8.view(np.int64)).to(dev)[:, sel].contiguous()
-        l8 = torch.from_numpy(loop8.view(np.int64)).to(dev).view(n_loop, n_exec, limit)
-        d_loop = l8[:, sel, :].reshape(n_loop, S * limit).contiguous()
-        del l8, loop8
-        expect = None if expect8 is None else expect8[((np.arange(S) + rank * S) % n_exec)]
-        state_words = VM_STATE_WORDS
+        d_outer = torch.from_numpy(outer_e.view(np.int64)).to(dev)[:, sel].contiguous()
+        le = torch.from_numpy(loop_e.view(np.int64)).to(dev).view(n_loop, n_exec, limit)
+        d_loop = le[:, sel, :].reshape(n_loop, S * limit).contiguous()
+        del le, loop_e
+        expect = None if expect_e is None else expect_e[((np.arange(S) + rank * S) % n_exec)]
     else:
         cs, limit = build_vm_shaped_cs(zkgl, args.log2_rows)
         n_outer, n_loop = cs.input_words()
@@ -220,34 +249,42 @@ def main():
         d_outer = torch.from_numpy(outer.view(np.int64)).to(dev)
         d_loop = torch.from_numpy(loop.view(np.int64)).to(dev)
         del loop
-        state_words = 183
+        n_exec, t_pack = 0, 0.0
     st = cs.stats()
     cs.set_batch(B)
-    seed_s = []
-    for _ in range(2):  # the second pass overwrites the carried words with the same values: a clean timing of the seeding alone
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        cs.seed_stream(S, d_outer, d_loop, stream)   # zk_cs_seed_stream: the sequential part, all K windows at once
-        torch.cuda.synchronize()
-        seed_s.append(time.perf_counter() - t)
-    t_seed = min(seed_s)
-    window = [0]
+
+    def seed_window(k, sync=True):
+        with torch.cuda.stream(seed_stream):
+            cs.seed_window_async(B, d_outer, S, d_loop, S * limit, k * B, seed_stream.cuda_stream)
+        if sync:
+            seed_stream.synchronize()
 
     def bind(k):
         cs.bind_inputs(False, d_outer, n_outer, lane_stride=S, lane_offset=k * B)
         cs.bind_inputs(True, d_loop, n_loop, lane_stride=S * limit, lane_offset=k * B * limit)
-        window[0] = k
 
-    bind(0)
-
+    # ---- seeding alone (not overlapped with anything): one window, and the whole stream in one pass
+    torch.cuda.synchronize()
+    seed_window(0)                                  # first call allocates the scratch
+    t = time.perf_counter(); seed_window(0); t_seed_window = time.perf_counter() - t
+    t = time.perf_counter(); cs.seed_stream(S, d_outer, d_loop, stream); torch.cuda.synchronize(); t_seed_stream = time.perf_counter() - t
+    window = [0]
     step_no = [0]
 
-    def step():
-        bind(step_no[0] % K)   # every step takes the next window of the seeded stream
-        step_no[0] += 1
+    def resolve(k):
+        bind(k)
+        window[0] = k
         ok, failure = cs.resolve_and_check(stream)  # witness generation + full satisfiability check, one pipeline
         if not ok and not os.environ.get("ZKGL_STUB_RUN"):  # ZKGL_STUB_RUN: tools/stub_bench.sh times deliberately wrong kernel variants
             raise RuntimeError(f"trace not satisfied: {failure}")
+
+    def step():
+        """one batch from the raw witness: seed the next window (second stream) while this window is resolved and checked"""
+        k = step_no[0] % K
+        step_no[0] += 1
+        seed_window((k + 1) % K, sync=False)
+        resolve(k)
+        seed_stream.synchronize()
 
     def fence():
         torch.cuda.synchronize()
@@ -259,73 +296,66 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    loop_ms, check_ms, gate_ms, outer_ms, step_ms = [], [], [], [], []
+    loop_ms, check_ms, gate_ms, outer_ms = [], [], [], []
     for _ in range(args.steps):
-        ts = time.perf_counter()
         step()
-        step_ms.append(1e3 * (time.perf_counter() - ts))
         loop_ms.append(cs.last_ms(1)); check_ms.append(cs.last_ms(2)); gate_ms.append(cs.last_ms(3)); outer_ms.append(cs.last_ms(4))
     fence()
     elapsed_local = time.perf_counter() - t0
-    # the path's only collective: gather the 4-element input commitments of every instance
-    from zkgl.dist import gather_commitments, gather_floats, max_over_ranks
-    elapsed = max_over_ranks(elapsed_local, coll_dev)
-    seed_all = max_over_ranks(t_seed, coll_dev)
-    per_rank_ms = gather_floats(1e3 * elapsed_local / args.steps, coll_dev)
     local = np.array([cs.public_inputs(i) for i in range(B)], dtype=np.uint64)
+    last_window = window[0]
+    # ---- the same K steps with the per-cycle state already resident (what rounds 1-2 reported as `value`)
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        resolve((last_window + 1 + i) % K)
+    torch.cuda.synchronize()
+    resident_local = time.perf_counter() - t1
+    # ---- materialised witness columns: the variable store is what the step writes; the trace proper (every cell of every column)
+    # is produced on demand — timed here for a few instances of the last batch (zk_cs_trace_columns: k_materialize + transposition)
+    mat_s = None
+    try:
+        n_mat = min(4, B)
+        cols = torch.empty((st["n_columns"] if "n_columns" in st else 164) << args.log2_rows, dtype=torch.int64, device=dev)
+        cs.trace_columns(0, cols, args.log2_rows, 1 << args.log2_rows, stream); torch.cuda.synchronize()
+        tm = time.perf_counter()
+        for i in range(n_mat):
+            cs.trace_columns(i, cols, args.log2_rows, 1 << args.log2_rows, stream)
+        torch.cuda.synchronize()
+        mat_s = (time.perf_counter() - tm) / n_mat
+        del cols
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] trace_columns timing unavailable: {e}", file=sys.stderr)
+
+    from zkgl.dist import gather_commitments, gather_floats, max_over_ranks
+    elapsed = max_over_ranks(elapsed_local)
+    resident = max_over_ranks(resident_local)
+    per_rank_ms = gather_floats(1e3 * elapsed_local / args.steps)
     parity = None
     if expect is not None:
-        parity = bool(np.array_equal(local, expect[window[0] * B:(window[0] + 1) * B]))
+        parity = bool(np.array_equal(local, expect[last_window * B:(last_window + 1) * B]))
         if not parity and not os.environ.get("ZKGL_STUB_RUN"):
             raise RuntimeError("public inputs differ from the native restatement's commitments stored in the fixture")
-    # the collective behind the C ABI: zk_comm_* + zk_cs_gather_commitments (one ncclAllGather of the packed public inputs over
-    # RCCL / xGMI); the launcher's part — handing rank 0's unique id to the other ranks — is a torch.distributed broadcast here
-    gather_path = "zk_cs_gather_commitments (RCCL all-gather behind the C ABI)"
-    import threading
-    attempt = {}
-
-    def c_abi_gather():   # on its own thread with a deadline: a communicator that cannot be formed must not cost the bench line
-        try:
-            torch.cuda.set_device(dev_index)   # the current device is per thread
-            uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
-            if rank == 0:
-                uid = torch.frombuffer(bytearray(zkgl.Comm.unique_id()), dtype=torch.uint8).to(coll_dev)
-            if world > 1:
-                dist.broadcast(uid, src=0)
-            comm = zkgl.Comm(bytes(uid.cpu().numpy().tobytes()), rank, world)
-            got = cs.gather_commitments(comm, stream)          # [world, B, 4] u64
-            torch.cuda.synchronize()
-            comm.close()
-            if not np.array_equal(got[rank], local):
-                raise RuntimeError("gathered commitments differ from this rank's public inputs")
-            attempt["commits"] = got
-        except Exception as e:  # noqa: BLE001
-            attempt["error"] = e
-
-    hung = False
+    # ---- the path's only collective: gather the 4-element input commitments of every instance, behind the C ABI:
+    # zk_comm_* + zk_cs_gather_commitments = one ncclAllGather of the packed public inputs over RCCL / xGMI.  The launcher's part —
+    # handing rank 0's unique id to the other ranks — goes over the gloo control plane.
+    bind(last_window)
     if shared_gpu:
-        attempt["error"] = RuntimeError("ranks share one GPU (smoke test): RCCL refuses duplicate devices")
+        gather_path = "torch.distributed (gloo) all_gather — ranks share one GPU (smoke test), RCCL refuses duplicate devices"
+        commits = gather_commitments(local)
     else:
-        th = threading.Thread(target=c_abi_gather, daemon=True)
-        th.start()
-        th.join(180.0)
-        if th.is_alive():
-            hung = True
-            attempt["error"] = TimeoutError("no communicator within 180 s")
-    ok_everywhere = 1 if "commits" in attempt else 0
-    if world > 1 and not hung:   # every rank takes the same path
-        flag = torch.tensor([ok_everywhere], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok_everywhere = int(flag.item())
-    if ok_everywhere:
-        commits = attempt["commits"]
-    else:
-        print(f"[bench] C-ABI gather unavailable ({attempt.get('error', 'another rank failed')}); using torch.distributed.all_gather", file=sys.stderr)
-        gather_path = "torch.distributed all_gather (fallback)"
-        commits = gather_commitments(local, coll_dev)   # [world, B, 4] u64: RCCL all_gather over xGMI when world > 1
+        gather_path = "zk_cs_gather_commitments (RCCL all-gather behind the C ABI)"
+        ids = [zkgl.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        comm = zkgl.Comm(bytes(ids[0]), rank, world)
+        commits = cs.gather_commitments(comm, stream)          # [world, B, 4] u64
+        comm.close()
+        if not np.array_equal(commits[rank], local):
+            raise RuntimeError("gathered commitments differ from this rank's public inputs")
     if rank == 0:
         n_inst = B * world
-        constraints = st["constraints_per_instance"] * n_inst * args.steps
+        per_step_constraints = st["constraints_per_instance"] * n_inst
+        constraints = per_step_constraints * args.steps
         rows = st["rows_per_instance"] * n_inst * args.steps
         # dominant kernel: the loop-scope witness interpreter.  ALGORITHMIC bytes per launch = every witness VALUE of the loop
         # rows written once (8 B; one per variable — the trace is a view of the variable store) + every input word
@@ -336,36 +366,51 @@ def main():
         k_ms = float(np.mean(loop_ms))
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_r2.json")))
-            traffic = pmc["traffic_over_algorithmic"] * algo_bytes
-            traffic_src = f"profiles/pmc_r2.json ratio {pmc['traffic_over_algorithmic']:.3f} measured at batch {pmc['batch']}"
-        except Exception:
-            pass
+        for name in ("pmc_r3.json", "pmc_r2.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                traffic = pmc["traffic_over_algorithmic"] * algo_bytes
+                traffic_src = f"profiles/{name} ratio {pmc['traffic_over_algorithmic']:.3f} measured at batch {pmc['batch']}"
+                break
+            except Exception:
+                pass
         step_s = elapsed / args.steps
+        res_s = resident / args.steps
+        flat = commits.reshape(-1).astype(np.uint64)
         out = {
             "metric": "constraints/s + witness-rows/s, main_vm 2^20 rows", "value": constraints / elapsed, "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * step_s,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks)", "data": "synthetic",
+            "value_is": "from the raw witness: every timed step seeds one window of the stream (second HIP stream) and resolves + checks one",
             "witness_rows_per_s": rows / elapsed,
-            # the whole path from the raw witness: one seeding pass over the K-window stream + K steps
-            "value_from_raw_witness": st["constraints_per_instance"] * n_inst * K / (seed_all + K * step_s),
-            "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/vm_bench_witness.npz)"
+            "vm_cycles_per_s": n_inst * limit * args.steps / elapsed,
+            "value_inputs_resident": per_step_constraints / res_s,
+            "value_from_raw_witness_serial": per_step_constraints / (res_s + t_seed_window),
+            "witness_rows_materialised_per_s": None if mat_s is None else st["rows_per_instance"] * n_inst / (step_s + B * mat_s),
+            "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/vm_bench_witness.npz, "
+                                    f"{n_exec} distinct executions through zk_pack_main_vm_witness)"
                                     if args.workload == "main_vm" else "main_vm-shaped micro-workload (round 1)") +
                                    f", geometry 140/0/8/deg8 + 3x8 lookups, 2^{args.log2_rows} rows/instance",
                        "instances_per_gpu": B, "cycles_per_instance": limit, "rows_per_instance": st["rows_per_instance"],
                        "constraints_per_instance": st["constraints_per_instance"], "parallelism": f"independent instances x{world}",
-                       "input_seeding_s": round(seed_all, 4), "seeded_stream_instances_per_gpu": S, "seeding_s_per_batch": round(seed_all / K, 4), "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
+                       "raw_witness_windows_resident_per_gpu": K,
+                       "seed_one_window_alone_s": round(t_seed_window, 4), "seed_whole_stream_alone_s": round(t_seed_stream, 4),
+                       "seeding_instances_per_s": S / t_seed_stream, "ms_per_step_inputs_resident": 1e3 * res_s,
+                       "host_pack_s": round(t_pack, 3), "trace_columns_s_per_instance": mat_s,
+                       "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
                        "commitments_equal_native_restatement": parity, "commitment_gather": gather_path},
             "roofline": {"bound": "hbm", "kernel": "zke::k_witness_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
+                         "unit_of_work": "values (one per variable, 8 B): the variable store; trace cells are a view of it",
                          "avg_launch_ms": k_ms,
                          "values_written_per_cycle": st["cells_written_loop"], "trace_cells_populated_per_cycle": st["cells_populated_loop"],
                          "trace_cell_equivalent_GBps": cell_bytes / (k_ms * 1e-3) / 1e9,
                          "hbm_busy_GBps": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,
                          "other_kernels_ms": {"loop_gates_plus_copies_check": float(np.mean(check_ms)), "k_check_gates_loop": float(np.mean(gate_ms)),
                                               "outer_post_and_checks_overlapped": float(np.mean(outer_ms))}},
-            "commitment_checksum": int(np.bitwise_xor.reduce(commits.reshape(-1))) & 0xFFFFFFFFFFFF,
+            # sum (mod 2^64) of every gathered commitment word times its position + 1: cannot cancel like an XOR of repeated rows
+            "commitment_checksum": int((flat * (np.arange(flat.size, dtype=np.uint64) + np.uint64(1))).sum(dtype=np.uint64)),
+            "distinct_commitments": int(len({tuple(r) for r in commits.reshape(-1, commits.shape[-1]).tolist()})),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.log2_rows)
@@ -373,9 +418,8 @@ def main():
             out["cpu_baseline"] = None
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
-    if hung:
-        os._exit(0)   # a thread is still inside a collective that will never complete
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -325,6 +325,11 @@ int zk_cs_resolve(zk_cs* cs, void* stream) {
     NEED(cs); NEED_INIT();
     return guard([&] { cs->cs->resolve(stream); });
 }
+int zk_cs_seed_window_async(zk_cs* cs, uint32_t n_instances, const uint64_t* dev_outer_window, uint64_t outer_lane_stride, uint64_t* dev_loop_window_rw,
+                            uint64_t loop_lane_stride, void* stream) {
+    NEED(cs);
+    return guard([&] { cs->cs->seed_stream(n_instances, dev_outer_window, dev_loop_window_rw, stream, false, outer_lane_stride, loop_lane_stride); });
+}
 int zk_cs_seed_carried_inputs(zk_cs* cs, uint64_t* dev_loop_inputs_rw, void* stream) {
     NEED(cs); NEED_INIT();
     return guard([&] { cs->cs->seed_carried_inputs(dev_loop_inputs_rw, stream); });

@@ -89,6 +89,7 @@ CS::~CS() {
     if (d_native_blob_) hipFree(d_native_blob_);
     if (d_state0_slot_) hipFree(d_state0_slot_);
     if (d_native_scratch_) hipFree(d_native_scratch_);
+    if (d_seed_outer_) hipFree(d_seed_outer_);
     for (auto p : d_streams_) if (p) hipFree(p);
     if (d_carries_) hipFree(d_carries_);
     for (int i = 0; i < 2; ++i) {
@@ -1196,10 +1197,10 @@ void CS::build_strands(Scope& s) {
 }
 
 // phase 0 = loop body / outer pre, 1 = outer side, 2 = outer post
-void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream) const {
+void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream, uint32_t n_lanes) const {
     const char* e = getenv("ZKGL_STRANDS");  // 0 off, 1 always, unset: by size and estimated gain
     const int mode = e ? atoi(e) : -1;
-    const uint32_t waves = (s.n_lanes + 63) / 64;
+    const uint32_t waves = ((n_lanes ? n_lanes : s.n_lanes) + 63) / 64;
     // worth it when the scope is short of wavefronts AND its op graph is wide (hash circuits); chains of Poseidon2
     // permutations (queue circuits, the commitments of every outer scope) only pay for the barriers.  A scope of a few
     // wavefronts (outer scopes) has the chip to itself and takes any gain; one of hundreds needs a clear one (measured:
@@ -2161,6 +2162,7 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
     const size_t need = zkdev::vm_seed_scratch_bytes(limit_, n);
     if (need > native_scratch_bytes_) {
         if (d_native_scratch_) hipFree(d_native_scratch_);
+    if (d_seed_outer_) hipFree(d_seed_outer_);
         d_native_scratch_ = nullptr; native_scratch_bytes_ = 0;
         hip_check(hipMalloc((void**)&d_native_scratch_, need), "hipMalloc vm seed scratch");
         native_scratch_bytes_ = need;
@@ -2216,7 +2218,8 @@ void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {
 // lanes, then the cone.  The chain of `limit` iterations is a latency bound per instance and the kernel keeps one small block
 // per few instances, so a pass over ~1000 instances costs what a pass over 8 does; a host seeds a long stream once and then
 // resolves it in windows (bind_inputs with lane_stride = the stream length).  Layouts: outer [word][n], loop [word][n * limit].
-void CS::seed_stream(uint32_t n, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream) {
+void CS::seed_stream(uint32_t n, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream, bool synchronize, uint64_t outer_stride,
+                     uint64_t loop_stride) {
     if (!finalized_) throw ZkError(ZK_ERR_INVALID, "seed_stream before finalize");
     if (!limit_ || n == 0) return;
     ensure_uploaded();
@@ -2225,24 +2228,25 @@ void CS::seed_stream(uint32_t n, const uint64_t* dev_outer_inputs, uint64_t* dev
     if ((uint64_t)n * limit_ >= 0xffffffffull) throw ZkError(ZK_ERR_CAPACITY, "n*limit exceeds 32-bit lane index");
     hipStream_t st = (hipStream_t)stream;
     const uint64_t tiles = ((uint64_t)n + 63) / 64;
-    uint64_t* tmp_outer = nullptr;
-    hip_check(hipMalloc((void**)&tmp_outer, std::max<size_t>((size_t)outer_.n_store * tiles * 64 * 8, 8)), "hipMalloc seed outer store");
-    Scope o = outer_, l = loop_;  // shallow views with the stream's lane counts (device pointers are shared, nothing is freed through them)
-    o.d_store = tmp_outer; o.n_lanes = n; o.d_inputs = dev_outer_inputs; o.input_stride = 0;
-    l.d_store = nullptr; l.n_lanes = (uint32_t)((uint64_t)n * limit_); l.d_inputs = dev_loop_inputs_rw; l.input_stride = 0;
-    try {
-        auto oa = scope_args(o, o, l, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
-        auto la = scope_args(l, o, l, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
-        launch_phase(o, oa, 0, st);
-        launch_seed(la, oa, dev_loop_inputs_rw, n, st);
-        hip_check(hipStreamSynchronize(st), "seed sync");
-    } catch (...) {
-        o.d_store = nullptr; l.d_store = nullptr;
-        hipFree(tmp_outer);
-        throw;
+    // temporary outer store of the stream's lane count: kept across calls (a host seeds stream after stream of the same size)
+    const size_t need = std::max<size_t>((size_t)outer_.n_store * tiles * 64 * 8, 8);
+    if (need > seed_outer_bytes_) {
+        if (d_seed_outer_) hipFree(d_seed_outer_);
+        d_seed_outer_ = nullptr; seed_outer_bytes_ = 0;
+        hip_check(hipMalloc((void**)&d_seed_outer_, need), "hipMalloc seed outer store");
+        seed_outer_bytes_ = need;
     }
-    o.d_store = nullptr; l.d_store = nullptr;
-    hipFree(tmp_outer);
+    // the scopes' own arguments with the stream's lane counts and buffers patched in (no copy of the Scope objects: their program
+    // vectors are tens of MB for main_vm)
+    auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
+    auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, nullptr, total_table_rows_);
+    if ((outer_stride && outer_stride < n) || (loop_stride && loop_stride < (uint64_t)n * limit_)) throw ZkError(ZK_ERR_INVALID, "seed_stream: lane stride shorter than the window");
+    oa.cells = d_seed_outer_; oa.n_lanes = n; oa.inputs = dev_outer_inputs; oa.in_stride = outer_stride ? outer_stride : n; oa.outer_cells = d_seed_outer_; oa.loop_cells = nullptr;
+    la.cells = nullptr; la.n_lanes = (uint32_t)((uint64_t)n * limit_); la.inputs = dev_loop_inputs_rw; la.in_stride = loop_stride ? loop_stride : (uint64_t)n * limit_;
+    la.outer_cells = d_seed_outer_; la.loop_cells = nullptr;
+    launch_phase(outer_, oa, 0, st, n);
+    launch_seed(la, oa, dev_loop_inputs_rw, n, st);
+    if (synchronize) hip_check(hipStreamSynchronize(st), "seed sync");
 }
 
 void CS::resolve(void* stream) {

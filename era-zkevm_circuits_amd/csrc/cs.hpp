@@ -192,7 +192,8 @@ class CS {
     int check_satisfied_impl(void* stream, zk_failure* first, bool macro);
     int hook_compare_witness(const zk_var* vars, uint32_t n_vars, const uint64_t* dev_expected, void* stream, zk_failure* first);
     uint32_t batch() const { return batch_; }
-    void seed_stream(uint32_t n_instances, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream);
+    void seed_stream(uint32_t n_instances, const uint64_t* dev_outer_inputs, uint64_t* dev_loop_inputs_rw, void* stream, bool synchronize = true,
+                     uint64_t outer_stride = 0, uint64_t loop_stride = 0);  // strides: lanes between words when the n instances are a window of a longer stream
     void resolve(void* stream);
     // sequential seeding of the carried input words (generic, slow): see kernels_engine.hpp k_witness_seq
     void seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream);
@@ -264,7 +265,7 @@ class CS {
     void check_streams(void* stream, bool compact);
     void check_inputs_canonical(void* outer_stream, void* loop_stream);
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
-    void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream) const;
+    void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream, uint32_t n_lanes = 0) const;  // n_lanes: lane count when the arguments were patched for a stream
     void build_check_program(Scope& s);
     void build_mult_sites(Scope& s);
     void count_multiplicities(void* stream);
@@ -349,6 +350,8 @@ class CS {
     uint32_t* d_state0_slot_ = nullptr;
     uint64_t* d_native_scratch_ = nullptr;
     size_t native_scratch_bytes_ = 0;
+    uint64_t* d_seed_outer_ = nullptr;   // seed_stream's outer store
+    size_t seed_outer_bytes_ = 0;
     void* ev_[8] = {nullptr};
     void* ev2_[8] = {nullptr};
     void* aux_stream_ = nullptr;

@@ -717,6 +717,7 @@ class ConstraintSystem:
         self._h = h
         self.geometry = geometry
         self._keep = []
+        self._keep_inputs = {}
 
     def close(self):
         if self._h:
@@ -954,7 +955,7 @@ class ConstraintSystem:
 
     def bind_inputs(self, loop_scope: bool, dev_words, n_words: int, lane_stride: int = 0, lane_offset: int = 0):
         """lane_stride / lane_offset: the batch is a window of a longer stream ([word][lane_stride] u64, first lane lane_offset)"""
-        self._keep.append(dev_words)
+        self._keep_inputs[bool(loop_scope)] = dev_words   # one reference per scope: the bound buffer must outlive the binding
         if lane_stride or lane_offset:
             base = (_ptr(dev_words).value or 0) + 8 * lane_offset
             _check(lib().zk_cs_bind_inputs_window(self._h, int(loop_scope), C.c_void_p(base), n_words, C.c_uint64(lane_stride)))
@@ -974,6 +975,7 @@ class ConstraintSystem:
         if comm._out is None or comm._out.n < comm.world * self._batch * 8:
             comm._out = DeviceBuffer(comm.world * self._batch * 8)
         _check(lib().zk_cs_gather_commitments(self._h, comm._h, _ptr(comm._out), C.byref(n), _ptr(stream)))
+        sync(stream)   # the pack kernel and the all-gather were queued on `stream`; the copy below is not ordered after a non-blocking stream
         flat = comm._out.to_numpy()[: comm.world * self._batch * n.value]
         return flat.reshape(comm.world, self._batch, n.value)
 
@@ -1006,6 +1008,14 @@ class ConstraintSystem:
     def seed_stream(self, n_instances: int, dev_outer_inputs, dev_loop_inputs, stream=None):
         """seed a stream of n_instances (any n, independent of set_batch): outer [word][n], loop [word][n * limit] (zk_cs_seed_stream)"""
         _check(lib().zk_cs_seed_stream(self._h, n_instances, _ptr(dev_outer_inputs), _ptr(dev_loop_inputs), _ptr(stream)))
+
+    def seed_window_async(self, n_instances: int, dev_outer, n_outer_lanes: int, dev_loop, n_loop_lanes: int, first_instance: int, stream=None):
+        """zk_cs_seed_window_async: seed instances [first, first + n) of a stream (outer [word][n_outer_lanes], loop [word][n_loop_lanes]);
+        the kernels are queued on `stream`, the caller synchronises it before the window is read"""
+        limit = self.stats()["limit"]
+        po = C.c_void_p(_ptr(dev_outer).value + 8 * first_instance)
+        pl = C.c_void_p(_ptr(dev_loop).value + 8 * first_instance * limit)
+        _check(lib().zk_cs_seed_window_async(self._h, n_instances, po, C.c_uint64(n_outer_lanes), pl, C.c_uint64(n_loop_lanes), _ptr(stream)))
 
     def check_if_satisfied(self, stream=None):
         """Returns (True, None) or (False, Failure)."""

@@ -183,6 +183,14 @@ int zk_cs_seed_carried_inputs(zk_cs *cs, uint64_t *dev_loop_inputs_rw, void *str
  * (zk_cs_bind_inputs_window).  Replaces the sequential part of the reference's witness resolution
  * (/root/reference/src/main_vm/mod.rs: the `for _cycle_idx in 0..limit` loop over vm_cycle). */
 int zk_cs_seed_stream(zk_cs *cs, uint32_t n_instances, const uint64_t *dev_outer_inputs, uint64_t *dev_loop_inputs_rw, void *stream);
+/* A WINDOW of a longer stream, without the final synchronisation: n_instances consecutive instances whose first lane the two pointers
+ * address (outer word w of instance i at dev_outer_window[w * outer_lane_stride + i], loop word w of cycle c at
+ * dev_loop_window_rw[w * loop_lane_stride + i * limit + c]; a stride of 0 = dense).  The kernels are queued on `stream` and the call
+ * returns: a host seeds the next window of raw witness on one HIP stream while zk_cs_resolve_and_check works through the previous one
+ * on another (seeding is a latency chain on a few hundred wavefronts, the step kernels are bandwidth-bound: they overlap).  One seeding
+ * pass at a time per zk_cs (its scratch buffers are reused); the window must not be read until the stream has been synchronised. */
+int zk_cs_seed_window_async(zk_cs *cs, uint32_t n_instances, const uint64_t *dev_outer_window, uint64_t outer_lane_stride,
+                            uint64_t *dev_loop_window_rw, uint64_t loop_lane_stride, void *stream);
 typedef struct zk_failure { uint32_t scope, instance, iteration, slot, kind, relation; } zk_failure;
 /* kind: a zk_gate_kind; 0x100 lookup tuple (relation = tuple); 0x200 copy constraint; 0x300 link / stream link;
  * ZK_FAILURE_NONCANONICAL_INPUT: input stream word `slot` (mod 256) of that lane is not a canonical field element (>= p) */

@@ -197,7 +197,7 @@ def test_c2_main_vm_2_20_rows(zk):
     st = cs.stats()
     assert st["rows_per_instance"] <= 1 << 20 and st["rows_per_instance"] > (1 << 20) - 2 * st["loop_slots"]
     B = 8
-    outer, loop, expect = bench.main_vm_streams(cs, limit, B)
+    outer, loop, expect = bench.main_vm_streams(zkgl, cs, limit, B)   # the fixture's VmCircuitWitnesses through zk_pack_main_vm_witness
     assert expect is not None, "the fixture was generated for another limit"
     assert not loop[0:bench.VM_STATE_WORDS].any()                      # raw witness only: the carried VmLocalState words are blank
     d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)

@@ -79,3 +79,20 @@ def test_packer_reports_underflow_and_rejects_foreign_circuits():
     other.pad_and_shrink()
     with pytest.raises(zkgl.ZkError):
         other.pack_main_vm_witness(vp.closed_form_input(run, 0), q.view(), 0, 1, outer, loop)
+
+
+def test_bench_fixture_packs_without_underflow():
+    """tests/golden/vm_bench_witness.npz (64 executions as WitnessOracle FIFOs) -> streams: every FIFO exactly consumed, 64 distinct
+    executions, raw words only (bench.py and tests/test_gpu_full_size.py feed the device from this)"""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    cs, limit = bench.build_main_vm_cs(zkgl, 20)
+    outer, loop, expect = bench.main_vm_streams(zkgl, cs, limit, 16)
+    assert expect is not None and outer.shape[1] == 16 and loop.shape[1] == 16 * limit
+    assert not loop[:243].any()
+    lay = cs.main_vm_layout()["loop"]
+    f, n = lay["code_word"]
+    assert len({loop[f:f + n, e * limit:(e + 1) * limit].tobytes() for e in range(16)}) == 16

@@ -412,7 +412,12 @@ def mixed_batch(cs, D, limit, min_instances, seeds=None):
             done_at = next(i for i, s in enumerate(probe.states) if s.depth == 0)
             n_inst = (done_at + 1 + limit - 1) // limit
             vrun = vn.VmRun(D, make_world_factory(D, ops, contracts), n_inst * limit)
-            o, l = pack_instance_streams(cs, D, vrun, limit, n_inst)
+            # the streams the circuit is fed come from the product's packer (zk_pack_main_vm_witness over the oracle FIFOs); the native
+            # model's own placement of the answers only checks them, and supplies the expected per-cycle VmLocalState
+            o, l = pack_through_the_c_abi(cs, vrun, limit, n_inst)[:2]
+            want_o, want_l = pack_instance_streams(cs, D, vrun, limit, n_inst)
+            assert np.array_equal(o, want_o) and np.array_equal(l[243:], want_l[243:]) and not l[:243].any(), (name, seed)
+            l[:243] = want_l[:243]   # expected state, blanked again by the tests before it reaches the device
             outers.append(o); loops.append(l)
             commits += [expected_commitment(D, vrun, limit, i) for i in range(n_inst)]
             info += [(name, seed, i) for i in range(n_inst)]
