@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=384, help="independent circuit instances per GPU per step")
-    ap.add_argument("--seed-windows", type=int, default=5, help="batches of raw witness resident per GPU (the stream = batch x windows instances, >= 2)")
+    ap.add_argument("--seed-windows", type=int, default=0, help="batches per stream of raw witness (0: = --steps, clamped to 2..8); two streams are resident per GPU")
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--workload", default="main_vm", choices=["main_vm", "vm_shaped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -222,11 +222,16 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     B = args.batch
-    K = max(2, args.seed_windows)     # the raw witness stream holds K batches: window k+1 is seeded while window k is resolved
+    # raw witness: a stream of K batches is resident; ONE seeding pass derives the VM state of all its K * B instances (a pass is a
+    # latency chain: it costs about the same for 384 and for 1920 instances, so long passes are the cheap way to do it), then K steps
+    # resolve and check its K windows.  K = --steps: any K consecutive steps contain exactly one pass.  (Running the pass of the next
+    # stream underneath the steps on a second HIP stream was measured and lost: its 2 000 long-lived wavefronts take registers from
+    # the bandwidth-bound step kernels for longer than the pass takes alone — profiles/r3_summary.md.)
+    K = args.seed_windows if args.seed_windows >= 2 else min(max(args.steps, 2), 8)
     S = B * K
     expect = None
     step_stream = torch.cuda.current_stream()
-    seed_stream = torch.cuda.Stream(device=dev, priority=-1)   # few long-lived wavefronts: let them in first
+    seed_stream = step_stream
     stream = step_stream.cuda_stream
     if args.workload == "main_vm":
         cs, limit = build_main_vm_cs(zkgl, args.log2_rows)
@@ -242,6 +247,7 @@ def main():
         d_loop = le[:, sel, :].reshape(n_loop, S * limit).contiguous()
         del le, loop_e
         expect = None if expect_e is None else expect_e[((np.arange(S) + rank * S) % n_exec)]
+        bufs = [d_loop]
     else:
         cs, limit = build_vm_shaped_cs(zkgl, args.log2_rows)
         n_outer, n_loop = cs.input_words()
@@ -250,24 +256,27 @@ def main():
         d_loop = torch.from_numpy(loop.view(np.int64)).to(dev)
         del loop
         n_exec, t_pack = 0, 0.0
+        bufs = [d_loop]
     st = cs.stats()
     cs.set_batch(B)
 
-    def seed_window(k, sync=True):
+    cur = [0]   # the stream being resolved; the other one is being seeded
+
+    def seed(buf, first, n, sync=True):
         with torch.cuda.stream(seed_stream):
-            cs.seed_window_async(B, d_outer, S, d_loop, S * limit, k * B, seed_stream.cuda_stream)
+            cs.seed_window_async(n, d_outer, S, bufs[buf], S * limit, first, seed_stream.cuda_stream)
         if sync:
             seed_stream.synchronize()
 
     def bind(k):
         cs.bind_inputs(False, d_outer, n_outer, lane_stride=S, lane_offset=k * B)
-        cs.bind_inputs(True, d_loop, n_loop, lane_stride=S * limit, lane_offset=k * B * limit)
+        cs.bind_inputs(True, bufs[cur[0]], n_loop, lane_stride=S * limit, lane_offset=k * B * limit)
 
-    # ---- seeding alone (not overlapped with anything): one window, and the whole stream in one pass
+    # ---- seeding alone (not overlapped with anything): one window, and a whole stream in one pass
     torch.cuda.synchronize()
-    seed_window(0)                                  # first call allocates the scratch
-    t = time.perf_counter(); seed_window(0); t_seed_window = time.perf_counter() - t
-    t = time.perf_counter(); cs.seed_stream(S, d_outer, d_loop, stream); torch.cuda.synchronize(); t_seed_stream = time.perf_counter() - t
+    seed(0, 0, S)                                   # first call allocates the scratch
+    t = time.perf_counter(); seed(0, 0, B); t_seed_window = time.perf_counter() - t
+    t = time.perf_counter(); seed(0, 0, S); t_seed_stream = time.perf_counter() - t
     window = [0]
     step_no = [0]
 
@@ -279,12 +288,12 @@ def main():
             raise RuntimeError(f"trace not satisfied: {failure}")
 
     def step():
-        """one batch from the raw witness: seed the next window (second stream) while this window is resolved and checked"""
+        """one batch from the raw witness: at window 0 the stream's seeding pass (all K batches), then window k is resolved and checked"""
         k = step_no[0] % K
+        if k == 0:
+            seed(0, 0, S, sync=False)       # same stream order as the step kernels: queued, not waited for
         step_no[0] += 1
-        seed_window((k + 1) % K, sync=False)
         resolve(k)
-        seed_stream.synchronize()
 
     def fence():
         torch.cuda.synchronize()
@@ -381,11 +390,11 @@ def main():
             "metric": "constraints/s + witness-rows/s, main_vm 2^20 rows", "value": constraints / elapsed, "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * step_s,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks)", "data": "synthetic",
-            "value_is": "from the raw witness: every timed step seeds one window of the stream (second HIP stream) and resolves + checks one",
+            "value_is": f"from the raw witness: every K = {K} steps start with ONE seeding pass that derives the per-cycle VM state of the stream's {S} instances, then resolve + check its K windows",
             "witness_rows_per_s": rows / elapsed,
             "vm_cycles_per_s": n_inst * limit * args.steps / elapsed,
             "value_inputs_resident": per_step_constraints / res_s,
-            "value_from_raw_witness_serial": per_step_constraints / (res_s + t_seed_window),
+            "value_from_raw_witness_serial": per_step_constraints / (res_s + t_seed_stream / K),
             "witness_rows_materialised_per_s": None if mat_s is None else st["rows_per_instance"] * n_inst / (step_s + B * mat_s),
             "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/vm_bench_witness.npz, "
                                     f"{n_exec} distinct executions through zk_pack_main_vm_witness)"
@@ -393,7 +402,7 @@ def main():
                                    f", geometry 140/0/8/deg8 + 3x8 lookups, 2^{args.log2_rows} rows/instance",
                        "instances_per_gpu": B, "cycles_per_instance": limit, "rows_per_instance": st["rows_per_instance"],
                        "constraints_per_instance": st["constraints_per_instance"], "parallelism": f"independent instances x{world}",
-                       "raw_witness_windows_resident_per_gpu": K,
+                       "windows_per_stream": K, "steps_is_a_multiple_of_windows": args.steps % K == 0,
                        "seed_one_window_alone_s": round(t_seed_window, 4), "seed_whole_stream_alone_s": round(t_seed_stream, 4),
                        "seeding_instances_per_s": S / t_seed_stream, "ms_per_step_inputs_resident": 1e3 * res_s,
                        "host_pack_s": round(t_pack, 3), "trace_columns_s_per_instance": mat_s,

@@ -123,6 +123,8 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_copies) hipFree(s.d_copies);
     if (s.d_alias) hipFree(s.d_alias);
     s.d_alias = nullptr;
+    if (s.d_slot1) hipFree(s.d_slot1);
+    s.d_slot1 = nullptr;
     if (s.d_mat_pairs) hipFree(s.d_mat_pairs);
     s.d_mat_pairs = nullptr;
     if (s.d_store) hipFree(s.d_store);
@@ -2162,7 +2164,6 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
     const size_t need = zkdev::vm_seed_scratch_bytes(limit_, n);
     if (need > native_scratch_bytes_) {
         if (d_native_scratch_) hipFree(d_native_scratch_);
-    if (d_seed_outer_) hipFree(d_seed_outer_);
         d_native_scratch_ = nullptr; native_scratch_bytes_ = 0;
         hip_check(hipMalloc((void**)&d_native_scratch_, need), "hipMalloc vm seed scratch");
         native_scratch_bytes_ = need;
@@ -2358,6 +2359,7 @@ void CS::ensure_materialized(void* stream) {
             size_t bytes = std::max<size_t>((size_t)s->n_cells * s->stride * 8, 8);
             if (hipMalloc((void**)&s->d_cells, bytes) != hipSuccess) {
                 s->d_cells = nullptr;
+                (void)hipGetLastError();  // the refusal is reported here: it must not surface again at the next launch check
                 throw ZkError(ZK_ERR_CAPACITY, "materialised trace does not fit in device memory at this batch size (the variable store is 4x smaller)");
             }
             hip_check(hipMemsetAsync(s->d_cells, 0, bytes, st), "hipMemset trace");
@@ -2714,13 +2716,27 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
 
 void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream) {
     if (!finalized_ || batch_ == 0) throw ZkError(ZK_ERR_INVALID, "trace_columns before set_batch");
-    ensure_materialized(stream);
+    // a compact batch stays compact: one instance's columns are read through the trace view (cell -> slot), the whole batch's trace
+    // (4x the store) is never allocated for this
+    if (compact_)
+        for (Scope* s : {&outer_, &loop_})
+            if (!s->d_slot1 && s->n_trace_cells) {
+                std::vector<uint32_t> t(s->n_trace_cells, 0);
+                for (auto& pr : s->mat_pairs)
+                    if (pr.cell < s->n_trace_cells) t[pr.cell] = pr.home + 1;
+                s->d_slot1 = upload(t);
+            }
     if (instance >= batch_) throw ZkError(ZK_ERR_INVALID, "trace_columns: instance out of range");
     const uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
     if (log_n > 32 || ((uint64_t)1 << log_n) < rows) throw ZkError(ZK_ERR_INVALID, "trace_columns: 2^log_n smaller than the trace");
     if (stride < ((uint64_t)1 << log_n)) throw ZkError(ZK_ERR_INVALID, "trace_columns: stride smaller than the column");
     zkdev::ColumnsArgs a;
-    a.loop_cells = loop_.d_cells; a.loop_n_cells = loop_.n_cells; a.outer_cells = outer_.d_cells; a.outer_n_cells = outer_.n_cells;
+    if (compact_) {
+        a.loop_cells = loop_.d_store; a.loop_n_cells = loop_.n_store; a.outer_cells = outer_.d_store; a.outer_n_cells = outer_.n_store;
+        a.loop_slot1 = loop_.d_slot1; a.outer_slot1 = outer_.d_slot1;
+    } else {
+        a.loop_cells = loop_.d_cells; a.loop_n_cells = loop_.n_cells; a.outer_cells = outer_.d_cells; a.outer_n_cells = outer_.n_cells;
+    }
     a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
     a.loop_slots = limit_ ? loop_.n_slots : 0; a.outer_slots = outer_.n_slots; a.limit = limit_; a.instance = instance;
     a.out = d_out; a.stride = stride; a.n_rows_padded = (uint64_t)1 << log_n;

@@ -137,6 +137,7 @@ struct Scope {
     zk_lookup_row_desc* d_lrows = nullptr;
     zk_copy_pair* d_copies = nullptr;
     uint32_t* d_alias = nullptr;
+    uint32_t* d_slot1 = nullptr;   // trace cell -> store slot + 1 of the variable placed there, 0 = unpopulated (trace_columns on the compact store)
     zk_copy_pair* d_mat_pairs = nullptr;
     uint64_t* d_store = nullptr;   // variable store, allocated by set_batch
     uint64_t* d_cells = nullptr;   // materialised trace, allocated by the first ensure_materialized

@@ -113,6 +113,7 @@ int launch_perm_z(const uint64_t* excl, const uint64_t* prefix, uint32_t n_lanes
 struct ColumnsArgs {  // mirrors zkn::ColumnsDev
     const uint64_t* loop_cells; uint64_t loop_n_cells; const uint64_t* outer_cells; uint64_t outer_n_cells;
     uint32_t n_cols, loop_slots, outer_slots, limit, instance; uint64_t* out; uint64_t stride; uint64_t n_rows_padded;
+    const uint32_t* loop_slot1 = nullptr; const uint32_t* outer_slot1 = nullptr;  // compact mode: trace cell -> store slot + 1 (0: unpopulated)
 };
 int launch_trace_columns(const ColumnsArgs& a, void* stream);
 int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t* c_hi, uint32_t n_hi, void* stream);

@@ -194,6 +194,9 @@ struct ColumnsDev {
     const uint64_t* outer_cells; uint64_t outer_n_cells;
     uint32_t n_cols, loop_slots, outer_slots, limit, instance;
     uint64_t* out; uint64_t stride; uint64_t n_rows_padded;
+    // compact mode (no materialised trace): *_cells = the variable stores, *_slot1[trace cell] = store slot + 1 of the variable placed
+    // there, 0 for an unpopulated cell — the columns are read straight through the trace view
+    const uint32_t* loop_slot1; const uint32_t* outer_slot1;
 };
 __device__ __forceinline__ size_t tiled(uint64_t n_cells, uint32_t cell, uint32_t lane) {
     return ((size_t)(lane >> 6) * n_cells + cell) * 64 + (lane & 63);
@@ -204,8 +207,12 @@ __global__ __launch_bounds__(256) void k_trace_columns_loop(ColumnsDev d) {
     const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (uint32_t sy = ty; sy < 32; sy += 4) {
         const uint32_t slot = s0 + sy, k = k0 + tx;
-        if (slot < d.loop_slots && k < d.limit)
-            tile[sy][tx] = d.loop_cells[tiled(d.loop_n_cells, slot * d.n_cols + col, d.instance * d.limit + k)];
+        if (slot < d.loop_slots && k < d.limit) {
+            uint32_t cell = slot * d.n_cols + col;
+            bool populated = true;
+            if (d.loop_slot1) { const uint32_t s1 = d.loop_slot1[cell]; populated = s1 != 0; cell = s1 - 1; }
+            tile[sy][tx] = populated ? d.loop_cells[tiled(d.loop_n_cells, cell, d.instance * d.limit + k)] : 0;
+        }
     }
     __syncthreads();
     const uint32_t sx = threadIdx.x & 31, ky = threadIdx.x >> 5;
@@ -221,7 +228,14 @@ __global__ __launch_bounds__(256) void k_trace_columns_tail(ColumnsDev d) {
     const uint64_t row = first + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= d.n_rows_padded) return;
     const uint64_t s = row - first;
-    d.out[(size_t)col * d.stride + row] = s < d.outer_slots ? d.outer_cells[tiled(d.outer_n_cells, (uint32_t)s * d.n_cols + col, d.instance)] : 0;
+    uint64_t v = 0;
+    if (s < d.outer_slots) {
+        uint32_t cell = (uint32_t)s * d.n_cols + col;
+        bool populated = true;
+        if (d.outer_slot1) { const uint32_t s1 = d.outer_slot1[cell]; populated = s1 != 0; cell = s1 - 1; }
+        if (populated) v = d.outer_cells[tiled(d.outer_n_cells, cell, d.instance)];
+    }
+    d.out[(size_t)col * d.stride + row] = v;
 }
 
 }  // namespace zkn

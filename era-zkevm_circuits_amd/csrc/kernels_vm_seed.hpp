@@ -45,7 +45,12 @@ struct SeedDev {
     uint4* counts;              // [inst][limit]: events of (mem, dec, fwd, sponge) in cycles < c
     uint4* totals;              // [inst]
     u32 n_loop_words;           // words per cycle of the loop stream (243 state words, then the oracle words)
+    // the pass is cut into chunks of cycles so that the chains of chunk j run (second stream) while the walker is in chunk j + 1:
+    u32 c0, c1, chunk;          // this launch: cycles [c0, c1), chunk index
+    uint4* chunk_totals;        // [chunk][inst]: events up to the end of the chunk
+    u32* saved_state;           // [inst][SAVE_WORDS]: the walker's State between chunks
 };
+constexpr u32 SAVE_WORDS = (sizeof(vmn::State) + 3) / 4;
 
 __device__ __forceinline__ u64 outer_value(const SeedDev& a, u32 inst, u32 slot) {
     return a.outer_store[((u64)(inst >> 6) * a.outer_n_store + slot) * 64 + (inst & 63)];
@@ -109,23 +114,28 @@ __global__ __launch_bounds__(64) void k_vm_walk(SeedDev a) {
     const u32 inst = blockIdx.x;
     const u64 lane0 = (u64)inst * a.limit;
     const u32 first_raw = vmn::STATE_WORDS, n_raw = a.n_loop_words - vmn::STATE_WORDS;
-    // cycle 0 takes the outer scope's words verbatim (chain words included: they are snapshot 0 of every chain)
-    for (u32 w = lane; w < (u32)vmn::STATE_WORDS; w += 64) {
-        const u64 v = outer_value(a, inst, a.state0_slot[w]);
-        flat[w] = v;
-        a.loop[(u64)w * a.in_stride + lane0] = v;
+    if (a.c0 == 0) {
+        // cycle 0 takes the outer scope's words verbatim (chain words included: they are snapshot 0 of every chain)
+        for (u32 w = lane; w < (u32)vmn::STATE_WORDS; w += 64) {
+            const u64 v = outer_value(a, inst, a.state0_slot[w]);
+            flat[w] = v;
+            a.loop[(u64)w * a.in_stride + lane0] = v;
+        }
+    } else {
+        for (u32 w = lane; w < SAVE_WORDS; w += 64) ((u32*)&st)[w] = a.saved_state[(u64)inst * SAVE_WORDS + w];
     }
     for (u32 i = lane; i < TABLE_ROWS_LDS; i += 64) { g_props[i] = a.D.props[i]; g_prices[i] = a.D.prices[i]; }
     auto fetch = [&](u32 c, u32 k) -> u64 { return k < n_raw ? a.loop[(u64)(first_raw + k) * a.in_stride + lane0 + c] : 0; };
-    raw[0][lane] = fetch(0, lane);
-    raw[0][lane + 64] = fetch(0, lane + 64);
+    raw[a.c0 & 1][lane] = fetch(a.c0, lane);
+    raw[a.c0 & 1][lane + 64] = fetch(a.c0, lane + 64);
     __syncthreads();
     const vmn::Defs& D = a.D;  // kernel argument: its small fields are scalar loads
     DevEnv env;
     if (lane == 0) {
         gctx.zkporter_is_available = (u32)a.outer_inputs[(u64)a.w_zkporter * a.outer_in_stride + inst];
         for (int i = 0; i < 8; ++i) gctx.default_aa_code_hash.l[i] = (u32)a.outer_inputs[(u64)(a.w_default_aa + i) * a.outer_in_stride + inst];
-        vmn::state_unflatten(st, [&](int w) { return flat[w]; });
+        if (a.c0 == 0) vmn::state_unflatten(st, [&](int w) { return flat[w]; });
+        else { const uint4 t = a.chunk_totals[(u64)(a.chunk - 1) * a.n_instances + inst]; env.n_mem = t.x; env.n_dec = t.y; env.n_fwd = t.z; env.n_sp = t.w; }
         env.first_raw = first_raw; env.lay = a.raw;
         env.mem_ev = a.mem_ev + (u64)inst * a.cap_mem * EV_MEM;
         env.dec_ev = a.dec_ev + (u64)inst * a.cap_one * EV_DEC;
@@ -135,10 +145,10 @@ __global__ __launch_bounds__(64) void k_vm_walk(SeedDev a) {
 #ifdef ZKGL_VM_WALK_PROFILE
     u64 t_walk = 0, t_flat = 0, t_io = 0, t_fam[16] = {0}, n_fam[16] = {0};
 #endif
-    for (u32 c = 0; c < a.limit; ++c) {
-        const bool more = c + 1 < a.limit;
+    for (u32 c = a.c0; c < a.c1; ++c) {
+        const bool more = c + 1 < a.limit, more_here = c + 1 < a.c1;
         u64 p0 = 0, p1 = 0;
-        if (more) { p0 = fetch(c + 1, lane); p1 = fetch(c + 1, lane + 64); }
+        if (more_here) { p0 = fetch(c + 1, lane); p1 = fetch(c + 1, lane + 64); }
 #ifdef ZKGL_VM_WALK_PROFILE
         const u64 t0 = wall_clock64();
 #endif
@@ -174,7 +184,13 @@ __global__ __launch_bounds__(64) void k_vm_walk(SeedDev a) {
         printf("\n");
     }
 #endif
-    if (lane == 0) a.totals[inst] = make_uint4(env.n_mem, env.n_dec, env.n_fwd, env.n_sp);
+    if (lane == 0) {
+        const uint4 t = make_uint4(env.n_mem, env.n_dec, env.n_fwd, env.n_sp);
+        a.chunk_totals[(u64)a.chunk * a.n_instances + inst] = t;
+        if (a.c1 == a.limit) a.totals[inst] = t;
+    }
+    if (a.c1 < a.limit)
+        for (u32 w = lane; w < SAVE_WORDS; w += 64) a.saved_state[(u64)inst * SAVE_WORDS + w] = ((const u32*)&st)[w];
 }
 
 // ---- phase B: 16-lane rows (one DPP row each), 12 lanes = the 12 state elements of one chain, lanes 12..15 hold zero.
@@ -270,8 +286,11 @@ __global__ __launch_bounds__(256) void k_vm_chains(SeedDev a) {
     const bool live = group < total_groups;
     const u32 kind = live ? (u32)(group / a.n_instances) : 0;
     const u32 inst = live ? (u32)(group % a.n_instances) : 0;
-    const uint4 tot = a.totals[inst];
-    u32 n = kind == 0 ? tot.x : kind == 1 ? tot.y : kind == 2 ? tot.z : tot.w;
+    const uint4 tot = a.chunk_totals[(u64)a.chunk * a.n_instances + inst];
+    uint4 tot0 = make_uint4(0, 0, 0, 0);
+    if (a.chunk) tot0 = a.chunk_totals[(u64)(a.chunk - 1) * a.n_instances + inst];
+    const u32 k0 = kind == 0 ? tot0.x : kind == 1 ? tot0.y : kind == 2 ? tot0.z : tot0.w;   // events [k0, k0 + n) belong to this chunk
+    u32 n = (kind == 0 ? tot.x : kind == 1 ? tot.y : kind == 2 ? tot.z : tot.w) - k0;
     if (!live) n = 0;
     // the wavefront walks max(n) events; rows that are done keep computing and store nothing
     u32 n_max = n;
@@ -279,12 +298,15 @@ __global__ __launch_bounds__(256) void k_vm_chains(SeedDev a) {
     for (int off = 16; off < 64; off <<= 1) n_max = max(n_max, (u32)__shfl_xor((int)n_max, off));
     const u32 first_word = kind == 0 ? vmn::SW_MEM_TAIL : kind == 1 ? vmn::SW_DEC_TAIL : kind == 2 ? vmn::SW_FWD_TAIL : vmn::SW_SPONGE;
     const u32 width = kind == 2 ? 4 : 12;
-    u64 x = (e < width) ? outer_value(a, inst, a.state0_slot[first_word + e]) : 0;
+    u64 x = 0;
     const u64* ev = kind == 0 ? a.mem_ev + (u64)inst * a.cap_mem * EV_MEM : kind == 1 ? a.dec_ev + (u64)inst * a.cap_one * EV_DEC
                   : kind == 2 ? a.fwd_ev + (u64)inst * a.cap_one * EV_FWD : a.sp_ev + (u64)inst * a.cap_one * EV_SP;
     u64* snap = kind == 0 ? a.mem_snap + (u64)inst * a.cap_mem * 12 : kind == 1 ? a.dec_snap + (u64)inst * a.cap_one * 12
               : kind == 2 ? a.fwd_snap + (u64)inst * a.cap_one * 4 : a.sp_snap + (u64)inst * a.cap_one * 12;
     const u32 ev_words = kind == 0 ? EV_MEM : kind == 1 ? EV_DEC : kind == 2 ? EV_FWD : EV_SP;
+    if (e < width) x = k0 ? snap[(u64)(k0 - 1) * width + e] : outer_value(a, inst, a.state0_slot[first_word + e]);   // the chain's state where the chunk starts
+    ev += (u64)k0 * ev_words;
+    snap += (u64)k0 * width;
     // permutations per event by kind: 1, 1, 3, 4 — every row runs the wavefront's maximum and keeps what it needs
     u32 kmax = kind;
 #pragma unroll

@@ -302,6 +302,7 @@ int launch_trace_columns(const ColumnsArgs& a, void* stream) {
     d.loop_cells = a.loop_cells; d.loop_n_cells = a.loop_n_cells; d.outer_cells = a.outer_cells; d.outer_n_cells = a.outer_n_cells;
     d.n_cols = a.n_cols; d.loop_slots = a.loop_slots; d.outer_slots = a.outer_slots; d.limit = a.limit; d.instance = a.instance;
     d.out = a.out; d.stride = a.stride; d.n_rows_padded = a.n_rows_padded;
+    d.loop_slot1 = a.loop_slot1; d.outer_slot1 = a.outer_slot1;
     if (a.limit && a.loop_slots) {
         dim3 grid(a.n_cols, (a.limit + 63) / 64, (a.loop_slots + 31) / 32);
         if (grid.y > 65535 || grid.z > 65535) { g_hip_err = "k_trace_columns_loop: grid too large"; return -2; }
@@ -414,7 +415,8 @@ int launch_seed_wave(const ScopeArgs& sc, const uint16_t* prog, uint32_t prog_u1
 
 // ---- chain-specialised main_vm seeding
 namespace {
-struct VmScratch { size_t mem_ev, dec_ev, fwd_ev, sp_ev, mem_snap, dec_snap, fwd_snap, sp_snap, counts, totals, end; };
+constexpr uint32_t VM_SEED_MAX_CHUNKS = 16;
+struct VmScratch { size_t mem_ev, dec_ev, fwd_ev, sp_ev, mem_snap, dec_snap, fwd_snap, sp_snap, counts, totals, chunk_totals, saved, end; };
 VmScratch vm_scratch_layout(uint32_t limit, uint32_t n) {
     VmScratch L;
     const size_t cap_mem = (size_t)limit * zkvm::MEM_EVENTS_PER_CYCLE, cap_one = limit;
@@ -430,8 +432,31 @@ VmScratch vm_scratch_layout(uint32_t limit, uint32_t n) {
     L.sp_snap = take((size_t)n * cap_one * 12);
     L.counts = take((size_t)n * limit * 2);
     L.totals = take((size_t)n * 2);
+    L.chunk_totals = take((size_t)n * 2 * VM_SEED_MAX_CHUNKS);
+    L.saved = take(((size_t)n * zkvm::SAVE_WORDS + 1) / 2);
     L.end = off;
     return L;
+}
+// two helper streams + events of the chunk pipeline (per process, created on first use)
+struct VmSeedStreams {
+    hipStream_t walk = nullptr, chains = nullptr;
+    hipEvent_t begin = nullptr, done = nullptr, walked[VM_SEED_MAX_CHUNKS] = {};
+    int device = -1;
+};
+VmSeedStreams g_vm_seed;
+int vm_seed_streams() {
+    int dev = 0;
+    if (int r = chk(hipGetDevice(&dev), "hipGetDevice")) return r;
+    if (g_vm_seed.device == dev) return 0;
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (int r = chk(hipStreamCreateWithPriority(&g_vm_seed.walk, hipStreamNonBlocking, hi), "hipStreamCreate")) return r;
+    if (int r = chk(hipStreamCreateWithPriority(&g_vm_seed.chains, hipStreamNonBlocking, hi), "hipStreamCreate")) return r;
+    if (int r = chk(hipEventCreateWithFlags(&g_vm_seed.begin, hipEventDisableTiming), "hipEventCreate")) return r;
+    if (int r = chk(hipEventCreateWithFlags(&g_vm_seed.done, hipEventDisableTiming), "hipEventCreate")) return r;
+    for (auto& e : g_vm_seed.walked) if (int r = chk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return r;
+    g_vm_seed.device = dev;
+    return 0;
 }
 }  // namespace
 size_t vm_seed_scratch_bytes(uint32_t limit, uint32_t n_instances) { return vm_scratch_layout(limit, n_instances).end; }
@@ -452,28 +477,58 @@ int launch_vm_seed(const VmSeedArgs& v, void* stream, float* phase_ms) {
     a.mem_snap = (uint64_t*)(base + L.mem_snap); a.dec_snap = (uint64_t*)(base + L.dec_snap); a.fwd_snap = (uint64_t*)(base + L.fwd_snap);
     a.sp_snap = (uint64_t*)(base + L.sp_snap);
     a.counts = (uint4*)(base + L.counts); a.totals = (uint4*)(base + L.totals);
+    a.chunk_totals = (uint4*)(base + L.chunk_totals); a.saved_state = (uint32_t*)(base + L.saved);
     a.cap_mem = v.limit * zkvm::MEM_EVENTS_PER_CYCLE; a.cap_one = v.limit;
     a.n_loop_words = v.n_loop_words;
     if (v.n_loop_words < (uint32_t)vmn::STATE_WORDS || v.n_loop_words - vmn::STATE_WORDS > zkvm::RAW_MAX) { g_hip_err = "vm seed: oracle words per cycle exceed the staging buffer"; return -1; }
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (phase_ms) for (auto& e : ev) if (int r = chk(hipEventCreate(&e), "hipEventCreate")) return r;
-    if (phase_ms) hipEventRecord(ev[0], st);
-    zkvm::k_vm_walk<<<v.n_instances, 64, 0, st>>>(a);
-    if (int r = LAUNCH_CHECK("k_vm_walk")) return r;
-    if (phase_ms) hipEventRecord(ev[1], st);
     const uint64_t groups = (uint64_t)v.n_instances * 4, per_block = 4 * zkvm::CH_GROUPS;
-    zkvm::k_vm_chains<<<(unsigned)((groups + per_block - 1) / per_block), 256, 0, st>>>(a);
-    if (int r = LAUNCH_CHECK("k_vm_chains")) return r;
-    if (phase_ms) hipEventRecord(ev[2], st);
-    zkvm::k_vm_fill<<<grid_for((size_t)v.n_instances * v.limit, 256), 256, 0, st>>>(a);
-    if (int r = LAUNCH_CHECK("k_vm_fill")) return r;
-    if (phase_ms) {
-        hipEventRecord(ev[3], st);
-        if (int r = chk(hipEventSynchronize(ev[3]), "vm seed sync")) return r;
-        for (int i = 0; i < 3; ++i) hipEventElapsedTime(&phase_ms[i], ev[i], ev[i + 1]);
-        for (auto& e : ev) hipEventDestroy(e);
+    const unsigned chain_grid = (unsigned)((groups + per_block - 1) / per_block);
+    // chunks of cycles: the chains of chunk j (their own stream) run underneath the walker's chunk j + 1.  Timed passes run one chunk,
+    // phase after phase.
+    uint32_t chunks = 6;
+    if (const char* e = std::getenv("ZKGL_VM_SEED_CHUNKS")) chunks = (uint32_t)std::max(1, atoi(e));
+    chunks = std::min<uint32_t>(std::min<uint32_t>(chunks, VM_SEED_MAX_CHUNKS), std::max<uint32_t>(1, v.limit / 64));
+    if (phase_ms) chunks = 1;
+    if (chunks == 1) {
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (phase_ms) for (auto& e : ev) if (int r = chk(hipEventCreate(&e), "hipEventCreate")) return r;
+        if (phase_ms) hipEventRecord(ev[0], st);
+        a.c0 = 0; a.c1 = v.limit; a.chunk = 0;
+        zkvm::k_vm_walk<<<v.n_instances, 64, 0, st>>>(a);
+        if (int r = LAUNCH_CHECK("k_vm_walk")) return r;
+        if (phase_ms) hipEventRecord(ev[1], st);
+        zkvm::k_vm_chains<<<chain_grid, 256, 0, st>>>(a);
+        if (int r = LAUNCH_CHECK("k_vm_chains")) return r;
+        if (phase_ms) hipEventRecord(ev[2], st);
+        zkvm::k_vm_fill<<<grid_for((size_t)v.n_instances * v.limit, 256), 256, 0, st>>>(a);
+        if (int r = LAUNCH_CHECK("k_vm_fill")) return r;
+        if (phase_ms) {
+            hipEventRecord(ev[3], st);
+            if (int r = chk(hipEventSynchronize(ev[3]), "vm seed sync")) return r;
+            for (int i = 0; i < 3; ++i) hipEventElapsedTime(&phase_ms[i], ev[i], ev[i + 1]);
+            for (auto& e : ev) hipEventDestroy(e);
+        }
+        return 0;
     }
-    return 0;
+    if (int r = vm_seed_streams()) return r;
+    VmSeedStreams& S = g_vm_seed;
+    if (int r = chk(hipEventRecord(S.begin, st), "hipEventRecord")) return r;
+    if (int r = chk(hipStreamWaitEvent(S.walk, S.begin, 0), "hipStreamWaitEvent")) return r;
+    for (uint32_t j = 0; j < chunks; ++j) {
+        a.chunk = j;
+        a.c0 = (uint32_t)((uint64_t)v.limit * j / chunks);
+        a.c1 = (uint32_t)((uint64_t)v.limit * (j + 1) / chunks);
+        zkvm::k_vm_walk<<<v.n_instances, 64, 0, S.walk>>>(a);
+        if (int r = LAUNCH_CHECK("k_vm_walk")) return r;
+        if (int r = chk(hipEventRecord(S.walked[j], S.walk), "hipEventRecord")) return r;
+        if (int r = chk(hipStreamWaitEvent(S.chains, S.walked[j], 0), "hipStreamWaitEvent")) return r;
+        zkvm::k_vm_chains<<<chain_grid, 256, 0, S.chains>>>(a);
+        if (int r = LAUNCH_CHECK("k_vm_chains")) return r;
+    }
+    if (int r = chk(hipEventRecord(S.done, S.chains), "hipEventRecord")) return r;
+    if (int r = chk(hipStreamWaitEvent(st, S.done, 0), "hipStreamWaitEvent")) return r;
+    zkvm::k_vm_fill<<<grid_for((size_t)v.n_instances * v.limit, 256), 256, 0, st>>>(a);
+    return LAUNCH_CHECK("k_vm_fill");
 }
 
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
