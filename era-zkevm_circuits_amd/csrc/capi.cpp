@@ -77,6 +77,7 @@ int need_init() { return g_inited ? ZK_OK : fail(ZK_ERR_HIP, "zk_init() has not 
 namespace zkgl {  // for comm.cpp
 void set_last_error(const std::string& m) { g_err = m; }
 CS* cs_of(zk_cs* h) { return h->cs; }
+int initialized_device() { return g_inited ? g_device : -1; }
 }  // namespace zkgl
 
 extern "C" {

@@ -18,9 +18,18 @@ struct zk_comm {
     size_t local_words = 0;
 };
 
-namespace zkgl { void set_last_error(const std::string& m); zkgl::CS* cs_of(zk_cs* h); }
+namespace zkgl { void set_last_error(const std::string& m); zkgl::CS* cs_of(zk_cs* h); int initialized_device(); }
 
-static int fail(const std::string& m) { zkgl::set_last_error(m); return ZK_ERR_HIP; }
+static int fail(const std::string& m, int code = ZK_ERR_HIP) { zkgl::set_last_error(m); return code; }
+// the communicator binds to the CURRENT HIP device: it must be the one zk_init bound this process to
+static int check_device() {
+    const int want = zkgl::initialized_device();
+    if (want < 0) return fail("zk_init() has not succeeded: no GPU context (there is no CPU fallback)");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail("hipGetDevice");
+    if (cur != want) return fail("the calling thread's current device is not the one zk_init bound this process to", ZK_ERR_INVALID);
+    return ZK_OK;
+}
 
 extern "C" {
 
@@ -36,7 +45,8 @@ int zk_comm_unique_id(uint8_t id[ZK_COMM_ID_BYTES]) {
 }
 
 int zk_comm_create(zk_comm** out, const uint8_t id[ZK_COMM_ID_BYTES], int rank, int world) {
-    if (!out || !id || world < 1 || rank < 0 || rank >= world) return ZK_ERR_INVALID;
+    if (!out || !id || world < 1 || rank < 0 || rank >= world) return fail("zk_comm_create: bad arguments", ZK_ERR_INVALID);
+    if (int rc = check_device()) return rc;
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
     zk_comm* c = new zk_comm;
@@ -56,9 +66,14 @@ int zk_comm_destroy(zk_comm* c) {
 }
 
 int zk_cs_gather_commitments(zk_cs* h, zk_comm* c, uint64_t* dev_out, uint32_t* n_public, void* stream) {
-    if (!h || !c || !dev_out) return ZK_ERR_INVALID;
+    if (!h || !c || !dev_out) return fail("zk_cs_gather_commitments: null argument", ZK_ERR_INVALID);
+    if (int rc = check_device()) return rc;
     try {
         zkgl::CS* cs = zkgl::cs_of(h);
+        if (cs->batch() == 0) return fail("zk_cs_gather_commitments before set_batch", ZK_ERR_INVALID);
+        const size_t n_pub = cs->public_cells().size();
+        if (n_pub == 0) return fail("zk_cs_gather_commitments: the circuit has no public inputs", ZK_ERR_INVALID);
+        if (n_pub > 8) return fail("more than 8 public inputs per instance", ZK_ERR_CAPACITY);   // before anything is written: the staging buffer holds 8
         const size_t words = (size_t)cs->batch() * 8;  // room for up to 8 public inputs per instance
         if (c->local_words < words) {
             if (c->d_local) hipFree(c->d_local);
@@ -66,7 +81,6 @@ int zk_cs_gather_commitments(zk_cs* h, zk_comm* c, uint64_t* dev_out, uint32_t* 
             c->local_words = words;
         }
         const uint32_t n = cs->pack_public_inputs(c->d_local, stream);
-        if (n > 8) return fail("more than 8 public inputs per instance");
         if (n_public) *n_public = n;
         const size_t count = (size_t)cs->batch() * n;
         // every rank holds the same batch size (instances are dealt round-robin and padded by the host): dev_out[rank][instance][k]

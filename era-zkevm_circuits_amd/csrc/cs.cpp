@@ -2475,7 +2475,7 @@ int CS::decode_failure(const unsigned long long* f, zk_failure* first) const {
         }
         if (ff[2] != NONE) {
             uint32_t li = (uint32_t)(ff[2] & 0xffffffffu);
-            if (li & 0x80000000u) fill(ff[2], 0, 0x400u, li & 0x7fffffffu);  // stream link: relation = stream index
+            if (li & 0x80000000u) fill(ff[2], 0, ZK_FAILURE_STREAM_LINK, li & 0x7fffffffu);  // stream link: relation = stream index
             else fill(ff[2], links_[li].loop_cell, 0x300u | links_[li].kind, li);
             return ZK_ERR_UNSATISFIED;
         }

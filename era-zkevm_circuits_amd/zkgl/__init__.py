@@ -637,6 +637,7 @@ class VmPackReport(C.Structure):             # zk_vm_pack_report
 
 
 VM_PACK_FILL_STATE = 1
+FAILURE_STREAM_LINK, FAILURE_NONCANONICAL_INPUT = 0x400, 0x500   # zk_failure.kind beyond the gate kinds (include/zkgl.h)
 
 
 class VmOracleQueues:

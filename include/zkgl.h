@@ -192,9 +192,11 @@ int zk_cs_seed_stream(zk_cs *cs, uint32_t n_instances, const uint64_t *dev_outer
 int zk_cs_seed_window_async(zk_cs *cs, uint32_t n_instances, const uint64_t *dev_outer_window, uint64_t outer_lane_stride,
                             uint64_t *dev_loop_window_rw, uint64_t loop_lane_stride, void *stream);
 typedef struct zk_failure { uint32_t scope, instance, iteration, slot, kind, relation; } zk_failure;
-/* kind: a zk_gate_kind; 0x100 lookup tuple (relation = tuple); 0x200 copy constraint; 0x300 link / stream link;
+/* kind: a zk_gate_kind; 0x100 lookup tuple (relation = tuple); 0x200 copy constraint; 0x300 | zk_link_kind: a link (slot = the loop
+ * cell, relation = link index); ZK_FAILURE_STREAM_LINK: a stream link (relation = stream index);
  * ZK_FAILURE_NONCANONICAL_INPUT: input stream word `slot` (mod 256) of that lane is not a canonical field element (>= p) */
-#define ZK_FAILURE_NONCANONICAL_INPUT 0x400u
+#define ZK_FAILURE_STREAM_LINK 0x400u
+#define ZK_FAILURE_NONCANONICAL_INPUT 0x500u
 /* check_if_satisfied: 0 satisfied; ZK_ERR_UNSATISFIED + first failure otherwise */
 int zk_cs_check_satisfied(zk_cs *cs, void *stream, zk_failure *first);
 /* fused resolve + check_if_satisfied; the latency-bound outer scope runs on an internal second stream

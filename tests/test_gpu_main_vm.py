@@ -148,3 +148,65 @@ def test_multiplicities_in_both_modes(zk, batch, monkeypatch, mode):
         assert np.array_equal(cs.multiplicities(i), run.mult[i * total:(i + 1) * total]), (mode, i)
     cs.resolve()   # the plain resolve path counts them too
     assert np.array_equal(cs.multiplicities(3), run.mult[3 * total:4 * total])
+
+
+def test_native_seeding_equals_cone_seeding(zk, batch, monkeypatch):
+    """the chain-specialised seeding (native walker + Poseidon2 chain kernels + fill: kernels_vm_seed.hpp) and the recorded cone of the
+    carried outputs (k_seed_wave) derive the same 243 words for every cycle — and both equal the native restatement; the window
+    entry point (zk_cs_seed_window_async) seeds a slice of a longer stream and leaves the rest alone"""
+    cs, D, outer, loop, commits, info = batch
+    S = outer.shape[1]
+    raw = loop.copy()
+    raw[0:243] = 0
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ZKGL_SEED_NATIVE", mode)
+        d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+        cs.seed_stream(S, d_o, d_l)
+        got[mode] = d_l.to_numpy().reshape(loop.shape)
+    assert np.array_equal(got["1"], got["0"]), "native seeding differs from the cone kernels"
+    assert np.array_equal(got["1"], loop), "seeded VmLocalState differs from the native restatement"
+    monkeypatch.setenv("ZKGL_SEED_NATIVE", "1")
+    monkeypatch.setenv("ZKGL_VM_SEED_CHUNKS", "1")        # one chunk, phase after phase on the caller's stream
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+    cs.seed_stream(S, d_o, d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
+    monkeypatch.delenv("ZKGL_VM_SEED_CHUNKS")
+    first, n = 5, 17
+    d_l2 = zk.DeviceBuffer.from_numpy(raw)
+    cs.seed_window_async(n, d_o, S, d_l2, S * LIMIT, first)
+    zk.sync()
+    win = d_l2.to_numpy().reshape(loop.shape)
+    want = raw.copy()
+    want[:, first * LIMIT:(first + n) * LIMIT] = loop[:, first * LIMIT:(first + n) * LIMIT]
+    assert np.array_equal(win, want)
+
+
+def test_main_vm_hook_compare_witness(zk):
+    """structured_input.hook_compare_witness (src/main_vm/mod.rs:218): the circuit's hidden_fsm_output / observable_output groups against
+    the closed-form input a host holds; input streams through zk_pack_main_vm_witness only"""
+    from oracle import main_vm_native as vn
+    d, D = vp.defs()
+    cs = vp.vm_cs(LIMIT)
+    ops, contracts = vp.program_calls(D, 3)
+    n_inst = 4
+    run = vn.VmRun(D, vp.make_world_factory(D, ops, contracts), n_inst * LIMIT)
+    outer, loop, reports = vp.pack_through_the_c_abi(cs, run, LIMIT, n_inst)
+    assert not any(r.underflow for r in reports)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.seed_stream(n_inst, d_o, d_l)
+    cs.set_batch(n_inst)
+    cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    hv = cs.hook_vars("hidden_fsm_output")
+    assert len(hv) == 243
+    expected = np.array([[int(x) for x in run.states[(i + 1) * LIMIT].flatten()] for i in range(n_inst)], dtype=np.uint64).T.copy()
+    ok, where = cs.hook_compare_witness(hv, zk.DeviceBuffer.from_numpy(expected))
+    assert ok, where
+    bad = expected.copy(); bad[146, 2] ^= 1     # the timestamp of instance 2
+    ok, where = cs.hook_compare_witness(hv, zk.DeviceBuffer.from_numpy(bad))
+    assert not ok and where == (2, 146)
+    assert len(cs.hook_vars("observable_output")) == 59   # VmOutputData: 9 + 25 + 25 (circuit_inputs/main_vm.rs:32-38)
+    for i in range(n_inst):
+        assert cs.public_inputs(i) == vp.expected_commitment(D, run, LIMIT, i)

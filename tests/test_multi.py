@@ -115,3 +115,64 @@ def test_two_ranks_drive_libzkgl_on_the_gpu():
     for r in range(world):
         for j, i in enumerate(range(r, n_total, world)):
             assert [int(x) for x in allc[r, j]] == insts[i]["commitment"]
+
+
+# ---- the RCCL collective itself on two real devices: one process per GPU, rank 0's unique id over the gloo control plane, ONE
+# communicator (zk_comm_create), zk_cs_gather_commitments = one ncclAllGather.  Needs two GPUs: skipped on a one-GPU box.
+def _rccl_worker(rank, world, port, n_total, limit, q):
+    for p in (ROOT, os.path.join(ROOT, "era-zkevm_circuits_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import zkgl
+    from helpers import ram_cs, random_instances
+    from oracle import ram_native as rn
+    from zkgl.dist import shard_instances
+
+    zkgl.init(rank)                      # one process per GPU
+    insts = random_instances(78, n_total, 5, limit)
+    mine = shard_instances(n_total, rank, world)
+    cs = ram_cs(limit)
+    outer, loop = rn.pack_streams([insts[i] for i in mine], limit)
+    cs.set_batch(len(mine))
+    d_o, d_l = zkgl.DeviceBuffer.from_numpy(outer), zkgl.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    ok, failure = cs.resolve_and_check()
+    assert ok, failure
+    ids = [zkgl.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    comm = zkgl.Comm(bytes(ids[0]), rank, world)
+    got = cs.gather_commitments(comm)    # [world, batch, 4]
+    comm.close()
+    q.put((rank, got.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_gather_behind_the_c_abi_on_two_gpus():
+    import zkgl
+    if zkgl.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU tier); a one-GPU box covers the collective on a one-rank communicator")
+    n_total, limit, world = 8, 8, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, n_total, limit, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import random_instances
+    insts = random_instances(78, n_total, 5, limit)
+    for viewer in range(world):            # every rank holds every rank's commitments
+        allc = np.array(results[viewer], dtype=np.uint64)
+        for r in range(world):
+            for j, i in enumerate(range(r, n_total, world)):
+                assert [int(x) for x in allc[r, j]] == insts[i]["commitment"]

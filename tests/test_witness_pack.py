@@ -195,6 +195,7 @@ def test_non_canonical_input_word_is_reported(zk):
     cs.resolve()
     ok, f = cs.check_if_satisfied()
     assert not ok and f.scope == 1 and f.instance == 1
+    assert f.kind == zk.FAILURE_NONCANONICAL_INPUT != zk.FAILURE_STREAM_LINK and f.slot == 50   # its own kind: not the stream links' 0x400
 
 
 # ---------------------------------------------------------------- storage_validity / log_sorter packers
