@@ -113,6 +113,9 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_cprog_full) hipFree(s.d_cprog_full);
     if (s.d_cmacros) hipFree(s.d_cmacros);
     if (s.d_cchunks_full) hipFree(s.d_cchunks_full);
+    if (s.d_cprog_fused) hipFree(s.d_cprog_fused);
+    if (s.d_cchunks_fused) hipFree(s.d_cchunks_fused);
+    s.d_cprog_fused = nullptr; s.d_cchunks_fused = nullptr;
     if (s.d_mult_sites) hipFree(s.d_mult_sites);
     if (s.d_sprog) hipFree(s.d_sprog);
     s.d_sprog = nullptr;
@@ -526,6 +529,7 @@ void CS::place_scope(Scope& s) {
 // scalar fetch (the 24-column matrix gates take two).  Chunks of whole packets, balanced by words, for the launch grid.
 void CS::build_check_program(Scope& s) {
     s.cprog.clear(); s.cchunks.clear(); s.cprog_full.clear(); s.cchunks_full.clear(); s.cmacros.clear(); s.n_macro_p2 = 0;
+    s.cprog_fused.clear(); s.cchunks_fused.clear();
     const uint32_t C = geo_.num_columns_under_copy_permutation, NC = C + lookup_width_ * lookup_reps_;
     std::vector<uint32_t> starts;
     auto cap_of = [](uint32_t kind) -> uint32_t {
@@ -620,8 +624,97 @@ void CS::build_check_program(Scope& s) {
             macros.push_back(m);
         }
     }
+    // ---- gates MIRRORED by the witness op that produces their output: the gadget layer emits `op; gate` pairs over the same variables
+    // and constants (gadgets.cpp: fma, linear_combination, select, is_zero, dot4, u32 add / fma-with-carry, allocate_constant), so the
+    // relation IS the op's field arithmetic on the registers it stores (FMA, linear combinations, dot products, zero checks with their
+    // exact inverse, constants) for every input whatsoever; SELECT's relation s (a - b) + b - r equals its op (r = s ? a : b) unless
+    // s > 1 and a != b, which the witness kernels test on the operands they hold (kernels_engine2.hpp) and report like a macro packet.
+    // So in the fused mode of resolve_and_check these gates are evaluated where their values are produced, and the check program
+    // keeps every OTHER gate — enforcements, booleans and range checks of inputs, integer add / multiply relations, relations whose
+    // output is a given variable — and every lookup.  Stored values (after write_cell / poke, or on request) are verified by the full
+    // programs as before.
+    s.gate_mirrored.assign(s.gates.size(), 0);
+    {
+        std::vector<int32_t> producer(s.n_vars, -1);
+        for (size_t oi = 0; oi < s.ops.size(); ++oi)
+            if (!s.ops[oi].seed_only) for (uint32_t ov : s.ops[oi].outs) producer[ov] = (int32_t)oi;
+        auto is_var = [](const Operand& o, uint32_t v) { return o.kind == Operand::VAR && o.idx == v; };
+        auto pool = [&](const Operand& o, uint64_t& out) { if (o.kind != Operand::CONSTPOOL) return false; out = s.const_pool[o.idx]; return true; };
+        for (size_t gi = 0; gi < s.gates.size(); ++gi) {
+            const GateRec& g = s.gates[gi];
+            bool m = false;
+            auto prod = [&](uint32_t v) -> const OpRec* { return producer[v] >= 0 ? &s.ops[producer[v]] : nullptr; };
+            switch (g.kind) {
+            case ZK_GATE_FMA: {
+                const OpRec* op = prod(g.vars[3]);
+                uint64_t q, l;
+                m = op && op->opcode == ZK_OP_FMA && op->ins.size() == 5 && pool(op->ins[0], q) && pool(op->ins[1], l) && q == g.consts[0] && l == g.consts[1] &&
+                    is_var(op->ins[2], g.vars[0]) && is_var(op->ins[3], g.vars[1]) && is_var(op->ins[4], g.vars[2]);
+            } break;
+            case ZK_GATE_REDUCTION4: case ZK_GATE_REDUCTION_BY_POWERS4: {
+                const OpRec* op = prod(g.vars[4]);
+                if (op && op->opcode == ZK_OP_LC4 && op->ins.size() == 8) {
+                    m = true;
+                    uint64_t pw = 1;
+                    for (int i = 0; i < 4 && m; ++i) {
+                        uint64_t k;
+                        const uint64_t want = g.kind == ZK_GATE_REDUCTION4 ? g.consts[i] : pw;
+                        m = pool(op->ins[i], k) && k == want && is_var(op->ins[4 + i], g.vars[i]);
+                        if (g.kind != ZK_GATE_REDUCTION4) pw = (uint64_t)((unsigned __int128)pw * g.consts[0] % 0xFFFFFFFF00000001ull);
+                    }
+                }
+            } break;
+            case ZK_GATE_SELECT: {
+                const OpRec* op = prod(g.vars[3]);
+                m = op && op->opcode == ZK_OP_SELECT && op->ins.size() == 3 && is_var(op->ins[0], g.vars[2]) && is_var(op->ins[1], g.vars[0]) && is_var(op->ins[2], g.vars[1]);
+            } break;
+            case ZK_GATE_ZEROCHECK: {
+                const OpRec* op = prod(g.vars[2]);
+                m = op && op->opcode == ZK_OP_ISZERO && is_var(op->ins[0], g.vars[0]) && op->outs[0] == g.vars[2] && op->outs[1] == g.vars[1];
+            } break;
+            case ZK_GATE_DOT4: {
+                const OpRec* op = prod(g.vars[8]);
+                m = op && op->opcode == ZK_OP_DOT4 && op->ins.size() == 8;
+                for (int i = 0; i < 8 && m; ++i) m = is_var(op->ins[i], g.vars[i]);
+            } break;
+            // ZK_GATE_UINTX_ADD / ZK_GATE_U32_FMA: their ops work on integers — the field relation equals the op only for operands in
+            // range, which other gates establish: they stay in the check program
+            case ZK_GATE_CONST: {
+                const OpRec* op = prod(g.vars[0]);
+                uint64_t c;
+                m = op && op->opcode == ZK_OP_CONST && pool(op->ins[0], c) && c == g.consts[0];
+            } break;
+            case ZK_GATE_BOOLEAN: {   // a flag some op produces as 0 / 1 by construction
+                const OpRec* op = prod(g.vars[0]);
+                m = op && ((op->opcode == ZK_OP_ISZERO && op->outs[0] == g.vars[0]) || (op->opcode == ZK_OP_SPLIT && op->b == 1));
+            } break;
+            default: break;
+            }
+            if (gate_macro[gi] >= 0) m = true;   // the Poseidon2 gadget's gates: mirrored by ZK_OP_P2_ROUNDS (verified above)
+            s.gate_mirrored[gi] = m ? 1 : 0;
+        }
+        if (getenv("ZKGL_PROG_STATS")) {
+            uint64_t tot[ZK_GATE__COUNT] = {0}, mir[ZK_GATE__COUNT] = {0}, refs_tot = 0, refs_left = 0;
+            for (size_t gi = 0; gi < s.gates.size(); ++gi) {
+                tot[s.gates[gi].kind]++; mir[s.gates[gi].kind] += s.gate_mirrored[gi];
+                refs_tot += s.gates[gi].vars.size(); if (!s.gate_mirrored[gi]) refs_left += s.gates[gi].vars.size();
+            }
+            fprintf(stderr, "[zkgl] %s scope gates mirrored by their producing op (kind: mirrored / total):", s.is_loop ? "loop" : "outer");
+            for (int k = 1; k < ZK_GATE__COUNT; ++k) if (tot[k]) fprintf(stderr, " %d: %llu/%llu", k, (unsigned long long)mir[k], (unsigned long long)tot[k]);
+            uint64_t lk = 0; for (auto& l : s.lookups) lk += l.vars.size();
+            fprintf(stderr, "; gate references %llu -> %llu left, lookup references %llu\n", (unsigned long long)refs_tot, (unsigned long long)refs_left, (unsigned long long)lk);
+        }
+    }
     bool lookups_ok = true;
-    auto emit = [&](std::vector<uint32_t>& prog, std::vector<uint32_t>& chunks, bool use_macros) {
+    // mode 0: every gate instance on its own; 1: Poseidon2 gadgets as macro packets (k_check_p2); 2: fused — the gates mirrored by their
+    // producing op (Poseidon2 gadgets included) are left to the witness kernels, no macro packets
+    auto emit = [&](std::vector<uint32_t>& prog, std::vector<uint32_t>& chunks, int mode) {
+        const bool use_macros = mode == 1;
+        auto skipped = [&](uint32_t slot, uint32_t j) -> bool {
+            if (mode == 0 || slot >= s.row_gates.size() || j >= s.row_gates[slot].size()) return false;
+            const uint32_t gi = s.row_gates[slot][j];
+            return mode == 1 ? gate_macro[gi] >= 0 : s.gate_mirrored[gi] != 0;
+        };
         starts.clear();
         std::vector<uint8_t> macro_done(macros.size(), 0);
         for (uint32_t slot = 0; slot < s.n_slots; ++slot) {
@@ -629,6 +722,7 @@ void CS::build_check_program(Scope& s) {
             const uint32_t cap = rd.kind < ZK_GATE__COUNT ? cap_of(rd.kind) : 0, w = rd.kind < ZK_GATE__COUNT ? GATES[rd.kind].width : 0;
             uint32_t j = 0;
             while (cap && j < rd.n_instances) {
+                if (mode == 2 && skipped(slot, j)) { ++j; continue; }
                 const int32_t mi = use_macros && slot < s.row_gates.size() && j < s.row_gates[slot].size() ? gate_macro[s.row_gates[slot][j]] : -1;
                 if (mi >= 0) {   // owned by a macro packet: emitted once, where its first gate sits
                     if (!macro_done[mi]) {   // the permutation goes to k_check_p2: descriptor = inputs, first output, row of its first gate
@@ -641,9 +735,7 @@ void CS::build_check_program(Scope& s) {
                     continue;
                 }
                 uint32_t cnt = 0;
-                while (cnt < cap && j + cnt < rd.n_instances &&
-                       !(use_macros && slot < s.row_gates.size() && j + cnt < s.row_gates[slot].size() && gate_macro[s.row_gates[slot][j + cnt]] >= 0))
-                    ++cnt;
+                while (cnt < cap && j + cnt < rd.n_instances && !skipped(slot, j + cnt)) ++cnt;
                 starts.push_back((uint32_t)prog.size());
                 prog.push_back(rd.kind | (cnt << 8) | (j << 16));
                 prog.push_back(slot);
@@ -685,9 +777,14 @@ void CS::build_check_program(Scope& s) {
         }
         chunks.push_back((uint32_t)prog.size());
     };
-    emit(s.cprog, s.cchunks, true);
-    if (lookups_ok && !macros.empty()) emit(s.cprog_full, s.cchunks_full, false);
-    if (!lookups_ok) { s.cprog.clear(); s.cchunks.clear(); s.cprog_full.clear(); s.cchunks_full.clear(); s.cmacros.clear(); return; }
+    emit(s.cprog, s.cchunks, 1);
+    if (lookups_ok && !macros.empty()) emit(s.cprog_full, s.cchunks_full, 0);
+    s.cprog_fused.clear(); s.cchunks_fused.clear();
+    if (lookups_ok) {
+        emit(s.cprog_fused, s.cchunks_fused, 2);
+        if (s.cprog_fused.empty()) { s.cprog_fused.assign(1, 0); s.cchunks_fused = {0, 0}; }   // nothing left to read: an empty program, not "no program"
+    }
+    if (!lookups_ok) { s.cprog.clear(); s.cchunks.clear(); s.cprog_full.clear(); s.cchunks_full.clear(); s.cmacros.clear(); s.cprog_fused.clear(); s.cchunks_fused.clear(); return; }
     s.n_macro_p2 = (uint32_t)macros.size();
     if (getenv("ZKGL_PROG_STATS"))
         fprintf(stderr, "[zkgl] %s scope check program: %zu words, %u Poseidon2 macro packets (gate by gate: %zu words)\n", s.is_loop ? "loop" : "outer", s.cprog.size(),
@@ -1891,6 +1988,12 @@ void CS::upload_scope(Scope& s) {
         s.d_cprog_full = upload(padded);
         s.d_cchunks_full = upload(s.cchunks_full);
     }
+    if (!s.cprog_fused.empty()) {
+        std::vector<uint32_t> padded(s.cprog_fused);
+        padded.resize(((padded.size() + 63) / 64) * 64 + 64, 0);
+        s.d_cprog_fused = upload(padded);
+        s.d_cchunks_fused = upload(s.cchunks_fused);
+    }
     if (!s.sprog.empty()) {
         std::vector<uint32_t> padded(s.sprog);
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
@@ -2277,13 +2380,17 @@ void CS::resolve(void* stream) {
     compact_ = true;  // home cells only: see check_satisfied / ensure_materialized
 }
 
-zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro) const {
+zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro, bool fused) const {
     zkdev::CheckArgs a;
     a.alias = compact ? s.d_alias : nullptr;
     const bool full = !macro && s.d_cprog_full;   // the program without macro packets: locates a failure a macro packet reported
     a.cprog = compact ? (full ? s.d_cprog_full : s.d_cprog) : nullptr; a.chunk_tab = full ? s.d_cchunks_full : s.d_cchunks;
     a.n_chunks = full ? (uint32_t)s.cchunks_full.size() - 1 : (s.cchunks.empty() ? 0 : (uint32_t)s.cchunks.size() - 1);
     a.macros = (compact && !full) ? s.d_cmacros : nullptr; a.n_macros = (compact && !full) ? s.n_macro_p2 : 0;
+    if (fused && compact && s.d_cprog_fused) {   // the gates the witness kernels did not evaluate themselves + every lookup
+        a.cprog = s.d_cprog_fused; a.chunk_tab = s.d_cchunks_fused; a.n_chunks = (uint32_t)s.cchunks_fused.size() - 1;
+        a.macros = nullptr; a.n_macros = 0;
+    }
     a.cells = compact ? s.d_store : s.d_cells; a.n_cells = compact ? s.n_store : s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
     a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
     a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
@@ -2506,6 +2613,12 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     uint32_t* const mult_inline = inline_multiplicities() ? d_mult_ : nullptr;
     auto oa = scope_args(outer_, outer_, loop_, limit_, d_tables_, d_table_words_, mult_inline, total_table_rows_);
     auto la = scope_args(loop_, outer_, loop_, limit_, d_tables_, d_table_words_, mult_inline, total_table_rows_);
+    // FUSED mode (default): the witness kernels evaluate the gates mirrored by their producing ops on the values they hold, the
+    // checkers read what is left.  ZKGL_VERIFY_STORED=1: every gate re-evaluated from the stored values (what check_if_satisfied does).
+    const char* vs = std::getenv("ZKGL_VERIFY_STORED");
+    const bool fused = !(vs && vs[0] == '1') && outer_.d_cprog_fused && (!limit_ || loop_.d_cprog_fused);
+    last_check_fused_ = fused;
+    if (fused) { oa.fail = d_fail_; la.fail = d_fail_ + 3; }
     hip_check(hipEventRecord(E(0), st), "event");                     // t0 (+ memsets done)
     hip_check(hipStreamWaitEvent(ax, E(0), 0), "wait");
     launch_phase(outer_, oa, 0, ax);    // outer PRE
@@ -2518,11 +2631,11 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hip_check(hipStreamWaitEvent(ax, E(3), 0), "wait");
     launch_phase(outer_, oa, 2, ax);  // outer POST
     // compact traces: the gate checkers read every cell through the alias map; no copy pass (see check_satisfied)
-    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, true), ax));
+    dev_check(zkdev::launch_check_gates(check_args(outer_, d_fail_, true, true, fused), ax));
     check_inputs_canonical(ax, ax);   // both scopes on the auxiliary stream: it has slack behind the loop-scope kernels
     hip_check(hipEventRecord(E(4), ax), "event");
     if (limit_) {
-        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, true), st));
+        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, true, true, fused), st));
         hip_check(hipEventRecord(E(5), st), "event");
     } else {
         hip_check(hipEventRecord(E(5), st), "event");

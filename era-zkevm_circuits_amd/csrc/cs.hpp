@@ -93,9 +93,12 @@ struct Scope {
     std::vector<uint32_t> cprog, cchunks;
     // the same without macro packets (every gate instance on its own): run when a macro packet reports, to locate the failing gate
     std::vector<uint32_t> cprog_full, cchunks_full;
+    // fused mode: without the gates mirrored by their producing op (gate_mirrored) — those are evaluated by the witness kernels
+    std::vector<uint32_t> cprog_fused, cchunks_fused;
     std::vector<uint32_t> cmacros;   // Poseidon2 macro descriptors (k_check_p2), 14 words each
     std::vector<std::vector<uint32_t>> row_gates;  // [row][instance] -> index into `gates`
     uint32_t n_macro_p2 = 0;
+    std::vector<uint8_t> gate_mirrored;   // per gate: its relation is the semantics of the op producing its output (same variables, constants)
     // lookup sites by table for k_multiplicities: 3 key slots per site; site_off[table id] .. site_off[table id + 1]
     std::vector<uint32_t> mult_sites, mult_site_off;
     uint32_t pre_words2 = 0, side_words2 = 0, pre_slots = 0, side_slots = 0;
@@ -129,6 +132,8 @@ struct Scope {
     uint32_t* d_cmacros = nullptr;
     uint32_t* d_cprog_full = nullptr;
     uint32_t* d_cchunks_full = nullptr;
+    uint32_t* d_cprog_fused = nullptr;
+    uint32_t* d_cchunks_fused = nullptr;
     uint32_t* d_mult_sites = nullptr;
     uint32_t* d_sprog = nullptr;
     uint64_t* d_consts = nullptr;
@@ -279,7 +284,7 @@ class CS {
     void free_scope_device(Scope& s);
     void check_var(zk_var v, bool want_loop) const;
     int decode_failure(const unsigned long long* f, zk_failure* first) const;
-    zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro = true) const;
+    zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro = true, bool fused = false) const;
 
     zk_geometry geo_;
     uint64_t max_trace_len_, max_variables_;
@@ -357,6 +362,7 @@ class CS {
     void* ev2_[8] = {nullptr};
     void* aux_stream_ = nullptr;
     float ms_[5] = {0, 0, 0, 0, 0};
+    bool last_check_fused_ = false;
 };
 
 // K11 (ntt.cpp): batched Goldilocks NTT / coset LDE over device-resident polynomials, see include/zkgl.h

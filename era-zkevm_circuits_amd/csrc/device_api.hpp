@@ -15,6 +15,7 @@ struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     const uint64_t* loop_cells; uint64_t loop_n_cells; uint32_t loop_limit;
     uint64_t in_stride;    // lanes between consecutive words of the input stream (>= n_lanes: a batch may be a window of a longer stream)
     uint32_t uses_bigint;  // host only: the program contains ZK_OP_NN_MULMOD -> launch the *_bigint kernel variants
+    unsigned long long* fail = nullptr;  // fused mode: where the witness kernels report a gate they evaluate themselves (SELECT with a non-boolean selector)
 };
 struct CheckArgs {  // mirrors zke::CheckDev
     const uint64_t* cells; uint64_t n_cells; uint32_t n_cols; uint32_t n_lanes; uint32_t n_slots;

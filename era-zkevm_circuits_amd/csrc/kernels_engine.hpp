@@ -53,6 +53,10 @@ struct ScopeDev {
     const uint64_t* loop_cells;
     uint64_t loop_n_cells;
     uint32_t loop_limit;
+    // fused mode of resolve_and_check: the witness kernel is the evaluator of the gates mirrored by its ops (cs.cpp build_check_program).
+    // Their relations are the ops' own field arithmetic, except SELECT: s (a - b) + b - r == 0 for r = s ? a : b fails exactly when
+    // s > 1 and a != b — tested on the operands in registers, reported under the macro row (the host then names the gate).
+    unsigned long long* fail;
 };
 
 constexpr int TPB = 256;

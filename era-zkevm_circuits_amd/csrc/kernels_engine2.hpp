@@ -93,6 +93,12 @@ __device__ __forceinline__ uint32_t table_find3(const zk_table_desc& t, const ui
     return t.n_rows;
 }
 
+// fused mode: a gate the witness kernel evaluates itself is violated -> the macro row of the failure key (the host re-runs the
+// gate-by-gate program on the stored values to name the gate)
+__device__ __forceinline__ void report_fused(unsigned long long* f, uint32_t lane) {
+    atomicMin(f, ((unsigned long long)lane << 32) | ((unsigned long long)0xffffeu << 12));
+}
+
 // STRANDS: the strand form (k_witness_strands2): one destination word per op behind the operands — the store slot of its first
 // output (a strand's ops are not consecutive in production order) — and ZK_OP_BARRIER between the dependency levels.
 template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB, bool STRANDS = false>
@@ -227,6 +233,12 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 pc += 1 + N * 3 + D * N;
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N * 3 + g) & 15]); st(in[g][0] ? in[g][1] : in[g][2]); }
+                if (sc.fail) {   // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ
+                    bool bad = false;
+#pragma unroll
+                    for (uint32_t g = 0; g < N; ++g) bad |= in[g][0] > 1 && in[g][1] != in[g][2];
+                    if (bad && active) report_fused(sc.fail, lane);
+                }
             };
             switch (pb) {
             case 0: body(GroupSize<1>{}); break;

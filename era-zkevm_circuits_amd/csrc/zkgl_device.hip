@@ -105,6 +105,7 @@ static zke::ScopeDev to_dev(const ScopeArgs& a) {
     d.limit = a.limit; d.is_loop = a.is_loop; d.tables = a.tables; d.table_words = a.table_words; d.mult = a.mult;
     d.total_table_rows = a.total_table_rows; d.loop_cells = a.loop_cells; d.loop_n_cells = a.loop_n_cells;
     d.loop_limit = a.loop_limit;
+    d.fail = a.fail;
     return d;
 }
 
