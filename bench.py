@@ -319,6 +319,17 @@ def main():
         resolve((last_window + 1 + i) % K)
     torch.cuda.synchronize()
     resident_local = time.perf_counter() - t1
+    # ---- and with every gate re-evaluated from the stored values (the mode of rounds 1-2; resolve_and_check's default is fused: the
+    # gates mirrored by their producing witness op are evaluated by the witness kernels)
+    os.environ["ZKGL_VERIFY_STORED"] = "1"
+    resolve(0); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        resolve((last_window + 1 + i) % K)
+    torch.cuda.synchronize()
+    stored_local = time.perf_counter() - t1
+    del os.environ["ZKGL_VERIFY_STORED"]
+    resolve(last_window)   # back to the window the commitments were read from (gather below), default mode
     # ---- materialised witness columns: the variable store is what the step writes; the trace proper (every cell of every column)
     # is produced on demand — timed here for a few instances of the last batch (zk_cs_trace_columns: k_materialize + transposition)
     mat_s = None
@@ -338,6 +349,7 @@ def main():
     from zkgl.dist import gather_commitments, gather_floats, max_over_ranks
     elapsed = max_over_ranks(elapsed_local)
     resident = max_over_ranks(resident_local)
+    stored = max_over_ranks(stored_local)
     per_rank_ms = gather_floats(1e3 * elapsed_local / args.steps)
     parity = None
     if expect is not None:
@@ -394,6 +406,10 @@ def main():
             "witness_rows_per_s": rows / elapsed,
             "vm_cycles_per_s": n_inst * limit * args.steps / elapsed,
             "value_inputs_resident": per_step_constraints / res_s,
+            "value_inputs_resident_verify_stored": per_step_constraints / (stored / args.steps),
+            "check_mode": "fused: gates mirrored by the witness op that produces their output (same variables and constants) are evaluated by the "
+                          "witness kernels on the values they hold; the check kernels read the binding gates and every lookup.  "
+                          "value_inputs_resident_verify_stored re-evaluates every gate from the stored values (ZKGL_VERIFY_STORED=1)",
             "value_from_raw_witness_serial": per_step_constraints / (res_s + t_seed_stream / K),
             "witness_rows_materialised_per_s": None if mat_s is None else st["rows_per_instance"] * n_inst / (step_s + B * mat_s),
             "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/vm_bench_witness.npz, "

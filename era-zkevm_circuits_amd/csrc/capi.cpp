@@ -331,6 +331,16 @@ int zk_cs_seed_window_async(zk_cs* cs, uint32_t n_instances, const uint64_t* dev
     NEED(cs);
     return guard([&] { cs->cs->seed_stream(n_instances, dev_outer_window, dev_loop_window_rw, stream, false, outer_lane_stride, loop_lane_stride); });
 }
+int zk_cs_carried_words(zk_cs* cs, uint32_t* words, uint32_t max_words, uint32_t* n_words) {
+    NEED(cs); NEED(n_words);
+    return guard([&] {
+        const std::vector<uint32_t> w = cs->cs->carried_words();
+        *n_words = (uint32_t)w.size();
+        if (!words) return;
+        if (max_words < w.size()) throw zkgl::ZkError(ZK_ERR_CAPACITY, "zk_cs_carried_words: buffer too small");
+        for (size_t i = 0; i < w.size(); ++i) words[i] = w[i];
+    });
+}
 int zk_cs_seed_carried_inputs(zk_cs* cs, uint64_t* dev_loop_inputs_rw, void* stream) {
     NEED(cs); NEED_INIT();
     return guard([&] { cs->cs->seed_carried_inputs(dev_loop_inputs_rw, stream); });

@@ -243,6 +243,8 @@ class CS {
     const zk_geometry& geometry() const { return geo_; }
     bool in_loop() const { return in_loop_; }
     uint32_t limit() const { return limit_; }
+    // the loop input words that are loop-carried (tied to the previous iteration's outputs): what seeding fills
+    std::vector<uint32_t> carried_words() const { std::vector<uint32_t> w; for (auto& c : carries_store_) w.push_back(c.word); return w; }
     uint32_t lookup_width() const { return lookup_width_; }
     bool finalized() const { return finalized_; }
     // words of input the circuits layer registered (for zk_circuit_input_words)

@@ -966,6 +966,14 @@ class ConstraintSystem:
     def resolve(self, stream=None):
         _check(lib().zk_cs_resolve(self._h, _ptr(stream)))
 
+    def carried_words(self):
+        """input words of the loop stream that are loop-carried (what seeding fills)"""
+        n = C.c_uint32(0)
+        _check(lib().zk_cs_carried_words(self._h, None, 0, C.byref(n)))
+        arr = (C.c_uint32 * max(1, n.value))()
+        _check(lib().zk_cs_carried_words(self._h, arr, n.value, C.byref(n)))
+        return [int(arr[i]) for i in range(n.value)]
+
     def seed_carried_inputs(self, dev_loop_inputs, stream=None):
         """fill the loop-carried words of the bound loop input stream sequentially on the GPU"""
         _check(lib().zk_cs_seed_carried_inputs(self._h, _ptr(dev_loop_inputs), _ptr(stream)))

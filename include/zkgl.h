@@ -177,6 +177,9 @@ int zk_cs_resolve(zk_cs *cs, void *stream);          /* witness generation */
  * the host has the raw witness but not the per-iteration state (the reference's closures get exactly
  * that); hosts that already know the per-cycle state (e.g. VmLocalState per cycle) skip it. */
 int zk_cs_seed_carried_inputs(zk_cs *cs, uint64_t *dev_loop_inputs_rw, void *stream);
+/* The loop-scope input words that are loop-carried (CARRY links onto stream words): the words seeding fills and a host may leave
+ * blank.  words = NULL returns the count. */
+int zk_cs_carried_words(zk_cs *cs, uint32_t *words, uint32_t max_words, uint32_t *n_words);
 /* The same over a stream of n_instances, independent of zk_cs_set_batch (layouts: outer words[w*n + inst], loop
  * words[w*(n*limit) + inst*limit + k]).  Seeding is a latency chain of `limit` iterations per instance: one pass over ~1000
  * instances costs what a pass over 8 does, so a host seeds a long stream once and resolves it in windows

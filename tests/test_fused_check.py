@@ -1,0 +1,77 @@
+"""Fused constraint evaluation (resolve_and_check's default mode): the gates mirrored by the witness op that produces their output are
+evaluated by the witness kernels on the values they hold, the check program reads the rest — binding gates (enforcements, booleans
+of inputs, relations whose output is a given variable) and every lookup.  The verdict must equal the one of the full re-evaluation
+of the stored values (ZKGL_VERIFY_STORED=1 / check_if_satisfied) for every witness, including the one case where an op and its
+gate differ: SELECT with a selector that is not 0 / 1."""
+import numpy as np
+import pytest
+
+import zkgl
+from helpers import Rec
+from zkgl import GATE as G, OP
+
+pytestmark = pytest.mark.gpu
+
+
+def build():
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(40, 0, 8, 4))
+    for k in ("CONST", "BOOLEAN", "FMA", "REDUCTION4", "SELECT", "ZEROCHECK", "PUBLIC_INPUT"):
+        cs.allow_gate(G[k])
+    r = Rec(cs)
+    s, a, b, c = r.inp(), r.inp(), r.inp(), r.inp()     # s: a selector the circuit forgets to constrain to 0 / 1
+    sel = cs.alloc_variable_without_value()
+    cs.emit_op(OP["SELECT"], [s, a, b], [sel])
+    cs.place_gate(G["SELECT"], [a, b, s, sel])             # mirrored by the op: evaluated in the witness kernel
+    prod = cs.alloc_variable_without_value()
+    cs.emit_op(OP["FMA"], [sel, c, a], [prod], [1, 1])     # sel * c + a
+    cs.place_gate(G["FMA"], [sel, c, a, prod], [1, 1])     # mirrored
+    one = cs.allocate_constant(1)
+    cs.place_gate(G["FMA"], [c, one, c, b], [1, 0])        # enforce c == b: its output is a GIVEN variable -> binding, stays in the check program
+    cs.place_gate(G["PUBLIC_INPUT"], [prod])
+    cs.pad_and_shrink()
+    return cs
+
+
+def run(cs, inp, monkeypatch, verify_stored):
+    if verify_stored:
+        monkeypatch.setenv("ZKGL_VERIFY_STORED", "1")
+    else:
+        monkeypatch.delenv("ZKGL_VERIFY_STORED", raising=False)
+    B = inp.shape[1]
+    cs.set_batch(B)
+    d = zkgl.DeviceBuffer.from_numpy(inp)
+    cs.bind_inputs(False, d, inp.shape[0])
+    return cs.resolve_and_check()
+
+
+@pytest.mark.parametrize("verify_stored", [False, True])
+def test_fused_and_stored_verdicts_agree(zk, monkeypatch, verify_stored):
+    cs = build()
+    B = 70
+    rng = np.random.default_rng(5)
+    good = np.zeros((4, B), dtype=np.uint64)
+    good[0] = rng.integers(0, 2, B); good[1] = rng.integers(0, 1 << 32, B); good[2] = rng.integers(0, 1 << 32, B); good[3] = good[2]
+    ok, f = run(cs, good, monkeypatch, verify_stored)
+    assert ok, f
+    for i in (0, B - 1):
+        s, a, b, c = (int(x) for x in good[:, i])
+        assert cs.public_inputs(i) == [((a if s else b) * c + a) % zkgl.P]
+    # (1) a binding gate: c != b in instance 33
+    bad = good.copy(); bad[3, 33] += 1
+    ok, f = run(cs, bad, monkeypatch, verify_stored)
+    assert not ok and f.instance == 33 and f.kind == G["FMA"]
+    # (2) the mirrored SELECT with selector 2 and different branches (instance 41): op and gate disagree -> reported by the witness kernel
+    # in the fused mode (the host names the gate from the stored values), by the check program otherwise: the same failure
+    bad = good.copy(); bad[0, 41] = 2; bad[1, 41] = 7; bad[2, 41] = 9; bad[3, 41] = 9
+    ok, f = run(cs, bad, monkeypatch, verify_stored)
+    assert not ok and f.instance == 41 and f.kind == G["SELECT"]
+    # (3) selector 2 with EQUAL branches satisfies s (a - b) + b - r == 0: accepted in both modes
+    fine = good.copy(); fine[0, 12] = 2; fine[1, 12] = 5; fine[2, 12] = 5; fine[3, 12] = 5
+    ok, f = run(cs, fine, monkeypatch, verify_stored)
+    assert ok, f
+    # (4) a stored value changed after the fact: check_if_satisfied re-evaluates every gate from memory, mirrored ones included
+    ok, f = run(cs, good, monkeypatch, verify_stored)
+    assert ok
+    cs.write_cell(False, cs.public_cells()[0], 3, 12345)
+    ok, f = cs.check_if_satisfied()
+    assert not ok and f.instance == 3 and f.kind == G["FMA"]

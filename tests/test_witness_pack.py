@@ -905,3 +905,43 @@ def test_sort_decommits_and_code_unpacker_bincode_round_trips():
     assert np.array_equal(o2[:, 0], outer[:, 0]) and np.array_equal(l2[:, :limit], loop[:, :limit])
     with pytest.raises(zkgl.ZkError):
         zkgl.decode_code_unpacker_witness_bincode(data, len(reqs), len(words) - 1)
+
+
+# ---------------------------------------------------------------- a byte vector NOT written by this file's writer
+def test_hand_derived_ram_bincode_vector_decodes_to_the_reference_fixture():
+    """tests/golden/ram_witness_bincode_vector.hex: the reference's ram_permutation fixture (src/ram_permutation/mod.rs:559-634) as
+    bincode bytes derived field by field from the serde derive order (tests/golden/make_ram_bincode_vector.py; every byte group is
+    listed with its rule in ram_witness_bincode_vector.md).  The C decoder must read exactly these bytes into the fixture's witness."""
+    import json, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data = bytes.fromhex(open(os.path.join(here, "ram_witness_bincode_vector.hex")).read().strip())
+    fx = json.load(open(os.path.join(here, "ram_fixture.json")))
+    w, used = zkgl.decode_ram_witness_bincode(data, 16)
+    assert used == len(data) == 2118
+    assert w.start_flag == 1 and w.completion_flag == 0 and w.n_unsorted == 3 and w.n_sorted == 3
+    assert w.unsorted_queue_initial_state.length == 3 and not any(w.unsorted_queue_initial_state.head)
+
+    def rec(row):
+        d = dict(zip(fx["fields"], row))
+        if d["memory_page"] == "BOOTLOADER_HEAP_PAGE":
+            d["memory_page"] = rn.BOOTLOADER_HEAP_PAGE
+        return d
+    for got, rows in ((w.unsorted_queue_witness, fx["unsorted"]), (w.sorted_queue_witness, fx["sorted"])):
+        for i, row in enumerate(rows):
+            d, m = rec(row), got[i]
+            assert (m.timestamp, m.memory_page, m.index, m.rw_flag, m.is_ptr) == (d["timestamp"], d["memory_page"], d["index"], d["rw_flag"], d["is_ptr"])
+            assert sum(int(x) << (32 * k) for k, x in enumerate(m.value)) == d["value"]
+    # the decoded witness packs into the same streams as the oracle's packer builds from the fixture
+    limit = 16
+    u = [rn.mq(*[rec(r)[k] for k in fx["fields"]]) for r in fx["unsorted"]]
+    s = [rn.mq(*[rec(r)[k] for k in fx["fields"]]) for r in fx["sorted"]]
+    inst = rn.instance(u, s, limit, 1)
+    outer = np.zeros((zkgl.RAM_OUTER_WORDS, 1), dtype=np.uint64)
+    loop = np.zeros((zkgl.RAM_LOOP_WORDS, limit), dtype=np.uint64)
+    w.hidden_fsm_input.num_nondeterministic_writes = 0
+    zkgl.pack_ram_witness(w, limit, 0, outer, loop)
+    eo, el = rn.pack_streams([inst], limit)
+    el = el.copy(); el[0:46] = 0
+    assert np.array_equal(loop, el)
+    tail_words = slice(12, 24)     # unsorted_queue_initial_state.tail inside the outer stream: the chain of the fixture's three pushes
+    assert np.array_equal(outer[tail_words, 0], eo[tail_words, 0])
