@@ -4,6 +4,7 @@
 #include <string>
 #include "../../include/zkgl.h"
 #include "../../include/zkgl_witness.h"
+#include "../../include/zkgl_vm.h"
 
 namespace zkgl { void set_last_error(const std::string& m); }
 
@@ -14,6 +15,7 @@ struct Cursor {
     const uint8_t* p; size_t n, at = 0; bool ok = true;
     bool need(size_t k) { if (!ok || n - at < k) { ok = false; return false; } return true; }
     uint8_t u8() { if (!need(1)) return 0; return p[at++]; }
+    uint16_t u16() { if (!need(2)) return 0; uint16_t v; std::memcpy(&v, p + at, 2); at += 2; return v; }
     uint32_t u32() { if (!need(4)) return 0; uint32_t v; std::memcpy(&v, p + at, 4); at += 4; return v; }
     uint64_t u64() { if (!need(8)) return 0; uint64_t v; std::memcpy(&v, p + at, 8); at += 8; return v; }
     bool boolean() { const uint8_t b = u8(); if (b > 1) ok = false; return b == 1; }
@@ -763,3 +765,76 @@ int zk_decode_code_unpacker_witness_bincode(const uint8_t* bytes, size_t n_bytes
 }
 
 }  // extern "C"
+
+
+// ---- VmCircuitInputOutputWitness = ClosedFormInputWitness<VmLocalState, VmInputData, VmOutputData> (circuit_inputs/main_vm.rs:7-62), the
+// closed-form half of VmCircuitWitness (its witness_oracle half is a host-defined type: the FIFOs of zk_vm_witness_oracle).
+namespace {
+// VmLocalStateWitness in serde's derive order (src/base_structures/vm_state/mod.rs:92-109) -> the 243 flattened words
+void vm_local_state(Cursor& c, uint64_t* o) {
+    uint32_t l8[8], l5[5];
+    int n = 0;
+    auto put256 = [&] { c.u256(l8); for (int i = 0; i < 8; ++i) o[n++] = l8[i]; };
+    put256();                                                   // previous_code_word: UInt256 -> U256
+    for (int r = 0; r < ZK_VM_REGISTERS; ++r) { o[n++] = c.boolean(); put256(); }   // registers[15]: VMRegister { is_pointer, value }
+    for (int i = 0; i < 3; ++i) o[n++] = c.boolean();           // flags: overflow_or_less_than, equal, greater_than
+    for (int i = 0; i < 4; ++i) o[n++] = c.u32();               // timestamp, memory_page_counter, tx_number_in_block, previous_code_page
+    o[n++] = c.u16();                                           // previous_super_pc: UInt16
+    o[n++] = c.boolean();                                       // pending_exception
+    o[n++] = c.u32();                                           // ergs_per_pubdata_byte
+    // callstack.current_context.saved_context: ExecutionContextRecord (saved_context.rs:37-68)
+    for (int a = 0; a < 3; ++a) { c.h160(l5); for (int i = 0; i < 5; ++i) o[n++] = l5[i]; }   // this, caller, code_address: UInt160 -> Address
+    for (int i = 0; i < 4; ++i) o[n++] = c.u32();               // code_page, base_page, heap_upper_bound, aux_heap_upper_bound
+    for (int i = 0; i < 8; ++i) o[n++] = c.field();             // reverted_queue_head[4], reverted_queue_tail[4]
+    o[n++] = c.u32();                                           // reverted_queue_segment_len
+    for (int i = 0; i < 3; ++i) o[n++] = c.u16();               // pc, sp, exception_handler_loc
+    o[n++] = c.u32();                                           // ergs_remaining
+    for (int i = 0; i < 2; ++i) o[n++] = c.boolean();           // is_static_execution, is_kernel_mode
+    for (int i = 0; i < 3; ++i) o[n++] = c.u8();                // this_shard_id, caller_shard_id, code_shard_id
+    for (int i = 0; i < 4; ++i) o[n++] = c.u32();               // context_u128_value_composite
+    o[n++] = c.boolean();                                       // is_local_call
+    for (int i = 0; i < 4; ++i) o[n++] = c.field();             // current_context.log_queue_forward_tail
+    o[n++] = c.u32();                                           // current_context.log_queue_forward_part_length
+    o[n++] = c.u32();                                           // callstack.context_stack_depth
+    for (int i = 0; i < 12; ++i) o[n++] = c.field();            // callstack.stack_sponge_state
+    for (int i = 0; i < 12; ++i) o[n++] = c.field();            // memory_queue_state
+    o[n++] = c.u32();                                           // memory_queue_length
+    for (int i = 0; i < 12; ++i) o[n++] = c.field();            // code_decommittment_queue_state
+    o[n++] = c.u32();                                           // code_decommittment_queue_length
+    for (int i = 0; i < 4; ++i) o[n++] = c.u32();               // context_composite_u128
+    if (n != 243) c.ok = false;
+}
+}  // namespace
+
+int zk_decode_vm_closed_form_input_bincode(const uint8_t* bytes, size_t n_bytes, zk_vm_closed_form_input* out, zk_vm_closed_form_rest* rest, size_t* consumed) {
+    if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_vm_closed_form_input_bincode: null argument");
+    Cursor c{bytes, n_bytes};
+    std::memset(out, 0, sizeof *out);
+    zk_vm_closed_form_rest tmp;
+    zk_vm_closed_form_rest& r = rest ? *rest : tmp;
+    std::memset(&r, 0, sizeof r);
+    out->start_flag = c.boolean();
+    r.completion_flag = c.boolean();
+    // observable_input: VmInputData (circuit_inputs/main_vm.rs:9-17)
+    for (auto& x : out->rollback_queue_tail_for_block) x = c.field();
+    for (auto& x : out->memory_queue_initial_tail) x = c.field();           // QueueTailStateWitness { tail, length }
+    out->memory_queue_initial_length = c.u32();
+    for (auto& x : out->decommitment_queue_initial_tail) x = c.field();
+    out->decommitment_queue_initial_length = c.u32();
+    out->zkporter_is_available = c.boolean();                                // per_block_context: GlobalContext (vm_state/mod.rs:157-160)
+    c.u256(out->default_aa_code_hash);
+    // observable_output: VmOutputData (:32-38): three QueueStateWitness { head, tail { tail, length } }
+    for (auto& x : r.log_queue_final_state.head) x = c.field();
+    for (auto& x : r.log_queue_final_state.tail) x = c.field();
+    r.log_queue_final_state.length = c.u32();
+    for (zk_full_queue_state_witness* q : {&r.memory_queue_final_state, &r.decommitment_queue_final_state}) {
+        for (auto& x : q->head) x = c.field();
+        for (auto& x : q->tail) x = c.field();
+        q->length = c.u32();
+    }
+    vm_local_state(c, out->hidden_fsm_input);
+    vm_local_state(c, r.hidden_fsm_output);
+    if (!c.ok) return bad(ZK_ERR_INVALID, "zk_decode_vm_closed_form_input_bincode: truncated or malformed input");
+    if (consumed) *consumed = c.at;
+    return ZK_OK;
+}

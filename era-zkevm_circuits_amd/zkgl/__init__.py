@@ -636,6 +636,19 @@ class VmPackReport(C.Structure):             # zk_vm_pack_report
                 ("used_decommit_pages", C.c_size_t), ("underflow", C.c_uint32), ("final_state", C.c_uint64 * 243)]
 
 
+class VmClosedFormRest(C.Structure):        # zk_vm_closed_form_rest
+    _fields_ = [("completion_flag", C.c_uint32), ("log_queue_final_state", QueueStateWitness), ("memory_queue_final_state", FullQueueStateWitness),
+                ("decommitment_queue_final_state", FullQueueStateWitness), ("hidden_fsm_output", C.c_uint64 * 243)]
+
+
+def decode_vm_closed_form_input_bincode(data: bytes):
+    """zk_decode_vm_closed_form_input_bincode -> (VmClosedFormInput, VmClosedFormRest, bytes consumed)"""
+    cf, rest, used = VmClosedFormInput(), VmClosedFormRest(), C.c_size_t(0)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    _check(lib().zk_decode_vm_closed_form_input_bincode(buf, C.c_size_t(len(data)), C.byref(cf), C.byref(rest), C.byref(used)))
+    return cf, rest, used.value
+
+
 VM_PACK_FILL_STATE = 1
 FAILURE_STREAM_LINK, FAILURE_NONCANONICAL_INPUT = 0x400, 0x500   # zk_failure.kind beyond the gate kinds (include/zkgl.h)
 

@@ -13,6 +13,7 @@
 #define ZKGL_VM_H
 #include <stdint.h>
 #include "zkgl.h"
+#include "zkgl_witness.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -142,6 +143,21 @@ typedef struct zk_vm_pack_report {
     uint32_t underflow;           /* a getter was called under `execute` with its FIFO empty (answered with zeros) */
     uint64_t final_state[243];    /* hidden_fsm_output of this chunk (hash-chain words valid only with ZK_VM_PACK_FILL_STATE) */
 } zk_vm_pack_report;
+/* what a VmCircuitInputOutputWitness holds beyond the circuit's inputs: the prover-side expectation of the outputs (compared with
+ * zk_cs_hook_compare_witness against the hook groups "hidden_fsm_output" / "observable_output") */
+typedef struct zk_vm_closed_form_rest {
+    uint32_t completion_flag;
+    zk_queue_state_witness log_queue_final_state;                       /* VmOutputData, circuit_inputs/main_vm.rs:32-38 */
+    zk_full_queue_state_witness memory_queue_final_state, decommitment_queue_final_state;
+    uint64_t hidden_fsm_output[243];
+} zk_vm_closed_form_rest;
+/* bincode 1.x bytes of VmCircuitInputOutputWitness<F> (ClosedFormInputWitness: start_flag, completion_flag, observable_input,
+ * observable_output, hidden_fsm_input, hidden_fsm_output — src/fsm_input_output/mod.rs:42-47) in serde's derive order; the [EXT] leaf
+ * forms are those of the other decoders (include/zkgl_witness.h: field element = u64, U256 / Address = hex strings, UInt16 = u16,
+ * UInt8 = u8, Boolean = 1 byte).  `rest` may be NULL.  VmCircuitWitness's second member, the witness oracle, is a host-defined type
+ * (any `W: WitnessOracle`): its per-getter FIFOs are handed over as zk_vm_witness_oracle. */
+int zk_decode_vm_closed_form_input_bincode(const uint8_t *bytes, size_t n_bytes, zk_vm_closed_form_input *out, zk_vm_closed_form_rest *rest,
+                                           size_t *consumed);
 #define ZK_VM_PACK_FILL_STATE 1u  /* also write the 243 VmLocalState words of every cycle (host-side chains: one core, for hosts
                                      that want a finished stream; the default leaves them to zk_cs_seed_stream on the device) */
 /* One instance (chunk of `limit` cycles of the recorded circuit) into the batch's host staging arrays, in the layout of every other

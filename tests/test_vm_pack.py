@@ -96,3 +96,78 @@ def test_bench_fixture_packs_without_underflow():
     lay = cs.main_vm_layout()["loop"]
     f, n = lay["code_word"]
     assert len({loop[f:f + n, e * limit:(e + 1) * limit].tobytes() for e in range(16)}) == 16
+
+
+# ---- VmCircuitInputOutputWitness from bincode bytes (test-side writer in serde's derive order, C decoder)
+def _vm_state_bincode(st):
+    import struct
+    f = [int(x) for x in st.flatten()]
+    u256 = lambda limbs: (lambda s: struct.pack("<Q", len(s)) + s)(("0x%x" % sum(v << (32 * i) for i, v in enumerate(limbs))).encode())
+    h160 = lambda limbs: struct.pack("<Q", 42) + ("0x%040x" % sum(v << (32 * i) for i, v in enumerate(limbs))).encode()
+    u8, u16, u32, u64 = (lambda v: struct.pack("<B", v)), (lambda v: struct.pack("<H", v)), (lambda v: struct.pack("<I", v)), (lambda v: struct.pack("<Q", v))
+    o, n = b"", 0
+    o += u256(f[0:8]); n = 8
+    for r in range(15):
+        o += u8(f[n]) + u256(f[n + 1:n + 9]); n += 9
+    o += b"".join(u8(x) for x in f[n:n + 3]); n += 3
+    o += b"".join(u32(x) for x in f[n:n + 4]); n += 4
+    o += u16(f[n]) + u8(f[n + 1]) + u32(f[n + 2]); n += 3
+    for a in range(3):
+        o += h160(f[n:n + 5]); n += 5
+    o += b"".join(u32(x) for x in f[n:n + 4]); n += 4
+    o += b"".join(u64(x) for x in f[n:n + 8]); n += 8
+    o += u32(f[n]); n += 1
+    o += b"".join(u16(x) for x in f[n:n + 3]); n += 3
+    o += u32(f[n]); n += 1
+    o += u8(f[n]) + u8(f[n + 1]); n += 2
+    o += b"".join(u8(x) for x in f[n:n + 3]); n += 3
+    o += b"".join(u32(x) for x in f[n:n + 4]); n += 4
+    o += u8(f[n]); n += 1
+    o += b"".join(u64(x) for x in f[n:n + 4]); n += 4
+    o += u32(f[n]) + u32(f[n + 1]); n += 2
+    o += b"".join(u64(x) for x in f[n:n + 12]); n += 12
+    o += b"".join(u64(x) for x in f[n:n + 12]) + u32(f[n + 12]); n += 13
+    o += b"".join(u64(x) for x in f[n:n + 12]) + u32(f[n + 12]); n += 13
+    o += b"".join(u32(x) for x in f[n:n + 4]); n += 4
+    assert n == 243
+    return o
+
+
+def test_vm_closed_form_input_bincode_decoder():
+    import struct
+    d, D = vp.defs()
+    ops, contracts = vp.program_calls(D, 1)
+    limit = 16
+    run = vn.VmRun(D, vp.make_world_factory(D, ops, contracts), 3 * limit, default_aa=0x0100000000000000000000000000000000000000000000000000000000001234)
+    c0 = limit                                   # the second chunk: a non-trivial hidden_fsm_input
+    st_in, st_out = run.states[c0], run.states[c0 + limit]
+    u64 = lambda v: struct.pack("<Q", int(v))
+    aa = ("0x%x" % run.gctx[1]).encode()
+    data = struct.pack("<BB", 0, 0)                                                            # start_flag, completion_flag
+    data += b"".join(u64(x) for x in run.rollback_tail_for_block)                                # VmInputData
+    data += b"".join(u64(0) for _ in range(12)) + struct.pack("<I", 0)
+    data += b"".join(u64(0) for _ in range(12)) + struct.pack("<I", 0)
+    data += struct.pack("<B", run.gctx[0]) + struct.pack("<Q", len(aa)) + aa
+    data += b"".join(u64(0) for _ in range(8)) + struct.pack("<I", 0)                            # VmOutputData: placeholders
+    data += (b"".join(u64(0) for _ in range(24)) + struct.pack("<I", 0)) * 2
+    data += _vm_state_bincode(st_in) + _vm_state_bincode(st_out)
+    cf, rest, used = zkgl.decode_vm_closed_form_input_bincode(data + b"xyz")
+    assert used == len(data)
+    want = vp.closed_form_input(run, c0)
+    for name in ("start_flag", "zkporter_is_available", "memory_queue_initial_length"):
+        assert getattr(cf, name) == getattr(want, name)
+    assert list(cf.rollback_queue_tail_for_block) == list(want.rollback_queue_tail_for_block)
+    assert list(cf.default_aa_code_hash) == list(want.default_aa_code_hash)
+    assert list(cf.hidden_fsm_input) == list(want.hidden_fsm_input) == [int(x) for x in st_in.flatten()]
+    assert list(rest.hidden_fsm_output) == [int(x) for x in st_out.flatten()]
+    with pytest.raises(zkgl.ZkError):
+        zkgl.decode_vm_closed_form_input_bincode(data[:-7])
+    # decoded input + the oracle FIFOs -> the same streams as the directly built closed-form input
+    cs = vp.vm_cs(limit)
+    ow, lw = cs.input_words()
+    q = vp.oracle_queues(run, c0, limit)
+    o1, l1 = np.zeros((ow, 1), dtype=np.uint64), np.zeros((lw, limit), dtype=np.uint64)
+    o2, l2 = np.zeros((ow, 1), dtype=np.uint64), np.zeros((lw, limit), dtype=np.uint64)
+    cs.pack_main_vm_witness(cf, q.view(), 0, 1, o1, l1)
+    cs.pack_main_vm_witness(want, q.view(), 0, 1, o2, l2)
+    assert np.array_equal(o1, o2) and np.array_equal(l1, l2)

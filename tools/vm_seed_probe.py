@@ -39,7 +39,7 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 cs, limit = bench.build_main_vm_cs(zkgl, 20)
 n_outer, n_loop = cs.input_words()
 outer8, loop8, expect8 = bench.main_vm_streams(zkgl, cs, limit, 8)
-sel = torch.arange(S, device=dev) % 8
+sel = torch.arange(S, device=dev) % int(os.environ.get('PROBE_EXECS', '8'))
 d_outer = torch.from_numpy(outer8.view(np.int64)).to(dev)[:, sel].contiguous()
 l8 = torch.from_numpy(loop8.view(np.int64)).to(dev).view(n_loop, 8, limit)
 d_loop = l8[:, sel, :].reshape(n_loop, S * limit).contiguous()
