@@ -4,14 +4,14 @@
 // recorded cone of the carried outputs through an interpreter, one wavefront per instance: 330 us per cycle.  What is sequential
 // in a cycle is much less than its cone:
 //   phase A  k_vm_walk    the non-hash VmLocalState (registers, flags, pc, callstack scalars ...): a few hundred integer operations
-//                         per cycle once the opcode is decoded natively (vm_native.hpp) — one thread per instance, few instances
-//                         per wavefront so that instances on different opcodes do not serialise each other.  It also lists, per
-//                         instance, what each of the four Poseidon2 chains absorbs (memory queue: src/main_vm/utils.rs:194-213,
+//                         per cycle once the opcode is decoded natively (vm_native.hpp) — one WAVEFRONT per instance: lane 0 walks with
+//                         the state in LDS, all 64 lanes prefetch the next cycle's oracle words and write the state words.  It also
+//                         lists, per instance, what each of the four Poseidon2 chains absorbs (memory queue: src/main_vm/utils.rs:194-213,
 //                         cycle.rs:846-884, uma.rs:706-726; decommit queue: far_call.rs:1418-1603; forward log queue: log.rs:508-609;
 //                         callstack sponge: call_ret.rs:170-270) and how many events precede every cycle;
-//   phase B  k_vm_chains  every chain is independent of the others once phase A fixed what is absorbed: 12 lanes own one chain, one
-//                         state element each — S-boxes in parallel, linear layers through an LDS exchange — and walk its events;
-//                         the state after every event goes to a snapshot array;
+//   phase B  k_vm_chains  every chain is independent of the others once phase A fixed what is absorbed: one DPP row (12 of 16 lanes) owns
+//                         one chain, one state element per lane — S-boxes in parallel, linear layers by quad_perm / row_ror moves — and
+//                         walks its events; the state after every event goes to a snapshot array;
 //   phase C  k_vm_fill    lane = (instance, cycle): the chain words of the cycle's input state = snapshot[events before the cycle].
 // Results are the same 243 words per cycle the cone kernels produce (tests: == native restatement, == k_seed_wave).
 #pragma once
@@ -33,7 +33,7 @@ constexpr u32 FWD_TYPE = 20, SP_TYPE = 32;                      // type word: 1 
 constexpr u32 MEM_EVENTS_PER_CYCLE = 6;                          // code, src0, then UMA's 2 reads + 2 writes or the dst0 write
 
 struct SeedDev {
-    vmn::Defs D;  // D.d -> device copy of the blob
+    vmn::Defs D;  // small fields by value (scalar loads of the kernel argument), the two 2048-row tables in device memory
     u64* loop; u64 in_stride; u32 limit, n_instances;
     RawLayout raw;
     const u64* outer_store; u64 outer_n_store;
