@@ -341,6 +341,11 @@ int zk_cs_carried_words(zk_cs* cs, uint32_t* words, uint32_t max_words, uint32_t
         for (size_t i = 0; i < w.size(); ++i) words[i] = w[i];
     });
 }
+int zk_cs_set_seed_given(zk_cs* cs, const uint32_t* loop_words, uint32_t n_words) {
+    NEED(cs);
+    if (n_words && !loop_words) return fail(ZK_ERR_INVALID, "zk_cs_set_seed_given: null words");
+    return guard([&] { cs->cs->set_seed_given(loop_words, n_words); });
+}
 int zk_cs_seed_carried_inputs(zk_cs* cs, uint64_t* dev_loop_inputs_rw, void* stream) {
     NEED(cs); NEED_INIT();
     return guard([&] { cs->cs->seed_carried_inputs(dev_loop_inputs_rw, stream); });

@@ -179,6 +179,13 @@ void ram_permutation_entry_point(CS& cs, uint32_t limit) {
         }
     }
 
+    // native seeding (kernels_queue_seed.hpp): with the queue heads given by the host (the witness's previous tails) the rest of the
+    // carried state is scans over the cycles; the kernel reads the challenges from the outer store
+    cs.native_seed_kind = 2;
+    cs.native_seed_param = BOOTLOADER_HEAP_PAGE;
+    cs.native_seed_outer_vars.clear();
+    for (int r = 0; r < REPS; ++r)
+        for (int i = 1; i <= ENC; ++i) cs.native_seed_outer_vars.push_back(challenges[r][i]);
     Num num_one = g.num_const(1);
     std::array<Num, REPS> lhs0, rhs0;
     for (int r = 0; r < REPS; ++r) {  // mod.rs:118-130

@@ -88,6 +88,7 @@ CS::~CS() {
     if (d_seed_carries_) hipFree(d_seed_carries_);
     if (d_native_blob_) hipFree(d_native_blob_);
     if (d_state0_slot_) hipFree(d_state0_slot_);
+    if (d_native_outer_slots_) hipFree(d_native_outer_slots_);
     if (d_native_scratch_) hipFree(d_native_scratch_);
     if (d_seed_outer_) hipFree(d_seed_outer_);
     for (auto p : d_streams_) if (p) hipFree(p);
@@ -2233,11 +2234,49 @@ uint32_t CS::layout_word(const char* scope, const char* name) const {
     return UINT32_MAX;
 }
 
-// main_vm (native_seed_kind 1): walker + Poseidon2 chains + fill (kernels_vm_seed.hpp) instead of the cone of the carried outputs
+void CS::set_seed_given(const uint32_t* loop_words, uint32_t n) {
+    if (!finalized_) throw ZkError(ZK_ERR_INVALID, "set_seed_given before finalize");
+    std::vector<uint32_t> w(loop_words, loop_words + n);
+    for (uint32_t x : w) {
+        bool carried = false;
+        for (auto& c : carries_store_) carried |= c.word == x;
+        if (!carried) throw ZkError(ZK_ERR_INVALID, "set_seed_given: not a loop-carried word");
+    }
+    seed_given_words_ = std::move(w);
+}
+bool CS::seed_words_given(const uint32_t* words, uint32_t n) const {
+    for (uint32_t i = 0; i < n; ++i)
+        if (std::find(seed_given_words_.begin(), seed_given_words_.end(), words[i]) == seed_given_words_.end()) return false;
+    return true;
+}
+
+// a circuit's native seeder instead of the cone of the carried outputs: main_vm (kind 1): walker + Poseidon2 chains + fill
+// (kernels_vm_seed.hpp); ram_permutation (kind 2) once the host has declared the queue heads given: scans (kernels_queue_seed.hpp)
 bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream) {
-    if (native_seed_kind != 1) return false;
     const char* e = std::getenv("ZKGL_SEED_NATIVE");
     if (e && e[0] == '0') return false;
+    if (native_seed_kind == 2) {
+        uint32_t heads[24];
+        for (uint32_t i = 0; i < 12; ++i) { heads[i] = 1 + i; heads[12 + i] = 14 + i; }
+        if (!seed_words_given(heads, 24) || native_seed_outer_vars.size() != 16 || carries_store_.size() != 46) return false;
+        if (!d_state0_slot_) {
+            std::vector<uint32_t> slots(46, UINT32_MAX), ch;
+            for (auto& c : carries_store_)
+                if (c.word < 46 && c.has_first) slots[c.word] = c.first_outer_cell;
+            for (uint32_t sl : slots)
+                if (sl == UINT32_MAX) return false;
+            for (zk_var v : native_seed_outer_vars) ch.push_back(outer_.var_slot[var_index(v)]);
+            d_state0_slot_ = upload(slots);
+            d_native_outer_slots_ = upload(ch);
+        }
+        zkdev::RamSeedArgs a;
+        a.loop = dev_loop_inputs_rw; a.in_stride = la.in_stride; a.limit = limit_; a.n_instances = n;
+        a.outer_store = la.outer_cells; a.outer_n_store = la.outer_n_cells; a.state0_slot = d_state0_slot_; a.ch_slot = d_native_outer_slots_;
+        a.bootloader_heap_page = native_seed_param;
+        dev_check(zkdev::launch_ram_seed(a, stream));
+        return true;
+    }
+    if (native_seed_kind != 1) return false;
     if (circuit_blob.size() != sizeof(zk_opcode_defs)) return false;
     zkdev::VmSeedArgs a;
     const char* names[14] = {"code_word", "src0_read_value", "src0_read_is_ptr", "log_pubdata_refund", "log_storage_read_value", "log_rollback_queue_prev_head",

@@ -206,7 +206,11 @@ class CS {
     void launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream);
     // chain-specialised seeding: a circuit whose carried state has a native walker registers it here (main_vm: kind 1).  Used by
     // launch_seed instead of the cone kernels unless ZKGL_SEED_NATIVE=0; last_seed_phase_ms: walker / chains / fill of the last pass.
-    int native_seed_kind = 0;
+    int native_seed_kind = 0;                       // 1: main_vm (walker + chains + fill); 2: ram_permutation (scans, needs the queue heads given)
+    std::vector<zk_var> native_seed_outer_vars;     // outer-scope variables the native seeder reads (ram: challenges[r][1..8]); slots uploaded on first use
+    uint32_t native_seed_param = 0;                 // ram: BOOTLOADER_HEAP_PAGE
+    void set_seed_given(const uint32_t* loop_words, uint32_t n);
+    bool seed_words_given(const uint32_t* words, uint32_t n) const;
     float last_seed_phase_ms[3] = {0, 0, 0};
     bool launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream);
     // first word of a field of the recorded input layout ("outer" / "loop"), UINT32_MAX when absent
@@ -356,6 +360,8 @@ class CS {
     // native seeding: device copies of the circuit blob and of the state-word -> outer slot table, scratch grown on demand
     void* d_native_blob_ = nullptr;
     uint32_t* d_state0_slot_ = nullptr;
+    uint32_t* d_native_outer_slots_ = nullptr;
+    std::vector<uint32_t> seed_given_words_;
     uint64_t* d_native_scratch_ = nullptr;
     size_t native_scratch_bytes_ = 0;
     uint64_t* d_seed_outer_ = nullptr;   // seed_stream's outer store

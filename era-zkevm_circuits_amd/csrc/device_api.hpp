@@ -74,6 +74,12 @@ struct VmSeedArgs {
 size_t vm_seed_scratch_bytes(uint32_t limit, uint32_t n_instances);
 // phase_ms (optional, 3 floats): walker / chains / fill, measured with events on `stream` (synchronises)
 int launch_vm_seed(const VmSeedArgs& a, void* stream, float* phase_ms);
+// ram_permutation seeding with the queue heads given (kernels_queue_seed.hpp): scans, no chain.  Mirrors zkq::RamSeedDev.
+struct RamSeedArgs {
+    uint64_t* loop; uint64_t in_stride; uint32_t limit, n_instances;
+    const uint64_t* outer_store; uint64_t outer_n_store; const uint32_t* state0_slot; const uint32_t* ch_slot; uint32_t bootloader_heap_page;
+};
+int launch_ram_seed(const RamSeedArgs& a, void* stream);
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);
 int launch_check_gates(const CheckArgs& cd, void* stream);

@@ -165,12 +165,32 @@ int zk_pack_ram_witness(const zk_ram_permutation_witness* w, uint32_t limit, uin
             }
         }
         if (k != ZK_RAM_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: ram loop layout");
+        // queue heads from the witness's previous tails: head before popping element c = the state before element c was pushed; past
+        // the last element the head has reached the tail of the state the circuit starts from (observable input, or the FSM input)
+        if (w->unsorted_previous_tails && w->sorted_previous_tails) {
+            const zk_full_queue_state_witness& qu = w->start_flag ? w->unsorted_queue_initial_state : w->hidden_fsm_input.current_unsorted_queue_state;
+            const zk_full_queue_state_witness& qs = w->start_flag ? w->sorted_queue_initial_state : w->hidden_fsm_input.current_sorted_queue_state;
+            for (int i = 0; i < 12; ++i) {
+                l[(1 + i) * lanes] = c < w->n_unsorted ? w->unsorted_previous_tails[c][i] : qu.tail[i];
+                l[(14 + i) * lanes] = c < w->n_sorted ? w->sorted_previous_tails[c][i] : qs.tail[i];
+            }
+        }
     }
     return ZK_OK;
 }
 
 int zk_decode_ram_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_ram_permutation_witness* out, zk_memory_query_witness* unsorted_buf,
                                   uint32_t unsorted_cap, zk_memory_query_witness* sorted_buf, uint32_t sorted_cap, size_t* consumed) {
+    return zk_decode_ram_witness_bincode_tails(bytes, n_bytes, out, unsorted_buf, unsorted_cap, sorted_buf, sorted_cap, nullptr, nullptr, consumed);
+}
+
+void zk_ram_head_words(uint32_t words[ZK_RAM_HEAD_WORDS]) {   // circuits/ram_permutation.cpp: [1..13) unsorted head, [14..26) sorted head
+    for (uint32_t i = 0; i < 12; ++i) { words[i] = 1 + i; words[12 + i] = 14 + i; }
+}
+
+int zk_decode_ram_witness_bincode_tails(const uint8_t* bytes, size_t n_bytes, zk_ram_permutation_witness* out, zk_memory_query_witness* unsorted_buf,
+                                        uint32_t unsorted_cap, zk_memory_query_witness* sorted_buf, uint32_t sorted_cap, uint64_t (*unsorted_tails)[12],
+                                        uint64_t (*sorted_tails)[12], size_t* consumed) {
     if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_ram_witness_bincode: null argument");
     Cursor c{bytes, n_bytes};
     std::memset(out, 0, sizeof *out);
@@ -190,10 +210,14 @@ int zk_decode_ram_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_ram_p
         if (n > cap || (n && !buf)) return bad(ZK_ERR_CAPACITY, "zk_decode_ram_witness_bincode: queue witness longer than the caller's buffer");
         for (uint64_t i = 0; i < n && c.ok; ++i) {
             c.memory_query(buf[i]);
-            for (int t = 0; t < 12; ++t) c.field();  // the queue tail before the push: not consumed by the circuit
+            uint64_t (*tails)[12] = side == 0 ? unsorted_tails : sorted_tails;
+            for (int t = 0; t < 12; ++t) {   // the queue state before this push = the head before its pop
+                const uint64_t v = c.field();
+                if (tails) tails[i][t] = v;
+            }
         }
-        if (side == 0) { out->unsorted_queue_witness = buf; out->n_unsorted = (uint32_t)n; }
-        else { out->sorted_queue_witness = buf; out->n_sorted = (uint32_t)n; }
+        if (side == 0) { out->unsorted_queue_witness = buf; out->n_unsorted = (uint32_t)n; out->unsorted_previous_tails = unsorted_tails; }
+        else { out->sorted_queue_witness = buf; out->n_sorted = (uint32_t)n; out->sorted_previous_tails = sorted_tails; }
     }
     if (!c.ok) return bad(ZK_ERR_INVALID, "zk_decode_ram_witness_bincode: truncated or malformed input");
     if (consumed) *consumed = c.at;

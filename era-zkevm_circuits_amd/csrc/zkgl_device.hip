@@ -11,6 +11,7 @@
 #include "kernels_engine2.hpp"
 #include "kernels_seed_wave.hpp"
 #include "kernels_vm_seed.hpp"
+#include "kernels_queue_seed.hpp"
 #include "kernels_lookup_arg.hpp"
 #include "kernels_ntt.hpp"
 #include "kernels_perm.hpp"
@@ -530,6 +531,16 @@ int launch_vm_seed(const VmSeedArgs& v, void* stream, float* phase_ms) {
     if (int r = chk(hipStreamWaitEvent(st, S.done, 0), "hipStreamWaitEvent")) return r;
     zkvm::k_vm_fill<<<grid_for((size_t)v.n_instances * v.limit, 256), 256, 0, st>>>(a);
     return LAUNCH_CHECK("k_vm_fill");
+}
+
+int launch_ram_seed(const RamSeedArgs& v, void* stream) {
+    if (v.n_instances == 0 || v.limit == 0) return 0;
+    zkq::RamSeedDev a;
+    a.loop = v.loop; a.in_stride = v.in_stride; a.limit = v.limit; a.n_instances = v.n_instances;
+    a.outer_store = v.outer_store; a.outer_n_store = v.outer_n_store; a.state0_slot = v.state0_slot; a.ch_slot = v.ch_slot;
+    a.bootloader_heap_page = v.bootloader_heap_page;
+    zkq::k_ram_seed<<<v.n_instances, 256, 0, (hipStream_t)stream>>>(a);
+    return LAUNCH_CHECK("k_ram_seed");
 }
 
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,

@@ -145,7 +145,8 @@ class RamPermutationWitness(C.Structure):
                 ("non_deterministic_bootloader_memory_snapshot_length", C.c_uint32),
                 ("hidden_fsm_input", RamFsmWitness), ("hidden_fsm_output", RamFsmWitness),
                 ("unsorted_queue_witness", C.POINTER(MemoryQueryWitness)), ("n_unsorted", C.c_uint32),
-                ("sorted_queue_witness", C.POINTER(MemoryQueryWitness)), ("n_sorted", C.c_uint32)]
+                ("sorted_queue_witness", C.POINTER(MemoryQueryWitness)), ("n_sorted", C.c_uint32),
+                ("unsorted_previous_tails", C.POINTER(C.c_uint64 * 12)), ("sorted_previous_tails", C.POINTER(C.c_uint64 * 12))]
 
 
 RAM_OUTER_WORDS, RAM_LOOP_WORDS = 121, 72
@@ -159,15 +160,27 @@ def pack_ram_witness(w: RamPermutationWitness, limit: int, instance: int, outer:
     _check(lib().zk_pack_ram_witness(C.byref(w), limit, instance, batch, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
 
 
-def decode_ram_witness_bincode(data: bytes, max_elements: int):
-    """zk_decode_ram_witness_bincode -> (RamPermutationWitness, bytes consumed); the element arrays stay referenced by the result"""
+def decode_ram_witness_bincode(data: bytes, max_elements: int, keep_tails: bool = False):
+    """zk_decode_ram_witness_bincode[_tails] -> (RamPermutationWitness, bytes consumed); the element arrays stay referenced by the result.
+    keep_tails: also keep the previous tail of every queue element (the packer then writes the queue heads of every cycle)"""
     w = RamPermutationWitness()
     ub, sb = (MemoryQueryWitness * max(max_elements, 1))(), (MemoryQueryWitness * max(max_elements, 1))()
     used = C.c_size_t(0)
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
-    _check(lib().zk_decode_ram_witness_bincode(buf, C.c_size_t(len(data)), C.byref(w), ub, max_elements, sb, max_elements, C.byref(used)))
-    w._keep = (ub, sb)
+    if keep_tails:
+        ut, stl = ((C.c_uint64 * 12) * max(max_elements, 1))(), ((C.c_uint64 * 12) * max(max_elements, 1))()
+        _check(lib().zk_decode_ram_witness_bincode_tails(buf, C.c_size_t(len(data)), C.byref(w), ub, max_elements, sb, max_elements, ut, stl, C.byref(used)))
+        w._keep = (ub, sb, ut, stl)
+    else:
+        _check(lib().zk_decode_ram_witness_bincode(buf, C.c_size_t(len(data)), C.byref(w), ub, max_elements, sb, max_elements, C.byref(used)))
+        w._keep = (ub, sb)
     return w, used.value
+
+
+def ram_head_words():
+    arr = (C.c_uint32 * 24)()
+    lib().zk_ram_head_words(arr)
+    return [int(x) for x in arr]
 
 
 class LogQueryWitness(C.Structure):
@@ -986,6 +999,11 @@ class ConstraintSystem:
         arr = (C.c_uint32 * max(1, n.value))()
         _check(lib().zk_cs_carried_words(self._h, arr, n.value, C.byref(n)))
         return [int(arr[i]) for i in range(n.value)]
+
+    def set_seed_given(self, words):
+        """zk_cs_set_seed_given: loop-carried words the host fills itself in the streams it seeds from now on ([] clears)"""
+        arr = (C.c_uint32 * max(1, len(words)))(*words)
+        _check(lib().zk_cs_set_seed_given(self._h, arr, len(words)))
 
     def seed_carried_inputs(self, dev_loop_inputs, stream=None):
         """fill the loop-carried words of the bound loop input stream sequentially on the GPU"""

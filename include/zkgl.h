@@ -180,6 +180,11 @@ int zk_cs_seed_carried_inputs(zk_cs *cs, uint64_t *dev_loop_inputs_rw, void *str
 /* The loop-scope input words that are loop-carried (CARRY links onto stream words): the words seeding fills and a host may leave
  * blank.  words = NULL returns the count. */
 int zk_cs_carried_words(zk_cs *cs, uint32_t *words, uint32_t max_words, uint32_t *n_words);
+/* Declares loop-carried words the host fills itself in the streams it hands to the seeding entry points from now on (e.g. queue heads
+ * taken from the previous tails the reference's queue witnesses carry).  A circuit's native seeder that needs no chain once they are
+ * given takes the parallel path (ram_permutation); the generic cone kernels recompute and overwrite them with the same values.
+ * n_words = 0 clears the declaration.  ZK_ERR_INVALID: a word that is not loop-carried. */
+int zk_cs_set_seed_given(zk_cs *cs, const uint32_t *loop_words, uint32_t n_words);
 /* The same over a stream of n_instances, independent of zk_cs_set_batch (layouts: outer words[w*n + inst], loop
  * words[w*(n*limit) + inst*limit + k]).  Seeding is a latency chain of `limit` iterations per instance: one pass over ~1000
  * instances costs what a pass over 8 does, so a host seeds a long stream once and resolves it in windows

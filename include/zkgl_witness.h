@@ -52,6 +52,13 @@ typedef struct zk_ram_permutation_witness {
     zk_ram_fsm_witness hidden_fsm_input, hidden_fsm_output;
     const zk_memory_query_witness *unsorted_queue_witness; uint32_t n_unsorted;
     const zk_memory_query_witness *sorted_queue_witness; uint32_t n_sorted;
+    /* the second member of every (element, tail) pair of the two queue witnesses: the queue state BEFORE that element was pushed
+     * (src/ram_permutation/input.rs:103-116) = the head the circuit holds before it pops it.  Optional (NULL: absent).  When both are
+     * given, zk_pack_ram_witness writes the queue heads of every cycle (24 of the 46 loop-carried words) from them — no hashing —
+     * and the host declares those words given (zk_cs_set_seed_given, zk_ram_head_words): seeding then has no chain left and runs as
+     * scans, lane = (instance, cycle). */
+    const uint64_t (*unsorted_previous_tails)[12];
+    const uint64_t (*sorted_previous_tails)[12];
 } zk_ram_permutation_witness;
 
 #define ZK_RAM_OUTER_WORDS 121
@@ -73,6 +80,14 @@ int zk_pack_ram_witness(const zk_ram_permutation_witness *w, uint32_t limit, uin
 int zk_decode_ram_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_ram_permutation_witness *out,
                                   zk_memory_query_witness *unsorted_buf, uint32_t unsorted_cap,
                                   zk_memory_query_witness *sorted_buf, uint32_t sorted_cap, size_t *consumed);
+/* The same, keeping the previous tails: unsorted_tails / sorted_tails are caller-owned [cap][12] arrays (NULL: dropped as above). */
+int zk_decode_ram_witness_bincode_tails(const uint8_t *bytes, size_t n_bytes, zk_ram_permutation_witness *out,
+                                        zk_memory_query_witness *unsorted_buf, uint32_t unsorted_cap,
+                                        zk_memory_query_witness *sorted_buf, uint32_t sorted_cap,
+                                        uint64_t (*unsorted_tails)[12], uint64_t (*sorted_tails)[12], size_t *consumed);
+/* the 24 loop-stream words of ram_permutation that hold the two queue heads (what the packer fills from the previous tails) */
+#define ZK_RAM_HEAD_WORDS 24
+void zk_ram_head_words(uint32_t words[ZK_RAM_HEAD_WORDS]);
 
 
 /* ---- LogQuery witness, /root/reference/src/base_structures/log_query/mod.rs:23-35 (UInt160 address: 5 little-endian u32 limbs) */

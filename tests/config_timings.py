@@ -14,13 +14,15 @@ from oracle import keccak_native as kn, log_sorter_native as ln, ram_native as r
 zkgl.init(0)
 
 
-def timed(name, cs, outer, loop, batch, seed_carried=1):
+def timed(name, cs, outer, loop, batch, seed_carried=1, given=()):
     """one configuration: seeding of the carried words from the raw stream (timed, compared with the native restatement's words), then
     one fused resolve_and_check (after a warm-up); from-raw rate = constraints / (seeding + step)"""
     cs.set_batch(batch)
     carried = cs.carried_words()
     raw = loop.copy()
-    raw[carried, :] = 0
+    raw[[w for w in carried if w not in given], :] = 0
+    if given:
+        cs.set_seed_given(list(given))                    # words the host packer fills (ram: the queue heads = the witness's previous tails)
     d_o, d_l = zkgl.DeviceBuffer.from_numpy(outer), zkgl.DeviceBuffer.from_numpy(raw)
     cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
     t_seed, seeded_ok = None, None
@@ -53,6 +55,7 @@ if want("C1"):
     inst = rn.instance(u, s, limit, nd)
     outer, loop = rn.pack_streams([inst] * 512, limit)
     timed("C1 ram_permutation 2^16 rows", cs, outer, loop, 512)
+    timed("C1 ram_permutation 2^16 rows, heads from the witness's previous tails", cs, outer, loop, 512, given=zkgl.ram_head_words())
 # C3
 if want("C3k"):
     cs, limit = T.fit(lambda c: c.configure_keccak(), lambda c, l: c.keccak256_round_function_entry_point(l), 20)

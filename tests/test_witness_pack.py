@@ -130,6 +130,66 @@ def test_ram_bincode_round_trip_and_errors():
         zkgl.pack_ram_witness(d, LIMIT - 10, 0, np.zeros((121, 1), dtype=np.uint64), np.zeros((72, LIMIT - 10), dtype=np.uint64))
 
 
+def _packed_with_tails(cases):
+    B = len(cases)
+    outer = np.zeros((zkgl.RAM_OUTER_WORDS, B), dtype=np.uint64)
+    loop = np.zeros((zkgl.RAM_LOOP_WORDS, B * LIMIT), dtype=np.uint64)
+    for i, (u, s, nd, inst) in enumerate(cases):
+        ub, sb = inst["heads"]
+        w, _ = zkgl.decode_ram_witness_bincode(bincode_bytes(witness_struct(inst, u, s, nd, rn.empty_fsm()), ub, sb), LIMIT, keep_tails=True)
+        zkgl.pack_ram_witness(w, LIMIT, i, outer, loop)
+    return outer, loop
+
+
+def test_ram_packer_writes_the_queue_heads_from_the_previous_tails():
+    """the decoder that keeps the witness's previous tails (CircuitQueueRawWitness elements are (item, previous_tail),
+    reference src/base_structures/vm_state/mod.rs FullStateCircuitQueueRawWitness) lets the packer write the head of both queues in
+    every cycle: those 24 words equal the native restatement's, the other carried words stay with the device"""
+    cases = [_case(500 + i, n) for i, n in enumerate((LIMIT, LIMIT - 9, 1, 0))]
+    outer, loop = _packed_with_tails(cases)
+    full_o, full_l = rn.pack_streams([c[3] for c in cases], LIMIT)
+    heads = zkgl.ram_head_words()
+    assert heads == list(range(1, 13)) + list(range(14, 26))
+    assert np.array_equal(loop[heads], full_l[heads])
+    rest = [w for w in range(46) if w not in heads]
+    assert not loop[rest].any()
+    assert np.array_equal(loop[46:], full_l[46:]) and np.array_equal(outer, full_o)
+
+
+@pytest.mark.gpu
+def test_ram_scan_seeding_from_given_heads_equals_the_cone_seeding(zk):
+    """kernels_queue_seed.hpp: with the heads given, the remaining carried words (accumulators, lengths, previous keys) are scans over
+    the cycles — bit-equal to the recorded-cone seeding and to the native restatement, instances ending early / empty included"""
+    from helpers import ram_cs
+    cases = [_case(600 + i, n) for i, n in enumerate((LIMIT, LIMIT - 7, LIMIT - 1, 3, 0, 1))]
+    outer, loop = _packed_with_tails(cases)
+    full_o, full_l = rn.pack_streams([c[3] for c in cases], LIMIT)
+    cs = ram_cs(LIMIT)
+    cs.set_batch(len(cases))
+    d_o = zk.DeviceBuffer.from_numpy(outer)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    # the cone (nothing given): from a stream without the heads
+    raw = loop.copy(); raw[0:46] = 0
+    d_cone = zk.DeviceBuffer.from_numpy(raw)
+    cs.bind_inputs(True, d_cone, loop.shape[0])
+    cs.seed_carried_inputs(d_cone)
+    assert np.array_equal(d_cone.to_numpy().reshape(loop.shape), full_l)
+    # the scan kernel
+    cs.set_seed_given(zkgl.ram_head_words())
+    d_l = zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    cs.seed_carried_inputs(d_l)
+    got = d_l.to_numpy().reshape(loop.shape)
+    bad = [w for w in range(46) if not np.array_equal(got[w], full_l[w])]
+    assert not bad, f"carried words {bad} differ from the native restatement"
+    assert np.array_equal(got, full_l)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, c in enumerate(cases):
+        assert cs.public_inputs(i) == c[3]["commitment"]
+    cs.set_seed_given([])
+
+
 @pytest.mark.gpu
 def test_ram_streams_built_through_the_c_abi_run_on_the_gpu(zk):
     from helpers import ram_cs
