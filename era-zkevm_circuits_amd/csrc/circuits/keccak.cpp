@@ -251,6 +251,7 @@ void keccak256_round_function_entry_point(CS& cs, uint32_t limit) {
     }
 
     // =========================== loop body (mod.rs:228-667), recorded once ===========================
+    cs.native_seed_kind = 3;  // the carried FSM state has a native walker (kernels_fsm_seed.hpp)
     cs.loop_begin(limit);
     K kk(g);
     std::array<zk_var, KF_CARRIED> in{}, out{};

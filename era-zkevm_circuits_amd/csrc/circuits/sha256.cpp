@@ -175,6 +175,7 @@ void sha256_round_function_entry_point(CS& cs, uint32_t limit) {
     }
 
     // =========================== loop body (mod.rs:139-331), recorded once ===========================
+    cs.native_seed_kind = 4;  // the carried FSM state has a native walker (kernels_fsm_seed.hpp)
     cs.loop_begin(limit);
     S s(g);
     std::array<zk_var, SHA_FSM_CARRIED> in{}, out{};

@@ -2276,6 +2276,24 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
         dev_check(zkdev::launch_ram_seed(a, stream));
         return true;
     }
+    if (native_seed_kind == 3 || native_seed_kind == 4) {   // keccak256 / sha256 round function FSMs (kernels_fsm_seed.hpp)
+        const uint32_t n_carried = native_seed_kind == 3 ? 423 : 60, n_words = native_seed_kind == 3 ? 507 : 112;
+        if (carries_store_.size() != n_carried || loop_.n_input_words != n_words) return false;
+        if (!d_state0_slot_) {
+            std::vector<uint32_t> slots(n_carried, UINT32_MAX);
+            for (auto& c : carries_store_)
+                if (c.word < n_carried && c.has_first) slots[c.word] = c.first_outer_cell;
+            for (uint32_t sl : slots)
+                if (sl == UINT32_MAX) return false;
+            d_state0_slot_ = upload(slots);
+        }
+        zkdev::FsmSeedArgs a;
+        a.kind = native_seed_kind - 3;
+        a.loop = dev_loop_inputs_rw; a.in_stride = la.in_stride; a.limit = limit_; a.n_instances = n;
+        a.outer_store = la.outer_cells; a.outer_n_store = la.outer_n_cells; a.state0_slot = d_state0_slot_;
+        dev_check(zkdev::launch_fsm_seed(a, stream));
+        return true;
+    }
     if (native_seed_kind != 1) return false;
     if (circuit_blob.size() != sizeof(zk_opcode_defs)) return false;
     zkdev::VmSeedArgs a;

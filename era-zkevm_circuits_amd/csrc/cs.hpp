@@ -206,7 +206,7 @@ class CS {
     void launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream);
     // chain-specialised seeding: a circuit whose carried state has a native walker registers it here (main_vm: kind 1).  Used by
     // launch_seed instead of the cone kernels unless ZKGL_SEED_NATIVE=0; last_seed_phase_ms: walker / chains / fill of the last pass.
-    int native_seed_kind = 0;                       // 1: main_vm (walker + chains + fill); 2: ram_permutation (scans, needs the queue heads given)
+    int native_seed_kind = 0;                       // 1: main_vm (walker + chains + fill); 2: ram_permutation (scans, needs the queue heads given); 3 / 4: keccak256 / sha256 round function FSM
     std::vector<zk_var> native_seed_outer_vars;     // outer-scope variables the native seeder reads (ram: challenges[r][1..8]); slots uploaded on first use
     uint32_t native_seed_param = 0;                 // ram: BOOTLOADER_HEAP_PAGE
     void set_seed_given(const uint32_t* loop_words, uint32_t n);

@@ -80,6 +80,12 @@ struct RamSeedArgs {
     const uint64_t* outer_store; uint64_t outer_n_store; const uint32_t* state0_slot; const uint32_t* ch_slot; uint32_t bootloader_heap_page;
 };
 int launch_ram_seed(const RamSeedArgs& a, void* stream);
+// precompile FSM seeding (kernels_fsm_seed.hpp): kind 0 keccak256_round_function, 1 sha256_round_function.  Mirrors zkf::FsmSeedDev.
+struct FsmSeedArgs {
+    int kind; uint64_t* loop; uint64_t in_stride; uint32_t limit, n_instances;
+    const uint64_t* outer_store; uint64_t outer_n_store; const uint32_t* state0_slot;
+};
+int launch_fsm_seed(const FsmSeedArgs& a, void* stream);
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);
 int launch_check_gates(const CheckArgs& cd, void* stream);

@@ -12,6 +12,7 @@
 #include "kernels_seed_wave.hpp"
 #include "kernels_vm_seed.hpp"
 #include "kernels_queue_seed.hpp"
+#include "kernels_fsm_seed.hpp"
 #include "kernels_lookup_arg.hpp"
 #include "kernels_ntt.hpp"
 #include "kernels_perm.hpp"
@@ -541,6 +542,17 @@ int launch_ram_seed(const RamSeedArgs& v, void* stream) {
     a.bootloader_heap_page = v.bootloader_heap_page;
     zkq::k_ram_seed<<<v.n_instances, 256, 0, (hipStream_t)stream>>>(a);
     return LAUNCH_CHECK("k_ram_seed");
+}
+
+int launch_fsm_seed(const FsmSeedArgs& v, void* stream) {
+    if (v.n_instances == 0 || v.limit == 0) return 0;
+    zkf::FsmSeedDev a;
+    a.loop = v.loop; a.in_stride = v.in_stride; a.limit = v.limit; a.n_instances = v.n_instances;
+    a.outer_store = v.outer_store; a.outer_n_store = v.outer_n_store; a.state0_slot = v.state0_slot;
+    if (v.kind == 0) zkf::k_fsm_seed<zkf::Keccak><<<v.n_instances, 128, 0, (hipStream_t)stream>>>(a);
+    else if (v.kind == 1) zkf::k_fsm_seed<zkf::Sha256><<<v.n_instances, 128, 0, (hipStream_t)stream>>>(a);
+    else return -1;
+    return LAUNCH_CHECK("k_fsm_seed");
 }
 
 int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32_t n_instances, uint32_t limit,
