@@ -95,6 +95,12 @@ void sort_and_deduplicate_storage_access_entry_point(CS& cs, uint32_t limit, boo
     fs_input.insert(fs_input.end(), obs_sorted.tail.begin(), obs_sorted.tail.end());
     fs_input.push_back(obs_sorted.length.v);
     auto challenges = produce_fs_challenges<ENC + 1>(g, fs_input);
+    // native seeding (kernels_queue_seed.hpp) once the host packer has walked the integer state: the accumulators are scans that read the challenges
+    cs.native_seed_kind = 5;
+    cs.native_seed_outer_vars.clear();
+    for (int r = 0; r < 2; ++r)
+        for (size_t i = 1; i <= ENC; ++i) cs.native_seed_outer_vars.push_back(challenges[r][i]);
+    cs.native_seed_outer_vars.push_back(shard_id.v);
 
     Num one = g.num_const(1);
     std::array<Num, 2> lhs0, rhs0;

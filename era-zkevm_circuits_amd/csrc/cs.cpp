@@ -2276,6 +2276,33 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
         dev_check(zkdev::launch_ram_seed(a, stream));
         return true;
     }
+    if (native_seed_kind == 5 || native_seed_kind == 6) {   // storage_validity / log_sorter: the host packer walked the integer state
+        const bool storage = native_seed_kind == 5;
+        const uint32_t n_carried = storage ? 67 : 57, acc = storage ? 2 : 1, tail = storage ? 17 : 15;
+        if (carries_store_.size() != n_carried || native_seed_outer_vars.size() != (storage ? 41u : 40u)) return false;
+        std::vector<uint32_t> need;
+        for (uint32_t w = 0; w < n_carried; ++w)
+            if (!(w >= acc && w < acc + 4) && !(w >= tail && w < tail + 4)) need.push_back(w);
+        if (!seed_words_given(need.data(), (uint32_t)need.size())) return false;
+        uint32_t tw[4] = {tail, tail + 1, tail + 2, tail + 3};
+        const bool tail_given = seed_words_given(tw, 4);
+        if (!d_state0_slot_) {
+            std::vector<uint32_t> slots(n_carried, UINT32_MAX), ch;
+            for (auto& c : carries_store_)
+                if (c.word < n_carried && c.has_first) slots[c.word] = c.first_outer_cell;
+            for (uint32_t sl : slots)
+                if (sl == UINT32_MAX) return false;
+            for (zk_var v : native_seed_outer_vars) ch.push_back(outer_.var_slot[var_index(v)]);
+            d_state0_slot_ = upload(slots);
+            d_native_outer_slots_ = upload(ch);
+        }
+        zkdev::LogqSeedArgs a;
+        a.kind = storage ? 0 : 1; a.with_chain = tail_given ? 0 : 1;
+        a.loop = dev_loop_inputs_rw; a.in_stride = la.in_stride; a.limit = limit_; a.n_instances = n;
+        a.outer_store = la.outer_cells; a.outer_n_store = la.outer_n_cells; a.state0_slot = d_state0_slot_; a.ch_slot = d_native_outer_slots_;
+        dev_check(zkdev::launch_logq_seed(a, stream));
+        return true;
+    }
     if (native_seed_kind == 3 || native_seed_kind == 4) {   // keccak256 / sha256 round function FSMs (kernels_fsm_seed.hpp)
         const uint32_t n_carried = native_seed_kind == 3 ? 423 : 60, n_words = native_seed_kind == 3 ? 507 : 112;
         if (carries_store_.size() != n_carried || loop_.n_input_words != n_words) return false;

@@ -86,6 +86,13 @@ struct FsmSeedArgs {
     const uint64_t* outer_store; uint64_t outer_n_store; const uint32_t* state0_slot;
 };
 int launch_fsm_seed(const FsmSeedArgs& a, void* stream);
+// the LogQuery sorters with the integer state given by the host packer (kernels_queue_seed.hpp): kind 0 storage_validity, 1 log_sorter;
+// with_chain: the output queue's tail is not given and is hashed here.  Mirrors zkq::LogqSeedDev.
+struct LogqSeedArgs {
+    int kind, with_chain; uint64_t* loop; uint64_t in_stride; uint32_t limit, n_instances;
+    const uint64_t* outer_store; uint64_t outer_n_store; const uint32_t* state0_slot; const uint32_t* ch_slot;
+};
+int launch_logq_seed(const LogqSeedArgs& a, void* stream);
 int launch_witness_seq(const ScopeArgs& loop_sc, const CarryArgs* d_carries, uint32_t n_carries, uint64_t* inputs_rw,
                        uint32_t n_instances, void* stream);
 int launch_check_gates(const CheckArgs& cd, void* stream);

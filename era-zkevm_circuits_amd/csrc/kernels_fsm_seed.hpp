@@ -26,6 +26,7 @@ struct FsmSeedDev {
     u64* loop; u64 in_stride; u32 limit, n_instances;
     const u64* outer_store; u64 outer_n_store;
     const u32* state0_slot;   // [n carried] outer store slot behind the FIRST link of every carried word
+    u32 debug;                // timing experiments (ZKGL_FSM_SEED_DEBUG): 1 = no hashing, 2 = no walking
 };
 
 constexpr u32 EV_MAX = 8;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(128) void k_fsm_seed(FsmSeedDev a) {
         if (walker) {
             for (u32 w = lane; w < CARRIED; w += 64)
                 if (!is_chain(w)) col[(u64)w * a.in_stride] = F::get(S, w);
-            if (lane == 0 && c + 1 < a.limit) F::step(S, raw[c & 1], ev[c & 1]);
+            if (lane == 0 && c + 1 < a.limit && !(a.debug & 2)) F::step(S, raw[c & 1], ev[c & 1]);
         } else {
             u64 nxt[(RAW + 63) / 64];
             const bool more = c + 1 < a.limit;
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(128) void k_fsm_seed(FsmSeedDev a) {
                 nxt[k] = (more && w < RAW) ? col[1 + (u64)(CARRIED + w) * a.in_stride] : 0;
             }
             if (c) {   // the events of cycle c - 1, then the chain words of cycle c
-                run_events(chain, ev[(c - 1) & 1], lane, rcf);
+                if (!(a.debug & 1)) run_events(chain, ev[(c - 1) & 1], lane, rcf);
                 if (lane < 12) col[(u64)(F::MEM_TAIL + lane) * a.in_stride] = chain[lane];
                 else if (lane < 16) col[(u64)(F::REQ_HEAD + lane - 12) * a.in_stride] = chain[lane];
             }

@@ -68,11 +68,14 @@ struct Cursor {
         q.tx_number_in_block = u32(); q.timestamp = u32();
     }
     // CircuitQueueRawWitness<LogQuery, 4, 20>: u64 count, then (item, previous tail[4]) pairs; the tails are not consumed by the circuits
-    bool log_queue(zk_log_query_witness* buf, uint32_t cap, uint32_t& n_out, int& err) {
+    bool log_queue(zk_log_query_witness* buf, uint32_t cap, uint32_t& n_out, int& err, uint64_t (*tails)[4] = nullptr) {
         const uint64_t n = u64();
         if (!ok) return false;
         if (n > cap || (n && !buf)) { err = ZK_ERR_CAPACITY; return false; }
-        for (uint64_t i = 0; i < n && ok; ++i) { log_query(buf[i]); for (int t = 0; t < 4; ++t) field(); }
+        for (uint64_t i = 0; i < n && ok; ++i) {
+            log_query(buf[i]);
+            for (int t = 0; t < 4; ++t) { const uint64_t v = field(); if (tails) tails[i][t] = v; }   // the queue's tail before this element was pushed
+        }
         n_out = (uint32_t)n;
         return ok;
     }
@@ -240,15 +243,96 @@ int zk_pack_storage_witness(const zk_storage_validity_witness* w, uint32_t limit
     o.w(f.this_cell_has_explicit_read_and_rollback_depth_zero ? 1 : 0); o.arr(f.this_cell_base_value); o.arr(f.this_cell_current_value); o.w(f.this_cell_current_depth);
     if (o.k != ZK_STORAGE_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: storage outer layout");
     const size_t lanes = (size_t)batch * limit;
+    // With the previous tails: the integer carried state of every cycle, walked here (sort_and_deduplicate_storage_access_inner,
+    // mod.rs:508-880; initial selection :230-330 = circuits/storage_validity.cpp).  Left to the device: the grand-product accumulators
+    // (words 2..5: they need the Fiat-Shamir challenges) and, without output_tails, the final queue's tail (words 17..20).
+    const bool walk = w->unsorted_previous_tails && w->sorted_previous_tails;
+    const zk_log_query_witness zero_item{};
+    const bool start = w->start_flag != 0;
+    const zk_queue_state_witness& u0 = start ? w->unsorted_log_queue_state : f.current_unsorted_queue_state;
+    const zk_queue_state_witness& s0 = start ? w->intermediate_sorted_queue_state : f.current_intermediate_sorted_queue_state;
+    uint32_t u_len = u0.length, s_len = s0.length, f_len = start ? 0 : f.current_final_sorted_queue_state.length, popped = 0, pushed = 0;
+    uint64_t f_tail[4];
+    for (int i = 0; i < 4; ++i) f_tail[i] = start ? 0 : f.current_final_sorted_queue_state.tail[i];
+    uint32_t cycle_idx = start ? 0 : f.cycle_idx, prev_ts = f.previous_timestamp, depth = f.this_cell_current_depth;
+    uint32_t prev_packed[13], prev_key[8], prev_addr[5], base[8], cur[8];
+    for (int i = 0; i < 13; ++i) prev_packed[i] = start ? 0 : f.previous_packed_key[i];
+    std::memcpy(prev_key, f.previous_key, sizeof prev_key); std::memcpy(prev_addr, f.previous_address, sizeof prev_addr);
+    std::memcpy(base, f.this_cell_base_value, sizeof base); std::memcpy(cur, f.this_cell_current_value, sizeof cur);
+    bool has_read = f.this_cell_has_explicit_read_and_rollback_depth_zero != 0, prev_trivial = u0.length == 0 || start;
     for (uint32_t c = 0; c < limit; ++c) {
         Out l{loop_words + (size_t)instance * limit + c, lanes};
-        for (int i = 0; i < 67; ++i) l.w(0);
+        const zk_log_query_witness& rec = c < w->n_sorted ? w->intermediate_sorted_queue_witness[c].record : zero_item;
+        const uint32_t sts = c < w->n_sorted ? w->intermediate_sorted_queue_witness[c].timestamp : 0;
+        if (!walk) for (int i = 0; i < 67; ++i) l.w(0);
+        else {
+            l.w(c == 0 ? 1 : 0); l.w(prev_trivial ? 1 : 0);
+            for (int i = 0; i < 4; ++i) l.w(0);
+            l.w(cycle_idx);
+            for (int i = 0; i < 4; ++i) l.w(popped < w->n_unsorted ? w->unsorted_previous_tails[popped][i] : u0.tail[i]);
+            l.w(u_len);
+            for (int i = 0; i < 4; ++i) l.w(popped < w->n_sorted ? w->sorted_previous_tails[popped][i] : s0.tail[i]);
+            l.w(s_len);
+            for (int i = 0; i < 4; ++i) l.w(w->output_tails ? f_tail[i] : 0);
+            l.w(f_len);
+            l.arr(prev_packed); l.arr(prev_key); l.arr(prev_addr); l.w(prev_ts); l.w(has_read ? 1 : 0); l.arr(base); l.arr(cur); l.w(depth);
+            // ---- the cycle
+            cycle_idx += 1;
+            const bool should_pop = u_len != 0 && s_len != 0, trivial = !should_pop;
+            if (should_pop) { u_len -= 1; s_len -= 1; popped += 1; }
+            uint32_t packed[13];
+            std::memcpy(packed, rec.key, 32); std::memcpy(packed + 8, rec.address, 20);
+            const bool keys_equal = std::memcmp(packed, prev_packed, sizeof packed) == 0;
+            const bool unchanged = std::memcmp(cur, base, sizeof cur) == 0;
+            const bool issue_read = has_read || (unchanged && depth != 0), should_write = !unchanged;
+            if (!prev_trivial && !keys_equal && (issue_read || should_write)) {
+                if (w->output_tails) {
+                    if (pushed >= w->n_output_tails) return bad(ZK_ERR_INVALID, "zk_pack_storage_witness: fewer output tails than the instance pushes");
+                    for (int i = 0; i < 4; ++i) f_tail[i] = w->output_tails[pushed][i];
+                }
+                pushed += 1; f_len += 1;
+            }
+            const bool new_cell = !trivial && !keys_equal, same_cell = !trivial && keys_equal, rw = rec.rw_flag != 0, rb = rec.rollback != 0;
+            if (new_cell) {
+                std::memcpy(base, rec.read_value, sizeof base);
+                std::memcpy(cur, rw ? rec.written_value : rec.read_value, sizeof cur);
+                depth = rw ? 1 : 0; has_read = !rw;
+            }
+            const bool read_same = same_cell && !rw, w_norb = same_cell && rw && !rb, w_rb = same_cell && rw && rb;
+            if (w_norb) { depth += 1; std::memcpy(cur, rec.written_value, sizeof cur); }
+            if (w_rb) { depth -= 1; std::memcpy(cur, rec.read_value, sizeof cur); }
+            if (depth == 0 && read_same) { std::memcpy(base, rec.read_value, sizeof base); has_read = true; }
+            std::memcpy(prev_addr, rec.address, sizeof prev_addr); std::memcpy(prev_key, rec.key, sizeof prev_key);
+            std::memcpy(prev_packed, packed, sizeof packed);
+            prev_trivial = trivial; prev_ts = sts;
+        }
         l.log_query(c < w->n_unsorted ? &w->unsorted_queue_witness[c] : nullptr);
         if (c < w->n_sorted) { l.log_query(&w->intermediate_sorted_queue_witness[c].record); l.w(w->intermediate_sorted_queue_witness[c].timestamp); }
         else { l.log_query(nullptr); l.w(0); }
         if (l.k != ZK_STORAGE_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: storage loop layout");
     }
     return ZK_OK;
+}
+
+uint32_t zk_storage_given_words(const zk_storage_validity_witness* w, uint32_t words[67]) {
+    if (!w || !words || !w->unsorted_previous_tails || !w->sorted_previous_tails) return 0;
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < 67; ++i) {
+        if (i >= 2 && i < 6) continue;                          // lhs / rhs accumulators
+        if (i >= 17 && i < 21 && !w->output_tails) continue;    // final queue tail
+        words[n++] = i;
+    }
+    return n;
+}
+uint32_t zk_log_sorter_given_words(const zk_log_sorter_witness* w, uint32_t words[57]) {
+    if (!w || !words || !w->initial_previous_tails || !w->sorted_previous_tails) return 0;
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < 57; ++i) {
+        if (i >= 1 && i < 5) continue;
+        if (i >= 15 && i < 19 && !w->output_tails) continue;
+        words[n++] = i;
+    }
+    return n;
 }
 
 int zk_pack_log_sorter_witness(const zk_log_sorter_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
@@ -265,9 +349,44 @@ int zk_pack_log_sorter_witness(const zk_log_sorter_witness* w, uint32_t limit, u
     o.w(f.previous_key); o.log_query(&f.previous_item);
     if (o.k != ZK_LOG_SORTER_OUTER_WORDS) return bad(ZK_ERR_INVALID, "internal: log_sorter outer layout");
     const size_t lanes = (size_t)batch * limit;
+    // with the previous tails: the integer carried state (repack_and_prove_events_rollbacks_inner, mod.rs:246-441), as in zk_pack_storage_witness
+    const bool walk = w->initial_previous_tails && w->sorted_previous_tails;
+    const zk_log_query_witness zero_item{};
+    const bool start = w->start_flag != 0;
+    const zk_queue_state_witness& u0 = start ? w->initial_log_queue_state : f.initial_unsorted_queue_state;
+    const zk_queue_state_witness& s0 = start ? w->intermediate_sorted_queue_state : f.intermediate_sorted_queue_state;
+    uint32_t u_len = u0.length, s_len = s0.length, r_len = start ? 0 : f.final_result_queue_state.length, popped = 0, pushed = 0;
+    uint64_t r_tail[4];
+    for (int i = 0; i < 4; ++i) r_tail[i] = start ? 0 : f.final_result_queue_state.tail[i];
+    uint32_t prev_key = start ? 0 : f.previous_key;
+    zk_log_query_witness prev_item = start ? zero_item : f.previous_item;
+    bool prev_trivial = u0.length == 0 || start;
     for (uint32_t c = 0; c < limit; ++c) {
         Out l{loop_words + (size_t)instance * limit + c, lanes};
-        for (int i = 0; i < 57; ++i) l.w(0);
+        if (!walk) for (int i = 0; i < 57; ++i) l.w(0);
+        else {
+            const zk_log_query_witness& sq = c < w->n_sorted ? w->intermediate_sorted_queue_witness[c] : zero_item;
+            l.w(prev_trivial ? 1 : 0);
+            for (int i = 0; i < 4; ++i) l.w(0);
+            for (int i = 0; i < 4; ++i) l.w(popped < w->n_initial ? w->initial_previous_tails[popped][i] : u0.tail[i]);
+            l.w(u_len);
+            for (int i = 0; i < 4; ++i) l.w(popped < w->n_sorted ? w->sorted_previous_tails[popped][i] : s0.tail[i]);
+            l.w(s_len);
+            for (int i = 0; i < 4; ++i) l.w(w->output_tails ? r_tail[i] : 0);
+            l.w(r_len);
+            l.w(prev_key); l.log_query(&prev_item);
+            const bool should_pop = u_len != 0, trivial = !should_pop;
+            if (should_pop) { u_len -= 1; s_len -= 1; popped += 1; }
+            const bool same_log = sq.timestamp == prev_key;
+            if (!prev_trivial && (!same_log || trivial) && !prev_item.rollback) {
+                if (w->output_tails) {
+                    if (pushed >= w->n_output_tails) return bad(ZK_ERR_INVALID, "zk_pack_log_sorter_witness: fewer output tails than the instance pushes");
+                    for (int i = 0; i < 4; ++i) r_tail[i] = w->output_tails[pushed][i];
+                }
+                pushed += 1; r_len += 1;
+            }
+            prev_trivial = trivial; prev_item = sq; prev_key = sq.timestamp;
+        }
         l.log_query(c < w->n_initial ? &w->initial_queue_witness[c] : nullptr);
         l.log_query(c < w->n_sorted ? &w->intermediate_sorted_queue_witness[c] : nullptr);
         if (l.k != ZK_LOG_SORTER_LOOP_WORDS) return bad(ZK_ERR_INVALID, "internal: log_sorter loop layout");
@@ -586,6 +705,11 @@ int finish(Cursor& c, int err, size_t* consumed, const char* what) {
 
 int zk_decode_storage_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_storage_validity_witness* out, zk_log_query_witness* unsorted_buf, uint32_t unsorted_cap,
                                       zk_timestamped_log_record_witness* sorted_buf, uint32_t sorted_cap, size_t* consumed) {
+    return zk_decode_storage_witness_bincode_tails(bytes, n_bytes, out, unsorted_buf, unsorted_cap, sorted_buf, sorted_cap, nullptr, nullptr, consumed);
+}
+int zk_decode_storage_witness_bincode_tails(const uint8_t* bytes, size_t n_bytes, zk_storage_validity_witness* out, zk_log_query_witness* unsorted_buf, uint32_t unsorted_cap,
+                                            zk_timestamped_log_record_witness* sorted_buf, uint32_t sorted_cap, uint64_t (*unsorted_tails)[4], uint64_t (*sorted_tails)[4],
+                                            size_t* consumed) {
     if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_storage_witness_bincode: null argument");
     Cursor c{bytes, n_bytes};
     std::memset(out, 0, sizeof *out);
@@ -595,13 +719,18 @@ int zk_decode_storage_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_s
     zk_queue_state_witness final_sorted;   // observable_output.final_sorted_queue_state: read, not needed by the packer
     c.queue_state4(final_sorted);
     storage_fsm(c, out->hidden_fsm_input); storage_fsm(c, out->hidden_fsm_output);
-    if (c.log_queue(unsorted_buf, unsorted_cap, out->n_unsorted, err)) {
+    if (c.log_queue(unsorted_buf, unsorted_cap, out->n_unsorted, err, unsorted_tails)) {
         out->unsorted_queue_witness = unsorted_buf;
+        out->unsorted_previous_tails = unsorted_tails;
         const uint64_t n = c.u64();   // CircuitQueueRawWitness<TimestampedStorageLogRecord, 4, ..>
         if (c.ok && (n > sorted_cap || (n && !sorted_buf))) err = ZK_ERR_CAPACITY;
         else {
-            for (uint64_t i = 0; i < n && c.ok; ++i) { c.log_query(sorted_buf[i].record); sorted_buf[i].timestamp = c.u32(); for (int t = 0; t < 4; ++t) c.field(); }
+            for (uint64_t i = 0; i < n && c.ok; ++i) {
+                c.log_query(sorted_buf[i].record); sorted_buf[i].timestamp = c.u32();
+                for (int t = 0; t < 4; ++t) { const uint64_t v = c.field(); if (sorted_tails) sorted_tails[i][t] = v; }
+            }
             out->intermediate_sorted_queue_witness = sorted_buf; out->n_sorted = (uint32_t)n;
+            out->sorted_previous_tails = sorted_tails;
         }
     }
     return finish(c, err, consumed, "zk_decode_storage_witness_bincode: truncated, malformed or longer than the caller's buffers");
@@ -609,6 +738,11 @@ int zk_decode_storage_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_s
 
 int zk_decode_log_sorter_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_log_sorter_witness* out, zk_log_query_witness* initial_buf, uint32_t initial_cap,
                                          zk_log_query_witness* sorted_buf, uint32_t sorted_cap, size_t* consumed) {
+    return zk_decode_log_sorter_witness_bincode_tails(bytes, n_bytes, out, initial_buf, initial_cap, sorted_buf, sorted_cap, nullptr, nullptr, consumed);
+}
+int zk_decode_log_sorter_witness_bincode_tails(const uint8_t* bytes, size_t n_bytes, zk_log_sorter_witness* out, zk_log_query_witness* initial_buf, uint32_t initial_cap,
+                                               zk_log_query_witness* sorted_buf, uint32_t sorted_cap, uint64_t (*initial_tails)[4], uint64_t (*sorted_tails)[4],
+                                               size_t* consumed) {
     if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_log_sorter_witness_bincode: null argument");
     Cursor c{bytes, n_bytes};
     std::memset(out, 0, sizeof *out);
@@ -618,9 +752,10 @@ int zk_decode_log_sorter_witness_bincode(const uint8_t* bytes, size_t n_bytes, z
     zk_queue_state_witness final_queue;   // observable_output.final_queue_state
     c.queue_state4(final_queue);
     log_sorter_fsm(c, out->hidden_fsm_input); log_sorter_fsm(c, out->hidden_fsm_output);
-    if (c.log_queue(initial_buf, initial_cap, out->n_initial, err)) {
+    if (c.log_queue(initial_buf, initial_cap, out->n_initial, err, initial_tails)) {
         out->initial_queue_witness = initial_buf;
-        if (c.log_queue(sorted_buf, sorted_cap, out->n_sorted, err)) out->intermediate_sorted_queue_witness = sorted_buf;
+        out->initial_previous_tails = initial_tails;
+        if (c.log_queue(sorted_buf, sorted_cap, out->n_sorted, err, sorted_tails)) { out->intermediate_sorted_queue_witness = sorted_buf; out->sorted_previous_tails = sorted_tails; }
     }
     return finish(c, err, consumed, "zk_decode_log_sorter_witness_bincode: truncated, malformed or longer than the caller's buffers");
 }

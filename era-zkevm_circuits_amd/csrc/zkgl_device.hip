@@ -544,11 +544,29 @@ int launch_ram_seed(const RamSeedArgs& v, void* stream) {
     return LAUNCH_CHECK("k_ram_seed");
 }
 
+int launch_logq_seed(const LogqSeedArgs& v, void* stream) {
+    if (v.n_instances == 0 || v.limit == 0) return 0;
+    zkq::LogqSeedDev a;
+    a.loop = v.loop; a.in_stride = v.in_stride; a.limit = v.limit; a.n_instances = v.n_instances;
+    a.outer_store = v.outer_store; a.outer_n_store = v.outer_n_store; a.state0_slot = v.state0_slot; a.ch_slot = v.ch_slot;
+    hipStream_t st = (hipStream_t)stream;
+    if (v.kind == 0) {
+        zkq::k_logq_seed<0><<<v.n_instances, zkq::LOGQ_TPB, 0, st>>>(a);
+        if (v.with_chain) zkq::k_tail4_chain<0><<<v.n_instances, 64, 0, st>>>(a);
+    } else if (v.kind == 1) {
+        zkq::k_logq_seed<1><<<v.n_instances, zkq::LOGQ_TPB, 0, st>>>(a);
+        if (v.with_chain) zkq::k_tail4_chain<1><<<v.n_instances, 64, 0, st>>>(a);
+    } else return -1;
+    return LAUNCH_CHECK("k_logq_seed");
+}
+
 int launch_fsm_seed(const FsmSeedArgs& v, void* stream) {
     if (v.n_instances == 0 || v.limit == 0) return 0;
     zkf::FsmSeedDev a;
     a.loop = v.loop; a.in_stride = v.in_stride; a.limit = v.limit; a.n_instances = v.n_instances;
     a.outer_store = v.outer_store; a.outer_n_store = v.outer_n_store; a.state0_slot = v.state0_slot;
+    const char* dbg = std::getenv("ZKGL_FSM_SEED_DEBUG");
+    a.debug = dbg ? (uint32_t)std::atoi(dbg) : 0;
     if (v.kind == 0) zkf::k_fsm_seed<zkf::Keccak><<<v.n_instances, 128, 0, (hipStream_t)stream>>>(a);
     else if (v.kind == 1) zkf::k_fsm_seed<zkf::Sha256><<<v.n_instances, 128, 0, (hipStream_t)stream>>>(a);
     else return -1;

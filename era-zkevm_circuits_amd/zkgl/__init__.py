@@ -211,7 +211,9 @@ class StorageValidityWitness(C.Structure):
                 ("unsorted_log_queue_state", QueueStateWitness), ("intermediate_sorted_queue_state", QueueStateWitness),
                 ("hidden_fsm_input", StorageFsmWitness), ("hidden_fsm_output", StorageFsmWitness),
                 ("unsorted_queue_witness", C.POINTER(LogQueryWitness)), ("n_unsorted", C.c_uint32),
-                ("intermediate_sorted_queue_witness", C.POINTER(TimestampedLogRecordWitness)), ("n_sorted", C.c_uint32)]
+                ("intermediate_sorted_queue_witness", C.POINTER(TimestampedLogRecordWitness)), ("n_sorted", C.c_uint32),
+                ("unsorted_previous_tails", C.POINTER(C.c_uint64 * 4)), ("sorted_previous_tails", C.POINTER(C.c_uint64 * 4)),
+                ("output_tails", C.POINTER(C.c_uint64 * 4)), ("n_output_tails", C.c_uint32)]
 
 
 class LogSorterFsmWitness(C.Structure):
@@ -224,7 +226,9 @@ class LogSorterWitness(C.Structure):
     _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("initial_log_queue_state", QueueStateWitness),
                 ("intermediate_sorted_queue_state", QueueStateWitness), ("hidden_fsm_input", LogSorterFsmWitness),
                 ("hidden_fsm_output", LogSorterFsmWitness), ("initial_queue_witness", C.POINTER(LogQueryWitness)), ("n_initial", C.c_uint32),
-                ("intermediate_sorted_queue_witness", C.POINTER(LogQueryWitness)), ("n_sorted", C.c_uint32)]
+                ("intermediate_sorted_queue_witness", C.POINTER(LogQueryWitness)), ("n_sorted", C.c_uint32),
+                ("initial_previous_tails", C.POINTER(C.c_uint64 * 4)), ("sorted_previous_tails", C.POINTER(C.c_uint64 * 4)),
+                ("output_tails", C.POINTER(C.c_uint64 * 4)), ("n_output_tails", C.c_uint32)]
 
 
 def _pack(fn, w, limit, instance, outer, loop, n_outer, n_loop):
@@ -387,15 +391,55 @@ def _decode_bincode(fn, w, data: bytes, bufs):
     return w, used.value
 
 
-def decode_storage_witness_bincode(data: bytes, max_elements: int):
-    """zk_decode_storage_witness_bincode -> (StorageValidityWitness, bytes consumed)"""
-    n = max(max_elements, 1)
-    return _decode_bincode(lib().zk_decode_storage_witness_bincode, StorageValidityWitness(), data, [(LogQueryWitness * n)(), (TimestampedLogRecordWitness * n)()])
+def _decode_bincode_tails(fn, w, data: bytes, bufs, tails):
+    used = C.c_size_t(0)
+    raw = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+    args = []
+    for arr in bufs:
+        args += [arr, len(arr)]
+    _check(fn(raw, C.c_size_t(len(data)), C.byref(w), *args, *tails, C.byref(used)))
+    w._keep = list(bufs) + list(tails)
+    return w, used.value
 
 
-def decode_log_sorter_witness_bincode(data: bytes, max_elements: int):
+def decode_storage_witness_bincode(data: bytes, max_elements: int, keep_tails: bool = False):
+    """zk_decode_storage_witness_bincode[_tails] -> (StorageValidityWitness, bytes consumed); keep_tails: the previous tail of every queue
+    element is kept and zk_pack_storage_witness then walks the integer carried state (see storage_given_words)"""
     n = max(max_elements, 1)
-    return _decode_bincode(lib().zk_decode_log_sorter_witness_bincode, LogSorterWitness(), data, [(LogQueryWitness * n)(), (LogQueryWitness * n)()])
+    bufs = [(LogQueryWitness * n)(), (TimestampedLogRecordWitness * n)()]
+    if keep_tails:
+        return _decode_bincode_tails(lib().zk_decode_storage_witness_bincode_tails, StorageValidityWitness(), data, bufs, [((C.c_uint64 * 4) * n)(), ((C.c_uint64 * 4) * n)()])
+    return _decode_bincode(lib().zk_decode_storage_witness_bincode, StorageValidityWitness(), data, bufs)
+
+
+def decode_log_sorter_witness_bincode(data: bytes, max_elements: int, keep_tails: bool = False):
+    n = max(max_elements, 1)
+    bufs = [(LogQueryWitness * n)(), (LogQueryWitness * n)()]
+    if keep_tails:
+        return _decode_bincode_tails(lib().zk_decode_log_sorter_witness_bincode_tails, LogSorterWitness(), data, bufs, [((C.c_uint64 * 4) * n)(), ((C.c_uint64 * 4) * n)()])
+    return _decode_bincode(lib().zk_decode_log_sorter_witness_bincode, LogSorterWitness(), data, bufs)
+
+
+def set_output_tails(w, tails):
+    """attach the output queue's tail after each push (host-simulated) to a Storage / LogSorter witness"""
+    arr = ((C.c_uint64 * 4) * max(len(tails), 1))()
+    for a, t in zip(arr, tails):
+        a[:] = [int(x) for x in t]
+    w.output_tails = C.cast(arr, C.POINTER(C.c_uint64 * 4))
+    w.n_output_tails = len(tails)
+    w._keep_out = arr
+
+
+def storage_given_words(w):
+    arr = (C.c_uint32 * 67)()
+    n = lib().zk_storage_given_words(C.byref(w), arr)
+    return [int(arr[i]) for i in range(n)]
+
+
+def log_sorter_given_words(w):
+    arr = (C.c_uint32 * 57)()
+    n = lib().zk_log_sorter_given_words(C.byref(w), arr)
+    return [int(arr[i]) for i in range(n)]
 
 
 def decode_demux_witness_bincode(data: bytes, max_elements: int):

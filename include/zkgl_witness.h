@@ -121,6 +121,14 @@ typedef struct zk_storage_validity_witness {
     zk_storage_fsm_witness hidden_fsm_input, hidden_fsm_output;
     const zk_log_query_witness *unsorted_queue_witness; uint32_t n_unsorted;
     const zk_timestamped_log_record_witness *intermediate_sorted_queue_witness; uint32_t n_sorted;
+    /* Optional (NULL / 0: absent).  The previous tail of every queue element, as the CircuitQueueRawWitness elements carry them
+     * (item, previous_tail): with BOTH present zk_pack_storage_witness also writes the integer carried state of every cycle
+     * (everything but the four grand-product accumulators and the output queue's tail) and the device seeds without a chain
+     * over the input queues.  output_tails[j] = tail of the final sorted queue after its (j + 1)-th push in this instance (known
+     * to a host that simulates the queue, e.g. from the next circuit's input witness): with it the output chain is skipped too. */
+    const uint64_t (*unsorted_previous_tails)[4];
+    const uint64_t (*sorted_previous_tails)[4];
+    const uint64_t (*output_tails)[4]; uint32_t n_output_tails;
 } zk_storage_validity_witness;
 #define ZK_STORAGE_OUTER_WORDS 97
 #define ZK_STORAGE_LOOP_WORDS 140
@@ -129,6 +137,9 @@ typedef struct zk_storage_validity_witness {
  * and TimestampedStorageLogRecord (37 words) per cycle, zero items past the queue length */
 int zk_pack_storage_witness(const zk_storage_validity_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                             uint64_t *outer_words, uint64_t *loop_words);
+/* the loop-carried words (of the 67) a witness with previous tails makes the packer fill — pass them to zk_cs_set_seed_given;
+ * returns their count (0 without previous tails: the device seeds everything through the recorded cone) */
+uint32_t zk_storage_given_words(const zk_storage_validity_witness *w, uint32_t words[67]);
 
 /* EventsDeduplicatorInstanceWitness, /root/reference/src/log_sorter/input.rs:101-106 (FSM :28-36, input data :57-60) */
 typedef struct zk_log_sorter_fsm_witness {
@@ -143,6 +154,10 @@ typedef struct zk_log_sorter_witness {
     zk_log_sorter_fsm_witness hidden_fsm_input, hidden_fsm_output;
     const zk_log_query_witness *initial_queue_witness; uint32_t n_initial;
     const zk_log_query_witness *intermediate_sorted_queue_witness; uint32_t n_sorted;
+    /* optional, as in zk_storage_validity_witness; output_tails = the result queue's tail after each of its pushes */
+    const uint64_t (*initial_previous_tails)[4];
+    const uint64_t (*sorted_previous_tails)[4];
+    const uint64_t (*output_tails)[4]; uint32_t n_output_tails;
 } zk_log_sorter_witness;
 #define ZK_LOG_SORTER_OUTER_WORDS 87
 #define ZK_LOG_SORTER_LOOP_WORDS 129
@@ -150,6 +165,7 @@ typedef struct zk_log_sorter_witness {
  * loop_words[129][batch * limit]; 57 carried words zeroed, two LogQuery items (36 words each) per cycle */
 int zk_pack_log_sorter_witness(const zk_log_sorter_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                                uint64_t *outer_words, uint64_t *loop_words);
+uint32_t zk_log_sorter_given_words(const zk_log_sorter_witness *w, uint32_t words[57]);
 
 /* EIP4844CircuitInstanceWitness, /root/reference/src/eip_4844/input.rs:61-66: versioned_hash, linear_hash_output, data_chunks
  * (BlobChunkWitness = 31 bytes, :31-33); the closed-form input has no observable input and no FSM state to pack */
@@ -329,6 +345,15 @@ int zk_decode_storage_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_s
 int zk_decode_log_sorter_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_log_sorter_witness *out,
                                          zk_log_query_witness *initial_buf, uint32_t initial_cap,
                                          zk_log_query_witness *sorted_buf, uint32_t sorted_cap, size_t *consumed);
+/* the same two decoders keeping the previous tails (caller-owned [cap][4] arrays) */
+int zk_decode_storage_witness_bincode_tails(const uint8_t *bytes, size_t n_bytes, zk_storage_validity_witness *out,
+                                            zk_log_query_witness *unsorted_buf, uint32_t unsorted_cap,
+                                            zk_timestamped_log_record_witness *sorted_buf, uint32_t sorted_cap,
+                                            uint64_t (*unsorted_tails)[4], uint64_t (*sorted_tails)[4], size_t *consumed);
+int zk_decode_log_sorter_witness_bincode_tails(const uint8_t *bytes, size_t n_bytes, zk_log_sorter_witness *out,
+                                               zk_log_query_witness *initial_buf, uint32_t initial_cap,
+                                               zk_log_query_witness *sorted_buf, uint32_t sorted_cap,
+                                               uint64_t (*initial_tails)[4], uint64_t (*sorted_tails)[4], size_t *consumed);
 int zk_decode_demux_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_demux_log_queue_witness *out,
                                     zk_log_query_witness *initial_buf, uint32_t initial_cap, size_t *consumed);
 int zk_decode_linear_hasher_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_linear_hasher_witness *out,

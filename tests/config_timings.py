@@ -21,8 +21,9 @@ def timed(name, cs, outer, loop, batch, seed_carried=1, given=()):
     carried = cs.carried_words()
     raw = loop.copy()
     raw[[w for w in carried if w not in given], :] = 0
+    cs.set_seed_given(list(given))
     if given:
-        cs.set_seed_given(list(given))                    # words the host packer fills (ram: the queue heads = the witness's previous tails)
+        pass                    # words the host packer fills (ram: the queue heads = the witness's previous tails)
     d_o, d_l = zkgl.DeviceBuffer.from_numpy(outer), zkgl.DeviceBuffer.from_numpy(raw)
     cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
     t_seed, seeded_ok = None, None
@@ -79,6 +80,9 @@ if want("C4s"):
     inst = sn.instance(u, s, limit)
     outer, loop = sn.pack_streams([inst] * 4, limit)
     timed("C4 storage_validity 2^22 rows", cs, outer, loop, 4)
+    g = [w for w in range(67) if not 2 <= w < 6]
+    timed("C4 storage_validity 2^22 rows, integer state walked by the packer (previous tails), output chain on the device", cs, outer, loop, 4, given=[w for w in g if not 17 <= w < 21])
+    timed("C4 storage_validity 2^22 rows, integer state walked by the packer, output tails from the host", cs, outer, loop, 4, given=g)
     o1, l1 = sn.pack_streams([inst], limit)
     timed("C4 storage_validity 2^22 rows, ONE instance (one GPU of BASELINE's 4)", cs, o1, l1, 1)
 if want("C4l"):
@@ -87,6 +91,9 @@ if want("C4l"):
     inst = ln.instance(u, s, limit)
     outer, loop = ln.pack_streams([inst] * 4, limit)
     timed("C4 log_sorter 2^22 rows", cs, outer, loop, 4)
+    g = [w for w in range(57) if not 1 <= w < 5]
+    timed("C4 log_sorter 2^22 rows, integer state walked by the packer (previous tails), output chain on the device", cs, outer, loop, 4, given=[w for w in g if not 15 <= w < 19])
+    timed("C4 log_sorter 2^22 rows, integer state walked by the packer, output tails from the host", cs, outer, loop, 4, given=g)
     o1, l1 = ln.pack_streams([inst], limit)
     timed("C4 log_sorter 2^22 rows, ONE instance", cs, o1, l1, 1)
 # C5: 8 blobs (BASELINE: one per GPU)
