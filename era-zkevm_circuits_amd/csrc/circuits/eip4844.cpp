@@ -85,6 +85,8 @@ void eip_4844_entry_point(CS& cs, uint32_t n_chunks) {
     zk_var outer_zero = g.zero();
 
     // =========================== loop: Keccak block t + cpi Horner steps (mod.rs:186-205, 207) ===========================
+    cs.native_seed_kind = 7;  // the sponge and the Horner recurrence have a native kernel (kernels_fsm_seed.hpp)
+    cs.native_seed_param = n_chunks;
     cs.loop_begin(n_blocks);
     K k(g);
     NNField fr(g, BLS_FR);

@@ -2276,6 +2276,17 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
         dev_check(zkdev::launch_ram_seed(a, stream));
         return true;
     }
+    if (native_seed_kind == 7) {   // eip_4844: native_seed_param = n_chunks; every carried word starts at zero (circuits/eip4844.cpp)
+        const uint32_t n_chunks = native_seed_param;
+        if (carries_store_.size() != 217 || loop_.n_input_words < 217 + 136 + 31 || (loop_.n_input_words - 217 - 136) % 31 || outer_.n_input_words != 64) return false;
+        const uint32_t cpi = (loop_.n_input_words - 217 - 136) / 31;
+        if (cpi > 8 || (uint64_t)cpi * limit_ < n_chunks) return false;
+        zkdev::EipSeedArgs a;
+        a.loop = dev_loop_inputs_rw; a.in_stride = la.in_stride; a.limit = limit_; a.n_instances = n; a.n_chunks = n_chunks; a.cpi = cpi;
+        a.outer_inputs = oa.inputs; a.outer_in_stride = oa.in_stride;
+        dev_check(zkdev::launch_eip4844_seed(a, stream));
+        return true;
+    }
     if (native_seed_kind == 5 || native_seed_kind == 6) {   // storage_validity / log_sorter: the host packer walked the integer state
         const bool storage = native_seed_kind == 5;
         const uint32_t n_carried = storage ? 67 : 57, acc = storage ? 2 : 1, tail = storage ? 17 : 15;

@@ -86,6 +86,11 @@ struct FsmSeedArgs {
     const uint64_t* outer_store; uint64_t outer_n_store; const uint32_t* state0_slot;
 };
 int launch_fsm_seed(const FsmSeedArgs& a, void* stream);
+// eip_4844 seeding (kernels_fsm_seed.hpp: sponge lane + Horner lane per instance).  Mirrors zkf::EipSeedDev.
+struct EipSeedArgs {
+    uint64_t* loop; uint64_t in_stride; uint32_t limit, n_instances, n_chunks, cpi; const uint64_t* outer_inputs; uint64_t outer_in_stride;
+};
+int launch_eip4844_seed(const EipSeedArgs& a, void* stream);
 // the LogQuery sorters with the integer state given by the host packer (kernels_queue_seed.hpp): kind 0 storage_validity, 1 log_sorter;
 // with_chain: the output queue's tail is not given and is hashed here.  Mirrors zkq::LogqSeedDev.
 struct LogqSeedArgs {

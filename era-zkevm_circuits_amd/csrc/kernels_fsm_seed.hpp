@@ -113,6 +113,38 @@ __device__ __forceinline__ void keccak_f(u64 (&A)[25]) {
     }
 }
 
+// Keccak-f[1600] on 25 lanes of one wavefront (lane = x + 5y holds A[x + 5y]), the cross-lane steps through LDS: a third of the single
+// lane's latency (14 k instructions there).  sh: 25 + 5 + 25 words of this wavefront's own.  Wavefront-scope fences order the LDS
+// traffic (one wavefront's DS instructions execute in order).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ u64 keccak_f_lanes(u64 a, u32 lane, u64* sh) {
+    constexpr int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    u64* const shA = sh, * const shC = sh + 25, * const shB = sh + 30;
+    const bool live = lane < 25;
+    const u32 l = live ? lane : 0, x = l % 5, y = l / 5;
+    u32 rot = 0;
+#pragma unroll
+    for (int i = 1; i < 25; ++i) rot = l == (u32)i ? (u32)ROT[i] : rot;
+    const u32 dest = y + 5 * ((2 * x + 3 * y) % 5);           // rho + pi: B[y, 2x + 3y] = rot(A[x, y])
+    const u32 row = 5 * y;
+#pragma unroll 1
+    for (int r = 0; r < 24; ++r) {
+        if (live) shA[l] = a;
+        wave_sync();
+        if (lane < 5) shC[lane] = shA[lane] ^ shA[lane + 5] ^ shA[lane + 10] ^ shA[lane + 15] ^ shA[lane + 20];
+        wave_sync();
+        const u64 c1 = shC[(x + 1) % 5];
+        a ^= shC[(x + 4) % 5] ^ ((c1 << 1) | (c1 >> 63));
+        const u64 rr = rot ? ((a << rot) | (a >> (64 - rot))) : a;
+        if (live) shB[dest] = rr;
+        wave_sync();
+        a = shB[row + x] ^ (~shB[row + (x + 1) % 5] & shB[row + (x + 2) % 5]);
+        if (lane == 0) a ^= KECCAK_RC[r];
+        wave_sync();
+    }
+    return a;
+}
+
 __constant__ const u32 SHA_K[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
     0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
@@ -400,6 +432,146 @@ __global__ __launch_bounds__(128) void k_fsm_seed(FsmSeedDev a) {
                 const u32 w = lane + 64 * k;
                 if (w < RAW) raw[(c + 1) & 1][w] = nxt[k];
             }
+        }
+        __syncthreads();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ eip_4844
+// eip_4844_entry_point (reference src/eip_4844/mod.rs:107-260; circuits/eip4844.cpp): iteration t absorbs Keccak block t of the blob
+// and performs `cpi` Horner steps of the opening y = sum chunk_i z^(n-1-i) in the BLS12-381 scalar field.  Carried: the sponge (200
+// bytes), the opening (16 limbs of 16 bits, lazily added before each reduction), the counter.  The two recurrences are independent:
+// one lane of wavefront 0 runs the sponge, one lane of wavefront 1 the Horner steps (Montgomery products on 9 limbs of 32 bits,
+// R = 2^288, so the lazily added operand < 2^257 needs no reduction first); every GROUP cycles all 128 threads flush the snapshots
+// and stage the next group's bytes.  z = the last 16 bytes of keccak256(linear_hash || versioned_hash) (mod.rs:156-175), recomputed here.
+struct EipSeedDev {
+    u64* loop; u64 in_stride; u32 limit, n_instances, n_chunks, cpi;
+    const u64* outer_inputs; u64 outer_in_stride;   // versioned_hash[32] | linear_hash_output[32], one byte per word
+};
+namespace bls {
+constexpr u32 NL = 9;
+__constant__ const u32 R_MOD[NL] = {0x00000001, 0xffffffff, 0xfffe5bfe, 0x53bda402, 0x09a1d805, 0x3339d808, 0x299d7d48, 0x73eda753, 0};
+__constant__ const u32 R2[NL] = {0xbba87a71, 0x344171c0, 0xdf7ed1ca, 0x3c0538d1, 0x7ed9fe9f, 0x4aa18ade, 0x0b4094fb, 0x63643e57, 0};   // 2^576 mod r
+constexpr u32 NPRIME = 0xffffffffu;   // -r^-1 mod 2^32
+// a * b * 2^-288 mod r, fully reduced; a * b < r * 2^288 (CIOS)
+__device__ __forceinline__ void mont_mul(u32 (&out)[NL], const u32 (&a)[NL], const u32 (&b)[NL]) {
+    u32 t[NL + 2];
+#pragma unroll
+    for (u32 i = 0; i < NL + 2; ++i) t[i] = 0;
+#pragma unroll
+    for (u32 i = 0; i < NL; ++i) {
+        u64 c = 0;
+#pragma unroll
+        for (u32 j = 0; j < NL; ++j) { c += (u64)a[j] * b[i] + t[j]; t[j] = (u32)c; c >>= 32; }
+        c += t[NL]; t[NL] = (u32)c; t[NL + 1] = (u32)(c >> 32);
+        const u32 m = t[0] * NPRIME;
+        c = ((u64)m * R_MOD[0] + t[0]) >> 32;
+#pragma unroll
+        for (u32 j = 1; j < NL; ++j) { c += (u64)m * R_MOD[j] + t[j]; t[j - 1] = (u32)c; c >>= 32; }
+        c += t[NL]; t[NL - 1] = (u32)c;
+        t[NL] = t[NL + 1] + (u32)(c >> 32);
+    }
+    // t < 2 r: one conditional subtraction
+    u32 d[NL];
+    u64 br = 0;
+#pragma unroll
+    for (u32 j = 0; j < NL; ++j) { const u64 x = (u64)t[j] - R_MOD[j] - br; d[j] = (u32)x; br = (x >> 32) & 1; }
+    const bool ge = t[NL] != 0 || br == 0;
+#pragma unroll
+    for (u32 j = 0; j < NL; ++j) out[j] = ge ? d[j] : t[j];
+}
+}  // namespace bls
+
+constexpr u32 EIP_GROUP = 16, EIP_MAX_CPI = 8;
+__global__ __launch_bounds__(128) void k_eip4844_seed(EipSeedDev a) {
+    constexpr u32 RATE = 136, CHUNK = 31, CARRIED = 217;
+    __shared__ u64 snapA[EIP_GROUP][25];
+    __shared__ u32 snapO[EIP_GROUP][16];
+    __shared__ alignas(8) unsigned char blk[EIP_GROUP][RATE];
+    __shared__ unsigned char chk[EIP_GROUP][CHUNK * EIP_MAX_CPI];
+    __shared__ u32 zR[bls::NL];
+    __shared__ u64 ksh[2][55];
+    const u32 inst = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const bool sponge = tid < 64;
+    u64* const col0 = a.loop + (u64)inst * a.limit;
+    const u32 chunk_bytes = CHUNK * a.cpi;
+    u64 A = 0;            // wavefront 0: lane x + 5y holds sponge lane (x, y)
+    u32 opening[16];      // wavefront 1, lane 0
+#pragma unroll
+    for (int i = 0; i < 16; ++i) opening[i] = 0;
+    if (!sponge) {        // z = the last 16 bytes of keccak256(linear_hash || versioned_hash), then z * R mod r
+        u64 Z = 0;
+        if (lane < 8) {
+            for (u32 k = 0; k < 8; ++k) {
+                const u32 j = 8 * lane + k;
+                Z |= (a.outer_inputs[(u64)(j < 32 ? 32 + j : j - 32) * a.outer_in_stride + inst] & 0xff) << (8 * k);
+            }
+        }
+        if (lane == 8) Z = 0x01;
+        if (lane == 16) Z = 0x80ULL << 56;
+        Z = keccak_f_lanes(Z, lane, ksh[1]);
+        if (lane < 4) ksh[1][lane] = Z;
+        wave_sync();
+        if (lane == 0) {
+            u32 z[bls::NL], r2[bls::NL], out[bls::NL];
+#pragma unroll
+            for (u32 i = 0; i < bls::NL; ++i) { z[i] = 0; r2[i] = bls::R2[i]; }
+            for (u32 j = 0; j < 16; ++j) {   // digest bytes 16..31 big-endian: byte 31 is the least significant
+                const u32 byte = (u32)(ksh[1][(31 - j) / 8] >> (8 * ((31 - j) % 8))) & 0xff;
+                z[j / 4] |= byte << (8 * (j % 4));
+            }
+            bls::mont_mul(out, z, r2);
+            for (u32 i = 0; i < bls::NL; ++i) zR[i] = out[i];
+        }
+    }
+    for (u32 g0 = 0; g0 < a.limit; g0 += EIP_GROUP) {
+        const u32 gn = min(EIP_GROUP, a.limit - g0);
+        // ---- stage the group's bytes (consecutive threads: consecutive cycles)
+        for (u32 i = tid; i < gn * RATE; i += 128) blk[i % gn][i / gn] = (unsigned char)col0[g0 + i % gn + (u64)(CARRIED + i / gn) * a.in_stride];
+        for (u32 i = tid; i < gn * chunk_bytes; i += 128) chk[i % gn][i / gn] = (unsigned char)col0[g0 + i % gn + (u64)(CARRIED + RATE + i / gn) * a.in_stride];
+        __syncthreads();
+        if (sponge) {
+            for (u32 k = 0; k < gn; ++k) {
+                if (lane < 25) snapA[k][lane] = A;
+                if (lane < 17) A ^= ((const u64*)blk[k])[lane];
+                A = keccak_f_lanes(A, lane, ksh[0]);   // the last block's padding only matters after the last cycle
+            }
+        } else if (lane == 0) {
+            u32 zr[bls::NL];
+#pragma unroll
+            for (u32 i = 0; i < bls::NL; ++i) zr[i] = zR[i];
+            for (u32 k = 0; k < gn; ++k) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) snapO[k][i] = opening[i];
+                for (u32 c = 0; c < a.cpi; ++c) {
+                    const u32 idx = a.cpi * (g0 + k) + c;
+                    if (idx >= a.n_chunks) break;
+                    const unsigned char* b = chk[k] + CHUNK * c;
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) opening[i] += (u32)b[2 * i] | ((u32)b[2 * i + 1] << 8);   // add_lazy: limb-wise, no carries
+                    opening[15] += b[30];
+                    if (idx + 1 == a.n_chunks) break;   // the last chunk is added without a multiplication (mod.rs:200-202)
+                    u32 v[bls::NL], out[bls::NL];
+                    u64 carry = 0;
+#pragma unroll
+                    for (u32 i = 0; i < 8; ++i) {
+                        carry += (u64)opening[2 * i] + ((u64)opening[2 * i + 1] << 16);
+                        v[i] = (u32)carry; carry >>= 32;
+                    }
+                    v[8] = (u32)carry;
+                    bls::mont_mul(out, v, zr);
+#pragma unroll
+                    for (u32 i = 0; i < 8; ++i) { opening[2 * i] = out[i] & 0xffff; opening[2 * i + 1] = out[i] >> 16; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the carried words of the group's cycles
+        for (u32 i = tid; i < gn * CARRIED; i += 128) {
+            const u32 k = i % gn, w = i / gn;
+            const u64 v = w < 200 ? ((const unsigned char*)snapA[k])[w] : w < 216 ? snapO[k][w - 200] : (u64)(g0 + k);
+            col0[g0 + k + (u64)w * a.in_stride] = v;
         }
         __syncthreads();
     }

@@ -560,6 +560,16 @@ int launch_logq_seed(const LogqSeedArgs& v, void* stream) {
     return LAUNCH_CHECK("k_logq_seed");
 }
 
+int launch_eip4844_seed(const EipSeedArgs& v, void* stream) {
+    if (v.n_instances == 0 || v.limit == 0) return 0;
+    if (v.cpi == 0 || v.cpi > zkf::EIP_MAX_CPI) return -1;
+    zkf::EipSeedDev a;
+    a.loop = v.loop; a.in_stride = v.in_stride; a.limit = v.limit; a.n_instances = v.n_instances; a.n_chunks = v.n_chunks; a.cpi = v.cpi;
+    a.outer_inputs = v.outer_inputs; a.outer_in_stride = v.outer_in_stride;
+    zkf::k_eip4844_seed<<<v.n_instances, 128, 0, (hipStream_t)stream>>>(a);
+    return LAUNCH_CHECK("k_eip4844_seed");
+}
+
 int launch_fsm_seed(const FsmSeedArgs& v, void* stream) {
     if (v.n_instances == 0 || v.limit == 0) return 0;
     zkf::FsmSeedDev a;

@@ -14,7 +14,7 @@ from oracle import keccak_native as kn, log_sorter_native as ln, ram_native as r
 zkgl.init(0)
 
 
-def timed(name, cs, outer, loop, batch, seed_carried=1, given=()):
+def timed(name, cs, outer, loop, batch, seed_carried=1, given=(), stream_x=0):
     """one configuration: seeding of the carried words from the raw stream (timed, compared with the native restatement's words), then
     one fused resolve_and_check (after a warm-up); from-raw rate = constraints / (seeding + step)"""
     cs.set_batch(batch)
@@ -34,6 +34,19 @@ def timed(name, cs, outer, loop, batch, seed_carried=1, given=()):
         t0 = time.perf_counter(); cs.seed_carried_inputs(d_l2); zkgl.sync(); t_seed = time.perf_counter() - t0
         seeded_ok = bool(np.array_equal(d_l2.to_numpy().reshape(loop.shape), loop))
         d_l = d_l2
+    t_stream = None
+    if stream_x and t_seed is not None:                   # one seeding pass over a stream of stream_x batches (the pass is latency-bound:
+        S = stream_x * batch                              # one workgroup per instance walks its cycles; more instances ride along for free)
+        limit = loop.shape[1] // batch
+        o_s = np.tile(outer, (1, stream_x))
+        l_s = np.tile(raw.reshape(raw.shape[0], batch, limit), (1, stream_x, 1)).reshape(raw.shape[0], S * limit)
+        d_os, d_ls = zkgl.DeviceBuffer.from_numpy(o_s), zkgl.DeviceBuffer.from_numpy(l_s)
+        cs.seed_stream(S, d_os, d_ls); zkgl.sync()
+        d_ls = zkgl.DeviceBuffer.from_numpy(l_s)
+        t0 = time.perf_counter(); cs.seed_stream(S, d_os, d_ls); zkgl.sync(); t_stream = time.perf_counter() - t0
+        got = d_ls.to_numpy().reshape(raw.shape[0], stream_x, batch * limit)
+        seeded_ok = seeded_ok and all(np.array_equal(got[:, k], loop) for k in range(stream_x))
+        del d_os, d_ls, got
     ok, f = cs.resolve_and_check(); assert ok or os.environ.get("ZKGL_STUB_RUN"), f
     t0 = time.perf_counter(); ok, f = cs.resolve_and_check(); dt = time.perf_counter() - t0
     st = cs.stats()
@@ -42,6 +55,8 @@ def timed(name, cs, outer, loop, batch, seed_carried=1, given=()):
                       "step_ms": round(1e3 * dt, 2), "constraints_per_s": round(total / dt), "rows_per_s": round(batch * st["rows_per_instance"] / dt),
                       "k_witness_loop_ms": round(cs.last_ms(1), 2), "carried_words": len(carried), "seed_s": None if t_seed is None else round(t_seed, 4),
                       "seeded_equals_native": seeded_ok,
+                      "seed_stream": None if t_stream is None else {"instances": stream_x * batch, "seed_s": round(t_stream, 4), "seed_s_per_step": round(t_stream / stream_x, 4),
+                                                                    "constraints_per_s_from_raw": round(total / (dt + t_stream / stream_x))},
                       "constraints_per_s_from_raw": None if t_seed is None else round(total / (dt + t_seed)),
                       "values_GBps_loop_kernel": round(batch * st["limit"] * st["cells_written_loop"] * 8 / (cs.last_ms(1) * 1e-3) / 1e9, 1) if cs.last_ms(1) > 0 else None}), flush=True)
 
@@ -64,7 +79,7 @@ if want("C3k"):
     inst = kn.instance(reqs, limit)
     B = 128
     outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
-    timed("C3 keccak256_round_function 2^20 rows", cs, outer, loop, B)
+    timed("C3 keccak256_round_function 2^20 rows", cs, outer, loop, B, stream_x=4)
 if want("C3s"):
     B = 128
     cs, limit = T.fit(lambda c: c.configure_sha256(), lambda c, l: c.sha256_round_function_entry_point(l), 20)
@@ -72,7 +87,7 @@ if want("C3s"):
     reqs = [shn.request(m, 1 + 2 * i, 10 + i, 0, 9000 + i, i) for i, m in enumerate(msgs)]
     inst = shn.instance(reqs, limit)
     outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
-    timed("C3 sha256_round_function 2^20 rows", cs, outer, loop, B)
+    timed("C3 sha256_round_function 2^20 rows", cs, outer, loop, B, stream_x=4)
 # C4 (4 instances on one GPU here; BASELINE shards them over 4 GPUs)
 if want("C4s"):
     cs, limit = T.fit(lambda c: c.configure_storage_validity(), lambda c, l: c.sort_and_deduplicate_storage_access_entry_point(l, True), 22)
@@ -106,4 +121,4 @@ if want("C5"):
         insts.append(en.instance(bytes(r.integers(0, 256, size=31 * 4096, dtype=np.uint8)), b"\x01" + bytes(r.integers(0, 256, size=31, dtype=np.uint8)), 4096))
     outer = np.array([i["outer"] for i in insts], dtype=np.uint64).T.copy()
     loop = np.array([r_ for i in insts for r_ in i["rows"]], dtype=np.uint64).T.copy()
-    timed("C5 eip_4844 8 blobs x 4096 chunks", cs, outer, loop, 8)
+    timed("C5 eip_4844 8 blobs x 4096 chunks", cs, outer, loop, 8, stream_x=8)

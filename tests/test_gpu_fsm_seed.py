@@ -80,3 +80,25 @@ def test_sha256_fsm_native_seeding(zk):
     _seed_both_ways(zk, cs, outer, loop, sn.CARRIED)
     for i, inst in enumerate(insts):
         assert cs.public_inputs(i) == inst["public_input"]
+
+
+@pytest.mark.parametrize("n_chunks", [27, 100, 9])
+def test_eip4844_native_seeding(zk, n_chunks):
+    """eip_4844: the sponge lane + the Horner lane (Montgomery products in the BLS12-381 scalar field) against the cone and the restatement"""
+    import zkgl
+    from oracle import eip4844_native as en
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
+    cs.configure_eip_4844()
+    cs.eip_4844_entry_point(n_chunks)
+    cs.pad_and_shrink()
+    rng = np.random.default_rng(4844 + n_chunks)
+    insts = []
+    for k in range(70):
+        blob = bytes(rng.integers(0, 256, size=31 * n_chunks, dtype=np.uint8)) if k % 5 else b"\xff" * (31 * n_chunks)
+        vh = b"\x01" + bytes(rng.integers(0, 256, size=31, dtype=np.uint8))
+        insts.append(en.instance(blob, vh, n_chunks))
+    outer = np.array([i["outer"] for i in insts], dtype=np.uint64).T.copy()
+    loop = np.array([r for i in insts for r in i["rows"]], dtype=np.uint64).T.copy()
+    _seed_both_ways(zk, cs, outer, loop, 217)
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
