@@ -101,37 +101,50 @@ struct DevEnv {
     __device__ void sponge_set(const u64 v[12]) { u64* p = sp_ev + (u64)n_sp * EV_SP; for (int i = 0; i < 12; ++i) p[i] = v[i]; p[SP_TYPE] = 2; ++n_sp; }
 };
 
-// ---- phase A: ONE wavefront per instance.  Lane 0 walks the VM (its state in LDS: registers are picked by dynamic index); all 64
-// lanes move the data: the next cycle's oracle words are fetched into LDS while lane 0 works on this one (no global load sits on the
-// cycle's dependency chain except the opcode-table row), and the 243 state words of a cycle leave as four coalesced-by-word stores
-// per lane instead of 203 stores of one lane.
+// ---- phase A: NI instances per wavefront (1, 2 or 4).  One lane per instance walks the VM (its state in LDS: registers are picked by
+// dynamic index); the 64 / NI lanes of its group move its data: the next cycle's oracle words are fetched into LDS while the walker
+// works on this one (no global load sits on the cycle's dependency chain except the opcode-table row), and the 243 state words of a
+// cycle leave as coalesced-by-word stores of the group instead of 203 stores of one lane.  A lone walking lane owns its SIMD's issue
+// slots: two walkers in one wavefront share every instruction both of them need (decode, operand fetch, flags, state update) and
+// serialise only where their opcodes differ.
+template <int NI>
 __global__ __launch_bounds__(64) void k_vm_walk(SeedDev a) {
-    __shared__ vmn::State st;
-    __shared__ vmn::Gctx gctx;
-    __shared__ u64 flat[256];
-    __shared__ u64 raw[2][RAW_MAX];
-    const u32 lane = threadIdx.x;
-    const u32 inst = blockIdx.x;
-    const u64 lane0 = (u64)inst * a.limit;
+    constexpr u32 G = 64 / NI;                      // lanes per instance
+    constexpr u32 RAW_PER_LANE = (RAW_MAX + G - 1) / G;
+    __shared__ vmn::State st_[NI];
+    __shared__ vmn::Gctx gctx_[NI];
+    __shared__ u64 flat_[NI][256];
+    __shared__ u64 raw_[NI][2][RAW_MAX];
+    const u32 lane = threadIdx.x, sub = lane / G, sl = lane % G;
+    const u32 inst = blockIdx.x * NI + sub;
+    const bool live = inst < a.n_instances;
+    const u64 lane0 = (u64)(live ? inst : 0) * a.limit;
+    vmn::State& st = st_[sub];
+    vmn::Gctx& gctx = gctx_[sub];
+    u64* const flat = flat_[sub];
     const u32 first_raw = vmn::STATE_WORDS, n_raw = a.n_loop_words - vmn::STATE_WORDS;
-    if (a.c0 == 0) {
-        // cycle 0 takes the outer scope's words verbatim (chain words included: they are snapshot 0 of every chain)
-        for (u32 w = lane; w < (u32)vmn::STATE_WORDS; w += 64) {
-            const u64 v = outer_value(a, inst, a.state0_slot[w]);
-            flat[w] = v;
-            a.loop[(u64)w * a.in_stride + lane0] = v;
+    if (live) {
+        if (a.c0 == 0) {
+            // cycle 0 takes the outer scope's words verbatim (chain words included: they are snapshot 0 of every chain)
+            for (u32 w = sl; w < (u32)vmn::STATE_WORDS; w += G) {
+                const u64 v = outer_value(a, inst, a.state0_slot[w]);
+                flat[w] = v;
+                a.loop[(u64)w * a.in_stride + lane0] = v;
+            }
+        } else {
+            for (u32 w = sl; w < SAVE_WORDS; w += G) ((u32*)&st)[w] = a.saved_state[(u64)inst * SAVE_WORDS + w];
         }
-    } else {
-        for (u32 w = lane; w < SAVE_WORDS; w += 64) ((u32*)&st)[w] = a.saved_state[(u64)inst * SAVE_WORDS + w];
     }
     for (u32 i = lane; i < TABLE_ROWS_LDS; i += 64) { g_props[i] = a.D.props[i]; g_prices[i] = a.D.prices[i]; }
-    auto fetch = [&](u32 c, u32 k) -> u64 { return k < n_raw ? a.loop[(u64)(first_raw + k) * a.in_stride + lane0 + c] : 0; };
-    raw[a.c0 & 1][lane] = fetch(a.c0, lane);
-    raw[a.c0 & 1][lane + 64] = fetch(a.c0, lane + 64);
+    auto fetch = [&](u32 c, u32 k) -> u64 { return (live && k < n_raw) ? a.loop[(u64)(first_raw + k) * a.in_stride + lane0 + c] : 0; };
+#pragma unroll
+    for (u32 r = 0; r < RAW_PER_LANE; ++r)
+        if (sl + G * r < RAW_MAX) raw_[sub][a.c0 & 1][sl + G * r] = fetch(a.c0, sl + G * r);
     __syncthreads();
     const vmn::Defs& D = a.D;  // kernel argument: its small fields are scalar loads
     DevEnv env;
-    if (lane == 0) {
+    const bool walker = sl == 0 && live;
+    if (walker) {
         gctx.zkporter_is_available = (u32)a.outer_inputs[(u64)a.w_zkporter * a.outer_in_stride + inst];
         for (int i = 0; i < 8; ++i) gctx.default_aa_code_hash.l[i] = (u32)a.outer_inputs[(u64)(a.w_default_aa + i) * a.outer_in_stride + inst];
         if (a.c0 == 0) vmn::state_unflatten(st, [&](int w) { return flat[w]; });
@@ -143,18 +156,20 @@ __global__ __launch_bounds__(64) void k_vm_walk(SeedDev a) {
         env.sp_ev = a.sp_ev + (u64)inst * a.cap_one * EV_SP;
     }
 #ifdef ZKGL_VM_WALK_PROFILE
+    static_assert(NI == 1 || NI == 2 || NI == 4, "");
     u64 t_walk = 0, t_flat = 0, t_io = 0, t_fam[16] = {0}, n_fam[16] = {0};
 #endif
     for (u32 c = a.c0; c < a.c1; ++c) {
         const bool more = c + 1 < a.limit, more_here = c + 1 < a.c1;
-        u64 p0 = 0, p1 = 0;
-        if (more_here) { p0 = fetch(c + 1, lane); p1 = fetch(c + 1, lane + 64); }
+        u64 p[RAW_PER_LANE];
+#pragma unroll
+        for (u32 r = 0; r < RAW_PER_LANE; ++r) p[r] = more_here ? fetch(c + 1, sl + G * r) : 0;
 #ifdef ZKGL_VM_WALK_PROFILE
         const u64 t0 = wall_clock64();
 #endif
-        if (lane == 0) {
+        if (walker) {
             a.counts[lane0 + c] = make_uint4(env.n_mem, env.n_dec, env.n_fwd, env.n_sp);
-            env.raw = raw[c & 1];
+            env.raw = raw_[sub][c & 1];
             vmn::vm_cycle(D, gctx, st, env);
 #ifdef ZKGL_VM_WALK_PROFILE
             const u64 t1 = wall_clock64();
@@ -166,11 +181,12 @@ __global__ __launch_bounds__(64) void k_vm_walk(SeedDev a) {
         const u64 t2 = wall_clock64();
 #endif
         __syncthreads();
-        if (more) {
+        if (more && live) {
             u64* const out = a.loop + lane0 + c + 1;
-            for (u32 w = lane; w < (u32)vmn::STATE_WORDS; w += 64) out[(u64)w * a.in_stride] = vmn::state_word(st, (int)w);  // chain words: phase C writes them
-            raw[(c + 1) & 1][lane] = p0;
-            raw[(c + 1) & 1][lane + 64] = p1;
+            for (u32 w = sl; w < (u32)vmn::STATE_WORDS; w += G) out[(u64)w * a.in_stride] = vmn::state_word(st, (int)w);  // chain words: phase C writes them
+#pragma unroll
+            for (u32 r = 0; r < RAW_PER_LANE; ++r)
+                if (sl + G * r < RAW_MAX) raw_[sub][(c + 1) & 1][sl + G * r] = p[r];
         }
         __syncthreads();
 #ifdef ZKGL_VM_WALK_PROFILE
@@ -178,19 +194,19 @@ __global__ __launch_bounds__(64) void k_vm_walk(SeedDev a) {
 #endif
     }
 #ifdef ZKGL_VM_WALK_PROFILE
-    if (lane == 0 && inst < 8) {   // 100 MHz constant clock: 10 ns units
+    if (walker && inst < 8) {   // 100 MHz constant clock: 10 ns units
         printf("[walk profile] inst %u: walk %llu flatten %llu io+sync %llu (x10ns) per family (count, x10ns):", inst, (unsigned long long)t_walk, (unsigned long long)t_flat, (unsigned long long)t_io);
         for (int f = 0; f < 16; ++f) printf(" %d:(%llu,%llu)", f, (unsigned long long)n_fam[f], (unsigned long long)t_fam[f]);
         printf("\n");
     }
 #endif
-    if (lane == 0) {
+    if (walker) {
         const uint4 t = make_uint4(env.n_mem, env.n_dec, env.n_fwd, env.n_sp);
         a.chunk_totals[(u64)a.chunk * a.n_instances + inst] = t;
         if (a.c1 == a.limit) a.totals[inst] = t;
     }
-    if (a.c1 < a.limit)
-        for (u32 w = lane; w < SAVE_WORDS; w += 64) a.saved_state[(u64)inst * SAVE_WORDS + w] = ((const u32*)&st)[w];
+    if (a.c1 < a.limit && live)
+        for (u32 w = sl; w < SAVE_WORDS; w += G) a.saved_state[(u64)inst * SAVE_WORDS + w] = ((const u32*)&st)[w];
 }
 
 // ---- phase B: 16-lane rows (one DPP row each), 12 lanes = the 12 state elements of one chain, lanes 12..15 hold zero.

@@ -492,12 +492,22 @@ int launch_vm_seed(const VmSeedArgs& v, void* stream, float* phase_ms) {
     if (const char* e = std::getenv("ZKGL_VM_SEED_CHUNKS")) chunks = (uint32_t)std::max(1, atoi(e));
     chunks = std::min<uint32_t>(std::min<uint32_t>(chunks, VM_SEED_MAX_CHUNKS), std::max<uint32_t>(1, v.limit / 64));
     if (phase_ms) chunks = 1;
+    // instances per walking wavefront: one walker lane per SIMD while the chip has room, then two or four share a wavefront
+    // (profiles/r3_summary.md §2: the pass is flat up to one wavefront per SIMD and linear beyond)
+    int ni = v.n_instances > 2048 ? 4 : v.n_instances > 1024 ? 2 : 1;
+    if (const char* e = std::getenv("ZKGL_VM_WALK_NI")) { const int x = atoi(e); if (x == 1 || x == 2 || x == 4) ni = x; }
+    auto walk = [&](hipStream_t s_) {
+        const unsigned grid = (v.n_instances + ni - 1) / ni;
+        if (ni == 1) zkvm::k_vm_walk<1><<<grid, 64, 0, s_>>>(a);
+        else if (ni == 2) zkvm::k_vm_walk<2><<<grid, 64, 0, s_>>>(a);
+        else zkvm::k_vm_walk<4><<<grid, 64, 0, s_>>>(a);
+    };
     if (chunks == 1) {
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
         if (phase_ms) for (auto& e : ev) if (int r = chk(hipEventCreate(&e), "hipEventCreate")) return r;
         if (phase_ms) hipEventRecord(ev[0], st);
         a.c0 = 0; a.c1 = v.limit; a.chunk = 0;
-        zkvm::k_vm_walk<<<v.n_instances, 64, 0, st>>>(a);
+        walk(st);
         if (int r = LAUNCH_CHECK("k_vm_walk")) return r;
         if (phase_ms) hipEventRecord(ev[1], st);
         zkvm::k_vm_chains<<<chain_grid, 256, 0, st>>>(a);
@@ -521,7 +531,7 @@ int launch_vm_seed(const VmSeedArgs& v, void* stream, float* phase_ms) {
         a.chunk = j;
         a.c0 = (uint32_t)((uint64_t)v.limit * j / chunks);
         a.c1 = (uint32_t)((uint64_t)v.limit * (j + 1) / chunks);
-        zkvm::k_vm_walk<<<v.n_instances, 64, 0, S.walk>>>(a);
+        walk(S.walk);
         if (int r = LAUNCH_CHECK("k_vm_walk")) return r;
         if (int r = chk(hipEventRecord(S.walked[j], S.walk), "hipEventRecord")) return r;
         if (int r = chk(hipStreamWaitEvent(S.chains, S.walked[j], 0), "hipStreamWaitEvent")) return r;
