@@ -631,8 +631,8 @@ void CS::build_check_program(Scope& s) {
     // exact inverse, constants) for every input whatsoever; SELECT's relation s (a - b) + b - r equals its op (r = s ? a : b) unless
     // s > 1 and a != b, which the witness kernels test on the operands they hold (kernels_engine2.hpp) and report like a macro packet.
     // So in the fused mode of resolve_and_check these gates are evaluated where their values are produced, and the check program
-    // keeps every OTHER gate — enforcements, booleans and range checks of inputs, integer add / multiply relations, relations whose
-    // output is a given variable — and every lookup.  Stored values (after write_cell / poke, or on request) are verified by the full
+    // keeps every OTHER gate — enforcements, booleans of inputs, integer add / multiply relations, relations whose output is a given
+    // variable.  Lookups: the op that looks the keys up reports a miss (below).  Stored values (after write_cell / poke, or on request) are verified by the full
     // programs as before.
     s.gate_mirrored.assign(s.gates.size(), 0);
     {
@@ -750,6 +750,9 @@ void CS::build_check_program(Scope& s) {
             const TableRec& t = tables_[lr.table - 1];
             const uint32_t tw = t.n_keys + t.n_vals;
             if (tw > 4 || t.n_keys > 3) { lookups_ok = false; return; }  // the row-descriptor checker handles such scopes
+            // fused: every lookup tuple is (the keys of a ZK_OP_LOOKUP, the fresh variables that op fills from the row it found) —
+            // CS::lookup records both together — so the tuple is a table row iff the op found its keys: the witness kernel reports a miss
+            if (mode == 2) continue;
             for (uint32_t u0 = 0; u0 < lr.n_tuples; u0 += 3) {
                 const uint32_t cnt = std::min(3u, lr.n_tuples - u0);
                 starts.push_back((uint32_t)prog.size());
@@ -2482,7 +2485,7 @@ zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool c
     a.cprog = compact ? (full ? s.d_cprog_full : s.d_cprog) : nullptr; a.chunk_tab = full ? s.d_cchunks_full : s.d_cchunks;
     a.n_chunks = full ? (uint32_t)s.cchunks_full.size() - 1 : (s.cchunks.empty() ? 0 : (uint32_t)s.cchunks.size() - 1);
     a.macros = (compact && !full) ? s.d_cmacros : nullptr; a.n_macros = (compact && !full) ? s.n_macro_p2 : 0;
-    if (fused && compact && s.d_cprog_fused) {   // the gates the witness kernels did not evaluate themselves + every lookup
+    if (fused && compact && s.d_cprog_fused) {   // the gates the witness kernels did not evaluate themselves
         a.cprog = s.d_cprog_fused; a.chunk_tab = s.d_cchunks_fused; a.n_chunks = (uint32_t)s.cchunks_fused.size() - 1;
         a.macros = nullptr; a.n_macros = 0;
     }

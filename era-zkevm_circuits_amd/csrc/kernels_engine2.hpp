@@ -148,6 +148,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     constexpr uint32_t D = STRANDS ? 1 : 0;  // destination words per op
     auto out_to = [&](uint32_t slot) { if constexpr (STRANDS) dst = WIDE ? slot : slot << 9; };
     uint32_t pc = word_begin;
+    bool fused_bad = false;   // fused mode: a gate evaluated here (SELECT's exception, a lookup miss) is violated; reported once, below
     while (pc < word_end) {
         const u32x16_a4 W = *(prog16_ptr)(prog + pc);  // s_load_dwordx16: header + up to 15 operand words (host pads the program)
         const uint32_t h = W[0];
@@ -233,12 +234,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 pc += 1 + N * 3 + D * N;
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N * 3 + g) & 15]); st(in[g][0] ? in[g][1] : in[g][2]); }
-                if (sc.fail) {   // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ
-                    bool bad = false;
+                // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ
 #pragma unroll
-                    for (uint32_t g = 0; g < N; ++g) bad |= in[g][0] > 1 && in[g][1] != in[g][2];
-                    if (bad && active) report_fused(sc.fail, lane);
-                }
+                for (uint32_t g = 0; g < N; ++g) fused_bad |= in[g][0] > 1 && in[g][1] != in[g][2];
             };
             switch (pb) {
             case 0: body(GroupSize<1>{}); break;
@@ -342,6 +340,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                             if (i < nv) st(val[g][i]);
                         mult_add(sc.mult, (size_t)inst * sc.total_table_rows + t.mult_off + row[g], ZKGL_MULT_ON && row[g] < t.n_rows && active && sc.mult);
                     }
+                    // fused mode: the tuple (keys, the values stored here) is a table row iff the keys were found
+#pragma unroll
+                    for (uint32_t g = 0; g < N; ++g) fused_bad |= row[g] >= t.n_rows;
                 };
                 switch (grp) {
                 case 1: body(GroupSize<1>{}); break;
@@ -363,6 +364,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                        : (t.dense & 2u) ? (uint64_t)tb[(size_t)row * t.n_vals + i]
                                         : sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i]);
                 mult_add(sc.mult, (size_t)inst * sc.total_table_rows + t.mult_off + row, ZKGL_MULT_ON && found && active && sc.mult);
+                fused_bad |= !found;
             }
         } break;
         case ZK_OP_POSEIDON2:      // witness-only permutation: 12 outputs
@@ -618,6 +620,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             return;  // malformed program: host validates before upload
         }
     }
+    if (sc.fail && fused_bad && active) report_fused(sc.fail, lane);
 }
 
 template <bool WITH_BIGINT, bool WIDE>
