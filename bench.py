@@ -305,10 +305,11 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    loop_ms, check_ms, gate_ms, outer_ms = [], [], [], []
+    loop_ms, check_ms, gate_ms, outer_ms, shader_mhz = [], [], [], [], []
     for _ in range(args.steps):
         step()
         loop_ms.append(cs.last_ms(1)); check_ms.append(cs.last_ms(2)); gate_ms.append(cs.last_ms(3)); outer_ms.append(cs.last_ms(4))
+        shader_mhz.append(cs.last_ms(8))
     fence()
     elapsed_local = time.perf_counter() - t0
     local = np.array([cs.public_inputs(i) for i in range(B)], dtype=np.uint64)
@@ -428,6 +429,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
                          "unit_of_work": "values (one per variable, 8 B): the variable store; trace cells are a view of it",
                          "avg_launch_ms": k_ms,
+                         # clock probe inside the kernel (s_memtime / s_memrealtime of its first wavefront): the kernel is ~2/3 VALU-busy
+                         # (profiles/r3_loop_probe.md), so its time follows the clock the power management grants the launch
+                         "shader_clock_mhz": float(np.mean(shader_mhz)),
                          "values_written_per_cycle": st["cells_written_loop"], "trace_cells_populated_per_cycle": st["cells_populated_loop"],
                          "trace_cell_equivalent_GBps": cell_bytes / (k_ms * 1e-3) / 1e9,
                          "hbm_busy_GBps": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,

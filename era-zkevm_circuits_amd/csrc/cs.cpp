@@ -40,7 +40,7 @@ const GateInfo GATES[ZK_GATE__COUNT] = {
 };
 
 // element offset of (cell, lane) in the wave-tiled cell storage (see kernels_engine.hpp)
-size_t tiled_offset(uint64_t n_cells, uint64_t cell, uint64_t lane) { return (((lane >> 6) * n_cells + cell) << 6) + (lane & 63); }
+size_t tiled_offset(uint64_t geom, uint64_t cell, uint64_t lane) { return zkgeom::offset(geom, cell, lane); }  // geom: store_geom.hpp (a bare count = 64-lane tiles)
 
 void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw ZkError(ZK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -939,7 +939,7 @@ void CS::count_multiplicities(void* stream) {
         for (size_t t = 1; t <= tables_.size(); ++t) {
             const uint32_t n = s.mult_site_off[t + 1] - s.mult_site_off[t];
             if (!n) continue;
-            dev_check(zkdev::launch_multiplicities(s.d_store, s.n_store, sc ? limit_ : 1, s.n_lanes, batch_, s.d_mult_sites + 3 * (size_t)s.mult_site_off[t], n,
+            dev_check(zkdev::launch_multiplicities(s.d_store, s.store_geom(), sc ? limit_ : 1, s.n_lanes, batch_, s.d_mult_sites + 3 * (size_t)s.mult_site_off[t], n,
                                                    tdesc_host_[t], d_table_words_, d_mult_, total_table_rows_, stream));
         }
     }
@@ -2172,8 +2172,22 @@ void CS::set_batch(uint32_t n) {
         if (s.d_store) { hipFree(s.d_store); s.d_store = nullptr; }
         if (s.d_cells) { hipFree(s.d_cells); s.d_cells = nullptr; }  // the materialised trace is re-allocated on demand
         s.n_lanes = (uint32_t)lanes;
-        s.stride = (lanes + 63) / 64 * 64;  // whole 64-lane tiles
-        size_t bytes = std::max<size_t>((size_t)s.n_store * s.stride * 8, 8);
+        s.stride = (lanes + 63) / 64 * 64;  // the materialised trace: whole 64-lane tiles
+        // Lane tiling of the variable store (store_geom.hpp): 64-lane tiles (one per wavefront) unless ZKGL_STORE_TILE_LOG2=7..12 asks
+        // for wider ones for the loop scope.  Wide tiles (a value = up to 32 KB contiguous, shared by 64 wavefronts) stream 5-8 % faster
+        // in the bare store pattern (profiles/r3_layout_probe.jsonl) but NOT in the real kernel: 40.4-40.8 ms against 39.3-40.3 ms for
+        // k_witness_loop at B = 384, same box, four fresh processes each (profiles/r3_loop_probe.md) — the kernel is 2/3 VALU-busy and
+        // its time follows the shader clock, not the page placement.  The switch stays for such A/B runs; the buffer-addressed kernels
+        // need slot << (T + 3) < 2^32.
+        s.store_tile_log2 = zkgeom::WAVE_TILE_LOG2;
+        if (s.is_loop) {
+            uint32_t t = zkgeom::WAVE_TILE_LOG2;
+            if (const char* e = std::getenv("ZKGL_STORE_TILE_LOG2")) t = std::min<uint32_t>(zkgeom::WIDE_TILE_LOG2, std::max<uint32_t>(zkgeom::WAVE_TILE_LOG2, (uint32_t)std::atoi(e)));
+            while (t > zkgeom::WAVE_TILE_LOG2 && (uint64_t)s.n_store >= (1ull << (29 - t))) --t;
+            s.store_tile_log2 = t;
+        }
+        const uint64_t store_lanes = zkgeom::padded_lanes(s.store_geom(), lanes);
+        size_t bytes = std::max<size_t>((size_t)s.n_store * store_lanes * 8, 8);
         // experiment (ZKGL_STORE_CONTIGUOUS=1): physically contiguous VRAM for the store.  The loop kernel's time varies from one process
         // to the next (38.6 ... 41.5 ms at B=384, profiles/r2_summary.md) with the physical pages the allocation happens to get; a
         // contiguous block is consistently the slowest layout (43.6 ms)
@@ -2184,7 +2198,7 @@ void CS::set_batch(uint32_t n) {
         }
         if (!got) hip_check(hipMalloc((void**)&s.d_store, bytes), "hipMalloc variable store");
         hip_check(hipMemset(s.d_store, 0, bytes), "hipMemset variable store");
-        if (std::getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] %s store at %p (%zu bytes)\n", s.is_loop ? "loop" : "outer", (void*)s.d_store, bytes);
+        if (std::getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] %s store at %p (%zu bytes, tiles of %u lanes)\n", s.is_loop ? "loop" : "outer", (void*)s.d_store, bytes, 1u << s.store_tile_log2);
     };
     uint64_t loop_lanes = (uint64_t)n * limit_;
     if (loop_lanes >= 0xffffffffull) throw ZkError(ZK_ERR_CAPACITY, "batch*limit exceeds 32-bit lane index");
@@ -2214,12 +2228,12 @@ static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Sco
                                    const zk_table_desc* tables, const uint64_t* words, uint32_t* mult, uint32_t total_rows) {
     zkdev::ScopeArgs a;
     a.prog = s.d_prog; a.n_words = (uint32_t)s.prog.size(); a.n_lanes = s.n_lanes; a.consts = s.d_consts;
-    a.cells = s.d_store; a.n_cells = s.n_store; a.inputs = s.d_inputs;  // the witness kernels work on the variable store
+    a.cells = s.d_store; a.n_cells = s.store_geom(); a.inputs = s.d_inputs;  // the witness kernels work on the variable store
     a.in_stride = s.input_stride ? s.input_stride : s.n_lanes;
-    a.outer_cells = outer.d_store; a.outer_n_cells = outer.n_store;
+    a.outer_cells = outer.d_store; a.outer_n_cells = outer.store_geom();
     a.limit = s.is_loop ? limit : 1; a.is_loop = s.is_loop ? 1 : 0;
     a.tables = tables; a.table_words = words; a.mult = mult; a.total_table_rows = total_rows;
-    a.loop_cells = loop.d_store; a.loop_n_cells = loop.n_store; a.loop_limit = limit;
+    a.loop_cells = loop.d_store; a.loop_n_cells = loop.store_geom(); a.loop_limit = limit;
     a.uses_bigint = s.uses_bigint ? 1 : 0;
     return a;
 }
@@ -2489,7 +2503,7 @@ zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool c
         a.cprog = s.d_cprog_fused; a.chunk_tab = s.d_cchunks_fused; a.n_chunks = (uint32_t)s.cchunks_fused.size() - 1;
         a.macros = nullptr; a.n_macros = 0;
     }
-    a.cells = compact ? s.d_store : s.d_cells; a.n_cells = compact ? s.n_store : s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
+    a.cells = compact ? s.d_store : s.d_cells; a.n_cells = compact ? s.store_geom() : s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
     a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
     a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
     a.lookup_width = lookup_width_; a.tables = d_tables_; a.table_words = d_table_words_; a.fail = fail;
@@ -2532,8 +2546,8 @@ int CS::check_satisfied_impl(void* stream, zk_failure* first, bool macro) {
             dev_check(zkdev::launch_check_copies(loop_.d_cells, loop_.n_cells, loop_.n_lanes, loop_.d_copies,
                                                  (uint32_t)loop_.copies.size(), d_fail_ + 3, st));
         if (compact)
-            dev_check(zkdev::launch_check_links(loop_.d_store, loop_.n_store, loop_.n_lanes, limit_, outer_.d_store,
-                                                outer_.n_store, d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));
+            dev_check(zkdev::launch_check_links(loop_.d_store, loop_.store_geom(), loop_.n_lanes, limit_, outer_.d_store,
+                                                outer_.store_geom(), d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));
         else
             dev_check(zkdev::launch_check_links(loop_.d_cells, loop_.n_cells, loop_.n_lanes, limit_, outer_.d_cells,
                                                 outer_.n_cells, d_links_, (uint32_t)links_.size(), d_fail_ + 3, st));
@@ -2569,7 +2583,7 @@ void CS::ensure_materialized(void* stream) {
             }
             hip_check(hipMemsetAsync(s->d_cells, 0, bytes, st), "hipMemset trace");
         }
-        dev_check(zkdev::launch_materialize(s->d_cells, s->n_cells, s->d_store, s->n_store, s->n_lanes, s->d_mat_pairs, (uint32_t)s->mat_pairs.size(), st));
+        dev_check(zkdev::launch_materialize(s->d_cells, s->n_cells, s->d_store, s->store_geom(), s->n_lanes, s->d_mat_pairs, (uint32_t)s->mat_pairs.size(), st));
     }
     hip_check(hipStreamSynchronize(st), "materialize sync");
     compact_ = false;
@@ -2636,7 +2650,7 @@ void CS::check_streams(void* stream, bool compact) {
     const auto& dev = compact ? d_streams_store_ : d_streams_;
     for (size_t i = 0; i < streams.size(); ++i) {
         const auto& sr = streams[i];
-        dev_check(zkdev::launch_check_stream(compact ? loop_.d_store : loop_.d_cells, compact ? loop_.n_store : loop_.n_cells, batch_, limit_, dev[i],
+        dev_check(zkdev::launch_check_stream(compact ? loop_.d_store : loop_.d_cells, compact ? loop_.store_geom() : loop_.n_cells, batch_, limit_, dev[i],
                                              (uint32_t)sr.a.size(), dev[i] + sr.a.size(), (uint32_t)sr.b.size(), sr.n_total, (uint32_t)i,
                                              d_fail_ + 3, stream));
     }
@@ -2717,6 +2731,7 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     const bool fused = !(vs && vs[0] == '1') && outer_.d_cprog_fused && (!limit_ || loop_.d_cprog_fused);
     last_check_fused_ = fused;
     if (fused) { oa.fail = d_fail_; la.fail = d_fail_ + 3; }
+    la.clock_probe = d_fail_ + 6;   // words 6, 7 of the block travel back with the verdict
     hip_check(hipEventRecord(E(0), st), "event");                     // t0 (+ memsets done)
     hip_check(hipStreamWaitEvent(ax, E(0), 0), "wait");
     launch_phase(outer_, oa, 0, ax);    // outer PRE
@@ -2742,8 +2757,8 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hip_check(hipStreamWaitEvent(st, E(4), 0), "wait");
     count_multiplicities(st);   // both scopes resolved: the lookup multiplicities of the batch (k_multiplicities, no atomics in the witness kernels)
     if (limit_) {
-        dev_check(zkdev::launch_check_links(loop_.d_store, loop_.n_store, loop_.n_lanes, limit_, outer_.d_store,
-                                            outer_.n_store, d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));
+        dev_check(zkdev::launch_check_links(loop_.d_store, loop_.store_geom(), loop_.n_lanes, limit_, outer_.d_store,
+                                            outer_.store_geom(), d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));
         check_streams(st, true);
     }
     hip_check(hipEventRecord(E(7), st), "event");
@@ -2757,6 +2772,8 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hipEventElapsedTime(&total, E(0), E(7));
     hipEventElapsedTime(&outer_post, E(3), E(4));
     ms_[0] = total; ms_[1] = loop_ms; ms_[2] = gates_ms + copies_ms; ms_[3] = gates_ms; ms_[4] = outer_post;
+    // shader clock of the loop launch: s_memtime ticks per s_memrealtime tick (100 MHz) over the grid's first wavefront
+    loop_shader_mhz_ = (limit_ && f[7] != ~0ull && f[7] != 0) ? (float)((double)f[6] / (double)f[7] * 100.0) : 0.0f;
     compact_ = true;
     const int rc = decode_failure(f, first);
     return rc == ZK_MACRO_FAILURE ? check_satisfied_impl(stream, first, false) : rc;
@@ -2773,7 +2790,7 @@ uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
     }
     uint64_t out = 0;
     if (compact_)
-        hip_check(hipMemcpy(&out, s.d_store + tiled_offset(s.n_store, s.var_slot[var_index(v)], lane), 8, hipMemcpyDeviceToHost), "read_var memcpy");
+        hip_check(hipMemcpy(&out, s.d_store + tiled_offset(s.store_geom(), s.var_slot[var_index(v)], lane), 8, hipMemcpyDeviceToHost), "read_var memcpy");
     else
         hip_check(hipMemcpy(&out, s.d_cells + tiled_offset(s.n_cells, s.var_cells[var_index(v)][0], lane), 8, hipMemcpyDeviceToHost), "read_var memcpy");
     return out;
@@ -2798,7 +2815,7 @@ int CS::hook_compare_witness(const zk_var* vars, uint32_t n_vars, const uint64_t
     hipStream_t st = (hipStream_t)stream;
     uint32_t* d_slots = upload(slots);
     hip_check(hipMemsetAsync(d_fail_, 0xff, sizeof(unsigned long long), st), "memset fail");
-    dev_check(zkdev::launch_hook_compare(outer_.d_store, outer_.n_store, d_slots, n_vars, batch_, dev_expected, d_fail_, st));
+    dev_check(zkdev::launch_hook_compare(outer_.d_store, outer_.store_geom(), d_slots, n_vars, batch_, dev_expected, d_fail_, st));
     unsigned long long f = 0;
     hip_check(hipMemcpyAsync(&f, d_fail_, sizeof f, hipMemcpyDeviceToHost, st), "memcpy fail");
     hip_check(hipStreamSynchronize(st), "hook sync");
@@ -2813,7 +2830,7 @@ int CS::hook_compare_witness(const zk_var* vars, uint32_t n_vars, const uint64_t
 void CS::debug_poke_store(bool loop_scope, uint32_t slot, uint32_t lane, uint64_t value) {
     Scope& s = loop_scope ? loop_ : outer_;
     if (batch_ == 0 || !compact_ || slot >= s.n_store || lane >= s.n_lanes) throw ZkError(ZK_ERR_INVALID, "debug_poke_store: out of range or trace materialised");
-    hip_check(hipMemcpy(s.d_store + tiled_offset(s.n_store, slot, lane), &value, 8, hipMemcpyHostToDevice), "poke memcpy");
+    hip_check(hipMemcpy(s.d_store + tiled_offset(s.store_geom(), slot, lane), &value, 8, hipMemcpyHostToDevice), "poke memcpy");
 }
 
 uint32_t CS::pack_public_inputs(uint64_t* dev_out, void* stream) {
@@ -2825,7 +2842,7 @@ uint32_t CS::pack_public_inputs(uint64_t* dev_out, void* stream) {
         for (uint32_t v : public_vars_) slots.push_back(outer_.var_slot[v]);
         d_public_slots_ = upload(slots);
     }
-    dev_check(zkdev::launch_pack_public(outer_.d_store, outer_.n_store, d_public_slots_, n, batch_, dev_out, stream));
+    dev_check(zkdev::launch_pack_public(outer_.d_store, outer_.store_geom(), d_public_slots_, n, batch_, dev_out, stream));
     return n;
 }
 
@@ -2872,12 +2889,14 @@ void CS::stats(zk_stats* o) const {
     o->scratch_cells_outer = outer_.n_scratch; o->scratch_cells_loop = loop_.n_scratch;
     o->cells_written_outer = outer_.cells_written; o->cells_written_loop = loop_.cells_written;
     o->cells_populated_outer = outer_.cells_populated; o->cells_populated_loop = loop_.cells_populated;
+    o->loop_store_tile_lanes = batch_ ? (1ull << loop_.store_tile_log2) : 0;
     o->copy_pairs_outer = outer_.copies.size(); o->copy_pairs_loop = loop_.copies.size();
     o->seed_ops = seed_ops_; o->seed_words = seed_prog_.size(); o->seed_slots = seed_slots_; o->loop_ops = loop_.ops.size();
 }
 
 float CS::last_ms(int which) const {
     if (which >= 5 && which < 8) return last_seed_phase_ms[which - 5];  // native seeding phases (ZKGL_SEED_PHASE_MS=1): walker, chains, fill
+    if (which == 8) return loop_shader_mhz_;  // not a time: the shader clock (MHz) the last resolve_and_check's loop launch ran at
     return (which >= 0 && which < 5) ? ms_[which] : -1.0f;
 }
 
@@ -2943,7 +2962,7 @@ void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint6
     if (stride < ((uint64_t)1 << log_n)) throw ZkError(ZK_ERR_INVALID, "trace_columns: stride smaller than the column");
     zkdev::ColumnsArgs a;
     if (compact_) {
-        a.loop_cells = loop_.d_store; a.loop_n_cells = loop_.n_store; a.outer_cells = outer_.d_store; a.outer_n_cells = outer_.n_store;
+        a.loop_cells = loop_.d_store; a.loop_n_cells = loop_.store_geom(); a.outer_cells = outer_.d_store; a.outer_n_cells = outer_.store_geom();
         a.loop_slot1 = loop_.d_slot1; a.outer_slot1 = outer_.d_slot1;
     } else {
         a.loop_cells = loop_.d_cells; a.loop_n_cells = loop_.n_cells; a.outer_cells = outer_.d_cells; a.outer_n_cells = outer_.n_cells;

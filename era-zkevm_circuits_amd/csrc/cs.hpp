@@ -145,6 +145,9 @@ struct Scope {
     uint32_t* d_slot1 = nullptr;   // trace cell -> store slot + 1 of the variable placed there, 0 = unpopulated (trace_columns on the compact store)
     zk_copy_pair* d_mat_pairs = nullptr;
     uint64_t* d_store = nullptr;   // variable store, allocated by set_batch
+    uint32_t store_tile_log2 = zkgeom::WAVE_TILE_LOG2;  // lane tiling of d_store (store_geom.hpp), chosen by set_batch
+    // what the launch interface carries beside d_store: the slot count with the tiling in its top byte (a bare count = 64-lane tiles)
+    uint64_t store_geom() const { return store_tile_log2 == zkgeom::WAVE_TILE_LOG2 ? (uint64_t)n_store : zkgeom::pack(n_store, store_tile_log2); }
     uint64_t* d_cells = nullptr;   // materialised trace, allocated by the first ensure_materialized
     uint64_t stride = 0;
     uint32_t n_lanes = 0;
@@ -370,6 +373,7 @@ class CS {
     void* ev2_[8] = {nullptr};
     void* aux_stream_ = nullptr;
     float ms_[5] = {0, 0, 0, 0, 0};
+    float loop_shader_mhz_ = 0;   // clock probe of the last resolve_and_check's loop launch (last_ms(8))
     bool last_check_fused_ = false;
 };
 

@@ -4,9 +4,12 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "../../include/zkgl_ir.h"
+#include "store_geom.hpp"
 
 namespace zkdev {
 
+// Every (pointer, n_cells / n_store) pair below is a store and its GEOMETRY WORD (store_geom.hpp): the slot count, with the lane tiling in
+// the top byte when it is not the 64-lane default.
 struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     const uint32_t* prog; uint32_t n_words; uint32_t n_lanes;
     const uint64_t* consts; uint64_t* cells; uint64_t n_cells; const uint64_t* inputs;
@@ -16,6 +19,7 @@ struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     uint64_t in_stride;    // lanes between consecutive words of the input stream (>= n_lanes: a batch may be a window of a longer stream)
     uint32_t uses_bigint;  // host only: the program contains ZK_OP_NN_MULMOD -> launch the *_bigint kernel variants
     unsigned long long* fail = nullptr;  // fused mode: where the witness kernels report a gate they evaluate themselves (SELECT with a non-boolean selector)
+    unsigned long long* clock_probe = nullptr;  // two words: shader-clock and 100 MHz ticks of the grid's first wavefront (kernels_engine2.hpp witness_entry2)
 };
 struct CheckArgs {  // mirrors zke::CheckDev
     const uint64_t* cells; uint64_t n_cells; uint32_t n_cols; uint32_t n_lanes; uint32_t n_slots;

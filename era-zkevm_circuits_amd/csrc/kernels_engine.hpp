@@ -5,14 +5,16 @@
 // Mapping: lane == (instance) for the outer scope, (instance*limit + iteration) for the loop
 // scope.  Every lane executes the same straight-line program (no divergence).
 //
-// Cell storage is TILED by wavefront: cells[((lane >> 6) * n_cells + cell) * 64 + (lane & 63)],
-// cell = slot * n_columns + column.  A wavefront owns one contiguous tile (n_cells * 512 B); every
-// cell access is one coalesced 512-byte transaction whose address is  tile_base + (cell << 9):
+// Cell storage is TILED by lane: cells[((lane >> T) * n_cells + cell) << T | (lane & (2^T - 1))] (store_geom.hpp; T = 6: one tile
+// per wavefront, T = 12: 64 wavefronts share a tile and a value of the tile is 32 KB contiguous),
+// cell = slot * n_columns + column.  Every cell access of a wavefront is one coalesced 512-byte transaction whose address is
+// tile_base + (cell << (T + 3)) + the wavefront's place in the tile:
 // consecutive columns of a gate instance and consecutively placed rows are adjacent in DRAM, so a
 // wave streams through its tile (DRAM-page and TLB locality) instead of striding by the lane count.
 #pragma once
 #include "../../include/zkgl_ir.h"
 #include "poseidon2_device.hpp"
+#include "store_geom.hpp"
 
 // Trace stores.  Round 1 stored every cell of a variable (55 k words per VM cycle) and streamed them out non-temporally.  With
 // compact traces a value is stored once, to its home cell, and is usually an operand of an op a few hundred words later: a
@@ -57,15 +59,28 @@ struct ScopeDev {
     // Their relations are the ops' own field arithmetic, except SELECT: s (a - b) + b - r == 0 for r = s ? a : b fails exactly when
     // s > 1 and a != b — tested on the operands in registers, reported under the macro row (the host then names the gate).
     unsigned long long* fail;
+    unsigned long long* clock_probe;  // nullable: {shader clock ticks, 100 MHz ticks} of the grid's first wavefront (witness_entry2)
 };
 
 constexpr int TPB = 256;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// element offset of (cell, lane) in the tiled layout
+// element offset of (cell, lane) in the tiled layout; n_cells = the store's geometry word (store_geom.hpp: a bare count = 64-lane tiles)
 __device__ __forceinline__ size_t cell_off(uint64_t n_cells, uint32_t cell, uint32_t lane) {
-    return (((size_t)(lane >> 6) * n_cells + cell) << 6) + (lane & 63);
+    return zkgeom::offset(n_cells, cell, lane);
+}
+// the pieces of the buffer-addressed fast paths: a wavefront's 64 lanes sit in ONE tile (tiles are multiples of 64 lanes);
+// V# base = the tile, voffset = the lane's byte in a value of the tile, soffset = slot << (T + 3)
+struct TileAddr { uint64_t* base; uint32_t lane_byte, shift; };
+__device__ __forceinline__ TileAddr tile_addr(uint64_t* cells, uint64_t geom, uint32_t lane) {
+    const uint32_t t = zkgeom::tile_log2(geom);
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> t));
+    TileAddr a;
+    a.base = cells + (((size_t)tile * zkgeom::slots(geom)) << t);
+    a.lane_byte = (lane & ((1u << t) - 1)) * 8;
+    a.shift = t + 3;
+    return a;
 }
 
 // locate the table row for a key tuple; returns n_rows when absent
@@ -292,15 +307,16 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                                          uint64_t* slots = nullptr, uint32_t slot_stride = 0, const uint64_t* in_area = nullptr) {
     uint64_t* __restrict__ cells = sc.cells + cell_off(sc.n_cells, 0, lane);  // this lane's column of its tile
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const uint32_t lane_byte = (lane & 63) * 8;
-    __amdgpu_buffer_rsrc_t tile_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        sc.cells + (size_t)(TILE_UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6)) : 0u) * sc.n_cells * 64, 0, -1,
+    const uint32_t tsh = zkgeom::tile_log2(sc.n_cells);   // a value of the tile is 2^tsh lanes wide
+    const TileAddr ta = TILE_UNIFORM ? tile_addr(sc.cells, sc.n_cells, lane) : TileAddr{sc.cells, (lane & 63) * 8, 9};
+    const uint32_t lane_byte = ta.lane_byte, bsh = ta.shift;
+    __amdgpu_buffer_rsrc_t tile_rsrc = __builtin_amdgcn_make_buffer_rsrc(ta.base, 0, -1,
         0x00020000);  // gfx9 raw buffer descriptor: stride 0, num_records 2^32-1, 32-bit data format
     // the same descriptor as four SGPRs for the hand-scheduled destination loop in st()
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     i32x4 tile_rsrc4;
     {
-        const uint64_t bp = (uint64_t)(sc.cells + (size_t)(TILE_UNIFORM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6)) : 0u) * sc.n_cells * 64);
+        const uint64_t bp = (uint64_t)ta.base;
         tile_rsrc4.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)bp);
         tile_rsrc4.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(bp >> 32));
         tile_rsrc4.z = -1;
@@ -324,11 +340,11 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 #ifdef ZKGL_STUB_LOADS  // time attribution only (tools/stub_bench.sh): operand values without the memory access
             return (uint64_t)idx * 0x9E3779B97F4A7C15ull + lane_byte;
 #else
-            u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc, lane_byte, idx << 9, 0);
+            u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc, lane_byte, idx << bsh, 0);
             return (uint64_t)v.x | ((uint64_t)v.y << 32);
 #endif
         }
-        return cells[(size_t)idx << 6];
+        return cells[(size_t)idx << tsh];
     };
     uint32_t pc = word_begin;
     auto st = [&](uint64_t v) {
@@ -376,10 +392,10 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 #ifdef ZKGL_STUB_STORES
                     asm volatile("" ::"v"(o), "s"(w));
 #else
-                    __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ZK_DEST_CELL_MASK) << 9, ZKGL_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ZK_DEST_CELL_MASK) << bsh, ZKGL_STORE_AUX);
 #endif
                 } else {
-                    cells[(size_t)(w & ZK_DEST_CELL_MASK) << 6] = v;  // 64-bit addressed scopes
+                    cells[(size_t)(w & ZK_DEST_CELL_MASK) << tsh] = v;  // 64-bit addressed scopes
                 }
             } while (w & ZK_DEST_MORE);
         }
@@ -977,6 +993,7 @@ __device__ __forceinline__ void check_gates_body(const CheckDev& cd) {
     const uint32_t s0 = blockIdx.y * cd.slots_per_chunk;
     const uint32_t s1 = min(s0 + cd.slots_per_chunk, cd.n_slots);
     const uint64_t* __restrict__ cells = cd.cells + cell_off(cd.n_cells, 0, lane);
+    const uint32_t tsh = zkgeom::tile_log2(cd.n_cells);
     const size_t NC = cd.n_cols;
     for (uint32_t slot = s0; slot < s1; ++slot) {
         const zk_row_desc d = cd.rows[slot];
@@ -987,8 +1004,8 @@ __device__ __forceinline__ void check_gates_body(const CheckDev& cd) {
         // compact trace: the cell's variable lives in its home cell (wave-uniform index from the alias map); homes are read
         // once per occurrence of the variable, so these loads stay cacheable
         auto cell = [&](uint32_t col) -> uint64_t {
-            if constexpr (ALIAS) return cells[(size_t)uni(cd.alias[(size_t)slot * NC + col]) << 6];
-            else return __builtin_nontemporal_load(&cells[((size_t)slot * NC + col) << 6]);
+            if constexpr (ALIAS) return cells[(size_t)uni(cd.alias[(size_t)slot * NC + col]) << tsh];
+            else return __builtin_nontemporal_load(&cells[((size_t)slot * NC + col) << tsh]);
         };
         for (uint32_t j = 0; j < ninst; ++j) {
             const uint32_t c0 = j * w;
@@ -1099,9 +1116,10 @@ __global__ __launch_bounds__(TPB) void k_materialize(uint64_t* __restrict__ trac
     uint64_t* __restrict__ trace = trace_all + cell_off(n_cells, 0, lane);
     const uint64_t* __restrict__ store = store_all + cell_off(n_store, 0, lane);
     const uint32_t p0 = blockIdx.y * pairs_per_chunk, p1 = min(p0 + pairs_per_chunk, n_pairs);
+    const uint32_t tsh = zkgeom::tile_log2(n_cells), ssh = zkgeom::tile_log2(n_store);
     for (uint32_t i = p0; i < p1; ++i) {
         const zk_copy_pair p = pairs[i];
-        __builtin_nontemporal_store(store[(size_t)uni(p.home) << 6], &trace[(size_t)uni(p.cell) << 6]);
+        __builtin_nontemporal_store(store[(size_t)uni(p.home) << ssh], &trace[(size_t)uni(p.cell) << tsh]);
     }
 }
 
@@ -1113,10 +1131,11 @@ __global__ __launch_bounds__(TPB) void k_check_copies(const uint64_t* __restrict
     if (lane >= n_lanes) return;
     const uint64_t* __restrict__ cells = cells_all + cell_off(n_cells, 0, lane);
     const uint32_t p0 = blockIdx.y * pairs_per_chunk, p1 = min(p0 + pairs_per_chunk, n_pairs);
+    const uint32_t tsh = zkgeom::tile_log2(n_cells);
     for (uint32_t i = p0; i < p1; ++i) {
         const zk_copy_pair p = pairs[i];
         // the non-home cell is read once (non-temporal, -2.2 %), the home cell again by the variable's next pair
-        uint64_t a = __builtin_nontemporal_load(&cells[(size_t)uni(p.cell) << 6]), b = cells[(size_t)uni(p.home) << 6];
+        uint64_t a = __builtin_nontemporal_load(&cells[(size_t)uni(p.cell) << tsh]), b = cells[(size_t)uni(p.home) << tsh];
         if (a != b) atomicMin(fail + 1, ((unsigned long long)lane << 32) | i);
     }
 }

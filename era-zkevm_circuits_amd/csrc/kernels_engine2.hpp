@@ -105,10 +105,12 @@ template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB, bool STRANDS = false>
 __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                           uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const uint32_t lane_byte = (lane & 63) * 8;
-    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6));
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(sc.cells + (size_t)tile * sc.n_cells * 64, 0, -1, 0x00020000);
-    uint64_t* __restrict__ wide_cells = sc.cells + (size_t)tile * sc.n_cells * 64 + (lane & 63);
+    // store_geom.hpp: V# = the lane tile of this wavefront, voffset = the lane's byte in a value of the tile, soffset = slot << bsh
+    const TileAddr ta = tile_addr(sc.cells, sc.n_cells, lane);
+    const uint32_t lane_byte = ta.lane_byte;
+    const uint32_t bsh = uni(ta.shift), tsh = bsh - 3, bstep = 1u << bsh;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ta.base, 0, -1, 0x00020000);
+    uint64_t* __restrict__ wide_cells = ta.base + (lane_byte >> 3);
     const prog1_ptr prog = (prog1_ptr)(uintptr_t)sc.prog;
     const cpool_ptr cpool = (cpool_ptr)(uintptr_t)sc.consts;
 #ifdef ZKGL_P2_IN_LDS  // A/B: the round-1 form (state staged in LDS, rolled S-box loops) for the plain kernels
@@ -118,35 +120,35 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #endif
     __shared__ uint64_t p2s[P2_IN_REGISTERS ? 1 : 12 * BLOCK];  // Poseidon2 state, [element][thread] (plain kernels: rolled S-box loops)
 
-    uint32_t dst = WIDE ? slot_begin : slot_begin << 9;  // next output: slot index (WIDE) or byte offset in the tile
+    uint32_t dst = WIDE ? slot_begin : slot_begin << bsh;  // next output: slot index (WIDE) or byte offset in the tile
     auto ldv = [&](uint32_t slot) -> uint64_t {
 #ifdef ZKGL_STUB_LOADS  // time attribution only (tools/stub_vm.sh): operand values without the memory access
         return (uint64_t)slot * 0x9E3779B97F4A7C15ull + lane_byte;
 #else
-        if constexpr (WIDE) return wide_cells[(size_t)slot << 6];
-        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << 9, 0);
+        if constexpr (WIDE) return wide_cells[(size_t)slot << tsh];
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << bsh, 0);
         return (uint64_t)v.x | ((uint64_t)v.y << 32);
 #endif
     };
     auto st = [&](uint64_t v) {
 #ifdef ZKGL_STUB_STORES
         asm volatile("" ::"v"(v), "s"(dst));
-        dst += WIDE ? 1 : 512;
+        dst += WIDE ? 1 : bstep;
 #else
         if constexpr (WIDE) {
-            wide_cells[(size_t)dst << 6] = v;
+            wide_cells[(size_t)dst << tsh] = v;
             dst += 1;
         } else {
             u32x2 o;
             o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
             __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, dst, 0);
-            dst += 512;
+            dst += bstep;
         }
 #endif
     };
 
     constexpr uint32_t D = STRANDS ? 1 : 0;  // destination words per op
-    auto out_to = [&](uint32_t slot) { if constexpr (STRANDS) dst = WIDE ? slot : slot << 9; };
+    auto out_to = [&](uint32_t slot) { if constexpr (STRANDS) dst = WIDE ? slot : slot << bsh; };
     uint32_t pc = word_begin;
     bool fused_bad = false;   // fused mode: a gate evaluated here (SELECT's exception, a lookup miss) is violated; reported once, below
     while (pc < word_end) {
@@ -201,8 +203,12 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) {
                     out_to(W[(1 + N * 5 + g) & 15]);
+#ifdef ZKGL_STUB_FMA  // time attribution only (tools/loop_probe.sh): the op without its multiplications
+                    st(in[g][0] ^ in[g][1] ^ in[g][2] ^ q[g] ^ l[g]);
+#else
                     const uint64_t ab = gl::mul(in[g][0], in[g][1]);
                     st(gl::add(q[g] == 1 ? ab : gl::mul(q[g], ab), l[g] == 1 ? in[g][2] : gl::mul(l[g], in[g][2])));
+#endif
                 }
             };
             switch (pb) {
@@ -253,7 +259,11 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             st(x == 0 ? 1ull : 0ull);
             // x^-1: flags and small counters dominate; 0 and 1 are their own (pseudo-)inverses, skip the 73-multiplication chain
             // when the whole wavefront holds such values
+#ifdef ZKGL_STUB_INV  // time attribution only: no inversion
+            st(x);
+#else
             st(__builtin_amdgcn_ballot_w64(x > 1) == 0 ? x : gl::inv(x));
+#endif
         } break;
         case ZK_OP_UADD: {
             const uint64_t x = ldv(W[1]), y = ldv(W[2]), ci = ldv(W[3]);
@@ -322,7 +332,11 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                     pc += 2 + N * pa + D * N;
 #pragma unroll
                     for (uint32_t g = 0; g < N; ++g) {
+#ifdef ZKGL_STUB_FIND  // time attribution only: no table search
+                        row[g] = (uint32_t)k0[g] & 7u;
+#else
                         row[g] = table_find2(t, sc.table_words, k0[g], k1[g]);
+#endif
                         const bool found = row[g] < t.n_rows;
 #pragma unroll
                         for (uint32_t i = 0; i < 2; ++i)
@@ -393,11 +407,17 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
                         for (int i = 0; i < 12; ++i) {
                             const uint64_t t = gl::add(s[i], p2::RC[12 * r + i]);
+#ifdef ZKGL_STUB_P2  // time attribution only: the S-box without its four multiplications
+                            const uint64_t x2 = t ^ 1, x3 = t ^ 2, x4 = t ^ 3, x7 = t ^ 4;
+#else
                             const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+#endif
                             if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
                             s[i] = x7;
                         }
+#ifndef ZKGL_STUB_P2LIN  // time attribution only: no linear layers
                         p2::mds_external(s);
+#endif
                         if (emit) {
 #pragma unroll
                             for (int i = 0; i < 12; ++i) st(s[i]);
@@ -407,10 +427,16 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll 1
                         for (int r = 4; r < 26; ++r) {
                             const uint64_t t = gl::add(s[0], p2::RC[12 * r]);
+#ifdef ZKGL_STUB_P2
+                            const uint64_t x2 = t ^ 1, x3 = t ^ 2, x4 = t ^ 3, x7 = t ^ 4;
+#else
                             const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+#endif
                             if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
                             s[0] = x7;
+#ifndef ZKGL_STUB_P2LIN
                             p2::mds_inner(s);
+#endif
                             if (emit) {
 #pragma unroll
                                 for (int i = 0; i < 12; ++i) st(s[i]);
@@ -629,7 +655,17 @@ __device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
     const bool active = lane < sc.n_lanes;
     lane = active ? lane : sc.n_lanes - 1;
+    // clock probe (loop launch of resolve_and_check): the first wavefront of the grid reads the shader clock counter (s_memtime) and the
+    // constant 100 MHz counter (s_memrealtime) around its own run — about half of the launch — so that the host can tell the
+    // shader clock the chip's power management gave THIS launch (the kernel is 2/3 VALU-busy: its time follows that clock)
+    const bool probe = sc.clock_probe && blockIdx.x == 0 && threadIdx.x < 64;
+    uint64_t t0 = 0, r0 = 0;
+    if (probe) { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
     run_tile2<WITH_BIGINT, WIDE>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end, slot_begin);
+    if (probe && threadIdx.x == 0) {
+        sc.clock_probe[0] = __builtin_readcyclecounter() - t0;
+        sc.clock_probe[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 // Strand mode: a scope with too few lanes to fill the chip (hash circuits: lanes = instances x cycles; every outer scope: lanes =
 // instances) runs one 64-lane tile per BLOCK of 8 wavefronts.  Wavefront w walks strand w of the program: the ops of every
@@ -1028,9 +1064,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= cd.n_lanes) return;
     const bool active = lane < cd.n_lanes;
     lane = active ? lane : cd.n_lanes - 1;
-    const uint32_t lane_byte = (lane & 63) * 8;
-    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6));
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(cd.cells) + (size_t)tile * cd.n_cells * 64, 0, -1, 0x00020000);
+    const TileAddr ta = tile_addr(const_cast<uint64_t*>(cd.cells), cd.n_cells, lane);
+    const uint32_t lane_byte = ta.lane_byte, bsh = uni(ta.shift);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ta.base, 0, -1, 0x00020000);
     const prog1_ptr prog = (prog1_ptr)(uintptr_t)cd.prog;
     const prog1_ptr tab = (prog1_ptr)(uintptr_t)cd.chunk_tab;
     const cpool_ptr consts = (cpool_ptr)(uintptr_t)cd.rowconsts;
@@ -1038,7 +1074,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_
     uint32_t pc = tab[c0];
     const uint32_t end = tab[c1];
     auto ldv = [&](uint32_t slot) -> uint64_t {
-        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << 9, 0);
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << bsh, 0);
         return (uint64_t)v.x | ((uint64_t)v.y << 32);
     };
     while (pc < end) {
@@ -1256,12 +1292,12 @@ __global__ __launch_bounds__(TPB) void k_check_p2(CheckP2Dev cd) {
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= cd.n_lanes) return;
     const bool active = lane < cd.n_lanes;
     lane = active ? lane : cd.n_lanes - 1;
-    const uint32_t lane_byte = (lane & 63) * 8;
-    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane >> 6));
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(cd.cells) + (size_t)tile * cd.n_cells * 64, 0, -1, 0x00020000);
+    const TileAddr ta = tile_addr(const_cast<uint64_t*>(cd.cells), cd.n_cells, lane);
+    const uint32_t lane_byte = ta.lane_byte, bsh = uni(ta.shift);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ta.base, 0, -1, 0x00020000);
     const prog1_ptr macros = (prog1_ptr)(uintptr_t)cd.macros;
     auto ldv = [&](uint32_t slot) -> uint64_t {
-        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << 9, 0);
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << bsh, 0);
         return (uint64_t)v.x | ((uint64_t)v.y << 32);
     };
     const uint32_t m0 = blockIdx.y * cd.per_block, m1 = min(m0 + cd.per_block, cd.n_macros);

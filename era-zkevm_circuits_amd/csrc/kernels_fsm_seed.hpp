@@ -33,7 +33,7 @@ constexpr u32 EV_MAX = 8;
 struct Events { u32 n; u32 kind[EV_MAX]; u64 pay[EV_MAX][20]; };   // kind 0: memory queue push (8 words), 1: request queue pop (20 words)
 
 __device__ __forceinline__ u64 ov(const FsmSeedDev& a, u32 inst, u32 slot) {
-    return a.outer_store[((u64)(inst >> 6) * a.outer_n_store + slot) * 64 + (inst & 63)];
+    return a.outer_store[zkgeom::offset(a.outer_n_store, slot, inst)];
 }
 
 // chain[0..12) = memory queue tail, chain[12..16) = request queue head; the events of one cycle, all lanes of the hasher wavefront

@@ -17,6 +17,7 @@
 #pragma once
 #include "gl_device.hpp"
 #include "../../include/zkgl_ir.h"
+#include "store_geom.hpp"
 
 namespace zkl {
 
@@ -48,7 +49,7 @@ struct LookupArgDev {
 };
 
 __device__ __forceinline__ size_t cell_off(uint64_t n_cells, uint32_t cell, uint32_t lane) {
-    return ((size_t)(lane >> 6) * n_cells + cell) * 64 + (lane & 63);
+    return zkgeom::offset(n_cells, cell, lane);  // n_cells = the geometry word of the store
 }
 
 // f = beta + c0 + gamma c1 + gamma^2 c2 (+ gamma^3 c3) + gamma^W t
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(TPB) void k_lookup_arg_witness(LookupArgDev d) {
     const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if (lane >= d.n_lanes) return;
     const uint64_t* __restrict__ cells = d.cells + cell_off(d.n_cells, 0, lane);
+    const uint32_t tsh = zkgeom::tile_log2(d.n_cells);
     E sum{0, 0};
     for (uint32_t slot = 0; slot < d.n_slots; ++slot) {
         const zk_lookup_row_desc lr = d.lrows[slot];
@@ -76,10 +78,10 @@ __global__ __launch_bounds__(TPB) void k_lookup_arg_witness(LookupArgDev d) {
         E run{1, 0};
         for (uint32_t u = 0; u < n; ++u) {  // prefix products
             const size_t c0 = (size_t)slot * d.n_cols + d.n_copy_cols + (size_t)u * d.lookup_width;
-            uint64_t v0 = cells[(c0 + 0) << 6];
-            uint64_t v1 = d.lookup_width > 1 ? cells[(c0 + 1) << 6] : 0;
-            uint64_t v2 = d.lookup_width > 2 ? cells[(c0 + 2) << 6] : 0;
-            uint64_t v3 = d.lookup_width > 3 ? cells[(c0 + 3) << 6] : 0;
+            uint64_t v0 = cells[(size_t)(c0 + 0) << tsh];
+            uint64_t v1 = d.lookup_width > 1 ? cells[(size_t)(c0 + 1) << tsh] : 0;
+            uint64_t v2 = d.lookup_width > 2 ? cells[(size_t)(c0 + 2) << tsh] : 0;
+            uint64_t v3 = d.lookup_width > 3 ? cells[(size_t)(c0 + 3) << tsh] : 0;
             f[u] = tuple_value(d, d.lookup_width, v0, v1, v2, v3, lr.table);
             pre[u] = run;
             run = emul(run, f[u]);

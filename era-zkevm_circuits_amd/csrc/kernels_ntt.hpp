@@ -22,6 +22,7 @@
 // the 2^64 = 2^32 - 1 folding): on gfx950 the passes are VALU-bound (VALUBusy 88 %), see profiles/r1_ntt.md.
 #pragma once
 #include "gl_device.hpp"
+#include "store_geom.hpp"
 
 namespace zkn {
 
@@ -199,7 +200,7 @@ struct ColumnsDev {
     const uint32_t* loop_slot1; const uint32_t* outer_slot1;
 };
 __device__ __forceinline__ size_t tiled(uint64_t n_cells, uint32_t cell, uint32_t lane) {
-    return ((size_t)(lane >> 6) * n_cells + cell) * 64 + (lane & 63);
+    return zkgeom::offset(n_cells, cell, lane);  // n_cells = the geometry word of the store
 }
 __global__ __launch_bounds__(256) void k_trace_columns_loop(ColumnsDev d) {
     __shared__ uint64_t tile[32][65];

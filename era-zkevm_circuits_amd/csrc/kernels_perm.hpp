@@ -51,6 +51,7 @@ __global__ __launch_bounds__(TPB) void k_perm_lane(PermDev d) {
     if (lane >= d.n_lanes) return;
     const uint32_t k = lane % d.lanes_per_instance;
     const uint64_t* __restrict__ cells = d.cells + zkl::cell_off(d.n_cells, 0, lane);
+    const uint32_t tsh = zkgeom::tile_log2(d.n_cells);
     const E A = eadd(escale(d.beta, gl::reduce(d.label_base + (uint64_t)k * d.label_step)), d.gamma);  // labels < 2^63 < p
     E num{1, 0}, den{1, 0};
     const uint32_t s0 = blockIdx.y * d.slots_per_chunk, s1 = min(s0 + d.slots_per_chunk, d.n_slots);
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(TPB) void k_perm_lane(PermDev d) {
 #pragma unroll 4
             for (uint32_t col = c0; col < c1; ++col) {
                 const uint32_t cell = slot * d.n_cols + col;
-                const uint64_t w = cells[(size_t)cell << 6];
+                const uint64_t w = cells[(size_t)cell << tsh];
                 const uint64_t* __restrict__ t = d.tb + 4 * (size_t)cell;
                 E tn = eadd(A, E{t[0], t[1]});
                 tn.a = gl::add(tn.a, w);

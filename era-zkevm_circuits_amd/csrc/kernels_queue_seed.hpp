@@ -31,7 +31,7 @@ struct RamSeedDev {
 constexpr u32 RAM_CARRIED = 46, RAM_ITEM_U = 46, RAM_ITEM_S = 59;
 
 __device__ __forceinline__ u64 ov(const RamSeedDev& a, u32 inst, u32 slot) {
-    return a.outer_store[((u64)(inst >> 6) * a.outer_n_store + slot) * 64 + (inst & 63)];
+    return a.outer_store[zkgeom::offset(a.outer_n_store, slot, inst)];
 }
 struct Item { u32 ts, page, index, rw, is_ptr; vmn::U256 value; };
 __device__ __forceinline__ Item load_item(const u64* col, u64 stride, u32 first) {
@@ -202,7 +202,7 @@ __device__ __forceinline__ bool logq_pops(const u64* col, u64 stride) {
 }
 
 __device__ __forceinline__ u64 ovq(const LogqSeedDev& a, u32 inst, u32 slot) {
-    return a.outer_store[((u64)(inst >> 6) * a.outer_n_store + slot) * 64 + (inst & 63)];
+    return a.outer_store[zkgeom::offset(a.outer_n_store, slot, inst)];
 }
 
 // one workgroup per instance; a thread owns a run of consecutive cycles: local products, a workgroup scan, the four words per cycle

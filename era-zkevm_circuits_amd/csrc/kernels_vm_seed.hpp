@@ -53,7 +53,7 @@ struct SeedDev {
 constexpr u32 SAVE_WORDS = (sizeof(vmn::State) + 3) / 4;
 
 __device__ __forceinline__ u64 outer_value(const SeedDev& a, u32 inst, u32 slot) {
-    return a.outer_store[((u64)(inst >> 6) * a.outer_n_store + slot) * 64 + (inst & 63)];
+    return a.outer_store[zkgeom::offset(a.outer_n_store, slot, inst)];
 }
 
 constexpr u32 RAW_MAX = 128;  // oracle words per cycle the walker stages in LDS (main_vm: 117)

@@ -100,6 +100,9 @@ int launch_grand_product(const uint64_t* enc, const uint64_t* flags, const uint6
     return LAUNCH_CHECK("k_gp");
 }
 
+// the buffer-addressed kernels put slot << (T + 3) in a 32-bit soffset (store_geom.hpp); larger stores take 64-bit addresses
+static bool needs_wide_addressing(uint64_t geom) { return zkgeom::slots(geom) >= (1ull << (29 - zkgeom::tile_log2(geom))); }
+
 static zke::ScopeDev to_dev(const ScopeArgs& a) {
     zke::ScopeDev d;
     d.prog = a.prog; d.n_words = a.n_words; d.n_lanes = a.n_lanes; d.consts = a.consts; d.cells = a.cells;
@@ -108,6 +111,7 @@ static zke::ScopeDev to_dev(const ScopeArgs& a) {
     d.total_table_rows = a.total_table_rows; d.loop_cells = a.loop_cells; d.loop_n_cells = a.loop_n_cells;
     d.loop_limit = a.loop_limit;
     d.fail = a.fail;
+    d.clock_probe = a.clock_probe;
     return d;
 }
 
@@ -123,7 +127,7 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
     if (sc.n_lanes == 0 || word_begin >= word_end) return 0;
     const dim3 grid = grid_for(sc.n_lanes, zke::TPB);
     hipStream_t s = (hipStream_t)stream;
-    if (sc.n_cells >= (1ull << 23)) zke::k_witness_wide<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
+    if (needs_wide_addressing(sc.n_cells)) zke::k_witness_wide<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.is_loop && sc.uses_bigint) zke::k_witness_loop_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.is_loop) zke::k_witness_loop<<<grid, zke::TPB, lds_pad("ZKGL_LOOP_LDS_PAD"), s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.uses_bigint) zke::k_witness_outer_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
@@ -139,7 +143,7 @@ int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER
     for (int i = 0; i < zke::STRANDS_PER_TILE; ++i) { tab.begin[i] = begin[i]; tab.end[i] = end[i]; any |= end[i] > begin[i]; }
     if (!any) return 0;
     const unsigned grid = grid_for(sc.n_lanes, 64);
-    if (sc.n_cells >= (1ull << 23)) zke::k_witness_strands2<true, true><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);  // 64-bit addressing
+    if (needs_wide_addressing(sc.n_cells)) zke::k_witness_strands2<true, true><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);  // 64-bit addressing
     else if (sc.uses_bigint) zke::k_witness_strands2<true, false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
     else zke::k_witness_strands2<false, false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
     return LAUNCH_CHECK("k_witness_strands");
@@ -164,7 +168,7 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
     d.cells = a.cells; d.n_cells = a.n_cells; d.n_cols = a.n_cols; d.n_lanes = a.n_lanes; d.n_slots = a.n_slots; d.rows = a.rows;
     d.rowconsts = a.rowconsts; d.lrows = a.lrows; d.n_copy_cols = a.n_copy_cols; d.lookup_width = a.lookup_width;
     d.tables = a.tables; d.table_words = a.table_words; d.fail = a.fail; d.slots_per_chunk = a.slots_per_chunk; d.alias = a.alias;
-    if (a.alias && a.cprog && a.n_chunks && a.n_cells < (1ull << 23)) {
+    if (a.alias && a.cprog && a.n_chunks && !needs_wide_addressing(a.n_cells)) {
         zke::CheckProgDev p;
         p.cells = a.cells; p.n_cells = a.n_cells; p.n_lanes = a.n_lanes; p.prog = a.cprog; p.chunk_tab = a.chunk_tab; p.n_chunks = a.n_chunks;
         p.rowconsts = a.rowconsts; p.tables = a.tables; p.table_words = a.table_words; p.fail = a.fail;

@@ -67,7 +67,8 @@ class _Stats(C.Structure):
                 ("cells_written_outer", C.c_uint64), ("cells_written_loop", C.c_uint64),
                 ("copy_pairs_outer", C.c_uint64), ("copy_pairs_loop", C.c_uint64),
                 ("seed_ops", C.c_uint64), ("seed_words", C.c_uint64), ("seed_slots", C.c_uint64), ("loop_ops", C.c_uint64),
-                ("cells_populated_outer", C.c_uint64), ("cells_populated_loop", C.c_uint64)]
+                ("cells_populated_outer", C.c_uint64), ("cells_populated_loop", C.c_uint64),
+                ("loop_store_tile_lanes", C.c_uint64)]
 
 
 _lib = None

@@ -260,6 +260,9 @@ typedef struct zk_stats {
     /* cone seeding program (backward slice of the carried outputs; 0 when the generic sequential mode is used) */
     uint64_t seed_ops, seed_words, seed_slots, loop_ops;
     uint64_t cells_populated_outer, cells_populated_loop; /* trace + scratch cells holding a value == cells the gate checker reads */
+    /* lane tiling of the loop scope's variable store for the bound batch (0 before zk_cs_set_batch): 64 = one tile per wavefront,
+     * 4096 = the wide tiling large batches get (csrc/store_geom.hpp).  A layout property only: every reader goes through the C ABI. */
+    uint64_t loop_store_tile_lanes;
 } zk_stats;
 /* K12 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
  * column chunking and cell identifiers are [EXT], the argument is defined in csrc/kernels_perm.hpp).  Labels: outer-scope
@@ -303,7 +306,10 @@ int zk_cs_stats(zk_cs *cs, zk_stats *out);           /* print_gate_stats counter
  * which: 0 resolve total (fused: whole pipeline), 1 loop witness kernel, 2 check total (fused: loop gates+copies),
  * 3 gate-check loop kernel, 4 outer kernels (fused: outer post + outer checks);
  * 5 / 6 / 7: the last seeding pass of a circuit with a native seeder (main_vm) when ZKGL_SEED_PHASE_MS is set: state walker,
- * Poseidon2 chains, fill */
+ * Poseidon2 chains, fill;
+ * 8: not a time — the shader clock in MHz that the loop witness kernel of the last zk_cs_resolve_and_check ran at (s_memtime against
+ * the constant 100 MHz counter over the grid's first wavefront): the chip's power management picks it per launch, and a kernel that is
+ * 2/3 VALU-busy follows it */
 int zk_cs_last_ms(zk_cs *cs, int which, float *ms);
 /* serialised scope (program + descriptors) for the CPU oracle / offline tooling.
  * Call with buf = NULL to get the size in words. */

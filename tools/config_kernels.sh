@@ -1,7 +1,7 @@
 #!/bin/bash
-# GPU box, repo root: per-kernel tables of the other BASELINE configurations -> gpurun_out/r2_config_kernels.md
+# GPU box, repo root: per-kernel tables of the other BASELINE configurations -> gpurun_out/r3_config_kernels.md (OUT_NAME overrides)
 # (rocprofv3 --kernel-trace --stats of `CONFIGS=<c> python tests/config_timings.py`, one run per configuration)
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r2_config_kernels.md; : > $OUT
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/${OUT_NAME:-r3_config_kernels.md}; : > $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in ${CFGS:-C1 C3k C3s C4s C4l C5}; do
   rm -rf /tmp/ck_$c
