@@ -2,16 +2,17 @@
 # Builds libzkgl.so (gfx950 only) in-tree.  Usage: era-zkevm_circuits_amd/build.sh
 set -euo pipefail
 cd "$(dirname "$0")/csrc"
-OUT=${ZKGL_OUT:-../libzkgl.so}   # ZKGL_OUT / ZKGL_DEFS: side-by-side kernel variants for tools/variant_bench.sh
+OUT=${ZKGL_OUT:-../libzkgl.so}   # ZKGL_OUT / ZKGL_DEFS / ZKGL_BUILD_DIR: side-by-side variants (host + device) for A/B runs
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value ${ZKGL_DEFS:-}"
-mkdir -p ../build
+BUILD=${ZKGL_BUILD_DIR:-../build}
+mkdir -p $BUILD
 pids=()
 for f in zkgl_device.hip; do
-  hipcc $FLAGS -c $f -o ../build/$(basename $f).o & pids+=($!)
+  hipcc $FLAGS -c $f -o $BUILD/$(basename $f).o & pids+=($!)
 done
 for f in comm.cpp witness_pack.cpp vm_pack.cpp cs.cpp cs_perm.cpp ntt.cpp gadgets.cpp poseidon_consts.cpp capi.cpp circuits/ram_permutation.cpp circuits/vm_shaped.cpp circuits/main_vm.cpp circuits/opcode_defs.cpp circuits/storage_validity.cpp circuits/log_sorter.cpp circuits/keccak.cpp circuits/sha256.cpp circuits/eip4844.cpp circuits/demux_log_queue.cpp circuits/sort_decommits.cpp circuits/code_unpacker.cpp circuits/linear_hasher.cpp; do
-  hipcc $FLAGS -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $f -o ../build/$(basename $f).o & pids+=($!)
+  hipcc $FLAGS -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $f -o $BUILD/$(basename $f).o & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../build/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $BUILD/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $(readlink -f $OUT)"

@@ -83,6 +83,21 @@ __device__ __forceinline__ TileAddr tile_addr(uint64_t* cells, uint64_t geom, ui
     return a;
 }
 
+// A table descriptor through the SCALAR unit.  `tables` is a plain global pointer: read as `tables[tid]` the compiler issues vector
+// loads, every field lands in VGPRs, and everything that depends on the descriptor — the dense / sorted branch, the byte-table
+// branch, the binary-search loop, the wait behind every gather — becomes per-lane control flow under exec masks (the strand kernel's
+// lookup body: one s_waitcnt vmcnt(0) per gather, the descriptor's key shifts staged through LDS).  The table id is wave-uniform
+// (it comes from a program word), so the descriptor is read from the constant address space: two scalar loads, fields in SGPRs,
+// scalar branches, gathers of a group back to back.
+typedef __attribute__((address_space(4))) const zk_table_desc* tdesc_ptr;
+__device__ __forceinline__ zk_table_desc load_table_desc(const zk_table_desc* tables, uint32_t tid) {
+    const tdesc_ptr p = (tdesc_ptr)(uintptr_t)tables + uni(tid);
+    zk_table_desc t;
+    t.word_off = p->word_off; t.mult_off = p->mult_off; t.n_rows = p->n_rows; t.n_keys = p->n_keys; t.n_vals = p->n_vals; t.dense = p->dense;
+    t.key_shift[0] = p->key_shift[0]; t.key_shift[1] = p->key_shift[1]; t.key_shift[2] = p->key_shift[2];
+    return t;
+}
+
 // locate the table row for a key tuple; returns n_rows when absent
 __device__ __forceinline__ uint32_t table_find(const zk_table_desc& t, const uint64_t* __restrict__ words,
                                                const uint64_t* key) {
@@ -554,7 +569,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         } break;
         case ZK_OP_LOOKUP: {
             const uint32_t tid = P.at(pc++);
-            const zk_table_desc t = sc.tables[tid];
+            const zk_table_desc t = load_table_desc(sc.tables, tid);
             const uint32_t nv = pb & 0xff;
             if constexpr (!SLOTS) {
                 // device programs: up to 8 independent lookups into one table under one header (cs.cpp emit_scope / build_strands);
@@ -1081,7 +1096,7 @@ __device__ __forceinline__ void check_gates_body(const CheckDev& cd) {
         const zk_lookup_row_desc lr = cd.lrows[slot];
         const uint32_t ntup = uni(lr.n_tuples);
         if (ntup) {
-            const zk_table_desc t = cd.tables[uni(lr.table)];
+            const zk_table_desc t = load_table_desc(cd.tables, lr.table);
             const uint32_t tw = t.n_keys + t.n_vals;
             for (uint32_t u = 0; u < ntup; ++u) {
                 const uint32_t c0 = cd.n_copy_cols + u * cd.lookup_width;

@@ -257,12 +257,10 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             out_to(W[2]);
             pc += 2 + D;
             st(x == 0 ? 1ull : 0ull);
-            // x^-1: flags and small counters dominate; 0 and 1 are their own (pseudo-)inverses, skip the 73-multiplication chain
-            // when the whole wavefront holds such values
 #ifdef ZKGL_STUB_INV  // time attribution only: no inversion
             st(x);
 #else
-            st(__builtin_amdgcn_ballot_w64(x > 1) == 0 ? x : gl::inv(x));
+            st(p2::inv_wave(x));   // small |x| in every lane (flags, counters, position differences): one gather instead of 72 multiplications
 #endif
         } break;
         case ZK_OP_UADD: {
@@ -314,7 +312,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
         } break;
         case ZK_OP_LOOKUP: {  // [table id][keys of every member]; pb = n_vals | (members - 1) << 8
             const uint32_t tid = W[1];
-            const zk_table_desc t = sc.tables[tid];
+            const zk_table_desc t = load_table_desc(sc.tables, tid);
             const uint32_t nv = pb & 0xff, grp = (pb >> 8) + 1;
             const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(sc.table_words + (t.dense >> 2));
             const uint32_t w = t.n_keys + t.n_vals;
@@ -337,13 +335,30 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #else
                         row[g] = table_find2(t, sc.table_words, k0[g], k1[g]);
 #endif
-                        const bool found = row[g] < t.n_rows;
+                    }
+                    // the value gathers of the whole group back to back, unconditionally (a missing key reads row 0 and is zeroed
+                    // below): no exec-masked branch and no wait between the members' gathers
+                    const bool bytes = (t.dense & 2u) != 0;   // scalar: packed one-byte values (xor8 / and8 / andn8 / byte splits ...)
+                    const bool two = nv > 1;
+                    uint64_t raw[N][2];
 #pragma unroll
-                        for (uint32_t i = 0; i < 2; ++i)
-                            if (i < nv)
-                                val[g][i] = !found ? 0ull
-                                            : (t.dense & 2u) ? (uint64_t)tb[(size_t)row[g] * t.n_vals + i]
-                                                             : sc.table_words[(size_t)t.word_off + (size_t)row[g] * w + t.n_keys + i];
+                    for (uint32_t g = 0; g < N; ++g) {
+                        const uint32_t rr = row[g] < t.n_rows ? row[g] : 0u;
+                        if (bytes) {
+                            const uint8_t* __restrict__ pv = tb + (size_t)rr * t.n_vals;
+                            raw[g][0] = nv ? pv[0] : 0;
+                            raw[g][1] = two ? pv[1] : 0;
+                        } else {
+                            const uint64_t* __restrict__ pv = sc.table_words + (size_t)t.word_off + (size_t)rr * w + t.n_keys;
+                            raw[g][0] = nv ? pv[0] : 0;
+                            raw[g][1] = two ? pv[1] : 0;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t g = 0; g < N; ++g) {
+                        const bool found = row[g] < t.n_rows;
+                        val[g][0] = found ? raw[g][0] : 0ull;
+                        val[g][1] = found ? raw[g][1] : 0ull;
                     }
 #pragma unroll
                     for (uint32_t g = 0; g < N; ++g) {
@@ -782,7 +797,7 @@ __device__ __forceinline__ void run_seed2(const ScopeDev& sc, const uint32_t ins
         case ZK_OP_ISZERO: {
             const uint64_t x = ldv(W[1]);
             stv(W[2], x == 0 ? 1ull : 0ull);
-            stv(W[3], __builtin_amdgcn_ballot_w64(x > 1) == 0 ? x : gl::inv(x));
+            stv(W[3], p2::inv_wave(x));
             pc += 4;
         } break;
         case ZK_OP_UADD: {
@@ -829,7 +844,7 @@ __device__ __forceinline__ void run_seed2(const ScopeDev& sc, const uint32_t ins
             pc += 2 + pa;
         } break;
         case ZK_OP_LOOKUP: {
-            const zk_table_desc t = sc.tables[W[1]];
+            const zk_table_desc t = load_table_desc(sc.tables, W[1]);
             const uint32_t nv = pb & 0xff;
             const uint64_t k0 = ldv(W[2]), k1 = pa > 1 ? ldv(W[3]) : 0, k2 = pa > 2 ? ldv(W[4]) : 0;
             const uint32_t row = table_find3(t, sc.table_words, k0, k1, k2);
@@ -1243,7 +1258,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_
             });
         } break;
         case ZK_CHECK_LOOKUP: {  // w2 = table id; cnt tuples of n_keys + n_vals (<= 4) slots each, (keys.., values..) must be a table row
-            const zk_table_desc t = cd.tables[W[2]];
+            const zk_table_desc t = load_table_desc(cd.tables, W[2]);
             const uint32_t nk = t.n_keys, nv = t.n_vals, tw = nk + nv;
             const uint8_t* __restrict__ tb = reinterpret_cast<const uint8_t*>(cd.table_words + (t.dense >> 2));
             dispatch_count<3>(cnt, [&](auto n_) {

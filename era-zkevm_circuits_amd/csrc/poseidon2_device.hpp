@@ -18,6 +18,24 @@ namespace p2 {
 // All device code is one translation unit (zkgl_device.hip), so the symbol is defined here.
 __constant__ uint64_t RC[360];
 
+// Inverses of the small field elements: INV_SMALL[k] = k^-1 mod p (0 for k = 0), filled by zk_init() beside the round constants.
+// The is_zero gadget's witness is x^-1, a 72-multiplication dependent chain when computed as x^(p-2); the zero-checks of the FSM
+// circuits compare buffer positions, counters and flags — x = d or p - d with d small — and there the inverse is one gather:
+// inv(p - d) = p - inv(d).  (keccak256_round_function: 1 690 zero-checks per cycle, one on the critical path of nearly every
+// dependency level of the strand kernel: 23.6 -> 18.6 ms with the inversions stubbed, profiles/r3_summary.md.)
+constexpr uint32_t INV_SMALL_N = 4096;
+__device__ uint64_t INV_SMALL[INV_SMALL_N];
+// x^-1 (0 -> 0): the table when every lane of the wavefront holds a small |x|, the addition chain otherwise — same value either way
+__device__ __forceinline__ uint64_t inv_wave(uint64_t x) {
+    const uint64_t nx = gl::P - x;
+    const bool pos = x < INV_SMALL_N, neg = nx < INV_SMALL_N;
+    if (__builtin_amdgcn_ballot_w64(!(pos || neg)) == 0) {
+        const uint64_t r = INV_SMALL[pos ? (uint32_t)x : (uint32_t)nx];
+        return pos ? r : gl::P - r;   // neg: x != 0 and x != p, so r != 0
+    }
+    return gl::inv(x);
+}
+
 constexpr int INNER_SHIFT[12] = {4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12};
 
 // M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] through the 8-addition chain; M_E = circ(2*M4, M4, M4); M_I = J + diag(2^k).

@@ -37,7 +37,19 @@ static inline unsigned grid_for(size_t n, int per_block, unsigned cap = 0x7fffff
 }
 
 int upload_round_constants(const uint64_t rc[360]) {
-    return chk(hipMemcpyToSymbol(HIP_SYMBOL(p2::RC), rc, 360 * sizeof(uint64_t)), "hipMemcpyToSymbol(RC)");
+    int e = chk(hipMemcpyToSymbol(HIP_SYMBOL(p2::RC), rc, 360 * sizeof(uint64_t)), "hipMemcpyToSymbol(RC)");
+    if (e) return e;
+    // inverses of 1 .. INV_SMALL_N - 1 by Montgomery's trick: prefix products, one exponentiation, back-substitution (host, once)
+    static uint64_t inv[p2::INV_SMALL_N];
+    auto mulm = [](uint64_t a, uint64_t b) { return (uint64_t)((unsigned __int128)a * b % 0xFFFFFFFF00000001ull); };
+    auto powm = [&](uint64_t a, uint64_t e2) { uint64_t r = 1; while (e2) { if (e2 & 1) r = mulm(r, a); a = mulm(a, a); e2 >>= 1; } return r; };
+    static uint64_t pre[p2::INV_SMALL_N];
+    pre[0] = 1;
+    for (uint32_t k = 1; k < p2::INV_SMALL_N; ++k) pre[k] = mulm(pre[k - 1], k);
+    uint64_t run = powm(pre[p2::INV_SMALL_N - 1], 0xFFFFFFFF00000001ull - 2);
+    inv[0] = 0;
+    for (uint32_t k = p2::INV_SMALL_N - 1; k >= 1; --k) { inv[k] = mulm(run, pre[k - 1]); run = mulm(run, k); }
+    return chk(hipMemcpyToSymbol(HIP_SYMBOL(p2::INV_SMALL), inv, sizeof inv), "hipMemcpyToSymbol(INV_SMALL)");
 }
 
 int launch_col(int op, uint64_t* dst, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint64_t q, uint64_t l,

@@ -562,14 +562,14 @@ def test_eip4844_gpu(zk):
 
 
 def test_eip4844_full_size_blobs_gpu(zk):
-    """the reference's size (4096 chunks, 934 blocks, ~1.17 M rows per blob): 3 blobs seeded, resolved and checked on the
+    """the reference's size (4096 chunks, 934 blocks, ~1.17 M rows per blob): BASELINE C5's 8 blobs seeded, resolved and checked on the
     device; linear hash / opening value / output hash agree with keccak256 + Python big-integer Horner through the public input"""
     from test_eip4844_host import make_instances, streams
     cs = zkgl.ConstraintSystem(zkgl.CSGeometry(60, 0, 8, 4), 1 << 21, 1 << 28)
     cs.configure_eip_4844()
     cs.eip_4844_entry_point(4096)
     cs.pad_and_shrink()
-    insts = make_instances(4096, [11, 12, 13])
+    insts = make_instances(4096, [11, 12, 13, 14, 15, 16, 17, 18])
     outer, loop = streams(insts)
     raw = loop.copy()
     raw[:217, :] = 0

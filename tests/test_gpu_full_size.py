@@ -153,15 +153,22 @@ def test_c3_sha256_round_function_2_20_rows(zk):
 def test_c4_storage_validity_2_22_rows(zk):
     cs, limit = fit(lambda c: c.configure_storage_validity(),
                     lambda c, l: c.sort_and_deduplicate_storage_access_entry_point(l, True), 22)
-    rng = np.random.default_rng(0xC4)
-    u, s = sn.random_storage_witness(rng, limit - 3, n_cells=512)
-    inst = sn.instance(u, s, limit)
-    assert inst["satisfiable"] and inst["completed"]
-    outer, loop = sn.pack_streams([inst], limit)
-    ok, f, keep = run_gpu(zk, cs, outer, loop, 1)
+    # BASELINE config C4: four sharded instances (one per GPU there; one batch of four different witnesses here)
+    insts, wit = [], []
+    for k in range(4):
+        rng = np.random.default_rng(0xC4 + 16 * k)
+        u, s = sn.random_storage_witness(rng, limit - 3 - 5 * k, n_cells=512 - 64 * k)
+        inst = sn.instance(u, s, limit)
+        assert inst["satisfiable"] and inst["completed"]
+        insts.append(inst); wit.append((u, s))
+    outer, loop = sn.pack_streams(insts, limit)
+    ok, f, keep = run_gpu(zk, cs, outer, loop, 4)
     assert ok, f
-    assert cs.public_inputs(0) == inst["commitment"]
+    for k in range(4):
+        assert cs.public_inputs(k) == insts[k]["commitment"]
+    assert len({tuple(i["commitment"]) for i in insts}) == 4
     del keep
+    u, s = wit[0]
     # not a permutation: one sorted record's written value changed -> grand products differ (entry-point check)
     q, ts = s[len(s) // 2]
     q = list(q); q[21] ^= 1
@@ -175,15 +182,19 @@ def test_c4_storage_validity_2_22_rows(zk):
 
 def test_c4_log_sorter_2_22_rows(zk):
     cs, limit = fit(lambda c: c.configure_log_sorter(), lambda c, l: c.sort_and_deduplicate_events_entry_point(l), 22)
-    rng = np.random.default_rng(0xC4 + 1)
-    u, s = ln.random_events(rng, int(limit / 1.1) - 8, rollback_frac=0.1)   # 10 % rollbacks, paired
-    assert len(u) <= limit
-    inst = ln.instance(u, s, limit)
-    assert inst["satisfiable"] and inst["completed"]
-    outer, loop = ln.pack_streams([inst], limit)
-    ok, f, keep = run_gpu(zk, cs, outer, loop, 1)
+    insts = []
+    for k in range(4):   # four sharded instances, as in BASELINE's C4
+        rng = np.random.default_rng(0xC4 + 1 + 16 * k)
+        u, s = ln.random_events(rng, int(limit / 1.1) - 8 - 3 * k, rollback_frac=0.1)   # 10 % rollbacks, paired
+        assert len(u) <= limit
+        inst = ln.instance(u, s, limit)
+        assert inst["satisfiable"] and inst["completed"]
+        insts.append(inst)
+    outer, loop = ln.pack_streams(insts, limit)
+    ok, f, keep = run_gpu(zk, cs, outer, loop, 4)
     assert ok, f
-    assert cs.public_inputs(0) == inst["commitment"]
+    for k in range(4):
+        assert cs.public_inputs(k) == insts[k]["commitment"]
     del keep
 
 
