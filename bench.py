@@ -372,7 +372,7 @@ def main():
         comm = zkgl.Comm(bytes(ids[0]), rank, world)
         commits = cs.gather_commitments(comm, stream)          # [world, B, 4] u64
         comm.close()
-        if not np.array_equal(commits[rank], local):
+        if not np.array_equal(commits[rank], local) and not os.environ.get("ZKGL_STUB_RUN"):  # stub variants store garbage
             raise RuntimeError("gathered commitments differ from this rank's public inputs")
     if rank == 0:
         n_inst = B * world
@@ -429,8 +429,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
                          "unit_of_work": "values (one per variable, 8 B): the variable store; trace cells are a view of it",
                          "avg_launch_ms": k_ms,
-                         # clock probe inside the kernel (s_memtime / s_memrealtime of its first wavefront): the kernel is ~2/3 VALU-busy
-                         # (profiles/r3_loop_probe.md), so its time follows the clock the power management grants the launch
+                         # clock probe inside the kernel (s_memtime / s_memrealtime of its first wavefront): the clock the power management
+                         # granted this launch (2.09-2.27 GHz seen; the kernel's time has not followed it, profiles/r3_loop_probe.md §4)
                          "shader_clock_mhz": float(np.mean(shader_mhz)),
                          "values_written_per_cycle": st["cells_written_loop"], "trace_cells_populated_per_cycle": st["cells_populated_loop"],
                          "trace_cell_equivalent_GBps": cell_bytes / (k_ms * 1e-3) / 1e9,

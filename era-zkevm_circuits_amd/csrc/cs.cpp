@@ -2176,8 +2176,7 @@ void CS::set_batch(uint32_t n) {
         // Lane tiling of the variable store (store_geom.hpp): 64-lane tiles (one per wavefront) unless ZKGL_STORE_TILE_LOG2=7..12 asks
         // for wider ones for the loop scope.  Wide tiles (a value = up to 32 KB contiguous, shared by 64 wavefronts) stream 5-8 % faster
         // in the bare store pattern (profiles/r3_layout_probe.jsonl) but NOT in the real kernel: 40.4-40.8 ms against 39.3-40.3 ms for
-        // k_witness_loop at B = 384, same box, four fresh processes each (profiles/r3_loop_probe.md) — the kernel is 2/3 VALU-busy and
-        // its time follows the shader clock, not the page placement.  The switch stays for such A/B runs; the buffer-addressed kernels
+        // k_witness_loop at B = 384, same box, four fresh processes each (profiles/r3_loop_probe.md §1).  The switch stays for such A/B runs; the buffer-addressed kernels
         // need slot << (T + 3) < 2^32.
         s.store_tile_log2 = zkgeom::WAVE_TILE_LOG2;
         if (s.is_loop) {

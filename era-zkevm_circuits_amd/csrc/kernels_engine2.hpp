@@ -672,7 +672,7 @@ __device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word
     lane = active ? lane : sc.n_lanes - 1;
     // clock probe (loop launch of resolve_and_check): the first wavefront of the grid reads the shader clock counter (s_memtime) and the
     // constant 100 MHz counter (s_memrealtime) around its own run — about half of the launch — so that the host can tell the
-    // shader clock the chip's power management gave THIS launch (the kernel is 2/3 VALU-busy: its time follows that clock)
+    // shader clock the chip's power management gave THIS launch (profiles/r3_loop_probe.md §4)
     const bool probe = sc.clock_probe && blockIdx.x == 0 && threadIdx.x < 64;
     uint64_t t0 = 0, r0 = 0;
     if (probe) { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
