@@ -58,6 +58,25 @@ def run_gpu(zk, cs, outer, loop, batch):
     return ok, f, (d_o, d_l)
 
 
+def assert_whole_trace_equals_oracle(zk, cs, outer, loop, k, limit, log_n):
+    """instance k of the resolved batch: every cell of its trace columns (zk_cs_trace_columns: loop rows, outer rows, zero padding)
+    against the oracle interpreter run on that instance's own streams — the witness columns at BASELINE's full size, not only the
+    commitments they hash to"""
+    st = cs.stats()
+    tables = zko.parse_export(cs.export(False))["tables"]
+    run = zko.CircuitRun(cs.export(False), cs.export(True), 1, int(sum(t["n_rows"] for t in tables)))
+    run.resolve(np.ascontiguousarray(outer[:, k:k + 1]), np.ascontiguousarray(loop[:, k * limit:(k + 1) * limit]))
+    n_cols, ls, osl = st["copy_columns"] + st["lookup_columns"], st["loop_slots"], st["outer_slots"]
+    cols = zk.DeviceBuffer(n_cols << log_n)
+    cs.trace_columns(k, cols, log_n)
+    got = cols.to_numpy().reshape(n_cols, 1 << log_n)
+    want_loop = run.lc[:ls * n_cols, :limit].reshape(ls, n_cols, limit).transpose(1, 2, 0).reshape(n_cols, limit * ls)
+    assert np.array_equal(got[:, :limit * ls], want_loop), "loop rows of the full-size trace differ from the oracle interpreter"
+    want_outer = run.oc[:osl * n_cols, 0].reshape(osl, n_cols).T
+    assert np.array_equal(got[:, limit * ls:limit * ls + osl], want_outer), "outer rows of the full-size trace differ from the oracle"
+    assert not got[:, limit * ls + osl:].any()
+
+
 def test_c1_ram_permutation_2_16_rows(zk):
     cs, limit = fit(lambda c: c.configure_ram_permutation(), lambda c, l: c.ram_permutation_entry_point(l), 16)
     rng = np.random.default_rng(0xC1)
@@ -71,6 +90,7 @@ def test_c1_ram_permutation_2_16_rows(zk):
     assert ok, f
     for i, inst in enumerate(insts):
         assert cs.public_inputs(i) == inst["commitment"]
+    assert_whole_trace_equals_oracle(zk, cs, outer, loop, 1, limit, 16)
     # order broken: swap two adjacent sorted items of instance 1 (heads/accumulators re-derived natively)
     u, s, nd = rn.random_ram_witness(np.random.default_rng(5), limit, n_cells=64)
     j = next(k for k in range(1, limit - 1) if s[k][:3] != s[k + 1][:3])
@@ -114,6 +134,7 @@ def test_c3_keccak256_round_function_2_20_rows(zk):
     assert ok, f
     for i, inst in enumerate(insts):
         assert cs.public_inputs(i) == inst["public_input"]
+    assert_whole_trace_equals_oracle(zk, cs, outer, loop, 1, limit, 20)
     loop[459, limit + 3] ^= 1   # a memory word read by instance 1 differs from the one its queue chain was built with
     ok, f, keep2 = run_gpu(zk, cs, outer, loop, len(insts))
     assert not ok and f.instance == 1
@@ -147,6 +168,7 @@ def test_c3_sha256_round_function_2_20_rows(zk):
     assert ok, f
     for i, inst in enumerate(insts):
         assert cs.public_inputs(i) == inst["public_input"]
+    assert_whole_trace_equals_oracle(zk, cs, outer, loop, 1, limit, 20)
     del keep
 
 
@@ -224,6 +246,9 @@ def test_c2_main_vm_2_20_rows(zk):
     for i in range(B):
         assert cs.public_inputs(i) == [int(x) for x in expect[i]], i
     assert int(cs.multiplicities(0).sum()) == st["lookups_per_instance"]
+    # the WHOLE trace of one full-size instance — 164 columns x 2^20 rows, every cell — against the oracle interpreter run on that
+    # instance's streams: the witness columns the prover would commit to (zk_cs_trace_columns), not only the commitments
+    assert_whole_trace_equals_oracle(zk, cs, outer, seeded, 3, limit, 20)
     # a flipped limb of an opcode word in the middle of instance 5
     lay = cs.main_vm_layout()["loop"]
     bad = seeded.copy()
