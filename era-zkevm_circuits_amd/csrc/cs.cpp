@@ -119,7 +119,8 @@ void CS::free_scope_device(Scope& s) {
     s.d_cprog_fused = nullptr; s.d_cchunks_fused = nullptr;
     if (s.d_mult_sites) hipFree(s.d_mult_sites);
     if (s.d_sprog) hipFree(s.d_sprog);
-    s.d_sprog = nullptr;
+    if (s.d_sprog_n) hipFree(s.d_sprog_n);
+    s.d_sprog = nullptr; s.d_sprog_n = nullptr;
     if (s.d_consts) hipFree(s.d_consts);
     if (s.d_rows) hipFree(s.d_rows);
     if (s.d_rowconsts) hipFree(s.d_rowconsts);
@@ -1165,9 +1166,17 @@ void CS::emit_dests(const Scope& s, const OpRec& op, std::vector<uint32_t>& out)
 // its operands inside the phase; the ops of a level are independent of each other and are dealt out over the 8 strands
 // (heaviest first, always to the lightest strand); every strand ends the level with ZK_OP_BARRIER.  Values cross strands only
 // through the cells, between levels.
-void CS::build_strands(Scope& s) {
-    constexpr uint32_t NS = zkdev::STRANDS_PER_TILE;
-    s.sprog.clear();
+void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
+    // narrow: the second strand form of a loop scope (NARROW_STRANDS per tile) kept beside the full one; launch_phase picks by tile count
+    constexpr uint32_t NS_MAX = zkdev::STRANDS_PER_TILE;
+    if (NS == 0 || NS > NS_MAX) throw ZkError(ZK_ERR_INVALID, "internal: strand count");
+    std::vector<uint32_t>& sprog = narrow ? s.sprog_n : s.sprog;
+    auto& s_begin = narrow ? s.sn_begin : s.s_begin;
+    auto& s_end = narrow ? s.sn_end : s.s_end;
+    auto& s_levels = narrow ? s.sn_levels : s.s_levels;
+    auto& s_gain = narrow ? s.sn_gain : s.s_gain;
+    sprog.clear();
+    for (int ph0 = 0; ph0 < 3; ++ph0) for (uint32_t k = 0; k < NS_MAX; ++k) s_begin[ph0][k] = s_end[ph0][k] = 0;
     const size_t n_ops = s.ops.size();
     size_t bounds[4] = {0, n_ops, n_ops, n_ops};
     if (!s.is_loop) { bounds[1] = std::min(s.pre_ops, n_ops); bounds[2] = std::min(std::max(s.side_ops, bounds[1]), n_ops); }
@@ -1231,8 +1240,8 @@ void CS::build_strands(Scope& s) {
         for (uint32_t lv = 0; lv < n_levels; ++lv) {
             auto& ops = by_level[lv];
             std::stable_sort(ops.begin(), ops.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
-            uint64_t load[NS] = {0};
-            std::vector<uint32_t> mine[NS];
+            uint64_t load[NS_MAX] = {0};
+            std::vector<uint32_t> mine[NS_MAX];
             for (uint32_t oi : ops) {
                 uint32_t best = 0;
                 for (uint32_t k = 1; k < NS; ++k) if (load[k] < load[best]) best = k;
@@ -1283,19 +1292,19 @@ void CS::build_strands(Scope& s) {
             critical += *std::max_element(load, load + NS) + 200;  // + the barrier: every strand drains its stores
             if (lv + 1 < n_levels) for (auto& st : strand) st.push_back(ZK_OP_BARRIER);
         }
-        s.s_gain[ph] = critical ? (float)total / (float)critical : 0.f;
+        s_gain[ph] = critical ? (float)total / (float)critical : 0.f;
         if (getenv("ZKGL_STRANDS_DEBUG") && o1 > o0) {
             uint32_t narrow = 0, wide = 0;
             for (auto& l : by_level) { narrow += l.size() < 8; wide += l.size() >= 64; }
             fprintf(stderr, "[zkgl] strands %s phase %d: %zu ops, %u levels (%u with fewer than 8 ops, %u with 64 or more), estimated gain %.2f\n",
-                    s.is_loop ? "loop" : "outer", ph, o1 - o0, n_levels, narrow, wide, s.s_gain[ph]);
+                    s.is_loop ? "loop" : "outer", ph, o1 - o0, n_levels, narrow, wide, s_gain[ph]);
         }
         for (uint32_t k = 0; k < NS; ++k) {
-            s.s_begin[ph][k] = (uint32_t)s.sprog.size();
-            s.sprog.insert(s.sprog.end(), strand[k].begin(), strand[k].end());
-            s.s_end[ph][k] = (uint32_t)s.sprog.size();
+            s_begin[ph][k] = (uint32_t)sprog.size();
+            sprog.insert(sprog.end(), strand[k].begin(), strand[k].end());
+            s_end[ph][k] = (uint32_t)sprog.size();
         }
-        s.s_levels[ph] = n_levels;
+        s_levels[ph] = n_levels;
     }
 }
 
@@ -1321,8 +1330,19 @@ void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* strea
         dev_check(zkdev::launch_witness(a, w0, w1, slot0, stream));
         return;
     }
+    // Strands per tile: 16 wavefronts of a tile share its levels' work, but only two such workgroups fit a CU; a loop scope with more
+    // tiles than that (keccak FSM at 128 instances: 672 tiles on 256 CUs) runs them in rounds.  The narrow form (8 strands: four
+    // workgroups per CU) keeps every tile resident: keccak FSM 23.7 -> 20.8 ms; eip_4844 (120 tiles) is 1.24 x slower with it and
+    // keeps 16 (profiles/r3_strands_ab.txt).  ZKGL_STRANDS_NARROW=0 / 1 forces the choice.
+    bool narrow = s.is_loop && s.d_sprog_n && phase == 0 && waves > 2 * 256;
+    if (const char* ne = getenv("ZKGL_STRANDS_NARROW")) narrow = s.is_loop && s.d_sprog_n && phase == 0 && ne[0] == '1';
+    if (narrow) {
+        a.prog = s.d_sprog_n; a.n_words = (uint32_t)s.sprog_n.size();
+        dev_check(zkdev::launch_witness_strands(a, s.sn_begin[phase], s.sn_end[phase], stream, NARROW_STRANDS));
+        return;
+    }
     a.prog = s.d_sprog; a.n_words = (uint32_t)s.sprog.size();
-    dev_check(zkdev::launch_witness_strands(a, s.s_begin[phase], s.s_end[phase], stream));
+    dev_check(zkdev::launch_witness_strands(a, s.s_begin[phase], s.s_end[phase], stream, zkdev::STRANDS_PER_TILE));
 }
 
 // one operand word of the scalar-decoded device forms (kernels_engine2.hpp): data operands are bare store slots, FMA / LC4 /
@@ -2003,6 +2023,11 @@ void CS::upload_scope(Scope& s) {
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
         s.d_sprog = upload(padded);
     }
+    if (!s.sprog_n.empty()) {
+        std::vector<uint32_t> padded(s.sprog_n);
+        padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
+        s.d_sprog_n = upload(padded);
+    }
     if (!s.mult_sites.empty()) s.d_mult_sites = upload(s.mult_sites);
     s.d_consts = upload(s.const_pool);
     s.d_rows = upload(s.rows);
@@ -2040,7 +2065,11 @@ void CS::finalize() {
     build_mult_sites(outer_);
     build_mult_sites(loop_);
     build_strands(outer_);
-    if (limit_) build_strands(loop_);
+    if (limit_) {
+        build_strands(loop_);
+        // the narrow form only where the full form would be used at all (wide op graphs: the hash circuits)
+        if (loop_.s_gain[0] >= 3.2f && zkdev::STRANDS_PER_TILE > NARROW_STRANDS) build_strands(loop_, NARROW_STRANDS, true);
+    }
     uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
     if (!loop_done_) rows = outer_.n_slots;
     if (rows > max_trace_len_) throw ZkError(ZK_ERR_CAPACITY, "trace rows exceed max_trace_len");

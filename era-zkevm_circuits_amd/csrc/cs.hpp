@@ -116,6 +116,12 @@ struct Scope {
     uint32_t s_begin[3][zkdev::STRANDS_PER_TILE] = {}, s_end[3][zkdev::STRANDS_PER_TILE] = {};
     uint32_t s_levels[3] = {0, 0, 0};
     float s_gain[3] = {0, 0, 0};  // estimated work / critical path over 8 strands: the strand form is used from 3 upwards
+    // narrow strand form (loop scopes with a wide op graph): NARROW_STRANDS per tile, used when the tiles outnumber what the chip
+    // keeps resident at STRANDS_PER_TILE wavefronts each (launch_phase)
+    std::vector<uint32_t> sprog_n;
+    uint32_t sn_begin[3][zkdev::STRANDS_PER_TILE] = {}, sn_end[3][zkdev::STRANDS_PER_TILE] = {};
+    uint32_t sn_levels[3] = {0, 0, 0};
+    float sn_gain[3] = {0, 0, 0};
     std::vector<zk_row_desc> rows;
     std::vector<uint64_t> rowconsts;
     std::vector<zk_lookup_row_desc> lrows;
@@ -136,6 +142,7 @@ struct Scope {
     uint32_t* d_cchunks_fused = nullptr;
     uint32_t* d_mult_sites = nullptr;
     uint32_t* d_sprog = nullptr;
+    uint32_t* d_sprog_n = nullptr;
     uint64_t* d_consts = nullptr;
     zk_row_desc* d_rows = nullptr;
     uint64_t* d_rowconsts = nullptr;
@@ -274,7 +281,8 @@ class CS {
     // compact trace -> full trace (kernels_engine.hpp k_materialize); no-op when the trace is already materialised
     void ensure_materialized(void* stream);
     bool compact_ = true;
-    void build_strands(Scope& s);
+    static constexpr uint32_t NARROW_STRANDS = 8;
+    void build_strands(Scope& s, uint32_t n_strands = zkdev::STRANDS_PER_TILE, bool narrow = false);
     void assign_store_slots(Scope& s);
     uint32_t home(const Scope& s, uint32_t var) const { return emit_full_ ? s.var_cells[var][0] : s.var_slot[var]; }
     void check_streams(void* stream, bool compact);

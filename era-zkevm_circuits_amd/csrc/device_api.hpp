@@ -58,7 +58,9 @@ constexpr uint32_t STRANDS_PER_TILE = ZKGL_STRANDS_PER_TILE;
 // the seeding kernels keep 8: a seeding pass is a latency chain per instance and its throughput is the number of resident blocks
 // (2048 instances: 2.5 s with 8-wave blocks, 3.6 s with 16-wave blocks)
 constexpr uint32_t SEED_STRANDS_PER_TILE = 8;
-int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], void* stream);
+// n_strands <= STRANDS_PER_TILE wavefronts per tile walk strands 0 .. n_strands - 1 (the program was dealt for that many)
+int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], void* stream,
+                           uint32_t n_strands = STRANDS_PER_TILE);
 struct CarryArgs { uint32_t word, out_cell, first_outer_cell, has_first; };  // mirrors zke::CarryDev
 // op-parallel seeding (kernels_seed_wave.hpp): one wavefront per instance, the program resident in LDS
 bool seed_wave_fits(uint32_t prog_u16, uint32_t n_slots, uint32_t n_input_words);

@@ -147,17 +147,19 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
     return LAUNCH_CHECK("k_witness");
 }
 
-int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], void* stream) {
+int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER_TILE], const uint32_t end[STRANDS_PER_TILE], void* stream, uint32_t n_strands) {
     if (sc.n_lanes == 0) return 0;
+    if (n_strands == 0 || n_strands > STRANDS_PER_TILE) { g_hip_err = "launch_witness_strands: strand count"; return -1; }
+    const unsigned block = 64 * n_strands;   // one wavefront per strand; the barrier of a level spans exactly these
     static_assert(zke::STRANDS_PER_TILE == (int)STRANDS_PER_TILE, "strand count");
     zke::StrandTab tab;
     bool any = false;
     for (int i = 0; i < zke::STRANDS_PER_TILE; ++i) { tab.begin[i] = begin[i]; tab.end[i] = end[i]; any |= end[i] > begin[i]; }
     if (!any) return 0;
     const unsigned grid = grid_for(sc.n_lanes, 64);
-    if (needs_wide_addressing(sc.n_cells)) zke::k_witness_strands2<true, true><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);  // 64-bit addressing
-    else if (sc.uses_bigint) zke::k_witness_strands2<true, false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
-    else zke::k_witness_strands2<false, false><<<grid, 64 * zke::STRANDS_PER_TILE, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
+    if (needs_wide_addressing(sc.n_cells)) zke::k_witness_strands2<true, true><<<grid, block, 0, (hipStream_t)stream>>>(to_dev(sc), tab);  // 64-bit addressing
+    else if (sc.uses_bigint) zke::k_witness_strands2<true, false><<<grid, block, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
+    else zke::k_witness_strands2<false, false><<<grid, block, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
     return LAUNCH_CHECK("k_witness_strands");
 }
 

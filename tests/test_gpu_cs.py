@@ -713,3 +713,14 @@ def test_linear_hasher_gpu(zk):
     run = zko.CircuitRun(cs.export(False), cs.export(True), 2, TABLE_ROWS)
     run.resolve(outer[:, :2], loop[:, :2])
     assert np.array_equal(cs.trace(True)[:, :2], run.lc[:, :2]) and np.array_equal(cs.trace(False)[:, :2], run.oc[:, :2])
+
+
+def test_narrow_strand_form_gpu(zk, monkeypatch):
+    """loop scopes with a wide op graph keep a second strand program dealt over 8 wavefronts per tile (launch_phase picks it when
+    the tiles outnumber what the chip keeps resident at 16); forced here at test sizes: same traces, digests and verdicts"""
+    monkeypatch.setenv("ZKGL_STRANDS", "1")
+    monkeypatch.setenv("ZKGL_STRANDS_NARROW", "1")
+    test_keccak256_round_function_fsm_gpu(zk)
+    test_sha256_round_function_fsm_gpu(zk)
+    test_eip4844_gpu(zk)
+    test_keccak256_gpu_digests(zk)
