@@ -1028,6 +1028,14 @@ class ConstraintSystem:
     def bind_inputs(self, loop_scope: bool, dev_words, n_words: int, lane_stride: int = 0, lane_offset: int = 0):
         """lane_stride / lane_offset: the batch is a window of a longer stream ([word][lane_stride] u64, first lane lane_offset)"""
         self._keep_inputs[bool(loop_scope)] = dev_words   # one reference per scope: the bound buffer must outlive the binding
+        # a DeviceBuffer knows its length (the C ABI takes a bare pointer): the window of the bound batch must lie inside it
+        if isinstance(dev_words, DeviceBuffer) and getattr(self, "batch", 0):
+            if getattr(self, "_limit_cache", None) is None:
+                self._limit_cache = int(self.stats()["limit"])
+            lanes = self.batch * (self._limit_cache if loop_scope else 1)
+            stride = lane_stride or lanes
+            if n_words and (n_words - 1) * stride + lane_offset + lanes > dev_words.n:
+                raise ZkError(-1, f"bind_inputs: {n_words} words x {lanes} lanes (stride {stride}, offset {lane_offset}) exceed the buffer's {dev_words.n} words")
         if lane_stride or lane_offset:
             base = (_ptr(dev_words).value or 0) + 8 * lane_offset
             _check(lib().zk_cs_bind_inputs_window(self._h, int(loop_scope), C.c_void_p(base), n_words, C.c_uint64(lane_stride)))
