@@ -1415,6 +1415,7 @@ struct MultDev {
     const uint32_t* sites; uint32_t n_sites;   // 3 key slots per site (0xffffffff: absent)
     zk_table_desc t; const uint64_t* table_words;
     uint32_t* mult; uint32_t total_table_rows; uint32_t chunk_rows;
+    uint32_t site_splits;   // >= 1: gridDim.z = lane ranges x site_splits — few instances x few lanes (eip_4844: 8 blobs) still fill the chip
 };
 constexpr uint32_t MULT_CHUNK_ROWS = 32768;
 __global__ __launch_bounds__(1024) void k_multiplicities(MultDev a) {
@@ -1423,11 +1424,13 @@ __global__ __launch_bounds__(1024) void k_multiplicities(MultDev a) {
     const uint32_t rows_here = min(a.chunk_rows, a.t.n_rows - base);
     for (uint32_t i = threadIdx.x; i < rows_here; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    // few instances: gridDim.z workgroups share an instance, each takes a contiguous range of its lanes (multiples of 64)
-    const uint32_t per = ((a.lanes_per_instance + gridDim.z - 1) / gridDim.z + 63) & ~63u;
-    const uint32_t lo = blockIdx.z * per, hi = min(lo + per, a.lanes_per_instance);
+    // few instances: gridDim.z workgroups share an instance, each takes a contiguous range of its lanes (multiples of 64) and one of
+    // site_splits interleaved subsets of the sites
+    const uint32_t lane_splits = gridDim.z / a.site_splits, lane_split = blockIdx.z / a.site_splits, site_split = blockIdx.z % a.site_splits;
+    const uint32_t per = ((a.lanes_per_instance + lane_splits - 1) / lane_splits + 63) & ~63u;
+    const uint32_t lo = lane_split * per, hi = min(lo + per, a.lanes_per_instance);
     const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, l0 = threadIdx.x & 63;
-    for (uint32_t site = wave; site < a.n_sites; site += n_waves) {
+    for (uint32_t site = site_split * n_waves + wave; site < a.n_sites; site += n_waves * a.site_splits) {
         const uint32_t s0 = uni(a.sites[3 * site]), s1 = uni(a.sites[3 * site + 1]), s2 = uni(a.sites[3 * site + 2]);
         for (uint32_t l = lo + l0; l < hi; l += 64) {
             const uint32_t lane = inst * a.lanes_per_instance + l;

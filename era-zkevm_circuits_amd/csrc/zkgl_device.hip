@@ -237,9 +237,15 @@ int launch_multiplicities(const uint64_t* store, uint64_t n_store, uint32_t lane
     // >= ~512 workgroups: few instances share each one among several workgroups (lane ranges)
     uint32_t splits = std::max<uint32_t>(1, 512 / std::max<uint32_t>(1, chunks * n_instances));
     splits = std::min<uint32_t>(splits, std::max<uint32_t>(1, lanes_per_instance / 256));
-    dim3 grid(chunks, n_instances, splits);
     // one wavefront per site at a time: small site lists (outer scopes) do not need 16 wavefronts
     const unsigned threads = n_sites >= 16 ? 1024 : 256;
+    // still short of ~512 workgroups (eip_4844: 8 blobs x 2 chunks x 3 lane ranges = 48 on 256 CUs): split the sites as well, each
+    // workgroup keeping at least two rounds of sites for its wavefronts
+    uint32_t site_splits = std::max<uint32_t>(1, 512 / std::max<uint32_t>(1, chunks * n_instances * splits));
+    site_splits = std::min<uint32_t>(site_splits, std::max<uint32_t>(1, n_sites / (2 * (threads / 64))));
+    site_splits = std::min<uint32_t>(site_splits, 65535u / std::max<uint32_t>(1, splits));
+    a.site_splits = site_splits;
+    dim3 grid(chunks, n_instances, splits * site_splits);
     zke::k_multiplicities<<<grid, threads, 0, (hipStream_t)stream>>>(a);
     return LAUNCH_CHECK("k_multiplicities");
 }
