@@ -5,8 +5,8 @@
 // T = 6 (the default everywhere): a wavefront owns one contiguous tile of n_slots * 512 B.
 // T = 7..12 (ZKGL_STORE_TILE_LOG2, loop scopes): 2^(T-6) wavefronts share a tile and a value of the tile is 2^(T+3) B contiguous.  The
 // bare store pattern of the loop kernel streams 5-8 % faster with T = 12 and stops depending on where the pages of the allocation sit
-// (tools/layout_probe.hip, profiles/r3_layout_probe.jsonl); the real kernel does not gain (profiles/r3_loop_probe.md: it is VALU-issue
-// bound for two thirds of its time), so the wide tiling is an A/B switch, covered by tests/test_gpu_store_tiling.py, not the default.
+// (tools/layout_probe.hip, profiles/r3_layout_probe.jsonl); the real kernel does not gain (profiles/r3_loop_probe.md §1: 40.4-40.8 ms
+// against 39.3-40.3 ms), so the wide tiling is an A/B switch, covered by tests/test_gpu_store_tiling.py, not the default.
 //
 // A store travels through the launch interface as (pointer, geometry word): the slot count with T in the top byte.  A bare slot count
 // (top byte 0) means T = 6, so interfaces that only ever see 64-lane-tiled memory pass their counts unchanged.
