@@ -1432,14 +1432,26 @@ __global__ __launch_bounds__(1024) void k_multiplicities(MultDev a) {
     const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, l0 = threadIdx.x & 63;
     for (uint32_t site = site_split * n_waves + wave; site < a.n_sites; site += n_waves * a.site_splits) {
         const uint32_t s0 = uni(a.sites[3 * site]), s1 = uni(a.sites[3 * site + 1]), s2 = uni(a.sites[3 * site + 2]);
-        for (uint32_t l = lo + l0; l < hi; l += 64) {
-            const uint32_t lane = inst * a.lanes_per_instance + l;
-            if (lane >= a.n_lanes) break;
-            const uint64_t k0 = a.store[cell_off(a.n_store, s0, lane)];
-            const uint64_t k1 = s1 != 0xffffffffu ? a.store[cell_off(a.n_store, s1, lane)] : 0;
-            const uint64_t k2 = s2 != 0xffffffffu ? a.store[cell_off(a.n_store, s2, lane)] : 0;
-            const uint32_t row = table_find3(a.t, a.table_words, k0, k1, k2);
-            if (row < a.t.n_rows && row - base < rows_here) atomicAdd(&cnt[row - base], 1u);
+        // four lane groups per trip: the key loads of all four go out before the first table search (the pass is bandwidth-bound on
+        // re-read keys; one group at a time left each wavefront with two or three loads in flight)
+        for (uint32_t l = lo + l0; l < hi; l += 256) {
+            uint64_t k0[4], k1[4], k2[4];
+            bool live[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t ll = l + 64 * j;
+                const uint32_t lane = inst * a.lanes_per_instance + ll;
+                live[j] = ll < hi && lane < a.n_lanes;
+                const uint32_t la = live[j] ? lane : inst * a.lanes_per_instance + lo;   // a lane of this range: loaded, not counted
+                k0[j] = a.store[cell_off(a.n_store, s0, la)];
+                k1[j] = s1 != 0xffffffffu ? a.store[cell_off(a.n_store, s1, la)] : 0;
+                k2[j] = s2 != 0xffffffffu ? a.store[cell_off(a.n_store, s2, la)] : 0;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t row = table_find3(a.t, a.table_words, k0[j], k1[j], k2[j]);
+                if (live[j] && row < a.t.n_rows && row - base < rows_here) atomicAdd(&cnt[row - base], 1u);
+            }
         }
     }
     __syncthreads();
