@@ -932,9 +932,10 @@ bool CS::inline_multiplicities() const {
 }
 
 // multiplicities of the batch from the resolved variable stores (PASS mode): per scope, per table
-void CS::count_multiplicities(void* stream) {
+void CS::count_multiplicities(void* stream, int scopes) {
     if (inline_multiplicities() || !total_table_rows_) return;
     for (int sc = 0; sc < 2; ++sc) {
+        if (!(scopes & (1 << sc))) continue;   // bit 0: outer scope, bit 1: loop scope
         const Scope& s = sc ? loop_ : outer_;
         if ((sc && !limit_) || !s.d_mult_sites) continue;
         for (size_t t = 1; t <= tables_.size(); ++t) {
@@ -2782,8 +2783,12 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
         hip_check(hipEventRecord(E(5), st), "event");
     }
     hip_check(hipEventRecord(E(6), st), "event");
+    // the lookup multiplicities of the batch (k_multiplicities, no atomics in the witness kernels): the loop scope's pass needs only
+    // the loop kernels and runs underneath the outer POST phase of the auxiliary stream (keccak FSM: a 5.7 ms pass under a 6.6 ms
+    // phase of sequential commitments); the outer scope's after it
+    count_multiplicities(st, 2);
     hip_check(hipStreamWaitEvent(st, E(4), 0), "wait");
-    count_multiplicities(st);   // both scopes resolved: the lookup multiplicities of the batch (k_multiplicities, no atomics in the witness kernels)
+    count_multiplicities(st, 1);
     if (limit_) {
         dev_check(zkdev::launch_check_links(loop_.d_store, loop_.store_geom(), loop_.n_lanes, limit_, outer_.d_store,
                                             outer_.store_geom(), d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));

@@ -291,7 +291,7 @@ class CS {
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream, uint32_t n_lanes = 0) const;  // n_lanes: lane count when the arguments were patched for a stream
     void build_check_program(Scope& s);
     void build_mult_sites(Scope& s);
-    void count_multiplicities(void* stream);
+    void count_multiplicities(void* stream, int scopes = 3);
     // true: wave-aggregated atomics inside the witness kernels; false: the k_multiplicities pass after them (cs.cpp)
     bool inline_multiplicities() const;
     void operand_v2(const Scope& s, const OpRec& op, size_t pos, std::vector<uint32_t>& out) const;
