@@ -1,6 +1,11 @@
 // zkgl_device.hip — the ONE device translation unit of libzkgl.so (gfx950 only).
 // Kernels live in kernels_primitives.hpp / kernels_engine.hpp; this file holds the launchers.
 #include <hip/hip_runtime.h>
+// Several kernels size their static LDS for gfx950's 160 KB per CU (k_seed_wave 156 KB, k_multiplicities 128 KB): refuse other targets
+// at compile time instead of failing at launch.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libzkgl's kernels are written for gfx950 (MI355X): LDS sizes, DPP rows and buffer addressing assume it"
+#endif
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
