@@ -1,4 +1,4 @@
-"""Prover-stage kernels on the bench workload (main_vm-shaped, 2^20 rows per instance): K10 lookup accumulators, K12 copy-permutation
+"""Prover-stage kernels on the bench workload (the REAL main_vm cycle since round 3, 2^20 rows per instance): K10 lookup accumulators, K12 copy-permutation
 grand product over the whole batch, and for one instance trace columns -> coefficients -> x8 coset LDE (K11).
 GPU box, repo root: python tools/prover_stage_bench.py [batch] -> one JSON line (wall-clock around synchronous calls, second call)."""
 import json, os, sys, time
@@ -7,14 +7,18 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "era-zkevm_circuits_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import zkgl
-from bench import build_vm_cs, vm_inputs
+from bench import build_main_vm_cs, main_vm_streams
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 zkgl.init(0)
 dev = torch.device("cuda", 0)
-cs, limit = build_vm_cs(zkgl, 20)
+cs, limit = build_main_vm_cs(zkgl, 20)
 n_outer, n_loop = cs.input_words()
-outer, loop = vm_inputs(np.random.default_rng(0xC2), n_outer, n_loop, B, limit)
+o64, l64, _ = main_vm_streams(zkgl, cs, limit)      # the fixture's 64 executions; instance i replays execution i mod 64
+E = o64.shape[1]
+idx = np.arange(B) % E
+outer = np.ascontiguousarray(o64[:, idx])
+loop = np.ascontiguousarray(l64.reshape(l64.shape[0], E, limit)[:, idx, :].reshape(l64.shape[0], B * limit))
 cs.set_batch(B)
 d_outer = torch.from_numpy(outer.view(np.int64)).to(dev)
 d_loop = torch.from_numpy(loop.view(np.int64)).to(dev)
