@@ -328,7 +328,8 @@ int zk_cs_resolve(zk_cs* cs, void* stream) {
 }
 int zk_cs_seed_window_async(zk_cs* cs, uint32_t n_instances, const uint64_t* dev_outer_window, uint64_t outer_lane_stride, uint64_t* dev_loop_window_rw,
                             uint64_t loop_lane_stride, void* stream) {
-    NEED(cs);
+    NEED(cs); NEED_INIT();
+    if (n_instances && (!dev_outer_window || !dev_loop_window_rw)) return fail(ZK_ERR_INVALID, "zk_cs_seed_window_async: null window");
     return guard([&] { cs->cs->seed_stream(n_instances, dev_outer_window, dev_loop_window_rw, stream, false, outer_lane_stride, loop_lane_stride); });
 }
 int zk_cs_carried_words(zk_cs* cs, uint32_t* words, uint32_t max_words, uint32_t* n_words) {
@@ -349,6 +350,11 @@ int zk_cs_set_seed_given(zk_cs* cs, const uint32_t* loop_words, uint32_t n_words
 int zk_cs_seed_carried_inputs(zk_cs* cs, uint64_t* dev_loop_inputs_rw, void* stream) {
     NEED(cs); NEED_INIT();
     return guard([&] { cs->cs->seed_carried_inputs(dev_loop_inputs_rw, stream); });
+}
+int zk_cs_set_check_mode(zk_cs* cs, uint32_t mode) {
+    NEED(cs);
+    if (mode > ZK_CHECK_STORED) return fail(ZK_ERR_INVALID, "zk_cs_set_check_mode: unknown mode");
+    return guard([&] { cs->cs->set_check_mode(mode == ZK_CHECK_STORED); });
 }
 int zk_cs_check_satisfied(zk_cs* cs, void* stream, zk_failure* first) {
     NEED(cs); NEED_INIT();

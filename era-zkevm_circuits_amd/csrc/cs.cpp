@@ -686,9 +686,12 @@ void CS::build_check_program(Scope& s) {
                 uint64_t c;
                 m = op && op->opcode == ZK_OP_CONST && pool(op->ins[0], c) && c == g.consts[0];
             } break;
-            case ZK_GATE_BOOLEAN: {   // a flag some op produces as 0 / 1 by construction
+            case ZK_GATE_BOOLEAN: {   // a flag some op produces as 0 / 1 for EVERY input: the is-zero flag, a masked 1-bit chunk of a SPLIT.
+                // NOT the last chunk of a SPLIT: it keeps the residual x >> (n-1) unmasked (kernels_engine2.hpp ZK_OP_SPLIT), which is
+                // 0 / 1 only when x < 2^n — exactly what this gate is placed to enforce (spread_into_bits: the range check of x)
                 const OpRec* op = prod(g.vars[0]);
-                m = op && ((op->opcode == ZK_OP_ISZERO && op->outs[0] == g.vars[0]) || (op->opcode == ZK_OP_SPLIT && op->b == 1));
+                m = op && ((op->opcode == ZK_OP_ISZERO && op->outs[0] == g.vars[0]) ||
+                           (op->opcode == ZK_OP_SPLIT && op->b == 1 && !op->outs.empty() && op->outs.back() != g.vars[0]));
             } break;
             default: break;
             }
@@ -2757,7 +2760,7 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     // FUSED mode (default): the witness kernels evaluate the gates mirrored by their producing ops on the values they hold, the
     // checkers read what is left.  ZKGL_VERIFY_STORED=1: every gate re-evaluated from the stored values (what check_if_satisfied does).
     const char* vs = std::getenv("ZKGL_VERIFY_STORED");
-    const bool fused = !(vs && vs[0] == '1') && outer_.d_cprog_fused && (!limit_ || loop_.d_cprog_fused);
+    const bool fused = !check_stored_ && !(vs && vs[0] == '1') && outer_.d_cprog_fused && (!limit_ || loop_.d_cprog_fused);
     last_check_fused_ = fused;
     if (fused) { oa.fail = d_fail_; la.fail = d_fail_ + 3; }
     la.clock_probe = d_fail_ + 6;   // words 6, 7 of the block travel back with the verdict
@@ -2925,6 +2928,16 @@ void CS::stats(zk_stats* o) const {
     o->loop_store_tile_lanes = batch_ ? (1ull << loop_.store_tile_log2) : 0;
     o->copy_pairs_outer = outer_.copies.size(); o->copy_pairs_loop = loop_.copies.size();
     o->seed_ops = seed_ops_; o->seed_words = seed_prog_.size(); o->seed_slots = seed_slots_; o->loop_ops = loop_.ops.size();
+    // fused mode: relations left to the check program (gates not mirrored by their producing op) / evaluated where they are produced
+    auto from_store = [](const Scope& s) {
+        uint64_t n = 0;
+        for (size_t gi = 0; gi < s.gates.size(); ++gi)
+            if (gi >= s.gate_mirrored.size() || !s.gate_mirrored[gi]) n += GATES[s.gates[gi].kind].n_relations;
+        return n;
+    };
+    const bool fused_ok = !outer_.cprog_fused.empty() && (!limit_ || !loop_.cprog_fused.empty());
+    o->constraints_from_store_fused = fused_ok ? from_store(outer_) + from_store(loop_) * limit_ : o->constraints_per_instance;
+    o->constraints_in_witness_fused = o->constraints_per_instance - o->constraints_from_store_fused;
 }
 
 float CS::last_ms(int which) const {

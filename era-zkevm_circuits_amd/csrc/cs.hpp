@@ -227,6 +227,7 @@ class CS {
     uint32_t layout_word(const char* scope, const char* name) const;
     int check_satisfied(void* stream, zk_failure* first);
     int resolve_and_check(void* stream, zk_failure* first);
+    void set_check_mode(bool stored) { check_stored_ = stored; }
     uint64_t read_var(zk_var v, uint32_t instance, uint32_t iteration);
     void write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value);
     std::vector<uint64_t> public_inputs(uint32_t instance);
@@ -383,6 +384,7 @@ class CS {
     float ms_[5] = {0, 0, 0, 0, 0};
     float loop_shader_mhz_ = 0;   // clock probe of the last resolve_and_check's loop launch (last_ms(8))
     bool last_check_fused_ = false;
+    bool check_stored_ = false;   // zk_cs_set_check_mode(ZK_CHECK_STORED)
 };
 
 // K11 (ntt.cpp): batched Goldilocks NTT / coset LDE over device-resident polynomials, see include/zkgl.h

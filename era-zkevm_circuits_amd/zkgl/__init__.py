@@ -68,7 +68,8 @@ class _Stats(C.Structure):
                 ("copy_pairs_outer", C.c_uint64), ("copy_pairs_loop", C.c_uint64),
                 ("seed_ops", C.c_uint64), ("seed_words", C.c_uint64), ("seed_slots", C.c_uint64), ("loop_ops", C.c_uint64),
                 ("cells_populated_outer", C.c_uint64), ("cells_populated_loop", C.c_uint64),
-                ("loop_store_tile_lanes", C.c_uint64)]
+                ("loop_store_tile_lanes", C.c_uint64),
+                ("constraints_from_store_fused", C.c_uint64), ("constraints_in_witness_fused", C.c_uint64)]
 
 
 _lib = None
@@ -708,7 +709,7 @@ def decode_vm_closed_form_input_bincode(data: bytes):
 
 
 VM_PACK_FILL_STATE = 1
-FAILURE_STREAM_LINK, FAILURE_NONCANONICAL_INPUT = 0x400, 0x500   # zk_failure.kind beyond the gate kinds (include/zkgl.h)
+FAILURE_NONCANONICAL_INPUT, FAILURE_STREAM_LINK = 0x400, 0x500   # zk_failure.kind beyond the gate kinds (include/zkgl.h)
 
 
 class VmOracleQueues:
@@ -1119,6 +1120,10 @@ class ConstraintSystem:
         if rc == ZK_ERR_UNSATISFIED:
             return False, Failure(f.scope, f.instance, f.iteration, f.slot, f.kind, f.relation)
         _check(rc)
+
+    def set_check_mode(self, stored: bool):
+        """zk_cs_set_check_mode: False = fused (default), True = every relation re-evaluated from the stored values"""
+        _check(lib().zk_cs_set_check_mode(self._h, 1 if stored else 0))
 
     def resolve_and_check(self, stream=None):
         """fused witness generation + check_if_satisfied (outer scope overlapped on a second stream)"""

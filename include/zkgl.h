@@ -203,13 +203,25 @@ typedef struct zk_failure { uint32_t scope, instance, iteration, slot, kind, rel
 /* kind: a zk_gate_kind; 0x100 lookup tuple (relation = tuple); 0x200 copy constraint; 0x300 | zk_link_kind: a link (slot = the loop
  * cell, relation = link index); ZK_FAILURE_STREAM_LINK: a stream link (relation = stream index);
  * ZK_FAILURE_NONCANONICAL_INPUT: input stream word `slot` (mod 256) of that lane is not a canonical field element (>= p) */
-#define ZK_FAILURE_STREAM_LINK 0x400u
-#define ZK_FAILURE_NONCANONICAL_INPUT 0x500u
+/* numbering: 0x400 has meant NONCANONICAL_INPUT since the kind was introduced (a stream-link failure was reported under it too for a
+ * while); stream links got their own value 0x500 — hosts built against either earlier header keep reading 0x400 correctly */
+#define ZK_FAILURE_NONCANONICAL_INPUT 0x400u
+#define ZK_FAILURE_STREAM_LINK 0x500u
 /* check_if_satisfied: 0 satisfied; ZK_ERR_UNSATISFIED + first failure otherwise */
 int zk_cs_check_satisfied(zk_cs *cs, void *stream, zk_failure *first);
 /* fused resolve + check_if_satisfied; the latency-bound outer scope runs on an internal second stream
  * concurrently with the loop-scope kernels.  Same result contract as zk_cs_check_satisfied. */
 int zk_cs_resolve_and_check(zk_cs *cs, void *stream, zk_failure *first);
+/* How zk_cs_resolve_and_check evaluates the relations (zk_stats.constraints_from_store_fused / constraints_in_witness_fused):
+ *   ZK_CHECK_FUSED (default)  gates mirrored by the witness op that produces their output and lookup tuples are evaluated by the
+ *                             witness kernels on the values they hold; the check kernels read the rest from the store;
+ *   ZK_CHECK_STORED           every relation is re-evaluated from the stored values, as zk_cs_check_satisfied does
+ *                             (check_if_satisfied, /root/reference/src/ram_permutation/mod.rs:556).
+ * Both give the same verdict for every input stream (tests/test_fused_differential.py).  The environment variable
+ * ZKGL_VERIFY_STORED=1 forces ZK_CHECK_STORED for every zk_cs of the process. */
+#define ZK_CHECK_FUSED 0u
+#define ZK_CHECK_STORED 1u
+int zk_cs_set_check_mode(zk_cs *cs, uint32_t mode);
 int zk_cs_read_var(zk_cs *cs, zk_var var, uint32_t instance, uint32_t iteration, uint64_t *out); /* witness_hook */
 /* hook_compare_witness (/root/reference/src/fsm_input_output/mod.rs:102-133) as a device-side diff: the circuit's values of the outer
  * variables `vars` (the closed-form input the host cares about: hidden_fsm_output, observable_output ...; recorded handles) against
@@ -263,6 +275,15 @@ typedef struct zk_stats {
     /* lane tiling of the loop scope's variable store for the bound batch (0 before zk_cs_set_batch): 64 = one tile per wavefront,
      * 4096 = the wide tiling large batches get (csrc/store_geom.hpp).  A layout property only: every reader goes through the C ABI. */
     uint64_t loop_store_tile_lanes;
+    /* Where zk_cs_resolve_and_check's default (fused) mode evaluates the relations counted in constraints_per_instance:
+     *   constraints_from_store_fused   — relations the CHECK kernels evaluate on stored values: enforcements, booleans / range checks of
+     *                                    inputs, integer add / multiply relations, relations whose output is a given variable;
+     *   constraints_in_witness_fused   — relations of gates mirrored by the witness op that produces their output (proved per gate at
+     *                                    finalize) + lookup tuples: evaluated by the witness kernel on the values it holds (SELECT's
+     *                                    exception and lookup misses are tested there), never re-read from memory.
+     * The two add up to constraints_per_instance.  With ZKGL_VERIFY_STORED=1 / zk_cs_check_satisfied every relation is evaluated from
+     * the stored values. */
+    uint64_t constraints_from_store_fused, constraints_in_witness_fused;
 } zk_stats;
 /* K12 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
  * column chunking and cell identifiers are [EXT], the argument is defined in csrc/kernels_perm.hpp).  Labels: outer-scope

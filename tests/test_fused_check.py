@@ -75,3 +75,38 @@ def test_fused_and_stored_verdicts_agree(zk, monkeypatch, verify_stored):
     cs.write_cell(False, cs.public_cells()[0], 3, 12345)
     ok, f = cs.check_if_satisfied()
     assert not ok and f.instance == 3 and f.kind == G["FMA"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The residual chunk of a 1-bit SPLIT (round-3 VERDICT / ADVICE): spread_into_bits(x, n) = SPLIT(n, 1) + BOOLEAN per bit + the
+# recomposition.  The op keeps x >> (n - 1) in its LAST output, so the BOOLEAN gate on that output is the range check x < 2^n — it
+# must stay in the fused check program (csrc/cs.cpp, `gate_mirrored`), while the masked bits below it are 0 / 1 for every x.
+def build_spread(n=4):
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(40, 0, 8, 4))
+    for k in ("CONST", "BOOLEAN", "FMA", "REDUCTION4", "SELECT", "ZEROCHECK", "PUBLIC_INPUT"):
+        cs.allow_gate(G[k])
+    r = Rec(cs)
+    x = r.inp()
+    bits = r.split(x, n, 1, [1 << i for i in range(n)])     # SPLIT + the recomposition (a binding REDUCTION4: its output x is given)
+    for b in bits:
+        cs.place_gate(G["BOOLEAN"], [b])
+    cs.place_gate(G["PUBLIC_INPUT"], [bits[n - 1]])
+    cs.pad_and_shrink()
+    return cs
+
+
+@pytest.mark.parametrize("verify_stored", [False, True])
+def test_one_bit_split_keeps_the_range_check_of_its_residual(zk, monkeypatch, verify_stored):
+    cs = build_spread(4)
+    B = 9
+    good = np.zeros((1, B), dtype=np.uint64)
+    good[0] = [0, 1, 7, 8, 15, 3, 9, 12, 5]
+    ok, f = run(cs, good, monkeypatch, verify_stored)
+    assert ok, f
+    # x = 21 >= 2^4: the masked bits are 1, 0, 1, the residual "bit" is 21 >> 3 = 2; 1 + 4 + 8 * 2 == 21, so the recomposition holds
+    # and only the BOOLEAN gate of the last output rejects the witness — in BOTH modes (fused accepted it before the fix)
+    for value, inst in ((21, 4), (16, 0), (zkgl.P - 1, 8)):
+        bad = good.copy(); bad[0, inst] = value
+        ok, f = run(cs, bad, monkeypatch, verify_stored)
+        assert not ok and f.instance == inst and f.kind == G["BOOLEAN"], (value, ok, f)
+        assert cs.public_inputs(inst) == [value >> 3]
