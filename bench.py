@@ -169,7 +169,7 @@ def cpu_baseline(log2_rows, seconds_target=20.0):
             "witness_rows_per_s": n_inst * st["rows_per_instance"] / med[1],
             "value_from_raw_witness": nrel / (med[0] + t_seed),
             "sample": f"{n_inst} full-size main_vm instances ({limit} cycles, {st['rows_per_instance']} rows, {nrel} constraints in total), "
-                      f"median of {len(times)} passes: resolve {med[1]:.2f}s + check {med[2]:.2f}s (+ sequential seeding {t_seed:.2f}s, outside `value`), "
+                      f"median of {len(times)} passes: resolve {med[1]:.2f}s + check {med[2]:.2f}s (+ seeding {t_seed:.2f}s: one thread per instance walks its cycles in order, outside `value`), "
                       f"OpenMP {cores} threads over instances x cycles, Goldilocks reduction by the 2^64 = 2^32 - 1 identity; "
                       f"CPU restatement (oracle), not the reference Rust binary"}
 
@@ -262,6 +262,36 @@ def main():
     st = cs.stats()
     cs.set_batch(B)
 
+    # ---- the path's only collective: ONE all-gather of the 4-element input commitments of the batch PER STEP, behind the
+    # C ABI (zk_comm_* + zk_cs_gather_commitments = k_pack_public + one ncclAllGather over RCCL / xGMI on the step's stream), INSIDE the
+    # timed region for every N — at N = 1 it is a one-rank all-gather.  The launcher's part (rank 0's unique id to the other ranks)
+    # goes over the gloo control plane.  Ranks that share a device (world > device_count: only the N>1 smoke test on a 1-GPU box) cannot
+    # form an RCCL communicator (duplicate devices are refused) and gather over gloo — the line says so.  Everywhere else a failing RCCL
+    # path is an ERROR: a scaling curve measured over a silent gloo fallback would not be the north star's.
+    comm = None
+    if shared_gpu:
+        gather_path = "torch.distributed (gloo) all_gather per step — ranks share one GPU (smoke test), RCCL refuses duplicate devices"
+    else:
+        gather_path = "zk_cs_gather_commitments per step (k_pack_public + one RCCL all-gather behind the C ABI, on the step stream)"
+        ids = [zkgl.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        try:
+            comm = zkgl.Comm(bytes(ids[0]), rank, world)
+        except Exception as e:  # noqa: BLE001
+            if not os.environ.get("ZKGL_BENCH_ALLOW_GLOO_GATHER"):
+                raise RuntimeError(f"rank {rank}: the RCCL communicator could not be created on {n_dev} visible device(s): {e} "
+                                   "(ZKGL_BENCH_ALLOW_GLOO_GATHER=1 falls back to gloo and labels the line)") from e
+            gather_path = f"torch.distributed (gloo) all_gather per step — RCCL communicator FAILED on rank {rank}: {e}"
+        if world > 1:   # every rank learns whether any rank fell back: one mode for the whole job
+            from zkgl.dist import gather_floats as gather_floats_early
+            oks = gather_floats_early(0.0 if comm is None else 1.0)
+            if min(oks) < 1.0 and comm is not None:
+                comm.close(); comm = None
+                gather_path = "torch.distributed (gloo) all_gather per step — RCCL communicator FAILED on another rank"
+    assert comm is not None or shared_gpu or os.environ.get("ZKGL_BENCH_ALLOW_GLOO_GATHER"), "RCCL gather expected"
+    gather_events = []
+
     cur = [0]   # the stream being resolved; the other one is being seeded
 
     def seed(buf, first, n, sync=True):
@@ -289,13 +319,33 @@ def main():
         if not ok and not os.environ.get("ZKGL_STUB_RUN"):  # ZKGL_STUB_RUN: tools/stub_bench.sh times deliberately wrong kernel variants
             raise RuntimeError(f"trace not satisfied: {failure}")
 
-    def step():
-        """one batch from the raw witness: at window 0 the stream's seeding pass (all K batches), then window k is resolved and checked"""
+    def gather(timed=False):
+        """the step's collective: all ranks' commitments of the window just resolved"""
+        if comm is not None:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(step_stream)
+            cs.gather_commitments_async(comm, stream)
+            if timed:
+                e1.record(step_stream)
+                gather_events.append((e0, e1))
+            return None
+        from zkgl.dist import gather_commitments
+        t = time.perf_counter()
+        c = gather_commitments(np.array([cs.public_inputs(i) for i in range(B)], dtype=np.uint64))
+        if timed:
+            gather_events.append(time.perf_counter() - t)
+        return c
+
+    def step(timed=False):
+        """one batch from the raw witness: at window 0 the stream's seeding pass (all K batches), then window k is resolved and checked,
+        then the batch's commitments are all-gathered"""
         k = step_no[0] % K
         if k == 0:
             seed(0, 0, S, sync=False)       # same stream order as the step kernels: queued, not waited for
         step_no[0] += 1
         resolve(k)
+        return gather(timed)
 
     def fence():
         torch.cuda.synchronize()
@@ -308,14 +358,37 @@ def main():
     fence()
     t0 = time.perf_counter()
     loop_ms, check_ms, gate_ms, outer_ms, shader_mhz = [], [], [], [], []
+    commits = None
     for _ in range(args.steps):
-        step()
+        commits = step(timed=True)
         loop_ms.append(cs.last_ms(1)); check_ms.append(cs.last_ms(2)); gate_ms.append(cs.last_ms(3)); outer_ms.append(cs.last_ms(4))
         shader_mhz.append(cs.last_ms(8))
     fence()
     elapsed_local = time.perf_counter() - t0
     local = np.array([cs.public_inputs(i) for i in range(B)], dtype=np.uint64)
     last_window = window[0]
+    if comm is not None:
+        commits = comm.gathered().copy()          # [world, B, 4]: the last step's gather
+        gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_events]))
+    else:
+        gather_ms = 1e3 * float(np.mean(gather_events))
+    if not np.array_equal(commits[rank], local) and not os.environ.get("ZKGL_STUB_RUN"):  # stub variants store garbage
+        raise RuntimeError("gathered commitments differ from this rank's public inputs")
+    # ---- the same K steps from the raw witness (seeding pass, gather) with EVERY relation re-evaluated from the stored values
+    # (zk_cs_set_check_mode(ZK_CHECK_STORED): what check_if_satisfied does, /root/reference/src/ram_permutation/mod.rs:556)
+    cs.set_check_mode(True)
+    step_no[0] = 0
+    for _ in range(min(args.warmup, 1)):
+        step()
+    step_no[0] = 0
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    raw_stored_local = time.perf_counter() - t1
+    cs.set_check_mode(False)
+    resolve(last_window)
     # ---- the same K steps with the per-cycle state already resident (what rounds 1-2 reported as `value`)
     t1 = time.perf_counter()
     for i in range(args.steps):
@@ -324,68 +397,48 @@ def main():
     resident_local = time.perf_counter() - t1
     # ---- and with every gate re-evaluated from the stored values (the mode of rounds 1-2; resolve_and_check's default is fused: the
     # gates mirrored by their producing witness op are evaluated by the witness kernels)
-    os.environ["ZKGL_VERIFY_STORED"] = "1"
+    cs.set_check_mode(True)
     resolve(0); torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(args.steps):
         resolve((last_window + 1 + i) % K)
     torch.cuda.synchronize()
     stored_local = time.perf_counter() - t1
-    del os.environ["ZKGL_VERIFY_STORED"]
-    resolve(last_window)   # back to the window the commitments were read from (gather below), default mode
-    # ---- materialised witness columns: the variable store is what the step writes; the trace proper (every cell of every column)
-    # is produced on demand — timed here for a few instances of the last batch (zk_cs_trace_columns: k_materialize + transposition)
-    mat_s = None
+    cs.set_check_mode(False)
+    resolve(last_window)   # back to the window the commitments were read from, default mode
+    # ---- materialised witness columns: the variable store is what the step writes; the trace proper (every cell of every column of
+    # every instance, as column polynomials) is produced on demand by zk_cs_trace_columns_batch — timed here for the WHOLE batch, in
+    # chunks of as many instances as fit beside the store (a batch's columns are 4x its store)
+    mat_s, mat_chunk, n_cols_trace = None, 0, int(st["copy_columns"] + st["lookup_columns"])
     try:
-        n_mat = min(4, B)
-        cols = torch.empty((st["n_columns"] if "n_columns" in st else 164) << args.log2_rows, dtype=torch.int64, device=dev)
-        cs.trace_columns(0, cols, args.log2_rows, 1 << args.log2_rows, stream); torch.cuda.synchronize()
+        free_b, _total_b = torch.cuda.mem_get_info(dev)
+        per_inst = n_cols_trace << (args.log2_rows + 3)
+        mat_chunk = int(max(1, min(B, 64, (free_b - (8 << 30)) // per_inst)))
+        cols = torch.empty(mat_chunk * (n_cols_trace << args.log2_rows), dtype=torch.int64, device=dev)
+        cs.trace_columns_batch(0, mat_chunk, cols, args.log2_rows, n_cols_trace, stream=stream); torch.cuda.synchronize()
         tm = time.perf_counter()
-        for i in range(n_mat):
-            cs.trace_columns(i, cols, args.log2_rows, 1 << args.log2_rows, stream)
+        for i0 in range(0, B, mat_chunk):
+            cs.trace_columns_batch(i0, min(mat_chunk, B - i0), cols, args.log2_rows, n_cols_trace, stream=stream)
         torch.cuda.synchronize()
-        mat_s = (time.perf_counter() - tm) / n_mat
+        mat_s = (time.perf_counter() - tm) / B
         del cols
     except Exception as e:  # noqa: BLE001
         print(f"[bench] trace_columns timing unavailable: {e}", file=sys.stderr)
 
-    from zkgl.dist import gather_commitments, gather_floats, max_over_ranks
+    from zkgl.dist import gather_floats, max_over_ranks
     elapsed = max_over_ranks(elapsed_local)
     resident = max_over_ranks(resident_local)
     stored = max_over_ranks(stored_local)
+    raw_stored = max_over_ranks(raw_stored_local)
+    gather_ms = max_over_ranks(gather_ms)
     per_rank_ms = gather_floats(1e3 * elapsed_local / args.steps)
     parity = None
     if expect is not None:
         parity = bool(np.array_equal(local, expect[last_window * B:(last_window + 1) * B]))
         if not parity and not os.environ.get("ZKGL_STUB_RUN"):
             raise RuntimeError("public inputs differ from the native restatement's commitments stored in the fixture")
-    # ---- the path's only collective: gather the 4-element input commitments of every instance, behind the C ABI:
-    # zk_comm_* + zk_cs_gather_commitments = one ncclAllGather of the packed public inputs over RCCL / xGMI.  The launcher's part —
-    # handing rank 0's unique id to the other ranks — goes over the gloo control plane.
-    bind(last_window)
-    if shared_gpu:
-        gather_path = "torch.distributed (gloo) all_gather — ranks share one GPU (smoke test), RCCL refuses duplicate devices"
-        commits = gather_commitments(local)
-    else:
-        gather_path = "zk_cs_gather_commitments (RCCL all-gather behind the C ABI)"
-        rccl_error = None
-        try:
-            ids = [zkgl.Comm.unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(ids, src=0)
-            comm = zkgl.Comm(bytes(ids[0]), rank, world)
-            commits = cs.gather_commitments(comm, stream)          # [world, B, 4] u64
-            comm.close()
-        except Exception as e:  # noqa: BLE001  (an error, not a hang: the timed result above must still be reported)
-            rccl_error = f"{type(e).__name__}: {e}"
-        # every rank learns whether the collective worked everywhere; if not, the commitments travel over the control plane and the
-        # line says so (the timed region is over: `value` does not depend on the gather)
-        if min(gather_floats(0.0 if rccl_error else 1.0)) < 1.0:
-            print(f"[bench] rank {rank}: RCCL gather unavailable ({rccl_error}); gathering over gloo", file=sys.stderr)
-            gather_path = f"torch.distributed (gloo) all_gather — the RCCL gather FAILED on at least one rank (rank {rank}: {rccl_error})"
-            commits = gather_commitments(local)
-        if not np.array_equal(commits[rank], local) and not os.environ.get("ZKGL_STUB_RUN"):  # stub variants store garbage
-            raise RuntimeError("gathered commitments differ from this rank's public inputs")
+    if comm is not None:
+        comm.close()
     if rank == 0:
         n_inst = B * world
         per_step_constraints = st["constraints_per_instance"] * n_inst
@@ -415,14 +468,23 @@ def main():
             "metric": "constraints/s + witness-rows/s, main_vm 2^20 rows", "value": constraints / elapsed, "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * step_s,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks)", "data": "synthetic",
-            "value_is": f"from the raw witness: every K = {K} steps start with ONE seeding pass that derives the per-cycle VM state of the stream's {S} instances, then resolve + check its K windows",
+            "value_is": f"from the raw witness: every K = {K} steps start with ONE seeding pass that derives the per-cycle VM state of the stream's {S} instances, then each step resolves + checks one window and all-gathers its commitments",
             "witness_rows_per_s": rows / elapsed,
             "vm_cycles_per_s": n_inst * limit * args.steps / elapsed,
             "value_inputs_resident": per_step_constraints / res_s,
             "value_inputs_resident_verify_stored": per_step_constraints / (stored / args.steps),
-            "check_mode": "fused: gates mirrored by the witness op that produces their output (same variables and constants) are evaluated by the "
-                          "witness kernels on the values they hold; the check kernels read the binding gates and every lookup.  "
-                          "value_inputs_resident_verify_stored re-evaluates every gate from the stored values (ZKGL_VERIFY_STORED=1)",
+            "value_from_raw_witness_verify_stored": per_step_constraints / (raw_stored / args.steps),
+            # where the relations counted in constraints_per_instance are evaluated in the default (fused) mode (zk_stats; the two add up):
+            "constraints_evaluated_from_store_per_instance": st["constraints_from_store_fused"],
+            "constraints_evaluated_in_witness_kernels_per_instance": st["constraints_in_witness_fused"],
+            "gather_ms_per_step": gather_ms,
+            "check_mode": "`value` is the FUSED mode: a gate mirrored by the witness op that produces its output (same variables and constants, proved "
+                          "per gate at finalize) and every lookup tuple is evaluated by the witness kernel on the values it holds "
+                          "(constraints_evaluated_in_witness_kernels_per_instance); the check kernels read the rest from the store "
+                          "(constraints_evaluated_from_store_per_instance: enforcements, range checks of inputs, integer relations).  "
+                          "value_from_raw_witness_verify_stored / value_inputs_resident_verify_stored: the same steps with EVERY relation "
+                          "re-evaluated from the stored values (zk_cs_set_check_mode(ZK_CHECK_STORED)); verdicts are identical "
+                          "(tests/test_fused_differential.py)",
             "value_from_raw_witness_serial": per_step_constraints / (res_s + t_seed_stream / K),
             "witness_rows_materialised_per_s": None if mat_s is None else st["rows_per_instance"] * n_inst / (step_s + B * mat_s),
             "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/vm_bench_witness.npz, "
@@ -435,6 +497,8 @@ def main():
                        "seed_one_window_alone_s": round(t_seed_window, 4), "seed_whole_stream_alone_s": round(t_seed_stream, 4),
                        "seeding_instances_per_s": S / t_seed_stream, "ms_per_step_inputs_resident": 1e3 * res_s,
                        "host_pack_s": round(t_pack, 3), "trace_columns_s_per_instance": mat_s,
+                       "trace_columns_measured_over": f"the whole batch ({B} instances) in chunks of {mat_chunk} (zk_cs_trace_columns_batch)",
+                       "trace_columns_GBps": None if mat_s is None else (n_cols_trace << (args.log2_rows + 3)) / mat_s / 1e9,
                        "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
                        "commitments_equal_native_restatement": parity, "commitment_gather": gather_path},
             "roofline": {"bound": "hbm", "kernel": "zke::k_witness_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -488,6 +488,11 @@ int zk_cs_trace_columns(zk_cs* cs, uint32_t instance, uint64_t* dev_out, uint32_
     NEED(cs); NEED(dev_out); NEED_INIT();
     return guard([&] { cs->cs->trace_columns(instance, dev_out, log_n, stride, stream); });
 }
+int zk_cs_trace_columns_batch(zk_cs* cs, uint32_t first_instance, uint32_t n_instances, uint64_t* dev_out, uint32_t log_n, uint64_t stride, uint64_t instance_stride,
+                              void* stream) {
+    NEED(cs); NEED(dev_out); NEED_INIT();
+    return guard([&] { cs->cs->trace_columns(first_instance, dev_out, log_n, stride, stream, n_instances, instance_stride); });
+}
 int zk_cs_trace_ptr(zk_cs* cs, int loop_scope, uint64_t** dev_cells, uint64_t* n_cells, uint64_t* stride) {
     NEED(cs); NEED(dev_cells); NEED(n_cells); NEED(stride);
     return guard([&] { cs->cs->trace_ptr(loop_scope != 0, dev_cells, n_cells, stride); });

@@ -2990,7 +2990,7 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
     return o;
 }
 
-void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream) {
+void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream, uint32_t n_instances, uint64_t instance_stride) {
     if (!finalized_ || batch_ == 0) throw ZkError(ZK_ERR_INVALID, "trace_columns before set_batch");
     // a compact batch stays compact: one instance's columns are read through the trace view (cell -> slot), the whole batch's trace
     // (4x the store) is never allocated for this
@@ -3002,7 +3002,8 @@ void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint6
                     if (pr.cell < s->n_trace_cells) t[pr.cell] = pr.home + 1;
                 s->d_slot1 = upload(t);
             }
-    if (instance >= batch_) throw ZkError(ZK_ERR_INVALID, "trace_columns: instance out of range");
+    if (n_instances == 0) return;
+    if (instance >= batch_ || n_instances > batch_ - instance) throw ZkError(ZK_ERR_INVALID, "trace_columns: instance out of range");
     const uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
     if (log_n > 32 || ((uint64_t)1 << log_n) < rows) throw ZkError(ZK_ERR_INVALID, "trace_columns: 2^log_n smaller than the trace");
     if (stride < ((uint64_t)1 << log_n)) throw ZkError(ZK_ERR_INVALID, "trace_columns: stride smaller than the column");
@@ -3016,6 +3017,9 @@ void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint6
     a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
     a.loop_slots = limit_ ? loop_.n_slots : 0; a.outer_slots = outer_.n_slots; a.limit = limit_; a.instance = instance;
     a.out = d_out; a.stride = stride; a.n_rows_padded = (uint64_t)1 << log_n;
+    const uint64_t n_cols = a.n_cols;
+    if (n_instances > 1 && instance_stride < (n_cols - 1) * stride + ((uint64_t)1 << log_n)) throw ZkError(ZK_ERR_INVALID, "trace_columns: instance stride smaller than an instance's columns");
+    a.n_instances = n_instances; a.instance_stride = instance_stride;
     dev_check(zkdev::launch_trace_columns(a, stream));
 }
 

@@ -145,6 +145,7 @@ struct ColumnsArgs {  // mirrors zkn::ColumnsDev
     const uint64_t* loop_cells; uint64_t loop_n_cells; const uint64_t* outer_cells; uint64_t outer_n_cells;
     uint32_t n_cols, loop_slots, outer_slots, limit, instance; uint64_t* out; uint64_t stride; uint64_t n_rows_padded;
     const uint32_t* loop_slot1 = nullptr; const uint32_t* outer_slot1 = nullptr;  // compact mode: trace cell -> store slot + 1 (0: unpopulated)
+    uint32_t n_instances = 1; uint64_t instance_stride = 0;   // batch form: instances [instance, instance + n_instances), out + i * instance_stride
 };
 int launch_trace_columns(const ColumnsArgs& a, void* stream);
 int launch_coset_tables(uint64_t base, uint64_t scale, uint64_t* c_lo, uint64_t* c_hi, uint32_t n_hi, void* stream);

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void k_coset_tables(uint64_t base, uint64_t sc
 // Trace of one instance as column polynomials: out[col * stride + row], rows = loop iterations in order (row = iteration *
 // loop_slots + slot) followed by the outer scope's slots, zero padded to n_rows_padded.  The wave-tiled cell storage keeps
 // 64 consecutive lanes of one cell together, the column layout wants consecutive rows of one lane together: a block
-// transposes 64 iterations x 32 slots of one column through LDS (512 B reads, 256 B writes).
+// transposes 64 iterations x 64 slots of one column through LDS (512 B reads, 512 B writes).  instance = the first instance, the batch
+// form writes instance i at out + (i - instance) * instance_stride.
 struct ColumnsDev {
     const uint64_t* loop_cells; uint64_t loop_n_cells;
     const uint64_t* outer_cells; uint64_t outer_n_cells;
@@ -202,29 +203,57 @@ struct ColumnsDev {
 __device__ __forceinline__ size_t tiled(uint64_t n_cells, uint32_t cell, uint32_t lane) {
     return zkgeom::offset(n_cells, cell, lane);  // n_cells = the geometry word of the store
 }
-__global__ __launch_bounds__(256) void k_trace_columns_loop(ColumnsDev d) {
-    __shared__ uint64_t tile[32][65];
-    const uint32_t col = blockIdx.x, k0 = blockIdx.y * 64, s0 = blockIdx.z * 32;
-    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (uint32_t sy = ty; sy < 32; sy += 4) {
-        const uint32_t slot = s0 + sy, k = k0 + tx;
-        if (slot < d.loop_slots && k < d.limit) {
-            uint32_t cell = slot * d.n_cols + col;
-            bool populated = true;
-            if (d.loop_slot1) { const uint32_t s1 = d.loop_slot1[cell]; populated = s1 != 0; cell = s1 - 1; }
-            tile[sy][tx] = populated ? d.loop_cells[tiled(d.loop_n_cells, cell, d.instance * d.limit + k)] : 0;
+// Batch form (round 4): a block owns one 64-lane TILE of the store (lanes = consecutive iterations, possibly of two neighbouring
+// instances), 64 consecutive slots (trace rows of an iteration) and one column.  Reads are whole 512 B values of the tile (aligned:
+// the block never straddles two tiles, which the per-instance form did whenever instance * limit was not a multiple of 64), writes
+// are 512 B runs of a column (64 consecutive rows of one iteration).  Block order = tile-major, then slot group, then column, dealt to
+// the XCDs in contiguous runs (blockIdx % 8 = XCD): the blocks in flight work on one or two tiles of the store, so the 2.1 other
+// cells a variable occupies on average are found in L2 / the memory-side cache instead of being fetched from HBM again.
+__global__ __launch_bounds__(256) void k_trace_columns_batch(ColumnsDev d, uint32_t first_tile, uint32_t n_tiles, uint32_t slot_groups, uint64_t instance_stride,
+                                                             uint32_t first_instance, uint32_t n_instances) {
+    __shared__ uint64_t tile[64][65];
+    const uint32_t n_blocks = gridDim.x;
+    // XCD-contiguous block order: the blocks an XCD receives (every 8th) cover one contiguous range of work items
+    const uint32_t per_xcd = (n_blocks + 7) / 8;
+    const uint32_t work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (work >= n_tiles * slot_groups * d.n_cols) return;
+    const uint32_t col = work % d.n_cols, sg = (work / d.n_cols) % slot_groups, t = first_tile + work / (d.n_cols * slot_groups);
+    const uint32_t s0 = sg * 64;
+    const uint32_t tx = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = t * 64 + tx;
+    // the view entry (trace cell -> store slot + 1) of slot s0 + tx: one coalesced load per wavefront, broadcast per slot below, so the
+    // sixteen value loads of a thread do not each wait for their own index load
+    uint32_t my_s1 = 0;
+    {
+        const uint32_t slot = s0 + tx;
+        if (slot < d.loop_slots) {
+            const uint32_t cell = slot * d.n_cols + col;
+            my_s1 = d.loop_slot1 ? d.loop_slot1[cell] : cell + 1;
         }
     }
+    const uint64_t* __restrict__ src = d.loop_cells + tiled(d.loop_n_cells, 0, lane);   // slot 0 of this lane; slot s is s << tile_log2 further
+    const uint32_t tsh = zkgeom::tile_log2(d.loop_n_cells);
+    uint64_t v[16];
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t s1 = __builtin_amdgcn_readlane(my_s1, w + 4 * i);   // wave-uniform
+        v[i] = s1 ? src[(size_t)(s1 - 1) << tsh] : 0;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) tile[w + 4 * i][tx] = v[i];
     __syncthreads();
-    const uint32_t sx = threadIdx.x & 31, ky = threadIdx.x >> 5;
-    for (uint32_t kk = ky; kk < 64; kk += 8) {
-        const uint32_t slot = s0 + sx, k = k0 + kk;
-        if (slot < d.loop_slots && k < d.limit) d.out[(size_t)col * d.stride + (size_t)k * d.loop_slots + slot] = tile[sx][kk];
+    for (uint32_t kk = w; kk < 64; kk += 4) {
+        const uint32_t ln = t * 64 + kk, inst = ln / d.limit, k = ln - inst * d.limit;
+        const uint32_t slot = s0 + tx;
+        if (inst >= first_instance && inst < first_instance + n_instances && slot < d.loop_slots)
+            d.out[(size_t)(inst - first_instance) * instance_stride + (size_t)col * d.stride + (size_t)k * d.loop_slots + slot] = tile[tx][kk];
     }
 }
 // the outer scope's rows and the zero padding behind them
-__global__ __launch_bounds__(256) void k_trace_columns_tail(ColumnsDev d) {
+__global__ __launch_bounds__(256) void k_trace_columns_tail(ColumnsDev d, uint64_t instance_stride) {
     const uint32_t col = blockIdx.y;
+    const uint32_t instance = d.instance + blockIdx.z;
+    uint64_t* __restrict__ out = d.out + (size_t)blockIdx.z * instance_stride;
     const uint64_t first = (uint64_t)d.limit * d.loop_slots;
     const uint64_t row = first + (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= d.n_rows_padded) return;
@@ -234,9 +263,9 @@ __global__ __launch_bounds__(256) void k_trace_columns_tail(ColumnsDev d) {
         uint32_t cell = (uint32_t)s * d.n_cols + col;
         bool populated = true;
         if (d.outer_slot1) { const uint32_t s1 = d.outer_slot1[cell]; populated = s1 != 0; cell = s1 - 1; }
-        if (populated) v = d.outer_cells[tiled(d.outer_n_cells, cell, d.instance)];
+        if (populated) v = d.outer_cells[tiled(d.outer_n_cells, cell, instance)];
     }
-    d.out[(size_t)col * d.stride + row] = v;
+    out[(size_t)col * d.stride + row] = v;
 }
 
 }  // namespace zkn

@@ -336,16 +336,31 @@ int launch_trace_columns(const ColumnsArgs& a, void* stream) {
     d.out = a.out; d.stride = a.stride; d.n_rows_padded = a.n_rows_padded;
     d.loop_slot1 = a.loop_slot1; d.outer_slot1 = a.outer_slot1;
     if (a.limit && a.loop_slots) {
-        dim3 grid(a.n_cols, (a.limit + 63) / 64, (a.loop_slots + 31) / 32);
-        if (grid.y > 65535 || grid.z > 65535) { g_hip_err = "k_trace_columns_loop: grid too large"; return -2; }
-        zkn::k_trace_columns_loop<<<grid, 256, 0, (hipStream_t)stream>>>(d);
-        if (int rc = LAUNCH_CHECK("k_trace_columns_loop")) return rc;
+        if (zkgeom::tile_log2(a.loop_n_cells) < 6) { g_hip_err = "k_trace_columns_batch: store tiles narrower than a wavefront"; return -2; }
+        const uint64_t lane0 = (uint64_t)a.instance * a.limit, lane1 = (uint64_t)(a.instance + a.n_instances) * a.limit;
+        const uint32_t first_tile = (uint32_t)(lane0 >> 6), n_tiles = (uint32_t)(((lane1 + 63) >> 6) - first_tile);
+        const uint32_t slot_groups = (a.loop_slots + 63) / 64;
+        const uint64_t work = (uint64_t)n_tiles * slot_groups * a.n_cols;
+        // launches of at most 2^30 blocks (grid.x is a 31-bit count): whole tiles per launch
+        const uint32_t tiles_per_launch = (uint32_t)std::max<uint64_t>(1, ((uint64_t)1 << 30) / ((uint64_t)slot_groups * a.n_cols));
+        (void)work;
+        for (uint32_t t0 = 0; t0 < n_tiles; t0 += tiles_per_launch) {
+            const uint32_t nt = std::min(tiles_per_launch, n_tiles - t0);
+            const uint64_t w = (uint64_t)nt * slot_groups * a.n_cols;
+            const uint32_t blocks = (uint32_t)((w + 7) / 8 * 8);
+            zkn::k_trace_columns_batch<<<blocks, 256, 0, (hipStream_t)stream>>>(d, first_tile + t0, nt, slot_groups, a.instance_stride, a.instance, a.n_instances);
+            if (int rc = LAUNCH_CHECK("k_trace_columns_batch")) return rc;
+        }
     }
     const uint64_t tail = a.n_rows_padded - (uint64_t)a.limit * a.loop_slots;
     if (tail) {
-        dim3 grid((unsigned)((tail + 255) / 256), a.n_cols);
-        zkn::k_trace_columns_tail<<<grid, 256, 0, (hipStream_t)stream>>>(d);
-        if (int rc = LAUNCH_CHECK("k_trace_columns_tail")) return rc;
+        for (uint32_t i0 = 0; i0 < a.n_instances; i0 += 65535) {
+            zkn::ColumnsDev dd = d;
+            dd.instance = a.instance + i0; dd.out = a.out + (size_t)i0 * a.instance_stride;
+            dim3 grid((unsigned)((tail + 255) / 256), a.n_cols, std::min<uint32_t>(65535, a.n_instances - i0));
+            zkn::k_trace_columns_tail<<<grid, 256, 0, (hipStream_t)stream>>>(dd, a.instance_stride);
+            if (int rc = LAUNCH_CHECK("k_trace_columns_tail")) return rc;
+        }
     }
     return 0;
 }

@@ -488,6 +488,11 @@ class Comm:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         _check(lib().zk_comm_create(C.byref(self._h), buf, rank, world))
 
+    def gathered(self) -> np.ndarray:
+        """the words of the last gather_commitments_async as u64 [world, batch, n_public] (the caller synchronised the stream)"""
+        w, b, n = self._shape
+        return self._out.to_numpy()[: w * b * n].reshape(w, b, n)
+
     def close(self):
         if self._h:
             lib().zk_comm_destroy(self._h)
@@ -1073,6 +1078,16 @@ class ConstraintSystem:
         flat = comm._out.to_numpy()[: comm.world * self._batch * n.value]
         return flat.reshape(comm.world, self._batch, n.value)
 
+    def gather_commitments_async(self, comm: "Comm", stream=None) -> int:
+        """zk_cs_gather_commitments queued on `stream` without waiting (one per step inside a timed region); the gathered words stay
+        in the communicator's device buffer, read them with Comm.gathered() after a synchronisation.  Returns n_public."""
+        n = C.c_uint32(0)
+        if comm._out is None or comm._out.n < comm.world * self._batch * 8:
+            comm._out = DeviceBuffer(comm.world * self._batch * 8)
+        _check(lib().zk_cs_gather_commitments(self._h, comm._h, _ptr(comm._out), C.byref(n), _ptr(stream)))
+        comm._shape = (comm.world, self._batch, n.value)
+        return n.value
+
     def debug_poke_store(self, loop_scope: bool, slot: int, lane: int, value: int):
         _check(lib().zk_cs_debug_poke_store(self._h, int(loop_scope), slot, lane, C.c_uint64(value)))
 
@@ -1210,6 +1225,13 @@ class ConstraintSystem:
         """K11 input: out[col * stride + row] = the instance's trace columns (loop rows, then outer rows, zero padded to 2^log_n)"""
         stride = (1 << log_n) if stride is None else stride
         _check(lib().zk_cs_trace_columns(self._h, C.c_uint32(instance), _ptr(out), C.c_uint32(log_n), C.c_uint64(stride), _ptr(stream)))
+
+    def trace_columns_batch(self, first_instance: int, n_instances: int, out, log_n: int, n_cols: int, stride=None, instance_stride=None, stream=None):
+        """zk_cs_trace_columns_batch: out[(i - first) * instance_stride + col * stride + row] for n_instances instances in one pass"""
+        stride = (1 << log_n) if stride is None else stride
+        instance_stride = n_cols * stride if instance_stride is None else instance_stride
+        _check(lib().zk_cs_trace_columns_batch(self._h, C.c_uint32(first_instance), C.c_uint32(n_instances), _ptr(out), C.c_uint32(log_n), C.c_uint64(stride),
+                                               C.c_uint64(instance_stride), _ptr(stream)))
 
     def trace(self, loop_scope: bool) -> np.ndarray:
         """Copy the scope's cells back as the logical array [n_cells, n_tiles*64] (cell-major, lane-minor).

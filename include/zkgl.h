@@ -339,6 +339,11 @@ int zk_cs_export(zk_cs *cs, int loop_scope, uint32_t *buf, size_t max_words, siz
  * 2^log_n (>= the instance's row count, zk_stats.rows_per_instance); stride >= 2^log_n.  The layout `into_assembly`
  * hands to the prover (/root/reference/src/ram_permutation/mod.rs:554) is boojum's ([EXT]); this one is the engine's. */
 int zk_cs_trace_columns(zk_cs *cs, uint32_t instance, uint64_t *dev_out, uint32_t log_n, uint64_t stride, void *stream);
+/* The same for instances [first_instance, first_instance + n_instances) of the bound batch in ONE pass: instance i at
+ * dev_out + (i - first_instance) * instance_stride (instance_stride >= (columns - 1) * stride + 2^log_n words).  A batch's columns are
+ * 4x its variable store (main_vm: 1.375 GB per instance), so a host materialises them in chunks it has room for. */
+int zk_cs_trace_columns_batch(zk_cs *cs, uint32_t first_instance, uint32_t n_instances, uint64_t *dev_out, uint32_t log_n, uint64_t stride,
+                              uint64_t instance_stride, void *stream);
 int zk_cs_trace_ptr(zk_cs *cs, int loop_scope, uint64_t **dev_cells, uint64_t *n_cells, uint64_t *stride);
 
 /* ---------------- circuits (host side mirrors of the reference entry points) ---------------- */

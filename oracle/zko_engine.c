@@ -377,10 +377,12 @@ int zko_scope_run_seq(const zko_scope *s, uint64_t *cells, size_t stride, uint32
                       const uint64_t *outer_cells, size_t outer_stride) {
     uint32_t n_lanes = n_instances * s->limit;
     run_ctx c = {s, cells, stride, n_lanes, inputs, outer_cells, outer_stride, NULL, 0, 0, NULL, 0};
-    for (uint32_t k = 0; k < s->limit; ++k) {
-        int bad = 0;
-#pragma omp parallel for schedule(static)
-        for (long inst = 0; inst < (long)n_instances; ++inst) {
+    /* instances are independent chains: one thread per instance walks its iterations in order (round 3 forked a parallel region per
+     * iteration; the work is the same, the 2 384 fork / joins of a main_vm pass are gone).  Threads used = min(instances, cores). */
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad)
+    for (long inst = 0; inst < (long)n_instances; ++inst) {
+        for (uint32_t k = 0; k < s->limit && !bad; ++k) {
             uint32_t lane = (uint32_t)inst * s->limit + k;
             for (uint32_t i = 0; i < s->n_carries; ++i) {
                 const uint32_t *cr = s->carries + 4 * i;
@@ -389,9 +391,8 @@ int zko_scope_run_seq(const zko_scope *s, uint64_t *cells, size_t stride, uint32
             }
             if (run_lane(&c, lane, 0, s->n_prog)) bad = 1;
         }
-        if (bad) return -1;
     }
-    return 0;
+    return bad ? -1 : 0;
 }
 
 static const unsigned char GW[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5};

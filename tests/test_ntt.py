@@ -239,6 +239,25 @@ def test_gpu_trace_columns_feed_the_transform(zk):
         cs.trace_columns(inst, out, log_n - 1, stride)
     with pytest.raises(zk.ZkError):
         cs.trace_columns(batch, out, log_n, stride)
+    # the batch form (zk_cs_trace_columns_batch): instances 1..2 in one pass == the per-instance calls; instance 0's lanes share a
+    # store tile with instance 1's (70 iterations) and must not leak into the output
+    istride = n_cols * stride + 40
+    outb = zk.DeviceBuffer(2 * istride)
+    outb.zero()
+    cs.trace_columns_batch(1, 2, outb, log_n, n_cols, stride, istride)
+    zk.sync()
+    gb = outb.to_numpy()
+    assert np.array_equal(gb[:n_cols * stride].reshape(n_cols, stride), want)
+    assert not gb[n_cols * stride:istride].any()
+    out2 = zk.DeviceBuffer(n_cols * stride)
+    out2.zero()
+    cs.trace_columns(2, out2, log_n, stride)
+    zk.sync()
+    assert np.array_equal(gb[istride:istride + n_cols * stride], out2.to_numpy())
+    with pytest.raises(zk.ZkError):
+        cs.trace_columns_batch(2, 2, outb, log_n, n_cols, stride, istride)      # past the batch
+    with pytest.raises(zk.ZkError):
+        cs.trace_columns_batch(0, 2, outb, log_n, n_cols, stride, stride)       # instances would overlap
     # rows -> bit-reversed coefficients -> rows
     zk.ntt(out, log_n, n_cols, stride, True, 1, None, True)
     zk.sync()
