@@ -15,10 +15,11 @@ namespace zkgl {
 void ram_permutation_configure(CS& cs);
 void ram_permutation_entry_point(CS& cs, uint32_t limit);
 void vm_shaped_configure(CS& cs);
-void main_vm_configure(CS& cs, const zk_opcode_defs& defs);
+void main_vm_configure(CS& cs, const zk_opcode_defs& defs, uint32_t flags);
 void main_vm_entry_point(CS& cs, uint32_t limit);
 void keccak_configure(CS& cs);
 void sha256_configure(CS& cs);
+void sha256_configure_reference_tables(CS& cs);
 void linear_hasher_configure(CS& cs);
 void linear_hasher_entry_point(CS& cs, uint32_t limit);
 void code_unpacker_configure(CS& cs);
@@ -589,6 +590,10 @@ int zk_circuit_linear_hasher(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { zkgl::linear_hasher_entry_point(*cs->cs, limit); });
 }
+int zk_circuit_sha256_configure_reference_tables(zk_cs* cs) {
+    NEED(cs);
+    return guard([&] { zkgl::sha256_configure_reference_tables(*cs->cs); });
+}
 int zk_circuit_sha256_configure(zk_cs* cs) {
     NEED(cs);
     return guard([&] { zkgl::sha256_configure(*cs->cs); });
@@ -609,10 +614,16 @@ int zk_circuit_vm_shaped(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { zkgl::vm_shaped_entry_point(*cs->cs, limit); });
 }
+int zk_circuit_main_vm_configure_flags(zk_cs* cs, const zk_opcode_defs* defs, uint32_t flags) {
+    NEED(cs);
+    if (!defs) return fail(ZK_ERR_INVALID, "zk_circuit_main_vm_configure_flags: null opcode-defs blob");
+    if (flags & ~(uint32_t)ZK_VM_CFG_U32_FMA_ROLE) return fail(ZK_ERR_INVALID, "zk_circuit_main_vm_configure_flags: unknown flag");
+    return guard([&] { zkgl::main_vm_configure(*cs->cs, *defs, flags); });
+}
 int zk_circuit_main_vm_configure(zk_cs* cs, const zk_opcode_defs* defs) {
     NEED(cs);
     if (!defs) return fail(ZK_ERR_INVALID, "zk_circuit_main_vm_configure: null opcode-defs blob");
-    return guard([&] { zkgl::main_vm_configure(*cs->cs, *defs); });
+    return guard([&] { zkgl::main_vm_configure(*cs->cs, *defs, 0); });
 }
 int zk_circuit_main_vm(zk_cs* cs, uint32_t limit) {
     NEED(cs);

@@ -20,7 +20,7 @@
 #include "decommit_query.hpp"
 #include "log_query.hpp"
 #include "memory_query.hpp"
-#include "sha256_gadget.hpp"
+#include "sha256_gadget4.hpp"
 
 namespace zkgl {
 
@@ -93,7 +93,7 @@ void unpack_code_into_memory_entry_point(CS& cs, uint32_t limit) {
 
     // =========================== loop body (mod.rs:181-438), recorded once ===========================
     cs.loop_begin(limit);
-    S s(g);
+    sha256_gadget4::AnySha s(g);
     std::array<zk_var, CARRIED> in{}, out{};
     for (int i = 0; i < CARRIED; ++i) {
         in[i] = g.next_input();

@@ -15,8 +15,8 @@
 // is exported by zk_circuit_main_vm_layout; the carried part (the 243 VmLocalState words) is filled on the device by
 // zk_cs_seed_carried_inputs from the raw oracle words.
 //
-// Engine-specific points: simulate_round_function runs unconditionally (its result is only used under the
-// same flag that would have gated it); witness closures are the closed IR ops (U256 add/sub chains, ZK_OP_U256_MULWIDE /
+// Engine-specific points: simulate_round_function takes the reference's `execute` flag (ZK_OP_POSEIDON2 a = 1: zeros
+// when it is off, and a wavefront whose cycles all have it off skips the permutation); witness closures are the closed IR ops (U256 add/sub chains, ZK_OP_U256_MULWIDE /
 // ZK_OP_U256_DIVREM, SPLIT); gate decompositions of boojum gadgets are this engine's own ([EXT]).
 #include <cstring>
 #include <string>
@@ -292,7 +292,7 @@ class VmCircuit {
         for (int i = 8; i < 12; ++i) s[i] = cap[i];
         return s;
     }
-    S12 simulate(const S12& in) { return g.simulate_round_function(in); }
+    S12 simulate(const S12& in, Boolean execute) { return g.simulate_round_function(in, execute); }
     std::array<V, 32> encode_ctx(const Ctx& c);
     std::array<V, 20> encode_log(const LogQuery& q) { return encode_log_query(g, q); }
 
@@ -572,7 +572,7 @@ void VmCircuit::create_prestate(State& st, Common& common, Carry& carry) {
         src0_from_mem.ptr = in_bool("src0_read_is_ptr");
         auto enc = memory_query_encode(ts_read, loc_src0.page, loc_src0.index, g.zero(), src0_from_mem.ptr, src0_from_mem.v);
         src0_sponge.init = absorb8(enc, st.mem_tail);
-        S12 simulated = simulate(src0_sponge.init);
+        S12 simulated = simulate(src0_sponge.init, should_read_memory_for_src0);
         src0_sponge.fin = g.select_n(should_read_memory_for_src0, simulated, st.mem_tail);
         src0_sponge.flag = should_read_memory_for_src0;
         st.mem_len = g.select(should_read_memory_for_src0, g.add(st.mem_len, g.one()), st.mem_len);
@@ -805,12 +805,12 @@ void VmCircuit::apply_log(const State& st, const Common& cm, const Carry& cr, Di
     // construct_hash_relations_for_log_and_new_queue_states
     S12 empty = g.empty_state();
     auto chunk = [&](const std::array<V, 20>& enc, int k) { std::array<V, 8> e; for (int i = 0; i < 8; ++i) e[i] = enc[8 * k + i]; return e; };
-    S12 r0_init = absorb8(chunk(packed_forward, 0), empty), r0_fin = simulate(r0_init);
-    S12 r1_init = absorb8(chunk(packed_forward, 1), r0_fin), r1_fin = simulate(r1_init);
+    S12 r0_init = absorb8(chunk(packed_forward, 0), empty), r0_fin = simulate(r0_init, execute_either);
+    S12 r1_init = absorb8(chunk(packed_forward, 1), r0_fin), r1_fin = simulate(r1_init, execute_either);
     std::array<V, 8> e2f, e2r;
     for (int i = 0; i < 4; ++i) { e2f[i] = packed_forward[16 + i]; e2f[4 + i] = st.cs.fwd_tail[i]; e2r[i] = packed_rollback[16 + i]; e2r[4 + i] = prev_revert_head[i]; }
-    S12 r2f_init = absorb8(e2f, r1_fin), r2f_fin = simulate(r2f_init);
-    S12 r2r_init = absorb8(e2r, r1_fin), r2r_fin = simulate(r2r_init);
+    S12 r2f_init = absorb8(e2f, r1_fin), r2f_fin = simulate(r2f_init, execute_either);
+    S12 r2r_init = absorb8(e2r, r1_fin), r2r_fin = simulate(r2r_init, execute_rollback);
     S4 new_fwd_cand = {r2f_fin[0], r2f_fin[1], r2f_fin[2], r2f_fin[3]}, sim_rollback_head = {r2r_fin[0], r2r_fin[1], r2r_fin[2], r2r_fin[3]};
     S4 new_forward_tail = g.select_n(execute_either, new_fwd_cand, st.cs.fwd_tail);
     S4 new_rollback_head = g.select_n(execute_rollback, prev_revert_head, c.rq_head);
@@ -982,7 +982,7 @@ void VmCircuit::apply_uma(const State& st, const Common& cm, const Carry& cr, Di
     V len = st.mem_len;
     auto queue_op = [&](V ts, V index, V rw, const W8& value, Boolean execute) {
         auto enc = memory_query_encode(ts, mem_page, index, rw, g.zero(), value);
-        S12 init = absorb8(enc, tail), fin = simulate(init);
+        S12 init = absorb8(enc, tail), fin = simulate(init, execute);
         relations.push_back({execute, init, fin});
         tail = g.select_n(execute, fin, tail);
         len = g.select(execute, g.add(len, g.one()), len);
@@ -1159,11 +1159,11 @@ void VmCircuit::apply_calls_and_ret(const State& st, const Common& cm, const Car
             auto enc = encode_log(log);
             S12 empty = g.empty_state();
             auto chunk = [&](int k) { std::array<V, 8> e; for (int i = 0; i < 8; ++i) e[i] = enc[8 * k + i]; return e; };
-            S12 r0_init = absorb8(chunk(0), empty), r0_fin = simulate(r0_init);
-            S12 r1_init = absorb8(chunk(1), r0_fin), r1_fin = simulate(r1_init);
+            S12 r0_init = absorb8(chunk(0), empty), r0_fin = simulate(r0_init, should_read);
+            S12 r1_init = absorb8(chunk(1), r0_fin), r1_fin = simulate(r1_init, should_read);
             std::array<V, 8> e2;
             for (int i = 0; i < 4; ++i) { e2[i] = enc[16 + i]; e2[4 + i] = st.cs.fwd_tail[i]; }
-            S12 r2_init = absorb8(e2, r1_fin), r2_fin = simulate(r2_init);
+            S12 r2_init = absorb8(e2, r1_fin), r2_fin = simulate(r2_init, should_read);
             far_new_forward_queue_len = g.select(should_read, g.add(st.cs.fwd_len, g.one()), st.cs.fwd_len);
             far_sponges.push_back({should_read, r0_init, r0_fin});
             far_sponges.push_back({should_read, r1_init, r1_fin});
@@ -1245,7 +1245,7 @@ void VmCircuit::apply_calls_and_ret(const State& st, const Common& cm, const Car
             Boolean refund = g.b_and(should_decommit, g.negated(is_first));
             ergs_remaining_after_decommit = g.select(refund, ergs_left_after_extra_costs, ergs_rem);
             auto enc = encode_decommit_query(g, dq);
-            S12 init = absorb8(enc, st.dec_tail), fin = simulate(init);
+            S12 init = absorb8(enc, st.dec_tail), fin = simulate(init, should_decommit);
             far_sponges.push_back({should_decommit, init, fin});
             new_decommittment_queue_tail = g.select_n(should_decommit, fin, st.dec_tail);
             new_decommittment_queue_len = g.select(should_decommit, g.add(st.dec_len, g.one()), st.dec_len);
@@ -1390,7 +1390,7 @@ void VmCircuit::apply_calls_and_ret(const State& st, const Common& cm, const Car
     for (int r = 0; r < 4; ++r) {
         std::array<V, 8> e;
         for (int i = 0; i < 8; ++i) e[i] = enc[8 * r + i];
-        S12 init = absorb8(e, current_state), fin = simulate(init);
+        S12 init = absorb8(e, current_state), fin = simulate(init, apply_any);
         common_relations.push_back({apply_any, init, fin});
         current_state = fin;
     }
@@ -1453,6 +1453,34 @@ void VmCircuit::enforce_addition_relation(const AddSubRelation& r) {
 
 // enforce_mul_relation — src/main_vm/opcodes/mod.rs:130-180: a * b + rem = mul_low + 2^256 mul_high through 64 UInt32::fma_with_carry
 void VmCircuit::enforce_mul_relation(const MulDivRelation& r) {
+    if (cs.gate_is_allowed(ZK_GATE_U8X4_FMA)) {   // the reference's only branch (`if cs.gate_is_allowed::<U8x4FMAGate>()`, mod.rs:146)
+        using B4 = G::Bytes4;
+        const B4 Z = {g.zero(), g.zero(), g.zero(), g.zero()};
+        std::array<B4, 8> ab, bb;
+        std::array<B4, 16> partial;
+        for (int i = 0; i < 8; ++i) {   // "fields a, b and rem will be range checked" (mod.rs:127): checked byte decompositions
+            ab[i] = g.bytes_checked(r.a[i]); bb[i] = g.bytes_checked(r.b[i]);
+            partial[i] = g.bytes_checked(r.rem[i]); partial[8 + i] = Z;
+        }
+        for (int a_idx = 0; a_idx < 8; ++a_idx) {
+            B4 overflow = Z;
+            for (int b_idx = 0; b_idx < 8; ++b_idx) {
+                auto lh = g.u8x4_fma_with_carry(ab[a_idx], bb[b_idx], partial[a_idx + b_idx], overflow);
+                partial[a_idx + b_idx] = lh.first;
+                overflow = lh.second;
+            }
+            // end of chain: partial_result[a_idx + 8] is still the zero it was initialised with when the reference adds the
+            // overflow to it (add_no_overflow(0, x)): the sum is the overflow word itself
+            partial[a_idx + 8] = overflow;
+        }
+        for (int i = 0; i < 16; ++i) {   // Num::enforce_equal(partial_result[i], mul_low / mul_high[i]): the bytes recompose to the given word
+            V vars[5] = {partial[i][0], partial[i][1], partial[i][2], partial[i][3], i < 8 ? r.mul_low[i] : r.mul_high[i - 8]};
+            uint64_t k[4] = {1, 1ull << 8, 1ull << 16, 1ull << 24};
+            cs.place_gate(ZK_GATE_REDUCTION4, vars, 5, k, 4);
+        }
+        return;
+    }
+    // engines configured without U8x4FMAGate (zk_circuit_main_vm_configure_flags: ZK_VM_CFG_U32_FMA_ROLE): one-relation u32 gates
     std::array<V, 16> partial;
     for (int i = 0; i < 8; ++i) { partial[i] = r.rem[i]; partial[8 + i] = g.zero(); }
     for (int a_idx = 0; a_idx < 8; ++a_idx) {
@@ -1510,7 +1538,7 @@ State VmCircuit::vm_cycle(State st) {
     {
         auto enc = memory_query_encode(cm.ts_dst, cr.dst0_location.page, cr.dst0_location.index, g.one(), dst0.ptr, dst0.v);
         dst0_write_sponge.init = absorb8(enc, draft.mem_tail);
-        dst0_write_sponge.fin = simulate(dst0_write_sponge.init);
+        dst0_write_sponge.fin = simulate(dst0_write_sponge.init, perform_dst0_memory_write_update);
         dst0_write_sponge.flag = perform_dst0_memory_write_update;
         ns.mem_len = g.select(perform_dst0_memory_write_update, g.add(draft.mem_len, g.one()), draft.mem_len);
         ns.mem_tail = g.select_n(perform_dst0_memory_write_update, dst0_write_sponge.fin, draft.mem_tail);
@@ -1742,13 +1770,14 @@ void VmCircuit::entry_point(uint32_t limit) {
 }  // namespace
 
 // geometry check + gate set + tables (src/main_vm/cycle.rs:959-966; tables: src/tables/*.rs)
-void main_vm_configure(CS& cs, const zk_opcode_defs& d) {
+void main_vm_configure(CS& cs, const zk_opcode_defs& d, uint32_t flags) {
     if (d.type_bits != ZK_VMF__COUNT || d.variant_bits > 16 || d.flag_bits > 4 || d.src_mode_bits != ZK_VMM__COUNT || d.dst_mode_bits != 4 ||
         d.description_bits_flattened % 8 || d.description_bits_flattened + d.aux_bits > 56 || d.aux_bits != 3 ||
         d.type_bits + d.variant_bits + d.flag_bits + d.src_mode_bits + d.dst_mode_bits > d.description_bits_flattened)
         throw ZkError(ZK_ERR_INVALID, "main_vm_configure: opcode-defs blob has an unsupported shape");
     cs.allow_lookup(3, 8, true);
-    for (uint32_t k = 1; k < ZK_GATE__COUNT; ++k) cs.allow_gate(k);
+    for (uint32_t k = 1; k < ZK_GATE__COUNT; ++k)
+        if (!(k == ZK_GATE_U8X4_FMA && (flags & ZK_VM_CFG_U32_FMA_ROLE))) cs.allow_gate(k);
     add_xor8_table(cs);
     add_binop_table(cs);
     {   // create_opcodes_decoding_and_pricing_table — src/tables/opcodes_decoding.rs:14-38: [opcode, price, properties]

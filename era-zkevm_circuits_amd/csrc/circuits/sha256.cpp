@@ -14,7 +14,7 @@
 //
 // INPUT STREAMS: outer none; loop 96 words = carried state[32] (word w little-endian bytes at 4w..4w+3) | block[64].
 #include "../gadgets.hpp"
-#include "sha256_gadget.hpp"
+#include "sha256_gadget4.hpp"
 #include "log_query.hpp"
 #include "memory_query.hpp"
 
@@ -28,6 +28,17 @@ void sha256_configure(CS& cs) {
     keccak_configure(cs);  // gate set, xor8, andn8, ByteSplit<1..7>
     add_and8_table(cs);
 }
+// The reference's own configuration of the SHA circuits (/root/reference/src/code_unpacker_sha256/mod.rs:484-566): lookup width 4 x 8
+// repetitions, the gate set of its test, and exactly the five width-4 tables — no 8-bit table.  The circuits recorded into such a CS
+// use the 4-bit-chunk compression (sha256_gadget4.hpp) and range-check bytes through TriXor4.
+void sha256_configure_reference_tables(CS& cs) {
+    cs.allow_lookup(4, 8, true);
+    for (uint32_t k : {ZK_GATE_CONST, ZK_GATE_FMA, ZK_GATE_REDUCTION4, ZK_GATE_BOOLEAN, ZK_GATE_UINTX_ADD, ZK_GATE_SELECT,
+                       ZK_GATE_ZEROCHECK, ZK_GATE_DOT4, ZK_GATE_MATMUL12_EXT, ZK_GATE_MATMUL12_INT, ZK_GATE_NOP,
+                       ZK_GATE_PUBLIC_INPUT})
+        cs.allow_gate(k);
+    sha256_gadget4::add_reference_sha_tables(cs);
+}
 
 // FSM entry point: see the block comment above sha256_round_function_entry_point below.
 // SHA-256 over `n_blocks` pre-padded 64-byte blocks; public inputs = the 32 digest bytes (big-endian word order).
@@ -37,7 +48,7 @@ void sha256_blocks_entry_point(CS& cs, uint32_t n_blocks) {
     for (int w = 0; w < 8; ++w)
         for (int k = 0; k < 4; ++k) iv_bytes[4 * w + k] = g.constant((SHA_IV[w] >> (8 * k)) & 0xff);
     cs.loop_begin(n_blocks);
-    S s(g);
+    sha256_gadget4::AnySha s(g);
     std::array<Word, 8> st;
     std::vector<zk_var> state_in, state_out;
     for (int w = 0; w < 8; ++w)
@@ -177,7 +188,7 @@ void sha256_round_function_entry_point(CS& cs, uint32_t limit) {
     // =========================== loop body (mod.rs:139-331), recorded once ===========================
     cs.native_seed_kind = 4;  // the carried FSM state has a native walker (kernels_fsm_seed.hpp)
     cs.loop_begin(limit);
-    S s(g);
+    sha256_gadget4::AnySha s(g);
     std::array<zk_var, SHA_FSM_CARRIED> in{}, out{};
     for (int i = 0; i < SHA_FSM_CARRIED; ++i) {
         in[i] = g.next_input();

@@ -14,6 +14,7 @@
 // The byte interface (state bytes in / out, block bytes in) is the 8-bit gadget's, so the FSM circuits and their seed hints
 // (ZK_OP_SHA256_COMPRESS over byte variables) do not change.
 #pragma once
+#include <memory>
 #include "sha256_gadget.hpp"
 
 namespace zkgl {
@@ -23,7 +24,7 @@ using sha256_gadget::SHA_K;
 using sha256_gadget::Word;   // four little-endian byte variables
 
 // table markers of the reference's set (the Rust types of code_unpacker_sha256/mod.rs:554-566)
-constexpr uint32_t TABLE_MAJ4 = 48, TABLE_TRIXOR4 = 49, TABLE_CH4 = 50, TABLE_SPLIT4_1 = 51, TABLE_SPLIT4_2 = 52;
+constexpr uint32_t TABLE_MAJ4 = 48, TABLE_CH4 = 50, TABLE_SPLIT4_1 = 51, TABLE_SPLIT4_2 = 52;   // TABLE_TRIXOR4 = 49: gadgets.hpp (the range checks use it too)
 
 inline void add_reference_sha_tables(CS& cs) {
     std::vector<uint64_t> maj, tri, ch;
@@ -207,6 +208,19 @@ struct S4 {
             st[i] = to_bytes(r);
         }
         range_check_nibbles(loose);
+    }
+};
+
+// the gadget a circuit gets: by the table set its CS was configured with
+struct AnySha {
+    std::unique_ptr<sha256_gadget::S> s8;
+    std::unique_ptr<S4> s4;
+    explicit AnySha(G& g) {
+        if (g.cs.has_table(TABLE_TRIXOR4) && !g.cs.has_table(TABLE_XOR8)) s4 = std::make_unique<S4>(g);
+        else s8 = std::make_unique<sha256_gadget::S>(g);
+    }
+    void compress_with_hint(std::array<Word, 8>& st, const std::array<Word, 16>& block_words) {
+        if (s4) s4->compress_with_hint(st, block_words); else s8->compress_with_hint(st, block_words);
     }
 };
 

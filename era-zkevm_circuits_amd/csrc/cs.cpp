@@ -37,6 +37,7 @@ const GateInfo GATES[ZK_GATE__COUNT] = {
     {1, 0, 0},   // PUBLIC_INPUT
     {6, 0, 1},   // U32_FMA
     {5, 1, 1},   // REDUCTION_BY_POWERS4
+    {26, 0, 2},  // U8X4_FMA
 };
 
 // element offset of (cell, lane) in the wave-tiled cell storage (see kernels_engine.hpp)
@@ -214,6 +215,12 @@ uint32_t CS::table_id(uint32_t marker) const {
     throw ZkError(ZK_ERR_INVALID, "table must be added before");  // reference: src/main_vm/utils.rs:95-97
 }
 
+bool CS::has_table(uint32_t marker) const {
+    for (auto& t : tables_)
+        if (t.marker == marker) return true;
+    return false;
+}
+
 // ------------------------------------------------------------------ recording
 void CS::check_var(zk_var v, bool want_loop) const {
     if (v == ZK_VAR_NONE) throw ZkError(ZK_ERR_INVALID, "placeholder variable used");
@@ -317,9 +324,10 @@ void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uin
     case ZK_OP_SPLIT:
         if (n_in != 1 || n_imm != 0 || n_out != a || a == 0 || b == 0 || b > 32) throw ZkError(ZK_ERR_INVALID, "SPLIT: bad shape");
         break;
-    case ZK_OP_POSEIDON2: need(12, 12, 0); break;
+    case ZK_OP_POSEIDON2: if (a == 1) need(13, 12, 0); else { need(12, 12, 0); if (a) throw ZkError(ZK_ERR_INVALID, "POSEIDON2: a must be 0 / 1"); } break;
     case ZK_OP_P2_ROUNDS: need(12, 962, 0); break;
     case ZK_OP_U32MULADD: need(4, 2, 0); break;
+    case ZK_OP_U8X4FMA: need(16, 10, 0); break;
     case ZK_OP_NN_MULMOD:
         if (a == 0 || a > 17 || b == 0 || b > 17 || a + b < 16 || n_in != a + b || n_imm != 16 || n_out != a + b - 15 + 16)
             throw ZkError(ZK_ERR_INVALID, "NN_MULMOD: bad shape");
@@ -540,7 +548,7 @@ void CS::build_check_program(Scope& s) {
         case ZK_GATE_FMA: case ZK_GATE_SELECT: return 3;
         case ZK_GATE_ZEROCHECK: return 4;
         case ZK_GATE_REDUCTION4: case ZK_GATE_UINTX_ADD: case ZK_GATE_U32_FMA: case ZK_GATE_REDUCTION_BY_POWERS4: return 2;
-        case ZK_GATE_DOT4: case ZK_GATE_MATMUL12_EXT: case ZK_GATE_MATMUL12_INT: return 1;
+        case ZK_GATE_DOT4: case ZK_GATE_MATMUL12_EXT: case ZK_GATE_MATMUL12_INT: case ZK_GATE_U8X4_FMA: return 1;
         default: return 0;  // NOP, PUBLIC_INPUT: no relation
         }
     };
@@ -1626,7 +1634,12 @@ void CS::build_seed_program() {
     const Scope& s = loop_;
     // the cone is built from the ops in RECORDING order: the locality schedule of the trace program (schedule_by_locality) stretches
     // live ranges inside the cone, and the seed kernels hold every live value of an instance in LDS
-    const std::vector<OpRec>& sops = loop_ops_recorded_.empty() ? s.ops : loop_ops_recorded_;
+    // the cone runs the gated witness-only permutations (ZK_OP_POSEIDON2 a = 1) ungated: their outputs only ever reach a carried word
+    // through a select on the same flag, and the seed kernels keep one POSEIDON2 form
+    std::vector<OpRec> sops_store = loop_ops_recorded_.empty() ? s.ops : loop_ops_recorded_;
+    for (auto& op : sops_store)
+        if (op.opcode == ZK_OP_POSEIDON2 && op.a == 1) { op.ins.pop_back(); op.a = 0; }
+    const std::vector<OpRec>& sops = sops_store;
     std::vector<uint32_t> out_vars;  // same order as carries_
     for (auto& l : links_raw_)
         if (l.kind == ZK_LINK_CARRY && s.input_word.count(l.loop_cell)) out_vars.push_back(l.other_cell);
@@ -2919,6 +2932,7 @@ void CS::stats(zk_stats* o) const {
     o->variables_outer = outer_.n_vars; o->variables_loop = loop_.n_vars;
     o->constraints_per_instance = outer_.n_constraints + loop_.n_constraints * limit_;
     o->var_cells_per_instance = o->rows_per_instance * (o->copy_columns + o->lookup_columns);
+    static_assert(ZK_GATE__COUNT <= 16, "zk_stats.gate_instances holds 16 kinds");
     for (int k = 0; k < ZK_GATE__COUNT; ++k) o->gate_instances[k] = outer_.gate_counts[k] + loop_.gate_counts[k] * limit_;
     o->lookups_per_instance = outer_.lookups.size() + loop_.lookups.size() * (uint64_t)limit_;
     o->program_words_outer = outer_.prog2.size(); o->program_words_loop = loop_.prog2.size();

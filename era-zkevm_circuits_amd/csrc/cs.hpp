@@ -174,6 +174,7 @@ class CS {
     bool gate_is_allowed(uint32_t kind) const;
     uint32_t add_table(uint32_t marker, uint32_t n_keys, uint32_t n_vals, const uint64_t* rows, uint32_t n_rows);
     uint32_t table_id(uint32_t marker) const;
+    bool has_table(uint32_t marker) const;
 
     // recording
     zk_var alloc_var();

@@ -129,6 +129,28 @@ Boolean G::equals(const UInt256& a, const UInt256& b) {
 uint32_t G::xor8_table() { return cs.table_id(TABLE_XOR8); }
 
 void G::range_check_u8_pair(zk_var a, zk_var b) {
+    if (!cs.has_table(TABLE_XOR8) && cs.has_table(TABLE_TRIXOR4)) {
+        // the reference's width-4 table set (code_unpacker_sha256/mod.rs:554-566 adds no 8-bit table): a byte is two 4-bit chunks,
+        // x = lo + 16 hi, each chunk a key of a TriXor4 lookup (three chunks per lookup)
+        std::vector<zk_var> nib;
+        std::vector<zk_var> bytes = {a};
+        if (b != a) bytes.push_back(b);
+        for (zk_var x : bytes) {
+            zk_var first = cs.alloc_vars(2);
+            zk_var parts[2] = {first, first + 1};
+            cs.emit_op(ZK_OP_SPLIT, 2, 4, &x, 1, parts, 2, nullptr, 0);
+            zk_var vars[5] = {parts[0], parts[1], zero(), zero(), x};
+            uint64_t k[4] = {1, 16, 0, 0};
+            cs.place_gate(ZK_GATE_REDUCTION4, vars, 5, k, 4);
+            nib.push_back(parts[0]); nib.push_back(parts[1]);
+        }
+        const uint32_t t = cs.table_id(TABLE_TRIXOR4);
+        for (size_t i = 0; i < nib.size(); i += 3) {
+            zk_var keys[3] = {nib[i], i + 1 < nib.size() ? nib[i + 1] : zero(), i + 2 < nib.size() ? nib[i + 2] : zero()}, val;
+            cs.lookup(t, keys, 3, &val, 1);
+        }
+        return;
+    }
     zk_var keys[2] = {a, b}, val;
     cs.lookup(xor8_table(), keys, 2, &val, 1);
 }
@@ -205,6 +227,17 @@ std::pair<UInt32, UInt32> G::u32_fma_with_carry(UInt32 a, UInt32 b, UInt32 c, UI
     return {UInt32{outs[0]}, UInt32{outs[1]}};
 }
 
+std::pair<G::Bytes4, G::Bytes4> G::u8x4_fma_with_carry(const Bytes4& a, const Bytes4& b, const Bytes4& c, const Bytes4& d) {
+    zk_var vars[26];
+    for (int i = 0; i < 4; ++i) { vars[i] = a[i]; vars[4 + i] = b[i]; vars[8 + i] = c[i]; vars[12 + i] = d[i]; }
+    zk_var first = cs.alloc_vars(10);
+    for (int i = 0; i < 10; ++i) vars[16 + i] = first + i;
+    cs.emit_op(ZK_OP_U8X4FMA, 0, 0, vars, 16, vars + 16, 10, nullptr, 0);
+    cs.place_gate(ZK_GATE_U8X4_FMA, vars, 26, nullptr, 0);
+    for (int i = 0; i < 10; i += 2) range_check_u8_pair(vars[16 + i], vars[17 + i]);   // lo, hi and the two carry bytes
+    return {Bytes4{vars[16], vars[17], vars[18], vars[19]}, Bytes4{vars[20], vars[21], vars[22], vars[23]}};
+}
+
 std::vector<zk_var> G::lookup(uint32_t table_id, const std::vector<zk_var>& keys, uint32_t n_vals) {
     std::vector<zk_var> vals(n_vals);
     cs.lookup(table_id, keys.data(), (uint32_t)keys.size(), vals.data(), n_vals);
@@ -266,6 +299,16 @@ std::array<zk_var, 12> G::simulate_round_function(const std::array<zk_var, 12>& 
     zk_var first = cs.alloc_vars(12);
     for (int i = 0; i < 12; ++i) out[i] = first + i;
     cs.emit_op(ZK_OP_POSEIDON2, 0, 0, state.data(), 12, out.data(), 12, nullptr, 0);
+    return out;
+}
+std::array<zk_var, 12> G::simulate_round_function(const std::array<zk_var, 12>& state, Boolean execute) {
+    std::array<zk_var, 12> out;
+    zk_var first = cs.alloc_vars(12);
+    for (int i = 0; i < 12; ++i) out[i] = first + i;
+    zk_var ins[13];
+    for (int i = 0; i < 12; ++i) ins[i] = state[i];
+    ins[12] = execute.v;
+    cs.emit_op(ZK_OP_POSEIDON2, 1, 0, ins, 13, out.data(), 12, nullptr, 0);
     return out;
 }
 

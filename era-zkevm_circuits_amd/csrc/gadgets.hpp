@@ -95,6 +95,10 @@ class G {  // gadget context bound to one CS
     std::pair<UInt8, Boolean> overflowing_sub_u8(UInt8 a, UInt8 b);
     // a*b + c + d = lo + 2^32 hi  [UInt32::fma_with_carry, src/main_vm/opcodes/mod.rs:152-158]
     std::pair<UInt32, UInt32> u32_fma_with_carry(UInt32 a, UInt32 b, UInt32 c, UInt32 d);
+    // the same over little-endian byte variables through U8x4FMAGate (the form the reference requires, opcodes/mod.rs:146): the
+    // outputs are range-checked bytes; operands must be range-checked bytes already
+    using Bytes4 = std::array<zk_var, 4>;
+    std::pair<Bytes4, Bytes4> u8x4_fma_with_carry(const Bytes4& a, const Bytes4& b, const Bytes4& c, const Bytes4& d);
 
     // ---- lookups ----
     std::vector<zk_var> lookup(uint32_t table_id, const std::vector<zk_var>& keys, uint32_t n_vals);
@@ -102,6 +106,8 @@ class G {  // gadget context bound to one CS
     // ---- Poseidon2 round function (CircuitRoundFunction<F,8,12,4>) ----
     std::array<zk_var, 12> compute_round_function(const std::array<zk_var, 12>& state);
     std::array<zk_var, 12> simulate_round_function(const std::array<zk_var, 12>& state);  // witness only
+    // simulate_round_function(cs, state, execute): zeros when `execute` is false (the reference passes the flag: log.rs:532, uma.rs:410)
+    std::array<zk_var, 12> simulate_round_function(const std::array<zk_var, 12>& state, Boolean execute);
     std::array<zk_var, 12> empty_state();
     // commit_encoding (src/fsm_input_output/mod.rs:281-326) -> 4 commitment elements
     std::array<Num, 4> commit_encoding(const std::vector<zk_var>& input);
@@ -158,6 +164,7 @@ enum TableMarker : uint32_t {
     TABLE_VM_SUBPC_TO_BITMASK = 20,     // VMSubPCToBitmaskTable
     TABLE_VM_UMA_SHIFT_TO_BITMASK = 21, // UMAShiftToBitmaskTable
     TABLE_VM_UMA_PTR_READ_CLEANUP = 22, // UMAPtrReadCleanupTable (src/tables/uma_ptr_read_cleanup.rs:9)
+    TABLE_TRIXOR4 = 49,   // boojum TriXor4Table (src/code_unpacker_sha256/mod.rs:557-558); the set lives in circuits/sha256_gadget4.hpp
 };
 void add_xor8_table(CS& cs);
 void add_and8_table(CS& cs);

@@ -123,4 +123,34 @@ __device__ __forceinline__ uint64_t inv(uint64_t x) {
     return mul(t, e32);
 }
 
+// ZK_OP_U8X4FMA (include/zkgl_ir.h): a*b + c + d over u32 operands given as bytes -> the eight bytes of the result and the two bytes
+// of k = the carry of the low 32 bits of the byte-product sum.  Plain wrapping u64 arithmetic (the oracle restates it word for
+// word): for operands that are not bytes the outputs are still defined, the gate rejects them.
+__host__ __device__ __forceinline__ void u8x4_fma(const uint64_t in[16], uint64_t out[10]) {
+    const uint64_t a = in[0] + (in[1] << 8) + (in[2] << 16) + (in[3] << 24), b = in[4] + (in[5] << 8) + (in[6] << 16) + (in[7] << 24);
+    const uint64_t c = in[8] + (in[9] << 8) + (in[10] << 16) + (in[11] << 24), d = in[12] + (in[13] << 8) + (in[14] << 16) + (in[15] << 24);
+    const uint64_t r = a * b + c + d;
+    const uint64_t t = in[0] * b + ((in[1] * (b & 0xffffffull)) << 8) + ((in[2] * (b & 0xffffull)) << 16) + ((in[3] * (b & 0xffull)) << 24);
+    const uint64_t k = (t + c + d) >> 32;
+    for (int i = 0; i < 8; ++i) out[i] = (r >> (8 * i)) & 0xff;
+    out[8] = k & 0xff;
+    out[9] = (k >> 8) & 0xff;
+}
+
+// ZK_GATE_U8X4_FMA: the two relations over the 26 variables a0..3, b0..3, c0..3, d0..3, lo0..3, hi0..3, k0, k1, evaluated in the field
+// (both are zero for a satisfied gate)
+__device__ __forceinline__ uint64_t le4(const uint64_t* x) {   // x0 + 2^8 x1 + 2^16 x2 + 2^24 x3
+    return add(add(x[0], mul_pow2(x[1], 8)), add(mul_pow2(x[2], 16), mul_pow2(x[3], 24)));
+}
+__device__ __forceinline__ void u8x4_relations(const uint64_t v[26], uint64_t& r0, uint64_t& r1) {
+    const uint64_t* a = v; const uint64_t* b = v + 4;
+    const uint64_t B1 = b[0], B2 = add(B1, mul_pow2(b[1], 8)), B3 = add(B2, mul_pow2(b[2], 16)), B4 = add(B3, mul_pow2(b[3], 24));
+    const uint64_t H3 = b[3], H2 = add(b[2], mul_pow2(b[3], 8)), H1 = add(b[1], mul_pow2(H2, 8));
+    const uint64_t T = add(add(mul(a[0], B4), mul_pow2(mul(a[1], B3), 8)), add(mul_pow2(mul(a[2], B2), 16), mul_pow2(mul(a[3], B1), 24)));
+    const uint64_t K = add(v[24], mul_pow2(v[25], 8));
+    r0 = sub(add(add(T, le4(v + 8)), le4(v + 12)), add(le4(v + 16), mul(K, 1ull << 32)));
+    const uint64_t Y = add(add(mul(a[1], H3), mul(a[2], H2)), mul(a[3], H1));
+    r1 = sub(add(Y, K), le4(v + 20));
+}
+
 }  // namespace gl

@@ -639,6 +639,8 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 #pragma unroll
             for (int i = 0; i < 12; ++i) s[i] = ld(P.at(pc + i));
             pc += 12;
+            bool lane_off = false;   // gated form (pa = 1): [.., execute] -> zeros where the flag is off
+            if (!emit && pa != 0) { lane_off = ld(P.at(pc)) == 0; pc += 1; }
             p2::mds_external(s);
 #pragma unroll
             for (int i = 0; i < 12; ++i) p2s[i * BLOCK + threadIdx.x] = s[i];
@@ -673,7 +675,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             }
             if (!emit) {
 #pragma unroll 1
-                for (int i = 0; i < 12; ++i) st(p2s[i * BLOCK + threadIdx.x]);
+                for (int i = 0; i < 12; ++i) st(lane_off ? 0ull : p2s[i * BLOCK + threadIdx.x]);
             }
         } break;
         case ZK_OP_LOOP_LAST: {
@@ -686,6 +688,15 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
             uint64_t r = a * b + c + d;  // < 2^64 for u32 operands
             st(r & 0xffffffffull);
             st(r >> 32);
+        } break;
+        case ZK_OP_U8X4FMA: {
+            uint64_t in[16], out[10];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) in[i] = ld(P.at(pc + i));
+            pc += 16;
+            gl::u8x4_fma(in, out);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) st(out[i]);
         } break;
         case ZK_OP_NN_MULMOD: if constexpr (WITH_BIGINT) {
             uint32_t mv[16], av[17], bv[17], res[19 + 16];
@@ -994,7 +1005,7 @@ struct CheckDev {
     const uint32_t* alias;
 };
 
-__device__ __constant__ const unsigned char GATE_WIDTH[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5};
+__device__ __constant__ const unsigned char GATE_WIDTH[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5, 26};
 
 __device__ __forceinline__ void report(unsigned long long* f, uint32_t lane, uint32_t slot, uint32_t j, uint32_t rel) {
     unsigned long long key = ((unsigned long long)lane << 32) | ((unsigned long long)slot << 12) | ((j & 0xff) << 4) | (rel & 0xf);
@@ -1081,6 +1092,14 @@ __device__ __forceinline__ void check_gates_body(const CheckDev& cd) {
                 uint64_t lhs = gl::add(gl::add(gl::mul(a, b), c), dd);
                 uint64_t rhs = gl::add(lo, gl::mul(hi, 1ull << 32));
                 if (lhs != rhs) report(cd.fail, lane, slot, j, 0);
+            } break;
+            case ZK_GATE_U8X4_FMA: {
+                uint64_t v[26], r0, r1;
+#pragma unroll
+                for (int i = 0; i < 26; ++i) v[i] = cell(c0 + i);
+                gl::u8x4_relations(v, r0, r1);
+                if (r0 != 0) report(cd.fail, lane, slot, j, 0);
+                if (r1 != 0) report(cd.fail, lane, slot, j, 1);
             } break;
             case ZK_GATE_REDUCTION_BY_POWERS4: {  // Horner in the row constant c
                 uint64_t r = cell(c0 + 3);

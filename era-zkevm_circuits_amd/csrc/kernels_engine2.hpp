@@ -403,8 +403,23 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             uint64_t s[12];
 #pragma unroll
             for (int i = 0; i < 12; ++i) s[i] = ldv(W[1 + i]);
-            out_to(W[13]);
-            pc += 13 + D;
+            // gated form (pa = 1, witness-only): [.., execute] -> zeros where the flag is off (simulate_round_function(cs, state, execute));
+            // a wavefront whose 64 cycles all have it off skips the permutation altogether
+            const bool gated = !emit && pa != 0;
+            bool lane_off = false;
+            if (gated) {
+                lane_off = ldv(W[13]) == 0;
+                out_to(W[14]);
+                pc += 14 + D;
+                if (__builtin_amdgcn_ballot_w64(!lane_off) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) st(0ull);
+                    break;
+                }
+            } else {
+                out_to(W[13]);
+                pc += 13 + D;
+            }
             p2::mds_external(s);
             if constexpr (P2_IN_REGISTERS) {
                 // state in registers, the twelve S-boxes of a full round unrolled, ONE copy of the full-round body (12 KB of code: the
@@ -461,7 +476,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 }
                 if (!emit) {
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) st(s[i]);
+                    for (int i = 0; i < 12; ++i) st(lane_off ? 0ull : s[i]);
                 }
             } else {
 #pragma unroll
@@ -497,7 +512,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }
             if (!emit) {
 #pragma unroll
-                for (int i = 0; i < 12; ++i) st(s[i]);
+                for (int i = 0; i < 12; ++i) st(lane_off ? 0ull : s[i]);
             }
             }
         } break;
@@ -530,6 +545,18 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             case 1: body(GroupSize<2>{}); break;
             default: body(GroupSize<3>{}); break;
             }
+        } break;
+        case ZK_OP_U8X4FMA: {   // [16 byte slots] -> 10 bytes; header + 16 operands = 17 words: the 17th (and the strand destination) from a second fetch
+            uint64_t in[16], out[10];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) in[i] = ldv(W[1 + i]);
+            const uint32_t w16 = prog[pc + 16];
+            in[15] = ldv(w16);
+            if constexpr (STRANDS) out_to(prog[pc + 17]);
+            pc += 17 + D;
+            gl::u8x4_fma(in, out);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) st(out[i]);
         } break;
         case ZK_OP_NN_MULMOD: if constexpr (WITH_BIGINT) {
             // fixed layout (cs.cpp emit_scope): 16 modulus limbs (pool indices), 17 A slots, 17 B slots (unused ones 0) = 51 words,
@@ -1237,6 +1264,18 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_
                 for (uint32_t g = 0; g < N; ++g)
                     bad(gl::add(gl::add(gl::mul(v[g][0], v[g][1]), v[g][2]), v[g][3]) != gl::add(v[g][4], gl::mul(v[g][5], 1ull << 32)), j0 + g, 0);
             });
+        } break;
+        case ZK_GATE_U8X4_FMA: {   // 3 header words + 26 slots: two 16-word fetches
+            const u32x16_a4 W2 = *(prog16_ptr)(prog + pc + 16);
+            uint64_t v[26], r0, r1;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) v[i] = ldv(W[3 + i]);
+#pragma unroll
+            for (int i = 13; i < 26; ++i) v[i] = ldv(W2[i - 13]);
+            pc += 29;
+            gl::u8x4_relations(v, r0, r1);
+            bad(r0 != 0, j0, 0);
+            bad(r1 != 0, j0, 1);
         } break;
         case ZK_GATE_REDUCTION_BY_POWERS4: {
             dispatch_count<2>(cnt, [&](auto n_) {

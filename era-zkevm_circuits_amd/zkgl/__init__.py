@@ -33,9 +33,9 @@ ZK_ERR_GATE_NOT_ALLOWED = -6
 
 # zk_opcode / zk_gate_kind / zk_link_kind (include/zkgl_ir.h)
 OP = dict(END=0, CONST=1, INPUT=2, FMA=3, LC4=4, SELECT=5, ISZERO=6, UADD=7, USUB=8, DOT4=9, MATMUL12=10,
-          SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16, DIVREM=18, NN_MULMOD=19, KECCAK_ABSORB=20, SHA256_COMPRESS=21, BARRIER=22, U256_MULWIDE=23, U256_DIVREM=24)
+          SPLIT=11, LOOKUP=12, POSEIDON2=13, P2_ROUNDS=14, LOOP_LAST=15, U32MULADD=16, DIVREM=18, NN_MULMOD=19, KECCAK_ABSORB=20, SHA256_COMPRESS=21, BARRIER=22, U256_MULWIDE=23, U256_DIVREM=24, U8X4FMA=25)
 GATE = dict(NOP=0, CONST=1, BOOLEAN=2, FMA=3, REDUCTION4=4, SELECT=5, ZEROCHECK=6, UINTX_ADD=7, DOT4=8,
-            MATMUL12_EXT=9, MATMUL12_INT=10, PUBLIC_INPUT=11, U32_FMA=12, REDUCTION_BY_POWERS4=13)
+            MATMUL12_EXT=9, MATMUL12_INT=10, PUBLIC_INPUT=11, U32_FMA=12, REDUCTION_BY_POWERS4=13, U8X4_FMA=14)
 GATE_NAMES = {v: k for k, v in GATE.items()}
 LINK = dict(CARRY=0, FIRST=1, LAST=2, BCAST=3)
 
@@ -61,7 +61,7 @@ class _Stats(C.Structure):
                 ("limit", C.c_uint64), ("copy_columns", C.c_uint64), ("lookup_columns", C.c_uint64),
                 ("variables_outer", C.c_uint64), ("variables_loop", C.c_uint64),
                 ("constraints_per_instance", C.c_uint64), ("var_cells_per_instance", C.c_uint64),
-                ("gate_instances", C.c_uint64 * 14), ("lookups_per_instance", C.c_uint64),
+                ("gate_instances", C.c_uint64 * 16), ("lookups_per_instance", C.c_uint64),
                 ("program_words_outer", C.c_uint64), ("program_words_loop", C.c_uint64),
                 ("scratch_cells_outer", C.c_uint64), ("scratch_cells_loop", C.c_uint64),
                 ("cells_written_outer", C.c_uint64), ("cells_written_loop", C.c_uint64),
@@ -975,8 +975,13 @@ class ConstraintSystem:
     def linear_hasher_entry_point(self, limit: int):
         _check(lib().zk_circuit_linear_hasher(self._h, limit))
 
-    def configure_sha256(self):
-        _check(lib().zk_circuit_sha256_configure(self._h))
+    def configure_sha256(self, reference_tables: bool = False):
+        """reference_tables: the reference's own width-4 table set (Maj4 / TriXor4 / Ch4 / Split4BitChunk<1,2>, lookup width 4) instead of
+        the engine's 8-bit tables; the circuits recorded afterwards pick the matching SHA-256 decomposition"""
+        if reference_tables:
+            _check(lib().zk_circuit_sha256_configure_reference_tables(self._h))
+        else:
+            _check(lib().zk_circuit_sha256_configure(self._h))
 
     def sha256_blocks_entry_point(self, n_blocks: int):
         _check(lib().zk_circuit_sha256_blocks(self._h, n_blocks))
@@ -990,10 +995,14 @@ class ConstraintSystem:
     def vm_shaped_entry_point(self, limit: int):
         _check(lib().zk_circuit_vm_shaped(self._h, limit))
 
-    def configure_main_vm(self, defs: "OpcodeDefs | None" = None):
-        """zk_circuit_main_vm_configure: tables / gate set of the VM CS from the opcode-defs blob (include/zkgl_vm.h)"""
+    def configure_main_vm(self, defs: "OpcodeDefs | None" = None, u8x4_fma_gate: bool = True):
+        """zk_circuit_main_vm_configure: tables / gate set of the VM CS from the opcode-defs blob (include/zkgl_vm.h).
+        u8x4_fma_gate=False: ZK_VM_CFG_U32_FMA_ROLE (the mul / div relation through the one-relation u32 gate of rounds 1-3)"""
         self._defs = defs if defs is not None else opcode_defs_default()
-        _check(lib().zk_circuit_main_vm_configure(self._h, C.byref(self._defs)))
+        if u8x4_fma_gate:
+            _check(lib().zk_circuit_main_vm_configure(self._h, C.byref(self._defs)))
+        else:
+            _check(lib().zk_circuit_main_vm_configure_flags(self._h, C.byref(self._defs), 1))
 
     def main_vm_entry_point(self, limit: int):
         _check(lib().zk_circuit_main_vm(self._h, C.c_uint32(limit)))

@@ -263,7 +263,7 @@ typedef struct zk_stats {
     uint64_t variables_outer, variables_loop;
     uint64_t constraints_per_instance; /* relations of placed gate instances + lookup tuples */
     uint64_t var_cells_per_instance;   /* trace cells (rows * variable columns) */
-    uint64_t gate_instances[ZK_GATE__COUNT]; /* per instance */
+    uint64_t gate_instances[16];     /* per instance, indexed by zk_gate_kind (16 slots: the struct does not change size with the gate set) */
     uint64_t lookups_per_instance;
     uint64_t program_words_outer, program_words_loop;
     uint64_t scratch_cells_outer, scratch_cells_loop;
@@ -400,6 +400,12 @@ int zk_circuit_eip_4844(zk_cs *cs, uint32_t n_chunks);
 /* SHA-256 over n_blocks pre-padded 64-byte blocks (compression step of sha256_precompile_inner,
  * src/sha256_round_function/mod.rs:271-285) through 8-bit lookup tables.  Public inputs = the 32 digest bytes. */
 int zk_circuit_sha256_configure(zk_cs *cs);
+/* The reference's OWN configuration of the SHA circuits (src/code_unpacker_sha256/mod.rs:484-566): lookup width 4 x 8 repetitions and
+ * exactly its five width-4 tables — Maj4Table, TriXor4Table, Ch4Table, Split4BitChunkTable<1>, Split4BitChunkTable<2> — and no 8-bit
+ * table.  zk_circuit_sha256_blocks / zk_circuit_sha256_round_function / zk_circuit_code_unpacker recorded into a CS configured this
+ * way use the 4-bit-chunk compression (csrc/circuits/sha256_gadget4.hpp) and range-check bytes through TriXor4; same input streams,
+ * same public inputs as with zk_circuit_sha256_configure (the 8-bit engine tables), a different row count (zk_stats). */
+int zk_circuit_sha256_configure_reference_tables(zk_cs *cs);
 int zk_circuit_sha256_blocks(zk_cs *cs, uint32_t n_blocks);
 /* sha256_round_function_entry_point (src/sha256_round_function/mod.rs:347-468): the precompile FSM — request
  * queue pop, 2 memory reads + 1 conditional write per cycle on the full-state memory queue, one compression

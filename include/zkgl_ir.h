@@ -45,7 +45,9 @@ enum zk_opcode {
     ZK_OP_MATMUL12 = 10, /* a=matrix id (0 external, 1 inner); [in0..11] -> out0..11  (MatrixMultiplicationGate) */
     ZK_OP_SPLIT = 11,    /* a=nchunks, b=bits per chunk; [x] -> chunks (LSB first)    (decompose_into_bytes etc.) */
     ZK_OP_LOOKUP = 12,   /* a=nkeys, b=nvals; [table id word, keys..] -> vals         (perform_lookup) */
-    ZK_OP_POSEIDON2 = 13,/* [in0..11] -> out0..11 witness-only permutation            (simulate_round_function) */
+    ZK_OP_POSEIDON2 = 13,/* [in0..11] -> out0..11 witness-only permutation            (simulate_round_function);
+                          * a=1: [in0..11, execute] -> execute ? permutation : 0^12, the reference's gated form
+                          * simulate_round_function(cs, state, execute) (/root/reference/src/main_vm/opcodes/log.rs:532) */
     ZK_OP_P2_ROUNDS = 14,/* in-circuit permutation macro-op: [in0..11, rc cell x118] -> every intermediate, see zkgl_ir docs */
     ZK_OP_LOOP_LAST = 15,/* outer scope, post phase: [loop cell word] -> value at the last iteration */
     ZK_OP_U32MULADD = 16,/* [a, b, c, d] -> lo, hi of a*b + c + d  (u32 each)         (UInt32::fma_with_carry) */
@@ -68,6 +70,10 @@ enum zk_opcode {
                               * /root/reference/src/main_vm/opcodes/mul_div.rs:20-92: ethereum_types::U256::full_mul) */
     ZK_OP_U256_DIVREM = 24,  /* [a0..7, b0..7] -> q0..7, r0..7 of a / b; b == 0 => q = 0, r = a
                               *                                              (allocate_div_result_unchecked, mul_div.rs:96-172) */
+    ZK_OP_U8X4FMA = 25,      /* [a0..3, b0..3, c0..3, d0..3] (little-endian bytes of four u32) -> lo0..3, hi0..3, k0, k1 (bytes):
+                              * a*b + c + d = lo + 2^32 hi; k = k0 + 256 k1 = the carry of the low 32 bits,
+                              * k = (sum_{i+j<4} a_i b_j 2^(8(i+j)) + c + d) >> 32          (UInt32::fma_with_carry over U8x4FMAGate,
+                              * /root/reference/src/main_vm/opcodes/mod.rs:146-158) */
     ZK_OP__COUNT
 };
 
@@ -88,6 +94,12 @@ enum zk_gate_kind {
     ZK_GATE_U32_FMA = 12,  /* a,b,c,d,lo,hi  : a*b + c + d - lo - 2^32 hi  (U8x4FMAGate role) */
     ZK_GATE_REDUCTION_BY_POWERS4 = 13, /* t0..t3,r ; c : t0 + c t1 + c^2 t2 + c^3 t3 - r  (ReductionByPowersGate<F,4>,
                                         * /root/reference/src/main_vm/decoded_opcode.rs:275, opcodes/binop.rs:203-217) */
+    ZK_GATE_U8X4_FMA = 14, /* a0..3,b0..3,c0..3,d0..3,lo0..3,hi0..3,k0,k1 (26 byte variables), two relations over integers < 2^50:
+                            *   sum_{i+j<4}  a_i b_j 2^(8(i+j))   + c + d - lo - 2^32 (k0 + 256 k1)
+                            *   sum_{i+j>=4} a_i b_j 2^(8(i+j-4)) + (k0 + 256 k1) - hi
+                            * (U8x4FMAGate, /root/reference/src/main_vm/opcodes/mod.rs:146; boojum's column order is [EXT]).  Unlike the
+                            * one-relation ZK_GATE_U32_FMA, whose a*b + c + d and lo + 2^32 hi both range up to 2^64 - 1 > p and may
+                            * therefore differ by p, no term here can wrap the field once the bytes are range-checked. */
     ZK_GATE__COUNT
 };
 

@@ -102,6 +102,12 @@ int zk_opcode_defs_find(const zk_opcode_defs *defs, uint32_t family, uint32_t va
  * loop body.  configure: geometry check (src/main_vm/cycle.rs:959-966), gate set, the VM tables of the src/tables sources built from
  * the blob, BinopTable, Xor8 (range checks).  Input streams: see csrc/circuits/main_vm.cpp and zk_circuit_main_vm_layout. */
 int zk_circuit_main_vm_configure(zk_cs *cs, const zk_opcode_defs *defs);
+/* The same with options.  ZK_VM_CFG_U32_FMA_ROLE: do NOT allow U8x4FMAGate (ZK_GATE_U8X4_FMA); the mul / div relation
+ * (enforce_mul_relation, src/main_vm/opcodes/mod.rs:130-180) is then recorded with the engine's one-relation u32 gate
+ * ZK_GATE_U32_FMA, the decomposition of rounds 1-3 — kept to report both row counts; the reference has only the U8x4FMAGate
+ * branch (`else { unimplemented!() }`), which is what zk_circuit_main_vm_configure records. */
+#define ZK_VM_CFG_U32_FMA_ROLE 1u
+int zk_circuit_main_vm_configure_flags(zk_cs *cs, const zk_opcode_defs *defs, uint32_t flags);
 int zk_circuit_main_vm(zk_cs *cs, uint32_t limit);
 /* text description of the input streams of the recorded circuit, one field per line: "<scope> <name> <first word> <n words>\n"
  * (scope = outer | loop).  buf = NULL returns the size. */

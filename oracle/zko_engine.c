@@ -215,6 +215,11 @@ static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
             uint64_t v[12];
             for (int i = 0; i < 12; ++i) v[i] = ld(c, prog[pc + i], lane, inst);
             pc += 12;
+            if (pa) { /* gated: simulate_round_function(cs, state, execute) yields zeros when the flag is off */
+                uint64_t execute = ld(c, prog[pc], lane, inst);
+                pc += 1;
+                if (!execute) { for (int i = 0; i < 12; ++i) st(c, prog, &pc, lane, 0); break; }
+            }
             zko_poseidon2_permute(v);
             for (int i = 0; i < 12; ++i) st(c, prog, &pc, lane, v[i]);
         } break;
@@ -248,6 +253,36 @@ static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
             uint64_t r = a * b + cc + d;
             st(c, prog, &pc, lane, r & 0xffffffffull);
             st(c, prog, &pc, lane, r >> 32);
+        } break;
+        case ZK_OP_U8X4FMA: { /* include/zkgl_ir.h: a*b + c + d over bytes, schoolbook over the 16 byte products; wrapping u64 arithmetic
+                               * like the device (defined for any operands, the gate judges them) */
+            uint64_t x[16];
+            for (int i = 0; i < 16; ++i) x[i] = ld(c, prog[pc + i], lane, inst);
+            pc += 16;
+            uint64_t cc = 0, dd = 0, low = 0, high = 0;
+            for (int i = 0; i < 4; ++i) { cc += x[8 + i] << (8 * i); dd += x[12 + i] << (8 * i); }
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t pr = x[i] * x[4 + j];
+                    if (i + j < 4) low += pr << (8 * (i + j)); else high += pr << (8 * (i + j - 4));
+                }
+            uint64_t X = low + cc + dd, kk = X >> 32, r_lo = X & 0xffffffffull, r_hi = high + kk;
+            /* the device forms r = a*b + c + d in one u64; identical whenever the operands are bytes (r_hi < 2^32).  For operands
+             * that are not, reproduce its wrapping result so that traces stay comparable: */
+            {
+                uint64_t a = x[0] + (x[1] << 8) + (x[2] << 16) + (x[3] << 24), b = x[4] + (x[5] << 8) + (x[6] << 16) + (x[7] << 24);
+                uint64_t r = a * b + cc + dd;
+                uint64_t t = x[0] * b + ((x[1] * (b & 0xffffffull)) << 8) + ((x[2] * (b & 0xffffull)) << 16) + ((x[3] * (b & 0xffull)) << 24);
+                uint64_t k2 = (t + cc + dd) >> 32;
+                int bytes_ok = 1;
+                for (int i = 0; i < 16; ++i) bytes_ok &= x[i] < 256;
+                if (bytes_ok && (r != (r_lo | (r_hi << 32)) || k2 != kk)) return -1; /* the two formulations must agree on bytes */
+                r_lo = r & 0xffffffffull; r_hi = r >> 32; kk = k2;
+            }
+            for (int i = 0; i < 4; ++i) st(c, prog, &pc, lane, (r_lo >> (8 * i)) & 0xff);
+            for (int i = 0; i < 4; ++i) st(c, prog, &pc, lane, (r_hi >> (8 * i)) & 0xff);
+            st(c, prog, &pc, lane, kk & 0xff);
+            st(c, prog, &pc, lane, (kk >> 8) & 0xff);
         } break;
         case ZK_OP_NN_MULMOD: { /* A*B = q*M + r, base 2^16: schoolbook product + bit-serial restoring division */
             uint64_t prod[40] = {0}, rem[18] = {0}, mod[16];
@@ -395,7 +430,7 @@ int zko_scope_run_seq(const zko_scope *s, uint64_t *cells, size_t stride, uint32
     return bad ? -1 : 0;
 }
 
-static const unsigned char GW[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5};
+static const unsigned char GW[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5, 26};
 
 /* Evaluate every gate relation + lookup tuple + copy pair. Returns the number of violated
  * relations; *first_key = packed (lane<<32 | slot<<12 | j<<4 | rel) of the smallest one (gates),
@@ -467,6 +502,27 @@ uint64_t zko_scope_check(const zko_scope *s, const uint64_t *cells, size_t strid
                     uint64_t lhs = zko_gl_add(zko_gl_add(zko_gl_mul(CELL(c0), CELL(c0 + 1)), CELL(c0 + 2)), CELL(c0 + 3));
                     uint64_t rhs = zko_gl_add(CELL(c0 + 4), zko_gl_mul(CELL(c0 + 5), 1ull << 32));
                     if (lhs != rhs) FAIL(j, 0);
+                } break;
+                case ZK_GATE_U8X4_FMA: { /* both relations term by term over the 16 byte products */
+                    nrel += 2;
+                    uint64_t r0 = 0, r1 = 0;
+                    for (int i = 0; i < 4; ++i)
+                        for (int jj = 0; jj < 4; ++jj) {
+                            uint64_t pr = zko_gl_mul(CELL(c0 + i), CELL(c0 + 4 + jj));
+                            if (i + jj < 4) r0 = zko_gl_add(r0, zko_gl_mul(pr, 1ull << (8 * (i + jj))));
+                            else r1 = zko_gl_add(r1, zko_gl_mul(pr, 1ull << (8 * (i + jj - 4))));
+                        }
+                    uint64_t kk = zko_gl_add(CELL(c0 + 24), zko_gl_mul(CELL(c0 + 25), 256));
+                    for (int i = 0; i < 4; ++i) {
+                        uint64_t sh = 1ull << (8 * i);
+                        r0 = zko_gl_add(r0, zko_gl_mul(zko_gl_add(CELL(c0 + 8 + i), CELL(c0 + 12 + i)), sh));
+                        r0 = zko_gl_sub(r0, zko_gl_mul(CELL(c0 + 16 + i), sh));
+                        r1 = zko_gl_sub(r1, zko_gl_mul(CELL(c0 + 20 + i), sh));
+                    }
+                    r0 = zko_gl_sub(r0, zko_gl_mul(kk, 1ull << 32));
+                    r1 = zko_gl_add(r1, kk);
+                    if (r0 != 0) FAIL(j, 0);
+                    if (r1 != 0) FAIL(j, 1);
                 } break;
                 case ZK_GATE_REDUCTION_BY_POWERS4: { /* t0 + c t1 + c^2 t2 + c^3 t3 == r, evaluated term by term */
                     ++nrel;
