@@ -40,7 +40,11 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 VM_STATE_WORDS = 243   # VmLocalState, the carried part of the loop stream
-FIXTURE = os.path.join(ROOT, "tests", "golden", "vm_bench_witness.npz")
+FIXTURES = {"default": os.path.join(ROOT, "tests", "golden", "vm_bench_witness.npz"),
+            # the compiled-contract-like opcode mix (tests/vm_programs.py program_bench_loop(realistic=True)): ~1 % logs, ~0.5 % calls,
+            # ~10 % heap accesses, the rest arithmetic / jumps / stack traffic; same circuit, same limit
+            "realistic": os.path.join(ROOT, "tests", "golden", "vm_bench_witness_realistic.npz")}
+FIXTURE = FIXTURES["default"]
 
 
 # ------------------------------------------------------------------------------------------------ main_vm workload
@@ -63,10 +67,10 @@ def build_main_vm_cs(zkgl, log2_rows):
 _FIFOS = ("memory_reads", "storage_reads", "refunds", "rollback_queue_witness", "rollback_tails_for_call", "callstack", "decommit_pages")
 
 
-def main_vm_streams(zkgl, cs, limit, n_exec=None):
+def main_vm_streams(zkgl, cs, limit, n_exec=None, fixture=None):
     """(outer [words, E], loop [words, E * limit] with the carried VM state zero, expected commitments [E, 4] or None): the fixture's
     VmCircuitWitnesses — closed-form input + the WitnessOracle's per-getter FIFOs — through the product's zk_pack_main_vm_witness"""
-    fx = np.load(FIXTURE)
+    fx = np.load(fixture or FIXTURE)
     E = int(fx["commitment"].shape[0]) if n_exec is None else min(int(n_exec), int(fx["commitment"].shape[0]))
     n_outer, n_loop = cs.input_words()
     outer = np.zeros((n_outer, E), dtype=np.uint64)
@@ -191,6 +195,7 @@ def main():
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--workload", default="main_vm", choices=["main_vm", "vm_shaped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fixture", default="default", choices=sorted(FIXTURES), help="which synthetic executions main_vm replays (default: every opcode family every ~150 cycles)")
     args = ap.parse_args()
     # ---- N > 1 without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -239,7 +244,7 @@ def main():
         cs, limit = build_main_vm_cs(zkgl, args.log2_rows)
         n_outer, n_loop = cs.input_words()
         t_pack = time.perf_counter()
-        outer_e, loop_e, expect_e = main_vm_streams(zkgl, cs, limit)   # zk_pack_main_vm_witness: FIFOs -> streams, all executions
+        outer_e, loop_e, expect_e = main_vm_streams(zkgl, cs, limit, fixture=FIXTURES[args.fixture])   # zk_pack_main_vm_witness: FIFOs -> streams, all executions
         t_pack = time.perf_counter() - t_pack
         n_exec = outer_e.shape[1]
         # the stream is assembled on the device: instance i replays execution (rank * S + i) % n_exec of the fixture
@@ -357,12 +362,12 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    loop_ms, check_ms, gate_ms, outer_ms, shader_mhz = [], [], [], [], []
+    loop_ms, check_ms, gate_ms, outer_ms, shader_mhz, p2_skipped = [], [], [], [], [], []
     commits = None
     for _ in range(args.steps):
         commits = step(timed=True)
         loop_ms.append(cs.last_ms(1)); check_ms.append(cs.last_ms(2)); gate_ms.append(cs.last_ms(3)); outer_ms.append(cs.last_ms(4))
-        shader_mhz.append(cs.last_ms(8))
+        shader_mhz.append(cs.last_ms(8)); p2_skipped.append(cs.last_ms(9))
     fence()
     elapsed_local = time.perf_counter() - t0
     local = np.array([cs.public_inputs(i) for i in range(B)], dtype=np.uint64)
@@ -453,7 +458,7 @@ def main():
         k_ms = float(np.mean(loop_ms))
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        for name in ("pmc_r3.json", "pmc_r2.json"):
+        for name in ("pmc_r4.json", "pmc_r3.json", "pmc_r2.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = pmc["traffic_over_algorithmic"] * algo_bytes
@@ -487,7 +492,7 @@ def main():
                           "(tests/test_fused_differential.py)",
             "value_from_raw_witness_serial": per_step_constraints / (res_s + t_seed_stream / K),
             "witness_rows_materialised_per_s": None if mat_s is None else st["rows_per_instance"] * n_inst / (step_s + B * mat_s),
-            "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/vm_bench_witness.npz, "
+            "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/" + os.path.basename(FIXTURES[args.fixture]) + ", "
                                     f"{n_exec} distinct executions through zk_pack_main_vm_witness)"
                                     if args.workload == "main_vm" else "main_vm-shaped micro-workload (round 1)") +
                                    f", geometry 140/0/8/deg8 + 3x8 lookups, 2^{args.log2_rows} rows/instance",
@@ -508,6 +513,9 @@ def main():
                          # clock probe inside the kernel (s_memtime / s_memrealtime of its first wavefront): the clock the power management
                          # granted this launch (2.09-2.27 GHz seen; the kernel's time has not followed it, profiles/r3_loop_probe.md §4)
                          "shader_clock_mhz": float(np.mean(shader_mhz)),
+                         # simulate_round_function(cs, state, execute): 18 of the cycle's 27 permutations are witness-only and gated by the
+                         # reference's flag; a wavefront (64 consecutive cycles of one instance) whose cycles all have it off skips the permutation
+                         "witness_only_permutations_skipped_frac": float(np.mean(p2_skipped)),
                          "values_written_per_cycle": st["cells_written_loop"], "trace_cells_populated_per_cycle": st["cells_populated_loop"],
                          "trace_cell_equivalent_GBps": cell_bytes / (k_ms * 1e-3) / 1e9,
                          "hbm_busy_GBps": None if traffic is None else traffic / (k_ms * 1e-3) / 1e9,

@@ -2201,7 +2201,7 @@ void CS::ensure_uploaded() {
         d_seed_sprog_ = upload(padded);
         d_seed_scarries_ = (void*)upload(seed_scarries_);
     }
-    hip_check(hipMalloc((void**)&d_fail_, 8 * sizeof(unsigned long long)), "hipMalloc fail words");
+    hip_check(hipMalloc((void**)&d_fail_, 16 * sizeof(unsigned long long)), "hipMalloc fail words");   // 0..5 failure keys, 6..7 clock probe, 8..9 permutation skip counters
     for (auto& e : ev_) {
         hipEvent_t he;
         hip_check(hipEventCreate(&he), "hipEventCreate");
@@ -2777,6 +2777,8 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     last_check_fused_ = fused;
     if (fused) { oa.fail = d_fail_; la.fail = d_fail_ + 3; }
     la.clock_probe = d_fail_ + 6;   // words 6, 7 of the block travel back with the verdict
+    hip_check(hipMemsetAsync(d_fail_ + 8, 0, 2 * sizeof(unsigned long long), st), "memset p2 stats");
+    la.p2_stats = d_fail_ + 8;      // words 8, 9: gated witness-only permutations skipped / run by the loop kernel's wavefronts
     hip_check(hipEventRecord(E(0), st), "event");                     // t0 (+ memsets done)
     hip_check(hipStreamWaitEvent(ax, E(0), 0), "wait");
     launch_phase(outer_, oa, 0, ax);    // outer PRE
@@ -2811,9 +2813,10 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
         check_streams(st, true);
     }
     hip_check(hipEventRecord(E(7), st), "event");
-    unsigned long long f[8];
+    unsigned long long f[10];
     hip_check(hipMemcpyAsync(f, d_fail_, sizeof f, hipMemcpyDeviceToHost, st), "memcpy fail");
     hip_check(hipStreamSynchronize(st), "pipeline sync");
+    p2_skipped_ = f[8]; p2_run_ = f[9];
     float loop_ms = 0, gates_ms = 0, copies_ms = 0, total = 0, outer_post = 0;
     hipEventElapsedTime(&loop_ms, E(2), E(3));
     hipEventElapsedTime(&gates_ms, E(3), E(5));
@@ -2956,7 +2959,8 @@ void CS::stats(zk_stats* o) const {
 
 float CS::last_ms(int which) const {
     if (which >= 5 && which < 8) return last_seed_phase_ms[which - 5];  // native seeding phases (ZKGL_SEED_PHASE_MS=1): walker, chains, fill
-    if (which == 8) return loop_shader_mhz_;  // not a time: the shader clock (MHz) the last resolve_and_check's loop launch ran at
+    if (which == 8) return loop_shader_mhz_;
+    if (which == 9) return (p2_skipped_ + p2_run_) ? (float)((double)p2_skipped_ / (double)(p2_skipped_ + p2_run_)) : 0.0f;  // not a time either  // not a time: the shader clock (MHz) the last resolve_and_check's loop launch ran at
     return (which >= 0 && which < 5) ? ms_[which] : -1.0f;
 }
 

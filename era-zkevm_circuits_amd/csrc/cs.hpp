@@ -385,6 +385,7 @@ class CS {
     float ms_[5] = {0, 0, 0, 0, 0};
     float loop_shader_mhz_ = 0;   // clock probe of the last resolve_and_check's loop launch (last_ms(8))
     bool last_check_fused_ = false;
+    uint64_t p2_skipped_ = 0, p2_run_ = 0;   // gated witness-only permutations of the last resolve_and_check's loop launch, per wavefront
     bool check_stored_ = false;   // zk_cs_set_check_mode(ZK_CHECK_STORED)
 };
 

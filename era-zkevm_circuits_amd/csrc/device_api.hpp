@@ -19,6 +19,7 @@ struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     uint64_t in_stride;    // lanes between consecutive words of the input stream (>= n_lanes: a batch may be a window of a longer stream)
     uint32_t uses_bigint;  // host only: the program contains ZK_OP_NN_MULMOD -> launch the *_bigint kernel variants
     unsigned long long* fail = nullptr;  // fused mode: where the witness kernels report a gate they evaluate themselves (SELECT with a non-boolean selector)
+    unsigned long long* p2_stats = nullptr;     // two counters: gated witness-only permutations a wavefront skipped / ran (ZK_OP_POSEIDON2 a = 1)
     unsigned long long* clock_probe = nullptr;  // two words: shader-clock and 100 MHz ticks of the grid's first wavefront (kernels_engine2.hpp witness_entry2)
 };
 struct CheckArgs {  // mirrors zke::CheckDev

@@ -411,7 +411,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 lane_off = ldv(W[13]) == 0;
                 out_to(W[14]);
                 pc += 14 + D;
-                if (__builtin_amdgcn_ballot_w64(!lane_off) == 0) {
+                const bool all_off = __builtin_amdgcn_ballot_w64(!lane_off) == 0;
+                if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats + (all_off ? 0 : 1), 1ull);
+                if (all_off) {
 #pragma unroll
                     for (int i = 0; i < 12; ++i) st(0ull);
                     break;

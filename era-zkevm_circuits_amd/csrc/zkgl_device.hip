@@ -129,6 +129,7 @@ static zke::ScopeDev to_dev(const ScopeArgs& a) {
     d.loop_limit = a.loop_limit;
     d.fail = a.fail;
     d.clock_probe = a.clock_probe;
+    d.p2_stats = a.p2_stats;
     return d;
 }
 

@@ -329,7 +329,9 @@ int zk_cs_stats(zk_cs *cs, zk_stats *out);           /* print_gate_stats counter
  * 5 / 6 / 7: the last seeding pass of a circuit with a native seeder (main_vm) when ZKGL_SEED_PHASE_MS is set: state walker,
  * Poseidon2 chains, fill;
  * 8: not a time — the shader clock in MHz that the loop witness kernel of the last zk_cs_resolve_and_check ran at (s_memtime against
- * the constant 100 MHz counter over the grid's first wavefront): the chip's power management picks it per launch */
+ * the constant 100 MHz counter over the grid's first wavefront): the chip's power management picks it per launch;
+ * 9: not a time — the share of the gated witness-only permutations (simulate_round_function(cs, state, execute), ZK_OP_POSEIDON2 a = 1)
+ * that the wavefronts of the last loop launch skipped because all their 64 cycles had the flag off */
 int zk_cs_last_ms(zk_cs *cs, int which, float *ms);
 /* serialised scope (program + descriptors) for the CPU oracle / offline tooling.
  * Call with buf = NULL to get the size in words. */

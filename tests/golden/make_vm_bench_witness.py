@@ -7,7 +7,7 @@ by the native restatement oracle/main_vm_native.py, plus the input commitment th
 into the circuit's input streams with the product's own zk_pack_main_vm_witness, lets the device derive the carried state
 (zk_cs_seed_window_async) and compares the public inputs it gets with the commitments stored here.
 
-    python tests/golden/make_vm_bench_witness.py
+    python tests/golden/make_vm_bench_witness.py [--realistic]
 """
 import json
 import os
@@ -29,7 +29,7 @@ FIFOS = ("memory_reads", "storage_reads", "refunds", "rollback_queue_witness", "
 WIDTH = dict(memory_reads=9, storage_reads=8, refunds=1, rollback_queue_witness=4, rollback_tails_for_call=4, callstack=54, decommit_pages=1)
 
 
-def main():
+def main(realistic=False):
     d, D = vp.defs()
     probe = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), 1 << 30, 1 << 28)
     probe.configure_main_vm(d)
@@ -43,7 +43,7 @@ def main():
     commits = np.zeros((N_EXEC, 4), dtype=np.uint64)
     families = np.zeros((N_EXEC, 16), dtype=np.uint32)
     for e in range(N_EXEC):
-        ops, contracts = vp.program_bench_loop(D, e)
+        ops, contracts = vp.program_bench_loop(D, e, realistic=realistic)
         vrun = vn.VmRun(D, vp.make_world_factory(D, ops, contracts), limit)
         q = vp.oracle_queues(vrun, 0, limit)
         rows = dict(memory_reads=[list(v) + [p] for v, p in q.memory_reads], storage_reads=[list(v) for v in q.storage_reads],
@@ -58,7 +58,7 @@ def main():
         tails[e] = np.array(vrun.rollback_tail_for_block, dtype=np.uint64)
         commits[e] = np.array(vp.expected_commitment(D, vrun, limit, 0), dtype=np.uint64)
         print(f"execution {e}: {limit} cycles, {[offsets[k][-1] - offsets[k][-2] for k in FIFOS]} oracle answers, commitment {[hex(int(x)) for x in commits[e]]}", flush=True)
-    out = os.path.join(HERE, "vm_bench_witness.npz")
+    out = os.path.join(HERE, "vm_bench_witness_realistic.npz" if realistic else "vm_bench_witness.npz")
     arrays = {k: np.array(fifo[k], dtype=np.uint64).reshape(-1, WIDTH[k]) for k in FIFOS}
     arrays.update({k + "_offsets": np.array(offsets[k], dtype=np.int64) for k in FIFOS})
     np.savez_compressed(out, rollback_tail=tails, commitment=commits, limit=np.array([limit]), log2_rows=np.array([LOG2_ROWS]),
@@ -67,4 +67,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(realistic="--realistic" in sys.argv)   # --realistic: the compiled-contract-like mix (vm_programs.program_bench_loop)

@@ -250,13 +250,45 @@ def program_calls(D, seed=0, callee_a=0x10001, callee_b=0x10002, callee_c=0x1000
     return a.ops, {callee_a: ca.ops, callee_b: cb.ops, callee_c: cc.ops}
 
 
-def program_bench_loop(D, seed=0, callee_a=0x10001, callee_c=0x10004):
+def program_bench_loop(D, seed=0, callee_a=0x10001, callee_c=0x10004, realistic=False):
     """endless mixed workload for the throughput runs (bench.py config C2): every family, calls nested two deep, the root frame
-    never returns.  One trip around the loop is ~150 cycles."""
+    never returns.  One trip around the loop is ~150 cycles.
+    realistic=True: the same trip behind a counted inner loop of register / stack / heap arithmetic (40 x 21 instructions), so that
+    the mix looks like compiled contract code — ~1 % storage / event logs, ~0.3 % near calls, ~0.2 % far calls, ~10 % heap accesses,
+    the rest arithmetic, jumps and stack traffic — instead of every family every 150 cycles."""
     a = Asm(D)
     a.li(9, 3)
     a.emit("CONTEXT", "CTX_SET_ERGS_PER_PUBDATA", src0=9)
     top = len(a.ops)
+    if realistic:
+        a.li(15, 40)
+        a.li(14, 1)
+        a.li(1, (0x1234 + 977 * seed) & 0xFFFF)
+        a.li(2, 77 + seed)
+        a.li(13, 7)
+        a.li(12, 96)
+        inner_top = len(a.ops)
+        a.emit("ADD", src0=1, src1=2, dst0=3)
+        a.emit("SUB", src0=3, src1=14, dst0=4, flags=("SET_FLAGS",))
+        a.emit("BINOP", "BINOP_AND", src0=3, src1=4, dst0=5)
+        a.emit("BINOP", "BINOP_XOR", src0=5, src1=1, dst0=6)
+        a.emit("SHIFT", "SHIFT_SHL", src0=6, src1=13, dst0=7)
+        a.emit("ADD", src0=7, src1=0, dst_mode="STACK_PUSH_POP", imm1=1)                    # push
+        a.emit("ADD", src0=4, src1=0, dst_mode="STACK_PUSH_POP", imm1=1)                    # push
+        a.emit("MUL", src0=3, src1=5, dst0=8, dst1=9)
+        a.emit("ADD", src_mode="STACK_PUSH_POP", imm0=1, src1=8, dst0=10)                   # pop
+        a.emit("ADD", src_mode="STACK_PUSH_POP", imm0=1, src1=10, dst0=11)                  # pop
+        a.emit("UMA", "UMA_HEAP_WRITE", src0=12, src1=11)
+        a.emit("BINOP", "BINOP_OR", src0=11, src1=2, dst0=1)
+        a.emit("UMA", "UMA_HEAP_READ", src0=12, dst0=2)
+        a.emit("ADD", src0=2, src1=14, dst0=2)
+        a.emit("SUB", src0=1, src1=2, dst0=3, flags=("SET_FLAGS",))
+        a.emit("ADD", src0=3, src1=1, dst0=1, cond="GT")
+        a.emit("SHIFT", "SHIFT_SHR", src0=1, src1=13, dst0=4)
+        a.emit("ADD", src_mode="CODE_PAGE", imm0=1, src1=4, dst0=5)
+        a.emit("DIV", src0=8, src1=13, dst0=6, dst1=7)
+        a.emit("SUB", src0=15, src1=14, dst0=15, flags=("SET_FLAGS",))
+        a.emit("JUMP", src_mode="IMM16", imm0=inner_top, cond="NE")
     a.li(1, (0x1234 + 977 * seed) & 0xFFFF)
     a.li(2, 77 + seed)
     a.emit("SUB", src0=2, src1=1, dst0=4, flags=("SET_FLAGS",))
