@@ -13,6 +13,7 @@
 #include "device_api.hpp"
 #include "poseidon_consts.hpp"
 #include "../../include/zkgl_vm.h"
+#include "keccak_macro.hpp"
 
 static constexpr int ZK_MACRO_FAILURE = 0x7fff0001;  // internal: a macro check packet failed, re-run the gate-by-gate program
 
@@ -328,6 +329,15 @@ void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uin
     case ZK_OP_P2_ROUNDS: need(12, 962, 0); break;
     case ZK_OP_U32MULADD: need(4, 2, 0); break;
     case ZK_OP_U8X4FMA: need(16, 10, 0); break;
+    case ZK_OP_KECCAK_F: {
+        if (!allow_macro_ops_) throw ZkError(ZK_ERR_INVALID, "emit_op: macro-ops are recorded by the engine's gadgets only");
+        zkk::CountBackend cb; int dummy[25] = {0}; uint64_t rc[24];
+        for (int i = 0; i < 24; ++i) rc[i] = zkk::RC[i];
+        zkk::keccak_f(cb, dummy, rc);
+        need(200, cb.n, 0);
+        s.uses_bigint = true;   // the heavy kernel variants (register budget of the macro-op) carry its handler
+        uses_lookup_macros_ = true;
+    } break;
     case ZK_OP_NN_MULMOD:
         if (a == 0 || a > 17 || b == 0 || b > 17 || a + b < 16 || n_in != a + b || n_imm != 16 || n_out != a + b - 15 + 16)
             throw ZkError(ZK_ERR_INVALID, "NN_MULMOD: bad shape");
@@ -376,6 +386,25 @@ void CS::lookup(uint32_t tid, const zk_var* keys, uint32_t n_keys, zk_var* vals,
     }
     s.ops.push_back(std::move(op));
     s.lookups.push_back(std::move(lr));
+}
+
+void CS::lookup_given(uint32_t tid, const zk_var* keys, uint32_t n_keys, const zk_var* vals, uint32_t n_vals) {
+    if (tid == 0 || tid > tables_.size()) throw ZkError(ZK_ERR_INVALID, "lookup_given: unknown table id");
+    const TableRec& t = tables_[tid - 1];
+    if (n_keys != t.n_keys || n_vals != t.n_vals) throw ZkError(ZK_ERR_INVALID, "lookup_given: K/V mismatch with table");
+    LookupRec lr;
+    lr.table = tid;
+    for (uint32_t i = 0; i < n_keys; ++i) { check_var(keys[i], in_loop_); lr.vars.push_back(var_index(keys[i])); }
+    for (uint32_t i = 0; i < n_vals; ++i) { check_var(vals[i], in_loop_); lr.vars.push_back(var_index(vals[i])); }
+    cur().lookups.push_back(std::move(lr));
+}
+
+void CS::emit_macro_op(uint32_t opcode, const zk_var* ins, uint32_t n_in, zk_var first_out, uint32_t n_out) {
+    std::vector<zk_var> outs(n_out);
+    for (uint32_t i = 0; i < n_out; ++i) outs[i] = first_out + i;
+    allow_macro_ops_ = true;
+    try { emit_op(opcode, 0, 0, ins, n_in, outs.data(), n_out, nullptr, 0); } catch (...) { allow_macro_ops_ = false; throw; }
+    allow_macro_ops_ = false;
 }
 
 void CS::loop_begin(uint32_t limit) {
@@ -663,6 +692,9 @@ void CS::build_check_program(Scope& s) {
             } break;
             case ZK_GATE_REDUCTION4: case ZK_GATE_REDUCTION_BY_POWERS4: {
                 const OpRec* op = prod(g.vars[4]);
+                // a rotated byte inside the Keccak macro-op: lo 2^b + hi computed by the op from the very lo / hi it stores (keccak_macro.hpp
+                // rotl); only the engine's gadget can record the op (emit_macro_op), and it places this gate from the same structure
+                if (op && op->opcode == ZK_OP_KECCAK_F && g.kind == ZK_GATE_REDUCTION4) { m = true; break; }
                 if (op && op->opcode == ZK_OP_LC4 && op->ins.size() == 8) {
                     m = true;
                     uint64_t pw = 1;
@@ -907,16 +939,11 @@ void CS::build_check_program(Scope& s) {
 void CS::build_mult_sites(Scope& s) {
     const size_t nt = tables_.size() + 1;  // table ids are 1-based
     std::vector<std::vector<uint32_t>> by_table(nt);
-    for (auto& op : s.ops) {
-        if (op.seed_only || op.opcode != ZK_OP_LOOKUP) continue;
-        const uint32_t tid = op.ins[0].idx;
-        if (tid >= nt) throw ZkError(ZK_ERR_INVALID, "internal: lookup into an unknown table");
-        for (size_t q = 1; q <= 3; ++q) {
-            if (q < op.ins.size()) {
-                if (op.ins[q].kind != Operand::VAR) throw ZkError(ZK_ERR_INVALID, "internal: lookup key is not a variable");
-                by_table[tid].push_back(s.var_slot[op.ins[q].idx]);
-            } else by_table[tid].push_back(0xffffffffu);
-        }
+    for (auto& l : s.lookups) {   // every recorded tuple: those of ZK_OP_LOOKUP and those placed on a macro-op's outputs (lookup_given)
+        const uint32_t tid = l.table;
+        if (tid == 0 || tid >= nt) throw ZkError(ZK_ERR_INVALID, "internal: lookup into an unknown table");
+        const uint32_t nk = tables_[tid - 1].n_keys;
+        for (size_t q = 0; q < 3; ++q) by_table[tid].push_back(q < nk ? s.var_slot[l.vars[q]] : 0xffffffffu);
     }
     s.mult_sites.clear(); s.mult_site_off.assign(nt + 1, 0);
     for (size_t t = 0; t < nt; ++t) {
@@ -937,9 +964,8 @@ bool CS::inline_multiplicities() const {
     const char* e = getenv("ZKGL_MULT_MODE");
     if (e && e[0] == 'i') return true;
     if (e && e[0] == 'p') return false;
-    size_t per_lane = 0;
-    for (auto& op : (limit_ ? loop_ : outer_).ops) per_lane += (!op.seed_only && op.opcode == ZK_OP_LOOKUP);
-    return per_lane <= 2048;
+    if (uses_lookup_macros_) return false;   // tuples evaluated inside a macro-op: no per-tuple atomics there
+    return (limit_ ? loop_ : outer_).lookups.size() <= 2048;
 }
 
 // multiplicities of the batch from the resolved variable stores (PASS mode): per scope, per table
@@ -1245,6 +1271,7 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
             if (op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2) c += 4000;
             if (op.opcode == ZK_OP_NN_MULMOD) c += 2000;
             if (op.opcode == ZK_OP_U256_DIVREM) c += 2500;
+            if (op.opcode == ZK_OP_KECCAK_F) c += 8000;   // + 2 per output above: ~70 k
             return c;
         };
         for (auto& st : strand) st.clear();
@@ -1255,6 +1282,11 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
             uint64_t load[NS_MAX] = {0};
             std::vector<uint32_t> mine[NS_MAX];
             for (uint32_t oi : ops) {
+                if (s.ops[oi].opcode == ZK_OP_KECCAK_F && (NS & (NS - 1)) == 0) {
+                    // cooperative macro-op: every strand runs it and stores its share of the outputs (kernels_engine2.hpp keccak_f_stream)
+                    for (uint32_t k = 0; k < NS; ++k) { load[k] += cost(oi) / NS + 3000; mine[k].push_back(oi); }
+                    continue;
+                }
                 uint32_t best = 0;
                 for (uint32_t k = 1; k < NS; ++k) if (load[k] < load[best]) best = k;
                 load[best] += cost(oi);
@@ -2455,9 +2487,13 @@ void CS::launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uin
     else if (d_seed_prog_ && !generic)
         dev_check(zkdev::launch_seed_cone(la, d_seed_prog_, (uint32_t)seed_prog_.size(), seed_slots_, loop_.n_input_words, (const zkdev::CarryArgs*)d_seed_carries_,
                                           (uint32_t)seed_carries_.size(), dev_loop_inputs_rw, n, st));
-    else
+    else {
+        // the generic sequential interpreter is the round-1 (v1) form, which has no handler for the macro-ops: their circuits seed
+        // through the native seeders / the cone (whose hints replace the macro-ops)
+        if (uses_lookup_macros_) throw ZkError(ZK_ERR_INVALID, "generic sequential seeding (ZKGL_SEED_GENERIC) does not run circuits recorded with hash macro-ops; record with ZKGL_NO_HASH_MACROS=1 or use the cone / native seeder");
         dev_check(zkdev::launch_witness_seq(la, (const zkdev::CarryArgs*)d_carries_, (uint32_t)carries_store_.size(), dev_loop_inputs_rw,
                                             n, st));
+    }
 }
 
 void CS::seed_carried_inputs(uint64_t* dev_loop_inputs_rw, void* stream) {

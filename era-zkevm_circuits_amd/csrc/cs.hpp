@@ -185,6 +185,12 @@ class CS {
     void emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uint32_t n_in, const zk_var* outs,
                  uint32_t n_out, const uint64_t* imm, uint32_t n_imm);
     void lookup(uint32_t table_id, const zk_var* keys, uint32_t n_keys, zk_var* vals, uint32_t n_vals);
+    // gadget layer only (not in the C ABI): a lookup TUPLE over variables a macro-op produces (no ZK_OP_LOOKUP is recorded), and the
+    // macro-ops themselves (ZK_OP_KECCAK_F): the fused check trusts such an op to evaluate the tuples and reduction gates placed on
+    // its outputs, which holds because gadget and op walk one structure (csrc/keccak_macro.hpp)
+    void lookup_given(uint32_t table_id, const zk_var* keys, uint32_t n_keys, const zk_var* vals, uint32_t n_vals);
+    void emit_macro_op(uint32_t opcode, const zk_var* ins, uint32_t n_in, zk_var first_out, uint32_t n_out);
+    bool uses_lookup_macros() const { return uses_lookup_macros_; }
     void side_begin();
     void loop_begin(uint32_t limit);
     void loop_end();
@@ -386,7 +392,9 @@ class CS {
     float loop_shader_mhz_ = 0;   // clock probe of the last resolve_and_check's loop launch (last_ms(8))
     bool last_check_fused_ = false;
     uint64_t p2_skipped_ = 0, p2_run_ = 0;   // gated witness-only permutations of the last resolve_and_check's loop launch, per wavefront
-    bool check_stored_ = false;   // zk_cs_set_check_mode(ZK_CHECK_STORED)
+    bool check_stored_ = false;
+    bool uses_lookup_macros_ = false;   // a macro-op whose outputs carry lookup tuples was recorded: multiplicities by the k_multiplicities pass
+    bool allow_macro_ops_ = false;   // zk_cs_set_check_mode(ZK_CHECK_STORED)
 };
 
 // K11 (ntt.cpp): batched Goldilocks NTT / coset LDE over device-resident polynomials, see include/zkgl.h

@@ -19,6 +19,7 @@
 // Same values, same slots as the strand / wide / sequential kernels that still run the v1 form.
 #pragma once
 #include "kernels_engine.hpp"
+#include "keccak_macro.hpp"
 #include <utility>
 
 namespace zke {
@@ -97,6 +98,46 @@ __device__ __forceinline__ uint32_t table_find3(const zk_table_desc& t, const ui
 // gate-by-gate program on the stored values to name the gate)
 __device__ __forceinline__ void report_fused(unsigned long long* f, uint32_t lane) {
     atomicMin(f, ((unsigned long long)lane << 32) | ((unsigned long long)0xffffeu << 12));
+}
+
+// K8, out of line: Keccak-f with the state in registers (inner loops unrolled: every lane index static), streaming its ~30 k outputs to
+// consecutive store slots of the wavefront's tile.  Its own function so that its register allocation (25 lanes = 50 VGPRs + theta's
+// columns) does not land on the interpreter loop; the 25 input lanes come in through scratch, the next output offset comes back.
+__device__ __noinline__ uint32_t keccak_f_stream(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_byte, uint32_t dst, uint32_t bstep, const uint64_t* in25,
+                                                  uint32_t share, uint32_t n_share_mask) {
+    // Cooperative form (strand kernels): the macro-op sits in EVERY strand's program; each of the tile's wavefronts computes the whole
+    // permutation (cheap: ~10 k VALU instructions) and stores the outputs whose running index & n_share_mask == share — a single
+    // wavefront sustains only ~14 stores / us (its 30 k stores took 2.2 ms and sat on the tile's critical path), sixteen share them.
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    uint64_t sl[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) sl[i] = in25[i];
+    struct Emit {
+        __amdgpu_buffer_rsrc_t rsrc;
+        uint32_t lane_byte, d, bstep, cnt, mine, mask;
+        __device__ __forceinline__ void store(uint32_t v, uint32_t at) {
+            u32x2 o;
+            o.x = v; o.y = 0u;
+            __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, at, 0);
+        }
+        // one block = eight consecutive outputs; the strands share the work block by block
+        __device__ __forceinline__ void block8(uint64_t v) {
+            if ((cnt & mask) == mine) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) store((uint32_t)(v >> (8 * k)) & 0xffu, d + k * bstep);
+            }
+            d += 8 * bstep;
+            ++cnt;
+        }
+        __device__ __forceinline__ void one(uint64_t v) {
+            if ((cnt & mask) == mine) store((uint32_t)v, d);
+            d += bstep;
+            ++cnt;
+        }
+    } emit{rsrc, lane_byte, uni(dst), bstep, 0u, uni(share), uni(n_share_mask)};
+    zkk::ComputeBackend<Emit> be(emit);
+    zkk::keccak_f_unrolled(be, sl, zkk::RC);
+    return emit.d;
 }
 
 // STRANDS: the strand form (k_witness_strands2): one destination word per op behind the operands — the store slot of its first
@@ -560,6 +601,47 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
             for (int i = 0; i < 10; ++i) st(out[i]);
         } break;
+        case ZK_OP_KECCAK_F: if constexpr (WITH_BIGINT) {
+            // K8: a whole Keccak-f[1600] as ONE op.  [200 state byte slots] -> every intermediate of the byte-table decomposition, in the
+            // order the gadget allocated them (both walk zkk::keccak_f, keccak_macro.hpp): the state lives in 25 register pairs, every
+            // primitive streams its outputs to the next consecutive store slots.  The lookup tuples on these outputs are table rows iff
+            // the 200 inputs are bytes (every later key is a byte computed here): an input >= 256 is the fused mode's lookup miss.
+            uint64_t sl[25];   // indexed dynamically below: lives in scratch by design (keccak_macro.hpp)
+            bool not_bytes = false;
+#pragma unroll 1
+            for (uint32_t l = 0; l < 25; ++l) {   // one lane = 8 operand words per step, all eight loads in flight together
+                uint64_t b[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) b[k] = ldv(prog[pc + 1 + 8 * l + k]);
+                uint64_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { not_bytes |= b[k] > 0xff; v |= (b[k] & 0xff) << (8 * k); }
+                sl[l] = v;
+            }
+            if constexpr (STRANDS) out_to(prog[pc + 201]);
+            pc += 201 + D;
+#ifndef ZKGL_STUB_STORES
+            if constexpr (!WIDE) {
+                // strand form: the op is in every strand's program (cs.cpp build_strands), strand w stores every (blockDim / 64)-th output
+                const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
+                dst = keccak_f_stream(rsrc, lane_byte, dst, bstep, sl, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+            } else
+#endif
+            {
+                auto st1 = [&](uint64_t v) { st(v); };
+                struct EmitAll {
+                    decltype(st1)& f;
+                    __device__ __forceinline__ void block8(uint64_t v) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) f((v >> (8 * k)) & 0xff);
+                    }
+                    __device__ __forceinline__ void one(uint64_t v) { f(v); }
+                } emit{st1};
+                zkk::ComputeBackend<EmitAll> be(emit);
+                zkk::keccak_f(be, sl, zkk::RC);   // 64-bit addressing (linear_hasher's scope): the rolled walk, state in scratch
+            }
+            fused_bad |= not_bytes;
+        } else { return; } break;
         case ZK_OP_NN_MULMOD: if constexpr (WITH_BIGINT) {
             // fixed layout (cs.cpp emit_scope): 16 modulus limbs (pool indices), 17 A slots, 17 B slots (unused ones 0) = 51 words,
             // four scalar fetches with static word positions

@@ -74,6 +74,12 @@ enum zk_opcode {
                               * a*b + c + d = lo + 2^32 hi; k = k0 + 256 k1 = the carry of the low 32 bits,
                               * k = (sum_{i+j<4} a_i b_j 2^(8(i+j)) + c + d) >> 32          (UInt32::fma_with_carry over U8x4FMAGate,
                               * /root/reference/src/main_vm/opcodes/mod.rs:146-158) */
+    ZK_OP_KECCAK_F = 26,     /* macro-op (kernel K8), recorded by the engine's own Keccak gadget only: [state bytes x200 (byte k of lane x+5y at
+                              * 8(x+5y)+k)] -> EVERY intermediate the byte-table decomposition of Keccak-f[1600] constrains (24 rounds of theta /
+                              * rho-pi / chi / iota: Xor8 / AndN8 / ByteSplit outputs and the rotated bytes), in the order of
+                              * csrc/keccak_macro.hpp zkk::keccak_f — the last values written are the 200 output bytes' producers
+                              *                                                               (keccak256_absorb_and_run_permutation,
+                              * /root/reference/src/keccak256_round_function/mod.rs:796-838) */
     ZK_OP__COUNT
 };
 

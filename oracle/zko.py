@@ -46,6 +46,8 @@ def lib():
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_uint32]
         L.zko_scope_run_seq.restype = C.c_int
         L.zko_scope_run_seq.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.zko_scope_multiplicities.restype = None
+        L.zko_scope_multiplicities.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.zko_scope_check.restype = C.c_uint64
         L.zko_scope_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]
         L.zko_links_check.restype = C.c_uint64
@@ -221,7 +223,7 @@ class CircuitRun:
         oi = np.ascontiguousarray(outer_inputs, dtype=np.uint64)
         li = np.ascontiguousarray(loop_inputs, dtype=np.uint64)
         nl = self.B * self.limit
-        mult = _p(self.mult) if self.total_rows else None
+        mult = None      # multiplicities are counted from the lookup tuples of the resolved trace, below
         rc = L.zko_scope_run(self.outer.h, 0, self.outer.pre_words, _p(self.oc), self.so, self.B, _p(oi), None, 0,
                              _p(self.lc), self.lc.shape[1], self.limit, mult, self.total_rows)
         assert rc == 0
@@ -232,6 +234,11 @@ class CircuitRun:
         rc = L.zko_scope_run(self.outer.h, self.outer.pre_words, self.outer.n_prog, _p(self.oc), self.so, self.B, _p(oi),
                              None, 0, _p(self.lc), self.lc.shape[1], self.limit, mult, self.total_rows)
         assert rc == 0
+        if self.total_rows:
+            self.mult[:] = 0
+            L.zko_scope_multiplicities(self.outer.h, _p(self.oc), C.c_size_t(self.so), self.B, 1, _p(self.mult), self.total_rows)
+            if self.limit:
+                L.zko_scope_multiplicities(self.loop.h, _p(self.lc), C.c_size_t(self.lc.shape[1]), nl, self.limit, _p(self.mult), self.total_rows)
 
     def seed(self, outer_inputs: np.ndarray, loop_inputs: np.ndarray) -> np.ndarray:
         """sequential seeding: returns loop_inputs with the carried words filled in (oracle twin of

@@ -129,6 +129,59 @@ static uint64_t pow7(uint64_t x) {
     return zko_gl_mul(x3, x4);
 }
 
+/* ZK_OP_KECCAK_F (include/zkgl_ir.h): Keccak-f[1600] with every intermediate of the byte-table decomposition written out, restated
+ * in plain C from the output order documented in era-zkevm_circuits_amd/csrc/keccak_macro.hpp (per round: theta column xors, the five
+ * rotl-by-1 + xor, the 25 state xors; rho-pi as the in-place chain; chi row by row; iota) — CPU ORACLE, test infrastructure. */
+static const uint64_t KECCAK_RC_O[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+static const int KECCAK_RHO_O[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+static const int KECCAK_PI_O[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+typedef struct { uint64_t *buf; size_t n; } kk_out;
+static void kk_emit8(kk_out *o, uint64_t v) { for (int k = 0; k < 8; ++k) o->buf[o->n++] = (v >> (8 * k)) & 0xff; }
+static uint64_t kk_rotl(kk_out *o, uint64_t a, int n) {
+    n %= 64;
+    int b = n % 8;
+    uint64_t full = n ? (a << n) | (a >> (64 - n)) : a;
+    if (!b) return full;
+    for (int k = 0; k < 8; ++k) {
+        uint64_t byte = (a >> (8 * k)) & 0xff;
+        o->buf[o->n++] = byte & ((1u << (8 - b)) - 1);
+        o->buf[o->n++] = byte >> (8 - b);
+    }
+    kk_emit8(o, (a << b) | (a >> (64 - b)));
+    return full;
+}
+static void kk_keccak_f(uint64_t s[25], kk_out *o) {
+    for (int rnd = 0; rnd < 24; ++rnd) {
+        uint64_t cc[5], d[5];
+        for (int x = 0; x < 5; ++x) {
+            cc[x] = s[x];
+            for (int j = 1; j < 5; ++j) { cc[x] ^= s[x + 5 * j]; kk_emit8(o, cc[x]); }
+        }
+        for (int x = 0; x < 5; ++x) { uint64_t r = kk_rotl(o, cc[(x + 1) % 5], 1); d[x] = cc[(x + 4) % 5] ^ r; kk_emit8(o, d[x]); }
+        for (int i = 0; i < 25; ++i) { s[i] ^= d[i % 5]; kk_emit8(o, s[i]); }
+        uint64_t t = s[1];
+        for (int i = 0; i < 24; ++i) { int j = KECCAK_PI_O[i]; uint64_t bc = s[j]; s[j] = kk_rotl(o, t, KECCAK_RHO_O[i]); t = bc; }
+        for (int y = 0; y < 5; ++y) {
+            uint64_t r[5];
+            for (int x = 0; x < 5; ++x) r[x] = s[x + 5 * y];
+            for (int x = 0; x < 5; ++x) {
+                uint64_t a = ~r[(x + 1) % 5] & r[(x + 2) % 5];
+                kk_emit8(o, a);
+                s[x + 5 * y] = r[x] ^ a;
+                kk_emit8(o, s[x + 5 * y]);
+            }
+        }
+        uint64_t nc = s[0] ^ KECCAK_RC_O[rnd];
+        for (int k = 0; k < 8; ++k) if ((KECCAK_RC_O[rnd] >> (8 * k)) & 0xff) o->buf[o->n++] = (nc >> (8 * k)) & 0xff;
+        s[0] = nc;
+    }
+}
+
 static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
     const zko_scope *s = c->s;
     const uint32_t *prog = s->prog;
@@ -284,6 +337,15 @@ static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
             st(c, prog, &pc, lane, kk & 0xff);
             st(c, prog, &pc, lane, (kk >> 8) & 0xff);
         } break;
+        case ZK_OP_KECCAK_F: {
+            uint64_t st8[25] = {0};
+            for (int j = 0; j < 200; ++j) st8[j / 8] |= (ld(c, prog[pc + j], lane, inst) & 0xff) << (8 * (j % 8));
+            pc += 200;
+            static _Thread_local uint64_t kbuf[40000];
+            kk_out o = {kbuf, 0};
+            kk_keccak_f(st8, &o);
+            for (size_t i = 0; i < o.n; ++i) st(c, prog, &pc, lane, kbuf[i]);
+        } break;
         case ZK_OP_NN_MULMOD: { /* A*B = q*M + r, base 2^16: schoolbook product + bit-serial restoring division */
             uint64_t prod[40] = {0}, rem[18] = {0}, mod[16];
             uint32_t nq = pa + pb - 15, np = pa + pb + 2;
@@ -428,6 +490,29 @@ int zko_scope_run_seq(const zko_scope *s, uint64_t *cells, size_t stride, uint32
         }
     }
     return bad ? -1 : 0;
+}
+
+/* Lookup multiplicities of a resolved scope, counted from the lookup TUPLES of the trace (every tuple whose keys are a table row adds one
+ * to that row of its instance) — the definition the prover's lookup argument uses, independent of which witness op produced the tuple
+ * (a ZK_OP_LOOKUP or a macro-op such as ZK_OP_KECCAK_F).  lanes_per_instance = limit for the loop scope, 1 for the outer scope. */
+void zko_scope_multiplicities(const zko_scope *s, const uint64_t *cells, size_t stride, uint32_t n_lanes, uint32_t lanes_per_instance,
+                              uint32_t *mult, uint32_t total_rows) {
+    const size_t NC = s->n_slots ? s->n_trace_cells / s->n_slots : 0;
+    for (uint32_t lane = 0; lane < n_lanes; ++lane) {
+        const uint32_t inst = lane / (lanes_per_instance ? lanes_per_instance : 1);
+        for (uint32_t slot = 0; slot < s->n_slots; ++slot) {
+            const zk_lookup_row_desc *lr = &s->lrows[slot];
+            if (!lr->n_tuples) continue;
+            const zk_table_desc *t = &s->tables[lr->table];
+            for (uint32_t u = 0; u < lr->n_tuples; ++u) {
+                uint32_t c0 = s->n_copy_cols + u * s->lookup_width;
+                uint64_t key[3] = {0, 0, 0};
+                for (uint32_t i = 0; i < t->n_keys; ++i) key[i] = cells[((size_t)slot * NC + c0 + i) * stride + lane];
+                uint32_t row = table_find(s, t, key);
+                if (row < t->n_rows) mult[(size_t)inst * total_rows + t->mult_off + row] += 1;
+            }
+        }
+    }
 }
 
 static const unsigned char GW[ZK_GATE__COUNT] = {0, 1, 1, 4, 5, 4, 3, 5, 9, 24, 24, 1, 6, 5, 26};
