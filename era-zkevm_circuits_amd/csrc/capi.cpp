@@ -79,6 +79,8 @@ namespace zkgl {  // for comm.cpp
 void set_last_error(const std::string& m) { g_err = m; }
 CS* cs_of(zk_cs* h) { return h->cs; }
 int initialized_device() { return g_inited ? g_device : -1; }
+static int g_cu_count = 256;
+int device_cu_count() { return g_cu_count; }   // compute units of the device zk_init bound (256 on a whole MI355X; fewer under CPX / partitioned modes)
 }  // namespace zkgl
 
 extern "C" {
@@ -103,6 +105,10 @@ int zk_init(int device) {
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     int rc = zkdev::upload_round_constants(zkgl::poseidon_round_constants());
     if (rc) return fail(ZK_ERR_HIP, zkdev::last_hip_error());
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) zkgl::g_cu_count = cus;
+    }
     g_inited = true;
     g_device = device;
     return ZK_OK;

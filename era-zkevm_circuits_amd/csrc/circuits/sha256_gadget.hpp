@@ -2,7 +2,9 @@
 // the block-chain circuit, the sha256 precompile FSM (sha256.cpp) and code_unpacker_sha256 (code_unpacker.cpp).
 // See sha256.cpp for the decomposition notes.
 #pragma once
+#include <cstdlib>
 #include "../gadgets.hpp"
+#include "../sha256_macro.hpp"
 
 namespace zkgl {
 namespace sha256_gadget {
@@ -20,25 +22,61 @@ inline const uint32_t SHA_IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53
 
 using Word = std::array<zk_var, 4>;  // little-endian bytes of a u32
 
+// The gadget is the HOST backend of zks::compress (csrc/sha256_macro.hpp), the walk the device macro-op ZK_OP_SHA256_ROUNDS and the
+// oracle make too.  With the macro-op (default) a compression records ONE witness op over 96 input bytes whose outputs are the
+// pre-allocated variables the walk then constrains; ZKGL_NO_HASH_MACROS=1 records one ZK_OP_LOOKUP / LC4 / SPLIT per value (rounds 1-3).
 struct S {
+    typedef sha256_gadget::Word Word;
     G& g;
     uint32_t t_xor, t_and, t_andn, t_split[8];
+    bool use_macro;
+    zk_var macro_next = ZK_VAR_NONE;
     explicit S(G& g) : g(g) {
         t_xor = g.cs.table_id(TABLE_XOR8);
         t_and = g.cs.table_id(TABLE_AND8);
         t_andn = g.cs.table_id(T_ANDN8);
         for (int k = 1; k < 8; ++k) t_split[k] = g.cs.table_id(T_SPLIT_BASE + k);
+        const char* e = getenv("ZKGL_NO_HASH_MACROS");
+        use_macro = !(e && e[0] == '1');
     }
-    Word bytewise(uint32_t table, const Word& a, const Word& b) {
+    // ---- recording primitives: plain (witness op + constraint) or macro mode (constraint over the next pre-allocated outputs)
+    std::vector<zk_var> look(uint32_t table, const std::vector<zk_var>& keys, uint32_t n_vals) {
+        if (macro_next == ZK_VAR_NONE) return g.lookup(table, keys, n_vals);
+        std::vector<zk_var> vals(n_vals);
+        for (uint32_t i = 0; i < n_vals; ++i) vals[i] = macro_next++;
+        g.cs.lookup_given(table, keys.data(), (uint32_t)keys.size(), vals.data(), n_vals);
+        return vals;
+    }
+    zk_var lc(const std::vector<std::pair<zk_var, uint64_t>>& terms) {   // G::linear_combination's chain, outputs given in macro mode
+        if (macro_next == ZK_VAR_NONE) return g.linear_combination(terms);
+        size_t pos = 0;
+        zk_var acc = ZK_VAR_NONE;
+        while (pos < terms.size() || acc == ZK_VAR_NONE) {
+            zk_var t[4];
+            uint64_t k[4];
+            int n = 0;
+            if (acc != ZK_VAR_NONE) { t[n] = acc; k[n] = 1; ++n; }
+            while (n < 4 && pos < terms.size()) { t[n] = terms[pos].first; k[n] = terms[pos].second; ++n; ++pos; }
+            while (n < 4) { t[n] = g.zero(); k[n] = 0; ++n; }
+            zk_var r = macro_next++;
+            zk_var vars[5] = {t[0], t[1], t[2], t[3], r};
+            g.cs.place_gate(ZK_GATE_REDUCTION4, vars, 5, k, 4);
+            acc = r;
+        }
+        return acc;
+    }
+    // ---- the backend interface of zks::compress
+    Word bytewise(int t, const Word& a, const Word& b) {
+        const uint32_t table = t == zks::T_XOR ? t_xor : t == zks::T_AND ? t_and : t_andn;
         Word r;
-        for (int k = 0; k < 4; ++k) r[k] = g.lookup(table, {a[k], b[k]}, 1)[0];
+        for (int k = 0; k < 4; ++k) r[k] = look(table, {a[k], b[k]}, 1)[0];
         return r;
     }
-    Word xor3(const Word& a, const Word& b, const Word& c) { return bytewise(t_xor, bytewise(t_xor, a, b), c); }
+    Word xor3(const Word& a, const Word& b, const Word& c) { Word ab = bytewise(zks::T_XOR, a, b); return bytewise(zks::T_XOR, ab, c); }
     // split every byte at bit position `at`: byte = lo (at bits) + 2^at * hi (8-at bits)
     void split_all(const Word& a, int at, Word& lo, Word& hi) {
         for (int k = 0; k < 4; ++k) {
-            auto v = g.lookup(t_split[at], {a[k]}, 2);
+            auto v = look(t_split[at], {a[k]}, 2);
             lo[k] = v[0]; hi[k] = v[1];
         }
     }
@@ -53,7 +91,7 @@ struct S {
         split_all(a, b, lo, hi);
         for (int k = 0; k < 4; ++k) {
             int j = (k + q) % 4;
-            r[k] = g.linear_combination({{hi[j], 1}, {lo[(j + 1) % 4], 1ull << (8 - b)}});
+            r[k] = lc({{hi[j], 1}, {lo[(j + 1) % 4], 1ull << (8 - b)}});
         }
         return r;
     }
@@ -65,30 +103,35 @@ struct S {
             int j = k + q;
             if (j >= 4) { r[k] = g.zero(); continue; }
             if (b == 0) { r[k] = a[j]; continue; }
-            if (j + 1 < 4) r[k] = g.linear_combination({{hi[j], 1}, {lo[j + 1], 1ull << (8 - b)}});
+            if (j + 1 < 4) r[k] = lc({{hi[j], 1}, {lo[j + 1], 1ull << (8 - b)}});
             else r[k] = hi[j];
         }
         return r;
     }
     // (sum of the given words + constant) mod 2^32, as range-checkable bytes
-    Word add_mod32(const std::vector<Word>& words, uint64_t constant) {
+    template <int N>
+    Word add_mod32(const Word* words, uint64_t constant) {
         std::vector<std::pair<zk_var, uint64_t>> terms;
-        for (auto& w : words)
-            for (int k = 0; k < 4; ++k) terms.push_back({w[k], 1ull << (8 * k)});
+        for (int i = 0; i < N; ++i)
+            for (int k = 0; k < 4; ++k) terms.push_back({words[i][k], 1ull << (8 * k)});
         if (constant) terms.push_back({g.one(), constant});
-        zk_var sum = g.linear_combination(terms);  // < (n+1) * 2^32 << p
+        zk_var sum = lc(terms);  // < (n+1) * 2^32 << p
         zk_var parts[5];
-        zk_var first = g.cs.alloc_vars(5);
-        for (int i = 0; i < 5; ++i) parts[i] = first + i;
-        g.cs.emit_op(ZK_OP_SPLIT, 5, 8, &sum, 1, parts, 5, nullptr, 0);  // 4 bytes + carry
-        zk_var low = g.linear_combination({{parts[0], 1}, {parts[1], 1ull << 8}, {parts[2], 1ull << 16}, {parts[3], 1ull << 24}});
-        g.enforce_equal(g.linear_combination({{low, 1}, {parts[4], 1ull << 32}}), sum);
-        g.range_check_u8_pair(parts[4], parts[4]);  // carry < 2^8 (it is < 8); the 4 bytes are range-checked by their consumers
+        if (macro_next == ZK_VAR_NONE) {
+            zk_var first = g.cs.alloc_vars(5);
+            for (int i = 0; i < 5; ++i) parts[i] = first + i;
+            g.cs.emit_op(ZK_OP_SPLIT, 5, 8, &sum, 1, parts, 5, nullptr, 0);  // 4 bytes + carry
+        } else {
+            for (int i = 0; i < 5; ++i) parts[i] = macro_next++;
+        }
+        zk_var low = lc({{parts[0], 1}, {parts[1], 1ull << 8}, {parts[2], 1ull << 16}, {parts[3], 1ull << 24}});
+        g.enforce_equal(lc({{low, 1}, {parts[4], 1ull << 32}}), sum);
+        (void)look(t_xor, {parts[4], parts[4]}, 1);  // carry < 2^8 (it is < 8); the 4 bytes are range-checked by their consumers
         return {parts[0], parts[1], parts[2], parts[3]};
     }
     void range_check_word(const Word& w) {
-        g.range_check_u8_pair(w[0], w[1]);
-        g.range_check_u8_pair(w[2], w[3]);
+        (void)look(t_xor, {w[0], w[1]}, 1);
+        (void)look(t_xor, {w[2], w[3]}, 1);
     }
     // compress + (loop scope) the seed hint ZK_OP_SHA256_COMPRESS over the same byte variables
     void compress_with_hint(std::array<Word, 8>& st, const std::array<Word, 16>& block_words) {
@@ -106,30 +149,25 @@ struct S {
         }
     }
     void compress(std::array<Word, 8>& st, const std::array<Word, 16>& block_words) {
-        std::vector<Word> w(block_words.begin(), block_words.end());
-        for (int i = 16; i < 64; ++i) {
-            Word s0 = xor3(rotr(w[i - 15], 7), rotr(w[i - 15], 18), shr(w[i - 15], 3));
-            Word s1 = xor3(rotr(w[i - 2], 17), rotr(w[i - 2], 19), shr(w[i - 2], 10));
-            w.push_back(add_mod32({w[i - 16], s0, w[i - 7], s1}, 0));
-        }
-        range_check_word(w[62]);  // the only schedule words no sigma lookup consumes
-        range_check_word(w[63]);
-        Word a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], gg = st[6], h = st[7];
-        for (int i = 0; i < 64; ++i) {
-            Word S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
-            Word ch = bytewise(t_xor, bytewise(t_and, e, f), bytewise(t_andn, e, gg));
-            Word S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
-            Word maj = bytewise(t_xor, bytewise(t_and, a, b), bytewise(t_and, c, bytewise(t_xor, a, b)));
-            Word new_e = add_mod32({d, h, S1, ch, w[i]}, SHA_K[i]);
-            Word new_a = add_mod32({h, S1, ch, w[i], S0, maj}, SHA_K[i]);
-            h = gg; gg = f; f = e; e = new_e; d = c; c = b; b = a; a = new_a;
-        }
-        range_check_word(a);  // outputs of the last round feed additions only
-        range_check_word(e);
-        const Word out[8] = {a, b, c, d, e, f, gg, h};
-        for (int i = 0; i < 8; ++i) {
-            st[i] = add_mod32({st[i], out[i]}, 0);
-            range_check_word(st[i]);
+        Word w[64];
+        if (use_macro) {
+            (void)g.zero(); (void)g.one();
+            zks::CountBackend cb;
+            int cst[8] = {0}, cblk[16] = {0}, cw[64];
+            zks::compress(cb, cst, cblk, cw, SHA_K);
+            std::vector<zk_var> ins;
+            for (auto& x : st)
+                for (auto b : x) ins.push_back(b);
+            for (auto& x : block_words)
+                for (auto b : x) ins.push_back(b);
+            const zk_var first = g.cs.alloc_vars(cb.n);
+            g.cs.emit_macro_op(ZK_OP_SHA256_ROUNDS, ins.data(), 96, first, cb.n);
+            macro_next = first;
+            zks::compress(*this, st.data(), block_words.data(), w, SHA_K);
+            if (macro_next != first + cb.n) throw ZkError(ZK_ERR_INVALID, "internal: the SHA-256 gadget and its macro-op disagree on the output count");
+            macro_next = ZK_VAR_NONE;
+        } else {
+            zks::compress(*this, st.data(), block_words.data(), w, SHA_K);
         }
     }
 };

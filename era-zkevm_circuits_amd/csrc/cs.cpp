@@ -14,10 +14,13 @@
 #include "poseidon_consts.hpp"
 #include "../../include/zkgl_vm.h"
 #include "keccak_macro.hpp"
+#include "sha256_macro.hpp"
 
 static constexpr int ZK_MACRO_FAILURE = 0x7fff0001;  // internal: a macro check packet failed, re-run the gate-by-gate program
 
 namespace zkgl {
+
+int device_cu_count();   // capi.cpp: the CU count zk_init read from the device
 
 namespace {
 
@@ -336,6 +339,14 @@ void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uin
         zkk::keccak_f(cb, dummy, rc);
         need(200, cb.n, 0);
         s.uses_bigint = true;   // the heavy kernel variants (register budget of the macro-op) carry its handler
+        uses_lookup_macros_ = true;
+    } break;
+    case ZK_OP_SHA256_ROUNDS: {
+        if (!allow_macro_ops_) throw ZkError(ZK_ERR_INVALID, "emit_op: macro-ops are recorded by the engine's gadgets only");
+        zks::CountBackend cb; int cst[8] = {0}, cblk[16] = {0}, cw[64];
+        zks::compress(cb, cst, cblk, cw, zks::K);
+        need(96, cb.n, 0);
+        s.uses_bigint = true;
         uses_lookup_macros_ = true;
     } break;
     case ZK_OP_NN_MULMOD:
@@ -694,7 +705,7 @@ void CS::build_check_program(Scope& s) {
                 const OpRec* op = prod(g.vars[4]);
                 // a rotated byte inside the Keccak macro-op: lo 2^b + hi computed by the op from the very lo / hi it stores (keccak_macro.hpp
                 // rotl); only the engine's gadget can record the op (emit_macro_op), and it places this gate from the same structure
-                if (op && op->opcode == ZK_OP_KECCAK_F && g.kind == ZK_GATE_REDUCTION4) { m = true; break; }
+                if (op && (op->opcode == ZK_OP_KECCAK_F || op->opcode == ZK_OP_SHA256_ROUNDS) && g.kind == ZK_GATE_REDUCTION4) { m = true; break; }
                 if (op && op->opcode == ZK_OP_LC4 && op->ins.size() == 8) {
                     m = true;
                     uint64_t pw = 1;
@@ -1271,7 +1282,7 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
             if (op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2) c += 4000;
             if (op.opcode == ZK_OP_NN_MULMOD) c += 2000;
             if (op.opcode == ZK_OP_U256_DIVREM) c += 2500;
-            if (op.opcode == ZK_OP_KECCAK_F) c += 8000;   // + 2 per output above: ~70 k
+            if (op.opcode == ZK_OP_KECCAK_F || op.opcode == ZK_OP_SHA256_ROUNDS) c += 8000;   // + 2 per output above
             return c;
         };
         for (auto& st : strand) st.clear();
@@ -1282,7 +1293,7 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
             uint64_t load[NS_MAX] = {0};
             std::vector<uint32_t> mine[NS_MAX];
             for (uint32_t oi : ops) {
-                if (s.ops[oi].opcode == ZK_OP_KECCAK_F && (NS & (NS - 1)) == 0) {
+                if ((s.ops[oi].opcode == ZK_OP_KECCAK_F || s.ops[oi].opcode == ZK_OP_SHA256_ROUNDS) && (NS & (NS - 1)) == 0) {
                     // cooperative macro-op: every strand runs it and stores its share of the outputs (kernels_engine2.hpp keccak_f_stream)
                     for (uint32_t k = 0; k < NS; ++k) { load[k] += cost(oi) / NS + 3000; mine[k].push_back(oi); }
                     continue;
@@ -1361,7 +1372,7 @@ void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* strea
     // permutations (queue circuits, the commitments of every outer scope) only pay for the barriers.  A scope of a few
     // wavefronts (outer scopes) has the chip to itself and takes any gain; one of hundreds needs a clear one (measured:
     // log_sorter's loop body at an estimated 2.8 runs 1.4x slower in strand form, keccak's at 3.7 runs 1.9x faster).
-    const bool strands = s.d_sprog && mode != 0 && (mode == 1 || (waves <= 1024 && s.s_gain[phase] >= (waves <= 64 ? 1.5f : 3.2f)));
+    const bool strands = s.d_sprog && mode != 0 && (mode == 1 || (waves <= 4 * (uint32_t)device_cu_count() && s.s_gain[phase] >= (waves <= (uint32_t)device_cu_count() / 4 ? 1.5f : 3.2f)));   // short of wavefronts: fewer than one per SIMD
     if (!strands) {
         const uint32_t end = (uint32_t)s.prog2.size();
         uint32_t w0 = 0, w1 = end, slot0 = 0;
@@ -1378,7 +1389,7 @@ void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* strea
     // tiles than that (keccak FSM at 128 instances: 672 tiles on 256 CUs) runs them in rounds.  The narrow form (8 strands: four
     // workgroups per CU) keeps every tile resident: keccak FSM 23.7 -> 20.8 ms; eip_4844 (120 tiles) is 1.24 x slower with it and
     // keeps 16 (profiles/r3_strands_ab.txt).  ZKGL_STRANDS_NARROW=0 / 1 forces the choice.
-    bool narrow = s.is_loop && s.d_sprog_n && phase == 0 && waves > 2 * 256;
+    bool narrow = s.is_loop && s.d_sprog_n && phase == 0 && waves > 2 * (uint32_t)device_cu_count();   // two 16-strand workgroups fit a CU
     if (const char* ne = getenv("ZKGL_STRANDS_NARROW")) narrow = s.is_loop && s.d_sprog_n && phase == 0 && ne[0] == '1';
     if (narrow) {
         a.prog = s.d_sprog_n; a.n_words = (uint32_t)s.sprog_n.size();

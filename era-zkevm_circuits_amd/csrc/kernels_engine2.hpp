@@ -20,6 +20,7 @@
 #pragma once
 #include "kernels_engine.hpp"
 #include "keccak_macro.hpp"
+#include "sha256_macro.hpp"
 #include <utility>
 
 namespace zke {
@@ -137,6 +138,38 @@ __device__ __noinline__ uint32_t keccak_f_stream(__amdgpu_buffer_rsrc_t rsrc, ui
     } emit{rsrc, lane_byte, uni(dst), bstep, 0u, uni(share), uni(n_share_mask)};
     zkk::ComputeBackend<Emit> be(emit);
     zkk::keccak_f_unrolled(be, sl, zkk::RC);
+    return emit.d;
+}
+
+// K8, out of line: one SHA-256 compression with every intermediate of the byte-table decomposition streamed out (zks::compress);
+// cooperative like keccak_f_stream: every strand computes, strand `share` stores every (mask + 1)-th block of outputs.
+__device__ __noinline__ uint32_t sha256_rounds_stream(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_byte, uint32_t dst, uint32_t bstep, const uint32_t* in24,
+                                                       uint32_t share, uint32_t n_share_mask) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    struct Emit {
+        __amdgpu_buffer_rsrc_t rsrc;
+        uint32_t lane_byte, d, bstep, cnt, mine, mask;
+        __device__ __forceinline__ void block(const uint64_t* v, int n) {
+            if ((cnt & mask) == mine) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < n) {
+                        u32x2 o;
+                        o.x = (uint32_t)v[k]; o.y = (uint32_t)(v[k] >> 32);
+                        __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, d + k * bstep, 0);
+                    }
+            }
+            d += n * bstep;
+            ++cnt;
+        }
+    } emit{rsrc, lane_byte, uni(dst), bstep, 0u, uni(share), uni(n_share_mask)};
+    uint32_t st[8], blk[16], w[64];   // w is indexed dynamically: scratch
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = in24[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) blk[i] = in24[8 + i];
+    zks::ComputeBackend<Emit> be(emit);
+    zks::compress(be, st, blk, w, zks::K);
     return emit.d;
 }
 
@@ -601,6 +634,54 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
             for (int i = 0; i < 10; ++i) st(out[i]);
         } break;
+        case ZK_OP_SHA256_ROUNDS: if constexpr (WITH_BIGINT) {
+            // K8: a whole SHA-256 compression as ONE op.  [32 state byte slots, 64 block byte slots] -> every intermediate, in the gadget's
+            // allocation order (both walk zks::compress, sha256_macro.hpp).  An input that is not a byte is the fused mode's lookup miss.
+            uint32_t wd[24];
+            bool not_bytes = false;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {   // 16 operand words = four u32 words per scalar fetch
+                const u32x16_a4 Wc = *(prog16_ptr)(prog + pc + 1 + 16 * c);
+                uint64_t b[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) b[i] = ldv(Wc[i]);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { not_bytes |= b[4 * h + k] > 0xff; v |= ((uint32_t)b[4 * h + k] & 0xffu) << (8 * k); }
+                    wd[4 * c + h] = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (STRANDS) out_to(prog[pc + 97]);
+            pc += 97 + D;
+#ifndef ZKGL_STUB_STORES
+            if constexpr (!WIDE) {
+                const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
+                dst = sha256_rounds_stream(rsrc, lane_byte, dst, bstep, wd, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+            } else
+#endif
+            {
+                auto st1 = [&](uint64_t v) { st(v); };
+                struct EmitAll {
+                    decltype(st1)& f;
+                    __device__ __forceinline__ void block(const uint64_t* v, int n) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (k < n) f(v[k]);
+                    }
+                } emit{st1};
+                uint32_t sst[8], blk[16], w[64];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sst[i] = wd[i];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) blk[i] = wd[8 + i];
+                zks::ComputeBackend<EmitAll> be(emit);
+                zks::compress(be, sst, blk, w, zks::K);
+            }
+            fused_bad |= not_bytes;
+        } else { return; } break;
         case ZK_OP_KECCAK_F: if constexpr (WITH_BIGINT) {
             // K8: a whole Keccak-f[1600] as ONE op.  [200 state byte slots] -> every intermediate of the byte-table decomposition, in the
             // order the gadget allocated them (both walk zkk::keccak_f, keccak_macro.hpp): the state lives in 25 register pairs, every

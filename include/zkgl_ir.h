@@ -80,6 +80,11 @@ enum zk_opcode {
                               * csrc/keccak_macro.hpp zkk::keccak_f — the last values written are the 200 output bytes' producers
                               *                                                               (keccak256_absorb_and_run_permutation,
                               * /root/reference/src/keccak256_round_function/mod.rs:796-838) */
+    ZK_OP_SHA256_ROUNDS = 27,/* macro-op (kernel K8), recorded by the engine's own SHA-256 gadget only: [state bytes x32 (word w little-endian at 4w),
+                              * block bytes x64 (word j little-endian at 4j)] -> EVERY intermediate of the byte-table decomposition of one
+                              * compression (message schedule, 64 rounds, feed-forward), in the order of csrc/sha256_macro.hpp zks::compress
+                              *                                                               (round_function_over_uint32,
+                              * /root/reference/src/sha256_round_function/mod.rs:271-285) */
     ZK_OP__COUNT
 };
 

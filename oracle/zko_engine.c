@@ -182,6 +182,83 @@ static void kk_keccak_f(uint64_t s[25], kk_out *o) {
     }
 }
 
+/* ZK_OP_SHA256_ROUNDS (include/zkgl_ir.h): one SHA-256 compression with every intermediate of the byte-table decomposition written
+ * out, restated in plain C from the output order documented in era-zkevm_circuits_amd/csrc/sha256_macro.hpp — CPU ORACLE. */
+static const uint32_t SHA_K_O[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static void sh_emit4(kk_out *o, uint32_t v) { for (int k = 0; k < 4; ++k) o->buf[o->n++] = (v >> (8 * k)) & 0xff; }
+static uint32_t sh_bw(kk_out *o, int t, uint32_t a, uint32_t b) { uint32_t r = t == 0 ? a ^ b : t == 1 ? a & b : ~a & b; sh_emit4(o, r); return r; }
+static uint32_t sh_xor3(kk_out *o, uint32_t a, uint32_t b, uint32_t c) { return sh_bw(o, 0, sh_bw(o, 0, a, b), c); }
+static void sh_split(kk_out *o, uint32_t a, int at) {
+    for (int k = 0; k < 4; ++k) { uint32_t byte = (a >> (8 * k)) & 0xff; o->buf[o->n++] = byte & ((1u << at) - 1); o->buf[o->n++] = byte >> at; }
+}
+static uint32_t sh_rotr(kk_out *o, uint32_t a, int n) {
+    uint32_t r = (a >> n) | (a << ((32 - n) & 31));
+    if (n % 8) { sh_split(o, a, n % 8); sh_emit4(o, r); }
+    return r;
+}
+static uint32_t sh_shr(kk_out *o, uint32_t a, int n) {
+    int q = n / 8, b = n % 8;
+    uint32_t r = a >> n;
+    if (b) { sh_split(o, a, b); for (int k = 0; k < 4; ++k) if (k + q + 1 < 4) o->buf[o->n++] = (r >> (8 * k)) & 0xff; }
+    return r;
+}
+static uint32_t sh_add(kk_out *o, const uint32_t *w, int nw, uint64_t c) {
+    int T = 4 * nw + (c ? 1 : 0);
+    uint64_t acc = 0;
+    for (int t = 0; t < T; ++t) {
+        acc += t < 4 * nw ? (uint64_t)((w[t / 4] >> (8 * (t % 4))) & 0xff) << (8 * (t % 4)) : c;
+        if (t == 3 || (t > 3 && (t - 4) % 3 == 2) || (t == T - 1 && t > 3)) o->buf[o->n++] = acc;   /* one reduction gate per 4, then per 3 terms */
+    }
+    uint32_t low = (uint32_t)acc;
+    sh_emit4(o, low);
+    o->buf[o->n++] = acc >> 32;
+    o->buf[o->n++] = low;
+    o->buf[o->n++] = acc;
+    o->buf[o->n++] = 0;
+    return low;
+}
+static void sh_rc(kk_out *o, uint32_t w) { o->buf[o->n++] = (w ^ (w >> 8)) & 0xff; o->buf[o->n++] = ((w >> 16) ^ (w >> 24)) & 0xff; }
+static void sh_compress(uint32_t st[8], const uint32_t blk[16], kk_out *o) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = blk[i];
+    for (int i = 16; i < 64; ++i) {
+        uint32_t a7 = sh_rotr(o, w[i - 15], 7), a18 = sh_rotr(o, w[i - 15], 18), a3 = sh_shr(o, w[i - 15], 3);
+        uint32_t s0 = sh_xor3(o, a7, a18, a3);
+        uint32_t b17 = sh_rotr(o, w[i - 2], 17), b19 = sh_rotr(o, w[i - 2], 19), b10 = sh_shr(o, w[i - 2], 10);
+        uint32_t s1 = sh_xor3(o, b17, b19, b10);
+        uint32_t t[4] = {w[i - 16], s0, w[i - 7], s1};
+        w[i] = sh_add(o, t, 4, 0);
+    }
+    sh_rc(o, w[62]); sh_rc(o, w[63]);
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; ++i) {
+        uint32_t e6 = sh_rotr(o, e, 6), e11 = sh_rotr(o, e, 11), e25 = sh_rotr(o, e, 25);
+        uint32_t S1 = sh_xor3(o, e6, e11, e25);
+        uint32_t ef = sh_bw(o, 1, e, f), ng = sh_bw(o, 2, e, g), ch = sh_bw(o, 0, ef, ng);
+        uint32_t a2 = sh_rotr(o, a, 2), a13 = sh_rotr(o, a, 13), a22 = sh_rotr(o, a, 22);
+        uint32_t S0 = sh_xor3(o, a2, a13, a22);
+        uint32_t ab = sh_bw(o, 1, a, b), axb = sh_bw(o, 0, a, b), cx = sh_bw(o, 1, c, axb), maj = sh_bw(o, 0, ab, cx);
+        uint32_t t1[5] = {d, h, S1, ch, w[i]}, t2[6] = {h, S1, ch, w[i], S0, maj};
+        uint32_t ne = sh_add(o, t1, 5, SHA_K_O[i]);
+        uint32_t na = sh_add(o, t2, 6, SHA_K_O[i]);
+        h = g; g = f; f = e; e = ne; d = c; c = b; b = a; a = na;
+    }
+    sh_rc(o, a); sh_rc(o, e);
+    uint32_t out[8] = {a, b, c, d, e, f, g, h};
+    for (int i = 0; i < 8; ++i) {
+        uint32_t t[2] = {st[i], out[i]};
+        st[i] = sh_add(o, t, 2, 0);
+        sh_rc(o, st[i]);
+    }
+}
+
 static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
     const zko_scope *s = c->s;
     const uint32_t *prog = s->prog;
@@ -336,6 +413,15 @@ static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
             for (int i = 0; i < 4; ++i) st(c, prog, &pc, lane, (r_hi >> (8 * i)) & 0xff);
             st(c, prog, &pc, lane, kk & 0xff);
             st(c, prog, &pc, lane, (kk >> 8) & 0xff);
+        } break;
+        case ZK_OP_SHA256_ROUNDS: {
+            uint32_t wd[24] = {0};
+            for (int j = 0; j < 96; ++j) wd[j / 4] |= (uint32_t)(ld(c, prog[pc + j], lane, inst) & 0xff) << (8 * (j % 4));
+            pc += 96;
+            static _Thread_local uint64_t sbuf[16000];
+            kk_out o = {sbuf, 0};
+            sh_compress(wd, wd + 8, &o);
+            for (size_t i = 0; i < o.n; ++i) st(c, prog, &pc, lane, sbuf[i]);
         } break;
         case ZK_OP_KECCAK_F: {
             uint64_t st8[25] = {0};
