@@ -1622,12 +1622,18 @@ struct MultDev {
     uint32_t site_splits;   // >= 1: gridDim.z = lane ranges x site_splits — few instances x few lanes (eip_4844: 8 blobs) still fill the chip
 };
 constexpr uint32_t MULT_CHUNK_ROWS = 32768;
+// PACKED: two 16-bit counters per LDS word, so that ONE workgroup covers a 65 536-row table (Xor8 / And8 / AndN8) and the keys of its
+// sites are read once instead of once per 32 768-row chunk (round 3: keccak's pass 7.5 ms, bandwidth-bound on re-read keys).  Bit 15 of
+// a counter is a guard: the increment that sets it books 32 768 on the instance's vector and clears it, so a row hit any number of
+// times (the all-zero rows of padded blocks) never carries into its neighbour.
+template <bool PACKED>
 __global__ __launch_bounds__(1024) void k_multiplicities(MultDev a) {
     __shared__ uint32_t cnt[MULT_CHUNK_ROWS];
     const uint32_t base = blockIdx.x * a.chunk_rows, inst = blockIdx.y;
     const uint32_t rows_here = min(a.chunk_rows, a.t.n_rows - base);
-    for (uint32_t i = threadIdx.x; i < rows_here; i += blockDim.x) cnt[i] = 0;
+    for (uint32_t i = threadIdx.x; i < (PACKED ? (rows_here + 1) / 2 : rows_here); i += blockDim.x) cnt[i] = 0;
     __syncthreads();
+    uint32_t* out = a.mult + (size_t)inst * a.total_table_rows + a.t.mult_off + base;
     // few instances: gridDim.z workgroups share an instance, each takes a contiguous range of its lanes (multiples of 64) and one of
     // site_splits interleaved subsets of the sites
     const uint32_t lane_splits = gridDim.z / a.site_splits, lane_split = blockIdx.z / a.site_splits, site_split = blockIdx.z % a.site_splits;
@@ -1654,18 +1660,29 @@ __global__ __launch_bounds__(1024) void k_multiplicities(MultDev a) {
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 const uint32_t row = table_find3(a.t, a.table_words, k0[j], k1[j], k2[j]);
-                if (live[j] && row < a.t.n_rows && row - base < rows_here) atomicAdd(&cnt[row - base], 1u);
+                if (live[j] && row < a.t.n_rows && row - base < rows_here) {
+                    const uint32_t r = row - base;
+                    if constexpr (PACKED) {
+                        const uint32_t sh = (r & 1u) * 16u;
+                        const uint32_t old = atomicAdd(&cnt[r >> 1], 1u << sh);
+                        if (((old >> sh) & 0xffffu) == 0x7fffu) {        // this increment set the field's guard bit: book 32 768 and clear it
+                            atomicSub(&cnt[r >> 1], 0x8000u << sh);      // (other increments may land in between: the field stays far below 2^16,
+                            atomicAdd(out + r, 32768u);                  //  so nothing ever carries into the neighbouring counter)
+                        }
+                    } else {
+                        atomicAdd(&cnt[r], 1u);
+                    }
+                }
             }
         }
     }
     __syncthreads();
-    uint32_t* out = a.mult + (size_t)inst * a.total_table_rows + a.t.mult_off + base;
     for (uint32_t i = threadIdx.x; i < rows_here; i += blockDim.x) {
-        const uint32_t v = cnt[i];
+        const uint32_t v = PACKED ? (cnt[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu : cnt[i];
         if (!v) continue;
-        // the vector is zeroed at the start of resolve and the launches of the two scopes are ordered on the stream; only the
-        // workgroups sharing an instance (gridDim.z > 1) meet on a counter
-        if (gridDim.z > 1) atomicAdd(out + i, v); else out[i] += v;
+        // the vector is zeroed at the start of resolve and the launches of the two scopes are ordered on the stream; workgroups sharing
+        // an instance (gridDim.z > 1) meet on a counter, and so do the overflow bookings of the packed form
+        if (gridDim.z > 1 || PACKED) atomicAdd(out + i, v); else out[i] += v;
     }
 }
 

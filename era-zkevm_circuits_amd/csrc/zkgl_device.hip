@@ -238,7 +238,9 @@ int launch_multiplicities(const uint64_t* store, uint64_t n_store, uint32_t lane
     if (!n_sites || !n_instances || !t.n_rows) return 0;
     zke::MultDev a;
     a.store = store; a.n_store = n_store; a.lanes_per_instance = lanes_per_instance; a.n_lanes = n_lanes; a.sites = sites; a.n_sites = n_sites;
-    a.t = t; a.table_words = table_words; a.mult = mult; a.total_table_rows = total_table_rows; a.chunk_rows = zke::MULT_CHUNK_ROWS;
+    a.t = t; a.table_words = table_words; a.mult = mult; a.total_table_rows = total_table_rows;
+    const bool packed = t.n_rows > zke::MULT_CHUNK_ROWS && t.n_rows <= 2 * zke::MULT_CHUNK_ROWS;   // 16-bit LDS counters: one workgroup per 65 536-row table
+    a.chunk_rows = packed ? 2 * zke::MULT_CHUNK_ROWS : zke::MULT_CHUNK_ROWS;
     const uint32_t chunks = (t.n_rows + a.chunk_rows - 1) / a.chunk_rows;
     // >= ~512 workgroups: few instances share each one among several workgroups (lane ranges)
     uint32_t splits = std::max<uint32_t>(1, 512 / std::max<uint32_t>(1, chunks * n_instances));
@@ -252,7 +254,8 @@ int launch_multiplicities(const uint64_t* store, uint64_t n_store, uint32_t lane
     site_splits = std::min<uint32_t>(site_splits, 65535u / std::max<uint32_t>(1, splits));
     a.site_splits = site_splits;
     dim3 grid(chunks, n_instances, splits * site_splits);
-    zke::k_multiplicities<<<grid, threads, 0, (hipStream_t)stream>>>(a);
+    if (packed) zke::k_multiplicities<true><<<grid, threads, 0, (hipStream_t)stream>>>(a);
+    else zke::k_multiplicities<false><<<grid, threads, 0, (hipStream_t)stream>>>(a);
     return LAUNCH_CHECK("k_multiplicities");
 }
 int launch_materialize(uint64_t* trace, uint64_t n_cells, const uint64_t* store, uint64_t n_store, uint32_t n_lanes, const zk_copy_pair* pairs,
