@@ -1389,7 +1389,9 @@ void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* strea
     // tiles than that (keccak FSM at 128 instances: 672 tiles on 256 CUs) runs them in rounds.  The narrow form (8 strands: four
     // workgroups per CU) keeps every tile resident: keccak FSM 23.7 -> 20.8 ms; eip_4844 (120 tiles) is 1.24 x slower with it and
     // keeps 16 (profiles/r3_strands_ab.txt).  ZKGL_STRANDS_NARROW=0 / 1 forces the choice.
-    bool narrow = s.is_loop && s.d_sprog_n && phase == 0 && waves > 2 * (uint32_t)device_cu_count();   // two 16-strand workgroups fit a CU
+    // (with cooperative macro-ops in the program the 16-strand form wins again: sixteen wavefronts share a macro-op's stores — keccak FSM
+    // 20.6 ms narrow, 19.0 ms wide, round 4)
+    bool narrow = s.is_loop && s.d_sprog_n && phase == 0 && waves > 2 * (uint32_t)device_cu_count() && !uses_lookup_macros_;   // two 16-strand workgroups fit a CU
     if (const char* ne = getenv("ZKGL_STRANDS_NARROW")) narrow = s.is_loop && s.d_sprog_n && phase == 0 && ne[0] == '1';
     if (narrow) {
         a.prog = s.d_sprog_n; a.n_words = (uint32_t)s.sprog_n.size();
