@@ -3057,18 +3057,23 @@ std::vector<uint32_t> CS::export_scope(bool loop_scope) const {
     return o;
 }
 
+// the trace as a VIEW of the compact store: d_slot1[trace cell] = store slot + 1 of the variable placed there, 0 = unpopulated (readers
+// that walk trace cells without materialising the batch: zk_cs_trace_columns*, K12)
+void CS::ensure_trace_view() {
+    for (Scope* s : {&outer_, &loop_})
+        if (!s->d_slot1 && s->n_trace_cells) {
+            std::vector<uint32_t> t(s->n_trace_cells, 0);
+            for (auto& pr : s->mat_pairs)
+                if (pr.cell < s->n_trace_cells) t[pr.cell] = pr.home + 1;
+            s->d_slot1 = upload(t);
+        }
+}
+
 void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream, uint32_t n_instances, uint64_t instance_stride) {
     if (!finalized_ || batch_ == 0) throw ZkError(ZK_ERR_INVALID, "trace_columns before set_batch");
     // a compact batch stays compact: one instance's columns are read through the trace view (cell -> slot), the whole batch's trace
     // (4x the store) is never allocated for this
-    if (compact_)
-        for (Scope* s : {&outer_, &loop_})
-            if (!s->d_slot1 && s->n_trace_cells) {
-                std::vector<uint32_t> t(s->n_trace_cells, 0);
-                for (auto& pr : s->mat_pairs)
-                    if (pr.cell < s->n_trace_cells) t[pr.cell] = pr.home + 1;
-                s->d_slot1 = upload(t);
-            }
+    if (compact_) ensure_trace_view();
     if (n_instances == 0) return;
     if (instance >= batch_ || n_instances > batch_ - instance) throw ZkError(ZK_ERR_INVALID, "trace_columns: instance out of range");
     const uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;

@@ -252,6 +252,7 @@ class CS {
     float last_ms(int which) const;
     std::vector<uint32_t> export_scope(bool loop_scope) const;
     // columns of one instance's trace as polynomials of 2^log_n values (kernels_ntt.hpp k_trace_columns_*)
+    void ensure_trace_view();
     void trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint64_t stride, void* stream, uint32_t n_instances = 1, uint64_t instance_stride = 0);
     void trace_ptr(bool loop_scope, uint64_t** cells, uint64_t* n_cells, uint64_t* stride);
 

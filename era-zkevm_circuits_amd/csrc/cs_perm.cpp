@@ -120,7 +120,9 @@ uint32_t CS::copy_permutation(const uint64_t beta[2], const uint64_t gamma[2], v
     if (batch_ == 0 || !uploaded_) throw ZkError(ZK_ERR_INVALID, "copy_permutation before set_batch / resolve");
     for (int i = 0; i < 2; ++i)
         if (beta[i] >= P || gamma[i] >= P) throw ZkError(ZK_ERR_INVALID, "copy_permutation: non-canonical challenge");
-    ensure_materialized(stream);  // the argument runs over every trace cell
+    // the argument runs over every populated trace cell; a compact batch is read through the trace view (cell -> store slot): the 4x
+    // larger materialised trace of the whole batch is not built for this (round 3: its materialisation was most of K12's 3.3 ms / instance)
+    if (compact_) ensure_trace_view();
     build_sigma();
     if (!d_sig_rel_[0]) {
         for (int s = 0; s < 2; ++s) { d_sig_rel_[s] = up(sig_rel_[s]); d_ep_index_[s] = up(ep_index_[s]); d_ovr_[s] = up(ovr_[s]); }
@@ -135,7 +137,9 @@ uint32_t CS::copy_permutation(const uint64_t beta[2], const uint64_t gamma[2], v
     uint32_t chunks[2], spc[2];
     for (int s = 0; s < 2; ++s) {
         const uint32_t lanes = s ? loop_lanes : outer_.n_lanes;
-        uint32_t want = lanes >= 16384 ? 1 : std::max<uint32_t>(1, 16384 / std::max<uint32_t>(lanes, 1));
+        // ~1 M threads per launch (16 wavefronts per SIMD): a lane's rows are walked with several scalar loads per cell, so the kernel lives
+        // on resident wavefronts (64 instances x 2 352 cycles = 2.3 wavefronts per SIMD ran at a third of its multiplication rate)
+        uint32_t want = std::max<uint32_t>(1, (1u << 20) / std::max<uint32_t>(lanes, 1));
         want = std::min(want, std::max<uint32_t>(n_slots[s], 1));
         spc[s] = (std::max<uint32_t>(n_slots[s], 1) + want - 1) / want;
         chunks[s] = (std::max<uint32_t>(n_slots[s], 1) + spc[s] - 1) / spc[s];
@@ -167,7 +171,9 @@ uint32_t CS::copy_permutation(const uint64_t beta[2], const uint64_t gamma[2], v
     auto side = [&](int s) {
         const Scope& sc = s ? loop_ : outer_;
         zkdev::PermArgs a;
-        a.cells = sc.d_cells; a.n_cells = sc.n_cells; a.n_cols = n_cols; a.n_lanes = sc.n_lanes; a.n_slots = sc.n_slots;
+        if (compact_) { a.cells = sc.d_store; a.n_cells = sc.store_geom(); a.slot1 = sc.d_slot1; }
+        else { a.cells = sc.d_cells; a.n_cells = sc.n_cells; a.slot1 = nullptr; }
+        a.n_cols = n_cols; a.n_lanes = sc.n_lanes; a.n_slots = sc.n_slots;
         a.n_copy_cols = geo_.num_columns_under_copy_permutation; a.lookup_width = lookup_width_; a.rows = sc.d_rows; a.lrows = sc.d_lrows;
         a.sigma_rel = d_sig_rel_[s]; a.ep_index = d_ep_index_[s]; a.ovr = d_ovr_[s]; a.lanes_per_instance = s ? limit_ : 1;
         a.label_base = s ? NTo : 0; a.label_step = s ? NTl : 0; a.tb = d_tb[s];

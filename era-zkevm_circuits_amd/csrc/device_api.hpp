@@ -136,6 +136,7 @@ struct PermArgs {
     const uint32_t* sigma_rel; const uint32_t* ep_index; const uint64_t* ovr; uint32_t lanes_per_instance;
     uint64_t label_base, label_step; const uint64_t* tb; uint64_t beta[2], gamma[2];
     uint32_t slots_per_chunk, n_chunks; uint64_t* lane_out; uint64_t* prefix;
+    const uint32_t* slot1 = nullptr;   // compact batch: `cells` is the variable store, slot1[trace cell] = store slot + 1
 };
 int launch_perm_lane(const PermArgs& a, void* stream);
 int launch_perm_tb(const uint64_t beta[2], const uint32_t* sigma_rel, uint64_t* tb, uint32_t n, void* stream);

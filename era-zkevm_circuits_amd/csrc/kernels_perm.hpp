@@ -42,7 +42,16 @@ struct PermDev {
     uint32_t slots_per_chunk, n_chunks;  // a thread walks one chunk of a lane's rows (the outer scope has one lane per instance)
     uint64_t* lane_out;         // [n_lanes][n_chunks][4]: numerator (a, b), denominator (a, b) of the chunk's rows
     uint64_t* prefix;           // optional [n_slots][n_lanes][4]: running products inside the chunk after each row
+    const uint32_t* slot1;      // compact batch: `cells` is the variable store and slot1[trace cell] = store slot + 1 (the trace is a view)
 };
+
+// Karatsuba form of the GF(p^2) product: three base-field multiplications instead of four (the kernel is bound by them: two
+// extension products per populated cell)
+__device__ __forceinline__ E emul3(E x, E y) {
+    const uint64_t aa = gl::mul(x.a, y.a), bb = gl::mul(x.b, y.b);
+    const uint64_t cross = gl::sub(gl::sub(gl::mul(gl::add(x.a, x.b), gl::add(y.a, y.b)), aa), bb);   // a d + b c
+    return {gl::add(aa, gl::add(gl::mul_pow2(bb, 3), gl::neg(bb))), cross};
+}
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -64,7 +73,9 @@ __global__ __launch_bounds__(TPB) void k_perm_lane(PermDev d) {
 #pragma unroll 4
             for (uint32_t col = c0; col < c1; ++col) {
                 const uint32_t cell = slot * d.n_cols + col;
-                const uint64_t w = cells[(size_t)cell << tsh];
+                // a column the row descriptor counts but no variable occupies (the unused columns of a narrow lookup tuple) holds 0
+                const uint32_t s1 = d.slot1 ? uni(d.slot1[cell]) : cell + 1u;
+                const uint64_t w = s1 ? cells[(size_t)(s1 - 1u) << tsh] : 0ull;
                 const uint64_t* __restrict__ t = d.tb + 4 * (size_t)cell;
                 E tn = eadd(A, E{t[0], t[1]});
                 tn.a = gl::add(tn.a, w);
@@ -72,8 +83,8 @@ __global__ __launch_bounds__(TPB) void k_perm_lane(PermDev d) {
                 E td = ep == NONE ? eadd(A, E{t[2], t[3]})
                                   : eadd(escale(d.beta, d.ovr[(size_t)ep * d.lanes_per_instance + k]), d.gamma);
                 td.a = gl::add(td.a, w);
-                num = emul(num, tn);
-                den = emul(den, td);
+                num = emul3(num, tn);
+                den = emul3(den, td);
             }
         }
         if (d.prefix) {

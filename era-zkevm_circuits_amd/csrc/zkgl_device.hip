@@ -311,7 +311,7 @@ int launch_perm_lane(const PermArgs& a, void* stream) {
     d.sigma_rel = a.sigma_rel; d.ep_index = a.ep_index; d.ovr = a.ovr; d.lanes_per_instance = a.lanes_per_instance;
     d.label_base = a.label_base; d.label_step = a.label_step; d.tb = a.tb;
     d.beta = {a.beta[0], a.beta[1]}; d.gamma = {a.gamma[0], a.gamma[1]};
-    d.slots_per_chunk = a.slots_per_chunk; d.n_chunks = a.n_chunks; d.lane_out = a.lane_out; d.prefix = a.prefix;
+    d.slots_per_chunk = a.slots_per_chunk; d.n_chunks = a.n_chunks; d.lane_out = a.lane_out; d.prefix = a.prefix; d.slot1 = a.slot1;
     zkp::k_perm_lane<<<dim3(grid_for(a.n_lanes, zkp::TPB), a.n_chunks), zkp::TPB, 0, (hipStream_t)stream>>>(d);
     return LAUNCH_CHECK("k_perm_lane");
 }

@@ -30,7 +30,7 @@ ok, f = cs.resolve_and_check(stream)
 assert ok, f
 st = cs.stats()
 rows, n_cols = st["rows_per_instance"], st["copy_columns"] + st["lookup_columns"]
-cells = st["cells_written_loop"] * limit + st["cells_written_outer"]
+cells = st["cells_populated_loop"] * limit + st["cells_populated_outer"]   # trace cells that hold a value: what K12 multiplies over
 
 
 def wall(fn):
