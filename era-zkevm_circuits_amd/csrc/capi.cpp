@@ -360,8 +360,12 @@ int zk_cs_seed_carried_inputs(zk_cs* cs, uint64_t* dev_loop_inputs_rw, void* str
 }
 int zk_cs_set_check_mode(zk_cs* cs, uint32_t mode) {
     NEED(cs);
-    if (mode > ZK_CHECK_STORED) return fail(ZK_ERR_INVALID, "zk_cs_set_check_mode: unknown mode");
-    return guard([&] { cs->cs->set_check_mode(mode == ZK_CHECK_STORED); });
+    if (mode > ZK_CHECK_FUSED_DEFER_P2) return fail(ZK_ERR_INVALID, "zk_cs_set_check_mode: unknown mode");
+    return guard([&] { cs->cs->set_check_mode(mode); });
+}
+int zk_cs_complete_store(zk_cs* cs, void* stream) {
+    NEED(cs); NEED_INIT();
+    return guard([&] { cs->cs->ensure_p2_filled(stream); });
 }
 int zk_cs_check_satisfied(zk_cs* cs, void* stream, zk_failure* first) {
     NEED(cs); NEED_INIT();

@@ -845,6 +845,8 @@ void CS::build_check_program(Scope& s) {
     }
     if (!lookups_ok) { s.cprog.clear(); s.cchunks.clear(); s.cprog_full.clear(); s.cchunks_full.clear(); s.cmacros.clear(); s.cprog_fused.clear(); s.cchunks_fused.clear(); return; }
     s.n_macro_p2 = (uint32_t)macros.size();
+    s.n_p2_rounds_ops = 0;
+    for (auto& op : s.ops) s.n_p2_rounds_ops += (!op.seed_only && op.opcode == ZK_OP_P2_ROUNDS);
     if (getenv("ZKGL_PROG_STATS"))
         fprintf(stderr, "[zkgl] %s scope check program: %zu words, %u Poseidon2 macro packets (gate by gate: %zu words)\n", s.is_loop ? "loop" : "outer", s.cprog.size(),
                 s.n_macro_p2, s.cprog_full.size());
@@ -2561,6 +2563,7 @@ void CS::seed_stream(uint32_t n, const uint64_t* dev_outer_inputs, uint64_t* dev
 
 void CS::resolve(void* stream) {
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "resolve before set_batch");
+    p2_pending_ = false;   // a plain resolve writes every value
     if (outer_.n_input_words && !outer_.d_inputs) throw ZkError(ZK_ERR_INVALID, "outer input stream not bound");
     if (loop_.n_input_words && !loop_.d_inputs) throw ZkError(ZK_ERR_INVALID, "loop input stream not bound");
     hipStream_t st = (hipStream_t)stream;
@@ -2619,6 +2622,7 @@ int CS::check_satisfied(void* stream, zk_failure* first) {
 
 int CS::check_satisfied_impl(void* stream, zk_failure* first, bool macro) {
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "check_satisfied before set_batch");
+    ensure_p2_filled(stream);
     hipStream_t st = (hipStream_t)stream;
     // compact trace (straight from the witness kernels): a variable has ONE stored value, the gate checker reads every cell
     // through the alias map and copy constraints inside a scope hold by construction (boojum's check_if_satisfied has no such
@@ -2662,6 +2666,7 @@ int CS::check_satisfied_impl(void* stream, zk_failure* first, bool macro) {
 
 void CS::ensure_materialized(void* stream) {
     if (!compact_ || batch_ == 0) return;
+    ensure_p2_filled(stream);
     hipStream_t st = (hipStream_t)stream;
     for (Scope* s : {&outer_, &loop_}) {
         if (s->is_loop && !limit_) {
@@ -2825,6 +2830,10 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     const bool fused = !check_stored_ && !(vs && vs[0] == '1') && outer_.d_cprog_fused && (!limit_ || loop_.d_cprog_fused);
     last_check_fused_ = fused;
     if (fused) { oa.fail = d_fail_; la.fail = d_fail_ + 3; }
+    // deferred mode: only when the step is fused (nothing in it reads the intermediates) and every in-circuit permutation of the loop scope
+    // has a verified descriptor for the fill kernel
+    const bool defer = fused && defer_p2_ && limit_ && loop_.d_cmacros && loop_.n_macro_p2 == loop_.n_p2_rounds_ops;
+    la.defer_p2 = defer ? 1u : 0u;
     la.clock_probe = d_fail_ + 6;   // words 6, 7 of the block travel back with the verdict
     hip_check(hipMemsetAsync(d_fail_ + 8, 0, 2 * sizeof(unsigned long long), st), "memset p2 stats");
     la.p2_stats = d_fail_ + 8;      // words 8, 9: gated witness-only permutations skipped / run by the loop kernel's wavefronts
@@ -2876,11 +2885,28 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     // shader clock of the loop launch: s_memtime ticks per s_memrealtime tick (100 MHz) over the grid's first wavefront
     loop_shader_mhz_ = (limit_ && f[7] != ~0ull && f[7] != 0) ? (float)((double)f[6] / (double)f[7] * 100.0) : 0.0f;
     compact_ = true;
+    p2_pending_ = defer;
     const int rc = decode_failure(f, first);
     return rc == ZK_MACRO_FAILURE ? check_satisfied_impl(stream, first, false) : rc;
 }
 
+void CS::set_check_mode(uint32_t mode) {
+    check_stored_ = mode == ZK_CHECK_STORED;
+    defer_p2_ = mode == ZK_CHECK_FUSED_DEFER_P2;
+}
+
+// deferred mode (ZK_CHECK_FUSED_DEFER_P2): the loop kernel left the 950 intermediates of every in-circuit Poseidon2 permutation
+// unwritten; everything that reads the store beyond the fused step (the full check, trace readers, the prover-stage kernels, read_var,
+// the fault-injection hooks) comes through here first
+void CS::ensure_p2_filled(void* stream) {
+    if (!p2_pending_) return;
+    dev_check(zkdev::launch_fill_p2(loop_.d_store, loop_.store_geom(), loop_.n_lanes, loop_.d_cmacros, loop_.n_macro_p2, stream));
+    hip_check(hipStreamSynchronize((hipStream_t)stream), "fill_p2 sync");
+    p2_pending_ = false;
+}
+
 uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
+    ensure_p2_filled(nullptr);
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "read_var before set_batch");
     Scope& s = scope_of(v);
     if (var_index(v) >= s.n_vars || instance >= batch_) throw ZkError(ZK_ERR_INVALID, "read_var: out of range");
@@ -2931,6 +2957,7 @@ int CS::hook_compare_witness(const zk_var* vars, uint32_t n_vars, const uint64_t
 void CS::debug_poke_store(bool loop_scope, uint32_t slot, uint32_t lane, uint64_t value) {
     Scope& s = loop_scope ? loop_ : outer_;
     if (batch_ == 0 || !compact_ || slot >= s.n_store || lane >= s.n_lanes) throw ZkError(ZK_ERR_INVALID, "debug_poke_store: out of range or trace materialised");
+    ensure_p2_filled(nullptr);
     hip_check(hipMemcpy(s.d_store + tiled_offset(s.store_geom(), slot, lane), &value, 8, hipMemcpyHostToDevice), "poke memcpy");
 }
 
@@ -3074,6 +3101,7 @@ void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint6
     // a compact batch stays compact: one instance's columns are read through the trace view (cell -> slot), the whole batch's trace
     // (4x the store) is never allocated for this
     if (compact_) ensure_trace_view();
+    ensure_p2_filled(stream);
     if (n_instances == 0) return;
     if (instance >= batch_ || n_instances > batch_ - instance) throw ZkError(ZK_ERR_INVALID, "trace_columns: instance out of range");
     const uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;

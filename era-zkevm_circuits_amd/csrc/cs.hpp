@@ -98,6 +98,7 @@ struct Scope {
     std::vector<uint32_t> cmacros;   // Poseidon2 macro descriptors (k_check_p2), 14 words each
     std::vector<std::vector<uint32_t>> row_gates;  // [row][instance] -> index into `gates`
     uint32_t n_macro_p2 = 0;
+    uint32_t n_p2_rounds_ops = 0;    // ZK_OP_P2_ROUNDS ops of the scope (deferred mode needs a verified descriptor for each)
     std::vector<uint8_t> gate_mirrored;   // per gate: its relation is the semantics of the op producing its output (same variables, constants)
     // lookup sites by table for k_multiplicities: 3 key slots per site; site_off[table id] .. site_off[table id + 1]
     std::vector<uint32_t> mult_sites, mult_site_off;
@@ -234,7 +235,8 @@ class CS {
     uint32_t layout_word(const char* scope, const char* name) const;
     int check_satisfied(void* stream, zk_failure* first);
     int resolve_and_check(void* stream, zk_failure* first);
-    void set_check_mode(bool stored) { check_stored_ = stored; }
+    void set_check_mode(uint32_t mode);   // ZK_CHECK_FUSED / ZK_CHECK_STORED / ZK_CHECK_FUSED_DEFER_P2
+    void ensure_p2_filled(void* stream);   // deferred mode: regenerate the Poseidon2 intermediates the last resolve_and_check left out
     uint64_t read_var(zk_var v, uint32_t instance, uint32_t iteration);
     void write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value);
     std::vector<uint64_t> public_inputs(uint32_t instance);
@@ -394,6 +396,8 @@ class CS {
     bool last_check_fused_ = false;
     uint64_t p2_skipped_ = 0, p2_run_ = 0;   // gated witness-only permutations of the last resolve_and_check's loop launch, per wavefront
     bool check_stored_ = false;
+    bool defer_p2_ = false;          // ZK_CHECK_FUSED_DEFER_P2
+    bool p2_pending_ = false;        // the loop store lacks the intermediates of its in-circuit permutations (k_fill_p2 not run yet)
     bool uses_lookup_macros_ = false;   // a macro-op whose outputs carry lookup tuples was recorded: multiplicities by the k_multiplicities pass
     bool allow_macro_ops_ = false;   // zk_cs_set_check_mode(ZK_CHECK_STORED)
 };

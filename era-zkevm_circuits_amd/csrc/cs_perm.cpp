@@ -123,6 +123,7 @@ uint32_t CS::copy_permutation(const uint64_t beta[2], const uint64_t gamma[2], v
     // the argument runs over every populated trace cell; a compact batch is read through the trace view (cell -> store slot): the 4x
     // larger materialised trace of the whole batch is not built for this (round 3: its materialisation was most of K12's 3.3 ms / instance)
     if (compact_) ensure_trace_view();
+    ensure_p2_filled(stream);
     build_sigma();
     if (!d_sig_rel_[0]) {
         for (int s = 0; s < 2; ++s) { d_sig_rel_[s] = up(sig_rel_[s]); d_ep_index_[s] = up(ep_index_[s]); d_ovr_[s] = up(ovr_[s]); }

@@ -19,6 +19,7 @@ struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     uint64_t in_stride;    // lanes between consecutive words of the input stream (>= n_lanes: a batch may be a window of a longer stream)
     uint32_t uses_bigint;  // host only: the program contains ZK_OP_NN_MULMOD -> launch the *_bigint kernel variants
     unsigned long long* fail = nullptr;  // fused mode: where the witness kernels report a gate they evaluate themselves (SELECT with a non-boolean selector)
+    uint32_t defer_p2 = 0;                       // 1: ZK_OP_P2_ROUNDS stores only its 12 final outputs (ZK_CHECK_FUSED_DEFER_P2), the 950 intermediates come from launch_fill_p2
     unsigned long long* p2_stats = nullptr;     // two counters: gated witness-only permutations a wavefront skipped / ran (ZK_OP_POSEIDON2 a = 1)
     unsigned long long* clock_probe = nullptr;  // two words: shader-clock and 100 MHz ticks of the grid's first wavefront (kernels_engine2.hpp witness_entry2)
 };
@@ -138,6 +139,8 @@ struct PermArgs {
     uint32_t slots_per_chunk, n_chunks; uint64_t* lane_out; uint64_t* prefix;
     const uint32_t* slot1 = nullptr;   // compact batch: `cells` is the variable store, slot1[trace cell] = store slot + 1
 };
+// the 950 intermediates of every in-circuit Poseidon2 permutation of a scope, recomputed from its 12 stored inputs (descriptors = the check macros)
+int launch_fill_p2(uint64_t* store, uint64_t n_store, uint32_t n_lanes, const uint32_t* macros, uint32_t n_macros, void* stream);
 int launch_perm_lane(const PermArgs& a, void* stream);
 int launch_perm_tb(const uint64_t beta[2], const uint32_t* sigma_rel, uint64_t* tb, uint32_t n, void* stream);
 int launch_perm_scan(const uint64_t* part, uint32_t per, const uint64_t* seed, uint64_t* excl, uint64_t* total, uint32_t n_instances, void* stream);

@@ -59,6 +59,7 @@ struct ScopeDev {
     // Their relations are the ops' own field arithmetic, except SELECT: s (a - b) + b - r == 0 for r = s ? a : b fails exactly when
     // s > 1 and a != b — tested on the operands in registers, reported under the macro row (the host then names the gate).
     unsigned long long* fail;
+    uint32_t defer_p2;                // 1: P2_ROUNDS writes its 12 final outputs only
     unsigned long long* p2_stats;     // nullable: {skipped, run} gated witness-only permutations, one count per wavefront
     unsigned long long* clock_probe;  // nullable: {shader clock ticks, 100 MHz ticks} of the grid's first wavefront (witness_entry2)
 };

@@ -473,13 +473,16 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
         case ZK_OP_POSEIDON2:      // witness-only permutation: 12 outputs
         case ZK_OP_P2_ROUNDS: {    // in-circuit permutation: every intermediate the gates constrain, in the order of gadgets.cpp
                                    // compute_round_function; state in LDS so that the S-box loop is not unrolled (I-cache)
-            const bool emit = (op == ZK_OP_P2_ROUNDS);
+            // deferred mode (sc.defer_p2): an in-circuit permutation is computed like a witness-only one and stores its 12 final outputs
+            // only, 950 slots further on — nothing in the fused step reads the intermediates; k_fill_p2 regenerates them on demand
+            const bool deferred = (op == ZK_OP_P2_ROUNDS) && sc.defer_p2 != 0;
+            const bool emit = (op == ZK_OP_P2_ROUNDS) && !deferred;
             uint64_t s[12];
 #pragma unroll
             for (int i = 0; i < 12; ++i) s[i] = ldv(W[1 + i]);
             // gated form (pa = 1, witness-only): [.., execute] -> zeros where the flag is off (simulate_round_function(cs, state, execute));
             // a wavefront whose 64 cycles all have it off skips the permutation altogether
-            const bool gated = !emit && pa != 0;
+            const bool gated = (op == ZK_OP_POSEIDON2) && pa != 0;
             bool lane_off = false;
             if (gated) {
                 lane_off = ldv(W[13]) == 0;
@@ -496,6 +499,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 out_to(W[13]);
                 pc += 13 + D;
             }
+            if (deferred) dst += WIDE ? 950u : 950u * bstep;
             p2::mds_external(s);
             if constexpr (P2_IN_REGISTERS) {
                 // state in registers, the twelve S-boxes of a full round unrolled, ONE copy of the full-round body (12 KB of code: the
@@ -1604,6 +1608,72 @@ __global__ void k_check_inputs(const uint64_t* __restrict__ inputs, uint32_t n_w
     if (lane >= n_lanes) return;
     for (uint32_t w = blockIdx.y; w < n_words; w += gridDim.y)
         if (inputs[(size_t)w * stride + lane] >= gl::P) report(fail, lane, 0xfffffu, w & 0xff, 0);
+}
+
+// The 950 intermediates of every in-circuit Poseidon2 permutation (all outputs of ZK_OP_P2_ROUNDS but the final 12), recomputed from
+// the 12 stored inputs and written to their slots — the other half of the deferred mode (ScopeDev::defer_p2): same values, same order
+// as run_tile2's emit path.  Descriptors = the check macros (12 input slots, first output slot, row).
+__global__ __launch_bounds__(TPB) void k_fill_p2(CheckP2Dev cd) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= cd.n_lanes) return;
+    lane = lane < cd.n_lanes ? lane : cd.n_lanes - 1;
+    const TileAddr ta = tile_addr(const_cast<uint64_t*>(cd.cells), cd.n_cells, lane);
+    const uint32_t lane_byte = ta.lane_byte, bsh = uni(ta.shift);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ta.base, 0, -1, 0x00020000);
+    const prog1_ptr macros = (prog1_ptr)(uintptr_t)cd.macros;
+    const uint32_t m0 = blockIdx.y * cd.per_block, m1 = min(m0 + cd.per_block, cd.n_macros);
+    for (uint32_t m = m0; m < m1; ++m) {
+        const u32x16_a4 W = *(prog16_ptr)(macros + 14 * m);
+        uint64_t s[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, W[i] << bsh, 0);
+            s[i] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        }
+        uint32_t o = W[12] << bsh;
+        const uint32_t step = 1u << bsh;
+        auto st = [&](uint64_t v) {
+            u32x2 w;
+            w.x = (uint32_t)v; w.y = (uint32_t)(v >> 32);
+            __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, lane_byte, o, 0);
+            o += step;
+        };
+        p2::mds_external(s);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) st(s[i]);
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = half * 26 + r4;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const uint64_t t = gl::add(s[i], p2::RC[12 * r + i]);
+                    const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+                    st(t); st(x2); st(x3); st(x4); st(x7);
+                    s[i] = x7;
+                }
+                p2::mds_external(s);
+                if (!(half == 1 && r4 == 3)) {   // the last layer's outputs are the 12 the witness kernel wrote
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) st(s[i]);
+                }
+            }
+            if (half == 0) {
+#pragma unroll 1
+                for (int r = 4; r < 26; ++r) {
+                    const uint64_t t = gl::add(s[0], p2::RC[12 * r]);
+                    const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
+                    st(t); st(x2); st(x3); st(x4); st(x7);
+                    s[0] = x7;
+                    p2::mds_inner(s);
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) st(s[i]);
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -130,6 +130,7 @@ static zke::ScopeDev to_dev(const ScopeArgs& a) {
     d.fail = a.fail;
     d.clock_probe = a.clock_probe;
     d.p2_stats = a.p2_stats;
+    d.defer_p2 = a.defer_p2;
     return d;
 }
 
@@ -303,6 +304,17 @@ int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream) {
     return LAUNCH_CHECK("k_ntt_pass");
 }
 
+int launch_fill_p2(uint64_t* store, uint64_t n_store, uint32_t n_lanes, const uint32_t* macros, uint32_t n_macros, void* stream) {
+    if (!n_lanes || !n_macros) return 0;
+    zke::CheckP2Dev d;
+    d.cells = store; d.n_cells = n_store; d.n_lanes = n_lanes; d.macros = macros; d.n_macros = n_macros; d.fail = nullptr;
+    const unsigned lane_tiles = grid_for(n_lanes, zke::TPB);
+    uint32_t chunks = std::max<uint32_t>(1, std::min<uint32_t>(n_macros, (4096 + lane_tiles - 1) / lane_tiles));
+    d.per_block = (n_macros + chunks - 1) / chunks;
+    chunks = (n_macros + d.per_block - 1) / d.per_block;
+    zke::k_fill_p2<<<dim3(lane_tiles, chunks), zke::TPB, 0, (hipStream_t)stream>>>(d);
+    return LAUNCH_CHECK("k_fill_p2");
+}
 int launch_perm_lane(const PermArgs& a, void* stream) {
     if (a.n_lanes == 0) return 0;
     zkp::PermDev d;

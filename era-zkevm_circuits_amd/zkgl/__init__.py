@@ -1145,9 +1145,14 @@ class ConstraintSystem:
             return False, Failure(f.scope, f.instance, f.iteration, f.slot, f.kind, f.relation)
         _check(rc)
 
-    def set_check_mode(self, stored: bool):
-        """zk_cs_set_check_mode: False = fused (default), True = every relation re-evaluated from the stored values"""
-        _check(lib().zk_cs_set_check_mode(self._h, 1 if stored else 0))
+    def set_check_mode(self, stored, defer_p2: bool = False):
+        """zk_cs_set_check_mode: False = fused (default), True = every relation re-evaluated from the stored values;
+        defer_p2=True: fused, and the Poseidon2 intermediates are written on demand only (ZK_CHECK_FUSED_DEFER_P2)"""
+        _check(lib().zk_cs_set_check_mode(self._h, 2 if defer_p2 else (1 if stored else 0)))
+
+    def complete_store(self, stream=None):
+        """zk_cs_complete_store: the deferred mode's fill of the Poseidon2 intermediates, on the caller's clock"""
+        _check(lib().zk_cs_complete_store(self._h, _ptr(stream)))
 
     def resolve_and_check(self, stream=None):
         """fused witness generation + check_if_satisfied (outer scope overlapped on a second stream)"""

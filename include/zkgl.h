@@ -221,7 +221,16 @@ int zk_cs_resolve_and_check(zk_cs *cs, void *stream, zk_failure *first);
  * ZKGL_VERIFY_STORED=1 forces ZK_CHECK_STORED for every zk_cs of the process. */
 #define ZK_CHECK_FUSED 0u
 #define ZK_CHECK_STORED 1u
+/* ZK_CHECK_FUSED_DEFER_P2: the fused mode, and the loop kernel does not write the 950 intermediates of an in-circuit Poseidon2
+ * permutation (main_vm: 8 550 of a cycle's 17 700 values) — nothing in the fused step reads them.  They are regenerated from the 12
+ * stored inputs, bit for bit, the first time anything reads the store beyond the step: zk_cs_check_satisfied, zk_cs_trace_columns*,
+ * zk_cs_trace_ptr, the prover-stage entry points, zk_cs_read_var, the fault-injection hooks (k_fill_p2).  Same verdicts, same
+ * values; a different split of the work between the step and its readers, reported separately by bench.py. */
+#define ZK_CHECK_FUSED_DEFER_P2 2u
 int zk_cs_set_check_mode(zk_cs *cs, uint32_t mode);
+/* ZK_CHECK_FUSED_DEFER_P2 only: write the values the last zk_cs_resolve_and_check left out now (every reader does it implicitly; a host
+ * that wants the cost on its own clock calls this).  No-op otherwise. */
+int zk_cs_complete_store(zk_cs *cs, void *stream);
 int zk_cs_read_var(zk_cs *cs, zk_var var, uint32_t instance, uint32_t iteration, uint64_t *out); /* witness_hook */
 /* hook_compare_witness (/root/reference/src/fsm_input_output/mod.rs:102-133) as a device-side diff: the circuit's values of the outer
  * variables `vars` (the closed-form input the host cares about: hidden_fsm_output, observable_output ...; recorded handles) against

@@ -210,3 +210,42 @@ def test_main_vm_hook_compare_witness(zk):
     assert len(cs.hook_vars("observable_output")) == 59   # VmOutputData: 9 + 25 + 25 (circuit_inputs/main_vm.rs:32-38)
     for i in range(n_inst):
         assert cs.public_inputs(i) == vp.expected_commitment(D, run, LIMIT, i)
+
+
+def test_main_vm_deferred_poseidon2_intermediates(zk, batch, monkeypatch):
+    """ZK_CHECK_FUSED_DEFER_P2: the loop kernel writes only the 12 final outputs of every in-circuit permutation; the verdict and the
+    public inputs are the fused mode's, and the first reader of the store (here the trace) finds every intermediate regenerated bit
+    for bit (k_fill_p2) — whole trace == oracle, the full re-evaluation passes, a corrupted intermediate is still caught"""
+    cs, D, outer, loop, commits, info = batch
+    B = outer.shape[1]
+    cs.set_batch(B)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    for strands in ("0", "1"):
+        monkeypatch.setenv("ZKGL_STRANDS", strands)
+        cs.set_check_mode(False, defer_p2=True)
+        try:
+            ok, f = cs.resolve_and_check()
+            assert ok, f
+            for i in (0, B - 1):
+                assert cs.public_inputs(i) == commits[i]
+            ok, f = cs.check_if_satisfied()          # every gate from the stored values: needs the intermediates
+            assert ok, f
+            run = run_oracle(cs, B)
+            run.resolve(outer, loop)
+            assert np.array_equal(cs.trace(True), run.lc), "loop-scope trace differs from the oracle after the deferred fill"
+        finally:
+            cs.set_check_mode(False)
+    # a tampered carried word is reported in the deferred mode like in the others
+    bad = loop.copy()
+    lay = cs.main_vm_layout()["loop"]
+    bad[lay["state"][0] + 9, 5 * LIMIT + 7] ^= 1
+    d_b = zk.DeviceBuffer.from_numpy(bad)
+    cs.bind_inputs(True, d_b, bad.shape[0])
+    cs.set_check_mode(False, defer_p2=True)
+    try:
+        ok, f = cs.resolve_and_check()
+        assert not ok and f.instance == 5
+    finally:
+        cs.set_check_mode(False)
