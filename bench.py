@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--workload", default="main_vm", choices=["main_vm", "vm_shaped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed default-mode steps (profiler runs: every k_witness_loop launch of the process is then a default-mode launch); the secondary figures are null")
     ap.add_argument("--fixture", default="default", choices=sorted(FIXTURES), help="which synthetic executions main_vm replays (default: every opcode family every ~150 cycles)")
     args = ap.parse_args()
     # ---- N > 1 without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
@@ -379,79 +380,83 @@ def main():
         gather_ms = 1e3 * float(np.mean(gather_events))
     if not np.array_equal(commits[rank], local) and not os.environ.get("ZKGL_STUB_RUN"):  # stub variants store garbage
         raise RuntimeError("gathered commitments differ from this rank's public inputs")
-    # ---- the same K steps from the raw witness (seeding pass, gather) with EVERY relation re-evaluated from the stored values
-    # (zk_cs_set_check_mode(ZK_CHECK_STORED): what check_if_satisfied does, /root/reference/src/ram_permutation/mod.rs:556)
-    cs.set_check_mode(True)
-    step_no[0] = 0
-    for _ in range(min(args.warmup, 1)):
-        step()
-    step_no[0] = 0
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    raw_stored_local = time.perf_counter() - t1
-    cs.set_check_mode(False)
-    resolve(last_window)
-    # ---- LABELLED MODE, not `value`: ZK_CHECK_FUSED_DEFER_P2 — the loop kernel leaves out the 950 intermediates of every in-circuit Poseidon2
-    # permutation (nothing in the fused step reads them); whoever reads the store later (the full check, the column readers) gets them
-    # regenerated bit for bit by k_fill_p2, timed here on its own (zk_cs_complete_store).  Its unit differs: fewer values per cycle.
-    deferred = None
-    if args.workload == "main_vm":
-        cs.set_check_mode(False, defer_p2=True)
+    # (--headline-only: profiler runs skip everything below, so that every k_witness_loop launch of the process is a default-mode launch)
+    raw_stored_local = resident_local = stored_local = float("nan")
+    deferred, mat_s, mat_chunk, n_cols_trace = None, None, 0, int(st["copy_columns"] + st["lookup_columns"])
+    if not args.headline_only:
+        # ---- the same K steps from the raw witness (seeding pass, gather) with EVERY relation re-evaluated from the stored values
+        # (zk_cs_set_check_mode(ZK_CHECK_STORED): what check_if_satisfied does, /root/reference/src/ram_permutation/mod.rs:556)
+        cs.set_check_mode(True)
         step_no[0] = 0
-        step(); fence()
+        for _ in range(min(args.warmup, 1)):
+            step()
         step_no[0] = 0
-        d_loop_ms = []
+        fence()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
-            d_loop_ms.append(cs.last_ms(1))
         fence()
-        d_elapsed = time.perf_counter() - t1
-        d_local = np.array([cs.public_inputs(i) for i in range(min(B, 8))], dtype=np.uint64)   # reads go through the fill
-        resolve(window[0]); torch.cuda.synchronize()
-        tf = time.perf_counter(); cs.complete_store(stream); torch.cuda.synchronize(); fill_s = time.perf_counter() - tf
-        deferred = {"elapsed": d_elapsed, "loop_ms": float(np.mean(d_loop_ms)), "fill_s": fill_s,
-                    "commitments_equal": bool(expect is None or np.array_equal(d_local, expect[window[0] * B: window[0] * B + d_local.shape[0]]))}
+        raw_stored_local = time.perf_counter() - t1
         cs.set_check_mode(False)
         resolve(last_window)
-    # ---- the same K steps with the per-cycle state already resident (what rounds 1-2 reported as `value`)
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        resolve((last_window + 1 + i) % K)
-    torch.cuda.synchronize()
-    resident_local = time.perf_counter() - t1
-    # ---- and with every gate re-evaluated from the stored values (the mode of rounds 1-2; resolve_and_check's default is fused: the
-    # gates mirrored by their producing witness op are evaluated by the witness kernels)
-    cs.set_check_mode(True)
-    resolve(0); torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        resolve((last_window + 1 + i) % K)
-    torch.cuda.synchronize()
-    stored_local = time.perf_counter() - t1
-    cs.set_check_mode(False)
-    resolve(last_window)   # back to the window the commitments were read from, default mode
-    # ---- materialised witness columns: the variable store is what the step writes; the trace proper (every cell of every column of
-    # every instance, as column polynomials) is produced on demand by zk_cs_trace_columns_batch — timed here for the WHOLE batch, in
-    # chunks of as many instances as fit beside the store (a batch's columns are 4x its store)
-    mat_s, mat_chunk, n_cols_trace = None, 0, int(st["copy_columns"] + st["lookup_columns"])
-    try:
-        free_b, _total_b = torch.cuda.mem_get_info(dev)
-        per_inst = n_cols_trace << (args.log2_rows + 3)
-        mat_chunk = int(max(1, min(B, 64, (free_b - (8 << 30)) // per_inst)))
-        cols = torch.empty(mat_chunk * (n_cols_trace << args.log2_rows), dtype=torch.int64, device=dev)
-        cs.trace_columns_batch(0, mat_chunk, cols, args.log2_rows, n_cols_trace, stream=stream); torch.cuda.synchronize()
-        tm = time.perf_counter()
-        for i0 in range(0, B, mat_chunk):
-            cs.trace_columns_batch(i0, min(mat_chunk, B - i0), cols, args.log2_rows, n_cols_trace, stream=stream)
+        # ---- LABELLED MODE, not `value`: ZK_CHECK_FUSED_DEFER_P2 — the loop kernel leaves out the 950 intermediates of every in-circuit Poseidon2
+        # permutation (nothing in the fused step reads them); whoever reads the store later (the full check, the column readers) gets them
+        # regenerated bit for bit by k_fill_p2, timed here on its own (zk_cs_complete_store).  Its unit differs: fewer values per cycle.
+        deferred = None
+        if args.workload == "main_vm":
+            cs.set_check_mode(False, defer_p2=True)
+            step_no[0] = 0
+            step(); fence()
+            step_no[0] = 0
+            d_loop_ms = []
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+                d_loop_ms.append(cs.last_ms(1))
+            fence()
+            d_elapsed = time.perf_counter() - t1
+            d_local = np.array([cs.public_inputs(i) for i in range(min(B, 8))], dtype=np.uint64)   # reads go through the fill
+            resolve(window[0]); torch.cuda.synchronize()
+            tf = time.perf_counter(); cs.complete_store(stream); torch.cuda.synchronize(); fill_s = time.perf_counter() - tf
+            deferred = {"elapsed": d_elapsed, "loop_ms": float(np.mean(d_loop_ms)), "fill_s": fill_s,
+                        "commitments_equal": bool(expect is None or np.array_equal(d_local, expect[window[0] * B: window[0] * B + d_local.shape[0]]))}
+            cs.set_check_mode(False)
+            resolve(last_window)
+        # ---- the same K steps with the per-cycle state already resident (what rounds 1-2 reported as `value`)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            resolve((last_window + 1 + i) % K)
         torch.cuda.synchronize()
-        mat_s = (time.perf_counter() - tm) / B
-        del cols
-    except Exception as e:  # noqa: BLE001
-        print(f"[bench] trace_columns timing unavailable: {e}", file=sys.stderr)
+        resident_local = time.perf_counter() - t1
+        # ---- and with every gate re-evaluated from the stored values (the mode of rounds 1-2; resolve_and_check's default is fused: the
+        # gates mirrored by their producing witness op are evaluated by the witness kernels)
+        cs.set_check_mode(True)
+        resolve(0); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            resolve((last_window + 1 + i) % K)
+        torch.cuda.synchronize()
+        stored_local = time.perf_counter() - t1
+        cs.set_check_mode(False)
+        resolve(last_window)   # back to the window the commitments were read from, default mode
+        # ---- materialised witness columns: the variable store is what the step writes; the trace proper (every cell of every column of
+        # every instance, as column polynomials) is produced on demand by zk_cs_trace_columns_batch — timed here for the WHOLE batch, in
+        # chunks of as many instances as fit beside the store (a batch's columns are 4x its store)
+        mat_s, mat_chunk, n_cols_trace = None, 0, int(st["copy_columns"] + st["lookup_columns"])
+        try:
+            free_b, _total_b = torch.cuda.mem_get_info(dev)
+            per_inst = n_cols_trace << (args.log2_rows + 3)
+            mat_chunk = int(max(1, min(B, 64, (free_b - (8 << 30)) // per_inst)))
+            cols = torch.empty(mat_chunk * (n_cols_trace << args.log2_rows), dtype=torch.int64, device=dev)
+            cs.trace_columns_batch(0, mat_chunk, cols, args.log2_rows, n_cols_trace, stream=stream); torch.cuda.synchronize()
+            tm = time.perf_counter()
+            for i0 in range(0, B, mat_chunk):
+                cs.trace_columns_batch(i0, min(mat_chunk, B - i0), cols, args.log2_rows, n_cols_trace, stream=stream)
+            torch.cuda.synchronize()
+            mat_s = (time.perf_counter() - tm) / B
+            del cols
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] trace_columns timing unavailable: {e}", file=sys.stderr)
 
     from zkgl.dist import gather_floats, max_over_ranks
     elapsed = max_over_ranks(elapsed_local)
@@ -566,7 +571,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.log2_rows)
         else:
             out["cpu_baseline"] = None
-        json_out.write(json.dumps(out) + "\n")
+        def _clean(x):   # --headline-only leaves the secondary figures unmeasured: null, not NaN
+            if isinstance(x, dict): return {k: _clean(v) for k, v in x.items()}
+            if isinstance(x, list): return [_clean(v) for v in x]
+            if isinstance(x, float) and x != x: return None
+            return x
+        json_out.write(json.dumps(_clean(out)) + "\n")
         json_out.flush()
     if world > 1:
         dist.barrier()

@@ -8,11 +8,11 @@ ROOT=$(pwd); mkdir -p "$ROOT/gpurun_out"
 B=${B:-384}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt_r4
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_r4 -o kt -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline < /dev/null > "$ROOT/gpurun_out/r4_bench_under_rocprof.json" 2> /tmp/kt_r4.err
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt_r4 -o kt -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --headline-only < /dev/null > "$ROOT/gpurun_out/r4_bench_under_rocprof.json" 2> /tmp/kt_r4.err
 db=$(find /tmp/kt_r4 -name "*_results.db" | head -1)
 [ -n "$db" ] && python "$ROOT/profiles/summarize_rocpd.py" "$db" > "$ROOT/gpurun_out/r4_kernel_trace.md"
 cd "$ROOT"
-export PMC_CMD="python $ROOT/bench.py --batch $B --seed-windows 2 --steps 2 --warmup 0 --no-cpu-baseline"
+export PMC_CMD="python $ROOT/bench.py --batch $B --seed-windows 2 --steps 2 --warmup 0 --no-cpu-baseline --headline-only"
 tools/pmc_pass.sh r4_fetch FETCH_SIZE > /dev/null
 tools/pmc_pass.sh r4_write WRITE_SIZE > /dev/null
 unset PMC_CMD
