@@ -569,6 +569,61 @@ int zk_pack_demux_witness(const zk_demux_log_queue_witness* w, uint32_t limit, u
     return ZK_OK;
 }
 
+// With the states the reference's witnesses already hold nothing is left to derive on the device: the input queue's witness is a
+// VecDeque of (LogQuery, previous tail) (input.rs:118-121: CircuitQueueRawWitness) — the head the circuit holds before it pops that
+// element — and each of the six output queues is the input queue of a later circuit whose witness holds the same pairs, i.e. the
+// tail after every push here.  The lengths are counts.  Every one of the 35 carried words of every cycle is then a function of the
+// witness alone (zk_demux_given_words = all of them): zk_cs_seed_* has no kernel to run, the circuit's own queue constraints and CARRY
+// links judge the words.
+int zk_pack_demux_witness_tails(const zk_demux_log_queue_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words,
+                                const uint64_t* input_previous_tails, const uint64_t* output_tails) {
+    if (!input_previous_tails || !output_tails) return bad(ZK_ERR_INVALID, "zk_pack_demux_witness_tails: null tails (use zk_pack_demux_witness and device seeding)");
+    if (int rc = zk_pack_demux_witness(w, limit, instance, batch, outer_words, loop_words)) return rc;
+    // the state the first cycle starts from: observable input (empty output queues) on the first instance, the FSM input otherwise
+    const zk_queue_state_witness& in0 = w->start_flag ? w->initial_log_queue_state : w->hidden_fsm_input.initial_log_queue_state;
+    uint64_t head[4], out_tail[6][4];
+    uint32_t len = in0.length, out_len[6];
+    for (int k = 0; k < 4; ++k) head[k] = in0.head[k];
+    for (int q = 0; q < 6; ++q) {
+        for (int k = 0; k < 4; ++k) out_tail[q][k] = w->start_flag ? 0 : w->hidden_fsm_input.output_queue_states[q].tail[k];
+        out_len[q] = w->start_flag ? 0 : w->hidden_fsm_input.output_queue_states[q].length;
+    }
+    if (len > w->n_initial && len > limit) { /* more elements than this instance's witness holds: the remaining cycles pop what is there */ }
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        const bool pops = len != 0 && c < w->n_initial;
+        if (pops) for (int k = 0; k < 4; ++k) head[k] = input_previous_tails[4 * (size_t)c + k];   // the head before this pop, from the witness
+        l.arr(head); l.w(len);
+        for (int q = 0; q < 6; ++q) { l.arr(out_tail[q]); l.w(out_len[q]); }
+        if (pops) {
+            const zk_log_query_witness& it = w->initial_queue_witness[c];
+            // the head after the pop = the previous tail of the next element, or the queue's tail when this was the last one
+            if (c + 1 < w->n_initial && len > 1) for (int k = 0; k < 4; ++k) head[k] = input_previous_tails[4 * (size_t)(c + 1) + k];
+            else for (int k = 0; k < 4; ++k) head[k] = in0.tail[k];
+            --len;
+            bool hi_zero = true;
+            for (int i = 1; i < 5; ++i) hi_zero &= it.address[i] == 0;
+            int q = -1;   // mod.rs:300-356 (aux byte, shard, formal precompile addresses [EXT] zkevm_opcode_defs)
+            if (it.aux_byte == 0 && it.shard_id == 0) q = 0;
+            else if (it.aux_byte == 1) q = 1;
+            else if (it.aux_byte == 2) q = 2;
+            else if (it.aux_byte == 3 && hi_zero && it.address[0] == 0x8010) q = 3;
+            else if (it.aux_byte == 3 && hi_zero && it.address[0] == 0x02) q = 4;
+            else if (it.aux_byte == 3 && hi_zero && it.address[0] == 0x01) q = 5;
+            if (q >= 0) {
+                for (int k = 0; k < 4; ++k) out_tail[q][k] = output_tails[4 * (size_t)c + k];
+                ++out_len[q];
+            }
+        }
+    }
+    return ZK_OK;
+}
+uint32_t zk_demux_given_words(uint32_t words[35]) {
+    for (uint32_t i = 0; i < 35; ++i) words[i] = i;
+    return 35;
+}
+
 namespace {
 void put_decommit(Out& o, const zk_decommit_query_witness* q) {   // DecommitQuery field order, 11 words; nullptr: the zero item
     if (!q) { for (int i = 0; i < 11; ++i) o.w(0); return; }

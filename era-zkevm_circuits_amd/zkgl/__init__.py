@@ -328,6 +328,17 @@ def pack_demux_witness(w, limit, instance, outer, loop):
     _pack(lib().zk_pack_demux_witness, w, limit, instance, outer, loop, 73, 71)
 
 
+def pack_demux_witness_tails(w, limit, instance, outer, loop, input_previous_tails, output_tails):
+    """zk_pack_demux_witness_tails: every carried word from the witness's own queue states ([n, 4] u64 each); returns the given words"""
+    assert outer.shape[0] == 73 and loop.shape[0] == 71 and loop.shape[1] == outer.shape[1] * limit
+    ipt = np.ascontiguousarray(input_previous_tails, dtype=np.uint64); ot = np.ascontiguousarray(output_tails, dtype=np.uint64)
+    _check(lib().zk_pack_demux_witness_tails(C.byref(w), limit, instance, outer.shape[1], outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p),
+                                             ipt.ctypes.data_as(C.c_void_p), ot.ctypes.data_as(C.c_void_p)))
+    words = (C.c_uint32 * 35)()
+    n = lib().zk_demux_given_words(words)
+    return list(words[:n])
+
+
 class DecommitQueryWitness(C.Structure):
     _fields_ = [("code_hash", C.c_uint32 * 8), ("page", C.c_uint32), ("is_first", C.c_uint8), ("timestamp", C.c_uint32)]
 

@@ -259,6 +259,15 @@ typedef struct zk_demux_log_queue_witness {
  * loop_words[71][batch * limit]; 35 carried words zeroed (device seeding), one popped LogQuery (36 words) per cycle */
 int zk_pack_demux_witness(const zk_demux_log_queue_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                           uint64_t *outer_words, uint64_t *loop_words);
+/* The same with the queue states the reference's witnesses hold (round 4): input_previous_tails[n_initial][4] = the second member of
+ * every (LogQuery, previous tail) element of initial_queue_witness (input.rs:118-121) — the head before that element is popped;
+ * output_tails[n_initial][4] = the tail of the element's TARGET queue after its push (the previous tails of the next circuits' input
+ * witnesses; ignored for an element no queue takes).  All 35 carried words of every cycle are then written by the packer
+ * (zk_demux_given_words -> zk_cs_set_seed_given): seeding has nothing left to compute (round 3: a cone of 7 dependent permutations per
+ * cycle, 86 ms for 1 187 cycles against a 1.7 ms step). */
+int zk_pack_demux_witness_tails(const zk_demux_log_queue_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                                uint64_t *outer_words, uint64_t *loop_words, const uint64_t *input_previous_tails, const uint64_t *output_tails);
+uint32_t zk_demux_given_words(uint32_t words[35]);
 
 /* ---- DecommitQuery witness, /root/reference/src/base_structures/decommit_query/mod.rs:22-29 */
 typedef struct zk_decommit_query_witness {

@@ -246,6 +246,18 @@ def test_c2_main_vm_2_20_rows(zk):
     for i in range(B):
         assert cs.public_inputs(i) == [int(x) for x in expect[i]], i
     assert int(cs.multiplicities(0).sum()) == st["lookups_per_instance"]
+    # the same batch with EVERY relation re-evaluated from the stored values (ZK_CHECK_STORED = check_if_satisfied's semantics,
+    # /root/reference/src/ram_permutation/mod.rs:556) and in the deferred-intermediates mode: same verdict, same public inputs
+    for mode in ((True, False), (False, True)):
+        cs.set_check_mode(mode[0], defer_p2=mode[1])
+        try:
+            ok, f = cs.resolve_and_check()
+            assert ok, (mode, f)
+            assert cs.public_inputs(B - 1) == [int(x) for x in expect[B - 1]]
+        finally:
+            cs.set_check_mode(False)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
     # the WHOLE trace of one full-size instance — 164 columns x 2^20 rows, every cell — against the oracle interpreter run on that
     # instance's streams: the witness columns the prover would commit to (zk_cs_trace_columns), not only the commitments
     assert_whole_trace_equals_oracle(zk, cs, outer, seeded, 3, limit, 20)
@@ -257,3 +269,9 @@ def test_c2_main_vm_2_20_rows(zk):
     cs.bind_inputs(True, d_b, bad.shape[0])
     ok, f = cs.resolve_and_check()
     assert not ok and f.instance == 5
+    cs.set_check_mode(True)
+    try:
+        ok, f2 = cs.resolve_and_check()
+        assert not ok and f2.instance == 5
+    finally:
+        cs.set_check_mode(False)

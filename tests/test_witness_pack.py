@@ -538,6 +538,92 @@ def test_demux_packer_equals_the_oracle_streams():
     assert np.array_equal(outer, eo) and np.array_equal(loop, el)
 
 
+def _demux_tails(inst, queue, limit):
+    """what the reference's witnesses hold beside the items: the previous tail of every popped element (the input queue's head before
+    the pop) and, for every element, the tail of its target queue after the push (the next circuit's previous tails)"""
+    from oracle import demux_native as dn
+    rows = inst["rows"]
+    n = min(len(queue), limit)
+    prev = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    out = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    fsm_out = inst["fsm_out"]["out"]
+    for c in range(n):
+        prev[c] = rows[c][0:4]
+        k, good = dn.target_queue(queue[c])
+        if k is not None:
+            nxt = rows[c + 1][5 + 5 * k:9 + 5 * k] if c + 1 < limit else fsm_out[k][4:8]
+            out[c] = nxt
+    return prev, out
+
+
+def _demux_packed_with_tails():
+    outer, loop, insts, limit = _demux_packed()
+    from oracle import demux_native as dn   # noqa: F401
+    # rebuild the two witnesses of _demux_packed and pack them again with the queue states
+    rng = np.random.default_rng(61)
+    from oracle.storage_native import log_query
+    qs = []
+    for t in range(11):
+        kind = int(rng.integers(0, 6))
+        address = {3: 0x8010, 4: 0x02, 5: 0x01}.get(kind, int(rng.integers(1 << 20, 1 << 40)))
+        qs.append(log_query(address=address, key=int.from_bytes(rng.bytes(32), "little"), read_value=int.from_bytes(rng.bytes(32), "little"),
+                            written_value=int.from_bytes(rng.bytes(32), "little"), rw_flag=int(rng.integers(0, 2)), aux_byte=[0, 1, 2, 3, 3, 3][kind],
+                            rollback=int(rng.integers(0, 2)), is_service=int(rng.integers(0, 2)), shard_id=0,
+                            tx_number_in_block=int(rng.integers(0, 1000)), timestamp=100 + t))
+    queues = [qs, insts[0]["rest"]]
+    outer2 = np.zeros((73, 2), dtype=np.uint64); loop2 = np.full((71, 2 * limit), 9, dtype=np.uint64)
+    given = None
+    for i, (inst, queue) in enumerate(zip(insts, queues)):
+        o = inst["outer"]
+        w = zkgl.DemuxLogQueueWitness()
+        w.start_flag, w.completion_flag = int(o[0]), int(inst["completed"])
+        w.initial_log_queue_state = _q4(o[1:10])
+        w.hidden_fsm_input.initial_log_queue_state = _q4(o[10:19])
+        for k in range(6):
+            w.hidden_fsm_input.output_queue_states[k] = _q4(o[19 + 9 * k:28 + 9 * k])
+        popped = queue[:limit]
+        arr = (zkgl.LogQueryWitness * max(len(popped), 1))(*[_lq(q) for q in popped])
+        w.initial_queue_witness, w.n_initial = arr, len(popped)
+        prev, out = _demux_tails(inst, queue, limit)
+        given = zkgl.pack_demux_witness_tails(w, limit, i, outer2, loop2, prev, out)
+    return outer2, loop2, insts, limit, given
+
+
+def test_demux_packer_with_the_witness_queue_states_writes_every_carried_word():
+    """zk_pack_demux_witness_tails: with the previous tails of the input witness and the tails the next circuits' witnesses hold, the
+    packer's stream — carried words included — IS the native restatement's: nothing is left to seed"""
+    outer, loop, insts, limit, given = _demux_packed_with_tails()
+    eo, el = _streams(insts)
+    assert given == list(range(35))
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+@pytest.mark.gpu
+def test_demux_with_the_witness_queue_states_needs_no_device_seeding(zk):
+    from test_demux_host import demux_cs
+    outer, loop, insts, limit, given = _demux_packed_with_tails()
+    cs = demux_cs(limit)
+    cs.set_batch(len(insts))
+    cs.set_seed_given(given)
+    try:
+        d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+        cs.bind_inputs(False, d_o, outer.shape[0])
+        cs.bind_inputs(True, d_l, loop.shape[0])
+        cs.seed_carried_inputs(d_l)                      # every carried word is declared given: no kernel runs
+        assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
+        ok, f = cs.resolve_and_check()
+        assert ok, f
+        for i, inst in enumerate(insts):
+            assert cs.public_inputs(i) == inst["public_input"]
+        bad = loop.copy(); bad[7, 3] ^= 1                # a wrong tail word from the host: the circuit's own constraints reject it
+        d_b = zk.DeviceBuffer.from_numpy(bad)
+        cs.bind_inputs(True, d_b, bad.shape[0])
+        ok, f = cs.resolve_and_check()
+        assert not ok
+    finally:
+        cs.set_seed_given([])
+
+
 def test_sort_decommits_packer_equals_the_oracle_streams():
     from oracle import decommit_native as dn
     u, s = dn.random_decommits(np.random.default_rng(62), 5)
