@@ -62,6 +62,12 @@ void sort_and_deduplicate_code_decommittments_entry_point(CS& cs, uint32_t limit
     for (auto& t : obs_sorted.tail) fs_input.push_back(t.v);
     fs_input.push_back(obs_sorted.length.v);
     auto challenges = produce_fs_challenges<ENC + 1>(g, fs_input);
+    // native seeding (kernels_queue_seed.hpp: k_decommit_seed) once the host packer has written the integer state and the queue states
+    // of every cycle (zk_pack_sort_decommits_witness_tails): the accumulators are scans that read the challenges
+    cs.native_seed_kind = 8;
+    cs.native_seed_outer_vars.clear();
+    for (int r = 0; r < REPS; ++r)
+        for (int i = 1; i <= ENC; ++i) cs.native_seed_outer_vars.push_back(challenges[r][i]);
 
     Num one_num = g.num_const(1);
     std::array<Num, REPS> lhs0, rhs0;

@@ -2430,6 +2430,29 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
         dev_check(zkdev::launch_logq_seed(a, stream));
         return true;
     }
+    if (native_seed_kind == 8) {   // sort_decommittment_requests: all but the four accumulator words (1..4) from the host packer with tails
+        if (carries_store_.size() != 65 || native_seed_outer_vars.size() != 16) return false;
+        std::vector<uint32_t> need;
+        for (uint32_t w = 0; w < 65; ++w)
+            if (!(w >= 1 && w <= 4)) need.push_back(w);
+        if (!seed_words_given(need.data(), (uint32_t)need.size())) return false;
+        if (!d_state0_slot_) {
+            std::vector<uint32_t> slots(65, UINT32_MAX), ch;
+            for (auto& c : carries_store_)
+                if (c.word < 65 && c.has_first) slots[c.word] = c.first_outer_cell;
+            for (uint32_t sl : slots)
+                if (sl == UINT32_MAX) return false;
+            for (zk_var v : native_seed_outer_vars) ch.push_back(outer_.var_slot[var_index(v)]);
+            d_state0_slot_ = upload(slots);
+            d_native_outer_slots_ = upload(ch);
+        }
+        zkdev::LogqSeedArgs a;
+        a.kind = 2; a.with_chain = 0;
+        a.loop = dev_loop_inputs_rw; a.in_stride = la.in_stride; a.limit = limit_; a.n_instances = n;
+        a.outer_store = la.outer_cells; a.outer_n_store = la.outer_n_cells; a.state0_slot = d_state0_slot_; a.ch_slot = d_native_outer_slots_;
+        dev_check(zkdev::launch_logq_seed(a, stream));
+        return true;
+    }
     if (native_seed_kind == 3 || native_seed_kind == 4) {   // keccak256 / sha256 round function FSMs (kernels_fsm_seed.hpp)
         const uint32_t n_carried = native_seed_kind == 3 ? 423 : 60, n_words = native_seed_kind == 3 ? 507 : 112;
         if (carries_store_.size() != n_carried || loop_.n_input_words != n_words) return false;

@@ -333,4 +333,88 @@ __global__ __launch_bounds__(64) void k_tail4_chain(LogqSeedDev a) {
     }
 }
 
+// sort_decommittment_requests with the integer state and the queue states written by the host packer (zk_pack_sort_decommits_witness_tails):
+// left here are the two grand-product accumulators per repetition — a multiplicative scan over the popping cycles of
+// ch[r][8] + sum_i enc_i * ch[r][i] over DecommitQuery::encode of the unsorted / the sorted element (mod.rs:232-260, decommit_query/mod.rs:33-113).
+// Carried layout (circuits/sort_decommits.cpp): 0 previous_trivial, 1-2 lhs, 3-4 rhs, 17 unsorted length, items at 65 and 76.
+struct DecommitLayout { static constexpr u32 ACC = 1, U_LEN = 17, ITEM_U = 65, ITEM_S = 76; };
+__device__ __forceinline__ void decommit_encode(u64 enc[8], const u64* col, u64 stride, u32 first) {
+    u32 h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (u32)col[(u64)(first + i) * stride];
+    const u32 page = (u32)col[(u64)(first + 8) * stride], is_first = (u32)col[(u64)(first + 9) * stride], ts = (u32)col[(u64)(first + 10) * stride];
+    enc[0] = (u64)h[0] | ((u64)(page & 0xffffffu) << 32);
+    enc[1] = (u64)h[1] | ((u64)(page >> 24) << 32) | ((u64)(ts & 0xffffu) << 40);
+    enc[2] = (u64)h[2] | ((u64)(ts >> 16) << 32) | ((u64)(is_first & 1u) << 48);
+#pragma unroll
+    for (int i = 3; i < 8; ++i) enc[i] = h[i];
+}
+__device__ __forceinline__ void decommit_terms(u64 out[4], const u64* col, u64 stride, const u64 (*ch)[9]) {
+    u64 enc[8];
+    decommit_encode(enc, col, stride, DecommitLayout::ITEM_U);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        u64 t = ch[r][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t = gl::fma(enc[i], ch[r][i], t);
+        out[r] = t;
+    }
+    decommit_encode(enc, col, stride, DecommitLayout::ITEM_S);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        u64 t = ch[r][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t = gl::fma(enc[i], ch[r][i], t);
+        out[2 + r] = t;
+    }
+}
+__global__ __launch_bounds__(LOGQ_TPB) void k_decommit_seed(LogqSeedDev a) {
+    using L = DecommitLayout;
+    __shared__ u64 part[2][4][LOGQ_TPB];
+    __shared__ u64 ch[2][9];
+    const u32 inst = blockIdx.x, t = threadIdx.x;
+    const u64 lane0 = (u64)inst * a.limit;
+    if (t < 16) ch[t / 8][1 + t % 8] = ovq(a, inst, a.ch_slot[t]);
+    if (t < 2) ch[t][0] = 1;
+    __syncthreads();
+    const u32 per = (a.limit + LOGQ_TPB - 1) / LOGQ_TPB;
+    const u32 c_begin = min(t * per, a.limit), c_end = min(c_begin + per, a.limit);
+    u64 p[4] = {1, 1, 1, 1};
+    for (u32 c = c_begin; c < c_end; ++c) {
+        const u64* col = a.loop + lane0 + c;
+        if (col[(u64)L::U_LEN * a.in_stride] == 0) continue;
+        u64 f[4];
+        decommit_terms(f, col, a.in_stride, ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = gl::mul(p[j], f[j]);
+    }
+    int cur = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[0][j][t] = p[j];
+    __syncthreads();
+    for (u32 d = 1; d < LOGQ_TPB; d <<= 1) {
+        const int nxt = cur ^ 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[nxt][j][t] = t >= d ? gl::mul(part[cur][j][t], part[cur][j][t - d]) : part[cur][j][t];
+        cur = nxt;
+        __syncthreads();
+    }
+    u64 acc[4];   // lhs[0], lhs[1], rhs[0], rhs[1] before cycle c_begin
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u64 init = ovq(a, inst, a.state0_slot[L::ACC + j]);
+        acc[j] = t ? gl::mul(init, part[cur][j][t - 1]) : init;
+    }
+    for (u32 c = c_begin; c < c_end; ++c) {
+        u64* col = a.loop + lane0 + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) col[(u64)(L::ACC + j) * a.in_stride] = acc[j];
+        if (col[(u64)L::U_LEN * a.in_stride] == 0) continue;
+        u64 f[4];
+        decommit_terms(f, col, a.in_stride, ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = gl::mul(acc[j], f[j]);
+    }
+}
+
 }  // namespace zkq

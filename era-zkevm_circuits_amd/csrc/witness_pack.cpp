@@ -656,6 +656,76 @@ int zk_pack_sort_decommits_witness(const zk_sort_decommits_witness* w, uint32_t 
     return ZK_OK;
 }
 
+// The deduplicator with the queue states its own and its neighbour's witnesses hold: both input queues' witnesses are VecDeques of
+// (DecommitQuery, previous tail) (input.rs:110-124: FullStateCircuitQueueRawWitness) — the 12-word heads before each pop — and the
+// result queue is the decommitter's requests queue, whose witness holds the same pairs, i.e. the tail after every push here
+// (`result_tails[k]` = the tail after the k-th push of this instance's loop).  The integer state (previous key / record, first
+// timestamp, lengths, previous_trivial: mod.rs:264-345) is walked here; the four grand-product words (1..4) are the device's scans
+// (k_decommit_seed) because they need the Fiat-Shamir challenges the circuit derives.
+int zk_pack_sort_decommits_witness_tails(const zk_sort_decommits_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words,
+                                         const uint64_t* initial_previous_tails, const uint64_t* sorted_previous_tails, const uint64_t* result_tails, uint32_t n_result_tails) {
+    if (w && w->n_initial && (!initial_previous_tails || !sorted_previous_tails))
+        return bad(ZK_ERR_INVALID, "zk_pack_sort_decommits_witness_tails: null tails (use zk_pack_sort_decommits_witness and device seeding)");
+    if (n_result_tails && !result_tails) return bad(ZK_ERR_INVALID, "zk_pack_sort_decommits_witness_tails: null result tails");
+    if (int rc = zk_pack_sort_decommits_witness(w, limit, instance, batch, outer_words, loop_words)) return rc;
+    const zk_sort_decommits_fsm_witness& f = w->hidden_fsm_input;
+    const zk_full_queue_state_witness& oq = w->start_flag ? w->initial_queue_state : f.initial_queue_state;
+    const zk_full_queue_state_witness& sq0 = w->start_flag ? w->sorted_queue_initial_state : f.sorted_queue_state;
+    uint64_t o_head[12], s_head[12], r_tail[12] = {0};
+    uint64_t o_len = oq.length, s_len = sq0.length, r_len = 0;
+    uint32_t prev_key[9] = {0}, first_ts = 0;
+    zk_decommit_query_witness prev_record{};
+    for (int k = 0; k < 12; ++k) { o_head[k] = oq.head[k]; s_head[k] = sq0.head[k]; }
+    if (!w->start_flag) {
+        for (int k = 0; k < 12; ++k) r_tail[k] = f.final_queue_state.tail[k];
+        r_len = f.final_queue_state.length;
+        for (int i = 0; i < 9; ++i) prev_key[i] = f.previous_packed_key[i];
+        first_ts = f.first_encountered_timestamp; prev_record = f.previous_record;
+    }
+    bool prev_trivial = o_len == 0 || w->start_flag;
+    uint32_t next = 0, next_result = 0;
+    const zk_decommit_query_witness zero{};
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        const bool pops = o_len != 0 && next < w->n_initial;
+        if (pops) for (int k = 0; k < 12; ++k) { o_head[k] = initial_previous_tails[12 * (size_t)next + k]; s_head[k] = sorted_previous_tails[12 * (size_t)next + k]; }
+        l.w(prev_trivial ? 1 : 0);
+        for (int i = 0; i < 4; ++i) l.w(0);   // lhs / rhs: k_decommit_seed
+        l.arr(o_head); l.w(o_len); l.arr(s_head); l.w(s_len); l.arr(r_tail); l.w(r_len);
+        l.arr(prev_key); l.w(first_ts); put_decommit(l, &prev_record);
+        if (l.k != 65) return bad(ZK_ERR_INVALID, "internal: sort_decommits carried layout");
+        const zk_decommit_query_witness& s = pops ? w->sorted_queue_witness[next] : zero;
+        if (pops) {
+            ++next; --o_len; if (s_len) --s_len;
+            // the heads after the pop: the previous tails of the next elements, the queues' tails once empty, else what the FSM hands on
+            for (int k = 0; k < 12; ++k) {
+                o_head[k] = next < w->n_initial ? initial_previous_tails[12 * (size_t)next + k] : o_len == 0 ? oq.tail[k] : w->hidden_fsm_output.initial_queue_state.head[k];
+                s_head[k] = next < w->n_sorted ? sorted_previous_tails[12 * (size_t)next + k] : s_len == 0 ? sq0.tail[k] : w->hidden_fsm_output.sorted_queue_state.head[k];
+            }
+        }
+        bool same_hash = true;
+        for (int i = 0; i < 8; ++i) same_hash &= prev_record.code_hash[i] == s.code_hash[i];
+        if (!prev_trivial && !same_hash) {   // the previous record was the last of its hash: it goes to the result queue (mod.rs:318-333)
+            if (next_result >= n_result_tails) return bad(ZK_ERR_INVALID, "zk_pack_sort_decommits_witness_tails: fewer result tails than pushes");
+            for (int k = 0; k < 12; ++k) r_tail[k] = result_tails[12 * (size_t)next_result + k];
+            ++next_result; ++r_len;
+        }
+        prev_trivial = !pops;
+        if (!same_hash) first_ts = s.timestamp;
+        prev_record = s; prev_record.is_first = s.is_first ? 1 : 0;
+        prev_key[0] = s.timestamp;
+        for (int i = 0; i < 8; ++i) prev_key[1 + i] = s.code_hash[i];
+    }
+    return ZK_OK;
+}
+uint32_t zk_sort_decommits_given_words(uint32_t words[65]) {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < 65; ++i)
+        if (!(i >= 1 && i <= 4)) words[n++] = i;
+    return n;
+}
+
 int zk_pack_code_unpacker_witness(const zk_code_unpacker_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
     if (!w || !outer_words || !loop_words || !limit || instance >= batch) return bad(ZK_ERR_INVALID, "zk_pack_code_unpacker_witness: bad argument");
     if ((w->n_requests && !w->sorted_requests_queue_witness) || (w->n_code_words && !w->code_words)) return bad(ZK_ERR_INVALID, "zk_pack_code_unpacker_witness: null witness array");
@@ -706,6 +776,117 @@ int zk_pack_code_unpacker_witness(const zk_code_unpacker_witness* w, uint32_t li
     }
     (void)finished;
     return ZK_OK;
+}
+
+namespace {
+// FIPS 180-4 compression on the host: the packer with tails walks the decommitter's SHA-256 state natively (one compression per cycle)
+void sha256_compress_host(uint32_t st[8], const uint32_t block[16]) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74,
+        0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d,
+        0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e,
+        0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5,
+        0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    auto rr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = block[i];
+    for (int i = 16; i < 64; ++i)
+        w[i] = w[i - 16] + (rr(w[i - 15], 7) ^ rr(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (rr(w[i - 2], 17) ^ rr(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; ++i) {
+        const uint32_t t1 = h + (rr(e, 6) ^ rr(e, 11) ^ rr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+        const uint32_t t2 = (rr(a, 2) ^ rr(a, 13) ^ rr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+}  // namespace
+
+// The decommitter with the queue states its neighbours' witnesses hold: the requests queue's witness is a VecDeque of (DecommitQuery,
+// previous tail) (input.rs:134-140: FullStateCircuitQueueRawWitness) — the 12-word head before each pop — and the memory queue it
+// writes is the RAM permutation's unsorted queue, whose witness holds (MemoryQuery, previous tail) for every element, i.e. the tail
+// after every push here (`memory_tails[k]` = the tail after the k-th code word of this instance went in).  Everything else the loop
+// carries is integer state: the FSM's scalars and the SHA-256 inner state, one native compression per cycle (mod.rs:302-400).  All 74
+// carried words of every cycle are written: nothing to seed on the device.
+int zk_pack_code_unpacker_witness_tails(const zk_code_unpacker_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words,
+                                        const uint64_t* request_previous_tails, const uint64_t* memory_tails) {
+    if ((w && w->n_requests && !request_previous_tails) || (w && w->n_code_words && !memory_tails))
+        return bad(ZK_ERR_INVALID, "zk_pack_code_unpacker_witness_tails: null tails (use zk_pack_code_unpacker_witness and device seeding)");
+    if (int rc = zk_pack_code_unpacker_witness(w, limit, instance, batch, outer_words, loop_words)) return rc;
+    const zk_code_unpacker_fsm_witness& f = w->hidden_fsm_input;
+    static const uint32_t IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    uint32_t state[8] = {0}, hash_cmp[8] = {0}, index = 0, page = 0, timestamp = 0, length_in_bits = 0;
+    uint64_t rounds_left = 0, req_len, mem_len;
+    bool get, decommit, finished;
+    uint64_t req_head[12], req_tail[12], mem_tail[12];
+    const zk_full_queue_state_witness& rq = w->start_flag ? w->sorted_requests_queue_initial_state : f.decommittment_requests_queue_state;
+    const zk_full_queue_state_witness& mq = w->start_flag ? w->memory_queue_initial_state : f.memory_queue_state;
+    for (int k = 0; k < 12; ++k) { req_head[k] = rq.head[k]; req_tail[k] = rq.tail[k]; mem_tail[k] = mq.tail[k]; }
+    req_len = rq.length; mem_len = mq.length;
+    if (w->start_flag) { get = true; decommit = false; finished = false; }
+    else {
+        for (int i = 0; i < 8; ++i) { state[i] = f.sha256_inner_state[i]; hash_cmp[i] = f.hash_to_compare_against[i]; }
+        index = f.current_index; page = f.current_page; timestamp = f.timestamp; rounds_left = f.num_rounds_left; length_in_bits = f.length_in_bits;
+        get = f.state_get_from_queue; decommit = f.state_decommit; finished = f.finished;
+    }
+    uint32_t next_req = 0, next_word = 0;
+    const size_t lanes = (size_t)batch * limit;
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        const bool pops = get && req_len != 0;
+        if (pops) for (int k = 0; k < 12; ++k) req_head[k] = request_previous_tails[12 * (size_t)next_req + k];   // the head before this pop
+        for (int i = 0; i < 8; ++i) for (int k = 0; k < 4; ++k) l.w((state[i] >> (8 * k)) & 0xff);
+        l.arr(hash_cmp);
+        l.w(index); l.w(page); l.w(timestamp); l.w(rounds_left); l.w(length_in_bits); l.w(get ? 1 : 0); l.w(decommit ? 1 : 0); l.w(finished ? 1 : 0);
+        l.arr(req_head); l.w(req_len); l.arr(mem_tail); l.w(mem_len);
+        if (l.k != 74) return bad(ZK_ERR_INVALID, "internal: code_unpacker carried layout");
+        if (get) {
+            const zk_decommit_query_witness* req = nullptr;
+            if (pops) {
+                req = &w->sorted_requests_queue_witness[next_req++];
+                --req_len;
+                // the head after the pop: the previous tail of the next request, the queue's tail once it is empty, else what the FSM hands on
+                if (next_req < w->n_requests) for (int k = 0; k < 12; ++k) req_head[k] = request_previous_tails[12 * (size_t)next_req + k];
+                else if (req_len == 0) for (int k = 0; k < 12; ++k) req_head[k] = req_tail[k];
+                else for (int k = 0; k < 12; ++k) req_head[k] = w->hidden_fsm_output.decommittment_requests_queue_state.head[k];
+            }
+            const uint32_t top = req ? req->code_hash[7] : 0;
+            const uint32_t length_in_words = top & 0xffff;
+            rounds_left = ((uint64_t)length_in_words + 1) / 2;
+            length_in_bits = length_in_words * 256;
+            timestamp = req ? req->timestamp : 0; page = req ? req->page : 0;
+            for (int i = 0; i < 7; ++i) hash_cmp[i] = req ? req->code_hash[i] : 0;
+            hash_cmp[7] = 0;
+            index = 0;
+            for (int i = 0; i < 8; ++i) state[i] = IV[i];
+        }
+        decommit = decommit || get;
+        get = false;
+        if (decommit) rounds_left = (rounds_left - 1) & 0xffff;
+        const bool last_round = rounds_left == 0, finalize = last_round && decommit, second = !last_round && decommit;
+        uint32_t block[16] = {0};
+        for (int r = 0; r < 2; ++r) {
+            const bool take = r == 0 ? decommit : second;
+            if (!take) continue;
+            if (next_word < w->n_code_words) {
+                for (int i = 0; i < 8; ++i) block[8 * r + i] = w->code_words[next_word][7 - i];
+                for (int k = 0; k < 12; ++k) mem_tail[k] = memory_tails[12 * (size_t)next_word + k];
+                ++next_word;
+            } else return bad(ZK_ERR_INVALID, "zk_pack_code_unpacker_witness_tails: the code witness is shorter than the schedule (no tail for the push of a zero word)");
+            ++mem_len; ++index;
+        }
+        if (finalize) { block[8] = 0x80000000u; for (int i = 9; i < 15; ++i) block[i] = 0; block[15] = length_in_bits; }
+        if (decommit) sha256_compress_host(state, block);
+        const bool is_empty = req_len == 0;
+        finished = finished || (is_empty && finalize);
+        get = !is_empty && finalize;
+        decommit = second;
+    }
+    return ZK_OK;
+}
+uint32_t zk_code_unpacker_given_words(uint32_t words[74]) {
+    for (uint32_t i = 0; i < 74; ++i) words[i] = i;
+    return 74;
 }
 
 int zk_pack_linear_hasher_witness(const zk_linear_hasher_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words) {
@@ -817,6 +998,10 @@ int zk_decode_log_sorter_witness_bincode_tails(const uint8_t* bytes, size_t n_by
 
 int zk_decode_demux_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_demux_log_queue_witness* out, zk_log_query_witness* initial_buf, uint32_t initial_cap,
                                     size_t* consumed) {
+    return zk_decode_demux_witness_bincode_tails(bytes, n_bytes, out, initial_buf, initial_cap, nullptr, consumed);
+}
+int zk_decode_demux_witness_bincode_tails(const uint8_t* bytes, size_t n_bytes, zk_demux_log_queue_witness* out, zk_log_query_witness* initial_buf, uint32_t initial_cap,
+                                          uint64_t (*initial_tails)[4], size_t* consumed) {
     if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_demux_witness_bincode: null argument");
     Cursor c{bytes, n_bytes};
     std::memset(out, 0, sizeof *out);
@@ -829,7 +1014,7 @@ int zk_decode_demux_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_dem
         c.queue_state4(f->initial_log_queue_state);
         for (auto& q : f->output_queue_states) c.queue_state4(q);
     }
-    if (c.log_queue(initial_buf, initial_cap, out->n_initial, err)) out->initial_queue_witness = initial_buf;
+    if (c.log_queue(initial_buf, initial_cap, out->n_initial, err, initial_tails)) out->initial_queue_witness = initial_buf;
     return finish(c, err, consumed, "zk_decode_demux_witness_bincode: truncated, malformed or longer than the caller's buffer");
 }
 
@@ -851,11 +1036,11 @@ namespace {
 void decommit_query(Cursor& c, zk_decommit_query_witness& q) {   // DecommitQuery field order (decommit_query/mod.rs:22-29)
     c.u256(q.code_hash); q.page = c.u32(); q.is_first = c.boolean(); q.timestamp = c.u32();
 }
-bool decommit_queue(Cursor& c, zk_decommit_query_witness* buf, uint32_t cap, uint32_t& n_out, int& err) {
+bool decommit_queue(Cursor& c, zk_decommit_query_witness* buf, uint32_t cap, uint32_t& n_out, int& err, uint64_t (*tails)[12] = nullptr) {
     const uint64_t n = c.u64();
     if (!c.ok) return false;
     if (n > cap || (n && !buf)) { err = ZK_ERR_CAPACITY; return false; }
-    for (uint64_t i = 0; i < n && c.ok; ++i) { decommit_query(c, buf[i]); for (int t = 0; t < 12; ++t) c.field(); }
+    for (uint64_t i = 0; i < n && c.ok; ++i) { decommit_query(c, buf[i]); for (int t = 0; t < 12; ++t) { const uint64_t v = c.field(); if (tails) tails[i][t] = v; } }
     n_out = (uint32_t)n;
     return c.ok;
 }
@@ -941,6 +1126,11 @@ int zk_decode_keccak_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_ke
 
 int zk_decode_sort_decommits_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_sort_decommits_witness* out, zk_decommit_query_witness* initial_buf, uint32_t initial_cap,
                                              zk_decommit_query_witness* sorted_buf, uint32_t sorted_cap, size_t* consumed) {
+    return zk_decode_sort_decommits_witness_bincode_tails(bytes, n_bytes, out, initial_buf, initial_cap, sorted_buf, sorted_cap, nullptr, nullptr, consumed);
+}
+int zk_decode_sort_decommits_witness_bincode_tails(const uint8_t* bytes, size_t n_bytes, zk_sort_decommits_witness* out, zk_decommit_query_witness* initial_buf,
+                                                   uint32_t initial_cap, zk_decommit_query_witness* sorted_buf, uint32_t sorted_cap, uint64_t (*initial_tails)[12],
+                                                   uint64_t (*sorted_tails)[12], size_t* consumed) {
     if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_sort_decommits_witness_bincode: null argument");
     Cursor c{bytes, n_bytes};
     std::memset(out, 0, sizeof *out);
@@ -950,15 +1140,19 @@ int zk_decode_sort_decommits_witness_bincode(const uint8_t* bytes, size_t n_byte
     zk_full_queue_state_witness final_queue;   // observable_output.final_queue_state
     c.queue_state(final_queue);
     sort_decommits_fsm(c, out->hidden_fsm_input); sort_decommits_fsm(c, out->hidden_fsm_output);
-    if (decommit_queue(c, initial_buf, initial_cap, out->n_initial, err)) {
+    if (decommit_queue(c, initial_buf, initial_cap, out->n_initial, err, initial_tails)) {
         out->initial_queue_witness = initial_buf;
-        if (decommit_queue(c, sorted_buf, sorted_cap, out->n_sorted, err)) out->sorted_queue_witness = sorted_buf;
+        if (decommit_queue(c, sorted_buf, sorted_cap, out->n_sorted, err, sorted_tails)) out->sorted_queue_witness = sorted_buf;
     }
     return finish(c, err, consumed, "zk_decode_sort_decommits_witness_bincode: truncated, malformed or longer than the caller's buffers");
 }
 
 int zk_decode_code_unpacker_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_code_unpacker_witness* out, zk_decommit_query_witness* requests_buf, uint32_t requests_cap,
                                             uint32_t (*words_buf)[8], uint32_t words_cap, size_t* consumed) {
+    return zk_decode_code_unpacker_witness_bincode_tails(bytes, n_bytes, out, requests_buf, requests_cap, words_buf, words_cap, nullptr, consumed);
+}
+int zk_decode_code_unpacker_witness_bincode_tails(const uint8_t* bytes, size_t n_bytes, zk_code_unpacker_witness* out, zk_decommit_query_witness* requests_buf,
+                                                  uint32_t requests_cap, uint32_t (*words_buf)[8], uint32_t words_cap, uint64_t (*request_tails)[12], size_t* consumed) {
     if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_code_unpacker_witness_bincode: null argument");
     Cursor c{bytes, n_bytes};
     std::memset(out, 0, sizeof *out);
@@ -968,7 +1162,7 @@ int zk_decode_code_unpacker_witness_bincode(const uint8_t* bytes, size_t n_bytes
     zk_full_queue_state_witness final_memory;   // observable_output.memory_queue_final_state
     c.queue_state(final_memory);
     code_unpacker_fsm(c, out->hidden_fsm_input); code_unpacker_fsm(c, out->hidden_fsm_output);
-    if (decommit_queue(c, requests_buf, requests_cap, out->n_requests, err)) {
+    if (decommit_queue(c, requests_buf, requests_cap, out->n_requests, err, request_tails)) {
         out->sorted_requests_queue_witness = requests_buf;
         const uint64_t n_codes = c.u64();   // Vec<Vec<U256>>
         bool good = c.ok;

@@ -626,6 +626,8 @@ int launch_logq_seed(const LogqSeedArgs& v, void* stream) {
     } else if (v.kind == 1) {
         zkq::k_logq_seed<1><<<v.n_instances, zkq::LOGQ_TPB, 0, st>>>(a);
         if (v.with_chain) zkq::k_tail4_chain<1><<<v.n_instances, 64, 0, st>>>(a);
+    } else if (v.kind == 2) {   // sort_decommittment_requests: every queue state is the host's, the scans are here
+        zkq::k_decommit_seed<<<v.n_instances, zkq::LOGQ_TPB, 0, st>>>(a);
     } else return -1;
     return LAUNCH_CHECK("k_logq_seed");
 }

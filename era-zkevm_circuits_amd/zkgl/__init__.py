@@ -380,6 +380,31 @@ def pack_code_unpacker_witness(w, limit, instance, outer, loop):
     _pack(lib().zk_pack_code_unpacker_witness, w, limit, instance, outer, loop, 125, 101)
 
 
+def pack_sort_decommits_witness_tails(w, limit, instance, outer, loop, initial_previous_tails, sorted_previous_tails, result_tails):
+    """zk_pack_sort_decommits_witness_tails: integer state and queue states from the witness ([n, 12] u64 each); returns the given words
+    (all but the four grand-product words, which the device scans)"""
+    assert outer.shape[0] == 151 and loop.shape[0] == 87 and loop.shape[1] == outer.shape[1] * limit
+    ip = np.ascontiguousarray(initial_previous_tails, dtype=np.uint64); sp = np.ascontiguousarray(sorted_previous_tails, dtype=np.uint64)
+    rt = np.ascontiguousarray(result_tails, dtype=np.uint64).reshape(-1, 12)
+    _check(lib().zk_pack_sort_decommits_witness_tails(C.byref(w), limit, instance, outer.shape[1], outer.ctypes.data_as(C.c_void_p),
+                                                      loop.ctypes.data_as(C.c_void_p), ip.ctypes.data_as(C.c_void_p), sp.ctypes.data_as(C.c_void_p),
+                                                      rt.ctypes.data_as(C.c_void_p), rt.shape[0]))
+    words = (C.c_uint32 * 65)()
+    n = lib().zk_sort_decommits_given_words(words)
+    return list(words[:n])
+
+
+def pack_code_unpacker_witness_tails(w, limit, instance, outer, loop, request_previous_tails, memory_tails):
+    """zk_pack_code_unpacker_witness_tails: every carried word from the witness ([n, 12] u64 queue states); returns the given words"""
+    assert outer.shape[0] == 125 and loop.shape[0] == 101 and loop.shape[1] == outer.shape[1] * limit
+    rp = np.ascontiguousarray(request_previous_tails, dtype=np.uint64); mt = np.ascontiguousarray(memory_tails, dtype=np.uint64)
+    _check(lib().zk_pack_code_unpacker_witness_tails(C.byref(w), limit, instance, outer.shape[1], outer.ctypes.data_as(C.c_void_p),
+                                                     loop.ctypes.data_as(C.c_void_p), rp.ctypes.data_as(C.c_void_p), mt.ctypes.data_as(C.c_void_p)))
+    words = (C.c_uint32 * 74)()
+    n = lib().zk_code_unpacker_given_words(words)
+    return list(words[:n])
+
+
 class LinearHasherWitness(C.Structure):
     _fields_ = [("start_flag", C.c_uint8), ("completion_flag", C.c_uint8), ("queue_state", QueueStateWitness),
                 ("queue_witness", C.POINTER(LogQueryWitness)), ("n_queue", C.c_uint32)]
@@ -455,8 +480,12 @@ def log_sorter_given_words(w):
     return [int(arr[i]) for i in range(n)]
 
 
-def decode_demux_witness_bincode(data: bytes, max_elements: int):
-    return _decode_bincode(lib().zk_decode_demux_witness_bincode, DemuxLogQueueWitness(), data, [(LogQueryWitness * max(max_elements, 1))()])
+def decode_demux_witness_bincode(data: bytes, max_elements: int, keep_tails: bool = False):
+    """keep_tails: w._keep[-1] = the previous tail of every element ([n][4]), the input of pack_demux_witness_tails"""
+    n = max(max_elements, 1)
+    if keep_tails:
+        return _decode_bincode_tails(lib().zk_decode_demux_witness_bincode_tails, DemuxLogQueueWitness(), data, [(LogQueryWitness * n)()], [((C.c_uint64 * 4) * n)()])
+    return _decode_bincode(lib().zk_decode_demux_witness_bincode, DemuxLogQueueWitness(), data, [(LogQueryWitness * n)()])
 
 
 def decode_linear_hasher_witness_bincode(data: bytes, max_elements: int):
@@ -473,12 +502,21 @@ def decode_keccak_witness_bincode(data: bytes, max_requests: int, max_reads: int
                            [(LogQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_reads, 1))()])
 
 
-def decode_sort_decommits_witness_bincode(data: bytes, max_elements: int):
+def decode_sort_decommits_witness_bincode(data: bytes, max_elements: int, keep_tails: bool = False):
+    """keep_tails: w._keep[-2:] = the previous tails of the two queues' elements ([n][12] each), inputs of pack_sort_decommits_witness_tails"""
     n = max(max_elements, 1)
+    if keep_tails:
+        return _decode_bincode_tails(lib().zk_decode_sort_decommits_witness_bincode_tails, SortDecommitsWitness(), data,
+                                     [(DecommitQueryWitness * n)(), (DecommitQueryWitness * n)()], [((C.c_uint64 * 12) * n)(), ((C.c_uint64 * 12) * n)()])
     return _decode_bincode(lib().zk_decode_sort_decommits_witness_bincode, SortDecommitsWitness(), data, [(DecommitQueryWitness * n)(), (DecommitQueryWitness * n)()])
 
 
-def decode_code_unpacker_witness_bincode(data: bytes, max_requests: int, max_words: int):
+def decode_code_unpacker_witness_bincode(data: bytes, max_requests: int, max_words: int, keep_tails: bool = False):
+    """keep_tails: w._keep[-1] = the previous tail of every request ([n][12]), an input of pack_code_unpacker_witness_tails"""
+    if keep_tails:
+        return _decode_bincode_tails(lib().zk_decode_code_unpacker_witness_bincode_tails, CodeUnpackerWitness(), data,
+                                     [(DecommitQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_words, 1))()],
+                                     [((C.c_uint64 * 12) * max(max_requests, 1))()])
     return _decode_bincode(lib().zk_decode_code_unpacker_witness_bincode, CodeUnpackerWitness(), data,
                            [(DecommitQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_words, 1))()])
 

@@ -299,6 +299,17 @@ typedef struct zk_sort_decommits_witness {
 int zk_pack_sort_decommits_witness(const zk_sort_decommits_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                                    uint64_t *outer_words, uint64_t *loop_words);
 
+/* The same with the integer state and the queue states of every cycle written by the host (61 of the 65 carried words:
+ * zk_sort_decommits_given_words -> zk_cs_set_seed_given; the four grand-product words are a device scan, k_decommit_seed):
+ * `initial_previous_tails` / `sorted_previous_tails` [n][12] = the 12-word head of each input queue before each pop — the
+ * previous_tail the reference's FullStateCircuitQueueRawWitness holds beside every element (input.rs:110-124); `result_tails[k][12]` =
+ * the result queue's tail after the k-th push inside this instance's loop — the previous tails of the decommitter's requests queue
+ * witness.  ZK_ERR_INVALID when there are fewer result tails than pushes. */
+int zk_pack_sort_decommits_witness_tails(const zk_sort_decommits_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                                         uint64_t *outer_words, uint64_t *loop_words, const uint64_t *initial_previous_tails,
+                                         const uint64_t *sorted_previous_tails, const uint64_t *result_tails, uint32_t n_result_tails);
+uint32_t zk_sort_decommits_given_words(uint32_t words[65]);
+
 /* CodeDecommitterCircuitInstanceWitness, /root/reference/src/code_unpacker_sha256/input.rs:134-140 (internal FSM :23-34, FSM :61-65,
  * input data :80-83) */
 typedef struct zk_code_unpacker_fsm_witness {
@@ -326,6 +337,17 @@ typedef struct zk_code_unpacker_witness {
  * 74 carried words zeroed.  ZK_ERR_INVALID when the witness runs out of requests before the schedule does. */
 int zk_pack_code_unpacker_witness(const zk_code_unpacker_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                                   uint64_t *outer_words, uint64_t *loop_words);
+
+/* The same with every carried word written by the host (nothing to seed: zk_code_unpacker_given_words -> zk_cs_set_seed_given):
+ * `request_previous_tails[n_requests][12]` = the 12-word head of the requests queue before each pop — the previous_tail the reference's
+ * FullStateCircuitQueueRawWitness holds beside every element (input.rs:134-140); `memory_tails[n_code_words][12]` = the memory queue's
+ * tail after each code word of this instance was pushed — the previous tails of the RAM permutation's unsorted queue witness.  The
+ * FSM scalars and the SHA-256 inner state are walked natively (one compression per cycle).  ZK_ERR_INVALID when the code witness
+ * runs out before the schedule does (a pushed word without a tail). */
+int zk_pack_code_unpacker_witness_tails(const zk_code_unpacker_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                                        uint64_t *outer_words, uint64_t *loop_words, const uint64_t *request_previous_tails,
+                                        const uint64_t *memory_tails);
+uint32_t zk_code_unpacker_given_words(uint32_t words[74]);
 
 /* LinearHasherCircuitInstanceWitness, /root/reference/src/linear_hasher/input.rs:71-80 (input data :27-29; no FSM state) */
 typedef struct zk_linear_hasher_witness {
@@ -365,6 +387,11 @@ int zk_decode_log_sorter_witness_bincode_tails(const uint8_t *bytes, size_t n_by
                                                uint64_t (*initial_tails)[4], uint64_t (*sorted_tails)[4], size_t *consumed);
 int zk_decode_demux_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_demux_log_queue_witness *out,
                                     zk_log_query_witness *initial_buf, uint32_t initial_cap, size_t *consumed);
+/* the same, keeping the previous tail bincode carries beside every queue element ([initial_cap][4], caller's buffer): the input of
+ * zk_pack_demux_witness_tails */
+int zk_decode_demux_witness_bincode_tails(const uint8_t *bytes, size_t n_bytes, zk_demux_log_queue_witness *out,
+                                          zk_log_query_witness *initial_buf, uint32_t initial_cap, uint64_t (*initial_tails)[4],
+                                          size_t *consumed);
 int zk_decode_linear_hasher_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_linear_hasher_witness *out,
                                             zk_log_query_witness *queue_buf, uint32_t queue_cap, size_t *consumed);
 
@@ -384,6 +411,16 @@ int zk_decode_sort_decommits_witness_bincode(const uint8_t *bytes, size_t n_byte
 int zk_decode_code_unpacker_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_code_unpacker_witness *out,
                                             zk_decommit_query_witness *requests_buf, uint32_t requests_cap,
                                             uint32_t (*words_buf)[8], uint32_t words_cap, size_t *consumed);
+/* the same two, keeping the 12-word previous tail bincode carries beside every FullStateCircuitQueueRawWitness element (caller's
+ * buffers, one row per element): the inputs of zk_pack_sort_decommits_witness_tails / zk_pack_code_unpacker_witness_tails */
+int zk_decode_sort_decommits_witness_bincode_tails(const uint8_t *bytes, size_t n_bytes, zk_sort_decommits_witness *out,
+                                                   zk_decommit_query_witness *initial_buf, uint32_t initial_cap,
+                                                   zk_decommit_query_witness *sorted_buf, uint32_t sorted_cap,
+                                                   uint64_t (*initial_tails)[12], uint64_t (*sorted_tails)[12], size_t *consumed);
+int zk_decode_code_unpacker_witness_bincode_tails(const uint8_t *bytes, size_t n_bytes, zk_code_unpacker_witness *out,
+                                                  zk_decommit_query_witness *requests_buf, uint32_t requests_cap,
+                                                  uint32_t (*words_buf)[8], uint32_t words_cap, uint64_t (*request_tails)[12],
+                                                  size_t *consumed);
 
 #ifdef __cplusplus
 }

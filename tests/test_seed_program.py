@@ -40,4 +40,6 @@ def test_hash_fsm_keeps_its_byte_buffer_in_the_cone():
     cs.keccak256_round_function_entry_point(2)
     cs.pad_and_shrink()
     st = cs.stats()
-    assert 40000 < st["seed_ops"] < 50000 and st["loop_ops"] > 75000
+    # (round 4: the loop program carries Keccak-f as ONE macro-op, ZK_OP_KECCAK_F, so it is barely longer than the cone; what is left in
+    # both is the ByteBuffer muxing)
+    assert 40000 < st["seed_ops"] < 50000 and st["loop_ops"] > st["seed_ops"]

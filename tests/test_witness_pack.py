@@ -651,9 +651,86 @@ def test_sort_decommits_packer_equals_the_oracle_streams():
         zkgl.pack_sort_decommits_witness(w, limit, 0, outer, loop)
 
 
-def _code_unpacker_packed():
-    from oracle import code_unpacker_native as cn
-    from oracle.decommit_native import dq
+def _sort_decommits_packed_with_tails():
+    """a start instance that stops in the middle of the queues and the continuation that finishes them, packed with the queue states
+    the reference's witnesses hold"""
+    from oracle import decommit_native as dn, zko
+    u, s = dn.random_decommits(np.random.default_rng(65), 6, max_repeats=3)
+    limit = (len(u) + 3) // 2 + 1
+    a = dn.instance(u, s, limit)
+    b = dn.instance(a["rest"][0], a["rest"][1], limit, start_flag=False, fsm_in=a["fsm_out"], obs=a["obs"])
+    assert a["satisfiable"] and b["satisfiable"] and not a["completed"] and b["completed"]
+    insts, queues = [a, b], [(u, s), a["rest"]]
+    outer = np.zeros((151, 2), dtype=np.uint64); loop = np.full((87, 2 * limit), 9, dtype=np.uint64)
+    given = None
+    for i, (inst, (uq, sq)) in enumerate(zip(insts, queues)):
+        o = inst["outer"]
+        w = zkgl.SortDecommitsWitness()
+        w.start_flag, w.completion_flag = int(o[0]), int(inst["completed"])
+        w.initial_queue_state, w.sorted_queue_initial_state = _q12(o[1:26]), _q12(o[26:51])
+        f, x = w.hidden_fsm_input, o[51:151]
+        f.initial_queue_state, f.sorted_queue_state, f.final_queue_state = _q12(x[0:25]), _q12(x[25:50]), _q12(x[50:75])
+        f.lhs_accumulator[:] = x[75:77]; f.rhs_accumulator[:] = x[77:79]; f.previous_packed_key[:] = x[79:88]
+        f.first_encountered_timestamp = int(x[88]); f.previous_record = _dq(x[89:100])
+        fo = inst["fsm_out"]
+        w.hidden_fsm_output.initial_queue_state, w.hidden_fsm_output.sorted_queue_state = _q12(fo["initial"]), _q12(fo["sorted"])
+        uq, sq = uq[:limit], sq[:limit]                      # the elements this instance pops
+        ua = (zkgl.DecommitQueryWitness * max(len(uq), 1))(*[_dq(q) for q in uq])
+        sa = (zkgl.DecommitQueryWitness * max(len(sq), 1))(*[_dq(q) for q in sq])
+        w.initial_queue_witness, w.n_initial, w.sorted_queue_witness, w.n_sorted = ua, len(uq), sa, len(sq)
+        st_u = (o[1:26] if o[0] else x[0:25]); st_s = (o[26:51] if o[0] else x[25:50]); st_r = [0] * 25 if o[0] else x[50:75]
+        hu, hs, pu, ps = [int(v) for v in st_u[0:12]], [int(v) for v in st_s[0:12]], [], []
+        for q, r in zip(uq, sq):
+            pu.append(hu); ps.append(hs)
+            hu, hs = zko.queue_full_push(hu, dn.encode(q)), zko.queue_full_push(hs, dn.encode(r))
+        rt, rts = [int(v) for v in st_r[12:24]], []
+        # pushes inside the loop (a completed instance pushes its last record after it, mod.rs:347-360): previous record not
+        # trivial and its hash differs from the sorted element's
+        n_loop_pushes = sum(1 for r in inst["rows"] if not r[0] and r[54:62] != r[76:84])
+        for q in inst["result"][:n_loop_pushes]:
+            rt = zko.queue_full_push(rt, dn.encode(q))
+            rts.append(rt)
+        given = zkgl.pack_sort_decommits_witness_tails(w, limit, i, outer, loop, np.array(pu or [[0] * 12], dtype=np.uint64),
+                                                       np.array(ps or [[0] * 12], dtype=np.uint64), np.array(rts, dtype=np.uint64).reshape(-1, 12))
+    return outer, loop, insts, limit, given
+
+
+def test_sort_decommits_packer_with_the_witness_queue_states_leaves_only_the_grand_products():
+    """zk_pack_sort_decommits_witness_tails: 61 of the 65 carried words of every cycle equal the native restatement's; words 1..4 (the
+    grand-product accumulators, which need the circuit's challenges) stay for the device scan"""
+    outer, loop, insts, limit, given = _sort_decommits_packed_with_tails()
+    eo, el = _streams(insts)
+    assert given == [0] + list(range(5, 65))
+    el = el.copy(); el[1:5] = 0
+    assert np.array_equal(outer, eo)
+    assert np.array_equal(loop, el), np.argwhere(loop != el)[:8]
+
+
+@pytest.mark.gpu
+def test_sort_decommits_with_the_witness_queue_states_seeds_by_a_scan(zk):
+    from test_decommit_host import decommit_cs
+    outer, loop, insts, limit, given = _sort_decommits_packed_with_tails()
+    cs = decommit_cs(limit)
+    cs.set_batch(len(insts))
+    cs.set_seed_given(given)
+    try:
+        d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+        cs.bind_inputs(False, d_o, outer.shape[0])
+        cs.bind_inputs(True, d_l, loop.shape[0])
+        cs.seed_carried_inputs(d_l)                      # k_decommit_seed: the two grand products per repetition
+        _, el = _streams(insts)
+        assert np.array_equal(d_l.to_numpy().reshape(loop.shape), el)
+        ok, f = cs.resolve_and_check()
+        assert ok, f
+        for i, inst in enumerate(insts):
+            assert cs.public_inputs(i) == inst["public_input"]
+    finally:
+        cs.set_seed_given([])
+
+
+def _code_unpacker_packed(tails=False):
+    from oracle import code_unpacker_native as cn, zko
+    from oracle.decommit_native import dq, encode
     rng = np.random.default_rng(63)
     reqs = []
     for k, n in enumerate((1, 5, 3)):
@@ -682,7 +759,25 @@ def _code_unpacker_packed():
         for dst, v in zip(wa, words):
             dst[:] = [(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
         w.sorted_requests_queue_witness, w.n_requests, w.code_words, w.n_code_words = qa, len(rq), wa, len(words)
-        zkgl.pack_code_unpacker_witness(w, limit, i, outer, loop)
+        if not tails:
+            zkgl.pack_code_unpacker_witness(w, limit, i, outer, loop)
+            continue
+        # what the reference's witnesses hold beside the elements: the requests queue's head before every pop, the memory queue's
+        # tail after every push (= the previous tails of the RAM permutation's unsorted queue witness)
+        start = o[1:26] if o[0] else x[24:49]
+        head, prev = [int(v) for v in start[0:12]], []
+        for q, _ in rq:
+            prev.append(head)
+            head = zko.queue_full_push(head, encode(q))
+        mt, mtails = [int(v) for v in (o[26:51] if o[0] else x[49:74])[12:24]], []
+        for m in inst["pushed"]:
+            mt = zko.queue_full_push(mt, zko.memory_query_encode(m))
+            mtails.append(mt)
+        w.code_words, w.n_code_words = wa, len(inst["pushed"])      # the words this instance consumes
+        w.hidden_fsm_output.decommittment_requests_queue_state = _q12(inst["fsm_out"]["req"])
+        given = zkgl.pack_code_unpacker_witness_tails(w, limit, i, outer, loop, np.array(prev or [[0] * 12], dtype=np.uint64),
+                                                      np.array(mtails or [[0] * 12], dtype=np.uint64))
+        assert given == list(range(74))
     return outer, loop, insts, limit
 
 
@@ -693,6 +788,40 @@ def test_code_unpacker_packer_walks_the_fsm_schedule():
     eo, el = _streams(insts)
     el = el.copy(); el[0:74] = 0
     assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+def test_code_unpacker_packer_with_the_witness_queue_states_writes_every_carried_word():
+    """zk_pack_code_unpacker_witness_tails: FSM scalars and the SHA-256 state walked natively, queue states taken from the witness — the
+    stream equals the native restatement's in all 101 words of every cycle"""
+    outer, loop, insts, limit = _code_unpacker_packed(tails=True)
+    eo, el = _streams(insts)
+    assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+
+
+@pytest.mark.gpu
+def test_code_unpacker_with_the_witness_queue_states_needs_no_device_seeding(zk):
+    from test_code_unpacker_host import unpacker_cs
+    outer, loop, insts, limit = _code_unpacker_packed(tails=True)
+    cs = unpacker_cs(limit)
+    cs.set_batch(len(insts))
+    cs.set_seed_given(list(range(74)))
+    try:
+        d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+        cs.bind_inputs(False, d_o, outer.shape[0])
+        cs.bind_inputs(True, d_l, loop.shape[0])
+        cs.seed_carried_inputs(d_l)
+        assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
+        ok, f = cs.resolve_and_check()
+        assert ok, f
+        for i, inst in enumerate(insts):
+            assert cs.public_inputs(i) == inst["public_input"]
+        bad = loop.copy(); bad[3, 2] ^= 1                # a wrong byte of the SHA state from the host: the links reject it
+        d_b = zk.DeviceBuffer.from_numpy(bad)
+        cs.bind_inputs(True, d_b, bad.shape[0])
+        ok, f = cs.resolve_and_check()
+        assert not ok
+    finally:
+        cs.set_seed_given([])
 
 
 @pytest.mark.gpu
@@ -866,6 +995,8 @@ def test_log_sorter_demux_linear_hasher_bincode_round_trips():
     outer = np.zeros((73, 2), dtype=np.uint64); loop = np.full((71, 2 * limit), 9, dtype=np.uint64)
     zkgl.pack_demux_witness(d, limit, 0, outer, loop)
     assert np.array_equal(outer[:, 0], pouter[:, 0]) and np.array_equal(loop[:, :limit], ploop[:, :limit])
+    d, used = zkgl.decode_demux_witness_bincode(data, limit, keep_tails=True)   # the previous tails bincode carries beside the elements
+    assert used == len(data) and all(list(d._keep[-1][i]) == [1000 + 4 * i + t for t in range(4)] for i in range(n))
     # linear_hasher
     from oracle.storage_native import log_query
     rng = np.random.default_rng(73)
@@ -1026,6 +1157,11 @@ def test_sort_decommits_and_code_unpacker_bincode_round_trips():
     assert all(bytes(d.initial_queue_witness[i]) == bytes(ia[i]) and bytes(d.sorted_queue_witness[i]) == bytes(sa[i]) for i in range(n))
     with pytest.raises(zkgl.ZkError):
         zkgl.decode_sort_decommits_witness_bincode(data, n - 1)
+    # ..._tails keeps the 12-word previous tail bincode carries beside every element (the inputs of the packers with tails)
+    d, used = zkgl.decode_sort_decommits_witness_bincode(data, n, keep_tails=True)
+    it, st = d._keep[-2], d._keep[-1]
+    assert used == len(data) and all(list(it[i]) == [77 + 12 * i + t for t in range(12)] and list(st[i]) == list(it[i]) for i in range(n))
+    assert all(bytes(d.sorted_queue_witness[i]) == bytes(sa[i]) for i in range(n))
     # code_unpacker_sha256: bytes of the start instance of _code_unpacker_packed -> decode -> pack == the oracle's streams
     from oracle import code_unpacker_native as cn
     outer, loop, insts, limit = _code_unpacker_packed()
@@ -1051,6 +1187,8 @@ def test_sort_decommits_and_code_unpacker_bincode_round_trips():
     assert np.array_equal(o2[:, 0], outer[:, 0]) and np.array_equal(l2[:, :limit], loop[:, :limit])
     with pytest.raises(zkgl.ZkError):
         zkgl.decode_code_unpacker_witness_bincode(data, len(reqs), len(words) - 1)
+    d, used = zkgl.decode_code_unpacker_witness_bincode(data, len(reqs), len(words), keep_tails=True)
+    assert used == len(data) and all(list(d._keep[-1][i]) == [0] * 12 for i in range(len(reqs)))
 
 
 # ---------------------------------------------------------------- a byte vector NOT written by this file's writer

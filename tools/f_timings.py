@@ -34,13 +34,18 @@ def timed(name, cs, insts, carried, limit):
     st = cs.stats()
     # the same instances with every carried word written by the host packer from the witness's queue states (demux: zk_pack_demux_witness_tails)
     given_ms = None
-    if os.environ.get("F_GIVEN", "1") == "1" and name == "demux_log_queue":
-        cs.set_seed_given(list(range(carried)))
-        d_g = zkgl.DeviceBuffer.from_numpy(loop); cs.bind_inputs(True, d_g, loop.shape[0])
+    # (demux, code_unpacker: all words; sort_decommits: all but the four grand-product words, which k_decommit_seed scans)
+    if os.environ.get("F_GIVEN", "1") == "1" and name != "linear_hasher":
+        device_words = [1, 2, 3, 4] if name == "sort_decommittment_requests" else []
+        cs.set_seed_given([w for w in range(carried) if w not in device_words])
+        part = loop.copy(); part[device_words] = 0
+        d_g = zkgl.DeviceBuffer.from_numpy(part); cs.bind_inputs(True, d_g, part.shape[0]); cs.seed_carried_inputs(d_g); zkgl.sync()
+        d_g = zkgl.DeviceBuffer.from_numpy(part); cs.bind_inputs(True, d_g, part.shape[0])
         t0 = time.perf_counter(); cs.seed_carried_inputs(d_g); zkgl.sync(); given_ms = round(1e3 * (time.perf_counter() - t0), 3)
+        assert np.array_equal(d_g.to_numpy().reshape(loop.shape), loop)
         ok, f = cs.resolve_and_check(); assert ok, f
         cs.set_seed_given([])
-    print(json.dumps({"circuit": name, "seed_ms_all_carried_words_given": given_ms, "instances": len(insts), "limit": limit, "rows_per_instance": st["rows_per_instance"], "seed_ms": round(1e3 * t_seed, 2),
+    print(json.dumps({"circuit": name, "seed_ms_queue_states_from_the_witness": given_ms, "instances": len(insts), "limit": limit, "rows_per_instance": st["rows_per_instance"], "seed_ms": round(1e3 * t_seed, 2),
                       "step_ms": round(1e3 * dt, 2), "seeded_equals_native": same, "seed_ops": st["seed_ops"], "loop_ops": st["loop_ops"]}), flush=True)
 
 
