@@ -1431,6 +1431,15 @@ void CS::emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool co
             for (size_t q = 1; q < s.ops[oi].ins.size(); ++q) operand_v2(s, s.ops[oi], q, out);
         return;
     }
+    if (first.opcode == ZK_OP_SELECT && plane_of_ && (*plane_of_)[first.ins[0].idx] != UINT32_MAX) {   // flags from the bit planes
+        out.push_back((uint32_t)ZK_OP_SELECT | (1u << 8) | ((uint32_t)(n - 1) << 16));
+        for (size_t oi : group) {
+            out.push_back((*plane_of_)[s.ops[oi].ins[0].idx]);
+            operand_v2(s, s.ops[oi], 1, out);
+            operand_v2(s, s.ops[oi], 2, out);
+        }
+        return;
+    }
     out.push_back((uint32_t)first.opcode | ((uint32_t)first.a << 8) | ((counted ? (uint32_t)(n - 1) : (uint32_t)first.b) << 16));
     if (first.opcode == ZK_OP_NN_MULMOD) {
         // fixed layout: 16 modulus limbs, 17 A slots, 17 B slots (unused ones 0): static word positions for the kernel's scalar fetches
@@ -1498,6 +1507,26 @@ void CS::emit_scope(Scope& s) {
         std::vector<uint32_t> produced_in_group(s.n_vars, UINT32_MAX);  // var -> id of the open group that produces it
         uint32_t group_id = 0, slots_done = 0;
         std::vector<size_t> group;  // op indices of the open group
+        // SELECT flags as bit planes (plain loop kernels: ZK_OP_FLAG_PLANES, kernels_engine2.hpp): the FLAG_PLANES most used flag
+        // variables of a loop scope get a plane id; a flag is copied into its plane by a ZK_OP_FLAG_PLANES op emitted lazily, in
+        // front of the first SELECT that needs it, together with every other flag produced by then (up to 7 per op)
+        std::vector<uint32_t> plane_of(s.n_vars, UINT32_MAX);
+        std::vector<uint8_t> plane_saved(s.n_vars, 0);
+        std::vector<uint32_t> plane_pending;   // produced, not yet copied
+        const char* fp_env = getenv("ZKGL_FLAG_PLANES");
+        const bool planes_on = v2 && s.is_loop && !(fp_env && fp_env[0] == '0');
+        if (planes_on) {
+            std::vector<uint32_t> uses(s.n_vars, 0);
+            for (auto& op : s.ops)
+                if (!op.seed_only && op.opcode == ZK_OP_SELECT && op.ins[0].kind == Operand::VAR) ++uses[op.ins[0].idx];
+            std::vector<uint32_t> order;
+            for (uint32_t v = 0; v < s.n_vars; ++v) if (uses[v] >= 2) order.push_back(v);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return uses[x] > uses[y]; });
+            if (order.size() > zkdev::FLAG_PLANES) order.resize(zkdev::FLAG_PLANES);
+            for (uint32_t k = 0; k < order.size(); ++k) plane_of[order[k]] = k;
+            s.flag_planes = (uint32_t)order.size();
+        }
+        plane_of_ = planes_on ? &plane_of : nullptr;
         auto operand = [&](const OpRec& op, size_t pos) {
             const Operand& in = op.ins[pos];
             if (v2) { operand_v2(s, op, pos, out); return; }
@@ -1545,11 +1574,32 @@ void CS::emit_scope(Scope& s) {
             if (joins)
                 for (auto& in : op.ins)
                     if (in.kind == Operand::VAR && produced_in_group[in.idx] == group_id) { joins = false; break; }
+            if (planes_on && op.opcode == ZK_OP_SELECT) {
+                const uint32_t fv = op.ins[0].idx;
+                const bool mine = plane_of[fv] != UINT32_MAX;
+                // a group is homogeneous: plane flags or slot flags
+                if (joins && ((plane_of[s.ops[group[0]].ins[0].idx] != UINT32_MAX) != mine)) joins = false;
+                if (mine && !plane_saved[fv]) {
+                    flush();   // the flag's producer may sit in the open group
+                    joins = false;
+                    for (size_t at = 0; at < plane_pending.size(); at += 7) {
+                        const size_t nn = std::min<size_t>(7, plane_pending.size() - at);
+                        out.push_back((uint32_t)ZK_OP_FLAG_PLANES | ((uint32_t)(nn - 1) << 16));
+                        for (size_t k = 0; k < nn; ++k) { out.push_back(s.var_slot[plane_pending[at + k]]); out.push_back(plane_of[plane_pending[at + k]]); plane_saved[plane_pending[at + k]] = 1; }
+                    }
+                    plane_pending.clear();
+                    if (!plane_saved[fv]) throw ZkError(ZK_ERR_INVALID, "internal: SELECT flag not produced before its use");
+                }
+            }
             if (!joins) flush();
             group.push_back(oi);
-            for (uint32_t ov : op.outs) produced_in_group[ov] = group_id;
+            for (uint32_t ov : op.outs) {
+                produced_in_group[ov] = group_id;
+                if (planes_on && plane_of[ov] != UINT32_MAX) plane_pending.push_back(ov);
+            }
         }
         flush();
+        plane_of_ = nullptr;
         if (!s.is_loop && s.pre_ops >= s.ops.size()) { (v2 ? s.pre_words2 : s.pre_words) = (uint32_t)out.size(); if (v2) s.pre_slots = slots_done; }
         if (!s.is_loop && s.side_ops >= s.ops.size()) { (v2 ? s.side_words2 : s.side_words) = (uint32_t)out.size(); if (v2) s.side_slots = slots_done; }
     }

@@ -103,6 +103,7 @@ struct Scope {
     // lookup sites by table for k_multiplicities: 3 key slots per site; site_off[table id] .. site_off[table id + 1]
     std::vector<uint32_t> mult_sites, mult_site_off;
     uint32_t pre_words2 = 0, side_words2 = 0, pre_slots = 0, side_slots = 0;
+    uint32_t flag_planes = 0;   // SELECT flags the plain loop kernel keeps as bit planes in LDS (emit_scope)
     // VARIABLE STORE: the witness kernels keep ONE value per variable, in a dense store indexed by production order
     // (store[((lane >> 6) * n_store + slot) * 64 + (lane & 63)]): a wave streams its results out sequentially and reads its
     // operands from recently written, nearby slots (TLB / L2 locality), and a VM instance needs 4x less memory than its trace.
@@ -307,6 +308,7 @@ class CS {
     bool inline_multiplicities() const;
     void operand_v2(const Scope& s, const OpRec& op, size_t pos, std::vector<uint32_t>& out) const;
     void emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool counted, std::vector<uint32_t>& out) const;
+    const std::vector<uint32_t>* plane_of_ = nullptr;   // emit_scope, v2 form of a loop scope: variable -> SELECT flag plane id (UINT32_MAX: none)
     void upload_scope(Scope& s);
     void ensure_uploaded();
     void free_scope_device(Scope& s);

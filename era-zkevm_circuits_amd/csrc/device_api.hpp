@@ -57,6 +57,8 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
 #define ZKGL_STRANDS_PER_TILE 16
 #endif
 constexpr uint32_t STRANDS_PER_TILE = ZKGL_STRANDS_PER_TILE;
+// SELECT flags kept as per-wavefront bit planes in LDS by the plain loop kernels (ZK_OP_FLAG_PLANES): plane ids per scope
+constexpr uint32_t FLAG_PLANES = 256;
 // the seeding kernels keep 8: a seeding pass is a latency chain per instance and its throughput is the number of resident blocks
 // (2048 instances: 2.5 s with 8-wave blocks, 3.6 s with 16-wave blocks)
 constexpr uint32_t SEED_STRANDS_PER_TILE = 8;

@@ -221,9 +221,16 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #endif
     };
 
+    // SELECT flags as bit planes (ZK_OP_FLAG_PLANES; plain kernels, loop scope): [wavefront of the block][0: != 0, 1: > 1][plane id]
+    __shared__ uint64_t flag_planes[STRANDS ? 1 : (BLOCK / 64) * 2 * zkdev::FLAG_PLANES];
+    uint64_t* const planes = flag_planes + (STRANDS ? 0 : uni(threadIdx.x >> 6) * 2 * zkdev::FLAG_PLANES);
+    // (this lane's index in its wavefront is recomputed where used — two mbcnt — rather than held in a VGPR across the interpreter loop)
+    auto wave_lane_now = [] { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };
+
     constexpr uint32_t D = STRANDS ? 1 : 0;  // destination words per op
     auto out_to = [&](uint32_t slot) { if constexpr (STRANDS) dst = WIDE ? slot : slot << bsh; };
     uint32_t pc = word_begin;
+    uint32_t nonbool_seen = 0;   // uniform: some flag copied into a plane held a value > 1 in some lane (never, on a satisfiable witness)
     bool fused_bad = false;   // fused mode: a gate evaluated here (SELECT's exception, a lookup miss) is violated; reported once, below
     while (pc < word_end) {
         const u32x16_a4 W = *(prog16_ptr)(prog + pc);  // s_load_dwordx16: header + up to 15 operand words (host pads the program)
@@ -302,7 +309,55 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             pc += 9 + D;
             st(r);
         } break;
-        case ZK_OP_SELECT: {
+        case ZK_OP_FLAG_PLANES: if constexpr (!STRANDS) {
+            const uint32_t n = pb + 1;
+            uint64_t v[7];
+#pragma unroll
+            for (uint32_t k = 0; k < 7; ++k) if (k < n) v[k] = ldv(W[1 + 2 * k]);
+            pc += 1 + 2 * n;
+#pragma unroll
+            for (uint32_t k = 0; k < 7; ++k)
+                if (k < n) {
+                    const uint64_t m = __ballot(v[k] != 0), nb = __ballot(v[k] > 1);
+                    if (wave_lane_now() == 0) { planes[W[2 + 2 * k]] = m; planes[zkdev::FLAG_PLANES + W[2 + 2 * k]] = nb; }
+                    nonbool_seen |= (uint32_t)(nb != 0);
+                }
+        } break;
+        case ZK_OP_SELECT: if (!STRANDS && pa == 1) {
+            // flags from the bit planes.  A wavefront whose lanes agree on a flag loads the selected operand twice (the second load hits
+            // the line the first one brought) instead of both: no branch, no fetch of the branch nobody takes.
+            auto body = [&](auto n_) {
+                constexpr uint32_t N = decltype(n_)::value;
+                uint64_t a[N], b[N];
+                const uint32_t wave_lane = wave_lane_now();
+                uint32_t fbits = 0;   // this lane's flag of member g in bit g
+                uint64_t mv[N];
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) mv[g] = planes[W[1 + g * 3]];   // all plane reads in flight before the first wait
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) {
+                    const uint32_t mlo = uni((uint32_t)mv[g]), mhi = uni((uint32_t)(mv[g] >> 32));
+                    fbits |= (uint32_t)((mv[g] >> wave_lane) & 1) << g;
+                    const uint32_t sa = W[1 + g * 3 + 1], sb = W[1 + g * 3 + 2];
+                    a[g] = ldv((mlo | mhi) == 0 ? sb : sa);
+                    b[g] = ldv(((mlo & mhi) == ~0u && !nonbool_seen) ? sa : sb);
+                }
+                pc += 1 + N * 3;
+#pragma unroll
+                for (uint32_t g = 0; g < N; ++g) st(((fbits >> g) & 1) ? a[g] : b[g]);
+                if (nonbool_seen) {   // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ
+#pragma unroll
+                    for (uint32_t g = 0; g < N; ++g) fused_bad |= ((planes[zkdev::FLAG_PLANES + W[1 + g * 3]] >> wave_lane) & 1) && a[g] != b[g];
+                }
+            };
+            switch (pb) {
+            case 0: body(GroupSize<1>{}); break;
+            case 1: body(GroupSize<2>{}); break;
+            case 2: body(GroupSize<3>{}); break;
+            case 3: body(GroupSize<4>{}); break;
+            default: body(GroupSize<5>{}); break;
+            }
+        } else {
             auto body = [&](auto n_) {
                 constexpr uint32_t N = decltype(n_)::value;
                 uint64_t in[N][3];

@@ -85,6 +85,12 @@ enum zk_opcode {
                               * compression (message schedule, 64 rounds, feed-forward), in the order of csrc/sha256_macro.hpp zks::compress
                               *                                                               (round_function_over_uint32,
                               * /root/reference/src/sha256_round_function/mod.rs:271-285) */
+    /* plain device programs of a loop scope only (never recorded, never exported; cs.cpp emit_scope): b = n - 1; n x [store slot,
+     * plane id] -> nothing.  Copies n values the program later uses as SELECT flags into per-wavefront BIT PLANES in LDS (bit l of
+     * plane id = value of lane l != 0; a second plane = value > 1, for the fused SelectionGate check).  A ZK_OP_SELECT with a = 1
+     * carries plane ids instead of flag slots: 8 bytes from LDS instead of 512 from L2 / HBM, and a wavefront whose 64 lanes agree
+     * on the flag loads only the selected operand. */
+    ZK_OP_FLAG_PLANES = 28,
     ZK_OP__COUNT
 };
 

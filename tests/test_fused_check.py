@@ -110,3 +110,98 @@ def test_one_bit_split_keeps_the_range_check_of_its_residual(zk, monkeypatch, ve
         ok, f = run(cs, bad, monkeypatch, verify_stored)
         assert not ok and f.instance == inst and f.kind == G["BOOLEAN"], (value, ok, f)
         assert cs.public_inputs(inst) == [value >> 3]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# SELECT flags as bit planes (round 4: ZK_OP_FLAG_PLANES, the plain loop kernels): a flag several SELECTs of a loop body share is read
+# from an LDS bit plane; a wavefront whose 64 lanes agree on it loads only the selected operand.  Same values and the same verdicts as
+# the slot form (ZKGL_FLAG_PLANES=0) and as the stored mode — including the selector that is not 0 / 1.
+def build_loop_selects(limit=3):
+    from zkgl import LINK
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(40, 0, 8, 4))
+    for k in ("CONST", "BOOLEAN", "FMA", "REDUCTION4", "SELECT", "ZEROCHECK", "PUBLIC_INPUT"):
+        cs.allow_gate(G[k])
+    r = Rec(cs)
+    start = r.inp()
+    cs.loop_begin(limit)
+    r.n_in = 0
+    acc_in = r.inp()
+    cs.link(LINK["FIRST"], acc_in, start)
+    s, t = r.inp(), r.inp()                      # two selectors the circuit does not constrain to 0 / 1
+    xs = [r.inp() for _ in range(6)]
+    outs = []
+    for k in range(3):                             # s is the flag of three SELECTs, t of two: both get a plane
+        v = cs.alloc_variable_without_value()
+        cs.emit_op(OP["SELECT"], [s, xs[2 * k], xs[2 * k + 1]], [v])
+        cs.place_gate(G["SELECT"], [xs[2 * k], xs[2 * k + 1], s, v])
+        outs.append(v)
+    for k in range(2):
+        v = cs.alloc_variable_without_value()
+        cs.emit_op(OP["SELECT"], [t, outs[k], outs[k + 1]], [v])
+        cs.place_gate(G["SELECT"], [outs[k], outs[k + 1], t, v])
+        outs.append(v)
+    acc = acc_in
+    for v in outs:
+        acc = r.fma(1, v, acc, 1, acc)
+    cs.link(LINK["CARRY"], acc_in, acc)
+    n_loop = r.n_in
+    cs.loop_end()
+    fin = cs.loop_last(acc)
+    cs.place_gate(G["PUBLIC_INPUT"], [fin])
+    cs.pad_and_shrink()
+    return cs, n_loop
+
+
+def _model(start, rows):
+    P = zkgl.P
+    acc = start
+    for (_, s, t, *xs) in rows:
+        o = [xs[2 * k] if s else xs[2 * k + 1] for k in range(3)]
+        o += [o[0] if t else o[1]]
+        o += [o[1] if t else o[2]]
+        for v in o:
+            acc = (v * acc + acc) % P
+    return acc
+
+
+@pytest.mark.parametrize("planes", ["1", "0"])
+@pytest.mark.parametrize("verify_stored", [False, True])
+def test_select_flags_from_bit_planes_equal_the_slot_form(zk, monkeypatch, verify_stored, planes):
+    monkeypatch.setenv("ZKGL_FLAG_PLANES", planes)
+    monkeypatch.setenv("ZKGL_STRANDS", "0")          # the plain loop kernel (the strand form keeps slot flags)
+    if verify_stored:
+        monkeypatch.setenv("ZKGL_VERIFY_STORED", "1")
+    else:
+        monkeypatch.delenv("ZKGL_VERIFY_STORED", raising=False)
+    limit = 3
+    cs, n_loop = build_loop_selects(limit)
+    B = 100                                         # 300 lanes: four full wavefronts + a tail
+    rng = np.random.default_rng(9)
+    outer = rng.integers(1, 1 << 30, size=(1, B), dtype=np.uint64)
+    loop = rng.integers(0, 1 << 32, size=(n_loop, B * limit), dtype=np.uint64)
+    loop[1] = rng.integers(0, 2, B * limit); loop[2] = rng.integers(0, 2, B * limit)
+    loop[1, :64] = 0; loop[2, :64] = 1              # wavefront 0: both flags uniform (s all zero, t all one)
+    loop[1, 64:128] = 1                             # wavefront 1: s all one, t mixed
+
+    def run(lp):
+        cs.set_batch(B)
+        d_o, d_l = zkgl.DeviceBuffer.from_numpy(outer), zkgl.DeviceBuffer.from_numpy(lp)
+        cs.bind_inputs(False, d_o, 1); cs.bind_inputs(True, d_l, n_loop)
+        cs.seed_carried_inputs(d_l)
+        return cs.resolve_and_check()
+
+    ok, f = run(loop.copy())
+    assert ok, f
+    for i in (0, 21, 22, 42, B - 1):
+        rows = [[int(x) for x in loop[:, i * limit + c]] for c in range(limit)]
+        assert cs.public_inputs(i) == [_model(int(outer[0, i]), rows)]
+    # selector 2 with different branches in a lane of the uniform-one wavefront: op and gate disagree -> rejected in both modes
+    bad = loop.copy(); bad[1, 70] = 2; bad[3, 70] = 5; bad[4, 70] = 6
+    ok, f = run(bad)
+    assert not ok and f.kind == G["SELECT"] and f.instance == 70 // limit
+    # selector 2 with EQUAL branches everywhere it is used satisfies the gate: accepted in both modes
+    fine = loop.copy(); fine[1, 70] = 2
+    for k in range(3):
+        fine[3 + 2 * k, 70] = 11; fine[4 + 2 * k, 70] = 11
+    ok, f = run(fine)
+    assert ok, f
