@@ -1130,6 +1130,23 @@ void CS::schedule_loop_ops() {
 // FETCH_SIZE agrees); this order leaves 6.6 k.  A window of 16 touches is the flat optimum of the model (12..20: 6.6-6.8 k; 8: 7.4 k,
 // 48: 8.2 k) and of the kernel (B=384, one box: recording order 43.5 ms, windows 8 / 16 / 48: 42.2 / 40.0 / 42.9 ms).  Weighting misses,
 // a last-consumer bonus or a larger group bonus change the model by < 2 %.
+// SELECT flags the plain loop kernel keeps as bit planes (ZK_OP_FLAG_PLANES): the FLAG_PLANES most used flag variables of a loop scope
+// that at least two SELECTs read.  One rule for the scheduler (such a read costs no operand fetch) and for emit_scope (the plane ids).
+std::vector<uint32_t> CS::select_plane_vars(const Scope& s) const {
+    std::vector<uint32_t> plane_of(s.n_vars, UINT32_MAX);
+    const char* fp_env = getenv("ZKGL_FLAG_PLANES");
+    if (!s.is_loop || (fp_env && fp_env[0] == '0')) return plane_of;
+    std::vector<uint32_t> uses(s.n_vars, 0);
+    for (auto& op : s.ops)
+        if (!op.seed_only && op.opcode == ZK_OP_SELECT && op.ins[0].kind == Operand::VAR) ++uses[op.ins[0].idx];
+    std::vector<uint32_t> order;
+    for (uint32_t v = 0; v < s.n_vars; ++v) if (uses[v] >= 2) order.push_back(v);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return uses[x] > uses[y]; });
+    if (order.size() > zkdev::FLAG_PLANES) order.resize(zkdev::FLAG_PLANES);
+    for (uint32_t k = 0; k < order.size(); ++k) plane_of[order[k]] = k;
+    return plane_of;
+}
+
 void CS::schedule_by_locality(const std::vector<double>& a, const std::vector<double>& m, double a_tot, double m_tot,
                               const std::vector<std::vector<uint32_t>>& succ, std::vector<uint32_t>& n_pred) {
     Scope& s = loop_;
@@ -1510,22 +1527,12 @@ void CS::emit_scope(Scope& s) {
         // SELECT flags as bit planes (plain loop kernels: ZK_OP_FLAG_PLANES, kernels_engine2.hpp): the FLAG_PLANES most used flag
         // variables of a loop scope get a plane id; a flag is copied into its plane by a ZK_OP_FLAG_PLANES op emitted lazily, in
         // front of the first SELECT that needs it, together with every other flag produced by then (up to 7 per op)
-        std::vector<uint32_t> plane_of(s.n_vars, UINT32_MAX);
-        std::vector<uint8_t> plane_saved(s.n_vars, 0);
-        std::vector<uint32_t> plane_pending;   // produced, not yet copied
         const char* fp_env = getenv("ZKGL_FLAG_PLANES");
         const bool planes_on = v2 && s.is_loop && !(fp_env && fp_env[0] == '0');
-        if (planes_on) {
-            std::vector<uint32_t> uses(s.n_vars, 0);
-            for (auto& op : s.ops)
-                if (!op.seed_only && op.opcode == ZK_OP_SELECT && op.ins[0].kind == Operand::VAR) ++uses[op.ins[0].idx];
-            std::vector<uint32_t> order;
-            for (uint32_t v = 0; v < s.n_vars; ++v) if (uses[v] >= 2) order.push_back(v);
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return uses[x] > uses[y]; });
-            if (order.size() > zkdev::FLAG_PLANES) order.resize(zkdev::FLAG_PLANES);
-            for (uint32_t k = 0; k < order.size(); ++k) plane_of[order[k]] = k;
-            s.flag_planes = (uint32_t)order.size();
-        }
+        std::vector<uint32_t> plane_of = planes_on ? select_plane_vars(s) : std::vector<uint32_t>(s.n_vars, UINT32_MAX);
+        std::vector<uint8_t> plane_saved(s.n_vars, 0);
+        std::vector<uint32_t> plane_pending;   // produced, not yet copied
+        if (planes_on) { s.flag_planes = 0; for (uint32_t pv : plane_of) s.flag_planes += pv != UINT32_MAX; }
         plane_of_ = planes_on ? &plane_of : nullptr;
         auto operand = [&](const OpRec& op, size_t pos) {
             const Operand& in = op.ins[pos];
@@ -1679,6 +1686,7 @@ void CS::emit_scope(Scope& s) {
                 auto sum = [&](size_t i) { int64_t r = 0; for (++i; i > 0; i -= i & (~i + 1)) r += bit[i]; return r; };
                 std::vector<uint32_t> flag_miss(s.n_vars, 0), flag_uses(s.n_vars, 0);
                 uint64_t miss_all = 0, miss_flags = 0, sel = 0;
+                std::map<uint32_t, uint64_t> miss_by_op;   // opcode * 4 + min(operand position, 3)
                 auto touch = [&](uint32_t v, bool read) -> bool {
                     bool miss = false;
                     if (read) miss = last[v] < 0 || (size_t)(sum((size_t)stamp) - sum((size_t)last[v])) >= K;
@@ -1686,12 +1694,16 @@ void CS::emit_scope(Scope& s) {
                     ++stamp; last[v] = stamp; upd((size_t)stamp, +1);
                     return miss;
                 };
+                const std::vector<uint32_t> plane_of = select_plane_vars(s);
+                uint64_t plane_reads = 0;
                 for (auto& op : s.ops) {
                     if (op.seed_only) continue;
                     for (size_t q = 0; q < op.ins.size(); ++q) {
                         if (op.ins[q].kind != Operand::VAR) continue;
+                        if (op.opcode == ZK_OP_SELECT && q == 0 && plane_of[op.ins[0].idx] != UINT32_MAX) { ++plane_reads; continue; }   // from LDS
                         const bool m = touch(op.ins[q].idx, true);
                         miss_all += m;
+                        if (m) ++miss_by_op[op.opcode * 4 + std::min<size_t>(q, 3)];
                         if (op.opcode == ZK_OP_SELECT && q == 0) { ++sel; ++flag_uses[op.ins[q].idx]; if (m) { ++miss_flags; ++flag_miss[op.ins[q].idx]; } }
                     }
                     for (auto ov : op.outs) touch(ov, false);
@@ -1699,6 +1711,10 @@ void CS::emit_scope(Scope& s) {
                 std::vector<std::pair<uint32_t, uint32_t>> fl;
                 for (uint32_t v = 0; v < s.n_vars; ++v) if (flag_uses[v]) fl.push_back({flag_miss[v], flag_uses[v]});
                 std::sort(fl.rbegin(), fl.rend());
+                fprintf(stderr, "   %llu SELECT flag reads come from bit planes (not modelled as fetches); modelled fetches (16 values) %llu\n", (unsigned long long)plane_reads, (unsigned long long)miss_all);
+                fprintf(stderr, "   modelled fetches by op / operand position:");
+                for (auto& kv : miss_by_op) fprintf(stderr, " %u.%u=%llu", kv.first / 4, kv.first % 4, (unsigned long long)kv.second);
+                fprintf(stderr, "\n");
                 fprintf(stderr, "   SELECT flags: %llu selects, %zu distinct flags, %llu of %llu modelled fetches are flags;", (unsigned long long)sel, fl.size(),
                         (unsigned long long)miss_flags, (unsigned long long)miss_all);
                 uint64_t acc = 0, accu = 0; size_t k = 0;

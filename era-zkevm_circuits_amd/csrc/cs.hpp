@@ -307,6 +307,7 @@ class CS {
     // true: wave-aggregated atomics inside the witness kernels; false: the k_multiplicities pass after them (cs.cpp)
     bool inline_multiplicities() const;
     void operand_v2(const Scope& s, const OpRec& op, size_t pos, std::vector<uint32_t>& out) const;
+    std::vector<uint32_t> select_plane_vars(const Scope& s) const;
     void emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool counted, std::vector<uint32_t>& out) const;
     const std::vector<uint32_t>* plane_of_ = nullptr;   // emit_scope, v2 form of a loop scope: variable -> SELECT flag plane id (UINT32_MAX: none)
     void upload_scope(Scope& s);

@@ -339,6 +339,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                     const uint32_t mlo = uni((uint32_t)mv[g]), mhi = uni((uint32_t)(mv[g] >> 32));
                     fbits |= (uint32_t)((mv[g] >> wave_lane) & 1) << g;
                     const uint32_t sa = W[1 + g * 3 + 1], sb = W[1 + g * 3 + 2];
+#ifdef ZKGL_PLANE_STATS  // measurement only: how many plane SELECTs see a wavefront-uniform flag (counted in the gated-permutation words)
+                    if (sc.p2_stats && wave_lane == 0) atomicAdd(sc.p2_stats + (((mlo | mhi) == 0 || (mlo & mhi) == ~0u) ? 0 : 1), 1ull);
+#endif
                     a[g] = ldv((mlo | mhi) == 0 ? sb : sa);
                     b[g] = ldv(((mlo & mhi) == ~0u && !nonbool_seen) ? sa : sb);
                 }
@@ -544,7 +547,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 out_to(W[14]);
                 pc += 14 + D;
                 const bool all_off = __builtin_amdgcn_ballot_w64(!lane_off) == 0;
+#ifndef ZKGL_PLANE_STATS
                 if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats + (all_off ? 0 : 1), 1ull);
+#endif
                 if (all_off) {
 #pragma unroll
                     for (int i = 0; i < 12; ++i) st(0ull);
