@@ -19,7 +19,7 @@ words placed at their cycles, no VM state) already lives in HBM:
 figure rounds 1-2 quoted) is measured right after it without the seeding, `value_from_raw_witness_serial` counts the seeding of
 a window as if nothing overlapped.  Rank 0 prints ONE JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--log2-rows 20] [--no-cpu-baseline] [--workload main_vm|vm_shaped]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--log2-rows 20] [--no-cpu-baseline]
 (--gpus N > 1 without a launcher re-executes itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
@@ -98,44 +98,6 @@ def main_vm_streams(zkgl, cs, limit, n_exec=None, fixture=None):
     return outer, loop, expect
 
 
-# ------------------------------------------------------------------------------------------------ round-1 micro-workload (kept for A/B)
-def vm_shaped_inputs(rng, n_outer, n_loop, batch, limit):
-    P = 0xFFFFFFFF00000001
-    outer = rng.integers(0, 2**32, size=(n_outer, batch), dtype=np.uint64)
-    outer[120:135] = rng.integers(0, 2, size=(15, batch))
-    outer[135] = rng.integers(0, 2**16, size=batch)
-    outer[138] = rng.integers(0, 2**30, size=batch)
-    outer[139:142] = rng.integers(0, 2, size=(3, batch))
-    outer[142:154] = rng.integers(0, 2**63, size=(12, batch), dtype=np.uint64) % np.uint64(P)
-    outer[154] = rng.integers(0, 2**20, size=batch)
-    outer[155:167] = rng.integers(0, 2**63, size=(12, batch), dtype=np.uint64) % np.uint64(P)
-    loop = np.zeros((n_loop, batch * limit), dtype=np.uint64)
-    loop[183:] = rng.integers(0, 2**32, size=(n_loop - 183, batch * limit), dtype=np.uint64)
-    loop[183 + 16] = rng.integers(0, 2, size=batch * limit)
-    return outer, loop
-
-
-vm_inputs = vm_shaped_inputs  # name used by tests/test_gpu_cs.py
-
-
-def build_vm_shaped_cs(zkgl, log2_rows):
-    probe = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), max_trace_len=1 << 30)
-    probe.configure_vm_shaped()
-    probe.vm_shaped_entry_point(1)
-    probe.pad_and_shrink()
-    st = probe.stats()
-    limit = ((1 << log2_rows) - st["outer_slots"]) // st["loop_slots"]
-    probe.close()
-    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), max_trace_len=1 << log2_rows)
-    cs.configure_vm_shaped()
-    cs.vm_shaped_entry_point(limit)
-    cs.pad_and_shrink()
-    return cs, limit
-
-
-build_vm_cs = build_vm_shaped_cs
-
-
 # ------------------------------------------------------------------------------------------------ CPU baseline (the only leg that may touch oracle/)
 def cpu_baseline(log2_rows, seconds_target=20.0):
     """CPU restatement ("port"): the oracle's IR interpreter + checker (oracle/zko_engine.c, gcc -O3 -march=native -flto, OpenMP over
@@ -193,7 +155,6 @@ def main():
     ap.add_argument("--batch", type=int, default=384, help="independent circuit instances per GPU per step")
     ap.add_argument("--seed-windows", type=int, default=0, help="batches per stream of raw witness (0: = --steps, clamped to 2..8); two streams are resident per GPU")
     ap.add_argument("--log2-rows", type=int, default=20)
-    ap.add_argument("--workload", default="main_vm", choices=["main_vm", "vm_shaped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="only the timed default-mode steps (profiler runs: every k_witness_loop launch of the process is then a default-mode launch); the secondary figures are null")
     ap.add_argument("--fixture", default="default", choices=sorted(FIXTURES), help="which synthetic executions main_vm replays (default: every opcode family every ~150 cycles)")
@@ -241,30 +202,20 @@ def main():
     step_stream = torch.cuda.current_stream()
     seed_stream = step_stream
     stream = step_stream.cuda_stream
-    if args.workload == "main_vm":
-        cs, limit = build_main_vm_cs(zkgl, args.log2_rows)
-        n_outer, n_loop = cs.input_words()
-        t_pack = time.perf_counter()
-        outer_e, loop_e, expect_e = main_vm_streams(zkgl, cs, limit, fixture=FIXTURES[args.fixture])   # zk_pack_main_vm_witness: FIFOs -> streams, all executions
-        t_pack = time.perf_counter() - t_pack
-        n_exec = outer_e.shape[1]
-        # the stream is assembled on the device: instance i replays execution (rank * S + i) % n_exec of the fixture
-        sel = (torch.arange(S, device=dev) + rank * S) % n_exec
-        d_outer = torch.from_numpy(outer_e.view(np.int64)).to(dev)[:, sel].contiguous()
-        le = torch.from_numpy(loop_e.view(np.int64)).to(dev).view(n_loop, n_exec, limit)
-        d_loop = le[:, sel, :].reshape(n_loop, S * limit).contiguous()
-        del le, loop_e
-        expect = None if expect_e is None else expect_e[((np.arange(S) + rank * S) % n_exec)]
-        bufs = [d_loop]
-    else:
-        cs, limit = build_vm_shaped_cs(zkgl, args.log2_rows)
-        n_outer, n_loop = cs.input_words()
-        outer, loop = vm_shaped_inputs(np.random.default_rng(0xC2 + rank), n_outer, n_loop, S, limit)
-        d_outer = torch.from_numpy(outer.view(np.int64)).to(dev)
-        d_loop = torch.from_numpy(loop.view(np.int64)).to(dev)
-        del loop
-        n_exec, t_pack = 0, 0.0
-        bufs = [d_loop]
+    cs, limit = build_main_vm_cs(zkgl, args.log2_rows)
+    n_outer, n_loop = cs.input_words()
+    t_pack = time.perf_counter()
+    outer_e, loop_e, expect_e = main_vm_streams(zkgl, cs, limit, fixture=FIXTURES[args.fixture])   # zk_pack_main_vm_witness: FIFOs -> streams, all executions
+    t_pack = time.perf_counter() - t_pack
+    n_exec = outer_e.shape[1]
+    # the stream is assembled on the device: instance i replays execution (rank * S + i) % n_exec of the fixture
+    sel = (torch.arange(S, device=dev) + rank * S) % n_exec
+    d_outer = torch.from_numpy(outer_e.view(np.int64)).to(dev)[:, sel].contiguous()
+    le = torch.from_numpy(loop_e.view(np.int64)).to(dev).view(n_loop, n_exec, limit)
+    d_loop = le[:, sel, :].reshape(n_loop, S * limit).contiguous()
+    del le, loop_e
+    expect = None if expect_e is None else expect_e[((np.arange(S) + rank * S) % n_exec)]
+    bufs = [d_loop]
     st = cs.stats()
     cs.set_batch(B)
 
@@ -403,25 +354,24 @@ def main():
         # permutation (nothing in the fused step reads them); whoever reads the store later (the full check, the column readers) gets them
         # regenerated bit for bit by k_fill_p2, timed here on its own (zk_cs_complete_store).  Its unit differs: fewer values per cycle.
         deferred = None
-        if args.workload == "main_vm":
-            cs.set_check_mode(False, defer_p2=True)
-            step_no[0] = 0
-            step(); fence()
-            step_no[0] = 0
-            d_loop_ms = []
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-                d_loop_ms.append(cs.last_ms(1))
-            fence()
-            d_elapsed = time.perf_counter() - t1
-            d_local = np.array([cs.public_inputs(i) for i in range(min(B, 8))], dtype=np.uint64)   # reads go through the fill
-            resolve(window[0]); torch.cuda.synchronize()
-            tf = time.perf_counter(); cs.complete_store(stream); torch.cuda.synchronize(); fill_s = time.perf_counter() - tf
-            deferred = {"elapsed": d_elapsed, "loop_ms": float(np.mean(d_loop_ms)), "fill_s": fill_s,
-                        "commitments_equal": bool(expect is None or np.array_equal(d_local, expect[window[0] * B: window[0] * B + d_local.shape[0]]))}
-            cs.set_check_mode(False)
-            resolve(last_window)
+        cs.set_check_mode(False, defer_p2=True)
+        step_no[0] = 0
+        step(); fence()
+        step_no[0] = 0
+        d_loop_ms = []
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            d_loop_ms.append(cs.last_ms(1))
+        fence()
+        d_elapsed = time.perf_counter() - t1
+        d_local = np.array([cs.public_inputs(i) for i in range(min(B, 8))], dtype=np.uint64)   # reads go through the fill
+        resolve(window[0]); torch.cuda.synchronize()
+        tf = time.perf_counter(); cs.complete_store(stream); torch.cuda.synchronize(); fill_s = time.perf_counter() - tf
+        deferred = {"elapsed": d_elapsed, "loop_ms": float(np.mean(d_loop_ms)), "fill_s": fill_s,
+                    "commitments_equal": bool(expect is None or np.array_equal(d_local, expect[window[0] * B: window[0] * B + d_local.shape[0]]))}
+        cs.set_check_mode(False)
+        resolve(last_window)
         # ---- the same K steps with the per-cycle state already resident (what rounds 1-2 reported as `value`)
         t1 = time.perf_counter()
         for i in range(args.steps):
@@ -524,8 +474,7 @@ def main():
             "value_from_raw_witness_serial": per_step_constraints / (res_s + t_seed_stream / K),
             "witness_rows_materialised_per_s": None if mat_s is None else st["rows_per_instance"] * n_inst / (step_s + B * mat_s),
             "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/" + os.path.basename(FIXTURES[args.fixture]) + ", "
-                                    f"{n_exec} distinct executions through zk_pack_main_vm_witness)"
-                                    if args.workload == "main_vm" else "main_vm-shaped micro-workload (round 1)") +
+                                    f"{n_exec} distinct executions through zk_pack_main_vm_witness)") +
                                    f", geometry 140/0/8/deg8 + 3x8 lookups, 2^{args.log2_rows} rows/instance",
                        "instances_per_gpu": B, "cycles_per_instance": limit, "rows_per_instance": st["rows_per_instance"],
                        "constraints_per_instance": st["constraints_per_instance"], "parallelism": f"independent instances x{world}",

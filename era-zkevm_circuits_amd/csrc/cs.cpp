@@ -2594,7 +2594,7 @@ void CS::launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uin
                                           (const zkdev::CarryArgs*)d_seed_wcarries_, (uint32_t)seed_wcarries_.size(), dev_loop_inputs_rw, n, st));
     else if (use_strands && !generic)
         dev_check(zkdev::launch_seed_cone_strands(la, d_seed_sprog_, seed_sbegin_, seed_send_, seed_sslots_, loop_.n_input_words,
-                                                  (const zkdev::CarryArgs*)d_seed_scarries_, (uint32_t)seed_scarries_.size(), dev_loop_inputs_rw, n, seed_v2_ok_ && !(getenv("ZKGL_SEED_V1")), st));
+                                                  (const zkdev::CarryArgs*)d_seed_scarries_, (uint32_t)seed_scarries_.size(), dev_loop_inputs_rw, n, seed_v2_ok_, st));
     else if (d_seed_prog_ && !generic)
         dev_check(zkdev::launch_seed_cone(la, d_seed_prog_, (uint32_t)seed_prog_.size(), seed_slots_, loop_.n_input_words, (const zkdev::CarryArgs*)d_seed_carries_,
                                           (uint32_t)seed_carries_.size(), dev_loop_inputs_rw, n, st));

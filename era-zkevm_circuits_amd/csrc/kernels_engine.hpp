@@ -858,15 +858,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 constexpr int STRANDS_PER_TILE = ZKGL_STRANDS_PER_TILE;
 constexpr int SEED_STRANDS_PER_TILE = 8;  // device_api.hpp
 struct StrandTab { uint32_t begin[STRANDS_PER_TILE], end[STRANDS_PER_TILE]; };
-template <bool WITH_BIGINT, bool BUFFER_ADDRESSING = true>
-__global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_witness_strands(ScopeDev sc, StrandTab tab) {
-    if (blockIdx.x * 64 >= sc.n_lanes) return;
-    const uint32_t w = uni(threadIdx.x >> 6);
-    uint32_t lane = blockIdx.x * 64 + (threadIdx.x & 63);
-    const bool active = lane < sc.n_lanes;
-    lane = active ? lane : sc.n_lanes - 1;
-    run_lane<WITH_BIGINT, false, BUFFER_ADDRESSING, 64 * STRANDS_PER_TILE, true>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, tab.begin[w], tab.end[w]);
-}
+// (the strand kernel itself is k_witness_strands2, kernels_engine2.hpp; the round-1 form over run_lane is gone)
 
 // Sequential seeding mode (generic, slow): thread == instance, iterations in order.  Before
 // iteration k the carried input words are filled from iteration k-1's outputs (k == 0: from the

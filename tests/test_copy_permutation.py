@@ -110,7 +110,7 @@ def test_gpu_z_equals_oracle_and_detects_broken_copies(zk):
 def test_gpu_grand_product_closes_on_the_vm_cycle(zk):
     """main_vm-shaped cycle (BASELINE config C2 at a short limit): 183 carried words per iteration, broadcast imports, lookups"""
     import torch
-    from bench import build_vm_cs, vm_inputs
+    from vm_shaped_fixture import build_vm_cs, vm_inputs
     cs, limit = build_vm_cs(zk, 12)   # 2^12 rows
     n_outer, n_loop = cs.input_words()
     B = 5

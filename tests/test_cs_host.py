@@ -261,7 +261,7 @@ VM_TABLE_ROWS = 65536 * 2 + 2048 + 64 + 16 + 1024
 
 
 def test_vm_shaped_cycle_budget_and_satisfiability():
-    from bench import vm_inputs
+    from vm_shaped_fixture import vm_inputs
     limit, batch = 3, 2
     cs = vm_cs(limit)
     st1, st3 = vm_cs(1).stats(), cs.stats()

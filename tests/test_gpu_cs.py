@@ -267,7 +267,7 @@ def test_resolve_is_repeatable_and_timed(zk):
 
 
 def test_vm_shaped_gpu_equals_oracle(zk):
-    from bench import vm_inputs
+    from vm_shaped_fixture import vm_inputs
     from test_cs_host import VM_TABLE_ROWS, vm_cs
     limit, batch = 5, 70
     cs = vm_cs(limit)

@@ -61,7 +61,7 @@ def test_device_sums_equal_restatement(zk):
 @pytest.mark.gpu
 def test_lookup_argument_on_the_bench_circuit(zk):
     """C2 shape (140 + 24 columns, 6 tables, 102 lookups per cycle) at a small limit: balances on the device"""
-    import bench
+    import vm_shaped_fixture as bench
     cs = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), max_trace_len=1 << 20)
     cs.configure_vm_shaped()
     cs.vm_shaped_entry_point(40)
