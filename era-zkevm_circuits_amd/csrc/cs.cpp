@@ -1306,8 +1306,26 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
         };
         for (auto& st : strand) st.clear();
         uint64_t total = 0, critical = 0;
+        // SELECT flags as bit planes in the strand form of a loop scope (ZKGL_STRAND_PLANES=1; kernels_engine2.hpp): the tile's wavefronts
+        // share one set of planes.  A flag produced in level L is copied by ONE strand in level L + 1 (ZK_OP_FLAG_PLANES reads the stored
+        // value, behind the barrier that ends L) and SELECTs from level L + 2 on read the plane (behind the barrier that ends L + 1);
+        // a SELECT in level L + 1 itself keeps the slot.
+        const char* spl_env = getenv("ZKGL_STRAND_PLANES");
+        const bool strand_planes = s.is_loop && ph == 0 && spl_env && spl_env[0] == '1';
+        const std::vector<uint32_t> plane_all = strand_planes ? select_plane_vars(s) : std::vector<uint32_t>();
+        std::vector<uint32_t> plane_now(strand_planes ? s.n_vars : 0, UINT32_MAX);   // variable -> plane id once its plane is readable
+        std::vector<std::vector<uint32_t>> copy_at(n_levels + 2), readable_at(n_levels + 3);
+        if (strand_planes) {
+            for (uint32_t v = 0; v < s.n_vars; ++v)
+                if (plane_all[v] != UINT32_MAX && producer[v] >= (int64_t)o0) {
+                    const uint32_t lf = level[(size_t)producer[v]];
+                    copy_at[lf + 1].push_back(v); readable_at[lf + 2].push_back(v);
+                }
+            plane_of_ = &plane_now;
+        }
         for (uint32_t lv = 0; lv < n_levels; ++lv) {
             auto& ops = by_level[lv];
+            if (strand_planes) for (uint32_t v : readable_at[lv]) plane_now[v] = plane_all[v];
             std::stable_sort(ops.begin(), ops.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
             uint64_t load[NS_MAX] = {0};
             std::vector<uint32_t> mine[NS_MAX];
@@ -1337,6 +1355,8 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
                     if (grouping) {
                         if (op.opcode == ZK_OP_LOOKUP && op.a <= 2 && op.b <= 2) key = ((uint64_t)ZK_OP_LOOKUP << 56) | ((uint64_t)op.ins[0].idx << 24) | ((uint64_t)op.a << 8) | op.b;
                         else if (op.opcode == ZK_OP_SELECT || op.opcode == ZK_OP_FMA || op.opcode == ZK_OP_INPUT || op.opcode == ZK_OP_U32MULADD) key = (uint64_t)op.opcode << 56;
+                        // a group is homogeneous: plane flags or slot flags
+                        if (strand_planes && op.opcode == ZK_OP_SELECT && op.ins[0].kind == Operand::VAR && plane_now[op.ins[0].idx] != UINT32_MAX) key |= 1;
                     }
                     if (!groups.count(key)) order.push_back(key);
                     groups[key].push_back(oi);
@@ -1362,10 +1382,22 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
                     }
                 }
             }
+            if (strand_planes && lv < copy_at.size() && !copy_at[lv].empty()) {   // this level's copies go to the lightest strand
+                uint32_t best = 0;
+                for (uint32_t k = 1; k < NS; ++k) if (load[k] < load[best]) best = k;
+                const auto& cp = copy_at[lv];
+                for (size_t at = 0; at < cp.size(); at += 7) {
+                    const size_t nn = std::min<size_t>(7, cp.size() - at);
+                    strand[best].push_back((uint32_t)ZK_OP_FLAG_PLANES | ((uint32_t)(nn - 1) << 16));
+                    for (size_t q = 0; q < nn; ++q) { strand[best].push_back(s.var_slot[cp[at + q]]); strand[best].push_back(plane_all[cp[at + q]]); }
+                    load[best] += 10 + 4 * nn;
+                }
+            }
             for (uint32_t k = 0; k < NS; ++k) total += load[k];
             critical += *std::max_element(load, load + NS) + 200;  // + the barrier: every strand drains its stores
             if (lv + 1 < n_levels) for (auto& st : strand) st.push_back(ZK_OP_BARRIER);
         }
+        plane_of_ = nullptr;
         s_gain[ph] = critical ? (float)total / (float)critical : 0.f;
         if (getenv("ZKGL_STRANDS_DEBUG") && o1 > o0) {
             uint32_t narrow = 0, wide = 0;

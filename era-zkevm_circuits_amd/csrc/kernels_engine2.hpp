@@ -222,7 +222,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     };
 
     // SELECT flags as bit planes (ZK_OP_FLAG_PLANES; plain kernels, loop scope): [wavefront of the block][0: != 0, 1: > 1][plane id]
-    __shared__ uint64_t flag_planes[STRANDS ? 1 : (BLOCK / 64) * 2 * zkdev::FLAG_PLANES];
+    // (strand form: the wavefronts of the workgroup share ONE tile, hence one set of planes; a plane is written in the level after its
+    // flag's and read from the level after that — cs.cpp build_strands — with the workgroup barrier of ZK_OP_BARRIER in between)
+    __shared__ uint64_t flag_planes[STRANDS ? 2 * zkdev::FLAG_PLANES : (BLOCK / 64) * 2 * zkdev::FLAG_PLANES];
     uint64_t* const planes = flag_planes + (STRANDS ? 0 : uni(threadIdx.x >> 6) * 2 * zkdev::FLAG_PLANES);
     // (this lane's index in its wavefront is recomputed where used — two mbcnt — rather than held in a VGPR across the interpreter loop)
     auto wave_lane_now = [] { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };
@@ -309,7 +311,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             pc += 9 + D;
             st(r);
         } break;
-        case ZK_OP_FLAG_PLANES: if constexpr (!STRANDS) {
+        case ZK_OP_FLAG_PLANES: {
             const uint32_t n = pb + 1;
             uint64_t v[7];
 #pragma unroll
@@ -320,10 +322,10 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 if (k < n) {
                     const uint64_t m = __ballot(v[k] != 0), nb = __ballot(v[k] > 1);
                     if (wave_lane_now() == 0) { planes[W[2 + 2 * k]] = m; planes[zkdev::FLAG_PLANES + W[2 + 2 * k]] = nb; }
-                    nonbool_seen |= (uint32_t)(nb != 0);
+                    if constexpr (!STRANDS) nonbool_seen |= (uint32_t)(nb != 0);   // (strands: another wavefront may have copied the flag — the SELECT reads both planes)
                 }
         } break;
-        case ZK_OP_SELECT: if (!STRANDS && pa == 1) {
+        case ZK_OP_SELECT: if (pa == 1) {
             // flags from the bit planes.  A wavefront whose lanes agree on a flag loads the selected operand twice (the second load hits
             // the line the first one brought) instead of both: no branch, no fetch of the branch nobody takes.
             auto body = [&](auto n_) {
@@ -331,24 +333,30 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 uint64_t a[N], b[N];
                 const uint32_t wave_lane = wave_lane_now();
                 uint32_t fbits = 0;   // this lane's flag of member g in bit g
-                uint64_t mv[N];
+                uint32_t nbany = nonbool_seen;   // uniform: a flag > 1 somewhere in the wavefront (strands: read per member from the second plane)
+                uint64_t mv[N], nv[N];
 #pragma unroll
-                for (uint32_t g = 0; g < N; ++g) mv[g] = planes[W[1 + g * 3]];   // all plane reads in flight before the first wait
+                for (uint32_t g = 0; g < N; ++g) {   // all plane reads in flight before the first wait
+                    mv[g] = planes[W[1 + g * 3]];
+                    if constexpr (STRANDS) nv[g] = planes[zkdev::FLAG_PLANES + W[1 + g * 3]];
+                }
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) {
                     const uint32_t mlo = uni((uint32_t)mv[g]), mhi = uni((uint32_t)(mv[g] >> 32));
+                    uint32_t nz = nonbool_seen;
+                    if constexpr (STRANDS) { nz = uni((uint32_t)nv[g] | (uint32_t)(nv[g] >> 32)); nbany |= nz; }
                     fbits |= (uint32_t)((mv[g] >> wave_lane) & 1) << g;
                     const uint32_t sa = W[1 + g * 3 + 1], sb = W[1 + g * 3 + 2];
 #ifdef ZKGL_PLANE_STATS  // measurement only: how many plane SELECTs see a wavefront-uniform flag (counted in the gated-permutation words)
                     if (sc.p2_stats && wave_lane == 0) atomicAdd(sc.p2_stats + (((mlo | mhi) == 0 || (mlo & mhi) == ~0u) ? 0 : 1), 1ull);
 #endif
                     a[g] = ldv((mlo | mhi) == 0 ? sb : sa);
-                    b[g] = ldv(((mlo & mhi) == ~0u && !nonbool_seen) ? sa : sb);
+                    b[g] = ldv(((mlo & mhi) == ~0u && !nz) ? sa : sb);
                 }
-                pc += 1 + N * 3;
+                pc += 1 + N * 3 + D * N;
 #pragma unroll
-                for (uint32_t g = 0; g < N; ++g) st(((fbits >> g) & 1) ? a[g] : b[g]);
-                if (nonbool_seen) {   // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ
+                for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N * 3 + g) & 15]); st(((fbits >> g) & 1) ? a[g] : b[g]); }
+                if (nbany) {   // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ
 #pragma unroll
                     for (uint32_t g = 0; g < N; ++g) fused_bad |= ((planes[zkdev::FLAG_PLANES + W[1 + g * 3]] >> wave_lane) & 1) && a[g] != b[g];
                 }
