@@ -890,11 +890,12 @@ def _b_lq(q):
             struct.pack("<BBBBBII", q.aux_byte, q.rw_flag, q.rollback, q.is_service, q.shard_id, q.tx_number_in_block, q.timestamp))
 
 
-def _b_log_queue(arr, n, with_ts=False):
+def _b_log_queue(arr, n, with_ts=False, tails=None):
     out = struct.pack("<Q", n)
     for i in range(n):
         out += (_b_lq(arr[i].record) + struct.pack("<I", arr[i].timestamp)) if with_ts else _b_lq(arr[i])
-        out += b"".join(struct.pack("<Q", 1000 + 4 * i + t) for t in range(4))   # the tail before the push: skipped by the decoder
+        # the tail before the push (the plain decoders skip it, the _tails ones keep it)
+        out += b"".join(struct.pack("<Q", int(tails[i][t]) if tails is not None else 1000 + 4 * i + t) for t in range(4))
     return out
 
 
@@ -997,6 +998,23 @@ def test_log_sorter_demux_linear_hasher_bincode_round_trips():
     assert np.array_equal(outer[:, 0], pouter[:, 0]) and np.array_equal(loop[:, :limit], ploop[:, :limit])
     d, used = zkgl.decode_demux_witness_bincode(data, limit, keep_tails=True)   # the previous tails bincode carries beside the elements
     assert used == len(data) and all(list(d._keep[-1][i]) == [1000 + 4 * i + t for t in range(4)] for i in range(n))
+    # end to end with the REAL previous tails on the wire: bytes -> decode (tails kept) -> packer with tails == the native stream, carried
+    # words included (the output tails are the next circuits' previous tails; taken from the native restatement here)
+    irows = insts[0]["rows"]
+    prev = [irows[c][0:4] for c in range(n)]
+    data2 = (struct.pack("<BB", w.start_flag, w.completion_flag) + _b_q4(w.initial_log_queue_state) + b"".join(_b_q4(zkgl.QueueStateWitness()) for _ in range(6)) +
+             fsm(w.hidden_fsm_input) + fsm(w.hidden_fsm_output) + _b_log_queue(qa, n, tails=prev))
+    d, used = zkgl.decode_demux_witness_bincode(data2, limit, keep_tails=True)
+    from oracle import demux_native as dmn
+    out_t = np.zeros((max(n, 1), 4), dtype=np.uint64)
+    for c in range(n):
+        k, _ = dmn.target_queue([int(x) for x in irows[c][35:71]])
+        if k is not None:
+            out_t[c] = irows[c + 1][5 + 5 * k:9 + 5 * k] if c + 1 < limit else insts[0]["fsm_out"]["out"][k][4:8]
+    o3 = np.zeros((73, 2), dtype=np.uint64); l3 = np.full((71, 2 * limit), 9, dtype=np.uint64)
+    zkgl.pack_demux_witness_tails(d, limit, 0, o3, l3, np.array([list(t) for t in d._keep[-1]], dtype=np.uint64), out_t)
+    eo, el = _streams(insts)
+    assert np.array_equal(o3[:, 0], eo[:, 0]) and np.array_equal(l3[:, :limit], el[:, :limit])
     # linear_hasher
     from oracle.storage_native import log_query
     rng = np.random.default_rng(73)
