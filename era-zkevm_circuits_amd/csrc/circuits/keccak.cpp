@@ -18,6 +18,8 @@
 #include "keccak_gadget.hpp"
 #include "log_query.hpp"
 #include "memory_query.hpp"
+#include <cstdlib>
+#include "../bytebuf_macro.hpp"
 
 namespace zkgl {
 
@@ -125,33 +127,68 @@ Boolean can_fill_bytes(G& g, const ByteBuffer& buf, zk_var bytes_to_fill) {
     return g.negated(uf);
 }
 
-// ByteBuffer::fill_with_bytes with trivial_mapping_function — buffer/mod.rs:69-136, mod.rs:100-142
+// ByteBuffer::fill_with_bytes with trivial_mapping_function — buffer/mod.rs:69-136, mod.rs:100-142.  The structure is
+// zkb::fill_with_bytes (bytebuf_macro.hpp); this is its HOST backend: every primitive records its gate, and its witness op unless the
+// whole fill is recorded as ONE macro-op (ZKGL_BYTEBUF_MACRO=1: ZK_OP_BYTEBUF_FILL, whose outputs are the pre-allocated variables the
+// walk then constrains — same variables, same gates, same cells as the op-by-op form).
+struct BufBackend {
+    typedef zk_var E;
+    typedef zk_var V;
+    G& g;
+    zk_var macro_next = ZK_VAR_NONE;
+    explicit BufBackend(G& g) : g(g) {}
+    V fma(uint64_t q, V a, V b, uint64_t l, V c) {
+        if (macro_next == ZK_VAR_NONE) return g.fma(q, a, b, l, c);
+        const V d = macro_next++;
+        zk_var vars[4] = {a, b, c, d};
+        uint64_t k[2] = {q, l};
+        g.cs.place_gate(ZK_GATE_FMA, vars, 4, k, 2);
+        return d;
+    }
+    V sub1(V x) { return fma(1, x, g.one(), GL_P - 1, g.one()); }
+    V add(V a, V b) { return fma(1, a, g.one(), 1, b); }
+    V mul(V a, V b) { return fma(1, a, b, 0, a); }
+    V band(V a, V b) { return mul(a, b); }
+    V bnot(V a) { return fma(GL_P - 1, a, g.one(), 1, g.one()); }
+    V bor(V a, V b) { const V s = add(a, b); return fma(GL_P - 1, a, b, 1, s); }
+    V is_zero(V x) {
+        if (macro_next == ZK_VAR_NONE) return g.is_zero(x).v;
+        const V flag = macro_next++, aux = macro_next++;
+        zk_var vars[3] = {x, aux, flag};
+        g.cs.place_gate(ZK_GATE_ZEROCHECK, vars, 3, nullptr, 0);
+        return flag;
+    }
+    V select(V s, V a, V b) {
+        if (a == b) throw ZkError(ZK_ERR_INVALID, "internal: ByteBuffer select over one variable (the macro-op's output count assumes none)");
+        if (macro_next == ZK_VAR_NONE) return g.select(Boolean{s}, a, b);
+        const V r = macro_next++;
+        zk_var vars[4] = {a, b, s, r};
+        g.cs.place_gate(ZK_GATE_SELECT, vars, 4, nullptr, 0);
+        return r;
+    }
+    V zero() { return g.zero(); }
+};
+
 void fill_with_bytes(G& g, ByteBuffer& buf, const std::array<zk_var, 32>& input, zk_var offset, zk_var meaningful) {
-    zk_var one = g.one(), zero = g.zero();
-    std::array<zk_var, 32> shifted = input;  // shift register: drop `offset` leading bytes
-    zk_var off = g.sub(offset, one);
-    for (int i = 1; i < 32; ++i) {
-        Boolean use_from_here = g.is_zero(off);
-        off = g.sub(off, one);
-        for (int j = 0; j < 32; ++j) shifted[j] = g.select(use_from_here, i + j < 32 ? input[i + j] : zero, shifted[j]);
+    BufBackend be(g);
+    (void)g.one(); (void)g.zero();   // the constants exist before the macro-op's outputs are allocated
+    const char* e = getenv("ZKGL_BYTEBUF_MACRO");
+    const bool use_macro = e && e[0] == '1';
+    zk_var first = ZK_VAR_NONE;
+    uint32_t n = 0;
+    if (use_macro) {
+        n = zkb::n_outputs();
+        std::vector<zk_var> ins(buf.bytes.begin(), buf.bytes.end());
+        ins.push_back(buf.filled);
+        ins.insert(ins.end(), input.begin(), input.end());
+        ins.push_back(offset); ins.push_back(meaningful);
+        first = g.cs.alloc_vars(n);
+        g.cs.emit_macro_op(ZK_OP_BYTEBUF_FILL, ins.data(), (uint32_t)ins.size(), first, n);
+        be.macro_next = first;
     }
-    // "start here" markers: position `filled`, only if there is something to fill
-    Boolean marker = g.negated(g.is_zero(meaningful));
-    std::array<Boolean, BUF> place;
-    zk_var tmp = buf.filled;
-    for (int j = 0; j < BUF; ++j) {
-        place[j] = g.b_and(g.is_zero(tmp), marker);
-        tmp = g.sub(tmp, one);
-    }
-    zk_var counter = meaningful;
-    Boolean exhausted = g.is_zero(meaningful);
-    for (int idx = 0; idx < 32; ++idx) {
-        zk_var src = masked(g, shifted[idx], g.negated(exhausted));
-        for (int j = idx; j < BUF; ++j) buf.bytes[j] = g.select(place[j - idx], src, buf.bytes[j]);
-        counter = g.sub(counter, one);
-        exhausted = g.b_or(g.is_zero(counter), exhausted);
-    }
-    buf.filled = g.add(buf.filled, meaningful);
+    zk_var shifted[zkb::IN], place[zkb::BUF];
+    zkb::fill_with_bytes(be, buf.bytes.data(), buf.filled, input.data(), offset, meaningful, shifted, place);
+    if (use_macro && be.macro_next != first + n) throw ZkError(ZK_ERR_INVALID, "internal: the ByteBuffer gadget and its macro-op disagree on the output count");
     g.range_check_u8_pair(buf.filled, g.sub(g.constant(BUF), buf.filled));  // filled <= capacity
 }
 

@@ -15,6 +15,7 @@
 #include "../../include/zkgl_vm.h"
 #include "keccak_macro.hpp"
 #include "sha256_macro.hpp"
+#include "bytebuf_macro.hpp"
 
 static constexpr int ZK_MACRO_FAILURE = 0x7fff0001;  // internal: a macro check packet failed, re-run the gate-by-gate program
 
@@ -349,6 +350,12 @@ void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uin
         s.uses_bigint = true;
         uses_lookup_macros_ = true;
     } break;
+    case ZK_OP_BYTEBUF_FILL:
+        if (!allow_macro_ops_) throw ZkError(ZK_ERR_INVALID, "emit_op: macro-ops are recorded by the engine's gadgets only");
+        need(zkb::N_INPUTS, zkb::n_outputs(), 0);
+        s.uses_bigint = true;
+        uses_lookup_macros_ = true;
+        break;
     case ZK_OP_NN_MULMOD:
         if (a == 0 || a > 17 || b == 0 || b > 17 || a + b < 16 || n_in != a + b || n_imm != 16 || n_out != a + b - 15 + 16)
             throw ZkError(ZK_ERR_INVALID, "NN_MULMOD: bad shape");
@@ -697,6 +704,10 @@ void CS::build_check_program(Scope& s) {
             switch (g.kind) {
             case ZK_GATE_FMA: {
                 const OpRec* op = prod(g.vars[3]);
+                // inside the ByteBuffer macro-op every FMA / Selection / ZeroCheck gate is placed by the gadget from the structure the op
+                // walks (bytebuf_macro.hpp): the op computes exactly these relations on the values it stores; its selectors are its own
+                // is-zero flags and their and / or / not, 0 / 1 for every input
+                if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = true; break; }
                 uint64_t q, l;
                 m = op && op->opcode == ZK_OP_FMA && op->ins.size() == 5 && pool(op->ins[0], q) && pool(op->ins[1], l) && q == g.consts[0] && l == g.consts[1] &&
                     is_var(op->ins[2], g.vars[0]) && is_var(op->ins[3], g.vars[1]) && is_var(op->ins[4], g.vars[2]);
@@ -719,10 +730,12 @@ void CS::build_check_program(Scope& s) {
             } break;
             case ZK_GATE_SELECT: {
                 const OpRec* op = prod(g.vars[3]);
+                if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = true; break; }
                 m = op && op->opcode == ZK_OP_SELECT && op->ins.size() == 3 && is_var(op->ins[0], g.vars[2]) && is_var(op->ins[1], g.vars[0]) && is_var(op->ins[2], g.vars[1]);
             } break;
             case ZK_GATE_ZEROCHECK: {
                 const OpRec* op = prod(g.vars[2]);
+                if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = producer[g.vars[1]] == producer[g.vars[2]]; break; }
                 m = op && op->opcode == ZK_OP_ISZERO && is_var(op->ins[0], g.vars[0]) && op->outs[0] == g.vars[2] && op->outs[1] == g.vars[1];
             } break;
             case ZK_GATE_DOT4: {
@@ -1301,7 +1314,7 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
             if (op.opcode == ZK_OP_P2_ROUNDS || op.opcode == ZK_OP_POSEIDON2) c += 4000;
             if (op.opcode == ZK_OP_NN_MULMOD) c += 2000;
             if (op.opcode == ZK_OP_U256_DIVREM) c += 2500;
-            if (op.opcode == ZK_OP_KECCAK_F || op.opcode == ZK_OP_SHA256_ROUNDS) c += 8000;   // + 2 per output above
+            if (op.opcode == ZK_OP_KECCAK_F || op.opcode == ZK_OP_SHA256_ROUNDS || op.opcode == ZK_OP_BYTEBUF_FILL) c += 8000;   // + 2 per output above
             return c;
         };
         for (auto& st : strand) st.clear();
@@ -1330,7 +1343,7 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
             uint64_t load[NS_MAX] = {0};
             std::vector<uint32_t> mine[NS_MAX];
             for (uint32_t oi : ops) {
-                if ((s.ops[oi].opcode == ZK_OP_KECCAK_F || s.ops[oi].opcode == ZK_OP_SHA256_ROUNDS) && (NS & (NS - 1)) == 0) {
+                if ((s.ops[oi].opcode == ZK_OP_KECCAK_F || s.ops[oi].opcode == ZK_OP_SHA256_ROUNDS || s.ops[oi].opcode == ZK_OP_BYTEBUF_FILL) && (NS & (NS - 1)) == 0) {
                     // cooperative macro-op: every strand runs it and stores its share of the outputs (kernels_engine2.hpp keccak_f_stream)
                     for (uint32_t k = 0; k < NS; ++k) { load[k] += cost(oi) / NS + 3000; mine[k].push_back(oi); }
                     continue;
@@ -1774,7 +1787,7 @@ void CS::emit_scope(Scope& s) {
 // Poseidon2 intermediates.  Keep only the backward slice of the carried outputs, collapse P2_ROUNDS to the 12-output
 // permutation and assign every surviving value an LDS slot by linear scan over its live range.
 void CS::build_seed_program() {
-    seed_prog_.clear(); seed_carries_.clear(); seed_slots_ = 0; seed_ops_ = 0;
+    seed_prog_.clear(); seed_carries_.clear(); seed_slots_ = 0; seed_ops_ = 0; seed_cone_unsupported_ = false;
     if (!limit_ || carries_store_.empty()) return;
     const Scope& s = loop_;
     // the cone is built from the ops in RECORDING order: the locality schedule of the trace program (schedule_by_locality) stretches
@@ -1813,6 +1826,7 @@ void CS::build_seed_program() {
         case ZK_OP_DIVREM: case ZK_OP_U256_MULWIDE: case ZK_OP_U256_DIVREM: break;
         default: seed_v2_ok_ = false;
         }
+        if (sops[oi].opcode == ZK_OP_BYTEBUF_FILL) seed_cone_unsupported_ = true;   // no seed kernel carries this macro-op (and it has no hint)
     }
     const int64_t INF = INT64_MAX;
     std::vector<int64_t> last_use(s.n_vars, -1);
@@ -2616,6 +2630,7 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
 void CS::launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (launch_seed_native(la, oa, dev_loop_inputs_rw, n, stream)) return;
+    if (seed_cone_unsupported_) throw ZkError(ZK_ERR_INVALID, "the seeding cone of this circuit contains ZK_OP_BYTEBUF_FILL, which only the trace kernels run: use the native seeder, or record without ZKGL_BYTEBUF_MACRO");
     const char* force_generic = std::getenv("ZKGL_SEED_GENERIC");
     const char* seed_strands = std::getenv("ZKGL_SEED_STRANDS");  // 0: plain cone, 1: strand form whenever it exists
     const bool generic = force_generic && force_generic[0] == '1';

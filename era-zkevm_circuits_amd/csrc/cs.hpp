@@ -360,6 +360,7 @@ class CS {
     // strand form of the cone (8 wavefronts per block, level barriers; slots recycled per level)
     uint32_t* d_public_slots_ = nullptr;
     bool seed_v2_ok_ = false;
+    bool seed_cone_unsupported_ = false;   // the cone holds an op no seed kernel runs (ZK_OP_BYTEBUF_FILL): seeding needs the native seeder
     // op-parallel seed program (k_seed_wave): 16-bit records, prologue segments then cycle segments
     std::vector<uint16_t> seed_wprog_;
     std::vector<Carry> seed_wcarries_;

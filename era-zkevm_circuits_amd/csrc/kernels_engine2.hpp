@@ -21,6 +21,7 @@
 #include "kernels_engine.hpp"
 #include "keccak_macro.hpp"
 #include "sha256_macro.hpp"
+#include "bytebuf_macro.hpp"
 #include <utility>
 
 namespace zke {
@@ -170,6 +171,38 @@ __device__ __noinline__ uint32_t sha256_rounds_stream(__amdgpu_buffer_rsrc_t rsr
     for (int i = 0; i < 16; ++i) blk[i] = in24[8 + i];
     zks::ComputeBackend<Emit> be(emit);
     zks::compress(be, st, blk, w, zks::K);
+    return emit.d;
+}
+
+// K8, out of line: ByteBuffer::fill_with_bytes with every intermediate streamed out (zkb::fill_with_bytes, bytebuf_macro.hpp): the byte
+// arrays are indexed dynamically (scratch), the values are small integers; cooperative like keccak_f_stream — every strand computes,
+// strand `share` stores every (mask + 1)-th run of eight outputs.
+__device__ __noinline__ uint32_t bytebuf_fill_stream(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_byte, uint32_t dst, uint32_t bstep, uint8_t* bytes, const uint8_t* input,
+                                                      int32_t filled, int32_t offset, int32_t meaningful, uint32_t share, uint32_t n_share_mask) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    struct Emit {
+        __amdgpu_buffer_rsrc_t rsrc;
+        uint32_t lane_byte, d, bstep, cnt, mine, mask;
+        __device__ __forceinline__ void one(uint64_t v) {
+            if (((cnt >> 3) & mask) == mine) {
+                u32x2 o;
+                o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
+                __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, d, 0);
+            }
+            d += bstep;
+            ++cnt;
+        }
+    } emit{rsrc, lane_byte, uni(dst), bstep, 0u, uni(share), uni(n_share_mask)};
+    struct Inv {
+        __device__ __forceinline__ uint64_t operator()(int32_t k) const {
+            const uint64_t r = p2::INV_SMALL[(uint32_t)(k < 0 ? -k : k) & (p2::INV_SMALL_N - 1)];
+            return k < 0 ? 0xFFFFFFFF00000001ull - r : r;
+        }
+    } inv;
+    zkb::ComputeBackend<Emit, Inv> be(emit, inv);
+    uint8_t shifted[zkb::IN], place[zkb::BUF];
+    int32_t f = filled;
+    zkb::fill_with_bytes(be, bytes, f, input, offset, meaningful, shifted, place);
     return emit.d;
 }
 
@@ -753,6 +786,53 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 zks::compress(be, sst, blk, w, zks::K);
             }
             fused_bad |= not_bytes;
+        } else { return; } break;
+        case ZK_OP_BYTEBUF_FILL: if constexpr (WITH_BIGINT) {
+            // K8: one ByteBuffer fill as ONE op.  [192 buffer bytes, filled, 32 input bytes, offset, meaningful] -> every intermediate, in the
+            // gadget's allocation order (both walk zkb::fill_with_bytes).  The op works on small integers: an operand outside its range
+            // (byte > 255, filled > 192, offset > 31, meaningful > 32 — each of them is range-checked by the circuit) is reported as the
+            // fused mode's failure, and the values stored for it then violate the op's own gates.
+            uint8_t bb[zkb::BUF], bin[zkb::IN];   // indexed dynamically by the walk: scratch by design
+            int32_t sc3[3] = {0, 0, 0};
+            bool out_of_range = false;
+#pragma unroll 1
+            for (uint32_t c8 = 0; c8 < (zkb::N_INPUTS + 7) / 8; ++c8) {   // eight operand loads in flight per step
+                uint64_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = c8 * 8 + k < (uint32_t)zkb::N_INPUTS ? ldv(prog[pc + 1 + c8 * 8 + k]) : 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t i = c8 * 8 + k;
+                    if (i < (uint32_t)zkb::BUF) { out_of_range |= v[k] > 0xff; bb[i] = (uint8_t)v[k]; }
+                    else if (i == (uint32_t)zkb::BUF) { out_of_range |= v[k] > (uint64_t)zkb::BUF; sc3[0] = (int32_t)(v[k] & 0xff); }
+                    else if (i < (uint32_t)(zkb::BUF + 1 + zkb::IN)) { out_of_range |= v[k] > 0xff; bin[i - zkb::BUF - 1] = (uint8_t)v[k]; }
+                    else if (i == (uint32_t)(zkb::BUF + 1 + zkb::IN)) { out_of_range |= v[k] > 31; sc3[1] = (int32_t)(v[k] & 31); }
+                    else if (i == (uint32_t)(zkb::BUF + 2 + zkb::IN)) { out_of_range |= v[k] > 32; sc3[2] = (int32_t)(v[k] & 63); }
+                }
+            }
+            if constexpr (STRANDS) out_to(prog[pc + 1 + zkb::N_INPUTS]);
+            pc += 1 + zkb::N_INPUTS + D;
+            if constexpr (!WIDE) {
+                const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
+                dst = bytebuf_fill_stream(rsrc, lane_byte, dst, bstep, bb, bin, sc3[0], sc3[1], sc3[2], STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+            } else {
+                auto st1 = [&](uint64_t v) { st(v); };
+                struct EmitAll {
+                    decltype(st1)& f;
+                    __device__ __forceinline__ void one(uint64_t v) { f(v); }
+                } emit{st1};
+                struct Inv {
+                    __device__ __forceinline__ uint64_t operator()(int32_t k) const {
+                        const uint64_t r = p2::INV_SMALL[(uint32_t)(k < 0 ? -k : k) & (p2::INV_SMALL_N - 1)];
+                        return k < 0 ? 0xFFFFFFFF00000001ull - r : r;
+                    }
+                } inv;
+                zkb::ComputeBackend<EmitAll, Inv> be(emit, inv);
+                uint8_t shifted[zkb::IN], place[zkb::BUF];
+                int32_t f = sc3[0];
+                zkb::fill_with_bytes(be, bb, f, bin, sc3[1], sc3[2], shifted, place);
+            }
+            fused_bad |= out_of_range;
         } else { return; } break;
         case ZK_OP_KECCAK_F: if constexpr (WITH_BIGINT) {
             // K8: a whole Keccak-f[1600] as ONE op.  [200 state byte slots] -> every intermediate of the byte-table decomposition, in the

@@ -91,6 +91,11 @@ enum zk_opcode {
      * carries plane ids instead of flag slots: 8 bytes from LDS instead of 512 from L2 / HBM, and a wavefront whose 64 lanes agree
      * on the flag loads only the selected operand. */
     ZK_OP_FLAG_PLANES = 28,
+    ZK_OP_BYTEBUF_FILL = 29, /* macro-op (kernel K8), recorded by the engine's keccak256 precompile circuit only (opt-in, ZKGL_BYTEBUF_MACRO=1):
+                              * [buffer bytes x192, filled, input bytes x32, offset, meaningful] -> EVERY intermediate of ByteBuffer::fill_with_bytes
+                              * (the shift by `offset`, the 192 position markers, the 32 conditional placements, the new `filled`) in the order of
+                              * csrc/bytebuf_macro.hpp zkb::fill_with_bytes
+                              *                               (/root/reference/src/keccak256_round_function/buffer/mod.rs:69-136) */
     ZK_OP__COUNT
 };
 

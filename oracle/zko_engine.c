@@ -423,6 +423,67 @@ static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
             sh_compress(wd, wd + 8, &o);
             for (size_t i = 0; i < o.n; ++i) st(c, prog, &pc, lane, sbuf[i]);
         } break;
+        case ZK_OP_BYTEBUF_FILL: { /* include/zkgl_ir.h: ByteBuffer::fill_with_bytes (/root/reference/src/keccak256_round_function/buffer/mod.rs:69-136)
+                                     * restated over field elements, every intermediate written out in the order of its gates: x - 1 (FMA),
+                                     * is-zero flag + inverse (ZeroCheck), selections, and / or / not of flags (FMA), the masked source bytes */
+            enum { BUF = 192, IN = 32 };
+            uint64_t bytes[BUF], input[IN], shifted[IN], place[BUF];
+            for (int j = 0; j < BUF; ++j) bytes[j] = ld(c, prog[pc + j], lane, inst);
+            uint64_t filled = ld(c, prog[pc + BUF], lane, inst);
+            for (int j = 0; j < IN; ++j) input[j] = ld(c, prog[pc + BUF + 1 + j], lane, inst);
+            const uint64_t offset = ld(c, prog[pc + BUF + 1 + IN], lane, inst), meaningful = ld(c, prog[pc + BUF + 2 + IN], lane, inst);
+            pc += BUF + IN + 3;
+#define BB_OUT(v) st(c, prog, &pc, lane, (v))
+            for (int j = 0; j < IN; ++j) shifted[j] = input[j];
+            uint64_t off = zko_gl_sub(offset, 1);
+            BB_OUT(off);
+            for (int i = 1; i < IN; ++i) {
+                const uint64_t use = off == 0;
+                BB_OUT(use); BB_OUT(zko_gl_inv(off));
+                off = zko_gl_sub(off, 1);
+                BB_OUT(off);
+                for (int j = 0; j < IN; ++j) {
+                    shifted[j] = use ? (i + j < IN ? input[i + j] : 0) : shifted[j];
+                    BB_OUT(shifted[j]);
+                }
+            }
+            const uint64_t nothing = meaningful == 0;
+            BB_OUT(nothing); BB_OUT(zko_gl_inv(meaningful));
+            const uint64_t marker = zko_gl_sub(1, nothing);
+            BB_OUT(marker);
+            uint64_t tmp = filled;
+            for (int j = 0; j < BUF; ++j) {
+                const uint64_t here = tmp == 0;
+                BB_OUT(here); BB_OUT(zko_gl_inv(tmp));
+                place[j] = zko_gl_mul(here, marker);
+                BB_OUT(place[j]);
+                tmp = zko_gl_sub(tmp, 1);
+                BB_OUT(tmp);
+            }
+            uint64_t counter = meaningful, exhausted = meaningful == 0;
+            BB_OUT(exhausted); BB_OUT(zko_gl_inv(meaningful));
+            for (int idx = 0; idx < IN; ++idx) {
+                const uint64_t live = zko_gl_sub(1, exhausted);
+                BB_OUT(live);
+                const uint64_t src = zko_gl_mul(shifted[idx], live);
+                BB_OUT(src);
+                for (int j = idx; j < BUF; ++j) {
+                    bytes[j] = place[j - idx] ? src : bytes[j];
+                    BB_OUT(bytes[j]);
+                }
+                counter = zko_gl_sub(counter, 1);
+                BB_OUT(counter);
+                const uint64_t done = counter == 0;
+                BB_OUT(done); BB_OUT(zko_gl_inv(counter));
+                const uint64_t sum = zko_gl_add(done, exhausted);
+                BB_OUT(sum);
+                exhausted = zko_gl_sub(sum, zko_gl_mul(done, exhausted));
+                BB_OUT(exhausted);
+            }
+            filled = zko_gl_add(filled, meaningful);
+            BB_OUT(filled);
+#undef BB_OUT
+        } break;
         case ZK_OP_KECCAK_F: {
             uint64_t st8[25] = {0};
             for (int j = 0; j < 200; ++j) st8[j / 8] |= (ld(c, prog[pc + j], lane, inst) & 0xff) << (8 * (j % 8));

@@ -1,0 +1,75 @@
+"""K8, third macro-op: ByteBuffer::fill_with_bytes as ZK_OP_BYTEBUF_FILL (opt-in at record time: ZKGL_BYTEBUF_MACRO=1).  The keccak256
+precompile FSM recorded with the macro-op must be THE SAME circuit as the op-by-op recording — same variables, same gates, same cells —
+and the oracle's restatement of the macro-op must write the same value into every cell (reference cases of
+/root/reference/src/keccak256_round_function/mod.rs:1096-1144, all nine in one batch).  Device parity under -m gpu."""
+import numpy as np
+import pytest
+
+import zkgl
+from oracle import keccak_native as N
+from oracle import zko
+from test_keccak_fsm_host import REFERENCE_CASES, TABLE_ROWS, reference_case, streams
+
+
+def record(monkeypatch, macro, limit=2):
+    if macro:
+        monkeypatch.setenv("ZKGL_BYTEBUF_MACRO", "1")
+    else:
+        monkeypatch.delenv("ZKGL_BYTEBUF_MACRO", raising=False)
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
+    cs.configure_keccak()
+    cs.keccak256_round_function_entry_point(limit)
+    cs.pad_and_shrink()
+    return cs
+
+
+def test_macro_recording_is_the_same_circuit_and_the_oracle_fills_the_same_cells(monkeypatch):
+    plain, macro = record(monkeypatch, False), record(monkeypatch, True)
+    sp, sm = plain.stats(), macro.stats()
+    for k in ("rows_per_instance", "constraints_per_instance", "loop_slots", "outer_slots", "gate_instances"):
+        assert sp[k] == sm[k], k
+    assert sm["loop_ops"] < sp["loop_ops"] - 6 * 7000          # six fills of ~7.7 k ops each became six ops
+    insts = [reference_case(l, u)[1] for l, u in REFERENCE_CASES]
+    outer, loop = streams(insts, 2)
+    runs = []
+    for cs in (plain, macro):
+        r = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
+        r.resolve(outer, loop)
+        bad, nrel = r.check()
+        assert bad == 0 and nrel == cs.stats()["constraints_per_instance"] * len(insts)
+        runs.append(r)
+    assert np.array_equal(runs[0].oc, runs[1].oc) and np.array_equal(runs[0].lc, runs[1].lc)
+    for i, inst in enumerate(insts):
+        assert [int(runs[1].oc[c, i]) for c in macro.public_cells()] == inst["public_input"]
+
+
+@pytest.mark.gpu
+def test_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
+    """whole trace of the macro recording, plain and strand kernels, both check modes; seeding through the native FSM seeder"""
+    cs = record(monkeypatch, True)
+    insts = [reference_case(l, u)[1] for l, u in REFERENCE_CASES] * 8        # 72 instances x 2 cycles: a few wavefronts
+    outer, loop = streams(insts, 2)
+    r = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
+    r.resolve(outer, loop)
+    for strands in ("0", "1"):
+        monkeypatch.setenv("ZKGL_STRANDS", strands)
+        cs.set_batch(len(insts))
+        raw = loop.copy(); raw[:N.CARRIED] = 0
+        d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+        cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
+        cs.seed_carried_inputs(d_l)
+        assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
+        for stored in (False, True):
+            cs.set_check_mode(stored)
+            ok, f = cs.resolve_and_check()
+            assert ok, (strands, stored, f)
+        from test_gpu_cs import assert_trace_equal
+        assert_trace_equal(cs, r)
+        bad = loop.copy(); bad[300, 5] = 256                                  # a buffer byte that is not a byte: rejected in both modes
+        d_b = zk.DeviceBuffer.from_numpy(bad)
+        cs.bind_inputs(True, d_b, loop.shape[0])
+        for stored in (False, True):
+            cs.set_check_mode(stored)
+            ok, f = cs.resolve_and_check()
+            assert not ok
+    cs.set_check_mode(False)
