@@ -24,8 +24,12 @@
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZKB_LOOP _Pragma("unroll 1")
+#define ZKB_UNROLL _Pragma("unroll")
+#define ZKB_ROLLED _Pragma("unroll 1")
 #else
 #define ZKB_LOOP
+#define ZKB_UNROLL
+#define ZKB_ROLLED
 #endif
 
 namespace zkb {
@@ -33,34 +37,33 @@ namespace zkb {
 constexpr int BUF = 192, IN = 32;
 constexpr int N_INPUTS = BUF + 1 + IN + 2;   // buffer bytes, filled, input bytes, offset, meaningful — the macro-op's operand order
 
-// bytes[BUF] / filled: the buffer (updated in place); input[IN]: the 32 bytes read; offset: leading bytes to drop; meaningful: bytes to take.
-// E = element type of the byte arrays, V = scalar value type (host: both variables; device: uint8_t and int32_t)
+// The walk.  The backend owns the four byte arrays (buffer bytes, input, shifted, place) and exposes them through accessors whose index is
+// a compile-time-unrollable inner-loop variable wherever the device needs one: the device keeps them packed in registers and slides
+// them by one position per OUTER iteration (next_input_shift / next_placement), so that no array is ever indexed dynamically.
+//   in_at(j)        input[i + j] of the current shift iteration i (0 beyond the end)       shifted(j) / set_shifted(j, v)
+//   shifted_front() shifted[idx] of the current placement iteration idx                     place_rel(j) = place[j - idx]
+//   set_place(j, v) called for j = 0, 1, ... BUF - 1 in this order, once each               byte(j) / set_byte(j, v)
 template <class B>
-ZKB_HD void fill_with_bytes(B& be, typename B::E* bytes, typename B::V& filled, const typename B::E* input, typename B::V offset, typename B::V meaningful,
-                            typename B::E* shifted /* [IN] scratch */, typename B::E* place /* [BUF] scratch */) {
+ZKB_HD void fill_with_bytes(B& be, typename B::V& filled, typename B::V offset, typename B::V meaningful) {
     typedef typename B::V V;
-    // shift register: drop `offset` leading bytes
-    ZKB_LOOP
-    for (int j = 0; j < IN; ++j) shifted[j] = input[j];
+    // shift register: drop `offset` leading bytes (shifted starts as the input)
     V off = be.sub1(offset);
     ZKB_LOOP
     for (int i = 1; i < IN; ++i) {
         const V use_from_here = be.is_zero(off);
         off = be.sub1(off);
-        ZKB_LOOP
-        for (int j = 0; j < IN; ++j) {
-            const V from = i + j < IN ? (V)input[i + j] : be.zero();
-            shifted[j] = be.select(use_from_here, from, (V)shifted[j]);
-        }
+        be.next_input_shift();   // in_at(j) is now input[i + j]
+        ZKB_UNROLL
+        for (int j = 0; j < IN; ++j) be.set_shifted(j, be.select(use_from_here, be.in_at(j), be.shifted(j)));
     }
     // "start here" markers: position `filled`, only if there is something to fill
     const V nothing = be.is_zero(meaningful);
     const V marker = be.bnot(nothing);
     V tmp = filled;
-    ZKB_LOOP
+    ZKB_ROLLED
     for (int j = 0; j < BUF; ++j) {
         const V here = be.is_zero(tmp);
-        place[j] = be.band(here, marker);
+        be.set_place(j, be.band(here, marker));
         tmp = be.sub1(tmp);
     }
     V counter = meaningful;
@@ -68,18 +71,42 @@ ZKB_HD void fill_with_bytes(B& be, typename B::E* bytes, typename B::V& filled, 
     ZKB_LOOP
     for (int idx = 0; idx < IN; ++idx) {
         const V live = be.bnot(exhausted);
-        const V src = be.mul((V)shifted[idx], live);
-        ZKB_LOOP
-        for (int j = idx; j < BUF; ++j) bytes[j] = be.select((V)place[j - idx], src, (V)bytes[j]);
+        const V src = be.mul(be.shifted_front(), live);
+        ZKB_UNROLL
+        for (int j = 0; j < BUF; ++j)
+            if (j >= idx) be.set_byte(j, be.select(be.place_rel(j), src, be.byte(j)));
         counter = be.sub1(counter);
         const V done = be.is_zero(counter);
         exhausted = be.bor(done, exhausted);
+        be.next_placement();   // shifted_front() -> shifted[idx + 1], place_rel(j) -> place[j - (idx + 1)]
     }
     filled = be.add(filled, meaningful);
 }
 
-struct CountBackend {
-    typedef int E;
+// storage of the array-holding backends that index plainly (host gadget, counting): E = element type
+template <class E>
+struct PlainArrays {
+    E bytes_[BUF], input_[IN], shifted_[IN], place_[BUF];
+    E zero_;
+    int i_ = 0, idx_ = 0;
+    void load(const E* bytes, const E* input, E zero) {
+        for (int j = 0; j < BUF; ++j) bytes_[j] = bytes[j];
+        for (int j = 0; j < IN; ++j) input_[j] = shifted_[j] = input[j];
+        zero_ = zero; i_ = 0; idx_ = 0;
+    }
+    void next_input_shift() { ++i_; }
+    E in_at(int j) const { return i_ + j < IN ? input_[i_ + j] : zero_; }
+    E shifted(int j) const { return shifted_[j]; }
+    void set_shifted(int j, E v) { shifted_[j] = v; }
+    void set_place(int j, E v) { place_[j] = v; }
+    E shifted_front() const { return shifted_[idx_]; }
+    E place_rel(int j) const { return place_[j - idx_]; }
+    E byte(int j) const { return bytes_[j]; }
+    void set_byte(int j, E v) { bytes_[j] = v; }
+    void next_placement() { ++idx_; }
+};
+
+struct CountBackend : PlainArrays<int> {
     typedef int V;
     uint32_t n = 0;
     V sub1(V) { ++n; return 0; }
@@ -90,24 +117,27 @@ struct CountBackend {
     V bor(V, V) { n += 2; return 0; }
     V mul(V, V) { ++n; return 0; }
     V add(V, V) { ++n; return 0; }
-    V zero() { return 0; }
 };
 inline uint32_t n_outputs() {
     CountBackend cb;
-    int bytes[BUF] = {0}, input[IN] = {0}, shifted[IN], place[BUF], filled = 0;
-    fill_with_bytes(cb, bytes, filled, input, 0, 0, shifted, place);
+    int bytes[BUF] = {0}, input[IN] = {0}, filled = 0;
+    cb.load(bytes, input, 0);
+    fill_with_bytes(cb, filled, 0, 0);
     return cb.n;
 }
 
 // compute backend over small integers: every value of the structure is a byte, a flag or a counter in (-2^15, 2^15) for inputs in their
 // ranges (bytes < 256, filled <= 192, offset < 32, meaningful <= 32 — the caller checks).  Emit receives the outputs in order as field
 // elements: one(v) with v in [0, p).  inv(k) = k^-1 mod p for 0 < |k| < 4096 (the device's INV_SMALL table).
+// The arrays are PACKED (four bytes per 32-bit word, the place flags one bit each) and every access is at an index that is a constant
+// after unrolling: they live in registers.  The slides: next_input_shift drops the first byte of the input (zero enters at the end),
+// next_placement drops the first byte of `shifted` and moves the place flags up by one position.
 template <class Emit, class Inv>
 struct ComputeBackend {
-    typedef uint8_t E;
     typedef int32_t V;
     Emit& emit;
     Inv& inv;
+    uint32_t bytes_[BUF / 4], in_[IN / 4], sh_[IN / 4], pl_[BUF / 32];
     ZKB_HD ComputeBackend(Emit& e, Inv& i) : emit(e), inv(i) {}
     ZKB_HD static uint64_t fe(V v) { return v < 0 ? 0xFFFFFFFF00000001ull - (uint64_t)(-v) : (uint64_t)v; }
     ZKB_HD V out(V v) { emit.one(fe(v)); return v; }
@@ -124,7 +154,32 @@ struct ComputeBackend {
     ZKB_HD V bor(V a, V b) { const V s = out(a + b); return out(s - a * b); }
     ZKB_HD V mul(V a, V b) { return out(a * b); }
     ZKB_HD V add(V a, V b) { return out(a + b); }
-    ZKB_HD V zero() { return 0; }
+    // ---- the arrays
+    ZKB_HD static V get8(const uint32_t* w, int j) { return (V)((w[j >> 2] >> (8 * (j & 3))) & 0xffu); }
+    ZKB_HD static void put8(uint32_t* w, int j, V v) { w[j >> 2] = (w[j >> 2] & ~(0xffu << (8 * (j & 3)))) | (((uint32_t)v & 0xffu) << (8 * (j & 3))); }
+    ZKB_HD void next_input_shift() {
+#pragma unroll
+        for (int k = 0; k < IN / 4; ++k) in_[k] = (in_[k] >> 8) | (k + 1 < IN / 4 ? in_[k + 1] << 24 : 0u);
+    }
+    ZKB_HD V in_at(int j) const { return get8(in_, j); }
+    ZKB_HD V shifted(int j) const { return get8(sh_, j); }
+    ZKB_HD void set_shifted(int j, V v) { put8(sh_, j, v); }
+    // the walk sets place[0], place[1], ... place[BUF - 1] once each, in this order (a rolled loop): the flag enters at the top and the
+    // flags slide down one position per call, so that after the last call bit j holds place[j] — no dynamic index
+    ZKB_HD void set_place(int, V v) {
+#pragma unroll
+        for (int k = 0; k < BUF / 32; ++k) pl_[k] = (pl_[k] >> 1) | (k + 1 < BUF / 32 ? pl_[k + 1] << 31 : ((uint32_t)v & 1u) << 31);
+    }
+    ZKB_HD V shifted_front() const { return (V)(sh_[0] & 0xffu); }
+    ZKB_HD V place_rel(int j) const { return (V)((pl_[j >> 5] >> (j & 31)) & 1u); }
+    ZKB_HD V byte(int j) const { return get8(bytes_, j); }
+    ZKB_HD void set_byte(int j, V v) { put8(bytes_, j, v); }
+    ZKB_HD void next_placement() {
+#pragma unroll
+        for (int k = 0; k < IN / 4; ++k) sh_[k] = (sh_[k] >> 8) | (k + 1 < IN / 4 ? sh_[k + 1] << 24 : 0u);
+#pragma unroll
+        for (int k = BUF / 32 - 1; k >= 0; --k) pl_[k] = (pl_[k] << 1) | (k ? pl_[k - 1] >> 31 : 0u);
+    }
 };
 
 }  // namespace zkb

@@ -131,8 +131,7 @@ Boolean can_fill_bytes(G& g, const ByteBuffer& buf, zk_var bytes_to_fill) {
 // zkb::fill_with_bytes (bytebuf_macro.hpp); this is its HOST backend: every primitive records its gate, and its witness op unless the
 // whole fill is recorded as ONE macro-op (ZKGL_BYTEBUF_MACRO=1: ZK_OP_BYTEBUF_FILL, whose outputs are the pre-allocated variables the
 // walk then constrains — same variables, same gates, same cells as the op-by-op form).
-struct BufBackend {
-    typedef zk_var E;
+struct BufBackend : zkb::PlainArrays<zk_var> {
     typedef zk_var V;
     G& g;
     zk_var macro_next = ZK_VAR_NONE;
@@ -166,7 +165,6 @@ struct BufBackend {
         g.cs.place_gate(ZK_GATE_SELECT, vars, 4, nullptr, 0);
         return r;
     }
-    V zero() { return g.zero(); }
 };
 
 void fill_with_bytes(G& g, ByteBuffer& buf, const std::array<zk_var, 32>& input, zk_var offset, zk_var meaningful) {
@@ -186,8 +184,9 @@ void fill_with_bytes(G& g, ByteBuffer& buf, const std::array<zk_var, 32>& input,
         g.cs.emit_macro_op(ZK_OP_BYTEBUF_FILL, ins.data(), (uint32_t)ins.size(), first, n);
         be.macro_next = first;
     }
-    zk_var shifted[zkb::IN], place[zkb::BUF];
-    zkb::fill_with_bytes(be, buf.bytes.data(), buf.filled, input.data(), offset, meaningful, shifted, place);
+    be.load(buf.bytes.data(), input.data(), g.zero());
+    zkb::fill_with_bytes(be, buf.filled, offset, meaningful);
+    for (int j = 0; j < BUF; ++j) buf.bytes[j] = be.byte(j);
     if (use_macro && be.macro_next != first + n) throw ZkError(ZK_ERR_INVALID, "internal: the ByteBuffer gadget and its macro-op disagree on the output count");
     g.range_check_u8_pair(buf.filled, g.sub(g.constant(BUF), buf.filled));  // filled <= capacity
 }

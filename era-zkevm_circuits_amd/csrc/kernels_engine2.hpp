@@ -174,10 +174,16 @@ __device__ __noinline__ uint32_t sha256_rounds_stream(__amdgpu_buffer_rsrc_t rsr
     return emit.d;
 }
 
+struct BytebufInv {   // k^-1 mod p for 0 < |k| < INV_SMALL_N
+    __device__ __forceinline__ uint64_t operator()(int32_t k) const {
+        const uint64_t r = p2::INV_SMALL[(uint32_t)(k < 0 ? -k : k) & (p2::INV_SMALL_N - 1)];
+        return k < 0 ? 0xFFFFFFFF00000001ull - r : r;
+    }
+};
 // K8, out of line: ByteBuffer::fill_with_bytes with every intermediate streamed out (zkb::fill_with_bytes, bytebuf_macro.hpp): the byte
-// arrays are indexed dynamically (scratch), the values are small integers; cooperative like keccak_f_stream — every strand computes,
+// arrays are packed in registers (bytebuf_macro.hpp ComputeBackend), the values are small integers; cooperative like keccak_f_stream — every strand computes,
 // strand `share` stores every (mask + 1)-th run of eight outputs.
-__device__ __noinline__ uint32_t bytebuf_fill_stream(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_byte, uint32_t dst, uint32_t bstep, uint8_t* bytes, const uint8_t* input,
+__device__ __noinline__ uint32_t bytebuf_fill_stream(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_byte, uint32_t dst, uint32_t bstep, const uint32_t* packed /* 48 + 8 words */,
                                                       int32_t filled, int32_t offset, int32_t meaningful, uint32_t share, uint32_t n_share_mask) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     struct Emit {
@@ -193,16 +199,16 @@ __device__ __noinline__ uint32_t bytebuf_fill_stream(__amdgpu_buffer_rsrc_t rsrc
             ++cnt;
         }
     } emit{rsrc, lane_byte, uni(dst), bstep, 0u, uni(share), uni(n_share_mask)};
-    struct Inv {
-        __device__ __forceinline__ uint64_t operator()(int32_t k) const {
-            const uint64_t r = p2::INV_SMALL[(uint32_t)(k < 0 ? -k : k) & (p2::INV_SMALL_N - 1)];
-            return k < 0 ? 0xFFFFFFFF00000001ull - r : r;
-        }
-    } inv;
-    zkb::ComputeBackend<Emit, Inv> be(emit, inv);
-    uint8_t shifted[zkb::IN], place[zkb::BUF];
+    BytebufInv inv;
+    zkb::ComputeBackend<Emit, BytebufInv> be(emit, inv);
+#pragma unroll
+    for (int k = 0; k < zkb::BUF / 4; ++k) be.bytes_[k] = packed[k];
+#pragma unroll
+    for (int k = 0; k < zkb::IN / 4; ++k) be.in_[k] = be.sh_[k] = packed[zkb::BUF / 4 + k];
+#pragma unroll
+    for (int k = 0; k < zkb::BUF / 32; ++k) be.pl_[k] = 0;
     int32_t f = filled;
-    zkb::fill_with_bytes(be, bytes, f, input, offset, meaningful, shifted, place);
+    zkb::fill_with_bytes(be, f, offset, meaningful);
     return emit.d;
 }
 
@@ -792,7 +798,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             // gadget's allocation order (both walk zkb::fill_with_bytes).  The op works on small integers: an operand outside its range
             // (byte > 255, filled > 192, offset > 31, meaningful > 32 — each of them is range-checked by the circuit) is reported as the
             // fused mode's failure, and the values stored for it then violate the op's own gates.
-            uint8_t bb[zkb::BUF], bin[zkb::IN];   // indexed dynamically by the walk: scratch by design
+            uint32_t packed[zkb::BUF / 4 + zkb::IN / 4];   // buffer bytes, then input bytes, four per word (passed to the out-of-line walk)
             int32_t sc3[3] = {0, 0, 0};
             bool out_of_range = false;
 #pragma unroll 1
@@ -800,12 +806,18 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 uint64_t v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = c8 * 8 + k < (uint32_t)zkb::N_INPUTS ? ldv(prog[pc + 1 + c8 * 8 + k]) : 0;
+                // operand i: [0, 192) buffer bytes, 192 filled, [193, 225) input bytes, 225 offset, 226 meaningful; eight per step, so the
+                // words of `packed` are whole steps except around `filled` (step 24 holds filled + 7 input bytes, ...): assemble by position
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t i = c8 * 8 + k;
-                    if (i < (uint32_t)zkb::BUF) { out_of_range |= v[k] > 0xff; bb[i] = (uint8_t)v[k]; }
+                    if (i < (uint32_t)zkb::BUF) { out_of_range |= v[k] > 0xff; packed[i >> 2] = (k & 3) ? packed[i >> 2] | (((uint32_t)v[k] & 0xffu) << (8 * (i & 3))) : ((uint32_t)v[k] & 0xffu); }
                     else if (i == (uint32_t)zkb::BUF) { out_of_range |= v[k] > (uint64_t)zkb::BUF; sc3[0] = (int32_t)(v[k] & 0xff); }
-                    else if (i < (uint32_t)(zkb::BUF + 1 + zkb::IN)) { out_of_range |= v[k] > 0xff; bin[i - zkb::BUF - 1] = (uint8_t)v[k]; }
+                    else if (i < (uint32_t)(zkb::BUF + 1 + zkb::IN)) {
+                        const uint32_t m = i - zkb::BUF - 1;
+                        out_of_range |= v[k] > 0xff;
+                        packed[zkb::BUF / 4 + (m >> 2)] = (m & 3) ? packed[zkb::BUF / 4 + (m >> 2)] | (((uint32_t)v[k] & 0xffu) << (8 * (m & 3))) : ((uint32_t)v[k] & 0xffu);
+                    }
                     else if (i == (uint32_t)(zkb::BUF + 1 + zkb::IN)) { out_of_range |= v[k] > 31; sc3[1] = (int32_t)(v[k] & 31); }
                     else if (i == (uint32_t)(zkb::BUF + 2 + zkb::IN)) { out_of_range |= v[k] > 32; sc3[2] = (int32_t)(v[k] & 63); }
                 }
@@ -814,23 +826,23 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             pc += 1 + zkb::N_INPUTS + D;
             if constexpr (!WIDE) {
                 const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
-                dst = bytebuf_fill_stream(rsrc, lane_byte, dst, bstep, bb, bin, sc3[0], sc3[1], sc3[2], STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+                dst = bytebuf_fill_stream(rsrc, lane_byte, dst, bstep, packed, sc3[0], sc3[1], sc3[2], STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
             } else {
                 auto st1 = [&](uint64_t v) { st(v); };
                 struct EmitAll {
                     decltype(st1)& f;
                     __device__ __forceinline__ void one(uint64_t v) { f(v); }
                 } emit{st1};
-                struct Inv {
-                    __device__ __forceinline__ uint64_t operator()(int32_t k) const {
-                        const uint64_t r = p2::INV_SMALL[(uint32_t)(k < 0 ? -k : k) & (p2::INV_SMALL_N - 1)];
-                        return k < 0 ? 0xFFFFFFFF00000001ull - r : r;
-                    }
-                } inv;
-                zkb::ComputeBackend<EmitAll, Inv> be(emit, inv);
-                uint8_t shifted[zkb::IN], place[zkb::BUF];
+                BytebufInv inv;
+                zkb::ComputeBackend<EmitAll, BytebufInv> be(emit, inv);
+#pragma unroll
+                for (int k = 0; k < zkb::BUF / 4; ++k) be.bytes_[k] = packed[k];
+#pragma unroll
+                for (int k = 0; k < zkb::IN / 4; ++k) be.in_[k] = be.sh_[k] = packed[zkb::BUF / 4 + k];
+#pragma unroll
+                for (int k = 0; k < zkb::BUF / 32; ++k) be.pl_[k] = 0;
                 int32_t f = sc3[0];
-                zkb::fill_with_bytes(be, bb, f, bin, sc3[1], sc3[2], shifted, place);
+                zkb::fill_with_bytes(be, f, sc3[1], sc3[2]);
             }
             fused_bad |= out_of_range;
         } else { return; } break;

@@ -43,6 +43,17 @@ def test_macro_recording_is_the_same_circuit_and_the_oracle_fills_the_same_cells
         assert [int(runs[1].oc[c, i]) for c in macro.public_cells()] == inst["public_input"]
 
 
+def test_device_backend_walk_equals_the_gate_arithmetic_on_the_cpu(tmp_path):
+    """zkb::ComputeBackend — the device's register-packed, sliding form of the four byte arrays — is host-compilable: walked on the CPU
+    against a plain field-element backend (the gates' own arithmetic), every emitted value and the final buffer, random in-range operands"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "bbcheck")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "native", "bytebuf_compute_check.cpp")], check=True)
+    out = subprocess.run([exe, "300"], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok 300 trials"), out
+
+
 @pytest.mark.gpu
 def test_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
     """whole trace of the macro recording, plain and strand kernels, both check modes; seeding through the native FSM seeder"""
