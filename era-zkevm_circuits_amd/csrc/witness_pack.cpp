@@ -884,6 +884,93 @@ int zk_pack_code_unpacker_witness_tails(const zk_code_unpacker_witness* w, uint3
     }
     return ZK_OK;
 }
+// The SHA-256 precompile FSM with the queue states its neighbours' witnesses hold: the request queue's witness is a VecDeque of
+// (LogQuery, previous tail) (input.rs:85-89: CircuitQueueRawWitness) — the 4-word head before each pop — and the memory queue it
+// writes (two reads per round, one digest write per call) is the RAM permutation's unsorted queue, whose witness holds the tail
+// after every push here.  The rest of the 60 carried words is integer state: flags, call parameters, timestamps and the SHA-256
+// inner state, one native compression per cycle (mod.rs:199-340).  Nothing is left to seed: the chain of 2 790 dependent
+// permutations per instance that the device pass spends 38 ms on is data the host already has.
+int zk_pack_sha256_witness_tails(const zk_sha256_round_function_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words,
+                                 const uint64_t* request_previous_tails, const uint64_t* memory_tails, uint32_t n_memory_tails) {
+    if ((w && w->n_requests && !request_previous_tails) || (n_memory_tails && !memory_tails))
+        return bad(ZK_ERR_INVALID, "zk_pack_sha256_witness_tails: null tails (use zk_pack_sha256_witness and device seeding)");
+    if (int rc = zk_pack_sha256_witness(w, limit, instance, batch, outer_words, loop_words)) return rc;
+    static const uint32_t IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    const zk_sha256_fsm_witness& f = w->hidden_fsm_input;
+    const uint64_t P = 0xFFFFFFFF00000001ull;
+    bool rpc, rwfr, completed;
+    uint32_t state[8];
+    uint64_t ts_read = 0, ts_write = 0, input_page = 0, input_offset = 0, output_page = 0, output_offset = 0, num_rounds = 0;
+    const zk_queue_state_witness& rq = w->start_flag ? w->initial_log_queue_state : f.log_queue_state;
+    const zk_full_queue_state_witness& mq = w->start_flag ? w->initial_memory_queue_state : f.memory_queue_state;
+    uint64_t req_head[4], req_len = rq.length, mem_tail[12], mem_len = mq.length;
+    for (int k = 0; k < 4; ++k) req_head[k] = rq.head[k];
+    for (int k = 0; k < 12; ++k) mem_tail[k] = mq.tail[k];
+    if (w->start_flag) { rpc = true; rwfr = false; completed = false; for (int i = 0; i < 8; ++i) state[i] = IV[i]; }
+    else {
+        rpc = f.read_precompile_call; rwfr = f.read_words_for_round; completed = f.completed;
+        for (int i = 0; i < 8; ++i) state[i] = f.sha256_inner_state[i];
+        ts_read = f.timestamp_to_use_for_read; ts_write = f.timestamp_to_use_for_write;
+        input_page = f.input_page; input_offset = f.input_offset; output_page = f.output_page; output_offset = f.output_offset; num_rounds = f.num_rounds;
+    }
+    if (rpc && req_len == 0) { rpc = false; rwfr = false; completed = true; }   // can_finish_immediatelly (mod.rs:120-137)
+    uint32_t next_req = 0, next_read = 0, next_push = 0;
+    const size_t lanes = (size_t)batch * limit;
+    auto push = [&]() -> bool {
+        if (next_push >= n_memory_tails) return false;
+        for (int k = 0; k < 12; ++k) mem_tail[k] = memory_tails[12 * (size_t)next_push + k];
+        ++next_push; ++mem_len;
+        return true;
+    };
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        const bool pops = rpc && req_len != 0;
+        if (pops) for (int k = 0; k < 4; ++k) req_head[k] = request_previous_tails[4 * (size_t)next_req + k];   // the head before this pop
+        l.w(rpc ? 1 : 0); l.w(rwfr ? 1 : 0); l.w(completed ? 1 : 0);
+        for (int i = 0; i < 8; ++i) for (int k = 0; k < 4; ++k) l.w((state[i] >> (8 * k)) & 0xff);
+        l.w(ts_read); l.w(ts_write); l.w(input_page); l.w(input_offset); l.w(output_page); l.w(output_offset); l.w(num_rounds);
+        l.arr(req_head); l.w(req_len); l.arr(mem_tail); l.w(mem_len);
+        if (l.k != 60) return bad(ZK_ERR_INVALID, "internal: sha256 carried layout");
+        if (rpc) {
+            const zk_log_query_witness* call = nullptr;
+            if (pops) {
+                call = &w->requests_queue_witness[next_req++];
+                --req_len;
+                for (int k = 0; k < 4; ++k)
+                    req_head[k] = next_req < w->n_requests ? request_previous_tails[4 * (size_t)next_req + k] : req_len == 0 ? rq.tail[k] : w->hidden_fsm_output.log_queue_state.head[k];
+            }
+            input_offset = call ? call->key[0] : 0; output_offset = call ? call->key[2] : 0; input_page = call ? call->key[4] : 0;
+            output_page = call ? call->key[5] : 0; num_rounds = call ? call->key[6] : 0;
+            ts_read = call ? call->timestamp : 0;
+            ts_write = ts_read + 1;
+        }
+        const bool reset_buffer = rpc || completed;
+        rwfr = rpc || rwfr;
+        rpc = false;
+        const bool should_read = num_rounds != 0;
+        uint32_t block[16] = {0};
+        for (int r = 0; r < 2; ++r) {
+            if (should_read && next_read < w->n_reads) { for (int i = 0; i < 8; ++i) block[8 * r + i] = w->memory_reads_witness[next_read][7 - i]; ++next_read; }
+            if (should_read && !push()) return bad(ZK_ERR_INVALID, "zk_pack_sha256_witness_tails: fewer memory tails than pushes");
+            if (rwfr) input_offset += 1;
+        }
+        if (rwfr) num_rounds = num_rounds ? num_rounds - 1 : P - 1;
+        if (reset_buffer) for (int i = 0; i < 8; ++i) state[i] = IV[i];
+        sha256_compress_host(state, block);
+        const bool write_result = rwfr && num_rounds == 0;
+        if (write_result && !push()) return bad(ZK_ERR_INVALID, "zk_pack_sha256_witness_tails: fewer memory tails than pushes");
+        const bool input_is_empty = req_len == 0;
+        rpc = write_result && !input_is_empty;
+        completed = (write_result && input_is_empty) || completed;
+        rwfr = !(rpc || completed);
+    }
+    return ZK_OK;
+}
+uint32_t zk_sha256_given_words(uint32_t words[60]) {
+    for (uint32_t i = 0; i < 60; ++i) words[i] = i;
+    return 60;
+}
+
 uint32_t zk_code_unpacker_given_words(uint32_t words[74]) {
     for (uint32_t i = 0; i < 74; ++i) words[i] = i;
     return 74;

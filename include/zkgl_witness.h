@@ -212,6 +212,17 @@ typedef struct zk_sha256_round_function_witness {
 int zk_pack_sha256_witness(const zk_sha256_round_function_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                            uint64_t *outer_words, uint64_t *loop_words);
 
+/* The same with every carried word written by the host (nothing to seed: zk_sha256_given_words -> zk_cs_set_seed_given):
+ * `request_previous_tails[n_requests][4]` = the head of the request queue before each pop — the previous_tail bincode carries beside
+ * every element of the witness (input.rs:85-89); `memory_tails[k][12]` = the memory queue's tail after the k-th push of this instance
+ * (two reads per round with rounds left, one digest write per finished call, in that order) — the previous tails of the RAM
+ * permutation's unsorted queue witness.  Flags, call parameters, timestamps and the SHA-256 inner state (one native compression per
+ * cycle) are walked on the host.  ZK_ERR_INVALID when there are fewer memory tails than pushes. */
+int zk_pack_sha256_witness_tails(const zk_sha256_round_function_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                                 uint64_t *outer_words, uint64_t *loop_words, const uint64_t *request_previous_tails,
+                                 const uint64_t *memory_tails, uint32_t n_memory_tails);
+uint32_t zk_sha256_given_words(uint32_t words[60]);
+
 /* Keccak256RoundFunctionCircuitInstanceWitness, /root/reference/src/keccak256_round_function/input.rs (FSM :29-39, call params
  * mod.rs:48-55, ByteBuffer buffer/mod.rs:42-48: bytes[192] + filled) */
 typedef struct zk_keccak_fsm_witness {

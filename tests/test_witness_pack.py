@@ -408,6 +408,87 @@ def test_sha256_packer_walks_the_fsm_schedule():
     assert np.array_equal(loop, el)
 
 
+def _sha256_packed_with_tails():
+    """a start instance that stops in the middle of a call and its continuation, packed with the queue states the reference's
+    witnesses hold: previous tails of the requests, the memory queue's tail after every push (= the RAM permutation's witness)"""
+    from oracle import sha256_native as shn, zko
+    from oracle.storage_native import encode
+    rng = np.random.default_rng(257)
+    msgs = [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in (10, 100, 64 * 3 - 9, 0)]
+    reqs = [shn.request(m, 1 + 2 * i, 10 + i, 3 * i, 9000 + i, i) for i, m in enumerate(msgs)]
+    limit = 5
+    first = shn.instance(reqs, limit)
+    second = shn.instance(first["rest"][0], limit, start_flag=False, fsm_in=first["fsm_out"], obs_req=first["obs_req"], obs_mem=first["obs_mem"],
+                          pending=first["rest"][1])
+    insts = [first, second]
+    outer = np.zeros((87, 2), dtype=np.uint64); loop = np.full((112, 2 * limit), 5, dtype=np.uint64)
+    all_reads = [v for r in reqs for v in r["reads"]]
+    consumed_reads = consumed_reqs = 0
+    given = None
+    for i, inst in enumerate(insts):
+        o = inst["outer"]
+        w = zkgl.Sha256RoundFunctionWitness()
+        w.start_flag = int(o[0])
+        w.initial_log_queue_state, w.initial_memory_queue_state = _q4(o[1:10]), _q12(o[10:35])
+        _sha_fsm(w.hidden_fsm_input, o[35:87])
+        w.hidden_fsm_output.log_queue_state = _q4(inst["fsm_out"]["req"])
+        rows = np.array(inst["rows"], dtype=np.uint64)
+        n_req = int(sum(1 for r in rows if r[60:96].any()))
+        n_rd = int(sum((1 if r[96:104].any() else 0) + (1 if r[104:112].any() else 0) for r in rows))
+        rq = reqs[consumed_reqs:consumed_reqs + n_req]                  # what this instance pops
+        rd = all_reads[consumed_reads:]
+        qa = (zkgl.LogQueryWitness * max(len(rq), 1))(*[_lq(r["query"]) for r in rq])
+        ra = ((zkgl.C.c_uint32 * 8) * max(len(rd), 1))()
+        for dst, v in zip(ra, rd):
+            dst[:] = [(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
+        w.requests_queue_witness, w.n_requests, w.memory_reads_witness, w.n_reads = qa, len(rq), ra, len(rd)
+        start_req = o[1:10] if o[0] else o[35 + 18:35 + 27]
+        start_mem = o[10:35] if o[0] else o[35 + 27:35 + 52]
+        head, prev = [int(v) for v in start_req[0:4]], []
+        for r in rq:
+            prev.append(head)
+            head = zko.queue_tail4_push20(head, encode(r["query"]))
+        mt, mtails = [int(v) for v in start_mem[12:24]], []
+        for q in inst["pushed"]:
+            mt = zko.queue_full_push(mt, zko.memory_query_encode(q))
+            mtails.append(mt)
+        given = zkgl.pack_sha256_witness_tails(w, limit, i, outer, loop, np.array(prev or [[0] * 4], dtype=np.uint64), np.array(mtails, dtype=np.uint64).reshape(-1, 12))
+        consumed_reqs += n_req; consumed_reads += n_rd
+    return outer, loop, insts, limit, given
+
+
+def test_sha256_packer_with_the_witness_queue_states_writes_every_carried_word():
+    """zk_pack_sha256_witness_tails: flags, call parameters and the SHA-256 inner state walked natively, queue states from the witness —
+    the stream equals the native restatement's in all 112 words of every cycle (the device pass it replaces is a chain of dependent
+    Poseidon2 permutations: 38 ms against a 10 ms step at full size)"""
+    outer, loop, insts, limit, given = _sha256_packed_with_tails()
+    assert given == list(range(60))
+    eo = np.array([x["outer"] for x in insts], dtype=np.uint64).T
+    el = np.array([r for x in insts for r in x["rows"]], dtype=np.uint64).T.copy()
+    assert np.array_equal(outer, eo)
+    assert np.array_equal(loop, el), np.argwhere(loop != el)[:8]
+
+
+@pytest.mark.gpu
+def test_sha256_fsm_with_the_witness_queue_states_needs_no_device_seeding(zk):
+    outer, loop, insts, limit, given = _sha256_packed_with_tails()
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
+    cs.configure_sha256()
+    cs.sha256_round_function_entry_point(limit)
+    cs.pad_and_shrink()
+    cs.set_batch(len(insts))
+    cs.set_seed_given(given)
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    cs.seed_carried_inputs(d_l)                      # every carried word is declared given: no kernel runs
+    assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["public_input"]
+
+
 def test_keccak_packer_walks_the_fsm_schedule():
     """the keccak precompile: six conditional unaligned reads per cycle through the 192-byte buffer — requests and read values placed
     at their cycles by the schedule walk; several requests (aligned, unaligned, empty, block-sized) and a continuation instance"""
