@@ -966,6 +966,148 @@ int zk_pack_sha256_witness_tails(const zk_sha256_round_function_witness* w, uint
     }
     return ZK_OK;
 }
+namespace {
+void keccak_f1600_host(uint64_t s[25]) {   // FIPS 202
+    static const uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL, 0x0000000080000001ULL,
+        0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+        0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    static const int RHO[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    static const int PI[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    auto rotl = [](uint64_t x, int n) { return (x << n) | (x >> (64 - n)); };
+    for (int r = 0; r < 24; ++r) {
+        uint64_t c[5];
+        for (int x = 0; x < 5; ++x) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+        for (int x = 0; x < 5; ++x) { const uint64_t d = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1); for (int y = 0; y < 25; y += 5) s[y + x] ^= d; }
+        uint64_t t = s[1];
+        for (int i = 0; i < 24; ++i) { const int j = PI[i]; const uint64_t b = s[j]; s[j] = rotl(t, RHO[i]); t = b; }
+        for (int y = 0; y < 25; y += 5) {
+            uint64_t row[5];
+            for (int x = 0; x < 5; ++x) row[x] = s[y + x];
+            for (int x = 0; x < 5; ++x) s[y + x] = row[x] ^ (~row[(x + 1) % 5] & row[(x + 2) % 5]);
+        }
+        s[0] ^= RC[r];
+    }
+}
+}  // namespace
+
+// The Keccak-256 precompile FSM with the queue states its neighbours' witnesses hold (as zk_pack_sha256_witness_tails): request queue
+// heads from the witness's previous tails, memory queue tails from the RAM permutation's witness (up to six reads and one digest write
+// per cycle, in that order).  The rest of the 423 carried words is integer state walked here: flags, call parameters, the 192-byte
+// ByteBuffer (fill_with_bytes / consume: buffer/mod.rs:69-163) and the sponge state, one native Keccak-f per cycle (mod.rs:497-590).
+int zk_pack_keccak_witness_tails(const zk_keccak_round_function_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words,
+                                 const uint64_t* request_previous_tails, const uint64_t* memory_tails, uint32_t n_memory_tails) {
+    if ((w && w->n_requests && !request_previous_tails) || (n_memory_tails && !memory_tails))
+        return bad(ZK_ERR_INVALID, "zk_pack_keccak_witness_tails: null tails (use zk_pack_keccak_witness and device seeding)");
+    if (int rc = zk_pack_keccak_witness(w, limit, instance, batch, outer_words, loop_words)) return rc;
+    constexpr uint32_t RATE = 136, BUF = 192, READS = 6;
+    const zk_keccak_fsm_witness& f = w->hidden_fsm_input;
+    bool rpc, ruw, padding_round, completed, needs_full = false;
+    uint64_t state[25] = {0};
+    uint8_t buffer[BUF] = {0};
+    uint64_t ts_read = 0, ts_write = 0, input_page = 0, byte_offset = 0, byte_length = 0, output_page = 0, output_word_offset = 0, filled = 0;
+    const zk_queue_state_witness& rq = w->start_flag ? w->initial_log_queue_state : f.log_queue_state;
+    const zk_full_queue_state_witness& mq = w->start_flag ? w->initial_memory_queue_state : f.memory_queue_state;
+    uint64_t req_head[4], req_len = rq.length, mem_tail[12], mem_len = mq.length;
+    for (int k = 0; k < 4; ++k) req_head[k] = rq.head[k];
+    for (int k = 0; k < 12; ++k) mem_tail[k] = mq.tail[k];
+    if (w->start_flag) { rpc = true; ruw = padding_round = completed = false; }
+    else {
+        rpc = f.read_precompile_call; ruw = f.read_unaligned_words_for_round; padding_round = f.padding_round; completed = f.completed;
+        for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) for (int k = 0; k < 8; ++k) state[i + 5 * j] |= (uint64_t)f.keccak_internal_state[i][j][k] << (8 * k);
+        ts_read = f.timestamp_to_use_for_read; ts_write = f.timestamp_to_use_for_write;
+        input_page = f.input_page; byte_offset = f.input_memory_byte_offset; byte_length = f.input_memory_byte_length;
+        output_page = f.output_page; output_word_offset = f.output_word_offset; needs_full = f.needs_full_padding_round;
+        for (uint32_t j = 0; j < BUF; ++j) buffer[j] = f.buffer_bytes[j];
+        filled = f.buffer_filled;
+    }
+    if (rpc && req_len == 0) { rpc = false; ruw = false; completed = true; }   // can_finish_immediatelly (mod.rs:200-213)
+    uint32_t next_req = 0, next_read = 0, next_push = 0;
+    const size_t lanes = (size_t)batch * limit;
+    auto push = [&]() -> bool {
+        if (next_push >= n_memory_tails) return false;
+        for (int k = 0; k < 12; ++k) mem_tail[k] = memory_tails[12 * (size_t)next_push + k];
+        ++next_push; ++mem_len;
+        return true;
+    };
+    for (uint32_t c = 0; c < limit; ++c) {
+        Out l{loop_words + (size_t)instance * limit + c, lanes};
+        const bool pops = rpc && req_len != 0;
+        if (pops) for (int k = 0; k < 4; ++k) req_head[k] = request_previous_tails[4 * (size_t)next_req + k];
+        l.w(rpc ? 1 : 0); l.w(ruw ? 1 : 0); l.w(padding_round ? 1 : 0); l.w(completed ? 1 : 0);
+        for (int lane = 0; lane < 25; ++lane) for (int k = 0; k < 8; ++k) l.w((state[lane] >> (8 * k)) & 0xff);
+        l.w(ts_read); l.w(ts_write); l.w(input_page); l.w(byte_offset); l.w(byte_length); l.w(output_page); l.w(output_word_offset); l.w(needs_full ? 1 : 0);
+        l.arr(buffer); l.w(filled);
+        l.arr(req_head); l.w(req_len); l.arr(mem_tail); l.w(mem_len);
+        if (l.k != 423) return bad(ZK_ERR_INVALID, "internal: keccak carried layout");
+        const zk_log_query_witness* call = nullptr;
+        if (pops) {
+            call = &w->requests_queue_witness[next_req++];
+            --req_len;
+            for (int k = 0; k < 4; ++k)
+                req_head[k] = next_req < w->n_requests ? request_previous_tails[4 * (size_t)next_req + k] : req_len == 0 ? rq.tail[k] : w->hidden_fsm_output.log_queue_state.head[k];
+        }
+        const uint64_t call_length = call ? call->key[1] : 0;
+        if (rpc) {
+            byte_offset = call ? call->key[0] : 0; byte_length = call_length; output_word_offset = call ? call->key[2] : 0;
+            input_page = call ? call->key[4] : 0; output_page = call ? call->key[5] : 0;
+            needs_full = call_length % RATE == 0;
+            ts_read = call ? call->timestamp : 0;
+            ts_write = ts_read + 1;
+        }
+        const bool reset_buffer = rpc || completed;
+        if (rpc && call_length == 0) padding_round = true;
+        if (rpc && call_length != 0) ruw = true;
+        rpc = false;
+        if (reset_buffer) { for (auto& b : buffer) b = 0; filled = 0; for (auto& x : state) x = 0; }
+        for (uint32_t r = 0; r < READS; ++r) {
+            const uint64_t unalignment = byte_offset % 32, at_most = 32 - unalignment;
+            const uint64_t meaningful = byte_length < at_most ? byte_length : at_most;
+            const bool should_read = meaningful != 0 && filled + meaningful <= BUF && ruw;
+            uint8_t be[32] = {0};   // value.to_be_bytes()
+            if (should_read && next_read < w->n_reads) {
+                for (int m = 0; m < 32; ++m) be[m] = (uint8_t)(w->memory_reads_witness[next_read][7 - m / 4] >> (8 * (3 - m % 4)));
+                ++next_read;
+            }
+            if (should_read) {
+                if (!push()) return bad(ZK_ERR_INVALID, "zk_pack_keccak_witness_tails: fewer memory tails than pushes");
+                byte_offset += meaningful; byte_length -= meaningful;
+                for (uint64_t idx = 0; idx < meaningful; ++idx)   // fill_with_bytes: `meaningful` bytes from `unalignment` on, at position `filled`
+                    if (filled + idx < BUF) buffer[filled + idx] = unalignment + idx < 32 ? be[unalignment + idx] : 0;
+                filled += meaningful;
+            }
+        }
+        const bool zero_bytes_left = byte_length == 0;
+        const uint64_t currently_filled = filled;
+        uint8_t block[RATE];
+        for (uint32_t j = 0; j < RATE; ++j) block[j] = buffer[j];
+        for (uint32_t j = 0; j < BUF; ++j) buffer[j] = j + RATE < BUF ? buffer[j + RATE] : 0;   // consume::<136>
+        filled = filled >= RATE ? filled - RATE : 0;
+        const bool buffer_now_empty = filled == 0;
+        const bool apply_padding = zero_bytes_left && buffer_now_empty && ruw && !needs_full;
+        if (apply_padding) {
+            if (currently_filled < RATE - 1) block[currently_filled] = 0x01;
+            block[RATE - 1] = currently_filled == RATE - 1 ? 0x81 : 0x80;
+        }
+        if (padding_round) { for (auto& b : block) b = 0; block[0] = 0x01; block[RATE - 1] = 0x80; }
+        for (uint32_t j = 0; j < RATE; ++j) state[j / 8] ^= (uint64_t)block[j] << (8 * (j % 8));
+        keccak_f1600_host(state);
+        const bool write_result = apply_padding || padding_round;
+        if (write_result && !push()) return bad(ZK_ERR_INVALID, "zk_pack_keccak_witness_tails: fewer memory tails than pushes");
+        const bool input_is_empty = req_len == 0;
+        rpc = write_result && !input_is_empty;
+        completed = (write_result && input_is_empty) || completed;
+        padding_round = ruw && zero_bytes_left && buffer_now_empty && needs_full;
+        ruw = !(rpc || padding_round || completed);
+    }
+    return ZK_OK;
+}
+uint32_t zk_keccak_given_words(uint32_t words[423]) {
+    for (uint32_t i = 0; i < 423; ++i) words[i] = i;
+    return 423;
+}
+
 uint32_t zk_sha256_given_words(uint32_t words[60]) {
     for (uint32_t i = 0; i < 60; ++i) words[i] = i;
     return 60;

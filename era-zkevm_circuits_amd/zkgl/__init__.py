@@ -380,6 +380,17 @@ def pack_code_unpacker_witness(w, limit, instance, outer, loop):
     _pack(lib().zk_pack_code_unpacker_witness, w, limit, instance, outer, loop, 125, 101)
 
 
+def pack_keccak_witness_tails(w, limit, instance, outer, loop, request_previous_tails, memory_tails):
+    """zk_pack_keccak_witness_tails: every carried word from the witness; returns the given words (all 423)"""
+    assert outer.shape[0] == 474 and loop.shape[0] == 507 and loop.shape[1] == outer.shape[1] * limit
+    rp = np.ascontiguousarray(request_previous_tails, dtype=np.uint64); mt = np.ascontiguousarray(memory_tails, dtype=np.uint64).reshape(-1, 12)
+    _check(lib().zk_pack_keccak_witness_tails(C.byref(w), limit, instance, outer.shape[1], outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p),
+                                              rp.ctypes.data_as(C.c_void_p), mt.ctypes.data_as(C.c_void_p), mt.shape[0]))
+    words = (C.c_uint32 * 423)()
+    n = lib().zk_keccak_given_words(words)
+    return list(words[:n])
+
+
 def pack_sha256_witness_tails(w, limit, instance, outer, loop, request_previous_tails, memory_tails):
     """zk_pack_sha256_witness_tails: every carried word from the witness ([n, 4] request previous tails, [pushes, 12] memory tails);
     returns the given words (all 60)"""

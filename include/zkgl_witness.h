@@ -251,6 +251,14 @@ typedef struct zk_keccak_round_function_witness {
  * mod.rs:300-420; buffer/mod.rs:90-163) — to place every request and read value at its cycle; 423 carried words zeroed */
 int zk_pack_keccak_witness(const zk_keccak_round_function_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                            uint64_t *outer_words, uint64_t *loop_words);
+/* The same with every carried word written by the host (zk_keccak_given_words -> zk_cs_set_seed_given), as zk_pack_sha256_witness_tails:
+ * `request_previous_tails[n_requests][4]`, `memory_tails[k][12]` = the memory queue's tail after the k-th push of this instance (up to six
+ * reads, then the digest write of a finished call, per cycle).  The ByteBuffer and the sponge state (one native Keccak-f per cycle)
+ * are walked on the host. */
+int zk_pack_keccak_witness_tails(const zk_keccak_round_function_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                                 uint64_t *outer_words, uint64_t *loop_words, const uint64_t *request_previous_tails,
+                                 const uint64_t *memory_tails, uint32_t n_memory_tails);
+uint32_t zk_keccak_given_words(uint32_t words[423]);
 
 /* ---- LogDemuxerCircuitInstanceWitness, /root/reference/src/demux_log_queue/input.rs:118-121 (FSM :26-34, input data :57-59; output
  * queues in the FSM's field order: storage, events, l1 messages, keccak256, sha256, ecrecover) */

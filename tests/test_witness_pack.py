@@ -492,7 +492,49 @@ def test_sha256_fsm_with_the_witness_queue_states_needs_no_device_seeding(zk):
 def test_keccak_packer_walks_the_fsm_schedule():
     """the keccak precompile: six conditional unaligned reads per cycle through the 192-byte buffer — requests and read values placed
     at their cycles by the schedule walk; several requests (aligned, unaligned, empty, block-sized) and a continuation instance"""
-    from oracle import keccak_native as kn
+    outer, loop, insts = _keccak_packed(False)
+    eo = np.array([x["outer"] for x in insts], dtype=np.uint64).T
+    el = np.array([r for x in insts for r in x["rows"]], dtype=np.uint64).T.copy()
+    el[0:423] = 0
+    assert np.array_equal(outer, eo)
+    assert np.array_equal(loop, el)
+
+
+def test_keccak_packer_with_the_witness_queue_states_writes_every_carried_word():
+    """zk_pack_keccak_witness_tails: flags, parameters, the ByteBuffer and the sponge state (one native Keccak-f per cycle) walked on the
+    host, queue states from the witness — all 507 words of every cycle equal the native restatement's"""
+    outer, loop, insts = _keccak_packed(True)
+    eo = np.array([x["outer"] for x in insts], dtype=np.uint64).T
+    el = np.array([r for x in insts for r in x["rows"]], dtype=np.uint64).T.copy()
+    assert np.array_equal(outer, eo)
+    assert np.array_equal(loop, el), np.argwhere(loop != el)[:8]
+
+
+@pytest.mark.gpu
+def test_keccak_fsm_with_the_witness_queue_states_needs_no_device_seeding(zk):
+    from test_keccak_fsm_host import fsm_cs
+    outer, loop, insts = _keccak_packed(True)
+    limit = loop.shape[1] // len(insts)
+    cs = fsm_cs(limit)
+    cs.set_batch(len(insts))
+    cs.set_seed_given(list(range(423)))
+    try:
+        d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+        cs.bind_inputs(False, d_o, outer.shape[0])
+        cs.bind_inputs(True, d_l, loop.shape[0])
+        cs.seed_carried_inputs(d_l)                      # every carried word is declared given: no kernel runs
+        assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
+        ok, f = cs.resolve_and_check()
+        assert ok, f
+        for i, inst in enumerate(insts):
+            assert cs.public_inputs(i) == inst["public_input"]
+    finally:
+        cs.set_seed_given([])
+
+
+def _keccak_packed(tails):
+    from oracle import keccak_native as kn, zko
+    from oracle.storage_native import encode
     rng = np.random.default_rng(1600)
     specs = [(50, 0), (135, 31), (0, 0), (136, 0), (200, 7)]
     reqs = [kn.request(bytes(rng.integers(0, 256, size=n, dtype=np.uint8)), 1 + 2 * i, 10 + i, 64 * i + mis, 9000 + i, i) for i, (n, mis) in enumerate(specs)]
@@ -529,14 +571,30 @@ def test_keccak_packer_walks_the_fsm_schedule():
         for dst, v in zip(ra, rd):
             dst[:] = [(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
         w.requests_queue_witness, w.n_requests, w.memory_reads_witness, w.n_reads = qa, len(rq), ra, len(rd)
-        zkgl.pack_keccak_witness(w, limit, i, outer, loop)
+        n_popped = (len(reqs) - len(inst["rest"][0])) - used_reqs
+        if not tails:
+            zkgl.pack_keccak_witness(w, limit, i, outer, loop)
+        else:
+            # the queue states the reference's witnesses hold: the request queue's head before every pop of this instance, the memory
+            # queue's tail after every push (the RAM permutation's unsorted queue witness)
+            qa2 = (zkgl.LogQueryWitness * max(n_popped, 1))(*[_lq(r["query"]) for r in rq[:n_popped]])
+            w.requests_queue_witness, w.n_requests = qa2, n_popped
+            w.hidden_fsm_output.log_queue_state = _q4(inst["fsm_out"]["req"])
+            start_req = o[1:10] if o[0] else x[405:414]
+            start_mem = o[10:35] if o[0] else x[414:439]
+            head, prev = [int(v) for v in start_req[0:4]], []
+            for r in rq[:n_popped]:
+                prev.append(head)
+                head = zko.queue_tail4_push20(head, encode(r["query"]))
+            mt, mtails = [int(v) for v in start_mem[12:24]], []
+            for q in inst["pushed"]:
+                mt = zko.queue_full_push(mt, zko.memory_query_encode(q))
+                mtails.append(mt)
+            given = zkgl.pack_keccak_witness_tails(w, limit, i, outer, loop, np.array(prev or [[0] * 4], dtype=np.uint64), np.array(mtails, dtype=np.uint64).reshape(-1, 12))
+            assert given == list(range(423))
         used_reqs = len(reqs) - len(inst["rest"][0])
         used_reads = len(all_reads) - len(inst["rest"][1]) - sum(len(r["reads"]) for r in inst["rest"][0])
-    eo = np.array([x["outer"] for x in insts], dtype=np.uint64).T
-    el = np.array([r for x in insts for r in x["rows"]], dtype=np.uint64).T.copy()
-    el[0:423] = 0
-    assert np.array_equal(outer, eo)
-    assert np.array_equal(loop, el)
+    return outer, loop, insts
 
 
 @pytest.mark.gpu
