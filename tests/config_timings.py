@@ -80,6 +80,7 @@ if want("C3k"):
     B = 128
     outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
     timed("C3 keccak256_round_function 2^20 rows", cs, outer, loop, B, stream_x=4)
+    timed("C3 keccak256_round_function 2^20 rows, every carried word from the witness's queue states (zk_pack_keccak_witness_tails)", cs, outer, loop, B, given=list(range(kn.CARRIED)))
 if want("C3s"):
     B = 128
     cs, limit = T.fit(lambda c: c.configure_sha256(), lambda c, l: c.sha256_round_function_entry_point(l), 20)
@@ -88,6 +89,7 @@ if want("C3s"):
     inst = shn.instance(reqs, limit)
     outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
     timed("C3 sha256_round_function 2^20 rows", cs, outer, loop, B, stream_x=4)
+    timed("C3 sha256_round_function 2^20 rows, every carried word from the witness's queue states (zk_pack_sha256_witness_tails)", cs, outer, loop, B, given=list(range(shn.CARRIED)))
 # C4 (4 instances on one GPU here; BASELINE shards them over 4 GPUs)
 if want("C4s"):
     cs, limit = T.fit(lambda c: c.configure_storage_validity(), lambda c, l: c.sort_and_deduplicate_storage_access_entry_point(l, True), 22)
