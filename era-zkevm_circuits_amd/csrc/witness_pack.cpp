@@ -1319,6 +1319,10 @@ void code_unpacker_fsm(Cursor& c, zk_code_unpacker_fsm_witness& f) {   // CodeDe
 
 int zk_decode_sha256_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_sha256_round_function_witness* out, zk_log_query_witness* requests_buf, uint32_t requests_cap,
                                      uint32_t (*reads_buf)[8], uint32_t reads_cap, size_t* consumed) {
+    return zk_decode_sha256_witness_bincode_tails(bytes, n_bytes, out, requests_buf, requests_cap, reads_buf, reads_cap, nullptr, consumed);
+}
+int zk_decode_sha256_witness_bincode_tails(const uint8_t* bytes, size_t n_bytes, zk_sha256_round_function_witness* out, zk_log_query_witness* requests_buf, uint32_t requests_cap,
+                                           uint32_t (*reads_buf)[8], uint32_t reads_cap, uint64_t (*request_tails)[4], size_t* consumed) {
     if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_sha256_witness_bincode: null argument");
     Cursor c{bytes, n_bytes};
     std::memset(out, 0, sizeof *out);
@@ -1328,7 +1332,7 @@ int zk_decode_sha256_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_sh
     zk_full_queue_state_witness final_memory;   // observable_output.final_memory_state
     c.queue_state(final_memory);
     sha256_fsm(c, out->hidden_fsm_input); sha256_fsm(c, out->hidden_fsm_output);
-    if (c.log_queue(requests_buf, requests_cap, out->n_requests, err)) {
+    if (c.log_queue(requests_buf, requests_cap, out->n_requests, err, request_tails)) {
         out->requests_queue_witness = requests_buf;
         if (u256_seq(c, reads_buf, reads_cap, out->n_reads, err)) out->memory_reads_witness = reads_buf;
     }
@@ -1337,6 +1341,10 @@ int zk_decode_sha256_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_sh
 
 int zk_decode_keccak_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_keccak_round_function_witness* out, zk_log_query_witness* requests_buf, uint32_t requests_cap,
                                      uint32_t (*reads_buf)[8], uint32_t reads_cap, size_t* consumed) {
+    return zk_decode_keccak_witness_bincode_tails(bytes, n_bytes, out, requests_buf, requests_cap, reads_buf, reads_cap, nullptr, consumed);
+}
+int zk_decode_keccak_witness_bincode_tails(const uint8_t* bytes, size_t n_bytes, zk_keccak_round_function_witness* out, zk_log_query_witness* requests_buf, uint32_t requests_cap,
+                                           uint32_t (*reads_buf)[8], uint32_t reads_cap, uint64_t (*request_tails)[4], size_t* consumed) {
     if (!bytes || !out) return bad(ZK_ERR_INVALID, "zk_decode_keccak_witness_bincode: null argument");
     Cursor c{bytes, n_bytes};
     std::memset(out, 0, sizeof *out);
@@ -1346,7 +1354,7 @@ int zk_decode_keccak_witness_bincode(const uint8_t* bytes, size_t n_bytes, zk_ke
     zk_full_queue_state_witness final_memory;
     c.queue_state(final_memory);
     keccak_fsm(c, out->hidden_fsm_input); keccak_fsm(c, out->hidden_fsm_output);
-    if (c.log_queue(requests_buf, requests_cap, out->n_requests, err)) {
+    if (c.log_queue(requests_buf, requests_cap, out->n_requests, err, request_tails)) {
         out->requests_queue_witness = requests_buf;
         if (u256_seq(c, reads_buf, reads_cap, out->n_reads, err)) out->memory_reads_witness = reads_buf;
     }

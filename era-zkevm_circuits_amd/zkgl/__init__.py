@@ -515,14 +515,19 @@ def decode_linear_hasher_witness_bincode(data: bytes, max_elements: int):
     return _decode_bincode(lib().zk_decode_linear_hasher_witness_bincode, LinearHasherWitness(), data, [(LogQueryWitness * max(max_elements, 1))()])
 
 
-def decode_sha256_witness_bincode(data: bytes, max_requests: int, max_reads: int):
-    return _decode_bincode(lib().zk_decode_sha256_witness_bincode, Sha256RoundFunctionWitness(), data,
-                           [(LogQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_reads, 1))()])
+def decode_sha256_witness_bincode(data: bytes, max_requests: int, max_reads: int, keep_tails: bool = False):
+    """keep_tails: w._keep[-1] = the previous tail of every request ([n][4]), an input of pack_sha256_witness_tails"""
+    bufs = [(LogQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_reads, 1))()]
+    if keep_tails:
+        return _decode_bincode_tails(lib().zk_decode_sha256_witness_bincode_tails, Sha256RoundFunctionWitness(), data, bufs, [((C.c_uint64 * 4) * max(max_requests, 1))()])
+    return _decode_bincode(lib().zk_decode_sha256_witness_bincode, Sha256RoundFunctionWitness(), data, bufs)
 
 
-def decode_keccak_witness_bincode(data: bytes, max_requests: int, max_reads: int):
-    return _decode_bincode(lib().zk_decode_keccak_witness_bincode, KeccakRoundFunctionWitness(), data,
-                           [(LogQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_reads, 1))()])
+def decode_keccak_witness_bincode(data: bytes, max_requests: int, max_reads: int, keep_tails: bool = False):
+    bufs = [(LogQueryWitness * max(max_requests, 1))(), ((C.c_uint32 * 8) * max(max_reads, 1))()]
+    if keep_tails:
+        return _decode_bincode_tails(lib().zk_decode_keccak_witness_bincode_tails, KeccakRoundFunctionWitness(), data, bufs, [((C.c_uint64 * 4) * max(max_requests, 1))()])
+    return _decode_bincode(lib().zk_decode_keccak_witness_bincode, KeccakRoundFunctionWitness(), data, bufs)
 
 
 def decode_sort_decommits_witness_bincode(data: bytes, max_elements: int, keep_tails: bool = False):

@@ -424,6 +424,14 @@ int zk_decode_sha256_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_sh
 int zk_decode_keccak_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_keccak_round_function_witness *out,
                                      zk_log_query_witness *requests_buf, uint32_t requests_cap,
                                      uint32_t (*reads_buf)[8], uint32_t reads_cap, size_t *consumed);
+/* the same two, keeping the 4-word previous tail bincode carries beside every request ([requests_cap][4], caller's buffer): an input of
+ * zk_pack_sha256_witness_tails / zk_pack_keccak_witness_tails */
+int zk_decode_sha256_witness_bincode_tails(const uint8_t *bytes, size_t n_bytes, zk_sha256_round_function_witness *out,
+                                           zk_log_query_witness *requests_buf, uint32_t requests_cap, uint32_t (*reads_buf)[8],
+                                           uint32_t reads_cap, uint64_t (*request_tails)[4], size_t *consumed);
+int zk_decode_keccak_witness_bincode_tails(const uint8_t *bytes, size_t n_bytes, zk_keccak_round_function_witness *out,
+                                           zk_log_query_witness *requests_buf, uint32_t requests_cap, uint32_t (*reads_buf)[8],
+                                           uint32_t reads_cap, uint64_t (*request_tails)[4], size_t *consumed);
 int zk_decode_sort_decommits_witness_bincode(const uint8_t *bytes, size_t n_bytes, zk_sort_decommits_witness *out,
                                              zk_decommit_query_witness *initial_buf, uint32_t initial_cap,
                                              zk_decommit_query_witness *sorted_buf, uint32_t sorted_cap, size_t *consumed);

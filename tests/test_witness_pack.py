@@ -1282,6 +1282,8 @@ def test_sha256_and_keccak_bincode_round_trips():
         assert bytes(d.hidden_fsm_input) == bytes(w.hidden_fsm_input) and bytes(d.hidden_fsm_output) == bytes(w.hidden_fsm_output)
         assert all(bytes(d.requests_queue_witness[i]) == bytes(qa[i]) for i in range(nq))
         assert all(list(d.memory_reads_witness[i]) == list(ra[i]) for i in range(nr))
+        d2, used2 = dec(data, nq, nr, keep_tails=True)       # the previous tails bincode carries beside the requests
+        assert used2 == len(data) and all(list(d2._keep[-1][i]) == [1000 + 4 * i + t for t in range(4)] for i in range(nq))
         with pytest.raises(zkgl.ZkError):
             dec(data, nq, nr - 1)
         with pytest.raises(zkgl.ZkError):
