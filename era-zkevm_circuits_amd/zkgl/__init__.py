@@ -260,8 +260,9 @@ def eip4844_stream_shape(n_chunks: int):
     return it.value, lw.value
 
 
-def pack_eip4844_witness(blob: bytes, versioned_hash: bytes, linear_hash: bytes, instance, outer, loop):
-    """zk_pack_eip4844_witness: outer [64, B], loop [loop_words, B * iterations]"""
+def pack_eip4844_witness(blob: bytes, versioned_hash: bytes, linear_hash: bytes, instance, outer, loop, full: bool = False):
+    """zk_pack_eip4844_witness: outer [64, B], loop [loop_words, B * iterations]; full: zk_pack_eip4844_witness_full (the 217 carried
+    words too — nothing to seed; declare zk_eip4844_given_words = all of them)"""
     n_chunks = len(blob) // 31
     assert len(blob) == 31 * n_chunks and len(versioned_hash) == 32 and len(linear_hash) == 32
     w = Eip4844Witness()
@@ -271,7 +272,8 @@ def pack_eip4844_witness(blob: bytes, versioned_hash: bytes, linear_hash: bytes,
     batch = outer.shape[1]
     it, lw = eip4844_stream_shape(n_chunks)
     assert outer.shape == (64, batch) and loop.shape == (lw, batch * it) and outer.flags.c_contiguous and loop.flags.c_contiguous
-    _check(lib().zk_pack_eip4844_witness(C.byref(w), instance, batch, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
+    fn = lib().zk_pack_eip4844_witness_full if full else lib().zk_pack_eip4844_witness
+    _check(fn(C.byref(w), instance, batch, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
 
 
 class Sha256FsmWitness(C.Structure):

@@ -183,6 +183,12 @@ int zk_eip4844_stream_shape(uint32_t n_chunks, uint32_t *n_iterations, uint32_t 
  * state, opening limbs, iteration counter: device seeding), then the 136 blob bytes of the iteration's Keccak block and the 31-byte
  * chunks of its Horner steps (zero bytes past the blob: the circuit pads the last block itself) */
 int zk_pack_eip4844_witness(const zk_eip4844_witness *w, uint32_t instance, uint32_t batch, uint64_t *outer_words, uint64_t *loop_words);
+/* The same with the 217 carried words of every iteration written by the host (zk_eip4844_given_words -> zk_cs_set_seed_given: no device
+ * seeding): the sponge state before each Keccak block of the blob, the 16 opening limbs before each iteration's Horner steps (BLS12-381
+ * scalar field, z from keccak256(linear_hash_output | versioned_hash)), the iteration counter — the values the reference's own test
+ * computes out of circuit (mod.rs:595-683). */
+int zk_pack_eip4844_witness_full(const zk_eip4844_witness *w, uint32_t instance, uint32_t batch, uint64_t *outer_words, uint64_t *loop_words);
+uint32_t zk_eip4844_given_words(uint32_t words[217]);
 
 /* Sha256RoundFunctionCircuitInstanceWitness, /root/reference/src/sha256_round_function/input.rs:85-89 (FSM :24-32, :53-57; call params:
  * input_page, input_offset, output_page, output_offset, num_rounds) */

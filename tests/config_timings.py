@@ -124,3 +124,4 @@ if want("C5"):
     outer = np.array([i["outer"] for i in insts], dtype=np.uint64).T.copy()
     loop = np.array([r_ for i in insts for r_ in i["rows"]], dtype=np.uint64).T.copy()
     timed("C5 eip_4844 8 blobs x 4096 chunks", cs, outer, loop, 8, stream_x=8)
+    timed("C5 eip_4844 8 blobs x 4096 chunks, the 217 carried words from the host packer (zk_pack_eip4844_witness_full)", cs, outer, loop, 8, given=list(range(217)))

@@ -349,8 +349,43 @@ def test_eip4844_packer_equals_the_oracle_rows():
         zkgl.pack_eip4844_witness(blob, vh, inst["linear_hash"], i, outer, loop)
     eo = np.array([c[2]["outer"] for c in cases], dtype=np.uint64).T
     el = np.array([r for c in cases for r in c[2]["rows"]], dtype=np.uint64).T.copy()
+    full = el.copy()
     el[0:217] = 0
     assert np.array_equal(outer, eo) and np.array_equal(loop, el)
+    # zk_pack_eip4844_witness_full: sponge states and opening limbs (BLS12-381 scalar field Horner) walked on the host — all words
+    for i, (blob, vh, inst) in enumerate(cases):
+        zkgl.pack_eip4844_witness(blob, vh, inst["linear_hash"], i, outer, loop, full=True)
+    assert np.array_equal(outer, eo) and np.array_equal(loop, full), np.argwhere(loop != full)[:8]
+
+
+@pytest.mark.gpu
+def test_eip4844_with_the_carried_words_from_the_host_needs_no_device_seeding(zk):
+    """zk_pack_eip4844_witness_full + zk_eip4844_given_words: the product path with no seeding kernel; commitments equal the restatement's"""
+    from oracle import eip4844_native as en
+    n_chunks = 27
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
+    cs.configure_eip_4844(); cs.eip_4844_entry_point(n_chunks); cs.pad_and_shrink()
+    rng = np.random.default_rng(4845)
+    cases = []
+    for k in range(5):
+        blob = bytes(rng.integers(0, 256, size=31 * n_chunks, dtype=np.uint8)) if k else b"\xff" * (31 * n_chunks)
+        vh = b"\x01" + bytes(rng.integers(0, 256, size=31, dtype=np.uint8))
+        cases.append((blob, vh, en.instance(blob, vh, n_chunks)))
+    it, lw = zkgl.eip4844_stream_shape(n_chunks)
+    B = len(cases)
+    outer = np.zeros((64, B), dtype=np.uint64); loop = np.zeros((lw, B * it), dtype=np.uint64)
+    for i, (blob, vh, inst) in enumerate(cases):
+        zkgl.pack_eip4844_witness(blob, vh, inst["linear_hash"], i, outer, loop, full=True)
+    cs.set_batch(B)
+    cs.set_seed_given(list(range(217)))
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, (_, _, inst) in enumerate(cases):
+        assert cs.public_inputs(i) == inst["public_input"]
 
 
 def _q12(words):
