@@ -1328,6 +1328,7 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
         const std::vector<uint32_t> plane_all = strand_planes ? select_plane_vars(s) : std::vector<uint32_t>();
         std::vector<uint32_t> plane_now(strand_planes ? s.n_vars : 0, UINT32_MAX);   // variable -> plane id once its plane is readable
         std::vector<std::vector<uint32_t>> copy_at(n_levels + 2), readable_at(n_levels + 3);
+        std::vector<uint32_t> copied_in(strand_planes ? s.n_vars : 0, UINT32_MAX);   // level whose program holds the flag's copy (checked below)
         if (strand_planes) {
             for (uint32_t v = 0; v < s.n_vars; ++v)
                 if (plane_all[v] != UINT32_MAX && producer[v] >= (int64_t)o0) {
@@ -1385,6 +1386,12 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
                     } else counted = f0.opcode == ZK_OP_SELECT || f0.opcode == ZK_OP_FMA || f0.opcode == ZK_OP_INPUT || f0.opcode == ZK_OP_U32MULADD || f0.opcode == ZK_OP_LC4;
                     for (size_t i0 = 0; i0 < g.size(); i0 += cap) {
                         std::vector<size_t> part(g.begin() + i0, g.begin() + std::min(g.size(), i0 + cap));
+                        if (strand_planes && f0.opcode == ZK_OP_SELECT)   // a plane is read only behind the barrier that ends the level of its copy
+                            for (size_t oi : part) {
+                                const uint32_t fv = s.ops[oi].ins[0].idx;
+                                if (s.ops[oi].ins[0].kind == Operand::VAR && plane_now[fv] != UINT32_MAX && !(copied_in[fv] < lv))
+                                    throw ZkError(ZK_ERR_INVALID, "internal: a SELECT reads a flag plane that no earlier level has written");
+                            }
                         emit_group_v2(s, part, counted, strand[k]);
                         for (size_t oi : part) {
                             const OpRec& op = s.ops[oi];
@@ -1402,7 +1409,12 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
                 for (size_t at = 0; at < cp.size(); at += 7) {
                     const size_t nn = std::min<size_t>(7, cp.size() - at);
                     strand[best].push_back((uint32_t)ZK_OP_FLAG_PLANES | ((uint32_t)(nn - 1) << 16));
-                    for (size_t q = 0; q < nn; ++q) { strand[best].push_back(s.var_slot[cp[at + q]]); strand[best].push_back(plane_all[cp[at + q]]); }
+                    for (size_t q = 0; q < nn; ++q) {
+                        const uint32_t fv = cp[at + q];
+                        if (level[(size_t)producer[fv]] >= lv) throw ZkError(ZK_ERR_INVALID, "internal: a flag plane is copied in the level that produces the flag");
+                        copied_in[fv] = lv;
+                        strand[best].push_back(s.var_slot[fv]); strand[best].push_back(plane_all[fv]);
+                    }
                     load[best] += 10 + 4 * nn;
                 }
             }
