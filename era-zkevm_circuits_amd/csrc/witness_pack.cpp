@@ -1258,6 +1258,67 @@ int zk_pack_linear_hasher_witness(const zk_linear_hasher_witness* w, uint32_t li
 }
 
 
+// linear_hasher with the queue heads of its witness (the previous tail beside every element, input.rs:71-80) and the sponge walked on
+// the host: the 206 carried words of every 17-cycle period (Keccak state, queue head, length, done flag) — LogQuery::into_bytes
+// (log_query/mod.rs:645-686: 88 bytes) against 136-byte blocks, padding after the last element (mod.rs:120-200).
+int zk_pack_linear_hasher_witness_tails(const zk_linear_hasher_witness* w, uint32_t limit, uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words,
+                                        const uint64_t* queue_previous_tails) {
+    if (w && w->n_queue && !queue_previous_tails) return bad(ZK_ERR_INVALID, "zk_pack_linear_hasher_witness_tails: null tails (use zk_pack_linear_hasher_witness and device seeding)");
+    if (int rc = zk_pack_linear_hasher_witness(w, limit, instance, batch, outer_words, loop_words)) return rc;
+    constexpr uint32_t RATE = 136, MSG = 88;
+    const uint32_t iters = limit / ZK_LINEAR_HASHER_PERIOD;
+    const size_t lanes = (size_t)batch * iters;
+    uint64_t state[25] = {0}, head[4], length = w->queue_state.length;
+    for (int k = 0; k < 4; ++k) head[k] = w->queue_state.head[k];
+    bool done = length == 0;
+    uint8_t buffer[RATE + MSG];
+    uint32_t fill = 0, next = 0;
+    auto absorb = [&](const uint8_t* block) { for (uint32_t j = 0; j < RATE; ++j) state[j / 8] ^= (uint64_t)block[j] << (8 * (j % 8)); keccak_f1600_host(state); };
+    for (uint32_t it = 0; it < iters; ++it) {
+        Out l{loop_words + (size_t)instance * iters + it, lanes};
+        if (length != 0 && next < w->n_queue) for (int k = 0; k < 4; ++k) head[k] = queue_previous_tails[4 * (size_t)next + k];   // the head before this period's first pop
+        for (int lane = 0; lane < 25; ++lane) for (int k = 0; k < 8; ++k) l.w((state[lane] >> (8 * k)) & 0xff);
+        l.arr(head); l.w(length); l.w(done ? 1 : 0);
+        if (l.k != 206) return bad(ZK_ERR_INVALID, "internal: linear_hasher carried layout");
+        for (uint32_t c = 0; c < ZK_LINEAR_HASHER_PERIOD; ++c) {
+            const bool should_pop = length != 0 && next < w->n_queue;
+            uint8_t msg[MSG] = {0};
+            if (should_pop) {
+                const zk_log_query_witness& q = w->queue_witness[next++];
+                --length;
+                for (int k = 0; k < 4; ++k) head[k] = next < w->n_queue ? queue_previous_tails[4 * (size_t)next + k] : w->queue_state.tail[k];
+                uint32_t at = 0;
+                msg[at++] = q.shard_id; msg[at++] = q.is_service ? 1 : 0;
+                msg[at++] = (uint8_t)(q.tx_number_in_block >> 8); msg[at++] = (uint8_t)q.tx_number_in_block;
+                auto be = [&](const uint32_t* limbs, int n) { for (int i = n - 1; i >= 0; --i) for (int sh = 24; sh >= 0; sh -= 8) msg[at++] = (uint8_t)(limbs[i] >> sh); };
+                be(q.address, 5); be(q.key, 8); be(q.written_value, 8);
+            }
+            const bool is_last = should_pop && length == 0;
+            for (uint32_t j = 0; j < MSG; ++j) buffer[fill + j] = msg[j];
+            fill += MSG;
+            const bool cont = !done;
+            if (fill >= RATE) {
+                if (cont) absorb(buffer);
+                for (uint32_t j = RATE; j < fill; ++j) buffer[j - RATE] = buffer[j];
+                fill -= RATE;
+            }
+            if (cont && is_last) {
+                uint8_t last[RATE] = {0};
+                for (uint32_t j = 0; j < fill; ++j) last[j] = buffer[j];
+                if (fill == RATE - 1) last[fill] = 0x81;
+                else { last[fill] = 0x01; last[RATE - 1] = 0x80; }
+                absorb(last);
+            }
+            done = done || is_last;
+        }
+    }
+    return ZK_OK;
+}
+uint32_t zk_linear_hasher_given_words(uint32_t words[206]) {
+    for (uint32_t i = 0; i < 206; ++i) words[i] = i;
+    return 206;
+}
+
 namespace {
 void storage_fsm(Cursor& c, zk_storage_fsm_witness& f) {   // StorageDeduplicatorFSMInputOutput (input.rs:37-52)
     for (auto& x : f.lhs_accumulator) x = c.field();

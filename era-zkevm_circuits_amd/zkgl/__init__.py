@@ -382,6 +382,17 @@ def pack_code_unpacker_witness(w, limit, instance, outer, loop):
     _pack(lib().zk_pack_code_unpacker_witness, w, limit, instance, outer, loop, 125, 101)
 
 
+def pack_linear_hasher_witness_tails(w, limit, instance, outer, loop, queue_previous_tails):
+    """zk_pack_linear_hasher_witness_tails: every carried word from the witness; returns the given words (all 206)"""
+    assert outer.shape[0] == 10 and loop.shape[0] == 818 and loop.shape[1] == outer.shape[1] * (limit // 17)
+    qp = np.ascontiguousarray(queue_previous_tails, dtype=np.uint64)
+    _check(lib().zk_pack_linear_hasher_witness_tails(C.byref(w), limit, instance, outer.shape[1], outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p),
+                                                     qp.ctypes.data_as(C.c_void_p)))
+    words = (C.c_uint32 * 206)()
+    n = lib().zk_linear_hasher_given_words(words)
+    return list(words[:n])
+
+
 def pack_keccak_witness_tails(w, limit, instance, outer, loop, request_previous_tails, memory_tails):
     """zk_pack_keccak_witness_tails: every carried word from the witness; returns the given words (all 423)"""
     assert outer.shape[0] == 474 and loop.shape[0] == 507 and loop.shape[1] == outer.shape[1] * limit

@@ -388,6 +388,11 @@ typedef struct zk_linear_hasher_witness {
  * outer_words[10][batch], loop_words[818][batch * limit / 17]: 206 carried words zeroed, then 17 LogQuery items (36 words each) */
 int zk_pack_linear_hasher_witness(const zk_linear_hasher_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
                                   uint64_t *outer_words, uint64_t *loop_words);
+/* The same with the 206 carried words of every period written by the host (zk_linear_hasher_given_words): `queue_previous_tails[n_queue][4]`
+ * = the previous tail bincode carries beside every queue element (the head before its pop); the sponge is walked on the host. */
+int zk_pack_linear_hasher_witness_tails(const zk_linear_hasher_witness *w, uint32_t limit, uint32_t instance, uint32_t batch,
+                                        uint64_t *outer_words, uint64_t *loop_words, const uint64_t *queue_previous_tails);
+uint32_t zk_linear_hasher_given_words(uint32_t words[206]);
 
 /* ---- bincode decoders for the witnesses built from LogQuery queues (same conventions and the same [EXT] caveats as
  * zk_decode_ram_witness_bincode: "parity unpinned" until reference-produced bytes exist).  ClosedFormInputWitness = start_flag,

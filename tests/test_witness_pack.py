@@ -1046,6 +1046,26 @@ def test_linear_hasher_packer_equals_the_oracle_streams():
     assert np.array_equal(outer, eo) and np.array_equal(loop, el)
     with pytest.raises(zkgl.ZkError):
         zkgl._check(zkgl.lib().zk_pack_linear_hasher_witness(C.byref(w), 33, 0, 1, outer.ctypes.data_as(C.c_void_p), loop.ctypes.data_as(C.c_void_p)))
+    # with the previous tails of the queue witness the packer also walks the sponge: all 818 words of every period
+    from oracle import zko
+    from oracle.storage_native import encode
+    for n_q, lim in ((20, 34), (0, 17), (17, 17), (31, 51)):    # queue ends inside a period / empty / exactly at the period's end / block-aligned total (31 * 88 = 2728 = 20 * 136 + 8)
+        qq = qs[:n_q] if n_q <= len(qs) else qs + qs[:n_q - len(qs)]
+        inst = hn.instance(qq, lim)
+        w = zkgl.LinearHasherWitness()
+        w.start_flag, w.completion_flag = 1, 1
+        w.queue_state = _q4(inst["outer"][1:10])
+        arr = (zkgl.LogQueryWitness * max(len(qq), 1))(*[_lq(q) for q in qq])
+        w.queue_witness, w.n_queue = arr, len(qq)
+        head, prev = [0] * 4, []
+        for q in qq:
+            prev.append(head)
+            head = zko.queue_tail4_push20(head, encode(q))
+        outer = np.zeros((10, 1), dtype=np.uint64); loop = np.full((818, lim // 17), 9, dtype=np.uint64)
+        given = zkgl.pack_linear_hasher_witness_tails(w, lim, 0, outer, loop, np.array(prev or [[0] * 4], dtype=np.uint64))
+        eo, el = _streams([inst])
+        assert given == list(range(206))
+        assert np.array_equal(outer, eo) and np.array_equal(loop, el), (n_q, lim, np.argwhere(loop != el)[:6])
 
 
 # ---------------------------------------------------------------- bincode of the LogQuery-queue witnesses (test-side writer, C decoder)
