@@ -58,7 +58,9 @@ void mds_inner(u64 s[12]) {
     for (int i = 0; i < 12; ++i) sum += s[i];
     for (int i = 0; i < 12; ++i) s[i] = gl_reduce128(sum + ((unsigned __int128)s[i] << SHIFT[i]));
 }
+thread_local size_t g_host_permutations = 0;
 void poseidon2(u64 s[12]) {
+    ++g_host_permutations;
     const u64* RC = zkgl::poseidon_round_constants();
     mds_external(s);
     for (int r = 0; r < 30; ++r) {
@@ -84,7 +86,26 @@ struct PackEnv {
     u32 w_code_word, w_src0_value, w_src0_is_ptr, w_refund, w_log_read, w_log_prev_head, w_near_tail, w_far_code_hash, w_far_page, w_far_tail, w_ret_ctx,
         w_ret_state, w_uma_a, w_uma_b;
     bool chains_on;
+    zk_vm_queue_states* qs = nullptr;   // ZK_VM_PACK_RECORD_STATES / ZK_VM_PACK_STATES_FROM_WITNESS
+    int qs_mode = 0;                    // 0: hash, 1: hash and record, 2: read the tails from the witness's queue states
+    bool qs_overflow = false;
     Chains ch;
+    // a chain step whose result the witness generator holds: read it, or compute it (and record it for a fixture)
+    template <int W, class F>
+    void chained(u64* tail, u64 (*arr)[W], size_t n, size_t& used, F&& hash) {
+        if (qs_mode == 2) {
+            if (used >= n) { rep->underflow = 1; return; }
+            for (int i = 0; i < W; ++i) tail[i] = arr[used][i];
+            ++used;
+            return;
+        }
+        hash();
+        if (qs_mode == 1) {
+            if (used >= n) { qs_overflow = true; return; }
+            for (int i = 0; i < W; ++i) arr[used][i] = tail[i];
+            ++used;
+        }
+    }
     void put(u32 w, u64 v) { col[(u64)w * stride] = v; }
     void opcode_row(const vmn::Defs& D, u32 variant, u32& price, u64& props) { price = D.prices[variant]; props = D.props[variant]; }
     void mem_read(bool exec, u32 w_value, int w_ptr, vmn::U256& v, u32* is_ptr) {
@@ -149,10 +170,17 @@ struct PackEnv {
         poseidon2(s);
         std::memcpy(tail, s, sizeof s);
     }
-    void mem_push(const u64 enc[8]) { if (chains_on) push12(ch.mem, enc); }
-    void dec_push(const u64 enc[8]) { if (chains_on) push12(ch.dec, enc); }
-    void fwd_push(const u64 enc[20]) {
+    void mem_push(const u64 enc[8]) {
         if (!chains_on) return;
+        if (!qs) { push12(ch.mem, enc); return; }
+        chained<12>(ch.mem, qs->memory_tails, qs->n_memory_tails, qs->used_memory_tails, [&] { push12(ch.mem, enc); });
+    }
+    void dec_push(const u64 enc[8]) {
+        if (!chains_on) return;
+        if (!qs) { push12(ch.dec, enc); return; }
+        chained<12>(ch.dec, qs->decommit_tails, qs->n_decommit_tails, qs->used_decommit_tails, [&] { push12(ch.dec, enc); });
+    }
+    void fwd_hash(const u64 enc[20]) {
         u64 s[12] = {0};
         for (int i = 0; i < 8; ++i) s[i] = enc[i];
         poseidon2(s);
@@ -161,6 +189,11 @@ struct PackEnv {
         for (int i = 0; i < 4; ++i) { s[i] = enc[16 + i]; s[4 + i] = ch.fwd[i]; }
         poseidon2(s);
         for (int i = 0; i < 4; ++i) ch.fwd[i] = s[i];
+    }
+    void fwd_push(const u64 enc[20]) {
+        if (!chains_on) return;
+        if (!qs) { fwd_hash(enc); return; }
+        chained<4>(ch.fwd, qs->log_forward_tails, qs->n_log_forward_tails, qs->used_log_forward_tails, [&] { fwd_hash(enc); });
     }
     void fwd_set(const u64 v[4]) { for (int i = 0; i < 4; ++i) ch.fwd[i] = v[i]; }
     void sponge_push(const u64 enc[32]) {
@@ -221,8 +254,26 @@ void write_state(const vmn::State& s, const Chains& ch, bool chains_on, u64* col
 
 extern "C" int zk_pack_main_vm_witness(zk_cs* h, const zk_vm_closed_form_input* in, const zk_vm_witness_oracle* oracle, uint32_t instance, uint32_t batch,
                                        uint64_t* outer_words, uint64_t* loop_words, uint32_t flags, zk_vm_pack_report* report) {
+    if (flags & (ZK_VM_PACK_RECORD_STATES | ZK_VM_PACK_STATES_FROM_WITNESS)) { zkgl::set_last_error("zk_pack_main_vm_witness: the queue-state flags need zk_pack_main_vm_witness_states"); return (int)ZK_ERR_INVALID; }
+    return zk_pack_main_vm_witness_states(h, in, oracle, nullptr, instance, batch, outer_words, loop_words, flags, report);
+}
+
+extern "C" int zk_pack_main_vm_witness_states(zk_cs* h, const zk_vm_closed_form_input* in, const zk_vm_witness_oracle* oracle, zk_vm_queue_states* states,
+                                              uint32_t instance, uint32_t batch, uint64_t* outer_words, uint64_t* loop_words, uint32_t flags, zk_vm_pack_report* report) {
     auto bad = [](const char* m) { zkgl::set_last_error(m); return (int)ZK_ERR_INVALID; };
     if (!h || !zkgl::cs_of(h) || !in || !oracle || !outer_words || !loop_words || !report) return bad("zk_pack_main_vm_witness: null argument");
+    const bool rec = (flags & ZK_VM_PACK_RECORD_STATES) != 0, from = (flags & ZK_VM_PACK_STATES_FROM_WITNESS) != 0;
+    if ((rec || from) && !states) return bad("zk_pack_main_vm_witness_states: the queue-state flags need `states`");
+    if (rec && from) return bad("zk_pack_main_vm_witness_states: RECORD_STATES and STATES_FROM_WITNESS exclude each other");
+    if (rec && !(flags & ZK_VM_PACK_FILL_STATE)) return bad("zk_pack_main_vm_witness_states: RECORD_STATES needs FILL_STATE");
+    if (from) flags |= ZK_VM_PACK_FILL_STATE;   // reading the states means writing the whole VmLocalState
+    if (states && (rec || from)) {
+        if ((states->n_memory_tails && !states->memory_tails) || (states->n_decommit_tails && !states->decommit_tails) || (states->n_log_forward_tails && !states->log_forward_tails))
+            return bad("zk_pack_main_vm_witness_states: null state array");
+        states->used_memory_tails = states->used_decommit_tails = states->used_log_forward_tails = 0;
+        states->host_permutations = 0;
+    }
+    g_host_permutations = 0;
     zkgl::CS& cs = *zkgl::cs_of(h);
     if (cs.native_seed_kind != 1 || cs.circuit_blob.size() != sizeof(zk_opcode_defs) || !cs.limit()) return bad("zk_pack_main_vm_witness: not a recorded main_vm circuit");
     if (instance >= batch) return bad("zk_pack_main_vm_witness: instance >= batch");
@@ -234,6 +285,7 @@ extern "C" int zk_pack_main_vm_witness(zk_cs* h, const zk_vm_closed_form_input* 
 
     PackEnv env;
     env.o = oracle; env.rep = report; env.cs = &cs; env.chains_on = chains_on;
+    if (rec || from) { env.qs = states; env.qs_mode = rec ? 1 : 2; }
     env.stride = (u64)batch * limit;
     struct { const char* name; u32* dst; } fields[] = {
         {"code_word", &env.w_code_word}, {"src0_read_value", &env.w_src0_value}, {"src0_read_is_ptr", &env.w_src0_is_ptr},
@@ -292,5 +344,7 @@ extern "C" int zk_pack_main_vm_witness(zk_cs* h, const zk_vm_closed_form_input* 
     u64 fin[vmn::STATE_WORDS] = {0};
     write_state(st, env.ch, true, fin, 1);
     std::memcpy(report->final_state, fin, sizeof fin);
+    if (states && (rec || from)) states->host_permutations = g_host_permutations;
+    if (env.qs_overflow) { zkgl::set_last_error("zk_pack_main_vm_witness_states: a state array is too small for this chunk"); return (int)ZK_ERR_CAPACITY; }
     return ZK_OK;
 }

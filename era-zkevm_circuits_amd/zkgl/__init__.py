@@ -790,6 +790,28 @@ class VmPackReport(C.Structure):             # zk_vm_pack_report
                 ("used_decommit_pages", C.c_size_t), ("underflow", C.c_uint32), ("final_state", C.c_uint64 * 243)]
 
 
+class VmQueueStates(C.Structure):            # zk_vm_queue_states
+    _fields_ = [("memory_tails", C.c_void_p), ("n_memory_tails", C.c_size_t), ("used_memory_tails", C.c_size_t),
+                ("decommit_tails", C.c_void_p), ("n_decommit_tails", C.c_size_t), ("used_decommit_tails", C.c_size_t),
+                ("log_forward_tails", C.c_void_p), ("n_log_forward_tails", C.c_size_t), ("used_log_forward_tails", C.c_size_t),
+                ("host_permutations", C.c_size_t)]
+
+    @staticmethod
+    def over(memory: np.ndarray, decommit: np.ndarray, log_forward: np.ndarray) -> "VmQueueStates":
+        """arrays [n, 12], [n, 12], [n, 4] (u64, C-contiguous): written under VM_PACK_RECORD_STATES, read under VM_PACK_STATES_FROM_WITNESS"""
+        q = VmQueueStates()
+        for a, w in ((memory, 12), (decommit, 12), (log_forward, 4)):
+            assert a.dtype == np.uint64 and a.flags.c_contiguous and a.ndim == 2 and a.shape[1] == w
+        q.memory_tails, q.n_memory_tails = memory.ctypes.data, memory.shape[0]
+        q.decommit_tails, q.n_decommit_tails = decommit.ctypes.data, decommit.shape[0]
+        q.log_forward_tails, q.n_log_forward_tails = log_forward.ctypes.data, log_forward.shape[0]
+        q._keep = (memory, decommit, log_forward)
+        return q
+
+
+VM_PACK_RECORD_STATES, VM_PACK_STATES_FROM_WITNESS = 2, 4
+
+
 class VmClosedFormRest(C.Structure):        # zk_vm_closed_form_rest
     _fields_ = [("completion_flag", C.c_uint32), ("log_queue_final_state", QueueStateWitness), ("memory_queue_final_state", FullQueueStateWitness),
                 ("decommitment_queue_final_state", FullQueueStateWitness), ("hidden_fsm_output", C.c_uint64 * 243)]
@@ -1117,6 +1139,16 @@ class ConstraintSystem:
         _check(lib().zk_pack_main_vm_witness(self._h, C.byref(closed_form), C.byref(oracle), C.c_uint32(instance), C.c_uint32(batch),
                                              outer_words.ctypes.data_as(C.c_void_p), loop_words.ctypes.data_as(C.c_void_p), C.c_uint32(flags),
                                              C.byref(rep)))
+        return rep
+
+    def pack_main_vm_witness_states(self, closed_form, oracle, states: "VmQueueStates", instance: int, batch: int, outer_words: np.ndarray,
+                                    loop_words: np.ndarray, flags: int) -> "VmPackReport":
+        """zk_pack_main_vm_witness_states: as pack_main_vm_witness, with the queue states (recorded into / read from `states`)"""
+        assert outer_words.dtype == np.uint64 and loop_words.dtype == np.uint64 and outer_words.flags.c_contiguous and loop_words.flags.c_contiguous
+        rep = VmPackReport()
+        _check(lib().zk_pack_main_vm_witness_states(self._h, C.byref(closed_form), C.byref(oracle), C.byref(states), C.c_uint32(instance), C.c_uint32(batch),
+                                                    outer_words.ctypes.data_as(C.c_void_p), loop_words.ctypes.data_as(C.c_void_p), C.c_uint32(flags),
+                                                    C.byref(rep)))
         return rep
 
     def input_words(self):

@@ -166,6 +166,26 @@ int zk_decode_vm_closed_form_input_bincode(const uint8_t *bytes, size_t n_bytes,
                                            size_t *consumed);
 #define ZK_VM_PACK_FILL_STATE 1u  /* also write the 243 VmLocalState words of every cycle (host-side chains: one core, for hosts
                                      that want a finished stream; the default leaves them to zk_cs_seed_stream on the device) */
+/* The queue states a witness generator holds beside the oracle: the tail of each queue the VM pushes to, after every push of this chunk
+ * — the memory queue (= previous tails of the RAM permutation's unsorted-queue witness), the code decommitment queue (= previous tails of
+ * sort_decommittment_requests' witness), the forward log queue (the log-queue simulator's states).  With them the packer writes every
+ * VmLocalState word of every cycle WITHOUT hashing these chains (only a call's callstack-sponge push is hashed on the host: four
+ * permutations per call).  `used_*` are outputs: how far the chunk consumed each array (the next chunk continues there).
+ * ZK_VM_PACK_RECORD_STATES (with ZK_VM_PACK_FILL_STATE): the packer hashes the chains and WRITES the tails into the arrays (capacity
+ * n_*) — the witness generator's role, for fixtures; ZK_VM_PACK_STATES_FROM_WITNESS: it READS them instead of hashing. */
+typedef struct zk_vm_queue_states {
+    uint64_t (*memory_tails)[12]; size_t n_memory_tails, used_memory_tails;
+    uint64_t (*decommit_tails)[12]; size_t n_decommit_tails, used_decommit_tails;
+    uint64_t (*log_forward_tails)[4]; size_t n_log_forward_tails, used_log_forward_tails;
+    size_t host_permutations;   /* out: Poseidon2 permutations the packer ran on the host for this chunk */
+} zk_vm_queue_states;
+#define ZK_VM_PACK_RECORD_STATES 2u
+#define ZK_VM_PACK_STATES_FROM_WITNESS 4u
+/* zk_pack_main_vm_witness with the queue states (flags as above; `states` may be NULL when neither flag is set).  A chunk that needs
+ * more states than the arrays hold reports `underflow` (ZK_VM_PACK_STATES_FROM_WITNESS) or fails with ZK_ERR_CAPACITY (RECORD). */
+int zk_pack_main_vm_witness_states(zk_cs *cs, const zk_vm_closed_form_input *input, const zk_vm_witness_oracle *oracle, zk_vm_queue_states *states,
+                                   uint32_t instance, uint32_t batch, uint64_t *outer_words, uint64_t *loop_words, uint32_t flags,
+                                   zk_vm_pack_report *report);
 /* One instance (chunk of `limit` cycles of the recorded circuit) into the batch's host staging arrays, in the layout of every other
  * packer (include/zkgl_witness.h): outer_words[w * batch + instance], loop_words[w * (batch * limit) + instance * limit + cycle].
  * ZK_ERR_INVALID: cs is not a recorded main_vm circuit.  FIFO underflow is reported, not fatal (the circuit will reject the trace). */

@@ -59,6 +59,56 @@ def test_packer_places_every_oracle_answer_at_its_cycle(fill_state):
                         len(q.callstack), len(q.decommit_pages)], (name, seed)
 
 
+def test_packer_with_the_queue_states_of_the_witness_hashes_only_the_callstack_pushes():
+    """zk_pack_main_vm_witness_states: a first pass plays the witness generator (FILL_STATE | RECORD_STATES: the memory / decommitment /
+    forward-log queue tails after every push are written out), a second pass reads them (STATES_FROM_WITNESS) — the same 243 state words
+    of every cycle as the native VM, with only the callstack sponge of a call (4 permutations) and of the bootloader frame hashed"""
+    d, D = vp.defs()
+    limit = 16
+    cs = vp.vm_cs(limit)
+    lay = cs.main_vm_layout()
+    total_hash, total_read = 0, 0
+    for name, seed, ops, contracts in _programs(D):
+        probe = vn.VmRun(D, vp.make_world_factory(D, ops, contracts), 4 * len(ops) + 64)
+        done_at = next(i for i, s in enumerate(probe.states) if s.depth == 0)
+        n_inst = (done_at + 1 + limit - 1) // limit + 1
+        run = vn.VmRun(D, vp.make_world_factory(D, ops, contracts), n_inst * limit)
+        want_outer, want_loop = vp.pack_instance_streams(cs, D, run, limit, n_inst)
+        ow, lw = cs.input_words()
+        q = vp.oracle_queues(run, 0, n_inst * limit)
+        recorded = []
+        for mode in ("record", "read"):
+            outer = np.zeros((ow, n_inst), dtype=np.uint64); loop = np.zeros((lw, n_inst * limit), dtype=np.uint64)
+            used = [0] * 7
+            for i in range(n_inst):
+                if mode == "record":
+                    arrs = (np.zeros((8 * limit, 12), dtype=np.uint64), np.zeros((2 * limit, 12), dtype=np.uint64), np.zeros((2 * limit, 4), dtype=np.uint64))
+                    st = zkgl.VmQueueStates.over(*arrs)
+                    flags = zkgl.VM_PACK_FILL_STATE | zkgl.VM_PACK_RECORD_STATES
+                else:
+                    arrs, n_used = recorded[i]
+                    st = zkgl.VmQueueStates.over(*[np.ascontiguousarray(a[:k]) for a, k in zip(arrs, n_used)])   # exactly what was pushed: nothing to spare
+                    flags = zkgl.VM_PACK_STATES_FROM_WITNESS
+                rep = cs.pack_main_vm_witness_states(vp.closed_form_input(run, i * limit), q.view(used), st, i, n_inst, outer, loop, flags)
+                assert not rep.underflow, (name, seed, mode, i)
+                got = [rep.used_memory_reads, rep.used_storage_reads, rep.used_refunds, rep.used_rollback_queue_witness, rep.used_rollback_tails_for_call,
+                       rep.used_callstack, rep.used_decommit_pages]
+                used = [a + b for a, b in zip(used, got)]
+                n_used = (st.used_memory_tails, st.used_decommit_tails, st.used_log_forward_tails)
+                if mode == "record":
+                    recorded.append((arrs, n_used))
+                    total_hash += st.host_permutations
+                else:
+                    assert n_used == recorded[i][1], (name, seed, i)
+                    total_read += st.host_permutations
+                    # what is still hashed: the callstack sponge — four permutations per pushed frame (+ the bootloader's formal frame)
+                    assert st.host_permutations % 4 == 0 and st.host_permutations <= 4 * (limit + 1), (name, seed, i, st.host_permutations)
+                assert list(rep.final_state) == [int(x) for x in run.states[(i + 1) * limit].flatten()], (name, seed, mode, i)
+            assert np.array_equal(outer, want_outer), (name, seed, mode)
+            assert np.array_equal(loop, want_loop), (name, seed, mode, _first_difference(loop, want_loop, lay))
+    assert total_read * 4 < total_hash, (total_read, total_hash)
+
+
 def test_packer_reports_underflow_and_rejects_foreign_circuits():
     d, D = vp.defs()
     limit = 16
