@@ -1403,6 +1403,33 @@ def test_sort_decommits_and_code_unpacker_bincode_round_trips():
         zkgl.decode_code_unpacker_witness_bincode(data, len(reqs), len(words) - 1)
     d, used = zkgl.decode_code_unpacker_witness_bincode(data, len(reqs), len(words), keep_tails=True)
     assert used == len(data) and all(list(d._keep[-1][i]) == [0] * 12 for i in range(len(reqs)))
+    # end to end with the REAL previous tails on the wire: bytes -> decode (tails kept) -> packer with tails == the native stream with its
+    # carried words (the memory queue's tails are the RAM permutation's witness; taken from the native restatement here)
+    from oracle import zko
+    from oracle.decommit_native import encode as dq_encode
+    head, prev = [int(v) for v in o[1:13]], []
+    for q in reqs:
+        prev.append(head)
+        head = zko.queue_full_push(head, dq_encode([int(v) for v in q]))
+    dq_queue2 = struct.pack("<Q", len(reqs)) + b"".join(_b_u256(q[0:8]) + struct.pack("<IBI", int(q[8]), int(q[9]), int(q[10])) +
+                                                        b"".join(struct.pack("<Q", int(t)) for t in prev[i]) for i, q in enumerate(reqs))
+    fsm_out = insts[0]["fsm_out"]
+    xo = cn.flatten_fsm(fsm_out)
+    fsm2 = (struct.pack("<8I", *[int(v) for v in xo[0:8]]) + _b_u256(xo[8:16]) + struct.pack("<III", int(xo[16]), int(xo[17]), int(xo[18])) + struct.pack("<H", int(xo[19])) +
+            struct.pack("<I", int(xo[20])) + struct.pack("<BBB", int(xo[21]), int(xo[22]), int(xo[23])) + qstate(xo[24:49]) + qstate(xo[49:74]))
+    n_used = len(insts[0]["pushed"])
+    cw2 = struct.pack("<Q", 1) + struct.pack("<Q", n_used) + b"".join(_b_u256(wd) for wd in words[:n_used])
+    data2 = struct.pack("<BB", 1, 0) + qstate(o[26:51]) + qstate(o[1:26]) + qstate([0] * 25) + fsm + fsm2 + dq_queue2 + cw2
+    d, used = zkgl.decode_code_unpacker_witness_bincode(data2, len(reqs), len(words), keep_tails=True)
+    assert used == len(data2)
+    mt, mtails = [int(v) for v in o[26:51][12:24]], []
+    for m in insts[0]["pushed"]:
+        mt = zko.queue_full_push(mt, zko.memory_query_encode(m))
+        mtails.append(mt)
+    o3 = np.zeros((125, 2), dtype=np.uint64); l3 = np.full((101, 2 * limit), 9, dtype=np.uint64)
+    zkgl.pack_code_unpacker_witness_tails(d, limit, 0, o3, l3, np.array([list(t) for t in d._keep[-1]], dtype=np.uint64), np.array(mtails, dtype=np.uint64))
+    eo, el = _streams(insts)
+    assert np.array_equal(o3[:, 0], eo[:, 0]) and np.array_equal(l3[:, :limit], el[:, :limit])
 
 
 # ---------------------------------------------------------------- a byte vector NOT written by this file's writer
