@@ -1769,6 +1769,27 @@ void CS::emit_scope(Scope& s) {
                 for (uint32_t v = 0; v < s.n_vars; ++v) if (flag_uses[v]) fl.push_back({flag_miss[v], flag_uses[v]});
                 std::sort(fl.rbegin(), fl.rend());
                 fprintf(stderr, "   %llu SELECT flag reads come from bit planes (not modelled as fetches); modelled fetches (16 values) %llu\n", (unsigned long long)plane_reads, (unsigned long long)miss_all);
+                {   // SELECT data operands: how many are the output of another SELECT (mux chains), and how recent that output is
+                    std::vector<int64_t> born_at(s.n_vars, -1); std::vector<uint8_t> by_select(s.n_vars, 0);
+                    int64_t produced2 = 0; uint64_t n_sel = 0, chain[2] = {0, 0}, chain_near[2] = {0, 0}, both_old = 0;
+                    for (auto& op : s.ops) {
+                        if (op.seed_only) continue;
+                        if (op.opcode == ZK_OP_SELECT) {
+                            ++n_sel;
+                            bool any_near = false;
+                            for (int q = 1; q <= 2; ++q) {
+                                if (op.ins[q].kind != Operand::VAR) continue;
+                                const uint32_t v = op.ins[q].idx;
+                                if (by_select[v]) { ++chain[q - 1]; if (produced2 - born_at[v] <= 16) { ++chain_near[q - 1]; any_near = true; } }
+                                else if (produced2 - born_at[v] <= 16) any_near = true;
+                            }
+                            both_old += !any_near;
+                        }
+                        for (uint32_t ov : op.outs) { born_at[ov] = produced2++; by_select[ov] = op.opcode == ZK_OP_SELECT; }
+                    }
+                    fprintf(stderr, "   SELECT data operands: %llu selects; a is a SELECT output in %llu (%llu of them within 16 values), b in %llu (%llu); %llu selects with both operands older than 16 values\n",
+                            (unsigned long long)n_sel, (unsigned long long)chain[0], (unsigned long long)chain_near[0], (unsigned long long)chain[1], (unsigned long long)chain_near[1], (unsigned long long)both_old);
+                }
                 fprintf(stderr, "   modelled fetches by op / operand position:");
                 for (auto& kv : miss_by_op) fprintf(stderr, " %u.%u=%llu", kv.first / 4, kv.first % 4, (unsigned long long)kv.second);
                 fprintf(stderr, "\n");
