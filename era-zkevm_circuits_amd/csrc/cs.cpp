@@ -1143,6 +1143,52 @@ void CS::schedule_loop_ops() {
 // FETCH_SIZE agrees); this order leaves 6.6 k.  A window of 16 touches is the flat optimum of the model (12..20: 6.6-6.8 k; 8: 7.4 k,
 // 48: 8.2 k) and of the kernel (B=384, one box: recording order 43.5 ms, windows 8 / 16 / 48: 42.2 / 40.0 / 42.9 ms).  Weighting misses,
 // a last-consumer bonus or a larger group bonus change the model by < 2 %.
+// Mux chains (opt-in, ZKGL_SELECT_CHAINS=1).  79 % of main_vm's SELECTs take another SELECT's output as their `b` operand:
+// r_k = f_k ? cand_k : r_(k-1) over the opcode families, recorded limb-parallel (parallel_select), so the schedule interleaves the links
+// of 8 / 12 chains and every link reads the previous one back from the store.  This pass transposes every run of consecutive SELECTs
+// whose flags and `a` operands all come from before the run: the links of one chain become consecutive ops (any topological order
+// fills the same cells), which is what the chain form of the device program needs (emit_scope: one op per chain, `r` in a register).
+void CS::chain_selects() {
+    const char* e = std::getenv("ZKGL_SELECT_CHAINS");   // 1: transpose (and, in a -DZKGL_SELECT_CHAINS_KERNEL build, emit chain ops); the order alone is valid everywhere
+    Scope& s = loop_;
+    if (!(e && e[0] == '1') || !limit_ || s.ops.empty()) return;
+    const size_t n = s.ops.size();
+    std::vector<int64_t> producer(s.n_vars, -1);
+    for (size_t i = 0; i < n; ++i) for (uint32_t ov : s.ops[i].outs) if (!s.ops[i].seed_only) producer[ov] = (int64_t)i;
+    std::vector<OpRec> out;
+    out.reserve(n);
+    size_t i = 0;
+    uint64_t runs = 0, moved = 0;
+    while (i < n) {
+        auto is_sel = [&](size_t k) { return !s.ops[k].seed_only && s.ops[k].opcode == ZK_OP_SELECT && s.ops[k].ins.size() == 3; };
+        if (!is_sel(i)) { out.push_back(std::move(s.ops[i])); ++i; continue; }
+        // the run [i, j): SELECTs whose flag and `a` are produced before i (or are not variables of this scope)
+        size_t j = i;
+        auto outside = [&](const Operand& o) { return o.kind != Operand::VAR || producer[o.idx] < (int64_t)i; };
+        while (j < n && is_sel(j) && outside(s.ops[j].ins[0]) && outside(s.ops[j].ins[1])) ++j;
+        if (j == i) { out.push_back(std::move(s.ops[i])); ++i; continue; }
+        // chains inside the run: next[x] = the first later op of the run whose `b` is x's output
+        const size_t len = j - i;
+        std::vector<int64_t> next(len, -1), head_of(len, -1);
+        std::vector<uint8_t> has_prev(len, 0);
+        for (size_t y = 0; y < len; ++y) {
+            const Operand& b = s.ops[i + y].ins[2];
+            if (b.kind != Operand::VAR) continue;
+            const int64_t p = producer[b.idx];
+            if (p >= (int64_t)i && p < (int64_t)(i + y) && next[(size_t)p - i] < 0) { next[(size_t)p - i] = (int64_t)y; has_prev[y] = 1; }
+        }
+        for (size_t h = 0; h < len; ++h) {
+            if (has_prev[h]) continue;
+            for (int64_t x = (int64_t)h; x >= 0; x = next[(size_t)x]) { moved += next[(size_t)x] >= 0; out.push_back(s.ops[i + (size_t)x]); }
+        }
+        ++runs;
+        i = j;
+    }
+    if (out.size() != n) throw ZkError(ZK_ERR_INVALID, "internal: chain_selects lost an op");
+    s.ops = std::move(out);
+    if (getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] chain_selects: %llu runs of SELECTs transposed, %llu chain links\n", (unsigned long long)runs, (unsigned long long)moved);
+}
+
 // SELECT flags the plain loop kernel keeps as bit planes (ZK_OP_FLAG_PLANES): the FLAG_PLANES most used flag variables of a loop scope
 // that at least two SELECTs read.  One rule for the scheduler (such a read costs no operand fetch) and for emit_scope (the plane ids).
 std::vector<uint32_t> CS::select_plane_vars(const Scope& s) const {
@@ -1505,6 +1551,15 @@ void CS::emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool co
             for (size_t q = 1; q < s.ops[oi].ins.size(); ++q) operand_v2(s, s.ops[oi], q, out);
         return;
     }
+    if (first.opcode == ZK_OP_SELECT && emit_chain_ && plane_of_) {   // a mux chain: [b0][plane id, a slot] per link
+        out.push_back((uint32_t)ZK_OP_SELECT | (2u << 8) | ((uint32_t)(n - 1) << 16));
+        operand_v2(s, first, 2, out);
+        for (size_t oi : group) {
+            out.push_back((*plane_of_)[s.ops[oi].ins[0].idx]);
+            operand_v2(s, s.ops[oi], 1, out);
+        }
+        return;
+    }
     if (first.opcode == ZK_OP_SELECT && plane_of_ && (*plane_of_)[first.ins[0].idx] != UINT32_MAX) {   // flags from the bit planes
         out.push_back((uint32_t)ZK_OP_SELECT | (1u << 8) | ((uint32_t)(n - 1) << 16));
         for (size_t oi : group) {
@@ -1581,6 +1636,13 @@ void CS::emit_scope(Scope& s) {
         std::vector<uint32_t> produced_in_group(s.n_vars, UINT32_MAX);  // var -> id of the open group that produces it
         uint32_t group_id = 0, slots_done = 0;
         std::vector<size_t> group;  // op indices of the open group
+        bool group_is_chain = false;   // the open group is a mux chain (members depend on each other through `b`)
+#ifdef ZKGL_SELECT_CHAINS_KERNEL   // the chain form exists only in builds whose kernels carry its handler (kernels_engine2.hpp)
+        const char* ch_env = getenv("ZKGL_SELECT_CHAINS");
+        const bool chains_on = v2 && s.is_loop && ch_env && ch_env[0] == '1';
+#else
+        const bool chains_on = false;
+#endif
         // SELECT flags as bit planes (plain loop kernels: ZK_OP_FLAG_PLANES, kernels_engine2.hpp): the FLAG_PLANES most used flag
         // variables of a loop scope get a plane id; a flag is copied into its plane by a ZK_OP_FLAG_PLANES op emitted lazily, in
         // front of the first SELECT that needs it, together with every other flag produced by then (up to 7 per op)
@@ -1605,6 +1667,7 @@ void CS::emit_scope(Scope& s) {
             const size_t n = group.size();
             const bool counted = group_cap(first, v2) > 1 || first.opcode == ZK_OP_INPUT || first.opcode == ZK_OP_SELECT || first.opcode == ZK_OP_FMA ||
                                  first.opcode == ZK_OP_LC4 || (v2 && first.opcode == ZK_OP_U32MULADD);
+            emit_chain_ = group_is_chain;
             if (v2) emit_group_v2(s, group, counted, out);
             else if (first.opcode == ZK_OP_LOOKUP) {
                 out.push_back((uint32_t)ZK_OP_LOOKUP | ((uint32_t)first.a << 8) | (((uint32_t)first.b | ((uint32_t)(n - 1) << 8)) << 16));
@@ -1621,6 +1684,8 @@ void CS::emit_scope(Scope& s) {
                 slots_done += (uint32_t)s.ops[oi].outs.size();
             }
             group.clear();
+            group_is_chain = false;
+            emit_chain_ = false;
             ++group_id;
         };
         for (size_t oi = 0; oi < s.ops.size(); ++oi) {
@@ -1655,6 +1720,16 @@ void CS::emit_scope(Scope& s) {
                     if (!plane_saved[fv]) throw ZkError(ZK_ERR_INVALID, "internal: SELECT flag not produced before its use");
                 }
             }
+            // mux chains (ZKGL_SELECT_CHAINS=1, after chain_selects): a plane SELECT whose `b` is the output of the open group's LAST member
+            // continues that group as a CHAIN (one op, the running value in a register) when the group is a single plane SELECT or already
+            // a chain, its flag's plane is written, and its `a` does not come from the group
+            if (chains_on && planes_on && op.opcode == ZK_OP_SELECT && !group.empty() && s.ops[group[0]].opcode == ZK_OP_SELECT && (group.size() == 1 || group_is_chain) &&
+                group.size() < 7 && op.ins[2].kind == Operand::VAR && op.ins[2].idx == s.ops[group.back()].outs[0] && op.ins[1].kind == Operand::VAR &&
+                produced_in_group[op.ins[1].idx] != group_id && plane_of[op.ins[0].idx] != UINT32_MAX && plane_saved[op.ins[0].idx] &&
+                plane_of[s.ops[group[0]].ins[0].idx] != UINT32_MAX && produced_in_group[op.ins[0].idx] != group_id) {
+                joins = true;
+                group_is_chain = true;
+            } else if (group_is_chain) joins = false;   // nothing else joins a chain
             if (!joins) flush();
             group.push_back(oi);
             for (uint32_t ov : op.outs) {
@@ -2265,6 +2340,7 @@ void CS::finalize() {
     }
     loop_ops_recorded_ = loop_.ops;
     schedule_loop_ops();
+    chain_selects();
     assign_store_slots(outer_);
     assign_store_slots(loop_);
     emit_scope(outer_);

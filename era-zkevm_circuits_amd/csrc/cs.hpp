@@ -284,6 +284,7 @@ class CS {
     void place_scope(Scope& s);
     std::vector<OpRec> loop_ops_recorded_;   // the loop body as recorded (build_seed_program)
     void schedule_loop_ops();
+    void chain_selects();   // opt-in: the links of one mux chain become consecutive ops (cs.cpp)
     void schedule_by_locality(const std::vector<double>& a, const std::vector<double>& m, double a_tot, double m_tot,
                               const std::vector<std::vector<uint32_t>>& succ, std::vector<uint32_t>& n_pred);
     void emit_scope(Scope& s);
@@ -309,6 +310,7 @@ class CS {
     void operand_v2(const Scope& s, const OpRec& op, size_t pos, std::vector<uint32_t>& out) const;
     std::vector<uint32_t> select_plane_vars(const Scope& s) const;
     void emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool counted, std::vector<uint32_t>& out) const;
+    bool emit_chain_ = false;   // emit_scope: the group being flushed is a mux chain (ZKGL_SELECT_CHAINS)
     const std::vector<uint32_t>* plane_of_ = nullptr;   // emit_scope, v2 form of a loop scope: variable -> SELECT flag plane id (UINT32_MAX: none)
     void upload_scope(Scope& s);
     void ensure_uploaded();

@@ -364,7 +364,38 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                     if constexpr (!STRANDS) nonbool_seen |= (uint32_t)(nb != 0);   // (strands: another wavefront may have copied the flag — the SELECT reads both planes)
                 }
         } break;
-        case ZK_OP_SELECT: if (pa == 1) {
+        case ZK_OP_SELECT:
+#ifdef ZKGL_SELECT_CHAINS_KERNEL   // built only on request (ZKGL_DEFS=-DZKGL_SELECT_CHAINS_KERNEL): its live set costs the interpreter loop spills
+        if (!STRANDS && pa == 2) {
+            // a mux chain (cs.cpp chain_selects / emit_scope): r_0 = b0, r_k = f_k ? a_k : r_(k-1), every r_k stored — [b0][plane id, a slot] x N.
+            // The running value stays in a register; the candidates of all links are loaded up front, and only where some lane of the
+            // wavefront selects them (a link whose flag is zero in all 64 lanes copies r).
+            const uint32_t n = pb + 1;
+            uint64_t a[7], mv[7];
+            uint64_t r = ldv(W[1]);
+            const uint32_t wave_lane = wave_lane_now();
+#pragma unroll
+            for (uint32_t k = 0; k < 7; ++k) if (k < n) mv[k] = planes[W[2 + 2 * k]];
+#pragma unroll
+            for (uint32_t k = 0; k < 7; ++k)
+                if (k < n) {
+                    a[k] = 0;
+                    if (uni((uint32_t)mv[k] | (uint32_t)(mv[k] >> 32))) a[k] = ldv(W[3 + 2 * k]);
+                }
+            pc += 2 + 2 * n;
+#pragma unroll
+            for (uint32_t k = 0; k < 7; ++k)
+                if (k < n) {
+                    const bool f = (mv[k] >> wave_lane) & 1;
+                    // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ (a flag > 1 is
+                    // also != 0, so its candidate was loaded)
+                    if (nonbool_seen) fused_bad |= ((planes[zkdev::FLAG_PLANES + W[2 + 2 * k]] >> wave_lane) & 1) && a[k] != r;
+                    r = f ? a[k] : r;
+                    st(r);
+                }
+        } else
+#endif
+        if (pa == 1) {
             // flags from the bit planes.  A wavefront whose lanes agree on a flag loads the selected operand twice (the second load hits
             // the line the first one brought) instead of both: no branch, no fetch of the branch nobody takes.
             auto body = [&](auto n_) {
