@@ -8,6 +8,7 @@
 #include <cstring>
 #include <array>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <queue>
 #include "device_api.hpp"
@@ -1485,6 +1486,213 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
     }
 }
 
+// ZKGL_VERIFY_DEVICE_PROGRAMS=1 (CPU tests): an independent walk over the scalar-decoded device programs of a scope — the plain form
+// (prog2) and the strand forms — with the op layouts as the KERNELS decode them (kernels_engine2.hpp run_tile2: words per op, members per
+// header, destination words of the strand form, the plane / chain forms of SELECT, ZK_OP_FLAG_PLANES), checked against the recorded
+// ops: every op once (a cooperative macro-op once per strand), its operand words, its output slots, consecutive slots in the plain
+// form, operands produced in an earlier level in the strand form, every plane written before it is read (plain: earlier in the
+// program; strands: in an earlier level, and after the level that produces the flag).  Throws on the first mismatch.
+void CS::verify_device_programs(const Scope& s) const {
+    auto fail = [&](const std::string& what, size_t pc) { throw ZkError(ZK_ERR_INVALID, "device program check (" + std::string(s.is_loop ? "loop" : "outer") + " scope, word " + std::to_string(pc) + "): " + what); };
+    auto operands_per_member = [&](const OpRec& op) -> size_t {   // what the kernel reads per member, from ITS case (not from op.ins)
+        switch (op.opcode) {
+        case ZK_OP_CONST: case ZK_OP_INPUT: case ZK_OP_ISZERO: case ZK_OP_SPLIT: case ZK_OP_LOOP_LAST: case ZK_OP_DIVREM: return 1;
+        case ZK_OP_FMA: return 5; case ZK_OP_LC4: case ZK_OP_DOT4: return 8; case ZK_OP_SELECT: case ZK_OP_UADD: case ZK_OP_USUB: return 3;
+        case ZK_OP_MATMUL12: case ZK_OP_P2_ROUNDS: return 12; case ZK_OP_POSEIDON2: return op.a ? 13 : 12;
+        case ZK_OP_LOOKUP: return op.a; case ZK_OP_U32MULADD: return 4; case ZK_OP_U8X4FMA: case ZK_OP_U256_MULWIDE: case ZK_OP_U256_DIVREM: return 16;
+        case ZK_OP_SHA256_ROUNDS: return 96; case ZK_OP_KECCAK_F: return 200; case ZK_OP_BYTEBUF_FILL: return zkb::N_INPUTS; case ZK_OP_NN_MULMOD: return 50;
+        default: return SIZE_MAX;
+        }
+    };
+    uint32_t max_slot = 0;
+    for (uint32_t v = 0; v < s.n_vars; ++v) if (s.var_slot[v] != UINT32_MAX) max_slot = std::max(max_slot, s.var_slot[v]);
+    std::vector<int64_t> producer(s.n_vars, -1), op_by_slot((size_t)max_slot + 2, -1), var_by_slot((size_t)max_slot + 2, -1);
+    for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+        if (s.ops[oi].seed_only) continue;
+        for (uint32_t ov : s.ops[oi].outs) { producer[ov] = (int64_t)oi; if (s.var_slot[ov] < var_by_slot.size()) var_by_slot[s.var_slot[ov]] = ov; }
+        if (!s.ops[oi].outs.empty() && s.var_slot[s.ops[oi].outs[0]] < op_by_slot.size()) op_by_slot[s.var_slot[s.ops[oi].outs[0]]] = (int64_t)oi;
+    }
+    const std::vector<uint32_t> plane_all = select_plane_vars(s);
+    // one member of one header against its op; returns nothing, throws
+    auto check_member = [&](const std::vector<uint32_t>& prog, size_t at, const OpRec& op, size_t pc) {
+        std::vector<uint32_t> want;
+        if (op.opcode == ZK_OP_NN_MULMOD) {
+            for (size_t q = 0; q < 16; ++q) operand_v2(s, op, q, want);
+            for (size_t q = 0; q < 17; ++q) { if (q < op.a) operand_v2(s, op, 16 + q, want); else want.push_back(0); }
+            for (size_t q = 0; q < 17; ++q) { if (q < op.b) operand_v2(s, op, 16 + op.a + q, want); else want.push_back(0); }
+        } else
+            for (size_t q = (op.opcode == ZK_OP_LOOKUP ? 1 : 0); q < op.ins.size(); ++q) operand_v2(s, op, q, want);
+        if (want.size() != operands_per_member(op)) fail("opcode " + std::to_string(op.opcode) + ": the kernel reads " + std::to_string(operands_per_member(op)) + " operand words, the op has " + std::to_string(want.size()), pc);
+        for (size_t k = 0; k < want.size(); ++k)
+            if (at + k >= prog.size() || prog[at + k] != want[k]) fail("opcode " + std::to_string(op.opcode) + ": operand word " + std::to_string(k) + " differs", pc);
+    };
+    // decode one header at pc of `prog`; D = destination words per member (strand form).  Calls on_op(op index, first output slot) per member,
+    // on_plane_write(slot, id), on_plane_read(id, op index).  Returns the next pc, or SIZE_MAX at a barrier.
+    struct Hooks { std::function<void(size_t, uint32_t, size_t)> on_op; std::function<void(uint32_t, uint32_t, size_t)> plane_write; std::function<void(uint32_t, size_t, size_t)> plane_read;
+                   std::function<int64_t(size_t, uint32_t)> expect; };
+    auto step = [&](const std::vector<uint32_t>& prog, size_t pc, uint32_t D, const Hooks& hk, bool& barrier) -> size_t {
+        barrier = false;
+        if (pc >= prog.size()) fail("ran past the end", pc);
+        const uint32_t h = prog[pc], opc = h & 0xff, pa = (h >> 8) & 0xff, pb = h >> 16;
+        if (opc == ZK_OP_BARRIER) { barrier = true; return pc + 1; }
+        if (opc == ZK_OP_FLAG_PLANES) {
+            const uint32_t n = pb + 1;
+            if (n > 7) fail("FLAG_PLANES with more than 7 flags", pc);
+            for (uint32_t k = 0; k < n; ++k) hk.plane_write(prog[pc + 1 + 2 * k], prog[pc + 2 + 2 * k], pc);
+            return pc + 1 + 2 * n;
+        }
+        if (opc == ZK_OP_SELECT && pa == 2) {   // chain (plain form only)
+            if (D) fail("a chain op in a strand program", pc);
+            const uint32_t n = pb + 1;
+            if (n > 7) fail("chain longer than 7", pc);
+            int64_t prev_out = -1;
+            for (uint32_t k = 0; k < n; ++k) {
+                const int64_t oi = hk.expect(pc, 0);
+                if (oi < 0) fail("chain link without an op", pc);
+                const OpRec& op = s.ops[(size_t)oi];
+                if (op.opcode != ZK_OP_SELECT) fail("chain link is not a SELECT", pc);
+                if (k == 0) { if (prog[pc + 1] != s.var_slot[op.ins[2].idx]) fail("chain: b0 slot", pc); }
+                else if ((int64_t)op.ins[2].idx != prev_out) fail("chain: link's b is not the previous link's output", pc);
+                if (plane_all[op.ins[0].idx] != prog[pc + 2 + 2 * k]) fail("chain: plane id", pc);
+                if (prog[pc + 3 + 2 * k] != s.var_slot[op.ins[1].idx]) fail("chain: a slot", pc);
+                hk.plane_read(prog[pc + 2 + 2 * k], (size_t)oi, pc);
+                hk.on_op((size_t)oi, s.var_slot[op.outs[0]], pc);
+                prev_out = op.outs[0];
+            }
+            return pc + 2 + 2 * n;
+        }
+        // members of the header, as the kernel derives them
+        uint32_t N = 1;
+        bool grouped_lookup = false;
+        if (opc == ZK_OP_INPUT || opc == ZK_OP_SELECT || opc == ZK_OP_FMA || opc == ZK_OP_U32MULADD) N = pb + 1;
+        if (opc == ZK_OP_LOOKUP) { const uint32_t nv = pb & 0xff; grouped_lookup = pa <= 2 && nv <= 2; N = grouped_lookup ? (pb >> 8) + 1 : 1; if (!grouped_lookup && (pb >> 8)) fail("wide lookup with members", pc); }
+        const size_t first_operand = pc + 1 + (opc == ZK_OP_LOOKUP ? 1 : 0);
+        size_t K = SIZE_MAX, at = first_operand;
+        std::vector<size_t> members;
+        for (uint32_t g = 0; g < N; ++g) {
+            // which op is this member?  plain form: the next op in order; strand form: the op whose first output slot is the destination word
+            int64_t oi;
+            if (D) {
+                // the member's operand count is needed to find its destination word: take it from the first member's op kind (same kind in a group)
+                if (K == SIZE_MAX) {
+                    // find K by trying the op at the destination position for each plausible K is circular: use the table by opcode / header
+                    OpRec probe; probe.opcode = (uint8_t)opc; probe.a = (uint8_t)pa; probe.b = (uint8_t)pb;
+                    if (opc == ZK_OP_NN_MULMOD) K = 50; else K = operands_per_member(probe);
+                    if (opc == ZK_OP_SELECT && pa == 1) K = 3;
+                }
+                const size_t dpos = first_operand + (size_t)N * K + g;
+                if (dpos >= prog.size()) fail("destination word past the end", pc);
+                oi = hk.expect(pc, prog[dpos]);
+            } else oi = hk.expect(pc, 0);
+            if (oi < 0) fail("no op for a member of opcode " + std::to_string(opc), pc);
+            const OpRec& op = s.ops[(size_t)oi];
+            if (op.opcode != opc) fail("opcode " + std::to_string(opc) + " in the program, op " + std::to_string(op.opcode) + " recorded", pc);
+            if (K == SIZE_MAX) K = operands_per_member(op);
+            if (K == SIZE_MAX) fail("opcode without a kernel layout", pc);
+            if (opc == ZK_OP_LOOKUP && prog[pc + 1] != op.ins[0].idx) fail("lookup table id", pc);
+            const bool counted = opc == ZK_OP_INPUT || opc == ZK_OP_SELECT || opc == ZK_OP_FMA || opc == ZK_OP_U32MULADD || opc == ZK_OP_LC4 || opc == ZK_OP_LOOKUP;
+            if (!(opc == ZK_OP_SELECT && pa == 1) && pa != op.a) fail("header a", pc);
+            if (!counted && pb != op.b) fail("header b", pc);
+            if (opc == ZK_OP_LOOKUP && (pb & 0xff) != op.b) fail("lookup n_vals", pc);
+            if (opc == ZK_OP_SELECT && pa == 1) {   // plane form: [plane id, a, b]
+                if (plane_all[op.ins[0].idx] == UINT32_MAX || prog[at] != plane_all[op.ins[0].idx]) fail("plane SELECT: plane id", pc);
+                if (prog[at + 1] != s.var_slot[op.ins[1].idx] || prog[at + 2] != s.var_slot[op.ins[2].idx]) fail("plane SELECT: a / b slot", pc);
+                hk.plane_read(prog[at], (size_t)oi, pc);
+            } else check_member(prog, at, op, pc);
+            at += K;
+            members.push_back((size_t)oi);
+        }
+        for (uint32_t g = 0; g < N; ++g) {
+            const OpRec& op = s.ops[members[g]];
+            const uint32_t first_slot = op.outs.empty() ? 0u : s.var_slot[op.outs[0]];
+            if (D && prog[at + g] != first_slot) fail("destination word", pc);
+            for (size_t q = 0; q < op.outs.size(); ++q) if (s.var_slot[op.outs[q]] != first_slot + q) fail("an op's outputs are not consecutive slots", pc);
+            hk.on_op(members[g], first_slot, pc);
+        }
+        return at + (size_t)D * N;
+    };
+    // ---- plain form: every op in order, consecutive output slots, planes written before they are read
+    {
+        std::vector<uint32_t> prog(s.prog2);
+        if (const char* sab = getenv("ZKGL_VERIFY_SABOTAGE")) {   // tests: the check must notice a changed word (loop scope's plain form)
+            const size_t at = (size_t)atoll(sab);
+            if (s.is_loop && at < prog.size()) prog[at] ^= 1u;
+        }
+        prog.resize(prog.size() + 16, 0);
+        size_t cursor = 0, pc = 0;
+        uint32_t next_slot = 0;
+        std::vector<uint8_t> written(zkdev::FLAG_PLANES, 0);
+        auto next_op = [&]() -> int64_t { while (cursor < s.ops.size() && s.ops[cursor].seed_only) ++cursor; return cursor < s.ops.size() ? (int64_t)cursor++ : -1; };
+        Hooks hk;
+        hk.expect = [&](size_t, uint32_t) { return next_op(); };
+        hk.on_op = [&](size_t oi, uint32_t first_slot, size_t at) {
+            if (!s.ops[oi].outs.empty() && first_slot != next_slot) fail("plain form: outputs are not the next consecutive slots", at);
+            next_slot += (uint32_t)s.ops[oi].outs.size();
+        };
+        hk.plane_write = [&](uint32_t slot, uint32_t id, size_t at) {
+            if (id >= zkdev::FLAG_PLANES || slot >= next_slot || var_by_slot[slot] < 0 || plane_all[(size_t)var_by_slot[slot]] != id) fail("FLAG_PLANES: slot / id do not name a produced flag variable", at);
+            written[id] = 1;
+        };
+        hk.plane_read = [&](uint32_t id, size_t, size_t at) { if (id >= zkdev::FLAG_PLANES || !written[id]) fail("a SELECT reads a plane nothing has written", at); };
+        while (pc < s.prog2.size()) { bool bar; pc = step(prog, pc, 0, hk, bar); if (bar) fail("barrier in the plain form", pc); }
+        if (next_op() != -1) fail("plain form ends before the last op", pc);
+    }
+    // ---- strand forms
+    for (int form = 0; form < 2; ++form) {
+        const std::vector<uint32_t>& sp = form ? s.sprog_n : s.sprog;
+        if (sp.empty()) continue;
+        const auto& sb = form ? s.sn_begin : s.s_begin;
+        const auto& se = form ? s.sn_end : s.s_end;
+        const uint32_t NS = form ? NARROW_STRANDS : zkdev::STRANDS_PER_TILE;
+        std::vector<uint32_t> prog(sp);
+        prog.resize(prog.size() + 16, 0);
+        std::vector<int64_t> level_of(s.ops.size(), -1);       // global level (phases in order)
+        std::vector<uint32_t> seen(s.ops.size(), 0);
+        std::vector<int64_t> plane_level(zkdev::FLAG_PLANES, -1);
+        int64_t level_base = 0;
+        for (int ph = 0; ph < 3; ++ph) {
+            int64_t levels_here = 0;
+            std::vector<std::pair<uint32_t, std::pair<size_t, int64_t>>> reads;   // plane id, (op, level)
+            for (uint32_t k = 0; k < NS; ++k) {
+                size_t pc = sb[ph][k];
+                int64_t lv = 0;
+                Hooks hk;
+                hk.expect = [&](size_t at, uint32_t dest) -> int64_t { if (dest >= op_by_slot.size()) fail("destination slot out of range", at); return op_by_slot[dest]; };
+                hk.on_op = [&](size_t oi, uint32_t, size_t at) {
+                    const bool coop = s.ops[oi].opcode == ZK_OP_KECCAK_F || s.ops[oi].opcode == ZK_OP_SHA256_ROUNDS || s.ops[oi].opcode == ZK_OP_BYTEBUF_FILL;
+                    if (level_of[oi] >= 0 && !(coop && level_of[oi] == level_base + lv)) fail("an op appears twice in the strand programs", at);
+                    level_of[oi] = level_base + lv; ++seen[oi];
+                };
+                hk.plane_write = [&](uint32_t slot, uint32_t id, size_t at) {
+                    if (id >= zkdev::FLAG_PLANES || slot >= var_by_slot.size() || var_by_slot[slot] < 0 || plane_all[(size_t)var_by_slot[slot]] != id) fail("FLAG_PLANES: slot / id do not name a flag variable", at);
+                    if (plane_level[id] >= 0) fail("a plane is written twice", at);
+                    plane_level[id] = level_base + lv;
+                };
+                hk.plane_read = [&](uint32_t id, size_t oi, size_t) { reads.push_back({id, {oi, level_base + lv}}); };
+                while (pc < se[ph][k]) { bool bar; pc = step(prog, pc, 1, hk, bar); if (bar) ++lv; }
+                if (pc != se[ph][k]) fail("a strand's last op runs past its end", pc);
+                levels_here = std::max(levels_here, lv + 1);
+            }
+            for (auto& r : reads)
+                if (r.first >= zkdev::FLAG_PLANES || plane_level[r.first] < 0 || !(plane_level[r.first] < r.second.second)) fail("strand form: a SELECT reads a plane that no EARLIER level has written", 0);
+            level_base += levels_here;
+        }
+        for (size_t oi = 0; oi < s.ops.size(); ++oi) {
+            const OpRec& op = s.ops[oi];
+            if (op.seed_only) continue;
+            const bool coop = (op.opcode == ZK_OP_KECCAK_F || op.opcode == ZK_OP_SHA256_ROUNDS || op.opcode == ZK_OP_BYTEBUF_FILL) && (NS & (NS - 1)) == 0;
+            if (seen[oi] != (coop ? NS : 1u)) fail("op " + std::to_string(oi) + " (opcode " + std::to_string(op.opcode) + ") appears " + std::to_string(seen[oi]) + " times in the strand programs", 0);
+            for (auto& in : op.ins)
+                if (in.kind == Operand::VAR && producer[in.idx] >= 0 && !(level_of[(size_t)producer[in.idx]] < level_of[oi])) fail("strand form: an operand is produced in the same or a later level", 0);
+        }
+        for (uint32_t id = 0; id < zkdev::FLAG_PLANES; ++id) {
+            if (plane_level[id] < 0) continue;
+            for (uint32_t v = 0; v < s.n_vars; ++v)
+                if (plane_all[v] == id && producer[v] >= 0 && !(level_of[(size_t)producer[v]] < plane_level[id])) fail("strand form: a plane is copied in the level that produces its flag", 0);
+        }
+    }
+}
+
 // phase 0 = loop body / outer pre, 1 = outer side, 2 = outer post
 void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream, uint32_t n_lanes) const {
     const char* e = getenv("ZKGL_STRANDS");  // 0 off, 1 always, unset: by size and estimated gain
@@ -2354,6 +2562,10 @@ void CS::finalize() {
         build_strands(loop_);
         // the narrow form only where the full form would be used at all (wide op graphs: the hash circuits)
         if (loop_.s_gain[0] >= 3.2f && zkdev::STRANDS_PER_TILE > NARROW_STRANDS) build_strands(loop_, NARROW_STRANDS, true);
+    }
+    if (getenv("ZKGL_VERIFY_DEVICE_PROGRAMS")) {
+        verify_device_programs(outer_);
+        if (limit_) verify_device_programs(loop_);
     }
     uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
     if (!loop_done_) rows = outer_.n_slots;

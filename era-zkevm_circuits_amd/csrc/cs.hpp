@@ -309,6 +309,7 @@ class CS {
     bool inline_multiplicities() const;
     void operand_v2(const Scope& s, const OpRec& op, size_t pos, std::vector<uint32_t>& out) const;
     std::vector<uint32_t> select_plane_vars(const Scope& s) const;
+    void verify_device_programs(const Scope& s) const;   // ZKGL_VERIFY_DEVICE_PROGRAMS=1: independent walk over prog2 / the strand programs
     void emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool counted, std::vector<uint32_t>& out) const;
     bool emit_chain_ = false;   // emit_scope: the group being flushed is a mux chain (ZKGL_SELECT_CHAINS)
     const std::vector<uint32_t>* plane_of_ = nullptr;   // emit_scope, v2 form of a loop scope: variable -> SELECT flag plane id (UINT32_MAX: none)
