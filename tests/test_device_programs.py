@@ -69,3 +69,17 @@ def test_the_check_notices_a_changed_program_word(monkeypatch):
         except zkgl.ZkError:
             caught += 1
     assert caught == 7
+
+
+@pytest.mark.parametrize("form", ["default", "strand_planes", "chain_order"])
+def test_random_programs_decode_to_their_ops(monkeypatch, form):
+    """the fuzz circuits of tests/test_fuzz_programs.py (random mixes of every light op kind over an outer and a loop scope)"""
+    from test_fuzz_programs import random_circuit
+    for k in ("ZKGL_STRAND_PLANES", "ZKGL_FLAG_PLANES", "ZKGL_SELECT_CHAINS", "ZKGL_VERIFY_SABOTAGE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("ZKGL_VERIFY_DEVICE_PROGRAMS", "1")
+    for k, v in FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    for seed in range(30, 60):
+        cs = random_circuit(seed)[0]
+        cs.close()
