@@ -2,6 +2,8 @@
 precompile FSM recorded with the macro-op must be THE SAME circuit as the op-by-op recording — same variables, same gates, same cells —
 and the oracle's restatement of the macro-op must write the same value into every cell (reference cases of
 /root/reference/src/keccak256_round_function/mod.rs:1096-1144, all nine in one batch).  Device parity under -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -55,6 +57,7 @@ def test_device_backend_walk_equals_the_gate_arithmetic_on_the_cpu(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("ZKGL_TEST_UNMEASURED") != "1", reason="opt-in device path written while the GPU was closed to the build: tools/k8_ab_r4.sh runs it (ZKGL_TEST_UNMEASURED=1)")
 def test_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
     """whole trace of the macro recording, plain and strand kernels, both check modes; seeding through the native FSM seeder"""
     cs = record(monkeypatch, True)
