@@ -31,6 +31,10 @@ def test_macro_recording_is_the_same_circuit_and_the_oracle_fills_the_same_cells
     for k in ("rows_per_instance", "constraints_per_instance", "loop_slots", "outer_slots", "gate_instances"):
         assert sp[k] == sm[k], k
     assert sm["loop_ops"] < sp["loop_ops"] - 6 * 7000          # six fills of ~7.7 k ops each became six ops
+    # the fused mode evaluates the same relations where their values are produced in both recordings: the macro-op mirrors exactly the
+    # FMA / Selection / ZeroCheck gates its op-by-op form mirrors, nothing moves into or out of the check program
+    for k in ("constraints_from_store_fused", "constraints_in_witness_fused"):
+        assert sp[k] == sm[k], (k, sp[k], sm[k])
     insts = [reference_case(l, u)[1] for l, u in REFERENCE_CASES]
     outer, loop = streams(insts, 2)
     runs = []
