@@ -33,6 +33,8 @@ void eip_4844_entry_point(CS& cs, uint32_t n_chunks);
 void sha256_blocks_entry_point(CS& cs, uint32_t n_blocks);
 void sha256_round_function_entry_point(CS& cs, uint32_t limit);
 void keccak256_blocks_entry_point(CS& cs, uint32_t n_blocks);
+void keccak_f1600_gadget(CS& cs, zk_var* state);
+void sha256_compress_gadget(CS& cs, zk_var* state, const zk_var* block);
 void keccak256_round_function_entry_point(CS& cs, uint32_t limit);
 void log_sorter_configure(CS& cs);
 void sort_and_deduplicate_events_entry_point(CS& cs, uint32_t limit);
@@ -555,6 +557,14 @@ int zk_circuit_keccak_configure(zk_cs* cs) {
 int zk_circuit_keccak256_blocks(zk_cs* cs, uint32_t n_blocks) {
     NEED(cs);
     return guard([&] { zkgl::keccak256_blocks_entry_point(*cs->cs, n_blocks); });
+}
+int zk_gadget_keccak_f1600(zk_cs* cs, zk_var* state_io) {
+    NEED(cs); NEED(state_io);
+    return guard([&] { zkgl::keccak_f1600_gadget(*cs->cs, state_io); });
+}
+int zk_gadget_sha256_compress(zk_cs* cs, zk_var* state_io, const zk_var* block) {
+    NEED(cs); NEED(state_io); NEED(block);
+    return guard([&] { zkgl::sha256_compress_gadget(*cs->cs, state_io, block); });
 }
 int zk_circuit_keccak256_round_function(zk_cs* cs, uint32_t limit) {
     NEED(cs);

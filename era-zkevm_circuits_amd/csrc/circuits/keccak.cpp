@@ -81,6 +81,20 @@ void keccak256_blocks_entry_point(CS& cs, uint32_t n_blocks) {
     }
 }
 
+// Keccak-f[1600] as a gadget call of a circuit recorded through the C ABI (zk_gadget_keccak_f1600): the permutation the crate reaches
+// through boojum's keccak256 round function (/root/reference/src/keccak256_round_function/mod.rs:796-838), on 200 byte variables of the
+// current scope; state[8 (x + 5 y) + k] = byte k (little-endian) of lane (x, y).
+void keccak_f1600_gadget(CS& cs, zk_var* state) {
+    G g(cs);
+    K k(g);
+    std::array<Lane, 25> s;
+    for (int i = 0; i < 25; ++i)
+        for (int b = 0; b < 8; ++b) s[i][b] = state[8 * i + b];
+    k.permutation(s);
+    for (int i = 0; i < 25; ++i)
+        for (int b = 0; b < 8; ++b) state[8 * i + b] = s[i][b];
+}
+
 // =====================================================================================================
 // keccak256_round_function_entry_point — host-side mirror of
 // /root/reference/src/keccak256_round_function/mod.rs:672-794 (entry point), :155-670 (keccak256_precompile_inner),
@@ -186,6 +200,7 @@ void fill_with_bytes(G& g, ByteBuffer& buf, const std::array<zk_var, 32>& input,
     }
     be.load(buf.bytes.data(), input.data(), g.zero());
     zkb::fill_with_bytes(be, buf.filled, offset, meaningful);
+    if (use_macro) g.cs.end_macro_op();
     for (int j = 0; j < BUF; ++j) buf.bytes[j] = be.byte(j);
     if (use_macro && be.macro_next != first + n) throw ZkError(ZK_ERR_INVALID, "internal: the ByteBuffer gadget and its macro-op disagree on the output count");
     g.range_check_u8_pair(buf.filled, g.sub(g.constant(BUF), buf.filled));  // filled <= capacity

@@ -129,6 +129,7 @@ struct K {
             g.cs.emit_macro_op(ZK_OP_KECCAK_F, ins.data(), 200, first, cb.n);
             macro_next = first;
             zkk::keccak_f(*this, s.data(), KECCAK_RC);
+            g.cs.end_macro_op();
             if (macro_next != first + cb.n) throw ZkError(ZK_ERR_INVALID, "internal: the Keccak gadget and its macro-op disagree on the output count");
             macro_next = ZK_VAR_NONE;
         } else {

@@ -78,6 +78,20 @@ void sha256_blocks_entry_point(CS& cs, uint32_t n_blocks) {
         }
 }
 
+// One SHA-256 compression as a gadget call of a circuit recorded through the C ABI (zk_gadget_sha256_compress): round_function_over_uint32
+// (/root/reference/src/sha256_round_function/mod.rs:271-285) on byte variables of the current scope.  state[4 w + k] = byte k (little-endian)
+// of working word w; block[4 w + k] = byte k (little-endian) of message word w.  The table set of the CS picks the decomposition.
+void sha256_compress_gadget(CS& cs, zk_var* state, const zk_var* block) {
+    G g(cs);
+    sha256_gadget4::AnySha s(g);
+    std::array<Word, 8> st;
+    std::array<Word, 16> bw;
+    for (int w = 0; w < 8; ++w) for (int k = 0; k < 4; ++k) st[w][k] = state[4 * w + k];
+    for (int w = 0; w < 16; ++w) for (int k = 0; k < 4; ++k) bw[w][k] = block[4 * w + k];
+    s.compress_with_hint(st, bw);
+    for (int w = 0; w < 8; ++w) for (int k = 0; k < 4; ++k) state[4 * w + k] = st[w][k];
+}
+
 // =====================================================================================================
 // sha256_round_function_entry_point — host-side mirror of
 // /root/reference/src/sha256_round_function/mod.rs:347-468 (entry point) and :88-340 (sha256_precompile_inner),

@@ -164,6 +164,7 @@ struct S {
             g.cs.emit_macro_op(ZK_OP_SHA256_ROUNDS, ins.data(), 96, first, cb.n);
             macro_next = first;
             zks::compress(*this, st.data(), block_words.data(), w, SHA_K);
+            g.cs.end_macro_op();
             if (macro_next != first + cb.n) throw ZkError(ZK_ERR_INVALID, "internal: the SHA-256 gadget and its macro-op disagree on the output count");
             macro_next = ZK_VAR_NONE;
         } else {

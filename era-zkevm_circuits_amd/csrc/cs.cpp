@@ -304,6 +304,7 @@ void CS::place_gate(uint32_t kind, const zk_var* vars, uint32_t n_vars, const ui
         if (in_loop_) throw ZkError(ZK_ERR_INVALID, "public inputs must be outer-scope variables");
         public_vars_.push_back(g.vars[0]);
     }
+    if (macro_window_op_ >= 0 && macro_window_loop_ == in_loop_) g.owner = (int32_t)cur().ops[macro_window_op_].outs.front();
     s.gates.push_back(std::move(g));
 }
 
@@ -403,6 +404,7 @@ void CS::lookup(uint32_t tid, const zk_var* keys, uint32_t n_keys, zk_var* vals,
         op.outs.push_back(var_index(first) + i);
         lr.vars.push_back(var_index(first) + i);
     }
+    lr.owner = OWNER_LOOKUP_OP;   // the ZK_OP_LOOKUP below finds the row (or reports the miss) and fills the fresh value variables
     s.ops.push_back(std::move(op));
     s.lookups.push_back(std::move(lr));
 }
@@ -415,6 +417,15 @@ void CS::lookup_given(uint32_t tid, const zk_var* keys, uint32_t n_keys, const z
     lr.table = tid;
     for (uint32_t i = 0; i < n_keys; ++i) { check_var(keys[i], in_loop_); lr.vars.push_back(var_index(keys[i])); }
     for (uint32_t i = 0; i < n_vals; ++i) { check_var(vals[i], in_loop_); lr.vars.push_back(var_index(vals[i])); }
+    // a tuple over existing variables is evaluated by the witness kernels only when a macro-op's gadget gives it inside its window AND the
+    // op produces every value of it (the op computes the row from the keys and tests that they are table keys); any other tuple is
+    // checked from the store in every mode
+    if (macro_window_op_ >= 0 && macro_window_loop_ == in_loop_) {
+        const OpRec& mop = cur().ops[macro_window_op_];
+        bool mine = n_vals > 0 && !mop.outs.empty();
+        for (uint32_t i = 0; i < n_vals && mine; ++i) { const uint32_t v = var_index(vals[i]); mine = v >= mop.outs.front() && v <= mop.outs.back(); }
+        if (mine) lr.owner = (int32_t)mop.outs.front();
+    }
     cur().lookups.push_back(std::move(lr));
 }
 
@@ -422,8 +433,16 @@ void CS::emit_macro_op(uint32_t opcode, const zk_var* ins, uint32_t n_in, zk_var
     std::vector<zk_var> outs(n_out);
     for (uint32_t i = 0; i < n_out; ++i) outs[i] = first_out + i;
     allow_macro_ops_ = true;
+    if (macro_window_op_ >= 0) throw ZkError(ZK_ERR_INVALID, "emit_macro_op: the previous macro-op's window is still open");
     try { emit_op(opcode, 0, 0, ins, n_in, outs.data(), n_out, nullptr, 0); } catch (...) { allow_macro_ops_ = false; throw; }
     allow_macro_ops_ = false;
+    macro_window_op_ = (int32_t)cur().ops.size() - 1;
+    macro_window_loop_ = in_loop_;
+}
+
+void CS::end_macro_op() {
+    if (macro_window_op_ < 0) throw ZkError(ZK_ERR_INVALID, "end_macro_op without emit_macro_op");
+    macro_window_op_ = -1;
 }
 
 void CS::loop_begin(uint32_t limit) {
@@ -543,7 +562,7 @@ void CS::place_scope(Scope& s) {
         s.n_constraints += gi.n_relations;
     }
     // lookups: one table per row, lookup_reps_ tuples per row
-    s.lrows.clear();
+    s.lrows.clear(); s.row_lookups.clear();
     uint32_t n_lookup_slots = 0;
     std::map<uint32_t, Open> lopen;
     for (auto& l : s.lookups) {
@@ -556,6 +575,8 @@ void CS::place_scope(Scope& s) {
         Open& o = it->second;
         uint32_t u = o.used++;
         s.lrows[o.slot].n_tuples = o.used;
+        if (s.row_lookups.size() <= o.slot) s.row_lookups.resize(o.slot + 1);
+        s.row_lookups[o.slot].push_back((uint32_t)(&l - s.lookups.data()));   // tuple u of the row == this record
         for (uint32_t c = 0; c < l.vars.size(); ++c) vc[l.vars[c]].push_back({C + u * lookup_width_ + c, o.slot});
         s.n_constraints += 1;
     }
@@ -698,6 +719,8 @@ void CS::build_check_program(Scope& s) {
             if (!s.ops[oi].seed_only) for (uint32_t ov : s.ops[oi].outs) producer[ov] = (int32_t)oi;
         auto is_var = [](const Operand& o, uint32_t v) { return o.kind == Operand::VAR && o.idx == v; };
         auto pool = [&](const Operand& o, uint64_t& out) { if (o.kind != Operand::CONSTPOOL) return false; out = s.const_pool[o.idx]; return true; };
+        // the gate was placed by the gadget of THIS macro-op inside its window (owner = the op's first output variable: stable under the schedulers)
+        auto owned_by = [](const GateRec& g, const OpRec* op) { return g.owner >= 0 && !op->outs.empty() && (uint32_t)g.owner == op->outs.front(); };
         for (size_t gi = 0; gi < s.gates.size(); ++gi) {
             const GateRec& g = s.gates[gi];
             bool m = false;
@@ -707,8 +730,10 @@ void CS::build_check_program(Scope& s) {
                 const OpRec* op = prod(g.vars[3]);
                 // inside the ByteBuffer macro-op every FMA / Selection / ZeroCheck gate is placed by the gadget from the structure the op
                 // walks (bytebuf_macro.hpp): the op computes exactly these relations on the values it stores; its selectors are its own
-                // is-zero flags and their and / or / not, 0 / 1 for every input
-                if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = true; break; }
+                // is-zero flags and their and / or / not, 0 / 1 for every input.  "Placed by the gadget" is recorded, not assumed: the gate
+                // carries the op it was placed for (GateRec::owner, set only inside the emit_macro_op .. end_macro_op window); a gate
+                // somebody else places on a macro output (zk_cs_place_gate is public) has no owner and stays in the check program
+                if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = owned_by(g, op); break; }
                 uint64_t q, l;
                 m = op && op->opcode == ZK_OP_FMA && op->ins.size() == 5 && pool(op->ins[0], q) && pool(op->ins[1], l) && q == g.consts[0] && l == g.consts[1] &&
                     is_var(op->ins[2], g.vars[0]) && is_var(op->ins[3], g.vars[1]) && is_var(op->ins[4], g.vars[2]);
@@ -717,7 +742,7 @@ void CS::build_check_program(Scope& s) {
                 const OpRec* op = prod(g.vars[4]);
                 // a rotated byte inside the Keccak macro-op: lo 2^b + hi computed by the op from the very lo / hi it stores (keccak_macro.hpp
                 // rotl); only the engine's gadget can record the op (emit_macro_op), and it places this gate from the same structure
-                if (op && (op->opcode == ZK_OP_KECCAK_F || op->opcode == ZK_OP_SHA256_ROUNDS) && g.kind == ZK_GATE_REDUCTION4) { m = true; break; }
+                if (op && (op->opcode == ZK_OP_KECCAK_F || op->opcode == ZK_OP_SHA256_ROUNDS)) { m = g.kind == ZK_GATE_REDUCTION4 && owned_by(g, op); break; }
                 if (op && op->opcode == ZK_OP_LC4 && op->ins.size() == 8) {
                     m = true;
                     uint64_t pw = 1;
@@ -731,12 +756,12 @@ void CS::build_check_program(Scope& s) {
             } break;
             case ZK_GATE_SELECT: {
                 const OpRec* op = prod(g.vars[3]);
-                if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = true; break; }
+                if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = owned_by(g, op); break; }
                 m = op && op->opcode == ZK_OP_SELECT && op->ins.size() == 3 && is_var(op->ins[0], g.vars[2]) && is_var(op->ins[1], g.vars[0]) && is_var(op->ins[2], g.vars[1]);
             } break;
             case ZK_GATE_ZEROCHECK: {
                 const OpRec* op = prod(g.vars[2]);
-                if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = producer[g.vars[1]] == producer[g.vars[2]]; break; }
+                if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = owned_by(g, op) && producer[g.vars[1]] == producer[g.vars[2]]; break; }
                 m = op && op->opcode == ZK_OP_ISZERO && is_var(op->ins[0], g.vars[0]) && op->outs[0] == g.vars[2] && op->outs[1] == g.vars[1];
             } break;
             case ZK_GATE_DOT4: {
@@ -819,17 +844,22 @@ void CS::build_check_program(Scope& s) {
             const TableRec& t = tables_[lr.table - 1];
             const uint32_t tw = t.n_keys + t.n_vals;
             if (tw > 4 || t.n_keys > 3) { lookups_ok = false; return; }  // the row-descriptor checker handles such scopes
-            // fused: every lookup tuple is (the keys of a ZK_OP_LOOKUP, the fresh variables that op fills from the row it found) —
-            // CS::lookup records both together — so the tuple is a table row iff the op found its keys: the witness kernel reports a miss
-            if (mode == 2) continue;
-            for (uint32_t u0 = 0; u0 < lr.n_tuples; u0 += 3) {
-                const uint32_t cnt = std::min(3u, lr.n_tuples - u0);
+            // fused: a tuple recorded by CS::lookup is (the keys of a ZK_OP_LOOKUP, the fresh variables that op fills from the row it found), a
+            // tuple given inside a macro-op's window is (keys, values the op computes from them) — either is a table row iff the op found /
+            // accepted its keys: the witness kernel reports a miss.  LookupRec::owner says so; a tuple nobody owns (lookup_given over
+            // variables of other producers) is read from the store like in the other modes.
+            auto owned = [&](uint32_t u) { return mode == 2 && slot < s.row_lookups.size() && u < s.row_lookups[slot].size() && s.lookups[s.row_lookups[slot][u]].owner >= 0; };
+            for (uint32_t u0 = 0; u0 < lr.n_tuples;) {
+                if (owned(u0)) { ++u0; continue; }
+                uint32_t cnt = 0;
+                while (cnt < 3 && u0 + cnt < lr.n_tuples && !owned(u0 + cnt)) ++cnt;
                 starts.push_back((uint32_t)prog.size());
                 prog.push_back(0x40u | (cnt << 8) | (u0 << 16));
                 prog.push_back(slot);
                 prog.push_back(lr.table);
                 for (uint32_t g = 0; g < cnt; ++g)
                     for (uint32_t i = 0; i < 4; ++i) prog.push_back(i < tw ? s.alias[(size_t)slot * NC + C + (u0 + g) * lookup_width_ + i] : 0u);
+                u0 += cnt;
             }
         }
         if (starts.empty()) { prog.clear(); return; }
@@ -2533,6 +2563,7 @@ void CS::upload_scope(Scope& s) {
 void CS::finalize() {
     if (finalized_) throw ZkError(ZK_ERR_INVALID, "already finalized");
     if (in_loop_) throw ZkError(ZK_ERR_INVALID, "finalize inside loop scope");
+    if (macro_window_op_ >= 0) throw ZkError(ZK_ERR_INVALID, "finalize inside a macro-op's gadget window");
     if (!loop_done_) { limit_ = 0; outer_.pre_ops = outer_.side_ops = outer_.ops.size(); }
     place_scope(outer_);
     place_scope(loop_);
@@ -2608,6 +2639,24 @@ void CS::finalize() {
         for (auto v : sr.b) { r.b.push_back(loop_.var_cells[v][0]); rs.b.push_back(loop_.var_slot[v]); }
         streams_.push_back(std::move(r));
         streams_store_.push_back(std::move(rs));
+    }
+    // ZK_CHECK_FUSED_DEFER_P2 leaves the 950 intermediates of every in-circuit permutation unwritten during the step: allowed only when
+    // nothing of the step reads one — no witness op, lookup tuple, link, stream link, or gate the fused check program keeps (ADVICE r4:
+    // ZK_OP_P2_ROUNDS is recordable through zk_cs_emit_op, so "every op has a verified descriptor" does not imply "nobody looks")
+    loop_.p2_intermediates_private = true;
+    if (limit_ && loop_.n_p2_rounds_ops) {
+        std::vector<uint8_t> inter(loop_.n_vars, 0);
+        for (auto& op : loop_.ops)
+            if (!op.seed_only && op.opcode == ZK_OP_P2_ROUNDS && op.outs.size() > 12)
+                for (size_t q = 0; q + 12 < op.outs.size(); ++q) inter[op.outs[q]] = 1;
+        bool read = false;
+        for (auto& op : loop_.ops) if (!op.seed_only) for (auto& in : op.ins) if (in.kind == Operand::VAR && inter[in.idx]) read = true;   // (seed hints run before the step, on their own values)
+        for (auto& l : loop_.lookups) for (uint32_t v : l.vars) if (inter[v]) read = true;
+        for (auto& l : links_raw_) { if (inter[l.loop_cell]) read = true; if (l.kind == ZK_LINK_CARRY && inter[l.other_cell]) read = true; }
+        for (auto& sr : streams_raw_) { for (auto v : sr.a) if (inter[v]) read = true; for (auto v : sr.b) if (inter[v]) read = true; }
+        for (size_t gi = 0; gi < loop_.gates.size(); ++gi)
+            if (!loop_.gate_mirrored[gi]) for (uint32_t v : loop_.gates[gi].vars) if (inter[v]) read = true;
+        loop_.p2_intermediates_private = !read;
     }
     // tables
     std::vector<zk_table_desc> tdesc(tables_.size() + 1);
@@ -3296,7 +3345,7 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     if (fused) { oa.fail = d_fail_; la.fail = d_fail_ + 3; }
     // deferred mode: only when the step is fused (nothing in it reads the intermediates) and every in-circuit permutation of the loop scope
     // has a verified descriptor for the fill kernel
-    const bool defer = fused && defer_p2_ && limit_ && loop_.d_cmacros && loop_.n_macro_p2 == loop_.n_p2_rounds_ops;
+    const bool defer = fused && defer_p2_ && limit_ && loop_.d_cmacros && loop_.n_macro_p2 == loop_.n_p2_rounds_ops && loop_.p2_intermediates_private;
     la.defer_p2 = defer ? 1u : 0u;
     la.clock_probe = d_fail_ + 6;   // words 6, 7 of the block travel back with the verdict
     hip_check(hipMemsetAsync(d_fail_ + 8, 0, 2 * sizeof(unsigned long long), st), "memset p2 stats");

@@ -46,11 +46,15 @@ struct GateRec {
     uint32_t kind;
     std::vector<uint32_t> vars;  // var indices
     std::vector<uint64_t> consts;
+    int32_t owner = -1;          // first output variable of the macro-op whose gadget placed this gate inside its window (CS::emit_macro_op .. end_macro_op); -1: anybody
 };
 
+constexpr int32_t OWNER_LOOKUP_OP = 0x7fffffff;
 struct LookupRec {
     uint32_t table;
     std::vector<uint32_t> vars;  // keys then values, var indices
+    int32_t owner = -1;          // who evaluates this tuple in the witness kernels: OWNER_LOOKUP_OP = the ZK_OP_LOOKUP CS::lookup records with it; >= 0 = first output
+                                 // variable of the macro-op whose gadget gave it inside its window (CS::lookup_given); -1: nobody — the fused check program keeps it
 };
 
 struct TableRec {
@@ -97,7 +101,9 @@ struct Scope {
     std::vector<uint32_t> cprog_fused, cchunks_fused;
     std::vector<uint32_t> cmacros;   // Poseidon2 macro descriptors (k_check_p2), 14 words each
     std::vector<std::vector<uint32_t>> row_gates;  // [row][instance] -> index into `gates`
+    std::vector<std::vector<uint32_t>> row_lookups;  // [row][tuple] -> index into `lookups`
     uint32_t n_macro_p2 = 0;
+    bool p2_intermediates_private = true;   // no op / lookup / link / kept gate of the step reads an intermediate of a ZK_OP_P2_ROUNDS (deferred mode)
     uint32_t n_p2_rounds_ops = 0;    // ZK_OP_P2_ROUNDS ops of the scope (deferred mode needs a verified descriptor for each)
     std::vector<uint8_t> gate_mirrored;   // per gate: its relation is the semantics of the op producing its output (same variables, constants)
     // lookup sites by table for k_multiplicities: 3 key slots per site; site_off[table id] .. site_off[table id + 1]
@@ -191,7 +197,11 @@ class CS {
     // macro-ops themselves (ZK_OP_KECCAK_F): the fused check trusts such an op to evaluate the tuples and reduction gates placed on
     // its outputs, which holds because gadget and op walk one structure (csrc/keccak_macro.hpp)
     void lookup_given(uint32_t table_id, const zk_var* keys, uint32_t n_keys, const zk_var* vals, uint32_t n_vals);
+    // A macro-op and the WINDOW of its gadget: between emit_macro_op and end_macro_op every gate placed / tuple given on the op's outputs is tagged
+    // with the op (GateRec::owner, LookupRec::owner).  Only tagged gates count as "evaluated by the macro-op" in the fused check; the window
+    // cannot be opened through the C ABI (zk_cs_place_gate on a macro output from outside stays in the check program).
     void emit_macro_op(uint32_t opcode, const zk_var* ins, uint32_t n_in, zk_var first_out, uint32_t n_out);
+    void end_macro_op();
     bool uses_lookup_macros() const { return uses_lookup_macros_; }
     void side_begin();
     void loop_begin(uint32_t limit);
@@ -406,6 +416,8 @@ class CS {
     bool defer_p2_ = false;          // ZK_CHECK_FUSED_DEFER_P2
     bool p2_pending_ = false;        // the loop store lacks the intermediates of its in-circuit permutations (k_fill_p2 not run yet)
     bool uses_lookup_macros_ = false;   // a macro-op whose outputs carry lookup tuples was recorded: multiplicities by the k_multiplicities pass
+    int32_t macro_window_op_ = -1;   // index (current scope) of the macro-op whose gadget window is open
+    bool macro_window_loop_ = false;
     bool allow_macro_ops_ = false;   // zk_cs_set_check_mode(ZK_CHECK_STORED)
 };
 

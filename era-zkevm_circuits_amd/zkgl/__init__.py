@@ -1054,6 +1054,21 @@ class ConstraintSystem:
     def keccak256_blocks_entry_point(self, n_blocks: int):
         _check(lib().zk_circuit_keccak256_blocks(self._h, n_blocks))
 
+    def keccak_f1600(self, state):
+        """zk_gadget_keccak_f1600: 200 byte variables (current scope) -> the 200 output byte variables"""
+        assert len(state) == 200
+        va = (C.c_uint32 * 200)(*state)
+        _check(lib().zk_gadget_keccak_f1600(self._h, va))
+        return list(va)
+
+    def sha256_compress(self, state, block):
+        """zk_gadget_sha256_compress: 32 state byte variables + 64 block byte variables -> the 32 output byte variables"""
+        assert len(state) == 32 and len(block) == 64
+        va = (C.c_uint32 * 32)(*state)
+        ba = (C.c_uint32 * 64)(*block)
+        _check(lib().zk_gadget_sha256_compress(self._h, va, ba))
+        return list(va)
+
     def keccak256_round_function_entry_point(self, limit: int):
         _check(lib().zk_circuit_keccak256_round_function(self._h, limit))
 

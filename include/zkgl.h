@@ -379,6 +379,15 @@ int zk_circuit_log_sorter(zk_cs *cs, uint32_t limit);
  * gadget, src/eip_4844/mod.rs:156-163).  Public inputs = the 32 digest bytes. */
 int zk_circuit_keccak_configure(zk_cs *cs);
 int zk_circuit_keccak256_blocks(zk_cs *cs, uint32_t n_blocks);
+/* Hash permutations as gadget calls of a circuit recorded through this ABI (what the crate's circuits reach through boojum's
+ * keccak256 / sha256 round functions: src/keccak256_round_function/mod.rs:796-838, src/sha256_round_function/mod.rs:271-285).
+ * Variables of the CURRENT scope, bytes, range-checked by the caller (the xor tables of the first round do it for Keccak); the CS must
+ * carry the table set of zk_circuit_keccak_configure / zk_circuit_sha256_configure{,_reference_tables}.  Records the permutation (one
+ * macro witness op + the lookup tuples and reduction gates its gadget places) and replaces state_io by the output byte variables.
+ * Keccak: state_io[8 (x + 5 y) + k] = byte k (little-endian) of lane (x, y).  SHA-256: state_io[4 w + k] / block[4 w + k] = byte k
+ * (little-endian) of working word w / message word w. */
+int zk_gadget_keccak_f1600(zk_cs *cs, zk_var state_io[200]);
+int zk_gadget_sha256_compress(zk_cs *cs, zk_var state_io[32], const zk_var block[64]);
 /* keccak256_round_function_entry_point (src/keccak256_round_function/mod.rs:672-794): the precompile FSM — request
  * queue pop, 6 conditional unaligned memory reads into the 192-byte ByteBuffer, padding, one Keccak-f per cycle,
  * conditional digest write; `limit` cycles.  Uses zk_circuit_keccak_configure.  Outer stream 474 words, loop 507. */

@@ -4,6 +4,7 @@ usage: python tools/pmc_json.py <tag> > profiles/pmc_<tag>.json        (tag: suf
 import json, re, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 G = "gpurun_out/"
+RT = tag.split("_")[0]   # file prefix written by tools/profile_tag.sh (TAG=r5 -> r5_*)
 
 
 def mean(path, kernel, counter):
@@ -13,14 +14,14 @@ def mean(path, kernel, counter):
     raise SystemExit(f"{kernel} {counter} not in {path}")
 
 
-fetch = 2 * 1024 * mean(G + "pmc_r4_fetch.txt", "zke::k_witness_loop", "FETCH_SIZE")
-write = 1024 * mean(G + "pmc_r4_write.txt", "zke::k_witness_loop", "WRITE_SIZE")
-bench = json.loads(open(G + "r4_bench.json").read().strip().splitlines()[-1])
-under = json.loads(open(G + "r4_bench_under_rocprof.json").read().strip().splitlines()[-1])
+fetch = 2 * 1024 * mean(G + "pmc_" + RT + "_fetch.txt", "zke::k_witness_loop", "FETCH_SIZE")
+write = 1024 * mean(G + "pmc_" + RT + "_write.txt", "zke::k_witness_loop", "WRITE_SIZE")
+bench = json.loads(open(G + RT + "_bench.json").read().strip().splitlines()[-1])
+under = json.loads(open(G + RT + "_bench_under_rocprof.json").read().strip().splitlines()[-1])
 roof = bench["roofline"]
 alg = roof["algorithmic_bytes_per_launch"] if "algorithmic_bytes_per_launch" in roof else roof["achieved"] * 1e9 * roof["avg_launch_ms"] * 1e-3
 kt = None
-for line in open(G + "r4_kernel_trace.md"):
+for line in open(G + RT + "_kernel_trace.md"):
     if "k_witness_loop" in line:
         nums = re.findall(r"[0-9]+\.[0-9]+", line)
         kt = line.strip()
