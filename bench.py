@@ -67,16 +67,11 @@ def build_main_vm_cs(zkgl, log2_rows):
 _FIFOS = ("memory_reads", "storage_reads", "refunds", "rollback_queue_witness", "rollback_tails_for_call", "callstack", "decommit_pages")
 
 
-def main_vm_streams(zkgl, cs, limit, n_exec=None, fixture=None):
-    """(outer [words, E], loop [words, E * limit] with the carried VM state zero, expected commitments [E, 4] or None): the fixture's
-    VmCircuitWitnesses — closed-form input + the WitnessOracle's per-getter FIFOs — through the product's zk_pack_main_vm_witness"""
-    fx = np.load(fixture or FIXTURE)
-    E = int(fx["commitment"].shape[0]) if n_exec is None else min(int(n_exec), int(fx["commitment"].shape[0]))
-    n_outer, n_loop = cs.input_words()
-    outer = np.zeros((n_outer, E), dtype=np.uint64)
-    loop = np.zeros((n_loop, E * limit), dtype=np.uint64)
+def fixture_witnesses(zkgl, fx, E):
+    """the fixture's first E VmCircuitWitnesses as the C ABI's structs: (closed-form inputs, WitnessOracle FIFO holders)"""
     arr = {k: fx[k] for k in _FIFOS}
     off = {k: fx[k + "_offsets"] for k in _FIFOS}
+    cfs, queues = [], []
     for e in range(E):
         q = zkgl.VmOracleQueues()
         sl = {k: arr[k][off[k][e]:off[k][e + 1]] for k in _FIFOS}
@@ -91,7 +86,22 @@ def main_vm_streams(zkgl, cs, limit, n_exec=None, fixture=None):
         cf = zkgl.VmClosedFormInput()
         cf.start_flag = 1
         cf.rollback_queue_tail_for_block[:] = [int(x) for x in fx["rollback_tail"][e]]
-        rep = cs.pack_main_vm_witness(cf, q.view(), e, E, outer, loop)
+        cfs.append(cf); queues.append(q)
+    return cfs, queues
+
+
+def main_vm_streams(zkgl, cs, limit, n_exec=None, fixture=None, n_threads=0):
+    """(outer [words, E], loop [words, E * limit] with the carried VM state zero, expected commitments [E, 4] or None): the fixture's
+    VmCircuitWitnesses — closed-form input + the WitnessOracle's per-getter FIFOs — through the product's packer
+    (zk_pack_main_vm_witness_batch: one chunk per host thread)"""
+    fx = np.load(fixture or FIXTURE)
+    E = int(fx["commitment"].shape[0]) if n_exec is None else min(int(n_exec), int(fx["commitment"].shape[0]))
+    n_outer, n_loop = cs.input_words()
+    outer = np.zeros((n_outer, E), dtype=np.uint64)
+    loop = np.zeros((n_loop, E * limit), dtype=np.uint64)
+    cfs, queues = fixture_witnesses(zkgl, fx, E)
+    reps = cs.pack_main_vm_witness_batch(cfs, [q.view() for q in queues], 0, E, outer, loop, n_threads=n_threads)
+    for e, rep in enumerate(reps):
         if rep.underflow:
             raise RuntimeError(f"fixture execution {e}: the packer ran out of oracle answers (fixture made for another circuit?)")
     expect = fx["commitment"][:E].copy() if int(fx["limit"][0]) == limit else None

@@ -18,7 +18,7 @@ for f in zkgl_device.hip; do
   o=$BUILD/$(basename $f).o
   if stale $f $o; then hipcc $FLAGS -c $f -o $o & pids+=($!); fi
 done
-for f in comm.cpp witness_pack.cpp vm_pack.cpp cs.cpp cs_perm.cpp ntt.cpp gadgets.cpp poseidon_consts.cpp capi.cpp circuits/ram_permutation.cpp circuits/vm_shaped.cpp circuits/main_vm.cpp circuits/opcode_defs.cpp circuits/storage_validity.cpp circuits/log_sorter.cpp circuits/keccak.cpp circuits/sha256.cpp circuits/eip4844.cpp circuits/demux_log_queue.cpp circuits/sort_decommits.cpp circuits/code_unpacker.cpp circuits/linear_hasher.cpp; do
+for f in comm.cpp host_pool.cpp witness_pack.cpp vm_pack.cpp cs.cpp cs_perm.cpp ntt.cpp gadgets.cpp poseidon_consts.cpp capi.cpp circuits/ram_permutation.cpp circuits/vm_shaped.cpp circuits/main_vm.cpp circuits/opcode_defs.cpp circuits/storage_validity.cpp circuits/log_sorter.cpp circuits/keccak.cpp circuits/sha256.cpp circuits/eip4844.cpp circuits/demux_log_queue.cpp circuits/sort_decommits.cpp circuits/code_unpacker.cpp circuits/linear_hasher.cpp; do
   o=$BUILD/$(basename $f).o
   if stale $f $o; then hipcc $FLAGS -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $f -o $o & pids+=($!); fi
 done

@@ -7,6 +7,9 @@
 // into the cycle that asked for it.  With ZK_VM_PACK_FILL_STATE it also runs the four Poseidon2 chains on the host and writes the
 // VmLocalState of every cycle — the same words zk_cs_seed_stream derives on the device (kernels_vm_seed.hpp).
 #include <cstring>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 #include <string>
 #include <vector>
 #include "../../include/zkgl.h"
@@ -75,6 +78,20 @@ void poseidon2(u64 s[12]) {
 }
 
 struct Chains { u64 mem[12], dec[12], fwd[4], sponge[12]; };
+
+// n words to a destination this core will not read again: non-temporal 8-byte stores (no read-for-ownership of the destination lines)
+inline void stream_out(u64* dst, const u64* src, uint32_t n) {
+#if defined(__x86_64__)
+    for (uint32_t i = 0; i < n; ++i) _mm_stream_si64((long long*)(dst + i), (long long)src[i]);
+#else
+    std::memcpy(dst, src, (size_t)n * sizeof(u64));
+#endif
+}
+inline void stream_fence() {
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+}
 
 // Env of the walker: FIFOs in, raw stream words + (optionally) hash chains out
 struct PackEnv {
@@ -281,12 +298,14 @@ extern "C" int zk_pack_main_vm_witness_states(zk_cs* h, const zk_vm_closed_form_
     std::memcpy(&defs, cs.circuit_blob.data(), sizeof defs);
     const uint32_t limit = cs.limit();
     const bool chains_on = (flags & ZK_VM_PACK_FILL_STATE) != 0;
+    const bool oracle_only = (flags & ZK_VM_PACK_ORACLE_WORDS_ONLY) != 0;
+    if (oracle_only && chains_on) return bad("zk_pack_main_vm_witness: ORACLE_WORDS_ONLY leaves the state rows to the device seeder; it excludes FILL_STATE / STATES_FROM_WITNESS");
+    if (oracle_only && cs.layout_word("loop", "state") != 0) return bad("zk_pack_main_vm_witness: the recorded layout does not start with the VmLocalState");
     std::memset(report, 0, sizeof *report);
 
     PackEnv env;
     env.o = oracle; env.rep = report; env.cs = &cs; env.chains_on = chains_on;
     if (rec || from) { env.qs = states; env.qs_mode = rec ? 1 : 2; }
-    env.stride = (u64)batch * limit;
     struct { const char* name; u32* dst; } fields[] = {
         {"code_word", &env.w_code_word}, {"src0_read_value", &env.w_src0_value}, {"src0_read_is_ptr", &env.w_src0_is_ptr},
         {"log_pubdata_refund", &env.w_refund}, {"log_storage_read_value", &env.w_log_read}, {"log_rollback_queue_prev_head", &env.w_log_prev_head},
@@ -333,14 +352,33 @@ extern "C" int zk_pack_main_vm_witness_states(zk_cs* h, const zk_vm_closed_form_
             env.ch.dec[i] = in->hidden_fsm_input[vmn::SW_DEC_TAIL + i];
         }
     }
+    // The stream is word-major (loop_words[w][instance][cycle]): a cycle's words are `batch * limit` apart, so writing cycle by cycle is one
+    // cache line and one page per word (round 4: 5.5 ms per instance, all of it store misses).  The walker writes into a TILE of TC cycles
+    // (word w of cycle c at tile[w * TC + c]: 360 words x 64 cycles = 184 KB, cache-resident) and the tile leaves as one contiguous run of
+    // TC words per stream word.
+    // The tile leaves with non-temporal stores: the staging array is written once and read by the DMA engine, never by this core — plain
+    // stores would first READ every line they fill.  ZK_VM_PACK_ORACLE_WORDS_ONLY: the 243 VmLocalState rows are not part of `loop_words` at
+    // all (the device seeder writes every one of them for every cycle): the array starts at row 243 — 117 of 360 rows written, and
+    // copied to the device in one piece (rows are contiguous in the word-major stream).
     const uint32_t n_loop_words = cs.loop_input_words();
-    for (uint32_t c = 0; c < limit; ++c) {
-        u64* const col = loop_words + (u64)instance * limit + c;
-        for (uint32_t w = 0; w < n_loop_words; ++w) col[(u64)w * env.stride] = 0;
-        if (chains_on) write_state(st, env.ch, true, col, env.stride);
-        env.col = col;
-        vmn::vm_cycle(D, G, st, env);
+    const uint32_t w_first = oracle_only ? (uint32_t)vmn::STATE_WORDS : 0u;
+    constexpr uint32_t TC = 64;
+    std::vector<u64> tile((size_t)n_loop_words * TC);
+    env.stride = TC;
+    u64* const dst0 = loop_words + (u64)instance * limit;
+    const u64 dst_stride = (u64)batch * limit;
+    for (uint32_t c0 = 0; c0 < limit; c0 += TC) {
+        const uint32_t nc = std::min(TC, limit - c0);
+        std::memset(tile.data() + (size_t)w_first * TC, 0, (tile.size() - (size_t)w_first * TC) * sizeof(u64));
+        for (uint32_t c = 0; c < nc; ++c) {
+            u64* const col = tile.data() + c;
+            if (chains_on) write_state(st, env.ch, true, col, TC);
+            env.col = col;
+            vmn::vm_cycle(D, G, st, env);
+        }
+        for (uint32_t w = w_first; w < n_loop_words; ++w) stream_out(dst0 + (u64)(w - w_first) * dst_stride + c0, tile.data() + (size_t)w * TC, nc);
     }
+    stream_fence();
     u64 fin[vmn::STATE_WORDS] = {0};
     write_state(st, env.ch, true, fin, 1);
     std::memcpy(report->final_state, fin, sizeof fin);

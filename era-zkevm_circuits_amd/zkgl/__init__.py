@@ -809,7 +809,7 @@ class VmQueueStates(C.Structure):            # zk_vm_queue_states
         return q
 
 
-VM_PACK_RECORD_STATES, VM_PACK_STATES_FROM_WITNESS = 2, 4
+VM_PACK_RECORD_STATES, VM_PACK_STATES_FROM_WITNESS, VM_PACK_ORACLE_WORDS_ONLY = 2, 4, 8
 
 
 class VmClosedFormRest(C.Structure):        # zk_vm_closed_form_rest
@@ -1165,6 +1165,25 @@ class ConstraintSystem:
                                                     outer_words.ctypes.data_as(C.c_void_p), loop_words.ctypes.data_as(C.c_void_p), C.c_uint32(flags),
                                                     C.byref(rep)))
         return rep
+
+    def pack_main_vm_witness_batch(self, closed_forms, oracles, first_instance: int, batch: int, outer_words: np.ndarray, loop_words: np.ndarray,
+                                   flags: int = 0, states=None, n_threads: int = 0):
+        """zk_pack_main_vm_witness_batch: len(closed_forms) chunks into instances first_instance.. of the batch, on n_threads host threads
+        (0: every hardware thread).  Returns the list of VmPackReport."""
+        assert outer_words.dtype == np.uint64 and loop_words.dtype == np.uint64 and outer_words.flags.c_contiguous and loop_words.flags.c_contiguous
+        n = len(closed_forms)
+        assert len(oracles) == n and (states is None or len(states) == n)
+        cfa = (VmClosedFormInput * n)(*closed_forms)
+        oa = (VmWitnessOracle * n)(*oracles)
+        sa = (VmQueueStates * n)(*states) if states is not None else None
+        reps = (VmPackReport * n)()
+        _check(lib().zk_pack_main_vm_witness_batch(self._h, C.c_uint32(n), cfa, oa, sa, C.c_uint32(first_instance), C.c_uint32(batch),
+                                                   outer_words.ctypes.data_as(C.c_void_p), loop_words.ctypes.data_as(C.c_void_p), C.c_uint32(flags), reps,
+                                                   C.c_uint32(n_threads)))
+        if states is not None:   # the `used_*` / host_permutations outputs travel back into the caller's objects
+            for dst, src in zip(states, sa):
+                C.memmove(C.byref(dst), C.byref(src), C.sizeof(VmQueueStates))
+        return list(reps)
 
     def input_words(self):
         a, b = C.c_uint32(), C.c_uint32()

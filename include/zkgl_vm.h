@@ -181,6 +181,12 @@ typedef struct zk_vm_queue_states {
 } zk_vm_queue_states;
 #define ZK_VM_PACK_RECORD_STATES 2u
 #define ZK_VM_PACK_STATES_FROM_WITNESS 4u
+/* The host side of device seeding: `loop_words` holds ONLY the oracle rows of the loop stream — loop_words[(w - 243) * (batch * limit) +
+ * instance * limit + cycle] for the words w >= 243 of the recorded layout — and is copied to row 243 of the device stream in one piece
+ * (the stream is word-major: rows 243.. are contiguous).  The 243 VmLocalState rows (words 0..242 of every cycle) are written on the
+ * device by zk_cs_seed_stream / zk_cs_seed_window_async, every one of them for every cycle, so a host that seeds there neither fills nor
+ * copies them: 117 of 360 rows cross PCIe.  Excludes ZK_VM_PACK_FILL_STATE / _STATES_FROM_WITNESS. */
+#define ZK_VM_PACK_ORACLE_WORDS_ONLY 8u
 /* zk_pack_main_vm_witness with the queue states (flags as above; `states` may be NULL when neither flag is set).  A chunk that needs
  * more states than the arrays hold reports `underflow` (ZK_VM_PACK_STATES_FROM_WITNESS) or fails with ZK_ERR_CAPACITY (RECORD). */
 int zk_pack_main_vm_witness_states(zk_cs *cs, const zk_vm_closed_form_input *input, const zk_vm_witness_oracle *oracle, zk_vm_queue_states *states,
@@ -191,6 +197,14 @@ int zk_pack_main_vm_witness_states(zk_cs *cs, const zk_vm_closed_form_input *inp
  * ZK_ERR_INVALID: cs is not a recorded main_vm circuit.  FIFO underflow is reported, not fatal (the circuit will reject the trace). */
 int zk_pack_main_vm_witness(zk_cs *cs, const zk_vm_closed_form_input *input, const zk_vm_witness_oracle *oracle, uint32_t instance, uint32_t batch,
                             uint64_t *outer_words, uint64_t *loop_words, uint32_t flags, zk_vm_pack_report *report);
+
+/* n_instances chunks (inputs[j], oracles[j], states[j] — `states` may be NULL —, reports[j]) into instances first_instance + j of the batch,
+ * on n_threads host threads (0: all; include/zkgl_witness.h zk_parallel_for).  The chunks are independent: chunks of ONE execution depend
+ * on each other only through hidden_fsm_input / the FIFO positions, which a witness generator holds per chunk
+ * (/root/reference/src/fsm_input_output/circuit_inputs/main_vm.rs:64-71).  Returns the code of the lowest failing chunk. */
+int zk_pack_main_vm_witness_batch(zk_cs *cs, uint32_t n_instances, const zk_vm_closed_form_input *inputs, const zk_vm_witness_oracle *oracles,
+                                  zk_vm_queue_states *states, uint32_t first_instance, uint32_t batch, uint64_t *outer_words, uint64_t *loop_words,
+                                  uint32_t flags, zk_vm_pack_report *reports, uint32_t n_threads);
 
 #ifdef __cplusplus
 }

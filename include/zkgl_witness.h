@@ -16,6 +16,16 @@
 extern "C" {
 #endif
 
+/* ---- the host pool.  Every zk_pack_* entry writes ONE instance's words of the batch staging arrays and shares nothing with the other
+ * instances: the reference resolves its witness closures on a worker pool (/root/reference/src/ram_permutation/mod.rs:553-556; closures
+ * `Send + Sync`, src/base_structures/memory_query/mod.rs:236).  zk_parallel_for runs fn(ctx, job) for job = 0 .. n_jobs-1 on n_threads
+ * host threads (0: every hardware thread; the calling thread works too) — fn packs instance `job` with whichever packer applies.  Returns
+ * the code of the LOWEST failing job (its message, prefixed "job <j>: ", in zk_last_error; *first_failed_job = j, UINT32_MAX when none;
+ * may be NULL); the other jobs still run.  (zk_pack_main_vm_witness_batch, include/zkgl_vm.h: the array form for main_vm.) */
+typedef int (*zk_job_fn)(void *ctx, uint32_t job);
+int zk_parallel_for(uint32_t n_jobs, uint32_t n_threads, zk_job_fn fn, void *ctx, uint32_t *first_failed_job);
+int zk_host_threads(void); /* hardware threads of the host (what n_threads = 0 uses) */
+
 /* MemoryQueryWitness, /root/reference/src/base_structures/memory_query/mod.rs:30-37 (value: UInt256 as 8 little-endian u32 limbs) */
 typedef struct zk_memory_query_witness {
     uint32_t timestamp, memory_page, index;

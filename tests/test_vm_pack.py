@@ -221,3 +221,76 @@ def test_vm_closed_form_input_bincode_decoder():
     cs.pack_main_vm_witness(cf, q.view(), 0, 1, o1, l1)
     cs.pack_main_vm_witness(want, q.view(), 0, 1, o2, l2)
     assert np.array_equal(o1, o2) and np.array_equal(l1, l2)
+
+
+def test_batch_packer_on_host_threads_equals_the_per_instance_packer():
+    """zk_pack_main_vm_witness_batch (host pool, include/zkgl_witness.h zk_parallel_for): the same words as one zk_pack_main_vm_witness
+    per chunk, whatever the thread count; a failing chunk is named"""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    cs, limit = bench.build_main_vm_cs(zkgl, 16)
+    fx = np.load(bench.FIXTURE)
+    E, B = 6, 9                                     # chunks land in instances 2..7 of a batch of 9
+    n_outer, n_loop = cs.input_words()
+    cfs, queues = bench.fixture_witnesses(zkgl, fx, E)
+    want_o = np.zeros((n_outer, B), dtype=np.uint64); want_l = np.zeros((n_loop, B * limit), dtype=np.uint64)
+    want_reps = [cs.pack_main_vm_witness(cfs[e], queues[e].view(), 2 + e, B, want_o, want_l) for e in range(E)]
+    for threads in (1, 3, 0):
+        o = np.zeros_like(want_o); l = np.zeros_like(want_l)
+        reps = cs.pack_main_vm_witness_batch(cfs, [q.view() for q in queues], 2, B, o, l, n_threads=threads)
+        assert np.array_equal(o, want_o) and np.array_equal(l, want_l)
+        for a, b in zip(reps, want_reps):
+            assert bytes(a) == bytes(b)
+    # with the host-side chains too (FILL_STATE): still the same words
+    fo = np.zeros_like(want_o); fl = np.zeros_like(want_l)
+    for e in range(E):
+        cs.pack_main_vm_witness(cfs[e], queues[e].view(), 2 + e, B, fo, fl, zkgl.VM_PACK_FILL_STATE)
+    o = np.zeros_like(want_o); l = np.zeros_like(want_l)
+    cs.pack_main_vm_witness_batch(cfs, [q.view() for q in queues], 2, B, o, l, flags=zkgl.VM_PACK_FILL_STATE, n_threads=4)
+    assert np.array_equal(o, fo) and np.array_equal(l, fl)
+    # out of range: refused before any thread starts
+    with pytest.raises(zkgl.ZkError):
+        cs.pack_main_vm_witness_batch(cfs, [q.view() for q in queues], B - 2, B, o, l)
+
+
+def test_parallel_for_runs_every_job_and_names_the_lowest_failure():
+    C = zkgl.C
+    seen = (C.c_uint32 * 40)()
+    JOB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32)
+
+    def job(ctx, j):
+        seen[j] += 1
+        return 0 if j not in (7, 31) else 2    # ZK_ERR_INVALID-like codes
+    first = C.c_uint32()
+    rc = zkgl.lib().zk_parallel_for(40, 5, JOB(job), None, C.byref(first))
+    assert rc == 2 and first.value == 7 and list(seen) == [1] * 40
+    assert zkgl.lib().zk_last_error().decode().startswith("job 7: ")
+    rc = zkgl.lib().zk_parallel_for(0, 0, JOB(job), None, C.byref(first))
+    assert rc == 0 and first.value == 0xFFFFFFFF
+    assert zkgl.lib().zk_host_threads() >= 1
+
+
+def test_oracle_words_only_packs_exactly_the_rows_behind_the_vm_state():
+    """ZK_VM_PACK_ORACLE_WORDS_ONLY: the array starts at row 243 of the loop stream; its content equals rows 243.. of the full packer's"""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    cs, limit = bench.build_main_vm_cs(zkgl, 16)
+    fx = np.load(bench.FIXTURE)
+    E = 5
+    n_outer, n_loop = cs.input_words()
+    cfs, queues = bench.fixture_witnesses(zkgl, fx, E)
+    views = [q.view() for q in queues]
+    full_o = np.zeros((n_outer, E), dtype=np.uint64); full_l = np.zeros((n_loop, E * limit), dtype=np.uint64)
+    cs.pack_main_vm_witness_batch(cfs, views, 0, E, full_o, full_l, n_threads=2)
+    assert not full_l[:243].any()
+    o = np.zeros_like(full_o); l = np.full((n_loop - 243, E * limit), 0xdead, dtype=np.uint64)
+    reps = cs.pack_main_vm_witness_batch(cfs, views, 0, E, o, l, flags=zkgl.VM_PACK_ORACLE_WORDS_ONLY, n_threads=3)
+    assert np.array_equal(o, full_o) and np.array_equal(l, full_l[243:]) and not any(r.underflow for r in reps)
+    with pytest.raises(zkgl.ZkError):   # the state rows are the device seeder's in this mode
+        cs.pack_main_vm_witness_batch(cfs, views, 0, E, o, l, flags=zkgl.VM_PACK_ORACLE_WORDS_ONLY | zkgl.VM_PACK_FILL_STATE)
