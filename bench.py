@@ -108,6 +108,138 @@ def main_vm_streams(zkgl, cs, limit, n_exec=None, fixture=None, n_threads=0):
     return outer, loop, expect
 
 
+# ------------------------------------------------------------------------------------------------ the host side of a step
+class HostFeed:
+    """What the host does per step when every batch is NEW witness data: the B chunks of a window packed on the host pool
+    (zk_pack_main_vm_witness_batch) into a staging array, the array copied to its place in the device stream.  Two forms:
+      "device_seeds"        ZK_VM_PACK_ORACLE_WORDS_ONLY: 117 of the 360 rows per cycle; the device pass derives the VmLocalState rows
+      "states_from_witness" ZK_VM_PACK_STATES_FROM_WITNESS: all 360 rows, the queue tails read from the witness generator's queue
+                            states (src/fsm_input_output/circuit_inputs/main_vm.rs:64-71, src/ram_permutation/input.rs:105-116): no device pass
+    The packing half needs no GPU (tests/test_vm_pack.py drives it with numpy staging)."""
+
+    def __init__(self, zkgl, cs, limit, B, fixture, mode, n_threads, first_execution=0):
+        self.zkgl, self.cs, self.limit, self.B, self.mode, self.n_threads = zkgl, cs, limit, B, mode, max(1, int(n_threads))
+        self.fx = np.load(fixture)
+        self.n_exec = int(self.fx["commitment"].shape[0])
+        self.first_execution = first_execution
+        self.n_outer, self.n_loop = cs.input_words()
+        self.cfs, self.queues = fixture_witnesses(zkgl, self.fx, self.n_exec)
+        self.views = [q.view() for q in self.queues]
+        self.flags = zkgl.VM_PACK_ORACLE_WORDS_ONLY if mode == "device_seeds" else zkgl.VM_PACK_STATES_FROM_WITNESS
+        self.first_row = VM_STATE_WORDS if mode == "device_seeds" else 0
+        self.states = None
+        if mode == "states_from_witness":       # the witness generator's queue states, produced once by the packer's RECORD mode (hashing, outside any timing)
+            self.states, self._keep = [], []
+            o = np.zeros((self.n_outer, 1), dtype=np.uint64); l = np.zeros((self.n_loop, limit), dtype=np.uint64)
+            for e in range(self.n_exec):
+                arrs = (np.zeros((8 * limit, 12), dtype=np.uint64), np.zeros((2 * limit, 12), dtype=np.uint64), np.zeros((2 * limit, 4), dtype=np.uint64))
+                st = zkgl.VmQueueStates.over(*arrs)
+                cs.pack_main_vm_witness_states(self.cfs[e], self.views[e], st, 0, 1, o, l, zkgl.VM_PACK_FILL_STATE | zkgl.VM_PACK_RECORD_STATES)
+                cut = [np.ascontiguousarray(a[:max(int(k), 1)]) for a, k in zip(arrs, (st.used_memory_tails, st.used_decommit_tails, st.used_log_forward_tails))]
+                self._keep.append(cut)
+                self.states.append(zkgl.VmQueueStates.over(*cut))
+        self._arrays = {}
+
+    def window_arrays(self, k):
+        """ctypes arrays of the B chunks of window k: chunk j replays execution (first_execution + k * B + j) % n_exec"""
+        if k not in self._arrays:
+            C, z = self.zkgl.C, self.zkgl
+            idx = [(self.first_execution + k * self.B + j) % self.n_exec for j in range(self.B)]
+            cfa = (z.VmClosedFormInput * self.B)(*[self.cfs[e] for e in idx])
+            oa = (z.VmWitnessOracle * self.B)(*[self.views[e] for e in idx])
+            sa = None if self.states is None else (z.VmQueueStates * self.B)(*[self.states[e] for e in idx])
+            self._arrays[k] = (cfa, oa, sa)
+        return self._arrays[k]
+
+    def rows(self):
+        return self.n_loop - self.first_row
+
+    def pack_window(self, k, stage_outer, stage_loop, n_threads=None):
+        """window k into stage_outer [n_outer, B] / stage_loop [rows(), B * limit] (u64, C-contiguous); seconds spent in the packer"""
+        cfa, oa, sa = self.window_arrays(k)
+        t = time.perf_counter()
+        reps = self.cs.pack_main_vm_witness_batch(cfa, oa, 0, self.B, stage_outer, stage_loop, flags=self.flags, states=sa,
+                                                  n_threads=self.n_threads if n_threads is None else n_threads)
+        dt = time.perf_counter() - t
+        if any(r.underflow for r in reps):
+            raise RuntimeError("host feed: the packer ran out of oracle answers / queue states")
+        return dt
+
+
+def host_fed_steps(torch, zkgl, cs, feed, dev, K, steps, step_stream, expect, gather_fn):
+    """`steps` steps in which every window is packed on the host and copied to the device WHILE the GPU resolves the previous one.
+    Two device streams of K windows: the GPU works through one (seeding pass at its first window in the "device_seeds" form) while the
+    feeder thread fills the other window by window.  Returns the measured figures; commitments of the last window are compared with
+    the fixture's (so the words the GPU consumed are the words the host packed: the device streams start out zeroed)."""
+    import threading
+    B, limit, n_outer, n_loop = feed.B, feed.limit, feed.n_outer, feed.n_loop
+    S = B * K
+    stage_o = torch.zeros((n_outer, B), dtype=torch.int64).pin_memory()
+    stage_l = torch.zeros((feed.rows(), B * limit), dtype=torch.int64).pin_memory()
+    so_np, sl_np = stage_o.numpy().view(np.uint64), stage_l.numpy().view(np.uint64)
+    d_o = [torch.zeros((n_outer, S), dtype=torch.int64, device=dev) for _ in range(2)]
+    d_l = [torch.zeros((n_loop, S * limit), dtype=torch.int64, device=dev) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    pack_s, h2d_s, errors = [], [], []
+
+    def fill(buf, k):
+        try:
+            pack_s.append(feed.pack_window(k, so_np, sl_np))
+            t = time.perf_counter()
+            with torch.cuda.device(dev), torch.cuda.stream(copy_stream):
+                d_l[buf][feed.first_row:, k * B * limit:(k + 1) * B * limit].copy_(stage_l, non_blocking=True)
+                d_o[buf][:, k * B:(k + 1) * B].copy_(stage_o, non_blocking=True)
+            copy_stream.synchronize()
+            h2d_s.append(time.perf_counter() - t)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def seed(buf):
+        if feed.mode == "device_seeds":
+            cs.seed_window_async(S, d_o[buf], S, d_l[buf], S * limit, 0, step_stream.cuda_stream)
+
+    def run(buf, k):
+        cs.bind_inputs(False, d_o[buf], n_outer, lane_stride=S, lane_offset=k * B)
+        cs.bind_inputs(True, d_l[buf], n_loop, lane_stride=S * limit, lane_offset=k * B * limit)
+        ok, failure = cs.resolve_and_check(step_stream.cuda_stream)
+        if not ok:
+            raise RuntimeError(f"host-fed trace not satisfied: {failure}")
+        gather_fn()
+
+    one_core_s = feed.pack_window(0, so_np, sl_np, n_threads=1) / B      # what ONE host core needs per chunk (staging already touched)
+    for k in range(K):          # the first stream, untimed
+        fill(0, k)
+    if errors:
+        raise RuntimeError(errors[0])
+    n_prologue = len(pack_s)
+    cur = 0
+    seed(cur)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last_k = 0
+    for i in range(steps):
+        k = i % K
+        if k == 0 and i > 0:
+            cur ^= 1
+            seed(cur)           # queued in front of the step kernels, like the resident-stream measurement
+        th = threading.Thread(target=fill, args=(cur ^ 1, k))
+        th.start()
+        run(cur, k)
+        th.join()
+        last_k = k
+        if errors:
+            raise RuntimeError(errors[0])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    local = np.array([cs.public_inputs(i) for i in range(B)], dtype=np.uint64)
+    parity = None if expect is None else bool(np.array_equal(local, expect[last_k * B:(last_k + 1) * B]))
+    pk, hd = pack_s[n_prologue:], h2d_s[n_prologue:]
+    staged_bytes = (stage_l.numel() + stage_o.numel()) * 8
+    del d_o, d_l, stage_o, stage_l
+    return {"elapsed": elapsed, "steps": steps, "pack_ms_per_window": 1e3 * float(np.mean(pk)), "h2d_ms_per_window": 1e3 * float(np.mean(hd)),
+            "pack_ms_per_instance_one_core": 1e3 * one_core_s, "staged_bytes_per_window": staged_bytes, "h2d_GBps": staged_bytes / float(np.mean(hd)) / 1e9, "commitments_equal_native_restatement": parity}
+
+
 # ------------------------------------------------------------------------------------------------ CPU baseline (the only leg that may touch oracle/)
 def cpu_baseline(log2_rows, seconds_target=20.0):
     """CPU restatement ("port"): the oracle's IR interpreter + checker (oracle/zko_engine.c, gcc -O3 -march=native -flto, OpenMP over
@@ -167,6 +299,7 @@ def main():
     ap.add_argument("--log2-rows", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="only the timed default-mode steps (profiler runs: every k_witness_loop launch of the process is then a default-mode launch); the secondary figures are null")
+    ap.add_argument("--no-host-feed", action="store_true", help="skip the host-fed figures (packing + H2D of every window overlapped with the steps)")
     ap.add_argument("--fixture", default="default", choices=sorted(FIXTURES), help="which synthetic executions main_vm replays (default: every opcode family every ~150 cycles)")
     args = ap.parse_args()
     # ---- N > 1 without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
@@ -418,6 +551,25 @@ def main():
         except Exception as e:  # noqa: BLE001
             print(f"[bench] trace_columns timing unavailable: {e}", file=sys.stderr)
 
+    # ---- the host side of the step, measured: every window packed from the WitnessOracle FIFOs on this rank's share of the host threads and
+    # copied to the device while the GPU resolves the previous window (HostFeed / host_fed_steps above).  Labelled figures beside `value`
+    # (whose inputs are resident, as the contract asks).  No collective inside: a failure on one rank must not hang the others.
+    host_feed = None
+    if not args.headline_only and not args.no_host_feed and not os.environ.get("ZKGL_STUB_RUN"):
+        host_feed = {}
+        n_threads = max(1, zkgl.host_threads() // max(1, world))
+        for mode in ("device_seeds", "states_from_witness"):
+            try:
+                feed = HostFeed(zkgl, cs, limit, B, FIXTURES[args.fixture], mode, n_threads, first_execution=rank * S)
+                cs.set_check_mode(False)
+                r = host_fed_steps(torch, zkgl, cs, feed, dev, K, args.steps, step_stream, expect, lambda: gather())
+                r["host_threads_used"] = n_threads
+                host_feed[mode] = r
+                del feed
+            except Exception as e:  # noqa: BLE001
+                host_feed[mode] = {"error": repr(e)}
+                print(f"[bench] host feed ({mode}) unavailable: {e}", file=sys.stderr)
+            torch.cuda.empty_cache()
     from zkgl.dist import gather_floats, max_over_ranks
     elapsed = max_over_ranks(elapsed_local)
     resident = max_over_ranks(resident_local)
@@ -460,6 +612,17 @@ def main():
         res_s = resident / args.steps
         p2_per_cycle = 9   # in-circuit Poseidon2 permutations of a main_vm cycle (the code-word read + the 8 enforced sponges, cycle.rs:670-784), 962 values each
         flat = commits.reshape(-1).astype(np.uint64)
+        def feed_line(r, what):
+            if r is None or "error" in r:
+                return r
+            ms = 1e3 * r["elapsed"] / r["steps"]
+            cores = r["pack_ms_per_instance_one_core"] * B / (1e3 * step_s)     # host cores that pack one window per step of `value`
+            return {"what": what, "value": st["constraints_per_instance"] * B * r["steps"] / r["elapsed"], "unit": "constraints/s (this rank's GPU)",
+                    "ms_per_step": ms, "host_threads_used": r["host_threads_used"], "host_threads_of_the_box": zkgl.host_threads(),
+                    "pack_ms_per_window": r["pack_ms_per_window"], "pack_ms_per_instance_one_core": r["pack_ms_per_instance_one_core"],
+                    "h2d_ms_per_window": r["h2d_ms_per_window"], "h2d_GBps": r["h2d_GBps"], "staged_bytes_per_window": r["staged_bytes_per_window"],
+                    "host_cores_per_gpu_to_sustain_value": cores, "gpus_one_host_can_feed": zkgl.host_threads() / cores if cores > 0 else None,
+                    "commitments_equal_native_restatement": r["commitments_equal_native_restatement"]}
         out = {
             "metric": "constraints/s + witness-rows/s, main_vm 2^20 rows", "value": constraints / elapsed, "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * step_s,
@@ -483,6 +646,14 @@ def main():
                           "(tests/test_fused_differential.py)",
             "value_from_raw_witness_serial": per_step_constraints / (res_s + t_seed_stream / K),
             "witness_rows_materialised_per_s": None if mat_s is None else st["rows_per_instance"] * n_inst / (step_s + B * mat_s),
+            # every window packed on the host pool and copied in WHILE the previous one is resolved (rank 0's figures; every rank runs it on
+            # host_threads / world threads, so at N = 8 this is what one box can do for its eight GPUs)
+            "value_including_host_pack": None if not host_feed else feed_line(host_feed.get("device_seeds"),
+                "every step's window is NEW: B chunks packed from the WitnessOracle FIFOs (zk_pack_main_vm_witness_batch, ZK_VM_PACK_ORACLE_WORDS_ONLY: "
+                "117 of 360 rows) on the host pool + one H2D copy, overlapped with the GPU step; the device pass derives the VmLocalState rows"),
+            "value_states_from_witness": None if not host_feed else feed_line(host_feed.get("states_from_witness"),
+                "as above with ZK_VM_PACK_STATES_FROM_WITNESS: the host writes all 360 rows, queue tails read from the witness's queue states "
+                "(circuit_inputs/main_vm.rs:64-71); NO device seeding pass"),
             "config": {"workload": ("main_vm (real vm_cycle, 11 opcode families; synthetic zkEVM programs from tests/golden/" + os.path.basename(FIXTURES[args.fixture]) + ", "
                                     f"{n_exec} distinct executions through zk_pack_main_vm_witness)") +
                                    f", geometry 140/0/8/deg8 + 3x8 lookups, 2^{args.log2_rows} rows/instance",

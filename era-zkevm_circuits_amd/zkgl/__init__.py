@@ -112,6 +112,11 @@ def poseidon_round_constants() -> np.ndarray:
     return out
 
 
+def host_threads() -> int:
+    """zk_host_threads: hardware threads of the host (what n_threads = 0 means to the host pool)"""
+    return int(lib().zk_host_threads())
+
+
 def _ptr(x):
     if isinstance(x, DeviceBuffer):
         return C.c_void_p(x.ptr)
@@ -1173,14 +1178,15 @@ class ConstraintSystem:
         assert outer_words.dtype == np.uint64 and loop_words.dtype == np.uint64 and outer_words.flags.c_contiguous and loop_words.flags.c_contiguous
         n = len(closed_forms)
         assert len(oracles) == n and (states is None or len(states) == n)
-        cfa = (VmClosedFormInput * n)(*closed_forms)
-        oa = (VmWitnessOracle * n)(*oracles)
-        sa = (VmQueueStates * n)(*states) if states is not None else None
+        # ctypes arrays are taken as they are (a caller that packs the same chunks again and again builds them once)
+        cfa = closed_forms if isinstance(closed_forms, C.Array) else (VmClosedFormInput * n)(*closed_forms)
+        oa = oracles if isinstance(oracles, C.Array) else (VmWitnessOracle * n)(*oracles)
+        sa = None if states is None else states if isinstance(states, C.Array) else (VmQueueStates * n)(*states)
         reps = (VmPackReport * n)()
         _check(lib().zk_pack_main_vm_witness_batch(self._h, C.c_uint32(n), cfa, oa, sa, C.c_uint32(first_instance), C.c_uint32(batch),
                                                    outer_words.ctypes.data_as(C.c_void_p), loop_words.ctypes.data_as(C.c_void_p), C.c_uint32(flags), reps,
                                                    C.c_uint32(n_threads)))
-        if states is not None:   # the `used_*` / host_permutations outputs travel back into the caller's objects
+        if states is not None and not isinstance(states, C.Array):   # the `used_*` / host_permutations outputs travel back into the caller's objects
             for dst, src in zip(states, sa):
                 C.memmove(C.byref(dst), C.byref(src), C.sizeof(VmQueueStates))
         return list(reps)

@@ -294,3 +294,29 @@ def test_oracle_words_only_packs_exactly_the_rows_behind_the_vm_state():
     assert np.array_equal(o, full_o) and np.array_equal(l, full_l[243:]) and not any(r.underflow for r in reps)
     with pytest.raises(zkgl.ZkError):   # the state rows are the device seeder's in this mode
         cs.pack_main_vm_witness_batch(cfs, views, 0, E, o, l, flags=zkgl.VM_PACK_ORACLE_WORDS_ONLY | zkgl.VM_PACK_FILL_STATE)
+
+
+@pytest.mark.parametrize("mode", ["device_seeds", "states_from_witness"])
+def test_bench_host_feed_packs_the_words_the_resident_stream_holds(mode):
+    """bench.py's HostFeed (the host half of value_including_host_pack / value_states_from_witness): window k of the stream, packed on
+    the host pool, equals the rows of the same instances packed one by one — the raw rows (device_seeds) or all 360 with the host-side
+    chains (states_from_witness: the queue tails are READ from the recorded queue states, only callstack pushes are hashed)"""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    cs, limit = bench.build_main_vm_cs(zkgl, 16)
+    B, K, first = 5, 3, 7
+    feed = bench.HostFeed(zkgl, cs, limit, B, bench.FIXTURE, mode, n_threads=3, first_execution=first)
+    n_outer, n_loop = cs.input_words()
+    so = np.zeros((n_outer, B), dtype=np.uint64); sl = np.zeros((feed.rows(), B * limit), dtype=np.uint64)
+    for k in (0, 2):
+        assert feed.pack_window(k, so, sl) > 0
+        wo = np.zeros((n_outer, B), dtype=np.uint64); wl = np.zeros((n_loop, B * limit), dtype=np.uint64)
+        for j in range(B):
+            e = (first + k * B + j) % feed.n_exec
+            cs.pack_main_vm_witness(feed.cfs[e], feed.views[e], j, B, wo, wl, zkgl.VM_PACK_FILL_STATE if mode == "states_from_witness" else 0)
+        assert np.array_equal(so, wo)
+        assert np.array_equal(sl, wl[feed.first_row:])
+    assert feed.rows() == (n_loop - 243 if mode == "device_seeds" else n_loop)
