@@ -18,10 +18,21 @@ for f in zkgl_device.hip; do
   o=$BUILD/$(basename $f).o
   if stale $f $o; then hipcc $FLAGS -c $f -o $o & pids+=($!); fi
 done
-for f in comm.cpp host_pool.cpp witness_pack.cpp vm_pack.cpp cs.cpp cs_perm.cpp ntt.cpp gadgets.cpp poseidon_consts.cpp capi.cpp circuits/ram_permutation.cpp circuits/vm_shaped.cpp circuits/main_vm.cpp circuits/opcode_defs.cpp circuits/storage_validity.cpp circuits/log_sorter.cpp circuits/keccak.cpp circuits/sha256.cpp circuits/eip4844.cpp circuits/demux_log_queue.cpp circuits/sort_decommits.cpp circuits/code_unpacker.cpp circuits/linear_hasher.cpp; do
+for f in comm.cpp host_pool.cpp witness_pack.cpp vm_pack.cpp cs.cpp cs_perm.cpp ntt.cpp gadgets.cpp poseidon_consts.cpp capi.cpp circuits/ram_permutation.cpp circuits/main_vm.cpp circuits/opcode_defs.cpp circuits/storage_validity.cpp circuits/log_sorter.cpp circuits/keccak.cpp circuits/sha256.cpp circuits/eip4844.cpp circuits/demux_log_queue.cpp circuits/sort_decommits.cpp circuits/code_unpacker.cpp circuits/linear_hasher.cpp; do
   o=$BUILD/$(basename $f).o
   if stale $f $o; then hipcc $FLAGS -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $f -o $o & pids+=($!); fi
 done
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $BUILD/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo "built $(readlink -f $OUT)"
+# test-only circuits: their own library beside the product's (links against it; tests load it through zkgl.testlib())
+if [ "$(basename $OUT)" = "libzkgl.so" ]; then
+  TB=$BUILD/testing; mkdir -p $TB
+  tp=()
+  for f in testing/vm_shaped.cpp testing/test_capi.cpp; do
+    o=$TB/$(basename $f).o
+    if stale $f $o; then hipcc $FLAGS -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $f -o $o & tp+=($!); fi
+  done
+  for p in "${tp[@]}"; do wait $p; done
+  hipcc -shared -fPIC -o $(dirname $OUT)/libzkgl_testcircuits.so $TB/*.o -L$(dirname $OUT) -lzkgl -Wl,-rpath,'$ORIGIN'
+fi

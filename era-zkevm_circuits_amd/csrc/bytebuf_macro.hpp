@@ -17,7 +17,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ZKB_HD __host__ __device__ __forceinline__
 #else
 #define ZKB_HD inline

@@ -14,7 +14,6 @@
 namespace zkgl {
 void ram_permutation_configure(CS& cs);
 void ram_permutation_entry_point(CS& cs, uint32_t limit);
-void vm_shaped_configure(CS& cs);
 void main_vm_configure(CS& cs, const zk_opcode_defs& defs, uint32_t flags);
 void main_vm_entry_point(CS& cs, uint32_t limit);
 void keccak_configure(CS& cs);
@@ -40,7 +39,6 @@ void log_sorter_configure(CS& cs);
 void sort_and_deduplicate_events_entry_point(CS& cs, uint32_t limit);
 void storage_validity_configure(CS& cs);
 void sort_and_deduplicate_storage_access_entry_point(CS& cs, uint32_t limit, bool enforce_permutation);
-void vm_shaped_entry_point(CS& cs, uint32_t limit);
 }  // namespace zkgl
 
 struct zk_cs {
@@ -625,14 +623,6 @@ int zk_circuit_sha256_blocks(zk_cs* cs, uint32_t n_blocks) {
 int zk_circuit_sha256_round_function(zk_cs* cs, uint32_t limit) {
     NEED(cs);
     return guard([&] { zkgl::sha256_round_function_entry_point(*cs->cs, limit); });
-}
-int zk_circuit_vm_shaped_configure(zk_cs* cs) {
-    NEED(cs);
-    return guard([&] { zkgl::vm_shaped_configure(*cs->cs); });
-}
-int zk_circuit_vm_shaped(zk_cs* cs, uint32_t limit) {
-    NEED(cs);
-    return guard([&] { zkgl::vm_shaped_entry_point(*cs->cs, limit); });
 }
 int zk_circuit_main_vm_configure_flags(zk_cs* cs, const zk_opcode_defs* defs, uint32_t flags) {
     NEED(cs);

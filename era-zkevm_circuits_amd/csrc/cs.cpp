@@ -894,102 +894,6 @@ void CS::build_check_program(Scope& s) {
     if (getenv("ZKGL_PROG_STATS"))
         fprintf(stderr, "[zkgl] %s scope check program: %zu words, %u Poseidon2 macro packets (gate by gate: %zu words)\n", s.is_loop ? "loop" : "outer", s.cprog.size(),
                 s.n_macro_p2, s.cprog_full.size());
-    if (getenv("ZKGL_CHECK_ORDER_STATS")) {
-        // how many value fetches a small LRU window (the share of L2 a wavefront can count on) leaves to HBM: packets in row order (as
-        // emitted) against gate instances ordered by their youngest operand
-        struct Inst { uint32_t key; std::vector<uint32_t> slots; };
-        std::vector<Inst> insts;
-        for (uint32_t slot = 0; slot < s.n_slots; ++slot) {
-            const zk_row_desc& rd = s.rows[slot];
-            const uint32_t w = rd.kind < ZK_GATE__COUNT ? GATES[rd.kind].width : 0;
-            if (rd.kind < ZK_GATE__COUNT && cap_of(rd.kind))
-                for (uint32_t j = 0; j < rd.n_instances; ++j) {
-                    if (slot < s.row_gates.size() && j < s.row_gates[slot].size() && gate_macro[s.row_gates[slot][j]] >= 0) continue;  // checked by k_check_p2
-                    Inst in; in.key = 0;
-                    for (uint32_t c = 0; c < w; ++c) { const uint32_t v = s.alias[(size_t)slot * NC + j * w + c]; in.slots.push_back(v); in.key = std::max(in.key, v); }
-                    insts.push_back(std::move(in));
-                }
-            const zk_lookup_row_desc& lr = s.lrows[slot];
-            if (lr.table != 0xffffffffu)
-                for (uint32_t u = 0; u < lr.n_tuples; ++u) {
-                    const TableRec& t = tables_[lr.table - 1];
-                    Inst in; in.key = 0;
-                    for (uint32_t c = 0; c < t.n_keys + t.n_vals; ++c) { const uint32_t v = s.alias[(size_t)slot * NC + C + u * lookup_width_ + c]; in.slots.push_back(v); in.key = std::max(in.key, v); }
-                    insts.push_back(std::move(in));
-                }
-        }
-        auto misses = [&](const std::vector<Inst>& order, size_t K) {
-            std::vector<int64_t> last(s.n_store, -1);
-            std::vector<uint32_t> ring;  // distinct-slot LRU approximated by a stamp of distinct touches
-            int64_t stamp = 0; uint64_t miss = 0, refs = 0;
-            for (auto& in : order)
-                for (uint32_t v : in.slots) {
-                    ++refs;
-                    if (last[v] < 0 || stamp - last[v] > (int64_t)K) { ++miss; }
-                    if (last[v] < 0 || stamp - last[v] > 0) ++stamp;
-                    last[v] = stamp;
-                }
-            return std::make_pair(miss, refs);
-        };
-        std::vector<Inst> sorted = insts, by_min = insts, by_mean = insts;
-        std::stable_sort(sorted.begin(), sorted.end(), [](const Inst& a, const Inst& b) { return a.key < b.key; });
-        auto mn = [](const Inst& a) { uint32_t m = UINT32_MAX; for (auto v : a.slots) m = std::min(m, v); return m; };
-        auto mean = [](const Inst& a) { uint64_t t = 0; for (auto v : a.slots) t += v; return a.slots.empty() ? 0 : t / a.slots.size(); };
-        std::stable_sort(by_min.begin(), by_min.end(), [&](const Inst& a, const Inst& b) { return mn(a) < mn(b); });
-        std::stable_sort(by_mean.begin(), by_mean.end(), [&](const Inst& a, const Inst& b) { return mean(a) < mean(b); });
-        {   // references of the remaining gates to values pinned by a constant gate, by constant
-            std::vector<int64_t> pinned(s.n_store, -1);
-            for (uint32_t slot = 0; slot < s.n_slots; ++slot) {
-                const zk_row_desc& rd = s.rows[slot];
-                if (rd.kind != ZK_GATE_CONST) continue;
-                for (uint32_t j = 0; j < rd.n_instances; ++j) pinned[s.alias[(size_t)slot * NC + j]] = (int64_t)(s.rowconsts[rd.const_off + j] & 0x7fffffffffffffffull);
-            }
-            std::map<int64_t, uint64_t> by_value; uint64_t tot = 0;
-            for (auto& in : insts) for (auto v : in.slots) if (pinned[v] >= 0) { by_value[pinned[v]]++; ++tot; }
-            std::vector<std::pair<uint64_t, int64_t>> top; for (auto& kv : by_value) top.push_back({kv.second, kv.first});
-            std::sort(top.rbegin(), top.rend());
-            fprintf(stderr, "[zkgl] %s scope: %llu references to constant-pinned values (incl. the constant gates themselves):", s.is_loop ? "loop" : "outer", (unsigned long long)tot);
-            for (size_t i = 0; i < top.size() && i < 8; ++i) fprintf(stderr, " %lld x%llu", (long long)top[i].second, (unsigned long long)top[i].first);
-            fprintf(stderr, "\n");
-        }
-        if (getenv("ZKGL_CHECK_GREEDY")) {   // gate instances in a greedy locality order (no dependencies between checks): potential of reordering
-            const int64_t W = std::atoll(getenv("ZKGL_CHECK_GREEDY"));
-            std::vector<int64_t> last(s.n_store, INT64_MIN / 2);
-            std::vector<std::vector<uint32_t>> users(s.n_store);
-            for (uint32_t i = 0; i < insts.size(); ++i) for (auto v : insts[i].slots) users[v].push_back(i);
-            std::vector<uint8_t> done(insts.size(), 0);
-            std::vector<Inst> greedy; greedy.reserve(insts.size());
-            int64_t stamp = 0; size_t next_unplaced = 0;
-            std::vector<uint32_t> recent;   // values touched lately (candidates come from their users)
-            while (greedy.size() < insts.size()) {
-                int64_t best = -1; double bs = -1e300;
-                for (size_t r = recent.size() > 24 ? recent.size() - 24 : 0; r < recent.size(); ++r)
-                    for (uint32_t i : users[recent[r]]) {
-                        if (done[i]) continue;
-                        double sc = 0;
-                        for (auto v : insts[i].slots) sc += (stamp - last[v] <= W) ? 1.0 : -1.0;
-                        if (sc > bs + 1e-12 || (std::fabs(sc - bs) <= 1e-12 && (int64_t)i < best)) { bs = sc; best = i; }
-                    }
-                if (best < 0 || bs < -1.5) {   // nothing near: continue in row order
-                    while (next_unplaced < insts.size() && done[next_unplaced]) ++next_unplaced;
-                    if (best < 0 || true) best = (int64_t)next_unplaced;
-                }
-                done[best] = 1; greedy.push_back(insts[best]);
-                for (auto v : insts[best].slots) { last[v] = ++stamp; recent.push_back(v); }
-            }
-            for (size_t K : {16, 32, 64}) {
-                auto a = misses(insts, K), g = misses(greedy, K);
-                fprintf(stderr, "[zkgl] %s scope greedy check order (window %lld): LRU %zu touches: row order %llu fetches, greedy %llu of %llu refs\n", s.is_loop ? "loop" : "outer",
-                        (long long)W, K, (unsigned long long)a.first, (unsigned long long)g.first, (unsigned long long)g.second);
-            }
-        }
-        for (size_t K : {16, 32, 64, 256, 1024}) {
-            auto a = misses(insts, K), b = misses(sorted, K), c = misses(by_min, K), d = misses(by_mean, K);
-            fprintf(stderr, "[zkgl] %s scope check order, window %zu touches: row order %llu fetches of %llu refs; by youngest operand %llu, by oldest %llu, by mean %llu (unique values %u)\n",
-                    s.is_loop ? "loop" : "outer", K, (unsigned long long)a.first, (unsigned long long)a.second, (unsigned long long)b.first, (unsigned long long)c.first,
-                    (unsigned long long)d.first, s.n_store);
-        }
-    }
 }
 
 // Lookup sites of a scope grouped by table (k_multiplicities): the key slots of every recorded lookup
@@ -1055,9 +959,6 @@ void CS::assign_store_slots(Scope& s) {
     for (uint32_t v = 0; v < s.n_vars; ++v)
         if (!seen[v]) s.var_slot[v] = next++;
     s.n_store = std::max<uint32_t>(next, 1);
-    // experiment (ZKGL_STORE_PAD_SLOTS=k): unused slots behind the last value change the tile stride (n_store * 512 B) and with it how the
-    // concurrent accesses of the wavefronts (same slot, different tiles) spread over the memory channels
-    if (const char* pad = std::getenv("ZKGL_STORE_PAD_SLOTS")) s.n_store += (uint32_t)std::atoi(pad);
     s.alias.assign(s.n_trace_cells, 0);
     s.mat_pairs.clear();
     for (uint32_t v = 0; v < s.n_vars; ++v)
@@ -1077,9 +978,8 @@ void CS::assign_store_slots(Scope& s) {
 // always emits the ready op bringing |ALU_done/ALU_total - MEM_done/MEM_total| closest to zero, ties to recording order.
 static uint32_t group_cap(const OpRec& op, bool v2);
 void CS::schedule_loop_ops() {
-    const char* off = std::getenv("ZKGL_SCHEDULE");
     Scope& s = loop_;
-    if (!limit_ || s.ops.size() < 3 || (off && off[0] == '0')) return;
+    if (!limit_ || s.ops.size() < 3) return;
     const size_t n = s.ops.size();
     auto alu_cost = [](const OpRec& op) -> double {
         switch (op.opcode) {
@@ -1130,41 +1030,7 @@ void CS::schedule_loop_ops() {
             ++n_pred[i];
         }
     }
-    // Light ops keep their recording order among themselves (operand locality in L2): only the FIRST ready light op (a
-    // min-heap on the recording index) is a candidate; every ready heavy op is.
-    if (!(off && off[0] == '1')) {   // default: light ops by operand locality (schedule_by_locality); ZKGL_SCHEDULE=1: the round-1 rule below
-        schedule_by_locality(a, m, a_tot, m_tot, succ, n_pred);
-        return;
-    }
-    std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> ready_light;
-    std::vector<uint32_t> ready_heavy, order;
-    order.reserve(n);
-    auto make_ready = [&](uint32_t i) { if (a[i] > 1000) ready_heavy.push_back(i); else ready_light.push(i); };
-    for (size_t i = 0; i < n; ++i)
-        if (n_pred[i] == 0) make_ready((uint32_t)i);
-    double a_done = 0, m_done = 0;
-    auto imbalance_after = [&](uint32_t i) { return std::fabs((a_done + a[i]) / a_tot - (m_done + m[i]) / m_tot); };
-    while (order.size() < n) {
-        uint32_t best = ready_light.empty() ? UINT32_MAX : ready_light.top();
-        double best_v = best == UINT32_MAX ? 1e300 : imbalance_after(best);
-        size_t best_h = SIZE_MAX;
-        for (size_t hi = 0; hi < ready_heavy.size(); ++hi) {
-            const uint32_t h = ready_heavy[hi];
-            double v = imbalance_after(h);
-            if (v < best_v - 1e-12 || (std::fabs(v - best_v) <= 1e-12 && h < best)) { best = h; best_v = v; best_h = hi; }
-        }
-        if (best == UINT32_MAX) return;  // dependency cycle: leave the program as recorded
-        if (best_h != SIZE_MAX) { ready_heavy[best_h] = ready_heavy.back(); ready_heavy.pop_back(); }
-        else ready_light.pop();
-        order.push_back(best);
-        a_done += a[best]; m_done += m[best];
-        for (auto nx : succ[best])
-            if (--n_pred[nx] == 0) make_ready(nx);
-    }
-    std::vector<OpRec> reordered;
-    reordered.reserve(n);
-    for (auto i : order) reordered.push_back(std::move(s.ops[i]));
-    s.ops = std::move(reordered);
+    schedule_by_locality(a, m, a_tot, m_tot, succ, n_pred);   // (rounds 1-2 kept the light ops in recording order; measured and retired, profiles/r2_summary.md)
 }
 
 // The default schedule: the same resource balance for the heavy ops, but among the ready light ops the one whose operands were touched
@@ -1241,13 +1107,12 @@ void CS::schedule_by_locality(const std::vector<double>& a, const std::vector<do
                               const std::vector<std::vector<uint32_t>>& succ, std::vector<uint32_t>& n_pred) {
     Scope& s = loop_;
     const size_t n = s.ops.size();
-    const char* kenv = std::getenv("ZKGL_SCHEDULE_WINDOW");
-    const int64_t W = kenv ? std::atoll(kenv) : 16;   // touches (reads + writes) a value stays "near" for
+    const int64_t W = 16;   // touches (reads + writes) a value stays "near" for (flat optimum 12..20 of the model and of the kernel, see above)
     std::vector<int64_t> last(s.n_vars, INT64_MIN / 2);
     int64_t stamp = 0;
     std::vector<uint32_t> ready_light, ready_heavy, order;
     std::vector<uint8_t> in_ready(n, 0);
-    const bool balance = !(std::getenv("ZKGL_SCHEDULE_BALANCE") && std::getenv("ZKGL_SCHEDULE_BALANCE")[0] == '0');
+    const bool balance = true;   // heavy ops (permutations, inversions) spread by resource balance
     auto make_ready = [&](uint32_t i) { (balance && a[i] > 1000 ? ready_heavy : ready_light).push_back(i); };
     for (size_t i = 0; i < n; ++i) if (n_pred[i] == 0) make_ready((uint32_t)i);
     double a_done = 0, m_done = 0;
@@ -2762,15 +2627,7 @@ void CS::set_batch(uint32_t n) {
         }
         const uint64_t store_lanes = zkgeom::padded_lanes(s.store_geom(), lanes);
         size_t bytes = std::max<size_t>((size_t)s.n_store * store_lanes * 8, 8);
-        // experiment (ZKGL_STORE_CONTIGUOUS=1): physically contiguous VRAM for the store.  The loop kernel's time varies from one process
-        // to the next (38.6 ... 41.5 ms at B=384, profiles/r2_summary.md) with the physical pages the allocation happens to get; a
-        // contiguous block is consistently the slowest layout (43.6 ms)
-        bool got = false;
-        if (std::getenv("ZKGL_STORE_CONTIGUOUS") && s.is_loop) {
-            got = hipExtMallocWithFlags((void**)&s.d_store, bytes, hipDeviceMallocContiguous) == hipSuccess;
-            if (!got) { (void)hipGetLastError(); fprintf(stderr, "[zkgl] contiguous store allocation refused, falling back\n"); }
-        }
-        if (!got) hip_check(hipMalloc((void**)&s.d_store, bytes), "hipMalloc variable store");
+        hip_check(hipMalloc((void**)&s.d_store, bytes), "hipMalloc variable store");
         hip_check(hipMemset(s.d_store, 0, bytes), "hipMemset variable store");
         if (std::getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] %s store at %p (%zu bytes, tiles of %u lanes)\n", s.is_loop ? "loop" : "outer", (void*)s.d_store, bytes, 1u << s.store_tile_log2);
     };

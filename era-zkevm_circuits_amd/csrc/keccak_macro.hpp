@@ -19,7 +19,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ZKK_HD __host__ __device__ __forceinline__
 #else
 #define ZKK_HD inline

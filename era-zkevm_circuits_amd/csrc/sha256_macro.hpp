@@ -18,7 +18,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ZKS_HD __host__ __device__ __forceinline__
 #else
 #define ZKS_HD inline

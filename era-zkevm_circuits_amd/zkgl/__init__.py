@@ -87,6 +87,18 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_testlib = None
+
+
+def testlib() -> C.CDLL:
+    """libzkgl_testcircuits.so: circuits that exist for the tests only (csrc/testing/), built beside libzkgl.so and linked against it"""
+    global _testlib
+    if _testlib is None:
+        lib()
+        _testlib = C.CDLL(os.path.join(os.path.dirname(_LIB_PATH), "libzkgl_testcircuits.so"))
+    return _testlib
+
+
 def _check(rc: int):
     if rc != 0:
         raise ZkError(rc, lib().zk_last_error().decode())
@@ -1122,10 +1134,10 @@ class ConstraintSystem:
         _check(lib().zk_circuit_sha256_round_function(self._h, limit))
 
     def configure_vm_shaped(self):
-        _check(lib().zk_circuit_vm_shaped_configure(self._h))
+        _check(testlib().zk_test_circuit_vm_shaped_configure(self._h))
 
     def vm_shaped_entry_point(self, limit: int):
-        _check(lib().zk_circuit_vm_shaped(self._h, limit))
+        _check(testlib().zk_test_circuit_vm_shaped(self._h, limit))
 
     def configure_main_vm(self, defs: "OpcodeDefs | None" = None, u8x4_fma_gate: bool = True):
         """zk_circuit_main_vm_configure: tables / gate set of the VM CS from the opcode-defs blob (include/zkgl_vm.h).

@@ -431,9 +431,6 @@ int zk_circuit_sha256_blocks(zk_cs *cs, uint32_t n_blocks);
  * queue pop, 2 memory reads + 1 conditional write per cycle on the full-state memory queue, one compression
  * per cycle; `limit` cycles.  Uses zk_circuit_sha256_configure.  Outer stream 87 words, loop stream 112. */
 int zk_circuit_sha256_round_function(zk_cs *cs, uint32_t limit);
-/* main_vm-shaped synthetic cycle (geometry src/main_vm/cycle.rs:959-966) */
-int zk_circuit_vm_shaped_configure(zk_cs *cs);
-int zk_circuit_vm_shaped(zk_cs *cs, uint32_t limit);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
-"""C-ABI surface checks that need no GPU: the library loads, exports every symbol include/zkgl.h
-declares, returns status codes (never aborts) on misuse, and refuses to compute without a GPU."""
+"""C-ABI surface checks that need no GPU: the library loads, exports every symbol the three headers under include/
+declare (zkgl.h, zkgl_vm.h, zkgl_witness.h), returns status codes (never aborts) on misuse, and refuses to compute without a GPU."""
 import ctypes as C
 import os
 import re
@@ -12,18 +12,39 @@ import zkgl
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "zkgl.h")).read()
+HEADERS = ("zkgl.h", "zkgl_vm.h", "zkgl_witness.h")
+
+
+def declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)                       # macros
+    text = re.sub(r"typedef\s+[^;{]*\(\s*\*\s*zk_[a-z0-9_]+\s*\)[^;]*;", "", text)   # function-pointer typedefs (zk_job_fn)
     return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", text)))
 
 
-def test_library_exports_every_declared_symbol():
+@pytest.mark.parametrize("header,at_least", [("zkgl.h", 100), ("zkgl_vm.h", 8), ("zkgl_witness.h", 30)])
+def test_library_exports_every_declared_symbol(header, at_least):
     L = zkgl.lib()
-    syms = declared_symbols()
-    assert len(syms) >= 55
+    syms = declared_symbols(header)
+    assert len(syms) >= at_least, (header, len(syms))
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, missing
+
+
+def test_headers_are_self_contained_c():
+    """every header compiles on its own as plain C (what a cgo / bindgen / ctypes user feeds a C compiler)"""
+    import subprocess, tempfile
+    for h in HEADERS:
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "t.c")
+            open(src, "w").write(f'#include "{os.path.join(ROOT, "include", h)}"\nint main(void) {{ return 0; }}\n')
+            subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", src], check=True)
+
+
+def test_test_only_circuits_are_not_in_the_product_library():
+    assert not hasattr(zkgl.lib(), "zk_test_circuit_vm_shaped") and not hasattr(zkgl.lib(), "zk_circuit_vm_shaped")
+    assert hasattr(zkgl.testlib(), "zk_test_circuit_vm_shaped")
 
 
 def test_round_constants_host_side_match_oracle(oracle):
