@@ -551,6 +551,50 @@ def main():
         except Exception as e:  # noqa: BLE001
             print(f"[bench] trace_columns timing unavailable: {e}", file=sys.stderr)
 
+    # ---- the SAME steps on the compiled-contract-like opcode mix (tests/golden/vm_bench_witness_realistic.npz: ~1 % logs, ~0.5 % calls, ~10 % heap
+    # accesses, large operands): a second labelled value beside the headline's synthetic mix.  Same circuit, same batch, from the raw witness
+    # (seeding pass + K windows + gather).  The interpreter's data-dependent costs differ: more gated permutations skipped, but zero-checks
+    # of large operands and U256 divisions in every wavefront (profiles/r4_loop_variants.md).
+    realistic = None
+    if not args.headline_only and args.fixture == "default" and not os.environ.get("ZKGL_STUB_RUN"):
+        keep = (d_outer, bufs[0], expect)
+        try:
+            outer_r, loop_r, expect_r = main_vm_streams(zkgl, cs, limit, fixture=FIXTURES["realistic"])
+            n_exec_r = outer_r.shape[1]
+            sel_r = (torch.arange(S, device=dev) + rank * S) % n_exec_r
+            d_outer = torch.from_numpy(outer_r.view(np.int64)).to(dev)[:, sel_r].contiguous()
+            le = torch.from_numpy(loop_r.view(np.int64)).to(dev).view(n_loop, n_exec_r, limit)
+            bufs[0] = le[:, sel_r, :].reshape(n_loop, S * limit).contiguous()
+            del le, loop_r
+            expect = None
+            cs.set_check_mode(False)
+            step_no[0] = 0
+            step(); fence()
+            step_no[0] = 0
+            r_loop_ms, r_skip = [], []
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+                r_loop_ms.append(cs.last_ms(1)); r_skip.append(cs.last_ms(9))
+            fence()
+            r_elapsed = time.perf_counter() - t1
+            r_local = np.array([cs.public_inputs(i) for i in range(min(B, 8))], dtype=np.uint64)
+            w = window[0]
+            want = None if expect_r is None else expect_r[((np.arange(S) + rank * S) % n_exec_r)][w * B: w * B + r_local.shape[0]]
+            realistic = {"elapsed": r_elapsed, "loop_ms": float(np.mean(r_loop_ms)), "skipped": float(np.mean(r_skip)),
+                         "commitments_equal": None if want is None else bool(np.array_equal(r_local, want)), "n_exec": int(n_exec_r)}
+        except Exception as e:  # noqa: BLE001
+            realistic = {"error": repr(e)}
+            print(f"[bench] realistic-fixture figure unavailable: {e}", file=sys.stderr)
+        d_outer, bufs[0], expect = keep
+        del keep
+        torch.cuda.empty_cache()
+        try:
+            cs.set_check_mode(False)
+            step_no[0] = 0
+            resolve(last_window)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] re-resolve after the realistic-fixture run failed: {e}", file=sys.stderr)
     # ---- the host side of the step, measured: every window packed from the WitnessOracle FIFOs on this rank's share of the host threads and
     # copied to the device while the GPU resolves the previous window (HostFeed / host_fed_steps above).  Labelled figures beside `value`
     # (whose inputs are resident, as the contract asks).  No collective inside: a failure on one rank must not hang the others.
@@ -600,11 +644,15 @@ def main():
         k_ms = float(np.mean(loop_ms))
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        for name in ("pmc_r4.json", "pmc_r3.json", "pmc_r2.json"):
+        valu_busy, valu_src = None, None
+        for name in ("pmc_r5.json", "pmc_r4.json", "pmc_r3.json", "pmc_r2.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = pmc["traffic_over_algorithmic"] * algo_bytes
                 traffic_src = f"profiles/{name} ratio {pmc['traffic_over_algorithmic']:.3f} measured at batch {pmc['batch']}"
+                vi = pmc.get("valu_issue") or {}
+                if vi.get("valu_busy_frac") is not None:
+                    valu_busy, valu_src = float(vi["valu_busy_frac"]), f"profiles/{name} (SQ_ACTIVE_INST_VALU x 4 / 32 / GRBM_GUI_ACTIVE, its own --pmc pass)"
                 break
             except Exception:
                 pass
@@ -648,6 +696,14 @@ def main():
             "witness_rows_materialised_per_s": None if mat_s is None else st["rows_per_instance"] * n_inst / (step_s + B * mat_s),
             # every window packed on the host pool and copied in WHILE the previous one is resolved (rank 0's figures; every rank runs it on
             # host_threads / world threads, so at N = 8 this is what one box can do for its eight GPUs)
+            "value_realistic_fixture": None if realistic is None else realistic if "error" in realistic else {
+                "what": "the same steps (from the raw witness: seeding pass per K windows, fused check, gather) replaying tests/golden/vm_bench_witness_realistic.npz — "
+                        "the compiled-contract-like opcode mix (~1 % logs, ~0.5 % calls, ~10 % heap accesses, large operands)",
+                "value": st["constraints_per_instance"] * B * args.steps / realistic["elapsed"], "unit": "constraints/s (this rank's GPU)",
+                "ms_per_step": 1e3 * realistic["elapsed"] / args.steps, "k_witness_loop_ms": realistic["loop_ms"],
+                "achieved_GBps": algo_bytes / (realistic["loop_ms"] * 1e-3) / 1e9, "frac": algo_bytes / (realistic["loop_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "witness_only_permutations_skipped_frac": realistic["skipped"], "distinct_executions": realistic["n_exec"],
+                "commitments_equal_native_restatement": realistic["commitments_equal"]},
             "value_including_host_pack": None if not host_feed else feed_line(host_feed.get("device_seeds"),
                 "every step's window is NEW: B chunks packed from the WitnessOracle FIFOs (zk_pack_main_vm_witness_batch, ZK_VM_PACK_ORACLE_WORDS_ONLY: "
                 "117 of 360 rows) on the host pool + one H2D copy, overlapped with the GPU step; the device pass derives the VmLocalState rows"),
@@ -679,7 +735,11 @@ def main():
                 "ms_per_step_with_fill": 1e3 * (deferred["elapsed"] / args.steps + deferred["fill_s"]),
                 "commitments_equal_native_restatement": deferred["commitments_equal"]},
             "roofline": {"bound": "hbm", "kernel": "zke::k_witness_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # the OTHER roofline that binds this kernel (co-limited): fraction of the cycles in which the vector ALUs of a
+                         # SIMD were issuing, from the PMC pass of the committed profile (peak = 1: every SIMD issues every cycle it can)
+                         "frac_valu_issue": valu_busy, "frac_valu_issue_source": valu_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
                          "unit_of_work": "values (one per variable, 8 B): the variable store; trace cells are a view of it",
                          "avg_launch_ms": k_ms,
                          # clock probe inside the kernel (s_memtime / s_memrealtime of its first wavefront): the clock the power management

@@ -1707,6 +1707,19 @@ static uint32_t group_cap(const OpRec& op, bool v2) {
 }
 
 void CS::emit_scope(Scope& s) {
+#ifdef ZKGL_BATCH_INV   // variant build (kernels_engine2.hpp): an ISZERO whose aux output no witness op reads may store it LATER, batched with others
+    {
+        std::vector<uint8_t> read_by_op(s.n_vars, 0);
+        for (auto& op : s.ops)
+            if (!op.seed_only) for (auto& in : op.ins) if (in.kind == Operand::VAR) read_by_op[in.idx] = 1;
+        for (auto& l : links_raw_) {   // (links are checked after the kernel: harmless, kept strict)
+            if (s.is_loop) { read_by_op[l.loop_cell] = 1; if (l.kind == ZK_LINK_CARRY) read_by_op[l.other_cell] = 1; }
+            else if (l.kind != ZK_LINK_CARRY) read_by_op[l.other_cell] = 1;
+        }
+        for (auto& op : s.ops)
+            if (!op.seed_only && op.opcode == ZK_OP_ISZERO && op.outs.size() == 2) op.a = read_by_op[op.outs[1]] ? 0 : 1;
+    }
+#endif
     std::vector<uint8_t> defined(s.n_vars, 0);
     s.prog.clear(); s.prog_full.clear(); s.prog2.clear();
     s.pre_words = 0; s.pre_words_full = 0; s.pre_words2 = 0; s.side_words2 = 0; s.pre_slots = 0; s.side_slots = 0;

@@ -273,7 +273,62 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     uint32_t pc = word_begin;
     uint32_t nonbool_seen = 0;   // uniform: some flag copied into a plane held a value > 1 in some lane (never, on a satisfiable witness)
     bool fused_bad = false;   // fused mode: a gate evaluated here (SELECT's exception, a lookup miss) is violated; reported once, below
+#ifdef ZKGL_BATCH_INV
+    // Montgomery-batched zero-check inversions (variant build; plain narrow kernels).  An ISZERO whose operand is large in some lane of the
+    // wavefront does not run the 72-multiplication chain on its own: it stores its flag, notes (operand offset, aux offset) in LDS — uniform
+    // words, 8 B per entry — and moves on; NBI entries (or the end of the program, or an entry whose aux somebody reads: header a = 0) are
+    // inverted together: operands re-loaded (they are in the store), prefix products, ONE chain, back-substitution — 3 multiplications per
+    // entry + 72 per batch.  x = 0 enters the product as 1 and leaves as 0.  Same values as inv_wave, later in time; the aux of a deferred
+    // entry (header a = 1: cs.cpp emit_scope proves no op reads it) is first read by the check kernels.
+    constexpr bool BATCH_INV = !STRANDS && !WIDE;
+    constexpr uint32_t NBI = 8;
+    __shared__ uint32_t inv_pend_all[BATCH_INV ? (BLOCK / 64) * 2 * NBI : 1];
+    uint32_t* const inv_pend = inv_pend_all + (BATCH_INV ? uni(threadIdx.x >> 6) * 2 * NBI : 0);
+    uint32_t n_pend = 0;      // uniform
+    bool flush_now = false;   // uniform
+    while (true) {
+        if constexpr (BATCH_INV) {
+            if (flush_now || (pc >= word_end && n_pend)) {
+                uint64_t x[NBI], pre[NBI];
+                uint32_t ao[NBI];
+#pragma unroll
+                for (uint32_t k = 0; k < NBI; ++k) {   // entries past n_pend repeat entry 0 (their stores are skipped)
+                    const uint32_t e = k < n_pend ? k : 0;
+                    const uint32_t xo = uni(inv_pend[2 * e]);
+                    ao[k] = uni(inv_pend[2 * e + 1]);
+                    u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, xo, 0);
+                    x[k] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                }
+                uint64_t acc = 1;
+#pragma unroll
+                for (uint32_t k = 0; k < NBI; ++k) {
+                    const uint64_t nz = (k < n_pend && x[k]) ? x[k] : 1ull;
+                    pre[k] = acc;
+                    acc = gl::mul(acc, nz);
+                }
+                uint64_t ia = gl::inv(acc);
+#pragma unroll
+                for (uint32_t kk = 0; kk < NBI; ++kk) {
+                    const uint32_t k = NBI - 1 - kk;
+                    const uint64_t nz = (k < n_pend && x[k]) ? x[k] : 1ull;
+                    const uint64_t r = gl::mul(ia, pre[k]);
+                    ia = gl::mul(ia, nz);
+                    if (k < n_pend) {
+                        const uint64_t o64 = x[k] ? r : 0ull;
+                        u32x2 o;
+                        o.x = (uint32_t)o64; o.y = (uint32_t)(o64 >> 32);
+                        __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, ao[k], 0);
+                    }
+                }
+                n_pend = 0;
+                flush_now = false;
+                continue;
+            }
+        }
+        if (pc >= word_end) break;
+#else
     while (pc < word_end) {
+#endif
         const u32x16_a4 W = *(prog16_ptr)(prog + pc);  // s_load_dwordx16: header + up to 15 operand words (host pads the program)
         const uint32_t h = W[0];
         const uint32_t op = h & 0xff, pa = (h >> 8) & 0xff, pb = h >> 16;
@@ -469,6 +524,20 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             st(x == 0 ? 1ull : 0ull);
 #ifdef ZKGL_STUB_INV  // time attribution only: no inversion
             st(x);
+#elif defined(ZKGL_BATCH_INV)
+            if constexpr (BATCH_INV) {
+                const uint64_t nx = gl::P - x;
+                const bool pos = x < p2::INV_SMALL_N, neg = nx < p2::INV_SMALL_N;
+                if (__builtin_amdgcn_ballot_w64(!(pos || neg)) == 0) {   // as inv_wave: every lane small -> one gather
+                    const uint64_t r = p2::INV_SMALL[pos ? (uint32_t)x : (uint32_t)nx];
+                    st(pos ? r : gl::P - r);
+                } else {                                                  // the chain: with the next NBI - 1 of its kind
+                    if (wave_lane_now() == 0) { inv_pend[2 * n_pend] = W[1] << bsh; inv_pend[2 * n_pend + 1] = dst; }
+                    dst += bstep;
+                    ++n_pend;
+                    flush_now = n_pend == NBI || pa == 0;
+                }
+            } else st(p2::inv_wave(x));
 #else
             st(p2::inv_wave(x));   // small |x| in every lane (flags, counters, position differences): one gather instead of 72 multiplications
 #endif

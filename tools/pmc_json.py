@@ -26,7 +26,31 @@ for line in open(G + RT + "_kernel_trace.md"):
         nums = re.findall(r"[0-9]+\.[0-9]+", line)
         kt = line.strip()
         break
-out = {"note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_r4.sh -> tools/pmc_pass.sh), bench.py --headline-only at batch 384, {tag} code (SELECT flags "
+def opt(path, kernel, counter):
+    try:
+        return mean(path, kernel, counter)
+    except (SystemExit, OSError):
+        return None
+
+
+# VALU-issue roofline of the same kernel (profiles/r3_loop_probe.md §2 method): SQ counters are per shader-engine slice (n = 32 x launches),
+# SQ_ACTIVE_INST_VALU counts quad-cycles per slice: busy = ACTIVE_INST_VALU * 4 / (SIMDs per slice = 32) / GRBM_GUI_ACTIVE
+K = "zke::k_witness_loop"
+valu = {"SQ_INSTS_VALU": opt(G + "pmc_" + RT + "_valu.txt", K, "SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU": opt(G + "pmc_" + RT + "_valu.txt", K, "SQ_ACTIVE_INST_VALU"),
+        "SQ_BUSY_CYCLES": opt(G + "pmc_" + RT + "_valu.txt", K, "SQ_BUSY_CYCLES"), "GRBM_GUI_ACTIVE": opt(G + "pmc_" + RT + "_valu.txt", K, "GRBM_GUI_ACTIVE"),
+        "SQ_INSTS_SALU": opt(G + "pmc_" + RT + "_salu.txt", K, "SQ_INSTS_SALU"), "SQ_WAVES": opt(G + "pmc_" + RT + "_salu.txt", K, "SQ_WAVES"),
+        "SQ_INSTS_VMEM_RD": opt(G + "pmc_" + RT + "_salu.txt", K, "SQ_INSTS_VMEM_RD"), "SQ_INSTS_VMEM_WR": opt(G + "pmc_" + RT + "_salu.txt", K, "SQ_INSTS_VMEM_WR")}
+valu_busy = None
+if valu["SQ_ACTIVE_INST_VALU"] and valu["GRBM_GUI_ACTIVE"]:
+    valu_busy = valu["SQ_ACTIVE_INST_VALU"] * 4 / 32 / valu["GRBM_GUI_ACTIVE"]
+per_wave = None
+if valu["SQ_INSTS_VALU"] and valu["SQ_WAVES"]:
+    per_wave = {"valu": valu["SQ_INSTS_VALU"] / valu["SQ_WAVES"], "salu": (valu["SQ_INSTS_SALU"] or 0) / valu["SQ_WAVES"],
+                "vmem_rd": (valu["SQ_INSTS_VMEM_RD"] or 0) / valu["SQ_WAVES"], "vmem_wr": (valu["SQ_INSTS_VMEM_WR"] or 0) / valu["SQ_WAVES"]}
+out = {"valu_issue": {"counters_per_slice_mean": valu, "valu_busy_frac": valu_busy, "instructions_per_wavefront": per_wave,
+                      "how": "VALUBusy = SQ_ACTIVE_INST_VALU x 4 / 32 SIMDs per slice / GRBM_GUI_ACTIVE (profiles/r3_loop_probe.md §2); the peak of this roofline is "
+                             "VALUBusy = 1: one wave-instruction issued per SIMD every cycle it can take one"},
+       "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_r4.sh -> tools/pmc_pass.sh), bench.py --headline-only at batch 384, {tag} code (SELECT flags "
                "as bit planes); counters in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 half-count); WRITE_SIZE as reported",
        "batch": 384, "kernel": "zke::k_witness_loop", "algorithmic_bytes_per_launch": alg, "fetch_bytes_x2": fetch, "write_bytes_reported": write,
        "hbm_traffic_bytes_per_launch": fetch + write, "traffic_over_algorithmic": (fetch + write) / alg,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box, repo root: the round-4 evidence set -> gpurun_out/${TAG}_* (copy what is judged into profiles/).
+# GPU box, repo root: the evidence set of a round (TAG=r5) -> gpurun_out/${TAG}_* (copy what is judged into profiles/).
 #  1. rocprofv3 --kernel-trace --stats of the default bench command            -> ${TAG}_kernel_trace.md, ${TAG}_bench_under_rocprof.json
 #  2. PMC passes (their own runs): FETCH_SIZE, WRITE_SIZE at the default batch   -> pmc_${TAG}_fetch.txt, pmc_${TAG}_write.txt
 #  3. the bench itself, no profiler                                             -> ${TAG}_bench.json
@@ -16,6 +16,9 @@ cd "$ROOT"
 export PMC_CMD="python $ROOT/bench.py --batch $B --seed-windows 2 --steps 2 --warmup 0 --no-cpu-baseline --headline-only"
 tools/pmc_pass.sh ${TAG}_fetch FETCH_SIZE > /dev/null
 tools/pmc_pass.sh ${TAG}_write WRITE_SIZE > /dev/null
+# VALU-issue side (its own passes): instructions and busy cycles of the vector ALUs against the GPU's active cycles
+tools/pmc_pass.sh ${TAG}_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE > /dev/null
+tools/pmc_pass.sh ${TAG}_salu SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS > /dev/null
 unset PMC_CMD
 timeout 900 python bench.py ${BENCH_ARGS:-} < /dev/null > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || tail -3 gpurun_out/${TAG}_bench.err
 head -24 gpurun_out/${TAG}_kernel_trace.md
