@@ -87,6 +87,23 @@ extern "C" {
 
 const char* zk_last_error(void) { return g_err.c_str(); }
 
+uint32_t zk_build_features(void) {
+    uint32_t f = 0;
+#ifdef ZKGL_BYTEBUF_KERNEL
+    f |= ZK_BUILD_BYTEBUF_KERNEL;
+#endif
+#ifdef ZKGL_STRAND_PLANES_KERNEL
+    f |= ZK_BUILD_STRAND_PLANES_KERNEL;
+#endif
+#ifdef ZKGL_SELECT_CHAINS_KERNEL
+    f |= ZK_BUILD_SELECT_CHAINS_KERNEL;
+#endif
+#ifdef ZKGL_BATCH_INV
+    f |= ZK_BUILD_BATCH_INV;
+#endif
+    return f;
+}
+
 int zk_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

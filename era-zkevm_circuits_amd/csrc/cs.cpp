@@ -354,6 +354,7 @@ void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uin
     } break;
     case ZK_OP_BYTEBUF_FILL:
         if (!allow_macro_ops_) throw ZkError(ZK_ERR_INVALID, "emit_op: macro-ops are recorded by the engine's gadgets only");
+        uses_bytebuf_macro_ = true;
         need(zkb::N_INPUTS, zkb::n_outputs(), 0);
         s.uses_bigint = true;
         uses_lookup_macros_ = true;
@@ -1267,6 +1268,7 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
         // a SELECT in level L + 1 itself keeps the slot.
         const char* spl_env = getenv("ZKGL_STRAND_PLANES");
         const bool strand_planes = s.is_loop && ph == 0 && spl_env && spl_env[0] == '1';
+        if (strand_planes) uses_strand_planes_ = true;
         const std::vector<uint32_t> plane_all = strand_planes ? select_plane_vars(s) : std::vector<uint32_t>();
         std::vector<uint32_t> plane_now(strand_planes ? s.n_vars : 0, UINT32_MAX);   // variable -> plane id once its plane is readable
         std::vector<std::vector<uint32_t>> copy_at(n_levels + 2), readable_at(n_levels + 3);
@@ -2620,6 +2622,14 @@ void CS::ensure_uploaded() {
 void CS::set_batch(uint32_t n) {
     if (!finalized_) throw ZkError(ZK_ERR_INVALID, "set_batch before finalize");
     if (n == 0) throw ZkError(ZK_ERR_INVALID, "batch must be > 0");
+    // device paths that exist only in builds made for them (never in the default binary until measured: kernels_engine2.hpp).  Recording and
+    // the host-side programs stay available everywhere (the oracle runs them, tests/test_device_programs.py walks them); the DEVICE refuses.
+#ifndef ZKGL_BYTEBUF_KERNEL
+    if (uses_bytebuf_macro_) throw ZkError(ZK_ERR_INVALID, "this circuit records ZK_OP_BYTEBUF_FILL (ZKGL_BYTEBUF_MACRO=1) but the library was built without its device backend (ZKGL_DEFS=-DZKGL_BYTEBUF_KERNEL)");
+#endif
+#ifndef ZKGL_STRAND_PLANES_KERNEL
+    if (uses_strand_planes_) throw ZkError(ZK_ERR_INVALID, "strand-form flag planes were requested (ZKGL_STRAND_PLANES=1) but the library was built without them (ZKGL_DEFS=-DZKGL_STRAND_PLANES_KERNEL)");
+#endif
     ensure_uploaded();
     auto alloc_cells = [&](Scope& s, uint64_t lanes) {
         if (s.d_store) { hipFree(s.d_store); s.d_store = nullptr; }

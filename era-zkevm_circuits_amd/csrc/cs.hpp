@@ -416,6 +416,7 @@ class CS {
     bool defer_p2_ = false;          // ZK_CHECK_FUSED_DEFER_P2
     bool p2_pending_ = false;        // the loop store lacks the intermediates of its in-circuit permutations (k_fill_p2 not run yet)
     bool uses_lookup_macros_ = false;   // a macro-op whose outputs carry lookup tuples was recorded: multiplicities by the k_multiplicities pass
+    bool uses_bytebuf_macro_ = false, uses_strand_planes_ = false;   // opt-in device paths the default build does not carry (set_batch refuses them there)
     int32_t macro_window_op_ = -1;   // index (current scope) of the macro-op whose gadget window is open
     bool macro_window_loop_ = false;
     bool allow_macro_ops_ = false;   // zk_cs_set_check_mode(ZK_CHECK_STORED)

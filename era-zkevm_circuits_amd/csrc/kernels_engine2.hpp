@@ -174,6 +174,9 @@ __device__ __noinline__ uint32_t sha256_rounds_stream(__amdgpu_buffer_rsrc_t rsr
     return emit.d;
 }
 
+// ZK_OP_BYTEBUF_FILL's device backend is built only on request (ZKGL_DEFS=-DZKGL_BYTEBUF_KERNEL; keccak.cpp refuses ZKGL_BYTEBUF_MACRO=1 in any
+// other build): written while the GPU was closed to the build, never executed — it stays out of the default binary until it has been measured.
+#ifdef ZKGL_BYTEBUF_KERNEL
 struct BytebufInv {   // k^-1 mod p for 0 < |k| < INV_SMALL_N
     __device__ __forceinline__ uint64_t operator()(int32_t k) const {
         const uint64_t r = p2::INV_SMALL[(uint32_t)(k < 0 ? -k : k) & (p2::INV_SMALL_N - 1)];
@@ -211,6 +214,8 @@ __device__ __noinline__ uint32_t bytebuf_fill_stream(__amdgpu_buffer_rsrc_t rsrc
     zkb::fill_with_bytes(be, f, offset, meaningful);
     return emit.d;
 }
+
+#endif  // ZKGL_BYTEBUF_KERNEL
 
 // STRANDS: the strand form (k_witness_strands2): one destination word per op behind the operands — the store slot of its first
 // output (a strand's ops are not consecutive in production order) — and ZK_OP_BARRIER between the dependency levels.
@@ -263,7 +268,15 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     // SELECT flags as bit planes (ZK_OP_FLAG_PLANES; plain kernels, loop scope): [wavefront of the block][0: != 0, 1: > 1][plane id]
     // (strand form: the wavefronts of the workgroup share ONE tile, hence one set of planes; a plane is written in the level after its
     // flag's and read from the level after that — cs.cpp build_strands — with the workgroup barrier of ZK_OP_BARRIER in between)
-    __shared__ uint64_t flag_planes[STRANDS ? 2 * zkdev::FLAG_PLANES : (BLOCK / 64) * 2 * zkdev::FLAG_PLANES];
+    // The strand form of the planes is built only on request (ZKGL_DEFS=-DZKGL_STRAND_PLANES_KERNEL; cs.cpp refuses ZKGL_STRAND_PLANES=1 in any
+    // other build): compiled in, it costs the strand kernels of EVERY circuit registers (k_witness_strands2<false,false>: 79 -> 92 VGPRs,
+    // 6 -> 5 wavefronts per SIMD, profiles/r5_resource_usage.md) and it has not been measured yet.
+#ifdef ZKGL_STRAND_PLANES_KERNEL
+    constexpr bool PLANES = true;
+#else
+    constexpr bool PLANES = !STRANDS;
+#endif
+    __shared__ uint64_t flag_planes[!PLANES ? 1 : STRANDS ? 2 * zkdev::FLAG_PLANES : (BLOCK / 64) * 2 * zkdev::FLAG_PLANES];
     uint64_t* const planes = flag_planes + (STRANDS ? 0 : uni(threadIdx.x >> 6) * 2 * zkdev::FLAG_PLANES);
     // (this lane's index in its wavefront is recomputed where used — two mbcnt — rather than held in a VGPR across the interpreter loop)
     auto wave_lane_now = [] { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };
@@ -405,7 +418,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             pc += 9 + D;
             st(r);
         } break;
-        case ZK_OP_FLAG_PLANES: {
+        case ZK_OP_FLAG_PLANES: if constexpr (PLANES) {
             const uint32_t n = pb + 1;
             uint64_t v[7];
 #pragma unroll
@@ -418,7 +431,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                     if (wave_lane_now() == 0) { planes[W[2 + 2 * k]] = m; planes[zkdev::FLAG_PLANES + W[2 + 2 * k]] = nb; }
                     if constexpr (!STRANDS) nonbool_seen |= (uint32_t)(nb != 0);   // (strands: another wavefront may have copied the flag — the SELECT reads both planes)
                 }
-        } break;
+        } else { return; } break;   // (not emitted for this form: cs.cpp)
         case ZK_OP_SELECT:
 #ifdef ZKGL_SELECT_CHAINS_KERNEL   // built only on request (ZKGL_DEFS=-DZKGL_SELECT_CHAINS_KERNEL): its live set costs the interpreter loop spills
         if (!STRANDS && pa == 2) {
@@ -450,7 +463,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 }
         } else
 #endif
-        if (pa == 1) {
+        if (PLANES && pa == 1) {
             // flags from the bit planes.  A wavefront whose lanes agree on a flag loads the selected operand twice (the second load hits
             // the line the first one brought) instead of both: no branch, no fetch of the branch nobody takes.
             auto body = [&](auto n_) {
@@ -893,6 +906,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }
             fused_bad |= not_bytes;
         } else { return; } break;
+#ifdef ZKGL_BYTEBUF_KERNEL
         case ZK_OP_BYTEBUF_FILL: if constexpr (WITH_BIGINT) {
             // K8: one ByteBuffer fill as ONE op.  [192 buffer bytes, filled, 32 input bytes, offset, meaningful] -> every intermediate, in the
             // gadget's allocation order (both walk zkb::fill_with_bytes).  The op works on small integers: an operand outside its range
@@ -946,6 +960,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }
             fused_bad |= out_of_range;
         } else { return; } break;
+#endif  // ZKGL_BYTEBUF_KERNEL
         case ZK_OP_KECCAK_F: if constexpr (WITH_BIGINT) {
             // K8: a whole Keccak-f[1600] as ONE op.  [200 state byte slots] -> every intermediate of the byte-table decomposition, in the
             // order the gadget allocated them (both walk zkk::keccak_f, keccak_macro.hpp): the state lives in 25 register pairs, every

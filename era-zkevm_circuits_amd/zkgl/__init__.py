@@ -124,6 +124,16 @@ def poseidon_round_constants() -> np.ndarray:
     return out
 
 
+BUILD_BYTEBUF_KERNEL, BUILD_STRAND_PLANES_KERNEL, BUILD_SELECT_CHAINS_KERNEL, BUILD_BATCH_INV = 1, 2, 4, 8
+
+
+def build_features() -> int:
+    """zk_build_features: opt-in device paths compiled into the loaded library (0 for the default build)"""
+    f = lib().zk_build_features
+    f.restype = C.c_uint32
+    return int(f())
+
+
 def host_threads() -> int:
     """zk_host_threads: hardware threads of the host (what n_threads = 0 means to the host pool)"""
     return int(lib().zk_host_threads())

@@ -40,6 +40,14 @@ typedef enum zk_status {
 } zk_status;
 
 const char *zk_last_error(void);
+/* opt-in device paths compiled into THIS library (A/B builds: era-zkevm_circuits_amd/build.sh with ZKGL_DEFS=-DZKGL_..._KERNEL).  The default
+ * build returns 0: it carries only paths that have been measured on the device.  A circuit / switch that needs an absent path is refused
+ * by zk_cs_set_batch with ZK_ERR_INVALID. */
+#define ZK_BUILD_BYTEBUF_KERNEL 1u        /* ZK_OP_BYTEBUF_FILL on the device (ZKGL_BYTEBUF_MACRO=1 recordings) */
+#define ZK_BUILD_STRAND_PLANES_KERNEL 2u  /* SELECT flags as bit planes in the strand form (ZKGL_STRAND_PLANES=1) */
+#define ZK_BUILD_SELECT_CHAINS_KERNEL 4u  /* mux-chain ops (ZKGL_SELECT_CHAINS=1) */
+#define ZK_BUILD_BATCH_INV 8u             /* Montgomery-batched zero-check inversions in the plain loop kernels */
+uint32_t zk_build_features(void);
 /* Select the device, upload Poseidon2 constants.  Fails loudly (ZK_ERR_HIP) without a GPU.  One device per process: a second
  * call with another device index is ZK_ERR_INVALID (process-wide device tables are bound to the first). */
 int zk_init(int device);

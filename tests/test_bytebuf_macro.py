@@ -61,10 +61,17 @@ def test_device_backend_walk_equals_the_gate_arithmetic_on_the_cpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("ZKGL_TEST_UNMEASURED") != "1", reason="opt-in device path written while the GPU was closed to the build: tools/k8_ab_r4.sh runs it (ZKGL_TEST_UNMEASURED=1)")
 def test_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
-    """whole trace of the macro recording, plain and strand kernels, both check modes; seeding through the native FSM seeder"""
+    """whole trace of the macro recording, plain and strand kernels, both check modes; seeding through the native FSM seeder.
+    The op's device backend is NOT part of the default library (never measured: it stays out of the product binary, kernels_engine2.hpp): there
+    the device must refuse the recording loudly; a library built with ZKGL_DEFS=-DZKGL_BYTEBUF_KERNEL (ZKGL_LIB=..., tools/ab_r5.sh) runs it."""
+    import zkgl
     cs = record(monkeypatch, True)
+    if not zkgl.build_features() & zkgl.BUILD_BYTEBUF_KERNEL:
+        with pytest.raises(zkgl.ZkError) as e:
+            cs.set_batch(4)
+        assert "ZKGL_BYTEBUF_KERNEL" in str(e.value)
+        return
     insts = [reference_case(l, u)[1] for l, u in REFERENCE_CASES] * 8        # 72 instances x 2 cycles: a few wavefronts
     outer, loop = streams(insts, 2)
     r = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
