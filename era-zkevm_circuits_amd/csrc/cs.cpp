@@ -2021,12 +2021,45 @@ void CS::build_seed_program() {
     // the cone runs the gated witness-only permutations (ZK_OP_POSEIDON2 a = 1) ungated: their outputs only ever reach a carried word
     // through a select on the same flag, and the seed kernels keep one POSEIDON2 form
     std::vector<OpRec> sops_store = loop_ops_recorded_.empty() ? s.ops : loop_ops_recorded_;
-    for (auto& op : sops_store)
-        if (op.opcode == ZK_OP_POSEIDON2 && op.a == 1) { op.ins.pop_back(); op.a = 0; }
-    const std::vector<OpRec>& sops = sops_store;
     std::vector<uint32_t> out_vars;  // same order as carries_
     for (auto& l : links_raw_)
         if (l.kind == ZK_LINK_CARRY && s.input_word.count(l.loop_cell)) out_vars.push_back(l.other_cell);
+    // ... which is VERIFIED, not assumed (ZK_OP_POSEIDON2 a = 1 is recordable through the public zk_cs_emit_op): the ungated outputs
+    // differ from the trace's (zeros) exactly where the flag is off.  Taint every value computed from them; a SELECT on the op's own flag
+    // that takes the tainted value on its flag-on side only is clean again (flag off: the other branch; flag on: the permutation really
+    // ran).  A carried output that stays tainted would be seeded with words the trace does not hold: the cone is then not offered
+    // (seed_cone_unsupported_; carry links would reject it anyway — a spurious UNSATISFIED, never unsoundness).
+    {
+        std::vector<uint32_t> taint(s.n_vars, UINT32_MAX);   // variable -> flag variable of the gated permutation it depends on (UINT32_MAX: clean; UINT32_MAX - 1: several)
+        bool any_gated = false;
+        for (auto& op : sops_store) {
+            if (op.seed_only) continue;
+            if (op.opcode == ZK_OP_POSEIDON2 && op.a == 1 && op.ins.size() == 13 && op.ins[12].kind == Operand::VAR) {
+                for (uint32_t ov : op.outs) taint[ov] = op.ins[12].idx;
+                any_gated = true;
+                continue;
+            }
+            if (!any_gated) continue;
+            uint32_t t = UINT32_MAX;
+            auto join = [&](uint32_t x) { if (x == UINT32_MAX) return; t = (t == UINT32_MAX || t == x) ? x : UINT32_MAX - 1; };
+            if (op.opcode == ZK_OP_SELECT && op.ins.size() == 3 && op.ins[0].kind == Operand::VAR) {
+                const uint32_t f = op.ins[0].idx;
+                join(taint[f]);                                                               // a tainted selector taints the result
+                if (op.ins[1].kind == Operand::VAR && taint[op.ins[1].idx] != f) join(taint[op.ins[1].idx]);   // flag-on side: clean when tainted by THIS flag
+                if (op.ins[2].kind == Operand::VAR) join(taint[op.ins[2].idx]);                // flag-off side: always propagates
+            } else {
+                for (auto& in : op.ins) if (in.kind == Operand::VAR) join(taint[in.idx]);
+            }
+            if (t != UINT32_MAX) for (uint32_t ov : op.outs) taint[ov] = t;
+        }
+        uint32_t bad = 0;
+        for (uint32_t v : out_vars) bad += taint[v] != UINT32_MAX;
+        if (bad) seed_cone_unsupported_ = true;
+        if (getenv("ZKGL_PROG_STATS") && any_gated) fprintf(stderr, "[zkgl] seeding cone: %u of %zu carried outputs depend on a gated permutation outside a select on its flag\n", bad, out_vars.size());
+    }
+    for (auto& op : sops_store)
+        if (op.opcode == ZK_OP_POSEIDON2 && op.a == 1) { op.ins.pop_back(); op.a = 0; }
+    const std::vector<OpRec>& sops = sops_store;
     std::vector<uint8_t> need(s.n_vars, 0), keep(sops.size(), 0);
     for (auto v : out_vars) need[v] = 1;
     for (size_t oi = sops.size(); oi-- > 0;) {
@@ -2880,7 +2913,7 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
 void CS::launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (launch_seed_native(la, oa, dev_loop_inputs_rw, n, stream)) return;
-    if (seed_cone_unsupported_) throw ZkError(ZK_ERR_INVALID, "the seeding cone of this circuit contains ZK_OP_BYTEBUF_FILL, which only the trace kernels run: use the native seeder, or record without ZKGL_BYTEBUF_MACRO");
+    if (seed_cone_unsupported_) throw ZkError(ZK_ERR_INVALID, "the seeding cone of this circuit cannot be run by the seed kernels (it contains ZK_OP_BYTEBUF_FILL, or a carried output depends on a gated ZK_OP_POSEIDON2 outside a select on its flag): use the native seeder or ZKGL_SEED_GENERIC=1");
     const char* force_generic = std::getenv("ZKGL_SEED_GENERIC");
     const char* seed_strands = std::getenv("ZKGL_SEED_STRANDS");  // 0: plain cone, 1: strand form whenever it exists
     const bool generic = force_generic && force_generic[0] == '1';

@@ -43,3 +43,58 @@ def test_hash_fsm_keeps_its_byte_buffer_in_the_cone():
     # (round 4: the loop program carries Keccak-f as ONE macro-op, ZK_OP_KECCAK_F, so it is barely longer than the cone; what is left in
     # both is the ByteBuffer muxing)
     assert 40000 < st["seed_ops"] < 50000 and st["loop_ops"] > st["seed_ops"]
+
+
+# ---- gated witness-only permutations in the cone: the cone runs ZK_OP_POSEIDON2 a = 1 ungated, which is right only when its
+# outputs reach the carried words through a select on the op's own flag — verified at finalize, not assumed
+def _gated_chain(select_on_flag: bool):
+    from helpers import LINK, Rec
+    from zkgl import GATE as G, OP
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(60, 0, 8, 4))
+    for k in ("CONST", "BOOLEAN", "FMA", "SELECT", "PUBLIC_INPUT"):
+        cs.allow_gate(G[k])
+    r = Rec(cs)
+    start = r.inp()                                       # outer word 0: the chain's initial value
+    cs.loop_begin(5)
+    r.n_in = 0
+    acc_in = r.inp()                                      # loop word 0: carried
+    cs.link(LINK["FIRST"], acc_in, start)
+    flag = r.inp()                                        # loop word 1: `execute`
+    cs.place_gate(G["BOOLEAN"], [flag])
+    one = r.const(1)
+    state = [acc_in] + [one] * 11
+    outs = cs.alloc_multiple_variables_without_values(12)
+    cs.emit_op(OP["POSEIDON2"], state + [flag], outs, a=1)   # simulate_round_function(cs, state, execute): zeros where the flag is off
+    nxt = r.select(flag, outs[0], acc_in) if select_on_flag else r.fma(1, outs[0], one, 1, acc_in)
+    cs.link(LINK["CARRY"], acc_in, nxt)
+    cs.loop_end()
+    cs.place_gate(G["PUBLIC_INPUT"], [cs.loop_last(nxt)])
+    cs.pad_and_shrink()
+    return cs
+
+
+@pytest.mark.gpu
+def test_cone_with_gated_permutations_is_verified_not_assumed(zk, monkeypatch):
+    import numpy as np
+    from oracle import zko
+    monkeypatch.setenv("ZKGL_SEED_NATIVE", "0")
+    B, limit = 70, 5
+    rng = np.random.default_rng(3)
+    outer = rng.integers(1, 1 << 60, size=(1, B), dtype=np.uint64)
+    loop = np.zeros((2, B * limit), dtype=np.uint64)
+    loop[1] = rng.integers(0, 2, size=B * limit)
+    for ok_form in (True, False):
+        cs = _gated_chain(ok_form)
+        cs.set_batch(B)
+        d_o, d_l = zkgl.DeviceBuffer.from_numpy(outer), zkgl.DeviceBuffer.from_numpy(loop)
+        cs.bind_inputs(False, d_o, 1); cs.bind_inputs(True, d_l, 2)
+        if not ok_form:      # the carried word would be seeded from an ungated output: the cone is not offered
+            with pytest.raises(zkgl.ZkError):
+                cs.seed_carried_inputs(d_l)
+            continue
+        cs.seed_carried_inputs(d_l)
+        seeded = d_l.to_numpy().reshape(loop.shape)
+        want = zko.CircuitRun(cs.export(False), cs.export(True), B, 1).seed(outer, loop)
+        assert np.array_equal(seeded, want)
+        ok, f = cs.resolve_and_check()
+        assert ok, f
