@@ -897,6 +897,68 @@ void CS::build_check_program(Scope& s) {
                 s.n_macro_p2, s.cprog_full.size());
 }
 
+// Census for the 4-byte-slot store: an upper bound per variable that holds in EVERY satisfying witness, derived from the
+// constraints alone (never from witness ops): constant gates, boolean gates, the is-zero flag, membership in a lookup table column,
+// reductions / FMA gates over bounded terms that cannot wrap, selections by a boolean-constrained selector.  A variable with bound
+// <= 2^32 could live in a 4-byte slot: a witness that puts a larger value there is unsatisfiable anyway (the store would report it).
+void CS::bound_values(Scope& s) {
+    typedef unsigned __int128 u128;
+    const u128 INF = ~(u128)0, PP = (u128)0xFFFFFFFF00000001ull;
+    std::vector<u128> ub(s.n_vars, INF);   // exclusive upper bound
+    auto lower = [&](uint32_t v, u128 b, bool& changed) { if (b < ub[v]) { ub[v] = b; changed = true; } };
+    std::vector<std::vector<uint64_t>> colmax(tables_.size());
+    for (size_t t = 0; t < tables_.size(); ++t) {
+        const TableRec& tr = tables_[t];
+        const uint32_t w = tr.n_keys + tr.n_vals;
+        colmax[t].assign(w, 0);
+        for (uint32_t r = 0; r < tr.n_rows; ++r)
+            for (uint32_t c = 0; c < w; ++c) colmax[t][c] = std::max(colmax[t][c], tr.rows[(size_t)r * w + c]);
+    }
+    bool changed = true;
+    for (int round = 0; round < 64 && changed; ++round) {
+        changed = false;
+        for (auto& l : s.lookups)
+            for (size_t c = 0; c < l.vars.size() && c < colmax[l.table - 1].size(); ++c) lower(l.vars[c], (u128)colmax[l.table - 1][c] + 1, changed);
+        for (auto& g : s.gates) {
+            switch (g.kind) {
+            case ZK_GATE_CONST: lower(g.vars[0], (u128)g.consts[0] + 1, changed); break;
+            case ZK_GATE_BOOLEAN: lower(g.vars[0], 2, changed); break;
+            case ZK_GATE_ZEROCHECK: lower(g.vars[2], 2, changed); break;   // x aux = 1 - flag, flag x = 0: flag is 0 / 1
+            case ZK_GATE_SELECT:   // (a, b, s, r): r in {a, b} once s is 0 / 1
+                if (ub[g.vars[2]] <= 2 && ub[g.vars[0]] != INF && ub[g.vars[1]] != INF) lower(g.vars[3], std::max(ub[g.vars[0]], ub[g.vars[1]]), changed);
+                break;
+            case ZK_GATE_REDUCTION4: case ZK_GATE_REDUCTION_BY_POWERS4: {
+                u128 sum = 0, pw = 1;
+                bool ok = true;
+                for (int i = 0; i < 4 && ok; ++i) {
+                    const u128 k = g.kind == ZK_GATE_REDUCTION4 ? (u128)g.consts[i] : pw;
+                    if (g.kind != ZK_GATE_REDUCTION4) pw = pw * g.consts[0] % PP;
+                    if (k == 0) continue;
+                    if (ub[g.vars[i]] == INF) { ok = false; break; }
+                    sum += k * (ub[g.vars[i]] - 1);
+                    if (sum >= PP) ok = false;
+                }
+                if (ok) lower(g.vars[4], sum + 1, changed);
+            } break;
+            case ZK_GATE_FMA: {   // q a b + l c = d
+                const u128 q = g.consts[0], l = g.consts[1];
+                u128 sum = 0;
+                bool ok = true;
+                if (q) { if (ub[g.vars[0]] == INF || ub[g.vars[1]] == INF) ok = false; else { const u128 pr = (ub[g.vars[0]] - 1) * (ub[g.vars[1]] - 1); if (pr >= PP || q * pr >= PP) ok = false; else sum += q * pr; } }
+                if (ok && l) { if (ub[g.vars[2]] == INF || l * (ub[g.vars[2]] - 1) >= PP) ok = false; else sum += l * (ub[g.vars[2]] - 1); }
+                if (ok && sum < PP) lower(g.vars[3], sum + 1, changed);
+            } break;
+            default: break;
+            }
+        }
+    }
+    s.values_below_2_32 = s.values_below_2_8 = 0;
+    for (uint32_t v = 0; v < s.n_vars; ++v) { s.values_below_2_32 += ub[v] <= ((u128)1 << 32); s.values_below_2_8 += ub[v] <= 256; }
+    if (getenv("ZKGL_PROG_STATS"))
+        fprintf(stderr, "[zkgl] %s scope: %u of %u variables are < 2^32 in every satisfying witness (%u of them < 2^8): candidates for 4-byte store slots\n",
+                s.is_loop ? "loop" : "outer", s.values_below_2_32, s.n_vars, s.values_below_2_8);
+}
+
 // Lookup sites of a scope grouped by table (k_multiplicities): the key slots of every recorded lookup
 void CS::build_mult_sites(Scope& s) {
     const size_t nt = tables_.size() + 1;  // table ids are 1-based
@@ -2501,6 +2563,8 @@ void CS::finalize() {
     build_check_program(loop_);
     build_mult_sites(outer_);
     build_mult_sites(loop_);
+    bound_values(outer_);
+    bound_values(loop_);
     build_strands(outer_);
     if (limit_) {
         build_strands(loop_);
@@ -3457,6 +3521,7 @@ void CS::stats(zk_stats* o) const {
     const bool fused_ok = !outer_.cprog_fused.empty() && (!limit_ || !loop_.cprog_fused.empty());
     o->constraints_from_store_fused = fused_ok ? from_store(outer_) + from_store(loop_) * limit_ : o->constraints_per_instance;
     o->constraints_in_witness_fused = o->constraints_per_instance - o->constraints_from_store_fused;
+    o->values_below_2_32_outer = outer_.values_below_2_32; o->values_below_2_32_loop = loop_.values_below_2_32;
 }
 
 float CS::last_ms(int which) const {

@@ -103,6 +103,7 @@ struct Scope {
     std::vector<std::vector<uint32_t>> row_gates;  // [row][instance] -> index into `gates`
     std::vector<std::vector<uint32_t>> row_lookups;  // [row][tuple] -> index into `lookups`
     uint32_t n_macro_p2 = 0;
+    uint32_t values_below_2_32 = 0, values_below_2_8 = 0;   // census (CS::bound_values): variables bounded by the constraints in every satisfying witness
     bool p2_intermediates_private = true;   // no op / lookup / link / kept gate of the step reads an intermediate of a ZK_OP_P2_ROUNDS (deferred mode)
     uint32_t n_p2_rounds_ops = 0;    // ZK_OP_P2_ROUNDS ops of the scope (deferred mode needs a verified descriptor for each)
     std::vector<uint8_t> gate_mirrored;   // per gate: its relation is the semantics of the op producing its output (same variables, constants)
@@ -314,6 +315,7 @@ class CS {
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream, uint32_t n_lanes = 0) const;  // n_lanes: lane count when the arguments were patched for a stream
     void build_check_program(Scope& s);
     void build_mult_sites(Scope& s);
+    void bound_values(Scope& s);
     void count_multiplicities(void* stream, int scopes = 3);
     // true: wave-aggregated atomics inside the witness kernels; false: the k_multiplicities pass after them (cs.cpp)
     bool inline_multiplicities() const;

@@ -301,6 +301,10 @@ typedef struct zk_stats {
      * The two add up to constraints_per_instance.  With ZKGL_VERIFY_STORED=1 / zk_cs_check_satisfied every relation is evaluated from
      * the stored values. */
     uint64_t constraints_from_store_fused, constraints_in_witness_fused;
+    /* census: variables (of cells_written_*) that are < 2^32 in EVERY satisfying witness, by the constraints alone (lookup-table membership,
+     * boolean / constant gates, non-wrapping reductions and products of bounded terms, selections by a boolean selector) — what a store
+     * with 4-byte slots could hold in half the bytes */
+    uint64_t values_below_2_32_outer, values_below_2_32_loop;
 } zk_stats;
 /* K12 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
  * column chunking and cell identifiers are [EXT], the argument is defined in csrc/kernels_perm.hpp).  Labels: outer-scope
