@@ -1,7 +1,7 @@
 """Host side of the packers with the witness's queue states, at BASELINE C3's full size (2^20 rows per instance): how long the C packer takes
 per instance (one core) for sha256_round_function and keccak256_round_function, against the device seeding pass it replaces.  Runs on the
 CPU (no GPU needed: the circuit is only recorded to learn `limit`).  Inputs come from the oracle's native restatements (test infrastructure),
-so this lives with the measurement tools.   usage: python tools/host_pack_timings.py > profiles/r4_host_pack_timings.json"""
+so this lives with the measurement tools.   usage: python tools/host_pack_timings.py > profiles/r5_host_pack_timings.json"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "era-zkevm_circuits_amd"), os.path.join(ROOT, "tests")):
@@ -83,54 +83,58 @@ for _ in range(5):
 el = np.array(inst["rows"], dtype=np.uint64).T
 out["keccak256_round_function"] = {"limit": limit, "requests": n_popped, "memory_pushes": int(mt.shape[0]), "pack_ms_per_instance_one_core": round(1e3 * min(ts), 3),
                                    "equals_native_stream": bool(np.array_equal(loop, el)), "device_seeding_pass_it_replaces_ms_128_instances": 17.6}
-# ---- main_vm (bench fixture: 64 executions x 2 352 cycles): the three forms of the packer
+# ---- main_vm (bench fixture: 64 executions x 2 352 cycles): the forms of the packer, one core and the host pool (round 5: 64-cycle tile + non-temporal
+# stores, zk_pack_main_vm_witness_batch; round 4's packer wrote cycle by cycle across the word-major stream: 5.55 ms per instance)
 import bench
 cs, limit = bench.build_main_vm_cs(zkgl, 20)
 fx = np.load(bench.FIXTURE)
-E = 8                                               # eight executions are enough for a per-instance figure
+E = 64
 n_outer, n_loop = cs.input_words()
-queues, cfs = [], []
-for e in range(E):
-    q = zkgl.VmOracleQueues()
-    sl = {k: fx[k][fx[k + "_offsets"][e]:fx[k + "_offsets"][e + 1]] for k in bench._FIFOS}
-    q.memory_reads = [(r[:8], r[8]) for r in sl["memory_reads"]]; q.storage_reads = list(sl["storage_reads"]); q.refunds = [r[0] for r in sl["refunds"]]
-    q.rollback_queue_witness = list(sl["rollback_queue_witness"]); q.rollback_tails_for_call = list(sl["rollback_tails_for_call"])
-    q.callstack = [(r[:42], r[42:]) for r in sl["callstack"]]; q.decommit_pages = [r[0] for r in sl["decommit_pages"]]
-    q.freeze()
-    cf = zkgl.VmClosedFormInput(); cf.start_flag = 1
-    cf.rollback_queue_tail_for_block[:] = [int(x) for x in fx["rollback_tail"][e]]
-    queues.append(q); cfs.append(cf)
+cfs, queues = bench.fixture_witnesses(zkgl, fx, E)
+views = [q.view() for q in queues]
 outer = np.zeros((n_outer, E), dtype=np.uint64); loop = np.zeros((n_loop, E * limit), dtype=np.uint64)
-for warm in range(2):                               # the first pass pays the page faults of the staging array
-    t0 = time.perf_counter()
-    for e in range(E):
-        cs.pack_main_vm_witness(cfs[e], queues[e].view(), e, E, outer, loop)
-    t_plain = (time.perf_counter() - t0) / E
-states, perms_hash = [], 0
+threads = zkgl.host_threads()
+
+
+def timed(flags, n_threads, dst, states=None, reps=3):
+    best = 1e9
+    for _ in range(reps):                            # the first pass pays the page faults of the staging array
+        t0 = time.perf_counter(); cs.pack_main_vm_witness_batch(cfs, views, 0, E, outer, dst, flags=flags, states=states, n_threads=n_threads); best = min(best, time.perf_counter() - t0)
+    return 1e3 * best / E
+
+
+raw1, rawN = timed(0, 1, loop), timed(0, 0, loop)
+ref = loop.copy()
+oracle_rows = np.zeros((n_loop - 243, E * limit), dtype=np.uint64)
+or1, orN = timed(zkgl.VM_PACK_ORACLE_WORDS_ONLY, 1, oracle_rows), timed(zkgl.VM_PACK_ORACLE_WORDS_ONLY, 0, oracle_rows)
+oracle_equal = bool(np.array_equal(oracle_rows, ref[243:]))
+del oracle_rows
 filled = np.zeros_like(loop)
-t0 = time.perf_counter()
-for e in range(E):
+states, keep, perms_hash = [], [], 0
+for e in range(E):                                   # the witness generator's role: record the queue states once (host hashing)
     arrs = (np.zeros((8 * limit, 12), dtype=np.uint64), np.zeros((2 * limit, 12), dtype=np.uint64), np.zeros((2 * limit, 4), dtype=np.uint64))
     st = zkgl.VmQueueStates.over(*arrs)
-    cs.pack_main_vm_witness_states(cfs[e], queues[e].view(), st, e, E, outer, filled, zkgl.VM_PACK_FILL_STATE | zkgl.VM_PACK_RECORD_STATES)
-    states.append((arrs, (st.used_memory_tails, st.used_decommit_tails, st.used_log_forward_tails))); perms_hash += st.host_permutations
-t_hash = (time.perf_counter() - t0) / E
-read = np.zeros_like(loop); perms_read = 0
-t0 = time.perf_counter()
-for e in range(E):
-    arrs, used = states[e]
-    st = zkgl.VmQueueStates.over(*[np.ascontiguousarray(a[:k]) for a, k in zip(arrs, used)])
-    cs.pack_main_vm_witness_states(cfs[e], queues[e].view(), st, e, E, outer, read, zkgl.VM_PACK_STATES_FROM_WITNESS)
-    perms_read += st.host_permutations
-t_read = (time.perf_counter() - t0) / E
-out["main_vm"] = {"limit": limit, "executions": E,
-                  "pack_ms_per_instance_raw_stream_device_seeds": round(1e3 * t_plain, 2),
-                  "pack_ms_per_instance_fill_state_host_hashes": round(1e3 * t_hash, 2), "host_permutations_per_instance_fill_state": perms_hash // E,
-                  "pack_ms_per_instance_states_from_witness": round(1e3 * t_read, 2), "host_permutations_per_instance_states_from_witness": perms_read // E,
-                  "queue_pushes_per_instance": [int(sum(u[1][k] for u in states) // E) for k in range(3)],
-                  "streams_equal": bool(np.array_equal(filled, read)),
-                  "device_seeding_pass_it_replaces": "one pass per 5 steps inside bench.py's timed region: value 274.5 G from raw against 320.4 G with the state resident (profiles/r4_bench.json)"}
+    cs.pack_main_vm_witness_states(cfs[e], views[e], st, e, E, outer, filled, zkgl.VM_PACK_FILL_STATE | zkgl.VM_PACK_RECORD_STATES)
+    cut = [np.ascontiguousarray(a[:max(int(k), 1)]) for a, k in zip(arrs, (st.used_memory_tails, st.used_decommit_tails, st.used_log_forward_tails))]
+    keep.append((cut, (st.used_memory_tails, st.used_decommit_tails, st.used_log_forward_tails))); perms_hash += st.host_permutations
+    states.append(zkgl.VmQueueStates.over(*cut))
+fill1, fillN = timed(zkgl.VM_PACK_FILL_STATE, 1, loop, reps=1), timed(zkgl.VM_PACK_FILL_STATE, 0, loop, reps=2)
+read = np.zeros_like(loop)
+sw1, swN = timed(zkgl.VM_PACK_STATES_FROM_WITNESS, 1, read, states=states, reps=2), timed(zkgl.VM_PACK_STATES_FROM_WITNESS, 0, read, states=states)
+out["main_vm"] = {"limit": limit, "executions": E, "host_threads": threads,
+                  "pack_ms_per_instance_one_core": {"raw_stream_360_rows_device_seeds": round(raw1, 3), "oracle_rows_only_117_rows_device_seeds": round(or1, 3),
+                                                    "fill_state_host_hashes_every_chain": round(fill1, 3), "states_from_witness_360_rows_no_device_pass": round(sw1, 3)},
+                  "pack_ms_per_instance_wall_all_threads": {"raw_stream_360_rows_device_seeds": round(rawN, 3), "oracle_rows_only_117_rows_device_seeds": round(orN, 3),
+                                                            "fill_state_host_hashes_every_chain": round(fillN, 3), "states_from_witness_360_rows_no_device_pass": round(swN, 3)},
+                  "bytes_per_instance": {"raw_stream": n_loop * limit * 8, "oracle_rows_only": (n_loop - 243) * limit * 8},
+                  "host_permutations_per_instance_fill_state": perms_hash // E,
+                  "queue_pushes_per_instance": [int(sum(u[1][k] for u in keep) // E) for k in range(3)],
+                  "oracle_rows_equal_rows_243_of_the_raw_stream": oracle_equal, "states_from_witness_stream_equals_fill_state_stream": bool(np.array_equal(filled, read)),
+                  "gpu_consumes_one_instance_every_ms": 0.136,
+                  "host_cores_per_gpu_at_that_rate": {"oracle_rows_only": round(or1 / 0.136, 1), "states_from_witness": round(sw1 / 0.136, 1)},
+                  "round_4_same_tool": {"raw_stream": 5.55, "fill_state": 14.02, "states_from_witness": 10.48}}
 cs.close()
-out["note"] = ("C packers zk_pack_{sha256,keccak}_witness_tails on one host core of this container, one full-size start instance (BASELINE C3: 2^20 rows); "
-               "the device passes they replace were measured at 128 instances (profiles/r4_config_timings_mid.jsonl)")
+out["note"] = ("C packers on the host cores of THIS container (8 threads, no GPU): zk_pack_{sha256,keccak}_witness_tails on one core, one full-size start instance "
+               "(BASELINE C3: 2^20 rows; the device passes they replace were measured at 128 instances, profiles/r4_config_timings_mid.jsonl); main_vm through "
+               "zk_pack_main_vm_witness_batch (host pool).  bench.py measures the same packers on the GPU box's cores, overlapped with the steps (value_including_host_pack)")
 print(json.dumps(out, indent=1))
