@@ -101,6 +101,9 @@ uint32_t zk_build_features(void) {
 #ifdef ZKGL_BATCH_INV
     f |= ZK_BUILD_BATCH_INV;
 #endif
+#ifdef ZKGL_SHA4_KERNEL
+    f |= ZK_BUILD_SHA4_KERNEL;
+#endif
     return f;
 }
 

@@ -16,6 +16,7 @@
 #pragma once
 #include <memory>
 #include "sha256_gadget.hpp"
+#include "../sha256_macro4.hpp"
 
 namespace zkgl {
 namespace sha256_gadget4 {
@@ -55,31 +56,90 @@ struct W4 {                 // a u32 as nibbles; `packed` (the word as one field
     zk_var packed = ZK_VAR_NONE;
 };
 
+// The gadget is the HOST backend of zks4::compress (csrc/sha256_macro4.hpp): the walk the device macro-op (ZK_OP_SHA256_ROUNDS, a = 1), the
+// counting backend and the oracle make too.  Plain mode (default): every primitive records its witness op AND its constraint.  Macro mode
+// (ZKGL_SHA4_MACRO=1): a compression records ONE witness op over the 96 input bytes whose outputs are pre-allocated variables, and the
+// walk places the same lookups / gates over them in the same order — the same circuit, cell for cell (tests/test_sha4_macro.py).
 struct S4 {
+    typedef Word Bytes;
+    typedef W4 W;
+    typedef Nib8 Nib;
+    typedef zk_var V;
+    // per-nibble split cache of one word: lo[s][j] = x_j & (2^s - 1), hi[s][j] = x_j >> s
+    struct Splits { Nib8 lo[4], hi[4]; bool have[4] = {false, false, false, false}; };
     G& g;
     uint32_t t_maj, t_tri, t_ch, t_s1, t_s2;
+    bool use_macro;
+    zk_var macro_next = ZK_VAR_NONE;   // macro mode: the next pre-allocated output variable
+    std::vector<std::pair<zk_var, uint64_t>> terms;
+    std::vector<zk_var> loose;          // nibbles no lookup consumes as a key: range-checked explicitly, three per lookup
     explicit S4(G& g) : g(g) {
         t_maj = g.cs.table_id(TABLE_MAJ4); t_tri = g.cs.table_id(TABLE_TRIXOR4); t_ch = g.cs.table_id(TABLE_CH4);
         t_s1 = g.cs.table_id(TABLE_SPLIT4_1); t_s2 = g.cs.table_id(TABLE_SPLIT4_2);
+        const char* e = getenv("ZKGL_SHA4_MACRO");
+        use_macro = e && e[0] == '1';
     }
-    // per-nibble split cache of one word: lo[s][j] = x_j & (2^s - 1), hi[s][j] = x_j >> s
-    struct Splits { Nib8 lo[4], hi[4]; bool have[4] = {false, false, false, false}; };
+    // ---- recording primitives: plain (witness op + constraint) or macro mode (constraint over the next pre-allocated outputs)
+    std::vector<zk_var> look(uint32_t table, const std::vector<zk_var>& keys, uint32_t n_vals) {
+        if (macro_next == ZK_VAR_NONE) return g.lookup(table, keys, n_vals);
+        std::vector<zk_var> vals(n_vals);
+        for (uint32_t i = 0; i < n_vals; ++i) vals[i] = macro_next++;
+        g.cs.lookup_given(table, keys.data(), (uint32_t)keys.size(), vals.data(), n_vals);
+        return vals;
+    }
+    zk_var fma(uint64_t q, zk_var a, zk_var b, uint64_t l, zk_var c) {   // q a b + l c
+        if (macro_next == ZK_VAR_NONE) return g.fma(q, a, b, l, c);
+        const zk_var r = macro_next++;
+        zk_var vars[4] = {a, b, c, r};
+        uint64_t ks[2] = {q, l};
+        g.cs.place_gate(ZK_GATE_FMA, vars, 4, ks, 2);
+        return r;
+    }
+    zk_var lc(const std::vector<std::pair<zk_var, uint64_t>>& ts) {   // G::linear_combination's chain, outputs given in macro mode
+        if (macro_next == ZK_VAR_NONE) return g.linear_combination(ts);
+        size_t pos = 0;
+        zk_var acc = ZK_VAR_NONE;
+        while (pos < ts.size() || acc == ZK_VAR_NONE) {
+            zk_var t[4];
+            uint64_t k[4];
+            int n = 0;
+            if (acc != ZK_VAR_NONE) { t[n] = acc; k[n] = 1; ++n; }
+            while (n < 4 && pos < ts.size()) { t[n] = ts[pos].first; k[n] = ts[pos].second; ++n; ++pos; }
+            while (n < 4) { t[n] = g.zero(); k[n] = 0; ++n; }
+            zk_var r = macro_next++;
+            zk_var vars[5] = {t[0], t[1], t[2], t[3], r};
+            g.cs.place_gate(ZK_GATE_REDUCTION4, vars, 5, k, 4);
+            acc = r;
+        }
+        return acc;
+    }
+    void split(zk_var x, uint32_t n_chunks, zk_var* parts) {   // ZK_OP_SPLIT into n_chunks 4-bit chunks (the last one keeps the residual)
+        if (macro_next == ZK_VAR_NONE) {
+            zk_var first = g.cs.alloc_vars(n_chunks);
+            for (uint32_t i = 0; i < n_chunks; ++i) parts[i] = first + i;
+            g.cs.emit_op(ZK_OP_SPLIT, n_chunks, 4, &x, 1, parts, n_chunks, nullptr, 0);
+        } else {
+            for (uint32_t i = 0; i < n_chunks; ++i) parts[i] = macro_next++;
+        }
+    }
+    // ---- the backend interface of zks4::compress
     void need(const W4& w, Splits& sp, int s) {
         if (sp.have[s]) return;
         if (s == 2) {
-            for (int j = 0; j < 8; ++j) { auto v = g.lookup(t_s2, {w.n[j]}, 3); sp.lo[2][j] = v[0]; sp.hi[2][j] = v[1]; }
+            for (int j = 0; j < 8; ++j) { auto v = look(t_s2, {w.n[j]}, 3); sp.lo[2][j] = v[0]; sp.hi[2][j] = v[1]; }
         } else {   // s = 1 and s = 3 come together
-            for (int j = 0; j < 8; ++j) { auto v = g.lookup(t_s1, {w.n[j]}, 3); sp.lo[1][j] = v[0]; sp.hi[1][j] = v[1]; }
+            for (int j = 0; j < 8; ++j) { auto v = look(t_s1, {w.n[j]}, 3); sp.lo[1][j] = v[0]; sp.hi[1][j] = v[1]; }
             sp.have[1] = true;
             if (s == 3)
                 for (int j = 0; j < 8; ++j) {
-                    auto v = g.lookup(t_s2, {sp.hi[1][j]}, 3);                       // (x >> 1) & 3, x >> 3
-                    sp.lo[3][j] = g.fma(2, v[0], g.one(), 1, sp.lo[1][j]);          // x & 7
+                    auto v = look(t_s2, {sp.hi[1][j]}, 3);                       // (x >> 1) & 3, x >> 3
+                    sp.lo[3][j] = fma(2, v[0], g.one(), 1, sp.lo[1][j]);          // x & 7
                     sp.hi[3][j] = v[1];
                 }
         }
         sp.have[s] = true;
     }
+    Nib8 nibs(const W4& w) { return w.n; }
     Nib8 rot(const W4& w, Splits& sp, int r, bool shift_only) {   // rotr (or shr) by r bits, 1 <= r < 32
         const int q = r / 4, s = r % 4;
         Nib8 o;
@@ -90,57 +150,60 @@ struct S4 {
             const int jj = j % 8, jn = (j + 1) % 8;
             if (s == 0) { o[i] = w.n[jj]; continue; }
             if (shift_only && j + 1 >= 8) { o[i] = sp.hi[s][jj]; continue; }
-            o[i] = g.fma(1ull << (4 - s), sp.lo[s][jn], g.one(), 1, sp.hi[s][jj]);
+            o[i] = fma(1ull << (4 - s), sp.lo[s][jn], g.one(), 1, sp.hi[s][jj]);
         }
         return o;
     }
-    Nib8 tri(uint32_t table, const Nib8& a, const Nib8& b, const Nib8& c) {
+    Nib8 tri(int t, const Nib8& a, const Nib8& b, const Nib8& c) {
+        const uint32_t table = t == zks4::T_TRI ? t_tri : t == zks4::T_CH ? t_ch : t_maj;
         Nib8 o;
-        for (int i = 0; i < 8; ++i) o[i] = g.lookup(table, {a[i], b[i], c[i]}, 1)[0];
+        for (int i = 0; i < 8; ++i) o[i] = look(table, {a[i], b[i], c[i]}, 1)[0];
         return o;
     }
-    void range_check_nibbles(const std::vector<zk_var>& v) {    // three chunks per TriXor4 lookup
-        for (size_t i = 0; i < v.size(); i += 3)
-            (void)g.lookup(t_tri, {v[i], i + 1 < v.size() ? v[i + 1] : g.zero(), i + 2 < v.size() ? v[i + 2] : g.zero()}, 1);
-    }
-    static void push_nibbles(std::vector<std::pair<zk_var, uint64_t>>& terms, const Nib8& n) {
-        for (int i = 0; i < 8; ++i) terms.push_back({n[i], 1ull << (4 * i)});
-    }
-    // (sum of the terms + constant) mod 2^32 as nibbles + the packed word; the carry (< 16) is range-checked here, the nibbles by
+    void sum_begin() { terms.clear(); }
+    void sum_packed(const W4& w) { terms.push_back({w.packed, 1}); }
+    void sum_nibs(const Nib8& n) { for (int i = 0; i < 8; ++i) terms.push_back({n[i], 1ull << (4 * i)}); }
+    void sum_scalar(zk_var v) { terms.push_back({v, 1}); }
+    void sum_const(uint64_t c) { if (c) terms.push_back({g.one(), c}); }
+    zk_var sum_end() { return lc(terms); }
+    // (the collected sum) mod 2^32 as nibbles + the packed word; the carry (< 16) is range-checked with the loose nibbles, the nibbles by
     // their consumers (or by the caller)
-    W4 add_mod32(std::vector<std::pair<zk_var, uint64_t>> terms, uint64_t constant, zk_var* carry_out) {
-        if (constant) terms.push_back({g.one(), constant});
-        zk_var sum = g.linear_combination(terms);
+    W4 add_mod32(zk_var* carry_out) {
+        zk_var sum = lc(terms);
         zk_var parts[9];
-        zk_var first = g.cs.alloc_vars(9);
-        for (int i = 0; i < 9; ++i) parts[i] = first + i;
-        g.cs.emit_op(ZK_OP_SPLIT, 9, 4, &sum, 1, parts, 9, nullptr, 0);   // eight nibbles + the carry
+        split(sum, 9, parts);   // eight nibbles + the carry
         W4 r;
         std::vector<std::pair<zk_var, uint64_t>> low;
         for (int i = 0; i < 8; ++i) { r.n[i] = parts[i]; low.push_back({parts[i], 1ull << (4 * i)}); }
-        r.packed = g.linear_combination(low);
-        g.enforce_equal(g.fma(1ull << 32, parts[8], g.one(), 1, r.packed), sum);
+        r.packed = lc(low);
+        g.enforce_equal(fma(1ull << 32, parts[8], g.one(), 1, r.packed), sum);
         *carry_out = parts[8];
         return r;
     }
     W4 from_bytes(const Word& b) {   // bytes (range-checked or not: the nibbles are checked by their consumers) -> nibbles
         W4 r;
         for (int k = 0; k < 4; ++k) {
-            zk_var first = g.cs.alloc_vars(2);
-            zk_var parts[2] = {first, first + 1};
-            g.cs.emit_op(ZK_OP_SPLIT, 2, 4, &b[k], 1, parts, 2, nullptr, 0);
+            zk_var parts[2];
+            split(b[k], 2, parts);
             zk_var vars[5] = {parts[0], parts[1], g.zero(), g.zero(), b[k]};
             uint64_t ks[4] = {1, 16, 0, 0};
             g.cs.place_gate(ZK_GATE_REDUCTION4, vars, 5, ks, 4);
             r.n[2 * k] = parts[0]; r.n[2 * k + 1] = parts[1];
         }
-        r.packed = g.linear_combination({{b[0], 1}, {b[1], 1ull << 8}, {b[2], 1ull << 16}, {b[3], 1ull << 24}});
+        r.packed = lc({{b[0], 1}, {b[1], 1ull << 8}, {b[2], 1ull << 16}, {b[3], 1ull << 24}});
         return r;
     }
     Word to_bytes(const W4& w) {
         Word b;
-        for (int k = 0; k < 4; ++k) b[k] = g.fma(16, w.n[2 * k + 1], g.one(), 1, w.n[2 * k]);
+        for (int k = 0; k < 4; ++k) b[k] = fma(16, w.n[2 * k + 1], g.one(), 1, w.n[2 * k]);
         return b;
+    }
+    void loose_nibs(const Nib8& n) { for (zk_var v : n) loose.push_back(v); }
+    void loose_v(zk_var v) { loose.push_back(v); }
+    void range_check_loose() {    // three chunks per TriXor4 lookup
+        for (size_t i = 0; i < loose.size(); i += 3)
+            (void)look(t_tri, {loose[i], i + 1 < loose.size() ? loose[i + 1] : g.zero(), i + 2 < loose.size() ? loose[i + 2] : g.zero()}, 1);
+        loose.clear();
     }
     void compress_with_hint(std::array<Word, 8>& st, const std::array<Word, 16>& block_words) {
         std::vector<zk_var> ins;
@@ -157,57 +220,29 @@ struct S4 {
         }
     }
     void compress(std::array<Word, 8>& st, const std::array<Word, 16>& block_words) {
-        std::vector<W4> w;
-        std::vector<zk_var> loose;   // nibbles no lookup consumes as a key: range-checked explicitly, three per lookup
-        for (int i = 0; i < 16; ++i) w.push_back(from_bytes(block_words[i]));
-        for (zk_var v : w[0].n) loose.push_back(v);   // w[0] feeds round 0's addition only
+        std::vector<W4> w(64);
         std::vector<Splits> wsp(64);
-        for (int i = 16; i < 64; ++i) {
-            Splits &a = wsp[i - 15], &b = wsp[i - 2];
-            Nib8 s0 = tri(t_tri, rot(w[i - 15], a, 7, false), rot(w[i - 15], a, 18, false), rot(w[i - 15], a, 3, true));
-            Nib8 s1 = tri(t_tri, rot(w[i - 2], b, 17, false), rot(w[i - 2], b, 19, false), rot(w[i - 2], b, 10, true));
-            std::vector<std::pair<zk_var, uint64_t>> terms = {{w[i - 16].packed, 1}, {w[i - 7].packed, 1}};
-            push_nibbles(terms, s0);
-            push_nibbles(terms, s1);
-            zk_var carry;
-            w.push_back(add_mod32(terms, 0, &carry));
-            loose.push_back(carry);
+        (void)g.zero(); (void)g.one();   // the constants exist before anything of the compression is allocated (both modes: same variables)
+        if (use_macro) {
+            zks4::CountBackend cb;
+            int cst[8] = {0}, cblk[16] = {0}, cw[64];
+            zks4::CountBackend::Splits csp[64];
+            zks4::compress(cb, cst, cblk, cw, csp, SHA_K);
+            std::vector<zk_var> ins;
+            for (auto& x : st)
+                for (auto b : x) ins.push_back(b);
+            for (auto& x : block_words)
+                for (auto b : x) ins.push_back(b);
+            const zk_var first = g.cs.alloc_vars(cb.n);
+            g.cs.emit_macro_op(ZK_OP_SHA256_ROUNDS, ins.data(), 96, first, cb.n, 1);   // a = 1: the 4-bit-chunk decomposition
+            macro_next = first;
+            zks4::compress(*this, st.data(), block_words.data(), w.data(), wsp.data(), SHA_K);
+            g.cs.end_macro_op();
+            if (macro_next != first + cb.n) throw ZkError(ZK_ERR_INVALID, "internal: the 4-bit SHA-256 gadget and its macro-op disagree on the output count");
+            macro_next = ZK_VAR_NONE;
+        } else {
+            zks4::compress(*this, st.data(), block_words.data(), w.data(), wsp.data(), SHA_K);
         }
-        for (int i : {62, 63})   // the only schedule words no sigma lookup consumes
-            for (zk_var v : w[i].n) loose.push_back(v);
-        W4 s[8];
-        for (int i = 0; i < 8; ++i) s[i] = from_bytes(st[i]);
-        W4 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], gg = s[6], h = s[7];
-        for (int i = 0; i < 64; ++i) {
-            Splits se, sa;
-            Nib8 S1 = tri(t_tri, rot(e, se, 6, false), rot(e, se, 11, false), rot(e, se, 25, false));
-            Nib8 ch = tri(t_ch, e.n, f.n, gg.n);
-            Nib8 S0 = tri(t_tri, rot(a, sa, 2, false), rot(a, sa, 13, false), rot(a, sa, 22, false));
-            Nib8 mj = tri(t_maj, a.n, b.n, c.n);
-            std::vector<std::pair<zk_var, uint64_t>> t1 = {{h.packed, 1}, {w[i].packed, 1}, {g.one(), SHA_K[i]}};
-            push_nibbles(t1, S1);
-            push_nibbles(t1, ch);
-            zk_var T1 = g.linear_combination(t1);                       // unreduced: < 5 * 2^32
-            std::vector<std::pair<zk_var, uint64_t>> t2 = {{T1, 1}};
-            push_nibbles(t2, S0);
-            push_nibbles(t2, mj);
-            zk_var c1, c2;
-            W4 new_e = add_mod32({{d.packed, 1}, {T1, 1}}, 0, &c1);
-            W4 new_a = add_mod32(t2, 0, &c2);
-            loose.push_back(c1); loose.push_back(c2);
-            h = gg; gg = f; f = e; e = new_e; d = c; c = b; b = a; a = new_a;
-        }
-        for (zk_var v : a.n) loose.push_back(v);   // outputs of the last round feed additions only
-        for (zk_var v : e.n) loose.push_back(v);
-        const W4 out[8] = {a, b, c, d, e, f, gg, h};
-        for (int i = 0; i < 8; ++i) {
-            zk_var carry;
-            W4 r = add_mod32({{s[i].packed, 1}, {out[i].packed, 1}}, 0, &carry);
-            loose.push_back(carry);
-            for (zk_var v : r.n) loose.push_back(v);
-            st[i] = to_bytes(r);
-        }
-        range_check_nibbles(loose);
     }
 };
 

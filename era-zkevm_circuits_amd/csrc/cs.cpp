@@ -16,6 +16,7 @@
 #include "../../include/zkgl_vm.h"
 #include "keccak_macro.hpp"
 #include "sha256_macro.hpp"
+#include "sha256_macro4.hpp"
 #include "bytebuf_macro.hpp"
 
 static constexpr int ZK_MACRO_FAILURE = 0x7fff0001;  // internal: a macro check packet failed, re-run the gate-by-gate program
@@ -346,9 +347,19 @@ void CS::emit_op(uint32_t opcode, uint32_t a, uint32_t b, const zk_var* ins, uin
     } break;
     case ZK_OP_SHA256_ROUNDS: {
         if (!allow_macro_ops_) throw ZkError(ZK_ERR_INVALID, "emit_op: macro-ops are recorded by the engine's gadgets only");
-        zks::CountBackend cb; int cst[8] = {0}, cblk[16] = {0}, cw[64];
-        zks::compress(cb, cst, cblk, cw, zks::K);
-        need(96, cb.n, 0);
+        if (a > 1) throw ZkError(ZK_ERR_INVALID, "SHA256_ROUNDS: a must be 0 (8-bit tables) / 1 (the reference's 4-bit-chunk tables)");
+        uint32_t n_outs;
+        if (a == 1) {   // the reference's table set: csrc/sha256_macro4.hpp
+            zks4::CountBackend cb; int cst[8] = {0}, cblk[16] = {0}, cw[64]; zks4::CountBackend::Splits csp[64];
+            zks4::compress(cb, cst, cblk, cw, csp, zks::K);
+            n_outs = cb.n;
+            uses_sha4_macro_ = true;
+        } else {
+            zks::CountBackend cb; int cst[8] = {0}, cblk[16] = {0}, cw[64];
+            zks::compress(cb, cst, cblk, cw, zks::K);
+            n_outs = cb.n;
+        }
+        need(96, n_outs, 0);
         s.uses_bigint = true;
         uses_lookup_macros_ = true;
     } break;
@@ -430,12 +441,12 @@ void CS::lookup_given(uint32_t tid, const zk_var* keys, uint32_t n_keys, const z
     cur().lookups.push_back(std::move(lr));
 }
 
-void CS::emit_macro_op(uint32_t opcode, const zk_var* ins, uint32_t n_in, zk_var first_out, uint32_t n_out) {
+void CS::emit_macro_op(uint32_t opcode, const zk_var* ins, uint32_t n_in, zk_var first_out, uint32_t n_out, uint32_t a) {
     std::vector<zk_var> outs(n_out);
     for (uint32_t i = 0; i < n_out; ++i) outs[i] = first_out + i;
     allow_macro_ops_ = true;
     if (macro_window_op_ >= 0) throw ZkError(ZK_ERR_INVALID, "emit_macro_op: the previous macro-op's window is still open");
-    try { emit_op(opcode, 0, 0, ins, n_in, outs.data(), n_out, nullptr, 0); } catch (...) { allow_macro_ops_ = false; throw; }
+    try { emit_op(opcode, a, 0, ins, n_in, outs.data(), n_out, nullptr, 0); } catch (...) { allow_macro_ops_ = false; throw; }
     allow_macro_ops_ = false;
     macro_window_op_ = (int32_t)cur().ops.size() - 1;
     macro_window_loop_ = in_loop_;
@@ -735,6 +746,9 @@ void CS::build_check_program(Scope& s) {
                 // carries the op it was placed for (GateRec::owner, set only inside the emit_macro_op .. end_macro_op window); a gate
                 // somebody else places on a macro output (zk_cs_place_gate is public) has no owner and stays in the check program
                 if (op && op->opcode == ZK_OP_BYTEBUF_FILL) { m = owned_by(g, op); break; }
+                // the 4-bit-chunk SHA-256 macro-op (a = 1, sha256_macro4.hpp): rotated nibbles hi + 2^(4-s) lo, x & 7 = 2 ((x >> 1) & 3) + (x & 1), the
+                // byte recompositions and 2^32 carry + low == sum are identities of the op's integer arithmetic on the values it stores
+                if (op && op->opcode == ZK_OP_SHA256_ROUNDS && op->a == 1) { m = owned_by(g, op); break; }
                 uint64_t q, l;
                 m = op && op->opcode == ZK_OP_FMA && op->ins.size() == 5 && pool(op->ins[0], q) && pool(op->ins[1], l) && q == g.consts[0] && l == g.consts[1] &&
                     is_var(op->ins[2], g.vars[0]) && is_var(op->ins[3], g.vars[1]) && is_var(op->ins[4], g.vars[2]);
@@ -2723,6 +2737,9 @@ void CS::set_batch(uint32_t n) {
     // the host-side programs stay available everywhere (the oracle runs them, tests/test_device_programs.py walks them); the DEVICE refuses.
 #ifndef ZKGL_BYTEBUF_KERNEL
     if (uses_bytebuf_macro_) throw ZkError(ZK_ERR_INVALID, "this circuit records ZK_OP_BYTEBUF_FILL (ZKGL_BYTEBUF_MACRO=1) but the library was built without its device backend (ZKGL_DEFS=-DZKGL_BYTEBUF_KERNEL)");
+#endif
+#ifndef ZKGL_SHA4_KERNEL
+    if (uses_sha4_macro_) throw ZkError(ZK_ERR_INVALID, "this circuit records the 4-bit-chunk SHA-256 macro-op (ZKGL_SHA4_MACRO=1) but the library was built without its device backend (ZKGL_DEFS=-DZKGL_SHA4_KERNEL)");
 #endif
 #ifndef ZKGL_STRAND_PLANES_KERNEL
     if (uses_strand_planes_) throw ZkError(ZK_ERR_INVALID, "strand-form flag planes were requested (ZKGL_STRAND_PLANES=1) but the library was built without them (ZKGL_DEFS=-DZKGL_STRAND_PLANES_KERNEL)");

@@ -201,7 +201,7 @@ class CS {
     // A macro-op and the WINDOW of its gadget: between emit_macro_op and end_macro_op every gate placed / tuple given on the op's outputs is tagged
     // with the op (GateRec::owner, LookupRec::owner).  Only tagged gates count as "evaluated by the macro-op" in the fused check; the window
     // cannot be opened through the C ABI (zk_cs_place_gate on a macro output from outside stays in the check program).
-    void emit_macro_op(uint32_t opcode, const zk_var* ins, uint32_t n_in, zk_var first_out, uint32_t n_out);
+    void emit_macro_op(uint32_t opcode, const zk_var* ins, uint32_t n_in, zk_var first_out, uint32_t n_out, uint32_t a = 0);
     void end_macro_op();
     bool uses_lookup_macros() const { return uses_lookup_macros_; }
     void side_begin();
@@ -418,7 +418,7 @@ class CS {
     bool defer_p2_ = false;          // ZK_CHECK_FUSED_DEFER_P2
     bool p2_pending_ = false;        // the loop store lacks the intermediates of its in-circuit permutations (k_fill_p2 not run yet)
     bool uses_lookup_macros_ = false;   // a macro-op whose outputs carry lookup tuples was recorded: multiplicities by the k_multiplicities pass
-    bool uses_bytebuf_macro_ = false, uses_strand_planes_ = false;   // opt-in device paths the default build does not carry (set_batch refuses them there)
+    bool uses_bytebuf_macro_ = false, uses_strand_planes_ = false, uses_sha4_macro_ = false;   // opt-in device paths the default build does not carry (set_batch refuses them there)
     int32_t macro_window_op_ = -1;   // index (current scope) of the macro-op whose gadget window is open
     bool macro_window_loop_ = false;
     bool allow_macro_ops_ = false;   // zk_cs_set_check_mode(ZK_CHECK_STORED)

@@ -21,6 +21,7 @@
 #include "kernels_engine.hpp"
 #include "keccak_macro.hpp"
 #include "sha256_macro.hpp"
+#include "sha256_macro4.hpp"
 #include "bytebuf_macro.hpp"
 #include <utility>
 
@@ -173,6 +174,38 @@ __device__ __noinline__ uint32_t sha256_rounds_stream(__amdgpu_buffer_rsrc_t rsr
     zks::compress(be, st, blk, w, zks::K);
     return emit.d;
 }
+
+// K8, out of line: one SHA-256 compression over the REFERENCE's 4-bit-chunk table set (ZK_OP_SHA256_ROUNDS with a = 1; zks4::compress, sha256_macro4.hpp):
+// 26 088 outputs; cooperative like sha256_rounds_stream — every strand computes, strand `share` stores every (mask + 1)-th run of eight outputs.
+// Built only on request (ZKGL_DEFS=-DZKGL_SHA4_KERNEL; zk_cs_set_batch refuses the recording in any other build): not yet measured on a device.
+#ifdef ZKGL_SHA4_KERNEL
+__device__ __noinline__ uint32_t sha256_rounds4_stream(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_byte, uint32_t dst, uint32_t bstep, const uint32_t* in24,
+                                                        uint32_t share, uint32_t n_share_mask) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    struct Emit {
+        __amdgpu_buffer_rsrc_t rsrc;
+        uint32_t lane_byte, d, bstep, cnt, mine, mask;
+        __device__ __forceinline__ void one(uint64_t v) {
+            if (((cnt >> 3) & mask) == mine) {
+                u32x2 o;
+                o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
+                __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, d, 0);
+            }
+            d += bstep;
+            ++cnt;
+        }
+    } emit{rsrc, lane_byte, uni(dst), bstep, 0u, uni(share), uni(n_share_mask)};
+    uint32_t st[8], blk[16], w[64];   // w is indexed dynamically: scratch
+    typename zks4::ComputeBackend<Emit>::Splits wsp[64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = in24[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) blk[i] = in24[8 + i];
+    zks4::ComputeBackend<Emit> be(emit);
+    zks4::compress(be, st, blk, w, wsp, zks::K);
+    return emit.d;
+}
+#endif  // ZKGL_SHA4_KERNEL
 
 // ZK_OP_BYTEBUF_FILL's device backend is built only on request (ZKGL_DEFS=-DZKGL_BYTEBUF_KERNEL; keccak.cpp refuses ZKGL_BYTEBUF_MACRO=1 in any
 // other build): written while the GPU was closed to the build, never executed — it stays out of the default binary until it has been measured.
@@ -883,7 +916,28 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #ifndef ZKGL_STUB_STORES
             if constexpr (!WIDE) {
                 const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
+#ifdef ZKGL_SHA4_KERNEL
+                if (pa == 1) dst = sha256_rounds4_stream(rsrc, lane_byte, dst, bstep, wd, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+                else
+#endif
                 dst = sha256_rounds_stream(rsrc, lane_byte, dst, bstep, wd, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+            } else
+#endif
+#ifdef ZKGL_SHA4_KERNEL
+            if (pa == 1) {   // (wide scopes / stub builds: every output through st)
+                auto st1 = [&](uint64_t v) { st(v); };
+                struct EmitAll4 {
+                    decltype(st1)& f;
+                    __device__ __forceinline__ void one(uint64_t v) { f(v); }
+                } emit{st1};
+                uint32_t sst[8], blk[16], w[64];
+                typename zks4::ComputeBackend<EmitAll4>::Splits wsp[64];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sst[i] = wd[i];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) blk[i] = wd[8 + i];
+                zks4::ComputeBackend<EmitAll4> be(emit);
+                zks4::compress(be, sst, blk, w, wsp, zks::K);
             } else
 #endif
             {

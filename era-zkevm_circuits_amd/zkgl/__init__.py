@@ -125,7 +125,7 @@ def poseidon_round_constants() -> np.ndarray:
     return out
 
 
-BUILD_BYTEBUF_KERNEL, BUILD_STRAND_PLANES_KERNEL, BUILD_SELECT_CHAINS_KERNEL, BUILD_BATCH_INV = 1, 2, 4, 8
+BUILD_BYTEBUF_KERNEL, BUILD_STRAND_PLANES_KERNEL, BUILD_SELECT_CHAINS_KERNEL, BUILD_BATCH_INV, BUILD_SHA4_KERNEL = 1, 2, 4, 8, 16
 
 
 def build_features() -> int:

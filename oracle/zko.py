@@ -162,6 +162,15 @@ def grand_product(enc: np.ndarray, flags, challenges, init=1):
 
 
 # ---- hashes ----
+def sha256_rounds_stream(a: int, state, block):
+    """zko_sha256_rounds_stream: (outputs of one ZK_OP_SHA256_ROUNDS with header a, final state) for 8 + 16 little-endian byte words"""
+    st = np.array(state, dtype=np.uint32); blk = np.array(block, dtype=np.uint32); out = np.zeros(32768, dtype=np.uint64)
+    f = lib().zko_sha256_rounds_stream
+    f.restype = C.c_size_t
+    n = f(C.c_uint32(a), st.ctypes.data_as(C.c_void_p), blk.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out[:n].copy(), [int(x) for x in st]
+
+
 def keccak256(msg: bytes) -> bytes:
     out = (C.c_uint8 * 32)()
     lib().zko_keccak256(msg, C.c_size_t(len(msg)), out)

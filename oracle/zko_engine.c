@@ -259,6 +259,130 @@ static void sh_compress(uint32_t st[8], const uint32_t blk[16], kk_out *o) {
     }
 }
 
+/* ZK_OP_SHA256_ROUNDS with a = 1 (include/zkgl_ir.h): one SHA-256 compression over 4-bit chunks through the reference's table set (Maj4 / TriXor4 /
+ * Ch4 / Split4BitChunk<1,2>, /root/reference/src/code_unpacker_sha256/mod.rs:554-566), every intermediate written out — restated in plain C from the
+ * output order documented in era-zkevm_circuits_amd/csrc/sha256_macro4.hpp.  CPU ORACLE, test infrastructure. */
+typedef struct { kk_out *o; uint64_t acc; uint32_t terms; uint8_t loose[320]; uint32_t n_loose; } s4_ctx;
+static uint32_t s4_nib(uint32_t w, int j) { return (w >> (4 * j)) & 15u; }
+static void s4_put(s4_ctx *x, uint64_t v) { x->o->buf[x->o->n++] = v; }
+static uint32_t s4_from_bytes(s4_ctx *x, uint32_t b) { for (int j = 0; j < 8; ++j) s4_put(x, s4_nib(b, j)); s4_put(x, b); return b; }
+static void s4_rows(s4_ctx *x, uint32_t w, int at) {   /* Split4BitChunk<at> rows of the eight chunks of w: (low, high, swapped halves) */
+    for (int j = 0; j < 8; ++j) { uint32_t c = s4_nib(w, j), lo = c & ((1u << at) - 1), hi = c >> at; s4_put(x, lo); s4_put(x, hi); s4_put(x, (lo << (4 - at)) | hi); }
+}
+static uint32_t s4_rot(s4_ctx *x, uint32_t w, uint8_t *have, int r, int shift_only) {
+    int q = r / 4, s = r % 4;
+    if (s && !(*have & (1 << s))) {
+        if (s == 2) s4_rows(x, w, 2);
+        else {
+            s4_rows(x, w, 1);
+            *have |= 2;
+            if (s == 3)
+                for (int j = 0; j < 8; ++j) {
+                    uint32_t c = s4_nib(w, j), h1 = c >> 1, lo = h1 & 3u, hi = h1 >> 2;
+                    s4_put(x, lo); s4_put(x, hi); s4_put(x, (lo << 2) | hi);
+                    s4_put(x, 2 * lo + (c & 1u));
+                }
+        }
+        *have |= (uint8_t)(1 << s);
+    }
+    uint32_t res = shift_only ? w >> r : (w >> r) | (w << (32 - r));
+    if (s)
+        for (int i = 0; i < 8; ++i) {
+            int j = i + q;
+            if (shift_only && (j >= 8 || j + 1 >= 8)) continue;   /* zero, or the bare high part: no gate */
+            uint32_t hi = s4_nib(w, j % 8) >> s, lo = s4_nib(w, (j + 1) % 8) & ((1u << s) - 1);
+            s4_put(x, hi + (lo << (4 - s)));
+        }
+    return res;
+}
+static uint32_t s4_tri(s4_ctx *x, int t, uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t p = s4_nib(a, i), q = s4_nib(b, i), z = s4_nib(c, i);
+        uint32_t v = t == 0 ? p ^ q ^ z : t == 1 ? (p & q) ^ (~p & 0xfu & z) : (p & q) ^ (p & z) ^ (q & z);
+        s4_put(x, v);
+        r |= v << (4 * i);
+    }
+    return r;
+}
+static void s4_term(s4_ctx *x, uint64_t v) { x->acc += v; ++x->terms; if (x->terms == 4 || (x->terms > 4 && (x->terms - 4) % 3 == 0)) s4_put(x, x->acc); }
+static void s4_nibs(s4_ctx *x, uint32_t n) { for (int i = 0; i < 8; ++i) s4_term(x, (uint64_t)s4_nib(n, i) << (4 * i)); }
+static uint64_t s4_end(s4_ctx *x) { if (x->terms < 4 || (x->terms - 4) % 3 != 0) s4_put(x, x->acc); return x->acc; }
+static uint32_t s4_add(s4_ctx *x, uint64_t *carry) {
+    uint64_t sum = s4_end(x);
+    uint32_t low = (uint32_t)sum;
+    for (int j = 0; j < 8; ++j) s4_put(x, s4_nib(low, j));
+    s4_put(x, sum >> 32);
+    s4_put(x, low & 0xffffu); s4_put(x, low & 0xfffffffu); s4_put(x, low);
+    s4_put(x, ((sum >> 32) << 32) + low);
+    *carry = sum >> 32;
+    return low;
+}
+static void s4_loose(s4_ctx *x, uint32_t v) { x->loose[x->n_loose++] = (uint8_t)(v & 15u); }
+static void s4_loose8(s4_ctx *x, uint32_t w) { for (int i = 0; i < 8; ++i) s4_loose(x, s4_nib(w, i)); }
+static void sh4_compress(uint32_t st[8], const uint32_t blk[16], kk_out *o) {
+    s4_ctx X = {o, 0, 0, {0}, 0}, *x = &X;
+    uint32_t w[64]; uint8_t have[64] = {0};
+    uint64_t cy;
+    for (int i = 0; i < 16; ++i) w[i] = s4_from_bytes(x, blk[i]);
+    s4_loose8(x, w[0]);
+    for (int i = 16; i < 64; ++i) {
+        uint32_t a7 = s4_rot(x, w[i - 15], &have[i - 15], 7, 0), a18 = s4_rot(x, w[i - 15], &have[i - 15], 18, 0), a3 = s4_rot(x, w[i - 15], &have[i - 15], 3, 1);
+        uint32_t s0 = s4_tri(x, 0, a7, a18, a3);
+        uint32_t b17 = s4_rot(x, w[i - 2], &have[i - 2], 17, 0), b19 = s4_rot(x, w[i - 2], &have[i - 2], 19, 0), b10 = s4_rot(x, w[i - 2], &have[i - 2], 10, 1);
+        uint32_t s1 = s4_tri(x, 0, b17, b19, b10);
+        x->acc = 0; x->terms = 0;
+        s4_term(x, w[i - 16]); s4_term(x, w[i - 7]); s4_nibs(x, s0); s4_nibs(x, s1);
+        w[i] = s4_add(x, &cy);
+        s4_loose(x, (uint32_t)cy);
+    }
+    s4_loose8(x, w[62]); s4_loose8(x, w[63]);
+    uint32_t s[8];
+    for (int i = 0; i < 8; ++i) s[i] = s4_from_bytes(x, st[i]);
+    uint32_t a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5], g = s[6], h = s[7];
+    for (int i = 0; i < 64; ++i) {
+        uint8_t he = 0, ha = 0;
+        uint32_t e6 = s4_rot(x, e, &he, 6, 0), e11 = s4_rot(x, e, &he, 11, 0), e25 = s4_rot(x, e, &he, 25, 0);
+        uint32_t S1 = s4_tri(x, 0, e6, e11, e25);
+        uint32_t ch = s4_tri(x, 1, e, f, g);
+        uint32_t a2 = s4_rot(x, a, &ha, 2, 0), a13 = s4_rot(x, a, &ha, 13, 0), a22 = s4_rot(x, a, &ha, 22, 0);
+        uint32_t S0 = s4_tri(x, 0, a2, a13, a22);
+        uint32_t mj = s4_tri(x, 2, a, b, c);
+        x->acc = 0; x->terms = 0;
+        s4_term(x, h); s4_term(x, w[i]); s4_term(x, SHA_K_O[i]); s4_nibs(x, S1); s4_nibs(x, ch);
+        uint64_t T1 = s4_end(x), c1, c2;
+        x->acc = 0; x->terms = 0;
+        s4_term(x, d); s4_term(x, T1);
+        uint32_t ne = s4_add(x, &c1);
+        x->acc = 0; x->terms = 0;
+        s4_term(x, T1); s4_nibs(x, S0); s4_nibs(x, mj);
+        uint32_t na = s4_add(x, &c2);
+        s4_loose(x, (uint32_t)c1); s4_loose(x, (uint32_t)c2);
+        h = g; g = f; f = e; e = ne; d = c; c = b; b = a; a = na;
+    }
+    s4_loose8(x, a); s4_loose8(x, e);
+    uint32_t out[8] = {a, b, c, d, e, f, g, h};
+    for (int i = 0; i < 8; ++i) {
+        x->acc = 0; x->terms = 0;
+        s4_term(x, s[i]); s4_term(x, out[i]);
+        uint32_t r = s4_add(x, &cy);
+        s4_loose(x, (uint32_t)cy); s4_loose8(x, r);
+        for (int k = 0; k < 4; ++k) s4_put(x, (r >> (8 * k)) & 0xff);
+        st[i] = r;
+    }
+    for (uint32_t i = 0; i < x->n_loose; i += 3)
+        s4_put(x, x->loose[i] ^ (i + 1 < x->n_loose ? x->loose[i + 1] : 0) ^ (i + 2 < x->n_loose ? x->loose[i + 2] : 0));
+}
+
+/* the output stream of one ZK_OP_SHA256_ROUNDS (a = 0: 8-bit tables, 1: the reference's 4-bit-chunk tables) for a state and a block given as
+ * little-endian byte words; st is updated; returns the number of outputs (out: capacity >= 32768).  Used by the tests that compare the
+ * device backends (host-compiled) with this restatement value by value. */
+size_t zko_sha256_rounds_stream(uint32_t a, uint32_t st[8], const uint32_t blk[16], uint64_t *out) {
+    kk_out o = {out, 0};
+    if (a == 1) sh4_compress(st, blk, &o); else sh_compress(st, blk, &o);
+    return o.n;
+}
+
 static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
     const zko_scope *s = c->s;
     const uint32_t *prog = s->prog;
@@ -418,9 +542,9 @@ static int run_lane(const run_ctx *c, uint32_t lane, uint32_t wb, uint32_t we) {
             uint32_t wd[24] = {0};
             for (int j = 0; j < 96; ++j) wd[j / 4] |= (uint32_t)(ld(c, prog[pc + j], lane, inst) & 0xff) << (8 * (j % 4));
             pc += 96;
-            static _Thread_local uint64_t sbuf[16000];
+            static _Thread_local uint64_t sbuf[32768];
             kk_out o = {sbuf, 0};
-            sh_compress(wd, wd + 8, &o);
+            if (pa == 1) sh4_compress(wd, wd + 8, &o); else sh_compress(wd, wd + 8, &o);
             for (size_t i = 0; i < o.n; ++i) st(c, prog, &pc, lane, sbuf[i]);
         } break;
         case ZK_OP_BYTEBUF_FILL: { /* include/zkgl_ir.h: ByteBuffer::fill_with_bytes (/root/reference/src/keccak256_round_function/buffer/mod.rs:69-136)

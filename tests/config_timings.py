@@ -1,7 +1,7 @@
 """Timings of BASELINE.json's other configurations at full size on one GPU (C1, C3, C4, C5): one fused
 resolve_and_check per configuration (after one warm-up), inputs from the native restatements used by the parity tests.
 Prints one JSON line per configuration.  It lives under tests/ because its input generators are the oracle's native restatements (test infrastructure).
-usage (GPU box, repo root): python tests/config_timings.py            (CONFIGS=C3k,C5 selects: C1 C3k C3s C4s C4l C5)"""
+usage (GPU box, repo root): python tests/config_timings.py            (CONFIGS=C3k,C5 selects: C1 C3k C3s C3s4 C4s C4l C5)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file is tests/config_timings.py)
 for p in (ROOT, os.path.join(ROOT, "era-zkevm_circuits_amd"), os.path.join(ROOT, "tests")):
@@ -90,6 +90,15 @@ if want("C3s"):
     outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
     timed("C3 sha256_round_function 2^20 rows", cs, outer, loop, B, stream_x=4)
     timed("C3 sha256_round_function 2^20 rows, every carried word from the witness's queue states (zk_pack_sha256_witness_tails)", cs, outer, loop, B, given=list(range(shn.CARRIED)))
+if want("C3s4"):   # the SAME circuit under the reference's own table set (src/code_unpacker_sha256/mod.rs:554-566: width-4 lookups, Maj4 / TriXor4 / Ch4 / Split4BitChunk<1,2>)
+    B = 128      # ZKGL_SHA4_MACRO=1 (in a -DZKGL_SHA4_KERNEL library) records the compression as one macro-op; otherwise it is interpreted op by op
+    cs, limit = T.fit(lambda c: c.configure_sha256(True), lambda c, l: c.sha256_round_function_entry_point(l), 20)
+    msgs = [bytes(rng.integers(0, 256, size=64 * 8 - 9, dtype=np.uint8)) for _ in range(limit // 8)]
+    reqs = [shn.request(m, 1 + 2 * i, 10 + i, 0, 9000 + i, i) for i, m in enumerate(msgs)]
+    inst = shn.instance(reqs, limit)
+    outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
+    form = "macro-op ZK_OP_SHA256_ROUNDS a = 1" if os.environ.get("ZKGL_SHA4_MACRO") == "1" else "op by op"
+    timed(f"C3 sha256_round_function 2^20 rows, REFERENCE table set (4-bit chunks, {form}), every carried word from the witness's queue states", cs, outer, loop, B, given=list(range(shn.CARRIED)))
 # C4 (4 instances on one GPU here; BASELINE shards them over 4 GPUs)
 if want("C4s"):
     cs, limit = T.fit(lambda c: c.configure_storage_validity(), lambda c, l: c.sort_and_deduplicate_storage_access_entry_point(l, True), 22)

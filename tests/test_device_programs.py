@@ -30,6 +30,8 @@ CIRCUITS = {
     "sort_decommits": lambda: _rec(lambda c: c.configure_sort_decommits(), lambda c: c.sort_and_deduplicate_code_decommittments_entry_point(4)),
     "code_unpacker": lambda: _rec(lambda c: c.configure_code_unpacker(), lambda c: c.unpack_code_into_memory_entry_point(3)),
     "linear_hasher": lambda: _rec(lambda c: c.configure_linear_hasher(), lambda c: c.linear_hasher_entry_point(17)),
+    "sha256_fsm_reference_tables": lambda: _rec(lambda c: c.configure_sha256(True), lambda c: c.sha256_round_function_entry_point(3)),
+    "code_unpacker_reference_tables": lambda: _rec(lambda c: c.configure_sha256(True), lambda c: c.unpack_code_into_memory_entry_point(3)),
     "main_vm": lambda: _rec(lambda c: c.configure_main_vm(), lambda c: c.main_vm_entry_point(3), zkgl.CSGeometry(140, 0, 8, 8)),
     "vm_shaped": lambda: _rec(lambda c: c.configure_vm_shaped(), lambda c: c.vm_shaped_entry_point(4), zkgl.CSGeometry(140, 0, 8, 8)),
 }
@@ -40,6 +42,7 @@ FORMS = {
     "no_hash_macros": {"ZKGL_NO_HASH_MACROS": "1"},
     "bytebuf_macro_and_strand_planes": {"ZKGL_BYTEBUF_MACRO": "1", "ZKGL_STRAND_PLANES": "1"},
     "chain_order": {"ZKGL_SELECT_CHAINS": "1"},
+    "sha4_macro": {"ZKGL_SHA4_MACRO": "1"},
 }
 
 
@@ -48,9 +51,11 @@ FORMS = {
 def test_device_programs_decode_to_the_recorded_ops(monkeypatch, circuit, form):
     if form == "bytebuf_macro_and_strand_planes" and circuit != "keccak_fsm":
         pytest.skip("the ByteBuffer is the keccak precompile's")
+    if form == "sha4_macro" and not circuit.endswith("reference_tables"):
+        pytest.skip("the 4-bit-chunk macro-op belongs to the reference's table set")
     if form == "no_hash_macros" and circuit not in ("keccak_fsm", "sha256_fsm", "eip_4844", "code_unpacker", "linear_hasher"):
         pytest.skip("no hash gadget")
-    for k in ("ZKGL_STRAND_PLANES", "ZKGL_FLAG_PLANES", "ZKGL_NO_HASH_MACROS", "ZKGL_BYTEBUF_MACRO", "ZKGL_SELECT_CHAINS", "ZKGL_VERIFY_SABOTAGE"):
+    for k in ("ZKGL_STRAND_PLANES", "ZKGL_FLAG_PLANES", "ZKGL_NO_HASH_MACROS", "ZKGL_BYTEBUF_MACRO", "ZKGL_SELECT_CHAINS", "ZKGL_VERIFY_SABOTAGE", "ZKGL_SHA4_MACRO"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("ZKGL_VERIFY_DEVICE_PROGRAMS", "1")
     for k, v in FORMS[form].items():

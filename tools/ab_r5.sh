@@ -29,4 +29,15 @@ for l in sys.stdin:
     d = json.loads(l); print('[$v]', d['config'], 'step_ms', d['step_ms'], 'loop_ms', d['k_witness_loop_ms'], 'seed_s', d['seed_s'])" | sed "s#$P/##g" | tee -a $OUT
   done
 fi
+# ---- (4) a16: the reference's SHA table set as a macro-op (ZK_OP_SHA256_ROUNDS a = 1): parity, then the C3 sha256 step under that table set
+if [ -f $P/libzkgl_sha4.so ]; then
+  t sha4 ZKGL_LIB=$P/libzkgl_sha4.so timeout 900 python -m pytest tests/test_sha4_macro.py -m gpu -x -q
+  t sha4_tables ZKGL_LIB=$P/libzkgl_sha4.so ZKGL_SHA4_MACRO=1 timeout 900 python -m pytest tests/test_sha256_reference_tables.py tests/test_macro_ownership.py -m gpu -x -q
+  for v in "A=0" "ZKGL_LIB=$P/libzkgl_sha4.so ZKGL_SHA4_MACRO=1" "A=0" "ZKGL_LIB=$P/libzkgl_sha4.so ZKGL_SHA4_MACRO=1"; do
+    env $v CONFIGS=C3s,C3s4 timeout 600 python tests/config_timings.py 2>/dev/null | grep "^{" | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('[$v]', d['config'][:110], 'step_ms', d['step_ms'], 'loop_ms', d['k_witness_loop_ms'], 'rows', d['rows_per_instance'])" | sed "s#$P/##g" | tee -a $OUT
+  done
+fi
 cat $OUT
