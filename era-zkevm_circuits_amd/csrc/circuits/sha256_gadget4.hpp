@@ -127,8 +127,9 @@ struct S4 {
         if (sp.have[s]) return;
         if (s == 2) {
             for (int j = 0; j < 8; ++j) { auto v = look(t_s2, {w.n[j]}, 3); sp.lo[2][j] = v[0]; sp.hi[2][j] = v[1]; }
-        } else {   // s = 1 and s = 3 come together
-            for (int j = 0; j < 8; ++j) { auto v = look(t_s1, {w.n[j]}, 3); sp.lo[1][j] = v[0]; sp.hi[1][j] = v[1]; }
+        } else {   // s = 3 builds on s = 1 (round 5: only when the word does not have those rows yet — 8 lookups less per schedule word)
+            if (!sp.have[1])
+                for (int j = 0; j < 8; ++j) { auto v = look(t_s1, {w.n[j]}, 3); sp.lo[1][j] = v[0]; sp.hi[1][j] = v[1]; }
             sp.have[1] = true;
             if (s == 3)
                 for (int j = 0; j < 8; ++j) {

@@ -12,7 +12,7 @@
 //   rot(w, sp, r, shr)       -> the splits the rotation needs and the word does not have yet (sp remembers), s = r % 4:
 //                                 s = 2: per nibble j = 0..7 the Split4BitChunk<2> row of x_j: (x & 3, x >> 2, swapped)                 3 each
 //                                 s = 1: per nibble the Split4BitChunk<1> row: (x & 1, x >> 1, swapped)                                  3 each
-//                                 s = 3: the s = 1 rows AGAIN (the gadget does not test whether it has them), then per nibble the
+//                                 s = 3: the s = 1 rows unless the word has them, then per nibble the
 //                                        Split4BitChunk<2> row of x >> 1: ((x >> 1) & 3, x >> 3, swapped) and x & 7 = 2 ((x >> 1) & 3) + (x & 1)   3 + 3 + 1 each
 //                               then, s != 0, one per output nibble i whose two halves come from different input nibbles:
 //                                 hi_s(x_j) + 2^(4-s) lo_s(x_(j+1)), j = i + r / 4 (rotation: indices mod 8; shift: nothing past nibble 7)
@@ -145,7 +145,7 @@ struct CountBackend {
         const int q = r / 4, s = r % 4;
         if (s && !(sp.have & (1 << s))) {
             if (s == 2) n += 8 * 3;
-            else { n += 8 * 3; sp.have |= 2; if (s == 3) n += 8 * 4; }
+            else { if (!(sp.have & 2)) n += 8 * 3; sp.have |= 2; if (s == 3) n += 8 * 4; }
             sp.have |= (uint8_t)(1 << s);
         }
         for (int i = 0; i < 8; ++i) {
@@ -203,7 +203,7 @@ struct ComputeBackend {
         if (s && !(sp.have & (1 << s))) {
             if (s == 2) split_rows(w, 2);
             else {
-                split_rows(w, 1);
+                if (!(sp.have & 2)) split_rows(w, 1);
                 sp.have |= 2;
                 if (s == 3) {
 #pragma unroll

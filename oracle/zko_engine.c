@@ -274,7 +274,7 @@ static uint32_t s4_rot(s4_ctx *x, uint32_t w, uint8_t *have, int r, int shift_on
     if (s && !(*have & (1 << s))) {
         if (s == 2) s4_rows(x, w, 2);
         else {
-            s4_rows(x, w, 1);
+            if (!(*have & 2)) s4_rows(x, w, 1);
             *have |= 2;
             if (s == 3)
                 for (int j = 0; j < 8; ++j) {
