@@ -2994,10 +2994,10 @@ bool CS::launch_seed_native(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& 
 void CS::launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uint64_t* dev_loop_inputs_rw, uint32_t n, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (launch_seed_native(la, oa, dev_loop_inputs_rw, n, stream)) return;
-    if (seed_cone_unsupported_) throw ZkError(ZK_ERR_INVALID, "the seeding cone of this circuit cannot be run by the seed kernels (it contains ZK_OP_BYTEBUF_FILL, or a carried output depends on a gated ZK_OP_POSEIDON2 outside a select on its flag): use the native seeder or ZKGL_SEED_GENERIC=1");
     const char* force_generic = std::getenv("ZKGL_SEED_GENERIC");
     const char* seed_strands = std::getenv("ZKGL_SEED_STRANDS");  // 0: plain cone, 1: strand form whenever it exists
     const bool generic = force_generic && force_generic[0] == '1';
+    if (seed_cone_unsupported_ && !generic) throw ZkError(ZK_ERR_INVALID, "the seeding cone of this circuit cannot be run by the seed kernels (it contains ZK_OP_BYTEBUF_FILL, or a carried output depends on a gated ZK_OP_POSEIDON2 outside a select on its flag): use the native seeder or ZKGL_SEED_GENERIC=1");
     const bool use_strands = d_seed_sprog_ && !(seed_strands && seed_strands[0] == '0') && ((seed_strands && seed_strands[0] == '1') || seed_sgain_ >= 1.5f);
     const char* seed_wave = std::getenv("ZKGL_SEED_WAVE");  // 0: never use the op-parallel kernel
     if (d_seed_wprog_ && !generic && !(seed_wave && seed_wave[0] == '0'))

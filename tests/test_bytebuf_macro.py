@@ -60,41 +60,4 @@ def test_device_backend_walk_equals_the_gate_arithmetic_on_the_cpu(tmp_path):
     assert out.startswith("ok 300 trials"), out
 
 
-@pytest.mark.gpu
-def test_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
-    """whole trace of the macro recording, plain and strand kernels, both check modes; seeding through the native FSM seeder.
-    The op's device backend is NOT part of the default library (never measured: it stays out of the product binary, kernels_engine2.hpp): there
-    the device must refuse the recording loudly; a library built with ZKGL_DEFS=-DZKGL_BYTEBUF_KERNEL (ZKGL_LIB=..., tools/ab_r5.sh) runs it."""
-    import zkgl
-    cs = record(monkeypatch, True)
-    if not zkgl.build_features() & zkgl.BUILD_BYTEBUF_KERNEL:
-        with pytest.raises(zkgl.ZkError) as e:
-            cs.set_batch(4)
-        assert "ZKGL_BYTEBUF_KERNEL" in str(e.value)
-        return
-    insts = [reference_case(l, u)[1] for l, u in REFERENCE_CASES] * 8        # 72 instances x 2 cycles: a few wavefronts
-    outer, loop = streams(insts, 2)
-    r = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
-    r.resolve(outer, loop)
-    for strands in ("0", "1"):
-        monkeypatch.setenv("ZKGL_STRANDS", strands)
-        cs.set_batch(len(insts))
-        raw = loop.copy(); raw[:N.CARRIED] = 0
-        d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
-        cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
-        cs.seed_carried_inputs(d_l)
-        assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
-        for stored in (False, True):
-            cs.set_check_mode(stored)
-            ok, f = cs.resolve_and_check()
-            assert ok, (strands, stored, f)
-        from test_gpu_cs import assert_trace_equal
-        assert_trace_equal(cs, r)
-        bad = loop.copy(); bad[300, 5] = 256                                  # a buffer byte that is not a byte: rejected in both modes
-        d_b = zk.DeviceBuffer.from_numpy(bad)
-        cs.bind_inputs(True, d_b, loop.shape[0])
-        for stored in (False, True):
-            cs.set_check_mode(stored)
-            ok, f = cs.resolve_and_check()
-            assert not ok
-    cs.set_check_mode(False)
+# (the device half of this file: tests/test_zz_round5_gpu.py — device paths that have not run on a GPU yet sort last)

@@ -73,28 +73,4 @@ def _gated_chain(select_on_flag: bool):
     return cs
 
 
-@pytest.mark.gpu
-def test_cone_with_gated_permutations_is_verified_not_assumed(zk, monkeypatch):
-    import numpy as np
-    from oracle import zko
-    monkeypatch.setenv("ZKGL_SEED_NATIVE", "0")
-    B, limit = 70, 5
-    rng = np.random.default_rng(3)
-    outer = rng.integers(1, 1 << 60, size=(1, B), dtype=np.uint64)
-    loop = np.zeros((2, B * limit), dtype=np.uint64)
-    loop[1] = rng.integers(0, 2, size=B * limit)
-    for ok_form in (True, False):
-        cs = _gated_chain(ok_form)
-        cs.set_batch(B)
-        d_o, d_l = zkgl.DeviceBuffer.from_numpy(outer), zkgl.DeviceBuffer.from_numpy(loop)
-        cs.bind_inputs(False, d_o, 1); cs.bind_inputs(True, d_l, 2)
-        if not ok_form:      # the carried word would be seeded from an ungated output: the cone is not offered
-            with pytest.raises(zkgl.ZkError):
-                cs.seed_carried_inputs(d_l)
-            continue
-        cs.seed_carried_inputs(d_l)
-        seeded = d_l.to_numpy().reshape(loop.shape)
-        want = zko.CircuitRun(cs.export(False), cs.export(True), B, 1).seed(outer, loop)
-        assert np.array_equal(seeded, want)
-        ok, f = cs.resolve_and_check()
-        assert ok, f
+# (GPU test of the two circuits above: tests/test_zz_round5_gpu.py)

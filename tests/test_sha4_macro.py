@@ -94,43 +94,4 @@ def test_device_backend_walk_equals_the_oracle_restatement(tmp_path):
         assert [int(x, 16) for x in lines[2].split()] == final
 
 
-@pytest.mark.gpu
-def test_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
-    """whole trace of the macro recording against the oracle interpreter, both check modes; adversarial inputs rejected in both.  The op's device
-    backend is not part of the default library (never measured): there the device must refuse the recording loudly."""
-    cs = record(monkeypatch, True)
-    if not zkgl.build_features() & zkgl.BUILD_SHA4_KERNEL:
-        with pytest.raises(zkgl.ZkError) as e:
-            cs.set_batch(4)
-        assert "ZKGL_SHA4_KERNEL" in str(e.value)
-        return
-    rng = np.random.default_rng(45)
-    msgs = [bytes(rng.integers(0, 256, size=int(n), dtype=np.uint8)) for n in rng.integers(56, 120, size=70)]
-    outer = np.zeros((0, len(msgs)), dtype=np.uint64)
-    raw = loop_stream(msgs, 2)
-    loop = zko.CircuitRun(cs.export(False), cs.export(True), len(msgs), REF_TABLE_ROWS).seed(outer, raw)
-    r = zko.CircuitRun(cs.export(False), cs.export(True), len(msgs), REF_TABLE_ROWS)
-    r.resolve(outer, loop)
-    for strands in ("0", "1"):
-        monkeypatch.setenv("ZKGL_STRANDS", strands)
-        cs.set_batch(len(msgs))
-        d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
-        cs.bind_inputs(False, d_o, 0); cs.bind_inputs(True, d_l, raw.shape[0])
-        cs.seed_carried_inputs(d_l)
-        assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
-        for stored in (False, True):
-            cs.set_check_mode(stored)
-            ok, f = cs.resolve_and_check()
-            assert ok, (strands, stored, f)
-        for i, m in enumerate(msgs):
-            assert bytes(cs.public_inputs(i)) == hashlib.sha256(m).digest()
-        from test_gpu_cs import assert_trace_equal
-        assert_trace_equal(cs, r)
-        bad = loop.copy(); bad[40, 5] = 256                                   # a block byte that is not a byte: rejected in both modes
-        d_b = zk.DeviceBuffer.from_numpy(bad)
-        cs.bind_inputs(True, d_b, loop.shape[0])
-        for stored in (False, True):
-            cs.set_check_mode(stored)
-            ok, f = cs.resolve_and_check()
-            assert not ok
-    cs.set_check_mode(False)
+# (the device half of this file: tests/test_zz_round5_gpu.py)

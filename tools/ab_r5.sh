@@ -19,9 +19,9 @@ if [ -f $P/libzkgl_chains.so ]; then
 fi
 # ---- (3) K8: ByteBuffer macro-op, strand-form flag planes (keccak / sha256 / eip_4844 steps)
 if [ -f $P/libzkgl_k8.so ]; then
-  t bytebuf ZKGL_LIB=$P/libzkgl_k8.so timeout 600 python -m pytest tests/test_bytebuf_macro.py -m gpu -x -q
-  t splanes ZKGL_LIB=$P/libzkgl_k8.so ZKGL_STRAND_PLANES=1 timeout 1200 python -m pytest tests/test_gpu_cs.py tests/test_gpu_fsm_seed.py tests/test_queue_seed.py tests/test_fuzz_programs.py tests/test_fused_check.py tests/test_macro_ownership.py -m gpu -x -q
-  t both ZKGL_LIB=$P/libzkgl_k8.so ZKGL_STRAND_PLANES=1 ZKGL_BYTEBUF_MACRO=1 timeout 600 python -m pytest tests/test_bytebuf_macro.py -m gpu -x -q
+  t bytebuf ZKGL_LIB=$P/libzkgl_k8.so timeout 600 python -m pytest tests/test_zz_round5_gpu.py -m gpu -x -q -k bytebuf
+  t splanes ZKGL_LIB=$P/libzkgl_k8.so ZKGL_STRAND_PLANES=1 timeout 1200 python -m pytest tests/test_gpu_cs.py tests/test_gpu_fsm_seed.py tests/test_queue_seed.py tests/test_fuzz_programs.py tests/test_fused_check.py tests/test_zz_round5_gpu.py -m gpu -k "forged or sha4" -x -q
+  t both ZKGL_LIB=$P/libzkgl_k8.so ZKGL_STRAND_PLANES=1 ZKGL_BYTEBUF_MACRO=1 timeout 600 python -m pytest tests/test_zz_round5_gpu.py -m gpu -x -q -k bytebuf
   for v in "A=0" "ZKGL_LIB=$P/libzkgl_k8.so" "ZKGL_LIB=$P/libzkgl_k8.so ZKGL_BYTEBUF_MACRO=1" "ZKGL_LIB=$P/libzkgl_k8.so ZKGL_STRAND_PLANES=1" "ZKGL_LIB=$P/libzkgl_k8.so ZKGL_BYTEBUF_MACRO=1 ZKGL_STRAND_PLANES=1" "A=0"; do
     env $v CONFIGS=C3k,C3s,C5 timeout 500 python tests/config_timings.py 2>/dev/null | grep "^{" | python -c "
 import sys, json
@@ -31,8 +31,9 @@ for l in sys.stdin:
 fi
 # ---- (4) a16: the reference's SHA table set as a macro-op (ZK_OP_SHA256_ROUNDS a = 1): parity, then the C3 sha256 step under that table set
 if [ -f $P/libzkgl_sha4.so ]; then
-  t sha4 ZKGL_LIB=$P/libzkgl_sha4.so timeout 900 python -m pytest tests/test_sha4_macro.py -m gpu -x -q
-  t sha4_tables ZKGL_LIB=$P/libzkgl_sha4.so ZKGL_SHA4_MACRO=1 timeout 900 python -m pytest tests/test_sha256_reference_tables.py tests/test_macro_ownership.py -m gpu -x -q
+  t sha4 ZKGL_LIB=$P/libzkgl_sha4.so timeout 900 python -m pytest tests/test_zz_round5_gpu.py -m gpu -x -q -k sha4
+  t sha4_tables ZKGL_LIB=$P/libzkgl_sha4.so ZKGL_SHA4_MACRO=1 timeout 900 python -m pytest tests/test_sha256_reference_tables.py -m gpu -x -q
+  t sha4_forged ZKGL_LIB=$P/libzkgl_sha4.so ZKGL_SHA4_MACRO=1 timeout 900 python -m pytest tests/test_zz_round5_gpu.py -m gpu -k forged -x -q
   for v in "A=0" "ZKGL_LIB=$P/libzkgl_sha4.so ZKGL_SHA4_MACRO=1" "A=0" "ZKGL_LIB=$P/libzkgl_sha4.so ZKGL_SHA4_MACRO=1"; do
     env $v CONFIGS=C3s,C3s4 timeout 600 python tests/config_timings.py 2>/dev/null | grep "^{" | python -c "
 import sys, json
