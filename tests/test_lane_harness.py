@@ -1,0 +1,82 @@
+"""The lane harness (tests/emu/README.md): the product's witness-interpreter SOURCE (csrc/kernels_engine2.hpp run_tile2 and the macro-op backends, cut
+out unchanged) compiled for the host and run one lane at a time on the device programs of recorded circuits; every trace cell, the public inputs
+and the fused-mode failure flag against the oracle interpreter.  Plain and strand forms; the default library and every opt-in library of
+tools/variants_r5.sh (each with the harness built with the same switches) — the device paths round 5 could not run on a GPU.
+TEST INFRASTRUCTURE: it shows op semantics, program decoding, store addressing and the strand level structure, not wavefront behaviour;
+the -m gpu tests remain the parity gate."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "era-zkevm_circuits_amd")
+
+
+def run_cases(cases, variant="", defs="", env=None):
+    e = dict(os.environ)
+    for k in ("ZKGL_LIB", "ZKGL_SHA4_MACRO", "ZKGL_BYTEBUF_MACRO", "ZKGL_STRAND_PLANES", "ZKGL_SELECT_CHAINS", "ZKGL_STRANDS"):
+        e.pop(k, None)
+    if variant:
+        lib = os.path.join(PKG, f"libzkgl_{variant}.so")
+        if not os.path.exists(lib):
+            pytest.skip(f"{lib} is not built (tools/variants_r5.sh)")
+        e.update(ZKGL_LIB=lib, EMU_VARIANT=variant, EMU_DEFS=defs)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "run_case.py"), *cases], capture_output=True, text=True, env=e, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def all_equal(results, n):
+    assert len(results) == n, results
+    for r in results:
+        assert r["outer_equal"] and r["loop_equal"] and not r["fused_failure"] and r["oracle_violations"] == 0, r
+        assert r.get("public_equal", True), r
+
+
+def test_default_library_every_circuit_kind_plain_and_strands():
+    res = run_cases(["ram", "keccak", "sha", "sha4", "vm", "iszero"])
+    all_equal(res, 2 + 2 + 2 + 2 + 1 + 1)
+    assert all(r["features"] == 0 for r in res)
+    assert {(r["case"], r["strands"]) for r in res} >= {("keccak", True), ("sha", True), ("ram", True)}
+
+
+def test_fused_failure_flag_of_the_witness_kernels():
+    res = {r["case"]: r for r in run_cases(["adversarial"])}
+    assert not res["adversarial_clean"]["fused_failure"]
+    assert res["adversarial_not_a_byte"]["fused_failure"] and res["adversarial_not_a_byte"]["failing_lane"] == 1
+
+
+def test_batched_inversions_variant():
+    """-DZKGL_BATCH_INV: zero-checks of large operands deferred and inverted eight at a time (full batches, a tail, one that cannot be deferred)"""
+    res = run_cases(["iszero", "vm", "keccak"], "binv", "-DZKGL_BATCH_INV")
+    all_equal(res, 1 + 1 + 2)
+    assert all(r["features"] & 8 for r in res)
+
+
+def test_mux_chain_variant():
+    """-DZKGL_SELECT_CHAINS_KERNEL with ZKGL_SELECT_CHAINS=1: runs of SELECTs as chain ops, the running value in a register"""
+    res = run_cases(["vm"], "chains", "-DZKGL_SELECT_CHAINS_KERNEL", {"ZKGL_SELECT_CHAINS": "1"})
+    all_equal(res, 1)
+    assert res[0]["features"] & 4
+
+
+@pytest.mark.parametrize("env", [{"ZKGL_BYTEBUF_MACRO": "1"}, {"ZKGL_STRAND_PLANES": "1"}, {"ZKGL_BYTEBUF_MACRO": "1", "ZKGL_STRAND_PLANES": "1"}],
+                         ids=["bytebuf_macro", "strand_planes", "both"])
+def test_bytebuf_macro_and_strand_planes_variant(env):
+    """-DZKGL_BYTEBUF_KERNEL -DZKGL_STRAND_PLANES_KERNEL: ZK_OP_BYTEBUF_FILL (plain and cooperative strand form), SELECT flags from the tile's planes"""
+    res = run_cases(["keccak", "ram"], "k8", "-DZKGL_BYTEBUF_KERNEL -DZKGL_STRAND_PLANES_KERNEL", env)
+    all_equal(res, 4)
+    if "ZKGL_BYTEBUF_MACRO" in env:
+        plain_ops = run_cases(["keccak"])[0]["loop_ops"]
+        assert [r for r in res if r["case"] == "keccak"][0]["loop_ops"] < plain_ops - 40000      # six fills of ~7.7 k ops each are six ops
+
+
+def test_sha4_macro_variant():
+    """-DZKGL_SHA4_KERNEL with ZKGL_SHA4_MACRO=1: the reference's 4-bit-chunk compression as ONE op (26 088 outputs), plain and cooperative strand form"""
+    res = run_cases(["sha4", "sha"], "sha4", "-DZKGL_SHA4_KERNEL", {"ZKGL_SHA4_MACRO": "1"})
+    all_equal(res, 4)
+    assert [r for r in res if r["case"] == "sha4"][0]["loop_ops"] < 300 and all(r["features"] & 16 for r in res)
