@@ -186,6 +186,81 @@ extern "C" int zk_emu_resolve(zk_cs* h, const uint64_t* outer_in, const uint64_t
     }
 }
 
+// The checkers of the step on the stored values of the last zk_emu_resolve: the product's check kernels (k_check_prog, k_check_p2, k_check_links,
+// k_check_stream, k_check_inputs — the same cut-out source) run lane by lane.  mode 0: the FUSED step's check program (what is left to the
+// store: cprog_fused), mode 1: every relation (cprog + the Poseidon2 macro packets) = zk_cs_set_check_mode(ZK_CHECK_STORED).  fail_out: the
+// device's six failure words (outer 0..2, loop 3..5; ~0 = none), merged with the witness kernels' fused flags in mode 0.  Returns 1 when the
+// batch is rejected, 0 when it is accepted, -1 on error.
+extern "C" int zk_emu_check(zk_cs* h, int mode, unsigned long long* fail_out) {
+    try {
+        if (!g_last) throw std::runtime_error("zk_emu_check before zk_emu_resolve");
+        Run& r = *g_last;
+        CS& cs = r.cs;
+        unsigned long long f[16];
+        for (auto& x : f) x = ~0ull;
+        if (mode == 0) for (int i = 0; i < 6; ++i) f[i] = r.fail[i];
+        for (int sc = 0; sc < 2; ++sc) {
+            const Scope& s = sc ? cs.loop_ : cs.outer_;
+            if (sc && !cs.limit_) continue;
+            const uint32_t lanes = sc ? r.batch * r.limit : r.batch;
+            const std::vector<uint32_t>& prog = mode == 0 ? s.cprog_fused : s.cprog;
+            const std::vector<uint32_t>& chunks = mode == 0 ? s.cchunks_fused : s.cchunks;
+            if (prog.empty() || chunks.size() < 2) throw std::runtime_error("this scope has no check program (lookup tables wider than the packets): not covered by the harness");
+            std::vector<uint32_t> pp = padded(prog);
+            zke::CheckProgDev cd;
+            cd.cells = r.store[sc].data(); cd.n_cells = r.geom[sc]; cd.n_lanes = lanes;
+            cd.prog = pp.data(); cd.chunk_tab = chunks.data(); cd.n_chunks = (uint32_t)chunks.size() - 1; cd.chunks_per_block = cd.n_chunks;
+            cd.rowconsts = s.rowconsts.data(); cd.tables = cs.tdesc_host_.data(); cd.table_words = cs.table_words_host_.data();
+            cd.fail = f + 3 * sc;
+            emu::bdim = {(unsigned)zke::TPB, 1, 1};
+            for (uint32_t lane = 0; lane < lanes; ++lane) {
+                emu::bid = {lane / zke::TPB, 0, 0}; emu::tid = {lane % zke::TPB, 0, 0};
+                if (chunks.back() > chunks.front()) zke::k_check_prog(cd);
+            }
+            if (mode == 1 && !s.cmacros.empty()) {
+                std::vector<uint32_t> mm(s.cmacros);
+                mm.resize(mm.size() + 64, 0);
+                zke::CheckP2Dev md;
+                md.cells = r.store[sc].data(); md.n_cells = r.geom[sc]; md.n_lanes = lanes; md.macros = mm.data(); md.n_macros = (uint32_t)(s.cmacros.size() / 14);
+                md.per_block = md.n_macros; md.fail = f + 3 * sc;
+                for (uint32_t lane = 0; lane < lanes; ++lane) {
+                    emu::bid = {lane / zke::TPB, 0, 0}; emu::tid = {lane % zke::TPB, 0, 0};
+                    zke::k_check_p2(md);
+                }
+            }
+            if (r.in[sc] && s.n_input_words)
+                for (uint32_t lane = 0; lane < lanes; ++lane) {
+                    emu::bid = {lane / 256, 0, 0}; emu::tid = {lane % 256, 0, 0}; emu::bdim = {256, 1, 1}; emu::gdim = {1, 1, 1};
+                    zke::k_check_inputs(r.in[sc], s.n_input_words, lanes, r.in_stride[sc], f + 3 * sc);
+                }
+            emu::bdim = {(unsigned)zke::TPB, 1, 1};
+        }
+        if (cs.limit_) {
+            const uint32_t lanes = r.batch * r.limit;
+            emu::bdim = {(unsigned)zke::TPB, 1, 1};
+            for (uint32_t lane = 0; lane < lanes; ++lane) {
+                emu::bid = {lane / zke::TPB, 0, 0}; emu::tid = {lane % zke::TPB, 0, 0};
+                zke::k_check_links(r.store[1].data(), r.geom[1], lanes, r.limit, r.store[0].data(), r.geom[0], cs.links_store_.data(), (uint32_t)cs.links_store_.size(), f + 3);
+            }
+            for (size_t i = 0; i < cs.streams_store_.size(); ++i) {
+                const auto& sr = cs.streams_store_[i];
+                const uint64_t n = (uint64_t)r.batch * sr.n_total;
+                for (uint64_t t = 0; t < n; ++t) {
+                    emu::bid = {(unsigned)(t / zke::TPB), 0, 0}; emu::tid = {(unsigned)(t % zke::TPB), 0, 0};
+                    zke::k_check_stream(r.store[1].data(), r.geom[1], r.batch, r.limit, sr.a.data(), (uint32_t)sr.a.size(), sr.b.data(), (uint32_t)sr.b.size(), sr.n_total, (uint32_t)i, f + 3);
+                }
+            }
+        }
+        bool rejected = false;
+        for (int i = 0; i < 6; ++i) rejected |= f[i] != ~0ull;
+        if (fail_out) for (int i = 0; i < 6; ++i) fail_out[i] = f[i];
+        return rejected ? 1 : 0;
+    } catch (const std::exception& e) {
+        zkgl::set_last_error(std::string("zk_emu_check: ") + e.what());
+        return -1;
+    }
+}
+
 // debugging aid: after zk_emu_resolve (the run is kept), the first op of a scope, in program order, one of whose outputs differs from the expected
 // trace (same layout as the traces above) in lane `lane`: prints the op, its operand values and the outputs got / wanted to stderr; returns its index or -1
 extern "C" int zk_emu_first_bad_op(zk_cs* h, int loop_scope, const uint64_t* want_trace, uint64_t stride, uint32_t lane) {

@@ -52,6 +52,8 @@ typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __threadfence() std::atomic_thread_fence(std::memory_order_seq_cst)
 #define __clz(x) __builtin_clz(x)
 #define __popcll(x) __builtin_popcountll(x)
+template <class T> inline T min(T a, T b) { return b < a ? b : a; }
+template <class T> inline T max(T a, T b) { return a < b ? b : a; }
 inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 template <class T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 template <class T> inline T atomicSub(T* p, T v) { return __atomic_fetch_sub(p, v, __ATOMIC_RELAXED); }

@@ -46,3 +46,15 @@ def resolve(cs, outer: np.ndarray, loop: np.ndarray, batch: int, strands: bool =
     r.fail = [int(x) for x in fail]
     r.fused_failure = any(x != 0xFFFFFFFFFFFFFFFF for x in r.fail[:6])
     return r
+
+
+def check(cs, stored: bool, variant: str = ""):
+    """the step's checkers (the product's check-kernel source, lane by lane) on the stored values of the LAST resolve(): mode fused (what the fused
+    step leaves to the store, merged with the witness kernels' own failure flags) or stored (every relation) -> (accepted, failing lane or None)"""
+    L = lib(variant)
+    fail = (C.c_ulonglong * 6)()
+    rc = L.zk_emu_check(cs._h, C.c_int(1 if stored else 0), fail)
+    if rc < 0:
+        raise RuntimeError(zkgl.lib().zk_last_error().decode())
+    keys = [int(x) for x in fail if int(x) != 0xFFFFFFFFFFFFFFFF]
+    return rc == 0, (min(keys) >> 32) if keys else None

@@ -135,6 +135,57 @@ def case_adversarial():
                           "failing_lane": None if not r.fused_failure else int(min(v for v in r.fail[:6] if v != 0xFFFFFFFFFFFFFFFF) >> 32)}), flush=True)
 
 
+def case_verdicts():
+    """resolve_and_check's verdict, fused and stored, from the product's witness + check kernel source: an outsider's gate on a macro-op output (honest /
+    forged), adversarial inputs — against the oracle checker.  (VERDICT r4 'mirror by trust': the forged gate must be judged in the fused mode too.)"""
+    import test_macro_ownership as MO
+    rng = np.random.default_rng(13)
+    B = 5
+    empty = np.zeros((0, B), dtype=np.uint64)
+    for kind, make, n_in in (("keccak", MO.keccak_circuit, 200), ("sha256", MO.sha_circuit, 96), ("sha256_reference_tables", lambda e=None: MO.sha_circuit(e, True), 96)):
+        inp = rng.integers(0, 256, size=(n_in, B), dtype=np.uint64)
+        for extra_name, extra in (("honest", MO.honest), ("forged", MO.forged)):
+            cs = make(extra)
+            run = zko.CircuitRun(cs.export(False), cs.export(True), B, 1 << 20)
+            for mut_name, mut in (("clean", None), ("not_a_byte", (n_in // 2, 3, 1 << 40))):
+                x = inp.copy()
+                if mut:
+                    x[mut[0], mut[1]] = mut[2]
+                run.resolve(x, empty)
+                nbad, _ = run.check()
+                LH.resolve(cs, x, empty, B, strands=False, variant=VAR, defs=DEFS)
+                ok_f, lane_f = LH.check(cs, False, VAR)
+                ok_s, lane_s = LH.check(cs, True, VAR)
+                print(json.dumps({"case": f"verdict_{kind}_{extra_name}_{mut_name}", "oracle_accepts": nbad == 0, "fused_accepts": ok_f, "stored_accepts": ok_s,
+                                  "fused_lane": lane_f, "stored_lane": lane_s}), flush=True)
+
+
+def case_fuzz_verdicts():
+    """tests/test_fused_differential.py's programs (random mixes of exactly the constructs whose soundness rests on a non-mirrored gate) x adversarial
+    input vectors, case by case: verdict(fused step) == verdict(every relation from the store) == verdict(oracle checker) — the GPU test's
+    comparison, with the product's witness + check kernel SOURCE on the lane harness in place of the device"""
+    import test_fused_differential as FD
+    n_prog = int(os.environ.get("EMU_FUZZ_PROGRAMS", "6")); n_cases = int(os.environ.get("EMU_FUZZ_CASES", "60"))
+    total = agree = rejected = 0
+    for p in range(n_prog):
+        pr, outer, loop = FD.program_and_cases(p, n_cases)
+        cs = pr.cs
+        want = FD.oracle_verdicts(pr, outer, loop)
+        eo, el = cs.export(False), cs.export(True)
+        for c in range(n_cases):
+            oc = np.ascontiguousarray(outer[:, c:c + 1])
+            lo = np.ascontiguousarray(loop[:, c * pr.limit:(c + 1) * pr.limit]) if pr.limit else np.zeros((0, 1), dtype=np.uint64)
+            if pr.limit:
+                lo = zko.CircuitRun(eo, el, 1, 256).seed(oc, lo)
+            LH.resolve(cs, oc, lo, 1, strands=False, variant=VAR, defs=DEFS)
+            ok_f, _ = LH.check(cs, False, VAR)
+            ok_s, _ = LH.check(cs, True, VAR)
+            total += 1; agree += int(ok_f == ok_s == bool(want[c])); rejected += int(not want[c])
+            if not (ok_f == ok_s == bool(want[c])):
+                print(json.dumps({"case": "fuzz_disagreement", "program": p, "input": c, "oracle_accepts": bool(want[c]), "fused_accepts": ok_f, "stored_accepts": ok_s}), flush=True)
+    print(json.dumps({"case": "fuzz_verdicts", "programs": n_prog, "cases": total, "agree": agree, "oracle_rejects": rejected}), flush=True)
+
+
 if __name__ == "__main__":
     for c in sys.argv[1:]:
         globals()["case_" + c]()

@@ -80,3 +80,23 @@ def test_sha4_macro_variant():
     res = run_cases(["sha4", "sha"], "sha4", "-DZKGL_SHA4_KERNEL", {"ZKGL_SHA4_MACRO": "1"})
     all_equal(res, 4)
     assert [r for r in res if r["case"] == "sha4"][0]["loop_ops"] < 300 and all(r["features"] & 16 for r in res)
+
+
+def test_verdicts_of_the_step_fused_and_stored_equal_the_oracle_checker():
+    """resolve_and_check's verdict from the product's witness + check kernel source: an outsider's gate on a macro-op output — honest: accepted, forged:
+    REJECTED IN THE FUSED MODE TOO (VERDICT r4 'mirror by trust') — and a macro-op input that is not a byte, for Keccak-f and both SHA table sets"""
+    res = {r["case"]: r for r in run_cases(["verdicts"])}
+    assert len(res) == 12
+    for name, r in res.items():
+        assert r["fused_accepts"] == r["stored_accepts"] == r["oracle_accepts"], r
+        assert r["oracle_accepts"] == name.endswith("_honest_clean"), r
+        if "_honest_not_a_byte" in name:
+            assert r["fused_lane"] == r["stored_lane"] == 3, r
+
+
+def test_differential_fuzz_fused_equals_stored_equals_oracle_on_the_harness():
+    """tests/test_fused_differential.py's hazard programs x adversarial inputs, case by case (the GPU test's comparison; 12 programs x 100 inputs here)"""
+    res = run_cases(["fuzz_verdicts"], env={"EMU_FUZZ_PROGRAMS": "12", "EMU_FUZZ_CASES": "100"})
+    assert [r for r in res if r["case"] == "fuzz_disagreement"] == []
+    s = [r for r in res if r["case"] == "fuzz_verdicts"][0]
+    assert s["cases"] == s["agree"] == 1200 and 200 < s["oracle_rejects"] < 1000
