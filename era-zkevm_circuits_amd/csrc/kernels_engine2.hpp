@@ -335,20 +335,20 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     while (true) {
         if constexpr (BATCH_INV) {
             if (flush_now || (pc >= word_end && n_pend)) {
-                uint64_t x[NBI], pre[NBI];
-                uint32_t ao[NBI];
-#pragma unroll
-                for (uint32_t k = 0; k < NBI; ++k) {   // entries past n_pend repeat entry 0 (their stores are skipped)
-                    const uint32_t e = k < n_pend ? k : 0;
-                    const uint32_t xo = uni(inv_pend[2 * e]);
-                    ao[k] = uni(inv_pend[2 * e + 1]);
+                // registers: the eight prefix products only — an operand is loaded when it is used (forward pass) and loaded AGAIN for the
+                // back-substitution (an L2 hit; a flush happens ~10 times per wavefront, its latency hides behind the other wavefronts), so the
+                // batch holds 8 + 2 values instead of 16 + 2 (the interpreter loop lives at the 72-VGPR limit of 7 wavefronts per SIMD)
+                uint64_t pre[NBI];
+                auto pend_x = [&](uint32_t k) -> uint64_t {   // entries past n_pend repeat entry 0 (their stores are skipped)
+                    const uint32_t xo = uni(inv_pend[2 * (k < n_pend ? k : 0)]);
                     u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, xo, 0);
-                    x[k] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-                }
+                    return (uint64_t)v.x | ((uint64_t)v.y << 32);
+                };
                 uint64_t acc = 1;
 #pragma unroll
                 for (uint32_t k = 0; k < NBI; ++k) {
-                    const uint64_t nz = (k < n_pend && x[k]) ? x[k] : 1ull;
+                    const uint64_t x = pend_x(k);
+                    const uint64_t nz = (k < n_pend && x) ? x : 1ull;
                     pre[k] = acc;
                     acc = gl::mul(acc, nz);
                 }
@@ -356,14 +356,15 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
                 for (uint32_t kk = 0; kk < NBI; ++kk) {
                     const uint32_t k = NBI - 1 - kk;
-                    const uint64_t nz = (k < n_pend && x[k]) ? x[k] : 1ull;
-                    const uint64_t r = gl::mul(ia, pre[k]);
-                    ia = gl::mul(ia, nz);
-                    if (k < n_pend) {
-                        const uint64_t o64 = x[k] ? r : 0ull;
+                    if (k < n_pend) {   // uniform
+                        const uint64_t x = pend_x(k);
+                        const uint64_t nz = x ? x : 1ull;
+                        const uint64_t r = gl::mul(ia, pre[k]);
+                        ia = gl::mul(ia, nz);
+                        const uint64_t o64 = x ? r : 0ull;
                         u32x2 o;
                         o.x = (uint32_t)o64; o.y = (uint32_t)(o64 >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, ao[k], 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, uni(inv_pend[2 * k + 1]), 0);
                     }
                 }
                 n_pend = 0;

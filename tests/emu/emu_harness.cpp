@@ -289,6 +289,33 @@ extern "C" int zk_emu_first_bad_op(zk_cs* h, int loop_scope, const uint64_t* wan
     return -1;
 }
 
+// statistics aid (DESIGN: what the batched inversions can gain): over the loop scope of the last zk_emu_resolve, per 64-lane wavefront, how many of the
+// ZK_OP_ISZERO ops leave the small-inverse table (some lane holds |x| >= INV_SMALL_N: the whole wavefront runs the 72-multiplication chain).
+// out[0] = zero-check ops per lane, out[1] = wavefronts, out[2] = sum over wavefronts of the ops that take the chain, out[3] = the same per LANE (a lane
+// alone: what a one-lane wavefront would do)
+extern "C" int zk_emu_iszero_stats(zk_cs* h, uint64_t out[4]) {
+    if (!g_last) return -1;
+    Run& r = *g_last;
+    const Scope& s = r.cs.loop_;
+    const uint64_t lanes = (uint64_t)r.batch * r.limit;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    out[1] = (lanes + 63) / 64;
+    for (auto& op : s.ops) {
+        if (op.seed_only || op.opcode != ZK_OP_ISZERO || op.ins[0].kind != zkgl::Operand::VAR) continue;
+        ++out[0];
+        for (uint64_t w0 = 0; w0 < lanes; w0 += 64) {
+            bool slow = false;
+            for (uint64_t l = w0; l < std::min(lanes, w0 + 64); ++l) {
+                const uint64_t x = r.store[1][zkgeom::offset(r.geom[1], s.var_slot[op.ins[0].idx], l)];
+                const bool big = x >= p2::INV_SMALL_N && gl::P - x >= p2::INV_SMALL_N;
+                slow |= big; out[3] += big;
+            }
+            out[2] += slow;
+        }
+    }
+    return 0;
+}
+
 extern "C" void zk_emu_sizes(zk_cs* h, uint32_t batch, uint64_t out[6]) {   // outer n_cells, outer stride, loop n_cells, loop stride, n_public, total_table_rows
     CS& cs = *zkgl::cs_of(h);
     out[0] = cs.outer_.n_cells; out[1] = ((uint64_t)batch + 63) / 64 * 64;
