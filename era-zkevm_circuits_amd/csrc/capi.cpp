@@ -104,6 +104,9 @@ uint32_t zk_build_features(void) {
 #ifdef ZKGL_SHA4_KERNEL
     f |= ZK_BUILD_SHA4_KERNEL;
 #endif
+#ifdef ZKGL_P2_MERGE
+    f |= ZK_BUILD_P2_MERGE;
+#endif
     return f;
 }
 

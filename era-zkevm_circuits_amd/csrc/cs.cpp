@@ -1122,6 +1122,68 @@ void CS::schedule_loop_ops() {
 // of 8 / 12 chains and every link reads the previous one back from the store.  This pass transposes every run of consecutive SELECTs
 // whose flags and `a` operands all come from before the run: the links of one chain become consecutive ops (any topological order
 // fills the same cells), which is what the chain form of the device program needs (emit_scope: one op per chain, `r` in a register).
+// Variant build (-DZKGL_P2_MERGE).  The execute-gated witness-only permutations of a loop body form a few dependency LEVELS (main_vm: 18
+// of them in 5: a level = the longest chain of gated permutations a site depends on, through any path of ops); the members of a level cannot
+// depend on each other, so they may sit next to each other in the program — where emit_scope puts them under one header (group cap 5) and the
+// kernel runs one permutation per round for the whole level.  This pass re-orders the scheduled ops so that they do: a list pass in the
+// current order in which a gated permutation is emitted only together with every other member of its level (bundles of <= 5 in order).
+void CS::bundle_gated_permutations() {
+#ifdef ZKGL_P2_MERGE
+    Scope& s = loop_;
+    if (!limit_ || s.ops.empty()) return;
+    const size_t n = s.ops.size();
+    std::vector<int> vlvl(s.n_vars, 0), bundle(n, -1);
+    std::vector<int64_t> producer(s.n_vars, -1);
+    std::map<int, std::vector<size_t>> by_level;
+    for (size_t oi = 0; oi < n; ++oi) {
+        const OpRec& op = s.ops[oi];
+        int in = 0;
+        for (auto& x : op.ins) if (x.kind == Operand::VAR) in = std::max(in, vlvl[x.idx]);
+        const bool gated = !op.seed_only && op.opcode == ZK_OP_POSEIDON2 && op.a == 1;
+        if (op.seed_only) continue;   // (a hint is a second producer of values the trace ops produce: it does not define levels)
+        for (uint32_t ov : op.outs) { vlvl[ov] = gated ? in + 1 : in; producer[ov] = (int64_t)oi; }
+        if (gated) by_level[in + 1].push_back(oi);
+    }
+    std::vector<std::vector<size_t>> bundles;
+    for (auto& kv : by_level)
+        for (size_t at = 0; at < kv.second.size(); at += 5) {
+            bundles.emplace_back(kv.second.begin() + at, kv.second.begin() + std::min(kv.second.size(), at + 5));
+            for (size_t oi : bundles.back()) bundle[oi] = (int)bundles.size() - 1;
+        }
+    if (bundles.empty()) return;
+    std::vector<uint8_t> done(n, 0);
+    auto ready = [&](size_t oi) {
+        for (auto& x : s.ops[oi].ins) if (x.kind == Operand::VAR && producer[x.idx] >= 0 && !done[(size_t)producer[x.idx]] && (size_t)producer[x.idx] != oi) return false;
+        return true;
+    };
+    std::vector<size_t> order;
+    order.reserve(n);
+    size_t head = 0;
+    while (order.size() < n) {
+        while (head < n && done[head]) ++head;
+        bool progressed = false;
+        for (size_t oi = head; oi < n; ++oi) {
+            if (done[oi] || !ready(oi)) continue;
+            if (bundle[oi] >= 0) {
+                const auto& b = bundles[(size_t)bundle[oi]];
+                bool all = true;
+                for (size_t m : b) all = all && ready(m);
+                if (!all) continue;
+                for (size_t m : b) { done[m] = 1; order.push_back(m); }
+            } else { done[oi] = 1; order.push_back(oi); }
+            progressed = true;
+            break;
+        }
+        if (!progressed) return;   // cannot happen (levels are antichains); leave the schedule as it is
+    }
+    std::vector<OpRec> out;
+    out.reserve(n);
+    for (size_t oi : order) out.push_back(std::move(s.ops[oi]));
+    s.ops = std::move(out);
+    if (getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] bundle_gated_permutations: %zu gated permutations in %zu levels, %zu bundles\n", [&] { size_t c = 0; for (auto& b : bundles) c += b.size(); return c; }(), by_level.size(), bundles.size());
+#endif
+}
+
 void CS::chain_selects() {
     const char* e = std::getenv("ZKGL_SELECT_CHAINS");   // 1: transpose (and, in a -DZKGL_SELECT_CHAINS_KERNEL build, emit chain ops); the order alone is valid everywhere
     Scope& s = loop_;
@@ -1538,6 +1600,8 @@ void CS::verify_device_programs(const Scope& s) const {
         uint32_t N = 1;
         bool grouped_lookup = false;
         if (opc == ZK_OP_INPUT || opc == ZK_OP_SELECT || opc == ZK_OP_FMA || opc == ZK_OP_U32MULADD) N = pb + 1;
+        const bool merged_p2 = opc == ZK_OP_POSEIDON2 && pa == 2;   // -DZKGL_P2_MERGE builds: <= 5 gated permutations under one header (plain form only)
+        if (merged_p2) { N = pb + 1; if (D || N < 2 || N > 5) fail("merged gated permutations: 2..5 members, plain form only", pc); }
         if (opc == ZK_OP_LOOKUP) { const uint32_t nv = pb & 0xff; grouped_lookup = pa <= 2 && nv <= 2; N = grouped_lookup ? (pb >> 8) + 1 : 1; if (!grouped_lookup && (pb >> 8)) fail("wide lookup with members", pc); }
         const size_t first_operand = pc + 1 + (opc == ZK_OP_LOOKUP ? 1 : 0);
         size_t K = SIZE_MAX, at = first_operand;
@@ -1564,8 +1628,9 @@ void CS::verify_device_programs(const Scope& s) const {
             if (K == SIZE_MAX) fail("opcode without a kernel layout", pc);
             if (opc == ZK_OP_LOOKUP && prog[pc + 1] != op.ins[0].idx) fail("lookup table id", pc);
             const bool counted = opc == ZK_OP_INPUT || opc == ZK_OP_SELECT || opc == ZK_OP_FMA || opc == ZK_OP_U32MULADD || opc == ZK_OP_LC4 || opc == ZK_OP_LOOKUP;
-            if (!(opc == ZK_OP_SELECT && pa == 1) && pa != op.a) fail("header a", pc);
-            if (!counted && pb != op.b) fail("header b", pc);
+            if (merged_p2) { if (op.a != 1) fail("merged gated permutations: a member is not gated", pc); }
+            else if (!(opc == ZK_OP_SELECT && pa == 1) && pa != op.a) fail("header a", pc);
+            if (!counted && !merged_p2 && pb != op.b) fail("header b", pc);
             if (opc == ZK_OP_LOOKUP && (pb & 0xff) != op.b) fail("lookup n_vals", pc);
             if (opc == ZK_OP_SELECT && pa == 1) {   // plane form: [plane id, a, b]
                 if (plane_all[op.ins[0].idx] == UINT32_MAX || prog[at] != plane_all[op.ins[0].idx]) fail("plane SELECT: plane id", pc);
@@ -1750,6 +1815,12 @@ void CS::emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool co
         }
         return;
     }
+    if (first.opcode == ZK_OP_POSEIDON2) {   // one gated permutation: a = 1 (b = 0); several (a -DZKGL_P2_MERGE build): a = 2, b = members - 1
+        out.push_back((uint32_t)ZK_OP_POSEIDON2 | ((n > 1 ? 2u : (uint32_t)first.a) << 8) | ((uint32_t)(n - 1) << 16));
+        for (size_t oi : group)
+            for (size_t q = 0; q < s.ops[oi].ins.size(); ++q) operand_v2(s, s.ops[oi], q, out);
+        return;
+    }
     out.push_back((uint32_t)first.opcode | ((uint32_t)first.a << 8) | ((counted ? (uint32_t)(n - 1) : (uint32_t)first.b) << 16));
     if (first.opcode == ZK_OP_NN_MULMOD) {
         // fixed layout: 16 modulus limbs, 17 A slots, 17 B slots (unused ones 0): static word positions for the kernel's scalar fetches
@@ -1780,6 +1851,9 @@ static uint32_t group_cap(const OpRec& op, bool v2) {
     case ZK_OP_LC4: return v2 ? 1 : 2;
     case ZK_OP_U32MULADD: return v2 ? 3 : 1;
     case ZK_OP_LOOKUP: return (op.a <= 2 && op.b <= 2) ? 4 : 1;
+#ifdef ZKGL_P2_MERGE   // variant build: gated witness-only permutations of one dependency level under one header (kernels_engine2.hpp)
+    case ZK_OP_POSEIDON2: return (v2 && op.a == 1) ? 5 : 1;
+#endif
     default: return 1;
     }
 }
@@ -1894,6 +1968,7 @@ void CS::emit_scope(Scope& s) {
                 const OpRec& f = s.ops[group[0]];
                 joins = f.a == op.a && f.b == op.b && f.ins[0].idx == op.ins[0].idx;
             }
+            if (joins && op.opcode == ZK_OP_POSEIDON2) joins = s.is_loop && s.ops[group[0]].a == 1 && op.a == 1;   // (merged form: loop scope, gated members only)
             if (joins)
                 for (auto& in : op.ins)
                     if (in.kind == Operand::VAR && produced_in_group[in.idx] == group_id) { joins = false; break; }
@@ -2569,6 +2644,7 @@ void CS::finalize() {
     loop_ops_recorded_ = loop_.ops;
     schedule_loop_ops();
     chain_selects();
+    bundle_gated_permutations();
     assign_store_slots(outer_);
     assign_store_slots(loop_);
     emit_scope(outer_);

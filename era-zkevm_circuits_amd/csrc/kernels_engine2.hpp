@@ -730,11 +730,42 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             const bool deferred = (op == ZK_OP_P2_ROUNDS) && sc.defer_p2 != 0;
             const bool emit = (op == ZK_OP_P2_ROUNDS) && !deferred;
             uint64_t s[12];
+#ifdef ZKGL_P2_MERGE
+            // MERGED gated form (pa = 2; plain kernels; variant build): n = pb + 1 <= 5 mutually independent gated witness-only permutations
+            // under ONE header — [12 state slots, flag slot] x n -> 12 x n outputs.  A cycle runs one opcode, so a LANE has at most one or two
+            // of a level's permutations on, while a WAVEFRONT of 64 different cycles has nearly all of them on somewhere: 15 of main_vm's 18
+            // gated permutations ran per wavefront where the lanes needed 0.83 each (profiles/r5_iszero_stats.json).  Here every lane picks ITS
+            // next member that is on, the wavefront runs ONE permutation on the picked states, each lane stores to its member's outputs; lanes
+            // with a second member on take another round.  Zeros everywhere else, as before.
+            uint32_t mrg_n = 0, mrg_pending = 0, mrg_base = 0, mrg_pc = 0;
+            int mrg_me = -1;
+            const bool merged = !STRANDS && !WIDE && (op == ZK_OP_POSEIDON2) && pa == 2;
+            if (merged) {
+                mrg_n = pb + 1; mrg_pc = pc; mrg_base = dst;
+#pragma unroll
+                for (uint32_t g = 0; g < 5; ++g)
+                    if (g < mrg_n) mrg_pending |= (ldv(prog[pc + 1 + g * 13 + 12]) != 0 ? 1u : 0u) << g;
+                pc += 1 + 13 * mrg_n;
+                for (uint32_t q = 0; q < 12 * mrg_n; ++q) st(0ull);   // every output is 0 until a lane's round says otherwise
+                const uint64_t any = __builtin_amdgcn_ballot_w64(mrg_pending != 0);
+#ifndef ZKGL_PLANE_STATS
+                if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats, (unsigned long long)mrg_n);   // (sites; the rounds run are added below)
+#endif
+                if (any == 0) break;
+            } else {
+#endif
 #pragma unroll
             for (int i = 0; i < 12; ++i) s[i] = ldv(W[1 + i]);
+#ifdef ZKGL_P2_MERGE
+            }
+#endif
             // gated form (pa = 1, witness-only): [.., execute] -> zeros where the flag is off (simulate_round_function(cs, state, execute));
             // a wavefront whose 64 cycles all have it off skips the permutation altogether
+#ifdef ZKGL_P2_MERGE
+            const bool gated = (op == ZK_OP_POSEIDON2) && pa == 1;
+#else
             const bool gated = (op == ZK_OP_POSEIDON2) && pa != 0;
+#endif
             bool lane_off = false;
             if (gated) {
                 lane_off = ldv(W[13]) == 0;
@@ -749,11 +780,33 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                     for (int i = 0; i < 12; ++i) st(0ull);
                     break;
                 }
-            } else {
+            }
+#ifdef ZKGL_P2_MERGE
+            else if (merged) { /* pc and dst are set */ }
+#endif
+            else {
                 out_to(W[13]);
                 pc += 13 + D;
             }
             if (deferred) dst += WIDE ? 950u : 950u * bstep;
+#ifdef ZKGL_P2_MERGE
+            for (;;) {   // one trip, or (merged form) one per round
+            if (merged) {
+                mrg_me = mrg_pending ? (int)__builtin_ctz(mrg_pending) : -1;
+                lane_off = mrg_me < 0;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) s[i] = 0;
+#pragma unroll 1
+                for (uint32_t g = 0; g < mrg_n; ++g) {
+                    if (__builtin_amdgcn_ballot_w64(mrg_me == (int)g) == 0) continue;   // uniform: nobody picked this member this round
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) { const uint64_t v = ldv(prog[mrg_pc + 1 + g * 13 + i]); s[i] = mrg_me == (int)g ? v : s[i]; }
+                }
+#ifndef ZKGL_PLANE_STATS
+                if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats + 1, 1ull);
+#endif
+            }
+#endif
             p2::mds_external(s);
             if constexpr (P2_IN_REGISTERS) {
                 // state in registers, the twelve S-boxes of a full round unrolled, ONE copy of the full-round body (12 KB of code: the
@@ -808,6 +861,20 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                         }
                     }
                 }
+#ifdef ZKGL_P2_MERGE
+                if (merged) {
+                    if (mrg_me >= 0) {   // this lane's member: its 12 outputs, at the member's place in the op's output run
+                        const uint32_t vo = lane_byte + (uint32_t)mrg_me * 12u * bstep;
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) {
+                            u32x2 o;
+                            o.x = (uint32_t)s[i]; o.y = (uint32_t)(s[i] >> 32);
+                            __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, vo, mrg_base + (uint32_t)i * bstep, 0);
+                        }
+                        mrg_pending &= mrg_pending - 1;
+                    }
+                } else
+#endif
                 if (!emit) {
 #pragma unroll
                     for (int i = 0; i < 12; ++i) st(lane_off ? 0ull : s[i]);
@@ -849,6 +916,10 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 for (int i = 0; i < 12; ++i) st(lane_off ? 0ull : s[i]);
             }
             }
+#ifdef ZKGL_P2_MERGE
+            if (!merged || __builtin_amdgcn_ballot_w64(mrg_pending != 0) == 0) break;
+            }   // for (;;)
+#endif
         } break;
         case ZK_OP_LOOP_LAST: {
             const uint32_t c = W[1];

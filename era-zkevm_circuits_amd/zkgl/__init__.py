@@ -125,7 +125,7 @@ def poseidon_round_constants() -> np.ndarray:
     return out
 
 
-BUILD_BYTEBUF_KERNEL, BUILD_STRAND_PLANES_KERNEL, BUILD_SELECT_CHAINS_KERNEL, BUILD_BATCH_INV, BUILD_SHA4_KERNEL = 1, 2, 4, 8, 16
+BUILD_BYTEBUF_KERNEL, BUILD_STRAND_PLANES_KERNEL, BUILD_SELECT_CHAINS_KERNEL, BUILD_BATCH_INV, BUILD_SHA4_KERNEL, BUILD_P2_MERGE = 1, 2, 4, 8, 16, 32
 
 
 def build_features() -> int:

@@ -48,6 +48,7 @@ const char *zk_last_error(void);
 #define ZK_BUILD_SELECT_CHAINS_KERNEL 4u  /* mux-chain ops (ZKGL_SELECT_CHAINS=1) */
 #define ZK_BUILD_BATCH_INV 8u             /* Montgomery-batched zero-check inversions in the plain loop kernels */
 #define ZK_BUILD_SHA4_KERNEL 16u          /* ZK_OP_SHA256_ROUNDS a = 1 on the device: the reference's 4-bit-chunk SHA tables as a macro-op (ZKGL_SHA4_MACRO=1 recordings) */
+#define ZK_BUILD_P2_MERGE 32u             /* the gated witness-only permutations of a dependency level under one header: one permutation per round per wavefront */
 uint32_t zk_build_features(void);
 /* Select the device, upload Poseidon2 constants.  Fails loudly (ZK_ERR_HIP) without a GPU.  One device per process: a second
  * call with another device index is ZK_ERR_INVALID (process-wide device tables are bound to the first). */

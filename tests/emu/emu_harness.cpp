@@ -316,6 +316,83 @@ extern "C" int zk_emu_iszero_stats(zk_cs* h, uint64_t out[4]) {
     return 0;
 }
 
+// the same for the execute-gated witness-only permutations (ZK_OP_POSEIDON2 a = 1: a wavefront runs the permutation as soon as ONE of its lanes has
+// the flag on).  out[0] = gated ops per lane, out[1] = wavefronts, out[2] = sum over wavefronts of the ops it runs, out[3] = sum over lanes of the ops
+// whose flag is on (what the lanes actually need)
+extern "C" int zk_emu_gated_p2_stats(zk_cs* h, uint64_t out[4]) {
+    if (!g_last) return -1;
+    Run& r = *g_last;
+    const Scope& s = r.cs.loop_;
+    const uint64_t lanes = (uint64_t)r.batch * r.limit;
+    out[0] = out[2] = out[3] = 0;
+    out[1] = (lanes + 63) / 64;
+    for (auto& op : s.ops) {
+        if (op.seed_only || op.opcode != ZK_OP_POSEIDON2 || op.a != 1 || op.ins.size() != 13) continue;
+        ++out[0];
+        for (uint64_t w0 = 0; w0 < lanes; w0 += 64) {
+            bool any = false;
+            for (uint64_t l = w0; l < std::min(lanes, w0 + 64); ++l) {
+                const bool on = r.store[1][zkgeom::offset(r.geom[1], s.var_slot[op.ins[12].idx], l)] != 0;
+                any |= on; out[3] += on;
+            }
+            out[2] += any;
+        }
+    }
+    return 0;
+}
+
+// ... and what merging the gated permutations of a dependency level would leave: per wavefront and level, the rounds = the largest number of members
+// any ONE lane has on.  out[0] = levels, out[1] = wavefronts, out[2] = sum over wavefronts of the rounds (the permutations a merged kernel runs)
+extern "C" int zk_emu_gated_p2_merged_rounds(zk_cs* h, uint64_t out[3]) {
+    if (!g_last) return -1;
+    Run& r = *g_last;
+    const Scope& s = r.cs.loop_;
+    const uint64_t lanes = (uint64_t)r.batch * r.limit;
+    std::vector<int> vlvl(s.n_vars, 0);
+    std::map<int, std::vector<uint32_t>> flags_of_level;
+    for (auto& op : s.ops) {
+        if (op.seed_only) continue;
+        int in = 0;
+        for (auto& x : op.ins) if (x.kind == zkgl::Operand::VAR) in = std::max(in, vlvl[x.idx]);
+        const bool gated = op.opcode == ZK_OP_POSEIDON2 && op.a == 1;
+        for (uint32_t ov : op.outs) vlvl[ov] = gated ? in + 1 : in;
+        if (gated) flags_of_level[in + 1].push_back(op.ins[12].idx);
+    }
+    out[0] = flags_of_level.size(); out[1] = (lanes + 63) / 64; out[2] = 0;
+    for (auto& kv : flags_of_level)
+        for (uint64_t w0 = 0; w0 < lanes; w0 += 64) {
+            uint32_t rounds = 0;
+            for (uint64_t l = w0; l < std::min(lanes, w0 + 64); ++l) {
+                uint32_t on = 0;
+                for (uint32_t fv : kv.second) on += r.store[1][zkgeom::offset(r.geom[1], s.var_slot[fv], l)] != 0;
+                rounds = std::max(rounds, on);
+            }
+            out[2] += rounds;
+        }
+    return 0;
+}
+
+// analysis aid: the dependency levels of the gated witness-only permutations of the loop scope (level = the longest chain of gated permutations a site
+// depends on, through any path of ops).  Prints one line per site to stderr; returns the number of levels.
+extern "C" int zk_emu_gated_p2_levels(zk_cs* h) {
+    CS& cs = *zkgl::cs_of(h);
+    const Scope& s = cs.loop_;
+    const auto& ops = cs.loop_ops_recorded_.empty() ? s.ops : cs.loop_ops_recorded_;   // recording order
+    std::vector<int> lvl(s.n_vars, 0);   // per variable: the number of gated permutations on the longest path that produces it
+    int n_levels = 0, site = 0;
+    for (size_t oi = 0; oi < ops.size(); ++oi) {
+        const zkgl::OpRec& op = ops[oi];
+        if (op.seed_only) continue;
+        int in = 0;
+        for (auto& x : op.ins) if (x.kind == zkgl::Operand::VAR) in = std::max(in, lvl[x.idx]);
+        const bool gated = op.opcode == ZK_OP_POSEIDON2 && op.a == 1;
+        const int out = gated ? in + 1 : in;
+        for (uint32_t ov : op.outs) lvl[ov] = out;
+        if (gated) { fprintf(stderr, "[emu] gated permutation %2d (op %zu of %zu): level %d, flag var %u\n", site++, oi, ops.size(), out, op.ins[12].idx); n_levels = std::max(n_levels, out); }
+    }
+    return n_levels;
+}
+
 extern "C" void zk_emu_sizes(zk_cs* h, uint32_t batch, uint64_t out[6]) {   // outer n_cells, outer stride, loop n_cells, loop stride, n_public, total_table_rows
     CS& cs = *zkgl::cs_of(h);
     out[0] = cs.outer_.n_cells; out[1] = ((uint64_t)batch + 63) / 64 * 64;

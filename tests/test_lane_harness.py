@@ -57,6 +57,13 @@ def test_batched_inversions_variant():
     assert all(r["features"] & 8 for r in res)
 
 
+def test_merged_gated_permutations_variant():
+    """-DZKGL_P2_MERGE: the execute-gated witness-only permutations of a dependency level under one header (main_vm: 18 in 5), one permutation per round"""
+    res = run_cases(["vm", "ram"], "p2m", "-DZKGL_P2_MERGE")
+    all_equal(res, 1 + 2)
+    assert all(r["features"] & 32 for r in res)
+
+
 def test_mux_chain_variant():
     """-DZKGL_SELECT_CHAINS_KERNEL with ZKGL_SELECT_CHAINS=1: runs of SELECTs as chain ops, the running value in a register"""
     res = run_cases(["vm"], "chains", "-DZKGL_SELECT_CHAINS_KERNEL", {"ZKGL_SELECT_CHAINS": "1"})

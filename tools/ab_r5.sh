@@ -12,6 +12,13 @@ if [ -f $P/libzkgl_binv.so ]; then
   t binv ZKGL_LIB=$P/libzkgl_binv.so timeout 1200 python -m pytest tests/test_gpu_main_vm.py tests/test_fused_check.py tests/test_fuzz_programs.py tests/test_gpu_cs.py -m gpu -x -q
   vm product A=0; vm binv ZKGL_LIB=$P/libzkgl_binv.so; vm product A=0; vm binv ZKGL_LIB=$P/libzkgl_binv.so
 fi
+# ---- (1b) merged gated permutations (profiles/r5_iszero_stats.json: 15.0 -> 7.9 permutations per wavefront on the default fixture), alone and with (1)
+for v in p2m p2m_binv; do
+  if [ -f $P/libzkgl_$v.so ]; then
+    t $v ZKGL_LIB=$P/libzkgl_$v.so timeout 1200 python -m pytest tests/test_gpu_main_vm.py tests/test_gpu_full_size.py tests/test_fused_check.py tests/test_fuzz_programs.py -m gpu -x -q
+    vm product A=0; vm $v ZKGL_LIB=$P/libzkgl_$v.so; vm product A=0; vm $v ZKGL_LIB=$P/libzkgl_$v.so
+  fi
+done
 # ---- (2) mux chains
 if [ -f $P/libzkgl_chains.so ]; then
   t chains ZKGL_LIB=$P/libzkgl_chains.so ZKGL_SELECT_CHAINS=1 timeout 900 python -m pytest tests/test_gpu_main_vm.py tests/test_fused_check.py tests/test_fuzz_programs.py -m gpu -x -q

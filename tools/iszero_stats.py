@@ -16,13 +16,21 @@ for name, path in bench.FIXTURES.items():
     outer, loop, expect = bench.main_vm_streams(zkgl, cs, limit, 2, fixture=path)
     t = time.time()
     seeded = zko.CircuitRun(cs.export(False), cs.export(True), 2, rows).seed(outer, loop)
-    r = LH.resolve(cs, outer, seeded, 2)
+    r = LH.resolve(cs, outer, seeded, 2, variant=os.environ.get('EMU_VARIANT', ''), defs=os.environ.get('EMU_DEFS', '').split())
     st = (C.c_uint64 * 4)()
-    LH.lib().zk_emu_iszero_stats(cs._h, st)
-    out[name] = {"instances": 2, "wavefronts": int(st[1]), "zero_checks_per_cycle": int(st[0]),
+    LH.lib(os.environ.get('EMU_VARIANT', '')).zk_emu_iszero_stats(cs._h, st)
+    gp = (C.c_uint64 * 4)()
+    LH.lib(os.environ.get('EMU_VARIANT', '')).zk_emu_gated_p2_stats(cs._h, gp)
+    mr = (C.c_uint64 * 3)()
+    LH.lib(os.environ.get('EMU_VARIANT', '')).zk_emu_gated_p2_merged_rounds(cs._h, mr)
+    out[name] = {"instances": 2, "gated_permutation_levels": int(mr[0]), "permutations_a_level_merged_kernel_runs_per_wavefront": round(mr[2] / mr[1], 2),
+                 "gated_witness_only_permutations_per_cycle": int(gp[0]), "gated_permutations_run_per_wavefront": round(gp[2] / gp[1], 2),
+                 "gated_permutations_needed_per_lane": round(gp[3] / (2 * limit), 3), "wavefronts": int(st[1]), "zero_checks_per_cycle": int(st[0]),
                  "zero_checks_taking_the_chain_per_wavefront": round(st[2] / st[1], 2), "per_lane_alone": round(st[3] / (2 * limit), 2),
                  "commitments_equal_fixture": bool(expect is not None and [int(x) for x in r.public[0]] == [int(x) for x in expect[0]]),
                  "fused_failure": r.fused_failure, "seconds": round(time.time() - t, 1)}
-out["reading"] = ("a wavefront runs the 72-multiplication x^(p-2) chain for a zero-check as soon as ONE of its 64 lanes holds |x| >= 4096; -DZKGL_BATCH_INV replaces k such "
+out["reading"] = ("gated permutations: a wavefront runs a witness-only permutation as soon as ONE of its 64 lanes (consecutive cycles, different opcodes) has its execute flag on; "
+                  "-DZKGL_P2_MERGE puts the mutually independent permutations of a dependency level under one header and runs one permutation per round (a round = every lane's next member that is on).  "
+                  "Zero-checks: a wavefront runs the 72-multiplication x^(p-2) chain for a zero-check as soon as ONE of its 64 lanes holds |x| >= 4096; -DZKGL_BATCH_INV replaces k such "
                   "chains by one chain + 3 k multiplications, eight at a time")
 print(json.dumps(out, indent=1))
