@@ -317,6 +317,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     constexpr uint32_t D = STRANDS ? 1 : 0;  // destination words per op
     auto out_to = [&](uint32_t slot) { if constexpr (STRANDS) dst = WIDE ? slot : slot << bsh; };
     uint32_t pc = word_begin;
+#ifdef ZKGL_P2_MERGE
+    uint32_t mrg_round = 0;   // uniform: the round of the merged gated-permutation op being executed (0 between such ops)
+#endif
     uint32_t nonbool_seen = 0;   // uniform: some flag copied into a plane held a value > 1 in some lane (never, on a satisfiable witness)
     bool fused_bad = false;   // fused mode: a gate evaluated here (SELECT's exception, a lookup miss) is violated; reported once, below
 #ifdef ZKGL_BATCH_INV
@@ -734,24 +737,53 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             // MERGED gated form (pa = 2; plain kernels; variant build): n = pb + 1 <= 5 mutually independent gated witness-only permutations
             // under ONE header — [12 state slots, flag slot] x n -> 12 x n outputs.  A cycle runs one opcode, so a LANE has at most one or two
             // of a level's permutations on, while a WAVEFRONT of 64 different cycles has nearly all of them on somewhere: 15 of main_vm's 18
-            // gated permutations ran per wavefront where the lanes needed 0.83 each (profiles/r5_iszero_stats.json).  Here every lane picks ITS
-            // next member that is on, the wavefront runs ONE permutation on the picked states, each lane stores to its member's outputs; lanes
-            // with a second member on take another round.  Zeros everywhere else, as before.
-            uint32_t mrg_n = 0, mrg_pending = 0, mrg_base = 0, mrg_pc = 0;
-            int mrg_me = -1;
+            // gated permutations ran per wavefront where the lanes needed 0.83 each (profiles/r5_iszero_stats.json).  The op is executed in
+            // ROUNDS (mrg_round, uniform, lives across the interpreter loop; the header is decoded again for the next round): in round r every
+            // lane picks ITS r-th member that is on, the wavefront runs ONE permutation on the picked states, each lane stores to its member's
+            // outputs.  Round 0 first writes zeros to every output.  No state but the round number survives the permutation body.
             const bool merged = !STRANDS && !WIDE && (op == ZK_OP_POSEIDON2) && pa == 2;
+            int mrg_me = -1;
+            bool mrg_more = false;
+            uint32_t mrg_base = 0;
             if (merged) {
-                mrg_n = pb + 1; mrg_pc = pc; mrg_base = dst;
+                const uint32_t n = pb + 1;
+                uint32_t cnt = 0;
 #pragma unroll
                 for (uint32_t g = 0; g < 5; ++g)
-                    if (g < mrg_n) mrg_pending |= (ldv(prog[pc + 1 + g * 13 + 12]) != 0 ? 1u : 0u) << g;
-                pc += 1 + 13 * mrg_n;
-                for (uint32_t q = 0; q < 12 * mrg_n; ++q) st(0ull);   // every output is 0 until a lane's round says otherwise
-                const uint64_t any = __builtin_amdgcn_ballot_w64(mrg_pending != 0);
+                    if (g < n) {
+                        const bool on = ldv(prog[pc + 1 + g * 13 + 12]) != 0;
+                        if (on && cnt == mrg_round) mrg_me = (int)g;
+                        cnt += on ? 1u : 0u;
+                    }
+                mrg_more = __builtin_amdgcn_ballot_w64(cnt > mrg_round + 1) != 0;
+                if (mrg_round == 0) {
+                    for (uint32_t q = 0; q < 12 * n; ++q) st(0ull);   // every output is 0 until a lane's round says otherwise
 #ifndef ZKGL_PLANE_STATS
-                if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats, (unsigned long long)mrg_n);   // (sites; the rounds run are added below)
+                    if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats, (unsigned long long)n);   // word 0: member sites met; word 1 (below): permutations run
 #endif
-                if (any == 0) break;
+                }
+                mrg_base = dst - 12u * n * bstep;
+                const bool idle = __builtin_amdgcn_ballot_w64(mrg_me >= 0) == 0;   // (only in round 0: a later round exists because a lane asked for it)
+                if (!mrg_more || idle) { pc += 1 + 13 * n; }
+                if (idle) { mrg_round = 0; break; }
+                // the picked member's state: ONE load per element, its slot chosen per lane (slot words are uniform scalars; the per-lane choice is a
+                // chain of selects on 32-bit offsets) — holding the state while loading candidates would double the live registers of the body
+                {
+                    const uint32_t hdr = mrg_more ? pc : pc - 1 - 13 * n;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        uint32_t vo = prog[hdr + 1 + i] << bsh;
+#pragma unroll
+                        for (uint32_t g = 1; g < 5; ++g)
+                            if (g < n) { const uint32_t so = prog[hdr + 1 + g * 13 + i] << bsh; vo = mrg_me == (int)g ? so : vo; }
+                        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte + vo, 0, 0);
+                        s[i] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                    }
+                }
+                mrg_round = mrg_more ? mrg_round + 1 : 0;
+#ifndef ZKGL_PLANE_STATS
+                if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats + 1, 1ull);
+#endif
             } else {
 #endif
 #pragma unroll
@@ -782,31 +814,13 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 }
             }
 #ifdef ZKGL_P2_MERGE
-            else if (merged) { /* pc and dst are set */ }
+            else if (merged) { lane_off = mrg_me < 0; }
 #endif
             else {
                 out_to(W[13]);
                 pc += 13 + D;
             }
             if (deferred) dst += WIDE ? 950u : 950u * bstep;
-#ifdef ZKGL_P2_MERGE
-            for (;;) {   // one trip, or (merged form) one per round
-            if (merged) {
-                mrg_me = mrg_pending ? (int)__builtin_ctz(mrg_pending) : -1;
-                lane_off = mrg_me < 0;
-#pragma unroll
-                for (int i = 0; i < 12; ++i) s[i] = 0;
-#pragma unroll 1
-                for (uint32_t g = 0; g < mrg_n; ++g) {
-                    if (__builtin_amdgcn_ballot_w64(mrg_me == (int)g) == 0) continue;   // uniform: nobody picked this member this round
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) { const uint64_t v = ldv(prog[mrg_pc + 1 + g * 13 + i]); s[i] = mrg_me == (int)g ? v : s[i]; }
-                }
-#ifndef ZKGL_PLANE_STATS
-                if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats + 1, 1ull);
-#endif
-            }
-#endif
             p2::mds_external(s);
             if constexpr (P2_IN_REGISTERS) {
                 // state in registers, the twelve S-boxes of a full round unrolled, ONE copy of the full-round body (12 KB of code: the
@@ -871,7 +885,6 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                             o.x = (uint32_t)s[i]; o.y = (uint32_t)(s[i] >> 32);
                             __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, vo, mrg_base + (uint32_t)i * bstep, 0);
                         }
-                        mrg_pending &= mrg_pending - 1;
                     }
                 } else
 #endif
@@ -916,10 +929,6 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 for (int i = 0; i < 12; ++i) st(lane_off ? 0ull : s[i]);
             }
             }
-#ifdef ZKGL_P2_MERGE
-            if (!merged || __builtin_amdgcn_ballot_w64(mrg_pending != 0) == 0) break;
-            }   // for (;;)
-#endif
         } break;
         case ZK_OP_LOOP_LAST: {
             const uint32_t c = W[1];

@@ -64,6 +64,13 @@ def test_merged_gated_permutations_variant():
     assert all(r["features"] & 32 for r in res)
 
 
+def test_both_valu_levers_together():
+    """-DZKGL_P2_MERGE -DZKGL_BATCH_INV: the library tools/ab_r5.sh times as the candidate for the default loop kernel"""
+    res = run_cases(["vm", "iszero", "ram"], "p2m_binv", "-DZKGL_P2_MERGE -DZKGL_BATCH_INV")
+    all_equal(res, 1 + 1 + 2)
+    assert all(r["features"] & 40 == 40 for r in res)
+
+
 def test_mux_chain_variant():
     """-DZKGL_SELECT_CHAINS_KERNEL with ZKGL_SELECT_CHAINS=1: runs of SELECTs as chain ops, the running value in a register"""
     res = run_cases(["vm"], "chains", "-DZKGL_SELECT_CHAINS_KERNEL", {"ZKGL_SELECT_CHAINS": "1"})
