@@ -19,6 +19,16 @@ for v in p2m p2m_binv; do
     vm product A=0; vm $v ZKGL_LIB=$P/libzkgl_$v.so; vm product A=0; vm $v ZKGL_LIB=$P/libzkgl_$v.so
   fi
 done
+# VALU instructions and busy cycles of the loop kernel: product vs both levers (the reduction the harness statistics predict: profiles/r5_iszero_stats.json)
+if [ -f $P/libzkgl_p2m_binv.so ]; then
+  for v in product p2m_binv; do
+    L=$P/libzkgl.so; [ $v = product ] || L=$P/libzkgl_$v.so
+    export PMC_CMD="env ZKGL_LIB=$L python $PWD/bench.py --batch 384 --seed-windows 2 --steps 2 --warmup 0 --no-cpu-baseline --headline-only"
+    tools/pmc_pass.sh ab_valu_$v SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES > /dev/null 2>&1
+    grep "k_witness_loop " gpurun_out/pmc_ab_valu_$v.txt | sed "s/^/[$v] /" | tee -a $OUT
+    unset PMC_CMD
+  done
+fi
 # ---- (2) mux chains
 if [ -f $P/libzkgl_chains.so ]; then
   t chains ZKGL_LIB=$P/libzkgl_chains.so ZKGL_SELECT_CHAINS=1 timeout 900 python -m pytest tests/test_gpu_main_vm.py tests/test_fused_check.py tests/test_fuzz_programs.py -m gpu -x -q
