@@ -967,7 +967,11 @@ void CS::bound_values(Scope& s) {
         }
     }
     s.values_below_2_32 = s.values_below_2_8 = 0;
-    for (uint32_t v = 0; v < s.n_vars; ++v) { s.values_below_2_32 += ub[v] <= ((u128)1 << 32); s.values_below_2_8 += ub[v] <= 256; }
+    s.value_class.assign(s.n_vars, 0);
+    for (uint32_t v = 0; v < s.n_vars; ++v) {
+        s.values_below_2_32 += ub[v] <= ((u128)1 << 32); s.values_below_2_8 += ub[v] <= 256;
+        s.value_class[v] = ub[v] <= 256 ? 2 : ub[v] <= ((u128)1 << 32) ? 1 : 0;
+    }
     if (getenv("ZKGL_PROG_STATS"))
         fprintf(stderr, "[zkgl] %s scope: %u of %u variables are < 2^32 in every satisfying witness (%u of them < 2^8): candidates for 4-byte store slots\n",
                 s.is_loop ? "loop" : "outer", s.values_below_2_32, s.n_vars, s.values_below_2_8);

@@ -103,6 +103,7 @@ struct Scope {
     std::vector<std::vector<uint32_t>> row_gates;  // [row][instance] -> index into `gates`
     std::vector<std::vector<uint32_t>> row_lookups;  // [row][tuple] -> index into `lookups`
     uint32_t n_macro_p2 = 0;
+    std::vector<uint8_t> value_class;   // per variable, CS::bound_values: 2 = < 2^8, 1 = < 2^32, 0 = a field element (in every satisfying witness)
     uint32_t values_below_2_32 = 0, values_below_2_8 = 0;   // census (CS::bound_values): variables bounded by the constraints in every satisfying witness
     bool p2_intermediates_private = true;   // no op / lookup / link / kept gate of the step reads an intermediate of a ZK_OP_P2_ROUNDS (deferred mode)
     uint32_t n_p2_rounds_ops = 0;    // ZK_OP_P2_ROUNDS ops of the scope (deferred mode needs a verified descriptor for each)

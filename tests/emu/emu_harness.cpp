@@ -393,6 +393,38 @@ extern "C" int zk_emu_gated_p2_levels(zk_cs* h) {
     return n_levels;
 }
 
+// analysis aid (round 6's narrow store): per opcode of the loop scope, how many outputs the census bounds by 2^8 / 2^32 (CS::bound_values) and
+// what packing WITHIN one op would save (k byte outputs of an op -> ceil(k / 8) slots; k narrow outputs -> ceil(k / 2)): an op's outputs are
+// the next consecutive slots and a packed slot has to be complete when the op ends (the next op may read it).
+extern "C" int zk_emu_narrow_stats(zk_cs* h, int outer) {
+    CS& cs = *zkgl::cs_of(h);
+    const Scope& s = outer ? cs.outer_ : cs.loop_;
+    if (s.value_class.size() != s.n_vars) return -1;
+    struct Row { uint64_t ops = 0, outs = 0, b8 = 0, b32 = 0, save8 = 0, save32 = 0, reads8 = 0, reads = 0; } rows[256], tot;
+    for (auto& op : s.ops) {
+        if (op.seed_only) continue;
+        Row& r = rows[op.opcode];
+        uint32_t k8 = 0, k32 = 0;
+        for (uint32_t v : op.outs) { k8 += s.value_class[v] == 2; k32 += s.value_class[v] >= 1; }
+        r.ops++; r.outs += op.outs.size(); r.b8 += k8; r.b32 += k32;
+        if (k8 >= 2) r.save8 += k8 - (k8 + 7) / 8;
+        if (k32 >= 2) r.save32 += (k32 - (k32 + 1) / 2);
+        for (auto& x : op.ins) if (x.kind == zkgl::Operand::VAR) { r.reads++; r.reads8 += s.value_class[x.idx] == 2; }
+    }
+    fprintf(stderr, "[emu] %s scope: %u variables, %u slots\n[emu] %-6s %8s %8s %8s %8s %10s %10s %8s %8s\n", outer ? "outer" : "loop", s.n_vars, s.n_slots,
+            "opcode", "ops", "outs", "<2^8", "<2^32", "save(8in1)", "save(2in1)", "reads", "reads<2^8");
+    for (int o = 0; o < 256; ++o) {
+        const Row& r = rows[o];
+        if (!r.ops) continue;
+        fprintf(stderr, "[emu] %-6d %8llu %8llu %8llu %8llu %10llu %10llu %8llu %8llu\n", o, (unsigned long long)r.ops, (unsigned long long)r.outs, (unsigned long long)r.b8,
+                (unsigned long long)r.b32, (unsigned long long)r.save8, (unsigned long long)r.save32, (unsigned long long)r.reads, (unsigned long long)r.reads8);
+        tot.ops += r.ops; tot.outs += r.outs; tot.b8 += r.b8; tot.b32 += r.b32; tot.save8 += r.save8; tot.save32 += r.save32; tot.reads += r.reads; tot.reads8 += r.reads8;
+    }
+    fprintf(stderr, "[emu] %-6s %8llu %8llu %8llu %8llu %10llu %10llu %8llu %8llu\n", "all", (unsigned long long)tot.ops, (unsigned long long)tot.outs, (unsigned long long)tot.b8,
+            (unsigned long long)tot.b32, (unsigned long long)tot.save8, (unsigned long long)tot.save32, (unsigned long long)tot.reads, (unsigned long long)tot.reads8);
+    return 0;
+}
+
 extern "C" void zk_emu_sizes(zk_cs* h, uint32_t batch, uint64_t out[6]) {   // outer n_cells, outer stride, loop n_cells, loop stride, n_public, total_table_rows
     CS& cs = *zkgl::cs_of(h);
     out[0] = cs.outer_.n_cells; out[1] = ((uint64_t)batch + 63) / 64 * 64;
