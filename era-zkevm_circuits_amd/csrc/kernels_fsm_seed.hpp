@@ -413,6 +413,7 @@ __global__ __launch_bounds__(128) void k_fsm_seed(FsmSeedDev a) {
         if (walker) {
             for (u32 w = lane; w < CARRIED; w += 64)
                 if (!is_chain(w)) col[(u64)w * a.in_stride] = F::get(S, w);
+            wave_sync();   // every lane has read the state of cycle c before lane 0 steps it (found by the emulated device of tests/emu: the lanes are in lockstep on the hardware, the memory model does not say so)
             if (lane == 0 && c + 1 < a.limit && !(a.debug & 2)) F::step(S, raw[c & 1], ev[c & 1]);
         } else {
             u64 nxt[(RAW + 63) / 64];

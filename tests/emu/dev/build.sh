@@ -1,0 +1,24 @@
+#!/bin/bash
+# tests/emu/dev/build.sh [defs...] — build the product for the EMULATED DEVICE (tests/emu/README.md): every source of era-zkevm_circuits_amd/csrc,
+# re-written by gen_dev.py, compiled as host C++ over tests/emu/dev/hip/hip_runtime.h, linked with the fiber scheduler (emu_rt.cpp).
+#   -> tests/emu/_gen/dev/libzkgl.so (+ libzkgl_testcircuits.so beside it): load it with ZKGL_LIB=<that path>.  TEST INFRASTRUCTURE.
+set -euo pipefail
+HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../../.." && pwd)
+GEN=$HERE/../_gen/dev; mkdir -p $GEN/obj $GEN/obj/testing
+python $HERE/gen_dev.py $GEN
+CXX=/opt/rocm/lib/llvm/bin/clang++
+FLAGS="-std=c++17 -O1 -g1 -fPIC -fno-omit-frame-pointer -Wno-unknown-attributes -Wno-ignored-attributes -Wno-macro-redefined -Wno-unused-value -Wno-pass-failed -Wno-keyword-macro -Wno-deprecated-declarations -I$HERE -I$GEN/src $*"
+if [ "$(cat $GEN/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f $GEN/obj/*.o $GEN/obj/testing/*.o; echo "$FLAGS" > $GEN/.flags; fi
+NEWEST_HDR=$(ls -t $GEN/src/*.hpp $GEN/src/circuits/*.hpp $ROOT/include/*.h $HERE/hip/*.h $HERE/rccl/*.h | head -1)
+pids=(); fails=0
+cc() {  # $1 source, $2 object
+  if [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ "$NEWEST_HDR" -nt "$2" ]; then $CXX $FLAGS -c "$1" -o "$2" & pids+=($!); fi
+}
+for f in $GEN/src/*.cpp $GEN/src/circuits/*.cpp; do cc $f $GEN/obj/$(basename $f).o; done
+cc $HERE/emu_rt.cpp $GEN/obj/emu_rt.o
+for f in $GEN/src/testing/*.cpp; do cc $f $GEN/obj/testing/$(basename $f).o; done
+for p in "${pids[@]}"; do wait $p || fails=1; done
+[ $fails = 0 ] || { echo "tests/emu/dev/build.sh: compilation failed"; exit 1; }
+$CXX -shared -fPIC -o $GEN/libzkgl.so $GEN/obj/*.o -lpthread
+$CXX -shared -fPIC -o $GEN/libzkgl_testcircuits.so $GEN/obj/testing/*.o -L$GEN -lzkgl -Wl,-rpath,'$ORIGIN'
+echo "built $GEN/libzkgl.so"

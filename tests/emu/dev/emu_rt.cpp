@@ -1,0 +1,243 @@
+// tests/emu/dev/emu_rt.cpp — TEST INFRASTRUCTURE: the scheduler of the emulated device (tests/emu/dev/hip/hip_runtime.h).
+//
+// One workgroup at a time; each work-item is a fiber with its own stack; a fiber runs until it finishes or blocks in __syncthreads / a
+// wavefront operation.  When every live lane of a wavefront is blocked, the lanes waiting at the same call site are served together (the
+// group is the operation's EXEC mask); when lanes of one wavefront wait at DIFFERENT call sites the wavefront has diverged around a
+// wavefront operation: the group at the lowest code address goes first (right for if-without-else and for loops with a divergent trip
+// count, which is all the kernels of this tree do) and the event is counted (EMU_STRICT=1: abort instead).  __syncthreads releases when
+// every live work-item of the workgroup waits in it.
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <cstdio>
+#include <vector>
+
+namespace emu {
+
+enum State : int { READY, WAIT_WAVE, WAIT_BLOCK, DONE };
+
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    int state = DONE;
+    unsigned lane = 0, wave = 0;
+    dim3 tidx;
+    // pending wavefront operation
+    const void* site = nullptr;
+    int op = 0;
+    uint64_t in = 0, aux = 0, aux2 = 0, out = 0;
+};
+
+thread_local Fiber* cur = nullptr;
+thread_local dim3 t_idx, b_idx, b_dim, g_dim;
+thread_local void* dyn_lds = nullptr;
+thread_local unsigned lane_in_wave = 0;
+
+static thread_local void* sched_sp = nullptr;
+static thread_local const Body* body = nullptr;
+static thread_local std::vector<Fiber>* fibers = nullptr;
+static thread_local unsigned long long n_divergent_sites = 0;
+
+constexpr size_t STACK_BYTES = 1u << 20;   // per work-item (the macro-op backends keep a few KB of locals; the host compile does not optimise them away)
+
+extern "C" void emu_switch(void** save_sp, void* to_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch,.-emu_switch
+)");
+
+static void yield_to_scheduler() { emu_switch(&cur->sp, sched_sp); }
+
+static void fiber_entry() {
+    body->run();
+    cur->state = DONE;
+    yield_to_scheduler();
+    __builtin_trap();
+}
+
+static void prepare(Fiber& f) {
+    if (!f.stack) {
+        f.stack = (char*)mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (f.stack == (char*)MAP_FAILED) { fprintf(stderr, "[emu] cannot map a fiber stack\n"); abort(); }
+    }
+    uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)15;
+    void** s = (void**)top;
+    *--s = nullptr;               // the return address fiber_entry would return to (it never does)
+    *--s = (void*)&fiber_entry;   // popped by emu_switch's ret
+    for (int i = 0; i < 6; ++i) *--s = nullptr;
+    f.sp = s;
+    f.state = READY;
+}
+
+uint64_t wave_op(int op, uint64_t in, uint64_t aux, uint64_t aux2) {
+    Fiber* f = cur;
+    f->site = __builtin_return_address(0);
+    f->op = op; f->in = in; f->aux = aux; f->aux2 = aux2;
+    f->state = WAIT_WAVE;
+    yield_to_scheduler();
+    return f->out;
+}
+
+void sync_threads() {
+    cur->state = WAIT_BLOCK;
+    yield_to_scheduler();
+}
+
+// DPP controls the kernels use (kernels_vm_seed.hpp mov32<CTRL>): row_shr:n = 0x110 + n, row_shl:n = 0x100 + n, row_ror:n = 0x120 + n,
+// quad_perm = 0x00..0xff, row_bcast15 = 0x142, row_bcast31 = 0x143, wave_shr:1 = 0x138, row_mirror = 0x140, row_half_mirror = 0x141
+static int dpp_source(unsigned ctrl, int lane, bool& valid) {
+    valid = true;
+    const int row = lane & ~15, i = lane & 15;
+    if (ctrl <= 0xff) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    if (ctrl >= 0x101 && ctrl <= 0x10f) { const int s = i + (int)(ctrl - 0x100); valid = s < 16; return row + (s & 15); }
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int s = i - (int)(ctrl - 0x110); valid = s >= 0; return row + (s & 15); }
+    if (ctrl >= 0x121 && ctrl <= 0x12f) return row + ((i - (int)(ctrl - 0x120)) & 15);
+    if (ctrl == 0x138) { valid = lane > 0; return lane - 1; }
+    if (ctrl == 0x140) return row + (15 - i);
+    if (ctrl == 0x141) return row + ((i & 8) | (7 - (i & 7)));
+    if (ctrl == 0x142) { valid = lane >= 16; return row - 1; }                 // row_bcast15: lane 15 of the previous row
+    if (ctrl == 0x143) { valid = lane >= 32; return (lane & 32) - 1; }          // row_bcast31: lane 31 to the upper half
+    fprintf(stderr, "[emu] update_dpp control 0x%x is not emulated\n", ctrl); abort();
+}
+
+static void serve(Fiber** g, int n) {   // the lanes of one wavefront waiting at one call site, in lane order
+    Fiber* by_lane[64] = {};
+    for (int k = 0; k < n; ++k) by_lane[g[k]->lane] = g[k];
+    const int op = g[0]->op;
+    uint64_t ballot = 0;
+    if (op == OP_BALLOT) for (int k = 0; k < n; ++k) ballot |= (uint64_t)(g[k]->in & 1) << g[k]->lane;
+    for (int k = 0; k < n; ++k) {
+        Fiber* f = g[k];
+        if (f->op != op) { fprintf(stderr, "[emu] two different wavefront operations at one call site\n"); abort(); }
+        switch (op) {
+        case OP_BALLOT: f->out = ballot; break;
+        case OP_READFIRST: f->out = g[0]->in; break;
+        case OP_READLANE: {
+            Fiber* s = by_lane[f->aux & 63];
+            if (!s) { fprintf(stderr, "[emu] readlane from lane %u, which is not at this call site (site %p)\n", (unsigned)(f->aux & 63), f->site); abort(); }
+            f->out = s->in;
+        } break;
+        case OP_SHFL: { Fiber* s = by_lane[f->aux & 63]; f->out = s ? s->in : f->in; } break;
+        case OP_SHFL_UP: { const int src = (int)f->lane - (int)f->aux; Fiber* s = src >= 0 ? by_lane[src] : nullptr; f->out = s ? s->in : f->in; } break;
+        case OP_SHFL_XOR: { Fiber* s = by_lane[(f->lane ^ (unsigned)f->aux) & 63]; f->out = s ? s->in : f->in; } break;
+        case OP_DPP: {
+            const unsigned ctrl = (unsigned)(f->aux & 0xffff), row_mask = (unsigned)(f->aux >> 16) & 15, bank_mask = (unsigned)(f->aux >> 20) & 15;
+            const bool bound_ctrl = (f->aux >> 24) & 1;
+            bool valid;
+            const int src = dpp_source(ctrl, (int)f->lane, valid);
+            const bool enabled = ((row_mask >> (f->lane >> 4)) & 1) && ((bank_mask >> ((f->lane >> 2) & 3)) & 1);
+            Fiber* s = valid && src >= 0 && src < 64 ? by_lane[src] : nullptr;
+            if (!enabled) f->out = f->aux2;
+            else if (s) f->out = s->in;
+            else f->out = bound_ctrl ? 0 : f->aux2;
+        } break;
+        case OP_WAVE_BARRIER: f->out = 0; break;
+        default: abort();
+        }
+    }
+    for (int k = 0; k < n; ++k) g[k]->state = READY;
+}
+
+static void run_block(std::vector<Fiber>& fb, unsigned n_threads) {
+    fibers = &fb;
+    unsigned live = n_threads;
+    const unsigned n_waves = (n_threads + 63) / 64;
+    for (unsigned t = 0; t < n_threads; ++t) prepare(fb[t]);
+    const bool strict = getenv("EMU_STRICT") != nullptr;
+    while (live) {
+        bool ran = false;
+        for (unsigned t = 0; t < n_threads; ++t) {
+            Fiber& f = fb[t];
+            if (f.state != READY) continue;
+            cur = &f; t_idx = f.tidx; lane_in_wave = f.lane;
+            emu_switch(&sched_sp, f.sp);
+            ran = true;
+            if (f.state == DONE) --live;
+        }
+        if (!live) break;
+        // wavefront operations: a wavefront whose live lanes are all blocked serves its lowest call site
+        bool released = false;
+        for (unsigned w = 0; w < n_waves; ++w) {
+            Fiber* g[64]; int n = 0;
+            const void* lowest = nullptr; bool diverged = false, all_blocked = true;
+            const unsigned t1 = std::min(n_threads, (w + 1) * 64);
+            for (unsigned t = w * 64; t < t1; ++t) {
+                Fiber& f = fb[t];
+                if (f.state == READY) { all_blocked = false; break; }
+                if (f.state != WAIT_WAVE) continue;
+                if (lowest && f.site != lowest) diverged = true;
+                if (!lowest || (uintptr_t)f.site < (uintptr_t)lowest) lowest = f.site;
+            }
+            if (!all_blocked || !lowest) continue;
+            if (diverged) {
+                ++n_divergent_sites;
+                if (strict) { fprintf(stderr, "[emu] EMU_STRICT: a wavefront waits at two call sites of wavefront operations\n"); abort(); }
+            }
+            for (unsigned t = w * 64; t < t1; ++t) if (fb[t].state == WAIT_WAVE && fb[t].site == lowest) g[n++] = &fb[t];
+            serve(g, n);
+            released = true;
+        }
+        if (released) continue;
+        // the workgroup barrier: every live work-item waits in it
+        bool all_at_barrier = true;
+        for (unsigned t = 0; t < n_threads; ++t) if (fb[t].state != DONE && fb[t].state != WAIT_BLOCK) { all_at_barrier = false; break; }
+        if (all_at_barrier) { for (unsigned t = 0; t < n_threads; ++t) if (fb[t].state == WAIT_BLOCK) fb[t].state = READY; continue; }
+        if (!ran) { fprintf(stderr, "[emu] deadlock: no work-item of the workgroup can run\n"); abort(); }
+    }
+}
+
+void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b) {
+    if (cur) { fprintf(stderr, "[emu] a kernel launched a kernel\n"); abort(); }
+    static thread_local std::vector<Fiber> fb;
+    static thread_local std::vector<char> lds;
+    const unsigned n_threads = block.x * block.y * block.z;
+    if (n_threads == 0 || (size_t)grid.x * grid.y * grid.z == 0) return;
+    if (n_threads > 1024) { fprintf(stderr, "[emu] workgroup of %u work-items\n", n_threads); abort(); }
+    if (fb.size() < n_threads) fb.resize(n_threads);
+    lds.assign(lds_bytes + 16, 0);
+    dyn_lds = lds.data();
+    body = &b;
+    b_dim = block; g_dim = grid;
+    for (unsigned t = 0; t < n_threads; ++t) {
+        fb[t].tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+        fb[t].lane = t & 63; fb[t].wave = t >> 6;
+    }
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) {
+                b_idx = dim3(x, y, z);
+                run_block(fb, n_threads);
+            }
+    cur = nullptr; body = nullptr;
+}
+
+// device memory: host memory filled with a pattern (hipMalloc does not zero; code that relies on zeros must show)
+void* alloc(size_t n) {
+    if (!n) return nullptr;
+    void* p = nullptr;
+    if (posix_memalign(&p, 256, (n + 255) & ~(size_t)255)) return nullptr;
+    if (!getenv("EMU_ZERO_ALLOC")) memset(p, 0xCD, n); else memset(p, 0, n);
+    return p;
+}
+void release(void* p) { free(p); }
+
+extern "C" unsigned long long zk_emu_divergent_wave_sites() { return n_divergent_sites; }
+
+}  // namespace emu
