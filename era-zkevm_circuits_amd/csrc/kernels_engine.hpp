@@ -1182,11 +1182,12 @@ __global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict_
         const zk_link L = links[i];
         const uint32_t kind = uni(L.kind);
         uint64_t mine = loop_cells[cell_off(loop_n_cells, uni(L.loop_cell), lane)];
+        const uint32_t other = uni(L.other_cell);   // (read where the wavefront is whole: the k > 0 test below splits it)
         bool ok = true;
         if (kind == ZK_LINK_CARRY) {
-            if (k > 0) ok = mine == loop_cells[cell_off(loop_n_cells, uni(L.other_cell), lane - 1)];
+            if (k > 0) ok = mine == loop_cells[cell_off(loop_n_cells, other, lane - 1)];
         } else {
-            uint64_t o = outer_cells[cell_off(outer_n_cells, uni(L.other_cell), inst)];
+            uint64_t o = outer_cells[cell_off(outer_n_cells, other, inst)];
             if (kind == ZK_LINK_FIRST) ok = (k != 0) || mine == o;
             else if (kind == ZK_LINK_LAST) ok = (k != limit - 1) || mine == o;
             else ok = mine == o;

@@ -88,6 +88,12 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def emulated_device() -> bool:
+    """True when ZKGL_LIB names the test suite's emulated-device build of the library (tests/emu/README.md): the -m gpu tests then run the device
+    SOURCE on host fibers.  The product library never answers True."""
+    return hasattr(lib(), "zk_emu_divergent_wave_sites")
+
+
 _testlib = None
 
 

@@ -2,20 +2,27 @@
 # tests/emu/dev/build.sh [defs...] — build the product for the EMULATED DEVICE (tests/emu/README.md): every source of era-zkevm_circuits_amd/csrc,
 # re-written by gen_dev.py, compiled as host C++ over tests/emu/dev/hip/hip_runtime.h, linked with the fiber scheduler (emu_rt.cpp).
 #   -> tests/emu/_gen/dev/libzkgl.so (+ libzkgl_testcircuits.so beside it): load it with ZKGL_LIB=<that path>.  TEST INFRASTRUCTURE.
+# EMU_VARIANT=<name> with defs (e.g. EMU_VARIANT=p2m_binv build.sh -DZKGL_P2_MERGE -DZKGL_BATCH_INV): an opt-in build of tools/variants_r5.sh -> tests/emu/_gen/dev_<name>/
+# EMU_OPT=-O2: the kernels' translation unit at -O2 (runs twice as fast, compiles in ~100 s instead of ~10) -> tests/emu/_gen/dev_O2/
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../../.." && pwd)
-GEN=$HERE/../_gen/dev; mkdir -p $GEN/obj $GEN/obj/testing
+OPT=${EMU_OPT:--O1}
+GEN=$HERE/../_gen/dev${EMU_VARIANT:+_$EMU_VARIANT}; [ "$OPT" = "-O1" ] || GEN=${GEN}_${OPT#-}
+mkdir -p $GEN/obj $GEN/obj/testing
 python $HERE/gen_dev.py $GEN
 CXX=/opt/rocm/lib/llvm/bin/clang++
 FLAGS="-std=c++17 -O1 -g1 -fPIC -fno-omit-frame-pointer -Wno-unknown-attributes -Wno-ignored-attributes -Wno-macro-redefined -Wno-unused-value -Wno-pass-failed -Wno-keyword-macro -Wno-deprecated-declarations -I$HERE -I$GEN/src $*"
 if [ "$(cat $GEN/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f $GEN/obj/*.o $GEN/obj/testing/*.o; echo "$FLAGS" > $GEN/.flags; fi
 NEWEST_HDR=$(ls -t $GEN/src/*.hpp $GEN/src/circuits/*.hpp $ROOT/include/*.h $HERE/hip/*.h $HERE/rccl/*.h | head -1)
 pids=(); fails=0
-cc() {  # $1 source, $2 object
-  if [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ "$NEWEST_HDR" -nt "$2" ]; then $CXX $FLAGS -c "$1" -o "$2" & pids+=($!); fi
+cc() {  # $1 source, $2 object, $3 extra flags
+  if [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ "$NEWEST_HDR" -nt "$2" ]; then $CXX $FLAGS ${3:-} -c "$1" -o "$2" & pids+=($!); fi
 }
-for f in $GEN/src/*.cpp $GEN/src/circuits/*.cpp; do cc $f $GEN/obj/$(basename $f).o; done
-cc $HERE/emu_rt.cpp $GEN/obj/emu_rt.o
+for f in $GEN/src/*.cpp $GEN/src/circuits/*.cpp; do
+  if [ $(basename $f) = zkgl_device.cpp ]; then cc $f $GEN/obj/$(basename $f).o $OPT   # the kernels
+  else cc $f $GEN/obj/$(basename $f).o; fi
+done
+cc $HERE/emu_rt.cpp $GEN/obj/emu_rt.o -O2
 for f in $GEN/src/testing/*.cpp; do cc $f $GEN/obj/testing/$(basename $f).o; done
 for p in "${pids[@]}"; do wait $p || fails=1; done
 [ $fails = 0 ] || { echo "tests/emu/dev/build.sh: compilation failed"; exit 1; }

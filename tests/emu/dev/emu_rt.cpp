@@ -8,6 +8,13 @@
 // every live work-item of the workgroup waits in it.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
+#include <dlfcn.h>
+#include <unistd.h>
+#include <cxxabi.h>
+#include <map>
+#include <mutex>
+#include <string>
 #include <cstdio>
 #include <vector>
 
@@ -36,6 +43,8 @@ static thread_local void* sched_sp = nullptr;
 static thread_local const Body* body = nullptr;
 static thread_local std::vector<Fiber>* fibers = nullptr;
 static thread_local unsigned long long n_divergent_sites = 0;
+static std::map<std::pair<const void*, const void*>, unsigned long long> divergent_pairs;   // (served first, left waiting) -> count
+static unsigned long long n_launches = 0, n_blocks = 0, n_wave_ops = 0;   // EMU_STATS=1: printed at exit
 
 constexpr size_t STACK_BYTES = 1u << 20;   // per work-item (the macro-op backends keep a few KB of locals; the host compile does not optimise them away)
 
@@ -160,46 +169,41 @@ static void run_block(std::vector<Fiber>& fb, unsigned n_threads) {
     unsigned live = n_threads;
     const unsigned n_waves = (n_threads + 63) / 64;
     for (unsigned t = 0; t < n_threads; ++t) prepare(fb[t]);
-    const bool strict = getenv("EMU_STRICT") != nullptr;
+    static const bool strict = getenv("EMU_STRICT") != nullptr;
     while (live) {
-        bool ran = false;
-        for (unsigned t = 0; t < n_threads; ++t) {
-            Fiber& f = fb[t];
-            if (f.state != READY) continue;
-            cur = &f; t_idx = f.tidx; lane_in_wave = f.lane;
-            emu_switch(&sched_sp, f.sp);
-            ran = true;
-            if (f.state == DONE) --live;
-        }
-        if (!live) break;
-        // wavefront operations: a wavefront whose live lanes are all blocked serves its lowest call site
-        bool released = false;
+        // a wavefront runs until each of its lanes has finished or waits in the workgroup barrier
         for (unsigned w = 0; w < n_waves; ++w) {
-            Fiber* g[64]; int n = 0;
-            const void* lowest = nullptr; bool diverged = false, all_blocked = true;
-            const unsigned t1 = std::min(n_threads, (w + 1) * 64);
-            for (unsigned t = w * 64; t < t1; ++t) {
-                Fiber& f = fb[t];
-                if (f.state == READY) { all_blocked = false; break; }
-                if (f.state != WAIT_WAVE) continue;
-                if (lowest && f.site != lowest) diverged = true;
-                if (!lowest || (uintptr_t)f.site < (uintptr_t)lowest) lowest = f.site;
+            const unsigned t0 = w * 64, t1 = std::min(n_threads, t0 + 64);
+            while (true) {
+                for (unsigned t = t0; t < t1; ++t) {
+                    Fiber& f = fb[t];
+                    if (f.state != READY) continue;
+                    cur = &f; t_idx = f.tidx; lane_in_wave = f.lane;
+                    emu_switch(&sched_sp, f.sp);
+                    if (f.state == DONE) --live;
+                }
+                // every live lane is blocked: serve the wavefront operation at the lowest call site
+                const void* lowest = nullptr; bool diverged = false;
+                for (unsigned t = t0; t < t1; ++t) {
+                    const Fiber& f = fb[t];
+                    if (f.state != WAIT_WAVE) continue;
+                    if (lowest && f.site != lowest) diverged = true;
+                    if (!lowest || (uintptr_t)f.site < (uintptr_t)lowest) lowest = f.site;
+                }
+                if (!lowest) break;
+                if (diverged) {
+                    ++n_divergent_sites;
+                    for (unsigned t = t0; t < t1; ++t) if (fb[t].state == WAIT_WAVE && fb[t].site != lowest) { ++divergent_pairs[{lowest, fb[t].site}]; break; }
+                    if (strict) { fprintf(stderr, "[emu] EMU_STRICT: a wavefront waits at two call sites of wavefront operations\n"); abort(); }
+                }
+                Fiber* g[64]; int n = 0;
+                for (unsigned t = t0; t < t1; ++t) if (fb[t].state == WAIT_WAVE && fb[t].site == lowest) g[n++] = &fb[t];
+                serve(g, n);
+                ++n_wave_ops;
             }
-            if (!all_blocked || !lowest) continue;
-            if (diverged) {
-                ++n_divergent_sites;
-                if (strict) { fprintf(stderr, "[emu] EMU_STRICT: a wavefront waits at two call sites of wavefront operations\n"); abort(); }
-            }
-            for (unsigned t = w * 64; t < t1; ++t) if (fb[t].state == WAIT_WAVE && fb[t].site == lowest) g[n++] = &fb[t];
-            serve(g, n);
-            released = true;
         }
-        if (released) continue;
         // the workgroup barrier: every live work-item waits in it
-        bool all_at_barrier = true;
-        for (unsigned t = 0; t < n_threads; ++t) if (fb[t].state != DONE && fb[t].state != WAIT_BLOCK) { all_at_barrier = false; break; }
-        if (all_at_barrier) { for (unsigned t = 0; t < n_threads; ++t) if (fb[t].state == WAIT_BLOCK) fb[t].state = READY; continue; }
-        if (!ran) { fprintf(stderr, "[emu] deadlock: no work-item of the workgroup can run\n"); abort(); }
+        for (unsigned t = 0; t < n_threads; ++t) if (fb[t].state == WAIT_BLOCK) fb[t].state = READY;
     }
 }
 
@@ -214,6 +218,7 @@ void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b) {
     lds.assign(lds_bytes + 16, 0);
     dyn_lds = lds.data();
     body = &b;
+    ++n_launches;
     b_dim = block; g_dim = grid;
     for (unsigned t = 0; t < n_threads; ++t) {
         fb[t].tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
@@ -223,20 +228,67 @@ void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b) {
         for (unsigned y = 0; y < grid.y; ++y)
             for (unsigned x = 0; x < grid.x; ++x) {
                 b_idx = dim3(x, y, z);
+                ++n_blocks;
                 run_block(fb, n_threads);
             }
     cur = nullptr; body = nullptr;
 }
 
 // device memory: host memory filled with a pattern (hipMalloc does not zero; code that relies on zeros must show)
+static unsigned long long n_allocs = 0, n_alloc_bytes = 0;
+static std::string where(const void* p) {
+    Dl_info di;
+    if (!dladdr(p, &di) || !di.dli_sname) return "?";
+    int st = 0;
+    char* d = abi::__cxa_demangle(di.dli_sname, nullptr, nullptr, &st);
+    std::string r = (st == 0 && d ? d : di.dli_sname);
+    free(d);
+    if (r.size() > 100) r = r.substr(0, 100) + "...";
+    char off[32]; snprintf(off, sizeof off, " + 0x%lx", (unsigned long)((const char*)p - (const char*)di.dli_saddr));
+    return r + off;
+}
+static void print_stats() {   // EMU_STATS=1: to stderr; EMU_STATS=<path prefix>: appended to <prefix>.<pid>
+    const char* dest = getenv("EMU_STATS");
+    FILE* o = stderr;
+    if (dest && strchr(dest, '/')) { o = fopen((std::string(dest) + "." + std::to_string((long)getpid())).c_str(), "a"); if (!o) o = stderr; }
+    for (auto& kv : divergent_pairs)
+        fprintf(o, "[emu] divergent x%llu: served %s | left waiting %s\n", kv.second, where(kv.first.first).c_str(), where(kv.first.second).c_str());
+    struct rusage ru; getrusage(RUSAGE_SELF, &ru);
+    fprintf(o, "[emu] process: %ld minor page faults, %.1f s user, %.1f s system\n", ru.ru_minflt, ru.ru_utime.tv_sec + ru.ru_utime.tv_usec / 1e6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec / 1e6);
+    fprintf(o, "[emu] %llu allocations (%.1f MB), %llu launches, %llu workgroups, %llu wavefront operations served, %llu divergent\n", n_allocs,
+            n_alloc_bytes / 1e6, n_launches, n_blocks, n_wave_ops, n_divergent_sites);
+    if (o != stderr) fclose(o);
+}
+// Freed blocks are kept and reused (a page fault is expensive in this container, and glibc returns large blocks to the system).
+static std::multimap<size_t, void*> free_blocks;
+static std::map<void*, size_t> block_size;
+static std::mutex alloc_mutex;
 void* alloc(size_t n) {
     if (!n) return nullptr;
+    if (!n_allocs++ && getenv("EMU_STATS")) atexit(print_stats);
+    n_alloc_bytes += n;
+    const size_t cap = (n + 4095) & ~(size_t)4095;
     void* p = nullptr;
-    if (posix_memalign(&p, 256, (n + 255) & ~(size_t)255)) return nullptr;
-    if (!getenv("EMU_ZERO_ALLOC")) memset(p, 0xCD, n); else memset(p, 0, n);
+    {
+    std::lock_guard<std::mutex> lock(alloc_mutex);
+    auto it = free_blocks.lower_bound(cap);
+    if (it != free_blocks.end() && it->first <= cap + cap / 4) { p = it->second; free_blocks.erase(it); }
+    else {
+        if (posix_memalign(&p, 4096, cap)) return nullptr;
+        block_size[p] = cap;
+    }
+    }
+    static const bool zero = getenv("EMU_ZERO_ALLOC") != nullptr;
+    memset(p, zero ? 0 : 0xCD, n);
     return p;
 }
-void release(void* p) { free(p); }
+void release(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(alloc_mutex);
+    auto it = block_size.find(p);
+    if (it == block_size.end()) { fprintf(stderr, "[emu] hipFree of an address hipMalloc did not return\n"); abort(); }
+    free_blocks.emplace(it->second, p);
+}
 
 extern "C" unsigned long long zk_emu_divergent_wave_sites() { return n_divergent_sites; }
 

@@ -59,8 +59,10 @@ extern thread_local dim3 t_idx, b_idx, b_dim, g_dim;
 extern thread_local void* dyn_lds;
 extern thread_local unsigned lane_in_wave;
 // the calling lane blocks until the live lanes of its wavefront meet at this call site; returns its result
-uint64_t wave_op(int op, uint64_t in, uint64_t aux, uint64_t aux2 = 0) __attribute__((noinline));
-void sync_threads() __attribute__((noinline));
+// (noduplicate + convergent: the host compiler may neither clone a call into the two arms of a branch nor make it depend on a new condition —
+//  a call site is the identity of the operation, as it is for the wavefront)
+uint64_t wave_op(int op, uint64_t in, uint64_t aux, uint64_t aux2 = 0) __attribute__((noinline, noduplicate, convergent));
+void sync_threads() __attribute__((noinline, noduplicate, convergent));
 struct Body { virtual void run() const = 0; };
 template <class F> struct BodyOf : Body { const F& f; explicit BodyOf(const F& f_) : f(f_) {} void run() const override { f(); } };
 void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b);
@@ -93,9 +95,9 @@ static inline void __threadfence_block() {}
     ((int)(uint32_t)emu::wave_op(emu::OP_DPP, (uint32_t)(src), (uint64_t)(ctrl) | ((uint64_t)(row_mask) << 16) | ((uint64_t)(bank_mask) << 20) | ((uint64_t)((bound_ctrl) ? 1 : 0) << 24), (uint32_t)(old)))
 #define __builtin_amdgcn_s_memrealtime() ((uint64_t)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10))
 #define __builtin_amdgcn_s_memtime() ((uint64_t)__builtin_readcyclecounter())
-template <class T> static __forceinline__ T __shfl(T v, int src, int /*width*/ = 64) { return (T)(uint32_t)emu::wave_op(emu::OP_SHFL, (uint32_t)v, (uint32_t)src); }
-template <class T> static __forceinline__ T __shfl_up(T v, unsigned d, int /*width*/ = 64) { return (T)(uint32_t)emu::wave_op(emu::OP_SHFL_UP, (uint32_t)v, d); }
-template <class T> static __forceinline__ T __shfl_xor(T v, int m, int /*width*/ = 64) { return (T)(uint32_t)emu::wave_op(emu::OP_SHFL_XOR, (uint32_t)v, (uint32_t)m); }
+template <class T> static __forceinline__ T __shfl(T v, int src, int /*width*/ = 64) { return (T)emu::wave_op(emu::OP_SHFL, (uint64_t)v, (uint32_t)src); }
+template <class T> static __forceinline__ T __shfl_up(T v, unsigned d, int /*width*/ = 64) { return (T)emu::wave_op(emu::OP_SHFL_UP, (uint64_t)v, d); }
+template <class T> static __forceinline__ T __shfl_xor(T v, int m, int /*width*/ = 64) { return (T)emu::wave_op(emu::OP_SHFL_XOR, (uint64_t)v, (uint32_t)m); }
 static inline unsigned __brev(unsigned x) { return __builtin_bitreverse32(x); }
 static inline unsigned long long __brevll(unsigned long long x) { return __builtin_bitreverse64(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }

@@ -1,0 +1,76 @@
+"""The -m gpu parity tests, run HERE on the emulated device (tests/emu/README.md, tests/emu/dev/).
+
+The product's device source — every kernel of zkgl_device.hip, with the launchers and the host side around them — is compiled as host C++ over a
+stand-in <hip/hip_runtime.h>; work-items are fibers, 64 consecutive ones a wavefront; ballots, readfirstlane / readlane, shuffles, DPP moves, the
+wave barrier and __syncthreads are rendezvous points.  The library is loaded through ZKGL_LIB exactly like a variant build, so the parity tests
+run unchanged: same C ABI, same oracle comparisons.  This is TEST INFRASTRUCTURE: it says nothing about time, coalescing or registers, and
+the product has no path to it (tests/test_abi.py: no GPU -> loud failure).
+
+A subset runs here on every CPU run (a few minutes of CPU in parallel workers); `tools/emulated_gpu_suite.sh` runs the whole -m gpu suite (minus
+the 2^20-row tests) — profiles/r5_emulated_device.md holds the round's record."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = os.path.join(ROOT, "tests", "emu", "dev")
+
+SUBSET = [
+    "tests/test_gpu_primitives.py",                                              # K1..K4 + the encodings, the grand-product scans (shuffles)
+    "tests/test_gpu_cs.py::test_ram_fixture_trace_bit_exact",                     # the reference's ram_permutation fixture
+    "tests/test_gpu_cs.py::test_ram_batch_of_instances",
+    "tests/test_gpu_cs.py::test_ram_unsatisfied_witnesses_are_rejected_like_the_oracle",
+    "tests/test_gpu_cs.py::test_copy_constraint_failures_name_the_pair",
+    "tests/test_gpu_cs.py::test_storage_validity_gpu_equals_oracle",
+    "tests/test_gpu_cs.py::test_demux_log_queue_gpu",
+    "tests/test_gpu_cs.py::test_sort_decommittment_requests_gpu",
+    "tests/test_gpu_cs.py::test_sha256_round_function_fsm_gpu",                   # macro-op SHA256_ROUNDS + the two-wavefront FSM seeder
+    "tests/test_queue_seed.py",                                                   # scan seeders: shuffles, DPP rows, ballots
+    "tests/test_ntt.py", "tests/test_copy_permutation.py",                        # K11 (LDS passes up to 2^22), K12 (scans)
+    "tests/test_gpu_main_vm.py::test_main_vm_gpu_bit_exact",                      # k_witness_loop on whole wavefronts: flag planes, gated permutations, wave-aggregated multiplicities
+]
+
+
+def build(variant="", defs=()):
+    env = dict(os.environ)
+    if variant:
+        env["EMU_VARIANT"] = variant
+    r = subprocess.run(["bash", os.path.join(DEV, "build.sh"), *defs], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return os.path.join(ROOT, "tests", "emu", "_gen", "dev" + ("_" + variant if variant else ""), "libzkgl.so")
+
+
+def run_gpu_tests(lib, nodes, jobs=6, timeout=1500):
+    env = dict(os.environ, ZKGL_LIB=lib)
+    env.pop("PYTEST_CURRENT_TEST", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-n", str(jobs), "-p", "no:cacheprovider", *nodes], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    tail = r.stdout[-4000:] + r.stderr[-2000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and " failed" not in r.stdout and " error" not in r.stdout, tail
+    return r.stdout
+
+
+def test_generator_rewrites_every_launch_and_nothing_else(tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(DEV, "gen_dev.py"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = open(os.path.join(ROOT, "era-zkevm_circuits_amd", "csrc", "zkgl_device.hip")).read()
+    gen = open(os.path.join(tmp_path, "src", "zkgl_device.cpp")).read()
+    assert "<<<" not in gen and gen.count("emu::launch(") == src.count("<<<") >= 70
+    # apart from the launches the device translation unit is the product's, line for line
+    a = [l for l in src.splitlines() if "<<<" not in l and ">>>" not in l]
+    b = [l for l in gen.splitlines()[1:] if "emu::launch(" not in l]
+    assert len(set(a) - set(b)) <= 8, sorted(set(a) - set(b))[:10]   # (continuation lines of multi-line launches)
+
+
+def test_gpu_parity_subset_on_the_emulated_device():
+    out = run_gpu_tests(build(), SUBSET)
+    n = int(out.strip().splitlines()[-1].split(" passed")[0].split()[-1])
+    assert n >= 80, out[-500:]
+
+
+def test_product_library_is_not_the_emulated_one():
+    import zkgl
+    assert not zkgl.emulated_device()

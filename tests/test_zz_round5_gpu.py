@@ -269,7 +269,14 @@ def run_bench(*args, timeout=600):
     return json.loads(lines[0])
 
 
+def _needs_hardware(zk):
+    # bench.py times a GPU through torch; on the emulated device of tests/emu (ZKGL_LIB = tests/emu/_gen/dev/libzkgl.so) there is nothing to time
+    if zk.emulated_device():
+        pytest.skip("bench.py needs the hardware: nothing to time on the emulated device")
+
+
 def test_one_gpu_line_carries_roofline_and_host_fed_figures(zk):
+    _needs_hardware(zk)
     d = run_bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "6", "--log2-rows", "16", "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["unit"] == "constraints/s"
     r = d["roofline"]
@@ -286,6 +293,7 @@ def test_one_gpu_line_carries_roofline_and_host_fed_figures(zk):
 
 def test_two_rank_launch_preflight(zk):
     import zkgl
+    _needs_hardware(zk)
     d = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--log2-rows", "16", "--no-cpu-baseline", "--headline-only")
     assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["config"]["per_rank_ms_per_step"]) == 2
     if zkgl.device_count() >= 2:
