@@ -3,10 +3,14 @@
 # re-written by gen_dev.py, compiled as host C++ over tests/emu/dev/hip/hip_runtime.h, linked with the fiber scheduler (emu_rt.cpp).
 #   -> tests/emu/_gen/dev/libzkgl.so (+ libzkgl_testcircuits.so beside it): load it with ZKGL_LIB=<that path>.  TEST INFRASTRUCTURE.
 # EMU_VARIANT=<name> with defs (e.g. EMU_VARIANT=p2m_binv build.sh -DZKGL_P2_MERGE -DZKGL_BATCH_INV): an opt-in build of tools/variants_r5.sh -> tests/emu/_gen/dev_<name>/
+# EMU_TSAN=1: the data-race detector build (emu_rt.cpp: every work-item a ThreadSanitizer fiber) -> tests/emu/_gen/dev_tsan/; run under
+#   LD_PRELOAD=/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so  (tools/emulated_race_check.sh)
 # EMU_OPT=-O2: the kernels' translation unit at -O2 (runs twice as fast, compiles in ~100 s instead of ~10) -> tests/emu/_gen/dev_O2/
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../../.." && pwd)
 OPT=${EMU_OPT:--O1}
+TSAN_CC=""; TSAN_LD=""
+if [ -n "${EMU_TSAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-tsan}; set -- "$@" -DEMU_TSAN=1; TSAN_CC="-fsanitize=thread"; TSAN_LD="-fsanitize=thread -shared-libsan"; fi
 GEN=$HERE/../_gen/dev${EMU_VARIANT:+_$EMU_VARIANT}; [ "$OPT" = "-O1" ] || GEN=${GEN}_${OPT#-}
 mkdir -p $GEN/obj $GEN/obj/testing
 python $HERE/gen_dev.py $GEN
@@ -19,13 +23,13 @@ cc() {  # $1 source, $2 object, $3 extra flags
   if [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ "$NEWEST_HDR" -nt "$2" ]; then $CXX $FLAGS ${3:-} -c "$1" -o "$2" & pids+=($!); fi
 }
 for f in $GEN/src/*.cpp $GEN/src/circuits/*.cpp; do
-  if [ $(basename $f) = zkgl_device.cpp ]; then cc $f $GEN/obj/$(basename $f).o $OPT   # the kernels
+  if [ $(basename $f) = zkgl_device.cpp ]; then cc $f $GEN/obj/$(basename $f).o "$OPT $TSAN_CC"   # the kernels
   else cc $f $GEN/obj/$(basename $f).o; fi
 done
 cc $HERE/emu_rt.cpp $GEN/obj/emu_rt.o -O2
 for f in $GEN/src/testing/*.cpp; do cc $f $GEN/obj/testing/$(basename $f).o; done
 for p in "${pids[@]}"; do wait $p || fails=1; done
 [ $fails = 0 ] || { echo "tests/emu/dev/build.sh: compilation failed"; exit 1; }
-$CXX -shared -fPIC -o $GEN/libzkgl.so $GEN/obj/*.o -lpthread
+$CXX -shared -fPIC $TSAN_LD -o $GEN/libzkgl.so $GEN/obj/*.o -lpthread
 $CXX -shared -fPIC -o $GEN/libzkgl_testcircuits.so $GEN/obj/testing/*.o -L$GEN -lzkgl -Wl,-rpath,'$ORIGIN'
 echo "built $GEN/libzkgl.so"

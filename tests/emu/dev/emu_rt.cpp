@@ -18,6 +18,30 @@
 #include <cstdio>
 #include <vector>
 
+// EMU_TSAN (tests/emu/dev/build.sh with EMU_TSAN=1): the kernels' translation unit is compiled with -fsanitize=thread and every work-item is a
+// ThreadSanitizer fiber.  Happens-before edges are exactly the device's: a wavefront operation orders the lanes that meet in it, __syncthreads
+// orders the workgroup, a launch is ordered after the previous launch.  Nothing else is: two work-items that touch one address without such
+// an edge between them (and without atomics) are reported as a data race — LDS exchanged on the strength of lockstep, two workgroups of a
+// launch writing one word, a kernel reading what its own launch writes elsewhere.  This file itself is NOT instrumented.
+#ifdef EMU_TSAN
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+void __tsan_acquire(void* addr);
+void __tsan_release(void* addr);
+void AnnotateBenignRaceSized(const char* file, int line, const volatile void* mem, long size, const char* desc);
+void AnnotateIgnoreReadsBegin(const char* file, int line);
+void AnnotateIgnoreReadsEnd(const char* file, int line);
+void AnnotateIgnoreWritesBegin(const char* file, int line);
+void AnnotateIgnoreWritesEnd(const char* file, int line);
+}
+extern char __start_emu_lds[], __stop_emu_lds[];
+#define TSAN(...) __VA_ARGS__
+#else
+#define TSAN(...)
+#endif
+
 namespace emu {
 
 enum State : int { READY, WAIT_WAVE, WAIT_BLOCK, DONE };
@@ -32,6 +56,8 @@ struct Fiber {
     const void* site = nullptr;
     int op = 0;
     uint64_t in = 0, aux = 0, aux2 = 0, out = 0;
+    void* tsan = nullptr;
+    bool ignoring = false;
 };
 
 thread_local Fiber* cur = nullptr;
@@ -72,10 +98,33 @@ emu_switch:
 .size emu_switch,.-emu_switch
 )");
 
-static void yield_to_scheduler() { emu_switch(&cur->sp, sched_sp); }
+#ifdef EMU_TSAN
+static void* sched_tsan = nullptr;
+static char launch_sync, launch_done, block_sync, block_start, block_done, wave_sync[16];
+// The workgroups of a launch run one after another on the same static LDS.  Two passes cover both kinds of race (EMU_TSAN_MODE):
+//   "lds"  (default) consecutive workgroups are ordered (the next one's LDS is new memory): races inside a workgroup — LDS and global — are found;
+//   "grid"           workgroups are NOT ordered and LDS is exempt: races between the workgroups of one launch on global memory are found.
+static bool grid_mode = false;
+#endif
+static void yield_to_scheduler() {
+    TSAN(__tsan_switch_to_fiber(sched_tsan, 1);)   // 1 = no synchronisation by the switch itself
+    emu_switch(&cur->sp, sched_sp);
+}
+
+void duplicate_lane(bool dup) {
+#ifdef EMU_TSAN
+    if (dup && !cur->ignoring) { AnnotateIgnoreReadsBegin(__FILE__, __LINE__); AnnotateIgnoreWritesBegin(__FILE__, __LINE__); cur->ignoring = true; }
+#else
+    (void)dup;
+#endif
+}
 
 static void fiber_entry() {
+    TSAN(__tsan_acquire(&launch_sync); if (!grid_mode) __tsan_acquire(&block_start);)
     body->run();
+    TSAN(if (!grid_mode) __tsan_release(&block_done);)
+    TSAN(if (cur->ignoring) { AnnotateIgnoreReadsEnd(__FILE__, __LINE__); AnnotateIgnoreWritesEnd(__FILE__, __LINE__); cur->ignoring = false; })
+    TSAN(__tsan_release(&launch_done);)
     cur->state = DONE;
     yield_to_scheduler();
     __builtin_trap();
@@ -93,6 +142,7 @@ static void prepare(Fiber& f) {
     for (int i = 0; i < 6; ++i) *--s = nullptr;
     f.sp = s;
     f.state = READY;
+    TSAN(if (!f.tsan) f.tsan = __tsan_create_fiber(0);)
 }
 
 uint64_t wave_op(int op, uint64_t in, uint64_t aux, uint64_t aux2) {
@@ -100,13 +150,17 @@ uint64_t wave_op(int op, uint64_t in, uint64_t aux, uint64_t aux2) {
     f->site = __builtin_return_address(0);
     f->op = op; f->in = in; f->aux = aux; f->aux2 = aux2;
     f->state = WAIT_WAVE;
+    TSAN(__tsan_release(&wave_sync[f->wave & 15]);)
     yield_to_scheduler();
+    TSAN(__tsan_acquire(&wave_sync[f->wave & 15]);)
     return f->out;
 }
 
 void sync_threads() {
     cur->state = WAIT_BLOCK;
+    TSAN(__tsan_release(&block_sync);)
     yield_to_scheduler();
+    TSAN(__tsan_acquire(&block_sync);)
 }
 
 // DPP controls the kernels use (kernels_vm_seed.hpp mov32<CTRL>): row_shr:n = 0x110 + n, row_shl:n = 0x100 + n, row_ror:n = 0x120 + n,
@@ -179,6 +233,7 @@ static void run_block(std::vector<Fiber>& fb, unsigned n_threads) {
                     Fiber& f = fb[t];
                     if (f.state != READY) continue;
                     cur = &f; t_idx = f.tidx; lane_in_wave = f.lane;
+                    TSAN(__tsan_switch_to_fiber(f.tsan, 1);)
                     emu_switch(&sched_sp, f.sp);
                     if (f.state == DONE) --live;
                 }
@@ -219,6 +274,20 @@ void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b) {
     dyn_lds = lds.data();
     body = &b;
     ++n_launches;
+#ifdef EMU_TSAN
+    static bool once = false;
+    if (!once) {
+        once = true;
+        const char* m = getenv("EMU_TSAN_MODE");
+        grid_mode = m && !strcmp(m, "grid");
+        if (grid_mode) AnnotateBenignRaceSized(__FILE__, __LINE__, __start_emu_lds, __stop_emu_lds - __start_emu_lds, "LDS of consecutive workgroups (grid mode)");
+    }
+    if (grid_mode && lds_bytes) {
+        static void* annotated = nullptr; static size_t annotated_size = 0;
+        if (annotated != lds.data() || annotated_size < lds.size()) { annotated = lds.data(); annotated_size = lds.size(); AnnotateBenignRaceSized(__FILE__, __LINE__, annotated, (long)annotated_size, "dynamic LDS (grid mode)"); }
+    }
+    sched_tsan = __tsan_get_current_fiber(); __tsan_release(&launch_sync);
+#endif
     b_dim = block; g_dim = grid;
     for (unsigned t = 0; t < n_threads; ++t) {
         fb[t].tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
@@ -229,8 +298,14 @@ void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b) {
             for (unsigned x = 0; x < grid.x; ++x) {
                 b_idx = dim3(x, y, z);
                 ++n_blocks;
+#ifdef EMU_TSAN   // a fresh workgroup's LDS: garbage as on the device
+                if (!grid_mode) __tsan_acquire(&block_done);
+                memset(__start_emu_lds, 0xCD, __stop_emu_lds - __start_emu_lds);
+                if (!grid_mode) __tsan_release(&block_start);
+#endif
                 run_block(fb, n_threads);
             }
+    TSAN(__tsan_acquire(&launch_done);)
     cur = nullptr; body = nullptr;
 }
 

@@ -29,7 +29,11 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
+#ifdef EMU_TSAN
+#define __shared__ __attribute__((section("emu_lds"))) static   // race-detector build: one process = one grid at a time; the scheduler knows where LDS is
+#else
 #define __shared__ static thread_local   // fibers of a workgroup share the OS thread
+#endif
 #define HIP_SYMBOL(x) (&(x))
 #define __noinline__ __attribute__((noinline))
 #define address_space(n)            /* __attribute__((address_space(4))) -> an empty attribute */
@@ -69,9 +73,15 @@ void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b);
 template <class F> inline void launch(dim3 grid, dim3 block, size_t lds_bytes, void* /*stream*/, const F& f) { launch_body(grid, block, lds_bytes, BodyOf<F>(f)); }
 template <class F> inline void launch(dim3 grid, dim3 block, const F& f) { launch_body(grid, block, 0, BodyOf<F>(f)); }
 void* alloc(size_t n);
+void duplicate_lane(bool dup);
 void release(void* p);
 }  // namespace emu
 
+#ifdef EMU_TSAN
+#define EMU_DUPLICATE_LANE(dup) emu::duplicate_lane(dup)
+#else
+#define EMU_DUPLICATE_LANE(dup) ((void)0)
+#endif
 #define threadIdx (emu::t_idx)
 #define blockIdx (emu::b_idx)
 #define blockDim (emu::b_dim)
@@ -112,15 +122,23 @@ using std::max;
 template <class A, class B> static inline auto min(A a, B b) -> typename std::common_type<A, B>::type { typedef typename std::common_type<A, B>::type T; return (T)a < (T)b ? (T)a : (T)b; }
 template <class A, class B> static inline auto max(A a, B b) -> typename std::common_type<A, B>::type { typedef typename std::common_type<A, B>::type T; return (T)a > (T)b ? (T)a : (T)b; }
 
-// ---- atomics (one OS thread runs the whole grid) ----
-template <class T, class U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
-template <class T, class U> static inline T atomicSub(T* p, U v) { T o = *p; *p = (T)(o - (T)v); return o; }
-template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
-template <class T, class U> static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
-template <class T, class U> static inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
-template <class T, class U> static inline T atomicAnd(T* p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }
-template <class T, class U> static inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
-template <class T, class U> static inline T atomicCAS(T* p, U cmp, U v) { T o = *p; if (o == (T)cmp) *p = (T)v; return o; }
+// ---- atomics (relaxed builtins: one OS thread runs the grid, but the race-detector build must see them as atomics) ----
+template <class T, class U> static inline T atomicAdd(T* p, U v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> static inline T atomicSub(T* p, U v) { return __atomic_fetch_sub(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> static inline T atomicOr(T* p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> static inline T atomicAnd(T* p, U v) { return __atomic_fetch_and(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> static inline T atomicExch(T* p, U v) { return __atomic_exchange_n(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> static inline T atomicCAS(T* p, U cmp, U v) { T e = (T)cmp; __atomic_compare_exchange_n(p, &e, (T)v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return e; }
+template <class T, class U> static inline T atomicMin(T* p, U v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while ((T)v < o && !__atomic_compare_exchange_n(p, &o, (T)v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+template <class T, class U> static inline T atomicMax(T* p, U v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while ((T)v > o && !__atomic_compare_exchange_n(p, &o, (T)v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
 
 // ---- buffer addressing: V# = a base address (the kernels use no bounds) ----
 struct emu_rsrc { char* base; };
@@ -128,7 +146,18 @@ typedef emu_rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) (emu_rsrc{(char*)(p)})
 typedef uint32_t emu_u32x2 __attribute__((ext_vector_type(2)));
 static inline emu_u32x2 emu_buffer_load_b64(emu_rsrc r, uint32_t voff, uint32_t soff) { emu_u32x2 v; memcpy(&v, r.base + (size_t)voff + (size_t)soff, 8); return v; }
+#ifdef EMU_TSAN
+// Race-detector build: a store of the value the cell already holds is not a write.  The witness kernels clamp the lanes beyond the batch to the
+// last valid lane (they redo its work and store the same values to the same cells: deterministic, and a write-write race by the letter);
+// a store of a DIFFERENT value to a cell another work-item wrote is reported as before.
+__attribute__((no_sanitize("thread"), noinline)) static bool emu_same_value(const char* p, emu_u32x2 v) { emu_u32x2 o; __builtin_memcpy(&o, p, 8); return o.x == v.x && o.y == v.y; }
+static inline void emu_buffer_store_b64(emu_u32x2 v, emu_rsrc r, uint32_t voff, uint32_t soff) {
+    char* p = r.base + (size_t)voff + (size_t)soff;
+    if (!emu_same_value(p, v)) memcpy(p, &v, 8);
+}
+#else
 static inline void emu_buffer_store_b64(emu_u32x2 v, emu_rsrc r, uint32_t voff, uint32_t soff) { memcpy(r.base + (size_t)voff + (size_t)soff, &v, 8); }
+#endif
 #define __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, aux) emu_buffer_load_b64((rsrc), (uint32_t)(voff), (uint32_t)(soff))
 #define __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, aux) emu_buffer_store_b64((v), (rsrc), (uint32_t)(voff), (uint32_t)(soff))
 
