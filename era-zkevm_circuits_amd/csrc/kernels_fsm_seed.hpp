@@ -36,6 +36,9 @@ __device__ __forceinline__ u64 ov(const FsmSeedDev& a, u32 inst, u32 slot) {
     return a.outer_store[zkgeom::offset(a.outer_n_store, slot, inst)];
 }
 
+// wavefront-scope fence + scheduling barrier: orders one wavefront's LDS traffic between its lanes (its DS instructions execute in order)
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
 // chain[0..12) = memory queue tail, chain[12..16) = request queue head; the events of one cycle, all lanes of the hasher wavefront
 __device__ __forceinline__ void run_events(u64* chain, const Events& ev, u32 lane, const u64 rcf[8]) {
     const u32 e = lane & 15;
@@ -57,8 +60,10 @@ __device__ __forceinline__ void run_events(u64* chain, const Events& ev, u32 lan
             h = zkvm::dpp::mov64<zkvm::dpp::SHR(4)>(s);              // new head = elements 0..3, kept on lanes 4..7
         }
     }
+    wave_sync();   // all 64 lanes have read chain[] above (with no event there is nothing else between that read and these writes)
     if (row0 && e < 12) chain[e] = x;
     if (row0 && e >= 4 && e < 8) chain[12 + e - 4] = h;
+    wave_sync();   // the callers read chain[12..15] on lanes 12..15, written here by lanes 4..7 (tests/emu race detector)
 }
 
 __device__ __forceinline__ void load_call(vmn::LogQ& q, const u64* raw) {   // flattened LogQuery, 36 words (log_query/mod.rs:60-99)
@@ -116,7 +121,6 @@ __device__ __forceinline__ void keccak_f(u64 (&A)[25]) {
 // Keccak-f[1600] on 25 lanes of one wavefront (lane = x + 5y holds A[x + 5y]), the cross-lane steps through LDS: a third of the single
 // lane's latency (14 k instructions there).  sh: 25 + 5 + 25 words of this wavefront's own.  Wavefront-scope fences order the LDS
 // traffic (one wavefront's DS instructions execute in order).
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ u64 keccak_f_lanes(u64 a, u32 lane, u64* sh) {
     constexpr int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     u64* const shA = sh, * const shC = sh + 25, * const shB = sh + 30;
