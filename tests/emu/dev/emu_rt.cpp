@@ -56,7 +56,7 @@ struct Fiber {
     const void* site = nullptr;
     int op = 0;
     uint64_t in = 0, aux = 0, aux2 = 0, out = 0;
-    void* tsan = nullptr;
+    void* tsan = nullptr;        // the detector's identity of this work-item
     bool ignoring = false;
 };
 
@@ -67,7 +67,6 @@ thread_local unsigned lane_in_wave = 0;
 
 static thread_local void* sched_sp = nullptr;
 static thread_local const Body* body = nullptr;
-static thread_local std::vector<Fiber>* fibers = nullptr;
 static thread_local unsigned long long n_divergent_sites = 0;
 static std::map<std::pair<const void*, const void*>, unsigned long long> divergent_pairs;   // (served first, left waiting) -> count
 static unsigned long long n_launches = 0, n_blocks = 0, n_wave_ops = 0;   // EMU_STATS=1: printed at exit
@@ -105,6 +104,7 @@ static char launch_sync, launch_done, block_sync, block_start, block_done, wave_
 //   "lds"  (default) consecutive workgroups are ordered (the next one's LDS is new memory): races inside a workgroup — LDS and global — are found;
 //   "grid"           workgroups are NOT ordered and LDS is exempt: races between the workgroups of one launch on global memory are found.
 static bool grid_mode = false;
+static bool grid_mode_enabled() { static const bool g = [] { const char* m = getenv("EMU_TSAN_MODE"); return m && !strcmp(m, "grid"); }(); return g; }
 #endif
 static void yield_to_scheduler() {
     TSAN(__tsan_switch_to_fiber(sched_tsan, 1);)   // 1 = no synchronisation by the switch itself
@@ -218,8 +218,7 @@ static void serve(Fiber** g, int n) {   // the lanes of one wavefront waiting at
     for (int k = 0; k < n; ++k) g[k]->state = READY;
 }
 
-static void run_block(std::vector<Fiber>& fb, unsigned n_threads) {
-    fibers = &fb;
+static void run_block(Fiber* fb, unsigned n_threads) {
     unsigned live = n_threads;
     const unsigned n_waves = (n_threads + 63) / 64;
     for (unsigned t = 0; t < n_threads; ++t) prepare(fb[t]);
@@ -269,7 +268,10 @@ void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b) {
     const unsigned n_threads = block.x * block.y * block.z;
     if (n_threads == 0 || (size_t)grid.x * grid.y * grid.z == 0) return;
     if (n_threads > 1024) { fprintf(stderr, "[emu] workgroup of %u work-items\n", n_threads); abort(); }
-    if (fb.size() < n_threads) fb.resize(n_threads);
+    // (race-detector build, grid mode: consecutive workgroups run on two disjoint sets of fibers — one identity and one stack would order them)
+    unsigned sets = 1;
+    TSAN(if (grid_mode_enabled()) sets = 2;)
+    if (fb.size() < (size_t)sets * n_threads) fb.resize((size_t)sets * n_threads);
     lds.assign(lds_bytes + 16, 0);
     dyn_lds = lds.data();
     body = &b;
@@ -278,8 +280,7 @@ void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b) {
     static bool once = false;
     if (!once) {
         once = true;
-        const char* m = getenv("EMU_TSAN_MODE");
-        grid_mode = m && !strcmp(m, "grid");
+        grid_mode = grid_mode_enabled();
         if (grid_mode) AnnotateBenignRaceSized(__FILE__, __LINE__, __start_emu_lds, __stop_emu_lds - __start_emu_lds, "LDS of consecutive workgroups (grid mode)");
     }
     if (grid_mode && lds_bytes) {
@@ -289,9 +290,10 @@ void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b) {
     sched_tsan = __tsan_get_current_fiber(); __tsan_release(&launch_sync);
 #endif
     b_dim = block; g_dim = grid;
-    for (unsigned t = 0; t < n_threads; ++t) {
-        fb[t].tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-        fb[t].lane = t & 63; fb[t].wave = t >> 6;
+    for (unsigned t = 0; t < sets * n_threads; ++t) {
+        const unsigned u = t % n_threads;
+        fb[t].tidx = dim3(u % block.x, (u / block.x) % block.y, u / (block.x * block.y));
+        fb[t].lane = u & 63; fb[t].wave = u >> 6;
     }
     for (unsigned z = 0; z < grid.z; ++z)
         for (unsigned y = 0; y < grid.y; ++y)
@@ -303,7 +305,7 @@ void launch_body(dim3 grid, dim3 block, size_t lds_bytes, const Body& b) {
                 memset(__start_emu_lds, 0xCD, __stop_emu_lds - __start_emu_lds);
                 if (!grid_mode) __tsan_release(&block_start);
 #endif
-                run_block(fb, n_threads);
+                run_block(fb.data() + (sets == 2 && (n_blocks & 1) ? n_threads : 0), n_threads);
             }
     TSAN(__tsan_acquire(&launch_done);)
     cur = nullptr; body = nullptr;
