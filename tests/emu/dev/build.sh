@@ -5,11 +5,14 @@
 # EMU_VARIANT=<name> with defs (e.g. EMU_VARIANT=p2m_binv build.sh -DZKGL_P2_MERGE -DZKGL_BATCH_INV): an opt-in build of tools/variants_r5.sh -> tests/emu/_gen/dev_<name>/
 # EMU_TSAN=1: the data-race detector build (emu_rt.cpp: every work-item a ThreadSanitizer fiber) -> tests/emu/_gen/dev_tsan/; run under
 #   LD_PRELOAD=/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so  (tools/emulated_race_check.sh)
+# EMU_ASAN=1: the address-sanitizer build (out-of-bounds / use-after-free in kernels: device buffers, LDS, local arrays) -> tests/emu/_gen/dev_asan/;
+#   run under LD_PRELOAD=.../libclang_rt.asan-x86_64.so  (tools/emulated_bounds_check.sh)
 # EMU_OPT=-O2: the kernels' translation unit at -O2 (runs twice as fast, compiles in ~100 s instead of ~10) -> tests/emu/_gen/dev_O2/
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../../.." && pwd)
 OPT=${EMU_OPT:--O1}
 TSAN_CC=""; TSAN_LD=""
+if [ -n "${EMU_ASAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-asan}; set -- "$@" -DEMU_ASAN=1; TSAN_CC="-fsanitize=address"; TSAN_LD="-fsanitize=address -shared-libsan"; fi
 if [ -n "${EMU_TSAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-tsan}; set -- "$@" -DEMU_TSAN=1; TSAN_CC="-fsanitize=thread"; TSAN_LD="-fsanitize=thread -shared-libsan"; fi
 GEN=$HERE/../_gen/dev${EMU_VARIANT:+_$EMU_VARIANT}; [ "$OPT" = "-O1" ] || GEN=${GEN}_${OPT#-}
 mkdir -p $GEN/obj $GEN/obj/testing

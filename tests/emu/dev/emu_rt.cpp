@@ -42,6 +42,19 @@ extern char __start_emu_lds[], __stop_emu_lds[];
 #define TSAN(...)
 #endif
 
+// EMU_ASAN (build.sh with EMU_ASAN=1): the kernels' translation unit under -fsanitize=address — out-of-bounds and use-after-free accesses of
+// device memory (every hipMalloc is its own heap block of the exact size), of LDS arrays and of kernel-local arrays.  The fiber switches are
+// announced to the runtime (it tracks the bounds of the current stack).
+#ifdef EMU_ASAN
+extern "C" {
+void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+}
+#define ASAN(...) __VA_ARGS__
+#else
+#define ASAN(...)
+#endif
+
 namespace emu {
 
 enum State : int { READY, WAIT_WAVE, WAIT_BLOCK, DONE };
@@ -58,6 +71,7 @@ struct Fiber {
     uint64_t in = 0, aux = 0, aux2 = 0, out = 0;
     void* tsan = nullptr;        // the detector's identity of this work-item
     bool ignoring = false;
+    void* asan_fake = nullptr;
 };
 
 thread_local Fiber* cur = nullptr;
@@ -106,9 +120,13 @@ static char launch_sync, launch_done, block_sync, block_start, block_done, wave_
 static bool grid_mode = false;
 static bool grid_mode_enabled() { static const bool g = [] { const char* m = getenv("EMU_TSAN_MODE"); return m && !strcmp(m, "grid"); }(); return g; }
 #endif
+ASAN(static const void* sched_stack_bottom = nullptr; static size_t sched_stack_size = 0;)
 static void yield_to_scheduler() {
     TSAN(__tsan_switch_to_fiber(sched_tsan, 1);)   // 1 = no synchronisation by the switch itself
-    emu_switch(&cur->sp, sched_sp);
+    Fiber* me = cur;
+    ASAN(__sanitizer_start_switch_fiber(me->state == DONE ? nullptr : &me->asan_fake, sched_stack_bottom, sched_stack_size);)
+    emu_switch(&me->sp, sched_sp);
+    ASAN(__sanitizer_finish_switch_fiber(me->asan_fake, &sched_stack_bottom, &sched_stack_size);)
 }
 
 void duplicate_lane(bool dup) {
@@ -120,6 +138,7 @@ void duplicate_lane(bool dup) {
 }
 
 static void fiber_entry() {
+    ASAN(__sanitizer_finish_switch_fiber(nullptr, &sched_stack_bottom, &sched_stack_size);)
     TSAN(__tsan_acquire(&launch_sync); if (!grid_mode) __tsan_acquire(&block_start);)
     body->run();
     TSAN(if (!grid_mode) __tsan_release(&block_done);)
@@ -233,7 +252,9 @@ static void run_block(Fiber* fb, unsigned n_threads) {
                     if (f.state != READY) continue;
                     cur = &f; t_idx = f.tidx; lane_in_wave = f.lane;
                     TSAN(__tsan_switch_to_fiber(f.tsan, 1);)
+                    ASAN(void* sched_fake = nullptr; __sanitizer_start_switch_fiber(&sched_fake, f.stack, STACK_BYTES);)
                     emu_switch(&sched_sp, f.sp);
+                    ASAN(__sanitizer_finish_switch_fiber(sched_fake, nullptr, nullptr);)
                     if (f.state == DONE) --live;
                 }
                 // every live lane is blocked: serve the wavefront operation at the lowest call site
@@ -344,6 +365,9 @@ void* alloc(size_t n) {
     if (!n) return nullptr;
     if (!n_allocs++ && getenv("EMU_STATS")) atexit(print_stats);
     n_alloc_bytes += n;
+#ifdef EMU_ASAN   // every allocation its own heap block of the exact size: the runtime's red zones and quarantine do the checking
+    { void* q = nullptr; if (posix_memalign(&q, 256, n)) return nullptr; memset(q, 0xCD, n); return q; }
+#endif
     const size_t cap = (n + 4095) & ~(size_t)4095;
     void* p = nullptr;
     {
@@ -361,6 +385,7 @@ void* alloc(size_t n) {
 }
 void release(void* p) {
     if (!p) return;
+    ASAN(free(p); return;)
     std::lock_guard<std::mutex> lock(alloc_mutex);
     auto it = block_size.find(p);
     if (it == block_size.end()) { fprintf(stderr, "[emu] hipFree of an address hipMalloc did not return\n"); abort(); }
