@@ -74,3 +74,17 @@ def test_gpu_parity_subset_on_the_emulated_device():
 def test_product_library_is_not_the_emulated_one():
     import zkgl
     assert not zkgl.emulated_device()
+
+
+SANITIZED = ["tests/test_gpu_primitives.py", "tests/test_gpu_cs.py::test_ram_fixture_trace_bit_exact", "tests/test_gpu_cs.py::test_storage_validity_gpu_equals_oracle",
+             "tests/test_queue_seed.py", "tests/test_copy_permutation.py"]
+
+
+@pytest.mark.skipif(not os.environ.get("ZKGL_EMU_SANITIZERS"), reason="two more builds of the emulated device (~2.5 min): set ZKGL_EMU_SANITIZERS=1; the round's full record is profiles/r5_emulated_device.md")
+@pytest.mark.parametrize("tool", ["emulated_race_check.sh", "emulated_bounds_check.sh"])
+def test_kernels_under_the_race_detector_and_the_bounds_check(tool, tmp_path):
+    """tools/emulated_race_check.sh (ThreadSanitizer fibers, the device's happens-before edges) / tools/emulated_bounds_check.sh (AddressSanitizer): no report"""
+    env = dict(os.environ, OUT=str(tmp_path), JOBS="6")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", tool), *SANITIZED], cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and " passed" in r.stdout and " failed" not in r.stdout, r.stdout[-3000:]
+    assert "reported: 0" in r.stdout, r.stdout[-3000:]

@@ -14,3 +14,4 @@ LD_PRELOAD=$RT TSAN_OPTIONS="halt_on_error=0 log_path=$OUT/report report_signal_
   python -m pytest -m gpu -q -p no:cacheprovider -n ${JOBS:-6} --timeout 6000 "$@" 2>&1 | tee $OUT/pytest.log | tail -3
 echo "data races reported: $(cat $OUT/report.* 2>/dev/null | grep -c 'WARNING: ThreadSanitizer')"
 cat $OUT/report.* 2>/dev/null | grep SUMMARY | sed 's/ (lib.*//; s#.*/src/##' | sort | uniq -c | sort -rn | head -40
+exit 0
