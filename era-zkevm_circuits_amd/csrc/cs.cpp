@@ -2186,26 +2186,41 @@ void CS::build_seed_program() {
     // (seed_cone_unsupported_; carry links would reject it anyway — a spurious UNSATISFIED, never unsoundness).
     {
         std::vector<uint32_t> taint(s.n_vars, UINT32_MAX);   // variable -> flag variable of the gated permutation it depends on (UINT32_MAX: clean; UINT32_MAX - 1: several)
+        const uint32_t SEVERAL = UINT32_MAX - 1;
         bool any_gated = false;
         for (auto& op : sops_store) {
-            if (op.seed_only) continue;
-            if (op.opcode == ZK_OP_POSEIDON2 && op.a == 1 && op.ins.size() == 13 && op.ins[12].kind == Operand::VAR) {
-                for (uint32_t ov : op.outs) taint[ov] = op.ins[12].idx;
-                any_gated = true;
-                continue;
-            }
-            if (!any_gated) continue;
+            // (seed_only hint ops are part of the cone: they propagate taint like any other op — ADVICE r5)
             uint32_t t = UINT32_MAX;
-            auto join = [&](uint32_t x) { if (x == UINT32_MAX) return; t = (t == UINT32_MAX || t == x) ? x : UINT32_MAX - 1; };
-            if (op.opcode == ZK_OP_SELECT && op.ins.size() == 3 && op.ins[0].kind == Operand::VAR) {
-                const uint32_t f = op.ins[0].idx;
-                join(taint[f]);                                                               // a tainted selector taints the result
-                if (op.ins[1].kind == Operand::VAR && taint[op.ins[1].idx] != f) join(taint[op.ins[1].idx]);   // flag-on side: clean when tainted by THIS flag
-                if (op.ins[2].kind == Operand::VAR) join(taint[op.ins[2].idx]);                // flag-off side: always propagates
+            auto join = [&](uint32_t x) { if (x == UINT32_MAX) return; t = (t == UINT32_MAX || t == x) ? x : SEVERAL; };
+            if (op.opcode == ZK_OP_POSEIDON2 && op.a == 1) {
+                any_gated = true;
+                // a flag that is not a variable (pool constant), or a malformed operand list: nothing to reason about -> not offered
+                if (op.ins.size() != 13 || op.ins[12].kind != Operand::VAR) { t = SEVERAL; }
+                else {
+                    // where the flag f is off the ungated cone computes P(state) while the trace holds zeros: the outputs are tainted by f.
+                    // A state input (or the flag) already tainted by ANOTHER flag g makes the ungated value wrong also where f is on and g
+                    // is off (chained gated permutations under different flags): 'several'.  Tainted by f itself: still exactly "wrong where f is off".
+                    const uint32_t f = op.ins[12].idx;
+                    for (auto& in : op.ins) if (in.kind == Operand::VAR) join(taint[in.idx]);
+                    t = (t == UINT32_MAX || t == f) ? f : SEVERAL;
+                }
             } else {
-                for (auto& in : op.ins) if (in.kind == Operand::VAR) join(taint[in.idx]);
+                if (!any_gated) continue;
+                if (op.opcode == ZK_OP_SELECT && op.ins.size() == 3 && op.ins[0].kind == Operand::VAR) {
+                    const uint32_t f = op.ins[0].idx;
+                    join(taint[f]);                                                               // a tainted selector taints the result
+                    if (op.ins[1].kind == Operand::VAR && taint[op.ins[1].idx] != f) join(taint[op.ins[1].idx]);   // flag-on side: clean when tainted by THIS flag
+                    if (op.ins[2].kind == Operand::VAR) join(taint[op.ins[2].idx]);                // flag-off side: always propagates
+                } else {
+                    for (auto& in : op.ins) if (in.kind == Operand::VAR) join(taint[in.idx]);
+                }
             }
-            if (t != UINT32_MAX) for (uint32_t ov : op.outs) taint[ov] = t;
+            // a variable written by a hint AND by its gate-by-gate producers keeps the join of both (the cone may use either)
+            for (uint32_t ov : op.outs) {
+                const uint32_t prev = taint[ov];
+                if (t == UINT32_MAX) continue;
+                taint[ov] = (prev == UINT32_MAX || prev == t) ? t : SEVERAL;
+            }
         }
         uint32_t bad = 0;
         for (uint32_t v : out_vars) bad += taint[v] != UINT32_MAX;
@@ -3613,12 +3628,14 @@ void CS::stats(zk_stats* o) const {
         uint64_t n = 0;
         for (size_t gi = 0; gi < s.gates.size(); ++gi)
             if (gi >= s.gate_mirrored.size() || !s.gate_mirrored[gi]) n += GATES[s.gates[gi].kind].n_relations;
+        for (auto& l : s.lookups) n += l.owner < 0;   // a tuple nobody's witness op evaluates stays in the fused check program (lookup_given outside a macro window)
         return n;
     };
     const bool fused_ok = !outer_.cprog_fused.empty() && (!limit_ || !loop_.cprog_fused.empty());
     o->constraints_from_store_fused = fused_ok ? from_store(outer_) + from_store(loop_) * limit_ : o->constraints_per_instance;
     o->constraints_in_witness_fused = o->constraints_per_instance - o->constraints_from_store_fused;
     o->values_below_2_32_outer = outer_.values_below_2_32; o->values_below_2_32_loop = loop_.values_below_2_32;
+    o->seed_cone_unsupported = seed_cone_unsupported_;
 }
 
 float CS::last_ms(int which) const {

@@ -296,8 +296,8 @@ class CS {
     void place_scope(Scope& s);
     std::vector<OpRec> loop_ops_recorded_;   // the loop body as recorded (build_seed_program)
     void schedule_loop_ops();
-    void chain_selects();
-    void bundle_gated_permutations();   // opt-in: the links of one mux chain become consecutive ops (cs.cpp)
+    void chain_selects();               // opt-in: the links of one mux chain become consecutive ops (cs.cpp)
+    void bundle_gated_permutations();   // opt-in: the gated witness-only permutations of one dependency level under one header (cs.cpp)
     void schedule_by_locality(const std::vector<double>& a, const std::vector<double>& m, double a_tot, double m_tot,
                               const std::vector<std::vector<uint32_t>>& succ, std::vector<uint32_t>& n_pred);
     void emit_scope(Scope& s);

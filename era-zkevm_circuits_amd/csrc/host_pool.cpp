@@ -3,6 +3,7 @@
 // closures `Send + Sync`, src/base_structures/memory_query/mod.rs:236).  zk_parallel_for is that pool behind the C ABI: a caller (Rust, C,
 // ctypes) hands it a plain function that packs instance `job`; zk_pack_main_vm_witness_batch is the array form for the headline circuit.
 #include <atomic>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -27,11 +28,14 @@ int run_jobs(uint32_t n_jobs, uint32_t n_threads, uint32_t* first_failed, F&& jo
     int rc_first = ZK_OK;
     uint32_t job_first = UINT32_MAX;
     std::string err_first;
-    auto worker = [&] {
+    auto worker = [&]() noexcept {
         for (;;) {
             const uint32_t j = next.fetch_add(1, std::memory_order_relaxed);
             if (j >= n_jobs) return;
-            const int rc = job(j);
+            int rc;
+            try { rc = job(j); }   // nothing may leave a worker thread (std::terminate) or, on the caller's thread, the extern "C" entry
+            catch (const std::exception& e) { zkgl::set_last_error(e.what()); rc = (int)ZK_ERR_INVALID; }
+            catch (...) { zkgl::set_last_error("job threw"); rc = (int)ZK_ERR_INVALID; }
             if (rc != ZK_OK) {   // the lowest failing job wins, whatever the interleaving; the other jobs still run (they are independent)
                 std::lock_guard<std::mutex> g(mu);
                 if (j < job_first) { job_first = j; rc_first = rc; err_first = zk_last_error(); }   // zk_last_error is per thread: take it here
@@ -42,7 +46,11 @@ int run_jobs(uint32_t n_jobs, uint32_t n_threads, uint32_t* first_failed, F&& jo
     else {
         std::vector<std::thread> ts;
         ts.reserve(n_threads - 1);
-        for (uint32_t t = 1; t < n_threads; ++t) ts.emplace_back(worker);
+        // thread creation can fail (std::system_error: thread limit, cgroup pids): carry on with the threads that did start — the caller's
+        // thread works too, every job still runs — and join them; nothing crosses the C ABI as an exception
+        try {
+            for (uint32_t t = 1; t < n_threads; ++t) ts.emplace_back(worker);
+        } catch (...) {}
         worker();
         for (auto& t : ts) t.join();
     }

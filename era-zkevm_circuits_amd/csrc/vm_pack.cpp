@@ -299,7 +299,9 @@ extern "C" int zk_pack_main_vm_witness_states(zk_cs* h, const zk_vm_closed_form_
     const uint32_t limit = cs.limit();
     const bool chains_on = (flags & ZK_VM_PACK_FILL_STATE) != 0;
     const bool oracle_only = (flags & ZK_VM_PACK_ORACLE_WORDS_ONLY) != 0;
-    if (oracle_only && chains_on) return bad("zk_pack_main_vm_witness: ORACLE_WORDS_ONLY leaves the state rows to the device seeder; it excludes FILL_STATE / STATES_FROM_WITNESS");
+    if (oracle_only && from) return bad("zk_pack_main_vm_witness: ORACLE_WORDS_ONLY excludes STATES_FROM_WITNESS (reading the states means writing the state rows, which this form does not ship)");
+    if (oracle_only && chains_on) return bad("zk_pack_main_vm_witness: ORACLE_WORDS_ONLY leaves the state rows to the device seeder; it excludes FILL_STATE");
+    if (oracle_only && cs.loop_input_words() <= (uint32_t)vmn::STATE_WORDS) return bad("zk_pack_main_vm_witness: ORACLE_WORDS_ONLY needs a loop layout with oracle rows behind the VmLocalState");
     if (oracle_only && cs.layout_word("loop", "state") != 0) return bad("zk_pack_main_vm_witness: the recorded layout does not start with the VmLocalState");
     std::memset(report, 0, sizeof *report);
 
@@ -315,6 +317,8 @@ extern "C" int zk_pack_main_vm_witness_states(zk_cs* h, const zk_vm_closed_form_
     for (auto& f : fields) {
         *f.dst = cs.layout_word("loop", f.name);
         if (*f.dst == UINT32_MAX) return bad("zk_pack_main_vm_witness: the recorded layout lacks an oracle field");
+        // ORACLE_WORDS_ONLY ships rows [STATE_WORDS, n) only: an oracle field recorded in front of them would be dropped silently
+        if (oracle_only && *f.dst < (uint32_t)vmn::STATE_WORDS) return bad("zk_pack_main_vm_witness: ORACLE_WORDS_ONLY needs every oracle field behind the VmLocalState rows of the recorded layout");
     }
     // ---- outer stream: VmCircuitInputOutput::alloc_ignoring_outputs order (circuits/main_vm.cpp entry_point)
     auto outer = [&](const char* name, uint32_t i, u64 v) {

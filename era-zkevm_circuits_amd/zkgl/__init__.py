@@ -70,7 +70,8 @@ class _Stats(C.Structure):
                 ("cells_populated_outer", C.c_uint64), ("cells_populated_loop", C.c_uint64),
                 ("loop_store_tile_lanes", C.c_uint64),
                 ("constraints_from_store_fused", C.c_uint64), ("constraints_in_witness_fused", C.c_uint64),
-                ("values_below_2_32_outer", C.c_uint64), ("values_below_2_32_loop", C.c_uint64)]
+                ("values_below_2_32_outer", C.c_uint64), ("values_below_2_32_loop", C.c_uint64),
+                ("seed_cone_unsupported", C.c_uint64)]
 
 
 _lib = None

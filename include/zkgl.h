@@ -307,6 +307,9 @@ typedef struct zk_stats {
      * boolean / constant gates, non-wrapping reductions and products of bounded terms, selections by a boolean selector) — what a store
      * with 4-byte slots could hold in half the bytes */
     uint64_t values_below_2_32_outer, values_below_2_32_loop;
+    /* 1: the seed kernels are not offered this circuit's cone (zk_cs_seed_* answers ZK_ERR_INVALID unless a native seeder is registered):
+     * it holds ZK_OP_BYTEBUF_FILL, or a carried output depends on a gated ZK_OP_POSEIDON2 other than through a select on that op's flag */
+    uint64_t seed_cone_unsupported;
 } zk_stats;
 /* K12 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
  * column chunking and cell identifiers are [EXT], the argument is defined in csrc/kernels_perm.hpp).  Labels: outer-scope

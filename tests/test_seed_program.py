@@ -74,3 +74,44 @@ def _gated_chain(select_on_flag: bool):
 
 
 # (GPU test of the two circuits above: tests/test_zz_round5_gpu.py)
+
+
+def _two_gated_permutations(flags_differ: bool, const_flag: bool = False):
+    """A gated by f feeds B gated by g, then select(g, B.out, acc): with g = 1, f = 0 the ungated cone would compute P(P(in)) where the trace
+    holds P(0 ..): the taint of B's state inputs must survive B.  Same flag twice is the reference's own chain shape (the
+    3-permutation log push under one `execute`, /root/reference/src/main_vm/opcodes/log.rs:532-595) and stays clean."""
+    from helpers import LINK, Rec
+    from zkgl import GATE as G, OP
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(60, 0, 8, 4))
+    for k in ("CONST", "BOOLEAN", "FMA", "SELECT", "PUBLIC_INPUT"):
+        cs.allow_gate(G[k])
+    r = Rec(cs)
+    start = r.inp()
+    cs.loop_begin(5)
+    r.n_in = 0
+    acc_in = r.inp()
+    cs.link(LINK["FIRST"], acc_in, start)
+    f = r.inp()
+    g = r.inp() if flags_differ else f
+    cs.place_gate(G["BOOLEAN"], [f])
+    if flags_differ:
+        cs.place_gate(G["BOOLEAN"], [g])
+    one = r.const(1)
+    a_out = cs.alloc_multiple_variables_without_values(12)
+    cs.emit_op(OP["POSEIDON2"], [acc_in] + [one] * 11 + [one if const_flag else f], a_out, a=1)
+    b_out = cs.alloc_multiple_variables_without_values(12)
+    cs.emit_op(OP["POSEIDON2"], list(a_out) + [g], b_out, a=1)
+    nxt = r.select(g, b_out[0], acc_in)
+    cs.link(LINK["CARRY"], acc_in, nxt)
+    cs.loop_end()
+    cs.place_gate(G["PUBLIC_INPUT"], [cs.loop_last(nxt)])
+    cs.pad_and_shrink()
+    return cs
+
+
+def test_cone_taint_survives_a_gated_permutation_under_another_flag():
+    assert _gated_chain(True).stats()["seed_cone_unsupported"] == 0
+    assert _gated_chain(False).stats()["seed_cone_unsupported"] == 1
+    assert _two_gated_permutations(False).stats()["seed_cone_unsupported"] == 0      # one flag: wrong exactly where the select looks away
+    assert _two_gated_permutations(True).stats()["seed_cone_unsupported"] == 1       # two flags: g on, f off reads P(P(in)) for P(0)
+    assert _two_gated_permutations(False, const_flag=True).stats()["seed_cone_unsupported"] == 1   # a flag that is no variable: not reasoned about
