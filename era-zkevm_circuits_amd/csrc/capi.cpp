@@ -390,6 +390,15 @@ int zk_cs_complete_store(zk_cs* cs, void* stream) {
     NEED(cs); NEED_INIT();
     return guard([&] { cs->cs->ensure_p2_filled(stream); });
 }
+int zk_cs_narrow_byte_input_words(zk_cs* cs, uint32_t* buf, size_t max_words, size_t* n_words) {
+    NEED(cs);
+    if (!n_words) return fail(ZK_ERR_INVALID, "zk_cs_narrow_byte_input_words: null count");
+    return guard([&] {
+        const std::vector<uint32_t> w = cs->cs->narrow_byte_input_words();
+        *n_words = w.size();
+        if (buf) { if (max_words < w.size()) throw zkgl::ZkError(ZK_ERR_CAPACITY, "zk_cs_narrow_byte_input_words: buffer too small"); std::copy(w.begin(), w.end(), buf); }
+    });
+}
 int zk_cs_check_satisfied(zk_cs* cs, void* stream, zk_failure* first) {
     NEED(cs); NEED_INIT();
     int result = ZK_OK;

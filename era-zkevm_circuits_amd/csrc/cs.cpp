@@ -86,7 +86,10 @@ CS::~CS() {
     if (d_mult_) hipFree(d_mult_);
     if (d_links_) hipFree(d_links_);
     if (d_links_store_) hipFree(d_links_store_);
+    if (d_links_store_n_) hipFree(d_links_store_n_);
+    if (d_loop_last_slots_) hipFree(d_loop_last_slots_);
     for (auto p : d_streams_store_) if (p) hipFree(p);
+    for (auto p : d_streams_store_n_) if (p) hipFree(p);
     if (d_public_slots_) hipFree(d_public_slots_);
     if (d_seed_prog_) hipFree(d_seed_prog_);
     if (d_seed_wprog_) hipFree(d_seed_wprog_);
@@ -142,6 +145,11 @@ void CS::free_scope_device(Scope& s) {
     s.d_mat_pairs = nullptr;
     if (s.d_store) hipFree(s.d_store);
     s.d_store = nullptr;
+    if (s.d_store_n) hipFree(s.d_store_n);
+    if (s.d_prog2n) hipFree(s.d_prog2n);
+    if (s.d_cprog_fused_n) hipFree(s.d_cprog_fused_n);
+    if (s.d_slot_aw) hipFree(s.d_slot_aw);
+    s.d_store_n = nullptr; s.d_prog2n = nullptr; s.d_cprog_fused_n = nullptr; s.d_slot_aw = nullptr;
     if (s.d_cells) hipFree(s.d_cells);
     s.d_prog = nullptr; s.d_prog2 = nullptr; s.d_cprog = nullptr; s.d_cchunks = nullptr; s.d_cprog_full = nullptr; s.d_cchunks_full = nullptr; s.d_cmacros = nullptr; s.d_mult_sites = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
     s.d_copies = nullptr; s.d_cells = nullptr;
@@ -977,6 +985,72 @@ void CS::bound_values(Scope& s) {
                 s.is_loop ? "loop" : "outer", s.values_below_2_32, s.n_vars, s.values_below_2_8);
 }
 
+// NARROW STORE of the loop scope (store_geom.hpp; opt-in: ZKGL_NARROW_STORE=1 at finalize).  bound_values says which variables are bytes in
+// every satisfying witness; a byte-class value takes ONE unit of its wavefront's tile (one byte per lane) instead of eight.  The class is a
+// storage decision of the host: a variable is byte-class only when (a) its bound is <= 2^8, (b) the op producing it is one whose handler in the
+// narrow kernel stores through the class word (narrow_capable), (c) it is among the first 31 outputs of its op.  A witness that puts a larger
+// value there is unsatisfiable; the kernel reports the overflow as the fused mode's failure and the step is repeated over the ordinary store
+// (CS::resolve_and_check), so verdicts and reported gates are those of the ordinary store.  Units are assigned in slot (= production) order,
+// no padding: a wavefront still streams its results out front to back.
+static bool narrow_capable(uint32_t opcode) {
+    switch (opcode) {
+    case ZK_OP_CONST: case ZK_OP_INPUT: case ZK_OP_FMA: case ZK_OP_LC4: case ZK_OP_SELECT: case ZK_OP_ISZERO: case ZK_OP_UADD: case ZK_OP_USUB:
+    case ZK_OP_SPLIT: case ZK_OP_LOOKUP: case ZK_OP_DIVREM: case ZK_OP_U8X4FMA: return true;
+    default: return false;
+    }
+}
+void CS::build_narrow_layout(Scope& s) {
+    s.narrow_ok = false; s.slot_aw.clear(); s.narrow_units = 0; s.narrow_byte_values = 0;
+    narrow_enabled_ = false;
+    const char* e = getenv("ZKGL_NARROW_STORE");
+    if (!(e && e[0] == '1') || !s.is_loop || !limit_ || s.uses_bigint) return;
+#if defined(ZKGL_P2_MERGE) || defined(ZKGL_BATCH_INV) || defined(ZKGL_SELECT_CHAINS_KERNEL)
+    return;   // (variant builds re-decode headers: the class words are indexed by decoded headers)
+#endif
+    for (auto& op : s.ops)   // macro-ops stream their outputs through their own store paths (and their circuits run in strand form)
+        if (!op.seed_only && (op.opcode == ZK_OP_KECCAK_F || op.opcode == ZK_OP_SHA256_ROUNDS || op.opcode == ZK_OP_BYTEBUF_FILL || op.opcode == ZK_OP_NN_MULMOD)) return;
+    std::vector<uint8_t> is_byte(s.n_store, 0);
+    for (auto& op : s.ops) {
+        if (op.seed_only || !narrow_capable(op.opcode)) continue;
+        for (size_t q = 0; q < op.outs.size() && q < 31; ++q)
+            if (s.value_class[op.outs[q]] == 2) is_byte[s.var_slot[op.outs[q]]] = 1;
+    }
+    s.slot_aw.assign(s.n_store, 0);
+    uint64_t unit = 0;
+    for (uint32_t slot = 0; slot < s.n_store; ++slot) {
+        if (unit >= zkgeom::AW_MASK - 8) { s.slot_aw.clear(); return; }   // (a tile beyond 2^28 units: 64-bit addressing anyway)
+        s.slot_aw[slot] = (uint32_t)unit | (is_byte[slot] ? zkgeom::AW_BYTE : 0u);
+        unit += is_byte[slot] ? 1 : 8;
+        s.narrow_byte_values += is_byte[slot];
+    }
+    s.narrow_units = (uint32_t)unit;
+    if (getenv("ZKGL_PROG_STATS"))
+        fprintf(stderr, "[zkgl] loop scope narrow store: %u of %u values in one-byte slots, %u B per lane instead of %u (%.3f)\n", s.narrow_byte_values, s.n_store, s.narrow_units,
+                s.n_store * 8, (double)s.narrow_units / (8.0 * s.n_store));
+}
+// the fused check program over the narrow store: the same packets (kinds, counts, rows, constants, chunk table) with address words for the slots
+void CS::build_narrow_check_program(Scope& s) {
+    s.cprog_fused_n.clear();
+    if (s.slot_aw.empty() || s.prog2n.empty() || s.cprog_fused.empty()) { s.slot_aw.clear(); s.prog2n.clear(); return; }
+    const std::vector<uint32_t>& src = s.cprog_fused;
+    std::vector<uint32_t> out(src);
+    size_t pc = 0;
+    if (!(src.size() == 1 && src[0] == 0))   // (an empty program is the single word 0)
+        while (pc < src.size()) {
+            const uint32_t kind = src[pc] & 0xff, cnt = (src[pc] >> 8) & 0xff;
+            const uint32_t w = kind == 0x40u ? 4u : (kind < ZK_GATE__COUNT ? GATES[kind].width : 0u);
+            if (!w || !cnt || pc + 3 + (size_t)cnt * w > src.size()) throw ZkError(ZK_ERR_INVALID, "internal: malformed fused check program");
+            for (size_t q = pc + 3; q < pc + 3 + (size_t)cnt * w; ++q) {
+                if (src[q] >= s.slot_aw.size()) throw ZkError(ZK_ERR_INVALID, "internal: fused check program names a slot outside the store");
+                out[q] = s.slot_aw[src[q]];
+            }
+            pc += 3 + (size_t)cnt * w;
+        }
+    s.cprog_fused_n = std::move(out);
+    s.narrow_ok = true;
+    narrow_enabled_ = true;
+}
+
 // Lookup sites of a scope grouped by table (k_multiplicities): the key slots of every recorded lookup
 void CS::build_mult_sites(Scope& s) {
     const size_t nt = tables_.size() + 1;  // table ids are 1-based
@@ -1736,6 +1810,14 @@ void CS::verify_device_programs(const Scope& s) const {
 }
 
 // phase 0 = loop body / outer pre, 1 = outer side, 2 = outer post
+bool CS::loop_runs_strands(const Scope& s, int phase, uint32_t n_lanes) const {
+    const char* e = getenv("ZKGL_STRANDS");
+    const int mode = e ? atoi(e) : -1;
+    const uint32_t waves = (n_lanes + 63) / 64;
+    const bool have = uploaded_ ? s.d_sprog != nullptr : !s.sprog.empty();
+    return have && mode != 0 && (mode == 1 || (waves <= 4 * (uint32_t)device_cu_count() && s.s_gain[phase] >= (waves <= (uint32_t)device_cu_count() / 4 ? 1.5f : 3.2f)));
+}
+
 void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream, uint32_t n_lanes) const {
     const char* e = getenv("ZKGL_STRANDS");  // 0 off, 1 always, unset: by size and estimated gain
     const int mode = e ? atoi(e) : -1;
@@ -1754,9 +1836,11 @@ void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* strea
             else { w0 = s.side_words2; slot0 = s.side_slots; }
         }
         a.prog = s.d_prog2; a.n_words = end;
+        if (a.cls) { a.prog = s.d_prog2n; a.cls = s.d_prog2n + s.cls_off; }   // narrow store (resolve_and_check): same words, address-word operands, class words behind
         dev_check(zkdev::launch_witness(a, w0, w1, slot0, stream));
         return;
     }
+    if (a.cls) throw ZkError(ZK_ERR_INVALID, "internal: the narrow store was bound for a batch whose loop launch takes the strand form (ZKGL_STRANDS changed after zk_cs_set_batch?)");
     // Strands per tile: 16 wavefronts of a tile share its levels' work, but only two such workgroups fit a CU; a loop scope with more
     // tiles than that (keccak FSM at 128 instances: 672 tiles on 256 CUs) runs them in rounds.  The narrow form (8 strands: four
     // workgroups per CU) keeps every tile resident: keccak FSM 23.7 -> 20.8 ms; eip_4844 (120 tiles) is 1.24 x slower with it and
@@ -1786,7 +1870,7 @@ void CS::operand_v2(const Scope& s, const OpRec& op, size_t pos, std::vector<uin
         if (in.kind == Operand::CONSTPOOL) out.push_back(ZK_OPERAND_CONST | in.idx);
         else if (in.kind == Operand::OUTER_VAR) out.push_back(ZK_OPERAND_OUTER | outer_.var_slot[in.idx]);
         else throw ZkError(ZK_ERR_INVALID, "internal: ZK_OP_CONST of a variable");
-    } else if (in.kind == Operand::VAR) out.push_back(s.var_slot[in.idx]);
+    } else if (in.kind == Operand::VAR) out.push_back(narrow_emit_ ? (*narrow_emit_)[s.var_slot[in.idx]] : s.var_slot[in.idx]);   // narrow form: the value's address word
     else if (in.kind == Operand::RAW) out.push_back(op.opcode == ZK_OP_LOOP_LAST ? loop_.var_slot[in.idx] : in.idx);
     else throw ZkError(ZK_ERR_INVALID, "internal: pool constant / outer value in a data operand position");
 }
@@ -1902,9 +1986,16 @@ void CS::emit_scope(Scope& s) {
     }
     if (!s.is_loop && s.pre_ops >= s.ops.size()) s.pre_words_full = (uint32_t)s.prog_full.size();
     // ---- the two device forms
-    for (int form = 1; form <= 2; ++form) {
-        const bool v2 = form == 2;
-        std::vector<uint32_t>& out = v2 ? s.prog2 : s.prog;
+    // form 3 (loop scopes with a narrow layout, build_narrow_layout): the v2 form again with address words in the data operand positions,
+    // and one CLASS WORD per header behind the program (bit k: the header's k-th output is a byte-class value) — same ops, same groups
+    s.prog2n.clear(); s.cls_off = 0;
+    std::vector<uint32_t> cls_words;
+    std::vector<uint8_t> slot_is_byte;
+    if (s.is_loop && !s.slot_aw.empty()) { slot_is_byte.resize(s.slot_aw.size()); for (size_t q = 0; q < s.slot_aw.size(); ++q) slot_is_byte[q] = (s.slot_aw[q] & zkgeom::AW_BYTE) != 0; }
+    for (int form = 1; form <= (slot_is_byte.empty() ? 2 : 3); ++form) {
+        const bool v2 = form >= 2, nform = form == 3;
+        std::vector<uint32_t>& out = nform ? s.prog2n : v2 ? s.prog2 : s.prog;
+        narrow_emit_ = nform ? &s.slot_aw : nullptr;
         std::vector<uint32_t> produced_in_group(s.n_vars, UINT32_MAX);  // var -> id of the open group that produces it
         uint32_t group_id = 0, slots_done = 0;
         std::vector<size_t> group;  // op indices of the open group
@@ -1940,6 +2031,12 @@ void CS::emit_scope(Scope& s) {
             const bool counted = group_cap(first, v2) > 1 || first.opcode == ZK_OP_INPUT || first.opcode == ZK_OP_SELECT || first.opcode == ZK_OP_FMA ||
                                  first.opcode == ZK_OP_LC4 || (v2 && first.opcode == ZK_OP_U32MULADD);
             emit_chain_ = group_is_chain;
+            if (nform) {   // class word of this header: outputs in the order the kernel stores them (members in order, each member's outputs in order)
+                uint32_t mask = 0, k = 0;
+                for (size_t oi : group)
+                    for (uint32_t ov : s.ops[oi].outs) { if (slot_is_byte[s.var_slot[ov]]) { if (k >= 32) throw ZkError(ZK_ERR_INVALID, "internal: byte-class output beyond the class word"); mask |= 1u << k; } ++k; }
+                cls_words.push_back(mask);
+            }
             if (v2) emit_group_v2(s, group, counted, out);
             else if (first.opcode == ZK_OP_LOOKUP) {
                 out.push_back((uint32_t)ZK_OP_LOOKUP | ((uint32_t)first.a << 8) | (((uint32_t)first.b | ((uint32_t)(n - 1) << 8)) << 16));
@@ -1987,7 +2084,8 @@ void CS::emit_scope(Scope& s) {
                     for (size_t at = 0; at < plane_pending.size(); at += 7) {
                         const size_t nn = std::min<size_t>(7, plane_pending.size() - at);
                         out.push_back((uint32_t)ZK_OP_FLAG_PLANES | ((uint32_t)(nn - 1) << 16));
-                        for (size_t k = 0; k < nn; ++k) { out.push_back(s.var_slot[plane_pending[at + k]]); out.push_back(plane_of[plane_pending[at + k]]); plane_saved[plane_pending[at + k]] = 1; }
+                        if (nform) cls_words.push_back(0);   // a header without outputs
+                        for (size_t k = 0; k < nn; ++k) { out.push_back(nform ? s.slot_aw[s.var_slot[plane_pending[at + k]]] : s.var_slot[plane_pending[at + k]]); out.push_back(plane_of[plane_pending[at + k]]); plane_saved[plane_pending[at + k]] = 1; }
                     }
                     plane_pending.clear();
                     if (!plane_saved[fv]) throw ZkError(ZK_ERR_INVALID, "internal: SELECT flag not produced before its use");
@@ -2012,6 +2110,14 @@ void CS::emit_scope(Scope& s) {
         }
         flush();
         plane_of_ = nullptr;
+        narrow_emit_ = nullptr;
+        if (nform) {   // [program, padded for the kernel's 16-word fetches][class words]
+            if (out.size() != s.prog2.size()) throw ZkError(ZK_ERR_INVALID, "internal: the narrow form of the loop program differs in length from the plain form");
+            out.resize(((out.size() + 63) / 64) * 64 + 64, 0);
+            s.cls_off = (uint32_t)out.size();
+            out.insert(out.end(), cls_words.begin(), cls_words.end());
+            out.resize(out.size() + 16, 0);
+        }
         if (!s.is_loop && s.pre_ops >= s.ops.size()) { (v2 ? s.pre_words2 : s.pre_words) = (uint32_t)out.size(); if (v2) s.pre_slots = slots_done; }
         if (!s.is_loop && s.side_ops >= s.ops.size()) { (v2 ? s.side_words2 : s.side_words) = (uint32_t)out.size(); if (v2) s.side_slots = slots_done; }
     }
@@ -2633,6 +2739,13 @@ void CS::upload_scope(Scope& s) {
         padded.resize(((padded.size() + 63) / 64) * 64 + 192, 0);
         s.d_sprog_n = upload(padded);
     }
+    if (s.narrow_ok) {   // (already padded: emit_scope, build_narrow_check_program)
+        s.d_prog2n = upload(s.prog2n);
+        std::vector<uint32_t> padded(s.cprog_fused_n);
+        padded.resize(((padded.size() + 63) / 64) * 64 + 64, 0);
+        s.d_cprog_fused_n = upload(padded);
+        s.d_slot_aw = upload(s.slot_aw);
+    }
     if (!s.mult_sites.empty()) s.d_mult_sites = upload(s.mult_sites);
     s.d_consts = upload(s.const_pool);
     s.d_rows = upload(s.rows);
@@ -2666,14 +2779,16 @@ void CS::finalize() {
     bundle_gated_permutations();
     assign_store_slots(outer_);
     assign_store_slots(loop_);
+    bound_values(outer_);     // (from the gates, lookups and tables alone: before the programs, the narrow layout wants the classes)
+    bound_values(loop_);
+    build_narrow_layout(loop_);
     emit_scope(outer_);
     emit_scope(loop_);
     build_check_program(outer_);
     build_check_program(loop_);
+    build_narrow_check_program(loop_);
     build_mult_sites(outer_);
     build_mult_sites(loop_);
-    bound_values(outer_);
-    bound_values(loop_);
     build_strands(outer_);
     if (limit_) {
         build_strands(loop_);
@@ -2791,6 +2906,23 @@ void CS::ensure_uploaded() {
     d_table_words_ = upload(table_words_host_);
     d_links_ = upload(links_);
     d_links_store_ = upload(links_store_);
+    if (loop_.narrow_ok) {
+        loop_last_slots_.clear();
+        for (auto& op : outer_.ops)
+            if (!op.seed_only && op.opcode == ZK_OP_LOOP_LAST && !op.ins.empty()) loop_last_slots_.push_back(loop_.var_slot[op.ins[0].idx]);
+        if (!loop_last_slots_.empty()) d_loop_last_slots_ = upload(loop_last_slots_);
+    }
+    if (loop_.narrow_ok) {   // the loop-scope endpoints as address words of the narrow store (outer-scope endpoints stay slots)
+        std::vector<zk_link> ln(links_store_);
+        for (auto& l : ln) { l.loop_cell = loop_.slot_aw[l.loop_cell]; if (l.kind == ZK_LINK_CARRY) l.other_cell = loop_.slot_aw[l.other_cell]; }
+        d_links_store_n_ = upload(ln);
+        for (auto& sr : streams_store_) {
+            std::vector<uint32_t> cells;
+            for (uint32_t c : sr.a) cells.push_back(loop_.slot_aw[c]);
+            for (uint32_t c : sr.b) cells.push_back(loop_.slot_aw[c]);
+            d_streams_store_n_.push_back(upload(cells));
+        }
+    }
     for (int k = 0; k < 2; ++k)
         for (auto& sr : (k ? streams_store_ : streams_)) {
             std::vector<uint32_t> cells(sr.a);
@@ -2866,7 +2998,37 @@ void CS::set_batch(uint32_t n) {
     uint64_t loop_lanes = (uint64_t)n * limit_;
     if (loop_lanes >= 0xffffffffull) throw ZkError(ZK_ERR_CAPACITY, "batch*limit exceeds 32-bit lane index");
     alloc_cells(outer_, n);
-    alloc_cells(loop_, loop_lanes);
+    if (loop_.d_store_n) { hipFree(loop_.d_store_n); loop_.d_store_n = nullptr; }
+    narrow_active_ = false; narrow_pending_ = false;
+    // Narrow store: this batch's fused steps write the loop scope's values into the narrow store when the loop launch is the plain kernel (not the
+    // strand form, not 64-bit addressing) and the multiplicities come from its inline atomics (the k_multiplicities pass reads the ordinary store).
+    // The ordinary store is allocated beside it when it fits (every reader outside the fused step sees the widened copy there), on first use otherwise.
+    const bool want_narrow = narrow_enabled_ && loop_.narrow_ok && limit_ && inline_multiplicities() && !loop_runs_strands(loop_, 0, (uint32_t)loop_lanes);
+    if (want_narrow) {
+        loop_.n_lanes = (uint32_t)loop_lanes;
+        loop_.store_tile_log2 = zkgeom::WAVE_TILE_LOG2;
+        if (const char* e = std::getenv("ZKGL_STORE_TILE_LOG2")) {
+            uint32_t t = std::min<uint32_t>(zkgeom::WIDE_TILE_LOG2, std::max<uint32_t>(zkgeom::WAVE_TILE_LOG2, (uint32_t)std::atoi(e)));
+            while (t > zkgeom::WAVE_TILE_LOG2 && (uint64_t)loop_.n_store >= (1ull << (29 - t))) --t;
+            loop_.store_tile_log2 = t;
+        }
+        const uint64_t n8 = zkgeom::slots(loop_.narrow_geom());
+        if (n8 < (1ull << (29 - loop_.store_tile_log2))) {
+            const size_t nbytes = std::max<size_t>((size_t)n8 * zkgeom::padded_lanes(loop_.narrow_geom(), loop_lanes) * 8, 8);
+            if (hipMalloc((void**)&loop_.d_store_n, nbytes) == hipSuccess) {
+                hip_check(hipMemset(loop_.d_store_n, 0, nbytes), "hipMemset narrow store");
+                narrow_active_ = true;
+            } else { loop_.d_store_n = nullptr; (void)hipGetLastError(); }
+        }
+    }
+    if (narrow_active_) {
+        // the ordinary store: beside the narrow one when it fits, else on first use (ensure_wide_store)
+        try { alloc_cells(loop_, loop_lanes); } catch (const ZkError&) { loop_.d_store = nullptr; (void)hipGetLastError(); }
+        if (!loop_.d_store && !loop_last_slots_.empty()) {   // the outer post phase needs the ordinary store in every step: no room for both, no narrow store
+            hipFree(loop_.d_store_n); loop_.d_store_n = nullptr; narrow_active_ = false;
+            alloc_cells(loop_, loop_lanes);
+        }
+    } else alloc_cells(loop_, loop_lanes);
     if (d_mult_) { hipFree(d_mult_); d_mult_ = nullptr; }
     size_t mbytes = std::max<size_t>((size_t)n * total_table_rows_ * 4, 4);
     hip_check(hipMalloc((void**)&d_mult_, mbytes), "hipMalloc multiplicities");
@@ -3166,6 +3328,8 @@ void CS::seed_stream(uint32_t n, const uint64_t* dev_outer_inputs, uint64_t* dev
 void CS::resolve(void* stream) {
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "resolve before set_batch");
     p2_pending_ = false;   // a plain resolve writes every value
+    if (narrow_active_) ensure_wide_store();
+    narrow_pending_ = false;   // ... into the ordinary store
     if (outer_.n_input_words && !outer_.d_inputs) throw ZkError(ZK_ERR_INVALID, "outer input stream not bound");
     if (loop_.n_input_words && !loop_.d_inputs) throw ZkError(ZK_ERR_INVALID, "loop input stream not bound");
     hipStream_t st = (hipStream_t)stream;
@@ -3191,7 +3355,7 @@ void CS::resolve(void* stream) {
     compact_ = true;  // home cells only: see check_satisfied / ensure_materialized
 }
 
-zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro, bool fused) const {
+zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro, bool fused, bool narrow) const {
     zkdev::CheckArgs a;
     a.alias = compact ? s.d_alias : nullptr;
     const bool full = !macro && s.d_cprog_full;   // the program without macro packets: locates a failure a macro packet reported
@@ -3203,6 +3367,10 @@ zkdev::CheckArgs CS::check_args(const Scope& s, unsigned long long* fail, bool c
         a.macros = nullptr; a.n_macros = 0;
     }
     a.cells = compact ? s.d_store : s.d_cells; a.n_cells = compact ? s.store_geom() : s.n_cells; a.n_cols = geo_.num_columns_under_copy_permutation + lookup_width_ * lookup_reps_;
+    if (narrow) {   // the fused step over the narrow store: the same packets with address words
+        if (!(fused && compact && s.d_cprog_fused_n && s.d_store_n)) throw ZkError(ZK_ERR_INVALID, "internal: narrow check arguments outside the fused step");
+        a.cprog = s.d_cprog_fused_n; a.cells = s.d_store_n; a.n_cells = s.narrow_geom();
+    }
     a.n_lanes = s.n_lanes; a.n_slots = s.n_slots; a.rows = s.d_rows;
     a.rowconsts = s.d_rowconsts; a.lrows = s.d_lrows; a.n_copy_cols = geo_.num_columns_under_copy_permutation;
     a.lookup_width = lookup_width_; a.tables = d_tables_; a.table_words = d_table_words_; a.fail = fail;
@@ -3346,12 +3514,12 @@ uint32_t CS::lookup_argument(const uint64_t beta[2], const uint64_t gamma[2], vo
     return bad;
 }
 
-void CS::check_streams(void* stream, bool compact) {
+void CS::check_streams(void* stream, bool compact, bool narrow) {
     const auto& streams = compact ? streams_store_ : streams_;
-    const auto& dev = compact ? d_streams_store_ : d_streams_;
+    const auto& dev = narrow ? d_streams_store_n_ : compact ? d_streams_store_ : d_streams_;
     for (size_t i = 0; i < streams.size(); ++i) {
         const auto& sr = streams[i];
-        dev_check(zkdev::launch_check_stream(compact ? loop_.d_store : loop_.d_cells, compact ? loop_.store_geom() : loop_.n_cells, batch_, limit_, dev[i],
+        dev_check(zkdev::launch_check_stream(narrow ? loop_.d_store_n : compact ? loop_.d_store : loop_.d_cells, narrow ? loop_.narrow_geom() : compact ? loop_.store_geom() : loop_.n_cells, batch_, limit_, dev[i],
                                              (uint32_t)sr.a.size(), dev[i] + sr.a.size(), (uint32_t)sr.b.size(), sr.n_total, (uint32_t)i,
                                              d_fail_ + 3, stream));
     }
@@ -3432,6 +3600,14 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     const bool fused = !check_stored_ && !(vs && vs[0] == '1') && outer_.d_cprog_fused && (!limit_ || loop_.d_cprog_fused);
     last_check_fused_ = fused;
     if (fused) { oa.fail = d_fail_; la.fail = d_fail_ + 3; }
+    // NARROW store (store_geom.hpp): the fused step writes and reads the loop scope's values there — the loop kernel, the fused check program,
+    // the links, ZK_OP_LOOP_LAST of the outer post phase; the ordinary store is stale until somebody asks for it (ensure_p2_filled widens)
+    const bool narrow = fused && narrow_active_ && !narrow_suspended_ && limit_;
+    if (narrow) {
+        la.cells = loop_.d_store_n; la.n_cells = loop_.narrow_geom(); la.cls = loop_.d_prog2n + loop_.cls_off;
+        if (!loop_last_slots_.empty()) ensure_wide_store();   // ZK_OP_LOOP_LAST of the outer post phase reads the ordinary store: k_widen_last below
+        ++narrow_steps_;
+    } else if (narrow_active_) ensure_wide_store();
     // deferred mode: only when the step is fused (nothing in it reads the intermediates) and every in-circuit permutation of the loop scope
     // has a verified descriptor for the fill kernel
     const bool defer = fused && defer_p2_ && limit_ && loop_.d_cmacros && loop_.n_macro_p2 == loop_.n_p2_rounds_ops && loop_.p2_intermediates_private;
@@ -3448,6 +3624,12 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     if (limit_) launch_phase(loop_, la, 0, st);   // LOOP
     hip_check(hipEventRecord(E(3), st), "event");
     launch_phase(outer_, oa, 1, ax);             // outer SIDE (|| LOOP)
+    if (narrow && !loop_last_slots_.empty()) {   // the values the outer post phase takes from the last iteration, into the ordinary store it reads
+        dev_check(zkdev::launch_widen_last(loop_.d_store_n, loop_.narrow_geom(), loop_.d_store, loop_.store_geom(), batch_, limit_, loop_.d_slot_aw, d_loop_last_slots_,
+                                           (uint32_t)loop_last_slots_.size(), st));
+        hip_check(hipEventRecord(E(8), st), "event");
+        hip_check(hipStreamWaitEvent(ax, E(8), 0), "wait");
+    }
     hip_check(hipStreamWaitEvent(ax, E(3), 0), "wait");
     launch_phase(outer_, oa, 2, ax);  // outer POST
     // compact traces: the gate checkers read every cell through the alias map; no copy pass (see check_satisfied)
@@ -3455,7 +3637,7 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     check_inputs_canonical(ax, ax);   // both scopes on the auxiliary stream: it has slack behind the loop-scope kernels
     hip_check(hipEventRecord(E(4), ax), "event");
     if (limit_) {
-        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, true, true, fused), st));
+        dev_check(zkdev::launch_check_gates(check_args(loop_, d_fail_ + 3, true, true, fused, narrow), st));
         hip_check(hipEventRecord(E(5), st), "event");
     } else {
         hip_check(hipEventRecord(E(5), st), "event");
@@ -3468,9 +3650,9 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     hip_check(hipStreamWaitEvent(st, E(4), 0), "wait");
     count_multiplicities(st, 1);
     if (limit_) {
-        dev_check(zkdev::launch_check_links(loop_.d_store, loop_.store_geom(), loop_.n_lanes, limit_, outer_.d_store,
-                                            outer_.store_geom(), d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));
-        check_streams(st, true);
+        dev_check(zkdev::launch_check_links(narrow ? loop_.d_store_n : loop_.d_store, narrow ? loop_.narrow_geom() : loop_.store_geom(), loop_.n_lanes, limit_, outer_.d_store,
+                                            outer_.store_geom(), narrow ? d_links_store_n_ : d_links_store_, (uint32_t)links_store_.size(), d_fail_ + 3, st));
+        check_streams(st, true, narrow);
     }
     hip_check(hipEventRecord(E(7), st), "event");
     unsigned long long f[10];
@@ -3488,7 +3670,18 @@ int CS::resolve_and_check(void* stream, zk_failure* first) {
     loop_shader_mhz_ = (limit_ && f[7] != ~0ull && f[7] != 0) ? (float)((double)f[6] / (double)f[7] * 100.0) : 0.0f;
     compact_ = true;
     p2_pending_ = defer;
+    narrow_pending_ = narrow;
     const int rc = decode_failure(f, first);
+    if (narrow && rc != ZK_OK) {
+        // anything reported over the narrow store — a violated relation, or a value that does not fit its byte slot (stored truncated) — is
+        // decided by repeating the step over the ordinary store: the verdict and the reported gate are exactly those of a build without narrow slots
+        ++narrow_repeats_;
+        narrow_suspended_ = true;
+        int rc2;
+        try { rc2 = resolve_and_check(stream, first); } catch (...) { narrow_suspended_ = false; throw; }
+        narrow_suspended_ = false;
+        return rc2;
+    }
     return rc == ZK_MACRO_FAILURE ? check_satisfied_impl(stream, first, false) : rc;
 }
 
@@ -3500,7 +3693,35 @@ void CS::set_check_mode(uint32_t mode) {
 // deferred mode (ZK_CHECK_FUSED_DEFER_P2): the loop kernel left the 950 intermediates of every in-circuit Poseidon2 permutation
 // unwritten; everything that reads the store beyond the fused step (the full check, trace readers, the prover-stage kernels, read_var,
 // the fault-injection hooks) comes through here first
+std::vector<uint32_t> CS::narrow_byte_input_words() const {
+    if (!finalized_) throw ZkError(ZK_ERR_INVALID, "narrow_byte_input_words before finalize");
+    std::vector<uint32_t> out;
+    if (!loop_.narrow_ok) return out;
+    for (auto& kv : loop_.input_word)
+        if (loop_.slot_aw[loop_.var_slot[kv.first]] & zkgeom::AW_BYTE) out.push_back(kv.second);
+    std::sort(out.begin(), out.end());
+    return out;
+}
+
+void CS::ensure_wide_store() {
+    if (loop_.d_store || !limit_) return;
+    const uint64_t store_lanes = zkgeom::padded_lanes(loop_.store_geom(), loop_.n_lanes);
+    const size_t bytes = std::max<size_t>((size_t)loop_.n_store * store_lanes * 8, 8);
+    if (hipMalloc((void**)&loop_.d_store, bytes) != hipSuccess) {
+        loop_.d_store = nullptr;
+        (void)hipGetLastError();
+        throw ZkError(ZK_ERR_CAPACITY, "the ordinary loop store does not fit beside the narrow one at this batch size (a reader outside the fused step asked for it)");
+    }
+    hip_check(hipMemset(loop_.d_store, 0, bytes), "hipMemset variable store");
+}
+
 void CS::ensure_p2_filled(void* stream) {
+    if (narrow_pending_) {   // the last step wrote the narrow store: expand it into the ordinary store every other reader addresses
+        ensure_wide_store();
+        dev_check(zkdev::launch_widen_store(loop_.d_store_n, loop_.narrow_geom(), loop_.d_store, loop_.store_geom(), loop_.n_lanes, loop_.d_slot_aw, loop_.n_store, stream));
+        hip_check(hipStreamSynchronize((hipStream_t)stream), "widen sync");
+        narrow_pending_ = false;
+    }
     if (!p2_pending_) return;
     dev_check(zkdev::launch_fill_p2(loop_.d_store, loop_.store_geom(), loop_.n_lanes, loop_.d_cmacros, loop_.n_macro_p2, stream));
     hip_check(hipStreamSynchronize((hipStream_t)stream), "fill_p2 sync");
@@ -3636,6 +3857,11 @@ void CS::stats(zk_stats* o) const {
     o->constraints_in_witness_fused = o->constraints_per_instance - o->constraints_from_store_fused;
     o->values_below_2_32_outer = outer_.values_below_2_32; o->values_below_2_32_loop = loop_.values_below_2_32;
     o->seed_cone_unsupported = seed_cone_unsupported_;
+    o->store_bytes_per_lane_loop = (uint64_t)loop_.cells_written * 8;
+    o->narrow_store_bytes_per_lane_loop = loop_.narrow_ok ? loop_.narrow_units : 0;
+    o->narrow_byte_values_loop = loop_.narrow_ok ? loop_.narrow_byte_values : 0;
+    o->narrow_store_active = narrow_active_ ? 1 : 0;
+    o->narrow_steps = narrow_steps_; o->narrow_repeats = narrow_repeats_;
 }
 
 float CS::last_ms(int which) const {

@@ -165,6 +165,23 @@ struct Scope {
     uint32_t store_tile_log2 = zkgeom::WAVE_TILE_LOG2;  // lane tiling of d_store (store_geom.hpp), chosen by set_batch
     // what the launch interface carries beside d_store: the slot count with the tiling in its top byte (a bare count = 64-lane tiles)
     uint64_t store_geom() const { return store_tile_log2 == zkgeom::WAVE_TILE_LOG2 ? (uint64_t)n_store : zkgeom::pack(n_store, store_tile_log2); }
+    // NARROW STORE (store_geom.hpp; loop scopes, opt-in ZKGL_NARROW_STORE=1; cs.cpp build_narrow_layout): the layout and the device programs of the
+    // fused step over it.  The ordinary store and its programs stay: everything outside the fused step reads the widened copy.
+    bool narrow_ok = false;              // a layout + programs exist
+    std::vector<uint32_t> slot_aw;       // store slot -> address word (first unit | class << 28)
+    uint32_t narrow_units = 0;           // units of a tile = bytes one lane writes
+    uint32_t narrow_byte_values = 0;     // values held in one-byte slots
+    std::vector<uint32_t> prog2n;        // prog2 with address-word operands; its class words (one per header) start at cls_off
+    uint32_t cls_off = 0;
+    std::vector<uint32_t> cprog_fused_n; // cprog_fused with address words (same packets: cchunks_fused)
+    uint32_t* d_prog2n = nullptr;
+    uint32_t* d_cprog_fused_n = nullptr;
+    uint32_t* d_slot_aw = nullptr;
+    uint64_t* d_store_n = nullptr;       // the narrow store of the bound batch (set_batch), nullptr when the batch does not use it
+    uint64_t narrow_geom() const {
+        const uint64_t n8 = ((uint64_t)narrow_units + 7) / 8;   // the tile in 8-byte slots: allocation and tile addressing as for an ordinary store
+        return zkgeom::NARROW | (store_tile_log2 == zkgeom::WAVE_TILE_LOG2 ? n8 : zkgeom::pack(n8, store_tile_log2));
+    }
     uint64_t* d_cells = nullptr;   // materialised trace, allocated by the first ensure_materialized
     uint64_t stride = 0;
     uint32_t n_lanes = 0;
@@ -249,6 +266,7 @@ class CS {
     int check_satisfied(void* stream, zk_failure* first);
     int resolve_and_check(void* stream, zk_failure* first);
     void set_check_mode(uint32_t mode);   // ZK_CHECK_FUSED / ZK_CHECK_STORED / ZK_CHECK_FUSED_DEFER_P2
+    std::vector<uint32_t> narrow_byte_input_words() const;   // loop input words held in one-byte slots of the narrow store (empty: no layout)
     void ensure_p2_filled(void* stream);   // deferred mode: regenerate the Poseidon2 intermediates the last resolve_and_check left out
     uint64_t read_var(zk_var v, uint32_t instance, uint32_t iteration);
     void write_cell(bool loop_scope, uint32_t cell, uint32_t lane, uint64_t value);
@@ -311,11 +329,16 @@ class CS {
     void build_strands(Scope& s, uint32_t n_strands = zkdev::STRANDS_PER_TILE, bool narrow = false);
     void assign_store_slots(Scope& s);
     uint32_t home(const Scope& s, uint32_t var) const { return emit_full_ ? s.var_cells[var][0] : s.var_slot[var]; }
-    void check_streams(void* stream, bool compact);
+    void check_streams(void* stream, bool compact, bool narrow = false);
     void check_inputs_canonical(void* outer_stream, void* loop_stream);
     // one witness launch: the plain program, or its strand form when the scope has too few wavefronts to fill the chip
     void launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream, uint32_t n_lanes = 0) const;  // n_lanes: lane count when the arguments were patched for a stream
     void build_check_program(Scope& s);
+    // narrow store of the loop scope (store_geom.hpp): classes + address words (before emit_scope), the fused check program over them (after build_check_program)
+    void build_narrow_layout(Scope& s);
+    void build_narrow_check_program(Scope& s);
+    bool loop_runs_strands(const Scope& s, int phase, uint32_t n_lanes) const;   // launch_phase's choice of the strand form
+    void ensure_wide_store();            // narrow batches: the ordinary loop store exists (allocated with the batch when it fits, here otherwise)
     void build_mult_sites(Scope& s);
     void bound_values(Scope& s);
     void count_multiplicities(void* stream, int scopes = 3);
@@ -326,13 +349,14 @@ class CS {
     void verify_device_programs(const Scope& s) const;   // ZKGL_VERIFY_DEVICE_PROGRAMS=1: independent walk over prog2 / the strand programs
     void emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool counted, std::vector<uint32_t>& out) const;
     bool emit_chain_ = false;   // emit_scope: the group being flushed is a mux chain (ZKGL_SELECT_CHAINS)
+    const std::vector<uint32_t>* narrow_emit_ = nullptr;   // emit_scope, narrow form of a loop scope: store slot -> address word (operand_v2)
     const std::vector<uint32_t>* plane_of_ = nullptr;   // emit_scope, v2 form of a loop scope: variable -> SELECT flag plane id (UINT32_MAX: none)
     void upload_scope(Scope& s);
     void ensure_uploaded();
     void free_scope_device(Scope& s);
     void check_var(zk_var v, bool want_loop) const;
     int decode_failure(const unsigned long long* f, zk_failure* first) const;
-    zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro = true, bool fused = false) const;
+    zkdev::CheckArgs check_args(const Scope& s, unsigned long long* fail, bool compact, bool macro = true, bool fused = false, bool narrow = false) const;
 
     zk_geometry geo_;
     uint64_t max_trace_len_, max_variables_;
@@ -348,6 +372,10 @@ class CS {
     std::vector<zk_link> links_;       // endpoints as trace cells (export, materialised-trace check)
     std::vector<zk_link> links_store_; // endpoints as store slots (compact check)
     zk_link* d_links_store_ = nullptr;
+    zk_link* d_links_store_n_ = nullptr;          // the same with the loop-scope endpoints as address words of the narrow store
+    std::vector<uint32_t*> d_streams_store_n_;
+    std::vector<uint32_t> loop_last_slots_;       // loop store slots ZK_OP_LOOP_LAST ops of the outer scope read (k_widen_last after a narrow loop launch)
+    uint32_t* d_loop_last_slots_ = nullptr;
     std::vector<uint32_t> public_vars_;
     struct StreamRec { std::vector<uint32_t> a, b; uint32_t n_total; };  // loop var indices -> home cells at finalize
     std::vector<StreamRec> streams_raw_, streams_, streams_store_;
@@ -410,7 +438,7 @@ class CS {
     uint64_t* d_seed_outer_ = nullptr;   // seed_stream's outer store
     size_t seed_outer_bytes_ = 0;
     void* ev_[8] = {nullptr};
-    void* ev2_[8] = {nullptr};
+    void* ev2_[9] = {nullptr};
     void* aux_stream_ = nullptr;
     float ms_[5] = {0, 0, 0, 0, 0};
     float loop_shader_mhz_ = 0;   // clock probe of the last resolve_and_check's loop launch (last_ms(8))
@@ -419,6 +447,11 @@ class CS {
     bool check_stored_ = false;
     bool defer_p2_ = false;          // ZK_CHECK_FUSED_DEFER_P2
     bool p2_pending_ = false;        // the loop store lacks the intermediates of its in-circuit permutations (k_fill_p2 not run yet)
+    bool narrow_enabled_ = false;    // ZKGL_NARROW_STORE=1 at finalize and the loop scope has a narrow layout
+    bool narrow_active_ = false;     // the bound batch runs its fused steps over the narrow store (set_batch: plain loop kernel, inline multiplicities)
+    bool narrow_pending_ = false;    // the last step wrote the narrow store only: the ordinary store is stale until k_widen_store (ensure_p2_filled)
+    bool narrow_suspended_ = false;  // a step that reported a failure over the narrow store is being repeated over the ordinary one
+    uint64_t narrow_steps_ = 0, narrow_repeats_ = 0;
     bool uses_lookup_macros_ = false;   // a macro-op whose outputs carry lookup tuples was recorded: multiplicities by the k_multiplicities pass
     bool uses_bytebuf_macro_ = false, uses_strand_planes_ = false, uses_sha4_macro_ = false;   // opt-in device paths the default build does not carry (set_batch refuses them there)
     int32_t macro_window_op_ = -1;   // index (current scope) of the macro-op whose gadget window is open

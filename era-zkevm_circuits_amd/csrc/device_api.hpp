@@ -22,6 +22,9 @@ struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     uint32_t defer_p2 = 0;                       // 1: ZK_OP_P2_ROUNDS stores only its 12 final outputs (ZK_CHECK_FUSED_DEFER_P2), the 950 intermediates come from launch_fill_p2
     unsigned long long* p2_stats = nullptr;     // two counters: gated witness-only permutations a wavefront skipped / ran (ZK_OP_POSEIDON2 a = 1)
     unsigned long long* clock_probe = nullptr;  // two words: shader-clock and 100 MHz ticks of the grid's first wavefront (kernels_engine2.hpp witness_entry2)
+    // host only — narrow store (store_geom.hpp): the class words of `prog` (one per header); cells / n_cells are then the narrow store and its
+    // geometry word, and launch_witness takes k_witness_loop_narrow
+    const uint32_t* cls = nullptr;
 };
 struct CheckArgs {  // mirrors zke::CheckDev
     const uint64_t* cells; uint64_t n_cells; uint32_t n_cols; uint32_t n_lanes; uint32_t n_slots;
@@ -143,6 +146,11 @@ struct PermArgs {
 };
 // the 950 intermediates of every in-circuit Poseidon2 permutation of a scope, recomputed from its 12 stored inputs (descriptors = the check macros)
 int launch_fill_p2(uint64_t* store, uint64_t n_store, uint32_t n_lanes, const uint32_t* macros, uint32_t n_macros, void* stream);
+// narrow store -> ordinary store (store_geom.hpp): aw[slot] = address word of the slot's value; the geometry words say which is which
+int launch_widen_store(const uint64_t* narrow, uint64_t narrow_geom, uint64_t* wide, uint64_t wide_geom, uint32_t n_lanes, const uint32_t* aw, uint32_t n_slots, void* stream);
+// the same for a list of slots at the last iteration of every instance (what ZK_OP_LOOP_LAST of the outer post phase reads from the ordinary store)
+int launch_widen_last(const uint64_t* narrow, uint64_t narrow_geom, uint64_t* wide, uint64_t wide_geom, uint32_t n_instances, uint32_t limit, const uint32_t* aw,
+                      const uint32_t* slots, uint32_t n_list, void* stream);
 int launch_perm_lane(const PermArgs& a, void* stream);
 int launch_perm_tb(const uint64_t beta[2], const uint32_t* sigma_rel, uint64_t* tb, uint32_t n, void* stream);
 int launch_perm_scan(const uint64_t* part, uint32_t per, const uint64_t* seed, uint64_t* excl, uint64_t* total, uint32_t n_instances, void* stream);

@@ -72,6 +72,12 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_re
 __device__ __forceinline__ size_t cell_off(uint64_t n_cells, uint32_t cell, uint32_t lane) {
     return zkgeom::offset(n_cells, cell, lane);
 }
+// one value of a store through plain pointers: `word` = slot (ordinary store) or address word (geometry word with zkgeom::NARROW)
+__device__ __forceinline__ uint64_t load_value(const uint64_t* __restrict__ cells, uint64_t geom, uint32_t word, uint32_t lane) {
+    if (!zkgeom::narrow(geom)) return cells[zkgeom::offset(geom, word, lane)];
+    const uint8_t* __restrict__ p = reinterpret_cast<const uint8_t*>(cells) + zkgeom::narrow_byte_offset(geom, word, lane);
+    return (word & zkgeom::AW_BYTE) ? (uint64_t)*p : *reinterpret_cast<const uint64_t*>(p);
+}
 // the pieces of the buffer-addressed fast paths: a wavefront's 64 lanes sit in ONE tile (tiles are multiples of 64 lanes);
 // V# base = the tile, voffset = the lane's byte in a value of the tile, soffset = slot << (T + 3)
 struct TileAddr { uint64_t* base; uint32_t lane_byte, shift; };
@@ -1181,11 +1187,11 @@ __global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict_
     for (uint32_t i = 0; i < n_links; ++i) {
         const zk_link L = links[i];
         const uint32_t kind = uni(L.kind);
-        uint64_t mine = loop_cells[cell_off(loop_n_cells, uni(L.loop_cell), lane)];
+        uint64_t mine = load_value(loop_cells, loop_n_cells, uni(L.loop_cell), lane);   // (a narrow loop store: the link table holds address words)
         const uint32_t other = uni(L.other_cell);   // (read where the wavefront is whole: the k > 0 test below splits it)
         bool ok = true;
         if (kind == ZK_LINK_CARRY) {
-            if (k > 0) ok = mine == loop_cells[cell_off(loop_n_cells, other, lane - 1)];
+            if (k > 0) ok = mine == load_value(loop_cells, loop_n_cells, other, lane - 1);
         } else {
             uint64_t o = outer_cells[cell_off(outer_n_cells, other, inst)];
             if (kind == ZK_LINK_FIRST) ok = (k != 0) || mine == o;
@@ -1205,8 +1211,8 @@ __global__ __launch_bounds__(TPB) void k_check_stream(const uint64_t* __restrict
     if (t >= (uint64_t)n_instances * n_total) return;
     const uint32_t inst = (uint32_t)(t / n_total), k = (uint32_t)(t % n_total);
     const uint32_t lane_a = inst * limit + k / pa, lane_b = inst * limit + k / pb;
-    const uint64_t va = loop_cells[cell_off(loop_n_cells, a_cells[k % pa], lane_a)];
-    const uint64_t vb = loop_cells[cell_off(loop_n_cells, b_cells[k % pb], lane_b)];
+    const uint64_t va = load_value(loop_cells, loop_n_cells, a_cells[k % pa], lane_a);
+    const uint64_t vb = load_value(loop_cells, loop_n_cells, b_cells[k % pb], lane_b);
     if (va != vb) atomicMin(fail + 2, ((unsigned long long)lane_a << 32) | 0x80000000u | stream_index);
 }
 

@@ -252,9 +252,13 @@ __device__ __noinline__ uint32_t bytebuf_fill_stream(__amdgpu_buffer_rsrc_t rsrc
 
 // STRANDS: the strand form (k_witness_strands2): one destination word per op behind the operands — the store slot of its first
 // output (a strand's ops are not consecutive in production order) — and ZK_OP_BARRIER between the dependency levels.
-template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB, bool STRANDS = false>
+// NARROW (k_witness_loop_narrow; store_geom.hpp, cs.cpp build_narrow_layout): the scope's store is a narrow store — data operand words are ADDRESS
+// WORDS (first unit | class << 28), an output is a byte-class value when its bit is set in the header's class word (sc.cls, one word per header):
+// buffer_load_ubyte / buffer_store_byte, 64 B per wavefront instead of 512.  A value that does not fit its byte slot is the fused mode's failure
+// (the class of a variable is a bound that holds in EVERY satisfying witness: CS::bound_values); the host then repeats the step on the ordinary store.
+template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB, bool STRANDS = false, bool NARROW = false>
 __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
-                                          uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+                                          uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, const uint32_t* cls_words = nullptr) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     // store_geom.hpp: V# = the lane tile of this wavefront, voffset = the lane's byte in a value of the tile, soffset = slot << bsh
     const TileAddr ta = tile_addr(sc.cells, sc.n_cells, lane);
@@ -271,12 +275,22 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #endif
     __shared__ uint64_t p2s[P2_IN_REGISTERS ? 1 : 12 * BLOCK];  // Poseidon2 state, [element][thread] (plain kernels: rolled S-box loops)
 
-    uint32_t dst = WIDE ? slot_begin : slot_begin << bsh;  // next output: slot index (WIDE) or byte offset in the tile
+    static_assert(!NARROW || (!WIDE && !STRANDS), "the narrow store is read by the plain buffer-addressed kernel only");
+    const uint32_t ush = bsh - 3;                   // NARROW: a unit of the tile = 1 << ush bytes (one byte per lane)
+    const uint32_t lane_unit = lane_byte >> 3;      // NARROW: this lane's byte in a unit
+    const prog1_ptr cls = (prog1_ptr)(uintptr_t)cls_words;   // NARROW: one class word per header of the program
+    uint32_t opi = 0;                               // NARROW: headers decoded so far (index into cls)
+    uint32_t dst = WIDE ? slot_begin : NARROW ? slot_begin << ush : slot_begin << bsh;  // next output: slot index (WIDE) or byte offset in the tile (NARROW: slot_begin = first unit)
     auto ldv = [&](uint32_t slot) -> uint64_t {
 #ifdef ZKGL_STUB_LOADS  // time attribution only (tools/stub_vm.sh): operand values without the memory access
         return (uint64_t)slot * 0x9E3779B97F4A7C15ull + lane_byte;
 #else
         if constexpr (WIDE) return wide_cells[(size_t)slot << tsh];
+        if constexpr (NARROW) {   // `slot` is an address word; its class is wave-uniform (a scalar branch around one of two loads)
+            if (slot & zkgeom::AW_BYTE) return (uint64_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, lane_unit, (slot & zkgeom::AW_MASK) << ush, 0);
+            u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << ush, 0);
+            return (uint64_t)v.x | ((uint64_t)v.y << 32);
+        }
         u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << bsh, 0);
         return (uint64_t)v.x | ((uint64_t)v.y << 32);
 #endif
@@ -322,6 +336,18 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #endif
     uint32_t nonbool_seen = 0;   // uniform: some flag copied into a plane held a value > 1 in some lane (never, on a satisfiable witness)
     bool fused_bad = false;   // fused mode: a gate evaluated here (SELECT's exception, a lookup miss) is violated; reported once, below
+    uint32_t ocm = 0;         // NARROW: class word of the header being executed (bit k: its k-th output is a byte-class value)
+    auto stn = [&](uint64_t v, uint32_t k) {   // output k of the header (ops whose outputs may be byte-class: cs.cpp narrow_capable)
+        if constexpr (NARROW) {
+            if ((ocm >> k) & 1u) {
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, rsrc, lane_unit, dst, 0);
+                fused_bad |= v > 0xffull;   // does not fit: no satisfying witness holds this value (the host repeats the step on the ordinary store)
+                dst += 1u << ush;
+                return;
+            }
+        }
+        st(v);
+    };
 #ifdef ZKGL_BATCH_INV
     // Montgomery-batched zero-check inversions (variant build; plain narrow kernels).  An ISZERO whose operand is large in some lane of the
     // wavefront does not run the 72-multiplication chain on its own: it stores its flag, notes (operand offset, aux offset) in LDS — uniform
@@ -380,6 +406,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     while (pc < word_end) {
 #endif
         const u32x16_a4 W = *(prog16_ptr)(prog + pc);  // s_load_dwordx16: header + up to 15 operand words (host pads the program)
+        if constexpr (NARROW) { ocm = cls[opi]; ++opi; }   // (a second scalar load in flight beside the header's)
         const uint32_t h = W[0];
         const uint32_t op = h & 0xff, pa = (h >> 8) & 0xff, pb = h >> 16;
         switch (op) {
@@ -390,7 +417,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             uint64_t v;
             if ((w & ZK_OPERAND_KIND_MASK) == ZK_OPERAND_OUTER) v = sc.outer_cells[cell_off(sc.outer_n_cells, w & ZK_OPERAND_IDX_MASK, inst)];
             else v = cpool[w & ZK_OPERAND_IDX_MASK];
-            st(v);
+            stn(v, 0);
         } break;
         // Grouped ops: one straight-line instance per group size (no predication: every operand load of the group is issued
         // before the first wait, and the register allocator sees exactly the live set of that size).
@@ -402,7 +429,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 for (uint32_t g = 0; g < N; ++g) v[g] = sc.inputs[(size_t)W[1 + g] * sc.in_stride + lane];
                 pc += 1 + N + D * N;
 #pragma unroll
-                for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N + g) & 15]); st(v[g]); }
+                for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N + g) & 15]); stn(v[g], g); }
             };
             switch (pb) {
             case 0: body(GroupSize<1>{}); break;
@@ -431,10 +458,10 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 for (uint32_t g = 0; g < N; ++g) {
                     out_to(W[(1 + N * 5 + g) & 15]);
 #ifdef ZKGL_STUB_FMA  // time attribution only (tools/loop_probe.sh): the op without its multiplications
-                    st(in[g][0] ^ in[g][1] ^ in[g][2] ^ q[g] ^ l[g]);
+                    stn(in[g][0] ^ in[g][1] ^ in[g][2] ^ q[g] ^ l[g], g);
 #else
                     const uint64_t ab = gl::mul(in[g][0], in[g][1]);
-                    st(gl::add(q[g] == 1 ? ab : gl::mul(q[g], ab), l[g] == 1 ? in[g][2] : gl::mul(l[g], in[g][2])));
+                    stn(gl::add(q[g] == 1 ? ab : gl::mul(q[g], ab), l[g] == 1 ? in[g][2] : gl::mul(l[g], in[g][2])), g);
 #endif
                 }
             };
@@ -453,7 +480,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             for (int i = 0; i < 4; ++i) r = gl::fma(cpool[W[1 + i]], t[i], r);
             out_to(W[9]);
             pc += 9 + D;
-            st(r);
+            stn(r, 0);
         } break;
         case ZK_OP_FLAG_PLANES: if constexpr (PLANES) {
             const uint32_t n = pb + 1;
@@ -530,7 +557,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 }
                 pc += 1 + N * 3 + D * N;
 #pragma unroll
-                for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N * 3 + g) & 15]); st(((fbits >> g) & 1) ? a[g] : b[g]); }
+                for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N * 3 + g) & 15]); stn(((fbits >> g) & 1) ? a[g] : b[g], g); }
                 if (nbany) {   // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ
 #pragma unroll
                     for (uint32_t g = 0; g < N; ++g) fused_bad |= ((planes[zkdev::FLAG_PLANES + W[1 + g * 3]] >> wave_lane) & 1) && a[g] != b[g];
@@ -554,7 +581,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 }
                 pc += 1 + N * 3 + D * N;
 #pragma unroll
-                for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N * 3 + g) & 15]); st(in[g][0] ? in[g][1] : in[g][2]); }
+                for (uint32_t g = 0; g < N; ++g) { out_to(W[(1 + N * 3 + g) & 15]); stn(in[g][0] ? in[g][1] : in[g][2], g); }
                 // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) fused_bad |= in[g][0] > 1 && in[g][1] != in[g][2];
@@ -571,7 +598,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             const uint64_t x = ldv(W[1]);
             out_to(W[2]);
             pc += 2 + D;
-            st(x == 0 ? 1ull : 0ull);
+            stn(x == 0 ? 1ull : 0ull, 0);
 #ifdef ZKGL_STUB_INV  // time attribution only: no inversion
             st(x);
 #elif defined(ZKGL_BATCH_INV)
@@ -589,7 +616,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 }
             } else st(p2::inv_wave(x));
 #else
-            st(p2::inv_wave(x));   // small |x| in every lane (flags, counters, position differences): one gather instead of 72 multiplications
+            stn(p2::inv_wave(x), 1);   // small |x| in every lane (flags, counters, position differences): one gather instead of 72 multiplications
 #endif
         } break;
         case ZK_OP_UADD: {
@@ -597,8 +624,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             out_to(W[4]);
             pc += 4 + D;
             const uint64_t s = x + y + ci;  // operands < 2^32
-            st(s & ((1ull << pa) - 1));
-            st(s >> pa);
+            stn(s & ((1ull << pa) - 1), 0);
+            stn(s >> pa, 1);
         } break;
         case ZK_OP_USUB: {
             const uint64_t x = ldv(W[1]), y = ldv(W[2]), bi = ldv(W[3]);
@@ -606,8 +633,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             pc += 4 + D;
             const uint64_t sub = y + bi;
             const uint64_t borrow = x < sub ? 1 : 0;
-            st((x + (borrow << pa)) - sub);
-            st(borrow);
+            stn((x + (borrow << pa)) - sub, 0);
+            stn(borrow, 1);
         } break;
         case ZK_OP_DOT4: {
             uint64_t v[8];
@@ -635,7 +662,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             out_to(W[2]);
             pc += 2 + D;
             for (uint32_t i = 0; i < pa; ++i) {
-                st(i + 1 == pa ? x : (x & ((1ull << pb) - 1)));
+                stn(i + 1 == pa ? x : (x & ((1ull << pb) - 1)), i < 32 ? i : 31);   // (class word: 32 outputs; the host keeps chunk 31 onwards in 8-byte slots)
                 x >>= pb;
             }
         } break;
@@ -695,7 +722,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                         (void)dpos;
 #pragma unroll
                         for (uint32_t i = 0; i < 2; ++i)
-                            if (i < nv) st(val[g][i]);
+                            if (i < nv) stn(val[g][i], g * nv + i);
                         mult_add(sc.mult, (size_t)inst * sc.total_table_rows + t.mult_off + row[g], ZKGL_MULT_ON && row[g] < t.n_rows && active && sc.mult);
                     }
                     // fused mode: the tuple (keys, the values stored here) is a table row iff the keys were found
@@ -718,9 +745,9 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 const uint32_t row = table_find(t, sc.table_words, key);
                 const bool found = row < t.n_rows;
                 for (uint32_t i = 0; i < nv; ++i)
-                    st(!found ? 0ull
-                       : (t.dense & 2u) ? (uint64_t)tb[(size_t)row * t.n_vals + i]
-                                        : sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i]);
+                    stn(!found ? 0ull
+                        : (t.dense & 2u) ? (uint64_t)tb[(size_t)row * t.n_vals + i]
+                                         : sc.table_words[(size_t)t.word_off + (size_t)row * w + t.n_keys + i], i);
                 mult_add(sc.mult, (size_t)inst * sc.total_table_rows + t.mult_off + row, ZKGL_MULT_ON && found && active && sc.mult);
                 fused_bad |= !found;
             }
@@ -970,7 +997,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             pc += 17 + D;
             gl::u8x4_fma(in, out);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) st(out[i]);
+            for (int i = 0; i < 10; ++i) stn(out[i], (uint32_t)i);
         } break;
         case ZK_OP_SHA256_ROUNDS: if constexpr (WITH_BIGINT) {
             // K8: a whole SHA-256 compression as ONE op.  [32 state byte slots, 64 block byte slots] -> every intermediate, in the gadget's
@@ -1171,8 +1198,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             const uint64_t x = ldv(W[1]);
             out_to(W[2]);
             pc += 2 + D;
-            st(x / pb);
-            st(x % pb);
+            stn(x / pb, 0);
+            stn(x % pb, 1);
         } break;
         case ZK_OP_U256_MULWIDE: {
             // column-wise schoolbook product, a 96-bit column accumulator (up to 8 products of 64 bits + carry)
@@ -1270,8 +1297,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     if (sc.fail && fused_bad && active) report_fused(sc.fail, lane);
 }
 
-template <bool WITH_BIGINT, bool WIDE>
-__device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+template <bool WITH_BIGINT, bool WIDE, bool NARROW = false>
+__device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, const uint32_t* cls_words = nullptr) {
     uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
     const bool active = lane < sc.n_lanes;
@@ -1282,7 +1309,7 @@ __device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word
     const bool probe = sc.clock_probe && blockIdx.x == 0 && threadIdx.x < 64;
     uint64_t t0 = 0, r0 = 0;
     if (probe) { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    run_tile2<WITH_BIGINT, WIDE>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end, slot_begin);
+    run_tile2<WITH_BIGINT, WIDE, TPB, false, NARROW>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end, slot_begin, cls_words);
     if (probe && threadIdx.x == 0) {
         sc.clock_probe[0] = __builtin_readcyclecounter() - t0;
         sc.clock_probe[1] = __builtin_amdgcn_s_memrealtime() - r0;
@@ -1310,6 +1337,10 @@ __global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_witness_strands2(Scop
 #endif
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_LOOP_WAVES2, 8))) void k_witness_loop(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
     witness_entry2<false, false>(sc, word_begin, word_end, slot_begin);
+}
+// the loop scope over a NARROW store (store_geom.hpp): address-word operands, byte-class outputs in one-byte slots; same program order, same values
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_LOOP_WAVES2, 8))) void k_witness_loop_narrow(ScopeDev sc, const uint32_t* cls_words, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+    witness_entry2<false, false, true>(sc, word_begin, word_end, slot_begin, cls_words);   // cls_words: one class word per header (bit k: the k-th output is byte-class)
 }
 __global__ __launch_bounds__(TPB) void k_witness_outer(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
     witness_entry2<false, false>(sc, word_begin, word_end, slot_begin);
@@ -1679,7 +1710,9 @@ __device__ __forceinline__ void dispatch_count(uint32_t n, F&& f) {
 #ifndef ZKGL_CHECK_WAVES
 #define ZKGL_CHECK_WAVES 4
 #endif
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_WAVES, 8))) void k_check_prog(CheckProgDev cd) {
+// NARROW: cd.cells is a narrow store (store_geom.hpp) and the packets carry address words (cs.cpp build_narrow_layout) — same packets, same relations
+template <bool NARROW>
+__device__ __forceinline__ void check_prog_body(const CheckProgDev& cd) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= cd.n_lanes) return;
@@ -1695,6 +1728,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_
     uint32_t pc = tab[c0];
     const uint32_t end = tab[c1];
     auto ldv = [&](uint32_t slot) -> uint64_t {
+        if constexpr (NARROW) {
+            if (slot & zkgeom::AW_BYTE) return (uint64_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, lane_byte >> 3, (slot & zkgeom::AW_MASK) << (bsh - 3), 0);
+            u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << (bsh - 3), 0);
+            return (uint64_t)v.x | ((uint64_t)v.y << 32);
+        }
         u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << bsh, 0);
         return (uint64_t)v.x | ((uint64_t)v.y << 32);
     };
@@ -1907,6 +1945,30 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_
             return;  // malformed program: built by the host
         }
     }
+}
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_WAVES, 8))) void k_check_prog(CheckProgDev cd) { check_prog_body<false>(cd); }
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_WAVES, 8))) void k_check_prog_narrow(CheckProgDev cd) { check_prog_body<true>(cd); }
+
+// narrow store -> ordinary store (store_geom.hpp; CS::ensure_p2_filled): every reader outside the fused step sees 8-byte slots.  aw[slot] = address
+// word of the slot's value.  A block = 256 lanes x one chunk of slots: reads 64 B or 512 B per wavefront and value, writes 512 B.
+__global__ __launch_bounds__(TPB) void k_widen_store(const uint64_t* __restrict__ narrow, uint64_t narrow_geom, uint64_t* __restrict__ wide, uint64_t wide_geom,
+                                                     uint32_t n_lanes, const uint32_t* __restrict__ aw, uint32_t n_slots, uint32_t slots_per_chunk) {
+    const uint32_t lane = blockIdx.x * TPB + threadIdx.x;
+    if (lane >= n_lanes) return;
+    const uint32_t s0 = blockIdx.y * slots_per_chunk, s1 = min(s0 + slots_per_chunk, n_slots);
+    const prog1_ptr awp = (prog1_ptr)(uintptr_t)aw;
+    uint64_t* __restrict__ out = wide + cell_off(wide_geom, 0, lane);
+    const uint32_t tsh = zkgeom::tile_log2(wide_geom);
+    for (uint32_t slot = s0; slot < s1; ++slot) out[(size_t)slot << tsh] = load_value(narrow, narrow_geom, awp[slot], lane);
+}
+// the same for a LIST of slots at the last iteration of every instance: what ZK_OP_LOOP_LAST of the outer post phase reads (thread = (instance, list entry))
+__global__ void k_widen_last(const uint64_t* __restrict__ narrow, uint64_t narrow_geom, uint64_t* __restrict__ wide, uint64_t wide_geom,
+                             uint32_t n_instances, uint32_t limit, const uint32_t* __restrict__ aw, const uint32_t* __restrict__ slots, uint32_t n_list) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n_instances * n_list) return;
+    const uint32_t inst = (uint32_t)(t % n_instances), slot = slots[t / n_instances];
+    const uint32_t lane = inst * limit + (limit - 1);
+    wide[cell_off(wide_geom, slot, lane)] = load_value(narrow, narrow_geom, aw[slot], lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

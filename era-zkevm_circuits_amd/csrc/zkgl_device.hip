@@ -146,7 +146,11 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
     if (sc.n_lanes == 0 || word_begin >= word_end) return 0;
     const dim3 grid = grid_for(sc.n_lanes, zke::TPB);
     hipStream_t s = (hipStream_t)stream;
-    if (needs_wide_addressing(sc.n_cells)) zke::k_witness_wide<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
+    if (sc.cls) {   // narrow store (store_geom.hpp): the host offers it to the plain loop kernel only (cs.cpp narrow_usable)
+        if (!sc.is_loop || sc.uses_bigint || needs_wide_addressing(sc.n_cells) || !zkgeom::narrow(sc.n_cells)) { g_hip_err = "launch_witness: a narrow store outside the plain loop kernel"; return -1; }
+        zke::k_witness_loop_narrow<<<grid, zke::TPB, lds_pad("ZKGL_LOOP_LDS_PAD"), s>>>(to_dev(sc), sc.cls, word_begin, word_end, slot_begin);
+    }
+    else if (needs_wide_addressing(sc.n_cells)) zke::k_witness_wide<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.is_loop && sc.uses_bigint) zke::k_witness_loop_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.is_loop) zke::k_witness_loop<<<grid, zke::TPB, lds_pad("ZKGL_LOOP_LDS_PAD"), s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.uses_bigint) zke::k_witness_outer_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
@@ -197,8 +201,10 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
         const uint32_t wanted = std::max<uint32_t>(2, (2048 + lane_tiles - 1) / lane_tiles);  // >= ~2048 workgroups
         p.chunks_per_block = std::max<uint32_t>(1, a.n_chunks / wanted);
         dim3 grid(lane_tiles, (a.n_chunks + p.chunks_per_block - 1) / p.chunks_per_block);
-        zke::k_check_prog<<<grid, zke::TPB, lds_pad("ZKGL_CHECK_LDS_PAD"), (hipStream_t)stream>>>(p);
+        if (zkgeom::narrow(a.n_cells)) zke::k_check_prog_narrow<<<grid, zke::TPB, lds_pad("ZKGL_CHECK_LDS_PAD"), (hipStream_t)stream>>>(p);
+        else zke::k_check_prog<<<grid, zke::TPB, lds_pad("ZKGL_CHECK_LDS_PAD"), (hipStream_t)stream>>>(p);
         if (a.macros && a.n_macros) {
+            if (zkgeom::narrow(a.n_cells)) { g_hip_err = "launch_check_gates: Poseidon2 macro packets over a narrow store"; return -1; }
             zke::CheckP2Dev m;
             m.cells = a.cells; m.n_cells = a.n_cells; m.n_lanes = a.n_lanes; m.macros = a.macros; m.n_macros = a.n_macros; m.fail = a.fail;
             const uint32_t want_y = std::max<uint32_t>(1, std::min<uint32_t>(a.n_macros, (2048 + lane_tiles - 1) / lane_tiles));
@@ -208,6 +214,7 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
         }
         return LAUNCH_CHECK("k_check_prog");
     }
+    if (zkgeom::narrow(a.n_cells)) { g_hip_err = "launch_check_gates: only the check program reads a narrow store"; return -1; }
     dim3 grid(grid_for(a.n_lanes, zke::TPB), (a.n_slots + a.slots_per_chunk - 1) / a.slots_per_chunk);
     if (a.alias) zke::k_check_gates_compact<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
     else zke::k_check_gates<<<grid, zke::TPB, 0, (hipStream_t)stream>>>(d);
@@ -302,6 +309,25 @@ int launch_ntt_pass(const NttPassArgs& a, uint32_t n_polys, void* stream) {
     }
     zkn::k_ntt_pass<<<(unsigned)blocks, zkn::TPB, lds, (hipStream_t)stream>>>(d);
     return LAUNCH_CHECK("k_ntt_pass");
+}
+
+int launch_widen_store(const uint64_t* narrow, uint64_t narrow_geom, uint64_t* wide, uint64_t wide_geom, uint32_t n_lanes, const uint32_t* aw, uint32_t n_slots, void* stream) {
+    if (!n_lanes || !n_slots) return 0;
+    if (!zkgeom::narrow(narrow_geom) || zkgeom::narrow(wide_geom)) { g_hip_err = "launch_widen_store: geometry words"; return -1; }
+    const unsigned lane_tiles = grid_for(n_lanes, zke::TPB);
+    uint32_t chunks = std::max<uint32_t>(1, std::min<uint32_t>(n_slots, (4096 + lane_tiles - 1) / lane_tiles));
+    const uint32_t per = (n_slots + chunks - 1) / chunks;
+    chunks = (n_slots + per - 1) / per;
+    zke::k_widen_store<<<dim3(lane_tiles, chunks), zke::TPB, 0, (hipStream_t)stream>>>(narrow, narrow_geom, wide, wide_geom, n_lanes, aw, n_slots, per);
+    return LAUNCH_CHECK("k_widen_store");
+}
+
+int launch_widen_last(const uint64_t* narrow, uint64_t narrow_geom, uint64_t* wide, uint64_t wide_geom, uint32_t n_instances, uint32_t limit, const uint32_t* aw,
+                      const uint32_t* slots, uint32_t n_list, void* stream) {
+    if (!n_instances || !n_list || !limit) return 0;
+    if (!zkgeom::narrow(narrow_geom) || zkgeom::narrow(wide_geom)) { g_hip_err = "launch_widen_last: geometry words"; return -1; }
+    zke::k_widen_last<<<grid_for((size_t)n_instances * n_list, 256), 256, 0, (hipStream_t)stream>>>(narrow, narrow_geom, wide, wide_geom, n_instances, limit, aw, slots, n_list);
+    return LAUNCH_CHECK("k_widen_last");
 }
 
 int launch_fill_p2(uint64_t* store, uint64_t n_store, uint32_t n_lanes, const uint32_t* macros, uint32_t n_macros, void* stream) {

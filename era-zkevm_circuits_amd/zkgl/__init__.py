@@ -71,7 +71,9 @@ class _Stats(C.Structure):
                 ("loop_store_tile_lanes", C.c_uint64),
                 ("constraints_from_store_fused", C.c_uint64), ("constraints_in_witness_fused", C.c_uint64),
                 ("values_below_2_32_outer", C.c_uint64), ("values_below_2_32_loop", C.c_uint64),
-                ("seed_cone_unsupported", C.c_uint64)]
+                ("seed_cone_unsupported", C.c_uint64),
+                ("store_bytes_per_lane_loop", C.c_uint64), ("narrow_store_bytes_per_lane_loop", C.c_uint64), ("narrow_byte_values_loop", C.c_uint64),
+                ("narrow_store_active", C.c_uint64), ("narrow_steps", C.c_uint64), ("narrow_repeats", C.c_uint64)]
 
 
 _lib = None
@@ -1341,6 +1343,14 @@ class ConstraintSystem:
         """zk_cs_set_check_mode: False = fused (default), True = every relation re-evaluated from the stored values;
         defer_p2=True: fused, and the Poseidon2 intermediates are written on demand only (ZK_CHECK_FUSED_DEFER_P2)"""
         _check(lib().zk_cs_set_check_mode(self._h, 2 if defer_p2 else (1 if stored else 0)))
+
+    def narrow_byte_input_words(self):
+        """zk_cs_narrow_byte_input_words: loop input words the narrow layout (ZKGL_NARROW_STORE=1) holds in one-byte slots"""
+        n = C.c_size_t(0)
+        _check(lib().zk_cs_narrow_byte_input_words(self._h, None, C.c_size_t(0), C.byref(n)))
+        buf = (C.c_uint32 * max(n.value, 1))()
+        _check(lib().zk_cs_narrow_byte_input_words(self._h, buf, C.c_size_t(n.value), C.byref(n)))
+        return [int(buf[i]) for i in range(n.value)]
 
     def complete_store(self, stream=None):
         """zk_cs_complete_store: the deferred mode's fill of the Poseidon2 intermediates, on the caller's clock"""

@@ -241,6 +241,11 @@ int zk_cs_set_check_mode(zk_cs *cs, uint32_t mode);
 /* ZK_CHECK_FUSED_DEFER_P2 only: write the values the last zk_cs_resolve_and_check left out now (every reader does it implicitly; a host
  * that wants the cost on its own clock calls this).  No-op otherwise. */
 int zk_cs_complete_store(zk_cs *cs, void *stream);
+/* NARROW STORE (zk_stats, csrc/store_geom.hpp): the loop input stream words whose variables the narrow layout holds in one-byte slots, i.e. the
+ * words the circuit's own constraints bound below 2^8 in every satisfying witness (a larger word there is reported by the step like any other
+ * violated range check).  buf = NULL for the count; 0 words when the circuit has no narrow layout.  zk_cs_complete_store also expands the
+ * narrow store into the ordinary one when the last step left it pending. */
+int zk_cs_narrow_byte_input_words(zk_cs *cs, uint32_t *buf, size_t max_words, size_t *n_words);
 int zk_cs_read_var(zk_cs *cs, zk_var var, uint32_t instance, uint32_t iteration, uint64_t *out); /* witness_hook */
 /* hook_compare_witness (/root/reference/src/fsm_input_output/mod.rs:102-133) as a device-side diff: the circuit's values of the outer
  * variables `vars` (the closed-form input the host cares about: hidden_fsm_output, observable_output ...; recorded handles) against
@@ -310,6 +315,17 @@ typedef struct zk_stats {
     /* 1: the seed kernels are not offered this circuit's cone (zk_cs_seed_* answers ZK_ERR_INVALID unless a native seeder is registered):
      * it holds ZK_OP_BYTEBUF_FILL, or a carried output depends on a gated ZK_OP_POSEIDON2 other than through a select on that op's flag */
     uint64_t seed_cone_unsupported;
+    /* NARROW STORE of the loop scope (opt-in: ZKGL_NARROW_STORE=1 when the circuit is finalized; csrc/store_geom.hpp).  Values that are bytes in
+     * every satisfying witness (the census above) live in one-byte slots of the variable store the fused step writes and reads:
+     *   store_bytes_per_lane_loop         — bytes one loop lane's witness kernel writes into the ordinary store (8 per value)
+     *   narrow_store_bytes_per_lane_loop  — the same with the narrow layout (0: the circuit has none — not asked for, strand-form / macro-op loop)
+     *   narrow_byte_values_loop           — values of a lane held in one-byte slots
+     *   narrow_store_active               — 1: the bound batch runs its fused steps over the narrow store (zk_cs_set_batch decides: plain loop
+     *                                       kernel, inline multiplicities); every other reader sees the ordinary store, expanded on demand
+     *   narrow_steps / narrow_repeats     — fused steps run over the narrow store / of those, steps repeated over the ordinary store because
+     *                                       something was reported (a violated relation, or a value that does not fit its slot): verdicts and
+     *                                       reported gates are always those of the ordinary store */
+    uint64_t store_bytes_per_lane_loop, narrow_store_bytes_per_lane_loop, narrow_byte_values_loop, narrow_store_active, narrow_steps, narrow_repeats;
 } zk_stats;
 /* K12 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
  * column chunking and cell identifiers are [EXT], the argument is defined in csrc/kernels_perm.hpp).  Labels: outer-scope

@@ -158,6 +158,16 @@ static inline void emu_buffer_store_b64(emu_u32x2 v, emu_rsrc r, uint32_t voff, 
 #else
 static inline void emu_buffer_store_b64(emu_u32x2 v, emu_rsrc r, uint32_t voff, uint32_t soff) { memcpy(r.base + (size_t)voff + (size_t)soff, &v, 8); }
 #endif
+// one-byte forms (narrow store: buffer_load_ubyte / buffer_store_byte)
+static inline uint8_t emu_buffer_load_b8(emu_rsrc r, uint32_t voff, uint32_t soff) { return (uint8_t)r.base[(size_t)voff + (size_t)soff]; }
+#ifdef EMU_TSAN
+__attribute__((no_sanitize("thread"), noinline)) static bool emu_same_byte(const char* p, uint8_t v) { return (uint8_t)*p == v; }
+static inline void emu_buffer_store_b8(uint8_t v, emu_rsrc r, uint32_t voff, uint32_t soff) { char* p = r.base + (size_t)voff + (size_t)soff; if (!emu_same_byte(p, v)) *p = (char)v; }
+#else
+static inline void emu_buffer_store_b8(uint8_t v, emu_rsrc r, uint32_t voff, uint32_t soff) { r.base[(size_t)voff + (size_t)soff] = (char)v; }
+#endif
+#define __builtin_amdgcn_raw_buffer_load_b8(rsrc, voff, soff, aux) emu_buffer_load_b8((rsrc), (uint32_t)(voff), (uint32_t)(soff))
+#define __builtin_amdgcn_raw_buffer_store_b8(v, rsrc, voff, soff, aux) emu_buffer_store_b8((uint8_t)(v), (rsrc), (uint32_t)(voff), (uint32_t)(soff))
 #define __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, aux) emu_buffer_load_b64((rsrc), (uint32_t)(voff), (uint32_t)(soff))
 #define __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, soff, aux) emu_buffer_store_b64((v), (rsrc), (uint32_t)(voff), (uint32_t)(soff))
 

@@ -1,0 +1,209 @@
+"""The NARROW STORE of a loop scope (csrc/store_geom.hpp, cs.cpp build_narrow_layout; opt-in: ZKGL_NARROW_STORE=1 when the circuit is finalized).
+
+CS::bound_values proves, from the constraints alone, which values are bytes in EVERY satisfying witness (main_vm: 5 103 of a cycle's 17 700);
+the narrow layout keeps them in one-byte slots of the store the fused step writes and reads (k_witness_loop_narrow, k_check_prog_narrow, links),
+every other reader sees the ordinary store k_widen_store expands it into.  Checked here:
+  host (no GPU): the layout exists, is a prefix sum of the classes, only narrow-capable ops own byte slots, the written bytes fall to <= 0.80 x;
+  -m gpu: main_vm over the narrow store == the oracle, cell for cell, for the whole trace (through the widening), same commitments and
+          multiplicities as the ordinary store; a value that does not fit its byte slot / a tampered witness gives the ordinary store's
+          verdict and failure report; the deferred-Poseidon2 mode on top; wide lane tilings; ram_permutation (reference fixture shape)."""
+import numpy as np
+import pytest
+
+import vm_programs as vp
+import zkgl
+from oracle import zko
+
+LIMIT = 32
+AW_BYTE = 1 << 28
+
+
+def _vm_cs(monkeypatch, narrow=True, limit=LIMIT):
+    if narrow:
+        monkeypatch.setenv("ZKGL_NARROW_STORE", "1")
+    else:
+        monkeypatch.delenv("ZKGL_NARROW_STORE", raising=False)
+    return vp.vm_cs(limit)
+
+
+# ------------------------------------------------------------------------------------------------ host
+def test_main_vm_narrow_layout_meets_the_byte_budget(monkeypatch):
+    cs = _vm_cs(monkeypatch)
+    st = cs.stats()
+    assert st["store_bytes_per_lane_loop"] == 8 * st["cells_written_loop"]
+    assert 0 < st["narrow_store_bytes_per_lane_loop"] <= 0.80 * st["store_bytes_per_lane_loop"], st      # <= 0.80 x
+    assert st["narrow_store_bytes_per_lane_loop"] == 8 * (st["cells_written_loop"] - st["narrow_byte_values_loop"]) + st["narrow_byte_values_loop"]
+    assert st["narrow_byte_values_loop"] <= st["values_below_2_32_loop"]
+    assert st["narrow_store_active"] == 0          # a batch decides (zk_cs_set_batch)
+    plain = _vm_cs(monkeypatch, narrow=False)
+    assert plain.stats()["narrow_store_bytes_per_lane_loop"] == 0     # not asked for: no layout, nothing changes
+
+
+def test_circuits_without_a_plain_loop_kernel_get_no_narrow_layout(monkeypatch):
+    """hash circuits run their loop scope in strand form with macro-ops that stream their own outputs: the layout is not offered"""
+    monkeypatch.setenv("ZKGL_NARROW_STORE", "1")
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
+    cs.configure_keccak()
+    cs.keccak256_round_function_entry_point(2)
+    cs.pad_and_shrink()
+    assert cs.stats()["narrow_store_bytes_per_lane_loop"] == 0
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
+    cs.configure_ram_permutation()
+    cs.ram_permutation_entry_point(8)
+    cs.pad_and_shrink()
+    st = cs.stats()
+    assert 0 < st["narrow_store_bytes_per_lane_loop"] < st["store_bytes_per_lane_loop"]
+
+
+# ------------------------------------------------------------------------------------------------ device
+@pytest.fixture(scope="module")
+def vm_batch():
+    import os
+    old = os.environ.get("ZKGL_NARROW_STORE")
+    os.environ["ZKGL_NARROW_STORE"] = "1"
+    try:
+        d, D = vp.defs()
+        cs = vp.vm_cs(LIMIT)
+    finally:
+        if old is None:
+            os.environ.pop("ZKGL_NARROW_STORE", None)
+        else:
+            os.environ["ZKGL_NARROW_STORE"] = old
+    outer, loop, commits, info = vp.mixed_batch(cs, D, LIMIT, 64)
+    return cs, D, outer, loop, commits, info
+
+
+def _bind(zk, cs, outer, loop):
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.bind_inputs(False, d_o, outer.shape[0])
+    cs.bind_inputs(True, d_l, loop.shape[0])
+    return d_o, d_l
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_log2", [None, "8", "12"], ids=["tiles64", "tiles256", "tiles4096"])
+def test_main_vm_over_the_narrow_store_equals_the_oracle(zk, vm_batch, monkeypatch, tile_log2):
+    from test_main_vm_host import run_oracle
+    cs, D, outer, loop, commits, info = vm_batch
+    B = outer.shape[1]
+    monkeypatch.setenv("ZKGL_STRANDS", "0")          # the plain loop kernel (what a full batch takes): the narrow store's kernel
+    if tile_log2:
+        monkeypatch.setenv("ZKGL_STORE_TILE_LOG2", tile_log2)
+    cs.set_batch(B)
+    assert cs.stats()["narrow_store_active"] == 1
+    raw = loop.copy()
+    raw[0:243] = 0
+    d_o, d_l = _bind(zk, cs, outer, raw)
+    cs.seed_carried_inputs(d_l)
+    assert np.array_equal(d_l.to_numpy().reshape(loop.shape), loop)
+    before = cs.stats()
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    st = cs.stats()
+    assert st["narrow_steps"] == before["narrow_steps"] + 1 and st["narrow_repeats"] == before["narrow_repeats"]    # ran over the narrow store, nothing repeated
+    for i in range(B):
+        assert cs.public_inputs(i) == commits[i], info[i]
+    run = run_oracle(cs, B)
+    run.resolve(outer, loop)
+    assert run.check()[0] == 0
+    # every cell of the trace — through k_widen_store (the ordinary store is what trace readers address)
+    assert np.array_equal(cs.trace(True), run.lc), "loop-scope trace read back from the narrow store differs from the oracle"
+    assert np.array_equal(cs.trace(False), run.oc)
+    total = run.mult.size // B
+    for i in (0, B // 2, B - 1):
+        assert np.array_equal(cs.multiplicities(i), run.mult[i * total:(i + 1) * total])
+    # the full (stored) check reads the widened values
+    ok, f = cs.check_if_satisfied()
+    assert ok, f
+    # a second step after the readers: narrow again
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    assert cs.stats()["narrow_steps"] == st["narrow_steps"] + 1
+
+
+@pytest.mark.gpu
+def test_narrow_store_failures_are_the_ordinary_stores(zk, vm_batch, monkeypatch):
+    """a tampered carried word, and an oracle word that does not fit the byte slot its range check gives it (written truncated, it would BE a
+    boolean): verdict and failure report of the narrow batch == those of the same circuit recorded without the layout (the step is repeated
+    over the ordinary store)"""
+    cs, D, outer, loop, commits, info = vm_batch
+    B = outer.shape[1]
+    monkeypatch.setenv("ZKGL_STRANDS", "0")
+    lay = cs.main_vm_layout()["loop"]
+    victim = next(i for i, (name, seed, chunk) in enumerate(info) if name == "calls" and chunk == 1)
+    bad_a = loop.copy()
+    bad_a[lay["state"][0] + 9, victim * LIMIT + 7] ^= 1
+    byte_words = cs.narrow_byte_input_words()
+    w = lay["src0_read_is_ptr"][0]
+    assert w in byte_words, "the range-checked oracle flag is expected in a one-byte slot"
+    bad_b = loop.copy()
+    bad_b[w, 5 * LIMIT + 3] += 256          # & 0xff it is the boolean the circuit wants: only the overflow test can object
+    plain = _vm_cs(monkeypatch, narrow=False)
+    assert plain.narrow_byte_input_words() == []
+    reports = {}
+    for mode, c in (("narrow", cs), ("ordinary", plain)):
+        c.set_batch(B)
+        assert c.stats()["narrow_store_active"] == (1 if mode == "narrow" else 0)
+        for name, bad in (("carried", bad_a), ("byte", bad_b)):
+            keep = _bind(zk, c, outer, bad)
+            r0 = c.stats()["narrow_repeats"]
+            ok, f = c.resolve_and_check()
+            assert not ok, (mode, name)
+            reports[(mode, name)] = (f.scope, f.instance, f.iteration, f.slot, f.kind, f.relation)
+            if mode == "narrow":
+                assert c.stats()["narrow_repeats"] == r0 + 1
+            del keep
+    assert reports[("narrow", "carried")] == reports[("ordinary", "carried")] and reports[("narrow", "carried")][1] == victim
+    assert reports[("narrow", "byte")] == reports[("ordinary", "byte")] and reports[("narrow", "byte")][1] == 5
+
+
+@pytest.mark.gpu
+def test_narrow_store_with_deferred_poseidon2_intermediates(zk, vm_batch, monkeypatch):
+    """ZK_CHECK_FUSED_DEFER_P2 over the narrow store: the loop kernel leaves the permutations' intermediates out, readers get them from
+    k_fill_p2 AFTER the widening — whole trace == the oracle"""
+    from test_main_vm_host import run_oracle
+    cs, D, outer, loop, commits, info = vm_batch
+    B = 16
+    o, l = outer[:, :B].copy(), loop[:, :B * LIMIT].copy()
+    monkeypatch.setenv("ZKGL_STRANDS", "0")
+    cs.set_batch(B)
+    cs.set_check_mode(False, defer_p2=True)
+    try:
+        _bind(zk, cs, o, l)
+        ok, f = cs.resolve_and_check()
+        assert ok, f
+        assert cs.stats()["narrow_store_active"] == 1
+        run = run_oracle(cs, B)
+        run.resolve(o, l)
+        assert np.array_equal(cs.trace(True), run.lc)
+        for i in range(B):
+            assert cs.public_inputs(i) == commits[i]
+    finally:
+        cs.set_check_mode(False)
+
+
+@pytest.mark.gpu
+def test_ram_permutation_over_the_narrow_store(zk, monkeypatch):
+    """a queue circuit (two Poseidon2 chains per item, LOOP_LAST values in the outer post phase): k_widen_last feeds the outer scope"""
+    from oracle import ram_native as rn
+    monkeypatch.setenv("ZKGL_NARROW_STORE", "1")
+    monkeypatch.setenv("ZKGL_STRANDS", "0")
+    limit = 8
+    cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
+    cs.configure_ram_permutation()
+    cs.ram_permutation_entry_point(limit)
+    cs.pad_and_shrink()
+    from helpers import random_instances
+    insts = random_instances(11, 70, 6, limit)
+    insts[3] = rn.instance([], [], limit, 0)                      # empty queue
+    outer, loop = rn.pack_streams(insts, limit)
+    cs.set_batch(len(insts))
+    assert cs.stats()["narrow_store_active"] == 1
+    _bind(zk, cs, outer, loop)
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    for i, inst in enumerate(insts):
+        assert cs.public_inputs(i) == inst["commitment"]
+    run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), 65536)
+    run.resolve(outer, loop)
+    assert np.array_equal(cs.trace(True), run.lc) and np.array_equal(cs.trace(False), run.oc)

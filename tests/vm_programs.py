@@ -24,13 +24,15 @@ _CS = {}
 
 
 def vm_cs(limit, max_trace_len=1 << 22):
-    if limit not in _CS:
+    import os
+    key = (limit, os.environ.get("ZKGL_NARROW_STORE") == "1")   # (a finalize-time switch: its own recording)
+    if key not in _CS:
         cs = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), max_trace_len, 1 << 28)  # reference_vm_geometry, cycle.rs:959-966
         cs.configure_main_vm(defs()[0])
         cs.main_vm_entry_point(limit)
         cs.pad_and_shrink()
-        _CS[limit] = cs
-    return _CS[limit]
+        _CS[key] = cs
+    return _CS[key]
 
 
 class Asm:
