@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="only the timed default-mode steps (profiler runs: every k_witness_loop launch of the process is then a default-mode launch); the secondary figures are null")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the host-fed figures (packing + H2D of every window overlapped with the steps)")
     ap.add_argument("--fixture", default="default", choices=sorted(FIXTURES), help="which synthetic executions main_vm replays (default: every opcode family every ~150 cycles)")
+    ap.add_argument("--narrow-store", action="store_true", help="run the HEADLINE steps over the narrow store (ZKGL_NARROW_STORE=1 at zk_cs_set_batch: byte-class values in one-byte slots, "
+                    "csrc/store_geom.hpp); without it the narrow store is a labelled mode beside `value` (mode_narrow_store)")
     args = ap.parse_args()
     # ---- N > 1 without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -360,7 +362,12 @@ def main():
     expect = None if expect_e is None else expect_e[((np.arange(S) + rank * S) % n_exec)]
     bufs = [d_loop]
     st = cs.stats()
+    if args.narrow_store:
+        os.environ["ZKGL_NARROW_STORE"] = "1"
     cs.set_batch(B)
+    headline_narrow = bool(cs.stats()["narrow_store_active"])
+    if args.narrow_store and not headline_narrow:
+        raise RuntimeError("--narrow-store: zk_cs_set_batch did not take the narrow store (no layout, strand-form loop launch, or no room for both stores)")
 
     # ---- the path's only collective: ONE all-gather of the 4-element input commitments of the batch PER STEP, behind the
     # C ABI (zk_comm_* + zk_cs_gather_commitments = k_pack_public + one ncclAllGather over RCCL / xGMI on the step's stream), INSIDE the
@@ -595,6 +602,48 @@ def main():
             resolve(last_window)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] re-resolve after the realistic-fixture run failed: {e}", file=sys.stderr)
+    # ---- LABELLED MODE, not `value`: the NARROW STORE (csrc/store_geom.hpp).  The values the circuit's own constraints bound below 2^8 in every
+    # satisfying witness (zk_stats.narrow_byte_values_loop of a cycle's values) live in one-byte slots of the store the fused step writes and
+    # reads; every other reader gets the ordinary store through k_widen_store (timed here on its own).  Same steps from the raw witness
+    # (seeding pass, fused check, gather), then the same with the Poseidon2 intermediates deferred on top (the two byte levers together).
+    narrow = None
+    if not args.headline_only and not headline_narrow and not os.environ.get("ZKGL_STUB_RUN") and st["narrow_store_bytes_per_lane_loop"]:
+        try:
+            os.environ["ZKGL_NARROW_STORE"] = "1"
+            cs.set_batch(B)
+            if not cs.stats()["narrow_store_active"]:
+                raise RuntimeError("zk_cs_set_batch did not take the narrow store at this batch")
+            narrow = {}
+            for label, defer in (("plain", False), ("p2_deferred", True)):
+                cs.set_check_mode(False, defer_p2=defer)
+                step_no[0] = 0
+                step(); fence()
+                step_no[0] = 0
+                n_loop_ms, n_gate_ms = [], []
+                r0 = cs.stats()["narrow_repeats"]
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                    n_loop_ms.append(cs.last_ms(1)); n_gate_ms.append(cs.last_ms(3))
+                fence()
+                n_elapsed = time.perf_counter() - t1
+                resolve(window[0]); torch.cuda.synchronize()
+                tw = time.perf_counter(); cs.complete_store(stream); torch.cuda.synchronize(); widen_s = time.perf_counter() - tw
+                n_local = np.array([cs.public_inputs(i) for i in range(min(B, 8))], dtype=np.uint64)
+                narrow[label] = {"elapsed": n_elapsed, "loop_ms": float(np.mean(n_loop_ms)), "gate_ms": float(np.mean(n_gate_ms)),
+                                 "complete_store_s": widen_s, "repeats": int(cs.stats()["narrow_repeats"] - r0),
+                                 "commitments_equal": bool(expect is None or np.array_equal(n_local, expect[window[0] * B: window[0] * B + n_local.shape[0]]))}
+        except Exception as e:  # noqa: BLE001
+            narrow = {"error": repr(e)}
+            print(f"[bench] narrow-store figure unavailable: {e}", file=sys.stderr)
+        os.environ.pop("ZKGL_NARROW_STORE", None)
+        try:
+            cs.set_check_mode(False)
+            cs.set_batch(B)          # back to the ordinary store for what follows
+            step_no[0] = 0
+            resolve(last_window)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] re-resolve after the narrow-store run failed: {e}", file=sys.stderr)
     # ---- the host side of the step, measured: every window packed from the WitnessOracle FIFOs on this rank's share of the host threads and
     # copied to the device while the GPU resolves the previous window (HostFeed / host_fed_steps above).  Labelled figures beside `value`
     # (whose inputs are resident, as the contract asks).  No collective inside: a failure on one rank must not hang the others.
@@ -639,7 +688,8 @@ def main():
         # rows written once (8 B; one per variable — the trace is a view of the variable store) + every input word
         # read once.  SURVEY §8(d) counts every trace CELL (a variable occupies 3.1 cells on average): that figure is reported
         # beside it as trace_cell_equivalent_GBps, it is not what the kernel has to move.
-        algo_bytes = B * st["limit"] * (st["cells_written_loop"] + n_loop) * 8
+        lane_bytes = (st["narrow_store_bytes_per_lane_loop"] if headline_narrow else st["cells_written_loop"] * 8) + n_loop * 8
+        algo_bytes = B * st["limit"] * lane_bytes
         cell_bytes = B * st["limit"] * (st["cells_populated_loop"] + n_loop) * 8
         k_ms = float(np.mean(loop_ms))
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
@@ -744,13 +794,29 @@ def main():
                 "k_fill_p2_ms_per_batch": 1e3 * deferred["fill_s"],
                 "ms_per_step_with_fill": 1e3 * (deferred["elapsed"] / args.steps + deferred["fill_s"]),
                 "commitments_equal_native_restatement": deferred["commitments_equal"]},
-            "roofline": {"bound": "hbm", "kernel": "zke::k_witness_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "mode_narrow_store": None if narrow is None else narrow if "error" in narrow else {
+                "what": "ZKGL_NARROW_STORE=1 at zk_cs_set_batch (csrc/store_geom.hpp): the values the constraints bound below 2^8 in every satisfying witness live in one-byte "
+                        "slots of the store the fused step writes and reads (k_witness_loop_narrow, k_check_prog_narrow, links); same steps from the raw witness (seeding pass, "
+                        "fused check, gather).  Every reader outside the step gets the ordinary store through k_widen_store (complete_store_ms_per_batch).  p2_deferred: "
+                        "ZK_CHECK_FUSED_DEFER_P2 on top (its complete_store = widening + k_fill_p2)",
+                "bytes_written_per_cycle": st["narrow_store_bytes_per_lane_loop"], "bytes_written_per_cycle_ordinary_store": st["store_bytes_per_lane_loop"],
+                "bytes_ratio": st["narrow_store_bytes_per_lane_loop"] / st["store_bytes_per_lane_loop"], "byte_values_per_cycle": st["narrow_byte_values_loop"],
+                **{label: {"value": st["constraints_per_instance"] * B * args.steps / r["elapsed"], "unit": "constraints/s (this rank's GPU)",
+                           "ms_per_step": 1e3 * r["elapsed"] / args.steps, "k_witness_loop_narrow_ms": r["loop_ms"], "k_check_prog_narrow_ms": r["gate_ms"],
+                           "algorithmic_bytes_per_launch": B * st["limit"] * (st["narrow_store_bytes_per_lane_loop"] - (950 * p2_per_cycle * 8 if label == "p2_deferred" else 0) + n_loop * 8),
+                           "achieved_GBps": B * st["limit"] * (st["narrow_store_bytes_per_lane_loop"] - (950 * p2_per_cycle * 8 if label == "p2_deferred" else 0) + n_loop * 8) / (r["loop_ms"] * 1e-3) / 1e9,
+                           "values_per_s_vs_ordinary_store_kernel": k_ms / r["loop_ms"],
+                           "complete_store_ms_per_batch": 1e3 * r["complete_store_s"], "steps_repeated_over_the_ordinary_store": r["repeats"],
+                           "commitments_equal_native_restatement": r["commitments_equal"]} for label, r in narrow.items()}},
+            "roofline": {"bound": "hbm", "kernel": "zke::k_witness_loop_narrow" if headline_narrow else "zke::k_witness_loop", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # the OTHER roofline that binds this kernel (co-limited): fraction of the cycles in which the vector ALUs of a
                          # SIMD were issuing, from the PMC pass of the committed profile (peak = 1: every SIMD issues every cycle it can)
                          "frac_valu_issue": valu_busy, "frac_valu_issue_source": valu_src,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
-                         "unit_of_work": "values (one per variable, 8 B): the variable store; trace cells are a view of it",
+                         "unit_of_work": ("values (one per variable; narrow store: 1 B for the values the constraints bound below 2^8, 8 B otherwise)" if headline_narrow else
+                                          "values (one per variable, 8 B): the variable store; trace cells are a view of it"),
+                         "bytes_written_per_cycle": lane_bytes - n_loop * 8,
                          "avg_launch_ms": k_ms,
                          # clock probe inside the kernel (s_memtime / s_memrealtime of its first wavefront): the clock the power management
                          # granted this launch (2.09-2.27 GHz seen; the kernel's time has not followed it, profiles/r3_loop_probe.md §4)

@@ -88,26 +88,7 @@ extern "C" {
 const char* zk_last_error(void) { return g_err.c_str(); }
 
 uint32_t zk_build_features(void) {
-    uint32_t f = 0;
-#ifdef ZKGL_BYTEBUF_KERNEL
-    f |= ZK_BUILD_BYTEBUF_KERNEL;
-#endif
-#ifdef ZKGL_STRAND_PLANES_KERNEL
-    f |= ZK_BUILD_STRAND_PLANES_KERNEL;
-#endif
-#ifdef ZKGL_SELECT_CHAINS_KERNEL
-    f |= ZK_BUILD_SELECT_CHAINS_KERNEL;
-#endif
-#ifdef ZKGL_BATCH_INV
-    f |= ZK_BUILD_BATCH_INV;
-#endif
-#ifdef ZKGL_SHA4_KERNEL
-    f |= ZK_BUILD_SHA4_KERNEL;
-#endif
-#ifdef ZKGL_P2_MERGE
-    f |= ZK_BUILD_P2_MERGE;
-#endif
-    return f;
+    return ZK_BUILD_BYTEBUF_KERNEL | ZK_BUILD_SHA4_KERNEL;   // one build: every device path of the tree is in it
 }
 
 int zk_device_count(void) {

@@ -57,8 +57,8 @@ struct W4 {                 // a u32 as nibbles; `packed` (the word as one field
 };
 
 // The gadget is the HOST backend of zks4::compress (csrc/sha256_macro4.hpp): the walk the device macro-op (ZK_OP_SHA256_ROUNDS, a = 1), the
-// counting backend and the oracle make too.  Plain mode (default): every primitive records its witness op AND its constraint.  Macro mode
-// (ZKGL_SHA4_MACRO=1): a compression records ONE witness op over the 96 input bytes whose outputs are pre-allocated variables, and the
+// counting backend and the oracle make too.  Plain mode (ZKGL_SHA4_MACRO=0): every primitive records its witness op AND its constraint.  Macro mode
+// (the default since round 6): a compression records ONE witness op over the 96 input bytes whose outputs are pre-allocated variables, and the
 // walk places the same lookups / gates over them in the same order — the same circuit, cell for cell (tests/test_sha4_macro.py).
 struct S4 {
     typedef Word Bytes;
@@ -77,7 +77,7 @@ struct S4 {
         t_maj = g.cs.table_id(TABLE_MAJ4); t_tri = g.cs.table_id(TABLE_TRIXOR4); t_ch = g.cs.table_id(TABLE_CH4);
         t_s1 = g.cs.table_id(TABLE_SPLIT4_1); t_s2 = g.cs.table_id(TABLE_SPLIT4_2);
         const char* e = getenv("ZKGL_SHA4_MACRO");
-        use_macro = e && e[0] == '1';
+        use_macro = !(e && e[0] == '0');   // round 6: the macro-op is the default recording of the reference's table set (its kernels: k_witness_*_x<X_SHA4>)
     }
     // ---- recording primitives: plain (witness op + constraint) or macro mode (constraint over the next pre-allocated outputs)
     std::vector<zk_var> look(uint32_t table, const std::vector<zk_var>& keys, uint32_t n_vals) {

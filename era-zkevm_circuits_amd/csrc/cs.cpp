@@ -985,7 +985,7 @@ void CS::bound_values(Scope& s) {
                 s.is_loop ? "loop" : "outer", s.values_below_2_32, s.n_vars, s.values_below_2_8);
 }
 
-// NARROW STORE of the loop scope (store_geom.hpp; opt-in: ZKGL_NARROW_STORE=1 at finalize).  bound_values says which variables are bytes in
+// NARROW STORE of the loop scope (store_geom.hpp; a batch uses it when ZKGL_NARROW_STORE=1 is set at zk_cs_set_batch).  bound_values says which variables are bytes in
 // every satisfying witness; a byte-class value takes ONE unit of its wavefront's tile (one byte per lane) instead of eight.  The class is a
 // storage decision of the host: a variable is byte-class only when (a) its bound is <= 2^8, (b) the op producing it is one whose handler in the
 // narrow kernel stores through the class word (narrow_capable), (c) it is among the first 31 outputs of its op.  A witness that puts a larger
@@ -1002,11 +1002,10 @@ static bool narrow_capable(uint32_t opcode) {
 void CS::build_narrow_layout(Scope& s) {
     s.narrow_ok = false; s.slot_aw.clear(); s.narrow_units = 0; s.narrow_byte_values = 0;
     narrow_enabled_ = false;
+    // the layout and its programs are built for every loop scope that can use them (host memory only: ~4 B per program word); a BATCH takes
+    // the narrow store when ZKGL_NARROW_STORE=1 is set at zk_cs_set_batch.  ZKGL_NARROW_STORE=0 at finalize: no layout at all.
     const char* e = getenv("ZKGL_NARROW_STORE");
-    if (!(e && e[0] == '1') || !s.is_loop || !limit_ || s.uses_bigint) return;
-#if defined(ZKGL_P2_MERGE) || defined(ZKGL_BATCH_INV) || defined(ZKGL_SELECT_CHAINS_KERNEL)
-    return;   // (variant builds re-decode headers: the class words are indexed by decoded headers)
-#endif
+    if ((e && e[0] == '0') || !s.is_loop || !limit_ || s.uses_bigint) return;
     for (auto& op : s.ops)   // macro-ops stream their outputs through their own store paths (and their circuits run in strand form)
         if (!op.seed_only && (op.opcode == ZK_OP_KECCAK_F || op.opcode == ZK_OP_SHA256_ROUNDS || op.opcode == ZK_OP_BYTEBUF_FILL || op.opcode == ZK_OP_NN_MULMOD)) return;
     std::vector<uint8_t> is_byte(s.n_store, 0);
@@ -1195,113 +1194,9 @@ void CS::schedule_loop_ops() {
 // FETCH_SIZE agrees); this order leaves 6.6 k.  A window of 16 touches is the flat optimum of the model (12..20: 6.6-6.8 k; 8: 7.4 k,
 // 48: 8.2 k) and of the kernel (B=384, one box: recording order 43.5 ms, windows 8 / 16 / 48: 42.2 / 40.0 / 42.9 ms).  Weighting misses,
 // a last-consumer bonus or a larger group bonus change the model by < 2 %.
-// Mux chains (opt-in, ZKGL_SELECT_CHAINS=1).  79 % of main_vm's SELECTs take another SELECT's output as their `b` operand:
-// r_k = f_k ? cand_k : r_(k-1) over the opcode families, recorded limb-parallel (parallel_select), so the schedule interleaves the links
-// of 8 / 12 chains and every link reads the previous one back from the store.  This pass transposes every run of consecutive SELECTs
-// whose flags and `a` operands all come from before the run: the links of one chain become consecutive ops (any topological order
-// fills the same cells), which is what the chain form of the device program needs (emit_scope: one op per chain, `r` in a register).
-// Variant build (-DZKGL_P2_MERGE).  The execute-gated witness-only permutations of a loop body form a few dependency LEVELS (main_vm: 18
-// of them in 5: a level = the longest chain of gated permutations a site depends on, through any path of ops); the members of a level cannot
-// depend on each other, so they may sit next to each other in the program — where emit_scope puts them under one header (group cap 5) and the
-// kernel runs one permutation per round for the whole level.  This pass re-orders the scheduled ops so that they do: a list pass in the
-// current order in which a gated permutation is emitted only together with every other member of its level (bundles of <= 5 in order).
-void CS::bundle_gated_permutations() {
-#ifdef ZKGL_P2_MERGE
-    Scope& s = loop_;
-    if (!limit_ || s.ops.empty()) return;
-    const size_t n = s.ops.size();
-    std::vector<int> vlvl(s.n_vars, 0), bundle(n, -1);
-    std::vector<int64_t> producer(s.n_vars, -1);
-    std::map<int, std::vector<size_t>> by_level;
-    for (size_t oi = 0; oi < n; ++oi) {
-        const OpRec& op = s.ops[oi];
-        int in = 0;
-        for (auto& x : op.ins) if (x.kind == Operand::VAR) in = std::max(in, vlvl[x.idx]);
-        const bool gated = !op.seed_only && op.opcode == ZK_OP_POSEIDON2 && op.a == 1;
-        if (op.seed_only) continue;   // (a hint is a second producer of values the trace ops produce: it does not define levels)
-        for (uint32_t ov : op.outs) { vlvl[ov] = gated ? in + 1 : in; producer[ov] = (int64_t)oi; }
-        if (gated) by_level[in + 1].push_back(oi);
-    }
-    std::vector<std::vector<size_t>> bundles;
-    for (auto& kv : by_level)
-        for (size_t at = 0; at < kv.second.size(); at += 5) {
-            bundles.emplace_back(kv.second.begin() + at, kv.second.begin() + std::min(kv.second.size(), at + 5));
-            for (size_t oi : bundles.back()) bundle[oi] = (int)bundles.size() - 1;
-        }
-    if (bundles.empty()) return;
-    std::vector<uint8_t> done(n, 0);
-    auto ready = [&](size_t oi) {
-        for (auto& x : s.ops[oi].ins) if (x.kind == Operand::VAR && producer[x.idx] >= 0 && !done[(size_t)producer[x.idx]] && (size_t)producer[x.idx] != oi) return false;
-        return true;
-    };
-    std::vector<size_t> order;
-    order.reserve(n);
-    size_t head = 0;
-    while (order.size() < n) {
-        while (head < n && done[head]) ++head;
-        bool progressed = false;
-        for (size_t oi = head; oi < n; ++oi) {
-            if (done[oi] || !ready(oi)) continue;
-            if (bundle[oi] >= 0) {
-                const auto& b = bundles[(size_t)bundle[oi]];
-                bool all = true;
-                for (size_t m : b) all = all && ready(m);
-                if (!all) continue;
-                for (size_t m : b) { done[m] = 1; order.push_back(m); }
-            } else { done[oi] = 1; order.push_back(oi); }
-            progressed = true;
-            break;
-        }
-        if (!progressed) return;   // cannot happen (levels are antichains); leave the schedule as it is
-    }
-    std::vector<OpRec> out;
-    out.reserve(n);
-    for (size_t oi : order) out.push_back(std::move(s.ops[oi]));
-    s.ops = std::move(out);
-    if (getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] bundle_gated_permutations: %zu gated permutations in %zu levels, %zu bundles\n", [&] { size_t c = 0; for (auto& b : bundles) c += b.size(); return c; }(), by_level.size(), bundles.size());
-#endif
-}
-
-void CS::chain_selects() {
-    const char* e = std::getenv("ZKGL_SELECT_CHAINS");   // 1: transpose (and, in a -DZKGL_SELECT_CHAINS_KERNEL build, emit chain ops); the order alone is valid everywhere
-    Scope& s = loop_;
-    if (!(e && e[0] == '1') || !limit_ || s.ops.empty()) return;
-    const size_t n = s.ops.size();
-    std::vector<int64_t> producer(s.n_vars, -1);
-    for (size_t i = 0; i < n; ++i) for (uint32_t ov : s.ops[i].outs) if (!s.ops[i].seed_only) producer[ov] = (int64_t)i;
-    std::vector<OpRec> out;
-    out.reserve(n);
-    size_t i = 0;
-    uint64_t runs = 0, moved = 0;
-    while (i < n) {
-        auto is_sel = [&](size_t k) { return !s.ops[k].seed_only && s.ops[k].opcode == ZK_OP_SELECT && s.ops[k].ins.size() == 3; };
-        if (!is_sel(i)) { out.push_back(std::move(s.ops[i])); ++i; continue; }
-        // the run [i, j): SELECTs whose flag and `a` are produced before i (or are not variables of this scope)
-        size_t j = i;
-        auto outside = [&](const Operand& o) { return o.kind != Operand::VAR || producer[o.idx] < (int64_t)i; };
-        while (j < n && is_sel(j) && outside(s.ops[j].ins[0]) && outside(s.ops[j].ins[1])) ++j;
-        if (j == i) { out.push_back(std::move(s.ops[i])); ++i; continue; }
-        // chains inside the run: next[x] = the first later op of the run whose `b` is x's output
-        const size_t len = j - i;
-        std::vector<int64_t> next(len, -1), head_of(len, -1);
-        std::vector<uint8_t> has_prev(len, 0);
-        for (size_t y = 0; y < len; ++y) {
-            const Operand& b = s.ops[i + y].ins[2];
-            if (b.kind != Operand::VAR) continue;
-            const int64_t p = producer[b.idx];
-            if (p >= (int64_t)i && p < (int64_t)(i + y) && next[(size_t)p - i] < 0) { next[(size_t)p - i] = (int64_t)y; has_prev[y] = 1; }
-        }
-        for (size_t h = 0; h < len; ++h) {
-            if (has_prev[h]) continue;
-            for (int64_t x = (int64_t)h; x >= 0; x = next[(size_t)x]) { moved += next[(size_t)x] >= 0; out.push_back(s.ops[i + (size_t)x]); }
-        }
-        ++runs;
-        i = j;
-    }
-    if (out.size() != n) throw ZkError(ZK_ERR_INVALID, "internal: chain_selects lost an op");
-    s.ops = std::move(out);
-    if (getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] chain_selects: %llu runs of SELECTs transposed, %llu chain links\n", (unsigned long long)runs, (unsigned long long)moved);
-}
+// (Round 5 carried two more passes here — mux chains of SELECTs as one op, and the gated witness-only permutations of a dependency level under
+// one header executed in rounds — as compile-time variants that no device ever ran; round 6 deleted both with their kernel halves.  What they were
+// after is in profiles/r5_iszero_stats.json; by the elimination runs of profiles/r3_loop_probe.md the kernel's memory traffic binds first.)
 
 // SELECT flags the plain loop kernel keeps as bit planes (ZK_OP_FLAG_PLANES): the FLAG_PLANES most used flag variables of a loop scope
 // that at least two SELECTs read.  One rule for the scheduler (such a read costs no operand fetch) and for emit_scope (the plane ids).
@@ -1478,28 +1373,9 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
         };
         for (auto& st : strand) st.clear();
         uint64_t total = 0, critical = 0;
-        // SELECT flags as bit planes in the strand form of a loop scope (ZKGL_STRAND_PLANES=1; kernels_engine2.hpp): the tile's wavefronts
-        // share one set of planes.  A flag produced in level L is copied by ONE strand in level L + 1 (ZK_OP_FLAG_PLANES reads the stored
-        // value, behind the barrier that ends L) and SELECTs from level L + 2 on read the plane (behind the barrier that ends L + 1);
-        // a SELECT in level L + 1 itself keeps the slot.
-        const char* spl_env = getenv("ZKGL_STRAND_PLANES");
-        const bool strand_planes = s.is_loop && ph == 0 && spl_env && spl_env[0] == '1';
-        if (strand_planes) uses_strand_planes_ = true;
-        const std::vector<uint32_t> plane_all = strand_planes ? select_plane_vars(s) : std::vector<uint32_t>();
-        std::vector<uint32_t> plane_now(strand_planes ? s.n_vars : 0, UINT32_MAX);   // variable -> plane id once its plane is readable
-        std::vector<std::vector<uint32_t>> copy_at(n_levels + 2), readable_at(n_levels + 3);
-        std::vector<uint32_t> copied_in(strand_planes ? s.n_vars : 0, UINT32_MAX);   // level whose program holds the flag's copy (checked below)
-        if (strand_planes) {
-            for (uint32_t v = 0; v < s.n_vars; ++v)
-                if (plane_all[v] != UINT32_MAX && producer[v] >= (int64_t)o0) {
-                    const uint32_t lf = level[(size_t)producer[v]];
-                    copy_at[lf + 1].push_back(v); readable_at[lf + 2].push_back(v);
-                }
-            plane_of_ = &plane_now;
-        }
+        // (strand programs keep SELECT flags in store slots: a strand form of the bit planes existed in round 5, unmeasured, and was deleted in round 6)
         for (uint32_t lv = 0; lv < n_levels; ++lv) {
             auto& ops = by_level[lv];
-            if (strand_planes) for (uint32_t v : readable_at[lv]) plane_now[v] = plane_all[v];
             std::stable_sort(ops.begin(), ops.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
             uint64_t load[NS_MAX] = {0};
             std::vector<uint32_t> mine[NS_MAX];
@@ -1529,8 +1405,6 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
                     if (grouping) {
                         if (op.opcode == ZK_OP_LOOKUP && op.a <= 2 && op.b <= 2) key = ((uint64_t)ZK_OP_LOOKUP << 56) | ((uint64_t)op.ins[0].idx << 24) | ((uint64_t)op.a << 8) | op.b;
                         else if (op.opcode == ZK_OP_SELECT || op.opcode == ZK_OP_FMA || op.opcode == ZK_OP_INPUT || op.opcode == ZK_OP_U32MULADD) key = (uint64_t)op.opcode << 56;
-                        // a group is homogeneous: plane flags or slot flags
-                        if (strand_planes && op.opcode == ZK_OP_SELECT && op.ins[0].kind == Operand::VAR && plane_now[op.ins[0].idx] != UINT32_MAX) key |= 1;
                     }
                     if (!groups.count(key)) order.push_back(key);
                     groups[key].push_back(oi);
@@ -1546,12 +1420,6 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
                     } else counted = f0.opcode == ZK_OP_SELECT || f0.opcode == ZK_OP_FMA || f0.opcode == ZK_OP_INPUT || f0.opcode == ZK_OP_U32MULADD || f0.opcode == ZK_OP_LC4;
                     for (size_t i0 = 0; i0 < g.size(); i0 += cap) {
                         std::vector<size_t> part(g.begin() + i0, g.begin() + std::min(g.size(), i0 + cap));
-                        if (strand_planes && f0.opcode == ZK_OP_SELECT)   // a plane is read only behind the barrier that ends the level of its copy
-                            for (size_t oi : part) {
-                                const uint32_t fv = s.ops[oi].ins[0].idx;
-                                if (s.ops[oi].ins[0].kind == Operand::VAR && plane_now[fv] != UINT32_MAX && !(copied_in[fv] < lv))
-                                    throw ZkError(ZK_ERR_INVALID, "internal: a SELECT reads a flag plane that no earlier level has written");
-                            }
                         emit_group_v2(s, part, counted, strand[k]);
                         for (size_t oi : part) {
                             const OpRec& op = s.ops[oi];
@@ -1560,22 +1428,6 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
                             strand[k].push_back(op.outs.empty() ? 0u : s.var_slot[op.outs[0]]);
                         }
                     }
-                }
-            }
-            if (strand_planes && lv < copy_at.size() && !copy_at[lv].empty()) {   // this level's copies go to the lightest strand
-                uint32_t best = 0;
-                for (uint32_t k = 1; k < NS; ++k) if (load[k] < load[best]) best = k;
-                const auto& cp = copy_at[lv];
-                for (size_t at = 0; at < cp.size(); at += 7) {
-                    const size_t nn = std::min<size_t>(7, cp.size() - at);
-                    strand[best].push_back((uint32_t)ZK_OP_FLAG_PLANES | ((uint32_t)(nn - 1) << 16));
-                    for (size_t q = 0; q < nn; ++q) {
-                        const uint32_t fv = cp[at + q];
-                        if (level[(size_t)producer[fv]] >= lv) throw ZkError(ZK_ERR_INVALID, "internal: a flag plane is copied in the level that produces the flag");
-                        copied_in[fv] = lv;
-                        strand[best].push_back(s.var_slot[fv]); strand[best].push_back(plane_all[fv]);
-                    }
-                    load[best] += 10 + 4 * nn;
                 }
             }
             for (uint32_t k = 0; k < NS; ++k) total += load[k];
@@ -1654,32 +1506,12 @@ void CS::verify_device_programs(const Scope& s) const {
             for (uint32_t k = 0; k < n; ++k) hk.plane_write(prog[pc + 1 + 2 * k], prog[pc + 2 + 2 * k], pc);
             return pc + 1 + 2 * n;
         }
-        if (opc == ZK_OP_SELECT && pa == 2) {   // chain (plain form only)
-            if (D) fail("a chain op in a strand program", pc);
-            const uint32_t n = pb + 1;
-            if (n > 7) fail("chain longer than 7", pc);
-            int64_t prev_out = -1;
-            for (uint32_t k = 0; k < n; ++k) {
-                const int64_t oi = hk.expect(pc, 0);
-                if (oi < 0) fail("chain link without an op", pc);
-                const OpRec& op = s.ops[(size_t)oi];
-                if (op.opcode != ZK_OP_SELECT) fail("chain link is not a SELECT", pc);
-                if (k == 0) { if (prog[pc + 1] != s.var_slot[op.ins[2].idx]) fail("chain: b0 slot", pc); }
-                else if ((int64_t)op.ins[2].idx != prev_out) fail("chain: link's b is not the previous link's output", pc);
-                if (plane_all[op.ins[0].idx] != prog[pc + 2 + 2 * k]) fail("chain: plane id", pc);
-                if (prog[pc + 3 + 2 * k] != s.var_slot[op.ins[1].idx]) fail("chain: a slot", pc);
-                hk.plane_read(prog[pc + 2 + 2 * k], (size_t)oi, pc);
-                hk.on_op((size_t)oi, s.var_slot[op.outs[0]], pc);
-                prev_out = op.outs[0];
-            }
-            return pc + 2 + 2 * n;
-        }
+        if (opc == ZK_OP_SELECT && pa == 2) fail("SELECT header with a = 2 (the mux-chain form was deleted in round 6: no kernel decodes it)", pc);
         // members of the header, as the kernel derives them
         uint32_t N = 1;
         bool grouped_lookup = false;
         if (opc == ZK_OP_INPUT || opc == ZK_OP_SELECT || opc == ZK_OP_FMA || opc == ZK_OP_U32MULADD) N = pb + 1;
-        const bool merged_p2 = opc == ZK_OP_POSEIDON2 && pa == 2;   // -DZKGL_P2_MERGE builds: <= 5 gated permutations under one header (plain form only)
-        if (merged_p2) { N = pb + 1; if (D || N < 2 || N > 5) fail("merged gated permutations: 2..5 members, plain form only", pc); }
+        if (opc == ZK_OP_POSEIDON2 && pa == 2) fail("POSEIDON2 header with a = 2 (the merged gated form was deleted in round 6: no kernel decodes it)", pc);
         if (opc == ZK_OP_LOOKUP) { const uint32_t nv = pb & 0xff; grouped_lookup = pa <= 2 && nv <= 2; N = grouped_lookup ? (pb >> 8) + 1 : 1; if (!grouped_lookup && (pb >> 8)) fail("wide lookup with members", pc); }
         const size_t first_operand = pc + 1 + (opc == ZK_OP_LOOKUP ? 1 : 0);
         size_t K = SIZE_MAX, at = first_operand;
@@ -1706,9 +1538,8 @@ void CS::verify_device_programs(const Scope& s) const {
             if (K == SIZE_MAX) fail("opcode without a kernel layout", pc);
             if (opc == ZK_OP_LOOKUP && prog[pc + 1] != op.ins[0].idx) fail("lookup table id", pc);
             const bool counted = opc == ZK_OP_INPUT || opc == ZK_OP_SELECT || opc == ZK_OP_FMA || opc == ZK_OP_U32MULADD || opc == ZK_OP_LC4 || opc == ZK_OP_LOOKUP;
-            if (merged_p2) { if (op.a != 1) fail("merged gated permutations: a member is not gated", pc); }
-            else if (!(opc == ZK_OP_SELECT && pa == 1) && pa != op.a) fail("header a", pc);
-            if (!counted && !merged_p2 && pb != op.b) fail("header b", pc);
+            if (!(opc == ZK_OP_SELECT && pa == 1) && pa != op.a) fail("header a", pc);
+            if (!counted && pb != op.b) fail("header b", pc);
             if (opc == ZK_OP_LOOKUP && (pb & 0xff) != op.b) fail("lookup n_vals", pc);
             if (opc == ZK_OP_SELECT && pa == 1) {   // plane form: [plane id, a, b]
                 if (plane_all[op.ins[0].idx] == UINT32_MAX || prog[at] != plane_all[op.ins[0].idx]) fail("plane SELECT: plane id", pc);
@@ -1819,6 +1650,7 @@ bool CS::loop_runs_strands(const Scope& s, int phase, uint32_t n_lanes) const {
 }
 
 void CS::launch_phase(const Scope& s, zkdev::ScopeArgs a, int phase, void* stream, uint32_t n_lanes) const {
+    a.xmacros = (uses_sha4_macro_ ? 1u : 0u) | (uses_bytebuf_macro_ ? 2u : 0u);   // kernels_engine2.hpp X_SHA4 / X_BYTEBUF: the kernels that carry those macro-op backends
     const char* e = getenv("ZKGL_STRANDS");  // 0 off, 1 always, unset: by size and estimated gain
     const int mode = e ? atoi(e) : -1;
     const uint32_t waves = ((n_lanes ? n_lanes : s.n_lanes) + 63) / 64;
@@ -1885,15 +1717,6 @@ void CS::emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool co
             for (size_t q = 1; q < s.ops[oi].ins.size(); ++q) operand_v2(s, s.ops[oi], q, out);
         return;
     }
-    if (first.opcode == ZK_OP_SELECT && emit_chain_ && plane_of_) {   // a mux chain: [b0][plane id, a slot] per link
-        out.push_back((uint32_t)ZK_OP_SELECT | (2u << 8) | ((uint32_t)(n - 1) << 16));
-        operand_v2(s, first, 2, out);
-        for (size_t oi : group) {
-            out.push_back((*plane_of_)[s.ops[oi].ins[0].idx]);
-            operand_v2(s, s.ops[oi], 1, out);
-        }
-        return;
-    }
     if (first.opcode == ZK_OP_SELECT && plane_of_ && (*plane_of_)[first.ins[0].idx] != UINT32_MAX) {   // flags from the bit planes
         out.push_back((uint32_t)ZK_OP_SELECT | (1u << 8) | ((uint32_t)(n - 1) << 16));
         for (size_t oi : group) {
@@ -1901,12 +1724,6 @@ void CS::emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool co
             operand_v2(s, s.ops[oi], 1, out);
             operand_v2(s, s.ops[oi], 2, out);
         }
-        return;
-    }
-    if (first.opcode == ZK_OP_POSEIDON2) {   // one gated permutation: a = 1 (b = 0); several (a -DZKGL_P2_MERGE build): a = 2, b = members - 1
-        out.push_back((uint32_t)ZK_OP_POSEIDON2 | ((n > 1 ? 2u : (uint32_t)first.a) << 8) | ((uint32_t)(n - 1) << 16));
-        for (size_t oi : group)
-            for (size_t q = 0; q < s.ops[oi].ins.size(); ++q) operand_v2(s, s.ops[oi], q, out);
         return;
     }
     out.push_back((uint32_t)first.opcode | ((uint32_t)first.a << 8) | ((counted ? (uint32_t)(n - 1) : (uint32_t)first.b) << 16));
@@ -1939,27 +1756,11 @@ static uint32_t group_cap(const OpRec& op, bool v2) {
     case ZK_OP_LC4: return v2 ? 1 : 2;
     case ZK_OP_U32MULADD: return v2 ? 3 : 1;
     case ZK_OP_LOOKUP: return (op.a <= 2 && op.b <= 2) ? 4 : 1;
-#ifdef ZKGL_P2_MERGE   // variant build: gated witness-only permutations of one dependency level under one header (kernels_engine2.hpp)
-    case ZK_OP_POSEIDON2: return (v2 && op.a == 1) ? 5 : 1;
-#endif
     default: return 1;
     }
 }
 
 void CS::emit_scope(Scope& s) {
-#ifdef ZKGL_BATCH_INV   // variant build (kernels_engine2.hpp): an ISZERO whose aux output no witness op reads may store it LATER, batched with others
-    {
-        std::vector<uint8_t> read_by_op(s.n_vars, 0);
-        for (auto& op : s.ops)
-            if (!op.seed_only) for (auto& in : op.ins) if (in.kind == Operand::VAR) read_by_op[in.idx] = 1;
-        for (auto& l : links_raw_) {   // (links are checked after the kernel: harmless, kept strict)
-            if (s.is_loop) { read_by_op[l.loop_cell] = 1; if (l.kind == ZK_LINK_CARRY) read_by_op[l.other_cell] = 1; }
-            else if (l.kind != ZK_LINK_CARRY) read_by_op[l.other_cell] = 1;
-        }
-        for (auto& op : s.ops)
-            if (!op.seed_only && op.opcode == ZK_OP_ISZERO && op.outs.size() == 2) op.a = read_by_op[op.outs[1]] ? 0 : 1;
-    }
-#endif
     std::vector<uint8_t> defined(s.n_vars, 0);
     s.prog.clear(); s.prog_full.clear(); s.prog2.clear();
     s.pre_words = 0; s.pre_words_full = 0; s.pre_words2 = 0; s.side_words2 = 0; s.pre_slots = 0; s.side_slots = 0;
@@ -1992,20 +1793,13 @@ void CS::emit_scope(Scope& s) {
     std::vector<uint32_t> cls_words;
     std::vector<uint8_t> slot_is_byte;
     if (s.is_loop && !s.slot_aw.empty()) { slot_is_byte.resize(s.slot_aw.size()); for (size_t q = 0; q < s.slot_aw.size(); ++q) slot_is_byte[q] = (s.slot_aw[q] & zkgeom::AW_BYTE) != 0; }
-    for (int form = 1; form <= (slot_is_byte.empty() ? 2 : 3); ++form) {
+    auto emit_form = [&](int form) {
         const bool v2 = form >= 2, nform = form == 3;
         std::vector<uint32_t>& out = nform ? s.prog2n : v2 ? s.prog2 : s.prog;
         narrow_emit_ = nform ? &s.slot_aw : nullptr;
         std::vector<uint32_t> produced_in_group(s.n_vars, UINT32_MAX);  // var -> id of the open group that produces it
         uint32_t group_id = 0, slots_done = 0;
         std::vector<size_t> group;  // op indices of the open group
-        bool group_is_chain = false;   // the open group is a mux chain (members depend on each other through `b`)
-#ifdef ZKGL_SELECT_CHAINS_KERNEL   // the chain form exists only in builds whose kernels carry its handler (kernels_engine2.hpp)
-        const char* ch_env = getenv("ZKGL_SELECT_CHAINS");
-        const bool chains_on = v2 && s.is_loop && ch_env && ch_env[0] == '1';
-#else
-        const bool chains_on = false;
-#endif
         // SELECT flags as bit planes (plain loop kernels: ZK_OP_FLAG_PLANES, kernels_engine2.hpp): the FLAG_PLANES most used flag
         // variables of a loop scope get a plane id; a flag is copied into its plane by a ZK_OP_FLAG_PLANES op emitted lazily, in
         // front of the first SELECT that needs it, together with every other flag produced by then (up to 7 per op)
@@ -2030,7 +1824,6 @@ void CS::emit_scope(Scope& s) {
             const size_t n = group.size();
             const bool counted = group_cap(first, v2) > 1 || first.opcode == ZK_OP_INPUT || first.opcode == ZK_OP_SELECT || first.opcode == ZK_OP_FMA ||
                                  first.opcode == ZK_OP_LC4 || (v2 && first.opcode == ZK_OP_U32MULADD);
-            emit_chain_ = group_is_chain;
             if (nform) {   // class word of this header: outputs in the order the kernel stores them (members in order, each member's outputs in order)
                 uint32_t mask = 0, k = 0;
                 for (size_t oi : group)
@@ -2053,8 +1846,6 @@ void CS::emit_scope(Scope& s) {
                 slots_done += (uint32_t)s.ops[oi].outs.size();
             }
             group.clear();
-            group_is_chain = false;
-            emit_chain_ = false;
             ++group_id;
         };
         for (size_t oi = 0; oi < s.ops.size(); ++oi) {
@@ -2069,7 +1860,6 @@ void CS::emit_scope(Scope& s) {
                 const OpRec& f = s.ops[group[0]];
                 joins = f.a == op.a && f.b == op.b && f.ins[0].idx == op.ins[0].idx;
             }
-            if (joins && op.opcode == ZK_OP_POSEIDON2) joins = s.is_loop && s.ops[group[0]].a == 1 && op.a == 1;   // (merged form: loop scope, gated members only)
             if (joins)
                 for (auto& in : op.ins)
                     if (in.kind == Operand::VAR && produced_in_group[in.idx] == group_id) { joins = false; break; }
@@ -2091,16 +1881,6 @@ void CS::emit_scope(Scope& s) {
                     if (!plane_saved[fv]) throw ZkError(ZK_ERR_INVALID, "internal: SELECT flag not produced before its use");
                 }
             }
-            // mux chains (ZKGL_SELECT_CHAINS=1, after chain_selects): a plane SELECT whose `b` is the output of the open group's LAST member
-            // continues that group as a CHAIN (one op, the running value in a register) when the group is a single plane SELECT or already
-            // a chain, its flag's plane is written, and its `a` does not come from the group
-            if (chains_on && planes_on && op.opcode == ZK_OP_SELECT && !group.empty() && s.ops[group[0]].opcode == ZK_OP_SELECT && (group.size() == 1 || group_is_chain) &&
-                group.size() < 7 && op.ins[2].kind == Operand::VAR && op.ins[2].idx == s.ops[group.back()].outs[0] && op.ins[1].kind == Operand::VAR &&
-                produced_in_group[op.ins[1].idx] != group_id && plane_of[op.ins[0].idx] != UINT32_MAX && plane_saved[op.ins[0].idx] &&
-                plane_of[s.ops[group[0]].ins[0].idx] != UINT32_MAX && produced_in_group[op.ins[0].idx] != group_id) {
-                joins = true;
-                group_is_chain = true;
-            } else if (group_is_chain) joins = false;   // nothing else joins a chain
             if (!joins) flush();
             group.push_back(oi);
             for (uint32_t ov : op.outs) {
@@ -2120,6 +1900,15 @@ void CS::emit_scope(Scope& s) {
         }
         if (!s.is_loop && s.pre_ops >= s.ops.size()) { (v2 ? s.pre_words2 : s.pre_words) = (uint32_t)out.size(); if (v2) s.pre_slots = slots_done; }
         if (!s.is_loop && s.side_ops >= s.ops.size()) { (v2 ? s.side_words2 : s.side_words) = (uint32_t)out.size(); if (v2) s.side_slots = slots_done; }
+    };
+    emit_form(1);
+    emit_form(2);
+    if (!slot_is_byte.empty()) {   // the narrow form is an extra: anything unexpected in it leaves the circuit without a narrow layout, never without its programs
+        try { emit_form(3); }
+        catch (const ZkError& e) {
+            if (getenv("ZKGL_PROG_STATS")) fprintf(stderr, "[zkgl] no narrow layout: %s\n", e.what());
+            s.prog2n.clear(); s.slot_aw.clear(); s.cls_off = 0; narrow_emit_ = nullptr; plane_of_ = nullptr;
+        }
     }
     if (!s.is_loop && s.side_words < s.pre_words) { s.side_words = s.pre_words; s.side_words2 = s.pre_words2; s.side_slots = s.pre_slots; }
     if (getenv("ZKGL_PROG_STATS")) {
@@ -2775,13 +2564,11 @@ void CS::finalize() {
     }
     loop_ops_recorded_ = loop_.ops;
     schedule_loop_ops();
-    chain_selects();
-    bundle_gated_permutations();
     assign_store_slots(outer_);
     assign_store_slots(loop_);
     bound_values(outer_);     // (from the gates, lookups and tables alone: before the programs, the narrow layout wants the classes)
     bound_values(loop_);
-    build_narrow_layout(loop_);
+    build_narrow_layout(loop_);   // (slot -> address word; its programs come out of emit_scope / build_narrow_check_program below)
     emit_scope(outer_);
     emit_scope(loop_);
     build_check_program(outer_);
@@ -2960,17 +2747,7 @@ void CS::ensure_uploaded() {
 void CS::set_batch(uint32_t n) {
     if (!finalized_) throw ZkError(ZK_ERR_INVALID, "set_batch before finalize");
     if (n == 0) throw ZkError(ZK_ERR_INVALID, "batch must be > 0");
-    // device paths that exist only in builds made for them (never in the default binary until measured: kernels_engine2.hpp).  Recording and
-    // the host-side programs stay available everywhere (the oracle runs them, tests/test_device_programs.py walks them); the DEVICE refuses.
-#ifndef ZKGL_BYTEBUF_KERNEL
-    if (uses_bytebuf_macro_) throw ZkError(ZK_ERR_INVALID, "this circuit records ZK_OP_BYTEBUF_FILL (ZKGL_BYTEBUF_MACRO=1) but the library was built without its device backend (ZKGL_DEFS=-DZKGL_BYTEBUF_KERNEL)");
-#endif
-#ifndef ZKGL_SHA4_KERNEL
-    if (uses_sha4_macro_) throw ZkError(ZK_ERR_INVALID, "this circuit records the 4-bit-chunk SHA-256 macro-op (ZKGL_SHA4_MACRO=1) but the library was built without its device backend (ZKGL_DEFS=-DZKGL_SHA4_KERNEL)");
-#endif
-#ifndef ZKGL_STRAND_PLANES_KERNEL
-    if (uses_strand_planes_) throw ZkError(ZK_ERR_INVALID, "strand-form flag planes were requested (ZKGL_STRAND_PLANES=1) but the library was built without them (ZKGL_DEFS=-DZKGL_STRAND_PLANES_KERNEL)");
-#endif
+    if (uses_bytebuf_macro_ && uses_sha4_macro_) throw ZkError(ZK_ERR_INVALID, "a circuit that records both ZK_OP_BYTEBUF_FILL and the 4-bit-chunk SHA-256 macro-op: no kernel carries both backends");
     ensure_uploaded();
     auto alloc_cells = [&](Scope& s, uint64_t lanes) {
         if (s.d_store) { hipFree(s.d_store); s.d_store = nullptr; }
@@ -3003,7 +2780,8 @@ void CS::set_batch(uint32_t n) {
     // Narrow store: this batch's fused steps write the loop scope's values into the narrow store when the loop launch is the plain kernel (not the
     // strand form, not 64-bit addressing) and the multiplicities come from its inline atomics (the k_multiplicities pass reads the ordinary store).
     // The ordinary store is allocated beside it when it fits (every reader outside the fused step sees the widened copy there), on first use otherwise.
-    const bool want_narrow = narrow_enabled_ && loop_.narrow_ok && limit_ && inline_multiplicities() && !loop_runs_strands(loop_, 0, (uint32_t)loop_lanes);
+    const char* ne = std::getenv("ZKGL_NARROW_STORE");
+    const bool want_narrow = ne && ne[0] == '1' && narrow_enabled_ && loop_.narrow_ok && limit_ && inline_multiplicities() && !loop_runs_strands(loop_, 0, (uint32_t)loop_lanes);
     if (want_narrow) {
         loop_.n_lanes = (uint32_t)loop_lanes;
         loop_.store_tile_log2 = zkgeom::WAVE_TILE_LOG2;
@@ -3060,7 +2838,7 @@ static zkdev::ScopeArgs scope_args(const Scope& s, const Scope& outer, const Sco
     a.tables = tables; a.table_words = words; a.mult = mult; a.total_table_rows = total_rows;
     a.loop_cells = loop.d_store; a.loop_n_cells = loop.store_geom(); a.loop_limit = limit;
     a.uses_bigint = s.uses_bigint ? 1 : 0;
-    return a;
+    return a;   // (a.xmacros: CS::scope_args_x below)
 }
 
 // the cone seeding launch over `n` instances: la = loop-scope arguments whose outer_cells hold the pre phase of those instances

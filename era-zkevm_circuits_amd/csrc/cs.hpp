@@ -165,7 +165,7 @@ struct Scope {
     uint32_t store_tile_log2 = zkgeom::WAVE_TILE_LOG2;  // lane tiling of d_store (store_geom.hpp), chosen by set_batch
     // what the launch interface carries beside d_store: the slot count with the tiling in its top byte (a bare count = 64-lane tiles)
     uint64_t store_geom() const { return store_tile_log2 == zkgeom::WAVE_TILE_LOG2 ? (uint64_t)n_store : zkgeom::pack(n_store, store_tile_log2); }
-    // NARROW STORE (store_geom.hpp; loop scopes, opt-in ZKGL_NARROW_STORE=1; cs.cpp build_narrow_layout): the layout and the device programs of the
+    // NARROW STORE (store_geom.hpp; loop scopes; cs.cpp build_narrow_layout; used by a batch when ZKGL_NARROW_STORE=1 at set_batch): the layout and the device programs of the
     // fused step over it.  The ordinary store and its programs stay: everything outside the fused step reads the widened copy.
     bool narrow_ok = false;              // a layout + programs exist
     std::vector<uint32_t> slot_aw;       // store slot -> address word (first unit | class << 28)
@@ -314,8 +314,6 @@ class CS {
     void place_scope(Scope& s);
     std::vector<OpRec> loop_ops_recorded_;   // the loop body as recorded (build_seed_program)
     void schedule_loop_ops();
-    void chain_selects();               // opt-in: the links of one mux chain become consecutive ops (cs.cpp)
-    void bundle_gated_permutations();   // opt-in: the gated witness-only permutations of one dependency level under one header (cs.cpp)
     void schedule_by_locality(const std::vector<double>& a, const std::vector<double>& m, double a_tot, double m_tot,
                               const std::vector<std::vector<uint32_t>>& succ, std::vector<uint32_t>& n_pred);
     void emit_scope(Scope& s);
@@ -348,7 +346,6 @@ class CS {
     std::vector<uint32_t> select_plane_vars(const Scope& s) const;
     void verify_device_programs(const Scope& s) const;   // ZKGL_VERIFY_DEVICE_PROGRAMS=1: independent walk over prog2 / the strand programs
     void emit_group_v2(const Scope& s, const std::vector<size_t>& group, bool counted, std::vector<uint32_t>& out) const;
-    bool emit_chain_ = false;   // emit_scope: the group being flushed is a mux chain (ZKGL_SELECT_CHAINS)
     const std::vector<uint32_t>* narrow_emit_ = nullptr;   // emit_scope, narrow form of a loop scope: store slot -> address word (operand_v2)
     const std::vector<uint32_t>* plane_of_ = nullptr;   // emit_scope, v2 form of a loop scope: variable -> SELECT flag plane id (UINT32_MAX: none)
     void upload_scope(Scope& s);
@@ -447,13 +444,13 @@ class CS {
     bool check_stored_ = false;
     bool defer_p2_ = false;          // ZK_CHECK_FUSED_DEFER_P2
     bool p2_pending_ = false;        // the loop store lacks the intermediates of its in-circuit permutations (k_fill_p2 not run yet)
-    bool narrow_enabled_ = false;    // ZKGL_NARROW_STORE=1 at finalize and the loop scope has a narrow layout
+    bool narrow_enabled_ = false;    // the loop scope has a narrow layout with its programs
     bool narrow_active_ = false;     // the bound batch runs its fused steps over the narrow store (set_batch: plain loop kernel, inline multiplicities)
     bool narrow_pending_ = false;    // the last step wrote the narrow store only: the ordinary store is stale until k_widen_store (ensure_p2_filled)
     bool narrow_suspended_ = false;  // a step that reported a failure over the narrow store is being repeated over the ordinary one
     uint64_t narrow_steps_ = 0, narrow_repeats_ = 0;
     bool uses_lookup_macros_ = false;   // a macro-op whose outputs carry lookup tuples was recorded: multiplicities by the k_multiplicities pass
-    bool uses_bytebuf_macro_ = false, uses_strand_planes_ = false, uses_sha4_macro_ = false;   // opt-in device paths the default build does not carry (set_batch refuses them there)
+    bool uses_bytebuf_macro_ = false, uses_sha4_macro_ = false;   // macro-ops with their own kernel instantiations (launch_phase: ScopeArgs::xmacros)
     int32_t macro_window_op_ = -1;   // index (current scope) of the macro-op whose gadget window is open
     bool macro_window_loop_ = false;
     bool allow_macro_ops_ = false;   // zk_cs_set_check_mode(ZK_CHECK_STORED)

@@ -18,6 +18,7 @@ struct ScopeArgs {  // mirrors zke::ScopeDev (plain data)
     const uint64_t* loop_cells; uint64_t loop_n_cells; uint32_t loop_limit;
     uint64_t in_stride;    // lanes between consecutive words of the input stream (>= n_lanes: a batch may be a window of a longer stream)
     uint32_t uses_bigint;  // host only: the program contains ZK_OP_NN_MULMOD -> launch the *_bigint kernel variants
+    uint32_t xmacros = 0;  // host only: macro-op backends beyond the basic set the circuit records (kernels_engine2.hpp X_SHA4 = 1, X_BYTEBUF = 2): their own kernels
     unsigned long long* fail = nullptr;  // fused mode: where the witness kernels report a gate they evaluate themselves (SELECT with a non-boolean selector)
     uint32_t defer_p2 = 0;                       // 1: ZK_OP_P2_ROUNDS stores only its 12 final outputs (ZK_CHECK_FUSED_DEFER_P2), the 950 intermediates come from launch_fill_p2
     unsigned long long* p2_stats = nullptr;     // two counters: gated witness-only permutations a wavefront skipped / ran (ZK_OP_POSEIDON2 a = 1)

@@ -19,13 +19,8 @@
 // Trace stores.  Round 1 stored every cell of a variable (55 k words per VM cycle) and streamed them out non-temporally.  With
 // compact traces a value is stored once, to its home cell, and is usually an operand of an op a few hundred words later: a
 // cacheable store keeps it in L2 for that load (the interpreter is bound by the latency of its dependent operand loads).
-#ifdef ZKGL_NT_STORES
-#define ZKGL_STORE_ASM "buffer_store_dwordx2 %[val], %[lb], %[rs], %[addr] offen nt\n"
-#define ZKGL_STORE_AUX 2
-#else
 #define ZKGL_STORE_ASM "buffer_store_dwordx2 %[val], %[lb], %[rs], %[addr] offen\n"
 #define ZKGL_STORE_AUX 0
-#endif
 #ifndef ZKGL_LOOP_WAVES
 #define ZKGL_LOOP_WAVES 4
 #endif
@@ -155,11 +150,7 @@ __device__ __forceinline__ void mult_add(uint32_t* mult, size_t index, bool pred
         if ((int)(threadIdx.x & 63) == leader) atomicAdd(mult + li, (uint32_t)__builtin_popcountll(same));
         todo &= ~same;
     }
-#ifdef ZKGL_MULT_WG_SCOPE  // experiment: L2-local atomics (correct only with one copy of the counters per XCD)
-    if (todo & (1ull << (threadIdx.x & 63))) __hip_atomic_fetch_add(mult + index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
     if (todo & (1ull << (threadIdx.x & 63))) atomicAdd(mult + index, 1u);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -360,12 +351,8 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
         if (kind == ZK_OPERAND_OUTER) return sc.outer_cells[cell_off(sc.outer_n_cells, idx, inst)];
         if constexpr (SLOTS) return slots[idx * slot_stride];
         if constexpr (TILE_UNIFORM) {
-#ifdef ZKGL_STUB_LOADS  // time attribution only (tools/stub_bench.sh): operand values without the memory access
-            return (uint64_t)idx * 0x9E3779B97F4A7C15ull + lane_byte;
-#else
             u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(tile_rsrc, lane_byte, idx << bsh, 0);
             return (uint64_t)v.x | ((uint64_t)v.y << 32);
-#endif
         }
         return cells[(size_t)idx << tsh];
     };
@@ -390,9 +377,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                         "v_readlane_b32 %[w], %[w0], %[off]\n"
                         "s_add_u32 %[off], %[off], 1\n"
                         "s_lshl_b32 %[addr], %[w], 9\n"
-#ifndef ZKGL_STUB_STORES  // time attribution only (tools/stub_bench.sh): the walk of the destination words without the store
                         ZKGL_STORE_ASM  // see ZKGL_NT_STORES above
-#endif
                         "s_bitcmp1_b32 %[w], 31\n"
                         "s_cbranch_scc0 .LDSTX%=\n"
                         "s_cmp_lt_u32 %[off], 64\n"
@@ -412,11 +397,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
                 if constexpr (TILE_UNIFORM) {
                     u32x2 o;
                     o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
-#ifdef ZKGL_STUB_STORES
-                    asm volatile("" ::"v"(o), "s"(w));
-#else
                     __builtin_amdgcn_raw_buffer_store_b64(o, tile_rsrc, lane_byte, (w & ZK_DEST_CELL_MASK) << bsh, ZKGL_STORE_AUX);
-#endif
                 } else {
                     cells[(size_t)(w & ZK_DEST_CELL_MASK) << tsh] = v;  // 64-bit addressed scopes
                 }
@@ -663,11 +644,7 @@ __device__ __forceinline__ void run_lane(const ScopeDev& sc, const uint32_t lane
 #pragma unroll 1
                 for (int i = 0; i < n; ++i) {
                     uint64_t t = gl::add(p2s[i * BLOCK + threadIdx.x], p2::RC[12 * r + i]);
-#ifdef ZKGL_STUB_P2  // time attribution only (tools/stub_bench.sh): the S-box without its four multiplications
-                    uint64_t x2 = t ^ 1, x3 = t ^ 2, x4 = t ^ 3, x7 = t ^ 4;
-#else
                     uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
-#endif
                     if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
                     p2s[i * BLOCK + threadIdx.x] = x7;
                 }

@@ -36,11 +36,18 @@ typedef __attribute__((address_space(4))) const uint64_t* cpool_ptr;
 constexpr uint32_t G2_INPUT = 8, G2_SELECT = 5, G2_FMA = 3, G2_LOOKUP = 4, G2_U32MULADD = 3;
 // multiplicities: wave-aggregated atomics in the interpreter when the host passes the vector (sc.mult), or the k_multiplicities pass
 // after the witness kernels when it passes nullptr (cs.cpp multiplicity_mode); -DZKGL_STUB_MULT: neither (time attribution)
-#ifdef ZKGL_STUB_MULT
-#define ZKGL_MULT_ON false
+// ELIMINATION PROBES (time attribution: profiles/r3_loop_probe.md, tools/variants.sh): a library built with -DZKGL_EXPERIMENT=<mask> leaves parts of the
+// interpreter out (WRONG results, timing only; bench.py runs it with ZKGL_STUB_RUN=1).  The product is built without: every probe is `false`
+// and its branch is discarded at compile time.  This is the only preprocessor switch of the interpreter besides the two opt-in macro-op backends.
+namespace probe {
+#ifdef ZKGL_EXPERIMENT
+constexpr uint32_t MASK = ZKGL_EXPERIMENT;
 #else
-#define ZKGL_MULT_ON true
+constexpr uint32_t MASK = 0;
 #endif
+constexpr bool NO_LOADS = MASK & 1, NO_STORES = MASK & 2, NO_P2_SBOX = MASK & 4, NO_P2_LINEAR = MASK & 8, NO_FMA = MASK & 16, NO_INV = MASK & 32, NO_FIND = MASK & 64, NO_MULT = MASK & 128;
+}  // namespace probe
+#define ZKGL_MULT_ON (!probe::NO_MULT)
 template <uint32_t N> struct GroupSize { static constexpr uint32_t value = N; };
 
 // table row of a key tuple of <= 2 keys (the grouped lookups), no key array: a dynamically indexed array would live in scratch
@@ -177,8 +184,8 @@ __device__ __noinline__ uint32_t sha256_rounds_stream(__amdgpu_buffer_rsrc_t rsr
 
 // K8, out of line: one SHA-256 compression over the REFERENCE's 4-bit-chunk table set (ZK_OP_SHA256_ROUNDS with a = 1; zks4::compress, sha256_macro4.hpp):
 // 26 088 outputs; cooperative like sha256_rounds_stream — every strand computes, strand `share` stores every (mask + 1)-th run of eight outputs.
-// Built only on request (ZKGL_DEFS=-DZKGL_SHA4_KERNEL; zk_cs_set_batch refuses the recording in any other build): not yet measured on a device.
-#ifdef ZKGL_SHA4_KERNEL
+// Called by the kernels instantiated with XMACROS & X_SHA4 only (k_witness_strands2_x / k_witness_plain_x below): the kernels of every other circuit
+// are compiled without it (with it inside, the hash circuits' strand kernel went from 26 to 219 spilled VGPRs — profiles/r6_resource_usage.md).
 __device__ __noinline__ uint32_t sha256_rounds4_stream(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_byte, uint32_t dst, uint32_t bstep, const uint32_t* in24,
                                                         uint32_t share, uint32_t n_share_mask) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -205,11 +212,8 @@ __device__ __noinline__ uint32_t sha256_rounds4_stream(__amdgpu_buffer_rsrc_t rs
     zks4::compress(be, st, blk, w, wsp, zks::K);
     return emit.d;
 }
-#endif  // ZKGL_SHA4_KERNEL
 
-// ZK_OP_BYTEBUF_FILL's device backend is built only on request (ZKGL_DEFS=-DZKGL_BYTEBUF_KERNEL; keccak.cpp refuses ZKGL_BYTEBUF_MACRO=1 in any
-// other build): written while the GPU was closed to the build, never executed — it stays out of the default binary until it has been measured.
-#ifdef ZKGL_BYTEBUF_KERNEL
+// ZK_OP_BYTEBUF_FILL's device backend: in the kernels instantiated with XMACROS & X_BYTEBUF only (recordings made with ZKGL_BYTEBUF_MACRO=1)
 struct BytebufInv {   // k^-1 mod p for 0 < |k| < INV_SMALL_N
     __device__ __forceinline__ uint64_t operator()(int32_t k) const {
         const uint64_t r = p2::INV_SMALL[(uint32_t)(k < 0 ? -k : k) & (p2::INV_SMALL_N - 1)];
@@ -248,15 +252,16 @@ __device__ __noinline__ uint32_t bytebuf_fill_stream(__amdgpu_buffer_rsrc_t rsrc
     return emit.d;
 }
 
-#endif  // ZKGL_BYTEBUF_KERNEL
-
 // STRANDS: the strand form (k_witness_strands2): one destination word per op behind the operands — the store slot of its first
 // output (a strand's ops are not consecutive in production order) — and ZK_OP_BARRIER between the dependency levels.
 // NARROW (k_witness_loop_narrow; store_geom.hpp, cs.cpp build_narrow_layout): the scope's store is a narrow store — data operand words are ADDRESS
 // WORDS (first unit | class << 28), an output is a byte-class value when its bit is set in the header's class word (sc.cls, one word per header):
 // buffer_load_ubyte / buffer_store_byte, 64 B per wavefront instead of 512.  A value that does not fit its byte slot is the fused mode's failure
 // (the class of a variable is a bound that holds in EVERY satisfying witness: CS::bound_values); the host then repeats the step on the ordinary store.
-template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB, bool STRANDS = false, bool NARROW = false>
+// XMACROS: macro-op backends beyond the basic set of WITH_BIGINT (X_SHA4: ZK_OP_SHA256_ROUNDS with a = 1, the reference's 4-bit-chunk tables; X_BYTEBUF:
+// ZK_OP_BYTEBUF_FILL).  Each has its own kernel instantiations, launched for the circuits that record the op: nobody else's kernel carries its registers.
+constexpr int X_SHA4 = 1, X_BYTEBUF = 2;
+template <bool WITH_BIGINT, bool WIDE, int BLOCK = TPB, bool STRANDS = false, bool NARROW = false, int XMACROS = 0>
 __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lane, const uint32_t inst, const bool active,
                                           uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, const uint32_t* cls_words = nullptr) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -268,12 +273,6 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     uint64_t* __restrict__ wide_cells = ta.base + (lane_byte >> 3);
     const prog1_ptr prog = (prog1_ptr)(uintptr_t)sc.prog;
     const cpool_ptr cpool = (cpool_ptr)(uintptr_t)sc.consts;
-#ifdef ZKGL_P2_IN_LDS  // A/B: the round-1 form (state staged in LDS, rolled S-box loops) for the plain kernels
-    constexpr bool P2_IN_REGISTERS = STRANDS;
-#else
-    constexpr bool P2_IN_REGISTERS = true;
-#endif
-    __shared__ uint64_t p2s[P2_IN_REGISTERS ? 1 : 12 * BLOCK];  // Poseidon2 state, [element][thread] (plain kernels: rolled S-box loops)
 
     static_assert(!NARROW || (!WIDE && !STRANDS), "the narrow store is read by the plain buffer-addressed kernel only");
     const uint32_t ush = bsh - 3;                   // NARROW: a unit of the tile = 1 << ush bytes (one byte per lane)
@@ -282,9 +281,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     uint32_t opi = 0;                               // NARROW: headers decoded so far (index into cls)
     uint32_t dst = WIDE ? slot_begin : NARROW ? slot_begin << ush : slot_begin << bsh;  // next output: slot index (WIDE) or byte offset in the tile (NARROW: slot_begin = first unit)
     auto ldv = [&](uint32_t slot) -> uint64_t {
-#ifdef ZKGL_STUB_LOADS  // time attribution only (tools/stub_vm.sh): operand values without the memory access
-        return (uint64_t)slot * 0x9E3779B97F4A7C15ull + lane_byte;
-#else
+        if constexpr (probe::NO_LOADS) return (uint64_t)slot * 0x9E3779B97F4A7C15ull + lane_byte;   // (operand values without the memory access)
         if constexpr (WIDE) return wide_cells[(size_t)slot << tsh];
         if constexpr (NARROW) {   // `slot` is an address word; its class is wave-uniform (a scalar branch around one of two loads)
             if (slot & zkgeom::AW_BYTE) return (uint64_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, lane_unit, (slot & zkgeom::AW_MASK) << ush, 0);
@@ -293,14 +290,12 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
         }
         u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, slot << bsh, 0);
         return (uint64_t)v.x | ((uint64_t)v.y << 32);
-#endif
     };
     auto st = [&](uint64_t v) {
-#ifdef ZKGL_STUB_STORES
-        asm volatile("" ::"v"(v), "s"(dst));
-        dst += WIDE ? 1 : bstep;
-#else
-        if constexpr (WIDE) {
+        if constexpr (probe::NO_STORES) {
+            asm volatile("" ::"v"(v), "s"(dst));
+            dst += WIDE ? 1 : bstep;
+        } else if constexpr (WIDE) {
             wide_cells[(size_t)dst << tsh] = v;
             dst += 1;
         } else {
@@ -309,20 +304,14 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, dst, 0);
             dst += bstep;
         }
-#endif
     };
 
     // SELECT flags as bit planes (ZK_OP_FLAG_PLANES; plain kernels, loop scope): [wavefront of the block][0: != 0, 1: > 1][plane id]
     // (strand form: the wavefronts of the workgroup share ONE tile, hence one set of planes; a plane is written in the level after its
     // flag's and read from the level after that — cs.cpp build_strands — with the workgroup barrier of ZK_OP_BARRIER in between)
-    // The strand form of the planes is built only on request (ZKGL_DEFS=-DZKGL_STRAND_PLANES_KERNEL; cs.cpp refuses ZKGL_STRAND_PLANES=1 in any
-    // other build): compiled in, it costs the strand kernels of EVERY circuit registers (k_witness_strands2<false,false>: 79 -> 92 VGPRs,
-    // 6 -> 5 wavefronts per SIMD, profiles/r5_resource_usage.md) and it has not been measured yet.
-#ifdef ZKGL_STRAND_PLANES_KERNEL
-    constexpr bool PLANES = true;
-#else
+    // (a strand form of the planes existed in round 5 and was never measured; compiled in, it cost the strand kernels of EVERY circuit registers —
+    // k_witness_strands2<false,false> 79 -> 92 VGPRs, 6 -> 5 wavefronts per SIMD, profiles/r5_resource_usage.md — and was deleted in round 6)
     constexpr bool PLANES = !STRANDS;
-#endif
     __shared__ uint64_t flag_planes[!PLANES ? 1 : STRANDS ? 2 * zkdev::FLAG_PLANES : (BLOCK / 64) * 2 * zkdev::FLAG_PLANES];
     uint64_t* const planes = flag_planes + (STRANDS ? 0 : uni(threadIdx.x >> 6) * 2 * zkdev::FLAG_PLANES);
     // (this lane's index in its wavefront is recomputed where used — two mbcnt — rather than held in a VGPR across the interpreter loop)
@@ -331,9 +320,6 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     constexpr uint32_t D = STRANDS ? 1 : 0;  // destination words per op
     auto out_to = [&](uint32_t slot) { if constexpr (STRANDS) dst = WIDE ? slot : slot << bsh; };
     uint32_t pc = word_begin;
-#ifdef ZKGL_P2_MERGE
-    uint32_t mrg_round = 0;   // uniform: the round of the merged gated-permutation op being executed (0 between such ops)
-#endif
     uint32_t nonbool_seen = 0;   // uniform: some flag copied into a plane held a value > 1 in some lane (never, on a satisfiable witness)
     bool fused_bad = false;   // fused mode: a gate evaluated here (SELECT's exception, a lookup miss) is violated; reported once, below
     uint32_t ocm = 0;         // NARROW: class word of the header being executed (bit k: its k-th output is a byte-class value)
@@ -348,63 +334,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
         }
         st(v);
     };
-#ifdef ZKGL_BATCH_INV
-    // Montgomery-batched zero-check inversions (variant build; plain narrow kernels).  An ISZERO whose operand is large in some lane of the
-    // wavefront does not run the 72-multiplication chain on its own: it stores its flag, notes (operand offset, aux offset) in LDS — uniform
-    // words, 8 B per entry — and moves on; NBI entries (or the end of the program, or an entry whose aux somebody reads: header a = 0) are
-    // inverted together: operands re-loaded (they are in the store), prefix products, ONE chain, back-substitution — 3 multiplications per
-    // entry + 72 per batch.  x = 0 enters the product as 1 and leaves as 0.  Same values as inv_wave, later in time; the aux of a deferred
-    // entry (header a = 1: cs.cpp emit_scope proves no op reads it) is first read by the check kernels.
-    constexpr bool BATCH_INV = !STRANDS && !WIDE;
-    constexpr uint32_t NBI = 8;
-    __shared__ uint32_t inv_pend_all[BATCH_INV ? (BLOCK / 64) * 2 * NBI : 1];
-    uint32_t* const inv_pend = inv_pend_all + (BATCH_INV ? uni(threadIdx.x >> 6) * 2 * NBI : 0);
-    uint32_t n_pend = 0;      // uniform
-    bool flush_now = false;   // uniform
-    while (true) {
-        if constexpr (BATCH_INV) {
-            if (flush_now || (pc >= word_end && n_pend)) {
-                // registers: the eight prefix products only — an operand is loaded when it is used (forward pass) and loaded AGAIN for the
-                // back-substitution (an L2 hit; a flush happens ~10 times per wavefront, its latency hides behind the other wavefronts), so the
-                // batch holds 8 + 2 values instead of 16 + 2 (the interpreter loop lives at the 72-VGPR limit of 7 wavefronts per SIMD)
-                uint64_t pre[NBI];
-                auto pend_x = [&](uint32_t k) -> uint64_t {   // entries past n_pend repeat entry 0 (their stores are skipped)
-                    const uint32_t xo = uni(inv_pend[2 * (k < n_pend ? k : 0)]);
-                    u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte, xo, 0);
-                    return (uint64_t)v.x | ((uint64_t)v.y << 32);
-                };
-                uint64_t acc = 1;
-#pragma unroll
-                for (uint32_t k = 0; k < NBI; ++k) {
-                    const uint64_t x = pend_x(k);
-                    const uint64_t nz = (k < n_pend && x) ? x : 1ull;
-                    pre[k] = acc;
-                    acc = gl::mul(acc, nz);
-                }
-                uint64_t ia = gl::inv(acc);
-#pragma unroll
-                for (uint32_t kk = 0; kk < NBI; ++kk) {
-                    const uint32_t k = NBI - 1 - kk;
-                    if (k < n_pend) {   // uniform
-                        const uint64_t x = pend_x(k);
-                        const uint64_t nz = x ? x : 1ull;
-                        const uint64_t r = gl::mul(ia, pre[k]);
-                        ia = gl::mul(ia, nz);
-                        const uint64_t o64 = x ? r : 0ull;
-                        u32x2 o;
-                        o.x = (uint32_t)o64; o.y = (uint32_t)(o64 >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, lane_byte, uni(inv_pend[2 * k + 1]), 0);
-                    }
-                }
-                n_pend = 0;
-                flush_now = false;
-                continue;
-            }
-        }
-        if (pc >= word_end) break;
-#else
     while (pc < word_end) {
-#endif
         const u32x16_a4 W = *(prog16_ptr)(prog + pc);  // s_load_dwordx16: header + up to 15 operand words (host pads the program)
         if constexpr (NARROW) { ocm = cls[opi]; ++opi; }   // (a second scalar load in flight beside the header's)
         const uint32_t h = W[0];
@@ -457,12 +387,11 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
                 for (uint32_t g = 0; g < N; ++g) {
                     out_to(W[(1 + N * 5 + g) & 15]);
-#ifdef ZKGL_STUB_FMA  // time attribution only (tools/loop_probe.sh): the op without its multiplications
-                    stn(in[g][0] ^ in[g][1] ^ in[g][2] ^ q[g] ^ l[g], g);
-#else
-                    const uint64_t ab = gl::mul(in[g][0], in[g][1]);
-                    stn(gl::add(q[g] == 1 ? ab : gl::mul(q[g], ab), l[g] == 1 ? in[g][2] : gl::mul(l[g], in[g][2])), g);
-#endif
+                    if constexpr (probe::NO_FMA) stn(in[g][0] ^ in[g][1] ^ in[g][2] ^ q[g] ^ l[g], g);
+                    else {
+                        const uint64_t ab = gl::mul(in[g][0], in[g][1]);
+                        stn(gl::add(q[g] == 1 ? ab : gl::mul(q[g], ab), l[g] == 1 ? in[g][2] : gl::mul(l[g], in[g][2])), g);
+                    }
                 }
             };
             switch (pb) {
@@ -497,36 +426,6 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 }
         } else { return; } break;   // (not emitted for this form: cs.cpp)
         case ZK_OP_SELECT:
-#ifdef ZKGL_SELECT_CHAINS_KERNEL   // built only on request (ZKGL_DEFS=-DZKGL_SELECT_CHAINS_KERNEL): its live set costs the interpreter loop spills
-        if (!STRANDS && pa == 2) {
-            // a mux chain (cs.cpp chain_selects / emit_scope): r_0 = b0, r_k = f_k ? a_k : r_(k-1), every r_k stored — [b0][plane id, a slot] x N.
-            // The running value stays in a register; the candidates of all links are loaded up front, and only where some lane of the
-            // wavefront selects them (a link whose flag is zero in all 64 lanes copies r).
-            const uint32_t n = pb + 1;
-            uint64_t a[7], mv[7];
-            uint64_t r = ldv(W[1]);
-            const uint32_t wave_lane = wave_lane_now();
-#pragma unroll
-            for (uint32_t k = 0; k < 7; ++k) if (k < n) mv[k] = planes[W[2 + 2 * k]];
-#pragma unroll
-            for (uint32_t k = 0; k < 7; ++k)
-                if (k < n) {
-                    a[k] = 0;
-                    if (uni((uint32_t)mv[k] | (uint32_t)(mv[k] >> 32))) a[k] = ldv(W[3 + 2 * k]);
-                }
-            pc += 2 + 2 * n;
-#pragma unroll
-            for (uint32_t k = 0; k < 7; ++k)
-                if (k < n) {
-                    const bool f = (mv[k] >> wave_lane) & 1;
-                    // SelectionGate on the operands held here: violated iff the selector is not 0 / 1 and the branches differ (a flag > 1 is
-                    // also != 0, so its candidate was loaded)
-                    if (nonbool_seen) fused_bad |= ((planes[zkdev::FLAG_PLANES + W[2 + 2 * k]] >> wave_lane) & 1) && a[k] != r;
-                    r = f ? a[k] : r;
-                    st(r);
-                }
-        } else
-#endif
         if (PLANES && pa == 1) {
             // flags from the bit planes.  A wavefront whose lanes agree on a flag loads the selected operand twice (the second load hits
             // the line the first one brought) instead of both: no branch, no fetch of the branch nobody takes.
@@ -549,9 +448,6 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                     if constexpr (STRANDS) { nz = uni((uint32_t)nv[g] | (uint32_t)(nv[g] >> 32)); nbany |= nz; }
                     fbits |= (uint32_t)((mv[g] >> wave_lane) & 1) << g;
                     const uint32_t sa = W[1 + g * 3 + 1], sb = W[1 + g * 3 + 2];
-#ifdef ZKGL_PLANE_STATS  // measurement only: how many plane SELECTs see a wavefront-uniform flag (counted in the gated-permutation words)
-                    if (sc.p2_stats && wave_lane == 0) atomicAdd(sc.p2_stats + (((mlo | mhi) == 0 || (mlo & mhi) == ~0u) ? 0 : 1), 1ull);
-#endif
                     a[g] = ldv((mlo | mhi) == 0 ? sb : sa);
                     b[g] = ldv(((mlo & mhi) == ~0u && !nz) ? sa : sb);
                 }
@@ -599,25 +495,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             out_to(W[2]);
             pc += 2 + D;
             stn(x == 0 ? 1ull : 0ull, 0);
-#ifdef ZKGL_STUB_INV  // time attribution only: no inversion
-            st(x);
-#elif defined(ZKGL_BATCH_INV)
-            if constexpr (BATCH_INV) {
-                const uint64_t nx = gl::P - x;
-                const bool pos = x < p2::INV_SMALL_N, neg = nx < p2::INV_SMALL_N;
-                if (__builtin_amdgcn_ballot_w64(!(pos || neg)) == 0) {   // as inv_wave: every lane small -> one gather
-                    const uint64_t r = p2::INV_SMALL[pos ? (uint32_t)x : (uint32_t)nx];
-                    st(pos ? r : gl::P - r);
-                } else {                                                  // the chain: with the next NBI - 1 of its kind
-                    if (wave_lane_now() == 0) { inv_pend[2 * n_pend] = W[1] << bsh; inv_pend[2 * n_pend + 1] = dst; }
-                    dst += bstep;
-                    ++n_pend;
-                    flush_now = n_pend == NBI || pa == 0;
-                }
-            } else st(p2::inv_wave(x));
-#else
-            stn(p2::inv_wave(x), 1);   // small |x| in every lane (flags, counters, position differences): one gather instead of 72 multiplications
-#endif
+            if constexpr (probe::NO_INV) stn(x, 1);
+            else stn(p2::inv_wave(x), 1);   // small |x| in every lane (flags, counters, position differences): one gather instead of 72 multiplications
         } break;
         case ZK_OP_UADD: {
             const uint64_t x = ldv(W[1]), y = ldv(W[2]), ci = ldv(W[3]);
@@ -686,11 +565,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                     pc += 2 + N * pa + D * N;
 #pragma unroll
                     for (uint32_t g = 0; g < N; ++g) {
-#ifdef ZKGL_STUB_FIND  // time attribution only: no table search
-                        row[g] = (uint32_t)k0[g] & 7u;
-#else
-                        row[g] = table_find2(t, sc.table_words, k0[g], k1[g]);
-#endif
+                        if constexpr (probe::NO_FIND) row[g] = (uint32_t)k0[g] & 7u;
+                        else row[g] = table_find2(t, sc.table_words, k0[g], k1[g]);
                     }
                     // the value gathers of the whole group back to back, unconditionally (a missing key reads row 0 and is zeroed
                     // below): no exec-masked branch and no wait between the members' gathers
@@ -760,96 +636,31 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             const bool deferred = (op == ZK_OP_P2_ROUNDS) && sc.defer_p2 != 0;
             const bool emit = (op == ZK_OP_P2_ROUNDS) && !deferred;
             uint64_t s[12];
-#ifdef ZKGL_P2_MERGE
-            // MERGED gated form (pa = 2; plain kernels; variant build): n = pb + 1 <= 5 mutually independent gated witness-only permutations
-            // under ONE header — [12 state slots, flag slot] x n -> 12 x n outputs.  A cycle runs one opcode, so a LANE has at most one or two
-            // of a level's permutations on, while a WAVEFRONT of 64 different cycles has nearly all of them on somewhere: 15 of main_vm's 18
-            // gated permutations ran per wavefront where the lanes needed 0.83 each (profiles/r5_iszero_stats.json).  The op is executed in
-            // ROUNDS (mrg_round, uniform, lives across the interpreter loop; the header is decoded again for the next round): in round r every
-            // lane picks ITS r-th member that is on, the wavefront runs ONE permutation on the picked states, each lane stores to its member's
-            // outputs.  Round 0 first writes zeros to every output.  No state but the round number survives the permutation body.
-            const bool merged = !STRANDS && !WIDE && (op == ZK_OP_POSEIDON2) && pa == 2;
-            int mrg_me = -1;
-            bool mrg_more = false;
-            uint32_t mrg_base = 0;
-            if (merged) {
-                const uint32_t n = pb + 1;
-                uint32_t cnt = 0;
-#pragma unroll
-                for (uint32_t g = 0; g < 5; ++g)
-                    if (g < n) {
-                        const bool on = ldv(prog[pc + 1 + g * 13 + 12]) != 0;
-                        if (on && cnt == mrg_round) mrg_me = (int)g;
-                        cnt += on ? 1u : 0u;
-                    }
-                mrg_more = __builtin_amdgcn_ballot_w64(cnt > mrg_round + 1) != 0;
-                if (mrg_round == 0) {
-                    for (uint32_t q = 0; q < 12 * n; ++q) st(0ull);   // every output is 0 until a lane's round says otherwise
-#ifndef ZKGL_PLANE_STATS
-                    if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats, (unsigned long long)n);   // word 0: member sites met; word 1 (below): permutations run
-#endif
-                }
-                mrg_base = dst - 12u * n * bstep;
-                const bool idle = __builtin_amdgcn_ballot_w64(mrg_me >= 0) == 0;   // (only in round 0: a later round exists because a lane asked for it)
-                if (!mrg_more || idle) { pc += 1 + 13 * n; }
-                if (idle) { mrg_round = 0; break; }
-                // the picked member's state: ONE load per element, its slot chosen per lane (slot words are uniform scalars; the per-lane choice is a
-                // chain of selects on 32-bit offsets) — holding the state while loading candidates would double the live registers of the body
-                {
-                    const uint32_t hdr = mrg_more ? pc : pc - 1 - 13 * n;
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) {
-                        uint32_t vo = prog[hdr + 1 + i] << bsh;
-#pragma unroll
-                        for (uint32_t g = 1; g < 5; ++g)
-                            if (g < n) { const uint32_t so = prog[hdr + 1 + g * 13 + i] << bsh; vo = mrg_me == (int)g ? so : vo; }
-                        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_byte + vo, 0, 0);
-                        s[i] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-                    }
-                }
-                mrg_round = mrg_more ? mrg_round + 1 : 0;
-#ifndef ZKGL_PLANE_STATS
-                if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats + 1, 1ull);
-#endif
-            } else {
-#endif
 #pragma unroll
             for (int i = 0; i < 12; ++i) s[i] = ldv(W[1 + i]);
-#ifdef ZKGL_P2_MERGE
-            }
-#endif
             // gated form (pa = 1, witness-only): [.., execute] -> zeros where the flag is off (simulate_round_function(cs, state, execute));
             // a wavefront whose 64 cycles all have it off skips the permutation altogether
-#ifdef ZKGL_P2_MERGE
-            const bool gated = (op == ZK_OP_POSEIDON2) && pa == 1;
-#else
             const bool gated = (op == ZK_OP_POSEIDON2) && pa != 0;
-#endif
             bool lane_off = false;
             if (gated) {
                 lane_off = ldv(W[13]) == 0;
                 out_to(W[14]);
                 pc += 14 + D;
                 const bool all_off = __builtin_amdgcn_ballot_w64(!lane_off) == 0;
-#ifndef ZKGL_PLANE_STATS
                 if (sc.p2_stats && (threadIdx.x & 63) == 0) atomicAdd(sc.p2_stats + (all_off ? 0 : 1), 1ull);
-#endif
                 if (all_off) {
 #pragma unroll
                     for (int i = 0; i < 12; ++i) st(0ull);
                     break;
                 }
             }
-#ifdef ZKGL_P2_MERGE
-            else if (merged) { lane_off = mrg_me < 0; }
-#endif
             else {
                 out_to(W[13]);
                 pc += 13 + D;
             }
             if (deferred) dst += WIDE ? 950u : 950u * bstep;
             p2::mds_external(s);
-            if constexpr (P2_IN_REGISTERS) {
+            {
                 // state in registers, the twelve S-boxes of a full round unrolled, ONE copy of the full-round body (12 KB of code: the
                 // fully unrolled permutation of round 1 was 190 KB and instruction-cache-bound, the LDS-staged rolled form that replaced
                 // it costs 10 % of the loop kernel against this one; no LDS: a 1 024-thread strand block would need 96 KB for it)
@@ -865,17 +676,12 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll
                         for (int i = 0; i < 12; ++i) {
                             const uint64_t t = gl::add(s[i], p2::RC[12 * r + i]);
-#ifdef ZKGL_STUB_P2  // time attribution only: the S-box without its four multiplications
-                            const uint64_t x2 = t ^ 1, x3 = t ^ 2, x4 = t ^ 3, x7 = t ^ 4;
-#else
-                            const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
-#endif
+                            const uint64_t x2 = probe::NO_P2_SBOX ? t ^ 1 : gl::sqr(t), x3 = probe::NO_P2_SBOX ? t ^ 2 : gl::mul(x2, t), x4 = probe::NO_P2_SBOX ? t ^ 3 : gl::sqr(x2),
+                                           x7 = probe::NO_P2_SBOX ? t ^ 4 : gl::mul(x3, x4);
                             if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
                             s[i] = x7;
                         }
-#ifndef ZKGL_STUB_P2LIN  // time attribution only: no linear layers
-                        p2::mds_external(s);
-#endif
+                        if constexpr (!probe::NO_P2_LINEAR) p2::mds_external(s);
                         if (emit) {
 #pragma unroll
                             for (int i = 0; i < 12; ++i) st(s[i]);
@@ -885,16 +691,11 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
 #pragma unroll 1
                         for (int r = 4; r < 26; ++r) {
                             const uint64_t t = gl::add(s[0], p2::RC[12 * r]);
-#ifdef ZKGL_STUB_P2
-                            const uint64_t x2 = t ^ 1, x3 = t ^ 2, x4 = t ^ 3, x7 = t ^ 4;
-#else
-                            const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
-#endif
+                            const uint64_t x2 = probe::NO_P2_SBOX ? t ^ 1 : gl::sqr(t), x3 = probe::NO_P2_SBOX ? t ^ 2 : gl::mul(x2, t), x4 = probe::NO_P2_SBOX ? t ^ 3 : gl::sqr(x2),
+                                           x7 = probe::NO_P2_SBOX ? t ^ 4 : gl::mul(x3, x4);
                             if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
                             s[0] = x7;
-#ifndef ZKGL_STUB_P2LIN
-                            p2::mds_inner(s);
-#endif
+                            if constexpr (!probe::NO_P2_LINEAR) p2::mds_inner(s);
                             if (emit) {
 #pragma unroll
                                 for (int i = 0; i < 12; ++i) st(s[i]);
@@ -902,59 +703,10 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                         }
                     }
                 }
-#ifdef ZKGL_P2_MERGE
-                if (merged) {
-                    if (mrg_me >= 0) {   // this lane's member: its 12 outputs, at the member's place in the op's output run
-                        const uint32_t vo = lane_byte + (uint32_t)mrg_me * 12u * bstep;
-#pragma unroll
-                        for (int i = 0; i < 12; ++i) {
-                            u32x2 o;
-                            o.x = (uint32_t)s[i]; o.y = (uint32_t)(s[i] >> 32);
-                            __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, vo, mrg_base + (uint32_t)i * bstep, 0);
-                        }
-                    }
-                } else
-#endif
                 if (!emit) {
 #pragma unroll
                     for (int i = 0; i < 12; ++i) st(lane_off ? 0ull : s[i]);
                 }
-            } else {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) p2s[i * BLOCK + threadIdx.x] = s[i];
-            if (emit) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) st(s[i]);
-            }
-#pragma unroll 1
-            for (int r = 0; r < 30; ++r) {
-                const bool full = (r < 4) || (r >= 26);
-                const int n = full ? 12 : 1;
-#pragma unroll 1
-                for (int i = 0; i < n; ++i) {
-                    const uint64_t t = gl::add(p2s[i * BLOCK + threadIdx.x], p2::RC[12 * r + i]);
-#ifdef ZKGL_STUB_P2  // time attribution only: the S-box without its four multiplications
-                    const uint64_t x2 = t ^ 1, x3 = t ^ 2, x4 = t ^ 3, x7 = t ^ 4;
-#else
-                    const uint64_t x2 = gl::sqr(t), x3 = gl::mul(x2, t), x4 = gl::sqr(x2), x7 = gl::mul(x3, x4);
-#endif
-                    if (emit) { st(t); st(x2); st(x3); st(x4); st(x7); }
-                    p2s[i * BLOCK + threadIdx.x] = x7;
-                }
-#pragma unroll
-                for (int i = 0; i < 12; ++i) s[i] = p2s[i * BLOCK + threadIdx.x];
-                if (full) p2::mds_external(s); else p2::mds_inner(s);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) p2s[i * BLOCK + threadIdx.x] = s[i];
-                if (emit) {
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) st(s[i]);
-                }
-            }
-            if (!emit) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) st(lane_off ? 0ull : s[i]);
-            }
             }
         } break;
         case ZK_OP_LOOP_LAST: {
@@ -1021,18 +773,17 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }
             if constexpr (STRANDS) out_to(prog[pc + 97]);
             pc += 97 + D;
-#ifndef ZKGL_STUB_STORES
-            if constexpr (!WIDE) {
+            if constexpr (!(XMACROS & X_SHA4)) { if (pa == 1) return; }   // (the 4-bit table set runs on the kernels made for it: the host launches those)
+            if constexpr (!WIDE && !probe::NO_STORES) {
                 const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
-#ifdef ZKGL_SHA4_KERNEL
-                if (pa == 1) dst = sha256_rounds4_stream(rsrc, lane_byte, dst, bstep, wd, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
-                else
-#endif
-                dst = sha256_rounds_stream(rsrc, lane_byte, dst, bstep, wd, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
-            } else
-#endif
-#ifdef ZKGL_SHA4_KERNEL
-            if (pa == 1) {   // (wide scopes / stub builds: every output through st)
+                if constexpr ((XMACROS & X_SHA4) != 0) {
+                    if (pa == 1) dst = sha256_rounds4_stream(rsrc, lane_byte, dst, bstep, wd, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+                    else dst = sha256_rounds_stream(rsrc, lane_byte, dst, bstep, wd, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+                } else dst = sha256_rounds_stream(rsrc, lane_byte, dst, bstep, wd, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+            } else {
+            bool done4 = false;
+            if constexpr ((XMACROS & X_SHA4) != 0) if (pa == 1) {   // (wide scopes / probe builds: every output through st)
+                done4 = true;
                 auto st1 = [&](uint64_t v) { st(v); };
                 struct EmitAll4 {
                     decltype(st1)& f;
@@ -1046,9 +797,8 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 for (int i = 0; i < 16; ++i) blk[i] = wd[8 + i];
                 zks4::ComputeBackend<EmitAll4> be(emit);
                 zks4::compress(be, sst, blk, w, wsp, zks::K);
-            } else
-#endif
-            {
+            }
+            if (!done4) {
                 auto st1 = [&](uint64_t v) { st(v); };
                 struct EmitAll {
                     decltype(st1)& f;
@@ -1066,10 +816,10 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
                 zks::ComputeBackend<EmitAll> be(emit);
                 zks::compress(be, sst, blk, w, zks::K);
             }
+            }
             fused_bad |= not_bytes;
         } else { return; } break;
-#ifdef ZKGL_BYTEBUF_KERNEL
-        case ZK_OP_BYTEBUF_FILL: if constexpr (WITH_BIGINT) {
+        case ZK_OP_BYTEBUF_FILL: if constexpr (WITH_BIGINT && (XMACROS & X_BYTEBUF) != 0) {
             // K8: one ByteBuffer fill as ONE op.  [192 buffer bytes, filled, 32 input bytes, offset, meaningful] -> every intermediate, in the
             // gadget's allocation order (both walk zkb::fill_with_bytes).  The op works on small integers: an operand outside its range
             // (byte > 255, filled > 192, offset > 31, meaningful > 32 — each of them is range-checked by the circuit) is reported as the
@@ -1122,7 +872,6 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }
             fused_bad |= out_of_range;
         } else { return; } break;
-#endif  // ZKGL_BYTEBUF_KERNEL
         case ZK_OP_KECCAK_F: if constexpr (WITH_BIGINT) {
             // K8: a whole Keccak-f[1600] as ONE op.  [200 state byte slots] -> every intermediate of the byte-table decomposition, in the
             // order the gadget allocated them (both walk zkk::keccak_f, keccak_macro.hpp): the state lives in 25 register pairs, every
@@ -1142,13 +891,11 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }
             if constexpr (STRANDS) out_to(prog[pc + 201]);
             pc += 201 + D;
-#ifndef ZKGL_STUB_STORES
-            if constexpr (!WIDE) {
+            if constexpr (!WIDE && !probe::NO_STORES) {
                 // strand form: the op is in every strand's program (cs.cpp build_strands), strand w stores every (blockDim / 64)-th output
                 const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
                 dst = keccak_f_stream(rsrc, lane_byte, dst, bstep, sl, STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
             } else
-#endif
             {
                 auto st1 = [&](uint64_t v) { st(v); };
                 struct EmitAll {
@@ -1297,7 +1044,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
     if (sc.fail && fused_bad && active) report_fused(sc.fail, lane);
 }
 
-template <bool WITH_BIGINT, bool WIDE, bool NARROW = false>
+template <bool WITH_BIGINT, bool WIDE, bool NARROW = false, int XMACROS = 0>
 __device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin, const uint32_t* cls_words = nullptr) {
     uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= sc.n_lanes) return;  // whole wave out of range
@@ -1309,7 +1056,7 @@ __device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word
     const bool probe = sc.clock_probe && blockIdx.x == 0 && threadIdx.x < 64;
     uint64_t t0 = 0, r0 = 0;
     if (probe) { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    run_tile2<WITH_BIGINT, WIDE, TPB, false, NARROW>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end, slot_begin, cls_words);
+    run_tile2<WITH_BIGINT, WIDE, TPB, false, NARROW, XMACROS>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, word_begin, word_end, slot_begin, cls_words);
     if (probe && threadIdx.x == 0) {
         sc.clock_probe[0] = __builtin_readcyclecounter() - t0;
         sc.clock_probe[1] = __builtin_amdgcn_s_memrealtime() - r0;
@@ -1318,14 +1065,14 @@ __device__ __forceinline__ void witness_entry2(const ScopeDev& sc, uint32_t word
 // Strand mode: a scope with too few lanes to fill the chip (hash circuits: lanes = instances x cycles; every outer scope: lanes =
 // instances) runs one 64-lane tile per BLOCK of 8 wavefronts.  Wavefront w walks strand w of the program: the ops of every
 // dependency level of the op graph are dealt out over the strands by the host (cs.cpp build_strands), ZK_OP_BARRIER between levels.
-template <bool WITH_BIGINT, bool WIDE>
+template <bool WITH_BIGINT, bool WIDE, int XMACROS = 0>
 __global__ __launch_bounds__(64 * STRANDS_PER_TILE) void k_witness_strands2(ScopeDev sc, StrandTab tab) {
     if (blockIdx.x * 64 >= sc.n_lanes) return;
     const uint32_t w = uni(threadIdx.x >> 6);
     uint32_t lane = blockIdx.x * 64 + (threadIdx.x & 63);
     const bool active = lane < sc.n_lanes;
     lane = active ? lane : sc.n_lanes - 1;
-    run_tile2<WITH_BIGINT, WIDE, 64 * STRANDS_PER_TILE, true>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, tab.begin[w], tab.end[w], 0);
+    run_tile2<WITH_BIGINT, WIDE, 64 * STRANDS_PER_TILE, true, false, XMACROS>(sc, lane, sc.is_loop ? lane / sc.limit : lane, active, tab.begin[w], tab.end[w], 0);
 }
 
 // Separate symbols so that profiles separate the loop-scope launch (the dominant kernel: B * limit lanes) from the
@@ -1354,6 +1101,12 @@ __global__ __launch_bounds__(TPB) void k_witness_loop_bigint(ScopeDev sc, uint32
 }
 __global__ __launch_bounds__(TPB) void k_witness_outer_bigint(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
     witness_entry2<true, false>(sc, word_begin, word_end, slot_begin);
+}
+// plain form (loop or outer scope) of the circuits that record a macro-op beyond the basic set (XMACROS: X_SHA4 / X_BYTEBUF); their strand form is
+// k_witness_strands2<true, false, XMACROS>
+template <int XMACROS>
+__global__ __launch_bounds__(TPB) void k_witness_plain_x(ScopeDev sc, uint32_t word_begin, uint32_t word_end, uint32_t slot_begin) {
+    witness_entry2<true, false, false, XMACROS>(sc, word_begin, word_end, slot_begin);
 }
 
 
@@ -1390,10 +1143,6 @@ __device__ __forceinline__ void run_seed2(const ScopeDev& sc, const uint32_t ins
             if (op == ZK_OP_LOOKUP) len += pa + (pb & 0xff);
             Wn = *(prog16_ptr)(prog + pc + len);
         }
-#ifdef ZKGL_SEED_PROFILE
-        const uint64_t t_op0 = __builtin_readcyclecounter();
-        const uint32_t prof_op = op;
-#endif
         switch (op) {
         case ZK_OP_BARRIER:
             pc += 1;
@@ -1619,9 +1368,6 @@ __device__ __forceinline__ void run_seed2(const ScopeDev& sc, const uint32_t ins
         default:
             return;  // not a seed-v2 op: the host never selects this kernel for such cones
         }
-#ifdef ZKGL_SEED_PROFILE
-        if (prof) { prof[prof_op * 2] += __builtin_readcyclecounter() - t_op0; prof[prof_op * 2 + 1] += 1; }
-#endif
     }
 }
 
@@ -1638,15 +1384,7 @@ __global__ __launch_bounds__(64 * SEED_STRANDS_PER_TILE) void k_seed_cone_strand
     const uint32_t inst = min(blockIdx.x * lpb + l, n_instances - 1);
     const uint32_t ml = inst - blockIdx.x * lpb;
     const uint32_t wb = tab.begin[w], we = tab.end[w];
-#ifdef ZKGL_SEED_PROFILE
-    uint64_t prof[64];
-    for (int i = 0; i < 64; ++i) prof[i] = 0;
-    uint64_t t_pro = 0, t_run = 0;
-#endif
     for (uint32_t k = 0; k < sc.limit; ++k) {
-#ifdef ZKGL_SEED_PROFILE
-        const uint64_t t0 = __builtin_readcyclecounter();
-#endif
         for (uint32_t idx = threadIdx.x; idx < n_input_words * lpb; idx += NT) {
             const uint32_t wd = idx / lpb, ll = idx % lpb;
             const uint32_t li = min(blockIdx.x * lpb + ll, n_instances - 1);
@@ -1663,23 +1401,9 @@ __global__ __launch_bounds__(64 * SEED_STRANDS_PER_TILE) void k_seed_cone_strand
             inputs_rw[(size_t)cd.word * sc.in_stride + (size_t)li * sc.limit + k] = v;
         }
         __syncthreads();
-#ifdef ZKGL_SEED_PROFILE
-        const uint64_t t1 = __builtin_readcyclecounter();
-        run_seed2<(int)NT>(sc, inst, wb, we, seed_sprog, slot_store + ml, lpb, in_store + ml, prof);
-        __syncthreads();
-        t_pro += t1 - t0; t_run += __builtin_readcyclecounter() - t1;
-#else
         run_seed2<(int)NT>(sc, inst, wb, we, seed_sprog, slot_store + ml, lpb, in_store + ml);
         __syncthreads();
-#endif
     }
-#ifdef ZKGL_SEED_PROFILE
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
-        printf("[seed profile] strand %u: prologue %llu cycles, run %llu cycles (s_memtime ticks)\n", w, (unsigned long long)t_pro, (unsigned long long)t_run);
-        for (int o = 0; o < 25; ++o)
-            if (prof[2 * o + 1]) printf("   strand %u op %2d: n=%llu ticks=%llu (%.0f per op)\n", w, o, (unsigned long long)prof[2 * o + 1], (unsigned long long)prof[2 * o], (double)prof[2 * o] / (double)prof[2 * o + 1]);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

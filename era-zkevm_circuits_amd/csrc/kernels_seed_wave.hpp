@@ -93,19 +93,12 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_seed_wave(SeedWaveDev a) {
     // executes the segments from `pos` up to the end marker.  A wavefront only ever reads what IT wrote to its slot area (the
     // program is read-only), and LDS instructions of one wavefront complete in issue order: between segments a compiler-level
     // fence is enough, no workgroup barrier — the wavefronts of a workgroup drift freely and fill each other's stalls.
-#ifdef ZKGL_SEED_PROFILE
-    uint64_t prof[40];
-    for (int i = 0; i < 40; ++i) prof[i] = 0;
-#endif
     auto wave_fence = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     auto run = [&](uint32_t pos) {
         for (;;) {
             const uint32_t kind = uni(prog[pos]), count = uni(prog[pos + 1]);  // the same words for every lane: scalar control flow
             pos += 4;
             if (kind == WK_END) break;
-#ifdef ZKGL_SEED_PROFILE
-            const uint64_t t_seg = __builtin_readcyclecounter();
-#endif
             switch (kind) {
             case WK_CONST:
                 for (uint32_t i = lane; i < count; i += 64) {
@@ -351,15 +344,9 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_seed_wave(SeedWaveDev a) {
                 return;  // malformed program: built by the host
             }
             wave_fence();
-#ifdef ZKGL_SEED_PROFILE
-            if (kind < 20) { prof[2 * kind] += __builtin_readcyclecounter() - t_seg; prof[2 * kind + 1] += 1; }
-#endif
         }
     };
 
-#ifdef ZKGL_SEED_PROFILE
-    uint64_t t_total0 = __builtin_readcyclecounter();
-#endif
     run(0);  // prologue: loop-invariant constants and outer imports
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
     // the raw input words of cycle k+1 are fetched while cycle k runs (a strided gather: one cache line per word), 8 per lane
@@ -393,13 +380,6 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_seed_wave(SeedWaveDev a) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         run(a.pro_words);
     }
-#ifdef ZKGL_SEED_PROFILE
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        printf("[seed wave profile] total %llu ticks\n", (unsigned long long)(__builtin_readcyclecounter() - t_total0));
-        for (int o = 0; o < 20; ++o)
-            if (prof[2 * o + 1]) printf("   kind %2d: segments=%llu ticks=%llu (%.0f per segment)\n", o, (unsigned long long)prof[2 * o + 1], (unsigned long long)prof[2 * o], (double)prof[2 * o] / (double)prof[2 * o + 1]);
-    }
-#endif
 }
 
 }  // namespace zke

@@ -11,7 +11,7 @@
 // A store travels through the launch interface as (pointer, geometry word): the slot count with T in the top byte.  A bare slot count
 // (top byte 0) means T = 6, so interfaces that only ever see 64-lane-tiled memory pass their counts unchanged.
 //
-// NARROW store (loop scopes, opt-in: cs.cpp build_narrow_layout).  CS::bound_values proves from the constraints alone that 29 % of main_vm's
+// NARROW store (loop scopes; cs.cpp build_narrow_layout; a batch takes it when ZKGL_NARROW_STORE=1 is set at zk_cs_set_batch).  CS::bound_values proves from the constraints alone that 29 % of main_vm's
 // values are bytes / booleans in every satisfying witness; held in 8-byte slots they are 26 % of the bytes the witness kernel writes (and of
 // what it re-fetches).  In a narrow store a value has a CLASS: 8 bytes per lane, or 1 byte per lane; a tile is a sequence of UNITS (one byte
 // per lane of the tile = 2^T bytes) and a value is named by its ADDRESS WORD

@@ -150,6 +150,12 @@ int launch_witness(const ScopeArgs& sc, uint32_t word_begin, uint32_t word_end, 
         if (!sc.is_loop || sc.uses_bigint || needs_wide_addressing(sc.n_cells) || !zkgeom::narrow(sc.n_cells)) { g_hip_err = "launch_witness: a narrow store outside the plain loop kernel"; return -1; }
         zke::k_witness_loop_narrow<<<grid, zke::TPB, lds_pad("ZKGL_LOOP_LDS_PAD"), s>>>(to_dev(sc), sc.cls, word_begin, word_end, slot_begin);
     }
+    else if (sc.xmacros) {   // a circuit that records ZK_OP_SHA256_ROUNDS a = 1 / ZK_OP_BYTEBUF_FILL: the kernels that carry that backend
+        if (needs_wide_addressing(sc.n_cells)) { g_hip_err = "launch_witness: the 4-bit SHA / ByteBuffer macro-ops are not offered to scopes with 64-bit store addressing"; return -1; }
+        if (sc.xmacros == zke::X_SHA4) zke::k_witness_plain_x<zke::X_SHA4><<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
+        else if (sc.xmacros == zke::X_BYTEBUF) zke::k_witness_plain_x<zke::X_BYTEBUF><<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
+        else { g_hip_err = "launch_witness: no kernel carries this combination of macro-op backends"; return -1; }
+    }
     else if (needs_wide_addressing(sc.n_cells)) zke::k_witness_wide<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.is_loop && sc.uses_bigint) zke::k_witness_loop_bigint<<<grid, zke::TPB, 0, s>>>(to_dev(sc), word_begin, word_end, slot_begin);
     else if (sc.is_loop) zke::k_witness_loop<<<grid, zke::TPB, lds_pad("ZKGL_LOOP_LDS_PAD"), s>>>(to_dev(sc), word_begin, word_end, slot_begin);
@@ -168,7 +174,13 @@ int launch_witness_strands(const ScopeArgs& sc, const uint32_t begin[STRANDS_PER
     for (int i = 0; i < zke::STRANDS_PER_TILE; ++i) { tab.begin[i] = begin[i]; tab.end[i] = end[i]; any |= end[i] > begin[i]; }
     if (!any) return 0;
     const unsigned grid = grid_for(sc.n_lanes, 64);
-    if (needs_wide_addressing(sc.n_cells)) zke::k_witness_strands2<true, true><<<grid, block, 0, (hipStream_t)stream>>>(to_dev(sc), tab);  // 64-bit addressing
+    if (sc.xmacros) {
+        if (needs_wide_addressing(sc.n_cells)) { g_hip_err = "launch_witness_strands: the 4-bit SHA / ByteBuffer macro-ops are not offered to scopes with 64-bit store addressing"; return -1; }
+        if (sc.xmacros == zke::X_SHA4) zke::k_witness_strands2<true, false, zke::X_SHA4><<<grid, block, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
+        else if (sc.xmacros == zke::X_BYTEBUF) zke::k_witness_strands2<true, false, zke::X_BYTEBUF><<<grid, block, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
+        else { g_hip_err = "launch_witness_strands: no kernel carries this combination of macro-op backends"; return -1; }
+    }
+    else if (needs_wide_addressing(sc.n_cells)) zke::k_witness_strands2<true, true><<<grid, block, 0, (hipStream_t)stream>>>(to_dev(sc), tab);  // 64-bit addressing
     else if (sc.uses_bigint) zke::k_witness_strands2<true, false><<<grid, block, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
     else zke::k_witness_strands2<false, false><<<grid, block, 0, (hipStream_t)stream>>>(to_dev(sc), tab);
     return LAUNCH_CHECK("k_witness_strands");

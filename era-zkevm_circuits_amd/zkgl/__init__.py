@@ -134,11 +134,11 @@ def poseidon_round_constants() -> np.ndarray:
     return out
 
 
-BUILD_BYTEBUF_KERNEL, BUILD_STRAND_PLANES_KERNEL, BUILD_SELECT_CHAINS_KERNEL, BUILD_BATCH_INV, BUILD_SHA4_KERNEL, BUILD_P2_MERGE = 1, 2, 4, 8, 16, 32
+BUILD_BYTEBUF_KERNEL, BUILD_SHA4_KERNEL = 1, 16   # (round 6: one build, every device path in it; bits 2, 4, 8, 32 named variants that no longer exist)
 
 
 def build_features() -> int:
-    """zk_build_features: opt-in device paths compiled into the loaded library (0 for the default build)"""
+    """zk_build_features: macro-op device backends the loaded library carries (round 6: one build, always BYTEBUF | SHA4)"""
     f = lib().zk_build_features
     f.restype = C.c_uint32
     return int(f())

@@ -40,15 +40,12 @@ typedef enum zk_status {
 } zk_status;
 
 const char *zk_last_error(void);
-/* opt-in device paths compiled into THIS library (A/B builds: era-zkevm_circuits_amd/build.sh with ZKGL_DEFS=-DZKGL_..._KERNEL).  The default
- * build returns 0: it carries only paths that have been measured on the device.  A circuit / switch that needs an absent path is refused
- * by zk_cs_set_batch with ZK_ERR_INVALID. */
-#define ZK_BUILD_BYTEBUF_KERNEL 1u        /* ZK_OP_BYTEBUF_FILL on the device (ZKGL_BYTEBUF_MACRO=1 recordings) */
-#define ZK_BUILD_STRAND_PLANES_KERNEL 2u  /* SELECT flags as bit planes in the strand form (ZKGL_STRAND_PLANES=1) */
-#define ZK_BUILD_SELECT_CHAINS_KERNEL 4u  /* mux-chain ops (ZKGL_SELECT_CHAINS=1) */
-#define ZK_BUILD_BATCH_INV 8u             /* Montgomery-batched zero-check inversions in the plain loop kernels */
-#define ZK_BUILD_SHA4_KERNEL 16u          /* ZK_OP_SHA256_ROUNDS a = 1 on the device: the reference's 4-bit-chunk SHA tables as a macro-op (ZKGL_SHA4_MACRO=1 recordings) */
-#define ZK_BUILD_P2_MERGE 32u             /* the gated witness-only permutations of a dependency level under one header: one permutation per round per wavefront */
+/* Macro-op device backends this library carries.  Since round 6 there is ONE build and it carries every device path of the tree (rounds 4-5 kept
+ * unmeasured paths in variant libraries: they were promoted into kernels of their own, or deleted): the value is the constant
+ * ZK_BUILD_BYTEBUF_KERNEL | ZK_BUILD_SHA4_KERNEL.  Bits 2, 4, 8, 32 named variants that no longer exist. */
+#define ZK_BUILD_BYTEBUF_KERNEL 1u        /* ZK_OP_BYTEBUF_FILL on the device (recordings made with ZKGL_BYTEBUF_MACRO=1): kernels k_witness_*_x<X_BYTEBUF> */
+#define ZK_BUILD_SHA4_KERNEL 16u          /* ZK_OP_SHA256_ROUNDS a = 1: the reference's 4-bit-chunk SHA tables as a macro-op (the default recording of
+                                           * configure_sha256(reference_tables); ZKGL_SHA4_MACRO=0 records op by op): kernels k_witness_*_x<X_SHA4> */
 uint32_t zk_build_features(void);
 /* Select the device, upload Poseidon2 constants.  Fails loudly (ZK_ERR_HIP) without a GPU.  One device per process: a second
  * call with another device index is ZK_ERR_INVALID (process-wide device tables are bound to the first). */
@@ -315,10 +312,10 @@ typedef struct zk_stats {
     /* 1: the seed kernels are not offered this circuit's cone (zk_cs_seed_* answers ZK_ERR_INVALID unless a native seeder is registered):
      * it holds ZK_OP_BYTEBUF_FILL, or a carried output depends on a gated ZK_OP_POSEIDON2 other than through a select on that op's flag */
     uint64_t seed_cone_unsupported;
-    /* NARROW STORE of the loop scope (opt-in: ZKGL_NARROW_STORE=1 when the circuit is finalized; csrc/store_geom.hpp).  Values that are bytes in
+    /* NARROW STORE of the loop scope (csrc/store_geom.hpp; a batch takes it when ZKGL_NARROW_STORE=1 is set at zk_cs_set_batch — opt-in).  Values that are bytes in
      * every satisfying witness (the census above) live in one-byte slots of the variable store the fused step writes and reads:
      *   store_bytes_per_lane_loop         — bytes one loop lane's witness kernel writes into the ordinary store (8 per value)
-     *   narrow_store_bytes_per_lane_loop  — the same with the narrow layout (0: the circuit has none — not asked for, strand-form / macro-op loop)
+     *   narrow_store_bytes_per_lane_loop  — the same with the narrow layout (0: the circuit has none — macro-op / big-integer loop scope, or ZKGL_NARROW_STORE=0 at finalize)
      *   narrow_byte_values_loop           — values of a lane held in one-byte slots
      *   narrow_store_active               — 1: the bound batch runs its fused steps over the narrow store (zk_cs_set_batch decides: plain loop
      *                                       kernel, inline multiplicities); every other reader sees the ordinary store, expanded on demand

@@ -91,13 +91,13 @@ if want("C3s"):
     timed("C3 sha256_round_function 2^20 rows", cs, outer, loop, B, stream_x=4)
     timed("C3 sha256_round_function 2^20 rows, every carried word from the witness's queue states (zk_pack_sha256_witness_tails)", cs, outer, loop, B, given=list(range(shn.CARRIED)))
 if want("C3s4"):   # the SAME circuit under the reference's own table set (src/code_unpacker_sha256/mod.rs:554-566: width-4 lookups, Maj4 / TriXor4 / Ch4 / Split4BitChunk<1,2>)
-    B = 128      # ZKGL_SHA4_MACRO=1 (in a -DZKGL_SHA4_KERNEL library) records the compression as one macro-op; otherwise it is interpreted op by op
+    B = 128      # the compression is ONE macro-op (ZK_OP_SHA256_ROUNDS a = 1: the default recording of this table set since round 6); ZKGL_SHA4_MACRO=0 interprets it op by op
     cs, limit = T.fit(lambda c: c.configure_sha256(True), lambda c, l: c.sha256_round_function_entry_point(l), 20)
     msgs = [bytes(rng.integers(0, 256, size=64 * 8 - 9, dtype=np.uint8)) for _ in range(limit // 8)]
     reqs = [shn.request(m, 1 + 2 * i, 10 + i, 0, 9000 + i, i) for i, m in enumerate(msgs)]
     inst = shn.instance(reqs, limit)
     outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
-    form = "macro-op ZK_OP_SHA256_ROUNDS a = 1" if os.environ.get("ZKGL_SHA4_MACRO") == "1" else "op by op"
+    form = "op by op" if os.environ.get("ZKGL_SHA4_MACRO") == "0" else "macro-op ZK_OP_SHA256_ROUNDS a = 1"
     timed(f"C3 sha256_round_function 2^20 rows, REFERENCE table set (4-bit chunks, {form}), every carried word from the witness's queue states", cs, outer, loop, B, given=list(range(shn.CARRIED)))
 # C4 (4 instances on one GPU here; BASELINE shards them over 4 GPUs)
 if want("C4s"):

@@ -97,13 +97,13 @@ struct Run {
         d.defer_p2 = 0; d.p2_stats = p2_stats; d.clock_probe = nullptr;
         return d;
     }
-    template <bool BIG>
+    template <bool BIG, int X = 0>
     void plain(const zke::ScopeDev& d, uint32_t w0, uint32_t w1, uint32_t slot0) {
         emu::tid = {0, 0, 0}; emu::bid = {0, 0, 0}; emu::bdim = {(unsigned)zke::TPB, 1, 1};
         for (uint32_t lane = 0; lane < d.n_lanes; ++lane)
-            zke::run_tile2<BIG, false>(d, lane, d.is_loop ? lane / d.limit : lane, true, w0, w1, slot0);
+            zke::run_tile2<BIG, false, zke::TPB, false, false, X>(d, lane, d.is_loop ? lane / d.limit : lane, true, w0, w1, slot0);
     }
-    template <bool BIG>
+    template <bool BIG, int X = 0>
     void strands(zke::ScopeDev d, const Scope& s, int phase) {
         constexpr uint32_t NS = zke::STRANDS_PER_TILE;
         d.prog = sprog[s.is_loop ? 1 : 0].data(); d.n_words = (uint32_t)s.sprog.size();
@@ -114,7 +114,7 @@ struct Run {
             for (uint32_t w = 0; w < NS; ++w)
                 ts.emplace_back([&, w] {
                     emu::tid = {64 * w, 0, 0}; emu::bid = {lane / 64, 0, 0}; emu::bdim = {64 * NS, 1, 1};
-                    zke::run_tile2<BIG, false, 64 * NS, true>(d, lane, d.is_loop ? lane / d.limit : lane, true, s.s_begin[phase][w], s.s_end[phase][w], 0);
+                    zke::run_tile2<BIG, false, 64 * NS, true, false, X>(d, lane, d.is_loop ? lane / d.limit : lane, true, s.s_begin[phase][w], s.s_end[phase][w], 0);
                 });
             for (auto& t : ts) t.join();
             emu::g_barrier = nullptr;
@@ -124,8 +124,12 @@ struct Run {
         const Scope& s = sc ? cs.loop_ : cs.outer_;
         zke::ScopeDev d = dev(sc, fused);
         if (d.n_lanes == 0) return;
+        // the kernels that carry a macro-op backend beyond the basic set (kernels_engine2.hpp X_SHA4 / X_BYTEBUF; CS::launch_phase -> zkdev::launch_witness*)
+        const int x = (cs.uses_sha4_macro_ ? zke::X_SHA4 : 0) | (cs.uses_bytebuf_macro_ ? zke::X_BYTEBUF : 0);
         if (use_strands && !s.sprog.empty()) {
-            if (s.uses_bigint) strands<true>(d, s, ph); else strands<false>(d, s, ph);
+            if (x == zke::X_SHA4) strands<true, zke::X_SHA4>(d, s, ph);
+            else if (x == zke::X_BYTEBUF) strands<true, zke::X_BYTEBUF>(d, s, ph);
+            else if (s.uses_bigint) strands<true>(d, s, ph); else strands<false>(d, s, ph);
             return;
         }
         const uint32_t end = (uint32_t)s.prog2.size();
@@ -136,7 +140,9 @@ struct Run {
             else { w0 = s.side_words2; slot0 = s.side_slots; }
         }
         if (w0 >= w1) return;
-        if (s.uses_bigint) plain<true>(d, w0, w1, slot0); else plain<false>(d, w0, w1, slot0);
+        if (x == zke::X_SHA4) plain<true, zke::X_SHA4>(d, w0, w1, slot0);
+        else if (x == zke::X_BYTEBUF) plain<true, zke::X_BYTEBUF>(d, w0, w1, slot0);
+        else if (s.uses_bigint) plain<true>(d, w0, w1, slot0); else plain<false>(d, w0, w1, slot0);
     }
     void trace(int sc, uint64_t* out, uint64_t stride) {   // k_materialize: trace cell <- store slot, the populated cells only
         const Scope& s = sc ? cs.loop_ : cs.outer_;

@@ -30,6 +30,8 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 inline Rsrc make_rsrc(const void* p) { return Rsrc{(char*)const_cast<void*>(p)}; }
 inline u32x2_t load_b64(Rsrc r, uint32_t voff, uint32_t soff) { u32x2_t v; std::memcpy(&v, r.base + (size_t)voff + soff, 8); return v; }
 inline void store_b64(u32x2_t v, Rsrc r, uint32_t voff, uint32_t soff) { std::memcpy(r.base + (size_t)voff + soff, &v, 8); }
+inline uint8_t load_b8(Rsrc r, uint32_t voff, uint32_t soff) { return (uint8_t)r.base[(size_t)voff + soff]; }                 // narrow store: one-byte slots
+inline void store_b8(uint8_t v, Rsrc r, uint32_t voff, uint32_t soff) { r.base[(size_t)voff + soff] = (char)v; }
 }  // namespace emu
 #define threadIdx emu::tid
 #define blockIdx emu::bid
@@ -40,6 +42,8 @@ typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) emu::make_rsrc(p)
 #define __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, aux) emu::load_b64(r, voff, soff)
 #define __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, aux) emu::store_b64(v, r, voff, soff)
+#define __builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, aux) emu::load_b8(r, voff, soff)
+#define __builtin_amdgcn_raw_buffer_store_b8(v, r, voff, soff, aux) emu::store_b8((uint8_t)(v), r, voff, soff)
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_readlane(v, l) (v)
 #define __builtin_amdgcn_ballot_w64(p) ((uint64_t)((p) ? 1 : 0))

@@ -37,25 +37,23 @@ CIRCUITS = {
 }
 FORMS = {
     "default": {},
-    "strand_planes": {"ZKGL_STRAND_PLANES": "1"},
     "planes_off": {"ZKGL_FLAG_PLANES": "0"},
     "no_hash_macros": {"ZKGL_NO_HASH_MACROS": "1"},
-    "bytebuf_macro_and_strand_planes": {"ZKGL_BYTEBUF_MACRO": "1", "ZKGL_STRAND_PLANES": "1"},
-    "chain_order": {"ZKGL_SELECT_CHAINS": "1"},
-    "sha4_macro": {"ZKGL_SHA4_MACRO": "1"},
+    "bytebuf_macro": {"ZKGL_BYTEBUF_MACRO": "1"},
+    "sha4_op_by_op": {"ZKGL_SHA4_MACRO": "0"},          # (the macro-op is the default recording of the reference's table set)
 }
 
 
 @pytest.mark.parametrize("form", sorted(FORMS))
 @pytest.mark.parametrize("circuit", sorted(CIRCUITS))
 def test_device_programs_decode_to_the_recorded_ops(monkeypatch, circuit, form):
-    if form == "bytebuf_macro_and_strand_planes" and circuit != "keccak_fsm":
+    if form == "bytebuf_macro" and circuit != "keccak_fsm":
         pytest.skip("the ByteBuffer is the keccak precompile's")
-    if form == "sha4_macro" and not circuit.endswith("reference_tables"):
-        pytest.skip("the 4-bit-chunk macro-op belongs to the reference's table set")
+    if form == "sha4_op_by_op" and not circuit.endswith("reference_tables"):
+        pytest.skip("the 4-bit-chunk decomposition belongs to the reference's table set")
     if form == "no_hash_macros" and circuit not in ("keccak_fsm", "sha256_fsm", "eip_4844", "code_unpacker", "linear_hasher"):
         pytest.skip("no hash gadget")
-    for k in ("ZKGL_STRAND_PLANES", "ZKGL_FLAG_PLANES", "ZKGL_NO_HASH_MACROS", "ZKGL_BYTEBUF_MACRO", "ZKGL_SELECT_CHAINS", "ZKGL_VERIFY_SABOTAGE", "ZKGL_SHA4_MACRO"):
+    for k in ("ZKGL_FLAG_PLANES", "ZKGL_NO_HASH_MACROS", "ZKGL_BYTEBUF_MACRO", "ZKGL_VERIFY_SABOTAGE", "ZKGL_SHA4_MACRO"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("ZKGL_VERIFY_DEVICE_PROGRAMS", "1")
     for k, v in FORMS[form].items():
@@ -76,11 +74,11 @@ def test_the_check_notices_a_changed_program_word(monkeypatch):
     assert caught == 7
 
 
-@pytest.mark.parametrize("form", ["default", "strand_planes", "chain_order"])
+@pytest.mark.parametrize("form", ["default", "planes_off"])
 def test_random_programs_decode_to_their_ops(monkeypatch, form):
     """the fuzz circuits of tests/test_fuzz_programs.py (random mixes of every light op kind over an outer and a loop scope)"""
     from test_fuzz_programs import random_circuit
-    for k in ("ZKGL_STRAND_PLANES", "ZKGL_FLAG_PLANES", "ZKGL_SELECT_CHAINS", "ZKGL_VERIFY_SABOTAGE"):
+    for k in ("ZKGL_FLAG_PLANES", "ZKGL_VERIFY_SABOTAGE"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("ZKGL_VERIFY_DEVICE_PROGRAMS", "1")
     for k, v in FORMS[form].items():

@@ -15,15 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "era-zkevm_circuits_amd")
 
 
-def run_cases(cases, variant="", defs="", env=None):
+def run_cases(cases, env=None):
     e = dict(os.environ)
-    for k in ("ZKGL_LIB", "ZKGL_SHA4_MACRO", "ZKGL_BYTEBUF_MACRO", "ZKGL_STRAND_PLANES", "ZKGL_SELECT_CHAINS", "ZKGL_STRANDS"):
+    for k in ("ZKGL_LIB", "ZKGL_SHA4_MACRO", "ZKGL_BYTEBUF_MACRO", "ZKGL_STRANDS", "EMU_VARIANT", "EMU_DEFS"):
         e.pop(k, None)
-    if variant:
-        lib = os.path.join(PKG, f"libzkgl_{variant}.so")
-        if not os.path.exists(lib):
-            pytest.skip(f"{lib} is not built (tools/variants_r5.sh)")
-        e.update(ZKGL_LIB=lib, EMU_VARIANT=variant, EMU_DEFS=defs)
     e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "run_case.py"), *cases], capture_output=True, text=True, env=e, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -40,7 +35,7 @@ def all_equal(results, n):
 def test_default_library_every_circuit_kind_plain_and_strands():
     res = run_cases(["ram", "keccak", "sha", "sha4", "vm", "iszero"])
     all_equal(res, 2 + 2 + 2 + 2 + 1 + 1)
-    assert all(r["features"] == 0 for r in res)
+    assert all(r["features"] == 17 for r in res)      # one build: both macro-op backends in it (zk_build_features)
     assert {(r["case"], r["strands"]) for r in res} >= {("keccak", True), ("sha", True), ("ram", True)}
 
 
@@ -50,50 +45,22 @@ def test_fused_failure_flag_of_the_witness_kernels():
     assert res["adversarial_not_a_byte"]["fused_failure"] and res["adversarial_not_a_byte"]["failing_lane"] == 1
 
 
-def test_batched_inversions_variant():
-    """-DZKGL_BATCH_INV: zero-checks of large operands deferred and inverted eight at a time (full batches, a tail, one that cannot be deferred)"""
-    res = run_cases(["iszero", "vm", "keccak"], "binv", "-DZKGL_BATCH_INV")
-    all_equal(res, 1 + 1 + 2)
-    assert all(r["features"] & 8 for r in res)
-
-
-def test_merged_gated_permutations_variant():
-    """-DZKGL_P2_MERGE: the execute-gated witness-only permutations of a dependency level under one header (main_vm: 18 in 5), one permutation per round"""
-    res = run_cases(["vm", "ram"], "p2m", "-DZKGL_P2_MERGE")
-    all_equal(res, 1 + 2)
-    assert all(r["features"] & 32 for r in res)
-
-
-def test_both_valu_levers_together():
-    """-DZKGL_P2_MERGE -DZKGL_BATCH_INV: the library tools/ab_r5.sh times as the candidate for the default loop kernel"""
-    res = run_cases(["vm", "iszero", "ram"], "p2m_binv", "-DZKGL_P2_MERGE -DZKGL_BATCH_INV")
-    all_equal(res, 1 + 1 + 2)
-    assert all(r["features"] & 40 == 40 for r in res)
-
-
-def test_mux_chain_variant():
-    """-DZKGL_SELECT_CHAINS_KERNEL with ZKGL_SELECT_CHAINS=1: runs of SELECTs as chain ops, the running value in a register"""
-    res = run_cases(["vm"], "chains", "-DZKGL_SELECT_CHAINS_KERNEL", {"ZKGL_SELECT_CHAINS": "1"})
-    all_equal(res, 1)
-    assert res[0]["features"] & 4
-
-
-@pytest.mark.parametrize("env", [{"ZKGL_BYTEBUF_MACRO": "1"}, {"ZKGL_STRAND_PLANES": "1"}, {"ZKGL_BYTEBUF_MACRO": "1", "ZKGL_STRAND_PLANES": "1"}],
-                         ids=["bytebuf_macro", "strand_planes", "both"])
-def test_bytebuf_macro_and_strand_planes_variant(env):
-    """-DZKGL_BYTEBUF_KERNEL -DZKGL_STRAND_PLANES_KERNEL: ZK_OP_BYTEBUF_FILL (plain and cooperative strand form), SELECT flags from the tile's planes"""
-    res = run_cases(["keccak", "ram"], "k8", "-DZKGL_BYTEBUF_KERNEL -DZKGL_STRAND_PLANES_KERNEL", env)
+def test_bytebuf_macro_recording_on_its_own_kernels():
+    """ZK_OP_BYTEBUF_FILL (ZKGL_BYTEBUF_MACRO=1 at record time): plain and cooperative strand form, the run_tile2 instantiation with X_BYTEBUF"""
+    res = run_cases(["keccak", "ram"], env={"ZKGL_BYTEBUF_MACRO": "1"})
     all_equal(res, 4)
-    if "ZKGL_BYTEBUF_MACRO" in env:
-        plain_ops = run_cases(["keccak"])[0]["loop_ops"]
-        assert [r for r in res if r["case"] == "keccak"][0]["loop_ops"] < plain_ops - 40000      # six fills of ~7.7 k ops each are six ops
+    plain_ops = [r for r in run_cases(["keccak"]) if r["case"] == "keccak"][0]["loop_ops"]
+    assert [r for r in res if r["case"] == "keccak"][0]["loop_ops"] < plain_ops - 40000      # six fills of ~7.7 k ops each are six ops
 
 
-def test_sha4_macro_variant():
-    """-DZKGL_SHA4_KERNEL with ZKGL_SHA4_MACRO=1: the reference's 4-bit-chunk compression as ONE op (26 088 outputs), plain and cooperative strand form"""
-    res = run_cases(["sha4", "sha"], "sha4", "-DZKGL_SHA4_KERNEL", {"ZKGL_SHA4_MACRO": "1"})
+def test_sha4_macro_is_the_default_recording_of_the_reference_tables():
+    """the reference's 4-bit-chunk compression as ONE op (26 088 outputs), plain and cooperative strand form (X_SHA4 instantiation); op by op with ZKGL_SHA4_MACRO=0"""
+    res = run_cases(["sha4", "sha"])
     all_equal(res, 4)
-    assert [r for r in res if r["case"] == "sha4"][0]["loop_ops"] < 300 and all(r["features"] & 16 for r in res)
+    assert [r for r in res if r["case"] == "sha4"][0]["loop_ops"] < 300
+    res0 = run_cases(["sha4"], env={"ZKGL_SHA4_MACRO": "0"})
+    all_equal(res0, 2)
+    assert res0[0]["loop_ops"] > 15000
 
 
 def test_verdicts_of_the_step_fused_and_stored_equal_the_oracle_checker():

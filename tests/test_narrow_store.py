@@ -1,4 +1,4 @@
-"""The NARROW STORE of a loop scope (csrc/store_geom.hpp, cs.cpp build_narrow_layout; opt-in: ZKGL_NARROW_STORE=1 when the circuit is finalized).
+"""The NARROW STORE of a loop scope (csrc/store_geom.hpp, cs.cpp build_narrow_layout; opt-in per batch: ZKGL_NARROW_STORE=1 at zk_cs_set_batch).
 
 CS::bound_values proves, from the constraints alone, which values are bytes in EVERY satisfying witness (main_vm: 5 103 of a cycle's 17 700);
 the narrow layout keeps them in one-byte slots of the store the fused step writes and reads (k_witness_loop_narrow, k_check_prog_narrow, links),
@@ -18,30 +18,33 @@ LIMIT = 32
 AW_BYTE = 1 << 28
 
 
-def _vm_cs(monkeypatch, narrow=True, limit=LIMIT):
+def _ask(monkeypatch, narrow=True):
+    """the narrow store is a decision of zk_cs_set_batch (ZKGL_NARROW_STORE=1); every loop scope that can use it carries the layout"""
     if narrow:
         monkeypatch.setenv("ZKGL_NARROW_STORE", "1")
     else:
         monkeypatch.delenv("ZKGL_NARROW_STORE", raising=False)
-    return vp.vm_cs(limit)
 
 
 # ------------------------------------------------------------------------------------------------ host
 def test_main_vm_narrow_layout_meets_the_byte_budget(monkeypatch):
-    cs = _vm_cs(monkeypatch)
+    cs = vp.vm_cs(LIMIT)
     st = cs.stats()
     assert st["store_bytes_per_lane_loop"] == 8 * st["cells_written_loop"]
     assert 0 < st["narrow_store_bytes_per_lane_loop"] <= 0.80 * st["store_bytes_per_lane_loop"], st      # VERDICT r5 item 4: <= 0.80 x
     assert st["narrow_store_bytes_per_lane_loop"] == 8 * (st["cells_written_loop"] - st["narrow_byte_values_loop"]) + st["narrow_byte_values_loop"]
     assert st["narrow_byte_values_loop"] <= st["values_below_2_32_loop"]
     assert st["narrow_store_active"] == 0          # a batch decides (zk_cs_set_batch)
-    plain = _vm_cs(monkeypatch, narrow=False)
-    assert plain.stats()["narrow_store_bytes_per_lane_loop"] == 0     # not asked for: no layout, nothing changes
+    monkeypatch.setenv("ZKGL_NARROW_STORE", "0")   # at finalize: no layout at all
+    cs0 = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), 1 << 22, 1 << 28)
+    cs0.configure_main_vm(vp.defs()[0])
+    cs0.main_vm_entry_point(4)
+    cs0.pad_and_shrink()
+    assert cs0.stats()["narrow_store_bytes_per_lane_loop"] == 0 and cs0.narrow_byte_input_words() == []
 
 
 def test_circuits_without_a_plain_loop_kernel_get_no_narrow_layout(monkeypatch):
     """hash circuits run their loop scope in strand form with macro-ops that stream their own outputs: the layout is not offered"""
-    monkeypatch.setenv("ZKGL_NARROW_STORE", "1")
     cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
     cs.configure_keccak()
     cs.keccak256_round_function_entry_point(2)
@@ -58,17 +61,8 @@ def test_circuits_without_a_plain_loop_kernel_get_no_narrow_layout(monkeypatch):
 # ------------------------------------------------------------------------------------------------ device
 @pytest.fixture(scope="module")
 def vm_batch():
-    import os
-    old = os.environ.get("ZKGL_NARROW_STORE")
-    os.environ["ZKGL_NARROW_STORE"] = "1"
-    try:
-        d, D = vp.defs()
-        cs = vp.vm_cs(LIMIT)
-    finally:
-        if old is None:
-            os.environ.pop("ZKGL_NARROW_STORE", None)
-        else:
-            os.environ["ZKGL_NARROW_STORE"] = old
+    d, D = vp.defs()
+    cs = vp.vm_cs(LIMIT)
     outer, loop, commits, info = vp.mixed_batch(cs, D, LIMIT, 64)
     return cs, D, outer, loop, commits, info
 
@@ -87,6 +81,7 @@ def test_main_vm_over_the_narrow_store_equals_the_oracle(zk, vm_batch, monkeypat
     cs, D, outer, loop, commits, info = vm_batch
     B = outer.shape[1]
     monkeypatch.setenv("ZKGL_STRANDS", "0")          # the plain loop kernel (what a full batch takes): the narrow store's kernel
+    _ask(monkeypatch)
     if tile_log2:
         monkeypatch.setenv("ZKGL_STORE_TILE_LOG2", tile_log2)
     cs.set_batch(B)
@@ -138,10 +133,10 @@ def test_narrow_store_failures_are_the_ordinary_stores(zk, vm_batch, monkeypatch
     assert w in byte_words, "the range-checked oracle flag is expected in a one-byte slot"
     bad_b = loop.copy()
     bad_b[w, 5 * LIMIT + 3] += 256          # & 0xff it is the boolean the circuit wants: only the overflow test can object
-    plain = _vm_cs(monkeypatch, narrow=False)
-    assert plain.narrow_byte_input_words() == []
     reports = {}
-    for mode, c in (("narrow", cs), ("ordinary", plain)):
+    c = cs
+    for mode in ("narrow", "ordinary"):
+        _ask(monkeypatch, mode == "narrow")
         c.set_batch(B)
         assert c.stats()["narrow_store_active"] == (1 if mode == "narrow" else 0)
         for name, bad in (("carried", bad_a), ("byte", bad_b)):
@@ -166,6 +161,7 @@ def test_narrow_store_with_deferred_poseidon2_intermediates(zk, vm_batch, monkey
     B = 16
     o, l = outer[:, :B].copy(), loop[:, :B * LIMIT].copy()
     monkeypatch.setenv("ZKGL_STRANDS", "0")
+    _ask(monkeypatch)
     cs.set_batch(B)
     cs.set_check_mode(False, defer_p2=True)
     try:

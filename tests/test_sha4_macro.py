@@ -1,9 +1,10 @@
 """a16 on the fast path: the SHA-256 compression over the REFERENCE's table set (Maj4 / TriXor4 / Ch4 / Split4BitChunk<1,2>,
-/root/reference/src/code_unpacker_sha256/mod.rs:554-566) as a macro-op — ZK_OP_SHA256_ROUNDS with a = 1, opt-in at record time
-(ZKGL_SHA4_MACRO=1).  One structure (csrc/sha256_macro4.hpp) is walked by the host gadget, the device op and the counting backend; the
+/root/reference/src/code_unpacker_sha256/mod.rs:554-566) as a macro-op — ZK_OP_SHA256_ROUNDS with a = 1, the default recording of
+configure_sha256(reference_tables=True) since round 6 (ZKGL_SHA4_MACRO=0 records op by op).  One structure (csrc/sha256_macro4.hpp) is walked by the host gadget, the device op and the counting backend; the
 oracle restates it in C.  The macro recording must be THE SAME circuit as the op-by-op recording — same variables, gates, cells — and
 the oracle's restatement must write the same value into every cell; digests equal hashlib.  The device backend is host-compilable and
-is walked on the CPU against the recorded gates' arithmetic.  Device parity under -m gpu in a library built with -DZKGL_SHA4_KERNEL."""
+is walked on the CPU against the recorded gates' arithmetic.  Device parity under -m gpu: tests/test_sha256_reference_tables.py, tests/test_zz_round5_gpu.py
+(its kernels: k_witness_strands2<.., X_SHA4> / k_witness_plain_x<X_SHA4>, in the one library)."""
 import hashlib
 import os
 import subprocess
@@ -21,9 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def record(monkeypatch, macro, entry="blocks", n=2):
     if macro:
-        monkeypatch.setenv("ZKGL_SHA4_MACRO", "1")
+        monkeypatch.delenv("ZKGL_SHA4_MACRO", raising=False)   # the default recording since round 6
     else:
-        monkeypatch.delenv("ZKGL_SHA4_MACRO", raising=False)
+        monkeypatch.setenv("ZKGL_SHA4_MACRO", "0")             # op by op
     cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
     cs.configure_sha256(reference_tables=True)
     {"blocks": cs.sha256_blocks_entry_point, "fsm": cs.sha256_round_function_entry_point, "unpacker": cs.unpack_code_into_memory_entry_point}[entry](n)

@@ -172,21 +172,16 @@ def test_cone_with_gated_permutations_is_verified_not_assumed(zk, monkeypatch):
         assert ok, f
 
 
-# ---- opt-in device backends
+# ---- macro-op backends with kernels of their own
 def test_bytebuf_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
-    """whole trace of the macro recording, plain and strand kernels, both check modes; seeding through the native FSM seeder.
-    The op's device backend is NOT part of the default library (never measured: it stays out of the product binary, kernels_engine2.hpp): there
-    the device must refuse the recording loudly; a library built with ZKGL_DEFS=-DZKGL_BYTEBUF_KERNEL (ZKGL_LIB=..., tools/ab_r5.sh) runs it."""
+    """whole trace of the macro recording (ZKGL_BYTEBUF_MACRO=1 at record time), plain and strand kernels, both check modes; seeding through the native
+    FSM seeder.  Since round 6 the op's device backend is in the one library, in kernels of its own (k_witness_strands2<.., X_BYTEBUF>, k_witness_plain_x<X_BYTEBUF>)."""
     import zkgl
     import test_bytebuf_macro as BB
     from test_keccak_fsm_host import REFERENCE_CASES, TABLE_ROWS, reference_case, streams
     from oracle import keccak_native as N
     cs = BB.record(monkeypatch, True)
-    if not zkgl.build_features() & zkgl.BUILD_BYTEBUF_KERNEL:
-        with pytest.raises(zkgl.ZkError) as e:
-            cs.set_batch(4)
-        assert "ZKGL_BYTEBUF_KERNEL" in str(e.value)
-        return
+    assert zkgl.build_features() & zkgl.BUILD_BYTEBUF_KERNEL
     insts = [reference_case(l, u)[1] for l, u in REFERENCE_CASES] * 8        # 72 instances x 2 cycles: a few wavefronts
     outer, loop = streams(insts, 2)
     r = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
@@ -216,17 +211,13 @@ def test_bytebuf_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
 
 
 def test_sha4_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
-    """whole trace of the macro recording against the oracle interpreter, both check modes; adversarial inputs rejected in both.  The op's device
-    backend is not part of the default library (never measured): there the device must refuse the recording loudly."""
+    """whole trace of the macro recording (the default recording of the reference's table set since round 6) against the oracle interpreter, both check
+    modes; adversarial inputs rejected in both.  Its kernels: k_witness_strands2<.., X_SHA4>, k_witness_plain_x<X_SHA4>."""
     import test_sha4_macro as S4
     from test_sha256_host import loop_stream
     REF_TABLE_ROWS = S4.REF_TABLE_ROWS
     cs = S4.record(monkeypatch, True)
-    if not zkgl.build_features() & zkgl.BUILD_SHA4_KERNEL:
-        with pytest.raises(zkgl.ZkError) as e:
-            cs.set_batch(4)
-        assert "ZKGL_SHA4_KERNEL" in str(e.value)
-        return
+    assert zkgl.build_features() & zkgl.BUILD_SHA4_KERNEL
     rng = np.random.default_rng(45)
     msgs = [bytes(rng.integers(0, 256, size=int(n), dtype=np.uint8)) for n in rng.integers(56, 120, size=70)]
     outer = np.zeros((0, len(msgs)), dtype=np.uint64)

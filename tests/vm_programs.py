@@ -24,8 +24,7 @@ _CS = {}
 
 
 def vm_cs(limit, max_trace_len=1 << 22):
-    import os
-    key = (limit, os.environ.get("ZKGL_NARROW_STORE") == "1")   # (a finalize-time switch: its own recording)
+    key = limit
     if key not in _CS:
         cs = zkgl.ConstraintSystem(zkgl.CSGeometry(140, 0, 8, 8), max_trace_len, 1 << 28)  # reference_vm_geometry, cycle.rs:959-966
         cs.configure_main_vm(defs()[0])
