@@ -149,6 +149,8 @@ void CS::free_scope_device(Scope& s) {
     if (s.d_prog2n) hipFree(s.d_prog2n);
     if (s.d_cprog_fused_n) hipFree(s.d_cprog_fused_n);
     if (s.d_slot_aw) hipFree(s.d_slot_aw);
+    if (s.d_aw1) hipFree(s.d_aw1);
+    s.d_aw1 = nullptr;
     s.d_store_n = nullptr; s.d_prog2n = nullptr; s.d_cprog_fused_n = nullptr; s.d_slot_aw = nullptr;
     if (s.d_cells) hipFree(s.d_cells);
     s.d_prog = nullptr; s.d_prog2 = nullptr; s.d_cprog = nullptr; s.d_cchunks = nullptr; s.d_cprog_full = nullptr; s.d_cchunks_full = nullptr; s.d_cmacros = nullptr; s.d_mult_sites = nullptr; s.d_consts = nullptr; s.d_rows = nullptr; s.d_rowconsts = nullptr; s.d_lrows = nullptr;
@@ -3507,9 +3509,9 @@ void CS::ensure_p2_filled(void* stream) {
 }
 
 uint64_t CS::read_var(zk_var v, uint32_t instance, uint32_t iteration) {
-    ensure_p2_filled(nullptr);
     if (batch_ == 0) throw ZkError(ZK_ERR_INVALID, "read_var before set_batch");
     Scope& s = scope_of(v);
+    if (s.is_loop || !compact_) ensure_p2_filled(nullptr);   // (only the loop scope's store can be incomplete: deferred intermediates, a pending narrow store)
     if (var_index(v) >= s.n_vars || instance >= batch_) throw ZkError(ZK_ERR_INVALID, "read_var: out of range");
     uint64_t lane = instance;
     if (s.is_loop) {
@@ -3640,6 +3642,7 @@ void CS::stats(zk_stats* o) const {
     o->narrow_byte_values_loop = loop_.narrow_ok ? loop_.narrow_byte_values : 0;
     o->narrow_store_active = narrow_active_ ? 1 : 0;
     o->narrow_steps = narrow_steps_; o->narrow_repeats = narrow_repeats_;
+    o->narrow_store_pending = narrow_pending_ ? 1 : 0;
 }
 
 float CS::last_ms(int which) const {
@@ -3702,6 +3705,12 @@ void CS::ensure_trace_view() {
             for (auto& pr : s->mat_pairs)
                 if (pr.cell < s->n_trace_cells) t[pr.cell] = pr.home + 1;
             s->d_slot1 = upload(t);
+            if (s->narrow_ok && !s->d_aw1) {   // the same view over the narrow store: address word + 1
+                std::vector<uint32_t> ta(s->n_trace_cells, 0);
+                for (auto& pr : s->mat_pairs)
+                    if (pr.cell < s->n_trace_cells) ta[pr.cell] = s->slot_aw[pr.home] + 1;
+                s->d_aw1 = upload(ta);
+            }
         }
 }
 
@@ -3710,7 +3719,10 @@ void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint6
     // a compact batch stays compact: one instance's columns are read through the trace view (cell -> slot), the whole batch's trace
     // (4x the store) is never allocated for this
     if (compact_) ensure_trace_view();
-    ensure_p2_filled(stream);
+    // the last fused step wrote the narrow store and left nothing out: the columns are read from it directly (k_trace_columns_batch decodes address
+    // words), the ordinary store is not expanded for them.  With deferred Poseidon2 intermediates the fill needs the ordinary store: widen, fill, read that.
+    const bool from_narrow = compact_ && narrow_pending_ && !p2_pending_ && limit_ && loop_.d_aw1;
+    if (!from_narrow) ensure_p2_filled(stream);
     if (n_instances == 0) return;
     if (instance >= batch_ || n_instances > batch_ - instance) throw ZkError(ZK_ERR_INVALID, "trace_columns: instance out of range");
     const uint64_t rows = (uint64_t)loop_.n_slots * limit_ + outer_.n_slots;
@@ -3720,6 +3732,7 @@ void CS::trace_columns(uint32_t instance, uint64_t* d_out, uint32_t log_n, uint6
     if (compact_) {
         a.loop_cells = loop_.d_store; a.loop_n_cells = loop_.store_geom(); a.outer_cells = outer_.d_store; a.outer_n_cells = outer_.store_geom();
         a.loop_slot1 = loop_.d_slot1; a.outer_slot1 = outer_.d_slot1;
+        if (from_narrow) { a.loop_cells = loop_.d_store_n; a.loop_n_cells = loop_.narrow_geom(); a.loop_slot1 = loop_.d_aw1; }
     } else {
         a.loop_cells = loop_.d_cells; a.loop_n_cells = loop_.n_cells; a.outer_cells = outer_.d_cells; a.outer_n_cells = outer_.n_cells;
     }

@@ -177,6 +177,7 @@ struct Scope {
     uint32_t* d_prog2n = nullptr;
     uint32_t* d_cprog_fused_n = nullptr;
     uint32_t* d_slot_aw = nullptr;
+    uint32_t* d_aw1 = nullptr;           // trace cell -> address word + 1 of the variable placed there (trace_columns straight from the narrow store)
     uint64_t* d_store_n = nullptr;       // the narrow store of the bound batch (set_batch), nullptr when the batch does not use it
     uint64_t narrow_geom() const {
         const uint64_t n8 = ((uint64_t)narrow_units + 7) / 8;   // the tile in 8-byte slots: allocation and tile addressing as for an ordinary store

@@ -203,12 +203,19 @@ struct ColumnsDev {
 __device__ __forceinline__ size_t tiled(uint64_t n_cells, uint32_t cell, uint32_t lane) {
     return zkgeom::offset(n_cells, cell, lane);  // n_cells = the geometry word of the store
 }
+// a value of a NARROW store (store_geom.hpp: the geometry word carries zkgeom::NARROW, the view holds address words + 1)
+__device__ __forceinline__ uint64_t narrow_value(const uint64_t* __restrict__ cells, uint64_t geom, uint32_t aw, uint32_t lane) {
+    const uint8_t* __restrict__ p = reinterpret_cast<const uint8_t*>(cells) + zkgeom::narrow_byte_offset(geom, aw, lane);
+    return (aw & zkgeom::AW_BYTE) ? (uint64_t)*p : *reinterpret_cast<const uint64_t*>(p);
+}
 // Batch form (round 4): a block owns one 64-lane TILE of the store (lanes = consecutive iterations, possibly of two neighbouring
 // instances), 64 consecutive slots (trace rows of an iteration) and one column.  Reads are whole 512 B values of the tile (aligned:
 // the block never straddles two tiles, which the per-instance form did whenever instance * limit was not a multiple of 64), writes
 // are 512 B runs of a column (64 consecutive rows of one iteration).  Block order = tile-major, then slot group, then column, dealt to
 // the XCDs in contiguous runs (blockIdx % 8 = XCD): the blocks in flight work on one or two tiles of the store, so the 2.1 other
 // cells a variable occupies on average are found in L2 / the memory-side cache instead of being fetched from HBM again.
+// Round 6: the loop store may be the NARROW store of the last fused step (the view then holds address words + 1): the columns are read from the
+// one-byte / eight-byte slots directly, no widened copy of the store is made for them.
 __global__ __launch_bounds__(256) void k_trace_columns_batch(ColumnsDev d, uint32_t first_tile, uint32_t n_tiles, uint32_t slot_groups, uint64_t instance_stride,
                                                              uint32_t first_instance, uint32_t n_instances) {
     __shared__ uint64_t tile[64][65];
@@ -231,13 +238,15 @@ __global__ __launch_bounds__(256) void k_trace_columns_batch(ColumnsDev d, uint3
             my_s1 = d.loop_slot1 ? d.loop_slot1[cell] : cell + 1;
         }
     }
-    const uint64_t* __restrict__ src = d.loop_cells + tiled(d.loop_n_cells, 0, lane);   // slot 0 of this lane; slot s is s << tile_log2 further
+    const uint64_t* __restrict__ src = d.loop_cells + tiled(d.loop_n_cells & ~zkgeom::NARROW, 0, lane);   // slot 0 of this lane; slot s is s << tile_log2 further (ordinary store)
     const uint32_t tsh = zkgeom::tile_log2(d.loop_n_cells);
+    const bool nar = zkgeom::narrow(d.loop_n_cells);   // uniform
     uint64_t v[16];
 #pragma unroll
     for (uint32_t i = 0; i < 16; ++i) {
         const uint32_t s1 = __builtin_amdgcn_readlane(my_s1, w + 4 * i);   // wave-uniform
-        v[i] = s1 ? src[(size_t)(s1 - 1) << tsh] : 0;
+        if (nar) v[i] = s1 ? narrow_value(d.loop_cells, d.loop_n_cells, s1 - 1, lane) : 0;
+        else v[i] = s1 ? src[(size_t)(s1 - 1) << tsh] : 0;
     }
 #pragma unroll
     for (uint32_t i = 0; i < 16; ++i) tile[w + 4 * i][tx] = v[i];

@@ -73,7 +73,7 @@ class _Stats(C.Structure):
                 ("values_below_2_32_outer", C.c_uint64), ("values_below_2_32_loop", C.c_uint64),
                 ("seed_cone_unsupported", C.c_uint64),
                 ("store_bytes_per_lane_loop", C.c_uint64), ("narrow_store_bytes_per_lane_loop", C.c_uint64), ("narrow_byte_values_loop", C.c_uint64),
-                ("narrow_store_active", C.c_uint64), ("narrow_steps", C.c_uint64), ("narrow_repeats", C.c_uint64)]
+                ("narrow_store_active", C.c_uint64), ("narrow_steps", C.c_uint64), ("narrow_repeats", C.c_uint64), ("narrow_store_pending", C.c_uint64)]
 
 
 _lib = None
@@ -89,12 +89,6 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(_LIB_PATH)
         _lib.zk_last_error.restype = C.c_char_p
     return _lib
-
-
-def emulated_device() -> bool:
-    """True when ZKGL_LIB names the test suite's emulated-device build of the library (tests/emu/README.md): the -m gpu tests then run the device
-    SOURCE on host fibers.  The product library never answers True."""
-    return hasattr(lib(), "zk_emu_divergent_wave_sites")
 
 
 _testlib = None

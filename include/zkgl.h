@@ -323,6 +323,7 @@ typedef struct zk_stats {
      *                                       something was reported (a violated relation, or a value that does not fit its slot): verdicts and
      *                                       reported gates are always those of the ordinary store */
     uint64_t store_bytes_per_lane_loop, narrow_store_bytes_per_lane_loop, narrow_byte_values_loop, narrow_store_active, narrow_steps, narrow_repeats;
+    uint64_t narrow_store_pending;   /* 1: the last step's values are in the narrow store only (zk_cs_trace_columns* read them there; any other reader expands them first) */
 } zk_stats;
 /* K12 — copy-permutation grand product over the resolved trace (SURVEY 8f-3 "copy-permutation grand product z(X)"; boojum's
  * column chunking and cell identifiers are [EXT], the argument is defined in csrc/kernels_perm.hpp).  Labels: outer-scope

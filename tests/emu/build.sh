@@ -1,6 +1,6 @@
 #!/bin/bash
-# tests/emu/build.sh [variant [defs]] — build the LANE HARNESS (tests/emu/README.md) against libzkgl.so, or against a variant library built by
-# tools/variants_r5.sh with the SAME compile-time switches:   tests/emu/build.sh binv -DZKGL_BATCH_INV
+# tests/emu/build.sh [variant [defs]] — build the LANE HARNESS (tests/emu/README.md) against libzkgl.so (or against a side-by-side library libzkgl_<variant>.so
+# built with the SAME compile-time switches, e.g. an elimination-probe build)
 # -> tests/emu/_gen/libzkgl_emu[_<variant>].so     (host clang of the ROCm toolchain: the device headers use ext_vector_type)
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd)

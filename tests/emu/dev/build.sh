@@ -2,7 +2,7 @@
 # tests/emu/dev/build.sh [defs...] — build the product for the EMULATED DEVICE (tests/emu/README.md): every source of era-zkevm_circuits_amd/csrc,
 # re-written by gen_dev.py, compiled as host C++ over tests/emu/dev/hip/hip_runtime.h, linked with the fiber scheduler (emu_rt.cpp).
 #   -> tests/emu/_gen/dev/libzkgl.so (+ libzkgl_testcircuits.so beside it): load it with ZKGL_LIB=<that path>.  TEST INFRASTRUCTURE.
-# EMU_VARIANT=<name> with defs (e.g. EMU_VARIANT=p2m_binv build.sh -DZKGL_P2_MERGE -DZKGL_BATCH_INV): an opt-in build of tools/variants_r5.sh -> tests/emu/_gen/dev_<name>/
+# EMU_VARIANT=<name> with defs (e.g. EMU_VARIANT=probe build.sh -DZKGL_EXPERIMENT=2): the device source with extra defines -> tests/emu/_gen/dev_<name>/
 # EMU_TSAN=1: the data-race detector build (emu_rt.cpp: every work-item a ThreadSanitizer fiber) -> tests/emu/_gen/dev_tsan/; run under
 #   LD_PRELOAD=/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so  (tools/emulated_race_check.sh)
 # EMU_ASAN=1: the address-sanitizer build (out-of-bounds / use-after-free in kernels: device buffers, LDS, local arrays) -> tests/emu/_gen/dev_asan/;

@@ -13,7 +13,7 @@ _libs = {}
 
 
 def lib(variant: str = "", defs=()):
-    """build (once per process) and load libzkgl_emu[_variant].so; `variant` names a library of tools/variants_r5.sh loaded through ZKGL_LIB"""
+    """build (once per process) and load libzkgl_emu[_variant].so; `variant` names a side-by-side library loaded through ZKGL_LIB"""
     key = variant
     if key not in _libs:
         if not os.environ.get("EMU_NO_BUILD"):

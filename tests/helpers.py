@@ -170,3 +170,10 @@ def load_storage_fixture():
     unsorted = [conv(d) for d in f["unsorted"]]
     sorted_records = [(conv(d), int(d["record_timestamp"])) for d in f["sorted"]]
     return unsorted, sorted_records, f["limit"]
+
+
+def emulated_device() -> bool:
+    """True when ZKGL_LIB names the test suite's emulated-device build of the library (tests/emu/README.md): the -m gpu tests then run the device
+    SOURCE on host fibers.  Test infrastructure: the product library has no such symbol and the product package does not ask."""
+    import zkgl
+    return hasattr(zkgl.lib(), "zk_emu_divergent_wave_sites")

@@ -108,7 +108,7 @@ def test_gpu_z_equals_oracle_and_detects_broken_copies(zk):
 @pytest.mark.gpu
 def test_gpu_grand_product_closes_on_the_vm_cycle(zk):
     """main_vm-shaped cycle (BASELINE config C2 at a short limit): 183 carried words per iteration, broadcast imports, lookups"""
-    if zk.emulated_device():
+    if __import__("helpers").emulated_device():
         pytest.skip("device memory of this test is a torch CUDA tensor: needs the hardware")
     import torch
     from vm_shaped_fixture import build_vm_cs, vm_inputs

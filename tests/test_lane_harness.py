@@ -1,7 +1,7 @@
 """The lane harness (tests/emu/README.md): the product's witness-interpreter SOURCE (csrc/kernels_engine2.hpp run_tile2 and the macro-op backends, cut
 out unchanged) compiled for the host and run one lane at a time on the device programs of recorded circuits; every trace cell, the public inputs
-and the fused-mode failure flag against the oracle interpreter.  Plain and strand forms; the default library and every opt-in library of
-tools/variants_r5.sh (each with the harness built with the same switches) — the device paths round 5 could not run on a GPU.
+and the fused-mode failure flag against the oracle interpreter.  Plain and strand forms of every circuit kind, the macro-op backends that have kernels of
+their own (the 4-bit SHA compression, the ByteBuffer fill) through the same instantiations CS::launch_phase launches.
 TEST INFRASTRUCTURE: it shows op semantics, program decoding, store addressing and the strand level structure, not wavefront behaviour;
 the -m gpu tests remain the parity gate."""
 import json

@@ -5,7 +5,7 @@ They live in ONE file that sorts last: the driver runs `pytest -x`, and a surpri
   * who evaluates a gate on a macro-op's output (tests/test_macro_ownership.py): forged / honest outside gates, adversarial inputs, both modes
   * C3 keccak, C3 sha256 (2^20 rows) and C5 (8 blobs x 4096 chunks) under check_if_satisfied's semantics (every relation from the stored values)
   * the seeding cone with gated witness-only permutations (tests/test_seed_program.py)
-  * opt-in device backends: refused loudly by the default library, whole-trace parity in a library built for them (tools/ab_r5.sh)
+  * macro-op backends with kernels of their own (round 6: in the one library): whole-trace parity (was: tools/ab_r5.sh)
   * bench.py end to end on a small configuration, one rank and two"""
 import hashlib
 import json
@@ -262,7 +262,7 @@ def run_bench(*args, timeout=600):
 
 def _needs_hardware(zk):
     # bench.py times a GPU through torch; on the emulated device of tests/emu (ZKGL_LIB = tests/emu/_gen/dev/libzkgl.so) there is nothing to time
-    if zk.emulated_device():
+    if __import__("helpers").emulated_device():
         pytest.skip("bench.py needs the hardware: nothing to time on the emulated device")
 
 

@@ -1,4 +1,7 @@
-"""The NARROW STORE of a loop scope (csrc/store_geom.hpp, cs.cpp build_narrow_layout; opt-in per batch: ZKGL_NARROW_STORE=1 at zk_cs_set_batch).
+"""(Sorts last, like tests/test_zz_round5_gpu.py: the driver runs `pytest -x`, and a surprise in code no device has run must not hide the established parity
+evidence behind the first failure.)
+
+The NARROW STORE of a loop scope (csrc/store_geom.hpp, cs.cpp build_narrow_layout; opt-in per batch: ZKGL_NARROW_STORE=1 at zk_cs_set_batch).
 
 CS::bound_values proves, from the constraints alone, which values are bytes in EVERY satisfying witness (main_vm: 5 103 of a cycle's 17 700);
 the narrow layout keeps them in one-byte slots of the store the fused step writes and reads (k_witness_loop_narrow, k_check_prog_narrow, links),
@@ -180,26 +183,51 @@ def test_narrow_store_with_deferred_poseidon2_intermediates(zk, vm_batch, monkey
 
 @pytest.mark.gpu
 def test_ram_permutation_over_the_narrow_store(zk, monkeypatch):
-    """a queue circuit (two Poseidon2 chains per item, LOOP_LAST values in the outer post phase): k_widen_last feeds the outer scope"""
+    """a queue circuit (two Poseidon2 chains per item, LOOP_LAST values in the outer post phase): k_widen_last feeds the outer scope; the witness
+    COLUMNS of the batch are read straight from the narrow store (k_trace_columns_batch decodes address words: no widened copy is made for them)"""
+    from helpers import random_instances
     from oracle import ram_native as rn
     monkeypatch.setenv("ZKGL_NARROW_STORE", "1")
     monkeypatch.setenv("ZKGL_STRANDS", "0")
-    limit = 8
+    limit = 70                      # an instance's lanes straddle the 64-lane tiles
     cs = zkgl.ConstraintSystem(zkgl.CSGeometry(100, 0, 8, 4))
     cs.configure_ram_permutation()
     cs.ram_permutation_entry_point(limit)
     cs.pad_and_shrink()
-    from helpers import random_instances
-    insts = random_instances(11, 70, 6, limit)
+    insts = random_instances(11, 9, 40, limit)
     insts[3] = rn.instance([], [], limit, 0)                      # empty queue
     outer, loop = rn.pack_streams(insts, limit)
     cs.set_batch(len(insts))
     assert cs.stats()["narrow_store_active"] == 1
-    _bind(zk, cs, outer, loop)
+    keep = _bind(zk, cs, outer, loop)
     ok, f = cs.resolve_and_check()
     assert ok, f
     for i, inst in enumerate(insts):
         assert cs.public_inputs(i) == inst["commitment"]
+    # ---- columns of instances 1..3 while the values are in the narrow store only
+    st = cs.stats()
+    assert st["narrow_store_pending"] == 1
+    n_cols = st["copy_columns"] + st["lookup_columns"]
+    S, So, rows = st["loop_slots"], st["outer_slots"], st["rows_per_instance"]
+    log_n = int(rows - 1).bit_length()
+    stride = (1 << log_n) + 8
+    istride = n_cols * stride
+    outb = zk.DeviceBuffer(3 * istride)
+    outb.zero()
+    cs.trace_columns_batch(1, 3, outb, log_n, n_cols, stride, istride)
+    zk.sync()
+    assert cs.stats()["narrow_store_pending"] == 1, "reading the columns expanded the narrow store"
+    got = outb.to_numpy().reshape(3, n_cols, stride)
+    # ---- every cell against the oracle (the trace readers below DO expand the store: the ordinary one is what they address)
     run = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), 65536)
     run.resolve(outer, loop)
-    assert np.array_equal(cs.trace(True), run.lc) and np.array_equal(cs.trace(False), run.oc)
+    tl, to = cs.trace(True), cs.trace(False)
+    assert cs.stats()["narrow_store_pending"] == 0
+    assert np.array_equal(tl, run.lc) and np.array_equal(to, run.oc)
+    for k, inst in enumerate((1, 2, 3)):
+        want = np.zeros((n_cols, stride), dtype=np.uint64)
+        for c in range(n_cols):
+            want[c, :limit * S] = tl[c::n_cols][:S, inst * limit:(inst + 1) * limit].T.reshape(-1)
+            want[c, limit * S: rows] = to[c::n_cols][:So, inst]
+        assert np.array_equal(got[k], want), inst
+    del keep

@@ -5,7 +5,7 @@ OUT=gpurun_out/r6b_ab.txt; : > $OUT
 line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$1', r['kernel'], 'loop_ms', round(r['avg_launch_ms'],2), 'clock', round(r['shader_clock_mhz']), 'step_ms', round(d['ms_per_step'],2), 'value', round(d['value']/1e9,1), 'G frac', round(r['frac'],3), 'bytes/cycle', r.get('bytes_written_per_cycle'), 'checksum', d['commitment_checksum'])"; }
 ab() { timeout 400 python bench.py --headline-only --steps 5 --warmup 2 --fixture $1 $2 2>gpurun_out/r6b_err.txt | line "[$1 ${2:-ordinary}]" | tee -a $OUT; }
 # ---- (1) parity first (the same tests the suite of call A ran; a red one stops the A/B)
-timeout 900 python -m pytest tests/test_narrow_store.py -m "gpu or not gpu" -x -q -p no:cacheprovider > gpurun_out/r6b_parity.log 2>&1; tail -2 gpurun_out/r6b_parity.log | tee -a $OUT
+timeout 900 python -m pytest tests/test_zz_round6_narrow_store.py -m "gpu or not gpu" -x -q -p no:cacheprovider > gpurun_out/r6b_parity.log 2>&1; tail -2 gpurun_out/r6b_parity.log | tee -a $OUT
 grep -q " passed" gpurun_out/r6b_parity.log && ! grep -q "failed" gpurun_out/r6b_parity.log || { echo "narrow-store parity is not green: no A/B" | tee -a $OUT; exit 1; }
 # ---- (2) k_witness_loop vs k_witness_loop_narrow, both fixtures, alternating, twice
 for rep in 1 2; do for fx in default realistic; do ab $fx ""; ab $fx "--narrow-store"; done; done
