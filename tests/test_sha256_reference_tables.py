@@ -107,9 +107,10 @@ def test_code_unpacker_reference_fixture_with_the_reference_tables():
     assert r.check()[0] > 0
 
 
-@pytest.mark.gpu
-def test_gpu_equals_oracle_with_the_reference_tables(zk):
-    """the device's trace of both circuits == the oracle interpreter's, cell for cell; fused and stored verdicts"""
+def gpu_equals_oracle_with_the_reference_tables(zk):
+    """the device's trace of both circuits == the oracle interpreter's, cell for cell; fused and stored verdicts.
+    Run as a test from tests/test_zz_round5_gpu.py (round 6): since the macro-op became the default recording of this table set, this is a device path no
+    device has run, and such tests sort last so that `pytest -x` cannot hide the established parity evidence behind them."""
     msgs = [b"abc", b"", bytes(range(55))]
     cs = sha_cs4(1)
     outer = np.zeros((0, len(msgs)), dtype=np.uint64)

@@ -250,6 +250,12 @@ def test_sha4_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
     cs.set_check_mode(False)
 
 
+def test_gpu_equals_oracle_with_the_reference_tables(zk):
+    """tests/test_sha256_reference_tables.py's device half (sha256 blocks + the code_unpacker reference fixture under the reference's width-4 tables)"""
+    from test_sha256_reference_tables import gpu_equals_oracle_with_the_reference_tables
+    gpu_equals_oracle_with_the_reference_tables(zk)
+
+
 # ---- bench.py end to end
 def run_bench(*args, timeout=600):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
