@@ -695,9 +695,11 @@ def main():
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         valu_busy, valu_src = None, None
-        for name in ("pmc_r5.json", "pmc_r4.json", "pmc_r3.json", "pmc_r2.json"):
+        for name in ("pmc_r6n.json" if headline_narrow else "pmc_r6.json", "pmc_r5.json", "pmc_r4.json", "pmc_r3.json", "pmc_r2.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if headline_narrow != pmc.get("kernel", "").endswith("_narrow"):
+                    continue     # a ratio measured on the other store's kernel says nothing about this one
                 traffic = pmc["traffic_over_algorithmic"] * algo_bytes
                 traffic_src = f"profiles/{name} ratio {pmc['traffic_over_algorithmic']:.3f} measured at batch {pmc['batch']}"
                 vi = pmc.get("valu_issue") or {}

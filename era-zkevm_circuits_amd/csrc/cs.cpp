@@ -3050,6 +3050,7 @@ void CS::launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uin
         // the generic sequential interpreter is the round-1 (v1) form, which has no handler for the macro-ops: their circuits seed
         // through the native seeders / the cone (whose hints replace the macro-ops)
         if (uses_lookup_macros_) throw ZkError(ZK_ERR_INVALID, "generic sequential seeding (ZKGL_SEED_GENERIC) does not run circuits recorded with hash macro-ops; record with ZKGL_NO_HASH_MACROS=1 or use the cone / native seeder");
+        if (!la.cells) throw ZkError(ZK_ERR_CAPACITY, "generic sequential seeding works in the ordinary loop store, which does not fit beside the narrow one at this batch size");   // (narrow batches: set_batch allocates both when they fit)
         dev_check(zkdev::launch_witness_seq(la, (const zkdev::CarryArgs*)d_carries_, (uint32_t)carries_store_.size(), dev_loop_inputs_rw,
                                             n, st));
     }
@@ -3496,6 +3497,7 @@ void CS::ensure_wide_store() {
 }
 
 void CS::ensure_p2_filled(void* stream) {
+    if (narrow_active_) ensure_wide_store();   // every reader that comes through here addresses the ordinary store: it exists from here on (ZK_ERR_CAPACITY if it cannot)
     if (narrow_pending_) {   // the last step wrote the narrow store: expand it into the ordinary store every other reader addresses
         ensure_wide_store();
         dev_check(zkdev::launch_widen_store(loop_.d_store_n, loop_.narrow_geom(), loop_.d_store, loop_.store_geom(), loop_.n_lanes, loop_.d_slot_aw, loop_.n_store, stream));

@@ -12,16 +12,15 @@ for rep in 1 2; do for fx in default realistic; do ab $fx ""; ab $fx "--narrow-s
 # ---- (3) the full line with mode_narrow_store (plain + deferred on top) and the widening cost
 timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-feed > gpurun_out/r6b_bench_modes.json 2> gpurun_out/r6b_bench_modes.err
 python -c "import json; d=json.loads(open('gpurun_out/r6b_bench_modes.json').read().strip().splitlines()[-1]); print(json.dumps(d.get('mode_narrow_store'), indent=1)); print('deferred', json.dumps(d.get('mode_p2_intermediates_deferred'), indent=1))" | tee -a $OUT
-# ---- (4) bytes actually moved by the narrow kernel: WRITE_SIZE / FETCH_SIZE / VALU passes of a --narrow-store run
-export PMC_CMD="python $PWD/bench.py --batch 384 --seed-windows 2 --steps 2 --warmup 0 --no-cpu-baseline --headline-only --narrow-store"
-tools/pmc_pass.sh r6n_fetch FETCH_SIZE > /dev/null; tools/pmc_pass.sh r6n_write WRITE_SIZE > /dev/null
-tools/pmc_pass.sh r6n_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE > /dev/null
-tools/pmc_pass.sh r6n_salu SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS > /dev/null
-unset PMC_CMD
+# ---- (4) the narrow kernel's own profile: kernel trace + FETCH / WRITE / SQ passes + the driver's bench command line, all with --narrow-store
+#          -> r6n_kernel_trace.md, pmc_r6n_*.txt, r6n_bench.json, pmc_r6n.json (tools/pmc_json.py for zke::k_witness_loop_narrow)
+TAG=r6n EXTRA_BENCH_ARGS=--narrow-store BENCH_ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline" KT_STEPS=5 timeout 1500 bash tools/profile_tag.sh > gpurun_out/r6n_profile.log 2>&1; tail -6 gpurun_out/r6n_profile.log | tee -a $OUT
 grep -h "k_witness_loop_narrow \|k_check_prog_narrow " gpurun_out/pmc_r6n_*.txt | tee -a $OUT
 # ---- (5) read-counter calibration in this kernel's access patterns (tools/rprobe.hip)
 hipcc --offload-arch=gfx950 -O3 tools/rprobe.hip -o gpurun_out/rprobe 2>/dev/null && gpurun_out/rprobe > gpurun_out/rprobe.json && cat gpurun_out/rprobe.json | tee -a $OUT
 PMC_CMD="$PWD/gpurun_out/rprobe" tools/pmc_pass.sh rprobe FETCH_SIZE | tee -a $OUT
+python tools/pmc_json.py r6n zke::k_witness_loop_narrow > gpurun_out/pmc_r6n.json 2> gpurun_out/pmc_json_r6n.err || tail -2 gpurun_out/pmc_json_r6n.err
+[ -f gpurun_out/r6_bench.json ] && python tools/pmc_json.py r6 > gpurun_out/pmc_r6.json 2>/dev/null   # (again, now with the measured FETCH_SIZE factor beside the guide's)
 # ---- (6) elimination probes of both kernels (tools/probe_variants.sh in the container built libzkgl_var_{S,L,SL,ALLV}.so): what binds the narrow kernel?
 for t in S L SL ALLV; do
   lib=$PWD/era-zkevm_circuits_amd/libzkgl_var_$t.so; [ -f $lib ] || continue

@@ -61,8 +61,8 @@ try:
     cal = {}
     for line in open(G + "pmc_rprobe.txt"):
         f = line.split()
-        if len(f) > 2 and f[1] == "FETCH_SIZE":
-            k = f[0].replace("void ", "")
+        if "FETCH_SIZE" in f:
+            k = "".join(f[:f.index("FETCH_SIZE")]).replace("void", "")   # ("void k_read<0>" for a templated kernel)
             m = re.search(r"mean=([0-9.e+]+)", line)
             for name, d in probe.items():
                 if name.replace(" ", "") in k.replace(" ", ""):
