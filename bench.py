@@ -798,13 +798,13 @@ def main():
                 "commitments_equal_native_restatement": deferred["commitments_equal"]},
             "mode_narrow_store": None if narrow is None else narrow if "error" in narrow else {
                 "what": "ZKGL_NARROW_STORE=1 at zk_cs_set_batch (csrc/store_geom.hpp): the values the constraints bound below 2^8 in every satisfying witness live in one-byte "
-                        "slots of the store the fused step writes and reads (k_witness_loop_narrow, k_check_prog_narrow, links); same steps from the raw witness (seeding pass, "
+                        "slots of the store the fused step writes and reads (k_witness_loop_narrow, k_check_prog_t<true>, links); same steps from the raw witness (seeding pass, "
                         "fused check, gather).  Every reader outside the step gets the ordinary store through k_widen_store (complete_store_ms_per_batch).  p2_deferred: "
                         "ZK_CHECK_FUSED_DEFER_P2 on top (its complete_store = widening + k_fill_p2)",
                 "bytes_written_per_cycle": st["narrow_store_bytes_per_lane_loop"], "bytes_written_per_cycle_ordinary_store": st["store_bytes_per_lane_loop"],
                 "bytes_ratio": st["narrow_store_bytes_per_lane_loop"] / st["store_bytes_per_lane_loop"], "byte_values_per_cycle": st["narrow_byte_values_loop"],
                 **{label: {"value": st["constraints_per_instance"] * B * args.steps / r["elapsed"], "unit": "constraints/s (this rank's GPU)",
-                           "ms_per_step": 1e3 * r["elapsed"] / args.steps, "k_witness_loop_narrow_ms": r["loop_ms"], "k_check_prog_narrow_ms": r["gate_ms"],
+                           "ms_per_step": 1e3 * r["elapsed"] / args.steps, "k_witness_loop_narrow_ms": r["loop_ms"], "k_check_prog_t_true_ms": r["gate_ms"],
                            "algorithmic_bytes_per_launch": B * st["limit"] * (st["narrow_store_bytes_per_lane_loop"] - (950 * p2_per_cycle * 8 if label == "p2_deferred" else 0) + n_loop * 8),
                            "achieved_GBps": B * st["limit"] * (st["narrow_store_bytes_per_lane_loop"] - (950 * p2_per_cycle * 8 if label == "p2_deferred" else 0) + n_loop * 8) / (r["loop_ms"] * 1e-3) / 1e9,
                            "values_per_s_vs_ordinary_store_kernel": k_ms / r["loop_ms"],

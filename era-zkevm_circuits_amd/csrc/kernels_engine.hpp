@@ -1153,7 +1153,9 @@ __global__ __launch_bounds__(TPB) void k_check_copies(const uint64_t* __restrict
 
 // copy constraints across iterations / scopes (the hidden_fsm chain of the reference:
 // /root/reference/src/ram_permutation/mod.rs:119-143,178-196)
-__global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict__ loop_cells, uint64_t loop_n_cells,
+// (NARROW: the loop store is a narrow store and the link table holds address words for the loop-scope endpoints; a template, so that <false> stays the kernel a device measured)
+template <bool NARROW>
+__global__ __launch_bounds__(TPB) void k_check_links_t(const uint64_t* __restrict__ loop_cells, uint64_t loop_n_cells,
                                                      uint32_t n_lanes, uint32_t limit,
                                                      const uint64_t* __restrict__ outer_cells, uint64_t outer_n_cells,
                                                      const zk_link* __restrict__ links, uint32_t n_links,
@@ -1164,11 +1166,14 @@ __global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict_
     for (uint32_t i = 0; i < n_links; ++i) {
         const zk_link L = links[i];
         const uint32_t kind = uni(L.kind);
-        uint64_t mine = load_value(loop_cells, loop_n_cells, uni(L.loop_cell), lane);   // (a narrow loop store: the link table holds address words)
+        uint64_t mine;
+        if constexpr (NARROW) mine = load_value(loop_cells, loop_n_cells, uni(L.loop_cell), lane);
+        else mine = loop_cells[cell_off(loop_n_cells, uni(L.loop_cell), lane)];
         const uint32_t other = uni(L.other_cell);   // (read where the wavefront is whole: the k > 0 test below splits it)
         bool ok = true;
         if (kind == ZK_LINK_CARRY) {
-            if (k > 0) ok = mine == load_value(loop_cells, loop_n_cells, other, lane - 1);
+            if constexpr (NARROW) { if (k > 0) ok = mine == load_value(loop_cells, loop_n_cells, other, lane - 1); }
+            else { if (k > 0) ok = mine == loop_cells[cell_off(loop_n_cells, other, lane - 1)]; }
         } else {
             uint64_t o = outer_cells[cell_off(outer_n_cells, other, inst)];
             if (kind == ZK_LINK_FIRST) ok = (k != 0) || mine == o;
@@ -1180,7 +1185,8 @@ __global__ __launch_bounds__(TPB) void k_check_links(const uint64_t* __restrict_
 }
 
 // Stream links (include/zkgl_ir.h): thread == (instance, global index k); both copies of element k must agree.
-__global__ __launch_bounds__(TPB) void k_check_stream(const uint64_t* __restrict__ loop_cells, uint64_t loop_n_cells,
+template <bool NARROW>
+__global__ __launch_bounds__(TPB) void k_check_stream_t(const uint64_t* __restrict__ loop_cells, uint64_t loop_n_cells,
                                                       uint32_t n_instances, uint32_t limit, const uint32_t* __restrict__ a_cells,
                                                       uint32_t pa, const uint32_t* __restrict__ b_cells, uint32_t pb,
                                                       uint32_t n_total, uint32_t stream_index, unsigned long long* fail) {
@@ -1188,8 +1194,14 @@ __global__ __launch_bounds__(TPB) void k_check_stream(const uint64_t* __restrict
     if (t >= (uint64_t)n_instances * n_total) return;
     const uint32_t inst = (uint32_t)(t / n_total), k = (uint32_t)(t % n_total);
     const uint32_t lane_a = inst * limit + k / pa, lane_b = inst * limit + k / pb;
-    const uint64_t va = load_value(loop_cells, loop_n_cells, a_cells[k % pa], lane_a);
-    const uint64_t vb = load_value(loop_cells, loop_n_cells, b_cells[k % pb], lane_b);
+    uint64_t va, vb;
+    if constexpr (NARROW) {
+        va = load_value(loop_cells, loop_n_cells, a_cells[k % pa], lane_a);
+        vb = load_value(loop_cells, loop_n_cells, b_cells[k % pb], lane_b);
+    } else {
+        va = loop_cells[cell_off(loop_n_cells, a_cells[k % pa], lane_a)];
+        vb = loop_cells[cell_off(loop_n_cells, b_cells[k % pb], lane_b)];
+    }
     if (va != vb) atomicMin(fail + 2, ((unsigned long long)lane_a << 32) | 0x80000000u | stream_index);
 }
 

@@ -773,7 +773,7 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }
             if constexpr (STRANDS) out_to(prog[pc + 97]);
             pc += 97 + D;
-            if constexpr (!(XMACROS & X_SHA4)) { if (pa == 1) return; }   // (the 4-bit table set runs on the kernels made for it: the host launches those)
+            // (pa = 1, the reference's 4-bit table set, runs on the kernels instantiated with X_SHA4: the host launches those — zkdev::launch_witness*)
             if constexpr (!WIDE && !probe::NO_STORES) {
                 const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
                 if constexpr ((XMACROS & X_SHA4) != 0) {
@@ -818,59 +818,6 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             }
             }
             fused_bad |= not_bytes;
-        } else { return; } break;
-        case ZK_OP_BYTEBUF_FILL: if constexpr (WITH_BIGINT && (XMACROS & X_BYTEBUF) != 0) {
-            // K8: one ByteBuffer fill as ONE op.  [192 buffer bytes, filled, 32 input bytes, offset, meaningful] -> every intermediate, in the
-            // gadget's allocation order (both walk zkb::fill_with_bytes).  The op works on small integers: an operand outside its range
-            // (byte > 255, filled > 192, offset > 31, meaningful > 32 — each of them is range-checked by the circuit) is reported as the
-            // fused mode's failure, and the values stored for it then violate the op's own gates.
-            uint32_t packed[zkb::BUF / 4 + zkb::IN / 4];   // buffer bytes, then input bytes, four per word (passed to the out-of-line walk)
-            int32_t sc3[3] = {0, 0, 0};
-            bool out_of_range = false;
-#pragma unroll 1
-            for (uint32_t c8 = 0; c8 < (zkb::N_INPUTS + 7) / 8; ++c8) {   // eight operand loads in flight per step
-                uint64_t v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = c8 * 8 + k < (uint32_t)zkb::N_INPUTS ? ldv(prog[pc + 1 + c8 * 8 + k]) : 0;
-                // operand i: [0, 192) buffer bytes, 192 filled, [193, 225) input bytes, 225 offset, 226 meaningful; eight per step, so the
-                // words of `packed` are whole steps except around `filled` (step 24 holds filled + 7 input bytes, ...): assemble by position
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t i = c8 * 8 + k;
-                    if (i < (uint32_t)zkb::BUF) { out_of_range |= v[k] > 0xff; packed[i >> 2] = (k & 3) ? packed[i >> 2] | (((uint32_t)v[k] & 0xffu) << (8 * (i & 3))) : ((uint32_t)v[k] & 0xffu); }
-                    else if (i == (uint32_t)zkb::BUF) { out_of_range |= v[k] > (uint64_t)zkb::BUF; sc3[0] = (int32_t)(v[k] & 0xff); }
-                    else if (i < (uint32_t)(zkb::BUF + 1 + zkb::IN)) {
-                        const uint32_t m = i - zkb::BUF - 1;
-                        out_of_range |= v[k] > 0xff;
-                        packed[zkb::BUF / 4 + (m >> 2)] = (m & 3) ? packed[zkb::BUF / 4 + (m >> 2)] | (((uint32_t)v[k] & 0xffu) << (8 * (m & 3))) : ((uint32_t)v[k] & 0xffu);
-                    }
-                    else if (i == (uint32_t)(zkb::BUF + 1 + zkb::IN)) { out_of_range |= v[k] > 31; sc3[1] = (int32_t)(v[k] & 31); }
-                    else if (i == (uint32_t)(zkb::BUF + 2 + zkb::IN)) { out_of_range |= v[k] > 32; sc3[2] = (int32_t)(v[k] & 63); }
-                }
-            }
-            if constexpr (STRANDS) out_to(prog[pc + 1 + zkb::N_INPUTS]);
-            pc += 1 + zkb::N_INPUTS + D;
-            if constexpr (!WIDE) {
-                const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
-                dst = bytebuf_fill_stream(rsrc, lane_byte, dst, bstep, packed, sc3[0], sc3[1], sc3[2], STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
-            } else {
-                auto st1 = [&](uint64_t v) { st(v); };
-                struct EmitAll {
-                    decltype(st1)& f;
-                    __device__ __forceinline__ void one(uint64_t v) { f(v); }
-                } emit{st1};
-                BytebufInv inv;
-                zkb::ComputeBackend<EmitAll, BytebufInv> be(emit, inv);
-#pragma unroll
-                for (int k = 0; k < zkb::BUF / 4; ++k) be.bytes_[k] = packed[k];
-#pragma unroll
-                for (int k = 0; k < zkb::IN / 4; ++k) be.in_[k] = be.sh_[k] = packed[zkb::BUF / 4 + k];
-#pragma unroll
-                for (int k = 0; k < zkb::BUF / 32; ++k) be.pl_[k] = 0;
-                int32_t f = sc3[0];
-                zkb::fill_with_bytes(be, f, sc3[1], sc3[2]);
-            }
-            fused_bad |= out_of_range;
         } else { return; } break;
         case ZK_OP_KECCAK_F: if constexpr (WITH_BIGINT) {
             // K8: a whole Keccak-f[1600] as ONE op.  [200 state byte slots] -> every intermediate of the byte-table decomposition, in the
@@ -1038,6 +985,64 @@ __device__ __forceinline__ void run_tile2(const ScopeDev& sc, const uint32_t lan
             __syncthreads();
         } else { return; } break;
         default:
+            // ZK_OP_BYTEBUF_FILL exists only in the kernels instantiated with X_BYTEBUF (a `case` of its own would change the jump table — and with it the code —
+            // of every other instantiation: tools/isa_diff.py keeps the measured kernels instruction-identical)
+            if constexpr (WITH_BIGINT && (XMACROS & X_BYTEBUF) != 0) {
+                if (op == ZK_OP_BYTEBUF_FILL) {
+            // K8: one ByteBuffer fill as ONE op.  [192 buffer bytes, filled, 32 input bytes, offset, meaningful] -> every intermediate, in the
+            // gadget's allocation order (both walk zkb::fill_with_bytes).  The op works on small integers: an operand outside its range
+            // (byte > 255, filled > 192, offset > 31, meaningful > 32 — each of them is range-checked by the circuit) is reported as the
+            // fused mode's failure, and the values stored for it then violate the op's own gates.
+            uint32_t packed[zkb::BUF / 4 + zkb::IN / 4];   // buffer bytes, then input bytes, four per word (passed to the out-of-line walk)
+            int32_t sc3[3] = {0, 0, 0};
+            bool out_of_range = false;
+#pragma unroll 1
+            for (uint32_t c8 = 0; c8 < (zkb::N_INPUTS + 7) / 8; ++c8) {   // eight operand loads in flight per step
+                uint64_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = c8 * 8 + k < (uint32_t)zkb::N_INPUTS ? ldv(prog[pc + 1 + c8 * 8 + k]) : 0;
+                // operand i: [0, 192) buffer bytes, 192 filled, [193, 225) input bytes, 225 offset, 226 meaningful; eight per step, so the
+                // words of `packed` are whole steps except around `filled` (step 24 holds filled + 7 input bytes, ...): assemble by position
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t i = c8 * 8 + k;
+                    if (i < (uint32_t)zkb::BUF) { out_of_range |= v[k] > 0xff; packed[i >> 2] = (k & 3) ? packed[i >> 2] | (((uint32_t)v[k] & 0xffu) << (8 * (i & 3))) : ((uint32_t)v[k] & 0xffu); }
+                    else if (i == (uint32_t)zkb::BUF) { out_of_range |= v[k] > (uint64_t)zkb::BUF; sc3[0] = (int32_t)(v[k] & 0xff); }
+                    else if (i < (uint32_t)(zkb::BUF + 1 + zkb::IN)) {
+                        const uint32_t m = i - zkb::BUF - 1;
+                        out_of_range |= v[k] > 0xff;
+                        packed[zkb::BUF / 4 + (m >> 2)] = (m & 3) ? packed[zkb::BUF / 4 + (m >> 2)] | (((uint32_t)v[k] & 0xffu) << (8 * (m & 3))) : ((uint32_t)v[k] & 0xffu);
+                    }
+                    else if (i == (uint32_t)(zkb::BUF + 1 + zkb::IN)) { out_of_range |= v[k] > 31; sc3[1] = (int32_t)(v[k] & 31); }
+                    else if (i == (uint32_t)(zkb::BUF + 2 + zkb::IN)) { out_of_range |= v[k] > 32; sc3[2] = (int32_t)(v[k] & 63); }
+                }
+            }
+            if constexpr (STRANDS) out_to(prog[pc + 1 + zkb::N_INPUTS]);
+            pc += 1 + zkb::N_INPUTS + D;
+            if constexpr (!WIDE) {
+                const uint32_t n_sh = STRANDS ? (uint32_t)(blockDim.x >> 6) : 1u;
+                dst = bytebuf_fill_stream(rsrc, lane_byte, dst, bstep, packed, sc3[0], sc3[1], sc3[2], STRANDS ? uni(threadIdx.x >> 6) : 0u, n_sh - 1);
+            } else {
+                auto st1 = [&](uint64_t v) { st(v); };
+                struct EmitAll {
+                    decltype(st1)& f;
+                    __device__ __forceinline__ void one(uint64_t v) { f(v); }
+                } emit{st1};
+                BytebufInv inv;
+                zkb::ComputeBackend<EmitAll, BytebufInv> be(emit, inv);
+#pragma unroll
+                for (int k = 0; k < zkb::BUF / 4; ++k) be.bytes_[k] = packed[k];
+#pragma unroll
+                for (int k = 0; k < zkb::IN / 4; ++k) be.in_[k] = be.sh_[k] = packed[zkb::BUF / 4 + k];
+#pragma unroll
+                for (int k = 0; k < zkb::BUF / 32; ++k) be.pl_[k] = 0;
+                int32_t f = sc3[0];
+                zkb::fill_with_bytes(be, f, sc3[1], sc3[2]);
+            }
+            fused_bad |= out_of_range;
+                            break;
+                }
+            }
             return;  // malformed program: host validates before upload
         }
     }
@@ -1436,7 +1441,7 @@ __device__ __forceinline__ void dispatch_count(uint32_t n, F&& f) {
 #endif
 // NARROW: cd.cells is a narrow store (store_geom.hpp) and the packets carry address words (cs.cpp build_narrow_layout) — same packets, same relations
 template <bool NARROW>
-__device__ __forceinline__ void check_prog_body(const CheckProgDev& cd) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_WAVES, 8))) void k_check_prog_t(CheckProgDev cd) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     uint32_t lane = blockIdx.x * TPB + threadIdx.x;
     if ((blockIdx.x * TPB + (threadIdx.x & ~63u)) >= cd.n_lanes) return;
@@ -1670,8 +1675,8 @@ __device__ __forceinline__ void check_prog_body(const CheckProgDev& cd) {
         }
     }
 }
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_WAVES, 8))) void k_check_prog(CheckProgDev cd) { check_prog_body<false>(cd); }
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(ZKGL_CHECK_WAVES, 8))) void k_check_prog_narrow(CheckProgDev cd) { check_prog_body<true>(cd); }
+// (one kernel template, not a body function called from two kernels: wrapped, the same source got another register allocation — 125 VGPRs for 123 — which
+//  tools/isa_diff.py showed; k_check_prog_t<false> is instruction for instruction the k_check_prog a device has measured)
 
 // narrow store -> ordinary store (store_geom.hpp; CS::ensure_p2_filled): every reader outside the fused step sees 8-byte slots.  aw[slot] = address
 // word of the slot's value.  A block = 256 lanes x one chunk of slots: reads 64 B or 512 B per wavefront and value, writes 512 B.

@@ -216,7 +216,8 @@ __device__ __forceinline__ uint64_t narrow_value(const uint64_t* __restrict__ ce
 // cells a variable occupies on average are found in L2 / the memory-side cache instead of being fetched from HBM again.
 // Round 6: the loop store may be the NARROW store of the last fused step (the view then holds address words + 1): the columns are read from the
 // one-byte / eight-byte slots directly, no widened copy of the store is made for them.
-__global__ __launch_bounds__(256) void k_trace_columns_batch(ColumnsDev d, uint32_t first_tile, uint32_t n_tiles, uint32_t slot_groups, uint64_t instance_stride,
+template <bool NARROW>
+__global__ __launch_bounds__(256) void k_trace_columns_batch_t(ColumnsDev d, uint32_t first_tile, uint32_t n_tiles, uint32_t slot_groups, uint64_t instance_stride,
                                                              uint32_t first_instance, uint32_t n_instances) {
     __shared__ uint64_t tile[64][65];
     const uint32_t n_blocks = gridDim.x;
@@ -238,14 +239,13 @@ __global__ __launch_bounds__(256) void k_trace_columns_batch(ColumnsDev d, uint3
             my_s1 = d.loop_slot1 ? d.loop_slot1[cell] : cell + 1;
         }
     }
-    const uint64_t* __restrict__ src = d.loop_cells + tiled(d.loop_n_cells & ~zkgeom::NARROW, 0, lane);   // slot 0 of this lane; slot s is s << tile_log2 further (ordinary store)
+    const uint64_t* __restrict__ src = d.loop_cells + tiled(d.loop_n_cells, 0, lane);   // slot 0 of this lane; slot s is s << tile_log2 further
     const uint32_t tsh = zkgeom::tile_log2(d.loop_n_cells);
-    const bool nar = zkgeom::narrow(d.loop_n_cells);   // uniform
     uint64_t v[16];
 #pragma unroll
     for (uint32_t i = 0; i < 16; ++i) {
         const uint32_t s1 = __builtin_amdgcn_readlane(my_s1, w + 4 * i);   // wave-uniform
-        if (nar) v[i] = s1 ? narrow_value(d.loop_cells, d.loop_n_cells, s1 - 1, lane) : 0;
+        if constexpr (NARROW) v[i] = s1 ? narrow_value(d.loop_cells, d.loop_n_cells, s1 - 1, lane) : 0;
         else v[i] = s1 ? src[(size_t)(s1 - 1) << tsh] : 0;
     }
 #pragma unroll

@@ -213,8 +213,8 @@ int launch_check_gates(const CheckArgs& a, void* stream) {
         const uint32_t wanted = std::max<uint32_t>(2, (2048 + lane_tiles - 1) / lane_tiles);  // >= ~2048 workgroups
         p.chunks_per_block = std::max<uint32_t>(1, a.n_chunks / wanted);
         dim3 grid(lane_tiles, (a.n_chunks + p.chunks_per_block - 1) / p.chunks_per_block);
-        if (zkgeom::narrow(a.n_cells)) zke::k_check_prog_narrow<<<grid, zke::TPB, lds_pad("ZKGL_CHECK_LDS_PAD"), (hipStream_t)stream>>>(p);
-        else zke::k_check_prog<<<grid, zke::TPB, lds_pad("ZKGL_CHECK_LDS_PAD"), (hipStream_t)stream>>>(p);
+        if (zkgeom::narrow(a.n_cells)) zke::k_check_prog_t<true><<<grid, zke::TPB, lds_pad("ZKGL_CHECK_LDS_PAD"), (hipStream_t)stream>>>(p);
+        else zke::k_check_prog_t<false><<<grid, zke::TPB, lds_pad("ZKGL_CHECK_LDS_PAD"), (hipStream_t)stream>>>(p);
         if (a.macros && a.n_macros) {
             if (zkgeom::narrow(a.n_cells)) { g_hip_err = "launch_check_gates: Poseidon2 macro packets over a narrow store"; return -1; }
             zke::CheckP2Dev m;
@@ -402,7 +402,8 @@ int launch_trace_columns(const ColumnsArgs& a, void* stream) {
             const uint32_t nt = std::min(tiles_per_launch, n_tiles - t0);
             const uint64_t w = (uint64_t)nt * slot_groups * a.n_cols;
             const uint32_t blocks = (uint32_t)((w + 7) / 8 * 8);
-            zkn::k_trace_columns_batch<<<blocks, 256, 0, (hipStream_t)stream>>>(d, first_tile + t0, nt, slot_groups, a.instance_stride, a.instance, a.n_instances);
+            if (zkgeom::narrow(a.loop_n_cells)) zkn::k_trace_columns_batch_t<true><<<blocks, 256, 0, (hipStream_t)stream>>>(d, first_tile + t0, nt, slot_groups, a.instance_stride, a.instance, a.n_instances);
+            else zkn::k_trace_columns_batch_t<false><<<blocks, 256, 0, (hipStream_t)stream>>>(d, first_tile + t0, nt, slot_groups, a.instance_stride, a.instance, a.n_instances);
             if (int rc = LAUNCH_CHECK("k_trace_columns_batch")) return rc;
         }
     }
@@ -697,8 +698,12 @@ int launch_check_stream(const uint64_t* loop_cells, uint64_t loop_n_cells, uint3
                         const uint32_t* a_cells, uint32_t pa, const uint32_t* b_cells, uint32_t pb, uint32_t n_total,
                         uint32_t stream_index, unsigned long long* fail, void* stream) {
     if (!n_instances || !n_total) return 0;
-    zke::k_check_stream<<<grid_for((size_t)n_instances * n_total, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(
-        loop_cells, loop_n_cells, n_instances, limit, a_cells, pa, b_cells, pb, n_total, stream_index, fail);
+    if (zkgeom::narrow(loop_n_cells))
+        zke::k_check_stream_t<true><<<grid_for((size_t)n_instances * n_total, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(
+            loop_cells, loop_n_cells, n_instances, limit, a_cells, pa, b_cells, pb, n_total, stream_index, fail);
+    else
+        zke::k_check_stream_t<false><<<grid_for((size_t)n_instances * n_total, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(
+            loop_cells, loop_n_cells, n_instances, limit, a_cells, pa, b_cells, pb, n_total, stream_index, fail);
     return LAUNCH_CHECK("k_check_stream");
 }
 
@@ -706,8 +711,12 @@ int launch_check_links(const uint64_t* loop_cells, uint64_t loop_n_cells, uint32
                        const uint64_t* outer_cells, uint64_t outer_n_cells, const zk_link* links, uint32_t n_links,
                        unsigned long long* fail, void* stream) {
     if (n_lanes == 0 || n_links == 0) return 0;
-    zke::k_check_links<<<grid_for(n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(
-        loop_cells, loop_n_cells, n_lanes, limit, outer_cells, outer_n_cells, links, n_links, fail);
+    if (zkgeom::narrow(loop_n_cells))
+        zke::k_check_links_t<true><<<grid_for(n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(
+            loop_cells, loop_n_cells, n_lanes, limit, outer_cells, outer_n_cells, links, n_links, fail);
+    else
+        zke::k_check_links_t<false><<<grid_for(n_lanes, zke::TPB), zke::TPB, 0, (hipStream_t)stream>>>(
+            loop_cells, loop_n_cells, n_lanes, limit, outer_cells, outer_n_cells, links, n_links, fail);
     return LAUNCH_CHECK("k_check_links");
 }
 

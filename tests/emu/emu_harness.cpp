@@ -221,7 +221,7 @@ extern "C" int zk_emu_check(zk_cs* h, int mode, unsigned long long* fail_out) {
             emu::bdim = {(unsigned)zke::TPB, 1, 1};
             for (uint32_t lane = 0; lane < lanes; ++lane) {
                 emu::bid = {lane / zke::TPB, 0, 0}; emu::tid = {lane % zke::TPB, 0, 0};
-                if (chunks.back() > chunks.front()) zke::k_check_prog(cd);
+                if (chunks.back() > chunks.front()) zke::k_check_prog_t<false>(cd);
             }
             if (mode == 1 && !s.cmacros.empty()) {
                 std::vector<uint32_t> mm(s.cmacros);
@@ -246,14 +246,14 @@ extern "C" int zk_emu_check(zk_cs* h, int mode, unsigned long long* fail_out) {
             emu::bdim = {(unsigned)zke::TPB, 1, 1};
             for (uint32_t lane = 0; lane < lanes; ++lane) {
                 emu::bid = {lane / zke::TPB, 0, 0}; emu::tid = {lane % zke::TPB, 0, 0};
-                zke::k_check_links(r.store[1].data(), r.geom[1], lanes, r.limit, r.store[0].data(), r.geom[0], cs.links_store_.data(), (uint32_t)cs.links_store_.size(), f + 3);
+                zke::k_check_links_t<false>(r.store[1].data(), r.geom[1], lanes, r.limit, r.store[0].data(), r.geom[0], cs.links_store_.data(), (uint32_t)cs.links_store_.size(), f + 3);
             }
             for (size_t i = 0; i < cs.streams_store_.size(); ++i) {
                 const auto& sr = cs.streams_store_[i];
                 const uint64_t n = (uint64_t)r.batch * sr.n_total;
                 for (uint64_t t = 0; t < n; ++t) {
                     emu::bid = {(unsigned)(t / zke::TPB), 0, 0}; emu::tid = {(unsigned)(t % zke::TPB), 0, 0};
-                    zke::k_check_stream(r.store[1].data(), r.geom[1], r.batch, r.limit, sr.a.data(), (uint32_t)sr.a.size(), sr.b.data(), (uint32_t)sr.b.size(), sr.n_total, (uint32_t)i, f + 3);
+                    zke::k_check_stream_t<false>(r.store[1].data(), r.geom[1], r.batch, r.limit, sr.a.data(), (uint32_t)sr.a.size(), sr.b.data(), (uint32_t)sr.b.size(), sr.n_total, (uint32_t)i, f + 3);
                 }
             }
         }

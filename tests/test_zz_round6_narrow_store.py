@@ -4,7 +4,7 @@ evidence behind the first failure.)
 The NARROW STORE of a loop scope (csrc/store_geom.hpp, cs.cpp build_narrow_layout; opt-in per batch: ZKGL_NARROW_STORE=1 at zk_cs_set_batch).
 
 CS::bound_values proves, from the constraints alone, which values are bytes in EVERY satisfying witness (main_vm: 5 103 of a cycle's 17 700);
-the narrow layout keeps them in one-byte slots of the store the fused step writes and reads (k_witness_loop_narrow, k_check_prog_narrow, links),
+the narrow layout keeps them in one-byte slots of the store the fused step writes and reads (k_witness_loop_narrow, k_check_prog_t<true>, links),
 every other reader sees the ordinary store k_widen_store expands it into.  Checked here:
   host (no GPU): the layout exists, is a prefix sum of the classes, only narrow-capable ops own byte slots, the written bytes fall to <= 0.80 x;
   -m gpu: main_vm over the narrow store == the oracle, cell for cell, for the whole trace (through the widening), same commitments and

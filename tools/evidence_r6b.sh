@@ -15,7 +15,7 @@ python -c "import json; d=json.loads(open('gpurun_out/r6b_bench_modes.json').rea
 # ---- (4) the narrow kernel's own profile: kernel trace + FETCH / WRITE / SQ passes + the driver's bench command line, all with --narrow-store
 #          -> r6n_kernel_trace.md, pmc_r6n_*.txt, r6n_bench.json, pmc_r6n.json (tools/pmc_json.py for zke::k_witness_loop_narrow)
 TAG=r6n EXTRA_BENCH_ARGS=--narrow-store BENCH_ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline" KT_STEPS=5 timeout 1500 bash tools/profile_tag.sh > gpurun_out/r6n_profile.log 2>&1; tail -6 gpurun_out/r6n_profile.log | tee -a $OUT
-grep -h "k_witness_loop_narrow \|k_check_prog_narrow " gpurun_out/pmc_r6n_*.txt | tee -a $OUT
+grep -h "k_witness_loop_narrow \|k_check_prog_t<true>" gpurun_out/pmc_r6n_*.txt | tee -a $OUT
 # ---- (5) read-counter calibration in this kernel's access patterns (tools/rprobe.hip)
 hipcc --offload-arch=gfx950 -O3 tools/rprobe.hip -o gpurun_out/rprobe 2>/dev/null && gpurun_out/rprobe > gpurun_out/rprobe.json && cat gpurun_out/rprobe.json | tee -a $OUT
 PMC_CMD="$PWD/gpurun_out/rprobe" tools/pmc_pass.sh rprobe FETCH_SIZE | tee -a $OUT
