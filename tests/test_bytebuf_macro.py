@@ -1,7 +1,7 @@
 """K8, third macro-op: ByteBuffer::fill_with_bytes as ZK_OP_BYTEBUF_FILL (opt-in at record time: ZKGL_BYTEBUF_MACRO=1).  The keccak256
 precompile FSM recorded with the macro-op must be THE SAME circuit as the op-by-op recording — same variables, same gates, same cells —
 and the oracle's restatement of the macro-op must write the same value into every cell (reference cases of
-/root/reference/src/keccak256_round_function/mod.rs:1096-1144, all nine in one batch).  Device parity under -m gpu."""
+/root/reference/src/keccak256_round_function/mod.rs:1096-1144, all ten in one batch).  Device parity under -m gpu."""
 import os
 
 import numpy as np

@@ -459,7 +459,7 @@ def test_sha256_round_function_fsm_gpu(zk):
 
 
 def test_keccak256_round_function_fsm_gpu(zk):
-    """a17 on the GPU: the nine reference cases (src/keccak256_round_function/mod.rs:1096-1144) plus multi-request
+    """a17 on the GPU: the ten reference cases (src/keccak256_round_function/mod.rs:1096-1144) plus multi-request
     instances, x8 to fill two wave tiles; carried words seeded on the device; trace bit-exact vs the oracle interpreter."""
     from oracle import keccak_native as kn
     from test_keccak_fsm_host import REFERENCE_CASES, TABLE_ROWS, fsm_cs, make_requests, reference_case, streams

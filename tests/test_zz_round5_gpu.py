@@ -182,7 +182,7 @@ def test_bytebuf_macro_recording_on_the_gpu_equals_the_oracle(zk, monkeypatch):
     from oracle import keccak_native as N
     cs = BB.record(monkeypatch, True)
     assert zkgl.build_features() & zkgl.BUILD_BYTEBUF_KERNEL
-    insts = [reference_case(l, u)[1] for l, u in REFERENCE_CASES] * 8        # 72 instances x 2 cycles: a few wavefronts
+    insts = [reference_case(l, u)[1] for l, u in REFERENCE_CASES] * 8        # 80 instances x 2 cycles: a few wavefronts
     outer, loop = streams(insts, 2)
     r = zko.CircuitRun(cs.export(False), cs.export(True), len(insts), TABLE_ROWS)
     r.resolve(outer, loop)
