@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="only the timed default-mode steps (profiler runs: every k_witness_loop launch of the process is then a default-mode launch); the secondary figures are null")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the host-fed figures (packing + H2D of every window overlapped with the steps)")
     ap.add_argument("--fixture", default="default", choices=sorted(FIXTURES), help="which synthetic executions main_vm replays (default: every opcode family every ~150 cycles)")
+    ap.add_argument("--with-narrow-store-mode", action="store_true", help="also measure the labelled mode `mode_narrow_store` (the same steps over the narrow store, then with the Poseidon2 "
+                    "intermediates deferred on top).  Off by default: its kernels have not run on a device yet, and a secondary figure must never be able to cost the line")
     ap.add_argument("--narrow-store", action="store_true", help="run the HEADLINE steps over the narrow store (ZKGL_NARROW_STORE=1 at zk_cs_set_batch: byte-class values in one-byte slots, "
                     "csrc/store_geom.hpp); without it the narrow store is a labelled mode beside `value` (mode_narrow_store)")
     args = ap.parse_args()
@@ -607,7 +609,7 @@ def main():
     # reads; every other reader gets the ordinary store through k_widen_store (timed here on its own).  Same steps from the raw witness
     # (seeding pass, fused check, gather), then the same with the Poseidon2 intermediates deferred on top (the two byte levers together).
     narrow = None
-    if not args.headline_only and not headline_narrow and not os.environ.get("ZKGL_STUB_RUN") and st["narrow_store_bytes_per_lane_loop"]:
+    if args.with_narrow_store_mode and not args.headline_only and not headline_narrow and not os.environ.get("ZKGL_STUB_RUN") and st["narrow_store_bytes_per_lane_loop"]:
         try:
             os.environ["ZKGL_NARROW_STORE"] = "1"
             cs.set_batch(B)

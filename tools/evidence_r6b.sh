@@ -10,7 +10,7 @@ grep -q " passed" gpurun_out/r6b_parity.log && ! grep -q "failed" gpurun_out/r6b
 # ---- (2) k_witness_loop vs k_witness_loop_narrow, both fixtures, alternating, twice
 for rep in 1 2; do for fx in default realistic; do ab $fx ""; ab $fx "--narrow-store"; done; done
 # ---- (3) the full line with mode_narrow_store (plain + deferred on top) and the widening cost
-timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-feed > gpurun_out/r6b_bench_modes.json 2> gpurun_out/r6b_bench_modes.err
+timeout 900 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-feed --with-narrow-store-mode > gpurun_out/r6b_bench_modes.json 2> gpurun_out/r6b_bench_modes.err
 python -c "import json; d=json.loads(open('gpurun_out/r6b_bench_modes.json').read().strip().splitlines()[-1]); print(json.dumps(d.get('mode_narrow_store'), indent=1)); print('deferred', json.dumps(d.get('mode_p2_intermediates_deferred'), indent=1))" | tee -a $OUT
 # ---- (4) the narrow kernel's own profile: kernel trace + FETCH / WRITE / SQ passes + the driver's bench command line, all with --narrow-store
 #          -> r6n_kernel_trace.md, pmc_r6n_*.txt, r6n_bench.json, pmc_r6n.json (tools/pmc_json.py for zke::k_witness_loop_narrow)
