@@ -5,7 +5,7 @@
 # garbage silently on the device — here it stops the run with both stacks.  Reports: $OUT/report.<pid>, pytest's output $OUT/pytest.log.
 set -uo pipefail
 cd "$(dirname "$0")/.."
-# an opt-in library: EMU_VARIANT=asan_p2m_binv DEFS="-DZKGL_P2_MERGE -DZKGL_BATCH_INV" tools/emulated_bounds_check.sh ...
+# extra defines (e.g. an elimination-probe build): EMU_VARIANT=asan_probe DEFS="-DZKGL_EXPERIMENT=2" tools/emulated_bounds_check.sh ...
 V=${EMU_VARIANT:-asan}
 EMU_ASAN=1 EMU_VARIANT=$V bash tests/emu/dev/build.sh ${DEFS:-} | tail -1 || exit 1
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)

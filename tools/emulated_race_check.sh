@@ -5,7 +5,7 @@
 # (default OUT=/tmp/emulated_race), pytest's output: $OUT/pytest.log; the last lines count the reports.  EMU_TSAN_MODE=grid: the second pass (races BETWEEN the workgroups of a launch; LDS exempt).  5-10x slower than the plain emulated device: pick the tests.
 set -uo pipefail
 cd "$(dirname "$0")/.."
-# an opt-in library under the detector: EMU_VARIANT=tsan_p2m_binv DEFS="-DZKGL_P2_MERGE -DZKGL_BATCH_INV" tools/emulated_race_check.sh ...
+# extra defines under the detector: EMU_VARIANT=tsan_probe DEFS="-DZKGL_EXPERIMENT=2" tools/emulated_race_check.sh ...
 V=${EMU_VARIANT:-tsan}
 EMU_TSAN=1 EMU_VARIANT=$V bash tests/emu/dev/build.sh ${DEFS:-} | tail -1 || exit 1
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | head -1)

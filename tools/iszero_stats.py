@@ -30,7 +30,7 @@ for name, path in bench.FIXTURES.items():
                  "commitments_equal_fixture": bool(expect is not None and [int(x) for x in r.public[0]] == [int(x) for x in expect[0]]),
                  "fused_failure": r.fused_failure, "seconds": round(time.time() - t, 1)}
 out["reading"] = ("gated permutations: a wavefront runs a witness-only permutation as soon as ONE of its 64 lanes (consecutive cycles, different opcodes) has its execute flag on; "
-                  "-DZKGL_P2_MERGE puts the mutually independent permutations of a dependency level under one header and runs one permutation per round (a round = every lane's next member that is on).  "
-                  "Zero-checks: a wavefront runs the 72-multiplication x^(p-2) chain for a zero-check as soon as ONE of its 64 lanes holds |x| >= 4096; -DZKGL_BATCH_INV replaces k such "
+                  "round 5's -DZKGL_P2_MERGE build (deleted unmeasured in round 6, recoverable from commit f8fecc7) put the mutually independent permutations of a dependency level under one header and runs one permutation per round (a round = every lane's next member that is on).  "
+                  "Zero-checks: a wavefront runs the 72-multiplication x^(p-2) chain for a zero-check as soon as ONE of its 64 lanes holds |x| >= 4096; round 5's -DZKGL_BATCH_INV build (same fate) replaced k such "
                   "chains by one chain + 3 k multiplications, eight at a time")
 print(json.dumps(out, indent=1))
