@@ -2699,6 +2699,8 @@ void CS::ensure_uploaded() {
         loop_last_slots_.clear();
         for (auto& op : outer_.ops)
             if (!op.seed_only && op.opcode == ZK_OP_LOOP_LAST && !op.ins.empty()) loop_last_slots_.push_back(loop_.var_slot[op.ins[0].idx]);
+        std::sort(loop_last_slots_.begin(), loop_last_slots_.end());   // (two ZK_OP_LOOP_LAST ops may read one variable: one thread per cell in k_widen_last —
+        loop_last_slots_.erase(std::unique(loop_last_slots_.begin(), loop_last_slots_.end()), loop_last_slots_.end());   //  the emulated race detector found the duplicate store)
         if (!loop_last_slots_.empty()) d_loop_last_slots_ = upload(loop_last_slots_);
     }
     if (loop_.narrow_ok) {   // the loop-scope endpoints as address words of the narrow store (outer-scope endpoints stay slots)
