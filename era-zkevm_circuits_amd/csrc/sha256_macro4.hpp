@@ -2,7 +2,7 @@
 // Split4BitChunk<1,2>, /root/reference/src/code_unpacker_sha256/mod.rs:554-566; round function surface
 // /root/reference/src/sha256_round_function/mod.rs:271-285), written once and walked by
 //   * the host gadget (circuits/sha256_gadget4.hpp S4): W = eight nibble variables + the packed word, every primitive records its lookups / gates;
-//   * the device macro-op ZK_OP_SHA256_ROUNDS with a = 1 (kernels_engine2.hpp, built with -DZKGL_SHA4_KERNEL): W = uint32, every primitive
+//   * the device macro-op ZK_OP_SHA256_ROUNDS with a = 1 (kernels_engine2.hpp: the kernels instantiated with X_SHA4): W = uint32, every primitive
 //     computes in registers and STREAMS OUT the same intermediates in the same order;
 //   * a counting backend (the number of outputs).
 // (the engine's 8-bit decomposition: sha256_macro.hpp.  The oracle restates this walk in plain C: oracle/zko_engine.c sh4_compress.)
