@@ -2047,6 +2047,42 @@ void CS::emit_scope(Scope& s) {
             for (size_t K : {16, 32, 64, 128})
                 fprintf(stderr, "   LRU model, %zu values per wavefront: %llu operand fetches; with the Poseidon2 intermediates streamed past the cache %llu\n", K,
                         (unsigned long long)lru_misses(K, false), (unsigned long long)lru_misses(K, true));
+            if (s.is_loop && !s.slot_aw.empty()) {
+                // the same model in BYTES, for the narrow store (store_geom.hpp): a wavefront's share of L2 is C bytes; a value occupies 512 B of it, or 64 B when it
+                // is byte-class in the narrow layout; a fetch costs the value's bytes.  SELECT flags read from the LDS planes are not fetches.  What the ratio of the
+                // two layouts predicts is how the kernel's FETCH_SIZE scales (profiles/r6_predictions.md).
+                const std::vector<uint32_t> planes = select_plane_vars(s);
+                auto lru_bytes = [&](uint64_t C, bool narrow) {
+                    std::vector<int64_t> last(s.n_vars, -1);
+                    int64_t stamp = 0; uint64_t fetched = 0;
+                    const size_t cap = 4 * (size_t)s.n_vars + 8 * s.ops.size() + 64;
+                    std::vector<int64_t> bit(cap + 1, 0);
+                    auto upd = [&](size_t i, int64_t d) { for (++i; i <= cap; i += i & (~i + 1)) bit[i] += d; };
+                    auto sum = [&](size_t i) { int64_t r = 0; for (++i; i > 0; i -= i & (~i + 1)) r += bit[i]; return r; };
+                    auto width = [&](uint32_t v) -> int64_t { return (narrow && (s.slot_aw[s.var_slot[v]] & zkgeom::AW_BYTE)) ? 64 : 512; };
+                    auto touch = [&](uint32_t v, bool read) {
+                        const int64_t w = width(v);
+                        if (read && (last[v] < 0 || (uint64_t)(sum((size_t)stamp) - sum((size_t)last[v])) >= C)) fetched += (uint64_t)w;
+                        if (last[v] >= 0) upd((size_t)last[v], -w);
+                        ++stamp; last[v] = stamp; upd((size_t)stamp, w);
+                    };
+                    for (auto& op : s.ops) {
+                        if (op.seed_only) continue;
+                        for (size_t q = 0; q < op.ins.size(); ++q) {
+                            if (op.ins[q].kind != Operand::VAR) continue;
+                            if (op.opcode == ZK_OP_SELECT && q == 0 && planes[op.ins[0].idx] != UINT32_MAX) continue;
+                            touch(op.ins[q].idx, true);
+                        }
+                        for (uint32_t ov : op.outs) touch(ov, false);
+                    }
+                    return fetched;
+                };
+                for (uint64_t C : {8192ull, 16384ull, 32768ull}) {
+                    const uint64_t a = lru_bytes(C, false), b = lru_bytes(C, true);
+                    fprintf(stderr, "   LRU model in bytes, %llu B of L2 per wavefront: operand bytes fetched per wavefront-cycle %llu (ordinary store) / %llu (narrow store) = %.3f\n",
+                            (unsigned long long)C, (unsigned long long)a, (unsigned long long)b, a ? (double)b / (double)a : 0.0);
+                }
+            }
         }
         fprintf(stderr, "   operand age (values produced since): <=8 %llu, <=32 %llu, <=128 %llu, <=512 %llu, <=2048 %llu, <=8192 %llu, more %llu\n",
                 (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2], (unsigned long long)hist[3], (unsigned long long)hist[4],

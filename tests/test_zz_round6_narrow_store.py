@@ -231,3 +231,44 @@ def test_ram_permutation_over_the_narrow_store(zk, monkeypatch):
             want[c, limit * S: rows] = to[c::n_cols][:So, inst]
         assert np.array_equal(got[k], want), inst
     del keep
+
+
+@pytest.mark.gpu
+def test_c2_main_vm_2_20_rows_over_the_narrow_store(zk, monkeypatch):
+    """BASELINE's C2 at full size (2^20 rows per instance, the bench fixture through zk_pack_main_vm_witness) with the batch on the narrow store: commitments ==
+    the fixture's, and the WHOLE trace of one instance — 164 columns x 2^20 rows, read by zk_cs_trace_columns straight from the one-byte / eight-byte slots —
+    == the oracle interpreter's, cell for cell; then the deferred-Poseidon2 mode on top (columns after widening + k_fill_p2)"""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    import test_gpu_full_size as T
+    monkeypatch.setenv("ZKGL_NARROW_STORE", "1")
+    cs, limit = bench.build_main_vm_cs(zkgl, 20)
+    B = 4
+    outer, loop, expect = bench.main_vm_streams(zkgl, cs, limit, B)
+    assert expect is not None
+    d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(loop)
+    cs.seed_stream(B, d_o, d_l)
+    seeded = d_l.to_numpy().reshape(loop.shape)
+    cs.set_batch(B)
+    st = cs.stats()
+    assert st["narrow_store_active"] == 1 and st["narrow_store_bytes_per_lane_loop"] <= 0.80 * st["store_bytes_per_lane_loop"]
+    cs.bind_inputs(False, d_o, outer.shape[0]); cs.bind_inputs(True, d_l, loop.shape[0])
+    ok, f = cs.resolve_and_check()
+    assert ok, f
+    assert cs.stats()["narrow_repeats"] == 0 and cs.stats()["narrow_store_pending"] == 1
+    for i in range(B):
+        assert cs.public_inputs(i) == [int(x) for x in expect[i]], i
+    T.assert_whole_trace_equals_oracle(zk, cs, outer, seeded, 1, limit, 20)
+    assert cs.stats()["narrow_store_pending"] == 1, "the columns were not read from the narrow store"
+    cs.set_check_mode(False, defer_p2=True)
+    try:
+        ok, f = cs.resolve_and_check()
+        assert ok, f
+        T.assert_whole_trace_equals_oracle(zk, cs, outer, seeded, 2, limit, 20)
+        assert cs.stats()["narrow_store_pending"] == 0      # the fill works in the ordinary store: widened first
+    finally:
+        cs.set_check_mode(False)
+    cs.close()
