@@ -30,6 +30,12 @@ SUBSET = [
     "tests/test_queue_seed.py",                                                   # scan seeders: shuffles, DPP rows, ballots
     "tests/test_ntt.py", "tests/test_copy_permutation.py",                        # K11 (LDS passes up to 2^22), K12 (scans)
     "tests/test_gpu_main_vm.py::test_main_vm_gpu_bit_exact",                      # k_witness_loop on whole wavefronts: flag planes, gated permutations, wave-aggregated multiplicities
+    # round 6: the loop scope over the NARROW store (k_witness_loop_narrow, k_check_prog_t<true>, links over address words, k_widen_last / k_widen_store, columns read from
+    # one-byte slots) on a queue circuit; the main_vm cases of that file and the other full-size configurations run in tools/emulated_gpu_suite.sh
+    "tests/test_zz_round6_narrow_store.py::test_ram_permutation_over_the_narrow_store",
+    "tests/test_gpu_full_size.py::test_c1_ram_permutation_2_16_rows",             # BASELINE's C1 at full size
+    # the macro-op backends with kernels of their own (XMACROS): the reference's 4-bit-chunk SHA compression, default recording of its table set
+    "tests/test_zz_round5_gpu.py::test_gpu_equals_oracle_with_the_reference_tables",
 ]
 
 
@@ -68,7 +74,7 @@ def test_generator_rewrites_every_launch_and_nothing_else(tmp_path):
 def test_gpu_parity_subset_on_the_emulated_device():
     out = run_gpu_tests(build(), SUBSET)
     n = int(out.strip().splitlines()[-1].split(" passed")[0].split()[-1])
-    assert n >= 80, out[-500:]
+    assert n >= 83, out[-500:]
 
 
 def test_product_library_is_not_the_emulated_one():
