@@ -79,10 +79,19 @@ void poseidon2(u64 s[12]) {
 
 struct Chains { u64 mem[12], dec[12], fwd[4], sponge[12]; };
 
-// n words to a destination this core will not read again: non-temporal 8-byte stores (no read-for-ownership of the destination lines)
+// n words to a destination this core will not read again: non-temporal 8-byte stores (no read-for-ownership of the destination lines) for
+// the WHOLE 64-byte lines of the run; the partial lines at its ends take plain stores.  A staging array that is not line-aligned (a numpy
+// array: 16 bytes off) makes every 512-byte run start and end inside a line whose other part belongs to the neighbouring tile: streamed,
+// those lines leave the write-combining buffers half-filled — measured here 0.65 ms per instance instead of 0.13 (round 6: the figure
+// round 5 published, 0.98 ms per instance per core, was that case; pinned staging memory is page-aligned).
 inline void stream_out(u64* dst, const u64* src, uint32_t n) {
 #if defined(__x86_64__)
-    for (uint32_t i = 0; i < n; ++i) _mm_stream_si64((long long*)(dst + i), (long long)src[i]);
+    uint32_t i = 0;
+    const uint32_t head = (uint32_t)(((64u - (uint32_t)((uintptr_t)dst & 63u)) & 63u) / 8u);   // (dst is 8-byte aligned)
+    for (; i < n && i < head; ++i) dst[i] = src[i];
+    const uint32_t whole = i + ((n - i) & ~7u);
+    for (; i < whole; ++i) _mm_stream_si64((long long*)(dst + i), (long long)src[i]);
+    for (; i < n; ++i) dst[i] = src[i];
 #else
     std::memcpy(dst, src, (size_t)n * sizeof(u64));
 #endif
@@ -321,10 +330,14 @@ extern "C" int zk_pack_main_vm_witness_states(zk_cs* h, const zk_vm_closed_form_
         if (oracle_only && *f.dst < (uint32_t)vmn::STATE_WORDS) return bad("zk_pack_main_vm_witness: ORACLE_WORDS_ONLY needs every oracle field behind the VmLocalState rows of the recorded layout");
     }
     // ---- outer stream: VmCircuitInputOutput::alloc_ignoring_outputs order (circuits/main_vm.cpp entry_point)
+    const char* last_name = nullptr; uint32_t last_w = 0;   // (one layout lookup per field, not per word: hidden_fsm_input is 243 words)
     auto outer = [&](const char* name, uint32_t i, u64 v) {
-        const uint32_t w = cs.layout_word("outer", name);
-        if (w == UINT32_MAX) throw zkgl::ZkError(ZK_ERR_INVALID, std::string("main_vm layout lacks ") + name);
-        outer_words[(u64)(w + i) * batch + instance] = v;
+        if (name != last_name) {
+            last_w = cs.layout_word("outer", name);
+            if (last_w == UINT32_MAX) throw zkgl::ZkError(ZK_ERR_INVALID, std::string("main_vm layout lacks ") + name);
+            last_name = name;
+        }
+        outer_words[(u64)(last_w + i) * batch + instance] = v;
     };
     try {
         outer("start_flag", 0, in->start_flag ? 1 : 0);
@@ -367,7 +380,8 @@ extern "C" int zk_pack_main_vm_witness_states(zk_cs* h, const zk_vm_closed_form_
     const uint32_t n_loop_words = cs.loop_input_words();
     const uint32_t w_first = oracle_only ? (uint32_t)vmn::STATE_WORDS : 0u;
     constexpr uint32_t TC = 64;
-    std::vector<u64> tile((size_t)n_loop_words * TC);
+    static thread_local std::vector<u64> tile;   // (184 KB: above malloc's mmap threshold — a fresh mapping per instance otherwise)
+    tile.resize((size_t)n_loop_words * TC);
     env.stride = TC;
     u64* const dst0 = loop_words + (u64)instance * limit;
     const u64 dst_stride = (u64)batch * limit;

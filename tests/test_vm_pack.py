@@ -294,6 +294,17 @@ def test_oracle_words_only_packs_exactly_the_rows_behind_the_vm_state():
     assert np.array_equal(o, full_o) and np.array_equal(l, full_l[243:]) and not any(r.underflow for r in reps)
     with pytest.raises(zkgl.ZkError):   # the state rows are the device seeder's in this mode
         cs.pack_main_vm_witness_batch(cfs, views, 0, E, o, l, flags=zkgl.VM_PACK_ORACLE_WORDS_ONLY | zkgl.VM_PACK_FILL_STATE)
+    # the tile leaves with non-temporal stores for whole cache lines and plain stores for the partial lines at the ends of a run: every
+    # alignment of the staging array (pinned memory: 0; a numpy array: 16 bytes into a line; the worst case: 56) gives the same words
+    rows, cols = n_loop - 243, E * limit
+    for off_words in (0, 1, 2, 5, 7):
+        raw = np.full(rows * cols + 16, 0xbeef, dtype=np.uint64)
+        base = (-raw.ctypes.data % 64) // 8 + off_words
+        dst = raw[base:base + rows * cols].reshape(rows, cols)
+        assert dst.ctypes.data % 64 == 8 * off_words
+        cs.pack_main_vm_witness_batch(cfs, views, 0, E, o, dst, flags=zkgl.VM_PACK_ORACLE_WORDS_ONLY, n_threads=1)
+        assert np.array_equal(dst, full_l[243:]), off_words
+        assert (raw[:base] == 0xbeef).all() and (raw[base + rows * cols:] == 0xbeef).all()   # nothing outside the array
 
 
 @pytest.mark.parametrize("mode", ["device_seeds", "states_from_witness"])
