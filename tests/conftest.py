@@ -15,9 +15,15 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     # every test that takes the `zk` fixture (an initialised GPU) is a GPU test, marked or not
+    # On a real device a kernel that never returns would hold the box until the caller's limit (a strike for the pool): every GPU test gets a
+    # ten-minute limit enforced from a watchdog thread (a hung HIP call never returns to Python, so the signal method could not fire); the whole
+    # device suite takes about three minutes, its slowest test well under one.  Not on the emulated device (ZKGL_LIB: minutes per test there).
+    limit = config.pluginmanager.hasplugin("timeout") and not os.environ.get("ZKGL_LIB")
     for item in items:
         if "zk" in getattr(item, "fixturenames", ()) and not item.get_closest_marker("gpu"):
             item.add_marker(pytest.mark.gpu)
+        if limit and item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
 
 
 @pytest.fixture(scope="session")
