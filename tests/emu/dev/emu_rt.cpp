@@ -393,5 +393,7 @@ void release(void* p) {
 }
 
 extern "C" unsigned long long zk_emu_divergent_wave_sites() { return n_divergent_sites; }
+unsigned long long buffer_ops[4] = {0, 0, 0, 0};
+extern "C" void zk_emu_buffer_ops(unsigned long long out[4]) { for (int i = 0; i < 4; ++i) out[i] = buffer_ops[i]; }
 
 }  // namespace emu

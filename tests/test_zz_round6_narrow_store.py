@@ -120,6 +120,52 @@ def test_main_vm_over_the_narrow_store_equals_the_oracle(zk, vm_batch, monkeypat
 
 
 @pytest.mark.gpu
+def test_issued_buffer_operations_of_the_two_stores(zk, vm_batch, monkeypatch):
+    """EMULATED DEVICE only (it counts the lane-level buffer operations the kernels issue; no such counter exists on hardware, where the PMC passes of
+    tools/evidence_r6b.sh read WRITE_SIZE / FETCH_SIZE): one fused step of main_vm over each store.  Every byte-class value is one 1-byte store instead of
+    one 8-byte store, every operand read one load of its class — the stored bytes fall by exactly what zk_stats says, and the issued load bytes
+    (the upper bound of what a cache-less device would fetch) are reported for profiles/r6_predictions.md."""
+    from helpers import emulated_device
+    if not emulated_device():
+        pytest.skip("lane-level operation counts exist on the emulated device only")
+    import ctypes as C
+    cs, D, outer, loop, commits, info = vm_batch
+    B = outer.shape[1]
+    monkeypatch.setenv("ZKGL_STRANDS", "0")
+
+    def counts():
+        out = (C.c_ulonglong * 4)()
+        zkgl.lib().zk_emu_buffer_ops(out)
+        return np.array(list(out), dtype=np.int64)
+
+    ops = {}
+    for mode in ("ordinary", "narrow"):
+        _ask(monkeypatch, mode == "narrow")
+        cs.set_batch(B)
+        assert cs.stats()["narrow_store_active"] == (1 if mode == "narrow" else 0)
+        keep = _bind(zk, cs, outer, loop)
+        c0 = counts()
+        ok, f = cs.resolve_and_check()
+        assert ok, f
+        ops[mode] = counts() - c0
+        del keep
+    st = cs.stats()
+    ld8_o, st8_o, ldb_o, stb_o = (int(x) for x in ops["ordinary"])
+    ld8_n, st8_n, ldb_n, stb_n = (int(x) for x in ops["narrow"])
+    lanes = -(-B * LIMIT // 64) * 64          # the lanes of the last wavefront beyond the batch redo the last lane's work
+    assert ldb_o == 0 and stb_o == 0
+    assert stb_n == lanes * st["narrow_byte_values_loop"]                       # one 1-byte store per byte-class value and lane ...
+    assert st8_o - st8_n == stb_n                                               # ... in place of one 8-byte store
+    assert (st8_o * 8) - (st8_n * 8 + stb_n) == lanes * (st["store_bytes_per_lane_loop"] - st["narrow_store_bytes_per_lane_loop"])
+    assert ld8_o == ld8_n + ldb_n                                               # every operand read is one load of the value's class
+    print(f"[narrow store, issued by the kernels per lane] stores {st8_o * 8 / lanes:.0f} -> {(st8_n * 8 + stb_n) / lanes:.0f} B "
+          f"({(st8_n * 8 + stb_n) / (st8_o * 8):.3f}); operand loads {ld8_o / lanes:.0f} of 8 B -> {ld8_n / lanes:.0f} of 8 B + {ldb_n / lanes:.0f} of 1 B "
+          f"({(ld8_n * 8 + ldb_n) / (ld8_o * 8):.3f} of the bytes)")
+    _ask(monkeypatch, False)
+    cs.set_batch(B)
+
+
+@pytest.mark.gpu
 def test_narrow_store_failures_are_the_ordinary_stores(zk, vm_batch, monkeypatch):
     """a tampered carried word, and an oracle word that does not fit the byte slot its range check gives it (written truncated, it would BE a
     boolean): verdict and failure report of the narrow batch == those of the same circuit recorded without the layout (the step is repeated
