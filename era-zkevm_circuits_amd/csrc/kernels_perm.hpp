@@ -70,7 +70,6 @@ __global__ __launch_bounds__(TPB) void k_perm_lane(PermDev d) {
         const uint32_t n_lookup_cols = uni(d.lrows[slot].n_tuples) * d.lookup_width;
         for (uint32_t part = 0; part < 2; ++part) {
             const uint32_t c0 = part ? d.n_copy_cols : 0, c1 = c0 + (part ? n_lookup_cols : n_gate_cols);
-#pragma unroll 4
             for (uint32_t col = c0; col < c1; ++col) {
                 const uint32_t cell = slot * d.n_cols + col;
                 // a column the row descriptor counts but no variable occupies (the unused columns of a narrow lookup tuple) holds 0
