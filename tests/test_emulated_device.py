@@ -77,6 +77,42 @@ def test_gpu_parity_subset_on_the_emulated_device():
     assert n >= 83, out[-500:]
 
 
+def test_bench_py_end_to_end_on_the_emulated_device():
+    """bench.py — the driver's instrument — with EVERY leg (stored mode, deferred intermediates, resident inputs, witness columns, the realistic fixture, both
+    host-fed forms, the narrow store's labelled mode) on a tiny configuration: one JSON line, no leg reports an error, the contract's keys are there, the legs
+    that compare commitments agree.  Several of these legs were written while no GPU call was accepted; until this runner nothing had executed them
+    (tests/emu/bench_on_emulator.py: torch.cuda patched from outside, host tensors as device tensors; the times mean nothing)."""
+    import json
+    lib = build()
+    env = dict(os.environ, ZKGL_LIB=lib)
+    env.pop("PYTEST_CURRENT_TEST", None)
+    base = [sys.executable, os.path.join(ROOT, "tests", "emu", "bench_on_emulator.py"), "--batch", "2", "--log2-rows", "15", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    for extra, kernel in ((["--with-narrow-store-mode"], "zke::k_witness_loop"), (["--narrow-store", "--headline-only"], "zke::k_witness_loop_narrow")):
+        r = subprocess.run(base + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in d, key
+        assert d["unit"] == "constraints/s" and d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None
+        rf = d["roofline"]
+        assert rf["bound"] == "hbm" and rf["kernel"] == kernel and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["achieved"] > 0
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+        assert "workload" in d["config"] and "model" not in d["config"]
+        assert [k for k, v in d.items() if isinstance(v, dict) and "error" in v] == []
+        if "--headline-only" in extra:
+            continue
+        for key in ("value_realistic_fixture", "value_including_host_pack", "value_states_from_witness", "mode_p2_intermediates_deferred", "mode_narrow_store"):
+            assert isinstance(d[key], dict) and d[key], key
+        assert d["mode_p2_intermediates_deferred"]["commitments_equal_native_restatement"] is True
+        for label in ("plain", "p2_deferred"):
+            leg = d["mode_narrow_store"][label]
+            assert leg["commitments_equal_native_restatement"] is True and leg["steps_repeated_over_the_ordinary_store"] == 0
+        assert 0.70 < d["mode_narrow_store"]["bytes_ratio"] < 0.80
+        assert d["witness_rows_materialised_per_s"] > 0
+
+
 def test_product_library_is_not_the_emulated_one():
     import zkgl
     assert not __import__("helpers").emulated_device()
