@@ -62,6 +62,10 @@ def timed(name, cs, outer, loop, batch, seed_carried=1, given=(), stream_x=0):
 
 
 rng = np.random.default_rng(1)
+# CONFIG_TIMINGS_MAX_INSTANCES=n: a DRY RUN of this tool with at most n instances per configuration (the emulated device runs every line of it that way,
+# tests/emu/README.md); the numbers of such a run mean nothing
+_CAP = int(os.environ.get("CONFIG_TIMINGS_MAX_INSTANCES", "0"))
+nb = lambda n: min(n, _CAP) if _CAP else n
 WANT = os.environ.get("CONFIGS")
 want = lambda tag: WANT is None or tag in WANT.split(",")
 # C1: ram_permutation 2^16 rows, 512 instances
@@ -69,20 +73,20 @@ if want("C1"):
     cs, limit = T.fit(lambda c: c.configure_ram_permutation(), lambda c, l: c.ram_permutation_entry_point(l), 16)
     u, s, nd = rn.random_ram_witness(rng, limit, n_cells=64)
     inst = rn.instance(u, s, limit, nd)
-    outer, loop = rn.pack_streams([inst] * 512, limit)
-    timed("C1 ram_permutation 2^16 rows", cs, outer, loop, 512)
-    timed("C1 ram_permutation 2^16 rows, heads from the witness's previous tails", cs, outer, loop, 512, given=zkgl.ram_head_words())
+    outer, loop = rn.pack_streams([inst] * nb(512), limit)
+    timed("C1 ram_permutation 2^16 rows", cs, outer, loop, nb(512))
+    timed("C1 ram_permutation 2^16 rows, heads from the witness's previous tails", cs, outer, loop, nb(512), given=zkgl.ram_head_words())
 # C3
 if want("C3k"):
     cs, limit = T.fit(lambda c: c.configure_keccak(), lambda c, l: c.keccak256_round_function_entry_point(l), 20)
     reqs, _ = T._keccak_requests(np.random.default_rng(0xC3), limit)
     inst = kn.instance(reqs, limit)
-    B = 128
+    B = nb(128)
     outer = np.array([inst["outer"]] * B, dtype=np.uint64).T.copy(); loop = np.array(inst["rows"] * B, dtype=np.uint64).T.copy()
     timed("C3 keccak256_round_function 2^20 rows", cs, outer, loop, B, stream_x=4)
     timed("C3 keccak256_round_function 2^20 rows, every carried word from the witness's queue states (zk_pack_keccak_witness_tails)", cs, outer, loop, B, given=list(range(kn.CARRIED)))
 if want("C3s"):
-    B = 128
+    B = nb(128)
     cs, limit = T.fit(lambda c: c.configure_sha256(), lambda c, l: c.sha256_round_function_entry_point(l), 20)
     msgs = [bytes(rng.integers(0, 256, size=64 * 8 - 9, dtype=np.uint8)) for _ in range(limit // 8)]
     reqs = [shn.request(m, 1 + 2 * i, 10 + i, 0, 9000 + i, i) for i, m in enumerate(msgs)]
@@ -91,7 +95,7 @@ if want("C3s"):
     timed("C3 sha256_round_function 2^20 rows", cs, outer, loop, B, stream_x=4)
     timed("C3 sha256_round_function 2^20 rows, every carried word from the witness's queue states (zk_pack_sha256_witness_tails)", cs, outer, loop, B, given=list(range(shn.CARRIED)))
 if want("C3s4"):   # the SAME circuit under the reference's own table set (src/code_unpacker_sha256/mod.rs:554-566: width-4 lookups, Maj4 / TriXor4 / Ch4 / Split4BitChunk<1,2>)
-    B = 128      # the compression is ONE macro-op (ZK_OP_SHA256_ROUNDS a = 1: the default recording of this table set since round 6); ZKGL_SHA4_MACRO=0 interprets it op by op
+    B = nb(128)      # the compression is ONE macro-op (ZK_OP_SHA256_ROUNDS a = 1: the default recording of this table set since round 6); ZKGL_SHA4_MACRO=0 interprets it op by op
     cs, limit = T.fit(lambda c: c.configure_sha256(True), lambda c, l: c.sha256_round_function_entry_point(l), 20)
     msgs = [bytes(rng.integers(0, 256, size=64 * 8 - 9, dtype=np.uint8)) for _ in range(limit // 8)]
     reqs = [shn.request(m, 1 + 2 * i, 10 + i, 0, 9000 + i, i) for i, m in enumerate(msgs)]
@@ -104,22 +108,22 @@ if want("C4s"):
     cs, limit = T.fit(lambda c: c.configure_storage_validity(), lambda c, l: c.sort_and_deduplicate_storage_access_entry_point(l, True), 22)
     u, s = sn.random_storage_witness(np.random.default_rng(0xC4), limit - 3, n_cells=512)
     inst = sn.instance(u, s, limit)
-    outer, loop = sn.pack_streams([inst] * 4, limit)
-    timed("C4 storage_validity 2^22 rows", cs, outer, loop, 4)
+    outer, loop = sn.pack_streams([inst] * nb(4), limit)
+    timed("C4 storage_validity 2^22 rows", cs, outer, loop, nb(4))
     g = [w for w in range(67) if not 2 <= w < 6]
-    timed("C4 storage_validity 2^22 rows, integer state walked by the packer (previous tails), output chain on the device", cs, outer, loop, 4, given=[w for w in g if not 17 <= w < 21])
-    timed("C4 storage_validity 2^22 rows, integer state walked by the packer, output tails from the host", cs, outer, loop, 4, given=g)
+    timed("C4 storage_validity 2^22 rows, integer state walked by the packer (previous tails), output chain on the device", cs, outer, loop, nb(4), given=[w for w in g if not 17 <= w < 21])
+    timed("C4 storage_validity 2^22 rows, integer state walked by the packer, output tails from the host", cs, outer, loop, nb(4), given=g)
     o1, l1 = sn.pack_streams([inst], limit)
     timed("C4 storage_validity 2^22 rows, ONE instance (one GPU of BASELINE's 4)", cs, o1, l1, 1)
 if want("C4l"):
     cs, limit = T.fit(lambda c: c.configure_log_sorter(), lambda c, l: c.sort_and_deduplicate_events_entry_point(l), 22)
     u, s = ln.random_events(np.random.default_rng(0xC4 + 1), int(limit / 1.1) - 8, rollback_frac=0.1)
     inst = ln.instance(u, s, limit)
-    outer, loop = ln.pack_streams([inst] * 4, limit)
-    timed("C4 log_sorter 2^22 rows", cs, outer, loop, 4)
+    outer, loop = ln.pack_streams([inst] * nb(4), limit)
+    timed("C4 log_sorter 2^22 rows", cs, outer, loop, nb(4))
     g = [w for w in range(57) if not 1 <= w < 5]
-    timed("C4 log_sorter 2^22 rows, integer state walked by the packer (previous tails), output chain on the device", cs, outer, loop, 4, given=[w for w in g if not 15 <= w < 19])
-    timed("C4 log_sorter 2^22 rows, integer state walked by the packer, output tails from the host", cs, outer, loop, 4, given=g)
+    timed("C4 log_sorter 2^22 rows, integer state walked by the packer (previous tails), output chain on the device", cs, outer, loop, nb(4), given=[w for w in g if not 15 <= w < 19])
+    timed("C4 log_sorter 2^22 rows, integer state walked by the packer, output tails from the host", cs, outer, loop, nb(4), given=g)
     o1, l1 = ln.pack_streams([inst], limit)
     timed("C4 log_sorter 2^22 rows, ONE instance", cs, o1, l1, 1)
 # C5: 8 blobs (BASELINE: one per GPU)
@@ -127,10 +131,10 @@ if want("C5"):
     cs = zkgl.ConstraintSystem(zkgl.CSGeometry(60, 0, 8, 4), 1 << 21, 1 << 28)
     cs.configure_eip_4844(); cs.eip_4844_entry_point(4096); cs.pad_and_shrink()
     insts = []
-    for k in range(8):
+    for k in range(nb(8)):
         r = np.random.default_rng(0xC5 + k)
         insts.append(en.instance(bytes(r.integers(0, 256, size=31 * 4096, dtype=np.uint8)), b"\x01" + bytes(r.integers(0, 256, size=31, dtype=np.uint8)), 4096))
     outer = np.array([i["outer"] for i in insts], dtype=np.uint64).T.copy()
     loop = np.array([r_ for i in insts for r_ in i["rows"]], dtype=np.uint64).T.copy()
-    timed("C5 eip_4844 8 blobs x 4096 chunks", cs, outer, loop, 8, stream_x=8)
-    timed("C5 eip_4844 8 blobs x 4096 chunks, the 217 carried words from the host packer (zk_pack_eip4844_witness_full)", cs, outer, loop, 8, given=list(range(217)))
+    timed("C5 eip_4844 8 blobs x 4096 chunks", cs, outer, loop, nb(8), stream_x=nb(8))
+    timed("C5 eip_4844 8 blobs x 4096 chunks, the 217 carried words from the host packer (zk_pack_eip4844_witness_full)", cs, outer, loop, nb(8), given=list(range(217)))
