@@ -111,6 +111,22 @@ def test_bench_py_end_to_end_on_the_emulated_device():
             assert leg["commitments_equal_native_restatement"] is True and leg["steps_repeated_over_the_ordinary_store"] == 0
         assert 0.70 < d["mode_narrow_store"]["bytes_ratio"] < 0.80
         assert d["witness_rows_materialised_per_s"] > 0
+    # the N > 1 launch in the driver's own form (one process per rank through torch.distributed.run, rendezvous on 127.0.0.1, max over ranks, rank 0 prints the line);
+    # the ranks get the torch.cuda stand-ins through tests/emu/site/sitecustomize.py.  Two ranks on one (emulated) device: the gather falls back to gloo and says so.
+    env2 = dict(env, ZKGL_EMU_TORCH="1", PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "emu", "site")] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else [])))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--log2-rows", "15", "--no-cpu-baseline", "--headline-only"],
+                       cwd=ROOT, env=env2, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and len(d["config"]["per_rank_ms_per_step"]) == 2
+    assert d["ms_per_step"] >= max(d["config"]["per_rank_ms_per_step"]) - 1e-6          # the MAX over ranks
+    assert d["distinct_commitments"] == 4 and "ranks share one GPU" in d["config"]["commitment_gather"]
 
 
 def test_product_library_is_not_the_emulated_one():
