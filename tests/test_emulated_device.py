@@ -36,6 +36,8 @@ SUBSET = [
     "tests/test_gpu_full_size.py::test_c1_ram_permutation_2_16_rows",             # BASELINE's C1 at full size
     # the macro-op backends with kernels of their own (XMACROS): the reference's 4-bit-chunk SHA compression, default recording of its table set
     "tests/test_zz_round5_gpu.py::test_gpu_equals_oracle_with_the_reference_tables",
+    # zk_comm_create / zk_cs_gather_commitments with a world of TWO processes (the stand-in collective of tests/emu/dev/rccl/rccl.h: comm.cpp's ranks, counts, buffers — not RCCL)
+    "tests/test_multi.py::test_rccl_gather_behind_the_c_abi_on_two_gpus",
 ]
 
 
