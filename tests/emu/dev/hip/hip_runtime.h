@@ -187,9 +187,13 @@ enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 1 };
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : e == hipErrorOutOfMemory ? "out of memory (emulated device)" : "invalid value (emulated device)"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+// one emulated device; EMU_DEVICES=n makes the process see n of them (all the same host memory) so that the one-process-per-GPU launch of bench.py --gpus n
+// binds rank r to "device" r and takes its RCCL path over the stand-in collective (tests/emu/dev/rccl/rccl.h)
+static inline int emu_device_count() { const char* e = getenv("EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n >= 1 && n <= 64 ? n : 1; }
+inline int& emu_current_device() { static int d = 0; return d; }   // (inline, not static: ONE current device for every translation unit of the library)
+static inline hipError_t hipGetDeviceCount(int* n) { *n = emu_device_count(); return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = emu_current_device(); return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= emu_device_count()) return hipErrorInvalidValue; emu_current_device() = d; return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
 template <class F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }

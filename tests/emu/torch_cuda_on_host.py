@@ -2,6 +2,7 @@
 synchronize and mem_get_info become host stand-ins, torch.device("cuda", i) maps to the host (the emulated device's memory IS host memory: a host tensor's
 data_ptr() is a valid "device" pointer for the emulated library).  Test infrastructure; the product and bench.py know nothing of it."""
 import contextlib
+import os
 import time
 
 
@@ -44,7 +45,8 @@ def apply():
     stream = _Stream()
     torch.device = _device
     torch.cuda.is_available = lambda: True
-    torch.cuda.device_count = lambda: 1
+    n_dev = int(os.environ.get("EMU_DEVICES", "1"))          # (tests/emu/dev/hip/hip_runtime.h reads the same variable)
+    torch.cuda.device_count = lambda: n_dev
     torch.cuda.set_device = lambda d: None
     torch.cuda.current_stream = lambda *a, **k: stream
     torch.cuda.Stream = _Stream

@@ -114,8 +114,9 @@ def test_bench_py_end_to_end_on_the_emulated_device():
         assert 0.70 < d["mode_narrow_store"]["bytes_ratio"] < 0.80
         assert d["witness_rows_materialised_per_s"] > 0
     # the N > 1 launch in the driver's own form (one process per rank through torch.distributed.run, rendezvous on 127.0.0.1, max over ranks, rank 0 prints the line);
-    # the ranks get the torch.cuda stand-ins through tests/emu/site/sitecustomize.py.  Two ranks on one (emulated) device: the gather falls back to gloo and says so.
-    env2 = dict(env, ZKGL_EMU_TORCH="1", PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "emu", "site")] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else [])))
+    # the ranks get the torch.cuda stand-ins through tests/emu/site/sitecustomize.py.  EMU_DEVICES=2: rank r binds "device" r and the step's gather is the product's
+    # (zk_cs_gather_commitments on a world-2 communicator made from rank 0's unique id; the collective underneath is the stand-in of tests/emu/dev/rccl/rccl.h).
+    env2 = dict(env, ZKGL_EMU_TORCH="1", EMU_DEVICES="2", PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "emu", "site")] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else [])))
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
@@ -128,7 +129,7 @@ def test_bench_py_end_to_end_on_the_emulated_device():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and len(d["config"]["per_rank_ms_per_step"]) == 2
     assert d["ms_per_step"] >= max(d["config"]["per_rank_ms_per_step"]) - 1e-6          # the MAX over ranks
-    assert d["distinct_commitments"] == 4 and "ranks share one GPU" in d["config"]["commitment_gather"]
+    assert d["distinct_commitments"] == 4 and d["config"]["commitment_gather"].startswith("zk_cs_gather_commitments per step")
 
 
 def test_product_library_is_not_the_emulated_one():
