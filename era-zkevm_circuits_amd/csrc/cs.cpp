@@ -652,7 +652,7 @@ void CS::build_check_program(Scope& s) {
     std::vector<int32_t> gate_macro(s.gates.size(), -1);
     struct MacroP2 { uint32_t in_slots[12]; uint32_t first_out; uint32_t first_gate; };
     std::vector<MacroP2> macros;
-    if (!getenv("ZKGL_NO_CHECK_MACROS")) {
+    {
         std::vector<uint64_t> const_full(s.n_vars, 0);
         std::vector<uint8_t> is_const(s.n_vars, 0);
         for (auto& op : s.ops)
@@ -1396,8 +1396,7 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
             // strand form, kernels_engine2.hpp k_witness_strands2): header, operand words of every member as in the plain v2
             // form, then ONE destination word per member — the store slot of its first output (an op's outputs are consecutive
             // slots).  Caps: a group fits the 16-word fetch (SELECT 3, FMA 2, INPUT 7, LOOKUP of <= 2 keys 3, U32MULADD 2).
-            const char* grp_env = getenv("ZKGL_LOOKUP_GROUPS");
-            const bool grouping = !(grp_env && grp_env[0] == '0');
+            const bool grouping = true;
             for (uint32_t k = 0; k < NS; ++k) {
                 std::map<uint64_t, std::vector<size_t>> groups;  // kind key -> ops of this strand and level
                 std::vector<uint64_t> order;
@@ -1438,7 +1437,7 @@ void CS::build_strands(Scope& s, uint32_t NS, bool narrow) {
         }
         plane_of_ = nullptr;
         s_gain[ph] = critical ? (float)total / (float)critical : 0.f;
-        if (getenv("ZKGL_STRANDS_DEBUG") && o1 > o0) {
+        if (getenv("ZKGL_PROG_STATS") && o1 > o0) {
             uint32_t narrow = 0, wide = 0;
             for (auto& l : by_level) { narrow += l.size() < 8; wide += l.size() >= 64; }
             fprintf(stderr, "[zkgl] strands %s phase %d: %zu ops, %u levels (%u with fewer than 8 ops, %u with 64 or more), estimated gain %.2f\n",
@@ -1767,8 +1766,7 @@ void CS::emit_scope(Scope& s) {
     s.prog.clear(); s.prog_full.clear(); s.prog2.clear();
     s.pre_words = 0; s.pre_words_full = 0; s.pre_words2 = 0; s.side_words2 = 0; s.pre_slots = 0; s.side_slots = 0;
     s.cells_written = 0; s.cells_populated = 0;
-    const char* grp_env = getenv("ZKGL_OP_GROUPS");
-    const bool grouping = !(grp_env && grp_env[0] == '0');
+    const bool grouping = true;
     // ---- the exported program + validation
     for (size_t oi = 0; oi < s.ops.size(); ++oi) {
         if (!s.is_loop && oi == s.pre_ops) s.pre_words_full = (uint32_t)s.prog_full.size();
@@ -2440,7 +2438,7 @@ void CS::build_seed_program() {
             seed_wslots_ = nws;
             if (!zkdev::seed_wave_fits((uint32_t)seed_wprog_.size(), nws, s.n_input_words)) { seed_wprog_.clear(); seed_wcarries_.clear(); }
         } else { seed_wcarries_.clear(); }
-        if (getenv("ZKGL_STRANDS_DEBUG"))
+        if (getenv("ZKGL_PROG_STATS"))
             fprintf(stderr, "[zkgl] seed wave program: %zu u16 words (%u prologue; built %zu + %zu, lane forms %s (%d)), %u slots%s\n", seed_wprog_.size(), seed_wpro_words_,
                     pro.size(), cyc.size(), ok ? "ok" : "MISSING", fail_reason, nws, seed_wprog_.empty() ? " - not usable, strand kernel stays" : "");
     }
@@ -2511,7 +2509,7 @@ void CS::build_seed_program() {
     }
     seed_sslots_ = ns;
     seed_sgain_ = critical ? (float)total / (float)critical : 0.f;
-    if (getenv("ZKGL_STRANDS_DEBUG"))
+    if (getenv("ZKGL_PROG_STATS"))
     {
         fprintf(stderr, "[zkgl] seed cone: %u ops, %u levels, %u slots (plain %u), estimated gain %.2f\n", seed_ops_, n_levels, ns, n_slots, seed_sgain_);
         std::map<uint32_t, uint32_t> hist;
@@ -3074,8 +3072,7 @@ void CS::launch_seed(const zkdev::ScopeArgs& la, const zkdev::ScopeArgs& oa, uin
     const bool generic = force_generic && force_generic[0] == '1';
     if (seed_cone_unsupported_ && !generic) throw ZkError(ZK_ERR_INVALID, "the seeding cone of this circuit cannot be run by the seed kernels (it contains ZK_OP_BYTEBUF_FILL, or a carried output depends on a gated ZK_OP_POSEIDON2 outside a select on its flag): use the native seeder or ZKGL_SEED_GENERIC=1");
     const bool use_strands = d_seed_sprog_ && !(seed_strands && seed_strands[0] == '0') && ((seed_strands && seed_strands[0] == '1') || seed_sgain_ >= 1.5f);
-    const char* seed_wave = std::getenv("ZKGL_SEED_WAVE");  // 0: never use the op-parallel kernel
-    if (d_seed_wprog_ && !generic && !(seed_wave && seed_wave[0] == '0'))
+    if (d_seed_wprog_ && !generic)
         dev_check(zkdev::launch_seed_wave(la, d_seed_wprog_, (uint32_t)seed_wprog_.size(), seed_wpro_words_, seed_wslots_, loop_.n_input_words,
                                           (const zkdev::CarryArgs*)d_seed_wcarries_, (uint32_t)seed_wcarries_.size(), dev_loop_inputs_rw, n, st));
     else if (use_strands && !generic)

@@ -29,6 +29,7 @@ SUBSET = [
     "tests/test_gpu_cs.py::test_sha256_round_function_fsm_gpu",                   # macro-op SHA256_ROUNDS + the two-wavefront FSM seeder
     "tests/test_queue_seed.py",                                                   # scan seeders: shuffles, DPP rows, ballots
     "tests/test_ntt.py", "tests/test_copy_permutation.py",                        # K11 (LDS passes up to 2^22), K12 (scans)
+    "tests/test_gpu_main_vm.py::test_native_seeding_with_several_walkers_per_wavefront",   # k_vm_walk<2> / <4>: the forms a full batch's seeding pass takes
     "tests/test_gpu_main_vm.py::test_main_vm_gpu_bit_exact",                      # k_witness_loop on whole wavefronts: flag planes, gated permutations, wave-aggregated multiplicities
     # round 6: the loop scope over the NARROW store (k_witness_loop_narrow, k_check_prog_t<true>, links over address words, k_widen_last / k_widen_store, columns read from
     # one-byte slots) on a queue circuit; the main_vm cases of that file and the other full-size configurations run in tools/emulated_gpu_suite.sh
@@ -128,7 +129,7 @@ def test_bench_py_end_to_end_on_the_emulated_device():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and len(d["config"]["per_rank_ms_per_step"]) == 2
-    assert d["ms_per_step"] >= max(d["config"]["per_rank_ms_per_step"]) - 1e-6          # the MAX over ranks
+    assert d["ms_per_step"] >= max(d["config"]["per_rank_ms_per_step"]) - 2e-3          # the MAX over ranks (the per-rank figures are rounded to 1 us)
     assert d["distinct_commitments"] == 4 and d["config"]["commitment_gather"].startswith("zk_cs_gather_commitments per step")
 
 

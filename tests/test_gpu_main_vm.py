@@ -182,6 +182,31 @@ def test_native_seeding_equals_cone_seeding(zk, batch, monkeypatch):
     assert np.array_equal(win, want)
 
 
+@pytest.mark.parametrize("ni", ["2", "4"])
+def test_native_seeding_with_several_walkers_per_wavefront(zk, batch, monkeypatch, ni):
+    """k_vm_walk<2> / <4>: two or four instances share a walking wavefront once a pass holds more than 1 024 / 2 048 instances (bench.py's 1 920-instance passes
+    take <2>).  A test batch is far smaller, so the form is forced (ZKGL_VM_WALK_NI): same 243 words per cycle as the native restatement, with an instance count
+    that leaves the last wavefront partly empty, in chunks and as one chunk."""
+    cs, D, outer, loop, commits, info = batch
+    S = outer.shape[1]
+    assert S % 4 != 0 or S > 4
+    raw = loop.copy()
+    raw[0:243] = 0
+    monkeypatch.setenv("ZKGL_SEED_NATIVE", "1")
+    monkeypatch.setenv("ZKGL_VM_WALK_NI", ni)
+    n = S - 1 if (S - 1) % int(ni) else S - 2          # the last walking wavefront is not full
+    for chunks in (None, "1"):
+        if chunks:
+            monkeypatch.setenv("ZKGL_VM_SEED_CHUNKS", chunks)
+        d_o, d_l = zk.DeviceBuffer.from_numpy(outer), zk.DeviceBuffer.from_numpy(raw)
+        cs.seed_window_async(n, d_o, S, d_l, S * LIMIT, 0)
+        zk.sync()
+        got = d_l.to_numpy().reshape(loop.shape)
+        want = raw.copy()
+        want[:, :n * LIMIT] = loop[:, :n * LIMIT]
+        assert np.array_equal(got, want), (ni, chunks)
+
+
 def test_main_vm_hook_compare_witness(zk):
     """structured_input.hook_compare_witness (src/main_vm/mod.rs:218): the circuit's hidden_fsm_output / observable_output groups against
     the closed-form input a host holds; input streams through zk_pack_main_vm_witness only"""
