@@ -57,3 +57,4 @@ def apply():
     torch.cuda.empty_cache = lambda: None
     torch.cuda.mem_get_info = lambda *a, **k: (48 << 30, 64 << 30)
     torch.Tensor.pin_memory = lambda self, *a, **k: self
+    torch.Tensor.cuda = lambda self, *a, **k: self          # tensor.cuda(): the tensor itself — host memory is the emulated device's memory

@@ -172,8 +172,8 @@ def test_gpu_lde_equals_oracle_and_the_big_transform(zk, log_n, log_blowup):
 @pytest.mark.parametrize("log_n", [20, 22])
 def test_gpu_full_size_properties(zk, log_n):
     """trace-sized transforms (2^20 rows main_vm / hashes, 2^22 storage): round trip, linearity, oracle on one polynomial"""
-    if __import__("helpers").emulated_device():
-        pytest.skip("device memory of this test is a torch CUDA tensor: needs the hardware")
+    if __import__("helpers").emulated_device() and __import__("os").environ.get("ZKGL_EMU_TORCH") != "1":
+        pytest.skip("device memory of this test is a torch CUDA tensor: the hardware, or the emulated device with the torch.cuda stand-ins (tools/emulated_gpu_suite.sh)")
     import torch
     n, n_polys = 1 << log_n, 6
     rng = np.random.default_rng(log_n)

@@ -6,6 +6,7 @@ set -uo pipefail
 cd "$(dirname "$0")/.."
 EMU_OPT=-O2 bash tests/emu/dev/build.sh || exit 1
 OUT=${OUT:-/tmp/emulated_gpu_suite}; mkdir -p $OUT; rm -f $OUT/stats.*
-EMU_STATS=$OUT/stats ZKGL_LIB=$PWD/tests/emu/_gen/dev_O2/libzkgl.so python -m pytest tests -m gpu -q -n ${JOBS:-6} --durations=30 -p no:cacheprovider \
+# (ZKGL_EMU_TORCH + tests/emu/site on PYTHONPATH: the tests whose device memory is a torch tensor get host tensors through the torch.cuda stand-ins, tests/emu/torch_cuda_on_host.py)
+ZKGL_EMU_TORCH=1 PYTHONPATH=$PWD/tests/emu/site${PYTHONPATH:+:$PYTHONPATH} EMU_STATS=$OUT/stats ZKGL_LIB=$PWD/tests/emu/_gen/dev_O2/libzkgl.so python -m pytest tests -m gpu -q -n ${JOBS:-6} --durations=30 -p no:cacheprovider \
   --deselect tests/test_gpu_cs.py::test_linear_hasher_gpu --timeout 3000 "$@" 2>&1 | tee $OUT/pytest.log
 echo "divergent wavefront-operation sites over the run (0 expected):"; cat $OUT/stats.* 2>/dev/null | grep -c "divergent x" || true
