@@ -7,6 +7,9 @@ control flow and JSON assembly on a tiny configuration; the TIMES it prints are 
 does not know about it (torch.cuda is patched from outside), the product has no path to it.
 
     python tests/emu/bench_on_emulator.py --batch 2 --log2-rows 15 --steps 2 --warmup 1 --no-cpu-baseline --with-narrow-store-mode
+    EMU_DEVICES=2 python tests/emu/bench_on_emulator.py --gpus 2 --batch 2 --log2-rows 15 --steps 2 --warmup 1 --no-cpu-baseline --headline-only
+        (bench.py launches its ranks itself; they get the same stand-ins through tests/emu/site/sitecustomize.py; EMU_DEVICES=N gives every rank its own
+         "device", so the step's gather is the product's zk_cs_gather_commitments over the N-process stand-in of tests/emu/dev/rccl/rccl.h)
 """
 import os
 import runpy
