@@ -148,27 +148,32 @@ typedef uint32_t emu_u32x2 __attribute__((ext_vector_type(2)));
 // how many lane-level buffer operations of each kind the kernels issued (8-byte loads, 8-byte stores, 1-byte loads, 1-byte stores): what a store layout
 // costs in issued bytes, counted where the kernel issues them (zk_emu_buffer_ops; tests/test_zz_round6_narrow_store.py compares it with zk_stats)
 namespace emu { extern unsigned long long buffer_ops[4]; }
-static inline emu_u32x2 emu_buffer_load_b64(emu_rsrc r, uint32_t voff, uint32_t soff) { ++emu::buffer_ops[0]; emu_u32x2 v; memcpy(&v, r.base + (size_t)voff + (size_t)soff, 8); return v; }
+#ifdef EMU_TSAN   // (the race-detector build does not count: a plain counter shared by the fibers would itself be reported)
+#define EMU_COUNT(i) ((void)0)
+#else
+#define EMU_COUNT(i) (++emu::buffer_ops[i])
+#endif
+static inline emu_u32x2 emu_buffer_load_b64(emu_rsrc r, uint32_t voff, uint32_t soff) { EMU_COUNT(0); emu_u32x2 v; memcpy(&v, r.base + (size_t)voff + (size_t)soff, 8); return v; }
 #ifdef EMU_TSAN
 // Race-detector build: a store of the value the cell already holds is not a write.  The witness kernels clamp the lanes beyond the batch to the
 // last valid lane (they redo its work and store the same values to the same cells: deterministic, and a write-write race by the letter);
 // a store of a DIFFERENT value to a cell another work-item wrote is reported as before.
 __attribute__((no_sanitize("thread"), noinline)) static bool emu_same_value(const char* p, emu_u32x2 v) { emu_u32x2 o; __builtin_memcpy(&o, p, 8); return o.x == v.x && o.y == v.y; }
 static inline void emu_buffer_store_b64(emu_u32x2 v, emu_rsrc r, uint32_t voff, uint32_t soff) {
-    ++emu::buffer_ops[1];
+    EMU_COUNT(1);
     char* p = r.base + (size_t)voff + (size_t)soff;
     if (!emu_same_value(p, v)) memcpy(p, &v, 8);
 }
 #else
-static inline void emu_buffer_store_b64(emu_u32x2 v, emu_rsrc r, uint32_t voff, uint32_t soff) { ++emu::buffer_ops[1]; memcpy(r.base + (size_t)voff + (size_t)soff, &v, 8); }
+static inline void emu_buffer_store_b64(emu_u32x2 v, emu_rsrc r, uint32_t voff, uint32_t soff) { EMU_COUNT(1); memcpy(r.base + (size_t)voff + (size_t)soff, &v, 8); }
 #endif
 // one-byte forms (narrow store: buffer_load_ubyte / buffer_store_byte)
-static inline uint8_t emu_buffer_load_b8(emu_rsrc r, uint32_t voff, uint32_t soff) { ++emu::buffer_ops[2]; return (uint8_t)r.base[(size_t)voff + (size_t)soff]; }
+static inline uint8_t emu_buffer_load_b8(emu_rsrc r, uint32_t voff, uint32_t soff) { EMU_COUNT(2); return (uint8_t)r.base[(size_t)voff + (size_t)soff]; }
 #ifdef EMU_TSAN
 __attribute__((no_sanitize("thread"), noinline)) static bool emu_same_byte(const char* p, uint8_t v) { return (uint8_t)*p == v; }
-static inline void emu_buffer_store_b8(uint8_t v, emu_rsrc r, uint32_t voff, uint32_t soff) { ++emu::buffer_ops[3]; char* p = r.base + (size_t)voff + (size_t)soff; if (!emu_same_byte(p, v)) *p = (char)v; }
+static inline void emu_buffer_store_b8(uint8_t v, emu_rsrc r, uint32_t voff, uint32_t soff) { EMU_COUNT(3); char* p = r.base + (size_t)voff + (size_t)soff; if (!emu_same_byte(p, v)) *p = (char)v; }
 #else
-static inline void emu_buffer_store_b8(uint8_t v, emu_rsrc r, uint32_t voff, uint32_t soff) { ++emu::buffer_ops[3]; r.base[(size_t)voff + (size_t)soff] = (char)v; }
+static inline void emu_buffer_store_b8(uint8_t v, emu_rsrc r, uint32_t voff, uint32_t soff) { EMU_COUNT(3); r.base[(size_t)voff + (size_t)soff] = (char)v; }
 #endif
 #define __builtin_amdgcn_raw_buffer_load_b8(rsrc, voff, soff, aux) emu_buffer_load_b8((rsrc), (uint32_t)(voff), (uint32_t)(soff))
 #define __builtin_amdgcn_raw_buffer_store_b8(v, rsrc, voff, soff, aux) emu_buffer_store_b8((uint8_t)(v), (rsrc), (uint32_t)(voff), (uint32_t)(soff))
