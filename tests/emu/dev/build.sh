@@ -14,6 +14,8 @@ OPT=${EMU_OPT:--O1}
 TSAN_CC=""; TSAN_LD=""
 if [ -n "${EMU_ASAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-asan}; set -- "$@" -DEMU_ASAN=1; TSAN_CC="-fsanitize=address"; TSAN_LD="-fsanitize=address -shared-libsan"; fi
 if [ -n "${EMU_TSAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-tsan}; set -- "$@" -DEMU_TSAN=1; TSAN_CC="-fsanitize=thread"; TSAN_LD="-fsanitize=thread -shared-libsan"; fi
+# EMU_ASAN=1 EMU_SAN_HOST=1: the HOST sources (recorder, packers, C ABI) under the address sanitizer too -> tests/emu/_gen/dev_asanhost/ (the `-m "not gpu"` tests through ZKGL_LIB)
+HOST_SAN=""; if [ -n "${EMU_SAN_HOST:-}" ] && [ -n "${EMU_ASAN:-}" ]; then HOST_SAN="$TSAN_CC"; [ "${EMU_VARIANT:-asan}" != asan ] || EMU_VARIANT=asanhost; fi
 GEN=$HERE/../_gen/dev${EMU_VARIANT:+_$EMU_VARIANT}; [ "$OPT" = "-O1" ] || GEN=${GEN}_${OPT#-}
 mkdir -p $GEN/obj $GEN/obj/testing
 python $HERE/gen_dev.py $GEN
@@ -27,7 +29,7 @@ cc() {  # $1 source, $2 object, $3 extra flags
 }
 for f in $GEN/src/*.cpp $GEN/src/circuits/*.cpp; do
   if [ $(basename $f) = zkgl_device.cpp ]; then cc $f $GEN/obj/$(basename $f).o "$OPT $TSAN_CC"   # the kernels
-  else cc $f $GEN/obj/$(basename $f).o; fi
+  else cc $f $GEN/obj/$(basename $f).o "${HOST_SAN:-}"; fi
 done
 cc $HERE/emu_rt.cpp $GEN/obj/emu_rt.o -O2
 for f in $GEN/src/testing/*.cpp; do cc $f $GEN/obj/testing/$(basename $f).o; done
