@@ -16,6 +16,9 @@ if [ -n "${EMU_ASAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-asan}; set -- "$@" -D
 if [ -n "${EMU_TSAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-tsan}; set -- "$@" -DEMU_TSAN=1; TSAN_CC="-fsanitize=thread"; TSAN_LD="-fsanitize=thread -shared-libsan"; fi
 # EMU_ASAN=1 EMU_SAN_HOST=1: the HOST sources (recorder, packers, C ABI) under the address sanitizer too -> tests/emu/_gen/dev_asanhost/ (the `-m "not gpu"` tests through ZKGL_LIB)
 HOST_SAN=""; if [ -n "${EMU_SAN_HOST:-}" ] && [ -n "${EMU_ASAN:-}" ]; then HOST_SAN="$TSAN_CC"; [ "${EMU_VARIANT:-asan}" != asan ] || EMU_VARIANT=asanhost; fi
+# EMU_UBSAN=1: the host sources under the undefined-behaviour sanitizer (shifts, signed overflow, misaligned or null accesses, bad enum / bool loads) -> tests/emu/_gen/dev_ubsan/;
+#   run under LD_PRELOAD=.../libclang_rt.ubsan_standalone-x86_64.so with UBSAN_OPTIONS=print_stacktrace=1
+if [ -n "${EMU_UBSAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-ubsan}; HOST_SAN="-fsanitize=undefined -fno-sanitize=vptr,function"; TSAN_LD="-fsanitize=undefined -shared-libsan"; fi
 GEN=$HERE/../_gen/dev${EMU_VARIANT:+_$EMU_VARIANT}; [ "$OPT" = "-O1" ] || GEN=${GEN}_${OPT#-}
 mkdir -p $GEN/obj $GEN/obj/testing
 python $HERE/gen_dev.py $GEN
