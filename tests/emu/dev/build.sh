@@ -31,7 +31,7 @@ cc() {  # $1 source, $2 object, $3 extra flags
   if [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ "$NEWEST_HDR" -nt "$2" ]; then $CXX $FLAGS ${3:-} -c "$1" -o "$2" & pids+=($!); fi
 }
 for f in $GEN/src/*.cpp $GEN/src/circuits/*.cpp; do
-  if [ $(basename $f) = zkgl_device.cpp ]; then cc $f $GEN/obj/$(basename $f).o "$OPT $TSAN_CC"   # the kernels
+  if [ $(basename $f) = zkgl_device.cpp ]; then cc $f $GEN/obj/$(basename $f).o "$OPT $TSAN_CC ${EMU_UBSAN:+$HOST_SAN}"   # the kernels
   else cc $f $GEN/obj/$(basename $f).o "${HOST_SAN:-}"; fi
 done
 cc $HERE/emu_rt.cpp $GEN/obj/emu_rt.o -O2
