@@ -16,6 +16,7 @@ if [ -n "${EMU_ASAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-asan}; set -- "$@" -D
 if [ -n "${EMU_TSAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-tsan}; set -- "$@" -DEMU_TSAN=1; TSAN_CC="-fsanitize=thread"; TSAN_LD="-fsanitize=thread -shared-libsan"; fi
 # EMU_ASAN=1 EMU_SAN_HOST=1: the HOST sources (recorder, packers, C ABI) under the address sanitizer too -> tests/emu/_gen/dev_asanhost/ (the `-m "not gpu"` tests through ZKGL_LIB)
 HOST_SAN=""; if [ -n "${EMU_SAN_HOST:-}" ] && [ -n "${EMU_ASAN:-}" ]; then HOST_SAN="$TSAN_CC"; [ "${EMU_VARIANT:-asan}" != asan ] || EMU_VARIANT=asanhost; fi
+if [ -n "${EMU_SAN_HOST:-}" ] && [ -n "${EMU_TSAN:-}" ]; then HOST_SAN="$TSAN_CC"; [ "${EMU_VARIANT:-tsan}" != tsan ] || EMU_VARIANT=tsanhost; fi   # the host pool's OS threads under the race detector
 # EMU_UBSAN=1: the host sources under the undefined-behaviour sanitizer (shifts, signed overflow, misaligned or null accesses, bad enum / bool loads) -> tests/emu/_gen/dev_ubsan/;
 #   run under LD_PRELOAD=.../libclang_rt.ubsan_standalone-x86_64.so with UBSAN_OPTIONS=print_stacktrace=1
 if [ -n "${EMU_UBSAN:-}" ]; then EMU_VARIANT=${EMU_VARIANT:-ubsan}; HOST_SAN="-fsanitize=undefined -fno-sanitize=vptr,function"; TSAN_LD="-fsanitize=undefined -shared-libsan"; fi
